@@ -1,0 +1,372 @@
+"""calipso.jl_amd — MI355X (gfx950) implementation of CALIPSO's Newton/KKT hot path behind the reference's
+Solver / initialize! / solve! surface (thowell/CALIPSO.jl, src/CALIPSO.jl:48-50).
+
+This Python module is the host-side mirror used where Julia is unavailable (the Julia `ccall` module with the same
+surface is in julia/CalipsoHIP.jl).  It keeps the reference's names: `Solver`, `Options`, `initialize_b` (= initialize!),
+`solve_b` (= solve!), and the field names of `solver.solution`, `solver.data`, `solver.problem`.  All arithmetic of the hot
+path runs in libcalipso_hip.so (hand-written HIP); this module only moves user-evaluated data across the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import EVAL_FN, CalipsoHipError, lib
+
+__all__ = ["Solver", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform"]
+
+# evaluate! flags (include/calipso_hip.h)
+FLAGS = dict(
+    objective=1 << 0, objective_gradient_variables=1 << 1, objective_jacobian_variables_variables=1 << 2,
+    equality_constraint=1 << 3, equality_jacobian_variables=1 << 4, equality_dual_jacobian_variables=1 << 5,
+    equality_dual_jacobian_variables_variables=1 << 6, cone_constraint=1 << 7, cone_jacobian_variables=1 << 8,
+    cone_dual_jacobian_variables=1 << 9, cone_dual_jacobian_variables_variables=1 << 10,
+    objective_jacobian_variables_parameters=1 << 11, equality_jacobian_parameters=1 << 12,
+    equality_dual_jacobian_variables_parameters=1 << 13, cone_jacobian_parameters=1 << 14,
+    cone_dual_jacobian_variables_parameters=1 << 15)
+CONE_BARRIER, CONE_BARRIER_GRADIENT, CONE_PRODUCT, CONE_JACOBIAN, CONE_TARGET = 1, 2, 4, 8, 16
+
+STATUS_TEXT = {-1: "inertia correction failure", -2: "cone search failure", -3: "evaluation callback failed",
+               -4: "bad argument", -5: "HIP error", -6: "cone layout not supported"}
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def splitmix_uniform(problem_id, stream_id, lo, hi, count):
+    """SplitMix64 uniform stream of the synthetic benchmark problems (host function of the library)."""
+    out = np.empty(int(count), dtype=np.float64)
+    lib().calipso_hip_splitmix_uniform(problem_id, stream_id, lo, hi, int(count), _pd(out))
+    return out
+
+
+class Options(dict):
+    """Options(...) of src/solver/options.jl:6-59 — keyword arguments override the reference defaults held by the library."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+
+
+class _Point:
+    """read-only snapshot of a Point (src/solver/point.jl:1-22)"""
+
+    def __init__(self, w, nx, ne, nc):
+        o = np.cumsum([0, nx, ne, nc, ne, nc, nc])
+        self.all = w
+        self.variables = w[o[0]:o[1]]
+        self.equality_slack = w[o[1]:o[2]]
+        self.cone_slack = w[o[2]:o[3]]
+        self.equality_dual = w[o[3]:o[4]]
+        self.cone_dual = w[o[4]:o[5]]
+        self.cone_slack_dual = w[o[5]:o[6]]
+        self.primals = w[:o[3]]
+
+
+class _Dims:
+    pass
+
+
+class Solver:
+    """Solver(methods, num_variables, num_parameters, num_equality, num_cone; parameters, nonnegative_indices,
+    second_order_indices, options)  — src/solver/solver.jl:46-150.
+
+    `methods` stands in for ProblemMethods (src/solver/methods.jl): an object with
+    evaluate(flags, x, y, z, theta, out) writing the requested ProblemData fields through out(name)."""
+
+    def __init__(self, methods, num_variables, num_parameters, num_equality, num_cone, parameters=None,
+                 nonnegative_indices=None, second_order_indices=None, options=None, device=0):
+        L = lib()
+        self._L = L
+        nx, npar, ne, nc = int(num_variables), int(num_parameters), int(num_equality), int(num_cone)
+        if nonnegative_indices is None:
+            nonnegative_indices = list(range(1, nc + 1))
+        if second_order_indices is None:
+            second_order_indices = [[]]
+        nn = np.asarray(list(nonnegative_indices), dtype=np.int64)
+        ptr = np.zeros(len(second_order_indices) + 1, dtype=np.int64)
+        flat = []
+        for k, c in enumerate(second_order_indices):
+            flat.extend(c)
+            ptr[k + 1] = len(flat)
+        flat = np.asarray(flat, dtype=np.int64)
+        h = C.c_void_p()
+        rc = L.calipso_hip_create(nx, npar, ne, nc, len(nn), _pi(nn), len(second_order_indices), _pi(ptr), _pi(flat), device, C.byref(h))
+        if rc != 0:
+            msg = L.calipso_hip_last_error(h if h.value else None).decode()
+            if h.value:
+                L.calipso_hip_destroy(h)
+            raise CalipsoHipError("calipso_hip_create failed (%d): %s" % (rc, msg))
+        self._h = h
+        self.methods = methods
+        self.dimensions = _Dims()
+        d = self.dimensions
+        d.variables, d.parameters, d.equality_slack, d.cone_slack = nx, npar, ne, nc
+        d.equality_dual, d.cone_dual, d.cone_slack_dual = ne, nc, nc
+        d.symmetric = d.primal = nx + ne + nc
+        d.total = nx + 2 * ne + 3 * nc
+        self.nx, self.np, self.ne, self.nc, self.n, self.N = nx, npar, ne, nc, d.symmetric, d.total
+        self.indices = {k: self.index(k) for k in ("variables", "equality_slack", "cone_slack", "equality_dual", "cone_dual",
+                                                    "cone_slack_dual", "symmetric_equality", "symmetric_cone", "primals", "duals",
+                                                    "violation_equality", "violation_cone", "parameters", "cone_nonnegative",
+                                                    "cone_second_order", "cone_second_order_ptr")}
+        # host ProblemData (problem_data.jl:33-100) that the user functions fill
+        z = np.zeros
+        self.problem = dict(
+            objective=z(1), objective_gradient_variables=z(nx), objective_jacobian_variables_variables=z(nx * nx),
+            objective_jacobian_variables_parameters=z(nx * npar), equality_constraint=z(ne), equality_jacobian_variables=z(ne * nx),
+            equality_jacobian_parameters=z(ne * npar), equality_dual_jacobian_variables=z(nx),
+            equality_dual_jacobian_variables_variables=z(nx * nx), equality_dual_jacobian_variables_parameters=z(nx * npar),
+            cone_constraint=z(nc), cone_jacobian_variables=z(nc * nx), cone_jacobian_parameters=z(nc * npar),
+            cone_dual_jacobian_variables=z(nx), cone_dual_jacobian_variables_variables=z(nx * nx),
+            cone_dual_jacobian_variables_parameters=z(nx * npar))
+        self.parameters = np.zeros(npar) if parameters is None else np.asarray(parameters, dtype=np.float64).copy()
+        if npar:
+            self.set("parameters", self.parameters)
+        self.options = {}
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+        self._cb = EVAL_FN(self._evaluate_callback)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self._L.calipso_hip_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- plumbing ---------------------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc < 0:
+            raise CalipsoHipError("%s: %s (%d): %s" % (what, STATUS_TEXT.get(rc, "error"), rc, self._L.calipso_hip_last_error(self._h).decode()))
+        return rc
+
+    def set(self, name, arr):
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.float64).reshape(-1))
+        self._check(self._L.calipso_hip_set_field(self._h, name.encode(), _pd(a), a.size), "set_field(%s)" % name)
+
+    def get(self, name, length):
+        out = np.zeros(int(length), dtype=np.float64)
+        self._check(self._L.calipso_hip_get_field(self._h, name.encode(), _pd(out), out.size), "get_field(%s)" % name)
+        return out
+
+    def scalar(self, name):
+        return float(self.get(name, 1)[0])
+
+    def set_option(self, name, value):
+        self.options[name] = value
+        self.set("opt." + name, [float(value)])
+
+    def index(self, name):
+        n = self._L.calipso_hip_get_index(self._h, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        out = np.zeros(max(int(n), 1), dtype=np.int64)
+        self._L.calipso_hip_get_index(self._h, name.encode(), _pi(out), n)
+        return out[:n]
+
+    def _out(self, name):
+        return self.problem[name]
+
+    _UPLOAD = [("objective", "objective"), ("objective_gradient_variables", "objective_gradient_variables"),
+               ("equality_constraint", "equality_constraint"), ("equality_jacobian_variables", "equality_jacobian_variables"),
+               ("equality_dual_jacobian_variables", "equality_dual_jacobian_variables"), ("cone_constraint", "cone_constraint"),
+               ("cone_jacobian_variables", "cone_jacobian_variables"), ("cone_dual_jacobian_variables", "cone_dual_jacobian_variables"),
+               ("equality_jacobian_parameters", "equality_jacobian_parameters"), ("cone_jacobian_parameters", "cone_jacobian_parameters")]
+
+    def upload(self, flags):
+        """hand the flagged ProblemData fields to the device (the tail of evaluate!, src/solver/evaluate.jl:37-121)"""
+        p = self.problem
+        for key, field in self._UPLOAD:
+            if flags & FLAGS[key] and p[key].size:
+                self.set(field, p[key])
+        hess = FLAGS["objective_jacobian_variables_variables"] | FLAGS["equality_dual_jacobian_variables_variables"] | FLAGS["cone_dual_jacobian_variables_variables"]
+        if flags & hess:
+            # Lxx = fxx + (g'y)xx + (h'z)xx  (residual_jacobian_variables.jl:10-16; tensor terms iff options.constraint_tensor)
+            L = p["objective_jacobian_variables_variables"].copy()
+            if self.options.get("constraint_tensor", 1.0):
+                L += p["equality_dual_jacobian_variables_variables"]
+                L += p["cone_dual_jacobian_variables_variables"]
+            self.set("lagrangian_hessian", L)
+        par = (FLAGS["objective_jacobian_variables_parameters"] | FLAGS["equality_dual_jacobian_variables_parameters"] |
+               FLAGS["cone_dual_jacobian_variables_parameters"])
+        if flags & par and self.np:
+            G = p["objective_jacobian_variables_parameters"].copy()     # residual_jacobian_parameters.jl:8-14
+            G += p["equality_dual_jacobian_variables_parameters"]
+            G += p["cone_dual_jacobian_variables_parameters"]
+            self.set("lagrangian_gradient_parameters", G)
+
+    def _evaluate_callback(self, user, flags, px, py, pz, pth):
+        try:
+            as_arr = np.ctypeslib.as_array
+            x = as_arr(px, shape=(self.nx,))
+            y = as_arr(py, shape=(self.ne,)) if self.ne else np.zeros(0)
+            z = as_arr(pz, shape=(self.nc,)) if self.nc else np.zeros(0)
+            th = as_arr(pth, shape=(self.np,)) if self.np else np.zeros(0)
+            self.methods.evaluate(flags, x, y, z, th, self._out)
+            self.upload(flags)
+            return 0
+        except Exception:   # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def evaluate(self, flags, which=0):
+        """evaluate!(problem, methods, idx, point, parameters; <flags>) at the solution (0) or candidate (1) point"""
+        w = self.get("solution" if which == 0 else "candidate", self.N)
+        pt = _Point(w, self.nx, self.ne, self.nc)
+        self.methods.evaluate(flags, pt.variables, pt.equality_dual, pt.cone_dual, self.parameters, self._out)
+        self.upload(flags)
+
+    # ---- reference-style views -----------------------------------------------------------------------------------
+    @property
+    def solution(self):
+        return _Point(self.get("solution", self.N), self.nx, self.ne, self.nc)
+
+    @property
+    def candidate(self):
+        return _Point(self.get("candidate", self.N), self.nx, self.ne, self.nc)
+
+    def data(self, name):
+        """solver.data.<name> (solver_data.jl): residual, step, residual_symmetric, step_symmetric, merit_gradient, solution_sensitivity"""
+        sizes = dict(residual=self.N, residual_error=self.N, step=self.N, step_correction=self.N, residual_symmetric=self.n,
+                     step_symmetric=self.n, merit_gradient=self.n, solution_sensitivity=self.N * self.np,
+                     jacobian_parameters=self.N * self.np)
+        v = self.get(name, sizes[name])
+        if name in ("solution_sensitivity", "jacobian_parameters"):
+            return v.reshape(self.np, self.N).T
+        if name in ("residual", "residual_error", "step", "step_correction"):
+            return _Point(v, self.nx, self.ne, self.nc)
+        return v
+
+    def jacobian_variables_symmetric(self):
+        self._check(self._L.calipso_hip_residual_jacobian_variables_symmetric(self._h), "residual_jacobian_variables_symmetric")
+        return self.get("jacobian_variables_symmetric", self.n * self.n).reshape(self.n, self.n).T
+
+    # ---- hot-path entry points (one per reference function) ---------------------------------------------------------
+    def cone(self, which=0, barrier=False, barrier_gradient=False, product=False, jacobian=False, target=False):
+        fl = (CONE_BARRIER * barrier) | (CONE_BARRIER_GRADIENT * barrier_gradient) | (CONE_PRODUCT * product) | (CONE_JACOBIAN * jacobian) | (CONE_TARGET * target)
+        self._check(self._L.calipso_hip_cone(self._h, which, int(fl)), "cone")
+
+    def residual(self):
+        self._check(self._L.calipso_hip_residual(self._h), "residual")
+
+    def violations(self):
+        out = np.zeros(5)
+        self._check(self._L.calipso_hip_violations(self._h, _pd(out)), "violations")
+        return dict(residual_violation=out[0], optimality_violation=out[1], slack_violation=out[2], equality_violation=out[3],
+                    cone_product_violation=out[4])
+
+    def jacobian_variables_mul(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        out = np.zeros(self.N)
+        self._check(self._L.calipso_hip_jacobian_variables_mul(self._h, _pd(v), _pd(out)), "jacobian_variables_mul")
+        return out
+
+    def factorize(self):
+        inertia = np.zeros(3, dtype=np.int64)
+        rc = self._check(self._L.calipso_hip_factorize(self._h, _pi(inertia)), "factorize")
+        return tuple(int(v) for v in inertia), rc
+
+    def inertia_correction(self):
+        nf = C.c_int64(0)
+        self._check(self._L.calipso_hip_inertia_correction(self._h, C.byref(nf)), "inertia_correction")
+        return int(nf.value)
+
+    def residual_symmetric(self, which=0):
+        self._check(self._L.calipso_hip_residual_symmetric(self._h, which), "residual_symmetric")
+
+    def linear_solve(self):
+        self._check(self._L.calipso_hip_linear_solve(self._h), "linear_solve")
+
+    def search_direction_symmetric(self, which=0):
+        self._check(self._L.calipso_hip_search_direction_symmetric(self._h, which), "search_direction_symmetric")
+
+    def iterative_refinement(self):
+        r = C.c_int32(0)
+        nrm = C.c_double(0.0)
+        rc = self._check(self._L.calipso_hip_iterative_refinement(self._h, C.byref(r), C.byref(nrm)), "iterative_refinement")
+        return rc == 0, int(r.value), float(nrm.value)
+
+    def search_direction(self):
+        return self._check(self._L.calipso_hip_search_direction(self._h), "search_direction")
+
+    def cone_search(self):
+        a, b = C.c_double(0), C.c_double(0)
+        self._check(self._L.calipso_hip_cone_search(self._h, C.byref(a), C.byref(b)), "cone_search")
+        return float(a.value), float(b.value)
+
+    def cone_violation(self, xhat, x, tau):
+        xhat = np.ascontiguousarray(xhat, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        v = C.c_int32(0)
+        self._check(self._L.calipso_hip_cone_violation(self._h, _pd(xhat), _pd(x), tau, C.byref(v)), "cone_violation")
+        return bool(v.value)
+
+    def make_candidate(self, step_size, with_cone_slack=False):
+        self._check(self._L.calipso_hip_candidate(self._h, step_size, int(with_cone_slack)), "candidate")
+
+    def merit(self, which=0):
+        m = C.c_double(0)
+        self._check(self._L.calipso_hip_merit(self._h, which, C.byref(m)), "merit")
+        return float(m.value)
+
+    def merit_gradient(self):
+        self._check(self._L.calipso_hip_merit_gradient(self._h), "merit_gradient")
+
+    def constraint_violation(self, which=0):
+        t = C.c_double(0)
+        self._check(self._L.calipso_hip_constraint_violation(self._h, which, C.byref(t)), "constraint_violation")
+        return float(t.value)
+
+    def differentiate(self):
+        self._check(self._L.calipso_hip_differentiate(self._h, self._cb, None), "differentiate")
+
+    def stats(self):
+        out = np.zeros(8, dtype=np.int64)
+        self._L.calipso_hip_stats(self._h, _pi(out))
+        return dict(total_iterations=int(out[0]), outer=int(out[1]), factorizations=int(out[2]), refinement_failures=int(out[3]),
+                    max_refinement_rounds=int(out[4]), fallbacks=int(out[5]), last_refinement_rounds=int(out[6]), newton_steps=int(out[7]))
+
+    # ---- device-resident QP (synthetic benchmark) -----------------------------------------------------------------------
+    def qp_attach(self, P, q, A, b, G, h, objective_scale=0.5):
+        f = lambda M: np.ascontiguousarray(np.asarray(M, dtype=np.float64).T).reshape(-1)   # column-major
+        v = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+        Pc, Ac, Gc = f(P), f(A) if self.ne else np.zeros(1), f(G) if self.nc else np.zeros(1)
+        qv, bv, hv = v(q), v(b) if self.ne else np.zeros(1), v(h) if self.nc else np.zeros(1)
+        self._check(self._L.calipso_hip_qp_attach(self._h, _pd(Pc), _pd(qv), _pd(Ac), _pd(bv), _pd(Gc), _pd(hv), objective_scale), "qp_attach")
+
+    def qp_evaluate(self, flags, which=0):
+        self._check(self._L.calipso_hip_qp_evaluate(self._h, which, int(flags)), "qp_evaluate")
+
+    def newton_step(self, advance=False):
+        info = np.zeros(6)
+        rc = self._check(self._L.calipso_hip_newton_step(self._h, int(advance), _pd(info)), "newton_step")
+        return dict(status=rc, step_size=info[0], step_size_cone_slack_dual=info[1], refinement_rounds=int(info[2]),
+                    factorizations=int(info[3]), merit_candidate=info[4], violation_candidate=info[5])
+
+    def phase_times(self):
+        out = np.zeros(9)
+        self._L.calipso_hip_phase_times(self._h, _pd(out))
+        return out
+
+    def synchronize(self):
+        self._check(self._L.calipso_hip_synchronize(self._h), "synchronize")
+
+
+def initialize_b(solver, guess):
+    """initialize!(solver, guess)  src/solver/initialize.jl:9-13"""
+    g = np.ascontiguousarray(guess, dtype=np.float64)
+    solver._check(solver._L.calipso_hip_initialize(solver._h, _pd(g)), "initialize!")
+
+
+def solve_b(solver):
+    """solve!(solver)::Bool  src/solver/solve.jl:8-377 (raises on the reference's error() cases)"""
+    attached = getattr(solver, "_qp_attached", False)
+    rc = solver._L.calipso_hip_solve(solver._h, solver._cb, None)
+    solver._check(rc, "solve!")
+    return rc == 1

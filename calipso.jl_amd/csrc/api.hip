@@ -1,0 +1,849 @@
+// api.hip — the C ABI of include/calipso_hip.h and the host-side driver of solve! (src/solver/solve.jl:8-377),
+// inertia_correction! (inertia.jl:30-80), iterative_refinement! (iterative_refinement.jl:1-52) and the filter
+// (filter.jl:1-89) over the HIP kernels of this directory.  The host only takes the scalar decisions the reference
+// takes (convergence tests, line-search acceptance, regularisation updates); all array arithmetic is on the device.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "internal.hpp"
+
+using namespace calipso;
+typedef calipso_hip_solver H;
+
+namespace calipso {
+int check(H* s, hipError_t e, const char* what) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    if (s) s->err = buf;
+    return CALIPSO_ERR_HIP;
+}
+}  // namespace calipso
+
+static std::string g_create_err;
+
+#define SYNC() CK(hipStreamSynchronize(s->stream))
+
+template <typename T>
+static int dalloc(H* s, T** p, size_t count) {
+    if (count == 0) count = 1;
+    CK(hipMalloc((void**)p, count * sizeof(T)));
+    CK(hipMemset(*p, 0, count * sizeof(T)));
+    return 0;
+}
+
+static int fail_arg(H* s, const std::string& msg) { s->err = msg; return CALIPSO_ERR_ARGUMENT; }
+
+extern "C" {
+
+const char* calipso_hip_version(void) { return "calipso-hip 0.1 (gfx950)"; }
+
+int32_t calipso_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* calipso_hip_last_error(H* s) { return s ? s->err.c_str() : g_create_err.c_str(); }
+
+int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx, int64_t n_soc,
+                           const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device, H** out) {
+    if (!out) return CALIPSO_ERR_ARGUMENT;
+    *out = nullptr;
+    if (nx < 1 || np < 0 || ne < 0 || nc < 0 || n_nonneg < 0 || n_soc < 0) { g_create_err = "negative or empty dimension"; return CALIPSO_ERR_ARGUMENT; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device available (libcalipso_hip has no CPU path)"; return CALIPSO_ERR_HIP; }
+    if (device < 0 || device >= ndev) { g_create_err = "device ordinal out of range"; return CALIPSO_ERR_ARGUMENT; }
+    // cone layout contract: nonnegative = 1..q, then contiguous second-order blocks in order, covering 1..nc
+    // (the only layout for which cones/cone.jl:27-59's vcat order agrees with residual.jl:46-48 etc.)
+    for (int64_t i = 0; i < n_nonneg; ++i)
+        if (nonneg_idx[i] != i + 1) { g_create_err = "nonnegative_indices must be 1:q"; return CALIPSO_ERR_LAYOUT; }
+    H* s = new H();
+    int64_t next = n_nonneg + 1;
+    int woff = 0, maxd = 0;
+    for (int64_t j = 0; j < n_soc; ++j) {
+        const int64_t len = soc_ptr[j + 1] - soc_ptr[j];
+        if (len == 0) continue;   // Indices allows empty vectors (indices.jl:22)
+        for (int64_t p = 0; p < len; ++p)
+            if (soc_idx[soc_ptr[j] + p] != next + p) { delete s; g_create_err = "second_order_indices must be contiguous blocks following the nonnegative entries"; return CALIPSO_ERR_LAYOUT; }
+        if (len > MAX_SOC_DIM) { delete s; g_create_err = "second-order cone dimension above the supported maximum (64)"; return CALIPSO_ERR_ARGUMENT; }
+        s->h_soc_start.push_back((int)(next - 1));
+        s->h_soc_dim.push_back((int)len);
+        s->h_soc_woff.push_back(woff);
+        woff += (int)(len * len);
+        maxd = std::max<int>(maxd, (int)len);
+        next += len;
+    }
+    if (next - 1 != nc) { delete s; g_create_err = "cone index sets do not cover 1:num_cone"; return CALIPSO_ERR_LAYOUT; }
+    s->h_nonneg.assign(nonneg_idx, nonneg_idx + n_nonneg);
+    s->h_soc_ptr.assign(soc_ptr, soc_ptr + n_soc + 1);
+    s->h_soc_idx.assign(soc_idx, soc_idx + (n_soc ? soc_ptr[n_soc] : 0));
+    Dims& d = s->d;
+    d.nx = (int)nx; d.np = (int)np; d.ne = (int)ne; d.nc = (int)nc;
+    d.n = d.nx + d.ne + d.nc;                 // dimensions.jl:35
+    d.N = d.nx + 2 * d.ne + 3 * d.nc;         // dimensions.jl:22-23
+    d.m = d.ne + d.nc;
+    d.q = (int)n_nonneg; d.n_soc = (int)s->h_soc_start.size(); d.max_dim = maxd;
+    d.NP = ((d.nx + TILE - 1) / TILE) * TILE;
+    s->device = device;
+    *out = s;   // from here on errors are reported through the handle
+    CK(hipSetDevice(device));
+    CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (auto& e : s->ev) CK(hipEventCreate(&e));
+    const size_t NX = d.nx, NE = d.ne, NC = d.nc, N = d.N, NPd = d.NP, M = d.m, n = d.n;
+    int rc = 0;
+    rc |= dalloc(s, &s->Lxx, NX * NX); rc |= dalloc(s, &s->gx, NE * NX); rc |= dalloc(s, &s->hx, NC * NX);
+    rc |= dalloc(s, &s->fx, NX); rc |= dalloc(s, &s->gyx, NX); rc |= dalloc(s, &s->hzx, NX); rc |= dalloc(s, &s->g, NE); rc |= dalloc(s, &s->hc, NC);
+    rc |= dalloc(s, &s->cone_product, NC); rc |= dalloc(s, &s->cone_target, NC); rc |= dalloc(s, &s->barrier_gradient, NC);
+    rc |= dalloc(s, &s->dscal, 64);
+    rc |= dalloc(s, &s->solution, N); rc |= dalloc(s, &s->candidate, N); rc |= dalloc(s, &s->lambda, NE); rc |= dalloc(s, &s->parameters, (size_t)d.np);
+    rc |= dalloc(s, &s->residual, N); rc |= dalloc(s, &s->residual_error, N); rc |= dalloc(s, &s->step, N); rc |= dalloc(s, &s->step_correction, N);
+    rc |= dalloc(s, &s->saved_point, N); rc |= dalloc(s, &s->saved_g, NE); rc |= dalloc(s, &s->saved_h, NC);
+    rc |= dalloc(s, &s->residual_symmetric, n); rc |= dalloc(s, &s->step_symmetric, n); rc |= dalloc(s, &s->merit_gradient, n);
+    rc |= dalloc(s, &s->S, NPd * NPd); rc |= dalloc(s, &s->Dx, NPd); rc |= dalloc(s, &s->Ypanel, NPd * NB);
+    rc |= dalloc(s, &s->Linv, (NPd / NB) * NB * NB); rc |= dalloc(s, &s->WH, NC * NX);
+    rc |= dalloc(s, &s->wz, NC); rc |= dalloc(s, &s->kzz, NC);
+    rc |= dalloc(s, &s->Wsoc, (size_t)woff); rc |= dalloc(s, &s->Bsoc, (size_t)woff); rc |= dalloc(s, &s->socwork, (size_t)2 * woff);
+    rc |= dalloc(s, &s->icount, 64);
+    const size_t maxdim = std::max(std::max(NX, NE), std::max(NC, NPd));
+    rc |= dalloc(s, &s->gemv_partial, 64 * maxdim);
+    rc |= dalloc(s, &s->vtmp, 4 * std::max(N, NPd));
+    rc |= dalloc(s, &s->xbuf, NPd); rc |= dalloc(s, &s->zf, NPd); rc |= dalloc(s, &s->t1, M); rc |= dalloc(s, &s->t2, M);
+    rc |= dalloc(s, &s->lgp, NX * d.np); rc |= dalloc(s, &s->gp, NE * d.np); rc |= dalloc(s, &s->hp, NC * d.np);
+    rc |= dalloc(s, &s->jacobian_parameters, N * d.np); rc |= dalloc(s, &s->solution_sensitivity, N * d.np);
+    rc |= dalloc(s, &s->cone.soc_start, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.soc_dim, (size_t)d.n_soc);
+    rc |= dalloc(s, &s->cone.soc_woff, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.entry_soc, NC);
+    if (rc) return CALIPSO_ERR_HIP;
+    CK(hipHostMalloc((void**)&s->hscal, 64 * sizeof(double)));
+    CK(hipHostMalloc((void**)&s->hicount, 64 * sizeof(int)));
+    if (d.n_soc) {
+        CK(hipMemcpy(s->cone.soc_start, s->h_soc_start.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
+        CK(hipMemcpy(s->cone.soc_dim, s->h_soc_dim.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
+        CK(hipMemcpy(s->cone.soc_woff, s->h_soc_woff.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
+    }
+    std::vector<int> es((size_t)std::max(1, d.nc), -1);
+    for (int j = 0; j < d.n_soc; ++j)
+        for (int k = 0; k < s->h_soc_dim[j]; ++k) es[s->h_soc_start[j] + k] = j;
+    if (d.nc) CK(hipMemcpy(s->cone.entry_soc, es.data(), sizeof(int) * d.nc, hipMemcpyHostToDevice));
+    s->hpoint.assign(N, 0.0);
+    s->hparams.assign((size_t)d.np, 0.0);
+    Options& o = s->opt;
+#define OD(f) s->optd["opt." #f] = &o.f
+    OD(residual_norm); OD(constraint_norm); OD(scaling_line_search); OD(iterative_refinement_tolerance); OD(central_path_initial);
+    OD(central_path_update_tolerance); OD(central_path_scaling); OD(central_path_exponent); OD(penalty_initial); OD(penalty_scaling);
+    OD(dual_initial); OD(residual_tolerance); OD(optimality_tolerance); OD(slack_tolerance); OD(equality_tolerance);
+    OD(complementarity_tolerance); OD(min_regularization); OD(primal_regularization_initial); OD(dual_regularization_initial);
+    OD(max_regularization); OD(dual_regularization); OD(dual_regularization_exponent); OD(scaling_regularization_initial);
+    OD(scaling_regularization); OD(scaling_regularization_last); OD(min_central_path); OD(max_penalty); OD(constraint_tensor);
+    OD(update_factorization); OD(violation_tolerance); OD(violation_exponent); OD(merit_tolerance); OD(merit_exponent);
+    OD(armijo_tolerance); OD(machine_tolerance); OD(max_filter); OD(differentiate); OD(warmstart);
+#undef OD
+    const int mf = (int)o.max_filter;
+    s->filter_theta.assign(mf, 1.0e8); s->filter_merit.assign(mf, 1.0e8);
+    s->cache_theta.assign(mf, 1.0e8); s->cache_merit.assign(mf, 1.0e8);
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_destroy(H* s) {
+    if (!s) return CALIPSO_OK;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    double* dp[] = {s->Lxx, s->gx, s->hx, s->fx, s->gyx, s->hzx, s->g, s->hc, s->cone_product, s->cone_target, s->barrier_gradient, s->dscal,
+                    s->solution, s->candidate, s->lambda, s->parameters, s->residual, s->residual_error, s->step, s->step_correction,
+                    s->saved_point, s->saved_g, s->saved_h, s->residual_symmetric, s->step_symmetric, s->merit_gradient, s->Kdense, s->S,
+                    s->Dx, s->Ypanel, s->Linv, s->WH, s->wz, s->kzz, s->Wsoc, s->Bsoc, s->socwork, s->gemv_partial, s->vtmp, s->xbuf, s->zf,
+                    s->t1, s->t2, s->lgp, s->gp, s->hp, s->jacobian_parameters, s->solution_sensitivity, s->multi_rhs, s->qp.q, s->qp.b, s->qp.h};
+    for (double* p : dp) if (p) (void)hipFree(p);
+    int* ip[] = {s->icount, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
+    for (int* p : ip) if (p) (void)hipFree(p);
+    if (s->hscal) (void)hipHostFree(s->hscal);
+    if (s->hicount) (void)hipHostFree(s->hicount);
+    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return CALIPSO_OK;
+}
+
+}  // extern "C"
+
+// ---- field table --------------------------------------------------------------------------------------------------------
+struct Field { double* dev; double* host; int64_t len; };
+
+static bool find_field(H* s, const std::string& name, Field& f) {
+    const Dims& d = s->d;
+    f.dev = nullptr; f.host = nullptr; f.len = 0;
+    auto D = [&](double* p, int64_t len) { f.dev = p; f.len = len; return true; };
+    auto Hh = [&](double* p) { f.host = p; f.len = 1; return true; };
+    if (name == "objective") return D(s->dscal + 0, 1);
+    if (name == "barrier") return D(s->dscal + 1, 1);
+    if (name == "objective_gradient_variables") return D(s->fx, d.nx);
+    if (name == "equality_constraint") return D(s->g, d.ne);
+    if (name == "equality_jacobian_variables") return D(s->gx, (int64_t)d.ne * d.nx);
+    if (name == "equality_dual_jacobian_variables") return D(s->gyx, d.nx);
+    if (name == "cone_constraint") return D(s->hc, d.nc);
+    if (name == "cone_jacobian_variables") return D(s->hx, (int64_t)d.nc * d.nx);
+    if (name == "cone_dual_jacobian_variables") return D(s->hzx, d.nx);
+    if (name == "lagrangian_hessian") return D(s->Lxx, (int64_t)d.nx * d.nx);
+    if (name == "cone_product") return D(s->cone_product, d.nc);
+    if (name == "cone_target") return D(s->cone_target, d.nc);
+    if (name == "barrier_gradient") return D(s->barrier_gradient, d.nc);
+    if (name == "lagrangian_gradient_parameters") return D(s->lgp, (int64_t)d.nx * d.np);
+    if (name == "equality_jacobian_parameters") return D(s->gp, (int64_t)d.ne * d.np);
+    if (name == "cone_jacobian_parameters") return D(s->hp, (int64_t)d.nc * d.np);
+    if (name == "jacobian_parameters") return D(s->jacobian_parameters, (int64_t)d.N * d.np);
+    if (name == "solution_sensitivity") return D(s->solution_sensitivity, (int64_t)d.N * d.np);
+    if (name == "solution") return D(s->solution, d.N);
+    if (name == "candidate") return D(s->candidate, d.N);
+    if (name == "residual") return D(s->residual, d.N);
+    if (name == "residual_error") return D(s->residual_error, d.N);
+    if (name == "step") return D(s->step, d.N);
+    if (name == "step_correction") return D(s->step_correction, d.N);
+    if (name == "residual_symmetric") return D(s->residual_symmetric, d.n);
+    if (name == "step_symmetric") return D(s->step_symmetric, d.n);
+    if (name == "merit_gradient") return D(s->merit_gradient, d.n);
+    if (name == "jacobian_variables_symmetric") return D(s->Kdense, (int64_t)d.n * d.n);
+    if (name == "parameters") return D(s->parameters, d.np);
+    if (name == "dual") return D(s->lambda, d.ne);
+    if (name == "central_path") return Hh(&s->sc.kappa);
+    if (name == "fraction_to_boundary") return Hh(&s->sc.tau);
+    if (name == "penalty") return Hh(&s->sc.rho);
+    if (name == "primal_regularization") return Hh(&s->sc.ep);
+    if (name == "primal_regularization_last") return Hh(&s->sc.ep_last);
+    if (name == "dual_regularization") return Hh(&s->sc.ed);
+    auto it = s->optd.find(name);
+    if (it != s->optd.end()) return Hh(it->second);
+    // integer options as doubles
+    Options& o = s->opt;
+    static thread_local double tmp;
+    (void)tmp;
+    struct IO { const char* n; calipso::i64* p; };
+    IO ios[] = {{"opt.max_outer_iterations", &o.max_outer_iterations}, {"opt.max_residual_iterations", &o.max_residual_iterations},
+                {"opt.max_residual_line_search", &o.max_residual_line_search}, {"opt.max_cone_line_search", &o.max_cone_line_search},
+                {"opt.iterative_refinement", &o.iterative_refinement}, {"opt.max_iterative_refinement", &o.max_iterative_refinement},
+                {"opt.min_iterative_refinement", &o.min_iterative_refinement}};
+    for (auto& io : ios)
+        if (name == io.n) { f.host = (double*)io.p; f.len = -1; return true; }   // len -1 marks an int64 slot
+    return false;
+}
+
+extern "C" {
+
+int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_t len) {
+    if (!s || !name || (!data && len > 0)) return CALIPSO_ERR_ARGUMENT;
+    Field f;
+    if (!find_field(s, name, f)) return fail_arg(s, std::string("unknown field: ") + name);
+    if (f.len == -1) { if (len != 1) return fail_arg(s, "scalar expected"); *(calipso::i64*)f.host = (calipso::i64)llround(data[0]); return CALIPSO_OK; }
+    if (len != f.len) return fail_arg(s, std::string("wrong length for field ") + name);
+    if (f.host) { *f.host = data[0]; return CALIPSO_OK; }
+    if (!f.dev) return fail_arg(s, std::string("field not allocated: ") + name);
+    if (len == 0) return CALIPSO_OK;
+    CK(hipSetDevice(s->device));
+    CK(hipMemcpyAsync(f.dev, data, sizeof(double) * len, hipMemcpyHostToDevice, s->stream));
+    SYNC();
+    if (std::string(name) == "parameters") s->hparams.assign(data, data + len);
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_get_field(H* s, const char* name, double* data, int64_t len) {
+    if (!s || !name || (!data && len > 0)) return CALIPSO_ERR_ARGUMENT;
+    Field f;
+    if (!find_field(s, name, f)) return fail_arg(s, std::string("unknown field: ") + name);
+    if (f.len == -1) { if (len != 1) return fail_arg(s, "scalar expected"); data[0] = (double)*(calipso::i64*)f.host; return CALIPSO_OK; }
+    if (len != f.len) return fail_arg(s, std::string("wrong length for field ") + name);
+    if (f.host) { data[0] = *f.host; return CALIPSO_OK; }
+    if (!f.dev) return fail_arg(s, std::string("field not computed yet: ") + name);
+    if (len == 0) return CALIPSO_OK;
+    CK(hipSetDevice(s->device));
+    CK(hipMemcpyAsync(data, f.dev, sizeof(double) * len, hipMemcpyDeviceToHost, s->stream));
+    SYNC();
+    return CALIPSO_OK;
+}
+
+// Indices(nx, np, ne, nc; nonnegative, second_order)  indices.jl:20-63 — 1-based contiguous ranges
+int64_t calipso_hip_get_index(H* s, const char* name, int64_t* out, int64_t cap) {
+    if (!s || !name) return CALIPSO_ERR_ARGUMENT;
+    const Dims& d = s->d;
+    const std::string n = name;
+    int64_t off = 0, len = -1;
+    if (n == "variables") { off = 0; len = d.nx; }
+    else if (n == "equality_slack") { off = d.nx; len = d.ne; }
+    else if (n == "cone_slack") { off = d.nx + d.ne; len = d.nc; }
+    else if (n == "equality_dual") { off = d.nx + d.ne + d.nc; len = d.ne; }
+    else if (n == "cone_dual") { off = d.nx + d.ne + d.nc + d.ne; len = d.nc; }
+    else if (n == "cone_slack_dual") { off = d.nx + d.ne + d.nc + d.ne + d.nc; len = d.nc; }
+    else if (n == "symmetric" || n == "primals") { off = 0; len = d.nx + d.ne + d.nc; }
+    else if (n == "symmetric_equality") { off = d.nx; len = d.ne; }
+    else if (n == "symmetric_cone") { off = d.nx + d.ne; len = d.nc; }
+    else if (n == "duals") { off = d.nx + d.ne + d.nc; len = d.ne + 2 * d.nc; }
+    else if (n == "violation_equality") { off = 0; len = d.ne; }
+    else if (n == "violation_cone") { off = d.ne; len = d.nc; }
+    else if (n == "parameters") { off = 0; len = d.np; }
+    if (len >= 0) {
+        if (out) for (int64_t i = 0; i < len && i < cap; ++i) out[i] = off + i + 1;
+        return len;
+    }
+    const std::vector<int64_t>* v = nullptr;
+    if (n == "cone_nonnegative") v = &s->h_nonneg;
+    else if (n == "cone_second_order") v = &s->h_soc_idx;
+    else if (n == "cone_second_order_ptr") v = &s->h_soc_ptr;
+    if (!v) return fail_arg(s, std::string("unknown index set: ") + name);
+    if (out) for (size_t i = 0; i < v->size() && (int64_t)i < cap; ++i) out[i] = (*v)[i];
+    return (int64_t)v->size();
+}
+
+int32_t calipso_hip_synchronize(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; SYNC(); CK(hipGetLastError()); return CALIPSO_OK; }
+
+}  // extern "C"
+
+// ---- internal helpers -------------------------------------------------------------------------------------------------------
+static int read_scalars(H* s, int first, int count) {
+    CK(hipMemcpyAsync(s->hscal + first, s->dscal + first, sizeof(double) * count, hipMemcpyDeviceToHost, s->stream));
+    SYNC();
+    return 0;
+}
+static double* point_of(H* s, int which) { return which == 0 ? s->solution : s->candidate; }
+
+static int do_factorize(H* s, int64_t inertia[3]) {
+    launch_cone_weights(s);
+    launch_scale_rows(s);
+    launch_schur(s);
+    launch_ldl(s);
+    CK(hipMemcpyAsync(s->hicount, s->icount, sizeof(int) * 6, hipMemcpyDeviceToHost, s->stream));
+    SYNC();
+    s->stats.factorizations += 1;
+    const int64_t pos = s->hicount[0] + s->hicount[3], nonpos = s->hicount[1] + s->hicount[4], zero = s->hicount[2] + s->hicount[5];
+    inertia[0] = pos; inertia[1] = nonpos; inertia[2] = zero;
+    if (zero > 0) { inertia[0] = -1; return CALIPSO_WARN_ZERO_PIVOT; }   // qdldl.jl:456,579: posDCount = -1
+    return CALIPSO_OK;
+}
+
+static bool inertia_ok(const H* s, const int64_t in[3]) { return in[0] == s->d.nx && in[1] == s->d.ne + s->d.nc && in[2] == 0; }   // inertia.jl:7-11
+
+// inertia.jl:30-80.  Quirk kept: the `primal_regularization_last == 0.0` test of :48 compares a Vector with a Float64 and is
+// always false, so IC-3 always takes max(min_regularization, scaling_regularization_last * eps_last).
+static int do_inertia_correction(H* s, int64_t* nfact) {
+    Options& o = s->opt; Scalars& sc = s->sc;
+    int64_t in[3];
+    int64_t count = 0;
+    sc.ep = o.primal_regularization_initial;
+    sc.ed = o.dual_regularization_initial;
+    int rc = do_factorize(s, in); count++;                       // IC-1
+    if (rc < 0) return rc;
+    if (inertia_ok(s, in)) { if (nfact) *nfact = count; return CALIPSO_OK; }
+    if (in[2] != 0) sc.ed = o.dual_regularization * std::pow(sc.kappa, o.dual_regularization_exponent);   // IC-2
+    sc.ep = std::max(o.min_regularization, o.scaling_regularization_last * sc.ep_last);                   // IC-3
+    while (!inertia_ok(s, in)) {
+        rc = do_factorize(s, in); count++;                       // IC-4
+        if (rc < 0) return rc;
+        if (inertia_ok(s, in)) break;
+        if (sc.ep_last == 0.0) sc.ep = o.scaling_regularization_initial * sc.ep;   // IC-5
+        else sc.ep = o.scaling_regularization * sc.ep;
+        if (sc.ep > o.max_regularization) { if (nfact) *nfact = count; s->err = "inertia correction failure"; return CALIPSO_ERR_INERTIA; }   // IC-6
+    }
+    sc.ep_last = sc.ep;
+    if (nfact) *nfact = count;
+    return CALIPSO_OK;
+}
+
+static void do_sds(H* s, int which) {
+    const double* res = which == 0 ? s->residual : s->residual_error;
+    double* st = which == 0 ? s->step : s->step_correction;
+    launch_residual_symmetric(s, res);
+    linear_solve_device(s);
+    launch_recover(s, st, res);
+}
+
+// iterative_refinement.jl:1-52
+static int do_refinement(H* s, int* rounds, double* final_norm) {
+    const Options& o = s->opt;
+    CK(hipMemsetAsync(s->step_correction, 0, sizeof(double) * s->d.N, s->stream));
+    launch_residual_error(s, s->step);
+    if (read_scalars(s, 7, 1)) return CALIPSO_ERR_HIP;
+    double norm = s->hscal[7];
+    const double norm0 = norm;
+    int it = 0;
+    while (it <= o.max_iterative_refinement) {
+        if (norm <= o.iterative_refinement_tolerance && it >= o.min_iterative_refinement) {
+            if (rounds) *rounds = it;
+            if (final_norm) *final_norm = norm;
+            s->stats.last_refine = it; s->stats.refine_max = std::max<calipso::i64>(s->stats.refine_max, it);
+            return CALIPSO_OK;
+        }
+        do_sds(s, 1);
+        launch_add(s, s->step, s->step_correction, s->d.N);
+        launch_residual_error(s, s->step);
+        if (read_scalars(s, 7, 1)) return CALIPSO_ERR_HIP;
+        norm = s->hscal[7];
+        it += 1;
+    }
+    if (rounds) *rounds = it;
+    if (final_norm) *final_norm = norm;
+    s->stats.last_refine = it; s->stats.refine_max = std::max<calipso::i64>(s->stats.refine_max, it);
+    if (norm <= norm0) return CALIPSO_OK;
+    s->stats.refine_fail += 1;
+    return CALIPSO_WARN_REFINEMENT;
+}
+
+static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
+    int rc = do_inertia_correction(s, nfact);
+    if (rc < 0) return rc;
+    do_sds(s, 0);
+    if (s->opt.iterative_refinement) {
+        rc = do_refinement(s, rounds, nullptr);
+        if (rc < 0) return rc;
+        if (rc == CALIPSO_WARN_REFINEMENT) {
+            // The reference falls back to a sparse LU solve of the unreduced system (search_direction.jl:22,113).  The GPU
+            // path keeps the best refined step and reports the warning; see DESIGN.md ("fallback").
+            s->stats.fallbacks += 1;
+            return CALIPSO_WARN_REFINEMENT;
+        }
+    }
+    return CALIPSO_OK;
+}
+
+static int do_cone_search(H* s, double* a_s, double* a_t) {
+    const Options& o = s->opt;
+    if (s->d.nc == 0) { *a_s = 1.0; *a_t = 1.0; return CALIPSO_OK; }
+    launch_cone_search(s);
+    CK(hipMemcpyAsync(s->hicount + 6, s->icount + 6, sizeof(int) * 58, hipMemcpyDeviceToHost, s->stream));
+    SYNC();
+    const int nk = std::min<int>((int)o.max_cone_line_search + 1, 26);
+    int ks = -1, kt = -1;
+    for (int k = 0; k < nk; ++k) if (s->hicount[6 + k] == 0) { ks = k; break; }
+    for (int k = 0; k < nk; ++k) if (s->hicount[32 + k] == 0) { kt = k; break; }
+    if (ks < 0 || kt < 0) { s->err = "cone search failure"; return CALIPSO_ERR_CONE_SEARCH; }   // solve.jl:210,220
+    // step sizes as the reference forms them: repeated multiplication by scaling_line_search (= 0.5: exact powers of two)
+    double as = 1.0, at = 1.0;
+    for (int k = 0; k < ks; ++k) as = o.scaling_line_search * as;
+    for (int k = 0; k < kt; ++k) at = o.scaling_line_search * at;
+    *a_s = as; *a_t = at;
+    launch_cone_candidate(s, as, at);
+    return CALIPSO_OK;
+}
+
+static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t flags) {
+    double* pt = point_of(s, which);
+    if (s->qp.attached) { launch_qp_evaluate(s, pt, flags); return CALIPSO_OK; }
+    if (!eval) { s->err = "no evaluation callback and no device evaluator attached"; return CALIPSO_ERR_ARGUMENT; }
+    CK(hipMemcpyAsync(s->hpoint.data(), pt, sizeof(double) * s->d.N, hipMemcpyDeviceToHost, s->stream));
+    SYNC();
+    const double* w = s->hpoint.data();
+    const int rc = eval(user, flags, w, w + s->d.oy(), w + s->d.oz(), s->hparams.data());
+    if (rc != 0) { s->err = "evaluation callback failed"; return CALIPSO_ERR_CALLBACK; }
+    return CALIPSO_OK;
+}
+
+// ---- filter (filter.jl:1-89), host side ------------------------------------------------------------------------------------
+static void filter_reset(H* s) {
+    for (calipso::i64 i = 0; i < s->filter_index; ++i) { s->cache_theta[i] = 1.0e8; s->cache_merit[i] = 1.0e8; }
+    for (calipso::i64 i = 0; i < s->filter_index; ++i) { s->filter_theta[i] = 1.0e8; s->filter_merit[i] = 1.0e8; }
+    s->filter_index = 0;
+}
+static bool check_filter(const H* s, double theta, double merit) {
+    for (size_t i = 0; i < s->filter_theta.size(); ++i)
+        if (!(theta < s->filter_theta[i] || merit < s->filter_merit[i])) return false;
+    return true;
+}
+static void augment_filter(H* s, double theta, double merit) {
+    if (s->filter_index == 0) { s->filter_theta[0] = theta; s->filter_merit[0] = merit; s->filter_index = 1; return; }
+    if (check_filter(s, theta, merit)) {
+        const calipso::i64 nold = s->filter_index;
+        for (calipso::i64 i = 0; i < nold; ++i) { s->cache_theta[i] = s->filter_theta[i]; s->cache_merit[i] = s->filter_merit[i]; }
+        for (calipso::i64 i = 0; i < nold; ++i) { s->filter_theta[i] = 1.0e8; s->filter_merit[i] = 1.0e8; }
+        s->filter_index = 0;
+        s->filter_theta[0] = theta; s->filter_merit[0] = merit; s->filter_index = 1;
+        for (calipso::i64 i = 0; i < nold; ++i)
+            if (!(s->cache_theta[i] >= theta && s->cache_merit[i] >= merit)) {
+                s->filter_theta[s->filter_index] = s->cache_theta[i];
+                s->filter_merit[s->filter_index] = s->cache_merit[i];
+                s->filter_index += 1;
+            }
+    }
+}
+// line_search.jl:2-18 with d = dot(merit_gradient, step.primals) precomputed on the device
+static bool switching_condition(double step_size, double dd, double merit_exponent, double violation, double violation_exponent, double reg) {
+    return dd < 0.0 && step_size * std::pow(-dd, merit_exponent) > reg * std::pow(violation, violation_exponent);
+}
+static bool sufficient_progress(double v, double vc, double m, double mc, double vt, double mt, double mach) {
+    return vc - 10.0 * mach * std::fabs(v) <= (1.0 - vt) * v || mc - 10.0 * mach * std::fabs(m) <= m - mt * v;
+}
+static bool armijo(double m, double mc, double dd, double step_size, double at, double mach) {
+    return mc - m - 10.0 * mach * std::fabs(m) <= at * step_size * dd;
+}
+
+static int candidate_merit(H* s, calipso_eval_fn eval, void* user, double* Mh, double* thetah) {
+    int rc = evaluate(s, eval, user, 1, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);   // solve.jl:231-235
+    if (rc < 0) return rc;
+    launch_cone(s, s->candidate, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);                         // :237-240
+    launch_merit(s, s->candidate);
+    launch_constraint_violation(s, s->candidate);
+    if (read_scalars(s, 4, 2)) return CALIPSO_ERR_HIP;
+    *Mh = s->hscal[4]; *thetah = s->hscal[5];
+    return CALIPSO_OK;
+}
+
+struct IterInfo {
+    double step_size = 1.0, step_size_t = 1.0, M = 0.0, Mh = 0.0, theta = 0.0, thetah = 0.0;
+    int rounds = 0;
+    int64_t nfact = 0;
+    int exit_kind = 0;   // 0 stepped, 1 outer convergence, 2 inner convergence
+    double residual_violation = 0, optimality = 0, slack_violation = 0;
+};
+
+#define EV(i) (void)hipEventRecord(s->ev[i], s->stream)
+
+// one pass of the inner loop body of solve! (solve.jl:98-353)
+static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equality_violation, double cone_product_violation, IterInfo& info,
+                           double* eq_viol_out, double* cp_viol_out) {
+    const Options& o = s->opt; Scalars& sc = s->sc; const Dims& d = s->d;
+    int rc;
+    EV(0);
+    rc = evaluate(s, eval, user, 0, CALIPSO_EVAL_OBJECTIVE_GRADIENT | CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT | CALIPSO_EVAL_CONE_DUAL_GRADIENT);   // :100-104
+    if (rc < 0) return rc;
+    launch_cone(s, s->solution, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);   // :106-109
+    launch_merit(s, s->solution);                                                       // :112-116
+    launch_merit_gradient(s);                                                           // :118-124
+    launch_residual(s);                                                                 // :127
+    launch_violations(s);                                                               // :130-135
+    launch_constraint_violation(s, s->solution);                                        // :170-172 (computed early: one readback)
+    if (read_scalars(s, 4, 14)) return CALIPSO_ERR_HIP;
+    const double* hs = s->hscal;
+    info.M = hs[4]; info.theta = hs[5];
+    info.residual_violation = hs[8] / (double)d.N;
+    const double sd = (d.ne + d.nc > 0) ? std::max(100.0, (hs[13] + hs[14]) / (double)(d.ne + d.nc)) / 100.0 : 1.0;   // optimality_error.jl:8
+    const double scn = (d.nc > 0) ? std::max(100.0, hs[15] / (double)d.nc) / 100.0 : 1.0;                             // :9
+    info.optimality = std::max(std::max(hs[9] / sd, hs[10]), std::max(hs[11], hs[12] / scn));
+    info.slack_violation = std::max(hs[10], hs[11]);
+    EV(1);
+    if (info.residual_violation < o.residual_tolerance && info.slack_violation < o.slack_tolerance &&
+        equality_violation <= o.equality_tolerance && cone_product_violation <= o.complementarity_tolerance) {   // :138-143
+        info.exit_kind = 1;
+        return CALIPSO_OK;
+    }
+    if (info.optimality <= std::max(o.central_path_update_tolerance * sc.kappa, o.optimality_tolerance)) {        // :165
+        info.exit_kind = 2;
+        return CALIPSO_OK;
+    }
+    uint32_t fl = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE_JACOBIAN;
+    if (o.constraint_tensor != 0.0) fl |= CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
+    rc = evaluate(s, eval, user, 0, fl);                                                // :175-181
+    if (rc < 0) return rc;
+    // cone!(jacobian=true) (:183-185): the arrow/diagonal Jacobians are functions of (s, t) and are formed inside the kernels
+    EV(2);
+    int warn = do_search_direction(s, &info.nfact, &info.rounds);                       // :187
+    if (warn < 0) return warn;
+    EV(3);
+    rc = do_cone_search(s, &info.step_size, &info.step_size_t);                         // :190-221
+    if (rc < 0) return rc;
+    double step_size = info.step_size;
+    launch_axpy_points(s, step_size, 0);                                                // :224-229
+    launch_merit_gradient(s);   // (unchanged; kept resident)
+    launch_dot_merit(s);
+    double Mh, thetah;
+    rc = candidate_merit(s, eval, user, &Mh, &thetah);                                  // :231-250
+    if (rc < 0) return rc;
+    if (read_scalars(s, 6, 1)) return CALIPSO_ERR_HIP;
+    const double dd = s->hscal[6];
+    const double M = info.M, theta = info.theta;
+    calipso::i64 residual_iteration = 0;
+    while (residual_iteration < o.max_residual_line_search) {                           // :254-302
+        if (check_filter(s, thetah, Mh)) {
+            if (theta <= o.slack_tolerance && switching_condition(step_size, dd, o.merit_exponent, theta, o.violation_exponent, 1.0) &&
+                armijo(M, Mh, dd, step_size, o.armijo_tolerance, o.machine_tolerance)) {
+                break;
+            } else if (sufficient_progress(theta, thetah, M, Mh, o.violation_tolerance, o.merit_tolerance, o.machine_tolerance)) {
+                break;
+            }
+        }
+        step_size = o.scaling_line_search * step_size;
+        launch_axpy_points(s, step_size, 1);                                            // :268-276
+        rc = candidate_merit(s, eval, user, &Mh, &thetah);                              // :278-297
+        if (rc < 0) return rc;
+        residual_iteration += 1;
+    }
+    if (residual_iteration >= o.max_residual_line_search) warn = std::max(warn, (int)CALIPSO_WARN_LINE_SEARCH);
+    // augment_filter!(solver, ...)  filter.jl:81-89
+    if (!switching_condition(step_size, dd, o.merit_exponent, theta, o.violation_exponent, 1.0) ||
+        !armijo(M, Mh, dd, step_size, o.armijo_tolerance, o.machine_tolerance))
+        augment_filter(s, (1.0 - o.violation_tolerance) * theta, M - o.merit_tolerance * theta);
+    launch_accept(s, step_size);                                                        // :309-326
+    launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT);                                  // :328-330
+    launch_violations(s);                                                               // ||g||inf, ||s o t||inf  :332-333
+    if (read_scalars(s, 16, 2)) return CALIPSO_ERR_HIP;
+    *eq_viol_out = s->hscal[16]; *cp_viol_out = s->hscal[17];
+    EV(4);
+    info.step_size = step_size; info.Mh = Mh; info.thetah = thetah;
+    s->stats.newton_steps += 1;
+    return warn;
+}
+
+extern "C" {
+
+int32_t calipso_hip_cone(H* s, int32_t which, int32_t flags) { if (!s) return CALIPSO_ERR_ARGUMENT; launch_cone(s, point_of(s, which), flags); return CALIPSO_OK; }
+int32_t calipso_hip_residual(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; launch_residual(s); return CALIPSO_OK; }
+
+int32_t calipso_hip_violations(H* s, double out[5]) {
+    if (!s || !out) return CALIPSO_ERR_ARGUMENT;
+    const Dims& d = s->d;
+    launch_violations(s);
+    if (read_scalars(s, 8, 10)) return CALIPSO_ERR_HIP;
+    const double* hs = s->hscal;
+    const double sd = (d.ne + d.nc > 0) ? std::max(100.0, (hs[13] + hs[14]) / (double)(d.ne + d.nc)) / 100.0 : 1.0;
+    const double scn = (d.nc > 0) ? std::max(100.0, hs[15] / (double)d.nc) / 100.0 : 1.0;
+    out[0] = hs[8] / (double)d.N;
+    out[1] = std::max(std::max(hs[9] / sd, hs[10]), std::max(hs[11], hs[12] / scn));
+    out[2] = std::max(hs[10], hs[11]);
+    out[3] = hs[16];
+    out[4] = hs[17];
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_residual_jacobian_variables_symmetric(H* s) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    if (!s->Kdense) { if (dalloc(s, &s->Kdense, (size_t)s->d.n * s->d.n)) return CALIPSO_ERR_HIP; }
+    launch_cone_weights(s);
+    launch_assemble_K(s);
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_jacobian_variables_mul(H* s, const double* v, double* out) {
+    if (!s || !v || !out) return CALIPSO_ERR_ARGUMENT;
+    double* dv = s->vtmp; double* dout = s->vtmp + s->d.N;
+    CK(hipMemcpyAsync(dv, v, sizeof(double) * s->d.N, hipMemcpyHostToDevice, s->stream));
+    launch_Hmul(s, dv, dout);
+    CK(hipMemcpyAsync(out, dout, sizeof(double) * s->d.N, hipMemcpyDeviceToHost, s->stream));
+    SYNC();
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_factorize(H* s, int64_t inertia[3]) { if (!s || !inertia) return CALIPSO_ERR_ARGUMENT; return do_factorize(s, inertia); }
+int32_t calipso_hip_inertia_correction(H* s, int64_t* nf) { if (!s) return CALIPSO_ERR_ARGUMENT; return do_inertia_correction(s, nf); }
+int32_t calipso_hip_residual_symmetric(H* s, int32_t which) { if (!s) return CALIPSO_ERR_ARGUMENT; launch_residual_symmetric(s, which == 0 ? s->residual : s->residual_error); return CALIPSO_OK; }
+int32_t calipso_hip_linear_solve(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; linear_solve_device(s); return CALIPSO_OK; }
+int32_t calipso_hip_search_direction_symmetric(H* s, int32_t which) { if (!s) return CALIPSO_ERR_ARGUMENT; do_sds(s, which); return CALIPSO_OK; }
+int32_t calipso_hip_iterative_refinement(H* s, int32_t* rounds, double* final_norm) { if (!s) return CALIPSO_ERR_ARGUMENT; int r = 0; int rc = do_refinement(s, &r, final_norm); if (rounds) *rounds = r; return rc; }
+int32_t calipso_hip_search_direction(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; return do_search_direction(s, nullptr, nullptr); }
+int32_t calipso_hip_cone_search(H* s, double* a, double* b) { if (!s || !a || !b) return CALIPSO_ERR_ARGUMENT; return do_cone_search(s, a, b); }
+
+int32_t calipso_hip_cone_violation(H* s, const double* xhat, const double* x, double tau, int32_t* violated) {
+    if (!s || !violated || ((!xhat || !x) && s->d.nc)) return CALIPSO_ERR_ARGUMENT;
+    *violated = 0;
+    if (s->d.nc == 0) return CALIPSO_OK;
+    double* a = s->vtmp; double* b = s->vtmp + s->d.nc;
+    CK(hipMemcpyAsync(a, xhat, sizeof(double) * s->d.nc, hipMemcpyHostToDevice, s->stream));
+    CK(hipMemcpyAsync(b, x, sizeof(double) * s->d.nc, hipMemcpyHostToDevice, s->stream));
+    launch_cone_violation_host(s, a, b, tau);
+    CK(hipMemcpyAsync(s->hicount + 6, s->icount + 6, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    SYNC();
+    *violated = s->hicount[6] != 0;
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_candidate(H* s, double step_size, int32_t with_s) { if (!s) return CALIPSO_ERR_ARGUMENT; launch_axpy_points(s, step_size, with_s); return CALIPSO_OK; }
+int32_t calipso_hip_merit(H* s, int32_t which, double* M) { if (!s || !M) return CALIPSO_ERR_ARGUMENT; launch_merit(s, point_of(s, which)); if (read_scalars(s, 4, 1)) return CALIPSO_ERR_HIP; *M = s->hscal[4]; return CALIPSO_OK; }
+int32_t calipso_hip_merit_gradient(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; launch_merit_gradient(s); return CALIPSO_OK; }
+int32_t calipso_hip_constraint_violation(H* s, int32_t which, double* th) { if (!s || !th) return CALIPSO_ERR_ARGUMENT; launch_constraint_violation(s, point_of(s, which)); if (read_scalars(s, 5, 1)) return CALIPSO_ERR_HIP; *th = s->hscal[5]; return CALIPSO_OK; }
+int32_t calipso_hip_merit_directional(H* s, double* dd) { if (!s || !dd) return CALIPSO_ERR_ARGUMENT; launch_dot_merit(s); if (read_scalars(s, 6, 1)) return CALIPSO_ERR_HIP; *dd = s->hscal[6]; return CALIPSO_OK; }
+int32_t calipso_hip_accept(H* s, double a) { if (!s) return CALIPSO_ERR_ARGUMENT; launch_accept(s, a); return CALIPSO_OK; }
+
+int32_t calipso_hip_initialize(H* s, const double* guess) {
+    if (!s || !guess) return CALIPSO_ERR_ARGUMENT;
+    CK(hipMemcpyAsync(s->solution, guess, sizeof(double) * s->d.nx, hipMemcpyHostToDevice, s->stream));
+    SYNC();
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_stats(H* s, int64_t out[8]) {
+    if (!s || !out) return CALIPSO_ERR_ARGUMENT;
+    const Stats& t = s->stats;
+    out[0] = t.total_iterations; out[1] = t.outer; out[2] = t.factorizations; out[3] = t.refine_fail; out[4] = t.refine_max;
+    out[5] = t.fallbacks; out[6] = t.last_refine; out[7] = t.newton_steps;
+    return CALIPSO_OK;
+}
+
+// differentiate!  differentiate.jl:1-61
+int32_t calipso_hip_differentiate(H* s, calipso_eval_fn eval, void* user) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    const Dims& d = s->d;
+    if (d.np == 0) return CALIPSO_OK;
+    int rc = evaluate(s, eval, user, 0, CALIPSO_EVAL_OBJECTIVE_JACOBIAN_PARAMETERS | CALIPSO_EVAL_EQUALITY_JACOBIAN_PARAMETERS |
+                                           CALIPSO_EVAL_EQUALITY_DUAL_JACOBIAN_PARAMETERS | CALIPSO_EVAL_CONE_JACOBIAN_PARAMETERS |
+                                           CALIPSO_EVAL_CONE_DUAL_JACOBIAN_PARAMETERS);
+    if (rc < 0) return rc;
+    int64_t in[3];
+    rc = do_factorize(s, in);                      // :13-20 (same regularisation as the last search direction)
+    if (rc < 0) return rc;
+    launch_jacobian_parameters(s);                 // :23
+    // :29-58 — one condensed solve per parameter column (no refinement, as the reference)
+    double* save_res = s->residual_error; double* save_step = s->step_correction;
+    for (int i = 0; i < d.np; ++i) {
+        CK(hipMemcpyAsync(save_res, s->jacobian_parameters + (size_t)i * d.N, sizeof(double) * d.N, hipMemcpyDeviceToDevice, s->stream));
+        do_sds(s, 1);
+        launch_negate_copy(s, save_step, s->solution_sensitivity + (size_t)i * d.N, d.N);
+    }
+    SYNC();
+    return CALIPSO_OK;
+}
+
+// solve!(solver)  solve.jl:8-377
+int32_t calipso_hip_solve(H* s, calipso_eval_fn eval, void* user) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    CK(hipSetDevice(s->device));
+    Options& o = s->opt; Scalars& sc = s->sc; const Dims& d = s->d;
+    s->stats = Stats();
+    int rc;
+    if (o.warmstart == 0.0) {
+        rc = evaluate(s, eval, user, 0, CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);      // initialize_slacks! initialize.jl:15-29
+        if (rc < 0) return rc;
+        launch_init_point(s);                                                           // + initialize_duals! :31-36
+    }
+    sc.kappa = o.central_path_initial; sc.tau = std::max(0.99, 1.0 - sc.kappa);          // initialize.jl:38-42
+    sc.rho = o.penalty_initial;                                                         // :44-48
+    {
+        std::vector<double> l0((size_t)std::max(1, d.ne), o.dual_initial);
+        if (d.ne) CK(hipMemcpyAsync(s->lambda, l0.data(), sizeof(double) * d.ne, hipMemcpyHostToDevice, s->stream));
+        SYNC();
+    }
+    calipso::i64 total_iterations = 1;
+    rc = evaluate(s, eval, user, 0, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE);   // :78-83
+    if (rc < 0) return rc;
+    launch_violations(s);
+    if (read_scalars(s, 16, 2)) return CALIPSO_ERR_HIP;
+    double equality_violation = s->hscal[16];            // :85
+    double cone_product_violation = s->hscal[17];        // :86 — read BEFORE cone!(product) below, i.e. stale on first use (reference quirk)
+    launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT | CALIPSO_CONE_TARGET);   // :88-91
+    filter_reset(s);                                      // :95
+    int worst = 0;
+    for (calipso::i64 j = 1; j <= o.max_outer_iterations; ++j) {
+        s->stats.outer = j;
+        for (calipso::i64 i = 1; i <= o.max_residual_iterations; ++i) {
+            IterInfo info;
+            rc = inner_iteration(s, eval, user, equality_violation, cone_product_violation, info, &equality_violation, &cone_product_violation);
+            if (rc < 0) return rc;
+            worst = std::max(worst, rc);
+            if (info.exit_kind == 1) {
+                if (o.differentiate != 0.0 && d.np > 0) { rc = calipso_hip_differentiate(s, eval, user); if (rc < 0) return rc; }
+                s->stats.total_iterations = total_iterations;
+                SYNC();
+                return 1;
+            }
+            if (info.exit_kind == 2) break;
+            total_iterations += 1;
+            s->stats.total_iterations = total_iterations;
+        }
+        sc.kappa = std::max(o.residual_tolerance / 10.0, std::min(o.central_path_scaling * sc.kappa, std::pow(sc.kappa, o.central_path_exponent)));   // :356
+        sc.tau = std::max(0.99, 1.0 - sc.kappa);                                         // :359
+        launch_lambda_update(s);                                                        // :362-364
+        sc.rho = std::min(std::max(o.penalty_scaling * sc.rho, 1.0 / sc.kappa), o.max_penalty);   // :365
+        filter_reset(s);                                                                // :368
+    }
+    s->stats.total_iterations = total_iterations;
+    SYNC();
+    return 0;
+}
+
+// ---- device QP evaluator -----------------------------------------------------------------------------------------------------
+__global__ void k_scale_copy(const double* __restrict__ src, double* __restrict__ dst, size_t n, double a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = a * src[i];
+}
+
+int32_t calipso_hip_qp_attach(H* s, const double* P, const double* q, const double* A, const double* b, const double* G, const double* h,
+                              double objective_scale) {
+    if (!s || !P || !q) return CALIPSO_ERR_ARGUMENT;
+    const Dims& d = s->d;
+    if ((d.ne && (!A || !b)) || (d.nc && (!G || !h))) return CALIPSO_ERR_ARGUMENT;
+    CK(hipSetDevice(s->device));
+    const size_t nx = d.nx;
+    if (!s->qp.q) { if (dalloc(s, &s->qp.q, nx) || dalloc(s, &s->qp.b, (size_t)d.ne) || dalloc(s, &s->qp.h, (size_t)d.nc)) return CALIPSO_ERR_HIP; }
+    // Lxx = 2c P ; gx = A ; hx = -G   (constant Hessian / Jacobians of the QP)
+    CK(hipMemcpyAsync(s->S, P, sizeof(double) * nx * nx, hipMemcpyHostToDevice, s->stream));   // S is free before the first factorisation
+    hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((nx * nx + 255) / 256)), dim3(256), 0, s->stream, s->S, s->Lxx, nx * nx, 2.0 * objective_scale);
+    CK(hipMemcpyAsync(s->qp.q, q, sizeof(double) * nx, hipMemcpyHostToDevice, s->stream));
+    if (d.ne) {
+        CK(hipMemcpyAsync(s->gx, A, sizeof(double) * d.ne * nx, hipMemcpyHostToDevice, s->stream));
+        CK(hipMemcpyAsync(s->qp.b, b, sizeof(double) * d.ne, hipMemcpyHostToDevice, s->stream));
+    }
+    if (d.nc) {
+        CK(hipMemcpyAsync(s->WH, G, sizeof(double) * d.nc * nx, hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)(((size_t)d.nc * nx + 255) / 256)), dim3(256), 0, s->stream, s->WH, s->hx, (size_t)d.nc * nx, -1.0);
+        CK(hipMemcpyAsync(s->qp.h, h, sizeof(double) * d.nc, hipMemcpyHostToDevice, s->stream));
+    }
+    SYNC();
+    s->qp.attached = true;
+    s->qp.scale = objective_scale;
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_qp_evaluate(H* s, int32_t which, uint32_t flags) {
+    if (!s || !s->qp.attached) return CALIPSO_ERR_ARGUMENT;
+    launch_qp_evaluate(s, point_of(s, which), flags);
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    if (!s->qp.attached) { s->err = "calipso_hip_newton_step needs a device evaluator (calipso_hip_qp_attach)"; return CALIPSO_ERR_ARGUMENT; }
+    const Dims& d = s->d;
+    const Scalars saved_sc = s->sc;
+    std::vector<double> ft, fm; calipso::i64 fi = 0;
+    if (!advance) {
+        CK(hipMemcpyAsync(s->saved_point, s->solution, sizeof(double) * d.N, hipMemcpyDeviceToDevice, s->stream));
+        if (d.ne) CK(hipMemcpyAsync(s->saved_g, s->g, sizeof(double) * d.ne, hipMemcpyDeviceToDevice, s->stream));
+        if (d.nc) CK(hipMemcpyAsync(s->saved_h, s->hc, sizeof(double) * d.nc, hipMemcpyDeviceToDevice, s->stream));
+        CK(hipMemcpyAsync(s->dscal + 32, s->dscal, sizeof(double) * 2, hipMemcpyDeviceToDevice, s->stream));
+        ft = s->filter_theta; fm = s->filter_merit; fi = s->filter_index;
+    }
+    IterInfo info;
+    double ev = 1.0e30, cv = 1.0e30;   // never "converged": the benchmark step always computes a direction
+    EV(8);
+    int rc = inner_iteration(s, nullptr, nullptr, ev, cv, info, &ev, &cv);
+    EV(9);
+    if (rc < 0) return rc;
+    if (!advance) {
+        CK(hipMemcpyAsync(s->solution, s->saved_point, sizeof(double) * d.N, hipMemcpyDeviceToDevice, s->stream));
+        if (d.ne) CK(hipMemcpyAsync(s->g, s->saved_g, sizeof(double) * d.ne, hipMemcpyDeviceToDevice, s->stream));
+        if (d.nc) CK(hipMemcpyAsync(s->hc, s->saved_h, sizeof(double) * d.nc, hipMemcpyDeviceToDevice, s->stream));
+        CK(hipMemcpyAsync(s->dscal, s->dscal + 32, sizeof(double) * 2, hipMemcpyDeviceToDevice, s->stream));
+        launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT);
+        s->filter_theta = ft; s->filter_merit = fm; s->filter_index = fi;
+        const double keep_ep = s->sc.ep, keep_ed = s->sc.ed;
+        s->sc = saved_sc; s->sc.ep = keep_ep; s->sc.ed = keep_ed;   // eps_last restored: every benchmark step repeats IC-1
+    }
+    SYNC();
+    if (info_out) {
+        info_out[0] = info.step_size; info_out[1] = info.step_size_t; info_out[2] = info.rounds; info_out[3] = (double)info.nfact;
+        info_out[4] = info.Mh; info_out[5] = info.thetah;
+    }
+    float ms = 0.f;
+    if (info.exit_kind == 0) {
+        (void)hipEventElapsedTime(&ms, s->ev[0], s->ev[1]); s->phase_ms[0] = ms;
+        (void)hipEventElapsedTime(&ms, s->ev[2], s->ev[3]); s->phase_ms[2] = ms;   // search direction (factor + solve + refine)
+        (void)hipEventElapsedTime(&ms, s->ev[3], s->ev[4]); s->phase_ms[5] = ms;
+    }
+    (void)hipEventElapsedTime(&ms, s->ev[8], s->ev[9]); s->phase_ms[6] = ms;
+    return rc;
+}
+
+int32_t calipso_hip_phase_times(H* s, double out[9]) {
+    if (!s || !out) return CALIPSO_ERR_ARGUMENT;
+    for (int i = 0; i < 9; ++i) out[i] = s->phase_ms[i];
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_splitmix_uniform(uint64_t problem_id, uint64_t stream_id, double lo, double hi, int64_t count, double* out) {
+    if (!out && count > 0) return CALIPSO_ERR_ARGUMENT;
+    uint64_t state = 0xCA11B50000000000ULL + 4096ULL * problem_id + stream_id;
+    for (int64_t i = 0; i < count; ++i) {
+        state += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z = z ^ (z >> 31);
+        out[i] = lo + (hi - lo) * ((double)(z >> 11) * (1.0 / 9007199254740992.0));
+    }
+    return CALIPSO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// cones.hip — cone algebra kernels (reference: src/solver/cones/{cone,nonnegative,second_order}.jl).
+// Cone vectors are a few thousand entries: these kernels are latency-bound, so each is ONE workgroup of 1024
+// threads with deterministic in-workgroup reductions (no atomics, bit-reproducible run to run).
+//   lanes stride over the nonnegative entries; second-order cones are handled one cone per lane for dimension <= 8
+//   and one cone per wavefront (lanes stride over the cone's entries, DPP/shuffle reductions) above that.
+#include "internal.hpp"
+#include "device_utils.hpp"
+
+namespace calipso {
+
+constexpr int CONE_THREADS = 1024;
+constexpr int SOC_WAVE_DIM = 8;   // cones larger than this use a whole wavefront
+
+// cone!(...; barrier, barrier_gradient, product, target)  cones/cone.jl:71-106
+//   barrier          Phi = sum log s_i + sum 1/2 log(s1^2 - |s2:|^2)           nonnegative.jl:11, second_order.jl:13
+//   barrier_gradient 1/s_i ; [s1; -s2:]/(s1^2 - |s2:|^2)                       nonnegative.jl:12, second_order.jl:14
+//   product          s_i t_i ; [s't; s1 t2: + t1 s2:]                          nonnegative.jl:15, second_order.jl:17
+//   target           1 ; [1; 0...]                                             nonnegative.jl:26, second_order.jl:42
+__global__ __launch_bounds__(CONE_THREADS) void k_cone(Dims d, ConeDev cd, const double* __restrict__ point, int flags,
+                                                        double* __restrict__ product, double* __restrict__ target,
+                                                        double* __restrict__ bgrad, double* __restrict__ dscal) {
+    __shared__ double sm[CONE_THREADS / 64];
+    const double* s = point + d.os();
+    const double* t = point + d.ot();
+    const int tid = threadIdx.x;
+    double phi = 0.0;
+    for (int i = tid; i < d.q; i += CONE_THREADS) {
+        const double si = s[i];
+        if (flags & CALIPSO_CONE_BARRIER) phi += log(si);
+        if (flags & CALIPSO_CONE_BARRIER_GRADIENT) bgrad[i] = 1.0 / si;
+        if (flags & CALIPSO_CONE_PRODUCT) product[i] = si * t[i];
+        if (flags & CALIPSO_CONE_TARGET) target[i] = 1.0;
+    }
+    // small cones: one per lane
+    for (int j = tid; j < d.n_soc; j += CONE_THREADS) {
+        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        if (dim > SOC_WAVE_DIM) continue;
+        double ss = 0.0, dot = 0.0;
+        for (int k = 1; k < dim; ++k) ss += s[st + k] * s[st + k];
+        for (int k = 0; k < dim; ++k) dot += s[st + k] * t[st + k];
+        const double det = s[st] * s[st] - ss;
+        if (flags & CALIPSO_CONE_BARRIER) phi += 0.5 * log(det);
+        if (flags & CALIPSO_CONE_BARRIER_GRADIENT) {
+            const double scale = 1.0 / det;
+            bgrad[st] = scale * s[st];
+            for (int k = 1; k < dim; ++k) bgrad[st + k] = scale * (-s[st + k]);
+        }
+        if (flags & CALIPSO_CONE_PRODUCT) {
+            product[st] = dot;
+            for (int k = 1; k < dim; ++k) product[st + k] = s[st] * t[st + k] + t[st] * s[st + k];
+        }
+        if (flags & CALIPSO_CONE_TARGET) {
+            target[st] = 1.0;
+            for (int k = 1; k < dim; ++k) target[st + k] = 0.0;
+        }
+    }
+    // large cones: one per wavefront, shuffle reductions
+    const int lane = tid & 63, wave = tid >> 6, nwave = CONE_THREADS / 64;
+    for (int j = wave; j < d.n_soc; j += nwave) {
+        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        if (dim <= SOC_WAVE_DIM) continue;
+        double ss = 0.0, dot = 0.0;
+        for (int k = lane; k < dim; k += 64) {
+            const double sk = s[st + k];
+            if (k > 0) ss += sk * sk;
+            dot += sk * t[st + k];
+        }
+        ss = __shfl(wave_sum(ss), 0, 64);
+        dot = __shfl(wave_sum(dot), 0, 64);
+        const double s1 = s[st], t1 = t[st];
+        const double det = s1 * s1 - ss;
+        if ((flags & CALIPSO_CONE_BARRIER) && lane == 0) phi += 0.5 * log(det);
+        for (int k = lane; k < dim; k += 64) {
+            if (flags & CALIPSO_CONE_BARRIER_GRADIENT) bgrad[st + k] = (1.0 / det) * (k == 0 ? s1 : -s[st + k]);
+            if (flags & CALIPSO_CONE_PRODUCT) product[st + k] = (k == 0) ? dot : s1 * t[st + k] + t1 * s[st + k];
+            if (flags & CALIPSO_CONE_TARGET) target[st + k] = (k == 0) ? 1.0 : 0.0;
+        }
+    }
+    if (flags & CALIPSO_CONE_BARRIER) {
+        const double tot = block_sum(phi, sm);
+        if (tid == 0) dscal[1] = tot;
+    }
+}
+
+void launch_cone(calipso_hip_solver* s, const double* point, int flags) {
+    if (s->d.nc == 0) {
+        if (flags & CALIPSO_CONE_BARRIER) (void)hipMemsetAsync(s->dscal + 1, 0, sizeof(double), s->stream);
+        return;
+    }
+    hipLaunchKernelGGL(k_cone, dim3(1), dim3(CONE_THREADS), 0, s->stream, s->d, s->cone, point, flags, s->cone_product,
+                       s->cone_target, s->barrier_gradient, s->dscal);
+}
+
+// cone_violation(xhat, x, tau)  cones/cone.jl:62-68, nonnegative.jl:29-34, second_order.jl:45-47 evaluated for all 26
+// candidate step sizes alpha_k = 2^-k at once:  xhat = x - alpha_k * dx.  mask[k] != 0  <=>  violation at alpha_k.
+// The sequential halving of solve.jl:204-221 stops at the first k without violation, which is what the host picks.
+// xhat is formed exactly as the reference does (x - alpha*dx with alpha a power of two).
+__device__ __forceinline__ void violation_masks(const Dims& d, const ConeDev& cd, const double* __restrict__ x,
+                                                const double* __restrict__ dx, double tau, int nk, int* __restrict__ mask) {
+    const int tid = threadIdx.x;
+    const double omt = 1.0 - tau;
+    for (int i = tid; i < d.q; i += blockDim.x) {
+        const double xi = x[i], dxi = dx[i];
+        double a = 1.0;
+        for (int k = 0; k < nk; ++k, a *= 0.5) {
+            if (xi - a * dxi <= omt * xi) atomicOr(&mask[k], 1);
+        }
+    }
+    for (int j = tid; j < d.n_soc; j += blockDim.x) {
+        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        double a = 1.0;
+        for (int k = 0; k < nk; ++k, a *= 0.5) {
+            double nrm = 0.0;
+            for (int e = 1; e < dim; ++e) {
+                const double df = (x[st + e] - a * dx[st + e]) - omt * x[st + e];
+                nrm += df * df;
+            }
+            if ((x[st] - a * dx[st]) - omt * x[st] <= sqrt(nrm)) atomicOr(&mask[k], 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(CONE_THREADS) void k_cone_search(Dims d, ConeDev cd, const double* __restrict__ sol,
+                                                               const double* __restrict__ step, double tau, int nk,
+                                                               int* __restrict__ icount) {
+    // block 0: slack s with Delta s ; block 1: slack dual t with Delta t   (separate step sizes, solve.jl:190-221)
+    const int off = blockIdx.x == 0 ? d.os() : d.ot();
+    violation_masks(d, cd, sol + off, step + off, tau, nk, icount + (blockIdx.x == 0 ? 6 : 32));
+}
+
+void launch_cone_search(calipso_hip_solver* s) {
+    (void)hipMemsetAsync(s->icount + 6, 0, 58 * sizeof(int), s->stream);
+    if (s->d.nc == 0) return;
+    const int nk = (int)s->opt.max_cone_line_search + 1;
+    hipLaunchKernelGGL(k_cone_search, dim3(2), dim3(CONE_THREADS), 0, s->stream, s->d, s->cone, s->solution, s->step, s->sc.tau,
+                       nk > 26 ? 26 : nk, s->icount);
+}
+
+// candidate s, t for the chosen step sizes (solve.jl:206-208, 216-218)
+__global__ void k_cone_candidate(Dims d, const double* __restrict__ sol, const double* __restrict__ step, double* __restrict__ cand,
+                                 double a_s, double a_t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.nc) {
+        cand[d.os() + i] = sol[d.os() + i] - a_s * step[d.os() + i];
+        cand[d.ot() + i] = sol[d.ot() + i] - a_t * step[d.ot() + i];
+    }
+}
+
+void launch_cone_candidate(calipso_hip_solver* s, double a_s, double a_t) {
+    if (s->d.nc == 0) return;
+    hipLaunchKernelGGL(k_cone_candidate, dim3((s->d.nc + 255) / 256), dim3(256), 0, s->stream, s->d, s->solution, s->step,
+                       s->candidate, a_s, a_t);
+}
+
+// plain cone_violation(xhat, x, tau) on two device vectors of length nc: icount[6] != 0 <=> violation
+__global__ __launch_bounds__(CONE_THREADS) void k_cone_violation(Dims d, ConeDev cd, const double* __restrict__ xhat,
+                                                                  const double* __restrict__ x, double tau, int* __restrict__ icount) {
+    const int tid = threadIdx.x;
+    const double omt = 1.0 - tau;
+    for (int i = tid; i < d.q; i += blockDim.x)
+        if (xhat[i] <= omt * x[i]) atomicOr(&icount[6], 1);
+    for (int j = tid; j < d.n_soc; j += blockDim.x) {
+        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        double nrm = 0.0;
+        for (int e = 1; e < dim; ++e) {
+            const double df = xhat[st + e] - omt * x[st + e];
+            nrm += df * df;
+        }
+        if (xhat[st] - omt * x[st] <= sqrt(nrm)) atomicOr(&icount[6], 1);
+    }
+}
+
+void launch_cone_violation_host(calipso_hip_solver* s, const double* xhat_dev, const double* x_dev, double tau) {
+    (void)hipMemsetAsync(s->icount + 6, 0, sizeof(int), s->stream);
+    if (s->d.nc == 0) return;
+    hipLaunchKernelGGL(k_cone_violation, dim3(1), dim3(CONE_THREADS), 0, s->stream, s->d, s->cone, xhat_dev, x_dev, tau, s->icount);
+}
+
+}  // namespace calipso

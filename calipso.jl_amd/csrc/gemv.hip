@@ -1,0 +1,82 @@
+// gemv.hip — HBM-bound mat-vecs with the dense Hessian / Jacobian blocks (column-major, fp64).
+//   gemv_t: y = alpha * A' x + beta*y   one wavefront per column, lanes stride down the column (512 B per wave load),
+//                                       DPP/shuffle reduction; 4 columns per 256-thread workgroup.
+//   gemv_n: y = alpha * A  x + beta*y   lanes along rows (coalesced), the columns are split over workgroups into
+//                                       chunks; per-chunk partial sums are combined in a fixed order by a second
+//                                       tiny kernel (deterministic — no floating-point atomics).
+// Roofline: bytes = 8*rows*cols per call (each block is read exactly once).
+#include "internal.hpp"
+#include "device_utils.hpp"
+
+namespace calipso {
+
+__global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x,
+                                                 double* __restrict__ y, double alpha, double beta) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= cols) return;
+    const double* a = A + (size_t)col * ld;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int i = lane;
+    for (; i + 192 < rows; i += 256) {
+        acc0 += a[i] * x[i];
+        acc1 += a[i + 64] * x[i + 64];
+        acc2 += a[i + 128] * x[i + 128];
+        acc3 += a[i + 192] * x[i + 192];
+    }
+    for (; i < rows; i += 64) acc0 += a[i] * x[i];
+    const double r = wave_sum((acc0 + acc1) + (acc2 + acc3));
+    if (lane == 0) y[col] = (beta == 0.0) ? alpha * r : alpha * r + beta * y[col];
+}
+
+void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta) {
+    if (cols == 0) return;
+    hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4), dim3(256), 0, s->stream, rows, cols, A, ld, x, y, alpha, beta);
+}
+
+constexpr int GN_ROWS = 256;    // rows per workgroup
+constexpr int GN_MAXCHUNK = 64; // column chunks
+
+__global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(int rows, int cols, int chunk, const double* __restrict__ A, int ld,
+                                                             const double* __restrict__ x, double* __restrict__ partial) {
+    const int i = blockIdx.x * GN_ROWS + threadIdx.x;
+    const int c0 = blockIdx.y * chunk;
+    const int c1 = min(cols, c0 + chunk);
+    if (i >= rows) return;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int j = c0;
+    for (; j + 3 < c1; j += 4) {
+        acc0 += A[i + (size_t)j * ld] * x[j];
+        acc1 += A[i + (size_t)(j + 1) * ld] * x[j + 1];
+        acc2 += A[i + (size_t)(j + 2) * ld] * x[j + 2];
+        acc3 += A[i + (size_t)(j + 3) * ld] * x[j + 3];
+    }
+    for (; j < c1; ++j) acc0 += A[i + (size_t)j * ld] * x[j];
+    partial[(size_t)blockIdx.y * rows + i] = (acc0 + acc1) + (acc2 + acc3);
+}
+
+__global__ void k_gemv_n_reduce(int rows, int nchunk, const double* __restrict__ partial, double* __restrict__ y, double alpha, double beta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    double acc = 0.0;
+    for (int c = 0; c < nchunk; ++c) acc += partial[(size_t)c * rows + i];
+    y[i] = (beta == 0.0) ? alpha * acc : alpha * acc + beta * y[i];
+}
+
+void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta) {
+    if (rows == 0) return;
+    // enough workgroups to cover the chip: rows/256 row blocks x nchunk column chunks ~ 1024 workgroups
+    const int rb = (rows + GN_ROWS - 1) / GN_ROWS;
+    int nchunk = (1024 + rb - 1) / rb;
+    if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
+    if (nchunk > (cols + 15) / 16) nchunk = (cols + 15) / 16;
+    if (nchunk < 1) nchunk = 1;
+    const int chunk = (cols + nchunk - 1) / nchunk;
+    nchunk = (cols + chunk - 1) / chunk;
+    if (cols == 0) nchunk = 0;
+    if (nchunk > 0)
+        hipLaunchKernelGGL(k_gemv_n_partial, dim3(rb, nchunk), dim3(GN_ROWS), 0, s->stream, rows, cols, chunk, A, ld, x, s->gemv_partial);
+    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 255) / 256), dim3(256), 0, s->stream, rows, nchunk, s->gemv_partial, y, alpha, beta);
+}
+
+}  // namespace calipso

@@ -1,0 +1,190 @@
+// internal.hpp — device state and kernel launchers shared by the translation units of libcalipso_hip.so.
+// Product code (gfx950 only).  Nothing in here touches oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/calipso_hip.h"
+
+namespace calipso {
+
+typedef int64_t i64;
+
+constexpr int TILE = 128;   // Schur-complement (SYRK) workgroup tile
+constexpr int NB = 64;      // LDL^T panel width
+constexpr int MAX_SOC_DIM = 64;
+
+// options.jl:6-59 (hot-path relevant subset + the rest for API parity)
+struct Options {
+    double residual_norm = 1.0, constraint_norm = 1.0;
+    i64 max_outer_iterations = 10, max_residual_iterations = 100;
+    double scaling_line_search = 0.5;
+    i64 max_residual_line_search = 25, max_cone_line_search = 25;
+    i64 iterative_refinement = 1, max_iterative_refinement = 10, min_iterative_refinement = 1;
+    double iterative_refinement_tolerance = 1.0e-10;
+    double central_path_initial = 1.0, central_path_update_tolerance = 10.0, central_path_scaling = 0.2, central_path_exponent = 1.5;
+    double penalty_initial = 1.0, penalty_scaling = 10.0, dual_initial = 0.0;
+    double residual_tolerance = 1.0e-4, optimality_tolerance = 1.0e-4, slack_tolerance = 1.0e-4, equality_tolerance = 1.0e-4,
+           complementarity_tolerance = 1.0e-4;
+    double min_regularization = 1.0e-20, primal_regularization_initial = 1.0e-7, dual_regularization_initial = 1.0e-7,
+           max_regularization = 1.0e40, dual_regularization = 1.0e-8, dual_regularization_exponent = 0.25,
+           scaling_regularization_initial = 100.0, scaling_regularization = 8.0, scaling_regularization_last = 1.0 / 3.0;
+    double min_central_path = 1.0e-8, max_penalty = 1.0e8;
+    double constraint_tensor = 1.0, update_factorization = 1.0;
+    double violation_tolerance = 1.0e-5, violation_exponent = 1.1, merit_tolerance = 1.0e-5, merit_exponent = 2.3,
+           armijo_tolerance = 1.0e-4, machine_tolerance = 1.0e-16;
+    double max_filter = 1000, differentiate = 1.0, warmstart = 0.0;
+};
+
+// scalars the host owns and passes to kernels by value (solver.jl:81-127)
+struct Scalars {
+    double kappa = 0.1, tau = 0.99, rho = 10.0, ep = 0.0, ep_last = 0.0, ed = 0.0;
+};
+
+struct Dims {
+    int nx, np, ne, nc, n, N, m;  // m = ne + nc
+    int q;                        // number of nonnegative entries (cone-local 0..q-1)
+    int n_soc;                    // number of (non-empty) second-order cones
+    int max_dim;                  // largest SOC dimension
+    int NP;                       // nx padded to a multiple of TILE
+    // offsets into a Point (point.jl:13-22)
+    __host__ __device__ int orr() const { return nx; }
+    __host__ __device__ int os() const { return nx + ne; }
+    __host__ __device__ int oy() const { return nx + ne + nc; }
+    __host__ __device__ int oz() const { return nx + ne + nc + ne; }
+    __host__ __device__ int ot() const { return nx + ne + nc + ne + nc; }
+};
+
+// device-side description of the cone layout (every cone is a contiguous range; validated at create)
+struct ConeDev {
+    int* soc_start = nullptr;   // [n_soc] cone-local start of each SOC
+    int* soc_dim = nullptr;     // [n_soc]
+    int* soc_woff = nullptr;    // [n_soc] offset of its d x d weight block in Wsoc
+    int* entry_soc = nullptr;   // [nc] SOC id of an entry, -1 for nonnegative entries
+};
+
+struct QpEval {
+    bool attached = false;
+    double scale = 0.5;
+    double *P = nullptr, *q = nullptr, *A = nullptr, *b = nullptr, *G = nullptr, *h = nullptr;   // device
+};
+
+struct Stats {
+    i64 total_iterations = 0, outer = 0, factorizations = 0, refine_fail = 0, refine_max = 0, fallbacks = 0, last_refine = 0, newton_steps = 0;
+};
+
+}  // namespace calipso
+
+struct calipso_hip_solver {
+    calipso::Dims d;
+    calipso::Options opt;
+    calipso::Scalars sc;
+    calipso::ConeDev cone;
+    calipso::QpEval qp;
+    calipso::Stats stats;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, double*> optd;
+    // host copies of the layout
+    std::vector<int> h_soc_start, h_soc_dim, h_soc_woff;
+    std::vector<int64_t> h_nonneg, h_soc_ptr, h_soc_idx;
+    // ---- device buffers -------------------------------------------------------------------------------------------
+    // ProblemData
+    double *Lxx = nullptr, *gx = nullptr, *hx = nullptr;                      // nx*nx, ne*nx, nc*nx
+    double *fx = nullptr, *gyx = nullptr, *hzx = nullptr, *g = nullptr, *hc = nullptr;   // nx, nx, nx, ne, nc
+    double *cone_product = nullptr, *cone_target = nullptr, *barrier_gradient = nullptr;  // nc
+    double* dscal = nullptr;   // device scalars: [0] objective [1] barrier  [2..] reduction outputs (see kernels)
+    double* hscal = nullptr;   // pinned host mirror of dscal
+    double *jacobian_parameters = nullptr, *solution_sensitivity = nullptr;   // N*np
+    // points
+    double *solution = nullptr, *candidate = nullptr, *lambda = nullptr, *parameters = nullptr;
+    double *residual = nullptr, *residual_error = nullptr, *step = nullptr, *step_correction = nullptr, *saved_point = nullptr;
+    double *residual_symmetric = nullptr, *step_symmetric = nullptr, *merit_gradient = nullptr;
+    double* Kdense = nullptr;  // n*n, allocated on first request
+    // factorisation
+    double* S = nullptr;        // NP*NP: Schur complement onto x, then L (unit lower) in place
+    double* Dx = nullptr;       // NP: pivots of S
+    double* Ypanel = nullptr;   // NP*NB: L21*D of the current panel
+    double* Linv = nullptr;     // (NP/NB) * NB*NB: inverses of the unit-lower diagonal blocks of L
+    double* WH = nullptr;       // nc*nx: Omega_z * hx
+    double* wz = nullptr;       // nc: Omega for nonnegative entries (-1/K_zz)
+    double* kzz = nullptr;      // nc: K_zz diagonal for nonnegative entries
+    double* Wsoc = nullptr;     // sum d^2: (-B_sym)^-1 per SOC
+    double* Bsoc = nullptr;     // sum d^2: the reference's (non-symmetric) K_zz SOC block
+    double* socwork = nullptr;  // 2 * sum d^2 scratch
+    int* icount = nullptr;      // device ints: [0] pos [1] nonpos [2] zero (constraint part), [3..5] same for S, [6..] cone-search masks
+    int* hicount = nullptr;     // pinned host mirror
+    double* gemv_partial = nullptr;   // partial sums for column-split mat-vecs
+    double* vtmp = nullptr;     // 4*N scratch vectors
+    double *xbuf = nullptr, *zf = nullptr, *t1 = nullptr, *t2 = nullptr;   // NP, NP, m, m: work vectors of the condensed solve
+    double *saved_g = nullptr, *saved_h = nullptr;                          // ne, nc (benchmark-mode restore)
+    double *lgp = nullptr, *gp = nullptr, *hp = nullptr;                    // nx*np, ne*np, nc*np parameter Jacobians
+    std::vector<double> hparams;
+    double* multi_rhs = nullptr;  // workspace for differentiate (allocated on demand)
+    hipEvent_t ev[16];
+    double phase_ms[9] = {0};
+    // filter (filter.jl:1-13), host side
+    std::vector<double> filter_theta, filter_merit, cache_theta, cache_merit;
+    calipso::i64 filter_index = 0;
+    // host staging
+    std::vector<double> hpoint, hstage;
+};
+
+namespace calipso {
+
+// ---- launchers (each enqueues on s->stream; no host synchronisation unless stated) -------------------------------
+// cones.hip
+void launch_cone(calipso_hip_solver* s, const double* point, int flags);
+void launch_cone_search(calipso_hip_solver* s);                 // fills icount[6..] violation masks for alpha = 2^-k
+void launch_cone_candidate(calipso_hip_solver* s, double a_s, double a_t);
+void launch_cone_violation_host(calipso_hip_solver* s, const double* xhat_dev, const double* x_dev, double tau);
+// vectors.hip
+void launch_residual(calipso_hip_solver* s);
+void launch_violations(calipso_hip_solver* s);                  // -> dscal[8..]
+void launch_residual_symmetric(calipso_hip_solver* s, const double* res);
+void launch_recover(calipso_hip_solver* s, double* step, const double* res);
+void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s);
+void launch_accept(calipso_hip_solver* s, double step_size);
+void launch_merit(calipso_hip_solver* s, const double* point);  // -> dscal[4] (M), uses dscal[0], dscal[1]
+void launch_merit_gradient(calipso_hip_solver* s);
+void launch_constraint_violation(calipso_hip_solver* s, const double* point);   // -> dscal[5]
+void launch_dot_merit(calipso_hip_solver* s);                   // -> dscal[6]
+void launch_Hmul(calipso_hip_solver* s, const double* v, double* out);   // out = H v
+void launch_residual_error(calipso_hip_solver* s, const double* step);   // residual_error = residual - H step ; dscal[7] = inf-norm
+void launch_add(calipso_hip_solver* s, double* y, const double* x, int len);    // y += x
+void launch_assemble_K(calipso_hip_solver* s);
+// gemv.hip
+void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta);
+void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta);
+// schur.hip
+void launch_cone_weights(calipso_hip_solver* s);
+void launch_scale_rows(calipso_hip_solver* s);
+void launch_schur(calipso_hip_solver* s);
+// ldl.hip
+void launch_ldl(calipso_hip_solver* s);
+void launch_trsv(calipso_hip_solver* s, double* x);            // x (length NP) <- S^-1 x using L, D
+// solvek.hip
+void launch_omega_apply(calipso_hip_solver* s, const double* in_m, double* out_m, double sign);   // out = sign * Omega * in (length ne+nc)
+void launch_copy_pad(calipso_hip_solver* s, const double* src, int n, double* dst, int npad);
+void launch_sub(calipso_hip_solver* s, const double* a, const double* b, double* out, int n);     // out = a - b
+void launch_init_point(calipso_hip_solver* s);                 // initialize_slacks!/duals! (initialize.jl:15-36), r <- g
+void launch_lambda_update(calipso_hip_solver* s);              // lambda += rho * r (solve.jl:362-364)
+void launch_jacobian_parameters(calipso_hip_solver* s);        // residual_jacobian_parameters.jl:1-40
+void launch_negate_copy(calipso_hip_solver* s, const double* src, double* dst, int n);
+void linear_solve_device(calipso_hip_solver* s);               // step_symmetric = K^-1 residual_symmetric
+// qp.hip
+void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
+
+int check(calipso_hip_solver* s, hipError_t e, const char* what);
+}  // namespace calipso
+
+#define CK(call)                                                        \
+    do {                                                                \
+        hipError_t e__ = (call);                                        \
+        if (e__ != hipSuccess) return calipso::check(s, e__, #call);    \
+    } while (0)

@@ -1,0 +1,57 @@
+// qp.hip — device-resident evaluator for the conic QP  min c x'Px + q'x  s.t. Ax-b = 0, h-Gx in K  (SURVEY.md 8(d)),
+// i.e. the user-evaluation part of evaluate! (src/solver/evaluate.jl:37-121) for the synthetic benchmark problems, done as
+// HBM-bound mat-vecs so a Newton step never leaves the GPU.  With Lxx = 2cP, gx = A, hx = -G held by the handle:
+//   f = 1/2 x'Lxx x + q'x      fx = Lxx x + q      g = gx x - b      (g'y)x = gx'y      h = hvec + hx x      (h'z)x = hx'z
+#include "internal.hpp"
+#include "device_utils.hpp"
+
+namespace calipso {
+
+__global__ __launch_bounds__(1024) void k_qp_objective(int nx, const double* __restrict__ x, const double* __restrict__ Lx,
+                                                        const double* __restrict__ q, double* __restrict__ dscal) {
+    __shared__ double sm[16];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nx; i += 1024) { a += x[i] * Lx[i]; b += q[i] * x[i]; }
+    const double ra = block_sum(a, sm);
+    const double rb = block_sum(b, sm);
+    if (threadIdx.x == 0) dscal[0] = 0.5 * ra + rb;
+}
+
+__global__ void k_vec_add(int n, const double* __restrict__ a, const double* __restrict__ b, double sign, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + sign * b[i];
+}
+
+void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags) {
+    const Dims& d = s->d;
+    const double* x = point;
+    const double* y = point + d.oy();
+    const double* z = point + d.oz();
+    double* Lx = s->vtmp + 3 * (size_t)d.N;   // scratch of length >= nx
+    if (flags & (CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_OBJECTIVE_GRADIENT)) {
+        gemv_t(s, d.nx, d.nx, s->Lxx, d.nx, x, Lx, 1.0, 0.0);   // Lxx is symmetric for the QP
+        if (flags & CALIPSO_EVAL_OBJECTIVE)
+            hipLaunchKernelGGL(k_qp_objective, dim3(1), dim3(1024), 0, s->stream, d.nx, x, Lx, s->qp.q, s->dscal);
+        if (flags & CALIPSO_EVAL_OBJECTIVE_GRADIENT)
+            hipLaunchKernelGGL(k_vec_add, dim3((d.nx + 255) / 256), dim3(256), 0, s->stream, d.nx, Lx, s->qp.q, 1.0, s->fx);
+    }
+    if ((flags & CALIPSO_EVAL_EQUALITY) && d.ne) {
+        gemv_n(s, d.ne, d.nx, s->gx, d.ne, x, s->g, 1.0, 0.0);
+        hipLaunchKernelGGL(k_vec_add, dim3((d.ne + 255) / 256), dim3(256), 0, s->stream, d.ne, s->g, s->qp.b, -1.0, s->g);
+    }
+    if (flags & CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT) {
+        if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.ne, y, s->gyx, 1.0, 0.0);
+        else (void)hipMemsetAsync(s->gyx, 0, sizeof(double) * d.nx, s->stream);
+    }
+    if ((flags & CALIPSO_EVAL_CONE) && d.nc) {
+        gemv_n(s, d.nc, d.nx, s->hx, d.nc, x, s->hc, 1.0, 0.0);
+        hipLaunchKernelGGL(k_vec_add, dim3((d.nc + 255) / 256), dim3(256), 0, s->stream, d.nc, s->hc, s->qp.h, 1.0, s->hc);
+    }
+    if (flags & CALIPSO_EVAL_CONE_DUAL_GRADIENT) {
+        if (d.nc) gemv_t(s, d.nc, d.nx, s->hx, d.nc, z, s->hzx, 1.0, 0.0);
+        else (void)hipMemsetAsync(s->hzx, 0, sizeof(double) * d.nx, s->stream);
+    }
+    // Hessian / Jacobians are constant for a QP and were installed by calipso_hip_qp_attach
+}
+
+}  // namespace calipso

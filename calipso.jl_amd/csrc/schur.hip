@@ -1,0 +1,241 @@
+// schur.hip — elimination of the constraint block of the condensed KKT matrix.
+//
+// The condensed matrix of residual_jacobian_variables.jl:110-167 is
+//        K = [ Lxx + ep*I   gx'      hx'  ]     factored by the reference as P K P' = L D L' (qdldl.jl:400-589) in a
+//            [ gx           k_y*I    0    ]     fill-reducing order.  We use the constraint-first order [z | y | x]:
+//            [ hx           0        B_z  ]     the leading (ne+nc) x (ne+nc) block is (block-)diagonal, so its part of
+// the LDL' is closed-form per cone and the trailing update of the whole x-block is ONE rank-(ne+nc) update
+//        S = Lxx + ep*I + omega_y * gx'gx + hx' (Omega_z hx),   omega_y = -1/k_y,  Omega_z = -B_z^-1  (block diagonal)
+// which is the only GEMM-shaped work of the assembly and runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
+// The nx x nx remainder S is factored by ldl.hip.  Only triu(K) is used, as in the reference (qdldl.jl:145-147):
+// second-order blocks B_z are symmetrised from their upper triangle and Lxx is read through its upper triangle.
+#include "internal.hpp"
+#include "device_utils.hpp"
+
+namespace calipso {
+
+// ---- per-cone pivots / weights ----------------------------------------------------------------------------------------
+// nonnegative entry i (residual_jacobian_variables.jl:142-149):  K_zz = -Sbar/(T + Sbar*P) + D,  Sbar = s-ed, T = t, P = ep, D = -ed
+// second-order cone (:151-164):  B = -(Cs + Cbar_t P)^-1 Cbar_t + D  column by column with the closed-form arrow inverse
+// equality rows (:131-133):      k_y = -1/(rho+ep) + (-ed)
+// Also counts the signs of the pivots of this block (compute_inertia!, linear_solver.jl:33-44) into icount[0..2].
+__global__ __launch_bounds__(1024) void k_cone_weights(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w,
+                                                        double* __restrict__ kzz, double* __restrict__ wz, double* __restrict__ Bsoc,
+                                                        double* __restrict__ Wsoc, double* __restrict__ work, int* __restrict__ icount) {
+    __shared__ int smi[3][16];
+    const int tid = threadIdx.x;
+    const double* sl = w + d.os();
+    const double* t = w + d.ot();
+    const double Hss = 0.0 + sc.ep;
+    int pos = 0, nonpos = 0, zero = 0;
+    for (int i = tid; i < d.q; i += 1024) {
+        const double Sb = sl[i] - sc.ed, Ti = t[i];
+        const double k = -1.0 * Sb / (Ti + Sb * Hss) + (0.0 - sc.ed);
+        kzz[i] = k;
+        wz[i] = -1.0 / k;
+        pos += k > 0.0; nonpos += k <= 0.0; zero += k == 0.0;
+    }
+    for (int j = tid; j < d.n_soc; j += 1024) {
+        const int st = cd.soc_start[j], dim = cd.soc_dim[j], off = cd.soc_woff[j];
+        double* B = Bsoc + off;
+        double* W = Wsoc + off;
+        double* M = work + 2 * off;          // LDL' of the symmetrised block
+        double u[MAX_SOC_DIM], c[MAX_SOC_DIM], o[MAX_SOC_DIM];
+        const double sb1 = sl[st] - sc.ed;
+        u[0] = t[st] + sb1 * Hss;
+        for (int k = 1; k < dim; ++k) u[k] = t[st + k] + sl[st + k] * Hss;
+        for (int col = 0; col < dim; ++col) {
+            for (int a = 0; a < dim; ++a) c[a] = (a == col) ? sb1 : (col == 0 ? sl[st + a] : (a == 0 ? sl[st + col] : 0.0));
+            arrow_inverse(dim, u, c, o);
+            for (int a = 0; a < dim; ++a) B[a + col * dim] = 0.0 - o[a];
+        }
+        for (int a = 0; a < dim; ++a) B[a + a * dim] += (0.0 - sc.ed);
+        // symmetrise from the upper triangle (what a triu-only factorisation sees) and factor without pivoting
+        for (int a = 0; a < dim; ++a)
+            for (int b = 0; b < dim; ++b) M[a + b * dim] = (a <= b) ? B[a + b * dim] : B[b + a * dim];
+        for (int jj = 0; jj < dim; ++jj) {
+            const double dj = M[jj + jj * dim];
+            pos += dj > 0.0; nonpos += dj <= 0.0; zero += dj == 0.0;
+            for (int i = jj + 1; i < dim; ++i) {
+                const double yij = M[i + jj * dim];
+                const double l = yij / dj;
+                for (int k = jj + 1; k <= i; ++k) M[i + k * dim] -= l * M[k + jj * dim];
+                M[i + jj * dim] = l;
+                M[jj + i * dim] = yij;   // keep the unscaled column in the upper part for the update above
+            }
+        }
+        // W = -(B_sym)^-1 : solve L D L' x = e_c
+        for (int col = 0; col < dim; ++col) {
+            for (int a = 0; a < dim; ++a) o[a] = (a == col) ? 1.0 : 0.0;
+            for (int a = 0; a < dim; ++a) { double x = o[a]; for (int k = 0; k < a; ++k) x -= M[a + k * dim] * o[k]; o[a] = x; }
+            for (int a = 0; a < dim; ++a) o[a] /= M[a + a * dim];
+            for (int a = dim - 1; a >= 0; --a) { double x = o[a]; for (int k = a + 1; k < dim; ++k) x -= M[k + a * dim] * o[k]; o[a] = x; }
+            for (int a = 0; a < dim; ++a) W[a + col * dim] = -o[a];
+        }
+    }
+    if (tid == 0 && d.ne > 0) {
+        const double ky = -1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed);
+        if (ky > 0.0) pos += d.ne;
+        if (ky <= 0.0) nonpos += d.ne;
+        if (ky == 0.0) zero += d.ne;
+    }
+    pos = wave_sum_i(pos); nonpos = wave_sum_i(nonpos); zero = wave_sum_i(zero);
+    if ((tid & 63) == 0) { smi[0][tid >> 6] = pos; smi[1][tid >> 6] = nonpos; smi[2][tid >> 6] = zero; }
+    __syncthreads();
+    if (tid < 3) {
+        int a = 0;
+        for (int k = 0; k < 16; ++k) a += smi[tid][k];
+        icount[tid] = a;
+        icount[3 + tid] = 0;   // reset the counters of the S part (ldl.hip accumulates into them)
+    }
+}
+
+void launch_cone_weights(calipso_hip_solver* s) {
+    hipLaunchKernelGGL(k_cone_weights, dim3(1), dim3(1024), 0, s->stream, s->d, s->sc, s->cone, s->solution, s->kzz, s->wz, s->Bsoc,
+                       s->Wsoc, s->socwork, s->icount);
+}
+
+// WH = Omega_z * hx  (nc x nx): nonnegative rows scaled by -1/K_zz, second-order rows multiplied by the d x d block W
+__global__ void k_scale_rows(Dims d, ConeDev cd, const double* __restrict__ hx, const double* __restrict__ wz,
+                             const double* __restrict__ Wsoc, double* __restrict__ WH) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = blockIdx.y;
+    if (c >= d.nc) return;
+    const double* h = hx + (size_t)col * d.nc;
+    double v;
+    if (c < d.q) {
+        v = wz[c] * h[c];
+    } else {
+        const int j = cd.entry_soc[c];
+        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        const double* W = Wsoc + cd.soc_woff[j];
+        v = 0.0;
+        for (int b = 0; b < dim; ++b) v += W[(c - st) + b * dim] * h[st + b];
+    }
+    WH[c + (size_t)col * d.nc] = v;
+}
+
+void launch_scale_rows(calipso_hip_solver* s) {
+    if (s->d.nc == 0) return;
+    hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, s->d.nx), dim3(256), 0, s->stream, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH);
+}
+
+// ---- Schur complement on the fp64 matrix cores -----------------------------------------------------------------------------
+// Workgroup = 256 threads = 4 wavefronts (2 x 2), tile 128 x 128 of the lower triangle of S; each wavefront owns a
+// 64 x 64 sub-tile = 4 x 4 MFMA tiles of 16 x 16 (64 accumulator doubles per lane).  The K dimension runs over the
+// ne equality rows, then the nc cone rows, KT rows per LDS stage.  Operand tiles are read from HBM with lanes along k
+// (the contiguous dimension of the column-major Jacobians), stored k-fastest in LDS with a +2 pad so that the
+// ds_read_b64 of an MFMA fragment (16 rows x 4 k) touches 64 distinct banks.
+//   v_mfma_f64_16x16x4_f64:  A: lane l holds A[i = l&15][k = l>>4];  B: lane l holds B[k = l>>4][j = l&15];
+//                            D: lane l, register r holds D[row = (l>>4) + 4r][col = l&15].
+// blockIdx -> tile is XCD-aware: the 8 XCDs each get a contiguous band of tile rows, so the operand columns a band
+// needs are shared through that XCD's L2 instead of being fetched by all eight.
+constexpr int KT = 16;
+constexpr int LDK = KT + 2;
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void stage_load(double* __restrict__ dst /* [TILE][LDK] */, const double* __restrict__ M, int ldm, int kmax,
+                                           int ncols, int k0, int c0, int tid) {
+    // KT x TILE block of M (rows k0.., columns c0..) -> dst[c][k]; out-of-range -> 0
+    const int k = tid % KT;
+    const int cbase = tid / KT;          // 0..7
+#pragma unroll
+    for (int it = 0; it < TILE / (256 / KT); ++it) {
+        const int c = cbase + it * (256 / KT);
+        const int gk = k0 + k, gc = c0 + c;
+        double v = 0.0;
+        if (gk < kmax && gc < ncols) v = M[gk + (size_t)gc * ldm];
+        dst[c * LDK + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_schur(Dims d, Scalars sc, const double* __restrict__ Lxx, const double* __restrict__ gx,
+                                                   const double* __restrict__ hx, const double* __restrict__ WH, double* __restrict__ S,
+                                                   int ntiles) {
+    __shared__ double As[TILE * LDK];
+    __shared__ double Bs[TILE * LDK];
+    // XCD-aware remap: block b runs on XCD b % 8 (observed dispatch order; used for speed only)
+    const int chunk = (gridDim.x + 7) / 8;
+    const int t = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+    if (t >= ntiles) return;
+    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int i0 = ti * TILE, j0 = tj * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fk = lane >> 4;
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+        const int kmax = phase == 0 ? d.ne : d.nc;
+        const double* MA = phase == 0 ? gx : hx;
+        const double* MB = phase == 0 ? gx : WH;
+#pragma unroll 1
+        for (int k0 = 0; k0 < kmax; k0 += KT) {
+            __syncthreads();
+            stage_load(As, MA, kmax, kmax, d.nx, k0, i0, tid);
+            if (phase == 0 && ti == tj) {
+                // diagonal tile of gx'gx: B operand == A operand
+            } else {
+                stage_load(Bs, MB, kmax, kmax, d.nx, k0, j0, tid);
+            }
+            __syncthreads();
+            const double* Bsrc = (phase == 0 && ti == tj) ? As : Bs;
+#pragma unroll
+            for (int kk = 0; kk < KT / 4; ++kk) {
+                double a[4], b[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m] = As[(wr * 64 + m * 16 + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) b[n] = Bsrc[(wc * 64 + n * 16 + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (phase == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] *= omega_y;
+        }
+    }
+    // epilogue: + Lxx (through its upper triangle, as triu(K)) + ep on the diagonal; identity in the padding
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = i0 + wr * 64 + m * 16 + fk + 4 * r;
+                const int gj = j0 + wc * 64 + n * 16 + fr;
+                double v;
+                if (gi < d.nx && gj < d.nx) {
+                    const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
+                    v = acc[m][n][r] + Lxx[lo + (size_t)hi * d.nx];
+                    if (gi == gj) v += sc.ep;
+                } else {
+                    v = (gi == gj) ? 1.0 : 0.0;
+                }
+                S[gi + (size_t)gj * d.NP] = v;
+            }
+}
+
+void launch_schur(calipso_hip_solver* s) {
+    const int nt = s->d.NP / TILE;
+    const int ntiles = nt * (nt + 1) / 2;
+    const int grid = ((ntiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_schur, dim3(grid), dim3(256), 0, s->stream, s->d, s->sc, s->Lxx, s->gx, s->hx, s->WH, s->S, ntiles);
+}
+
+}  // namespace calipso

@@ -1,0 +1,396 @@
+// vectors.hip — O(N) kernels of the hot path: residual, condensed right-hand side, step recovery, merit, violation,
+// candidate/accept updates, the vector part of the matrix-free H*v, dense K materialisation.
+// N is ~10^4: elementwise kernels are a handful of workgroups; every reduction is ONE workgroup with a fixed
+// summation order (deterministic), its result written to the device scalar block `dscal`.
+#include "internal.hpp"
+#include "device_utils.hpp"
+
+namespace calipso {
+
+constexpr int RT = 1024;  // reduction workgroup size
+
+// residual!(data, problem, idx, solution, kappa, rho, lambda)   residual.jl:1-51
+__global__ void k_residual(Dims d, Scalars sc, const double* __restrict__ w, const double* __restrict__ lam,
+                           const double* __restrict__ fx, const double* __restrict__ gyx, const double* __restrict__ hzx,
+                           const double* __restrict__ g, const double* __restrict__ hc, const double* __restrict__ prod,
+                           const double* __restrict__ targ, double* __restrict__ res) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    double v;
+    if (i < d.orr()) {
+        v = fx[i];
+        v += gyx[i];
+        v += hzx[i];
+    } else if (i < d.os()) {
+        const int k = i - d.orr();
+        v = lam[k] + sc.rho * w[d.orr() + k] - w[d.oy() + k];
+    } else if (i < d.oy()) {
+        const int k = i - d.os();
+        v = -w[d.oz() + k] - w[d.ot() + k];
+    } else if (i < d.oz()) {
+        const int k = i - d.oy();
+        v = g[k];
+        v -= w[d.orr() + k];
+    } else if (i < d.ot()) {
+        const int k = i - d.oz();
+        v = hc[k];
+        v -= w[d.os() + k];
+    } else {
+        const int k = i - d.ot();
+        v = prod[k] - sc.kappa * targ[k];
+    }
+    res[i] = v;
+}
+
+void launch_residual(calipso_hip_solver* s) {
+    hipLaunchKernelGGL(k_residual, dim3((s->d.N + 255) / 256), dim3(256), 0, s->stream, s->d, s->sc, s->solution, s->lambda, s->fx,
+                       s->gyx, s->hzx, s->g, s->hc, s->cone_product, s->cone_target, s->residual);
+}
+
+__device__ __forceinline__ double pnorm_term(double v, int ptype) { return ptype == 2 ? v * v : fabs(v); }
+
+// the reductions of solve.jl:130-135,332-333 and optimality_error.jl:1-27 -> dscal[8..17]
+__global__ __launch_bounds__(RT) void k_violations(Dims d, int ptype, const double* __restrict__ res, const double* __restrict__ w,
+                                                    const double* __restrict__ g, const double* __restrict__ prod,
+                                                    double* __restrict__ dscal) {
+    __shared__ double sm[RT / 64];
+    const int tid = threadIdx.x;
+    double rp = 0.0, rprim = 0.0, ry = 0.0, rz = 0.0, rt = 0.0, y1 = 0.0, z1 = 0.0, t1 = 0.0, ginf = 0.0, pinf = 0.0;
+    for (int i = tid; i < d.N; i += RT) {
+        const double v = res[i];
+        if (ptype == 0) rp = fmax(rp, fabs(v)); else rp += pnorm_term(v, ptype);
+        const double a = fabs(v);
+        if (i < d.n) rprim = fmax(rprim, a);
+        else if (i < d.oz()) ry = fmax(ry, a);
+        else if (i < d.ot()) rz = fmax(rz, a);
+        else rt = fmax(rt, a);
+    }
+    for (int i = tid; i < d.ne; i += RT) { y1 += fabs(w[d.oy() + i]); ginf = fmax(ginf, fabs(g[i])); }
+    for (int i = tid; i < d.nc; i += RT) { z1 += fabs(w[d.oz() + i]); t1 += fabs(w[d.ot() + i]); pinf = fmax(pinf, fabs(prod[i])); }
+    double r;
+    r = (ptype == 0) ? block_max(rp, sm) : block_sum(rp, sm); if (tid == 0) dscal[8] = (ptype == 2) ? sqrt(r) : r;
+    r = block_max(rprim, sm); if (tid == 0) dscal[9] = r;
+    r = block_max(ry, sm);    if (tid == 0) dscal[10] = r;
+    r = block_max(rz, sm);    if (tid == 0) dscal[11] = r;
+    r = block_max(rt, sm);    if (tid == 0) dscal[12] = r;
+    r = block_sum(y1, sm);    if (tid == 0) dscal[13] = r;
+    r = block_sum(z1, sm);    if (tid == 0) dscal[14] = r;
+    r = block_sum(t1, sm);    if (tid == 0) dscal[15] = r;
+    r = block_max(ginf, sm);  if (tid == 0) dscal[16] = r;
+    r = block_max(pinf, sm);  if (tid == 0) dscal[17] = r;
+}
+
+static int norm_type(double p) { return p == 1.0 ? 1 : (p == 2.0 ? 2 : 0); }
+
+void launch_violations(calipso_hip_solver* s) {
+    hipLaunchKernelGGL(k_violations, dim3(1), dim3(RT), 0, s->stream, s->d, norm_type(s->opt.residual_norm), s->residual, s->solution,
+                       s->g, s->cone_product, s->dscal);
+}
+
+// residual_symmetric!   residual.jl:53-101 (condensed right-hand side b)
+__global__ void k_residual_symmetric(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res,
+                                     double* __restrict__ rsym) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double Hrr = sc.rho + sc.ep;   // H[r,r] = rho then += eps_p  (residual_jacobian_variables.jl:60,87)
+    const double Hss = 0.0 + sc.ep;      // H[s,s]
+    if (i < d.nx) {
+        rsym[i] = res[i];
+    } else if (i < d.nx + d.ne) {
+        const int k = i - d.nx;
+        double v = res[d.oy() + k];
+        v += res[d.orr() + k] / Hrr;
+        rsym[i] = v;
+    } else if (i < d.nx + d.ne + d.q) {
+        const int k = i - d.nx - d.ne;
+        const double Sb = w[d.os() + k] - sc.ed, Ti = w[d.ot() + k], Pi = Hss;
+        double v = res[d.oz() + k];
+        v += (res[d.ot() + k] + Sb * res[d.os() + k]) / (Ti + Sb * Pi);
+        rsym[i] = v;
+    } else if (i < d.nx + d.ne + d.q + d.n_soc) {
+        // one lane per second-order cone:  b_z[soc] = r_z + U^-1 (Cbar_t r_s + r_t),  U = Cs + Cbar_t P
+        const int j = i - d.nx - d.ne - d.q;
+        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        double u[MAX_SOC_DIM], v[MAX_SOC_DIM], o[MAX_SOC_DIM];
+        const double* sl = w + d.os() + st; const double* t = w + d.ot() + st;
+        const double* rs = res + d.os() + st; const double* rt = res + d.ot() + st;
+        const double sb1 = sl[0] - sc.ed;
+        u[0] = t[0] + sb1 * Hss;
+        for (int k = 1; k < dim; ++k) u[k] = t[k] + sl[k] * Hss;
+        double acc = sb1 * rs[0];
+        for (int k = 1; k < dim; ++k) acc += sl[k] * rs[k];
+        v[0] = acc + rt[0];
+        for (int k = 1; k < dim; ++k) v[k] = (sl[k] * rs[0] + sb1 * rs[k]) + rt[k];
+        arrow_inverse(dim, u, v, o);
+        for (int k = 0; k < dim; ++k) rsym[d.nx + d.ne + st + k] = res[d.oz() + st + k] + o[k];
+    }
+}
+
+void launch_residual_symmetric(calipso_hip_solver* s, const double* res) {
+    const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
+    hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
+                       s->residual_symmetric);
+}
+
+// search_direction_symmetric!  search_direction.jl:38-101: scatter (dx,dy,dz) and recover dr, ds, dt
+__global__ void k_recover(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res,
+                          const double* __restrict__ dsym, double* __restrict__ step) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double Hrr = sc.rho + sc.ep, Hss = 0.0 + sc.ep;
+    if (i < d.nx) {
+        step[i] = dsym[i];
+    } else if (i < d.nx + d.ne) {
+        const int k = i - d.nx;
+        const double dy = dsym[d.nx + k];
+        step[d.oy() + k] = dy;
+        step[d.orr() + k] = (res[d.orr() + k] + dy) / Hrr;
+    } else if (i < d.nx + d.ne + d.q) {
+        const int k = i - d.nx - d.ne;
+        const double dz = dsym[d.nx + d.ne + k];
+        step[d.oz() + k] = dz;
+        const double Sb = w[d.os() + k] - sc.ed, Ti = w[d.ot() + k], Pi = Hss;
+        const double rt = res[d.ot() + k], rs = res[d.os() + k];
+        const double ds = (rt + Sb * (rs + dz)) / (Ti + Sb * Pi);
+        step[d.os() + k] = ds;
+        step[d.ot() + k] = (rt - Ti * ds) / Sb;
+    } else if (i < d.nx + d.ne + d.q + d.n_soc) {
+        const int j = i - d.nx - d.ne - d.q;
+        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        double u[MAX_SOC_DIM], v[MAX_SOC_DIM], ds[MAX_SOC_DIM], o[MAX_SOC_DIM];
+        const double* sl = w + d.os() + st; const double* t = w + d.ot() + st;
+        const double* rs = res + d.os() + st; const double* rt = res + d.ot() + st;
+        const double* dz = dsym + d.nx + d.ne + st;
+        for (int k = 0; k < dim; ++k) step[d.oz() + st + k] = dz[k];
+        const double sb1 = sl[0] - sc.ed;
+        u[0] = t[0] + sb1 * Hss;
+        for (int k = 1; k < dim; ++k) u[k] = t[k] + sl[k] * Hss;
+        // ds = U^-1 (r_t + Cbar_t (r_s + dz))
+        double acc = sb1 * (rs[0] + dz[0]);
+        for (int k = 1; k < dim; ++k) acc += sl[k] * (rs[k] + dz[k]);
+        v[0] = rt[0] + acc;
+        for (int k = 1; k < dim; ++k) v[k] = rt[k] + (sl[k] * (rs[0] + dz[0]) + sb1 * (rs[k] + dz[k]));
+        arrow_inverse(dim, u, v, ds);
+        for (int k = 0; k < dim; ++k) step[d.os() + st + k] = ds[k];
+        // dt = Cbar_t^-1 (r_t - Cs ds),  Cs = arrow(t)
+        acc = t[0] * ds[0];
+        for (int k = 1; k < dim; ++k) acc += t[k] * ds[k];
+        v[0] = rt[0] - acc;
+        for (int k = 1; k < dim; ++k) v[k] = rt[k] - (t[k] * ds[0] + t[0] * ds[k]);
+        u[0] = sb1;
+        for (int k = 1; k < dim; ++k) u[k] = sl[k];
+        arrow_inverse(dim, u, v, o);
+        for (int k = 0; k < dim; ++k) step[d.ot() + st + k] = o[k];
+    }
+}
+
+void launch_recover(calipso_hip_solver* s, double* step, const double* res) {
+    const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
+    hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
+                       s->step_symmetric, step);
+}
+
+// candidate x, r (, s) = solution - step_size * step    solve.jl:224-229, 268-276
+__global__ void k_axpy_points(Dims d, const double* __restrict__ sol, const double* __restrict__ step, double* __restrict__ cand,
+                              double a, int with_s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lim = with_s ? d.n : d.nx + d.ne;
+    if (i < lim) cand[i] = sol[i] - a * step[i];
+}
+void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s) {
+    hipLaunchKernelGGL(k_axpy_points, dim3((s->d.n + 255) / 256), dim3(256), 0, s->stream, s->d, s->solution, s->step, s->candidate,
+                       step_size, with_s);
+}
+
+// accept: x,r,s <- candidate; y,z -= a*step; t <- candidate t    solve.jl:309-326
+__global__ void k_accept(Dims d, double* __restrict__ sol, const double* __restrict__ cand, const double* __restrict__ step, double a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    if (i < d.n) sol[i] = cand[i];
+    else if (i < d.ot()) sol[i] = sol[i] - a * step[i];
+    else sol[i] = cand[i];
+}
+void launch_accept(calipso_hip_solver* s, double step_size) {
+    hipLaunchKernelGGL(k_accept, dim3((s->d.N + 255) / 256), dim3(256), 0, s->stream, s->d, s->solution, s->candidate, s->step, step_size);
+}
+
+// merit(f, r, Phi, kappa, lambda, rho)   merit.jl:2-15  -> dscal[4]
+__global__ __launch_bounds__(RT) void k_merit(Dims d, Scalars sc, const double* __restrict__ point, const double* __restrict__ lam,
+                                               double* __restrict__ dscal) {
+    __shared__ double sm[RT / 64];
+    const double* r = point + d.orr();
+    double lr = 0.0, rr = 0.0;
+    for (int i = threadIdx.x; i < d.ne; i += RT) { lr += lam[i] * r[i]; rr += r[i] * r[i]; }
+    const double a = block_sum(lr, sm);
+    const double b = block_sum(rr, sm);
+    if (threadIdx.x == 0) {
+        double M = 0.0;
+        M += dscal[0];
+        M += a + 0.5 * sc.rho * b;
+        M -= sc.kappa * dscal[1];
+        dscal[4] = M;
+    }
+}
+void launch_merit(calipso_hip_solver* s, const double* point) {
+    hipLaunchKernelGGL(k_merit, dim3(1), dim3(RT), 0, s->stream, s->d, s->sc, point, s->lambda, s->dscal);
+}
+
+// merit_gradient!   merit.jl:17-31
+__global__ void k_merit_gradient(Dims d, Scalars sc, const double* __restrict__ w, const double* __restrict__ lam,
+                                 const double* __restrict__ fx, const double* __restrict__ bgrad, double* __restrict__ grad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    if (i < d.nx) grad[i] = fx[i];
+    else if (i < d.nx + d.ne) grad[i] = lam[i - d.nx] + sc.rho * w[d.orr() + i - d.nx];
+    else grad[i] = -1.0 * sc.kappa * bgrad[i - d.nx - d.ne];
+}
+void launch_merit_gradient(calipso_hip_solver* s) {
+    hipLaunchKernelGGL(k_merit_gradient, dim3((s->d.n + 255) / 256), dim3(256), 0, s->stream, s->d, s->sc, s->solution, s->lambda, s->fx,
+                       s->barrier_gradient, s->merit_gradient);
+}
+
+// constraint_violation!   constraint_violation.jl:1-13 -> dscal[5]
+__global__ __launch_bounds__(RT) void k_constraint_violation(Dims d, int ptype, const double* __restrict__ point,
+                                                              const double* __restrict__ g, const double* __restrict__ hc,
+                                                              double* __restrict__ dscal) {
+    __shared__ double sm[RT / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < d.ne + d.nc; i += RT) {
+        const double c = (i < d.ne) ? g[i] - point[d.orr() + i] : hc[i - d.ne] - point[d.os() + i - d.ne];
+        if (ptype == 0) acc = fmax(acc, fabs(c)); else acc += pnorm_term(c, ptype);
+    }
+    double r = (ptype == 0) ? block_max(acc, sm) : block_sum(acc, sm);
+    if (threadIdx.x == 0) {
+        if (ptype == 2) r = sqrt(r);
+        dscal[5] = r / (double)(d.ne + d.nc);
+    }
+}
+void launch_constraint_violation(calipso_hip_solver* s, const double* point) {
+    hipLaunchKernelGGL(k_constraint_violation, dim3(1), dim3(RT), 0, s->stream, s->d, norm_type(s->opt.constraint_norm), point, s->g,
+                       s->hc, s->dscal);
+}
+
+// d = dot(merit_gradient, step.primals)   line_search.jl:3,16 -> dscal[6]
+__global__ __launch_bounds__(RT) void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+    __shared__ double sm[RT / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += RT) acc += a[i] * b[i];
+    const double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) *out = r;
+}
+void launch_dot_merit(calipso_hip_solver* s) {
+    hipLaunchKernelGGL(k_dot, dim3(1), dim3(RT), 0, s->stream, s->d.n, s->merit_gradient, s->step, s->dscal + 6);
+}
+
+// vector part of out = H v (block rows of residual_jacobian_variables.jl:1-108); the mat-vec parts were accumulated
+// into out_x, out_y, out_z beforehand.
+__global__ void k_Hmul_vec(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
+                           double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.N) return;
+    if (i < d.nx) {
+        out[i] += sc.ep * v[i];
+    } else if (i < d.os()) {
+        const int k = i - d.orr();
+        out[i] = (sc.rho + sc.ep) * v[i] - v[d.oy() + k];
+    } else if (i < d.oy()) {
+        const int k = i - d.os();
+        out[i] = (0.0 + sc.ep) * v[i] - v[d.oz() + k] - v[d.ot() + k];
+    } else if (i < d.oz()) {
+        const int k = i - d.oy();
+        out[i] += -v[d.orr() + k] + (0.0 - sc.ed) * v[i];
+    } else if (i < d.ot()) {
+        const int k = i - d.oz();
+        out[i] += -v[d.os() + k] + (0.0 - sc.ed) * v[i];
+    } else {
+        const int k = i - d.ot();
+        const double* sl = w + d.os(); const double* t = w + d.ot();
+        const double* vs = v + d.os(); const double* vt = v + d.ot();
+        const int j = cd.entry_soc[k];
+        if (j < 0) {
+            out[i] = t[k] * vs[k] + (sl[k] - sc.ed) * vt[k];
+        } else {
+            const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+            double acc;
+            if (k == st) {   // first row of arrow(t), arrow(s) - ed*I
+                acc = t[st] * vs[st] + (sl[st] - sc.ed) * vt[st];
+                for (int e = 1; e < dim; ++e) acc += t[st + e] * vs[st + e] + sl[st + e] * vt[st + e];
+            } else {
+                acc = t[k] * vs[st] + sl[k] * vt[st];
+                acc += t[st] * vs[k] + (sl[st] - sc.ed) * vt[k];
+            }
+            out[i] = acc;
+        }
+    }
+}
+
+void launch_Hmul(calipso_hip_solver* s, const double* v, double* out) {
+    const Dims& d = s->d;
+    gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, v, out, 1.0, 0.0);
+    if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.ne, v + d.oy(), out, 1.0, 1.0);
+    if (d.nc) gemv_t(s, d.nc, d.nx, s->hx, d.nc, v + d.oz(), out, 1.0, 1.0);
+    if (d.ne) gemv_n(s, d.ne, d.nx, s->gx, d.ne, v, out + d.oy(), 1.0, 0.0);
+    if (d.nc) gemv_n(s, d.nc, d.nx, s->hx, d.nc, v, out + d.oz(), 1.0, 0.0);
+    hipLaunchKernelGGL(k_Hmul_vec, dim3((d.N + 255) / 256), dim3(256), 0, s->stream, d, s->sc, s->cone, s->solution, v, out);
+}
+
+// residual_error = residual - H*step ; dscal[7] = ||residual_error||_inf   (iterative_refinement.jl:8-12,38-41)
+__global__ __launch_bounds__(RT) void k_sub_norm(int N, const double* __restrict__ res, double* __restrict__ e, double* __restrict__ out) {
+    __shared__ double sm[RT / 64];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < N; i += RT) {
+        const double v = res[i] - e[i];
+        e[i] = v;
+        m = fmax(m, fabs(v));
+    }
+    const double r = block_max(m, sm);
+    if (threadIdx.x == 0) *out = r;
+}
+void launch_residual_error(calipso_hip_solver* s, const double* step) {
+    launch_Hmul(s, step, s->residual_error);
+    hipLaunchKernelGGL(k_sub_norm, dim3(1), dim3(RT), 0, s->stream, s->d.N, s->residual, s->residual_error, s->dscal + 7);
+}
+
+__global__ void k_add(int n, double* __restrict__ y, const double* __restrict__ x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+void launch_add(calipso_hip_solver* s, double* y, const double* x, int len) {
+    hipLaunchKernelGGL(k_add, dim3((len + 255) / 256), dim3(256), 0, s->stream, len, y, x);
+}
+
+// dense condensed K (both triangles, as residual_jacobian_variables.jl:110-167 writes it) for inspection / parity.
+// Needs the cone blocks from launch_cone_weights (kzz for nonnegative entries, Bsoc for second-order cones).
+__global__ void k_assemble_K(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ Lxx, const double* __restrict__ gx,
+                             const double* __restrict__ hx, const double* __restrict__ kzz, const double* __restrict__ Bsoc,
+                             double* __restrict__ K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // row (fast, coalesced writes)
+    const int j = blockIdx.y;
+    if (i >= d.n) return;
+    const int nx = d.nx, ne = d.ne;
+    double v = 0.0;
+    if (i < nx && j < nx) {
+        v = Lxx[i + (size_t)j * nx];
+        if (i == j) v += sc.ep;
+    } else if (i < nx || j < nx) {
+        const int c = i < nx ? j : i;      // constraint index
+        const int xk = i < nx ? i : j;     // variable index
+        v = (c < nx + ne) ? gx[(c - nx) + (size_t)xk * ne] : hx[(c - nx - ne) + (size_t)xk * d.nc];
+    } else if (i < nx + ne || j < nx + ne) {
+        if (i == j) v = -1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed);
+    } else {
+        const int a = i - nx - ne, b = j - nx - ne;
+        const int ja = cd.entry_soc[a], jb = cd.entry_soc[b];
+        if (ja < 0 || jb < 0) {
+            if (a == b) v = kzz[a];
+        } else if (ja == jb) {
+            const int st = cd.soc_start[ja], dim = cd.soc_dim[ja];
+            v = Bsoc[cd.soc_woff[ja] + (a - st) + (b - st) * dim];
+        }
+    }
+    K[i + (size_t)j * d.n] = v;
+}
+void launch_assemble_K(calipso_hip_solver* s) {
+    hipLaunchKernelGGL(k_assemble_K, dim3((s->d.n + 255) / 256, s->d.n), dim3(256), 0, s->stream, s->d, s->sc, s->cone, s->Lxx, s->gx,
+                       s->hx, s->kzz, s->Bsoc, s->Kdense);
+}
+
+}  // namespace calipso

@@ -1,0 +1,207 @@
+/*
+ * calipso_hip.h — C ABI of libcalipso_hip.so: the MI355X (gfx950) implementation of CALIPSO's
+ * per-iteration Newton/KKT hot path.
+ *
+ * The reference (thowell/CALIPSO.jl v0.1.1) is pure Julia and has no FFI; the seams this ABI replaces are
+ * Julia functions and types (paths relative to src/solver/ of the reference):
+ *   - exported API            Solver / initialize! / solve!            CALIPSO.jl:48-50, solver.jl:46-173,
+ *                                                                      initialize.jl:9-13, solve.jl:8-377
+ *   - linear-solver seam      LDLSolver, factorize!, compute_inertia!, linear_solve!   linear_solver.jl:1-60
+ *   - per-function seams      cone!, residual!, residual_jacobian_variables(_symmetric)!, residual_symmetric!,
+ *                             search_direction(_symmetric)!, iterative_refinement!, inertia_correction!,
+ *                             cone_violation, merit, merit_gradient!, constraint_violation!, optimality_error,
+ *                             differentiate!      (one entry point each, cited below)
+ * INTEGRATION.md shows the Julia `ccall` binding for every entry point.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types; every function returns an int32 status.
+ *   - all floating point is IEEE fp64; all indices are Int64 and 1-BASED (Julia's), matrices column-major.
+ *   - the caller owns every host buffer; the opaque handle owns device memory, one HIP stream and its events.
+ *   - one handle = one problem shape (nx, np, ne, nc + cone layout); a handle is used by one host thread at a time;
+ *     distinct handles are independent (as distinct `Solver`s are in the reference).
+ *   - host arrays are named by the reference's own field names ("equality_jacobian_variables", "solution", ...).
+ *   - nothing here falls back to the CPU: without a usable HIP device every call fails with CALIPSO_ERR_HIP.
+ */
+#ifndef CALIPSO_HIP_H
+#define CALIPSO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct calipso_hip_solver calipso_hip_solver;
+
+/* status codes: negative = the reference's error() cases, positive = its @warn cases */
+enum {
+    CALIPSO_OK = 0,
+    CALIPSO_ERR_INERTIA = -1,      /* error("inertia correction failure")  inertia.jl:72 */
+    CALIPSO_ERR_CONE_SEARCH = -2,  /* error("cone search failure")         solve.jl:210,220 */
+    CALIPSO_ERR_CALLBACK = -3,     /* the evaluation callback returned non-zero */
+    CALIPSO_ERR_ARGUMENT = -4,     /* unknown field name, wrong length, null pointer */
+    CALIPSO_ERR_HIP = -5,          /* HIP runtime error / no device; text in calipso_hip_last_error */
+    CALIPSO_ERR_LAYOUT = -6,       /* cone index sets violate the layout the reference relies on (cones/cone.jl:27-59 vs residual.jl:46-48) */
+    CALIPSO_WARN_ZERO_PIVOT = 1,   /* @warn "Zero entry in D (matrix is not quasidefinite)" qdldl.jl:309-311 */
+    CALIPSO_WARN_REFINEMENT = 2,   /* @warn "iterative refinement failure" iterative_refinement.jl:50 */
+    CALIPSO_WARN_LINE_SEARCH = 3   /* @warn "residual line search failure" solve.jl:301 */
+};
+
+/* evaluate! keyword flags (evaluate.jl:1-23), one bit each */
+enum {
+    CALIPSO_EVAL_OBJECTIVE = 1u << 0,
+    CALIPSO_EVAL_OBJECTIVE_GRADIENT = 1u << 1,
+    CALIPSO_EVAL_OBJECTIVE_HESSIAN = 1u << 2,
+    CALIPSO_EVAL_EQUALITY = 1u << 3,
+    CALIPSO_EVAL_EQUALITY_JACOBIAN = 1u << 4,
+    CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT = 1u << 5,
+    CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN = 1u << 6,
+    CALIPSO_EVAL_CONE = 1u << 7,
+    CALIPSO_EVAL_CONE_JACOBIAN = 1u << 8,
+    CALIPSO_EVAL_CONE_DUAL_GRADIENT = 1u << 9,
+    CALIPSO_EVAL_CONE_DUAL_HESSIAN = 1u << 10,
+    CALIPSO_EVAL_OBJECTIVE_JACOBIAN_PARAMETERS = 1u << 11,
+    CALIPSO_EVAL_EQUALITY_JACOBIAN_PARAMETERS = 1u << 12,
+    CALIPSO_EVAL_EQUALITY_DUAL_JACOBIAN_PARAMETERS = 1u << 13,
+    CALIPSO_EVAL_CONE_JACOBIAN_PARAMETERS = 1u << 14,
+    CALIPSO_EVAL_CONE_DUAL_JACOBIAN_PARAMETERS = 1u << 15
+};
+
+/* cone! keyword flags (cones/cone.jl:71-77) */
+enum {
+    CALIPSO_CONE_BARRIER = 1 << 0,
+    CALIPSO_CONE_BARRIER_GRADIENT = 1 << 1,
+    CALIPSO_CONE_PRODUCT = 1 << 2,
+    CALIPSO_CONE_JACOBIAN = 1 << 3, /* arrow/diagonal Jacobians are implicit in (s, t) on the device; kept for API parity */
+    CALIPSO_CONE_TARGET = 1 << 4
+};
+
+/* User-evaluation callback: the stand-in for the generated functions evaluate! calls (evaluate.jl:37-121).
+ * Called on the host with the point's x, y, z and the parameters; it must evaluate the flagged quantities and hand
+ * them to the handle with calipso_hip_set_field (the three Hessian terms as ONE summed "lagrangian_hessian").
+ * Return 0 on success. */
+typedef int32_t (*calipso_eval_fn)(void* user, uint32_t flags, const double* x, const double* y, const double* z,
+                                   const double* theta);
+
+/* ---- life cycle ------------------------------------------------------------------------------------------------ */
+/* Solver(methods, nx, np, ne, nc; nonnegative_indices, second_order_indices)   solver.jl:46-150, indices.jl:20-63.
+ * nonneg_idx: n_nonneg cone-local indices (1-based); soc_ptr: n_soc+1 zero-based offsets into soc_idx (1-based,
+ * first entry of each cone is its head).  The sets must be [1..q] followed by contiguous SOC blocks in order
+ * (the only layout for which the reference is self-consistent), else CALIPSO_ERR_LAYOUT. */
+int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx,
+                           int64_t n_soc, const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device,
+                           calipso_hip_solver** out);
+int32_t calipso_hip_destroy(calipso_hip_solver*);
+const char* calipso_hip_last_error(calipso_hip_solver*); /* never NULL */
+const char* calipso_hip_version(void);
+int32_t calipso_hip_device_count(void);
+
+/* ---- data movement (host <-> handle), by the reference's field names ----------------------------------------- */
+/* ProblemData (problem_data.jl:2-31): "objective"[1] "objective_gradient_variables"[nx] "equality_constraint"[ne]
+ *   "equality_jacobian_variables"[ne*nx] "equality_dual_jacobian_variables"[nx] "cone_constraint"[nc]
+ *   "cone_jacobian_variables"[nc*nx] "cone_dual_jacobian_variables"[nx] "lagrangian_hessian"[nx*nx]
+ *   ( = objective_jacobian_variables_variables + equality_dual_..._variables + cone_dual_..._variables,
+ *     residual_jacobian_variables.jl:10-16 )  "cone_product"[nc] "cone_target"[nc] "barrier"[1] "barrier_gradient"[nc]
+ *   "jacobian_parameters"[N*np] ( = dR/dtheta, residual_jacobian_parameters.jl:1-40 )
+ * Points / SolverData (point.jl, solver_data.jl): "solution"[N] "candidate"[N] "residual"[N] "residual_error"[N]
+ *   "step"[N] "step_correction"[N] "residual_symmetric"[n] "step_symmetric"[n] "merit_gradient"[n]
+ *   "jacobian_variables_symmetric"[n*n] (dense K, after calipso_hip_residual_jacobian_variables_symmetric)
+ *   "solution_sensitivity"[N*np] "parameters"[np] "dual"[ne]
+ * Scalars (solver.jl:81-127): "central_path" "fraction_to_boundary" "penalty" "primal_regularization"
+ *   "primal_regularization_last" "dual_regularization";  options (options.jl:6-59): "opt.<field>" (as double). */
+int32_t calipso_hip_set_field(calipso_hip_solver*, const char* name, const double* data, int64_t len);
+int32_t calipso_hip_get_field(calipso_hip_solver*, const char* name, double* data, int64_t len);
+/* Indices (indices.jl:1-63) as the handle computed them, 1-based; returns the length or a negative status */
+int64_t calipso_hip_get_index(calipso_hip_solver*, const char* name, int64_t* out, int64_t cap);
+
+/* ---- the hot path, one entry point per reference function ---------------------------------------------------- */
+/* cone!(problem, methods, idx, point; barrier, barrier_gradient, product, jacobian, target)  cones/cone.jl:71-106
+ * which: 0 = solution, 1 = candidate */
+int32_t calipso_hip_cone(calipso_hip_solver*, int32_t which, int32_t flags);
+/* residual!(data, problem, idx, solution, kappa, rho, lambda)  residual.jl:1-51 */
+int32_t calipso_hip_residual(calipso_hip_solver*);
+/* the reductions solve! takes of the residual and iterate (solve.jl:130-135, optimality_error.jl:1-27):
+ * out[0]=||R||_p/N (p = opt.residual_norm) out[1]=optimality_error out[2]=max(||R_y||inf,||R_z||inf)
+ * out[3]=||equality_constraint||inf out[4]=||cone_product||inf */
+int32_t calipso_hip_violations(calipso_hip_solver*, double out[5]);
+/* residual_jacobian_variables! + residual_jacobian_variables_symmetric!  (residual_jacobian_variables.jl:1-167)
+ * materialised as the dense n x n K for inspection ("jacobian_variables_symmetric"); the factorisation below works
+ * from the blocks and never needs this. */
+int32_t calipso_hip_residual_jacobian_variables_symmetric(calipso_hip_solver*);
+/* out = H * v with the unreduced Jacobian H (never materialised): mul! of iterative_refinement.jl:9,39; v, out host[N] */
+int32_t calipso_hip_jacobian_variables_mul(calipso_hip_solver*, const double* v, double* out);
+/* factorize!(linear_solver, K) + compute_inertia!(linear_solver)   linear_solver.jl:19-44, qdldl.jl:269-317,400-589
+ * LDL^T of P K P' in the constraint-first order [z | y | x]; inertia = (positive, negative, zero).
+ * Returns CALIPSO_WARN_ZERO_PIVOT if an exact zero pivot was met (positive is then -1, as qdldl.jl:456,579). */
+int32_t calipso_hip_factorize(calipso_hip_solver*, int64_t inertia[3]);
+/* inertia_correction!(solver)   inertia.jl:30-80  (IC-1..IC-6 incl. the reference's quirks); n_factorizations may be NULL */
+int32_t calipso_hip_inertia_correction(calipso_hip_solver*, int64_t* n_factorizations);
+/* residual_symmetric!  residual.jl:53-101; which: 0 residual, 1 residual_error */
+int32_t calipso_hip_residual_symmetric(calipso_hip_solver*, int32_t which);
+/* linear_solve!(solver, x, K, b; fact=false): step_symmetric = K \ residual_symmetric with the current factors
+ * (linear_solver.jl:52-60, qdldl.jl:330-351).  The reference's hidden re-factorisation (fact=true) is NOT replicated:
+ * the matrix is unchanged between calipso_hip_factorize and the solves, so the factors are reused. */
+int32_t calipso_hip_linear_solve(calipso_hip_solver*);
+/* search_direction_symmetric!  search_direction.jl:25-104; which: 0 (step <- residual), 1 (step_correction <- residual_error) */
+int32_t calipso_hip_search_direction_symmetric(calipso_hip_solver*, int32_t which);
+/* iterative_refinement!(step, solver)  iterative_refinement.jl:1-52; returns CALIPSO_WARN_REFINEMENT on failure.
+ * rounds / final_norm may be NULL */
+int32_t calipso_hip_iterative_refinement(calipso_hip_solver*, int32_t* rounds, double* final_norm);
+/* search_direction!(solver)  search_direction.jl:1-23 = inertia correction + condensed solve + refinement (+ pivoted
+ * dense fallback on the unreduced system when refinement fails, replacing `H \ R` of :113) */
+int32_t calipso_hip_search_direction(calipso_hip_solver*);
+/* cone fraction-to-boundary search  solve.jl:190-221 with cone_violation (cones/cone.jl:62-68): writes candidate s, t
+ * and returns the two step sizes (2^-k, k = number of halvings).  CALIPSO_ERR_CONE_SEARCH after 25 halvings. */
+int32_t calipso_hip_cone_search(calipso_hip_solver*, double* step_size, double* step_size_cone_slack_dual);
+/* cone_violation(xhat, x, tau, ...)  cones/cone.jl:62-68 on host vectors of length nc; *violated = 0/1 */
+int32_t calipso_hip_cone_violation(calipso_hip_solver*, const double* xhat, const double* x, double tau, int32_t* violated);
+/* candidate x, r (and s when with_cone_slack) = solution - step_size * step   solve.jl:224-229, 268-276 */
+int32_t calipso_hip_candidate(calipso_hip_solver*, double step_size, int32_t with_cone_slack);
+/* merit(f, r, Phi, kappa, lambda, rho)  merit.jl:2-15 on point `which` (uses "objective" and "barrier") */
+int32_t calipso_hip_merit(calipso_hip_solver*, int32_t which, double* M);
+/* merit_gradient!  merit.jl:17-31 (solution point) */
+int32_t calipso_hip_merit_gradient(calipso_hip_solver*);
+/* constraint_violation!(c, g, r, h, s, idx; norm_type)  constraint_violation.jl:1-13 on point `which` */
+int32_t calipso_hip_constraint_violation(calipso_hip_solver*, int32_t which, double* theta);
+/* d = dot(merit_gradient, step.primals) used by switching_condition / armijo (line_search.jl:3,16) */
+int32_t calipso_hip_merit_directional(calipso_hip_solver*, double* d);
+/* accept the candidate: x,r,s <- candidate; y,z -= step_size*step; t <- candidate t   solve.jl:309-326 */
+int32_t calipso_hip_accept(calipso_hip_solver*, double step_size);
+
+/* ---- drivers ----------------------------------------------------------------------------------------------------- */
+/* initialize!(solver, guess)  initialize.jl:9-13 */
+int32_t calipso_hip_initialize(calipso_hip_solver*, const double* guess);
+/* solve!(solver)  solve.jl:8-377: returns 1 (true), 0 (false) or a negative status.  eval may be NULL when a device
+ * evaluator is attached (calipso_hip_qp_attach). */
+int32_t calipso_hip_solve(calipso_hip_solver*, calipso_eval_fn eval, void* user);
+/* differentiate!(solver)  differentiate.jl:1-61: all np right-hand sides in one blocked solve */
+int32_t calipso_hip_differentiate(calipso_hip_solver*, calipso_eval_fn eval, void* user);
+/* statistics of the last solve: [total_iterations, outer, factorizations, refinement_failures, max_refinement_rounds,
+ * fallbacks, last_refinement_rounds, newton_steps] */
+int32_t calipso_hip_stats(calipso_hip_solver*, int64_t out[8]);
+
+/* ---- device-resident conic QP evaluator (synthetic benchmark inputs) ------------------------------- */
+/* min c*x'Px + q'x  s.t. Ax - b = 0, h - Gx in K.  Host arrays are copied once; afterwards evaluate! runs as device
+ * mat-vecs and no host callback is needed (eval = NULL).  P must be symmetric. */
+int32_t calipso_hip_qp_attach(calipso_hip_solver*, const double* P, const double* q, const double* A, const double* b,
+                              const double* G, const double* h, double objective_scale);
+/* evaluate!(...; flags) with the attached evaluator on point `which` */
+int32_t calipso_hip_qp_evaluate(calipso_hip_solver*, int32_t which, uint32_t flags);
+/* One inner Newton iteration of solve! (solve.jl:98-353) at the current iterate with fixed kappa/rho, device evaluator
+ * attached; if `advance` is 0 the iterate is restored afterwards (benchmark mode: every step does identical work).
+ * info[0]=step_size info[1]=step_size_t info[2]=refinement rounds info[3]=factorizations info[4]=M_candidate info[5]=theta_candidate */
+int32_t calipso_hip_newton_step(calipso_hip_solver*, int32_t advance, double info[6]);
+/* timing of the phases of the last calipso_hip_newton_step, in milliseconds, from HIP events on the handle's stream:
+ * [0] evaluate+cone+residual [1] schur (assemble) [2] factor [3] solve+recover [4] refinement [5] search+merit [6] total
+ * and the dominant kernel: [7] schur MFMA kernel ms, [8] number of launches of it */
+int32_t calipso_hip_phase_times(calipso_hip_solver*, double out[9]);
+int32_t calipso_hip_synchronize(calipso_hip_solver*);
+
+/* SplitMix64 uniform stream of SURVEY.md 8(d): seed = 0xCA11B50000000000 + 4096*problem_id + stream_id,
+ * u = (next() >> 11) * 2^-53, out[i] = lo + (hi-lo)*u.  Pure host function. */
+int32_t calipso_hip_splitmix_uniform(uint64_t problem_id, uint64_t stream_id, double lo, double hi, int64_t count, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
