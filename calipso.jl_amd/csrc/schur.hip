@@ -59,7 +59,7 @@ __global__ __launch_bounds__(1024) void k_cone_weights(Dims d, Scalars sc, ConeD
             for (int i = jj + 1; i < dim; ++i) {
                 const double yij = M[i + jj * dim];
                 const double l = yij / dj;
-                for (int k = jj + 1; k <= i; ++k) M[i + k * dim] -= l * M[k + jj * dim];
+                for (int k = jj + 1; k <= i; ++k) M[i + k * dim] -= l * (k == i ? yij : M[jj + k * dim]);   // y_k = unscaled column entry
                 M[i + jj * dim] = l;
                 M[jj + i * dim] = yij;   // keep the unscaled column in the upper part for the update above
             }

@@ -1,0 +1,119 @@
+"""GPU: the full solve! loop (calipso_hip_solve over the HIP kernels) on the reference's own test problems — the same
+known answers / convergence criteria the reference asserts (and that pin the oracle in test_oracle_solve.py), plus agreement
+of the converged solution with the oracle's."""
+import numpy as np
+import pytest
+
+import problems as pr
+from helpers import load_pkg
+from test_oracle_solve import run as run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def run_hip(prob, **opts):
+    pkg = load_pkg()
+    s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, parameters=prob.parameters, nonnegative_indices=prob.nonnegative_indices,
+                   second_order_indices=prob.second_order_indices, options=opts)
+    pkg.initialize_b(s, prob.x0)
+    ok = pkg.solve_b(s)
+    return s, ok
+
+
+def criteria(s, tol=1e-4):
+    """the four checks of every reference solver test, e.g. test/solver/test1.jl:21-30"""
+    res = s.data("residual")
+    assert np.abs(res.all).sum() / s.N < tol
+    slack = max(np.abs(res.equality_dual).max() if s.ne else 0.0, np.abs(res.cone_dual).max() if s.nc else 0.0)
+    assert slack < tol
+    if s.ne:
+        assert np.abs(s.get("equality_constraint", s.ne)).max() <= tol
+    if s.nc:
+        assert np.abs(s.get("cone_product", s.nc)).max() <= tol
+
+
+def test_wachter_c1():
+    """BASELINE config C1: README.md:97-121 / test/solver/wachter.jl:47: x* = [1, 0, 0.5] +- 1e-3"""
+    s, ok = run_hip(pr.wachter())
+    assert ok
+    criteria(s)
+    assert np.abs(s.solution.variables - np.array([1.0, 0.0, 0.5])).max() < 1e-3
+
+
+def test_pendulum_c2(oracle_mod):
+    """BASELINE config C2: pendulum swing-up T = 11 (test/examples/pendulum.jl:3-73), single instance on one MI355X"""
+    prob = pr.pendulum(action_guess=np.zeros(10))
+    s, ok = run_hip(prob)
+    assert ok
+    criteria(s)
+    x = s.solution.variables
+    assert np.abs(x[-2:] - np.array([np.pi, 0.0])).max() < 1e-3 and np.abs(x[:2]).max() < 1e-3
+    o, st = run_oracle(oracle_mod, prob)
+    assert st == 1
+    assert np.abs(x - o.point()["x"]).max() < 1e-3    # same local solution as the oracle
+    assert abs(s.stats()["total_iterations"] - o.stats()["total_iterations"]) <= 2
+
+
+@pytest.mark.parametrize("name", ["maratos", "test1", "knitro"])
+def test_reference_problems(oracle_mod, name):
+    prob = getattr(pr, name)()
+    s, ok = run_hip(prob)
+    assert ok
+    criteria(s)
+    o, st = run_oracle(oracle_mod, prob)
+    assert np.abs(s.solution.variables - o.point()["x"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("v,mu,gamma", [([0.0, 1.0, 1.0], 0.5, 1.0), ([0.0, 10.0, 1.0], 1.0, 1.0), ([0.0, 1.0, 0.0], 0.0, 1.0)])
+def test_friction_cone(v, mu, gamma):
+    """test/solver/friction_cone.jl:19-63 (one second-order cone, no nonnegative cones)"""
+    prob = pr.friction_cone(v, mu, gamma, np.random.default_rng(11).standard_normal(3))
+    s, ok = run_hip(prob)
+    assert ok
+    criteria(s)
+    x = s.solution.variables
+    assert not s.cone_violation(x, np.zeros(3), 0.0)
+    if mu > 0:
+        v_dir = np.array(v[1:]) / np.linalg.norm(v[1:])
+        assert np.abs(v_dir + x[1:] / np.linalg.norm(x[1:])).max() < 1e-3 and np.linalg.norm(x[1:]) <= mu * gamma + 1e-12
+
+
+def test_portfolio():
+    """test/solver/portfolio.jl:6-62: 2 nonnegative + a second-order cone of dimension 12"""
+    prob = pr.portfolio(seed=2)
+    s, ok = run_hip(prob)
+    assert ok
+    criteria(s)
+    sl = s.solution.cone_slack
+    assert np.all(sl[:2] > -1e-5) and np.linalg.norm(sl[3:14]) < sl[2] + 1e-5
+    assert np.abs(prob.b_cone - prob.A_cone @ s.solution.variables - sl).max() < 1e-4
+
+
+def test_qp_equality_sensitivity_c5_style(oracle_mod):
+    """test/solver/qp_equality.jl:37-122: differentiate! — sensitivities vs the analytic KKT inverse (1e-2) and vs the oracle"""
+    prob = pr.qp_equality_parametric(seed=5)
+    s, ok = run_hip(prob, residual_tolerance=1e-8, equality_tolerance=1e-6, complementarity_tolerance=1e-6, differentiate=1)
+    assert ok
+    criteria(s, tol=1e-6)
+    nx, ne = prob.nx, prob.ne
+    rz = np.block([[np.diag(prob.Pd), prob.A.T], [prob.A, np.zeros((ne, ne))]])
+    fxp = s.problem["objective_jacobian_variables_parameters"].reshape(prob.np, nx).T
+    gyxp = s.problem["equality_dual_jacobian_variables_parameters"].reshape(prob.np, nx).T
+    gp = s.problem["equality_jacobian_parameters"].reshape(prob.np, ne).T
+    sens = -np.linalg.solve(rz, np.vstack([fxp + gyxp, gp]))
+    S = s.data("solution_sensitivity")
+    assert np.abs(sens[:nx] - S[:nx]).max() < 1e-2
+    o, st = run_oracle(oracle_mod, prob, residual_tolerance=1e-8, equality_tolerance=1e-6, complementarity_tolerance=1e-6, differentiate=1)
+    assert np.abs(S - o.mat("solution_sensitivity", o.N, prob.np)).max() < 1e-5
+
+
+def test_error_paths():
+    pkg = load_pkg()
+    prob = pr.wachter()
+    with pytest.raises(pkg.CalipsoHipError):     # layout the reference itself is inconsistent for
+        pkg.Solver(prob, 3, 0, 2, 2, nonnegative_indices=[2], second_order_indices=[[]])
+    s = pkg.Solver(prob, 3, 0, 2, 2)
+    with pytest.raises(pkg.CalipsoHipError):
+        s.set("no_such_field", [1.0])
+    with pytest.raises(pkg.CalipsoHipError):
+        s.set("solution", np.zeros(5))
