@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — Newton steps/s of the CALIPSO KKT hot path on MI355X (BASELINE.json metric).
+
+A "step" = one inner Newton iteration of solve! (src/solver/solve.jl:98-353) on each of the B independent problem
+instances this rank holds: evaluate (QP mat-vecs on the device) -> cone! -> residual! -> inertia-corrected LDL^T of the
+condensed KKT matrix -> condensed solve + step recovery -> >= 1 refinement round against the unreduced system -> cone
+fraction-to-boundary search -> candidate merit / violation -> filter line-search decision.  Inputs are resident in HBM
+before the timed region.  Workload = BASELINE config C3 (synthetic dense conic QP, nx=2500, ne=1500, nc=400 R+ + 200 x SOC3
+=> n = 5000 condensed, N = 8500 unreduced), problem ids  rank*B .. rank*B+B-1  (SplitMix64 streams).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Multi-GPU: problems are independent => ranks share nothing on the data path (weak scaling); torch.distributed (RCCL) is
+used only for the barrier and the max-over-ranks time.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CONFIGS = {
+    # name: (nx, ne, n_nonneg, n_soc, soc_dim)
+    "C3": (2500, 1500, 400, 200, 3),
+    "C4": (2302, 2208, 244, 240, 2),
+    "small": (600, 300, 100, 50, 3),
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; bench/mfma_f64_peak.hip measures the achievable ceiling)
+
+
+def make_instance(pkg, pr, pid, shape, device):
+    nx, ne, n_nn, n_soc, dim = shape
+    prob, pt, lam = pr.synthetic_conic_qp(pkg.splitmix_uniform, pid, nx, ne, n_nn, n_soc, dim)
+    s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices,
+                   second_order_indices=prob.second_order_indices, device=device)
+    w = np.concatenate([pt[k] for k in "xrsyzt"])
+    s.set("solution", w)
+    s.set("dual", lam)
+    for name, v in (("central_path", 0.17), ("penalty", 52.0), ("fraction_to_boundary", 0.99)):
+        s.set(name, [v])
+    s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
+    fl = pkg.FLAGS
+    s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
+    s.cone(product=True, target=True)
+    s.synchronize()
+    return prob, pt, lam, w, s
+
+
+def cpu_baseline(shape):
+    """The oracle (faithful single-thread restatement of the reference's CPU path) on ONE Newton step of the same C3
+    problem (problem id 0): search_direction! = assemble + sparse up-looking LDL^T (QDLDL order of operations, constraint-first
+    permutation) + solve + refinement, with ONE factorisation per step (the reference re-factorises before every solve —
+    linear_solver.jl:53 — so this is favourable to it)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    import problems as pr
+    nx, ne, n_nn, n_soc, dim = shape
+    prob, pt, lam = pr.synthetic_conic_qp(oracle.splitmix_uniform, 0, nx, ne, n_nn, n_soc, dim)
+    o = oracle.OracleSolver(prob.nx, 0, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
+    o.point()["all"][:] = np.concatenate([pt[k] for k in "xrsyzt"])
+    o.buf("dual")[:] = lam
+    o.buf("central_path")[0] = 0.17
+    o.buf("penalty")[0] = 52.0
+    o.set_int("linear_solve_refactor", 0)
+    t0 = time.perf_counter()
+    prob.evaluate(pr.ALL_VARIABLE_FLAGS, pt["x"], pt["y"], pt["z"], np.zeros(0), o.buf)
+    o.cone(product=True, jacobian=True, target=True, barrier=True, barrier_gradient=True)
+    o.residual()
+    rc = o.search_direction()
+    dt = time.perf_counter() - t0
+    st = o.stats()
+    return dict(value=1.0 / dt, unit="Newton steps/s", cores=1, kind="port",
+                sample="1 Newton step (evaluate + cone + residual + search_direction: 1 LDL^T factorisation, %d solves) of C3 problem 0, %.1f s; "
+                       "with the reference's re-factorisation before every solve it would be %dx the factorisation time" % (
+                           1 + st["last_refinement_rounds"], dt, 1 + st["last_refinement_rounds"]),
+                status=int(rc))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="independent problem instances per GPU (each on its own HIP stream)")
+    ap.add_argument("--config", default="C3", choices=list(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    import problems as pr
+    shape = CONFIGS[args.config]
+    B = args.batch
+    inst = [make_instance(pkg, pr, rank * B + b, shape, local_rank) for b in range(B)]
+    solvers = [t[4] for t in inst]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        for s in solvers:
+            s.synchronize()
+
+    def one_step():
+        infos = [s.newton_step(advance=False) for s in solvers]
+        return infos
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    sch, ldl, tot, sd = [], [], [], []
+    for _ in range(args.steps):
+        infos = one_step()
+        pt = solvers[0].phase_times()
+        sch.append(pt[7]); ldl.append(pt[3]); tot.append(pt[6]); sd.append(pt[2])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    info = infos[0]
+    nx, ne, n_nn, n_soc, dim = shape
+    nc = n_nn + n_soc * dim
+    m = ne + nc
+    value = world * B * args.steps / elapsed
+    # dominant kernel: the Schur-complement update S = Lxx + ep*I + Z' Omega Z on the fp64 matrix cores (k_schur).
+    # algorithmic flops per launch = multiply-adds of the lower triangle incl. diagonal: nx (nx+1) m
+    sch_ms = float(np.mean(sch))
+    flops = float(nx) * (nx + 1) * m
+    achieved = flops / (sch_ms * 1e-3) * 1e-12
+    out = {
+        "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s synthetic dense conic QP: nx=%d ne=%d nc=%d (%d R+ + %d x SOC%d), n=%d condensed, N=%d unreduced; "
+                               "%d independent instance(s) per GPU; 1 LDL^T factorisation, %d refinement round(s) per step" % (
+                                   args.config, nx, ne, nc, n_nn, n_soc, dim, nx + m, nx + 2 * ne + 3 * nc, B, info["refinement_rounds"]),
+                   "instances_per_gpu": B, "parallelism": "independent problems per GPU (no data-path collective)",
+                   "refinement_rounds": info["refinement_rounds"], "factorizations_per_step": info["factorizations"],
+                   "phase_ms": {"whole_step_gpu": float(np.mean(tot)), "search_direction": float(np.mean(sd)), "schur_mfma": sch_ms,
+                                "ldl_of_schur_complement": float(np.mean(ldl))}},
+        "roofline": {"kernel": "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                     "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "flops_per_launch": flops, "avg_launch_ms": sch_ms},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(shape)
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

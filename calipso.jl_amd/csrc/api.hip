@@ -305,13 +305,24 @@ static int read_scalars(H* s, int first, int count) {
 static double* point_of(H* s, int which) { return which == 0 ? s->solution : s->candidate; }
 
 static int do_factorize(H* s, int64_t inertia[3]) {
+    (void)hipEventRecord(s->ev[10], s->stream);
     launch_cone_weights(s);
     launch_scale_rows(s);
+    (void)hipEventRecord(s->ev[11], s->stream);
     launch_schur(s);
+    (void)hipEventRecord(s->ev[12], s->stream);
     launch_ldl(s);
+    (void)hipEventRecord(s->ev[13], s->stream);
     CK(hipMemcpyAsync(s->hicount, s->icount, sizeof(int) * 6, hipMemcpyDeviceToHost, s->stream));
     SYNC();
     s->stats.factorizations += 1;
+    {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, s->ev[10], s->ev[11]); s->phase_ms[1] = ms;   // cone pivots + Omega*hx
+        (void)hipEventElapsedTime(&ms, s->ev[11], s->ev[12]); s->phase_ms[7] = ms;   // Schur complement (MFMA kernel), one launch
+        (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[13]); s->phase_ms[3] = ms;   // LDL^T of S
+        s->phase_ms[8] += 1.0;
+    }
     const int64_t pos = s->hicount[0] + s->hicount[3], nonpos = s->hicount[1] + s->hicount[4], zero = s->hicount[2] + s->hicount[5];
     inertia[0] = pos; inertia[1] = nonpos; inertia[2] = zero;
     if (zero > 0) { inertia[0] = -1; return CALIPSO_WARN_ZERO_PIVOT; }   // qdldl.jl:456,579: posDCount = -1

@@ -191,9 +191,10 @@ int32_t calipso_hip_qp_evaluate(calipso_hip_solver*, int32_t which, uint32_t fla
  * attached; if `advance` is 0 the iterate is restored afterwards (benchmark mode: every step does identical work).
  * info[0]=step_size info[1]=step_size_t info[2]=refinement rounds info[3]=factorizations info[4]=M_candidate info[5]=theta_candidate */
 int32_t calipso_hip_newton_step(calipso_hip_solver*, int32_t advance, double info[6]);
-/* timing of the phases of the last calipso_hip_newton_step, in milliseconds, from HIP events on the handle's stream:
- * [0] evaluate+cone+residual [1] schur (assemble) [2] factor [3] solve+recover [4] refinement [5] search+merit [6] total
- * and the dominant kernel: [7] schur MFMA kernel ms, [8] number of launches of it */
+/* timing of the last calipso_hip_newton_step / factorisation, in milliseconds, from HIP events on the handle's stream:
+ * [0] evaluate + cone + residual + reductions   [1] cone pivots + Omega*hx   [2] search_direction! total (factor + solves + refinement)
+ * [3] LDL^T of the Schur complement   [5] cone search + line search + accept   [6] whole step
+ * [7] the Schur-complement MFMA kernel (k_schur), last launch   [8] number of factorisations timed so far */
 int32_t calipso_hip_phase_times(calipso_hip_solver*, double out[9]);
 int32_t calipso_hip_synchronize(calipso_hip_solver*);
 
