@@ -85,7 +85,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     d.N = d.nx + 2 * d.ne + 3 * d.nc;         // dimensions.jl:22-23
     d.m = d.ne + d.nc;
     d.q = (int)n_nonneg; d.n_soc = (int)s->h_soc_start.size(); d.max_dim = maxd;
-    d.NP = ((d.nx + TILE - 1) / TILE) * TILE;
+    d.NP = ((d.nx + 511) / 512) * 512;   // multiple of the triangular-solve block (and of TILE, NB)
     s->device = device;
     *out = s;   // from here on errors are reported through the handle
     CK(hipSetDevice(device));
@@ -93,7 +93,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     for (auto& e : s->ev) CK(hipEventCreate(&e));
     const size_t NX = d.nx, NE = d.ne, NC = d.nc, N = d.N, NPd = d.NP, M = d.m, n = d.n;
     int rc = 0;
-    rc |= dalloc(s, &s->Lxx, NX * NX); rc |= dalloc(s, &s->gx, NE * NX); rc |= dalloc(s, &s->hx, NC * NX);
+    rc |= dalloc(s, &s->Lxx, NX * NX); rc |= dalloc(s, &s->Lsym, NX * NX); rc |= dalloc(s, &s->gx, NE * NX); rc |= dalloc(s, &s->hx, NC * NX);
     rc |= dalloc(s, &s->fx, NX); rc |= dalloc(s, &s->gyx, NX); rc |= dalloc(s, &s->hzx, NX); rc |= dalloc(s, &s->g, NE); rc |= dalloc(s, &s->hc, NC);
     rc |= dalloc(s, &s->cone_product, NC); rc |= dalloc(s, &s->cone_target, NC); rc |= dalloc(s, &s->barrier_gradient, NC);
     rc |= dalloc(s, &s->dscal, 64);
@@ -102,7 +102,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     rc |= dalloc(s, &s->saved_point, N); rc |= dalloc(s, &s->saved_g, NE); rc |= dalloc(s, &s->saved_h, NC);
     rc |= dalloc(s, &s->residual_symmetric, n); rc |= dalloc(s, &s->step_symmetric, n); rc |= dalloc(s, &s->merit_gradient, n);
     rc |= dalloc(s, &s->S, NPd * NPd); rc |= dalloc(s, &s->Dx, NPd); rc |= dalloc(s, &s->Ypanel, NPd * NB);
-    rc |= dalloc(s, &s->Linv, (NPd / NB) * NB * NB); rc |= dalloc(s, &s->WH, NC * NX);
+    rc |= dalloc(s, &s->Tinv, (NPd / 512) * 512 * 512); rc |= dalloc(s, &s->Ttmp, NPd * 128); rc |= dalloc(s, &s->zf2, NPd); rc |= dalloc(s, &s->WH, NC * NX);
     rc |= dalloc(s, &s->wz, NC); rc |= dalloc(s, &s->kzz, NC);
     rc |= dalloc(s, &s->Wsoc, (size_t)woff); rc |= dalloc(s, &s->Bsoc, (size_t)woff); rc |= dalloc(s, &s->socwork, (size_t)2 * woff);
     rc |= dalloc(s, &s->icount, 64);
@@ -149,10 +149,10 @@ int32_t calipso_hip_destroy(H* s) {
     if (!s) return CALIPSO_OK;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    double* dp[] = {s->Lxx, s->gx, s->hx, s->fx, s->gyx, s->hzx, s->g, s->hc, s->cone_product, s->cone_target, s->barrier_gradient, s->dscal,
+    double* dp[] = {s->Lxx, s->Lsym, s->gx, s->hx, s->fx, s->gyx, s->hzx, s->g, s->hc, s->cone_product, s->cone_target, s->barrier_gradient, s->dscal,
                     s->solution, s->candidate, s->lambda, s->parameters, s->residual, s->residual_error, s->step, s->step_correction,
                     s->saved_point, s->saved_g, s->saved_h, s->residual_symmetric, s->step_symmetric, s->merit_gradient, s->Kdense, s->S,
-                    s->Dx, s->Ypanel, s->Linv, s->WH, s->wz, s->kzz, s->Wsoc, s->Bsoc, s->socwork, s->gemv_partial, s->vtmp, s->xbuf, s->zf,
+                    s->Dx, s->Ypanel, s->Tinv, s->Ttmp, s->zf2, s->WH, s->wz, s->kzz, s->Wsoc, s->Bsoc, s->socwork, s->gemv_partial, s->vtmp, s->xbuf, s->zf,
                     s->t1, s->t2, s->lgp, s->gp, s->hp, s->jacobian_parameters, s->solution_sensitivity, s->multi_rhs, s->qp.q, s->qp.b, s->qp.h};
     for (double* p : dp) if (p) (void)hipFree(p);
     int* ip[] = {s->icount, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
@@ -242,6 +242,7 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
     CK(hipMemcpyAsync(f.dev, data, sizeof(double) * len, hipMemcpyHostToDevice, s->stream));
     SYNC();
     if (std::string(name) == "parameters") s->hparams.assign(data, data + len);
+    if (std::string(name) == "lagrangian_hessian") s->hessian_dirty = true;
     return CALIPSO_OK;
 }
 
@@ -782,6 +783,7 @@ int32_t calipso_hip_qp_attach(H* s, const double* P, const double* q, const doub
         CK(hipMemcpyAsync(s->qp.h, h, sizeof(double) * d.nc, hipMemcpyHostToDevice, s->stream));
     }
     SYNC();
+    s->hessian_dirty = true;
     s->qp.attached = true;
     s->qp.scale = objective_scale;
     return CALIPSO_OK;

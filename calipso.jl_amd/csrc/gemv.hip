@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, const double
     const double* a = A + (size_t)col * ld;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
     int i = lane;
+#pragma unroll 4
     for (; i + 192 < rows; i += 256) {
         acc0 += a[i] * x[i];
         acc1 += a[i + 64] * x[i + 64];
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(int rows, int cols, 
     if (i >= rows) return;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
     int j = c0;
+#pragma unroll 4
     for (; j + 3 < c1; j += 4) {
         acc0 += A[i + (size_t)j * ld] * x[j];
         acc1 += A[i + (size_t)(j + 1) * ld] * x[j + 1];
@@ -55,12 +57,22 @@ __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(int rows, int cols, 
     partial[(size_t)blockIdx.y * rows + i] = (acc0 + acc1) + (acc2 + acc3);
 }
 
-__global__ void k_gemv_n_reduce(int rows, int nchunk, const double* __restrict__ partial, double* __restrict__ y, double alpha, double beta) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
+// y = alpha * sum_chunks partial + beta*y: 64 rows per workgroup, 4 lanes per row each summing every 4th chunk in a fixed order
+__global__ __launch_bounds__(256) void k_gemv_n_reduce(int rows, int nchunk, const double* __restrict__ partial, double* __restrict__ y, double alpha, double beta) {
+    __shared__ double part[4][64];
+    const int r = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + r;
     double acc = 0.0;
-    for (int c = 0; c < nchunk; ++c) acc += partial[(size_t)c * rows + i];
-    y[i] = (beta == 0.0) ? alpha * acc : alpha * acc + beta * y[i];
+    if (i < rows) {
+#pragma unroll 4
+        for (int c = p; c < nchunk; c += 4) acc += partial[(size_t)c * rows + i];
+    }
+    part[p][r] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && i < rows) {
+        const double v = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+        y[i] = (beta == 0.0) ? alpha * v : alpha * v + beta * y[i];
+    }
 }
 
 void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta) {
@@ -76,7 +88,7 @@ void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, 
     if (cols == 0) nchunk = 0;
     if (nchunk > 0)
         hipLaunchKernelGGL(k_gemv_n_partial, dim3(rb, nchunk), dim3(GN_ROWS), 0, s->stream, rows, cols, chunk, A, ld, x, s->gemv_partial);
-    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 255) / 256), dim3(256), 0, s->stream, rows, nchunk, s->gemv_partial, y, alpha, beta);
+    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 63) / 64), dim3(256), 0, s->stream, rows, nchunk, s->gemv_partial, y, alpha, beta);
 }
 
 }  // namespace calipso

@@ -96,6 +96,8 @@ struct calipso_hip_solver {
     // ---- device buffers -------------------------------------------------------------------------------------------
     // ProblemData
     double *Lxx = nullptr, *gx = nullptr, *hx = nullptr;                      // nx*nx, ne*nx, nc*nx
+    double* Lsym = nullptr;     // nx*nx: Lxx mirrored from its upper triangle (what triu(K) sees)
+    bool hessian_dirty = true;
     double *fx = nullptr, *gyx = nullptr, *hzx = nullptr, *g = nullptr, *hc = nullptr;   // nx, nx, nx, ne, nc
     double *cone_product = nullptr, *cone_target = nullptr, *barrier_gradient = nullptr;  // nc
     double* dscal = nullptr;   // device scalars: [0] objective [1] barrier  [2..] reduction outputs (see kernels)
@@ -110,7 +112,9 @@ struct calipso_hip_solver {
     double* S = nullptr;        // NP*NP: Schur complement onto x, then L (unit lower) in place
     double* Dx = nullptr;       // NP: pivots of S
     double* Ypanel = nullptr;   // NP*NB: L21*D of the current panel
-    double* Linv = nullptr;     // (NP/NB) * NB*NB: inverses of the unit-lower diagonal blocks of L
+    double* Tinv = nullptr;     // (NP/512) * 512*512: inverses of the unit-lower 512 x 512 diagonal blocks of L
+    double* Ttmp = nullptr;     // NP*128 scratch of the inverse assembly
+    double* zf2 = nullptr;      // NP
     double* WH = nullptr;       // nc*nx: Omega_z * hx
     double* wz = nullptr;       // nc: Omega for nonnegative entries (-1/K_zz)
     double* kzz = nullptr;      // nc: K_zz diagonal for nonnegative entries

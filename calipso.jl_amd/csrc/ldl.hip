@@ -1,229 +1,401 @@
 // ldl.hip — blocked right-looking LDL^T (no pivoting) of the nx x nx Schur complement S produced by schur.hip, and the
 // triangular solves with its factors.  Together with the closed-form constraint pivots of schur.hip this is the
 // factorisation  P K P' = L D L'  of factorize!/QDLDL_factor! (linear_solver.jl:19-31, qdldl.jl:400-589) in the order
-// [z | y | x]; S is quasi-definite's positive block, so every pivot must be > 0 for the inertia test (inertia.jl:7-11).
+// [z | y | x]; every pivot of S must be > 0 for the inertia test (inertia.jl:7-11).
 //
-// Per panel of NB = 64 columns:
-//   k_ldl_diag      one workgroup factors the 64 x 64 diagonal block in LDS (right-looking, one barrier pair per column),
-//                   counts pivot signs (compute_inertia!, linear_solver.jl:33-44) and flags exact zeros (qdldl.jl:579)
-//   k_ldl_panel     one lane per row below: y L11' = a  by substitution with L11 broadcast from LDS;  L21 = y / d,
-//                   Y21 = y (= L21 * D) kept for the trailing update
-//   k_ldl_trailing  A22 -= L21 * Y21'   on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), one wavefront per 64 x 64
-//                   tile of the lower triangle, operands straight from L2 (the two panels are 1.3 MB each)
-// Triangular solves use the explicit inverses of the unit-lower diagonal blocks (k_invert_blocks), so each block step is
-// two small mat-vecs instead of a 64-long dependent chain.
+// Per panel of NB = 64 columns (all on one stream, kernel boundaries are the only synchronisation):
+//   k_ldl_diag      one workgroup; the 64 x 64 diagonal block lives in registers (16 entries per lane), the pivot column
+//                   is exchanged through LDS with ONE barrier per column.  The same sweep applies the elementary
+//                   eliminations to an identity, so the kernel also emits X = L11^-1 (needed by the panel step and by
+//                   the triangular solves), counts pivot signs (compute_inertia!, linear_solver.jl:33-44) and flags
+//                   exact zeros (qdldl.jl:579).
+//   k_ldl_panel     Y21 = A21 * L11^-T and L21 = Y21 * D^-1 as a small GEMM with the inverse on the fp64 matrix cores
+//   k_ldl_trailing  A22 -= L21 * Y21'  on the matrix cores: 128 x 128 tiles of the lower triangle, 1024 threads (16
+//                   wavefronts, fp64 MFMA needs >= 4 waves per SIMD), both 128 x 64 operand panels staged in LDS once.
+// Triangular solves work on 512-wide blocks: the inverses of the 512 x 512 unit-lower diagonal blocks of L are assembled
+// from the 64 x 64 inverses by three levels of small matrix-core GEMMs (k_tinv_*), so a solve is 2 launches per block
+// instead of a 256-long dependent chain.
 #include "internal.hpp"
 #include "device_utils.hpp"
 
 namespace calipso {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int LDP = NB + 1;
+constexpr int TB = 512;            // triangular-solve block
+constexpr int LDT = NB + 2;        // LDS leading dimension of a k-fastest 64-deep operand panel
 
-__global__ __launch_bounds__(256) void k_ldl_diag(int NP, int nx, int k0, double* __restrict__ S, double* __restrict__ Dx, int* __restrict__ icount) {
-    __shared__ double A[NB * LDP];
-    __shared__ double col_y[NB], col_l[NB];
-    const int tid = threadIdx.x;
-    const int i = tid & 63, kq = tid >> 6;
-    for (int c = kq; c < NB; c += 4) A[i * LDP + c] = (i >= c) ? S[(k0 + i) + (size_t)(k0 + c) * NP] : 0.0;
-    __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        const double dj = A[j * LDP + j];
-        if (tid < NB && tid > j) {
-            const double yv = A[tid * LDP + j];
-            col_y[tid] = yv;
-            col_l[tid] = yv / dj;
-        }
-        __syncthreads();
-        for (int k = j + 1 + kq; k < NB; k += 4)
-            if (i >= k) A[i * LDP + k] -= col_l[i] * col_y[k];
-        if (tid < NB && tid > j) A[tid * LDP + j] = col_l[tid];
-        __syncthreads();
+// ---- diagonal block ---------------------------------------------------------------------------------------------------------
+// 1024 threads: lane i = tid & 63 is a ROW of the block, wavefront cg = tid >> 6 owns the columns k = cg + 16 c (c = 0..3)
+// of both the block A and the inverse X, in registers.  Per column j: ONE barrier; the pivot column (unscaled), the
+// pivot's reciprocal and row j of X travel through LDS.  The update is branch-free: all LDS operands of a step are read
+// in one batch and masked lanes multiply by zero, so a step costs one LDS round trip instead of one per column
+//     A[i][k] -= l_i A[k][j]   (k > j, i >= k)          X[i][k] -= l_i X[j][k]   (k <= j, i > j)
+// (the same elementary operation M_j = I - l_j e_j' applied to the identity gives X = L11^-1).
+// Nothing is written to global memory inside the column loop (a pending store would make every barrier wait on memory).
+constexpr int DIAG_THREADS = 1024;
+__global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(int NP, int nx, int k0, double* __restrict__ S, double* __restrict__ Dx,
+                                                            double* __restrict__ Tinv, int* __restrict__ icount) {
+    __shared__ double colbuf[2][NB];   // column j of the partially eliminated block (unscaled: y_i = l_i d_j)
+    __shared__ double xrow[2][NB];     // row j of X before elimination step j
+    __shared__ double rinvbuf[2];
+    __shared__ double dd[NB];
+    const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
+    double a[4], x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = cg + 16 * c;
+        a[c] = (i >= k) ? S[(k0 + i) + (size_t)(k0 + k) * NP] : 0.0;
+        x[c] = (i == k) ? 1.0 : 0.0;
     }
-    for (int c = kq; c < NB; c += 4)
-        if (i > c) S[(k0 + i) + (size_t)(k0 + c) * NP] = A[i * LDP + c];
+    if (cg == 0) {
+        colbuf[0][i] = a[0];
+        if (i == 0) { rinvbuf[0] = 1.0 / a[0]; dd[0] = a[0]; }
+    }
+    if (i == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xrow[0][cg + 16 * c] = x[c];
+    }
+#pragma unroll 1
+    for (int jb = 0; jb < NB; jb += 16)
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = jb + jj;
+        const int cur = jj & 1, nxt = cur ^ 1;
+        __syncthreads();
+        double yk[4], xk[4];
+        const double yi = colbuf[cur][i];
+        const double rinv = rinvbuf[cur];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { yk[c] = colbuf[cur][cg + 16 * c]; xk[c] = xrow[cur][cg + 16 * c]; }
+        const double li = yi * rinv;
+        const double lrow = (i > j) ? li : 0.0;          // rows at or above the pivot are finished
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = cg + 16 * c;                   // wavefront-uniform
+            const double la = (k > j && i >= k) ? li : 0.0;
+            const double lx = (k <= j) ? lrow : 0.0;
+            a[c] -= la * yk[c];
+            x[c] -= lx * xk[c];
+        }
+        if (j + 1 < NB) {
+            if (cg == (jj + 1) % 16) {                   // the wavefront that owns column j+1 publishes it
+                const int cs = (j + 1) >> 4;
+                const double v = cs == 0 ? a[0] : (cs == 1 ? a[1] : (cs == 2 ? a[2] : a[3]));
+                colbuf[nxt][i] = v;
+                if (i == j + 1) { rinvbuf[nxt] = 1.0 / v; dd[j + 1] = v; }
+            }
+            if (i == j + 1) {                            // row j+1 of X, spread over all wavefronts
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xrow[nxt][cg + 16 * c] = x[c];
+            }
+        }
+    }
+    __syncthreads();
+    // column k of L: its owner still holds the unscaled entries y_i = l_i d_k (never touched after step k)
+    {
+        const int q = k0 / TB, o = k0 % TB;
+        double* T = Tinv + (size_t)q * TB * TB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = cg + 16 * c;
+            if (i > k) S[(k0 + i) + (size_t)(k0 + k) * NP] = a[c] * (1.0 / dd[k]);
+            T[(o + i) + (size_t)(o + k) * TB] = (i >= k) ? x[c] : 0.0;   // X = L11^-1 on the diagonal of the inverse block
+        }
+    }
     if (tid < NB) {
-        const double dd = A[tid * LDP + tid];
-        Dx[k0 + tid] = dd;
+        const double d = dd[tid];
+        Dx[k0 + tid] = d;
         int pos = 0, nonpos = 0, zero = 0;
-        if (k0 + tid < nx) { pos = dd > 0.0; nonpos = dd <= 0.0; zero = dd == 0.0; }
+        if (k0 + tid < nx) { pos = d > 0.0; nonpos = d <= 0.0; zero = d == 0.0; }
         pos = wave_sum_i(pos); nonpos = wave_sum_i(nonpos); zero = wave_sum_i(zero);
         if (tid == 0) { atomicAdd(&icount[3], pos); atomicAdd(&icount[4], nonpos); atomicAdd(&icount[5], zero); }
     }
 }
 
-__global__ __launch_bounds__(256) void k_ldl_panel(int NP, int k0, double* __restrict__ S, const double* __restrict__ Dx, double* __restrict__ Y) {
-    __shared__ double L11[NB * NB];   // L11[c*NB + k] = L[c][k], k < c
+// ---- panel: Y21 = A21 X', L21 = Y21 / d --------------------------------------------------------------------------------------
+// D[c][r] = sum_k X[c][k] A21[r][k]: MFMA A operand = X (rows c), B operand = A21' so that the 16-lane fast index of the
+// result is the contiguous row index r of the column-major panel.  One workgroup (16 wavefronts) per 64 rows; wavefront
+// (wr, wc) computes the 16 x 16 tile rows 16 wr.., columns 16 wc.. ; X is staged in LDS.
+__global__ __launch_bounds__(1024) void k_ldl_panel(int NP, int k0, double* __restrict__ S, const double* __restrict__ Dx,
+                                                     const double* __restrict__ Tinv, double* __restrict__ Y) {
+    __shared__ double Xs[NB * LDT];   // Xs[c][k]
     __shared__ double dinv[NB];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int c = idx >> 6, k = idx & 63;
-        L11[idx] = (k < c) ? S[(k0 + c) + (size_t)(k0 + k) * NP] : 0.0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int r0 = k0 + NB + blockIdx.x * 64 + wr * 16;
+    double b[NB / 4];
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) b[kk] = S[(r0 + fr) + (size_t)(k0 + kk * 4 + fk) * NP];
+    {
+        const int q = k0 / TB, o = k0 % TB;
+        const double* T = Tinv + (size_t)q * TB * TB;
+        const int c = tid & 63;
+#pragma unroll
+        for (int kk = tid >> 6; kk < NB; kk += 16) Xs[c * LDT + kk] = T[(o + c) + (size_t)(o + kk) * TB];
+        if (tid < NB) dinv[tid] = 1.0 / Dx[k0 + tid];
     }
-    if (tid < NB) dinv[tid] = 1.0 / Dx[k0 + tid];
     __syncthreads();
-    const int r = k0 + NB + blockIdx.x * 256 + tid;
-    if (r >= NP) return;
-    double a[NB];
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = S[r + (size_t)(k0 + c) * NP];
-#pragma unroll
-    for (int c = 1; c < NB; ++c) {
-        double y = a[c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) y -= a[k] * L11[c * NB + k];
-        a[c] = y;
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const double xa = Xs[(wc * 16 + fr) * LDT + kk * 4 + fk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, b[kk], acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
-        Y[r + (size_t)c * NP] = a[c];
-        S[r + (size_t)(k0 + c) * NP] = a[c] * dinv[c];
+    for (int r = 0; r < 4; ++r) {
+        const int c = wc * 16 + fk + 4 * r;   // MFMA row  -> panel column
+        const int row = r0 + fr;              // MFMA col  -> panel row (contiguous)
+        const double y = acc[r];
+        Y[row + (size_t)c * NP] = y;
+        S[row + (size_t)(k0 + c) * NP] = y * dinv[c];
     }
 }
 
-// A22 -= L21 * Y21'  (lower triangle).  The tile is computed transposed (D[j][i] = sum_k Y[j,k] L[i,k]) so that the
-// 16-lane fast index of the MFMA result maps to the contiguous (row) dimension of the column-major S.
-__global__ __launch_bounds__(256) void k_ldl_trailing(int NP, int k0, double* __restrict__ S, const double* __restrict__ Y, int ntiles) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= ntiles) return;
+// ---- trailing update A22 -= L21 * Y21' -------------------------------------------------------------------------------------------
+// 64 x 64 tile of the lower triangle per workgroup of 1024 threads (16 wavefronts, one 16 x 16 MFMA tile each; two
+// workgroups fit a CU => 8 wavefronts per SIMD, which fp64 MFMA needs).  Small tiles keep all 256 CUs busy on the shrinking
+// trailing matrix.  The tile is computed transposed (MFMA row <-> column j of S) so result stores are 128-byte runs.
+constexpr int TR_THREADS = 1024;
+constexpr int TT = 64;
+__global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(int NP, int k0, double* __restrict__ S, const double* __restrict__ Y, int ntiles) {
+    __shared__ double Ls[TT * LDT];       // Ls[i][k]: rows of the i block of L21
+    __shared__ double Ys[TT * LDT];       // Ys[j][k]: rows of the j block of Y21
+    const int t = blockIdx.x;
     int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     while (ti * (ti + 1) / 2 > t) --ti;
     const int tj = t - ti * (ti + 1) / 2;
     const int r0 = k0 + NB;
-    const int i0 = r0 + ti * 64, j0 = r0 + tj * 64;
+    const int i0 = r0 + ti * TT, j0 = r0 + tj * TT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fk = lane >> 4;
-    v4d acc[4][4];
+    // the entries of S this lane updates: loads issued first so their latency hides behind the staging and the MFMAs
+    double cS[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int r = 0; r < 4; ++r) cS[r] = S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP];
+    {
+        const int row = tid & 63, cb = tid >> 6;   // 16 column groups
+        const double* Lp = S + (size_t)k0 * NP;
+        double lv[4], yv[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double* Lp = S + (size_t)k0 * NP;   // L21 lives in columns k0..k0+63 of S
-#pragma unroll 4
+        for (int it = 0; it < 4; ++it) {
+            const int c = cb + it * 16;
+            lv[it] = Lp[(i0 + row) + (size_t)c * NP];
+            yv[it] = Y[(j0 + row) + (size_t)c * NP];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = cb + it * 16;
+            Ls[row * LDT + c] = lv[it];
+            Ys[row * LDT + c] = yv[it];
+        }
+    }
+    __syncthreads();
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
-        const int k = kk * 4 + fk;
-        double ya[4], lb[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) ya[m] = Y[(j0 + m * 16 + fr) + (size_t)k * NP];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) lb[n] = Lp[(i0 + n * 16 + fr) + (size_t)k * NP];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[m], lb[n], acc[m][n], 0, 0, 0);
+        const double la = Ls[(wr * 16 + fr) * LDT + kk * 4 + fk];
+        const double yb = Ys[(wc * 16 + fr) * LDT + kk * 4 + fk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yb, la, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gj = j0 + m * 16 + fk + 4 * r;   // MFMA row  -> S column
-                const int gi = i0 + n * 16 + fr;           // MFMA col  -> S row (contiguous)
-                S[gi + (size_t)gj * NP] -= acc[m][n][r];
-            }
+    for (int r = 0; r < 4; ++r) S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP] = cS[r] - acc[r];
 }
 
-// X = L_kk^-1 for every 64 x 64 unit-lower diagonal block (one wavefront per block, lane c builds column c)
-__global__ __launch_bounds__(64) void k_invert_blocks(int NP, const double* __restrict__ S, double* __restrict__ Linv) {
-    __shared__ double Ls[NB * LDP];
-    __shared__ double Xs[NB * LDP];
-    const int k0 = blockIdx.x * NB, c = threadIdx.x;
-    for (int i = 0; i < NB; ++i) Ls[i * LDP + c] = (i > c) ? S[(k0 + i) + (size_t)(k0 + c) * NP] : 0.0;
-    __syncthreads();
-    for (int i = 0; i < NB; ++i) {
-        double acc = (i == c) ? 1.0 : 0.0;
-        for (int k = c; k < i; ++k) acc -= Ls[i * LDP + k] * Xs[k * LDP + c];
-        Xs[i * LDP + c] = (i >= c) ? acc : 0.0;
+// ---- inverses of the 256 x 256 diagonal blocks from the 64 x 64 ones -----------------------------------------------------------
+// inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1  C^-1].  Level 1 joins 64-blocks into 128-blocks, level 2 joins 128-blocks into
+// 256-blocks.  Each level is two launches of the same 64 x 64-output-tile GEMM (T = B * A^-1, then X21 = -C^-1 * T).
+// C_tile(64 x 64) = alpha * A(64 x K) * B(K x 64), K <= 128, operands staged whole in LDS, 1024 threads (16 wavefronts, one
+// 16 x 16 MFMA tile each).
+struct GemmDesc { const double* A; int lda; const double* B; int ldb; double* C; int ldc; };
+
+__device__ __forceinline__ void gemm_tile64(const GemmDesc g, int K, double alpha, double* smem) {
+    constexpr int KC = 128;                 // K chunk held in LDS
+    double* As = smem;                      // As[i][k], ld KC+2
+    double* Bs = smem + 64 * (KC + 2);      // Bs[j][k]
+    const int ldk = KC + 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 2, wj = wave & 3;
+    const int fr = lane & 15, fk = lane >> 4;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int kc = 0; kc < K; kc += KC) {
+        const int kn = (K - kc) < KC ? (K - kc) : KC;
+        __syncthreads();
+        for (int idx = tid; idx < 64 * kn; idx += 1024) {
+            const int i = idx & 63, kk = idx >> 6;            // A column-major: lanes along i (contiguous)
+            As[i * ldk + kk] = g.A[i + (size_t)(kc + kk) * g.lda];
+        }
+        for (int idx = tid; idx < 64 * kn; idx += 1024) {
+            const int kk = idx % kn, j = idx / kn;            // B column-major: lanes along k (contiguous)
+            Bs[j * ldk + kk] = g.B[(kc + kk) + (size_t)j * g.ldb];
+        }
+        __syncthreads();
+        for (int kk = 0; kk < kn / 4; ++kk) {
+            const double a = As[(wi * 16 + fr) * ldk + kk * 4 + fk];
+            const double b = Bs[(wj * 16 + fr) * ldk + kk * 4 + fk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);   // transposed: row <-> j, col <-> i
+        }
     }
-    double* out = Linv + (size_t)blockIdx.x * NB * NB;
-    for (int i = 0; i < NB; ++i) out[i + c * NB] = Xs[i * LDP + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = wj * 16 + fk + 4 * r, i = wi * 16 + fr;
+        g.C[i + (size_t)j * g.ldc] = alpha * acc[r];
+    }
+}
+
+// level 1, 2, 3: half = 64, 128, 256; phase 0: T = L21 * X11 ; phase 1: X21 = -X22 * T
+__global__ __launch_bounds__(1024) void k_tinv_merge(int NP, int half, int phase, const double* __restrict__ S, double* __restrict__ Tinv,
+                                                      double* __restrict__ Ttmp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tiles = half / 64;                 // tiles per side of the half x half result
+    const int pair = blockIdx.x / (tiles * tiles);
+    const int tt = blockIdx.x % (tiles * tiles);
+    const int tiy = tt / tiles, tjx = tt % tiles;
+    const int g0 = pair * 2 * half;              // first row/col of the pair in the global numbering
+    const int q = g0 / TB, o = g0 % TB;
+    double* T = Tinv + (size_t)q * TB * TB;
+    double* tmp = Ttmp + (size_t)pair * half * half;
+    GemmDesc g;
+    if (phase == 0) {        // tmp(half x half) = L21 * X11
+        g.A = S + (g0 + half + tiy * 64) + (size_t)g0 * NP; g.lda = NP;
+        g.B = T + o + (size_t)(o + tjx * 64) * TB; g.ldb = TB;
+        g.C = tmp + tiy * 64 + (size_t)(tjx * 64) * half; g.ldc = half;
+        gemm_tile64(g, half, 1.0, smem);
+    } else {                 // X21 = -X22 * tmp
+        g.A = T + (o + half + tiy * 64) + (size_t)(o + half) * TB; g.lda = TB;
+        g.B = tmp + (size_t)(tjx * 64) * half; g.ldb = half;
+        g.C = T + (o + half + tiy * 64) + (size_t)(o + tjx * 64) * TB; g.ldc = TB;
+        gemm_tile64(g, half, -1.0, smem);
+    }
 }
 
 void launch_ldl(calipso_hip_solver* s) {
     const int NP = s->d.NP, nblk = NP / NB;
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KiB of dynamic LDS must be requested explicitly
+        (void)hipFuncSetAttribute((const void*)k_tinv_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 64 * (128 + 2) * sizeof(double)));
+        attr_set = true;
+    }
     for (int kb = 0; kb < nblk; ++kb) {
         const int k0 = kb * NB;
-        hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(256), 0, s->stream, NP, s->d.nx, k0, s->S, s->Dx, s->icount);
+        hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DIAG_THREADS), 0, s->stream, NP, s->d.nx, k0, s->S, s->Dx, s->Tinv, s->icount);
         const int rows = NP - k0 - NB;
         if (rows > 0) {
-            hipLaunchKernelGGL(k_ldl_panel, dim3((rows + 255) / 256), dim3(256), 0, s->stream, NP, k0, s->S, s->Dx, s->Ypanel);
-            const int ntr = rows / 64, ntiles = ntr * (ntr + 1) / 2;
-            hipLaunchKernelGGL(k_ldl_trailing, dim3((ntiles + 3) / 4), dim3(256), 0, s->stream, NP, k0, s->S, s->Ypanel, ntiles);
+            hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64), dim3(1024), 0, s->stream, NP, k0, s->S, s->Dx, s->Tinv, s->Ypanel);
+            const int ntr = rows / TT, ntiles = ntr * (ntr + 1) / 2;
+            hipLaunchKernelGGL(k_ldl_trailing, dim3(ntiles), dim3(TR_THREADS), 0, s->stream, NP, k0, s->S, s->Ypanel, ntiles);
         }
     }
-    hipLaunchKernelGGL(k_invert_blocks, dim3(nblk), dim3(64), 0, s->stream, NP, s->S, s->Linv);
-}
-
-// ---- triangular solves -------------------------------------------------------------------------------------------------------
-// forward step kb: every workgroup forms x_k = Linv_kk * b_k in LDS; workgroup 0 publishes it, workgroup w > 0 updates
-// its own 64 rows  b_{kb+w} -= L[(kb+w), kb] x_k.  The diagonal scaling by 1/D is fused into the publish.
-__global__ __launch_bounds__(256) void k_trsv_fwd(int NP, int kb, const double* __restrict__ S, const double* __restrict__ Linv,
-                                                   const double* __restrict__ Dx, double* __restrict__ b, double* __restrict__ xf) {
-    __shared__ double bs[NB], part[4][NB], xs[NB];
-    const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
-    const int k0 = kb * NB;
-    if (tid < NB) bs[tid] = b[k0 + tid];
-    __syncthreads();
-    const double* Li = Linv + (size_t)kb * NB * NB;
-    double acc = 0.0;
-#pragma unroll 4
-    for (int c = q * 16; c < q * 16 + 16; ++c) acc += Li[i + c * NB] * bs[c];
-    part[q][i] = acc;
-    __syncthreads();
-    if (tid < NB) xs[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (tid < NB) xf[k0 + tid] = xs[tid] / Dx[k0 + tid];   // z = D^-1 (L^-1 b)
-        return;
+    const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
+    for (int level = 1; level <= 3; ++level) {
+        const int half = 32 << level, tiles = half / 64, pairs = NP / (2 * half);
+        for (int phase = 0; phase < 2; ++phase)
+            hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles), dim3(1024), mg_lds, s->stream, NP, half, phase, s->S, s->Tinv, s->Ttmp);
     }
-    const int r0 = k0 + blockIdx.x * NB;
-    acc = 0.0;
-#pragma unroll 4
-    for (int c = q * 16; c < q * 16 + 16; ++c) acc += S[(r0 + i) + (size_t)(k0 + c) * NP] * xs[c];
-    part[q][i] = acc;
-    __syncthreads();
-    if (tid < NB) b[r0 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
-// backward step kb: v_k = Linv_kk' * z_k ; workgroup w > 0 updates block j = w-1:  z_j -= L[kb, j]' v_k
-__global__ __launch_bounds__(256) void k_trsv_bwd(int NP, int kb, const double* __restrict__ S, const double* __restrict__ Linv,
-                                                   double* __restrict__ z, double* __restrict__ v) {
-    __shared__ double zs[NB], part[4][NB], vs[NB];
-    const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
-    const int k0 = kb * NB;
-    if (tid < NB) zs[tid] = z[k0 + tid];
+// ---- triangular solves with 256-wide blocks --------------------------------------------------------------------------------------
+// forward:  L u = b.   kernel B_k: u_k = Tinv_k b_k ;  kernel A_k: b_rest -= L[rest, k] u_k
+// backward: L' v = z.  kernel B'_k: v_k = Tinv_k' z_k ; kernel A'_k: z_above -= L[k, above]' v_k
+// Each output entry is a dot product of a matrix row/column with a 256-vector; the vector sits in LDS.
+
+// u_k = Tinv_k b_k (lower-triangular mat-vec, lanes along rows) ; out = u_k * scale  (scale = 1/D folded for the forward pass)
+__global__ __launch_bounds__(256) void k_trsv_block_n(int kb, const double* __restrict__ Tinv, const double* __restrict__ b, const double* __restrict__ Dx,
+                                                       double* __restrict__ u, double* __restrict__ z) {
+    __shared__ double bs[TB];
+    __shared__ double part[8][32];
+    const int tid = threadIdx.x, k0 = kb * TB;
+    for (int i = tid; i < TB; i += 256) bs[i] = b[k0 + i];
     __syncthreads();
-    const double* Li = Linv + (size_t)kb * NB * NB;
+    const int r = tid & 31, p = tid >> 5;          // 32 rows per workgroup, 8 column parts
+    const int row = blockIdx.x * 32 + r;
+    const double* T = Tinv + (size_t)kb * TB * TB;
+    const int cend = blockIdx.x * 32 + 32;         // lower triangular: columns beyond the workgroup's last row are zero
     double acc = 0.0;
-#pragma unroll 4
-    for (int c = q * 16; c < q * 16 + 16; ++c) acc += Li[c + i * NB] * zs[c];   // (Linv')[i][c] = Linv[c][i]
-    part[q][i] = acc;
+#pragma unroll 16
+    for (int c = p; c < cend; c += 8) acc += T[row + (size_t)c * TB] * bs[c];
+    part[p][r] = acc;
     __syncthreads();
-    if (tid < NB) vs[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (tid < NB) v[k0 + tid] = vs[tid];
-        return;
+    if (tid < 32) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += part[q][tid];
+        const int gi = k0 + blockIdx.x * 32 + tid;
+        u[gi] = v;
+        z[gi] = v / Dx[gi];
     }
-    const int j0 = (blockIdx.x - 1) * NB;
-    acc = 0.0;
-#pragma unroll 4
-    for (int c = q * 16; c < q * 16 + 16; ++c) acc += S[(k0 + c) + (size_t)(j0 + i) * NP] * vs[c];   // L[kb rows c, column j0+i]
-    part[q][i] = acc;
-    __syncthreads();
-    if (tid < NB) z[j0 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
-// x (length NP, padded entries zero) <- S^-1 x ; uses vtmp[0..2NP) as scratch
+// b[rows below block kb] -= L[rows, block kb] * u_k      (64 rows per workgroup, 4 column parts; loads batched 32 deep)
+__global__ __launch_bounds__(256) void k_trsv_update_n(int NP, int kb, const double* __restrict__ S, const double* __restrict__ u, double* __restrict__ b) {
+    __shared__ double us[TB];
+    __shared__ double part[4][64];
+    const int tid = threadIdx.x, k0 = kb * TB;
+    for (int i = tid; i < TB; i += 256) us[i] = u[k0 + i];
+    __syncthreads();
+    const int r = tid & 63, p = tid >> 6;
+    const int row = k0 + TB + blockIdx.x * 64 + r;
+    const double* Sp = S + row + (size_t)k0 * NP;
+    double acc = 0.0;
+#pragma unroll 1
+    for (int cb = 0; cb < TB; cb += 128) {
+        double v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = Sp[(size_t)(cb + p + 4 * q) * NP];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc += v[q] * us[cb + p + 4 * q];
+    }
+    part[p][r] = acc;
+    __syncthreads();
+    if (tid < 64) b[k0 + TB + blockIdx.x * 64 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+}
+
+// v_k = Tinv_k' z_k : one wavefront per column (4 columns per workgroup), lanes stride down the column
+__global__ __launch_bounds__(256) void k_trsv_block_t(int kb, const double* __restrict__ Tinv, const double* __restrict__ z, double* __restrict__ v) {
+    __shared__ double zs[TB];
+    const int tid = threadIdx.x, lane = tid & 63, k0 = kb * TB;
+    for (int i = tid; i < TB; i += 256) zs[i] = z[k0 + i];
+    __syncthreads();
+    const int c = blockIdx.x * 4 + (tid >> 6);
+    const double* T = Tinv + (size_t)kb * TB * TB + (size_t)c * TB;
+    double acc = 0.0;
+#pragma unroll
+    for (int r = (c & ~63) + lane; r < TB; r += 64) acc += T[r] * zs[r];   // column c is zero above row c
+    acc = wave_sum(acc);
+    if (lane == 0) v[k0 + c] = acc;
+}
+
+// z[columns left of block kb] -= L[block kb, columns]' v_k : one wavefront per column
+__global__ __launch_bounds__(256) void k_trsv_update_t(int NP, int kb, const double* __restrict__ S, const double* __restrict__ v, double* __restrict__ z) {
+    __shared__ double vs[TB];
+    const int tid = threadIdx.x, lane = tid & 63, k0 = kb * TB;
+    for (int i = tid; i < TB; i += 256) vs[i] = v[k0 + i];
+    __syncthreads();
+    const int c = blockIdx.x * 4 + (tid >> 6);     // c < k0
+    const double* Lc = S + (size_t)c * NP + k0;
+    double acc = 0.0;
+#pragma unroll
+    for (int r = lane; r < TB; r += 64) acc += Lc[r] * vs[r];
+    acc = wave_sum(acc);
+    if (lane == 0) z[c] -= acc;
+}
+
+// x (length NP, padded entries zero) <- S^-1 x
 void launch_trsv(calipso_hip_solver* s, double* x) {
-    const int NP = s->d.NP, nblk = NP / NB;
-    double* zf = s->vtmp;   // forward result (already scaled by 1/D)
-    for (int kb = 0; kb < nblk; ++kb)
-        hipLaunchKernelGGL(k_trsv_fwd, dim3(nblk - kb), dim3(256), 0, s->stream, NP, kb, s->S, s->Linv, s->Dx, x, zf);
-    for (int kb = nblk - 1; kb >= 0; --kb)
-        hipLaunchKernelGGL(k_trsv_bwd, dim3(kb + 1), dim3(256), 0, s->stream, NP, kb, s->S, s->Linv, zf, x);
+    const int NP = s->d.NP, nb = NP / TB;
+    double* u = s->zf;         // forward result (unscaled), consumed by the updates
+    double* z = s->zf2;        // D^-1 u, then overwritten block by block with v
+    for (int kb = 0; kb < nb; ++kb) {
+        hipLaunchKernelGGL(k_trsv_block_n, dim3(TB / 32), dim3(256), 0, s->stream, kb, s->Tinv, x, s->Dx, u, z);
+        const int rest = NP - (kb + 1) * TB;
+        if (rest > 0) hipLaunchKernelGGL(k_trsv_update_n, dim3(rest / 64), dim3(256), 0, s->stream, NP, kb, s->S, u, x);
+    }
+    for (int kb = nb - 1; kb >= 0; --kb) {
+        hipLaunchKernelGGL(k_trsv_block_t, dim3(TB / 4), dim3(256), 0, s->stream, kb, s->Tinv, z, x);
+        if (kb > 0) hipLaunchKernelGGL(k_trsv_update_t, dim3(kb * TB / 4), dim3(256), 0, s->stream, NP, kb, s->S, x, z);
+    }
 }
 
 }  // namespace calipso

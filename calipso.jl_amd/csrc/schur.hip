@@ -130,28 +130,43 @@ void launch_scale_rows(calipso_hip_solver* s) {
 //                            D: lane l, register r holds D[row = (l>>4) + 4r][col = l&15].
 // blockIdx -> tile is XCD-aware: the 8 XCDs each get a contiguous band of tile rows, so the operand columns a band
 // needs are shared through that XCD's L2 instead of being fetched by all eight.
-constexpr int KT = 16;
+// fp64 MFMA on gfx950 needs >= 4 wavefronts per SIMD to keep the matrix pipe busy (bench/mfma_f64_peak.hip: one wave per
+// SIMD reaches 36 TFLOP/s, four reach 47-49), so the workgroup is 1024 threads = 16 wavefronts (4 x 4), each owning a
+// 32 x 32 sub-tile (2 x 2 MFMA tiles, 32 accumulator VGPRs) of the 128 x 128 tile.
+constexpr int KT = 32;
 constexpr int LDK = KT + 2;
+constexpr int SCHUR_THREADS = 1024;
+constexpr int SLD = TILE * KT / SCHUR_THREADS;   // doubles per thread per operand per stage
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void stage_load(double* __restrict__ dst /* [TILE][LDK] */, const double* __restrict__ M, int ldm, int kmax,
-                                           int ncols, int k0, int c0, int tid) {
-    // KT x TILE block of M (rows k0.., columns c0..) -> dst[c][k]; out-of-range -> 0
-    const int k = tid % KT;
-    const int cbase = tid / KT;          // 0..7
-#pragma unroll
-    for (int it = 0; it < TILE / (256 / KT); ++it) {
-        const int c = cbase + it * (256 / KT);
-        const int gk = k0 + k, gc = c0 + c;
-        double v = 0.0;
-        if (gk < kmax && gc < ncols) v = M[gk + (size_t)gc * ldm];
-        dst[c * LDK + k] = v;
-    }
+struct SchurStage { const double* MA; const double* MB; int kmax; int k0; double bscale; };
+
+__device__ __forceinline__ SchurStage schur_stage(int st, int nst0, const Dims& d, const double* gx, const double* hx, const double* WH, double omega_y) {
+    SchurStage g;
+    if (st < nst0) { g.MA = gx; g.MB = gx; g.kmax = d.ne; g.k0 = st * KT; g.bscale = omega_y; }
+    else { g.MA = hx; g.MB = WH; g.kmax = d.nc; g.k0 = (st - nst0) * KT; g.bscale = 1.0; }
+    return g;
 }
 
-__global__ __launch_bounds__(256, 2) void k_schur(Dims d, Scalars sc, const double* __restrict__ Lxx, const double* __restrict__ gx,
-                                                   const double* __restrict__ hx, const double* __restrict__ WH, double* __restrict__ S,
-                                                   int ntiles) {
+// global -> registers: KT x TILE block of M (rows k0.., columns c0..), lanes along k; out-of-range -> 0
+__device__ __forceinline__ void stage_fetch(double (&r)[SLD], const double* __restrict__ M, int kmax, int ncols, int k0, int c0, int tid, double scale) {
+    const int k = tid % KT, cbase = tid / KT;
+#pragma unroll
+    for (int it = 0; it < SLD; ++it) {
+        const int gk = k0 + k, gc = c0 + cbase + it * (SCHUR_THREADS / KT);
+        r[it] = (gk < kmax && gc < ncols) ? scale * M[gk + (size_t)gc * kmax] : 0.0;
+    }
+}
+// registers -> LDS, k fastest: dst[c][k]
+__device__ __forceinline__ void stage_store(double* __restrict__ dst, const double (&r)[SLD], int tid) {
+    const int k = tid % KT, cbase = tid / KT;
+#pragma unroll
+    for (int it = 0; it < SLD; ++it) dst[(cbase + it * (SCHUR_THREADS / KT)) * LDK + k] = r[it];
+}
+
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur(Dims d, Scalars sc, const double* __restrict__ Lsym, const double* __restrict__ gx,
+                                                          const double* __restrict__ hx, const double* __restrict__ WH, double* __restrict__ S,
+                                                          int ntiles) {
     __shared__ double As[TILE * LDK];
     __shared__ double Bs[TILE * LDK];
     // XCD-aware remap: block b runs on XCD b % 8 (observed dispatch order; used for speed only)
@@ -164,65 +179,61 @@ __global__ __launch_bounds__(256, 2) void k_schur(Dims d, Scalars sc, const doub
     const int tj = t - ti * (ti + 1) / 2;
     const int i0 = ti * TILE, j0 = tj * TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 2, wc = wave & 3;     // wavefront's 32 x 32 sub-tile: rows (i) block wr, columns (j) block wc
     const int fr = lane & 15, fk = lane >> 4;
 
-    v4d acc[4][4];
+    // acc[n][m]: MFMA row index <-> column j of S, MFMA column index (the 16-lane fast index) <-> row i of S, so that the
+    // epilogue's stores are 128-byte contiguous runs of the column-major S
+    v4d acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+    const int nst0 = (d.ne + KT - 1) / KT, nst = nst0 + (d.nc + KT - 1) / KT;
+    double ra[SLD], rb[SLD];
+    if (nst > 0) {
+        const SchurStage g = schur_stage(0, nst0, d, gx, hx, WH, omega_y);
+        stage_fetch(ra, g.MA, g.kmax, d.nx, g.k0, i0, tid, 1.0);
+        stage_fetch(rb, g.MB, g.kmax, d.nx, g.k0, j0, tid, g.bscale);
+    }
 #pragma unroll 1
-    for (int phase = 0; phase < 2; ++phase) {
-        const int kmax = phase == 0 ? d.ne : d.nc;
-        const double* MA = phase == 0 ? gx : hx;
-        const double* MB = phase == 0 ? gx : WH;
-#pragma unroll 1
-        for (int k0 = 0; k0 < kmax; k0 += KT) {
-            __syncthreads();
-            stage_load(As, MA, kmax, kmax, d.nx, k0, i0, tid);
-            if (phase == 0 && ti == tj) {
-                // diagonal tile of gx'gx: B operand == A operand
-            } else {
-                stage_load(Bs, MB, kmax, kmax, d.nx, k0, j0, tid);
-            }
-            __syncthreads();
-            const double* Bsrc = (phase == 0 && ti == tj) ? As : Bs;
-#pragma unroll
-            for (int kk = 0; kk < KT / 4; ++kk) {
-                double a[4], b[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) a[m] = As[(wr * 64 + m * 16 + fr) * LDK + kk * 4 + fk];
-#pragma unroll
-                for (int n = 0; n < 4; ++n) b[n] = Bsrc[(wc * 64 + n * 16 + fr) * LDK + kk * 4 + fk];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
-            }
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();
+        stage_store(As, ra, tid);
+        stage_store(Bs, rb, tid);
+        __syncthreads();
+        if (st + 1 < nst) {   // prefetch the next stage while the matrix cores work on this one
+            const SchurStage g = schur_stage(st + 1, nst0, d, gx, hx, WH, omega_y);
+            stage_fetch(ra, g.MA, g.kmax, d.nx, g.k0, i0, tid, 1.0);
+            stage_fetch(rb, g.MB, g.kmax, d.nx, g.k0, j0, tid, g.bscale);
         }
-        if (phase == 0) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+        for (int kk = 0; kk < KT / 4; ++kk) {
+            double a[2], b[2];
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] *= omega_y;
+            for (int m = 0; m < 2; ++m) a[m] = As[(wr * 32 + m * 16 + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = Bs[(wc * 32 + n * 16 + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a[m], acc[n][m], 0, 0, 0);
         }
     }
     // epilogue: + Lxx (through its upper triangle, as triu(K)) + ep on the diagonal; identity in the padding
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gi = i0 + wr * 64 + m * 16 + fk + 4 * r;
-                const int gj = j0 + wc * 64 + n * 16 + fr;
+                const int gj = j0 + wc * 32 + n * 16 + fk + 4 * r;   // MFMA row
+                const int gi = i0 + wr * 32 + m * 16 + fr;           // MFMA column: contiguous rows of S
                 double v;
                 if (gi < d.nx && gj < d.nx) {
-                    const int lo = gi < gj ? gi : gj, hi = gi < gj ? gj : gi;
-                    v = acc[m][n][r] + Lxx[lo + (size_t)hi * d.nx];
+                    v = acc[n][m][r] + Lsym[gi + (size_t)gj * d.nx];   // = Lxx[min, max]: triu(K) mirrored (k_symmetrize_upper)
                     if (gi == gj) v += sc.ep;
                 } else {
                     v = (gi == gj) ? 1.0 : 0.0;
@@ -231,11 +242,46 @@ __global__ __launch_bounds__(256, 2) void k_schur(Dims d, Scalars sc, const doub
             }
 }
 
+// Lsym[i,j] = Lxx[min(i,j), max(i,j)]: the Hessian as a triu-only factorisation sees it (qdldl.jl:145-147), laid out so the
+// Schur epilogue can read its lower triangle with unit stride.  32 x 32 tiles transposed through LDS.
+__global__ __launch_bounds__(256) void k_symmetrize_upper(int nx, const double* __restrict__ Lxx, double* __restrict__ Lsym) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.x, bj = blockIdx.y;   // tile (rows bi, cols bj) of Lsym
+    if (bi < bj) {                                // strictly upper tile: plain copy
+        for (int c = threadIdx.y; c < 32; c += 8) {
+            const int i = bi * 32 + threadIdx.x, j = bj * 32 + c;
+            if (i < nx && j < nx) Lsym[i + (size_t)j * nx] = Lxx[i + (size_t)j * nx];
+        }
+        return;
+    }
+    // lower (or diagonal) tile: read the mirrored upper tile (rows bj, cols bi) and transpose
+    for (int c = threadIdx.y; c < 32; c += 8) {
+        const int r = bj * 32 + threadIdx.x, cc = bi * 32 + c;
+        tile[c][threadIdx.x] = (r < nx && cc < nx) ? Lxx[r + (size_t)cc * nx] : 0.0;
+    }
+    __syncthreads();
+    for (int c = threadIdx.y; c < 32; c += 8) {
+        const int i = bi * 32 + threadIdx.x, j = bj * 32 + c;
+        if (i < nx && j < nx) {
+            // Lsym[i][j] with i in tile rows bi, j in tile cols bj: = Lxx[j][i] when i > j, = Lxx[i][j] otherwise
+            double v = tile[threadIdx.x][c];      // = Lxx[row j][col i]
+            if (bi == bj && i < j) v = Lxx[i + (size_t)j * nx];
+            Lsym[i + (size_t)j * nx] = v;
+        }
+    }
+}
+
+void launch_symmetrize(calipso_hip_solver* s) {
+    const int nt = (s->d.nx + 31) / 32;
+    hipLaunchKernelGGL(k_symmetrize_upper, dim3(nt, nt), dim3(32, 8), 0, s->stream, s->d.nx, s->Lxx, s->Lsym);
+}
+
 void launch_schur(calipso_hip_solver* s) {
+    if (s->hessian_dirty) { launch_symmetrize(s); s->hessian_dirty = false; }
     const int nt = s->d.NP / TILE;
     const int ntiles = nt * (nt + 1) / 2;
     const int grid = ((ntiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_schur, dim3(grid), dim3(256), 0, s->stream, s->d, s->sc, s->Lxx, s->gx, s->hx, s->WH, s->S, ntiles);
+    hipLaunchKernelGGL(k_schur, dim3(grid), dim3(SCHUR_THREADS), 0, s->stream, s->d, s->sc, s->Lsym, s->gx, s->hx, s->WH, s->S, ntiles);
 }
 
 }  // namespace calipso
