@@ -109,8 +109,11 @@ def main():
     import problems as pr
     shape = CONFIGS[args.config]
     B = args.batch
-    inst = [make_instance(pkg, pr, rank * B + b, shape, local_rank) for b in range(B)]
+    from calipso_jl_amd.batch import BatchSolver, gather_results, shard_range
+    ids = list(shard_range(world * B, rank, world))          # block-contiguous problem ids of this rank
+    inst = [make_instance(pkg, pr, pid, shape, local_rank) for pid in ids]
     solvers = [t[4] for t in inst]
+    batch = BatchSolver(solvers)
 
     def barrier():
         if dist is not None:
@@ -120,8 +123,7 @@ def main():
             s.synchronize()
 
     def one_step():
-        infos = [s.newton_step(advance=False) for s in solvers]
-        return infos
+        return batch.newton_step(advance=False)             # instances run concurrently, one HIP stream each
 
     for _ in range(args.warmup):
         one_step()
@@ -138,6 +140,10 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # post-round exchange (outside the data path): per-problem status rows all-gathered, step counters all-reduced
+    status = [[int(i["status"] >= 0), args.steps, i["refinement_rounds"], i["factorizations"]] for i in infos]
+    all_status, counters = gather_results(status, [float(len(solvers) * args.steps)])
+    assert all_status.shape[0] == world * B and int(counters[0]) == world * B * args.steps
     info = infos[0]
     nx, ne, n_nn, n_soc, dim = shape
     nc = n_nn + n_soc * dim

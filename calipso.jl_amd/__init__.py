@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import EVAL_FN, CalipsoHipError, lib
+from ._lib import CALLBACK_FN, EVAL_FN, CalipsoHipError, lib
 
 __all__ = ["Solver", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform"]
 
@@ -325,6 +325,14 @@ class Solver:
 
     def differentiate(self):
         self._check(self._L.calipso_hip_differentiate(self._h, self._cb, None), "differentiate")
+
+    def set_callbacks(self, inner=None, outer=None):
+        """callback_inner(custom, solver) / callback_outer(custom, solver) (src/solver/solver.jl:183,193): python callables taking the Solver"""
+        self._cbi = CALLBACK_FN(lambda u, h: inner(self)) if inner else None
+        self._cbo = CALLBACK_FN(lambda u, h: outer(self)) if outer else None
+        ci = C.cast(self._cbi, C.c_void_p) if self._cbi else None
+        co = C.cast(self._cbo, C.c_void_p) if self._cbo else None
+        self._check(self._L.calipso_hip_set_callbacks(self._h, ci, co, None), "set_callbacks")
 
     def stats(self):
         out = np.zeros(8, dtype=np.int64)

@@ -1,0 +1,73 @@
+"""Batched / multi-GPU driver: many independent problem instances in flight (BASELINE config C4).
+
+The reference has no batching (distinct `Solver`s are simply independent); the only cross-problem loop it has is
+the per-parameter loop of differentiate! (src/solver/differentiate.jl:29-58).  Here
+  * problems are sharded block-contiguously over the ranks of one node: problem ids [rank*B/W, (rank+1)*B/W);
+  * inside a rank every instance owns a HIP stream (its handle), and instances are driven concurrently from host threads
+    (the C ABI calls release the GIL), so the latency-bound phases of one instance overlap the matrix-core phases of another;
+  * there is NO collective on the data path.  After a batch round the per-problem status / iteration counts are
+    all-gathered and the step counters all-reduced (RCCL over xGMI when the backend is nccl; gloo on CPU for the tests).
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def shard_range(n_problems, rank, world):
+    """block-contiguous problem ids of `rank` (uneven remainders go to the low ranks)"""
+    base, rem = divmod(int(n_problems), int(world))
+    lo = rank * base + min(rank, rem)
+    return range(lo, lo + base + (1 if rank < rem else 0))
+
+
+class BatchSolver:
+    """A set of independent Solver handles on one GPU, stepped / solved concurrently."""
+
+    def __init__(self, solvers, max_workers=None):
+        self.solvers = list(solvers)
+        self.pool = ThreadPoolExecutor(max_workers=max_workers or max(1, len(self.solvers)))
+
+    def newton_step(self, advance=False):
+        return list(self.pool.map(lambda s: s.newton_step(advance=advance), self.solvers))
+
+    def solve(self, solve_fn):
+        """solve_fn(solver) -> bool for every instance; returns (status int32[k, 4]) rows = [converged, iterations, outer, factorizations]"""
+        def one(s):
+            ok = solve_fn(s)
+            st = s.stats()
+            return [int(ok), st["total_iterations"], st["outer"], st["factorizations"]]
+        return np.array(list(self.pool.map(one, self.solvers)), dtype=np.int32).reshape(len(self.solvers), 4)
+
+    def synchronize(self):
+        for s in self.solvers:
+            s.synchronize()
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+def gather_results(local_status, local_counters, device=None):
+    """all-gather the per-problem status rows (int32[k, 4], k may differ per rank) and all-reduce the counters (sum).
+    Returns (status of all problems in global problem-id order, summed counters).  Needs torch.distributed initialised;
+    with a single process it is the identity."""
+    import torch
+    import torch.distributed as dist
+    local_status = np.ascontiguousarray(local_status, dtype=np.int32).reshape(-1, 4)
+    counters = np.ascontiguousarray(local_counters, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_status, counters
+    world = dist.get_world_size()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    k = torch.tensor([local_status.shape[0]], dtype=torch.int64, device=dev)
+    ks = [torch.zeros_like(k) for _ in range(world)]
+    dist.all_gather(ks, k)
+    kmax = int(max(int(t.item()) for t in ks))
+    pad = np.full((kmax, 4), -1, dtype=np.int32)
+    pad[:local_status.shape[0]] = local_status
+    mine = torch.from_numpy(pad).to(dev)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    rows = [p.cpu().numpy()[:int(n.item())] for p, n in zip(parts, ks)]
+    c = torch.from_numpy(counters.copy()).to(dev)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return np.concatenate(rows, axis=0), c.cpu().numpy()

@@ -666,6 +666,12 @@ int32_t calipso_hip_initialize(H* s, const double* guess) {
     return CALIPSO_OK;
 }
 
+int32_t calipso_hip_set_callbacks(H* s, calipso_callback_fn inner, calipso_callback_fn outer, void* user) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    s->cb_inner = inner; s->cb_outer = outer; s->cb_user = user;
+    return CALIPSO_OK;
+}
+
 int32_t calipso_hip_stats(H* s, int64_t out[8]) {
     if (!s || !out) return CALIPSO_ERR_ARGUMENT;
     const Stats& t = s->stats;
@@ -741,6 +747,7 @@ int32_t calipso_hip_solve(H* s, calipso_eval_fn eval, void* user) {
                 return 1;
             }
             if (info.exit_kind == 2) break;
+            if (s->cb_inner) { SYNC(); s->cb_inner(s->cb_user, s); }     // callback_inner(custom, solver)  solve.jl:350
             total_iterations += 1;
             s->stats.total_iterations = total_iterations;
         }
@@ -749,6 +756,7 @@ int32_t calipso_hip_solve(H* s, calipso_eval_fn eval, void* user) {
         launch_lambda_update(s);                                                        // :362-364
         sc.rho = std::min(std::max(o.penalty_scaling * sc.rho, 1.0 / sc.kappa), o.max_penalty);   // :365
         filter_reset(s);                                                                // :368
+        if (s->cb_outer) { SYNC(); s->cb_outer(s->cb_user, s); }         // callback_outer(custom, solver)  solve.jl:371
     }
     s->stats.total_iterations = total_iterations;
     SYNC();

@@ -89,6 +89,8 @@ struct calipso_hip_solver {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    calipso_callback_fn cb_inner = nullptr, cb_outer = nullptr;   // options.callback_inner / callback_outer (solver.jl:183,193)
+    void* cb_user = nullptr;
     std::map<std::string, double*> optd;
     // host copies of the layout
     std::vector<int> h_soc_start, h_soc_dim, h_soc_woff;

@@ -83,6 +83,9 @@ enum {
 typedef int32_t (*calipso_eval_fn)(void* user, uint32_t flags, const double* x, const double* y, const double* z,
                                    const double* theta);
 
+/* callback_inner(custom, solver) / callback_outer(custom, solver)  (solver.jl:183,193; called at solve.jl:350,371) */
+typedef void (*calipso_callback_fn)(void* user, calipso_hip_solver* solver);
+
 /* ---- life cycle ------------------------------------------------------------------------------------------------ */
 /* Solver(methods, nx, np, ne, nc; nonnegative_indices, second_order_indices)   solver.jl:46-150, indices.jl:20-63.
  * nonneg_idx: n_nonneg cone-local indices (1-based); soc_ptr: n_soc+1 zero-based offsets into soc_idx (1-based,
@@ -176,6 +179,8 @@ int32_t calipso_hip_initialize(calipso_hip_solver*, const double* guess);
 int32_t calipso_hip_solve(calipso_hip_solver*, calipso_eval_fn eval, void* user);
 /* differentiate!(solver)  differentiate.jl:1-61: all np right-hand sides in one blocked solve */
 int32_t calipso_hip_differentiate(calipso_hip_solver*, calipso_eval_fn eval, void* user);
+/* install the per-inner-iteration / per-outer-update callbacks (NULL disables; options.callback_inner/outer) */
+int32_t calipso_hip_set_callbacks(calipso_hip_solver*, calipso_callback_fn inner, calipso_callback_fn outer, void* user);
 /* statistics of the last solve: [total_iterations, outer, factorizations, refinement_failures, max_refinement_rounds,
  * fallbacks, last_refinement_rounds, newton_steps] */
 int32_t calipso_hip_stats(calipso_hip_solver*, int64_t out[8]);

@@ -262,6 +262,7 @@ struct oracle_solver {
     bool have_symbolic = false;
     i64 inertia[3] = {0, 0, 0};
     // stats
+    std::vector<vec> trace;   // solution.all after every accepted inner iteration (test fixture support)
     i64 stat_total_iterations = 0, stat_outer = 0, stat_factorizations = 0, stat_refine_fail = 0,
         stat_refine_max = 0, stat_lu_fallback = 0, stat_last_refine_rounds = 0;
 
@@ -965,6 +966,12 @@ int oracle_armijo(double merit, double merit_candidate, const double* grad, cons
     return (merit_candidate - merit - 10.0 * machine_tolerance * std::fabs(merit) <= armijo_tolerance * step_size * d) ? 1 : 0;
 }
 
+int64_t oracle_trace(oracle_solver* s, double* out, int64_t cap_rows) {
+    i64 n = std::min<i64>((i64)s->trace.size(), cap_rows);
+    if (out) for (i64 k = 0; k < n; ++k) std::copy(s->trace[k].begin(), s->trace[k].end(), out + k * s->N);
+    return (i64)s->trace.size();
+}
+
 void oracle_stats(oracle_solver* s, int64_t out[8]) {
     out[0] = s->stat_total_iterations; out[1] = s->stat_outer; out[2] = s->stat_factorizations; out[3] = s->stat_refine_fail;
     out[4] = s->stat_refine_max; out[5] = s->stat_lu_fallback; out[6] = s->stat_last_refine_rounds; out[7] = 0;
@@ -988,6 +995,7 @@ int oracle_solve(oracle_solver* s, oracle_eval_fn eval, void* user) {
     const double* Dp = step;   // step.primals = first nx+ne+nc entries (point.jl:20)
     double& kappa = s->P("central_path")[0]; double& tau = s->P("fraction_to_boundary")[0];
     double& rho = s->P("penalty")[0]; double* lam = s->P("dual");
+    s->trace.clear();
     s->stat_total_iterations = 0; s->stat_outer = 0; s->stat_factorizations = 0; s->stat_refine_fail = 0; s->stat_refine_max = 0; s->stat_lu_fallback = 0;
 
     if (!o.warmstart) {
@@ -1096,6 +1104,7 @@ int oracle_solve(oracle_solver* s, oracle_eval_fn eval, void* user) {
             cone_product_violation = norm_inf(s->P("cone_product"), nc);      // :333
             total_iterations += 1;
             s->stat_total_iterations = total_iterations;
+            if (s->trace.size() < 512) s->trace.push_back(vec(w, w + N));
         }
         kappa = std::max(o.residual_tolerance / 10.0, std::min(o.central_path_scaling * kappa, std::pow(kappa, o.central_path_exponent)));   // :356
         tau = std::max(0.99, 1.0 - kappa);                                    // :359

@@ -109,6 +109,9 @@ int oracle_armijo(double merit, double merit_candidate, const double* grad, cons
 int oracle_solve(oracle_solver*, oracle_eval_fn eval, void* user);
 /* differentiate!(solver) differentiate.jl:1-61 */
 int oracle_differentiate(oracle_solver*, oracle_eval_fn eval, void* user);
+/* iterate trace of the last oracle_solve: row k = solution.all after the k-th accepted inner iteration (solve.jl:309-326).
+ * Returns the number of rows available; copies min(rows, cap_rows) rows of length N. */
+int64_t oracle_trace(oracle_solver*, double* out, int64_t cap_rows);
 /* per-solve statistics: [total_iterations, outer, factorizations, refinement_failures, max_refinement_rounds] */
 void oracle_stats(oracle_solver*, int64_t out[8]);
 /* elimination order used by factorize! (1-based perm of 1:n).  Default: [z | y | x]. */

@@ -94,6 +94,8 @@ def lib():
         L.oracle_solve.argtypes = [vp, EVAL_FN, vp]
         L.oracle_differentiate.argtypes = [vp, EVAL_FN, vp]
         L.oracle_stats.argtypes = [vp, pi64]
+        L.oracle_trace.restype = i64
+        L.oracle_trace.argtypes = [vp, pd, i64]
         L.oracle_set_perm.argtypes = [vp, pi64]
         L.oracle_qdldl_permute_symmetric.argtypes = [i64, pi64, pi64, pd, pi64, pi64, pi64, pd, pi64]
         L.oracle_qdldl_etree.restype = i64
@@ -266,6 +268,12 @@ class OracleSolver:
     def set_perm(self, perm_1based):
         p = np.ascontiguousarray(perm_1based, dtype=np.int64)
         self._L.oracle_set_perm(self._h, _pi(p))
+
+    def trace(self):
+        n = int(self._L.oracle_trace(self._h, None, 0))
+        out = np.zeros((max(n, 1), self.N))
+        self._L.oracle_trace(self._h, _pd(out), n)
+        return out[:n]
 
     def stats(self):
         out = np.zeros(8, dtype=np.int64)

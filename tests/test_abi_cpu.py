@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary (no GPU needed): the shared library loads, exports every symbol that
+include/calipso_hip.h declares, the ctypes table covers exactly those symbols, and the library refuses to work without a
+HIP device instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, load_pkg
+
+HEADER = os.path.join(ROOT, "include", "calipso_hip.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(calipso_hip_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    pkg = load_pkg()
+    from calipso_jl_amd._lib import LIB_PATH, SYMBOLS, lib
+    assert os.path.exists(LIB_PATH), "libcalipso_hip.so must be built in-tree (python __graft_entry__.py build)"
+    L = lib()
+    decl = declared_symbols()
+    assert len(decl) >= 35
+    for name in decl:
+        assert hasattr(L, name), "missing export: " + name
+    assert sorted(SYMBOLS) == decl            # the ctypes binding table is exactly the header
+
+
+def test_host_side_functions_work_without_gpu():
+    pkg = load_pkg()
+    from calipso_jl_amd._lib import lib
+    L = lib()
+    assert L.calipso_hip_version().startswith(b"calipso-hip")
+    u = pkg.splitmix_uniform(7, 3, -1.0, 1.0, 5)
+    # SplitMix64 reference values (seed 0xCA11B50000000000 + 4096*7 + 3), independent python implementation
+    state = (0xCA11B50000000000 + 4096 * 7 + 3) & (2**64 - 1)
+    ref = []
+    for _ in range(5):
+        state = (state + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        z = z ^ (z >> 31)
+        ref.append(-1.0 + 2.0 * ((z >> 11) * 2.0**-53))
+    assert np.array_equal(u, np.array(ref))
+
+
+def test_no_cpu_fallback():
+    """without a HIP device the product must fail loudly (there is no CPU path behind the C ABI)"""
+    pkg = load_pkg()
+    from calipso_jl_amd._lib import lib
+    if lib().calipso_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.CalipsoHipError) as e:
+        pkg.Solver(None, 3, 0, 2, 2)
+    assert "no HIP device" in str(e.value)
+
+
+def test_product_does_not_reference_oracle():
+    """oracle/ is test infrastructure: nothing under calipso.jl_amd/ may import, link or mention it"""
+    pk = os.path.join(ROOT, "calipso.jl_amd")
+    for dp, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".jl", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "liboracle" not in txt and "import oracle" not in txt and "calipso_oracle" not in txt, os.path.join(dp, f)
