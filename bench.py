@@ -154,6 +154,12 @@ def main():
     sch_ms = float(np.mean(sch))
     flops = float(nx) * (nx + 1) * m
     achieved = flops / (sch_ms * 1e-3) * 1e-12
+    traffic = None
+    try:   # HBM bytes per launch of k_schur from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C3 shape only)
+        if args.config == "C3":
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["calipso::k_schur"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -167,7 +173,7 @@ def main():
                                 "ldl_of_schur_complement": float(np.mean(ldl))}},
         "roofline": {"kernel": "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "flops_per_launch": flops, "avg_launch_ms": sch_ms},
+                     "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": sch_ms},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(shape)

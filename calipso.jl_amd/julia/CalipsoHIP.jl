@@ -1,0 +1,221 @@
+# CalipsoHIP.jl — Julia host layer over libcalipso_hip.so (include/calipso_hip.h).
+#
+# Keeps the reference's surface for the Newton/KKT hot path (CALIPSO.jl v0.1.1):
+#     Solver(...)  ->  HIPSolver(solver::CALIPSO.Solver)      wraps an ordinary CALIPSO.Solver (its codegen'd methods,
+#                                                            ProblemData, Indices, Options are reused unchanged)
+#     initialize!(hs, x0)            src/solver/initialize.jl:9-13
+#     solve!(hs)::Bool               src/solver/solve.jl:8-377   — the whole loop runs in the library; Julia only evaluates the
+#                                                                  user functions (evaluate!) when the library calls back
+#     HIPLDLSolver <: LinearSolver   src/solver/linear_solver.jl:1-60 seam: factorize!, compute_inertia!, linear_solve!
+#
+# NOTE: Julia is not installed in the build container of this repository, so this file has not been executed there; it is the
+# binding a maintainer adds (see INTEGRATION.md).  The same C ABI is exercised end-to-end by the Python ctypes mirror
+# (calipso.jl_amd/__init__.py) in tests/.
+module CalipsoHIP
+
+using CALIPSO
+using LinearAlgebra
+
+const lib = get(ENV, "CALIPSO_HIP_LIB", joinpath(@__DIR__, "..", "libcalipso_hip.so"))
+
+# evaluate! flags (include/calipso_hip.h)
+const EVAL_OBJECTIVE = UInt32(1) << 0
+const EVAL_OBJECTIVE_GRADIENT = UInt32(1) << 1
+const EVAL_OBJECTIVE_HESSIAN = UInt32(1) << 2
+const EVAL_EQUALITY = UInt32(1) << 3
+const EVAL_EQUALITY_JACOBIAN = UInt32(1) << 4
+const EVAL_EQUALITY_DUAL_GRADIENT = UInt32(1) << 5
+const EVAL_EQUALITY_DUAL_HESSIAN = UInt32(1) << 6
+const EVAL_CONE = UInt32(1) << 7
+const EVAL_CONE_JACOBIAN = UInt32(1) << 8
+const EVAL_CONE_DUAL_GRADIENT = UInt32(1) << 9
+const EVAL_CONE_DUAL_HESSIAN = UInt32(1) << 10
+const EVAL_OBJECTIVE_JACOBIAN_PARAMETERS = UInt32(1) << 11
+const EVAL_EQUALITY_JACOBIAN_PARAMETERS = UInt32(1) << 12
+const EVAL_EQUALITY_DUAL_JACOBIAN_PARAMETERS = UInt32(1) << 13
+const EVAL_CONE_JACOBIAN_PARAMETERS = UInt32(1) << 14
+const EVAL_CONE_DUAL_JACOBIAN_PARAMETERS = UInt32(1) << 15
+
+struct HIPError <: Exception
+    code::Int32
+    msg::String
+end
+
+mutable struct HIPSolver
+    handle::Ptr{Cvoid}
+    solver::CALIPSO.Solver          # the reference Solver: methods, problem (ProblemData), indices, options, parameters
+    eval_cfunction::Base.CFunction  # keeps the @cfunction alive
+end
+
+last_error(h) = unsafe_string(ccall((:calipso_hip_last_error, lib), Cstring, (Ptr{Cvoid},), h))
+
+function check(h, rc::Integer, what)
+    rc == -1 && error("inertia correction failure")    # same text as src/solver/inertia.jl:72
+    rc == -2 && error("cone search failure")           # src/solver/solve.jl:210,220
+    rc < 0 && throw(HIPError(Int32(rc), "$what: $(last_error(h))"))
+    rc == 1 && @warn "Zero entry in D (matrix is not quasidefinite)"     # src/solver/qdldl.jl:309-311
+    rc == 2 && @warn "iterative refinement failure"                       # src/solver/iterative_refinement.jl:50
+    return rc
+end
+
+set_field!(h, name::String, v::AbstractArray{Float64}) =
+    check(h, ccall((:calipso_hip_set_field, lib), Int32, (Ptr{Cvoid}, Cstring, Ptr{Float64}, Int64), h, name, v, length(v)), "set_field($name)")
+set_field!(h, name::String, v::Real) = set_field!(h, name, [Float64(v)])
+function get_field(h, name::String, len::Integer)
+    out = zeros(len)
+    check(h, ccall((:calipso_hip_get_field, lib), Int32, (Ptr{Cvoid}, Cstring, Ptr{Float64}, Int64), h, name, out, len), "get_field($name)")
+    return out
+end
+
+"""
+    HIPSolver(solver::CALIPSO.Solver; device=0)
+
+Create the device handle for an existing reference `Solver` (src/solver/solver.jl:46-150).  Index sets are passed 1-based,
+exactly as `solver.indices` holds them.
+"""
+function HIPSolver(solver::CALIPSO.Solver; device::Integer=0)
+    d = solver.dimensions
+    idx = solver.indices
+    nn = Vector{Int64}(idx.cone_nonnegative)
+    soc = idx.cone_second_order
+    ptr = Int64[0]
+    flat = Int64[]
+    for c in soc
+        append!(flat, c)
+        push!(ptr, length(flat))
+    end
+    href = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:calipso_hip_create, lib), Int32,
+        (Int64, Int64, Int64, Int64, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ptr{Ptr{Cvoid}}),
+        d.variables, d.parameters, d.equality_dual, d.cone_dual, length(nn), nn, length(soc), ptr, flat, device, href)
+    rc != 0 && throw(HIPError(rc, "calipso_hip_create: $(last_error(href[]))"))
+    hs = HIPSolver(href[], solver, @cfunction($(evaluate_callback), Int32, (Ptr{Cvoid}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64})))
+    finalizer(x -> ccall((:calipso_hip_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), hs)
+    # options (src/solver/options.jl:6-59) -> handle
+    for f in fieldnames(typeof(solver.options))
+        v = getfield(solver.options, f)
+        v isa Real && f != :linear_solver && ccall((:calipso_hip_set_field, lib), Int32, (Ptr{Cvoid}, Cstring, Ptr{Float64}, Int64), hs.handle, "opt.$f", [Float64(v)], 1)
+    end
+    length(solver.parameters) > 0 && set_field!(hs.handle, "parameters", solver.parameters)
+    return hs
+end
+
+const ACTIVE = Ref{Union{Nothing,HIPSolver}}(nothing)   # the solver being driven by solve! (one per thread of control)
+
+# evaluate!(problem, methods, idx, point, parameters; <flags>)  (src/solver/evaluate.jl:1-124) at the point the library hands
+# over, then upload of the flagged ProblemData fields (the three Hessian terms as one summed "lagrangian_hessian",
+# src/solver/residual_jacobian_variables.jl:10-16).
+function evaluate_callback(user::Ptr{Cvoid}, flags::UInt32, px::Ptr{Float64}, py::Ptr{Float64}, pz::Ptr{Float64}, pth::Ptr{Float64})::Int32
+    hs = ACTIVE[]
+    s = hs.solver
+    d = s.dimensions
+    try
+        pt = s.candidate                      # scratch Point the generated functions read from
+        pt.variables .= unsafe_wrap(Array, px, d.variables)
+        d.equality_dual > 0 && (pt.equality_dual .= unsafe_wrap(Array, py, d.equality_dual))
+        d.cone_dual > 0 && (pt.cone_dual .= unsafe_wrap(Array, pz, d.cone_dual))
+        has(f) = (flags & f) != 0
+        CALIPSO.evaluate!(s.problem, s.methods, s.indices, pt, s.parameters;
+            objective=has(EVAL_OBJECTIVE), objective_gradient_variables=has(EVAL_OBJECTIVE_GRADIENT),
+            objective_jacobian_variables_variables=has(EVAL_OBJECTIVE_HESSIAN),
+            equality_constraint=has(EVAL_EQUALITY), equality_jacobian_variables=has(EVAL_EQUALITY_JACOBIAN),
+            equality_dual_jacobian_variables=has(EVAL_EQUALITY_DUAL_GRADIENT),
+            equality_dual_jacobian_variables_variables=has(EVAL_EQUALITY_DUAL_HESSIAN),
+            cone_constraint=has(EVAL_CONE), cone_jacobian_variables=has(EVAL_CONE_JACOBIAN),
+            cone_dual_jacobian_variables=has(EVAL_CONE_DUAL_GRADIENT),
+            cone_dual_jacobian_variables_variables=has(EVAL_CONE_DUAL_HESSIAN),
+            objective_jacobian_variables_parameters=has(EVAL_OBJECTIVE_JACOBIAN_PARAMETERS),
+            equality_jacobian_parameters=has(EVAL_EQUALITY_JACOBIAN_PARAMETERS),
+            equality_dual_jacobian_variables_parameters=has(EVAL_EQUALITY_DUAL_JACOBIAN_PARAMETERS),
+            cone_jacobian_parameters=has(EVAL_CONE_JACOBIAN_PARAMETERS),
+            cone_dual_jacobian_variables_parameters=has(EVAL_CONE_DUAL_JACOBIAN_PARAMETERS))
+        p = s.problem
+        h = hs.handle
+        has(EVAL_OBJECTIVE) && set_field!(h, "objective", p.objective)
+        has(EVAL_OBJECTIVE_GRADIENT) && set_field!(h, "objective_gradient_variables", p.objective_gradient_variables)
+        has(EVAL_EQUALITY) && d.equality_dual > 0 && set_field!(h, "equality_constraint", p.equality_constraint)
+        has(EVAL_EQUALITY_JACOBIAN) && d.equality_dual > 0 && set_field!(h, "equality_jacobian_variables", p.equality_jacobian_variables)
+        has(EVAL_EQUALITY_DUAL_GRADIENT) && set_field!(h, "equality_dual_jacobian_variables", p.equality_dual_jacobian_variables)
+        has(EVAL_CONE) && d.cone_dual > 0 && set_field!(h, "cone_constraint", p.cone_constraint)
+        has(EVAL_CONE_JACOBIAN) && d.cone_dual > 0 && set_field!(h, "cone_jacobian_variables", p.cone_jacobian_variables)
+        has(EVAL_CONE_DUAL_GRADIENT) && set_field!(h, "cone_dual_jacobian_variables", p.cone_dual_jacobian_variables)
+        if has(EVAL_OBJECTIVE_HESSIAN)
+            L = copy(p.objective_jacobian_variables_variables)
+            if s.options.constraint_tensor
+                L .+= p.equality_dual_jacobian_variables_variables
+                L .+= p.cone_dual_jacobian_variables_variables
+            end
+            set_field!(h, "lagrangian_hessian", L)
+        end
+        if has(EVAL_OBJECTIVE_JACOBIAN_PARAMETERS) && d.parameters > 0
+            G = p.objective_jacobian_variables_parameters + p.equality_dual_jacobian_variables_parameters + p.cone_dual_jacobian_variables_parameters
+            set_field!(h, "lagrangian_gradient_parameters", G)
+            d.equality_dual > 0 && set_field!(h, "equality_jacobian_parameters", p.equality_jacobian_parameters)
+            d.cone_dual > 0 && set_field!(h, "cone_jacobian_parameters", p.cone_jacobian_parameters)
+        end
+        return Int32(0)
+    catch err
+        @error "evaluate! callback failed" err
+        return Int32(1)
+    end
+end
+
+"initialize!(solver, guess)  src/solver/initialize.jl:9-13"
+function CALIPSO.initialize!(hs::HIPSolver, guess)
+    g = Vector{Float64}(guess)
+    hs.solver.solution.variables .= g
+    check(hs.handle, ccall((:calipso_hip_initialize, lib), Int32, (Ptr{Cvoid}, Ptr{Float64}), hs.handle, g), "initialize!")
+    return
+end
+
+"solve!(solver)::Bool  src/solver/solve.jl:8-377 — results are copied back into the wrapped Solver's fields"
+function CALIPSO.solve!(hs::HIPSolver)
+    ACTIVE[] = hs
+    rc = ccall((:calipso_hip_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), hs.handle, hs.eval_cfunction, C_NULL)
+    ACTIVE[] = nothing
+    check(hs.handle, rc, "solve!")
+    s = hs.solver
+    d = s.dimensions
+    s.solution.all .= get_field(hs.handle, "solution", d.total)
+    s.data.residual.all .= get_field(hs.handle, "residual", d.total)
+    s.data.step.all .= get_field(hs.handle, "step", d.total)
+    d.cone_dual > 0 && (s.problem.cone_product .= get_field(hs.handle, "cone_product", d.cone_dual))
+    for (name, ref) in (("central_path", s.central_path), ("penalty", s.penalty), ("fraction_to_boundary", s.fraction_to_boundary),
+                        ("primal_regularization", s.primal_regularization), ("dual_regularization", s.dual_regularization),
+                        ("primal_regularization_last", s.primal_regularization_last))
+        ref[1] = get_field(hs.handle, name, 1)[1]
+    end
+    d.equality_dual > 0 && (s.dual .= get_field(hs.handle, "dual", d.equality_dual))
+    if s.options.differentiate && d.parameters > 0
+        s.data.solution_sensitivity .= reshape(get_field(hs.handle, "solution_sensitivity", d.total * d.parameters), d.total, d.parameters)
+    end
+    return rc == 1
+end
+
+# ---- linear-solver seam (src/solver/linear_solver.jl:1-60) -------------------------------------------------------------------
+"Drop-in for LDLSolver: the factorisation works from the blocks already on the device, `A` is accepted for signature parity."
+mutable struct HIPLDLSolver <: CALIPSO.LinearSolver
+    hs::HIPSolver
+    inertia::CALIPSO.Inertia
+end
+HIPLDLSolver(hs::HIPSolver) = HIPLDLSolver(hs, CALIPSO.Inertia(0, 0, 0))
+
+function CALIPSO.factorize!(s::HIPLDLSolver, A=nothing; update=true)
+    out = zeros(Int64, 3)
+    check(s.hs.handle, ccall((:calipso_hip_factorize, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), s.hs.handle, out), "factorize!")
+    s.inertia.positive, s.inertia.negative, s.inertia.zero = out
+    return nothing
+end
+CALIPSO.compute_inertia!(s::HIPLDLSolver) = nothing      # filled by factorize! (one device pass counts the pivot signs)
+
+function CALIPSO.linear_solve!(s::HIPLDLSolver, x::Vector{Float64}, A, b::Vector{Float64}; fact=true, update=true)
+    fact && CALIPSO.factorize!(s, A; update=update)
+    set_field!(s.hs.handle, "residual_symmetric", b)
+    check(s.hs.handle, ccall((:calipso_hip_linear_solve, lib), Int32, (Ptr{Cvoid},), s.hs.handle), "linear_solve!")
+    x .= get_field(s.hs.handle, "step_symmetric", length(b))
+    return
+end
+
+export HIPSolver, HIPLDLSolver
+
+end # module
