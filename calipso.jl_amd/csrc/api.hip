@@ -3,6 +3,7 @@
 // (filter.jl:1-89) over the HIP kernels of this directory.  The host only takes the scalar decisions the reference
 // takes (convergence tests, line-search acceptance, regularisation updates); all array arithmetic is on the device.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -89,7 +90,17 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     s->device = device;
     *out = s;   // from here on errors are reported through the handle
     CK(hipSetDevice(device));
-    CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    {
+        // Instances are meant to run concurrently (one stream each).  Streams of equal priority may be multiplexed onto one
+        // hardware queue, which serialises them; alternating the priority class spreads consecutive handles over queues.
+        static std::atomic<int> n_handles{0};
+        int least = 0, greatest = 0;
+        CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int k = n_handles.fetch_add(1);
+        const int span = least - greatest;   // numerically lower = higher priority
+        const int prio = span > 0 ? greatest + (k % (span + 1)) : least;
+        CK(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio));
+    }
     for (auto& e : s->ev) CK(hipEventCreate(&e));
     const size_t NX = d.nx, NE = d.ne, NC = d.nc, N = d.N, NPd = d.NP, M = d.m, n = d.n;
     int rc = 0;

@@ -4,11 +4,10 @@
 // [z | y | x]; every pivot of S must be > 0 for the inertia test (inertia.jl:7-11).
 //
 // Per panel of NB = 64 columns (all on one stream, kernel boundaries are the only synchronisation):
-//   k_ldl_diag      one workgroup; the 64 x 64 diagonal block lives in registers (16 entries per lane), the pivot column
-//                   is exchanged through LDS with ONE barrier per column.  The same sweep applies the elementary
-//                   eliminations to an identity, so the kernel also emits X = L11^-1 (needed by the panel step and by
-//                   the triangular solves), counts pivot signs (compute_inertia!, linear_solver.jl:33-44) and flags
-//                   exact zeros (qdldl.jl:579).
+//   k_ldl_diag      one workgroup; the 64 x 64 diagonal block lives in registers, the pivot column is exchanged through LDS
+//                   with ONE barrier per column; afterwards the kernel forms X = L11^-1 by blocked inversion (needed by
+//                   the panel step and by the triangular solves), counts pivot signs (compute_inertia!,
+//                   linear_solver.jl:33-44) and flags exact zeros (qdldl.jl:579).
 //   k_ldl_panel     Y21 = A21 * L11^-T and L21 = Y21 * D^-1 as a small GEMM with the inverse on the fp64 matrix cores
 //   k_ldl_trailing  A22 -= L21 * Y21'  on the matrix cores: 128 x 128 tiles of the lower triangle, 1024 threads (16
 //                   wavefronts, fp64 MFMA needs >= 4 waves per SIMD), both 128 x 64 operand panels staged in LDS once.
@@ -25,90 +24,150 @@ constexpr int TB = 512;            // triangular-solve block
 constexpr int LDT = NB + 2;        // LDS leading dimension of a k-fastest 64-deep operand panel
 
 // ---- diagonal block ---------------------------------------------------------------------------------------------------------
-// 1024 threads: lane i = tid & 63 is a ROW of the block, wavefront cg = tid >> 6 owns the columns k = cg + 16 c (c = 0..3)
-// of both the block A and the inverse X, in registers.  Per column j: ONE barrier; the pivot column (unscaled), the
-// pivot's reciprocal and row j of X travel through LDS.  The update is branch-free: all LDS operands of a step are read
-// in one batch and masked lanes multiply by zero, so a step costs one LDS round trip instead of one per column
-//     A[i][k] -= l_i A[k][j]   (k > j, i >= k)          X[i][k] -= l_i X[j][k]   (k <= j, i > j)
-// (the same elementary operation M_j = I - l_j e_j' applied to the identity gives X = L11^-1).
+// The 2500 sequential pivots of S are the critical path of the factorisation; this kernel is tuned with the stand-alone
+// harness bench/diag_bench.hip (variant v4).  1024 threads: lane i = tid & 63 is a ROW of the block, wavefront
+// cg = tid >> 6 owns the columns k = cg + 16 c (c = 0..3) in registers.
+//   phase 1  LDL^T: per column j ONE barrier; the unscaled pivot column y (y_i = l_i d_j) and a vector of reciprocals travel
+//            through LDS; the update a[c] -= l_i y_k is unmasked (a finished column was stashed in LDS when it was
+//            published, rows at/above the pivot only collect garbage that is never read) -> 4 FMAs per lane per column.
+//   phase 2  X = L11^-1 (needed by the panel GEMM and by the triangular solves): the four 16 x 16 diagonal blocks by
+//            wave-synchronous forward substitution in registers, then two merge levels inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1, C^-1]
+//            as small dense products out of LDS.
 // Nothing is written to global memory inside the column loop (a pending store would make every barrier wait on memory).
 constexpr int DIAG_THREADS = 1024;
+constexpr int LDD = NB + 1;
+
+__device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton steps (pivots are normal numbers; 0 -> inf as 1/0)
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+
 __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(int NP, int nx, int k0, double* __restrict__ S, double* __restrict__ Dx,
                                                             double* __restrict__ Tinv, int* __restrict__ icount) {
-    __shared__ double colbuf[2][NB];   // column j of the partially eliminated block (unscaled: y_i = l_i d_j)
-    __shared__ double xrow[2][NB];     // row j of X before elimination step j
-    __shared__ double rinvbuf[2];
-    __shared__ double dd[NB];
+    constexpr int WAVES = 16, CPW = 4;
+    __shared__ double colbuf[2][NB];
+    __shared__ double rinvvec[2][NB];
+    __shared__ double Ls[NB * LDD];
+    __shared__ double Xs[NB * LDD];
+    __shared__ double Ts[32 * 33];
     const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
-    double a[4], x[4];
+    double a[CPW];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int k = cg + 16 * c;
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
         a[c] = (i >= k) ? S[(k0 + i) + (size_t)(k0 + k) * NP] : 0.0;
-        x[c] = (i == k) ? 1.0 : 0.0;
     }
     if (cg == 0) {
         colbuf[0][i] = a[0];
-        if (i == 0) { rinvbuf[0] = 1.0 / a[0]; dd[0] = a[0]; }
-    }
-    if (i == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xrow[0][cg + 16 * c] = x[c];
+        rinvvec[0][i] = fast_rcp(a[0]);
+        Ls[i * LDD + 0] = a[0];
     }
 #pragma unroll 1
-    for (int jb = 0; jb < NB; jb += 16)
+    for (int jb = 0; jb < NB; jb += WAVES)
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
+    for (int jj = 0; jj < WAVES; ++jj) {
         const int j = jb + jj;
         const int cur = jj & 1, nxt = cur ^ 1;
-        __syncthreads();
-        double yk[4], xk[4];
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only LDS traffic is outstanding here
+        __builtin_amdgcn_s_barrier();
         const double yi = colbuf[cur][i];
-        const double rinv = rinvbuf[cur];
+        const double rinv = rinvvec[cur][j];
+        double yk[CPW];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { yk[c] = colbuf[cur][cg + 16 * c]; xk[c] = xrow[cur][cg + 16 * c]; }
-        const double li = yi * rinv;
-        const double lrow = (i > j) ? li : 0.0;          // rows at or above the pivot are finished
+        for (int c = 0; c < CPW; ++c) yk[c] = colbuf[cur][cg + WAVES * c];
+        const double li = (i > j) ? yi * rinv : 0.0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = cg + 16 * c;                   // wavefront-uniform
-            const double la = (k > j && i >= k) ? li : 0.0;
-            const double lx = (k <= j) ? lrow : 0.0;
-            a[c] -= la * yk[c];
-            x[c] -= lx * xk[c];
-        }
-        if (j + 1 < NB) {
-            if (cg == (jj + 1) % 16) {                   // the wavefront that owns column j+1 publishes it
-                const int cs = (j + 1) >> 4;
-                const double v = cs == 0 ? a[0] : (cs == 1 ? a[1] : (cs == 2 ? a[2] : a[3]));
-                colbuf[nxt][i] = v;
-                if (i == j + 1) { rinvbuf[nxt] = 1.0 / v; dd[j + 1] = v; }
-            }
-            if (i == j + 1) {                            // row j+1 of X, spread over all wavefronts
+        for (int c = 0; c < CPW; ++c) a[c] -= li * yk[c];
+        if (j + 1 < NB && cg == (jj + 1) % WAVES) {      // the wavefront that owns column j+1 publishes and stashes it
+            const int cs = (j + 1) / WAVES;
+            double v = a[0];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xrow[nxt][cg + 16 * c] = x[c];
-            }
+            for (int c = 1; c < CPW; ++c) v = (cs == c) ? a[c] : v;
+            colbuf[nxt][i] = v;
+            rinvvec[nxt][i] = fast_rcp(v);               // every lane; readers pick entry j+1 (no divergent single-lane path)
+            Ls[i * LDD + j + 1] = v;                     // unscaled column j+1, pivot on the diagonal
         }
     }
     __syncthreads();
-    // column k of L: its owner still holds the unscaled entries y_i = l_i d_k (never touched after step k)
-    {
-        const int q = k0 / TB, o = k0 % TB;
-        double* T = Tinv + (size_t)q * TB * TB;
+    double dk[CPW];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = cg + 16 * c;
-            if (i > k) S[(k0 + i) + (size_t)(k0 + k) * NP] = a[c] * (1.0 / dd[k]);
-            T[(o + i) + (size_t)(o + k) * TB] = (i >= k) ? x[c] : 0.0;   // X = L11^-1 on the diagonal of the inverse block
-        }
-    }
+    for (int c = 0; c < CPW; ++c) dk[c] = Ls[(cg + WAVES * c) * LDD + cg + WAVES * c];
     if (tid < NB) {
-        const double d = dd[tid];
+        const double d = Ls[tid * LDD + tid];
         Dx[k0 + tid] = d;
         int pos = 0, nonpos = 0, zero = 0;
         if (k0 + tid < nx) { pos = d > 0.0; nonpos = d <= 0.0; zero = d == 0.0; }
         pos = wave_sum_i(pos); nonpos = wave_sum_i(nonpos); zero = wave_sum_i(zero);
         if (tid == 0) { atomicAdd(&icount[3], pos); atomicAdd(&icount[4], nonpos); atomicAdd(&icount[5], zero); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        const double lv = (i > k) ? Ls[i * LDD + k] * (1.0 / dk[c]) : 0.0;
+        Ls[i * LDD + k] = lv;
+        Xs[i * LDD + k] = 0.0;
+        if (i > k) S[(k0 + i) + (size_t)(k0 + k) * NP] = lv;
+    }
+    __syncthreads();
+    // (a) the four 16 x 16 diagonal blocks of X: wavefront w < 4, lane c < 16 builds column c by forward substitution
+    if (cg < 4 && i < 16) {
+        const int o = 16 * cg;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < r; ++k) acc -= Ls[(o + r) * LDD + o + k] * x[k];
+            x[r] = (r >= i) ? acc : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Xs[(o + r) * LDD + o + i] = x[r];
+    }
+    __syncthreads();
+    // (b) level 1: X21 = -X22 (L21 X11) inside each 32-block; 512 threads, one output each
+    {
+        const int p = tid >> 8, ii = (tid >> 4) & 15, jc = tid & 15, o = 32 * p;
+        if (tid < 512) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += Ls[(o + 16 + ii) * LDD + o + k] * Xs[(o + k) * LDD + o + jc];
+            Ts[(p * 16 + ii) * 33 + jc] = t;
+        }
+        __syncthreads();
+        if (tid < 512) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v -= Xs[(o + 16 + ii) * LDD + o + 16 + k] * Ts[(p * 16 + k) * 33 + jc];
+            Xs[(o + 16 + ii) * LDD + o + jc] = v;
+        }
+        __syncthreads();
+    }
+    // (c) level 2: X21 (32 x 32) = -X22 (L21 X11); 1024 threads, one output each
+    {
+        const int ii = tid >> 5, jc = tid & 31;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += Ls[(32 + ii) * LDD + k] * Xs[k * LDD + jc];
+        Ts[ii * 33 + jc] = t;
+        __syncthreads();
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v -= Xs[(32 + ii) * LDD + 32 + k] * Ts[k * 33 + jc];
+        __syncthreads();
+        Xs[(32 + ii) * LDD + jc] = v;
+    }
+    __syncthreads();
+    {
+        const int q = k0 / TB, o = k0 % TB;
+        double* T = Tinv + (size_t)q * TB * TB;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int k = cg + WAVES * c;
+            T[(o + i) + (size_t)(o + k) * TB] = Xs[i * LDD + k];     // X = L11^-1 on the diagonal of the inverse block (zeros above)
+        }
     }
 }
 
@@ -301,7 +360,8 @@ void launch_ldl(calipso_hip_solver* s) {
 // backward: L' v = z.  kernel B'_k: v_k = Tinv_k' z_k ; kernel A'_k: z_above -= L[k, above]' v_k
 // Each output entry is a dot product of a matrix row/column with a 256-vector; the vector sits in LDS.
 
-// u_k = Tinv_k b_k (lower-triangular mat-vec, lanes along rows) ; out = u_k * scale  (scale = 1/D folded for the forward pass)
+// u_k = Tinv_k b_k (lower-triangular mat-vec, lanes along rows); also z_k = u_k / D.  32 rows per workgroup, 8 column parts;
+// loads are issued in explicit batches of 16 so that many are in flight per lane (these kernels are latency-bound).
 __global__ __launch_bounds__(256) void k_trsv_block_n(int kb, const double* __restrict__ Tinv, const double* __restrict__ b, const double* __restrict__ Dx,
                                                        double* __restrict__ u, double* __restrict__ z) {
     __shared__ double bs[TB];
@@ -309,13 +369,19 @@ __global__ __launch_bounds__(256) void k_trsv_block_n(int kb, const double* __re
     const int tid = threadIdx.x, k0 = kb * TB;
     for (int i = tid; i < TB; i += 256) bs[i] = b[k0 + i];
     __syncthreads();
-    const int r = tid & 31, p = tid >> 5;          // 32 rows per workgroup, 8 column parts
+    const int r = tid & 31, p = tid >> 5;
     const int row = blockIdx.x * 32 + r;
-    const double* T = Tinv + (size_t)kb * TB * TB;
+    const double* T = Tinv + (size_t)kb * TB * TB + row;
     const int cend = blockIdx.x * 32 + 32;         // lower triangular: columns beyond the workgroup's last row are zero
     double acc = 0.0;
-#pragma unroll 16
-    for (int c = p; c < cend; c += 8) acc += T[row + (size_t)c * TB] * bs[c];
+#pragma unroll 1
+    for (int cb = 0; cb < cend; cb += 128) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int c = cb + p + 8 * q; v[q] = (c < cend) ? T[(size_t)c * TB] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int c = cb + p + 8 * q; acc += v[q] * bs[c < TB ? c : 0]; }
+    }
     part[p][r] = acc;
     __syncthreads();
     if (tid < 32) {
@@ -360,9 +426,12 @@ __global__ __launch_bounds__(256) void k_trsv_block_t(int kb, const double* __re
     __syncthreads();
     const int c = blockIdx.x * 4 + (tid >> 6);
     const double* T = Tinv + (size_t)kb * TB * TB + (size_t)c * TB;
+    double tv[TB / 64];
+#pragma unroll
+    for (int q = 0; q < TB / 64; ++q) { const int r = lane + 64 * q; tv[q] = (r >= (c & ~63)) ? T[r] : 0.0; }   // column c is zero above row c
     double acc = 0.0;
 #pragma unroll
-    for (int r = (c & ~63) + lane; r < TB; r += 64) acc += T[r] * zs[r];   // column c is zero above row c
+    for (int q = 0; q < TB / 64; ++q) acc += tv[q] * zs[lane + 64 * q];
     acc = wave_sum(acc);
     if (lane == 0) v[k0 + c] = acc;
 }
@@ -375,9 +444,12 @@ __global__ __launch_bounds__(256) void k_trsv_update_t(int NP, int kb, const dou
     __syncthreads();
     const int c = blockIdx.x * 4 + (tid >> 6);     // c < k0
     const double* Lc = S + (size_t)c * NP + k0;
+    double lv[TB / 64];
+#pragma unroll
+    for (int q = 0; q < TB / 64; ++q) lv[q] = Lc[lane + 64 * q];
     double acc = 0.0;
 #pragma unroll
-    for (int r = lane; r < TB; r += 64) acc += Lc[r] * vs[r];
+    for (int q = 0; q < TB / 64; ++q) acc += lv[q] * vs[lane + 64 * q];
     acc = wave_sum(acc);
     if (lane == 0) z[c] -= acc;
 }
