@@ -104,8 +104,8 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     for (auto& e : s->ev) CK(hipEventCreate(&e));
     const size_t NX = d.nx, NE = d.ne, NC = d.nc, N = d.N, NPd = d.NP, M = d.m, n = d.n;
     int rc = 0;
-    rc |= dalloc(s, &s->Lxx, NX * NX); rc |= dalloc(s, &s->Lsym, NX * NX); rc |= dalloc(s, &s->gx, NE * NX); rc |= dalloc(s, &s->hx, NC * NX);
-    rc |= dalloc(s, &s->fx, NX); rc |= dalloc(s, &s->gyx, NX); rc |= dalloc(s, &s->hzx, NX); rc |= dalloc(s, &s->g, NE); rc |= dalloc(s, &s->hc, NC);
+    rc |= dalloc(s, &s->Lxx, NX * NX); rc |= dalloc(s, &s->Lsym, NX * NX); rc |= dalloc(s, &s->Z, M * NX); s->gx = s->Z; s->hx = s->Z ? s->Z + NE : nullptr;
+    rc |= dalloc(s, &s->fx, NX); rc |= dalloc(s, &s->gyx, NX); rc |= dalloc(s, &s->hzx, NX); rc |= dalloc(s, &s->gh, M); s->g = s->gh; s->hc = s->gh ? s->gh + NE : nullptr;
     rc |= dalloc(s, &s->cone_product, NC); rc |= dalloc(s, &s->cone_target, NC); rc |= dalloc(s, &s->barrier_gradient, NC);
     rc |= dalloc(s, &s->dscal, 64);
     rc |= dalloc(s, &s->solution, N); rc |= dalloc(s, &s->candidate, N); rc |= dalloc(s, &s->lambda, NE); rc |= dalloc(s, &s->parameters, (size_t)d.np);
@@ -160,11 +160,11 @@ int32_t calipso_hip_destroy(H* s) {
     if (!s) return CALIPSO_OK;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    double* dp[] = {s->Lxx, s->Lsym, s->gx, s->hx, s->fx, s->gyx, s->hzx, s->g, s->hc, s->cone_product, s->cone_target, s->barrier_gradient, s->dscal,
+    double* dp[] = {s->Lxx, s->Lsym, s->Z, s->fx, s->gyx, s->hzx, s->gh, s->cone_product, s->cone_target, s->barrier_gradient, s->dscal,
                     s->solution, s->candidate, s->lambda, s->parameters, s->residual, s->residual_error, s->step, s->step_correction,
                     s->saved_point, s->saved_g, s->saved_h, s->residual_symmetric, s->step_symmetric, s->merit_gradient, s->Kdense, s->S,
                     s->Dx, s->Ypanel, s->Tinv, s->Ttmp, s->zf2, s->WH, s->wz, s->kzz, s->Wsoc, s->Bsoc, s->socwork, s->gemv_partial, s->vtmp, s->xbuf, s->zf,
-                    s->t1, s->t2, s->lgp, s->gp, s->hp, s->jacobian_parameters, s->solution_sensitivity, s->multi_rhs, s->qp.q, s->qp.b, s->qp.h};
+                    s->t1, s->t2, s->lgp, s->gp, s->hp, s->jacobian_parameters, s->solution_sensitivity, s->multi_rhs, s->qp.q, s->qp.bh};
     for (double* p : dp) if (p) (void)hipFree(p);
     int* ip[] = {s->icount, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
     for (int* p : ip) if (p) (void)hipFree(p);
@@ -179,21 +179,21 @@ int32_t calipso_hip_destroy(H* s) {
 }  // extern "C"
 
 // ---- field table --------------------------------------------------------------------------------------------------------
-struct Field { double* dev; double* host; int64_t len; };
+struct Field { double* dev; double* host; int64_t len; int64_t rows = 0, ld = 0; };   // rows/ld != 0: a column-major sub-block of a stacked matrix
 
 static bool find_field(H* s, const std::string& name, Field& f) {
     const Dims& d = s->d;
-    f.dev = nullptr; f.host = nullptr; f.len = 0;
+    f.dev = nullptr; f.host = nullptr; f.len = 0; f.rows = 0; f.ld = 0;
     auto D = [&](double* p, int64_t len) { f.dev = p; f.len = len; return true; };
     auto Hh = [&](double* p) { f.host = p; f.len = 1; return true; };
     if (name == "objective") return D(s->dscal + 0, 1);
     if (name == "barrier") return D(s->dscal + 1, 1);
     if (name == "objective_gradient_variables") return D(s->fx, d.nx);
     if (name == "equality_constraint") return D(s->g, d.ne);
-    if (name == "equality_jacobian_variables") return D(s->gx, (int64_t)d.ne * d.nx);
+    if (name == "equality_jacobian_variables") { f.rows = d.ne; f.ld = d.m; return D(s->gx, (int64_t)d.ne * d.nx); }
     if (name == "equality_dual_jacobian_variables") return D(s->gyx, d.nx);
     if (name == "cone_constraint") return D(s->hc, d.nc);
-    if (name == "cone_jacobian_variables") return D(s->hx, (int64_t)d.nc * d.nx);
+    if (name == "cone_jacobian_variables") { f.rows = d.nc; f.ld = d.m; return D(s->hx, (int64_t)d.nc * d.nx); }
     if (name == "cone_dual_jacobian_variables") return D(s->hzx, d.nx);
     if (name == "lagrangian_hessian") return D(s->Lxx, (int64_t)d.nx * d.nx);
     if (name == "cone_product") return D(s->cone_product, d.nc);
@@ -250,7 +250,10 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
     if (!f.dev) return fail_arg(s, std::string("field not allocated: ") + name);
     if (len == 0) return CALIPSO_OK;
     CK(hipSetDevice(s->device));
-    CK(hipMemcpyAsync(f.dev, data, sizeof(double) * len, hipMemcpyHostToDevice, s->stream));
+    if (f.ld)
+        CK(hipMemcpy2DAsync(f.dev, sizeof(double) * f.ld, data, sizeof(double) * f.rows, sizeof(double) * f.rows, len / f.rows, hipMemcpyHostToDevice, s->stream));
+    else
+        CK(hipMemcpyAsync(f.dev, data, sizeof(double) * len, hipMemcpyHostToDevice, s->stream));
     SYNC();
     if (std::string(name) == "parameters") s->hparams.assign(data, data + len);
     if (std::string(name) == "lagrangian_hessian") s->hessian_dirty = true;
@@ -267,7 +270,10 @@ int32_t calipso_hip_get_field(H* s, const char* name, double* data, int64_t len)
     if (!f.dev) return fail_arg(s, std::string("field not computed yet: ") + name);
     if (len == 0) return CALIPSO_OK;
     CK(hipSetDevice(s->device));
-    CK(hipMemcpyAsync(data, f.dev, sizeof(double) * len, hipMemcpyDeviceToHost, s->stream));
+    if (f.ld)
+        CK(hipMemcpy2DAsync(data, sizeof(double) * f.rows, f.dev, sizeof(double) * f.ld, sizeof(double) * f.rows, len / f.rows, hipMemcpyDeviceToHost, s->stream));
+    else
+        CK(hipMemcpyAsync(data, f.dev, sizeof(double) * len, hipMemcpyDeviceToHost, s->stream));
     SYNC();
     return CALIPSO_OK;
 }
@@ -369,12 +375,12 @@ static int do_inertia_correction(H* s, int64_t* nfact) {
     return CALIPSO_OK;
 }
 
-static void do_sds(H* s, int which) {
+static void do_sds(H* s, int which, double* accumulate = nullptr) {
     const double* res = which == 0 ? s->residual : s->residual_error;
     double* st = which == 0 ? s->step : s->step_correction;
-    launch_residual_symmetric(s, res);
-    linear_solve_device(s);
-    launch_recover(s, st, res);
+    launch_residual_symmetric(s, res);     // b, and the first operands of the condensed solve (xbuf, t1)
+    linear_solve_device(s);                // dx = S^-1(...) in xbuf, t2 = [gx; hx] dx
+    launch_recover(s, st, res, accumulate);   // dy, dz back-substitution + dr, ds, dt recovery (+ step += correction)
 }
 
 // iterative_refinement.jl:1-52
@@ -393,8 +399,7 @@ static int do_refinement(H* s, int* rounds, double* final_norm) {
             s->stats.last_refine = it; s->stats.refine_max = std::max<calipso::i64>(s->stats.refine_max, it);
             return CALIPSO_OK;
         }
-        do_sds(s, 1);
-        launch_add(s, s->step, s->step_correction, s->d.N);
+        do_sds(s, 1, s->step);             // step += step_correction fused into the recovery kernel
         launch_residual_error(s, s->step);
         if (read_scalars(s, 7, 1)) return CALIPSO_ERR_HIP;
         norm = s->hscal[7];
@@ -643,7 +648,13 @@ int32_t calipso_hip_jacobian_variables_mul(H* s, const double* v, double* out) {
 int32_t calipso_hip_factorize(H* s, int64_t inertia[3]) { if (!s || !inertia) return CALIPSO_ERR_ARGUMENT; return do_factorize(s, inertia); }
 int32_t calipso_hip_inertia_correction(H* s, int64_t* nf) { if (!s) return CALIPSO_ERR_ARGUMENT; return do_inertia_correction(s, nf); }
 int32_t calipso_hip_residual_symmetric(H* s, int32_t which) { if (!s) return CALIPSO_ERR_ARGUMENT; launch_residual_symmetric(s, which == 0 ? s->residual : s->residual_error); return CALIPSO_OK; }
-int32_t calipso_hip_linear_solve(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; linear_solve_device(s); return CALIPSO_OK; }
+int32_t calipso_hip_linear_solve(H* s) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    // b = "residual_symmetric" as currently held by the handle (set by calipso_hip_residual_symmetric or by the caller):
+    // rebuild the solve operands from it, solve, and back-substitute into "step_symmetric"
+    launch_solve_from_b(s);
+    return CALIPSO_OK;
+}
 int32_t calipso_hip_search_direction_symmetric(H* s, int32_t which) { if (!s) return CALIPSO_ERR_ARGUMENT; do_sds(s, which); return CALIPSO_OK; }
 int32_t calipso_hip_iterative_refinement(H* s, int32_t* rounds, double* final_norm) { if (!s) return CALIPSO_ERR_ARGUMENT; int r = 0; int rc = do_refinement(s, &r, final_norm); if (rounds) *rounds = r; return rc; }
 int32_t calipso_hip_search_direction(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; return do_search_direction(s, nullptr, nullptr); }
@@ -708,7 +719,7 @@ int32_t calipso_hip_differentiate(H* s, calipso_eval_fn eval, void* user) {
     double* save_res = s->residual_error; double* save_step = s->step_correction;
     for (int i = 0; i < d.np; ++i) {
         CK(hipMemcpyAsync(save_res, s->jacobian_parameters + (size_t)i * d.N, sizeof(double) * d.N, hipMemcpyDeviceToDevice, s->stream));
-        do_sds(s, 1);
+        do_sds(s, 1, nullptr);
         launch_negate_copy(s, save_step, s->solution_sensitivity + (size_t)i * d.N, d.N);
     }
     SYNC();
@@ -780,6 +791,14 @@ __global__ void k_scale_copy(const double* __restrict__ src, double* __restrict_
     if (i < n) dst[i] = a * src[i];
 }
 
+__global__ void k_qp_install(Dims d, const double* __restrict__ Gtmp, const double* __restrict__ b, const double* __restrict__ h,
+                             double* __restrict__ hx, double* __restrict__ bh) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)d.nc * d.nx) { const int c = (int)(i % d.nc); const size_t col = i / d.nc; hx[c + col * d.m] = -Gtmp[i]; }   // hx = -G into the stacked Jacobian
+    if (i < (size_t)d.ne) bh[i] = -b[i];
+    if (i < (size_t)d.nc) bh[d.ne + i] = h[i];
+}
+
 int32_t calipso_hip_qp_attach(H* s, const double* P, const double* q, const double* A, const double* b, const double* G, const double* h,
                               double objective_scale) {
     if (!s || !P || !q) return CALIPSO_ERR_ARGUMENT;
@@ -787,20 +806,21 @@ int32_t calipso_hip_qp_attach(H* s, const double* P, const double* q, const doub
     if ((d.ne && (!A || !b)) || (d.nc && (!G || !h))) return CALIPSO_ERR_ARGUMENT;
     CK(hipSetDevice(s->device));
     const size_t nx = d.nx;
-    if (!s->qp.q) { if (dalloc(s, &s->qp.q, nx) || dalloc(s, &s->qp.b, (size_t)d.ne) || dalloc(s, &s->qp.h, (size_t)d.nc)) return CALIPSO_ERR_HIP; }
-    // Lxx = 2c P ; gx = A ; hx = -G   (constant Hessian / Jacobians of the QP)
+    if (!s->qp.q) { if (dalloc(s, &s->qp.q, nx) || dalloc(s, &s->qp.bh, (size_t)d.m)) return CALIPSO_ERR_HIP; }
+    // Lxx = 2c P ; gx = A ; hx = -G   (constant Hessian / Jacobians of the QP); bh = [-b; h]
     CK(hipMemcpyAsync(s->S, P, sizeof(double) * nx * nx, hipMemcpyHostToDevice, s->stream));   // S is free before the first factorisation
     hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((nx * nx + 255) / 256)), dim3(256), 0, s->stream, s->S, s->Lxx, nx * nx, 2.0 * objective_scale);
     CK(hipMemcpyAsync(s->qp.q, q, sizeof(double) * nx, hipMemcpyHostToDevice, s->stream));
     if (d.ne) {
-        CK(hipMemcpyAsync(s->gx, A, sizeof(double) * d.ne * nx, hipMemcpyHostToDevice, s->stream));
-        CK(hipMemcpyAsync(s->qp.b, b, sizeof(double) * d.ne, hipMemcpyHostToDevice, s->stream));
+        CK(hipMemcpy2DAsync(s->gx, sizeof(double) * d.m, A, sizeof(double) * d.ne, sizeof(double) * d.ne, nx, hipMemcpyHostToDevice, s->stream));
+        CK(hipMemcpyAsync(s->t1, b, sizeof(double) * d.ne, hipMemcpyHostToDevice, s->stream));
     }
     if (d.nc) {
         CK(hipMemcpyAsync(s->WH, G, sizeof(double) * d.nc * nx, hipMemcpyHostToDevice, s->stream));
-        hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)(((size_t)d.nc * nx + 255) / 256)), dim3(256), 0, s->stream, s->WH, s->hx, (size_t)d.nc * nx, -1.0);
-        CK(hipMemcpyAsync(s->qp.h, h, sizeof(double) * d.nc, hipMemcpyHostToDevice, s->stream));
+        CK(hipMemcpyAsync(s->t2, h, sizeof(double) * d.nc, hipMemcpyHostToDevice, s->stream));
     }
+    const size_t work = std::max<size_t>((size_t)d.nc * nx, (size_t)d.m);
+    if (work) hipLaunchKernelGGL(k_qp_install, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s->stream, d, s->WH, s->t1, s->t2, s->hx, s->qp.bh);
     SYNC();
     s->hessian_dirty = true;
     s->qp.attached = true;

@@ -70,7 +70,7 @@ struct ConeDev {
 struct QpEval {
     bool attached = false;
     double scale = 0.5;
-    double *P = nullptr, *q = nullptr, *A = nullptr, *b = nullptr, *G = nullptr, *h = nullptr;   // device
+    double *q = nullptr, *bh = nullptr;   // device: q[nx], bh = [-b; h] (m)
 };
 
 struct Stats {
@@ -97,10 +97,15 @@ struct calipso_hip_solver {
     std::vector<int64_t> h_nonneg, h_soc_ptr, h_soc_idx;
     // ---- device buffers -------------------------------------------------------------------------------------------
     // ProblemData
-    double *Lxx = nullptr, *gx = nullptr, *hx = nullptr;                      // nx*nx, ne*nx, nc*nx
+    double* Lxx = nullptr;      // nx*nx
+    double* Z = nullptr;        // (ne+nc) x nx, ld = m: the equality Jacobian stacked on the cone Jacobian, so that every
+                                // mat-vec with [gx; hx] is ONE launch (y and z are adjacent in a Point, point.jl:13-22)
+    double *gx = nullptr, *hx = nullptr;   // = Z, Z + ne (leading dimension m)
     double* Lsym = nullptr;     // nx*nx: Lxx mirrored from its upper triangle (what triu(K) sees)
     bool hessian_dirty = true;
-    double *fx = nullptr, *gyx = nullptr, *hzx = nullptr, *g = nullptr, *hc = nullptr;   // nx, nx, nx, ne, nc
+    double *fx = nullptr, *gyx = nullptr, *hzx = nullptr;   // nx each
+    double* gh = nullptr;       // m: [equality_constraint; cone_constraint] contiguous
+    double *g = nullptr, *hc = nullptr;    // = gh, gh + ne
     double *cone_product = nullptr, *cone_target = nullptr, *barrier_gradient = nullptr;  // nc
     double* dscal = nullptr;   // device scalars: [0] objective [1] barrier  [2..] reduction outputs (see kernels)
     double* hscal = nullptr;   // pinned host mirror of dscal
@@ -152,8 +157,8 @@ void launch_cone_violation_host(calipso_hip_solver* s, const double* xhat_dev, c
 // vectors.hip
 void launch_residual(calipso_hip_solver* s);
 void launch_violations(calipso_hip_solver* s);                  // -> dscal[8..]
-void launch_residual_symmetric(calipso_hip_solver* s, const double* res);
-void launch_recover(calipso_hip_solver* s, double* step, const double* res);
+void launch_residual_symmetric(calipso_hip_solver* s, const double* res);   // also fills xbuf (b_x, zero padded) and t1 = Omega b_m
+void launch_recover(calipso_hip_solver* s, double* step, const double* res, double* accumulate);   // back-substitution + recovery (+ accumulate += step)
 void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s);
 void launch_accept(calipso_hip_solver* s, double step_size);
 void launch_merit(calipso_hip_solver* s, const double* point);  // -> dscal[4] (M), uses dscal[0], dscal[1]
@@ -175,14 +180,13 @@ void launch_schur(calipso_hip_solver* s);
 void launch_ldl(calipso_hip_solver* s);
 void launch_trsv(calipso_hip_solver* s, double* x);            // x (length NP) <- S^-1 x using L, D
 // solvek.hip
-void launch_omega_apply(calipso_hip_solver* s, const double* in_m, double* out_m, double sign);   // out = sign * Omega * in (length ne+nc)
 void launch_copy_pad(calipso_hip_solver* s, const double* src, int n, double* dst, int npad);
-void launch_sub(calipso_hip_solver* s, const double* a, const double* b, double* out, int n);     // out = a - b
 void launch_init_point(calipso_hip_solver* s);                 // initialize_slacks!/duals! (initialize.jl:15-36), r <- g
 void launch_lambda_update(calipso_hip_solver* s);              // lambda += rho * r (solve.jl:362-364)
 void launch_jacobian_parameters(calipso_hip_solver* s);        // residual_jacobian_parameters.jl:1-40
 void launch_negate_copy(calipso_hip_solver* s, const double* src, double* dst, int n);
-void linear_solve_device(calipso_hip_solver* s);               // step_symmetric = K^-1 residual_symmetric
+void linear_solve_device(calipso_hip_solver* s);               // middle of the condensed solve (operands from k_residual_symmetric)
+void launch_solve_from_b(calipso_hip_solver* s);               // step_symmetric = K^-1 residual_symmetric for a caller-provided b
 // qp.hip
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 

@@ -35,20 +35,23 @@ void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t fla
         if (flags & CALIPSO_EVAL_OBJECTIVE_GRADIENT)
             hipLaunchKernelGGL(k_vec_add, dim3((d.nx + 255) / 256), dim3(256), 0, s->stream, d.nx, Lx, s->qp.q, 1.0, s->fx);
     }
-    if ((flags & CALIPSO_EVAL_EQUALITY) && d.ne) {
-        gemv_n(s, d.ne, d.nx, s->gx, d.ne, x, s->g, 1.0, 0.0);
-        hipLaunchKernelGGL(k_vec_add, dim3((d.ne + 255) / 256), dim3(256), 0, s->stream, d.ne, s->g, s->qp.b, -1.0, s->g);
+    const bool want_g = (flags & CALIPSO_EVAL_EQUALITY) && d.ne, want_h = (flags & CALIPSO_EVAL_CONE) && d.nc;
+    if (want_g && want_h) {            // [g; h] = [gx; hx] x + [-b; hvec]  — one pass over the stacked Jacobian
+        gemv_n(s, d.m, d.nx, s->Z, d.m, x, s->gh, 1.0, 0.0);
+        hipLaunchKernelGGL(k_vec_add, dim3((d.m + 255) / 256), dim3(256), 0, s->stream, d.m, s->gh, s->qp.bh, 1.0, s->gh);
+    } else if (want_g) {
+        gemv_n(s, d.ne, d.nx, s->gx, d.m, x, s->g, 1.0, 0.0);
+        hipLaunchKernelGGL(k_vec_add, dim3((d.ne + 255) / 256), dim3(256), 0, s->stream, d.ne, s->g, s->qp.bh, 1.0, s->g);
+    } else if (want_h) {
+        gemv_n(s, d.nc, d.nx, s->hx, d.m, x, s->hc, 1.0, 0.0);
+        hipLaunchKernelGGL(k_vec_add, dim3((d.nc + 255) / 256), dim3(256), 0, s->stream, d.nc, s->hc, s->qp.bh + d.ne, 1.0, s->hc);
     }
     if (flags & CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT) {
-        if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.ne, y, s->gyx, 1.0, 0.0);
+        if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.m, y, s->gyx, 1.0, 0.0);
         else (void)hipMemsetAsync(s->gyx, 0, sizeof(double) * d.nx, s->stream);
     }
-    if ((flags & CALIPSO_EVAL_CONE) && d.nc) {
-        gemv_n(s, d.nc, d.nx, s->hx, d.nc, x, s->hc, 1.0, 0.0);
-        hipLaunchKernelGGL(k_vec_add, dim3((d.nc + 255) / 256), dim3(256), 0, s->stream, d.nc, s->hc, s->qp.h, 1.0, s->hc);
-    }
     if (flags & CALIPSO_EVAL_CONE_DUAL_GRADIENT) {
-        if (d.nc) gemv_t(s, d.nc, d.nx, s->hx, d.nc, z, s->hzx, 1.0, 0.0);
+        if (d.nc) gemv_t(s, d.nc, d.nx, s->hx, d.m, z, s->hzx, 1.0, 0.0);
         else (void)hipMemsetAsync(s->hzx, 0, sizeof(double) * d.nx, s->stream);
     }
     // Hessian / Jacobians are constant for a QP and were installed by calipso_hip_qp_attach

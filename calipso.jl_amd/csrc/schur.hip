@@ -101,7 +101,7 @@ __global__ void k_scale_rows(Dims d, ConeDev cd, const double* __restrict__ hx, 
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int col = blockIdx.y;
     if (c >= d.nc) return;
-    const double* h = hx + (size_t)col * d.nc;
+    const double* h = hx + (size_t)col * d.m;     // hx is the lower part of the stacked Jacobian (ld = m)
     double v;
     if (c < d.q) {
         v = wz[c] * h[c];
@@ -139,22 +139,22 @@ constexpr int SCHUR_THREADS = 1024;
 constexpr int SLD = TILE * KT / SCHUR_THREADS;   // doubles per thread per operand per stage
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-struct SchurStage { const double* MA; const double* MB; int kmax; int k0; double bscale; };
+struct SchurStage { const double* MA; const double* MB; int kmax; int k0; double bscale; int lda, ldb; };
 
 __device__ __forceinline__ SchurStage schur_stage(int st, int nst0, const Dims& d, const double* gx, const double* hx, const double* WH, double omega_y) {
     SchurStage g;
-    if (st < nst0) { g.MA = gx; g.MB = gx; g.kmax = d.ne; g.k0 = st * KT; g.bscale = omega_y; }
-    else { g.MA = hx; g.MB = WH; g.kmax = d.nc; g.k0 = (st - nst0) * KT; g.bscale = 1.0; }
+    if (st < nst0) { g.MA = gx; g.MB = gx; g.kmax = d.ne; g.k0 = st * KT; g.bscale = omega_y; g.lda = d.m; g.ldb = d.m; }
+    else { g.MA = hx; g.MB = WH; g.kmax = d.nc; g.k0 = (st - nst0) * KT; g.bscale = 1.0; g.lda = d.m; g.ldb = d.nc; }
     return g;
 }
 
 // global -> registers: KT x TILE block of M (rows k0.., columns c0..), lanes along k; out-of-range -> 0
-__device__ __forceinline__ void stage_fetch(double (&r)[SLD], const double* __restrict__ M, int kmax, int ncols, int k0, int c0, int tid, double scale) {
+__device__ __forceinline__ void stage_fetch(double (&r)[SLD], const double* __restrict__ M, int ldm, int kmax, int ncols, int k0, int c0, int tid, double scale) {
     const int k = tid % KT, cbase = tid / KT;
 #pragma unroll
     for (int it = 0; it < SLD; ++it) {
         const int gk = k0 + k, gc = c0 + cbase + it * (SCHUR_THREADS / KT);
-        r[it] = (gk < kmax && gc < ncols) ? scale * M[gk + (size_t)gc * kmax] : 0.0;
+        r[it] = (gk < kmax && gc < ncols) ? scale * M[gk + (size_t)gc * ldm] : 0.0;
     }
 }
 // registers -> LDS, k fastest: dst[c][k]
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(Dims d, Scalars sc, con
     double ra[SLD], rb[SLD];
     if (nst > 0) {
         const SchurStage g = schur_stage(0, nst0, d, gx, hx, WH, omega_y);
-        stage_fetch(ra, g.MA, g.kmax, d.nx, g.k0, i0, tid, 1.0);
-        stage_fetch(rb, g.MB, g.kmax, d.nx, g.k0, j0, tid, g.bscale);
+        stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, tid, 1.0);
+        stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, tid, g.bscale);
     }
 #pragma unroll 1
     for (int st = 0; st < nst; ++st) {
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(Dims d, Scalars sc, con
         __syncthreads();
         if (st + 1 < nst) {   // prefetch the next stage while the matrix cores work on this one
             const SchurStage g = schur_stage(st + 1, nst0, d, gx, hx, WH, omega_y);
-            stage_fetch(ra, g.MA, g.kmax, d.nx, g.k0, i0, tid, 1.0);
-            stage_fetch(rb, g.MB, g.kmax, d.nx, g.k0, j0, tid, g.bscale);
+            stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, tid, 1.0);
+            stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, tid, g.bscale);
         }
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {

@@ -1,39 +1,12 @@
 // solvek.hip — the condensed solve  K [dx; dy; dz] = b  with the factors of schur.hip / ldl.hip (the counterpart of
 // linear_solve!/QDLDL_solve!, linear_solver.jl:52-60, qdldl.jl:330-351,592-640, in the order [z | y | x]):
 //     dx = S^-1 ( b_x + gx'(omega_y b_y) + hx'(Omega_z b_z) )          forward/backward substitution with L, D of S
-//     [dy; dz] = -Omega ( b_m - [gx; hx] dx )                           back-substitution through the constraint pivots
+//     [dy; dz] = -Omega ( b_m - [gx; hx] dx )                           back-substitution (fused into k_recover, vectors.hip)
 // plus a few O(N) helpers of the solve! driver.
 #include "internal.hpp"
 #include "device_utils.hpp"
 
 namespace calipso {
-
-__global__ void k_omega_apply(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ in, const double* __restrict__ wz,
-                              const double* __restrict__ Wsoc, double* __restrict__ out, double sign) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.m) return;
-    if (i < d.ne) {
-        const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
-        out[i] = sign * omega_y * in[i];
-    } else {
-        const int c = i - d.ne;
-        const double* z = in + d.ne;
-        if (c < d.q) {
-            out[i] = sign * wz[c] * z[c];
-        } else {
-            const int j = cd.entry_soc[c];
-            const int st = cd.soc_start[j], dim = cd.soc_dim[j];
-            const double* W = Wsoc + cd.soc_woff[j];
-            double v = 0.0;
-            for (int b = 0; b < dim; ++b) v += W[(c - st) + b * dim] * z[st + b];
-            out[i] = sign * v;
-        }
-    }
-}
-void launch_omega_apply(calipso_hip_solver* s, const double* in_m, double* out_m, double sign) {
-    if (s->d.m == 0) return;
-    hipLaunchKernelGGL(k_omega_apply, dim3((s->d.m + 255) / 256), dim3(256), 0, s->stream, s->d, s->sc, s->cone, in_m, s->wz, s->Wsoc, out_m, sign);
-}
 
 __global__ void k_copy_pad(const double* __restrict__ src, int n, double* __restrict__ dst, int npad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,15 +14,6 @@ __global__ void k_copy_pad(const double* __restrict__ src, int n, double* __rest
 }
 void launch_copy_pad(calipso_hip_solver* s, const double* src, int n, double* dst, int npad) {
     hipLaunchKernelGGL(k_copy_pad, dim3((npad + 255) / 256), dim3(256), 0, s->stream, src, n, dst, npad);
-}
-
-__global__ void k_sub(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] - b[i];
-}
-void launch_sub(calipso_hip_solver* s, const double* a, const double* b, double* out, int n) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_sub, dim3((n + 255) / 256), dim3(256), 0, s->stream, a, b, out, n);
 }
 
 __global__ void k_negate_copy(const double* __restrict__ src, double* __restrict__ dst, int n) {
@@ -60,20 +24,68 @@ void launch_negate_copy(calipso_hip_solver* s, const double* src, double* dst, i
     hipLaunchKernelGGL(k_negate_copy, dim3((n + 255) / 256), dim3(256), 0, s->stream, src, dst, n);
 }
 
+// operands prepared by k_residual_symmetric: xbuf = [b_x; 0], t1 = Omega b_m.  Leaves dx in xbuf and t2 = [gx; hx] dx; the
+// back-substitution [dy; dz] = -Omega (b_m - t2) is fused into k_recover.
 void linear_solve_device(calipso_hip_solver* s) {
     const Dims& d = s->d;
-    const double* b = s->residual_symmetric;
-    double* out = s->step_symmetric;
-    launch_omega_apply(s, b + d.nx, s->t1, 1.0);                                   // t1 = Omega b_m
-    launch_copy_pad(s, b, d.nx, s->xbuf, d.NP);
-    if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.ne, s->t1, s->xbuf, 1.0, 1.0);
-    if (d.nc) gemv_t(s, d.nc, d.nx, s->hx, d.nc, s->t1 + d.ne, s->xbuf, 1.0, 1.0);
+    if (d.m) gemv_t(s, d.m, d.nx, s->Z, d.m, s->t1, s->xbuf, 1.0, 1.0);           // b_x + gx'(omega_y b_y) + hx'(Omega_z b_z)
     launch_trsv(s, s->xbuf);                                                       // xbuf = S^-1 xbuf
-    if (d.ne) gemv_n(s, d.ne, d.nx, s->gx, d.ne, s->xbuf, s->t2, 1.0, 0.0);
-    if (d.nc) gemv_n(s, d.nc, d.nx, s->hx, d.nc, s->xbuf, s->t2 + d.ne, 1.0, 0.0);
-    launch_sub(s, b + d.nx, s->t2, s->t2, d.m);                                    // t2 = b_m - Z dx
-    launch_omega_apply(s, s->t2, out + d.nx, -1.0);                                // [dy; dz] = -Omega t2
-    launch_copy_pad(s, s->xbuf, d.nx, out, d.nx);
+    if (d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->xbuf, s->t2, 1.0, 0.0);            // t2 = [gx; hx] dx
+}
+
+// stand-alone linear_solve! on a caller-provided right-hand side b (= "residual_symmetric"): operands, solve, back-substitution
+__global__ void k_solve_prepare(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ b, const double* __restrict__ wz,
+                                const double* __restrict__ Wsoc, double* __restrict__ xbuf, double* __restrict__ t1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.NP) { xbuf[i] = i < d.nx ? b[i] : 0.0; return; }
+    const int e = i - d.NP;
+    if (e >= d.m) return;
+    const double* bm = b + d.nx;
+    if (e < d.ne) {
+        const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+        t1[e] = omega_y * bm[e];
+    } else {
+        const int c = e - d.ne;
+        if (c < d.q) t1[e] = wz[c] * bm[e];
+        else {
+            const int j = cd.entry_soc[c], st = cd.soc_start[j], dim = cd.soc_dim[j];
+            const double* W = Wsoc + cd.soc_woff[j];
+            double v = 0.0;
+            for (int q = 0; q < dim; ++q) v += W[(c - st) + q * dim] * bm[d.ne + st + q];
+            t1[e] = v;
+        }
+    }
+}
+__global__ void k_solve_finish(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ b, const double* __restrict__ dx,
+                               const double* __restrict__ t2, const double* __restrict__ wz, const double* __restrict__ Wsoc,
+                               double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    if (i < d.nx) { out[i] = dx[i]; return; }
+    const int e = i - d.nx;
+    const double* bm = b + d.nx;
+    if (e < d.ne) {
+        const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+        out[i] = -1.0 * omega_y * (bm[e] - t2[e]);
+    } else {
+        const int c = e - d.ne;
+        if (c < d.q) out[i] = -1.0 * wz[c] * (bm[e] - t2[e]);
+        else {
+            const int j = cd.entry_soc[c], st = cd.soc_start[j], dim = cd.soc_dim[j];
+            const double* W = Wsoc + cd.soc_woff[j];
+            double v = 0.0;
+            for (int q = 0; q < dim; ++q) v += W[(c - st) + q * dim] * (bm[d.ne + st + q] - t2[d.ne + st + q]);
+            out[i] = -1.0 * v;
+        }
+    }
+}
+void launch_solve_from_b(calipso_hip_solver* s) {
+    const Dims& d = s->d;
+    hipLaunchKernelGGL(k_solve_prepare, dim3((d.NP + d.m + 255) / 256), dim3(256), 0, s->stream, d, s->sc, s->cone, s->residual_symmetric, s->wz,
+                       s->Wsoc, s->xbuf, s->t1);
+    linear_solve_device(s);
+    hipLaunchKernelGGL(k_solve_finish, dim3((d.n + 255) / 256), dim3(256), 0, s->stream, d, s->sc, s->cone, s->residual_symmetric, s->xbuf, s->t2,
+                       s->wz, s->Wsoc, s->step_symmetric);
 }
 
 // initialize_slacks! / initialize_duals!  initialize.jl:15-36: r = g(x0); nonnegative slacks/duals = 1;

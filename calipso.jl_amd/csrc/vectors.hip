@@ -87,28 +87,37 @@ void launch_violations(calipso_hip_solver* s) {
                        s->g, s->cone_product, s->dscal);
 }
 
-// residual_symmetric!   residual.jl:53-101 (condensed right-hand side b)
+// residual_symmetric!   residual.jl:53-101 (condensed right-hand side b).  The same kernel also emits the first operands of
+// the condensed solve: xbuf = [b_x; 0 padding] and t1 = Omega b_m (omega_y b_y ; Omega_z b_z), see solvek.hip.
 __global__ void k_residual_symmetric(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res,
-                                     double* __restrict__ rsym) {
+                                     const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ rsym,
+                                     double* __restrict__ xbuf, double* __restrict__ t1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const double Hrr = sc.rho + sc.ep;   // H[r,r] = rho then += eps_p  (residual_jacobian_variables.jl:60,87)
     const double Hss = 0.0 + sc.ep;      // H[s,s]
-    if (i < d.nx) {
-        rsym[i] = res[i];
-    } else if (i < d.nx + d.ne) {
-        const int k = i - d.nx;
-        double v = res[d.oy() + k];
-        v += res[d.orr() + k] / Hrr;
-        rsym[i] = v;
-    } else if (i < d.nx + d.ne + d.q) {
-        const int k = i - d.nx - d.ne;
+    if (i < d.NP) {
+        const double v = i < d.nx ? res[i] : 0.0;
+        if (i < d.nx) rsym[i] = v;
+        xbuf[i] = v;
+        return;
+    }
+    const int e = i - d.NP;              // index into the constraint part
+    if (e < d.ne) {
+        double v = res[d.oy() + e];
+        v += res[d.orr() + e] / Hrr;
+        rsym[d.nx + e] = v;
+        const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+        t1[e] = omega_y * v;
+    } else if (e < d.ne + d.q) {
+        const int k = e - d.ne;
         const double Sb = w[d.os() + k] - sc.ed, Ti = w[d.ot() + k], Pi = Hss;
         double v = res[d.oz() + k];
         v += (res[d.ot() + k] + Sb * res[d.os() + k]) / (Ti + Sb * Pi);
-        rsym[i] = v;
-    } else if (i < d.nx + d.ne + d.q + d.n_soc) {
+        rsym[d.nx + d.ne + k] = v;
+        t1[d.ne + k] = wz[k] * v;
+    } else if (e < d.ne + d.q + d.n_soc) {
         // one lane per second-order cone:  b_z[soc] = r_z + U^-1 (Cbar_t r_s + r_t),  U = Cs + Cbar_t P
-        const int j = i - d.nx - d.ne - d.q;
+        const int j = e - d.ne - d.q;
         const int st = cd.soc_start[j], dim = cd.soc_dim[j];
         double u[MAX_SOC_DIM], v[MAX_SOC_DIM], o[MAX_SOC_DIM];
         const double* sl = w + d.os() + st; const double* t = w + d.ot() + st;
@@ -121,45 +130,69 @@ __global__ void k_residual_symmetric(Dims d, Scalars sc, ConeDev cd, const doubl
         v[0] = acc + rt[0];
         for (int k = 1; k < dim; ++k) v[k] = (sl[k] * rs[0] + sb1 * rs[k]) + rt[k];
         arrow_inverse(dim, u, v, o);
-        for (int k = 0; k < dim; ++k) rsym[d.nx + d.ne + st + k] = res[d.oz() + st + k] + o[k];
+        for (int k = 0; k < dim; ++k) { o[k] = res[d.oz() + st + k] + o[k]; rsym[d.nx + d.ne + st + k] = o[k]; }
+        const double* W = Wsoc + cd.soc_woff[j];
+        for (int a = 0; a < dim; ++a) {
+            double s = 0.0;
+            for (int b = 0; b < dim; ++b) s += W[a + b * dim] * o[b];
+            t1[d.ne + st + a] = s;
+        }
     }
 }
 
 void launch_residual_symmetric(calipso_hip_solver* s, const double* res) {
-    const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
+    const int work = s->d.NP + s->d.ne + s->d.q + s->d.n_soc;
     hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
-                       s->residual_symmetric);
+                       s->wz, s->Wsoc, s->residual_symmetric, s->xbuf, s->t1);
 }
 
-// search_direction_symmetric!  search_direction.jl:38-101: scatter (dx,dy,dz) and recover dr, ds, dt
+// Tail of the condensed solve + search_direction_symmetric! (search_direction.jl:38-101) in one kernel:
+//   [dy; dz] = -Omega (b_m - [gx; hx] dx)      (back-substitution through the constraint pivots; t2 = [gx; hx] dx)
+//   scatter (dx, dy, dz); recover dr, ds, dt (diagonal for nonnegative entries, arrow inverses for second-order cones)
+//   optionally accumulate += step  (iterative_refinement.jl:34: step .+= step_correction)
 __global__ void k_recover(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res,
-                          const double* __restrict__ dsym, double* __restrict__ step) {
+                          const double* __restrict__ b, const double* __restrict__ dx, const double* __restrict__ t2,
+                          const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ dsym,
+                          double* __restrict__ step, double* __restrict__ accum) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const double Hrr = sc.rho + sc.ep, Hss = 0.0 + sc.ep;
     if (i < d.nx) {
-        step[i] = dsym[i];
+        const double v = dx[i];
+        dsym[i] = v; step[i] = v;
+        if (accum) accum[i] += v;
     } else if (i < d.nx + d.ne) {
         const int k = i - d.nx;
-        const double dy = dsym[d.nx + k];
+        const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+        const double dy = -1.0 * omega_y * (b[d.nx + k] - t2[k]);
+        dsym[d.nx + k] = dy;
+        const double dr = (res[d.orr() + k] + dy) / Hrr;
         step[d.oy() + k] = dy;
-        step[d.orr() + k] = (res[d.orr() + k] + dy) / Hrr;
+        step[d.orr() + k] = dr;
+        if (accum) { accum[d.oy() + k] += dy; accum[d.orr() + k] += dr; }
     } else if (i < d.nx + d.ne + d.q) {
         const int k = i - d.nx - d.ne;
-        const double dz = dsym[d.nx + d.ne + k];
-        step[d.oz() + k] = dz;
+        const double dz = -1.0 * wz[k] * (b[d.nx + d.ne + k] - t2[d.ne + k]);
+        dsym[d.nx + d.ne + k] = dz;
         const double Sb = w[d.os() + k] - sc.ed, Ti = w[d.ot() + k], Pi = Hss;
         const double rt = res[d.ot() + k], rs = res[d.os() + k];
         const double ds = (rt + Sb * (rs + dz)) / (Ti + Sb * Pi);
-        step[d.os() + k] = ds;
-        step[d.ot() + k] = (rt - Ti * ds) / Sb;
+        const double dt = (rt - Ti * ds) / Sb;
+        step[d.oz() + k] = dz; step[d.os() + k] = ds; step[d.ot() + k] = dt;
+        if (accum) { accum[d.oz() + k] += dz; accum[d.os() + k] += ds; accum[d.ot() + k] += dt; }
     } else if (i < d.nx + d.ne + d.q + d.n_soc) {
         const int j = i - d.nx - d.ne - d.q;
         const int st = cd.soc_start[j], dim = cd.soc_dim[j];
-        double u[MAX_SOC_DIM], v[MAX_SOC_DIM], ds[MAX_SOC_DIM], o[MAX_SOC_DIM];
+        double u[MAX_SOC_DIM], v[MAX_SOC_DIM], ds[MAX_SOC_DIM], o[MAX_SOC_DIM], dz[MAX_SOC_DIM];
         const double* sl = w + d.os() + st; const double* t = w + d.ot() + st;
         const double* rs = res + d.os() + st; const double* rt = res + d.ot() + st;
-        const double* dz = dsym + d.nx + d.ne + st;
-        for (int k = 0; k < dim; ++k) step[d.oz() + st + k] = dz[k];
+        const double* W = Wsoc + cd.soc_woff[j];
+        for (int a = 0; a < dim; ++a) o[a] = b[d.nx + d.ne + st + a] - t2[d.ne + st + a];
+        for (int a = 0; a < dim; ++a) {
+            double s = 0.0;
+            for (int c = 0; c < dim; ++c) s += W[a + c * dim] * o[c];
+            dz[a] = -1.0 * s;
+            dsym[d.nx + d.ne + st + a] = dz[a];
+        }
         const double sb1 = sl[0] - sc.ed;
         u[0] = t[0] + sb1 * Hss;
         for (int k = 1; k < dim; ++k) u[k] = t[k] + sl[k] * Hss;
@@ -169,7 +202,6 @@ __global__ void k_recover(Dims d, Scalars sc, ConeDev cd, const double* __restri
         v[0] = rt[0] + acc;
         for (int k = 1; k < dim; ++k) v[k] = rt[k] + (sl[k] * (rs[0] + dz[0]) + sb1 * (rs[k] + dz[k]));
         arrow_inverse(dim, u, v, ds);
-        for (int k = 0; k < dim; ++k) step[d.os() + st + k] = ds[k];
         // dt = Cbar_t^-1 (r_t - Cs ds),  Cs = arrow(t)
         acc = t[0] * ds[0];
         for (int k = 1; k < dim; ++k) acc += t[k] * ds[k];
@@ -178,14 +210,17 @@ __global__ void k_recover(Dims d, Scalars sc, ConeDev cd, const double* __restri
         u[0] = sb1;
         for (int k = 1; k < dim; ++k) u[k] = sl[k];
         arrow_inverse(dim, u, v, o);
-        for (int k = 0; k < dim; ++k) step[d.ot() + st + k] = o[k];
+        for (int k = 0; k < dim; ++k) {
+            step[d.oz() + st + k] = dz[k]; step[d.os() + st + k] = ds[k]; step[d.ot() + st + k] = o[k];
+            if (accum) { accum[d.oz() + st + k] += dz[k]; accum[d.os() + st + k] += ds[k]; accum[d.ot() + st + k] += o[k]; }
+        }
     }
 }
 
-void launch_recover(calipso_hip_solver* s, double* step, const double* res) {
+void launch_recover(calipso_hip_solver* s, double* step, const double* res, double* accumulate) {
     const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
     hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
-                       s->step_symmetric, step);
+                       s->residual_symmetric, s->xbuf, s->t2, s->wz, s->Wsoc, s->step_symmetric, step, accumulate);
 }
 
 // candidate x, r (, s) = solution - step_size * step    solve.jl:224-229, 268-276
@@ -322,31 +357,59 @@ __global__ void k_Hmul_vec(Dims d, Scalars sc, ConeDev cd, const double* __restr
     }
 }
 
-void launch_Hmul(calipso_hip_solver* s, const double* v, double* out) {
+static void hmul_matvecs(calipso_hip_solver* s, const double* v, double* out) {
     const Dims& d = s->d;
     gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, v, out, 1.0, 0.0);
-    if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.ne, v + d.oy(), out, 1.0, 1.0);
-    if (d.nc) gemv_t(s, d.nc, d.nx, s->hx, d.nc, v + d.oz(), out, 1.0, 1.0);
-    if (d.ne) gemv_n(s, d.ne, d.nx, s->gx, d.ne, v, out + d.oy(), 1.0, 0.0);
-    if (d.nc) gemv_n(s, d.nc, d.nx, s->hx, d.nc, v, out + d.oz(), 1.0, 0.0);
-    hipLaunchKernelGGL(k_Hmul_vec, dim3((d.N + 255) / 256), dim3(256), 0, s->stream, d, s->sc, s->cone, s->solution, v, out);
+    if (d.m) gemv_t(s, d.m, d.nx, s->Z, d.m, v + d.oy(), out, 1.0, 1.0);        // + gx'v_y + hx'v_z : y and z are adjacent in a Point
+    if (d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, v, out + d.oy(), 1.0, 0.0);        // [gx; hx] v_x
 }
 
-// residual_error = residual - H*step ; dscal[7] = ||residual_error||_inf   (iterative_refinement.jl:8-12,38-41)
-__global__ __launch_bounds__(RT) void k_sub_norm(int N, const double* __restrict__ res, double* __restrict__ e, double* __restrict__ out) {
+void launch_Hmul(calipso_hip_solver* s, const double* v, double* out) {
+    hmul_matvecs(s, v, out);
+    hipLaunchKernelGGL(k_Hmul_vec, dim3((s->d.N + 255) / 256), dim3(256), 0, s->stream, s->d, s->sc, s->cone, s->solution, v, out);
+}
+
+// residual_error = residual - H*step ; dscal[7] = ||residual_error||_inf   (iterative_refinement.jl:8-12,38-41).
+// One workgroup: the vector part of H*step, the subtraction and the norm in a single pass over the N entries.
+__global__ __launch_bounds__(RT) void k_Hmul_err(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
+                                                  const double* __restrict__ res, double* __restrict__ e, double* __restrict__ out) {
     __shared__ double sm[RT / 64];
+    const double* sl = w + d.os(); const double* t = w + d.ot();
+    const double* vs = v + d.os(); const double* vt = v + d.ot();
     double m = 0.0;
-    for (int i = threadIdx.x; i < N; i += RT) {
-        const double v = res[i] - e[i];
-        e[i] = v;
-        m = fmax(m, fabs(v));
+    for (int i = threadIdx.x; i < d.N; i += RT) {
+        double hv;
+        if (i < d.nx) hv = e[i] + sc.ep * v[i];
+        else if (i < d.os()) hv = (sc.rho + sc.ep) * v[i] - v[d.oy() + i - d.orr()];
+        else if (i < d.oy()) { const int k = i - d.os(); hv = (0.0 + sc.ep) * v[i] - v[d.oz() + k] - v[d.ot() + k]; }
+        else if (i < d.oz()) hv = e[i] + (-v[d.orr() + i - d.oy()] + (0.0 - sc.ed) * v[i]);
+        else if (i < d.ot()) hv = e[i] + (-v[d.os() + i - d.oz()] + (0.0 - sc.ed) * v[i]);
+        else {
+            const int k = i - d.ot();
+            const int j = cd.entry_soc[k];
+            if (j < 0) hv = t[k] * vs[k] + (sl[k] - sc.ed) * vt[k];
+            else {
+                const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+                if (k == st) {
+                    hv = t[st] * vs[st] + (sl[st] - sc.ed) * vt[st];
+                    for (int q = 1; q < dim; ++q) hv += t[st + q] * vs[st + q] + sl[st + q] * vt[st + q];
+                } else {
+                    hv = t[k] * vs[st] + sl[k] * vt[st];
+                    hv += t[st] * vs[k] + (sl[st] - sc.ed) * vt[k];
+                }
+            }
+        }
+        const double r = res[i] - hv;
+        e[i] = r;
+        m = fmax(m, fabs(r));
     }
     const double r = block_max(m, sm);
     if (threadIdx.x == 0) *out = r;
 }
+
 void launch_residual_error(calipso_hip_solver* s, const double* step) {
-    launch_Hmul(s, step, s->residual_error);
-    hipLaunchKernelGGL(k_sub_norm, dim3(1), dim3(RT), 0, s->stream, s->d.N, s->residual, s->residual_error, s->dscal + 7);
+    hmul_matvecs(s, step, s->residual_error);
+    hipLaunchKernelGGL(k_Hmul_err, dim3(1), dim3(RT), 0, s->stream, s->d, s->sc, s->cone, s->solution, step, s->residual, s->residual_error, s->dscal + 7);
 }
 
 __global__ void k_add(int n, double* __restrict__ y, const double* __restrict__ x) {
@@ -373,7 +436,7 @@ __global__ void k_assemble_K(Dims d, Scalars sc, ConeDev cd, const double* __res
     } else if (i < nx || j < nx) {
         const int c = i < nx ? j : i;      // constraint index
         const int xk = i < nx ? i : j;     // variable index
-        v = (c < nx + ne) ? gx[(c - nx) + (size_t)xk * ne] : hx[(c - nx - ne) + (size_t)xk * d.nc];
+        v = (c < nx + ne) ? gx[(c - nx) + (size_t)xk * d.m] : hx[(c - nx - ne) + (size_t)xk * d.m];   // stacked Jacobian, ld = m
     } else if (i < nx + ne || j < nx + ne) {
         if (i == j) v = -1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed);
     } else {
