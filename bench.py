@@ -91,6 +91,8 @@ def main():
                     "stream-priority classes, which the runtime maps to distinct hardware queues)")
     ap.add_argument("--config", default="C3", choices=list(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets two ranks share one GPU")
+    ap.add_argument("--force-device", type=int, default=-1, help="testing only: every rank uses this device ordinal")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,12 +100,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    if args.force_device >= 0:
+        local_rank = args.force_device
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))    # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -146,7 +151,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # post-round exchange (outside the data path): per-problem status rows all-gathered, step counters all-reduced

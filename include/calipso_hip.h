@@ -177,7 +177,8 @@ int32_t calipso_hip_initialize(calipso_hip_solver*, const double* guess);
 /* solve!(solver)  solve.jl:8-377: returns 1 (true), 0 (false) or a negative status.  eval may be NULL when a device
  * evaluator is attached (calipso_hip_qp_attach). */
 int32_t calipso_hip_solve(calipso_hip_solver*, calipso_eval_fn eval, void* user);
-/* differentiate!(solver)  differentiate.jl:1-61: all np right-hand sides in one blocked solve */
+/* differentiate!(solver)  differentiate.jl:1-61: dR/dtheta assembled on the device, one factorisation, then one condensed
+ * solve + recovery per parameter column (as differentiate.jl:29-58, without its per-column re-factorisation) */
 int32_t calipso_hip_differentiate(calipso_hip_solver*, calipso_eval_fn eval, void* user);
 /* install the per-inner-iteration / per-outer-update callbacks (NULL disables; options.callback_inner/outer) */
 int32_t calipso_hip_set_callbacks(calipso_hip_solver*, calipso_callback_fn inner, calipso_callback_fn outer, void* user);

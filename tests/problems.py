@@ -384,3 +384,79 @@ def synthetic_conic_qp(uniform, problem_id, nx, ne, n_nn, n_soc, soc_dim):
     pt["s"], pt["t"] = s, t
     lam = U("lam", -1, 1, ne)
     return prob, pt, lam
+
+
+def cartpole_mpc(horizon=10, h=0.05, perturb=0.05):
+    """BASELINE config C5 shape: cart-pole MPC of examples/autotuning/cartpole.jl:85-146 (model examples/autotuning/models/cartpole.jl:2-33):
+    H = 10 stages, 4 states, 1 action => nx = 49, ne = 40 (36 explicit-midpoint dynamics + x_1 - x_init), nc = 0, p = 102 parameters
+    theta_t = [xbar(4); ubar(1); w_Q(4); w_R(1); x_init(4) if t = 1], theta_T = [xbar(4); w_Q(4)].
+    The tracking reference is synthetic (the reference's comes from a prior swing-up solve)."""
+    import sympy as sp
+    ns, na = 4, 1
+    T = horizon
+    nz = ns * T + na * (T - 1)
+    mc, mp_, l, g = 1.0, 0.2, 0.5, 9.81
+
+    def fcont(x, u):
+        s_, c_ = sp.sin(x[1]), sp.cos(x[1])
+        H11, H12, H22 = mc + mp_, mp_ * l * c_, mp_ * l ** 2
+        det = H11 * H22 - H12 * H12
+        Cqd0 = -mp_ * x[3] * l * s_ * x[3]
+        r0 = Cqd0 + 0 - u[0]
+        r1 = 0 + mp_ * g * l * s_ - 0
+        qdd0 = -(H22 * r0 - H12 * r1) / det
+        qdd1 = -(-H12 * r0 + H11 * r1) / det
+        return [x[2], x[3], qdd0, qdd1]
+
+    def fdisc(x, u):
+        k1 = fcont(x, u)
+        xm = [x[i] + 0.5 * h * k1[i] for i in range(4)]
+        k2 = fcont(xm, u)
+        return [x[i] + h * k2[i] for i in range(4)]
+
+    xs = lambda z, t: z[t * (ns + na): t * (ns + na) + ns]
+    us = lambda z, t: z[t * (ns + na) + ns: t * (ns + na) + ns + na]
+    # parameter offsets
+    offs = [0]
+    for t in range(T - 1):
+        offs.append(offs[-1] + (14 if t == 0 else 10))
+    npar = offs[-1] + 8
+
+    def objective(z, th):
+        J = 0
+        for t in range(T - 1):
+            w = th[offs[t]:]
+            X, U = xs(z, t), us(z, t)
+            J += sum(0.5 * w[5 + i] ** 2 * (X[i] - w[i]) ** 2 for i in range(4)) + 0.5 * w[9] ** 2 * (U[0] - w[4]) ** 2
+        w = th[offs[T - 1]:]
+        XT = xs(z, T - 1)
+        return J + sum(0.5 * w[4 + i] ** 2 * (XT[i] - w[i]) ** 2 for i in range(4))
+
+    def equality(z, th):
+        e = []
+        for t in range(T - 1):
+            X, U, Y = xs(z, t), us(z, t), xs(z, t + 1)
+            fd = fdisc(X, U)
+            e += [Y[i] - fd[i] for i in range(4)]
+        X1 = xs(z, 0)
+        e += [X1[i] - th[10 + i] for i in range(4)]
+        return e
+
+    theta = np.zeros(npar)
+    x0 = np.zeros(nz)
+    for t in range(T):
+        xbar = np.array([0.0, np.pi * t / (T - 1), 0.0, 0.0])
+        if t < T - 1:
+            theta[offs[t]:offs[t] + 4] = xbar
+            theta[offs[t] + 4] = 0.0
+            theta[offs[t] + 5:offs[t] + 9] = 1.0
+            theta[offs[t] + 9] = 1.0
+            if t == 0:
+                theta[10:14] = xbar + perturb * np.array([1.0, -1.0, 0.5, 0.25])
+        else:
+            theta[offs[t]:offs[t] + 4] = xbar
+            theta[offs[t] + 4:offs[t] + 8] = 1.0
+        x0[t * (ns + na): t * (ns + na) + ns] = xbar
+    prob = SymbolicProblem(nz, objective, equality, None, np_=npar, parameters=theta, x0=x0, name="cartpole_mpc")
+    prob.horizon = T
+    return prob
