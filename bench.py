@@ -137,8 +137,10 @@ def main():
     barrier()
     ts = time.perf_counter()
     n_single = max(3, min(10, args.steps))
+    sch_alone = []
     for _ in range(n_single):
         solvers[0].newton_step(advance=False)
+        sch_alone.append(solvers[0].phase_times()[7])
     solvers[0].synchronize()
     single_rate = n_single / (time.perf_counter() - ts)
     barrier()
@@ -165,7 +167,10 @@ def main():
     value = world * B * args.steps / elapsed
     # dominant kernel: the Schur-complement update S = Lxx + ep*I + Z' Omega Z on the fp64 matrix cores (k_schur).
     # algorithmic flops per launch = multiply-adds of the lower triangle incl. diagonal: nx (nx+1) m
-    sch_ms = float(np.mean(sch))
+    # its launch duration is taken from HIP events on the handle's stream while ONE instance is in flight (the kernel has the
+    # device to itself; with several instances in flight concurrent launches share the CUs and a per-launch time is ill-defined)
+    sch_ms = float(np.mean(sch_alone))
+    sch_ms_concurrent = float(np.mean(sch))
     flops = float(nx) * (nx + 1) * m
     achieved = flops / (sch_ms * 1e-3) * 1e-12
     traffic = None
@@ -188,7 +193,8 @@ def main():
                                 "ldl_of_schur_complement": float(np.mean(ldl))}},
         "roofline": {"kernel": "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": sch_ms},
+                     "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": sch_ms,
+                     "avg_launch_ms_with_%d_instances_in_flight" % B: sch_ms_concurrent},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(shape)
