@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.hpp"
@@ -137,6 +138,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     for (int j = 0; j < d.n_soc; ++j)
         for (int k = 0; k < s->h_soc_dim[j]; ++k) es[s->h_soc_start[j] + k] = j;
     if (d.nc) CK(hipMemcpy(s->cone.entry_soc, es.data(), sizeof(int) * d.nc, hipMemcpyHostToDevice));
+    if (const char* g = getenv("CALIPSO_HIP_GRAPHS")) s->use_graphs = atoi(g) != 0;
     s->hpoint.assign(N, 0.0);
     s->hparams.assign((size_t)d.np, 0.0);
     Options& o = s->opt;
@@ -171,6 +173,8 @@ int32_t calipso_hip_destroy(H* s) {
     if (s->hscal) (void)hipHostFree(s->hscal);
     if (s->hicount) (void)hipHostFree(s->hicount);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->graph_ldl) (void)hipGraphExecDestroy(s->graph_ldl);
+    if (s->graph_trsv) (void)hipGraphExecDestroy(s->graph_trsv);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return CALIPSO_OK;

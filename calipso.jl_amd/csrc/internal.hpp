@@ -138,6 +138,8 @@ struct calipso_hip_solver {
     std::vector<double> hparams;
     double* multi_rhs = nullptr;  // workspace for differentiate (allocated on demand)
     hipEvent_t ev[16];
+    hipGraphExec_t graph_ldl = nullptr, graph_trsv = nullptr;   // captured once per handle (fixed launch sequences)
+    bool graph_ldl_tried = false, graph_trsv_tried = false, use_graphs = true;
     double phase_ms[9] = {0};
     // filter (filter.jl:1-13), host side
     std::vector<double> filter_theta, filter_merit, cache_theta, cache_merit;

@@ -330,13 +330,9 @@ __global__ __launch_bounds__(1024) void k_tinv_merge(int NP, int half, int phase
     }
 }
 
-void launch_ldl(calipso_hip_solver* s) {
+static void enqueue_ldl(calipso_hip_solver* s) {
     const int NP = s->d.NP, nblk = NP / NB;
-    static bool attr_set = false;
-    if (!attr_set) {   // > 64 KiB of dynamic LDS must be requested explicitly
-        (void)hipFuncSetAttribute((const void*)k_tinv_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 64 * (128 + 2) * sizeof(double)));
-        attr_set = true;
-    }
+
     for (int kb = 0; kb < nblk; ++kb) {
         const int k0 = kb * NB;
         hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DIAG_THREADS), 0, s->stream, NP, s->d.nx, k0, s->S, s->Dx, s->Tinv, s->icount);
@@ -455,7 +451,7 @@ __global__ __launch_bounds__(256) void k_trsv_update_t(int NP, int kb, const dou
 }
 
 // x (length NP, padded entries zero) <- S^-1 x
-void launch_trsv(calipso_hip_solver* s, double* x) {
+static void enqueue_trsv(calipso_hip_solver* s, double* x) {
     const int NP = s->d.NP, nb = NP / TB;
     double* u = s->zf;         // forward result (unscaled), consumed by the updates
     double* z = s->zf2;        // D^-1 u, then overwritten block by block with v
@@ -468,6 +464,41 @@ void launch_trsv(calipso_hip_solver* s, double* x) {
         hipLaunchKernelGGL(k_trsv_block_t, dim3(TB / 4), dim3(256), 0, s->stream, kb, s->Tinv, z, x);
         if (kb > 0) hipLaunchKernelGGL(k_trsv_update_t, dim3(kb * TB / 4), dim3(256), 0, s->stream, NP, kb, s->S, x, z);
     }
+}
+
+// The factorisation of S and the triangular solves are fixed kernel sequences with fixed arguments (118 and 18 launches):
+// they are captured once per handle into hipGraphs and replayed, so the host issues one graph launch instead of queueing every
+// kernel (the GPU otherwise waits on the host between the many few-microsecond kernels).
+void ldl_set_attributes() {
+    static bool done = false;
+    if (!done) {   // > 64 KiB of dynamic LDS must be requested explicitly
+        (void)hipFuncSetAttribute((const void*)k_tinv_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 64 * (128 + 2) * sizeof(double)));
+        done = true;
+    }
+}
+
+template <typename F>
+static bool replay_or_capture(calipso_hip_solver* s, hipGraphExec_t& exec, bool& tried, F enqueue) {
+    if (exec) return hipGraphLaunch(exec, s->stream) == hipSuccess;
+    if (tried) return false;
+    tried = true;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+    enqueue();
+    if (hipStreamEndCapture(s->stream, &graph) != hipSuccess || !graph) return false;
+    const bool ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    (void)hipGraphDestroy(graph);
+    if (!ok) { exec = nullptr; return false; }
+    return hipGraphLaunch(exec, s->stream) == hipSuccess;
+}
+
+void launch_ldl(calipso_hip_solver* s) {
+    ldl_set_attributes();
+    if (!s->use_graphs || !replay_or_capture(s, s->graph_ldl, s->graph_ldl_tried, [&] { enqueue_ldl(s); })) enqueue_ldl(s);
+}
+
+void launch_trsv(calipso_hip_solver* s, double* x) {
+    if (x != s->xbuf || !s->use_graphs || !replay_or_capture(s, s->graph_trsv, s->graph_trsv_tried, [&] { enqueue_trsv(s, s->xbuf); })) enqueue_trsv(s, x);
 }
 
 }  // namespace calipso
