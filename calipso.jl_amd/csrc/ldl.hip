@@ -3,7 +3,8 @@
 // factorisation  P K P' = L D L'  of factorize!/QDLDL_factor! (linear_solver.jl:19-31, qdldl.jl:400-589) in the order
 // [z | y | x]; every pivot of S must be > 0 for the inertia test (inertia.jl:7-11).
 //
-// Per panel of NB = 64 columns (all on one stream, kernel boundaries are the only synchronisation):
+// Per panel of NB = 64 columns (all on one stream, kernel boundaries are the only synchronisation; the diagonal block of
+// panel k+1 is factored inside the trailing-update launch of panel k, so a panel step is two launches):
 //   k_ldl_diag      one workgroup; the 64 x 64 diagonal block lives in registers, the pivot column is exchanged through LDS
 //                   with ONE barrier per column; afterwards the kernel forms X = L11^-1 by blocked inversion (needed by
 //                   the panel step and by the triangular solves), counts pivot signs (compute_inertia!,
@@ -44,21 +45,27 @@ __device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton
     return r;
 }
 
-__global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(int NP, int nx, int k0, double* __restrict__ S, double* __restrict__ Dx,
-                                                            double* __restrict__ Tinv, int* __restrict__ icount) {
+// LDS carve (doubles): Ls | Xs | Ts | colbuf | rinvvec.  When the block arrives through LDS (fused with the trailing update) it
+// sits in the Ls region and is consumed into registers before Ls is first written.
+constexpr int DIAG_LDS_DOUBLES = 2 * NB * LDD + 32 * 33 + 4 * NB;
+template <bool FROM_LDS>
+__device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, int nx, int k0, double* __restrict__ S, double* __restrict__ Dx,
+                                           double* __restrict__ Tinv, int* __restrict__ icount) {
     constexpr int WAVES = 16, CPW = 4;
-    __shared__ double colbuf[2][NB];
-    __shared__ double rinvvec[2][NB];
-    __shared__ double Ls[NB * LDD];
-    __shared__ double Xs[NB * LDD];
-    __shared__ double Ts[32 * 33];
+    double* Ls = smem;
+    double* Xs = Ls + NB * LDD;
+    double* Ts = Xs + NB * LDD;
+    double (*colbuf)[NB] = reinterpret_cast<double (*)[NB]>(Ts + 32 * 33);
+    double (*rinvvec)[NB] = reinterpret_cast<double (*)[NB]>(Ts + 32 * 33 + 2 * NB);
     const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
     double a[CPW];
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
         const int k = cg + WAVES * c;
-        a[c] = (i >= k) ? S[(k0 + i) + (size_t)(k0 + k) * NP] : 0.0;
+        if (FROM_LDS) a[c] = (i >= k) ? Ls[i * LDD + k] : 0.0;
+        else a[c] = (i >= k) ? S[(k0 + i) + (size_t)(k0 + k) * NP] : 0.0;
     }
+    if (FROM_LDS) __syncthreads();   // every lane has its entries before the Ls region is reused
     if (cg == 0) {
         colbuf[0][i] = a[0];
         rinvvec[0][i] = fast_rcp(a[0]);
@@ -171,6 +178,12 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(int NP, int nx, int k
     }
 }
 
+__global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(int NP, int nx, int k0, double* __restrict__ S, double* __restrict__ Dx,
+                                                            double* __restrict__ Tinv, int* __restrict__ icount) {
+    __shared__ double smem[DIAG_LDS_DOUBLES];
+    diag_block<false>(smem, NP, nx, k0, S, Dx, Tinv, icount);
+}
+
 // ---- panel: Y21 = A21 X', L21 = Y21 / d --------------------------------------------------------------------------------------
 // D[c][r] = sum_k X[c][k] A21[r][k]: MFMA A operand = X (rows c), B operand = A21' so that the 16-lane fast index of the
 // result is the contiguous row index r of the column-major panel.  One workgroup (16 wavefronts) per 64 rows; wavefront
@@ -217,9 +230,16 @@ __global__ __launch_bounds__(1024) void k_ldl_panel(int NP, int k0, double* __re
 // trailing matrix.  The tile is computed transposed (MFMA row <-> column j of S) so result stores are 128-byte runs.
 constexpr int TR_THREADS = 1024;
 constexpr int TT = 64;
-__global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(int NP, int k0, double* __restrict__ S, const double* __restrict__ Y, int ntiles) {
-    __shared__ double Ls[TT * LDT];       // Ls[i][k]: rows of the i block of L21
-    __shared__ double Ys[TT * LDT];       // Ys[j][k]: rows of the j block of Y21
+constexpr int TR_LDS_DOUBLES = 2 * TT * LDT;
+constexpr int FUSED_LDS_DOUBLES = TR_LDS_DOUBLES > DIAG_LDS_DOUBLES ? TR_LDS_DOUBLES : DIAG_LDS_DOUBLES;
+// Tile 0 of the trailing update IS the next diagonal block: its workgroup keeps going and factors that block (diag_block),
+// so the 64-column pivot chain of panel k+1 runs inside this launch, overlapped with the other tiles, and a panel step is two
+// launches (this kernel, then the panel GEMM) instead of three.
+__global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(int NP, int nx, int k0, double* __restrict__ S, const double* __restrict__ Y,
+                                                             double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount) {
+    __shared__ double smem[FUSED_LDS_DOUBLES];
+    double* Ls = smem;                    // Ls[i][k]: rows of the i block of L21
+    double* Ys = smem + TT * LDT;         // Ys[j][k]: rows of the j block of Y21
     const int t = blockIdx.x;
     int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
@@ -259,8 +279,17 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(int NP, int k0, dou
         const double yb = Ys[(wc * 16 + fr) * LDT + kk * 4 + fk];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yb, la, acc, 0, 0, 0);
     }
+    if (t != 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP] = cS[r] - acc[r];
+        for (int r = 0; r < 4; ++r) S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP] = cS[r] - acc[r];
+        return;
+    }
+    // tile 0 = the diagonal block of the next panel: hand it over through LDS (row-major, stride LDD) and factor it
+    __syncthreads();                      // all MFMA operand reads of Ls/Ys are done
+#pragma unroll
+    for (int r = 0; r < 4; ++r) smem[(wr * 16 + fr) * LDD + (wc * 16 + fk + 4 * r)] = cS[r] - acc[r];
+    __syncthreads();
+    diag_block<true>(smem, NP, nx, r0, S, Dx, Tinv, icount);
 }
 
 // ---- inverses of the 256 x 256 diagonal blocks from the 64 x 64 ones -----------------------------------------------------------
@@ -332,16 +361,14 @@ __global__ __launch_bounds__(1024) void k_tinv_merge(int NP, int half, int phase
 
 static void enqueue_ldl(calipso_hip_solver* s) {
     const int NP = s->d.NP, nblk = NP / NB;
-
-    for (int kb = 0; kb < nblk; ++kb) {
+    hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DIAG_THREADS), 0, s->stream, NP, s->d.nx, 0, s->S, s->Dx, s->Tinv, s->icount);
+    for (int kb = 0; kb + 1 < nblk; ++kb) {
         const int k0 = kb * NB;
-        hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DIAG_THREADS), 0, s->stream, NP, s->d.nx, k0, s->S, s->Dx, s->Tinv, s->icount);
         const int rows = NP - k0 - NB;
-        if (rows > 0) {
-            hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64), dim3(1024), 0, s->stream, NP, k0, s->S, s->Dx, s->Tinv, s->Ypanel);
-            const int ntr = rows / TT, ntiles = ntr * (ntr + 1) / 2;
-            hipLaunchKernelGGL(k_ldl_trailing, dim3(ntiles), dim3(TR_THREADS), 0, s->stream, NP, k0, s->S, s->Ypanel, ntiles);
-        }
+        hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64), dim3(1024), 0, s->stream, NP, k0, s->S, s->Dx, s->Tinv, s->Ypanel);
+        const int ntr = rows / TT, ntiles = ntr * (ntr + 1) / 2;
+        // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
+        hipLaunchKernelGGL(k_ldl_trailing, dim3(ntiles), dim3(TR_THREADS), 0, s->stream, NP, s->d.nx, k0, s->S, s->Ypanel, s->Dx, s->Tinv, s->icount);
     }
     const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
     for (int level = 1; level <= 3; ++level) {
