@@ -383,62 +383,61 @@ static void enqueue_ldl(calipso_hip_solver* s) {
 // backward: L' v = z.  kernel B'_k: v_k = Tinv_k' z_k ; kernel A'_k: z_above -= L[k, above]' v_k
 // Each output entry is a dot product of a matrix row/column with a 256-vector; the vector sits in LDS.
 
-// u_k = Tinv_k b_k (lower-triangular mat-vec, lanes along rows); also z_k = u_k / D.  32 rows per workgroup, 8 column parts;
-// loads are issued in explicit batches of 16 so that many are in flight per lane (these kernels are latency-bound).
+// u_k = Tinv_k b_k (lower-triangular mat-vec, lanes along rows); also z_k = u_k / D.  32 rows per workgroup, 8 column parts of
+// 64 columns; each lane issues ALL its loads before using any (these kernels are latency-bound: one round trip, not four).
 __global__ __launch_bounds__(256) void k_trsv_block_n(int kb, const double* __restrict__ Tinv, const double* __restrict__ b, const double* __restrict__ Dx,
                                                        double* __restrict__ u, double* __restrict__ z) {
     __shared__ double bs[TB];
     __shared__ double part[8][32];
     const int tid = threadIdx.x, k0 = kb * TB;
-    for (int i = tid; i < TB; i += 256) bs[i] = b[k0 + i];
-    __syncthreads();
     const int r = tid & 31, p = tid >> 5;
     const int row = blockIdx.x * 32 + r;
     const double* T = Tinv + (size_t)kb * TB * TB + row;
     const int cend = blockIdx.x * 32 + 32;         // lower triangular: columns beyond the workgroup's last row are zero
+    double v[TB / 8];
+#pragma unroll
+    for (int q = 0; q < TB / 8; ++q) { const int c = p + 8 * q; v[q] = (c < cend) ? T[(size_t)c * TB] : 0.0; }
+    for (int i = tid; i < TB; i += 256) bs[i] = b[k0 + i];
+    __syncthreads();
     double acc = 0.0;
-#pragma unroll 1
-    for (int cb = 0; cb < cend; cb += 128) {
-        double v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { const int c = cb + p + 8 * q; v[q] = (c < cend) ? T[(size_t)c * TB] : 0.0; }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { const int c = cb + p + 8 * q; acc += v[q] * bs[c < TB ? c : 0]; }
-    }
+    for (int q = 0; q < TB / 8; ++q) acc += v[q] * bs[p + 8 * q];
     part[p][r] = acc;
     __syncthreads();
     if (tid < 32) {
-        double v = 0.0;
+        double s = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v += part[q][tid];
+        for (int q = 0; q < 8; ++q) s += part[q][tid];
         const int gi = k0 + blockIdx.x * 32 + tid;
-        u[gi] = v;
-        z[gi] = v / Dx[gi];
+        u[gi] = s;
+        z[gi] = s / Dx[gi];
     }
 }
 
-// b[rows below block kb] -= L[rows, block kb] * u_k      (64 rows per workgroup, 4 column parts; loads batched 32 deep)
+// b[rows below block kb] -= L[rows, block kb] * u_k      (32 rows per workgroup, 8 column parts of 64 columns, one load batch)
 __global__ __launch_bounds__(256) void k_trsv_update_n(int NP, int kb, const double* __restrict__ S, const double* __restrict__ u, double* __restrict__ b) {
     __shared__ double us[TB];
-    __shared__ double part[4][64];
+    __shared__ double part[8][32];
     const int tid = threadIdx.x, k0 = kb * TB;
+    const int r = tid & 31, p = tid >> 5;
+    const int row = k0 + TB + blockIdx.x * 32 + r;
+    const double* Sp = S + row + (size_t)k0 * NP;
+    double v[TB / 8];
+#pragma unroll
+    for (int q = 0; q < TB / 8; ++q) v[q] = Sp[(size_t)(p + 8 * q) * NP];
     for (int i = tid; i < TB; i += 256) us[i] = u[k0 + i];
     __syncthreads();
-    const int r = tid & 63, p = tid >> 6;
-    const int row = k0 + TB + blockIdx.x * 64 + r;
-    const double* Sp = S + row + (size_t)k0 * NP;
     double acc = 0.0;
-#pragma unroll 1
-    for (int cb = 0; cb < TB; cb += 128) {
-        double v[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = Sp[(size_t)(cb + p + 4 * q) * NP];
-#pragma unroll
-        for (int q = 0; q < 32; ++q) acc += v[q] * us[cb + p + 4 * q];
-    }
+    for (int q = 0; q < TB / 8; ++q) acc += v[q] * us[p + 8 * q];
     part[p][r] = acc;
     __syncthreads();
-    if (tid < 64) b[k0 + TB + blockIdx.x * 64 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    if (tid < 32) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += part[q][tid];
+        b[k0 + TB + blockIdx.x * 32 + tid] -= s;
+    }
 }
 
 // v_k = Tinv_k' z_k : one wavefront per column (4 columns per workgroup), lanes stride down the column
@@ -485,7 +484,7 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
     for (int kb = 0; kb < nb; ++kb) {
         hipLaunchKernelGGL(k_trsv_block_n, dim3(TB / 32), dim3(256), 0, s->stream, kb, s->Tinv, x, s->Dx, u, z);
         const int rest = NP - (kb + 1) * TB;
-        if (rest > 0) hipLaunchKernelGGL(k_trsv_update_n, dim3(rest / 64), dim3(256), 0, s->stream, NP, kb, s->S, u, x);
+        if (rest > 0) hipLaunchKernelGGL(k_trsv_update_n, dim3(rest / 32), dim3(256), 0, s->stream, NP, kb, s->S, u, x);
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
         hipLaunchKernelGGL(k_trsv_block_t, dim3(TB / 4), dim3(256), 0, s->stream, kb, s->Tinv, z, x);
