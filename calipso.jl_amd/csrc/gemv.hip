@@ -16,17 +16,20 @@ __global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, const double
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= cols) return;
     const double* a = A + (size_t)col * ld;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int i = lane;
-#pragma unroll 4
-    for (; i + 192 < rows; i += 256) {
-        acc0 += a[i] * x[i];
-        acc1 += a[i + 64] * x[i + 64];
-        acc2 += a[i + 128] * x[i + 128];
-        acc3 += a[i + 192] * x[i + 192];
+    double acc0 = 0.0, acc1 = 0.0;
+    // batches of 24 loads per lane, all issued before the first use (latency-bound otherwise)
+    for (int base = 0; base < rows; base += 64 * 24) {
+        double v[24];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) { const int i = base + lane + 64 * q; v[q] = i < rows ? a[i] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 24; q += 2) {
+            const int i = base + lane + 64 * q;
+            acc0 += v[q] * (i < rows ? x[i] : 0.0);
+            acc1 += v[q + 1] * (i + 64 < rows ? x[i + 64] : 0.0);
+        }
     }
-    for (; i < rows; i += 64) acc0 += a[i] * x[i];
-    const double r = wave_sum((acc0 + acc1) + (acc2 + acc3));
+    const double r = wave_sum(acc0 + acc1);
     if (lane == 0) y[col] = (beta == 0.0) ? alpha * r : alpha * r + beta * y[col];
 }
 
@@ -44,17 +47,19 @@ __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(int rows, int cols, 
     const int c0 = blockIdx.y * chunk;
     const int c1 = min(cols, c0 + chunk);
     if (i >= rows) return;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int j = c0;
-#pragma unroll 4
-    for (; j + 3 < c1; j += 4) {
-        acc0 += A[i + (size_t)j * ld] * x[j];
-        acc1 += A[i + (size_t)(j + 1) * ld] * x[j + 1];
-        acc2 += A[i + (size_t)(j + 2) * ld] * x[j + 2];
-        acc3 += A[i + (size_t)(j + 3) * ld] * x[j + 3];
+    double acc0 = 0.0, acc1 = 0.0;
+    // batches of 24 loads per lane, all issued before the first use
+    for (int j0 = c0; j0 < c1; j0 += 24) {
+        double v[24];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) v[q] = (j0 + q < c1) ? A[i + (size_t)(j0 + q) * ld] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 24; q += 2) {
+            acc0 += v[q] * (j0 + q < c1 ? x[j0 + q] : 0.0);
+            acc1 += v[q + 1] * (j0 + q + 1 < c1 ? x[j0 + q + 1] : 0.0);
+        }
     }
-    for (; j < c1; ++j) acc0 += A[i + (size_t)j * ld] * x[j];
-    partial[(size_t)blockIdx.y * rows + i] = (acc0 + acc1) + (acc2 + acc3);
+    partial[(size_t)blockIdx.y * rows + i] = acc0 + acc1;
 }
 
 // y = alpha * sum_chunks partial + beta*y: 64 rows per workgroup, 4 lanes per row each summing every 4th chunk in a fixed order
@@ -79,7 +84,7 @@ void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, 
     if (rows == 0) return;
     // enough workgroups to cover the chip: rows/256 row blocks x nchunk column chunks ~ 1024 workgroups
     const int rb = (rows + GN_ROWS - 1) / GN_ROWS;
-    int nchunk = (1024 + rb - 1) / rb;
+    int nchunk = (768 + rb - 1) / rb;
     if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
     if (nchunk > (cols + 15) / 16) nchunk = (cols + 15) / 16;
     if (nchunk < 1) nchunk = 1;
