@@ -87,8 +87,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=3, help="independent problem instances in flight per GPU, one HIP stream each (3 = the number of\n"
-                    "stream-priority classes, which the runtime maps to distinct hardware queues)")
+    ap.add_argument("--batch", type=int, default=6, help="independent problem instances per GPU; 3 are in flight at a time (one per HIP\n"
+                    "stream-priority class, which the runtime maps to distinct hardware queues), see calipso.jl_amd/batch.py")
     ap.add_argument("--config", default="C3", choices=list(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets two ranks share one GPU")
@@ -186,7 +186,7 @@ def main():
         "config": {"workload": "%s synthetic dense conic QP: nx=%d ne=%d nc=%d (%d R+ + %d x SOC%d), n=%d condensed, N=%d unreduced; "
                                "%d independent instance(s) per GPU; 1 LDL^T factorisation, %d refinement round(s) per step" % (
                                    args.config, nx, ne, nc, n_nn, n_soc, dim, nx + m, nx + 2 * ne + 3 * nc, B, info["refinement_rounds"]),
-                   "instances_per_gpu": B, "parallelism": "independent problems per GPU (no data-path collective)",
+                   "instances_per_gpu": B, "instances_in_flight": batch.lanes, "parallelism": "independent problems per GPU (no data-path collective)",
                    "refinement_rounds": info["refinement_rounds"], "factorizations_per_step": info["factorizations"],
                    "single_instance_steps_per_s": single_rate,
                    "phase_ms": {"whole_step_gpu": float(np.mean(tot)), "search_direction": float(np.mean(sd)), "schur_mfma": sch_ms,

@@ -419,6 +419,137 @@ __global__ __launch_bounds__(1024) void k_diag_v4(int ld, double* __restrict__ S
     }
 }
 
+// v5 = v4 templated on the number of wavefronts (v3 + unmasked column updates, finished columns stashed in LDS, per-lane reciprocal vector): LDL^T loop without the inverse; X = L^-1 afterwards by 16 x 16 wave-synchronous inversions + two merge levels in LDS
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_diag_v5(int ld, double* __restrict__ S, double* __restrict__ Dx, double* __restrict__ Xout) {
+    constexpr int CPW = NB / WAVES;
+    __shared__ double colbuf[2][NB];
+    __shared__ double rinvvec[2][NB];
+    __shared__ double Ls[NB * LDD3];
+    __shared__ double Xs[NB * LDD3];
+    __shared__ double Ts[32 * 33];
+    const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
+    double a[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        a[c] = (i >= k) ? S[i + (size_t)k * ld] : 0.0;
+    }
+    if (cg == 0) {
+        colbuf[0][i] = a[0];
+        rinvvec[0][i] = fast_rcp(a[0]);
+        Ls[i * LDD3 + 0] = a[0];
+    }
+#pragma unroll 1
+    for (int jb = 0; jb < NB; jb += WAVES)
+#pragma unroll
+    for (int jj = 0; jj < WAVES; ++jj) {
+        const int j = jb + jj;
+        const int cur = jj & 1, nxt = cur ^ 1;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        const double yi = colbuf[cur][i];
+        const double rinv = rinvvec[cur][j];
+        double yk[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) yk[c] = colbuf[cur][cg + WAVES * c];
+        const double li = (i > j) ? yi * rinv : 0.0;      // rows at/above the pivot: no update (upper part is never read)
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int k = cg + WAVES * c;
+            a[c] -= li * yk[c];          // finished columns (k <= j) were stashed in Ls when published; garbage here is never read
+            (void)k;
+        }
+        if (j + 1 < NB && cg == (jj + 1) % WAVES) {
+            const int cs = (j + 1) / WAVES;
+            double v = a[0];
+#pragma unroll
+            for (int c = 1; c < CPW; ++c) v = (cs == c) ? a[c] : v;
+            colbuf[nxt][i] = v;
+            rinvvec[nxt][i] = fast_rcp(v);           // every lane: readers pick entry j+1 (no divergent single-lane path)
+            Ls[i * LDD3 + j + 1] = v;                // unscaled column j+1 (rows >= j+1 meaningful), pivot on the diagonal
+        }
+    }
+    __syncthreads();
+    // scale the stashed columns: L into LDS (for the inverse) and to global; pivots out
+    double dk[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) dk[c] = Ls[(cg + WAVES * c) * LDD3 + cg + WAVES * c];
+    if (tid < NB) Dx[tid] = Ls[tid * LDD3 + tid];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        const double l = (i > k) ? Ls[i * LDD3 + k] * (1.0 / dk[c]) : 0.0;
+        Ls[i * LDD3 + k] = l;
+        Xs[i * LDD3 + k] = 0.0;
+        if (i > k) S[i + (size_t)k * ld] = l;
+    }
+    __syncthreads();
+    // (a) the four 16 x 16 diagonal blocks of X: wave w, lane c < 16 builds column c by forward substitution (registers, no barrier)
+    for (int blk = cg; blk < 4; blk += WAVES) if (i < 16) {
+        const int o = 16 * blk;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < r; ++k) acc -= Ls[(o + r) * LDD3 + o + k] * x[k];
+            x[r] = (r >= i) ? acc : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Xs[(o + r) * LDD3 + o + i] = x[r];
+    }
+    __syncthreads();
+    // (b) level 1: X21 = -X22 (L21 X11) for the two 32-blocks; 512 threads, one output each
+    {
+        for (int e = tid; e < 512; e += WAVES * 64) {
+            const int p = e >> 8, ii = (e >> 4) & 15, jj2 = e & 15, o = 32 * p;
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += Ls[(o + 16 + ii) * LDD3 + o + k] * Xs[(o + k) * LDD3 + o + jj2];
+            Ts[(p * 16 + ii) * 33 + jj2] = t;
+        }
+        __syncthreads();
+        for (int e = tid; e < 512; e += WAVES * 64) {
+            const int p = e >> 8, ii = (e >> 4) & 15, jj2 = e & 15, o = 32 * p;
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v -= Xs[(o + 16 + ii) * LDD3 + o + 16 + k] * Ts[(p * 16 + k) * 33 + jj2];
+            Xs[(o + 16 + ii) * LDD3 + o + jj2] = v;
+        }
+        __syncthreads();
+    }
+    // (c) level 2: X21 (32 x 32) = -X22 (L21 X11); 1024 threads, one output each
+    {
+        for (int e = tid; e < 1024; e += WAVES * 64) {
+            const int ii = e >> 5, jj2 = e & 31;
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) t += Ls[(32 + ii) * LDD3 + k] * Xs[k * LDD3 + jj2];
+            Ts[ii * 33 + jj2] = t;
+        }
+        __syncthreads();
+        double vv[1024 / (WAVES * 64)];
+        for (int e = tid, n = 0; e < 1024; e += WAVES * 64, ++n) {
+            const int ii = e >> 5, jj2 = e & 31;
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v -= Xs[(32 + ii) * LDD3 + 32 + k] * Ts[k * 33 + jj2];
+            vv[n] = v;
+        }
+        __syncthreads();
+        for (int e = tid, n = 0; e < 1024; e += WAVES * 64, ++n) Xs[(32 + (e >> 5)) * LDD3 + (e & 31)] = vv[n];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        Xout[i + k * NB] = Xs[i * LDD3 + k];
+    }
+}
+
 template <typename K>
 void run(const char* name, K kern, int threads, const std::vector<double>& A0, bool with_x) {
     const int ld = NB, reps = 200;
@@ -474,6 +605,9 @@ int main() {
     run("skeleton  1 wave + rcp", k_skeleton<1,1>, 64, A, false);
     run("v3: LDL loop + blocked inverse", k_diag_v3, 1024, A, true);
     run("v4: v3 + unmasked/stash/rcp-vector", k_diag_v4, 1024, A, true);
+    run("v5 16 waves", k_diag_v5<16>, 1024, A, true);
+    run("v5  8 waves", k_diag_v5<8>, 512, A, true);
+    run("v5  4 waves", k_diag_v5<4>, 256, A, true);
     run("merged 16 waves", k_diag_merged<16>, 1024, A, true);
     run("merged  8 waves", k_diag_merged<8>, 512, A, true);
     run("merged  4 waves", k_diag_merged<4>, 256, A, true);

@@ -21,14 +21,31 @@ def shard_range(n_problems, rank, world):
 
 
 class BatchSolver:
-    """A set of independent Solver handles on one GPU, stepped / solved concurrently."""
+    """A set of independent Solver handles on one GPU, stepped / solved concurrently.
 
-    def __init__(self, solvers, max_workers=None):
+    At most `lanes` instances are in flight at a time (default 3 = the number of HIP stream-priority classes, which the runtime
+    maps to distinct hardware queues; handles are created with priority class = creation index mod 3).  Instance k is always
+    driven by host thread k mod lanes, so instances that run concurrently never share a priority class — streams of equal
+    priority can be multiplexed onto one hardware queue, which serialises them and was measured to be slower than running
+    them back to back."""
+
+    def __init__(self, solvers, lanes=3):
         self.solvers = list(solvers)
-        self.pool = ThreadPoolExecutor(max_workers=max_workers or max(1, len(self.solvers)))
+        self.lanes = max(1, min(int(lanes), len(self.solvers))) if self.solvers else 1
+        self.pool = ThreadPoolExecutor(max_workers=self.lanes)
+
+    def _run(self, fn):
+        """fn(solver) for every instance; lane w handles instances w, w+lanes, ... in order; results in instance order"""
+        out = [None] * len(self.solvers)
+
+        def lane(w):
+            for k in range(w, len(self.solvers), self.lanes):
+                out[k] = fn(self.solvers[k])
+        list(self.pool.map(lane, range(self.lanes)))
+        return out
 
     def newton_step(self, advance=False):
-        return list(self.pool.map(lambda s: s.newton_step(advance=advance), self.solvers))
+        return self._run(lambda s: s.newton_step(advance=advance))
 
     def solve(self, solve_fn):
         """solve_fn(solver) -> bool for every instance; returns (status int32[k, 4]) rows = [converged, iterations, outer, factorizations]"""
@@ -36,7 +53,7 @@ class BatchSolver:
             ok = solve_fn(s)
             st = s.stats()
             return [int(ok), st["total_iterations"], st["outer"], st["factorizations"]]
-        return np.array(list(self.pool.map(one, self.solvers)), dtype=np.int32).reshape(len(self.solvers), 4)
+        return np.array(self._run(one), dtype=np.int32).reshape(len(self.solvers), 4)
 
     def synchronize(self):
         for s in self.solvers:

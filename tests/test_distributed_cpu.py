@@ -57,3 +57,28 @@ def test_gather_results_single_process_identity():
     st = np.array([[1, 5, 2, 9]], dtype=np.int32)
     a, c = gather_results(st, np.array([3.0]))
     assert np.array_equal(a, st) and c[0] == 3.0
+
+
+def test_batch_lanes_keep_priority_classes_apart():
+    """BatchSolver drives instance k from host lane k mod 3, so concurrently running instances never share a stream-priority
+    class (= creation index mod 3); results come back in instance order"""
+    import threading
+    load_pkg()
+    from calipso_jl_amd.batch import BatchSolver
+
+    class Fake:
+        def __init__(self, k):
+            self.k = k
+            self.thread = None
+
+        def newton_step(self, advance=False):
+            self.thread = threading.get_ident()
+            return dict(status=0, k=self.k)
+
+    fakes = [Fake(k) for k in range(8)]
+    b = BatchSolver(fakes)
+    out = b.newton_step()
+    assert [o["k"] for o in out] == list(range(8)) and b.lanes == 3
+    for lane in range(3):
+        assert len({f.thread for f in fakes[lane::3]}) == 1          # one host thread per lane
+    b.close()
