@@ -118,6 +118,8 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     rc |= dalloc(s, &s->wz, NC); rc |= dalloc(s, &s->kzz, NC);
     rc |= dalloc(s, &s->Wsoc, (size_t)woff); rc |= dalloc(s, &s->Bsoc, (size_t)woff); rc |= dalloc(s, &s->socwork, (size_t)2 * woff);
     rc |= dalloc(s, &s->icount, 64);
+    schur_plan(s);
+    rc |= dalloc(s, &s->tile_list, s->h_tile_list.size());
     const size_t maxdim = std::max(std::max(NX, M), NPd);   // rows of the largest mat-vec (the stacked Jacobian has m = ne + nc rows)
     rc |= dalloc(s, &s->gemv_partial, 64 * maxdim);
     rc |= dalloc(s, &s->vtmp, 4 * std::max(N, NPd));
@@ -129,6 +131,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     if (rc) return CALIPSO_ERR_HIP;
     CK(hipHostMalloc((void**)&s->hscal, 64 * sizeof(double)));
     CK(hipHostMalloc((void**)&s->hicount, 64 * sizeof(int)));
+    CK(hipMemcpy(s->tile_list, s->h_tile_list.data(), sizeof(int) * s->h_tile_list.size(), hipMemcpyHostToDevice));
     if (d.n_soc) {
         CK(hipMemcpy(s->cone.soc_start, s->h_soc_start.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
         CK(hipMemcpy(s->cone.soc_dim, s->h_soc_dim.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
@@ -168,7 +171,7 @@ int32_t calipso_hip_destroy(H* s) {
                     s->Dx, s->Ypanel, s->Tinv, s->Ttmp, s->zf2, s->WH, s->wz, s->kzz, s->Wsoc, s->Bsoc, s->socwork, s->gemv_partial, s->vtmp, s->xbuf, s->zf,
                     s->t1, s->t2, s->lgp, s->gp, s->hp, s->jacobian_parameters, s->solution_sensitivity, s->multi_rhs, s->qp.q, s->qp.bh};
     for (double* p : dp) if (p) (void)hipFree(p);
-    int* ip[] = {s->icount, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
+    int* ip[] = {s->icount, s->tile_list, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
     for (int* p : ip) if (p) (void)hipFree(p);
     if (s->hscal) (void)hipHostFree(s->hscal);
     if (s->hicount) (void)hipHostFree(s->hicount);

@@ -12,6 +12,8 @@
 #include "internal.hpp"
 #include "device_utils.hpp"
 
+#include <algorithm>
+
 namespace calipso {
 
 // ---- per-cone pivots / weights ----------------------------------------------------------------------------------------
@@ -131,8 +133,12 @@ void launch_scale_rows(calipso_hip_solver* s) {
 // blockIdx -> tile is XCD-aware: the 8 XCDs each get a contiguous band of tile rows, so the operand columns a band
 // needs are shared through that XCD's L2 instead of being fetched by all eight.
 // fp64 MFMA on gfx950 needs >= 4 wavefronts per SIMD to keep the matrix pipe busy (bench/mfma_f64_peak.hip: one wave per
-// SIMD reaches 36 TFLOP/s, four reach 47-49), so the workgroup is 1024 threads = 16 wavefronts (4 x 4), each owning a
-// 32 x 32 sub-tile (2 x 2 MFMA tiles, 32 accumulator VGPRs) of the 128 x 128 tile.
+// SIMD reaches 36 TFLOP/s, four reach 47-49), so the workgroup is 1024 threads = 16 wavefronts.
+// Tile = 128 rows x TJ columns of the lower triangle, TJ = 16 nj with nj in 4..8 chosen on the host so that the tiles that
+// intersect the triangle fill the 256 CUs in as few, as small rounds as possible (C3: 128 x 112 -> 249 tiles, one round;
+// 128 x 128 would be 210 tiles at 8/7 the tile time).  The 8 x nj MFMA tiles of a workgroup are dealt so that every SIMD gets
+// 2 nj of them: wavefront w < 8 owns row-tile w and the first ceil(nj/2) column tiles, wavefront w >= 8 owns row-tile w-8 and
+// the rest (consecutive groups of four wavefronts sit on the four SIMDs).
 constexpr int KT = 32;
 constexpr int LDK = KT + 2;
 constexpr int SCHUR_THREADS = 1024;
@@ -148,13 +154,15 @@ __device__ __forceinline__ SchurStage schur_stage(int st, int nst0, const Dims& 
     return g;
 }
 
-// global -> registers: KT x TILE block of M (rows k0.., columns c0..), lanes along k; out-of-range -> 0
-__device__ __forceinline__ void stage_fetch(double (&r)[SLD], const double* __restrict__ M, int ldm, int kmax, int ncols, int k0, int c0, int tid, double scale) {
+// global -> registers: KT x width block of M (rows k0.., columns c0..c0+width), lanes along k; out-of-range -> 0
+__device__ __forceinline__ void stage_fetch(double (&r)[SLD], const double* __restrict__ M, int ldm, int kmax, int ncols, int k0, int c0, int width,
+                                            int tid, double scale) {
     const int k = tid % KT, cbase = tid / KT;
 #pragma unroll
     for (int it = 0; it < SLD; ++it) {
-        const int gk = k0 + k, gc = c0 + cbase + it * (SCHUR_THREADS / KT);
-        r[it] = (gk < kmax && gc < ncols) ? scale * M[gk + (size_t)gc * ldm] : 0.0;
+        const int c = cbase + it * (SCHUR_THREADS / KT);
+        const int gk = k0 + k, gc = c0 + c;
+        r[it] = (gk < kmax && gc < ncols && c < width) ? scale * M[gk + (size_t)gc * ldm] : 0.0;
     }
 }
 // registers -> LDS, k fastest: dst[c][k]
@@ -166,37 +174,36 @@ __device__ __forceinline__ void stage_store(double* __restrict__ dst, const doub
 
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(Dims d, Scalars sc, const double* __restrict__ Lsym, const double* __restrict__ gx,
                                                           const double* __restrict__ hx, const double* __restrict__ WH, double* __restrict__ S,
-                                                          int ntiles) {
+                                                          const int* __restrict__ tile_list, int ntiles, int nj) {
     __shared__ double As[TILE * LDK];
     __shared__ double Bs[TILE * LDK];
-    // XCD-aware remap: block b runs on XCD b % 8 (observed dispatch order; used for speed only)
+    // XCD-aware remap: block b runs on XCD b % 8 (observed dispatch order; used for speed only): each XCD gets a contiguous
+    // band of the (row-major) tile list, so the operand columns a band needs are shared through that XCD's L2
     const int chunk = (gridDim.x + 7) / 8;
     const int t = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
     if (t >= ntiles) return;
-    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    const int i0 = ti * TILE, j0 = tj * TILE;
+    const int TJ = 16 * nj;
+    const int i0 = tile_list[2 * t] * TILE, j0 = tile_list[2 * t + 1] * TJ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;     // wavefront's 32 x 32 sub-tile: rows (i) block wr, columns (j) block wc
+    const int wi = wave & 7;                          // row tile (16 rows) of this wavefront
+    const int nlo = (nj + 1) >> 1;
+    const int jt0 = wave < 8 ? 0 : nlo;               // first column tile
+    const int jcnt = wave < 8 ? nlo : nj - nlo;       // number of column tiles (<= 4)
     const int fr = lane & 15, fk = lane >> 4;
 
-    // acc[n][m]: MFMA row index <-> column j of S, MFMA column index (the 16-lane fast index) <-> row i of S, so that the
+    // acc[n]: MFMA row index <-> column j of S, MFMA column index (the 16-lane fast index) <-> row i of S, so that the
     // epilogue's stores are 128-byte contiguous runs of the column-major S
-    v4d acc[2][2];
+    v4d acc[4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < 4; ++n) acc[n] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
     const int nst0 = (d.ne + KT - 1) / KT, nst = nst0 + (d.nc + KT - 1) / KT;
     double ra[SLD], rb[SLD];
     if (nst > 0) {
         const SchurStage g = schur_stage(0, nst0, d, gx, hx, WH, omega_y);
-        stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, tid, 1.0);
-        stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, tid, g.bscale);
+        stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, TILE, tid, 1.0);
+        stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, TJ, tid, g.bscale);
     }
 #pragma unroll 1
     for (int st = 0; st < nst; ++st) {
@@ -206,40 +213,46 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(Dims d, Scalars sc, con
         __syncthreads();
         if (st + 1 < nst) {   // prefetch the next stage while the matrix cores work on this one
             const SchurStage g = schur_stage(st + 1, nst0, d, gx, hx, WH, omega_y);
-            stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, tid, 1.0);
-            stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, tid, g.bscale);
+            stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, TILE, tid, 1.0);
+            stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, TJ, tid, g.bscale);
         }
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
-            double a[2], b[2];
+            const double a = As[(wi * 16 + fr) * LDK + kk * 4 + fk];
+            double b[4];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = As[(wr * 32 + m * 16 + fr) * LDK + kk * 4 + fk];
+            for (int n = 0; n < 4; ++n) b[n] = Bs[((jt0 + n) * 16 + fr) * LDK + kk * 4 + fk];   // rows beyond the tile are zero-filled
 #pragma unroll
-            for (int n = 0; n < 2; ++n) b[n] = Bs[(wc * 32 + n * 16 + fr) * LDK + kk * 4 + fk];
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a[m], acc[n][m], 0, 0, 0);
+            for (int n = 0; n < 4; ++n)
+                if (n < jcnt) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a, acc[n], 0, 0, 0);   // wavefront-uniform
         }
     }
     // epilogue: + Lxx (through its upper triangle, as triu(K)) + ep on the diagonal; identity in the padding
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 4; ++n) {
+        if (n >= jcnt) break;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gj = j0 + wc * 32 + n * 16 + fk + 4 * r;   // MFMA row
-                const int gi = i0 + wr * 32 + m * 16 + fr;           // MFMA column: contiguous rows of S
-                double v;
-                if (gi < d.nx && gj < d.nx) {
-                    v = acc[n][m][r] + Lsym[gi + (size_t)gj * d.nx];   // = Lxx[min, max]: triu(K) mirrored (k_symmetrize_upper)
-                    if (gi == gj) v += sc.ep;
-                } else {
-                    v = (gi == gj) ? 1.0 : 0.0;
-                }
-                S[gi + (size_t)gj * d.NP] = v;
+        for (int r = 0; r < 4; ++r) {
+            const int gj = j0 + (jt0 + n) * 16 + fk + 4 * r;   // MFMA row
+            const int gi = i0 + wi * 16 + fr;                  // MFMA column: contiguous rows of S
+            if (gi >= d.NP || gj >= d.NP) continue;
+            double v;
+            if (gi < d.nx && gj < d.nx) {
+                v = acc[n][r] + Lsym[gi + (size_t)gj * d.nx];   // = Lxx[min, max]: triu(K) mirrored (k_symmetrize_upper)
+                if (gi == gj) v += sc.ep;
+            } else {
+                v = (gi == gj) ? 1.0 : 0.0;
             }
+            S[gi + (size_t)gj * d.NP] = v;
+        }
+    }
+}
+
+// identity in the padded rows [nx, NP) of the lower triangle (the tiles only cover what intersects the real triangle)
+__global__ void k_pad_identity(Dims d, double* __restrict__ S) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = d.nx + blockIdx.y;
+    if (i < d.NP && j <= i) S[i + (size_t)j * d.NP] = (i == j) ? 1.0 : 0.0;
 }
 
 // Lsym[i,j] = Lxx[min(i,j), max(i,j)]: the Hessian as a triu-only factorisation sees it (qdldl.jl:145-147), laid out so the
@@ -276,12 +289,33 @@ void launch_symmetrize(calipso_hip_solver* s) {
     hipLaunchKernelGGL(k_symmetrize_upper, dim3(nt, nt), dim3(32, 8), 0, s->stream, s->d.nx, s->Lxx, s->Lsym);
 }
 
+// host: tile shape and the list of tiles that intersect { j <= i < nx }, row-major
+void schur_plan(calipso_hip_solver* s) {
+    const int nx = s->d.nx;
+    long best_cost = -1;
+    for (int nj = 4; nj <= 8; ++nj) {
+        const int TJ = 16 * nj;
+        const int nbi = (nx + TILE - 1) / TILE, nbj = (nx + TJ - 1) / TJ;
+        std::vector<int> list;
+        for (int bi = 0; bi < nbi; ++bi) {
+            const int imax = std::min(nx, (bi + 1) * TILE) - 1;
+            for (int bj = 0; bj < nbj; ++bj)
+                if (bj * TJ <= imax) { list.push_back(bi); list.push_back(bj); }
+        }
+        const long cnt = (long)list.size() / 2;
+        const long cost = ((cnt + 255) / 256) * nj;      // rounds over the 256 CUs x per-SIMD MFMA count of a tile
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && nj > s->schur_nj)) { best_cost = cost; s->schur_nj = nj; s->h_tile_list = list; }
+    }
+}
+
 void launch_schur(calipso_hip_solver* s) {
     if (s->hessian_dirty) { launch_symmetrize(s); s->hessian_dirty = false; }
-    const int nt = s->d.NP / TILE;
-    const int ntiles = nt * (nt + 1) / 2;
+    const int ntiles = (int)s->h_tile_list.size() / 2;
     const int grid = ((ntiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_schur, dim3(grid), dim3(SCHUR_THREADS), 0, s->stream, s->d, s->sc, s->Lsym, s->gx, s->hx, s->WH, s->S, ntiles);
+    if (s->d.NP > s->d.nx)
+        hipLaunchKernelGGL(k_pad_identity, dim3((s->d.NP + 255) / 256, s->d.NP - s->d.nx), dim3(256), 0, s->stream, s->d, s->S);
+    hipLaunchKernelGGL(k_schur, dim3(grid), dim3(SCHUR_THREADS), 0, s->stream, s->d, s->sc, s->Lsym, s->gx, s->hx, s->WH, s->S, s->tile_list, ntiles,
+                       s->schur_nj);
 }
 
 }  // namespace calipso
