@@ -87,7 +87,8 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     d.N = d.nx + 2 * d.ne + 3 * d.nc;         // dimensions.jl:22-23
     d.m = d.ne + d.nc;
     d.q = (int)n_nonneg; d.n_soc = (int)s->h_soc_start.size(); d.max_dim = maxd;
-    d.NP = ((d.nx + 511) / 512) * 512;   // multiple of the triangular-solve block (and of TILE, NB)
+    // nx padded: a power-of-two multiple of 64 up to 512 (small systems: one solve block), multiples of 512 above
+    if (d.nx <= 512) { d.NP = 64; while (d.NP < d.nx) d.NP *= 2; } else d.NP = ((d.nx + 511) / 512) * 512;   // multiple of the triangular-solve block (and of TILE, NB)
     s->device = device;
     *out = s;   // from here on errors are reported through the handle
     CK(hipSetDevice(device));
@@ -114,7 +115,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     rc |= dalloc(s, &s->saved_point, N); rc |= dalloc(s, &s->saved_g, NE); rc |= dalloc(s, &s->saved_h, NC);
     rc |= dalloc(s, &s->residual_symmetric, n); rc |= dalloc(s, &s->step_symmetric, n); rc |= dalloc(s, &s->merit_gradient, n);
     rc |= dalloc(s, &s->S, NPd * NPd); rc |= dalloc(s, &s->Dx, NPd); rc |= dalloc(s, &s->Ypanel, NPd * NB);
-    rc |= dalloc(s, &s->Tinv, (NPd / 512) * 512 * 512); rc |= dalloc(s, &s->Ttmp, NPd * 128); rc |= dalloc(s, &s->zf2, NPd); rc |= dalloc(s, &s->WH, NC * NX);
+    rc |= dalloc(s, &s->Tinv, NPd < 512 ? NPd * NPd : (NPd / 512) * 512 * 512); rc |= dalloc(s, &s->Ttmp, NPd * 128); rc |= dalloc(s, &s->zf2, NPd); rc |= dalloc(s, &s->WH, NC * NX);
     rc |= dalloc(s, &s->wz, NC); rc |= dalloc(s, &s->kzz, NC);
     rc |= dalloc(s, &s->Wsoc, (size_t)woff); rc |= dalloc(s, &s->Bsoc, (size_t)woff); rc |= dalloc(s, &s->socwork, (size_t)2 * woff);
     rc |= dalloc(s, &s->icount, 64);

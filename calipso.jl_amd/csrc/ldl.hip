@@ -21,7 +21,7 @@
 namespace calipso {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int TB = 512;            // triangular-solve block
+constexpr int TB = 512;            // largest triangular-solve block; the block actually used is tb = min(TB, NP) (small systems)
 constexpr int LDT = NB + 2;        // LDS leading dimension of a k-fastest 64-deep operand panel
 
 // ---- diagonal block ---------------------------------------------------------------------------------------------------------
@@ -49,7 +49,7 @@ __device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton
 // sits in the Ls region and is consumed into registers before Ls is first written.
 constexpr int DIAG_LDS_DOUBLES = 2 * NB * LDD + 32 * 33 + 4 * NB;
 template <bool FROM_LDS>
-__device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, int nx, int k0, double* __restrict__ S, double* __restrict__ Dx,
+__device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
                                            double* __restrict__ Tinv, int* __restrict__ icount) {
     constexpr int WAVES = 16, CPW = 4;
     double* Ls = smem;
@@ -168,27 +168,27 @@ __device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, in
     }
     __syncthreads();
     {
-        const int q = k0 / TB, o = k0 % TB;
-        double* T = Tinv + (size_t)q * TB * TB;
+        const int q = k0 / tb, o = k0 % tb;
+        double* T = Tinv + (size_t)q * tb * tb;
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
             const int k = cg + WAVES * c;
-            T[(o + i) + (size_t)(o + k) * TB] = Xs[i * LDD + k];     // X = L11^-1 on the diagonal of the inverse block (zeros above)
+            T[(o + i) + (size_t)(o + k) * tb] = Xs[i * LDD + k];     // X = L11^-1 on the diagonal of the inverse block (zeros above)
         }
     }
 }
 
-__global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(int NP, int nx, int k0, double* __restrict__ S, double* __restrict__ Dx,
+__global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
                                                             double* __restrict__ Tinv, int* __restrict__ icount) {
     __shared__ double smem[DIAG_LDS_DOUBLES];
-    diag_block<false>(smem, NP, nx, k0, S, Dx, Tinv, icount);
+    diag_block<false>(smem, NP, nx, k0, tb, S, Dx, Tinv, icount);
 }
 
 // ---- panel: Y21 = A21 X', L21 = Y21 / d --------------------------------------------------------------------------------------
 // D[c][r] = sum_k X[c][k] A21[r][k]: MFMA A operand = X (rows c), B operand = A21' so that the 16-lane fast index of the
 // result is the contiguous row index r of the column-major panel.  One workgroup (16 wavefronts) per 64 rows; wavefront
 // (wr, wc) computes the 16 x 16 tile rows 16 wr.., columns 16 wc.. ; X is staged in LDS.
-__global__ __launch_bounds__(1024) void k_ldl_panel(int NP, int k0, double* __restrict__ S, const double* __restrict__ Dx,
+__global__ __launch_bounds__(1024) void k_ldl_panel(int NP, int k0, int tb, double* __restrict__ S, const double* __restrict__ Dx,
                                                      const double* __restrict__ Tinv, double* __restrict__ Y) {
     __shared__ double Xs[NB * LDT];   // Xs[c][k]
     __shared__ double dinv[NB];
@@ -200,11 +200,11 @@ __global__ __launch_bounds__(1024) void k_ldl_panel(int NP, int k0, double* __re
 #pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) b[kk] = S[(r0 + fr) + (size_t)(k0 + kk * 4 + fk) * NP];
     {
-        const int q = k0 / TB, o = k0 % TB;
-        const double* T = Tinv + (size_t)q * TB * TB;
+        const int q = k0 / tb, o = k0 % tb;
+        const double* T = Tinv + (size_t)q * tb * tb;
         const int c = tid & 63;
 #pragma unroll
-        for (int kk = tid >> 6; kk < NB; kk += 16) Xs[c * LDT + kk] = T[(o + c) + (size_t)(o + kk) * TB];
+        for (int kk = tid >> 6; kk < NB; kk += 16) Xs[c * LDT + kk] = T[(o + c) + (size_t)(o + kk) * tb];
         if (tid < NB) dinv[tid] = 1.0 / Dx[k0 + tid];
     }
     __syncthreads();
@@ -235,7 +235,7 @@ constexpr int FUSED_LDS_DOUBLES = TR_LDS_DOUBLES > DIAG_LDS_DOUBLES ? TR_LDS_DOU
 // Tile 0 of the trailing update IS the next diagonal block: its workgroup keeps going and factors that block (diag_block),
 // so the 64-column pivot chain of panel k+1 runs inside this launch, overlapped with the other tiles, and a panel step is two
 // launches (this kernel, then the panel GEMM) instead of three.
-__global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(int NP, int nx, int k0, double* __restrict__ S, const double* __restrict__ Y,
+__global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(int NP, int nx, int k0, int tb, double* __restrict__ S, const double* __restrict__ Y,
                                                              double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount) {
     __shared__ double smem[FUSED_LDS_DOUBLES];
     double* Ls = smem;                    // Ls[i][k]: rows of the i block of L21
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(int NP, int nx, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) smem[(wr * 16 + fr) * LDD + (wc * 16 + fk + 4 * r)] = cS[r] - acc[r];
     __syncthreads();
-    diag_block<true>(smem, NP, nx, r0, S, Dx, Tinv, icount);
+    diag_block<true>(smem, NP, nx, r0, tb, S, Dx, Tinv, icount);
 }
 
 // ---- inverses of the 256 x 256 diagonal blocks from the 64 x 64 ones -----------------------------------------------------------
@@ -334,7 +334,7 @@ __device__ __forceinline__ void gemm_tile64(const GemmDesc g, int K, double alph
 }
 
 // level 1, 2, 3: half = 64, 128, 256; phase 0: T = L21 * X11 ; phase 1: X21 = -X22 * T
-__global__ __launch_bounds__(1024) void k_tinv_merge(int NP, int half, int phase, const double* __restrict__ S, double* __restrict__ Tinv,
+__global__ __launch_bounds__(1024) void k_tinv_merge(int NP, int tb, int half, int phase, const double* __restrict__ S, double* __restrict__ Tinv,
                                                       double* __restrict__ Ttmp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tiles = half / 64;                 // tiles per side of the half x half result
@@ -342,39 +342,40 @@ __global__ __launch_bounds__(1024) void k_tinv_merge(int NP, int half, int phase
     const int tt = blockIdx.x % (tiles * tiles);
     const int tiy = tt / tiles, tjx = tt % tiles;
     const int g0 = pair * 2 * half;              // first row/col of the pair in the global numbering
-    const int q = g0 / TB, o = g0 % TB;
-    double* T = Tinv + (size_t)q * TB * TB;
+    const int q = g0 / tb, o = g0 % tb;
+    double* T = Tinv + (size_t)q * tb * tb;
     double* tmp = Ttmp + (size_t)pair * half * half;
     GemmDesc g;
     if (phase == 0) {        // tmp(half x half) = L21 * X11
         g.A = S + (g0 + half + tiy * 64) + (size_t)g0 * NP; g.lda = NP;
-        g.B = T + o + (size_t)(o + tjx * 64) * TB; g.ldb = TB;
+        g.B = T + o + (size_t)(o + tjx * 64) * tb; g.ldb = tb;
         g.C = tmp + tiy * 64 + (size_t)(tjx * 64) * half; g.ldc = half;
         gemm_tile64(g, half, 1.0, smem);
     } else {                 // X21 = -X22 * tmp
-        g.A = T + (o + half + tiy * 64) + (size_t)(o + half) * TB; g.lda = TB;
+        g.A = T + (o + half + tiy * 64) + (size_t)(o + half) * tb; g.lda = tb;
         g.B = tmp + (size_t)(tjx * 64) * half; g.ldb = half;
-        g.C = T + (o + half + tiy * 64) + (size_t)(o + tjx * 64) * TB; g.ldc = TB;
+        g.C = T + (o + half + tiy * 64) + (size_t)(o + tjx * 64) * tb; g.ldc = tb;
         gemm_tile64(g, half, -1.0, smem);
     }
 }
 
 static void enqueue_ldl(calipso_hip_solver* s) {
-    const int NP = s->d.NP, nblk = NP / NB;
-    hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DIAG_THREADS), 0, s->stream, NP, s->d.nx, 0, s->S, s->Dx, s->Tinv, s->icount);
+    const int NP = s->d.NP, nblk = NP / NB, tb = NP < TB ? NP : TB;
+    hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DIAG_THREADS), 0, s->stream, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, s->icount);
     for (int kb = 0; kb + 1 < nblk; ++kb) {
         const int k0 = kb * NB;
         const int rows = NP - k0 - NB;
-        hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64), dim3(1024), 0, s->stream, NP, k0, s->S, s->Dx, s->Tinv, s->Ypanel);
+        hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64), dim3(1024), 0, s->stream, NP, k0, tb, s->S, s->Dx, s->Tinv, s->Ypanel);
         const int ntr = rows / TT, ntiles = ntr * (ntr + 1) / 2;
         // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
-        hipLaunchKernelGGL(k_ldl_trailing, dim3(ntiles), dim3(TR_THREADS), 0, s->stream, NP, s->d.nx, k0, s->S, s->Ypanel, s->Dx, s->Tinv, s->icount);
+        hipLaunchKernelGGL(k_ldl_trailing, dim3(ntiles), dim3(TR_THREADS), 0, s->stream, NP, s->d.nx, k0, tb, s->S, s->Ypanel, s->Dx, s->Tinv, s->icount);
     }
     const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
     for (int level = 1; level <= 3; ++level) {
         const int half = 32 << level, tiles = half / 64, pairs = NP / (2 * half);
+        if (2 * half > tb) break;
         for (int phase = 0; phase < 2; ++phase)
-            hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles), dim3(1024), mg_lds, s->stream, NP, half, phase, s->S, s->Tinv, s->Ttmp);
+            hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles), dim3(1024), mg_lds, s->stream, NP, tb, half, phase, s->S, s->Tinv, s->Ttmp);
     }
 }
 
@@ -385,19 +386,19 @@ static void enqueue_ldl(calipso_hip_solver* s) {
 
 // u_k = Tinv_k b_k (lower-triangular mat-vec, lanes along rows); also z_k = u_k / D.  32 rows per workgroup, 8 column parts of
 // 64 columns; each lane issues ALL its loads before using any (these kernels are latency-bound: one round trip, not four).
-__global__ __launch_bounds__(256) void k_trsv_block_n(int kb, const double* __restrict__ Tinv, const double* __restrict__ b, const double* __restrict__ Dx,
+__global__ __launch_bounds__(256) void k_trsv_block_n(int kb, int tb, const double* __restrict__ Tinv, const double* __restrict__ b, const double* __restrict__ Dx,
                                                        double* __restrict__ u, double* __restrict__ z) {
     __shared__ double bs[TB];
     __shared__ double part[8][32];
-    const int tid = threadIdx.x, k0 = kb * TB;
+    const int tid = threadIdx.x, k0 = kb * tb;
     const int r = tid & 31, p = tid >> 5;
     const int row = blockIdx.x * 32 + r;
-    const double* T = Tinv + (size_t)kb * TB * TB + row;
+    const double* T = Tinv + (size_t)kb * tb * tb + row;
     const int cend = blockIdx.x * 32 + 32;         // lower triangular: columns beyond the workgroup's last row are zero
     double v[TB / 8];
 #pragma unroll
-    for (int q = 0; q < TB / 8; ++q) { const int c = p + 8 * q; v[q] = (c < cend) ? T[(size_t)c * TB] : 0.0; }
-    for (int i = tid; i < TB; i += 256) bs[i] = b[k0 + i];
+    for (int q = 0; q < TB / 8; ++q) { const int c = p + 8 * q; v[q] = (c < cend) ? T[(size_t)c * tb] : 0.0; }
+    for (int i = tid; i < TB; i += 256) bs[i] = i < tb ? b[k0 + i] : 0.0;
     __syncthreads();
     double acc = 0.0;
 #pragma unroll
@@ -441,16 +442,16 @@ __global__ __launch_bounds__(256) void k_trsv_update_n(int NP, int kb, const dou
 }
 
 // v_k = Tinv_k' z_k : one wavefront per column (4 columns per workgroup), lanes stride down the column
-__global__ __launch_bounds__(256) void k_trsv_block_t(int kb, const double* __restrict__ Tinv, const double* __restrict__ z, double* __restrict__ v) {
+__global__ __launch_bounds__(256) void k_trsv_block_t(int kb, int tb, const double* __restrict__ Tinv, const double* __restrict__ z, double* __restrict__ v) {
     __shared__ double zs[TB];
-    const int tid = threadIdx.x, lane = tid & 63, k0 = kb * TB;
-    for (int i = tid; i < TB; i += 256) zs[i] = z[k0 + i];
+    const int tid = threadIdx.x, lane = tid & 63, k0 = kb * tb;
+    for (int i = tid; i < TB; i += 256) zs[i] = i < tb ? z[k0 + i] : 0.0;
     __syncthreads();
     const int c = blockIdx.x * 4 + (tid >> 6);
-    const double* T = Tinv + (size_t)kb * TB * TB + (size_t)c * TB;
+    const double* T = Tinv + (size_t)kb * tb * tb + (size_t)c * tb;
     double tv[TB / 64];
 #pragma unroll
-    for (int q = 0; q < TB / 64; ++q) { const int r = lane + 64 * q; tv[q] = (r >= (c & ~63)) ? T[r] : 0.0; }   // column c is zero above row c
+    for (int q = 0; q < TB / 64; ++q) { const int r = lane + 64 * q; tv[q] = (r >= (c & ~63) && r < tb) ? T[r] : 0.0; }   // column c is zero above row c
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < TB / 64; ++q) acc += tv[q] * zs[lane + 64 * q];
@@ -478,16 +479,16 @@ __global__ __launch_bounds__(256) void k_trsv_update_t(int NP, int kb, const dou
 
 // x (length NP, padded entries zero) <- S^-1 x
 static void enqueue_trsv(calipso_hip_solver* s, double* x) {
-    const int NP = s->d.NP, nb = NP / TB;
+    const int NP = s->d.NP, tb = NP < TB ? NP : TB, nb = NP / tb;
     double* u = s->zf;         // forward result (unscaled), consumed by the updates
     double* z = s->zf2;        // D^-1 u, then overwritten block by block with v
     for (int kb = 0; kb < nb; ++kb) {
-        hipLaunchKernelGGL(k_trsv_block_n, dim3(TB / 32), dim3(256), 0, s->stream, kb, s->Tinv, x, s->Dx, u, z);
+        hipLaunchKernelGGL(k_trsv_block_n, dim3(tb / 32), dim3(256), 0, s->stream, kb, tb, s->Tinv, x, s->Dx, u, z);
         const int rest = NP - (kb + 1) * TB;
         if (rest > 0) hipLaunchKernelGGL(k_trsv_update_n, dim3(rest / 32), dim3(256), 0, s->stream, NP, kb, s->S, u, x);
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
-        hipLaunchKernelGGL(k_trsv_block_t, dim3(TB / 4), dim3(256), 0, s->stream, kb, s->Tinv, z, x);
+        hipLaunchKernelGGL(k_trsv_block_t, dim3(tb / 4), dim3(256), 0, s->stream, kb, tb, s->Tinv, z, x);
         if (kb > 0) hipLaunchKernelGGL(k_trsv_update_t, dim3(kb * TB / 4), dim3(256), 0, s->stream, NP, kb, s->S, x, z);
     }
 }
