@@ -170,7 +170,7 @@ int32_t calipso_hip_destroy(H* s) {
                     s->solution, s->candidate, s->lambda, s->parameters, s->residual, s->residual_error, s->step, s->step_correction,
                     s->saved_point, s->saved_g, s->saved_h, s->residual_symmetric, s->step_symmetric, s->merit_gradient, s->Kdense, s->S,
                     s->Dx, s->Ypanel, s->Tinv, s->Ttmp, s->zf2, s->WH, s->wz, s->kzz, s->Wsoc, s->Bsoc, s->socwork, s->gemv_partial, s->vtmp, s->xbuf, s->zf,
-                    s->t1, s->t2, s->lgp, s->gp, s->hp, s->jacobian_parameters, s->solution_sensitivity, s->multi_rhs, s->qp.q, s->qp.bh};
+                    s->t1, s->t2, s->lgp, s->gp, s->hp, s->jacobian_parameters, s->solution_sensitivity, s->multi_rhs, s->dsym_multi, s->qp.q, s->qp.bh};
     for (double* p : dp) if (p) (void)hipFree(p);
     int* ip[] = {s->icount, s->tile_list, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
     for (int* p : ip) if (p) (void)hipFree(p);
@@ -723,13 +723,24 @@ int32_t calipso_hip_differentiate(H* s, calipso_eval_fn eval, void* user) {
     rc = do_factorize(s, in);                      // :13-20 (same regularisation as the last search direction)
     if (rc < 0) return rc;
     launch_jacobian_parameters(s);                 // :23
-    // :29-58 — one condensed solve per parameter column (no refinement, as the reference)
-    double* save_res = s->residual_error; double* save_step = s->step_correction;
-    for (int i = 0; i < d.np; ++i) {
-        CK(hipMemcpyAsync(save_res, s->jacobian_parameters + (size_t)i * d.N, sizeof(double) * d.N, hipMemcpyDeviceToDevice, s->stream));
-        do_sds(s, 1, nullptr);
-        launch_negate_copy(s, save_step, s->solution_sensitivity + (size_t)i * d.N, d.N);
+    // :29-58 — the reference solves one condensed system per parameter column (no refinement); here all np columns go through
+    // the same factors together: condensation per column, mat-vecs as GEMMs, block triangular solves as TRSMs
+    const int p = d.np;
+    const size_t NPd = d.NP, M = d.m, n = d.n;
+    if (!s->multi_rhs) {
+        if (dalloc(s, &s->multi_rhs, (n + 3 * NPd + 2 * M) * (size_t)p) || dalloc(s, &s->dsym_multi, n * (size_t)p)) return CALIPSO_ERR_HIP;
     }
+    double* rsymM = s->multi_rhs;                  // n  x p   condensed right-hand sides
+    double* xbufM = rsymM + n * p;                 // NP x p   b_x (zero padded) -> dx
+    double* uM = xbufM + NPd * p;                  // NP x p   forward-substitution scratch
+    double* zM = uM + NPd * p;                     // NP x p
+    double* t1M = zM + NPd * p;                    // m  x p   Omega b_m
+    double* t2M = t1M + M * p;                     // m  x p   [gx; hx] dx
+    launch_residual_symmetric_multi(s, s->jacobian_parameters, p, rsymM, xbufM, t1M);
+    if (d.m) gemm(s, d.nx, p, d.m, 1.0, s->Z, d.m, true, t1M, d.m, 1.0, xbufM, d.NP);      // b_x + [gx; hx]' Omega b_m
+    trsm_multi(s, xbufM, p, uM, zM);                                                        // dx = S^-1 (...)
+    if (d.m) gemm(s, d.m, p, d.nx, 1.0, s->Z, d.m, false, xbufM, d.NP, 0.0, t2M, d.m);      // [gx; hx] dx
+    launch_recover_multi(s, s->jacobian_parameters, p, rsymM, xbufM, t2M, s->solution_sensitivity, -1.0);   // :54-56 sensitivity = -step
     SYNC();
     return CALIPSO_OK;
 }

@@ -138,7 +138,8 @@ struct calipso_hip_solver {
     double *saved_g = nullptr, *saved_h = nullptr;                          // ne, nc (benchmark-mode restore)
     double *lgp = nullptr, *gp = nullptr, *hp = nullptr;                    // nx*np, ne*np, nc*np parameter Jacobians
     std::vector<double> hparams;
-    double* multi_rhs = nullptr;  // workspace for differentiate (allocated on demand)
+    double* multi_rhs = nullptr;  // workspace of the multi-right-hand-side solve of differentiate! (allocated on demand)
+    double* dsym_multi = nullptr; // n * np
     hipEvent_t ev[16];
     hipGraphExec_t graph_ldl = nullptr, graph_trsv = nullptr;   // captured once per handle (fixed launch sequences)
     bool graph_ldl_tried = false, graph_trsv_tried = false, use_graphs = true;
@@ -192,6 +193,12 @@ void launch_jacobian_parameters(calipso_hip_solver* s);        // residual_jacob
 void launch_negate_copy(calipso_hip_solver* s, const double* src, double* dst, int n);
 void linear_solve_device(calipso_hip_solver* s);               // middle of the condensed solve (operands from k_residual_symmetric)
 void launch_solve_from_b(calipso_hip_solver* s);               // step_symmetric = K^-1 residual_symmetric for a caller-provided b
+// gemm.hip
+void gemm(calipso_hip_solver* s, int M, int N, int K, double alpha, const double* A, int lda, bool transA, const double* B, int ldb, double beta,
+          double* C, int ldc);
+void trsm_multi(calipso_hip_solver* s, double* X, int p, double* U, double* Zm);
+void launch_residual_symmetric_multi(calipso_hip_solver* s, const double* res, int p, double* rsym, double* xbuf, double* t1);
+void launch_recover_multi(calipso_hip_solver* s, const double* res, int p, const double* rsym, const double* xbuf, const double* t2, double* step, double scale);
 // qp.hip
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 

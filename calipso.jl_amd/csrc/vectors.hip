@@ -89,9 +89,14 @@ void launch_violations(calipso_hip_solver* s) {
 
 // residual_symmetric!   residual.jl:53-101 (condensed right-hand side b).  The same kernel also emits the first operands of
 // the condensed solve: xbuf = [b_x; 0 padding] and t1 = Omega b_m (omega_y b_y ; Omega_z b_z), see solvek.hip.
-__global__ void k_residual_symmetric(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res,
-                                     const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ rsym,
-                                     double* __restrict__ xbuf, double* __restrict__ t1) {
+__global__ void k_residual_symmetric(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res_,
+                                     const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ rsym_,
+                                     double* __restrict__ xbuf_, double* __restrict__ t1_) {
+    // blockIdx.y = right-hand-side column (differentiate!: one column per parameter); columns are N / n / NP / m apart
+    const double* res = res_ + (size_t)blockIdx.y * d.N;
+    double* rsym = rsym_ + (size_t)blockIdx.y * d.n;
+    double* xbuf = xbuf_ + (size_t)blockIdx.y * d.NP;
+    double* t1 = t1_ + (size_t)blockIdx.y * d.m;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const double Hrr = sc.rho + sc.ep;   // H[r,r] = rho then += eps_p  (residual_jacobian_variables.jl:60,87)
     const double Hss = 0.0 + sc.ep;      // H[s,s]
@@ -145,15 +150,27 @@ void launch_residual_symmetric(calipso_hip_solver* s, const double* res) {
     hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
                        s->wz, s->Wsoc, s->residual_symmetric, s->xbuf, s->t1);
 }
+void launch_residual_symmetric_multi(calipso_hip_solver* s, const double* res, int p, double* rsym, double* xbuf, double* t1) {
+    const int work = s->d.NP + s->d.ne + s->d.q + s->d.n_soc;
+    hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128, p), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
+                       s->wz, s->Wsoc, rsym, xbuf, t1);
+}
 
 // Tail of the condensed solve + search_direction_symmetric! (search_direction.jl:38-101) in one kernel:
 //   [dy; dz] = -Omega (b_m - [gx; hx] dx)      (back-substitution through the constraint pivots; t2 = [gx; hx] dx)
 //   scatter (dx, dy, dz); recover dr, ds, dt (diagonal for nonnegative entries, arrow inverses for second-order cones)
 //   optionally accumulate += step  (iterative_refinement.jl:34: step .+= step_correction)
-__global__ void k_recover(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res,
-                          const double* __restrict__ b, const double* __restrict__ dx, const double* __restrict__ t2,
-                          const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ dsym,
-                          double* __restrict__ step, double* __restrict__ accum) {
+__global__ void k_recover(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res_,
+                          const double* __restrict__ b_, const double* __restrict__ dx_, const double* __restrict__ t2_,
+                          const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ dsym_,
+                          double* __restrict__ step_, double* __restrict__ accum) {
+    // blockIdx.y = right-hand-side column (see k_residual_symmetric); dsym_ may be null for the multi-column use
+    const double* res = res_ + (size_t)blockIdx.y * d.N;
+    const double* b = b_ + (size_t)blockIdx.y * d.n;
+    const double* dx = dx_ + (size_t)blockIdx.y * d.NP;
+    const double* t2 = t2_ + (size_t)blockIdx.y * d.m;
+    double* dsym = dsym_ + (size_t)blockIdx.y * d.n;
+    double* step = step_ + (size_t)blockIdx.y * d.N;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const double Hrr = sc.rho + sc.ep, Hss = 0.0 + sc.ep;
     if (i < d.nx) {
@@ -221,6 +238,20 @@ void launch_recover(calipso_hip_solver* s, double* step, const double* res, doub
     const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
     hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
                        s->residual_symmetric, s->xbuf, s->t2, s->wz, s->Wsoc, s->step_symmetric, step, accumulate);
+}
+__global__ void k_scale_inplace(size_t n, double* __restrict__ x, double a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = a * x[i];
+}
+// all p columns at once; rsym is reused as the dsym scratch (each lane reads b before the same lane writes dsym)
+void launch_recover_multi(calipso_hip_solver* s, const double* res, int p, const double* rsym, const double* xbuf, const double* t2, double* step, double scale) {
+    const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
+    hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128, p), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
+                       rsym, xbuf, t2, s->wz, s->Wsoc, s->dsym_multi, step, (double*)nullptr);
+    if (scale != 1.0) {
+        const size_t n = (size_t)s->d.N * p;
+        hipLaunchKernelGGL(k_scale_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, step, scale);
+    }
 }
 
 // candidate x, r (, s) = solution - step_size * step    solve.jl:224-229, 268-276

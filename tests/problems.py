@@ -172,6 +172,54 @@ class ConicQP:
             _put(out, "cone_dual_jacobian_variables_variables", np.zeros((self.nx, self.nx)))
 
 
+class ParametricConicQP(ConicQP):
+    """ConicQP whose linear data moves with parameters  theta = [dq; db; dh]  (np = nx + ne + nc):
+        min 1/2 x'Px + (q + dq)'x   s.t.  Ax - (b + db) = 0,   (h + dh) - Gx in K
+    so every block of dR/dtheta (residual_jacobian_parameters.jl:1-40) is populated and differentiate! has many right-hand sides."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.np = self.nx + self.ne + self.nc
+        self.parameters = np.zeros(self.np)
+
+    def evaluate(self, flags, x, y, z, theta, out):
+        theta = np.asarray(theta, dtype=np.float64)
+        nx, ne, nc, npar = self.nx, self.ne, self.nc, self.np
+        dq, db, dh = theta[:nx], theta[nx:nx + ne], theta[nx + ne:]
+        q0, b0, h0 = self.q, self.b, self.h
+        self.q, self.b, self.h = q0 + dq, b0 + db, h0 + dh
+        try:
+            super().evaluate(flags, x, y, z, theta, out)
+        finally:
+            self.q, self.b, self.h = q0, b0, h0
+        if flags & OBJECTIVE_JACOBIAN_PARAMETERS:
+            J = np.zeros((nx, npar)); J[:, :nx] = np.eye(nx)
+            _put(out, "objective_jacobian_variables_parameters", J)
+        if flags & EQUALITY_JACOBIAN_PARAMETERS and ne:
+            J = np.zeros((ne, npar)); J[:, nx:nx + ne] = -np.eye(ne)
+            _put(out, "equality_jacobian_parameters", J)
+        if flags & EQUALITY_DUAL_JACOBIAN_PARAMETERS:
+            _put(out, "equality_dual_jacobian_variables_parameters", np.zeros((nx, npar)))
+        if flags & CONE_JACOBIAN_PARAMETERS and nc:
+            J = np.zeros((nc, npar)); J[:, nx + ne:] = np.eye(nc)
+            _put(out, "cone_jacobian_parameters", J)
+        if flags & CONE_DUAL_JACOBIAN_PARAMETERS:
+            _put(out, "cone_dual_jacobian_variables_parameters", np.zeros((nx, npar)))
+
+
+def parametric_conic_qp(nx, ne, n_nn, n_soc, soc_dim, seed=0):
+    rng = np.random.default_rng(seed)
+    nc = n_nn + n_soc * soc_dim
+    Q = rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    P = Q.T @ Q + np.eye(nx)
+    A = rng.standard_normal((ne, nx)) / np.sqrt(nx)
+    G = rng.standard_normal((nc, nx)) / np.sqrt(nx)
+    nn = list(range(1, n_nn + 1))
+    soc = [list(range(n_nn + 1 + j * soc_dim, n_nn + 1 + (j + 1) * soc_dim)) for j in range(n_soc)] or [[]]
+    return ParametricConicQP(P, rng.standard_normal(nx), A, rng.standard_normal(ne), G, rng.random(nc) + 1.0, nonnegative_indices=nn,
+                             second_order_indices=soc, name="parametric_conic_qp")
+
+
 # ---- the reference's test problems ---------------------------------------------------------------
 def wachter():
     """README.md:97-121 = test/solver/wachter.jl:3-15; x* = [1, 0, 0.5] (wachter.jl:47).  BASELINE config C1."""
