@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=6, help="independent problem instances per GPU; 3 are in flight at a time (one per HIP\n"
                     "stream-priority class, which the runtime maps to distinct hardware queues), see calipso.jl_amd/batch.py")
+    ap.add_argument("--lanes", type=int, default=3, help="instances in flight at a time")
     ap.add_argument("--config", default="C3", choices=list(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets two ranks share one GPU")
@@ -119,7 +120,7 @@ def main():
     ids = list(shard_range(world * B, rank, world))          # block-contiguous problem ids of this rank
     inst = [make_instance(pkg, pr, pid, shape, local_rank) for pid in ids]
     solvers = [t[4] for t in inst]
-    batch = BatchSolver(solvers)
+    batch = BatchSolver(solvers, lanes=args.lanes)
 
     def barrier():
         if dist is not None:
@@ -137,10 +138,11 @@ def main():
     barrier()
     ts = time.perf_counter()
     n_single = max(3, min(10, args.steps))
-    sch_alone = []
+    sch_alone, alone = [], []
     for _ in range(n_single):
         solvers[0].newton_step(advance=False)
-        sch_alone.append(solvers[0].phase_times()[7])
+        alone.append(solvers[0].phase_times())
+        sch_alone.append(alone[-1][7])
     solvers[0].synchronize()
     single_rate = n_single / (time.perf_counter() - ts)
     barrier()
@@ -173,6 +175,24 @@ def main():
     sch_ms_concurrent = float(np.mean(sch))
     flops = float(nx) * (nx + 1) * m
     achieved = flops / (sch_ms * 1e-3) * 1e-12
+    # per-phase rooflines from SURVEY.md 8(d)'s algorithmic figures, one instance in flight (HIP-event phase times of the handle)
+    al = np.mean(np.asarray(alone), axis=0)
+    n_cond = nx + m
+    n_r = int(info["refinement_rounds"])
+    t_factor = float(al[1] + al[7] + al[3])                       # cone pivots + Schur complement + LDL^T of S
+    t_solve = float(al[2]) - t_factor                              # condensed solves + recovery + refinement residuals
+    f_survey = n_cond ** 3 / 3.0                                   # dense n^3/3 of 8(d)
+    f_exec = flops + nx ** 3 / 3.0                                 # what the constraint-first order executes
+    b_solves = (1 + n_r) * 2 * 8 * n_cond * (n_cond + 1) / 2       # 8(d): each solve reads the factor twice
+    b_resid = (1 + n_r) * 8.0 * (nx * nx + ne * nx + nc * nx)      # 8(d): matrix-free R - H*step per refinement residual
+    phases = {
+        "factor": {"ms": t_factor, "bound": "mfma", "flops_survey_n3_over_3": f_survey, "flops_executed": f_exec,
+                   "achieved_TFLOPs_survey": f_survey / t_factor * 1e-9, "achieved_TFLOPs_executed": f_exec / t_factor * 1e-9,
+                   "frac_survey": f_survey / t_factor * 1e-9 / FP64_MFMA_PEAK_TFLOPS, "frac_executed": f_exec / t_factor * 1e-9 / FP64_MFMA_PEAK_TFLOPS},
+        "solve_and_refine": {"ms": t_solve, "bound": "hbm", "bytes_survey": b_solves + b_resid, "solves": 1 + n_r,
+                             "achieved_GBs_survey": (b_solves + b_resid) / t_solve * 1e-6, "frac_survey": (b_solves + b_resid) / t_solve * 1e-6 / 8000.0},
+        "whole_step_ms": float(al[6]),
+    }
     traffic = None
     try:   # HBM bytes per launch of k_schur from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C3 shape only)
         if args.config == "C3":
@@ -188,7 +208,8 @@ def main():
                                    args.config, nx, ne, nc, n_nn, n_soc, dim, nx + m, nx + 2 * ne + 3 * nc, B, info["refinement_rounds"]),
                    "instances_per_gpu": B, "instances_in_flight": batch.lanes, "parallelism": "independent problems per GPU (no data-path collective)",
                    "refinement_rounds": info["refinement_rounds"], "factorizations_per_step": info["factorizations"],
-                   "single_instance_steps_per_s": single_rate,
+                   "single_instance_steps_per_s": single_rate, "problems_per_s_of_10_steps": value / 10.0,
+                   "roofline_phases_single_instance": phases,
                    "phase_ms": {"whole_step_gpu": float(np.mean(tot)), "search_direction": float(np.mean(sd)), "schur_mfma": sch_ms,
                                 "ldl_of_schur_complement": float(np.mean(ldl))}},
         "roofline": {"kernel": "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)", "bound": "mfma",

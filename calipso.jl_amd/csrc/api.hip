@@ -99,34 +99,53 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
         int least = 0, greatest = 0;
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         const int k = n_handles.fetch_add(1);
-        const int span = least - greatest;   // numerically lower = higher priority
+        int span = least - greatest;   // numerically lower = higher priority
+        if (const char* e = getenv("CALIPSO_HIP_PRIORITY_CLASSES")) { const int c = atoi(e); if (c >= 1 && c - 1 < span) span = c - 1; }   // experiments
         const int prio = span > 0 ? greatest + (k % (span + 1)) : least;
         CK(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio));
     }
     for (auto& e : s->ev) CK(hipEventCreate(&e));
     const size_t NX = d.nx, NE = d.ne, NC = d.nc, N = d.N, NPd = d.NP, M = d.m, n = d.n;
     int rc = 0;
-    rc |= dalloc(s, &s->Lxx, NX * NX); rc |= dalloc(s, &s->Lsym, NX * NX); rc |= dalloc(s, &s->Z, M * NX); s->gx = s->Z; s->hx = s->Z ? s->Z + NE : nullptr;
-    rc |= dalloc(s, &s->fx, NX); rc |= dalloc(s, &s->gyx, NX); rc |= dalloc(s, &s->hzx, NX); rc |= dalloc(s, &s->gh, M); s->g = s->gh; s->hc = s->gh ? s->gh + NE : nullptr;
-    rc |= dalloc(s, &s->cone_product, NC); rc |= dalloc(s, &s->cone_target, NC); rc |= dalloc(s, &s->barrier_gradient, NC);
-    rc |= dalloc(s, &s->dscal, 64);
-    rc |= dalloc(s, &s->solution, N); rc |= dalloc(s, &s->candidate, N); rc |= dalloc(s, &s->lambda, NE); rc |= dalloc(s, &s->parameters, (size_t)d.np);
-    rc |= dalloc(s, &s->residual, N); rc |= dalloc(s, &s->residual_error, N); rc |= dalloc(s, &s->step, N); rc |= dalloc(s, &s->step_correction, N);
-    rc |= dalloc(s, &s->saved_point, N); rc |= dalloc(s, &s->saved_g, NE); rc |= dalloc(s, &s->saved_h, NC);
-    rc |= dalloc(s, &s->residual_symmetric, n); rc |= dalloc(s, &s->step_symmetric, n); rc |= dalloc(s, &s->merit_gradient, n);
-    rc |= dalloc(s, &s->S, NPd * NPd); rc |= dalloc(s, &s->Dx, NPd); rc |= dalloc(s, &s->Ypanel, NPd * NB);
-    rc |= dalloc(s, &s->Tinv, NPd < 512 ? NPd * NPd : (NPd / 512) * 512 * 512); rc |= dalloc(s, &s->Ttmp, NPd * 128); rc |= dalloc(s, &s->zf2, NPd); rc |= dalloc(s, &s->WH, NC * NX);
-    rc |= dalloc(s, &s->wz, NC); rc |= dalloc(s, &s->kzz, NC);
-    rc |= dalloc(s, &s->Wsoc, (size_t)woff); rc |= dalloc(s, &s->Bsoc, (size_t)woff); rc |= dalloc(s, &s->socwork, (size_t)2 * woff);
-    rc |= dalloc(s, &s->icount, 64);
+    // Every per-instance buffer is carved out of ONE slab (256-byte aligned pieces, same order for every handle of a shape), so
+    // that two handles of the same shape differ by a single pointer offset — what lets a group step them through the same
+    // launches (internal.hpp: Batch).  Shape-only data (tile list, cone index arrays) is outside the slab.
+    std::vector<std::pair<double**, size_t>> carve;
+    auto SL = [&](double** pp, size_t count) { carve.push_back({pp, count ? count : 1}); };
+    double* icount_d = nullptr;
+    SL(&s->Lxx, NX * NX); SL(&s->Lsym, NX * NX); SL(&s->Z, M * NX);
+    SL(&s->fx, NX); SL(&s->gyx, NX); SL(&s->hzx, NX); SL(&s->gh, M);
+    SL(&s->cone_product, NC); SL(&s->cone_target, NC); SL(&s->barrier_gradient, NC);
+    SL(&s->dscal, 64);
+    SL(&s->solution, N); SL(&s->candidate, N); SL(&s->lambda, NE); SL(&s->parameters, (size_t)d.np);
+    SL(&s->residual, N); SL(&s->residual_error, N); SL(&s->step, N); SL(&s->step_correction, N);
+    SL(&s->saved_point, N); SL(&s->saved_g, NE); SL(&s->saved_h, NC);
+    SL(&s->residual_symmetric, n); SL(&s->step_symmetric, n); SL(&s->merit_gradient, n);
+    SL(&s->S, NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, NPd * NB);
+    SL(&s->Tinv, NPd < 512 ? NPd * NPd : (NPd / 512) * 512 * 512); SL(&s->Ttmp, NPd * 128); SL(&s->zf2, NPd); SL(&s->WH, NC * NX);
+    SL(&s->wz, NC); SL(&s->kzz, NC);
+    SL(&s->Wsoc, (size_t)woff); SL(&s->Bsoc, (size_t)woff); SL(&s->socwork, (size_t)2 * woff);
+    SL(&icount_d, 32);                                        // 64 ints
+    const size_t maxdim = std::max(std::max(NX, M), NPd);   // rows of the largest mat-vec (the stacked Jacobian has m = ne + nc rows)
+    SL(&s->gemv_partial, 64 * maxdim);
+    SL(&s->vtmp, 4 * std::max(N, NPd));
+    SL(&s->xbuf, NPd); SL(&s->zf, NPd); SL(&s->t1, M); SL(&s->t2, M);
+    SL(&s->lgp, NX * d.np); SL(&s->gp, NE * d.np); SL(&s->hp, NC * d.np);
+    SL(&s->jacobian_parameters, N * d.np); SL(&s->solution_sensitivity, N * d.np);
+    SL(&s->qp.q, NX); SL(&s->qp.bh, M);
+    size_t total = 0;
+    for (auto& c : carve) total += (c.second + 31) & ~(size_t)31;
+    CK(hipMalloc((void**)&s->slab, total * sizeof(double)));
+    CK(hipMemset(s->slab, 0, total * sizeof(double)));
+    s->slab_doubles = total;
+    {
+        size_t off = 0;
+        for (auto& c : carve) { *c.first = s->slab + off; off += (c.second + 31) & ~(size_t)31; }
+    }
+    s->icount = reinterpret_cast<int*>(icount_d);
+    s->gx = s->Z; s->hx = s->Z + NE; s->g = s->gh; s->hc = s->gh + NE;
     schur_plan(s);
     rc |= dalloc(s, &s->tile_list, s->h_tile_list.size());
-    const size_t maxdim = std::max(std::max(NX, M), NPd);   // rows of the largest mat-vec (the stacked Jacobian has m = ne + nc rows)
-    rc |= dalloc(s, &s->gemv_partial, 64 * maxdim);
-    rc |= dalloc(s, &s->vtmp, 4 * std::max(N, NPd));
-    rc |= dalloc(s, &s->xbuf, NPd); rc |= dalloc(s, &s->zf, NPd); rc |= dalloc(s, &s->t1, M); rc |= dalloc(s, &s->t2, M);
-    rc |= dalloc(s, &s->lgp, NX * d.np); rc |= dalloc(s, &s->gp, NE * d.np); rc |= dalloc(s, &s->hp, NC * d.np);
-    rc |= dalloc(s, &s->jacobian_parameters, N * d.np); rc |= dalloc(s, &s->solution_sensitivity, N * d.np);
     rc |= dalloc(s, &s->cone.soc_start, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.soc_dim, (size_t)d.n_soc);
     rc |= dalloc(s, &s->cone.soc_woff, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.entry_soc, NC);
     if (rc) return CALIPSO_ERR_HIP;
@@ -166,13 +185,9 @@ int32_t calipso_hip_destroy(H* s) {
     if (!s) return CALIPSO_OK;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    double* dp[] = {s->Lxx, s->Lsym, s->Z, s->fx, s->gyx, s->hzx, s->gh, s->cone_product, s->cone_target, s->barrier_gradient, s->dscal,
-                    s->solution, s->candidate, s->lambda, s->parameters, s->residual, s->residual_error, s->step, s->step_correction,
-                    s->saved_point, s->saved_g, s->saved_h, s->residual_symmetric, s->step_symmetric, s->merit_gradient, s->Kdense, s->S,
-                    s->Dx, s->Ypanel, s->Tinv, s->Ttmp, s->zf2, s->WH, s->wz, s->kzz, s->Wsoc, s->Bsoc, s->socwork, s->gemv_partial, s->vtmp, s->xbuf, s->zf,
-                    s->t1, s->t2, s->lgp, s->gp, s->hp, s->jacobian_parameters, s->solution_sensitivity, s->multi_rhs, s->dsym_multi, s->qp.q, s->qp.bh};
+    double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
     for (double* p : dp) if (p) (void)hipFree(p);
-    int* ip[] = {s->icount, s->tile_list, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
+    int* ip[] = {s->tile_list, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
     for (int* p : ip) if (p) (void)hipFree(p);
     if (s->hscal) (void)hipHostFree(s->hscal);
     if (s->hicount) (void)hipHostFree(s->hicount);
@@ -394,7 +409,7 @@ static void do_sds(H* s, int which, double* accumulate = nullptr) {
 // iterative_refinement.jl:1-52
 static int do_refinement(H* s, int* rounds, double* final_norm) {
     const Options& o = s->opt;
-    CK(hipMemsetAsync(s->step_correction, 0, sizeof(double) * s->d.N, s->stream));
+    fill_d(s, s->step_correction, s->d.N, 0.0);
     launch_residual_error(s, s->step);
     if (read_scalars(s, 7, 1)) return CALIPSO_ERR_HIP;
     double norm = s->hscal[7];
@@ -825,7 +840,6 @@ int32_t calipso_hip_qp_attach(H* s, const double* P, const double* q, const doub
     if ((d.ne && (!A || !b)) || (d.nc && (!G || !h))) return CALIPSO_ERR_ARGUMENT;
     CK(hipSetDevice(s->device));
     const size_t nx = d.nx;
-    if (!s->qp.q) { if (dalloc(s, &s->qp.q, nx) || dalloc(s, &s->qp.bh, (size_t)d.m)) return CALIPSO_ERR_HIP; }
     // Lxx = 2c P ; gx = A ; hx = -G   (constant Hessian / Jacobians of the QP); bh = [-b; h]
     CK(hipMemcpyAsync(s->S, P, sizeof(double) * nx * nx, hipMemcpyHostToDevice, s->stream));   // S is free before the first factorisation
     hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((nx * nx + 255) / 256)), dim3(256), 0, s->stream, s->S, s->Lxx, nx * nx, 2.0 * objective_scale);
@@ -860,10 +874,10 @@ int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) {
     const Scalars saved_sc = s->sc;
     std::vector<double> ft, fm; calipso::i64 fi = 0;
     if (!advance) {
-        CK(hipMemcpyAsync(s->saved_point, s->solution, sizeof(double) * d.N, hipMemcpyDeviceToDevice, s->stream));
-        if (d.ne) CK(hipMemcpyAsync(s->saved_g, s->g, sizeof(double) * d.ne, hipMemcpyDeviceToDevice, s->stream));
-        if (d.nc) CK(hipMemcpyAsync(s->saved_h, s->hc, sizeof(double) * d.nc, hipMemcpyDeviceToDevice, s->stream));
-        CK(hipMemcpyAsync(s->dscal + 32, s->dscal, sizeof(double) * 2, hipMemcpyDeviceToDevice, s->stream));
+        copy_d(s, s->saved_point, s->solution, d.N);
+        copy_d(s, s->saved_g, s->g, d.ne);
+        copy_d(s, s->saved_h, s->hc, d.nc);
+        copy_d(s, s->dscal + 32, s->dscal, 2);
         ft = s->filter_theta; fm = s->filter_merit; fi = s->filter_index;
     }
     IterInfo info;
@@ -873,10 +887,10 @@ int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) {
     EV(9);
     if (rc < 0) return rc;
     if (!advance) {
-        CK(hipMemcpyAsync(s->solution, s->saved_point, sizeof(double) * d.N, hipMemcpyDeviceToDevice, s->stream));
-        if (d.ne) CK(hipMemcpyAsync(s->g, s->saved_g, sizeof(double) * d.ne, hipMemcpyDeviceToDevice, s->stream));
-        if (d.nc) CK(hipMemcpyAsync(s->hc, s->saved_h, sizeof(double) * d.nc, hipMemcpyDeviceToDevice, s->stream));
-        CK(hipMemcpyAsync(s->dscal, s->dscal + 32, sizeof(double) * 2, hipMemcpyDeviceToDevice, s->stream));
+        copy_d(s, s->solution, s->saved_point, d.N);
+        copy_d(s, s->g, s->saved_g, d.ne);
+        copy_d(s, s->hc, s->saved_h, d.nc);
+        copy_d(s, s->dscal, s->dscal + 32, 2);
         launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT);
         s->filter_theta = ft; s->filter_merit = fm; s->filter_index = fi;
         const double keep_ep = s->sc.ep, keep_ed = s->sc.ed;

@@ -16,10 +16,11 @@ constexpr int SOC_WAVE_DIM = 8;   // cones larger than this use a whole wavefron
 //   barrier_gradient 1/s_i ; [s1; -s2:]/(s1^2 - |s2:|^2)                       nonnegative.jl:12, second_order.jl:14
 //   product          s_i t_i ; [s't; s1 t2: + t1 s2:]                          nonnegative.jl:15, second_order.jl:17
 //   target           1 ; [1; 0...]                                             nonnegative.jl:26, second_order.jl:42
-__global__ __launch_bounds__(CONE_THREADS) void k_cone(Dims d, ConeDev cd, const double* __restrict__ point, int flags,
+__global__ __launch_bounds__(CONE_THREADS) void k_cone(Batch bt, Dims d, ConeDev cd, const double* __restrict__ point, int flags,
                                                         double* __restrict__ product, double* __restrict__ target,
                                                         double* __restrict__ bgrad, double* __restrict__ dscal) {
     __shared__ double sm[CONE_THREADS / 64];
+    inst_shift(bt, point, product, target, bgrad, dscal);
     const double* s = point + d.os();
     const double* t = point + d.ot();
     const int tid = threadIdx.x;
@@ -84,10 +85,11 @@ __global__ __launch_bounds__(CONE_THREADS) void k_cone(Dims d, ConeDev cd, const
 
 void launch_cone(calipso_hip_solver* s, const double* point, int flags) {
     if (s->d.nc == 0) {
-        if (flags & CALIPSO_CONE_BARRIER) (void)hipMemsetAsync(s->dscal + 1, 0, sizeof(double), s->stream);
+        if (flags & CALIPSO_CONE_BARRIER) fill_d(s, s->dscal + 1, 1, 0.0);
         return;
     }
-    hipLaunchKernelGGL(k_cone, dim3(1), dim3(CONE_THREADS), 0, s->stream, s->d, s->cone, point, flags, s->cone_product,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_cone, dim3(1, 1, B.b.n), dim3(CONE_THREADS), 0, s->stream, B.b, s->d, s->cone, point, flags, s->cone_product,
                        s->cone_target, s->barrier_gradient, s->dscal);
 }
 
@@ -120,25 +122,32 @@ __device__ __forceinline__ void violation_masks(const Dims& d, const ConeDev& cd
     }
 }
 
-__global__ __launch_bounds__(CONE_THREADS) void k_cone_search(Dims d, ConeDev cd, const double* __restrict__ sol,
-                                                               const double* __restrict__ step, double tau, int nk,
+__global__ __launch_bounds__(CONE_THREADS) void k_cone_search(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ sol,
+                                                               const double* __restrict__ step, int nk,
                                                                int* __restrict__ icount) {
+    inst_shift(bt.b, sol, step);
+    inst_shift_i(bt.b, icount);
+    const double tau = bt.sc[blockIdx.z].tau;
     // block 0: slack s with Delta s ; block 1: slack dual t with Delta t   (separate step sizes, solve.jl:190-221)
     const int off = blockIdx.x == 0 ? d.os() : d.ot();
     violation_masks(d, cd, sol + off, step + off, tau, nk, icount + (blockIdx.x == 0 ? 6 : 32));
 }
 
 void launch_cone_search(calipso_hip_solver* s) {
-    (void)hipMemsetAsync(s->icount + 6, 0, 58 * sizeof(int), s->stream);
+    fill_i(s, s->icount + 6, 58, 0);
     if (s->d.nc == 0) return;
     const int nk = (int)s->opt.max_cone_line_search + 1;
-    hipLaunchKernelGGL(k_cone_search, dim3(2), dim3(CONE_THREADS), 0, s->stream, s->d, s->cone, s->solution, s->step, s->sc.tau,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_cone_search, dim3(2, 1, B.b.n), dim3(CONE_THREADS), 0, s->stream, B, s->d, s->cone, s->solution, s->step,
                        nk > 26 ? 26 : nk, s->icount);
 }
 
 // candidate s, t for the chosen step sizes (solve.jl:206-208, 216-218)
-__global__ void k_cone_candidate(Dims d, const double* __restrict__ sol, const double* __restrict__ step, double* __restrict__ cand,
-                                 double a_s, double a_t) {
+struct StepSizes { double a_s[MAX_BATCH], a_t[MAX_BATCH]; };
+__global__ void k_cone_candidate(Batch bt, Dims d, const double* __restrict__ sol, const double* __restrict__ step, double* __restrict__ cand,
+                                 StepSizes a) {
+    inst_shift(bt, sol, step, cand);
+    const double a_s = a.a_s[blockIdx.z], a_t = a.a_t[blockIdx.z];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d.nc) {
         cand[d.os() + i] = sol[d.os() + i] - a_s * step[d.os() + i];
@@ -146,15 +155,21 @@ __global__ void k_cone_candidate(Dims d, const double* __restrict__ sol, const d
     }
 }
 
-void launch_cone_candidate(calipso_hip_solver* s, double a_s, double a_t) {
+void launch_cone_candidate_batch(calipso_hip_solver* s, const double* a_s, const double* a_t) {   // one (a_s, a_t) per covered instance
     if (s->d.nc == 0) return;
-    hipLaunchKernelGGL(k_cone_candidate, dim3((s->d.nc + 255) / 256), dim3(256), 0, s->stream, s->d, s->solution, s->step,
-                       s->candidate, a_s, a_t);
+    const BatchSc B = batch_of(s);
+    StepSizes a;
+    for (int k = 0; k < B.b.n; ++k) { a.a_s[k] = a_s[k]; a.a_t[k] = a_t[k]; }
+    hipLaunchKernelGGL(k_cone_candidate, dim3((s->d.nc + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->solution, s->step,
+                       s->candidate, a);
 }
+void launch_cone_candidate(calipso_hip_solver* s, double a_s, double a_t) { launch_cone_candidate_batch(s, &a_s, &a_t); }
 
 // plain cone_violation(xhat, x, tau) on two device vectors of length nc: icount[6] != 0 <=> violation
-__global__ __launch_bounds__(CONE_THREADS) void k_cone_violation(Dims d, ConeDev cd, const double* __restrict__ xhat,
+__global__ __launch_bounds__(CONE_THREADS) void k_cone_violation(Batch bt, Dims d, ConeDev cd, const double* __restrict__ xhat,
                                                                   const double* __restrict__ x, double tau, int* __restrict__ icount) {
+    inst_shift(bt, xhat, x);
+    inst_shift_i(bt, icount);
     const int tid = threadIdx.x;
     const double omt = 1.0 - tau;
     for (int i = tid; i < d.q; i += blockDim.x)
@@ -171,9 +186,10 @@ __global__ __launch_bounds__(CONE_THREADS) void k_cone_violation(Dims d, ConeDev
 }
 
 void launch_cone_violation_host(calipso_hip_solver* s, const double* xhat_dev, const double* x_dev, double tau) {
-    (void)hipMemsetAsync(s->icount + 6, 0, sizeof(int), s->stream);
+    fill_i(s, s->icount + 6, 1, 0);
     if (s->d.nc == 0) return;
-    hipLaunchKernelGGL(k_cone_violation, dim3(1), dim3(CONE_THREADS), 0, s->stream, s->d, s->cone, xhat_dev, x_dev, tau, s->icount);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_cone_violation, dim3(1, 1, B.b.n), dim3(CONE_THREADS), 0, s->stream, B.b, s->d, s->cone, xhat_dev, x_dev, tau, s->icount);
 }
 
 }  // namespace calipso

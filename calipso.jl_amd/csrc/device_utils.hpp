@@ -4,6 +4,16 @@
 
 namespace calipso {
 
+// ---- instance addressing (internal.hpp: Batch): shift every per-instance pointer of a kernel to the slab of its instance -----
+template <typename... P> __device__ __forceinline__ void inst_shift(const Batch& b, P&... p) {
+    const long long o = b.delta[blockIdx.z];
+    ((p += o), ...);
+}
+template <typename... P> __device__ __forceinline__ void inst_shift_i(const Batch& b, P&... p) {   // 4-byte element buffers
+    const long long o = 2 * b.delta[blockIdx.z];
+    ((p += o), ...);
+}
+
 // ---- wave64 reductions by DPP/shuffle (a CDNA wavefront is 64 lanes) ------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -10,8 +10,9 @@
 
 namespace calipso {
 
-__global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x,
+__global__ __launch_bounds__(256) void k_gemv_t(Batch bt, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x,
                                                  double* __restrict__ y, double alpha, double beta) {
+    inst_shift(bt, A, x, y);
     const int lane = threadIdx.x & 63;
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= cols) return;
@@ -35,14 +36,16 @@ __global__ __launch_bounds__(256) void k_gemv_t(int rows, int cols, const double
 
 void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta) {
     if (cols == 0) return;
-    hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4), dim3(256), 0, s->stream, rows, cols, A, ld, x, y, alpha, beta);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, rows, cols, A, ld, x, y, alpha, beta);
 }
 
 constexpr int GN_ROWS = 256;    // rows per workgroup
 constexpr int GN_MAXCHUNK = 64; // column chunks
 
-__global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(int rows, int cols, int chunk, const double* __restrict__ A, int ld,
+__global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, int rows, int cols, int chunk, const double* __restrict__ A, int ld,
                                                              const double* __restrict__ x, double* __restrict__ partial) {
+    inst_shift(bt, A, x, partial);
     const int i = blockIdx.x * GN_ROWS + threadIdx.x;
     const int c0 = blockIdx.y * chunk;
     const int c1 = min(cols, c0 + chunk);
@@ -63,8 +66,9 @@ __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(int rows, int cols, 
 }
 
 // y = alpha * sum_chunks partial + beta*y: 64 rows per workgroup, 4 lanes per row each summing every 4th chunk in a fixed order
-__global__ __launch_bounds__(256) void k_gemv_n_reduce(int rows, int nchunk, const double* __restrict__ partial, double* __restrict__ y, double alpha, double beta) {
+__global__ __launch_bounds__(256) void k_gemv_n_reduce(Batch bt, int rows, int nchunk, const double* __restrict__ partial, double* __restrict__ y, double alpha, double beta) {
     __shared__ double part[4][64];
+    inst_shift(bt, partial, y);
     const int r = threadIdx.x & 63, p = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + r;
     double acc = 0.0;
@@ -91,9 +95,10 @@ void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, 
     const int chunk = (cols + nchunk - 1) / nchunk;
     nchunk = (cols + chunk - 1) / chunk;
     if (cols == 0) nchunk = 0;
+    const BatchSc B = batch_of(s);
     if (nchunk > 0)
-        hipLaunchKernelGGL(k_gemv_n_partial, dim3(rb, nchunk), dim3(GN_ROWS), 0, s->stream, rows, cols, chunk, A, ld, x, s->gemv_partial);
-    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 63) / 64), dim3(256), 0, s->stream, rows, nchunk, s->gemv_partial, y, alpha, beta);
+        hipLaunchKernelGGL(k_gemv_n_partial, dim3(rb, nchunk, B.b.n), dim3(GN_ROWS), 0, s->stream, B.b, rows, cols, chunk, A, ld, x, s->gemv_partial);
+    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, rows, nchunk, s->gemv_partial, y, alpha, beta);
 }
 
 }  // namespace calipso

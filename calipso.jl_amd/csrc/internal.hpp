@@ -45,6 +45,20 @@ struct Scalars {
     double kappa = 0.1, tau = 0.99, rho = 10.0, ep = 0.0, ep_last = 0.0, ed = 0.0;
 };
 
+// Which problem instances a launch covers.  Every handle carves all its device buffers out of ONE slab with the same layout, so
+// "buffer X of instance k" = "buffer X of the base handle" + delta[k] doubles, for every X.  Kernels take this by value, use
+// blockIdx.z as the instance slot and shift their pointers (device_utils.hpp: inst_shift).  A single handle is a batch of one
+// with delta 0; a group (group.hip) steps several same-shape handles in lockstep through the same launches.
+constexpr int MAX_BATCH = 16;
+struct Batch {
+    int n = 1;                       // gridDim.z
+    long long delta[MAX_BATCH] = {0};
+};
+struct BatchSc {                     // + the per-instance scalars
+    Batch b;
+    Scalars sc[MAX_BATCH];
+};
+
 struct Dims {
     int nx, np, ne, nc, n, N, m;  // m = ne + nc
     int q;                        // number of nonnegative entries (cone-local 0..q-1)
@@ -86,6 +100,8 @@ struct calipso_hip_solver {
     calipso::ConeDev cone;
     calipso::QpEval qp;
     calipso::Stats stats;
+    const calipso::BatchSc* cur = nullptr;   // set by the group driver on its base handle: launches cover these instances
+    double* slab = nullptr; size_t slab_doubles = 0;   // all per-instance device buffers live here (see calipso::Batch)
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -158,6 +174,7 @@ namespace calipso {
 void launch_cone(calipso_hip_solver* s, const double* point, int flags);
 void launch_cone_search(calipso_hip_solver* s);                 // fills icount[6..] violation masks for alpha = 2^-k
 void launch_cone_candidate(calipso_hip_solver* s, double a_s, double a_t);
+void launch_cone_candidate_batch(calipso_hip_solver* s, const double* a_s, const double* a_t);   // one pair per covered instance
 void launch_cone_violation_host(calipso_hip_solver* s, const double* xhat_dev, const double* x_dev, double tau);
 // vectors.hip
 void launch_residual(calipso_hip_solver* s);
@@ -166,6 +183,8 @@ void launch_residual_symmetric(calipso_hip_solver* s, const double* res);   // a
 void launch_recover(calipso_hip_solver* s, double* step, const double* res, double* accumulate);   // back-substitution + recovery (+ accumulate += step)
 void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s);
 void launch_accept(calipso_hip_solver* s, double step_size);
+void launch_axpy_points_batch(calipso_hip_solver* s, const double* step_size, int with_s);
+void launch_accept_batch(calipso_hip_solver* s, const double* step_size);
 void launch_merit(calipso_hip_solver* s, const double* point);  // -> dscal[4] (M), uses dscal[0], dscal[1]
 void launch_merit_gradient(calipso_hip_solver* s);
 void launch_constraint_violation(calipso_hip_solver* s, const double* point);   // -> dscal[5]
@@ -181,6 +200,7 @@ void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, 
 void launch_cone_weights(calipso_hip_solver* s);
 void launch_scale_rows(calipso_hip_solver* s);
 void launch_schur(calipso_hip_solver* s);
+void launch_symmetrize(calipso_hip_solver* s);          // Lsym from the upper triangle of Lxx (for the covered instances)
 void schur_plan(calipso_hip_solver* s);   // host: choose the tile shape, build the tile list
 // ldl.hip
 void launch_ldl(calipso_hip_solver* s);
@@ -203,6 +223,17 @@ void launch_recover_multi(calipso_hip_solver* s, const double* res, int p, const
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 
 int check(calipso_hip_solver* s, hipError_t e, const char* what);
+// the batch a launch on `s` covers: the group's active set if a group is driving `s`, else `s` alone with its own scalars
+inline BatchSc batch_of(const calipso_hip_solver* s) {
+    if (s->cur) return *s->cur;
+    BatchSc b;
+    b.b.n = 1; b.b.delta[0] = 0; b.sc[0] = s->sc;
+    return b;
+}
+// batched fills / copies (vectors.hip) — replace hipMemsetAsync / hipMemcpyAsync on the hot path so that groups are covered
+void fill_d(calipso_hip_solver* s, double* p, size_t n, double v);
+void fill_i(calipso_hip_solver* s, int* p, size_t n, int v);
+void copy_d(calipso_hip_solver* s, double* dst, const double* src, size_t n);
 }  // namespace calipso
 
 #define CK(call)                                                        \

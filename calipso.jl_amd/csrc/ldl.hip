@@ -178,9 +178,11 @@ __device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, in
     }
 }
 
-__global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
+__global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(Batch bt, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
                                                             double* __restrict__ Tinv, int* __restrict__ icount) {
     __shared__ double smem[DIAG_LDS_DOUBLES];
+    inst_shift(bt, S, Dx, Tinv);
+    inst_shift_i(bt, icount);
     diag_block<false>(smem, NP, nx, k0, tb, S, Dx, Tinv, icount);
 }
 
@@ -188,10 +190,11 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(int NP, int nx, int k
 // D[c][r] = sum_k X[c][k] A21[r][k]: MFMA A operand = X (rows c), B operand = A21' so that the 16-lane fast index of the
 // result is the contiguous row index r of the column-major panel.  One workgroup (16 wavefronts) per 64 rows; wavefront
 // (wr, wc) computes the 16 x 16 tile rows 16 wr.., columns 16 wc.. ; X is staged in LDS.
-__global__ __launch_bounds__(1024) void k_ldl_panel(int NP, int k0, int tb, double* __restrict__ S, const double* __restrict__ Dx,
+__global__ __launch_bounds__(1024) void k_ldl_panel(Batch bt, int NP, int k0, int tb, double* __restrict__ S, const double* __restrict__ Dx,
                                                      const double* __restrict__ Tinv, double* __restrict__ Y) {
     __shared__ double Xs[NB * LDT];   // Xs[c][k]
     __shared__ double dinv[NB];
+    inst_shift(bt, S, Dx, Tinv, Y);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fk = lane >> 4;
@@ -235,9 +238,11 @@ constexpr int FUSED_LDS_DOUBLES = TR_LDS_DOUBLES > DIAG_LDS_DOUBLES ? TR_LDS_DOU
 // Tile 0 of the trailing update IS the next diagonal block: its workgroup keeps going and factors that block (diag_block),
 // so the 64-column pivot chain of panel k+1 runs inside this launch, overlapped with the other tiles, and a panel step is two
 // launches (this kernel, then the panel GEMM) instead of three.
-__global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(int NP, int nx, int k0, int tb, double* __restrict__ S, const double* __restrict__ Y,
+__global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, int nx, int k0, int tb, double* __restrict__ S, const double* __restrict__ Y,
                                                              double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount) {
     __shared__ double smem[FUSED_LDS_DOUBLES];
+    inst_shift(bt, S, Y, Dx, Tinv);
+    inst_shift_i(bt, icount);
     double* Ls = smem;                    // Ls[i][k]: rows of the i block of L21
     double* Ys = smem + TT * LDT;         // Ys[j][k]: rows of the j block of Y21
     const int t = blockIdx.x;
@@ -334,9 +339,10 @@ __device__ __forceinline__ void gemm_tile64(const GemmDesc g, int K, double alph
 }
 
 // level 1, 2, 3: half = 64, 128, 256; phase 0: T = L21 * X11 ; phase 1: X21 = -X22 * T
-__global__ __launch_bounds__(1024) void k_tinv_merge(int NP, int tb, int half, int phase, const double* __restrict__ S, double* __restrict__ Tinv,
+__global__ __launch_bounds__(1024) void k_tinv_merge(Batch bt, int NP, int tb, int half, int phase, const double* __restrict__ S, double* __restrict__ Tinv,
                                                       double* __restrict__ Ttmp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    inst_shift(bt, S, Tinv, Ttmp);
     const int tiles = half / 64;                 // tiles per side of the half x half result
     const int pair = blockIdx.x / (tiles * tiles);
     const int tt = blockIdx.x % (tiles * tiles);
@@ -361,21 +367,23 @@ __global__ __launch_bounds__(1024) void k_tinv_merge(int NP, int tb, int half, i
 
 static void enqueue_ldl(calipso_hip_solver* s) {
     const int NP = s->d.NP, nblk = NP / NB, tb = NP < TB ? NP : TB;
-    hipLaunchKernelGGL(k_ldl_diag, dim3(1), dim3(DIAG_THREADS), 0, s->stream, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, s->icount);
+    const Batch bt = batch_of(s).b;
+    const unsigned nz = bt.n;
+    hipLaunchKernelGGL(k_ldl_diag, dim3(1, 1, nz), dim3(DIAG_THREADS), 0, s->stream, bt, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, s->icount);
     for (int kb = 0; kb + 1 < nblk; ++kb) {
         const int k0 = kb * NB;
         const int rows = NP - k0 - NB;
-        hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64), dim3(1024), 0, s->stream, NP, k0, tb, s->S, s->Dx, s->Tinv, s->Ypanel);
+        hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64, 1, nz), dim3(1024), 0, s->stream, bt, NP, k0, tb, s->S, s->Dx, s->Tinv, s->Ypanel);
         const int ntr = rows / TT, ntiles = ntr * (ntr + 1) / 2;
         // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
-        hipLaunchKernelGGL(k_ldl_trailing, dim3(ntiles), dim3(TR_THREADS), 0, s->stream, NP, s->d.nx, k0, tb, s->S, s->Ypanel, s->Dx, s->Tinv, s->icount);
+        hipLaunchKernelGGL(k_ldl_trailing, dim3(ntiles, 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, tb, s->S, s->Ypanel, s->Dx, s->Tinv, s->icount);
     }
     const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
     for (int level = 1; level <= 3; ++level) {
         const int half = 32 << level, tiles = half / 64, pairs = NP / (2 * half);
         if (2 * half > tb) break;
         for (int phase = 0; phase < 2; ++phase)
-            hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles), dim3(1024), mg_lds, s->stream, NP, tb, half, phase, s->S, s->Tinv, s->Ttmp);
+            hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles, 1, nz), dim3(1024), mg_lds, s->stream, bt, NP, tb, half, phase, s->S, s->Tinv, s->Ttmp);
     }
 }
 
@@ -386,10 +394,11 @@ static void enqueue_ldl(calipso_hip_solver* s) {
 
 // u_k = Tinv_k b_k (lower-triangular mat-vec, lanes along rows); also z_k = u_k / D.  32 rows per workgroup, 8 column parts of
 // 64 columns; each lane issues ALL its loads before using any (these kernels are latency-bound: one round trip, not four).
-__global__ __launch_bounds__(256) void k_trsv_block_n(int kb, int tb, const double* __restrict__ Tinv, const double* __restrict__ b, const double* __restrict__ Dx,
+__global__ __launch_bounds__(256) void k_trsv_block_n(Batch bt, int kb, int tb, const double* __restrict__ Tinv, const double* __restrict__ b, const double* __restrict__ Dx,
                                                        double* __restrict__ u, double* __restrict__ z) {
     __shared__ double bs[TB];
     __shared__ double part[8][32];
+    inst_shift(bt, Tinv, b, Dx, u, z);
     const int tid = threadIdx.x, k0 = kb * tb;
     const int r = tid & 31, p = tid >> 5;
     const int row = blockIdx.x * 32 + r;
@@ -416,9 +425,10 @@ __global__ __launch_bounds__(256) void k_trsv_block_n(int kb, int tb, const doub
 }
 
 // b[rows below block kb] -= L[rows, block kb] * u_k      (32 rows per workgroup, 8 column parts of 64 columns, one load batch)
-__global__ __launch_bounds__(256) void k_trsv_update_n(int NP, int kb, const double* __restrict__ S, const double* __restrict__ u, double* __restrict__ b) {
+__global__ __launch_bounds__(256) void k_trsv_update_n(Batch bt, int NP, int kb, const double* __restrict__ S, const double* __restrict__ u, double* __restrict__ b) {
     __shared__ double us[TB];
     __shared__ double part[8][32];
+    inst_shift(bt, S, u, b);
     const int tid = threadIdx.x, k0 = kb * TB;
     const int r = tid & 31, p = tid >> 5;
     const int row = k0 + TB + blockIdx.x * 32 + r;
@@ -442,8 +452,9 @@ __global__ __launch_bounds__(256) void k_trsv_update_n(int NP, int kb, const dou
 }
 
 // v_k = Tinv_k' z_k : one wavefront per column (4 columns per workgroup), lanes stride down the column
-__global__ __launch_bounds__(256) void k_trsv_block_t(int kb, int tb, const double* __restrict__ Tinv, const double* __restrict__ z, double* __restrict__ v) {
+__global__ __launch_bounds__(256) void k_trsv_block_t(Batch bt, int kb, int tb, const double* __restrict__ Tinv, const double* __restrict__ z, double* __restrict__ v) {
     __shared__ double zs[TB];
+    inst_shift(bt, Tinv, z, v);
     const int tid = threadIdx.x, lane = tid & 63, k0 = kb * tb;
     for (int i = tid; i < TB; i += 256) zs[i] = i < tb ? z[k0 + i] : 0.0;
     __syncthreads();
@@ -460,8 +471,9 @@ __global__ __launch_bounds__(256) void k_trsv_block_t(int kb, int tb, const doub
 }
 
 // z[columns left of block kb] -= L[block kb, columns]' v_k : one wavefront per column
-__global__ __launch_bounds__(256) void k_trsv_update_t(int NP, int kb, const double* __restrict__ S, const double* __restrict__ v, double* __restrict__ z) {
+__global__ __launch_bounds__(256) void k_trsv_update_t(Batch bt, int NP, int kb, const double* __restrict__ S, const double* __restrict__ v, double* __restrict__ z) {
     __shared__ double vs[TB];
+    inst_shift(bt, S, v, z);
     const int tid = threadIdx.x, lane = tid & 63, k0 = kb * TB;
     for (int i = tid; i < TB; i += 256) vs[i] = v[k0 + i];
     __syncthreads();
@@ -482,14 +494,16 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
     const int NP = s->d.NP, tb = NP < TB ? NP : TB, nb = NP / tb;
     double* u = s->zf;         // forward result (unscaled), consumed by the updates
     double* z = s->zf2;        // D^-1 u, then overwritten block by block with v
+    const Batch bt = batch_of(s).b;
+    const unsigned nz = bt.n;
     for (int kb = 0; kb < nb; ++kb) {
-        hipLaunchKernelGGL(k_trsv_block_n, dim3(tb / 32), dim3(256), 0, s->stream, kb, tb, s->Tinv, x, s->Dx, u, z);
+        hipLaunchKernelGGL(k_trsv_block_n, dim3(tb / 32, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, s->Tinv, x, s->Dx, u, z);
         const int rest = NP - (kb + 1) * TB;
-        if (rest > 0) hipLaunchKernelGGL(k_trsv_update_n, dim3(rest / 32), dim3(256), 0, s->stream, NP, kb, s->S, u, x);
+        if (rest > 0) hipLaunchKernelGGL(k_trsv_update_n, dim3(rest / 32, 1, nz), dim3(256), 0, s->stream, bt, NP, kb, s->S, u, x);
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
-        hipLaunchKernelGGL(k_trsv_block_t, dim3(tb / 4), dim3(256), 0, s->stream, kb, tb, s->Tinv, z, x);
-        if (kb > 0) hipLaunchKernelGGL(k_trsv_update_t, dim3(kb * TB / 4), dim3(256), 0, s->stream, NP, kb, s->S, x, z);
+        hipLaunchKernelGGL(k_trsv_block_t, dim3(tb / 4, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, s->Tinv, z, x);
+        if (kb > 0) hipLaunchKernelGGL(k_trsv_update_t, dim3(kb * TB / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, kb, s->S, x, z);
     }
 }
 
@@ -521,11 +535,12 @@ static bool replay_or_capture(calipso_hip_solver* s, hipGraphExec_t& exec, bool&
 
 void launch_ldl(calipso_hip_solver* s) {
     ldl_set_attributes();
-    if (!s->use_graphs || !replay_or_capture(s, s->graph_ldl, s->graph_ldl_tried, [&] { enqueue_ldl(s); })) enqueue_ldl(s);
+    // (a group launch covers a changing set of instances: its kernel arguments differ from call to call, so no graph there)
+    if (s->cur || !s->use_graphs || !replay_or_capture(s, s->graph_ldl, s->graph_ldl_tried, [&] { enqueue_ldl(s); })) enqueue_ldl(s);
 }
 
 void launch_trsv(calipso_hip_solver* s, double* x) {
-    if (x != s->xbuf || !s->use_graphs || !replay_or_capture(s, s->graph_trsv, s->graph_trsv_tried, [&] { enqueue_trsv(s, s->xbuf); })) enqueue_trsv(s, x);
+    if (s->cur || x != s->xbuf || !s->use_graphs || !replay_or_capture(s, s->graph_trsv, s->graph_trsv_tried, [&] { enqueue_trsv(s, s->xbuf); })) enqueue_trsv(s, x);
 }
 
 }  // namespace calipso

@@ -7,9 +7,10 @@
 
 namespace calipso {
 
-__global__ __launch_bounds__(1024) void k_qp_objective(int nx, const double* __restrict__ x, const double* __restrict__ Lx,
+__global__ __launch_bounds__(1024) void k_qp_objective(Batch bt, int nx, const double* __restrict__ x, const double* __restrict__ Lx,
                                                         const double* __restrict__ q, double* __restrict__ dscal) {
     __shared__ double sm[16];
+    inst_shift(bt, x, Lx, q, dscal);
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < nx; i += 1024) { a += x[i] * Lx[i]; b += q[i] * x[i]; }
     const double ra = block_sum(a, sm);
@@ -17,7 +18,8 @@ __global__ __launch_bounds__(1024) void k_qp_objective(int nx, const double* __r
     if (threadIdx.x == 0) dscal[0] = 0.5 * ra + rb;
 }
 
-__global__ void k_vec_add(int n, const double* __restrict__ a, const double* __restrict__ b, double sign, double* __restrict__ out) {
+__global__ void k_vec_add(Batch bt, int n, const double* __restrict__ a, const double* __restrict__ b, double sign, double* __restrict__ out) {
+    inst_shift(bt, a, b, out);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + sign * b[i];
 }
@@ -28,31 +30,33 @@ void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t fla
     const double* y = point + d.oy();
     const double* z = point + d.oz();
     double* Lx = s->vtmp + 3 * (size_t)d.N;   // scratch of length >= nx
+    const Batch bt = batch_of(s).b;
+    const unsigned nz = bt.n;
     if (flags & (CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_OBJECTIVE_GRADIENT)) {
         gemv_t(s, d.nx, d.nx, s->Lxx, d.nx, x, Lx, 1.0, 0.0);   // Lxx is symmetric for the QP
         if (flags & CALIPSO_EVAL_OBJECTIVE)
-            hipLaunchKernelGGL(k_qp_objective, dim3(1), dim3(1024), 0, s->stream, d.nx, x, Lx, s->qp.q, s->dscal);
+            hipLaunchKernelGGL(k_qp_objective, dim3(1, 1, nz), dim3(1024), 0, s->stream, bt, d.nx, x, Lx, s->qp.q, s->dscal);
         if (flags & CALIPSO_EVAL_OBJECTIVE_GRADIENT)
-            hipLaunchKernelGGL(k_vec_add, dim3((d.nx + 255) / 256), dim3(256), 0, s->stream, d.nx, Lx, s->qp.q, 1.0, s->fx);
+            hipLaunchKernelGGL(k_vec_add, dim3((d.nx + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.nx, Lx, s->qp.q, 1.0, s->fx);
     }
     const bool want_g = (flags & CALIPSO_EVAL_EQUALITY) && d.ne, want_h = (flags & CALIPSO_EVAL_CONE) && d.nc;
     if (want_g && want_h) {            // [g; h] = [gx; hx] x + [-b; hvec]  — one pass over the stacked Jacobian
         gemv_n(s, d.m, d.nx, s->Z, d.m, x, s->gh, 1.0, 0.0);
-        hipLaunchKernelGGL(k_vec_add, dim3((d.m + 255) / 256), dim3(256), 0, s->stream, d.m, s->gh, s->qp.bh, 1.0, s->gh);
+        hipLaunchKernelGGL(k_vec_add, dim3((d.m + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.m, s->gh, s->qp.bh, 1.0, s->gh);
     } else if (want_g) {
         gemv_n(s, d.ne, d.nx, s->gx, d.m, x, s->g, 1.0, 0.0);
-        hipLaunchKernelGGL(k_vec_add, dim3((d.ne + 255) / 256), dim3(256), 0, s->stream, d.ne, s->g, s->qp.bh, 1.0, s->g);
+        hipLaunchKernelGGL(k_vec_add, dim3((d.ne + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.ne, s->g, s->qp.bh, 1.0, s->g);
     } else if (want_h) {
         gemv_n(s, d.nc, d.nx, s->hx, d.m, x, s->hc, 1.0, 0.0);
-        hipLaunchKernelGGL(k_vec_add, dim3((d.nc + 255) / 256), dim3(256), 0, s->stream, d.nc, s->hc, s->qp.bh + d.ne, 1.0, s->hc);
+        hipLaunchKernelGGL(k_vec_add, dim3((d.nc + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.nc, s->hc, s->qp.bh + d.ne, 1.0, s->hc);
     }
     if (flags & CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT) {
         if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.m, y, s->gyx, 1.0, 0.0);
-        else (void)hipMemsetAsync(s->gyx, 0, sizeof(double) * d.nx, s->stream);
+        else fill_d(s, s->gyx, d.nx, 0.0);
     }
     if (flags & CALIPSO_EVAL_CONE_DUAL_GRADIENT) {
         if (d.nc) gemv_t(s, d.nc, d.nx, s->hx, d.m, z, s->hzx, 1.0, 0.0);
-        else (void)hipMemsetAsync(s->hzx, 0, sizeof(double) * d.nx, s->stream);
+        else fill_d(s, s->hzx, d.nx, 0.0);
     }
     // Hessian / Jacobians are constant for a QP and were installed by calipso_hip_qp_attach
 }

@@ -21,10 +21,13 @@ namespace calipso {
 // second-order cone (:151-164):  B = -(Cs + Cbar_t P)^-1 Cbar_t + D  column by column with the closed-form arrow inverse
 // equality rows (:131-133):      k_y = -1/(rho+ep) + (-ed)
 // Also counts the signs of the pivots of this block (compute_inertia!, linear_solver.jl:33-44) into icount[0..2].
-__global__ __launch_bounds__(1024) void k_cone_weights(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w,
+__global__ __launch_bounds__(1024) void k_cone_weights(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w,
                                                         double* __restrict__ kzz, double* __restrict__ wz, double* __restrict__ Bsoc,
                                                         double* __restrict__ Wsoc, double* __restrict__ work, int* __restrict__ icount) {
     __shared__ int smi[3][16];
+    inst_shift(bt.b, w, kzz, wz, Bsoc, Wsoc, work);
+    inst_shift_i(bt.b, icount);
+    const Scalars sc = bt.sc[blockIdx.z];
     const int tid = threadIdx.x;
     const double* sl = w + d.os();
     const double* t = w + d.ot();
@@ -93,13 +96,15 @@ __global__ __launch_bounds__(1024) void k_cone_weights(Dims d, Scalars sc, ConeD
 }
 
 void launch_cone_weights(calipso_hip_solver* s) {
-    hipLaunchKernelGGL(k_cone_weights, dim3(1), dim3(1024), 0, s->stream, s->d, s->sc, s->cone, s->solution, s->kzz, s->wz, s->Bsoc,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_cone_weights, dim3(1, 1, B.b.n), dim3(1024), 0, s->stream, B, s->d, s->cone, s->solution, s->kzz, s->wz, s->Bsoc,
                        s->Wsoc, s->socwork, s->icount);
 }
 
 // WH = Omega_z * hx  (nc x nx): nonnegative rows scaled by -1/K_zz, second-order rows multiplied by the d x d block W
-__global__ void k_scale_rows(Dims d, ConeDev cd, const double* __restrict__ hx, const double* __restrict__ wz,
+__global__ void k_scale_rows(Batch bt, Dims d, ConeDev cd, const double* __restrict__ hx, const double* __restrict__ wz,
                              const double* __restrict__ Wsoc, double* __restrict__ WH) {
+    inst_shift(bt, hx, wz, Wsoc, WH);
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int col = blockIdx.y;
     if (c >= d.nc) return;
@@ -119,7 +124,8 @@ __global__ void k_scale_rows(Dims d, ConeDev cd, const double* __restrict__ hx, 
 
 void launch_scale_rows(calipso_hip_solver* s) {
     if (s->d.nc == 0) return;
-    hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, s->d.nx), dim3(256), 0, s->stream, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, s->d.nx, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH);
 }
 
 // ---- Schur complement on the fp64 matrix cores -----------------------------------------------------------------------------
@@ -172,11 +178,13 @@ __device__ __forceinline__ void stage_store(double* __restrict__ dst, const doub
     for (int it = 0; it < SLD; ++it) dst[(cbase + it * (SCHUR_THREADS / KT)) * LDK + k] = r[it];
 }
 
-__global__ __launch_bounds__(SCHUR_THREADS) void k_schur(Dims d, Scalars sc, const double* __restrict__ Lsym, const double* __restrict__ gx,
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, const double* __restrict__ Lsym, const double* __restrict__ gx,
                                                           const double* __restrict__ hx, const double* __restrict__ WH, double* __restrict__ S,
                                                           const int* __restrict__ tile_list, int ntiles, int nj) {
     __shared__ double As[TILE * LDK];
     __shared__ double Bs[TILE * LDK];
+    inst_shift(bt.b, Lsym, gx, hx, WH, S);
+    const Scalars sc = bt.sc[blockIdx.z];
     // XCD-aware remap: block b runs on XCD b % 8 (observed dispatch order; used for speed only): each XCD gets a contiguous
     // band of the (row-major) tile list, so the operand columns a band needs are shared through that XCD's L2
     const int chunk = (gridDim.x + 7) / 8;
@@ -249,7 +257,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(Dims d, Scalars sc, con
 }
 
 // identity in the padded rows [nx, NP) of the lower triangle (the tiles only cover what intersects the real triangle)
-__global__ void k_pad_identity(Dims d, double* __restrict__ S) {
+__global__ void k_pad_identity(Batch bt, Dims d, double* __restrict__ S) {
+    inst_shift(bt, S);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = d.nx + blockIdx.y;
     if (i < d.NP && j <= i) S[i + (size_t)j * d.NP] = (i == j) ? 1.0 : 0.0;
@@ -257,8 +266,9 @@ __global__ void k_pad_identity(Dims d, double* __restrict__ S) {
 
 // Lsym[i,j] = Lxx[min(i,j), max(i,j)]: the Hessian as a triu-only factorisation sees it (qdldl.jl:145-147), laid out so the
 // Schur epilogue can read its lower triangle with unit stride.  32 x 32 tiles transposed through LDS.
-__global__ __launch_bounds__(256) void k_symmetrize_upper(int nx, const double* __restrict__ Lxx, double* __restrict__ Lsym) {
+__global__ __launch_bounds__(256) void k_symmetrize_upper(Batch bt, int nx, const double* __restrict__ Lxx, double* __restrict__ Lsym) {
     __shared__ double tile[32][33];
+    inst_shift(bt, Lxx, Lsym);
     const int bi = blockIdx.x, bj = blockIdx.y;   // tile (rows bi, cols bj) of Lsym
     if (bi < bj) {                                // strictly upper tile: plain copy
         for (int c = threadIdx.y; c < 32; c += 8) {
@@ -286,7 +296,8 @@ __global__ __launch_bounds__(256) void k_symmetrize_upper(int nx, const double* 
 
 void launch_symmetrize(calipso_hip_solver* s) {
     const int nt = (s->d.nx + 31) / 32;
-    hipLaunchKernelGGL(k_symmetrize_upper, dim3(nt, nt), dim3(32, 8), 0, s->stream, s->d.nx, s->Lxx, s->Lsym);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_symmetrize_upper, dim3(nt, nt, B.b.n), dim3(32, 8), 0, s->stream, B.b, s->d.nx, s->Lxx, s->Lsym);
 }
 
 // host: tile shape and the list of tiles that intersect { j <= i < nx }, row-major
@@ -309,12 +320,13 @@ void schur_plan(calipso_hip_solver* s) {
 }
 
 void launch_schur(calipso_hip_solver* s) {
-    if (s->hessian_dirty) { launch_symmetrize(s); s->hessian_dirty = false; }
+    if (s->hessian_dirty && !s->cur) { launch_symmetrize(s); s->hessian_dirty = false; }   // (a group refreshes its members itself)
     const int ntiles = (int)s->h_tile_list.size() / 2;
     const int grid = ((ntiles + 7) / 8) * 8;
+    const BatchSc B = batch_of(s);
     if (s->d.NP > s->d.nx)
-        hipLaunchKernelGGL(k_pad_identity, dim3((s->d.NP + 255) / 256, s->d.NP - s->d.nx), dim3(256), 0, s->stream, s->d, s->S);
-    hipLaunchKernelGGL(k_schur, dim3(grid), dim3(SCHUR_THREADS), 0, s->stream, s->d, s->sc, s->Lsym, s->gx, s->hx, s->WH, s->S, s->tile_list, ntiles,
+        hipLaunchKernelGGL(k_pad_identity, dim3((s->d.NP + 255) / 256, s->d.NP - s->d.nx, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->S);
+    hipLaunchKernelGGL(k_schur, dim3(grid, 1, B.b.n), dim3(SCHUR_THREADS), 0, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, s->tile_list, ntiles,
                        s->schur_nj);
 }
 

@@ -10,10 +10,12 @@ namespace calipso {
 constexpr int RT = 1024;  // reduction workgroup size
 
 // residual!(data, problem, idx, solution, kappa, rho, lambda)   residual.jl:1-51
-__global__ void k_residual(Dims d, Scalars sc, const double* __restrict__ w, const double* __restrict__ lam,
+__global__ void k_residual(BatchSc bt, Dims d, const double* __restrict__ w, const double* __restrict__ lam,
                            const double* __restrict__ fx, const double* __restrict__ gyx, const double* __restrict__ hzx,
                            const double* __restrict__ g, const double* __restrict__ hc, const double* __restrict__ prod,
                            const double* __restrict__ targ, double* __restrict__ res) {
+    inst_shift(bt.b, w, lam, fx, gyx, hzx, g, hc, prod, targ, res);
+    const Scalars sc = bt.sc[blockIdx.z];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N) return;
     double v;
@@ -43,17 +45,19 @@ __global__ void k_residual(Dims d, Scalars sc, const double* __restrict__ w, con
 }
 
 void launch_residual(calipso_hip_solver* s) {
-    hipLaunchKernelGGL(k_residual, dim3((s->d.N + 255) / 256), dim3(256), 0, s->stream, s->d, s->sc, s->solution, s->lambda, s->fx,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_residual, dim3((s->d.N + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B, s->d, s->solution, s->lambda, s->fx,
                        s->gyx, s->hzx, s->g, s->hc, s->cone_product, s->cone_target, s->residual);
 }
 
 __device__ __forceinline__ double pnorm_term(double v, int ptype) { return ptype == 2 ? v * v : fabs(v); }
 
 // the reductions of solve.jl:130-135,332-333 and optimality_error.jl:1-27 -> dscal[8..17]
-__global__ __launch_bounds__(RT) void k_violations(Dims d, int ptype, const double* __restrict__ res, const double* __restrict__ w,
+__global__ __launch_bounds__(RT) void k_violations(Batch bt, Dims d, int ptype, const double* __restrict__ res, const double* __restrict__ w,
                                                     const double* __restrict__ g, const double* __restrict__ prod,
                                                     double* __restrict__ dscal) {
     __shared__ double sm[RT / 64];
+    inst_shift(bt, res, w, g, prod, dscal);
     const int tid = threadIdx.x;
     double rp = 0.0, rprim = 0.0, ry = 0.0, rz = 0.0, rt = 0.0, y1 = 0.0, z1 = 0.0, t1 = 0.0, ginf = 0.0, pinf = 0.0;
     for (int i = tid; i < d.N; i += RT) {
@@ -83,15 +87,18 @@ __global__ __launch_bounds__(RT) void k_violations(Dims d, int ptype, const doub
 static int norm_type(double p) { return p == 1.0 ? 1 : (p == 2.0 ? 2 : 0); }
 
 void launch_violations(calipso_hip_solver* s) {
-    hipLaunchKernelGGL(k_violations, dim3(1), dim3(RT), 0, s->stream, s->d, norm_type(s->opt.residual_norm), s->residual, s->solution,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_violations, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B.b, s->d, norm_type(s->opt.residual_norm), s->residual, s->solution,
                        s->g, s->cone_product, s->dscal);
 }
 
 // residual_symmetric!   residual.jl:53-101 (condensed right-hand side b).  The same kernel also emits the first operands of
 // the condensed solve: xbuf = [b_x; 0 padding] and t1 = Omega b_m (omega_y b_y ; Omega_z b_z), see solvek.hip.
-__global__ void k_residual_symmetric(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res_,
+__global__ void k_residual_symmetric(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res_,
                                      const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ rsym_,
                                      double* __restrict__ xbuf_, double* __restrict__ t1_) {
+    inst_shift(bt.b, w, res_, wz, Wsoc, rsym_, xbuf_, t1_);
+    const Scalars sc = bt.sc[blockIdx.z];
     // blockIdx.y = right-hand-side column (differentiate!: one column per parameter); columns are N / n / NP / m apart
     const double* res = res_ + (size_t)blockIdx.y * d.N;
     double* rsym = rsym_ + (size_t)blockIdx.y * d.n;
@@ -147,12 +154,14 @@ __global__ void k_residual_symmetric(Dims d, Scalars sc, ConeDev cd, const doubl
 
 void launch_residual_symmetric(calipso_hip_solver* s, const double* res) {
     const int work = s->d.NP + s->d.ne + s->d.q + s->d.n_soc;
-    hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128, 1, B.b.n), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
                        s->wz, s->Wsoc, s->residual_symmetric, s->xbuf, s->t1);
 }
 void launch_residual_symmetric_multi(calipso_hip_solver* s, const double* res, int p, double* rsym, double* xbuf, double* t1) {
     const int work = s->d.NP + s->d.ne + s->d.q + s->d.n_soc;
-    hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128, p), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
+    const BatchSc B = batch_of(s);   // (the multi-column path is single-instance)
+    hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128, p, 1), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
                        s->wz, s->Wsoc, rsym, xbuf, t1);
 }
 
@@ -160,10 +169,13 @@ void launch_residual_symmetric_multi(calipso_hip_solver* s, const double* res, i
 //   [dy; dz] = -Omega (b_m - [gx; hx] dx)      (back-substitution through the constraint pivots; t2 = [gx; hx] dx)
 //   scatter (dx, dy, dz); recover dr, ds, dt (diagonal for nonnegative entries, arrow inverses for second-order cones)
 //   optionally accumulate += step  (iterative_refinement.jl:34: step .+= step_correction)
-__global__ void k_recover(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res_,
+__global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res_,
                           const double* __restrict__ b_, const double* __restrict__ dx_, const double* __restrict__ t2_,
                           const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ dsym_,
                           double* __restrict__ step_, double* __restrict__ accum) {
+    inst_shift(bt.b, w, res_, b_, dx_, t2_, wz, Wsoc, dsym_, step_);
+    if (accum) inst_shift(bt.b, accum);
+    const Scalars sc = bt.sc[blockIdx.z];
     // blockIdx.y = right-hand-side column (see k_residual_symmetric); dsym_ may be null for the multi-column use
     const double* res = res_ + (size_t)blockIdx.y * d.N;
     const double* b = b_ + (size_t)blockIdx.y * d.n;
@@ -236,7 +248,8 @@ __global__ void k_recover(Dims d, Scalars sc, ConeDev cd, const double* __restri
 
 void launch_recover(calipso_hip_solver* s, double* step, const double* res, double* accumulate) {
     const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
-    hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128, 1, B.b.n), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
                        s->residual_symmetric, s->xbuf, s->t2, s->wz, s->Wsoc, s->step_symmetric, step, accumulate);
 }
 __global__ void k_scale_inplace(size_t n, double* __restrict__ x, double a) {
@@ -246,7 +259,8 @@ __global__ void k_scale_inplace(size_t n, double* __restrict__ x, double a) {
 // all p columns at once; rsym is reused as the dsym scratch (each lane reads b before the same lane writes dsym)
 void launch_recover_multi(calipso_hip_solver* s, const double* res, int p, const double* rsym, const double* xbuf, const double* t2, double* step, double scale) {
     const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
-    hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128, p), dim3(128), 0, s->stream, s->d, s->sc, s->cone, s->solution, res,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128, p, 1), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
                        rsym, xbuf, t2, s->wz, s->Wsoc, s->dsym_multi, step, (double*)nullptr);
     if (scale != 1.0) {
         const size_t n = (size_t)s->d.N * p;
@@ -255,33 +269,48 @@ void launch_recover_multi(calipso_hip_solver* s, const double* res, int p, const
 }
 
 // candidate x, r (, s) = solution - step_size * step    solve.jl:224-229, 268-276
-__global__ void k_axpy_points(Dims d, const double* __restrict__ sol, const double* __restrict__ step, double* __restrict__ cand,
-                              double a, int with_s) {
+struct PerInst { double v[MAX_BATCH]; };
+__global__ void k_axpy_points(Batch bt, Dims d, const double* __restrict__ sol, const double* __restrict__ step, double* __restrict__ cand,
+                              PerInst av, int with_s) {
+    inst_shift(bt, sol, step, cand);
+    const double a = av.v[blockIdx.z];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lim = with_s ? d.n : d.nx + d.ne;
     if (i < lim) cand[i] = sol[i] - a * step[i];
 }
-void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s) {
-    hipLaunchKernelGGL(k_axpy_points, dim3((s->d.n + 255) / 256), dim3(256), 0, s->stream, s->d, s->solution, s->step, s->candidate,
-                       step_size, with_s);
+void launch_axpy_points_batch(calipso_hip_solver* s, const double* step_size, int with_s) {   // one step size per covered instance
+    const BatchSc B = batch_of(s);
+    PerInst av;
+    for (int k = 0; k < B.b.n; ++k) av.v[k] = step_size[k];
+    hipLaunchKernelGGL(k_axpy_points, dim3((s->d.n + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->solution, s->step, s->candidate,
+                       av, with_s);
 }
+void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s) { launch_axpy_points_batch(s, &step_size, with_s); }
 
 // accept: x,r,s <- candidate; y,z -= a*step; t <- candidate t    solve.jl:309-326
-__global__ void k_accept(Dims d, double* __restrict__ sol, const double* __restrict__ cand, const double* __restrict__ step, double a) {
+__global__ void k_accept(Batch bt, Dims d, double* __restrict__ sol, const double* __restrict__ cand, const double* __restrict__ step, PerInst av) {
+    inst_shift(bt, sol, cand, step);
+    const double a = av.v[blockIdx.z];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N) return;
     if (i < d.n) sol[i] = cand[i];
     else if (i < d.ot()) sol[i] = sol[i] - a * step[i];
     else sol[i] = cand[i];
 }
-void launch_accept(calipso_hip_solver* s, double step_size) {
-    hipLaunchKernelGGL(k_accept, dim3((s->d.N + 255) / 256), dim3(256), 0, s->stream, s->d, s->solution, s->candidate, s->step, step_size);
+void launch_accept_batch(calipso_hip_solver* s, const double* step_size) {
+    const BatchSc B = batch_of(s);
+    PerInst av;
+    for (int k = 0; k < B.b.n; ++k) av.v[k] = step_size[k];
+    hipLaunchKernelGGL(k_accept, dim3((s->d.N + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->solution, s->candidate, s->step, av);
 }
+void launch_accept(calipso_hip_solver* s, double step_size) { launch_accept_batch(s, &step_size); }
 
 // merit(f, r, Phi, kappa, lambda, rho)   merit.jl:2-15  -> dscal[4]
-__global__ __launch_bounds__(RT) void k_merit(Dims d, Scalars sc, const double* __restrict__ point, const double* __restrict__ lam,
+__global__ __launch_bounds__(RT) void k_merit(BatchSc bt, Dims d, const double* __restrict__ point, const double* __restrict__ lam,
                                                double* __restrict__ dscal) {
     __shared__ double sm[RT / 64];
+    inst_shift(bt.b, point, lam, dscal);
+    const Scalars sc = bt.sc[blockIdx.z];
     const double* r = point + d.orr();
     double lr = 0.0, rr = 0.0;
     for (int i = threadIdx.x; i < d.ne; i += RT) { lr += lam[i] * r[i]; rr += r[i] * r[i]; }
@@ -296,12 +325,15 @@ __global__ __launch_bounds__(RT) void k_merit(Dims d, Scalars sc, const double* 
     }
 }
 void launch_merit(calipso_hip_solver* s, const double* point) {
-    hipLaunchKernelGGL(k_merit, dim3(1), dim3(RT), 0, s->stream, s->d, s->sc, point, s->lambda, s->dscal);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_merit, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, point, s->lambda, s->dscal);
 }
 
 // merit_gradient!   merit.jl:17-31
-__global__ void k_merit_gradient(Dims d, Scalars sc, const double* __restrict__ w, const double* __restrict__ lam,
+__global__ void k_merit_gradient(BatchSc bt, Dims d, const double* __restrict__ w, const double* __restrict__ lam,
                                  const double* __restrict__ fx, const double* __restrict__ bgrad, double* __restrict__ grad) {
+    inst_shift(bt.b, w, lam, fx, bgrad, grad);
+    const Scalars sc = bt.sc[blockIdx.z];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.n) return;
     if (i < d.nx) grad[i] = fx[i];
@@ -309,15 +341,17 @@ __global__ void k_merit_gradient(Dims d, Scalars sc, const double* __restrict__ 
     else grad[i] = -1.0 * sc.kappa * bgrad[i - d.nx - d.ne];
 }
 void launch_merit_gradient(calipso_hip_solver* s) {
-    hipLaunchKernelGGL(k_merit_gradient, dim3((s->d.n + 255) / 256), dim3(256), 0, s->stream, s->d, s->sc, s->solution, s->lambda, s->fx,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_merit_gradient, dim3((s->d.n + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B, s->d, s->solution, s->lambda, s->fx,
                        s->barrier_gradient, s->merit_gradient);
 }
 
 // constraint_violation!   constraint_violation.jl:1-13 -> dscal[5]
-__global__ __launch_bounds__(RT) void k_constraint_violation(Dims d, int ptype, const double* __restrict__ point,
+__global__ __launch_bounds__(RT) void k_constraint_violation(Batch bt, Dims d, int ptype, const double* __restrict__ point,
                                                               const double* __restrict__ g, const double* __restrict__ hc,
                                                               double* __restrict__ dscal) {
     __shared__ double sm[RT / 64];
+    inst_shift(bt, point, g, hc, dscal);
     double acc = 0.0;
     for (int i = threadIdx.x; i < d.ne + d.nc; i += RT) {
         const double c = (i < d.ne) ? g[i] - point[d.orr() + i] : hc[i - d.ne] - point[d.os() + i - d.ne];
@@ -330,26 +364,31 @@ __global__ __launch_bounds__(RT) void k_constraint_violation(Dims d, int ptype, 
     }
 }
 void launch_constraint_violation(calipso_hip_solver* s, const double* point) {
-    hipLaunchKernelGGL(k_constraint_violation, dim3(1), dim3(RT), 0, s->stream, s->d, norm_type(s->opt.constraint_norm), point, s->g,
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_constraint_violation, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B.b, s->d, norm_type(s->opt.constraint_norm), point, s->g,
                        s->hc, s->dscal);
 }
 
 // d = dot(merit_gradient, step.primals)   line_search.jl:3,16 -> dscal[6]
-__global__ __launch_bounds__(RT) void k_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+__global__ __launch_bounds__(RT) void k_dot(Batch bt, int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
     __shared__ double sm[RT / 64];
+    inst_shift(bt, a, b, out);
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += RT) acc += a[i] * b[i];
     const double r = block_sum(acc, sm);
     if (threadIdx.x == 0) *out = r;
 }
 void launch_dot_merit(calipso_hip_solver* s) {
-    hipLaunchKernelGGL(k_dot, dim3(1), dim3(RT), 0, s->stream, s->d.n, s->merit_gradient, s->step, s->dscal + 6);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_dot, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B.b, s->d.n, s->merit_gradient, s->step, s->dscal + 6);
 }
 
 // vector part of out = H v (block rows of residual_jacobian_variables.jl:1-108); the mat-vec parts were accumulated
 // into out_x, out_y, out_z beforehand.
-__global__ void k_Hmul_vec(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
+__global__ void k_Hmul_vec(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
                            double* __restrict__ out) {
+    inst_shift(bt.b, w, v, out);
+    const Scalars sc = bt.sc[blockIdx.z];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N) return;
     if (i < d.nx) {
@@ -397,14 +436,17 @@ static void hmul_matvecs(calipso_hip_solver* s, const double* v, double* out) {
 
 void launch_Hmul(calipso_hip_solver* s, const double* v, double* out) {
     hmul_matvecs(s, v, out);
-    hipLaunchKernelGGL(k_Hmul_vec, dim3((s->d.N + 255) / 256), dim3(256), 0, s->stream, s->d, s->sc, s->cone, s->solution, v, out);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_Hmul_vec, dim3((s->d.N + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B, s->d, s->cone, s->solution, v, out);
 }
 
 // residual_error = residual - H*step ; dscal[7] = ||residual_error||_inf   (iterative_refinement.jl:8-12,38-41).
 // One workgroup: the vector part of H*step, the subtraction and the norm in a single pass over the N entries.
-__global__ __launch_bounds__(RT) void k_Hmul_err(Dims d, Scalars sc, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
+__global__ __launch_bounds__(RT) void k_Hmul_err(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
                                                   const double* __restrict__ res, double* __restrict__ e, double* __restrict__ out) {
     __shared__ double sm[RT / 64];
+    inst_shift(bt.b, w, v, res, e, out);
+    const Scalars sc = bt.sc[blockIdx.z];
     const double* sl = w + d.os(); const double* t = w + d.ot();
     const double* vs = v + d.os(); const double* vt = v + d.ot();
     double m = 0.0;
@@ -440,15 +482,50 @@ __global__ __launch_bounds__(RT) void k_Hmul_err(Dims d, Scalars sc, ConeDev cd,
 
 void launch_residual_error(calipso_hip_solver* s, const double* step) {
     hmul_matvecs(s, step, s->residual_error);
-    hipLaunchKernelGGL(k_Hmul_err, dim3(1), dim3(RT), 0, s->stream, s->d, s->sc, s->cone, s->solution, step, s->residual, s->residual_error, s->dscal + 7);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_Hmul_err, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->cone, s->solution, step, s->residual, s->residual_error, s->dscal + 7);
 }
 
-__global__ void k_add(int n, double* __restrict__ y, const double* __restrict__ x) {
+__global__ void k_add(Batch bt, int n, double* __restrict__ y, const double* __restrict__ x) {
+    inst_shift(bt, y, x);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += x[i];
 }
 void launch_add(calipso_hip_solver* s, double* y, const double* x, int len) {
-    hipLaunchKernelGGL(k_add, dim3((len + 255) / 256), dim3(256), 0, s->stream, len, y, x);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_add, dim3((len + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B.b, len, y, x);
+}
+
+// fills / copies of per-instance buffers (one launch covers every instance of the batch)
+__global__ void k_fill_d(Batch bt, double* __restrict__ p, size_t n, double v) {
+    inst_shift(bt, p);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_fill_i(Batch bt, int* __restrict__ p, size_t n, int v) {
+    inst_shift_i(bt, p);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_copy_d(Batch bt, double* __restrict__ dst, const double* __restrict__ src, size_t n) {
+    inst_shift(bt, dst, src);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+void fill_d(calipso_hip_solver* s, double* p, size_t n, double v) {
+    if (!n) return;
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_fill_d, dim3((unsigned)((n + 255) / 256), 1, B.b.n), dim3(256), 0, s->stream, B.b, p, n, v);
+}
+void fill_i(calipso_hip_solver* s, int* p, size_t n, int v) {
+    if (!n) return;
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_fill_i, dim3((unsigned)((n + 255) / 256), 1, B.b.n), dim3(256), 0, s->stream, B.b, p, n, v);
+}
+void copy_d(calipso_hip_solver* s, double* dst, const double* src, size_t n) {
+    if (!n) return;
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_copy_d, dim3((unsigned)((n + 255) / 256), 1, B.b.n), dim3(256), 0, s->stream, B.b, dst, src, n);
 }
 
 // dense condensed K (both triangles, as residual_jacobian_variables.jl:110-167 writes it) for inspection / parity.
