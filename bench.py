@@ -87,11 +87,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=6, help="independent problem instances per GPU; 3 are in flight at a time (one per HIP\n"
+    ap.add_argument("--batch", type=int, default=24, help="independent problem instances per GPU; 3 are in flight at a time (one per HIP\n"
                     "stream-priority class, which the runtime maps to distinct hardware queues), see calipso.jl_amd/batch.py")
-    ap.add_argument("--lanes", type=int, default=3, help="instances in flight at a time")
+    ap.add_argument("--lanes", type=int, default=3, help="host threads / HIP streams driving the units (groups or single instances) concurrently")
+    ap.add_argument("--group", type=int, default=8, help="instances per group: the members of a group are stepped in lockstep through the same\n"
+                    "kernel launches (calipso_hip_group_*); --batch must be a multiple of it")
     ap.add_argument("--config", default="C3", choices=list(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the informational single-instance loop (profiling runs: every launch\n"
+                    "in the trace then carries a whole group)")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets two ranks share one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="testing only: every rank uses this device ordinal")
     args = ap.parse_args()
@@ -117,10 +121,16 @@ def main():
     shape = CONFIGS[args.config]
     B = args.batch
     from calipso_jl_amd.batch import BatchSolver, gather_results, shard_range
+    G = max(1, args.group)
+    assert B % G == 0, "--batch must be a multiple of --group"
     ids = list(shard_range(world * B, rank, world))          # block-contiguous problem ids of this rank
-    inst = [make_instance(pkg, pr, pid, shape, local_rank) for pid in ids]
-    solvers = [t[4] for t in inst]
-    batch = BatchSolver(solvers, lanes=args.lanes)
+    # creation order: the first member of every unit first, so that the streams that carry the launches get distinct priority
+    # classes (handles take class = creation index mod 3, calipso_hip_create)
+    order = [k for k in range(B) if k % G == 0] + [k for k in range(B) if k % G != 0]
+    made = {k: make_instance(pkg, pr, ids[k], shape, local_rank) for k in order}
+    solvers = [made[k][4] for k in range(B)]
+    units = [pkg.Group(solvers[k:k + G]) for k in range(0, B, G)] if G > 1 else solvers
+    batch = BatchSolver(units, lanes=args.lanes)
 
     def barrier():
         if dist is not None:
@@ -130,21 +140,35 @@ def main():
             s.synchronize()
 
     def one_step():
-        return batch.newton_step(advance=False)             # instances run concurrently, one HIP stream each
+        out = batch.newton_step(advance=False)              # units run concurrently, one HIP stream each
+        return [i for u in out for i in u] if G > 1 else out
 
     for _ in range(args.warmup):
         one_step()
     # single-instance latency rate (informational): instance 0 alone, same step
     barrier()
-    ts = time.perf_counter()
     n_single = max(3, min(10, args.steps))
+    single_rate = None
+    if not args.no_single:
+        for _ in range(2):
+            solvers[0].newton_step(advance=False)            # (first single-handle call captures its launch graphs)
+        solvers[0].synchronize()
+        ts = time.perf_counter()
+        for _ in range(n_single):
+            solvers[0].newton_step(advance=False)
+        solvers[0].synchronize()
+        single_rate = n_single / (time.perf_counter() - ts)
+    # unit 0 alone (one group of G instances, or one instance): its launches have the device to themselves, so the HIP-event
+    # durations of its kernels are clean per-launch figures (the roofline below uses them)
+    barrier()
+    ts = time.perf_counter()
     sch_alone, alone = [], []
     for _ in range(n_single):
-        solvers[0].newton_step(advance=False)
-        alone.append(solvers[0].phase_times())
+        units[0].newton_step(advance=False)
+        alone.append(units[0].phase_times())
         sch_alone.append(alone[-1][7])
-    solvers[0].synchronize()
-    single_rate = n_single / (time.perf_counter() - ts)
+    units[0].synchronize()
+    unit_rate = G * n_single / (time.perf_counter() - ts)
     barrier()
     t0 = time.perf_counter()
     sch, ldl, tot, sd = [], [], [], []
@@ -167,24 +191,25 @@ def main():
     nc = n_nn + n_soc * dim
     m = ne + nc
     value = world * B * args.steps / elapsed
-    # dominant kernel: the Schur-complement update S = Lxx + ep*I + Z' Omega Z on the fp64 matrix cores (k_schur).
-    # algorithmic flops per launch = multiply-adds of the lower triangle incl. diagonal: nx (nx+1) m
-    # its launch duration is taken from HIP events on the handle's stream while ONE instance is in flight (the kernel has the
-    # device to itself; with several instances in flight concurrent launches share the CUs and a per-launch time is ill-defined)
+    # dominant kernel: the Schur-complement update S = Lxx + ep*I + Z' Omega Z on the fp64 matrix cores (k_schur); one launch
+    # covers the G instances of a group.  algorithmic flops per launch = G x multiply-adds of the lower triangle incl. diagonal,
+    # nx (nx+1) m each.  Its launch duration is taken from HIP events on the stream while ONE unit is in flight (the kernel has
+    # the device to itself; with several units in flight concurrent launches share the CUs and a per-launch time is ill-defined)
     sch_ms = float(np.mean(sch_alone))
     sch_ms_concurrent = float(np.mean(sch))
-    flops = float(nx) * (nx + 1) * m
+    flops1 = float(nx) * (nx + 1) * m
+    flops = G * flops1
     achieved = flops / (sch_ms * 1e-3) * 1e-12
     # per-phase rooflines from SURVEY.md 8(d)'s algorithmic figures, one instance in flight (HIP-event phase times of the handle)
     al = np.mean(np.asarray(alone), axis=0)
     n_cond = nx + m
     n_r = int(info["refinement_rounds"])
-    t_factor = float(al[1] + al[7] + al[3])                       # cone pivots + Schur complement + LDL^T of S
+    t_factor = float(al[1] + al[7] + al[3])                       # cone pivots + Schur complement + LDL^T of S (G instances)
     t_solve = float(al[2]) - t_factor                              # condensed solves + recovery + refinement residuals
-    f_survey = n_cond ** 3 / 3.0                                   # dense n^3/3 of 8(d)
-    f_exec = flops + nx ** 3 / 3.0                                 # what the constraint-first order executes
-    b_solves = (1 + n_r) * 2 * 8 * n_cond * (n_cond + 1) / 2       # 8(d): each solve reads the factor twice
-    b_resid = (1 + n_r) * 8.0 * (nx * nx + ne * nx + nc * nx)      # 8(d): matrix-free R - H*step per refinement residual
+    f_survey = G * n_cond ** 3 / 3.0                               # dense n^3/3 of 8(d), per instance
+    f_exec = G * (flops1 + nx ** 3 / 3.0)                          # what the constraint-first order executes
+    b_solves = G * (1 + n_r) * 2 * 8 * n_cond * (n_cond + 1) / 2   # 8(d): each solve reads the factor twice
+    b_resid = G * (1 + n_r) * 8.0 * (nx * nx + ne * nx + nc * nx)  # 8(d): matrix-free R - H*step per refinement residual
     phases = {
         "factor": {"ms": t_factor, "bound": "mfma", "flops_survey_n3_over_3": f_survey, "flops_executed": f_exec,
                    "achieved_TFLOPs_survey": f_survey / t_factor * 1e-9, "achieved_TFLOPs_executed": f_exec / t_factor * 1e-9,
@@ -196,7 +221,8 @@ def main():
     traffic = None
     try:   # HBM bytes per launch of k_schur from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C3 shape only)
         if args.config == "C3":
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["calipso::k_schur"]["hbm_bytes_per_launch"]
+            e = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["calipso::k_schur"]
+            traffic = e["hbm_bytes_per_launch"] * G / float(e.get("instances_per_launch", 1))
     except Exception:
         traffic = None
     out = {
@@ -206,16 +232,16 @@ def main():
         "config": {"workload": "%s synthetic dense conic QP: nx=%d ne=%d nc=%d (%d R+ + %d x SOC%d), n=%d condensed, N=%d unreduced; "
                                "%d independent instance(s) per GPU; 1 LDL^T factorisation, %d refinement round(s) per step" % (
                                    args.config, nx, ne, nc, n_nn, n_soc, dim, nx + m, nx + 2 * ne + 3 * nc, B, info["refinement_rounds"]),
-                   "instances_per_gpu": B, "instances_in_flight": batch.lanes, "parallelism": "independent problems per GPU (no data-path collective)",
+                   "instances_per_gpu": B, "instances_per_group": G, "instances_in_flight": batch.lanes * G, "parallelism": "independent problems per GPU (no data-path collective)",
                    "refinement_rounds": info["refinement_rounds"], "factorizations_per_step": info["factorizations"],
-                   "single_instance_steps_per_s": single_rate, "problems_per_s_of_10_steps": value / 10.0,
-                   "roofline_phases_single_instance": phases,
+                   "single_instance_steps_per_s": single_rate, "one_unit_alone_steps_per_s": unit_rate,
+                   "problems_per_s_of_10_steps": value / 10.0, "roofline_phases_one_unit_alone": phases,
                    "phase_ms": {"whole_step_gpu": float(np.mean(tot)), "search_direction": float(np.mean(sd)), "schur_mfma": sch_ms,
                                 "ldl_of_schur_complement": float(np.mean(ldl))}},
         "roofline": {"kernel": "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                      "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": sch_ms,
-                     "avg_launch_ms_with_%d_instances_in_flight" % B: sch_ms_concurrent},
+                     "traffic": traffic, "flops_per_launch": flops, "instances_per_launch": G, "avg_launch_ms": sch_ms,
+                     "avg_launch_ms_with_%d_units_in_flight" % batch.lanes: sch_ms_concurrent},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(shape)

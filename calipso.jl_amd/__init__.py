@@ -12,7 +12,7 @@ import numpy as np
 
 from ._lib import CALLBACK_FN, EVAL_FN, CalipsoHipError, lib
 
-__all__ = ["Solver", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform"]
+__all__ = ["Solver", "Group", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform"]
 
 # evaluate! flags (include/calipso_hip.h)
 FLAGS = dict(
@@ -364,6 +364,57 @@ class Solver:
 
     def synchronize(self):
         self._check(self._L.calipso_hip_synchronize(self._h), "synchronize")
+
+
+class Group:
+    """Up to 16 Solver handles of one shape (same dimensions and cone layout, same device) stepped in lockstep: every kernel
+    launch of a group step covers all members (include/calipso_hip.h, "groups").  The reference has no counterpart — its
+    `Solver`s are independent objects; this is how BASELINE config C4 keeps many of them in flight on one GPU."""
+
+    def __init__(self, solvers):
+        import ctypes as C
+        self.solvers = list(solvers)
+        self._L = self.solvers[0]._L
+        arr = (C.c_void_p * len(self.solvers))(*[s._h for s in self.solvers])
+        h = C.c_void_p()
+        rc = self._L.calipso_hip_group_create(arr, len(self.solvers), C.byref(h))
+        if rc != 0:
+            raise CalipsoHipError("group_create failed (%d): %s" % (rc, self._L.calipso_hip_last_error(self.solvers[0]._h).decode()))
+        self._g = h
+
+    def newton_step(self, advance=False):
+        """calipso_hip_newton_step for every member; returns one info dict per member (same keys as Solver.newton_step)"""
+        import ctypes as C
+        B = len(self.solvers)
+        info = np.zeros(6 * B)
+        status = (C.c_int32 * B)()
+        rc = self._L.calipso_hip_group_newton_step(self._g, int(advance), _pd(info), status)
+        if rc < 0:
+            raise CalipsoHipError("group_newton_step: %s (%d): %s" % (STATUS_TEXT.get(rc, "error"), rc,
+                                                                      self._L.calipso_hip_last_error(self.solvers[0]._h).decode()))
+        out = []
+        for k in range(B):
+            r = info[6 * k: 6 * k + 6]
+            out.append(dict(status=int(status[k]), step_size=r[0], step_size_cone_slack_dual=r[1], refinement_rounds=int(r[2]),
+                            factorizations=int(r[3]), merit_candidate=r[4], violation_candidate=r[5]))
+        return out
+
+    def phase_times(self):
+        return self.solvers[0].phase_times()
+
+    def synchronize(self):
+        self.solvers[0].synchronize()
+
+    def close(self):
+        if self._g is not None:
+            self._L.calipso_hip_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def initialize_b(solver, guess):

@@ -197,6 +197,18 @@ int32_t calipso_hip_qp_evaluate(calipso_hip_solver*, int32_t which, uint32_t fla
  * attached; if `advance` is 0 the iterate is restored afterwards (benchmark mode: every step does identical work).
  * info[0]=step_size info[1]=step_size_t info[2]=refinement rounds info[3]=factorizations info[4]=M_candidate info[5]=theta_candidate */
 int32_t calipso_hip_newton_step(calipso_hip_solver*, int32_t advance, double info[6]);
+/* ---- groups: several handles of one shape stepped in lockstep through the same kernel launches ------------------------------
+ * The reference has no batching: distinct `Solver`s are simply independent; BASELINE config C4 runs many of them
+ * per GPU.  A group covers up to 16 handles created with identical dimensions and cone layout on one device; every launch of a
+ * group step carries all members (the instance is a grid dimension), so the latency-bound parts of the step cost the same for
+ * the whole group as for one handle.  Per member the arithmetic is exactly that of calipso_hip_newton_step.  Members stay
+ * usable through the single-handle entry points between group calls (not concurrently with them). */
+typedef struct calipso_hip_group calipso_hip_group;
+int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, calipso_hip_group** out);
+int32_t calipso_hip_group_destroy(calipso_hip_group*);
+/* calipso_hip_newton_step for every member: info = count x 6 doubles (row per member, fields as above), status = count codes */
+int32_t calipso_hip_group_newton_step(calipso_hip_group*, int32_t advance, double* info, int32_t* status);
+
 /* timing of the last calipso_hip_newton_step / factorisation, in milliseconds, from HIP events on the handle's stream:
  * [0] evaluate + cone + residual + reductions   [1] cone pivots + Omega*hx   [2] search_direction! total (factor + solves + refinement)
  * [3] LDL^T of the Schur complement   [5] cone search + line search + accept   [6] whole step

@@ -1,0 +1,102 @@
+"""GPU: groups — several handles of one shape stepped in lockstep through the same launches (include/calipso_hip.h "groups";
+BASELINE config C4 runs many independent instances per GPU).  Per member the arithmetic must be exactly that of
+stepping the member alone: every comparison below is bit-for-bit."""
+import numpy as np
+import pytest
+
+import problems as pr
+from helpers import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = (300, 140, 40, 20, 3)
+
+
+def build(pkg, pid, shape=SHAPE, indefinite=0.0):
+    nx, ne, n_nn, n_soc, dim = shape
+    prob, pt, lam = pr.synthetic_conic_qp(pkg.splitmix_uniform, pid, nx, ne, n_nn, n_soc, dim)
+    if indefinite:
+        prob.P = prob.P - indefinite * np.eye(nx)      # negative curvature: the inertia test fails at IC-1 and the regularisation loop runs
+    s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices)
+    s.set("solution", np.concatenate([pt[k] for k in "xrsyzt"]))
+    s.set("dual", lam)
+    for name, v in (("central_path", 0.17), ("penalty", 52.0), ("fraction_to_boundary", 0.99)):
+        s.set(name, [v])
+    s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
+    fl = pkg.FLAGS
+    s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
+    s.cone(product=True, target=True)
+    s.synchronize()
+    return s
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_group_step_is_bitwise_the_single_step():
+    pkg = load_pkg()
+    ids = [3, 4, 5, 6]
+    singles = [build(pkg, p) for p in ids]
+    members = [build(pkg, p) for p in ids]
+    g = pkg.Group(members)
+    ref = [s.newton_step(advance=False) for s in singles]
+    got = g.newton_step(advance=False)
+    for r, q, s, m in zip(ref, got, singles, members):
+        assert r == q, (r, q)
+        assert same(s.data("step").all, m.data("step").all)
+        assert same(s.data("residual").all, m.data("residual").all)
+        assert same(s.solution.all, m.solution.all)                      # restored iterate
+    # a second identical call gives identical results (benchmark mode restores the state)
+    again = g.newton_step(advance=False)
+    assert again == got
+    g.close()
+
+
+def test_group_advancing_iterates_stay_bitwise_equal():
+    pkg = load_pkg()
+    ids = [11, 12, 13]
+    singles = [build(pkg, p) for p in ids]
+    members = [build(pkg, p) for p in ids]
+    g = pkg.Group(members)
+    for it in range(4):
+        ref = [s.newton_step(advance=True) for s in singles]
+        got = g.newton_step(advance=True)
+        for r, q, s, m in zip(ref, got, singles, members):
+            assert r == q, (it, r, q)
+            assert same(s.solution.all, m.solution.all), it
+    # members remain usable on their own afterwards
+    r = singles[1].newton_step(advance=True)
+    q = members[1].newton_step(advance=True)
+    assert r == q and same(singles[1].solution.all, members[1].solution.all)
+    g.close()
+
+
+def test_group_members_take_different_paths():
+    """one member needs the regularisation loop of inertia_correction! (inertia.jl:30-80), the others do not: the re-factorisation
+    rounds run on the sub-list of members that need them"""
+    pkg = load_pkg()
+    spec = [(21, 0.0), (22, 6.0), (23, 0.0), (24, 40.0)]
+    singles = [build(pkg, p, indefinite=v) for p, v in spec]
+    members = [build(pkg, p, indefinite=v) for p, v in spec]
+    g = pkg.Group(members)
+    ref = [s.newton_step(advance=True) for s in singles]
+    got = g.newton_step(advance=True)
+    assert [r["factorizations"] for r in ref][0] == 1 and max(r["factorizations"] for r in ref) > 1
+    for r, q, s, m in zip(ref, got, singles, members):
+        assert r == q, (r, q)
+        assert same(s.solution.all, m.solution.all)
+        assert s.get("primal_regularization", 1)[0] == m.get("primal_regularization", 1)[0]
+        assert s.stats() == m.stats()
+    g.close()
+
+
+def test_group_of_one_and_shape_mismatch():
+    pkg = load_pkg()
+    a, b = build(pkg, 31), build(pkg, 31)
+    g = pkg.Group([b])
+    assert a.newton_step(advance=False) == g.newton_step(advance=False)[0]
+    g.close()
+    c = build(pkg, 32, shape=(200, 90, 30, 20, 3))
+    with pytest.raises(pkg.CalipsoHipError):
+        pkg.Group([a, c])
