@@ -295,6 +295,10 @@ class Solver:
     def search_direction(self):
         return self._check(self._L.calipso_hip_search_direction(self._h), "search_direction")
 
+    def search_direction_nonsymmetric(self):
+        """step = H \\ residual on the unreduced system (src/solver/search_direction.jl:106-119), the reference's fallback when refinement fails"""
+        return self._check(self._L.calipso_hip_search_direction_nonsymmetric(self._h), "search_direction_nonsymmetric")
+
     def cone_search(self):
         a, b = C.c_double(0), C.c_double(0)
         self._check(self._L.calipso_hip_cone_search(self._h, C.byref(a), C.byref(b)), "cone_search")

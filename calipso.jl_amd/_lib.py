@@ -37,6 +37,7 @@ SYMBOLS = {
     "calipso_hip_search_direction_symmetric": (_i32, [_vp, _i32]),
     "calipso_hip_iterative_refinement": (_i32, [_vp, _pi32, _pd]),
     "calipso_hip_search_direction": (_i32, [_vp]),
+    "calipso_hip_search_direction_nonsymmetric": (_i32, [_vp]),
     "calipso_hip_cone_search": (_i32, [_vp, _pd, _pd]),
     "calipso_hip_cone_violation": (_i32, [_vp, _pd, _pd, _dbl, _pi32]),
     "calipso_hip_candidate": (_i32, [_vp, _dbl, _i32]),

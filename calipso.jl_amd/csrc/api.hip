@@ -187,6 +187,7 @@ int32_t calipso_hip_destroy(H* s) {
     if (!s) return CALIPSO_OK;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    nonsymmetric_release(s);
     double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
     for (double* p : dp) if (p) (void)hipFree(p);
     int* ip[] = {s->tile_list, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
@@ -446,9 +447,9 @@ static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
         rc = do_refinement(s, rounds, nullptr);
         if (rc < 0) return rc;
         if (rc == CALIPSO_WARN_REFINEMENT) {
-            // The reference falls back to a sparse LU solve of the unreduced system (search_direction.jl:22,113).  The GPU
-            // path keeps the best refined step and reports the warning; see DESIGN.md ("fallback").
-            s->stats.fallbacks += 1;
+            // the reference falls back to `H \ residual` on the unreduced system (search_direction.jl:22,113): fallback.hip
+            const int fr = nonsymmetric_solve(s, s->residual, s->step);
+            if (fr < 0) return fr;
             return CALIPSO_WARN_REFINEMENT;
         }
     }
@@ -682,6 +683,7 @@ int32_t calipso_hip_linear_solve(H* s) {
 }
 int32_t calipso_hip_search_direction_symmetric(H* s, int32_t which) { if (!s) return CALIPSO_ERR_ARGUMENT; do_sds(s, which); return CALIPSO_OK; }
 int32_t calipso_hip_iterative_refinement(H* s, int32_t* rounds, double* final_norm) { if (!s) return CALIPSO_ERR_ARGUMENT; int r = 0; int rc = do_refinement(s, &r, final_norm); if (rounds) *rounds = r; return rc; }
+int32_t calipso_hip_search_direction_nonsymmetric(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; return nonsymmetric_solve(s, s->residual, s->step); }
 int32_t calipso_hip_search_direction(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; return do_search_direction(s, nullptr, nullptr); }
 int32_t calipso_hip_cone_search(H* s, double* a, double* b) { if (!s || !a || !b) return CALIPSO_ERR_ARGUMENT; return do_cone_search(s, a, b); }
 
@@ -1064,7 +1066,11 @@ static int gb_refinement(G* g, const Set& a, std::vector<int>& rc, std::vector<i
             bool finished = false;
             if (it[i] > o.max_iterative_refinement) {        // loop exhausted: fail <=> the final error exceeds the initial one
                 finished = true;
-                if (!(norm[i] <= norm0[i])) { h->stats.refine_fail += 1; h->stats.fallbacks += 1; rc[i] = std::max(rc[i], (int)CALIPSO_WARN_REFINEMENT); }
+                if (!(norm[i] <= norm0[i])) {           // search_direction.jl:22 -> H \ residual on the member's own stream
+                    h->stats.refine_fail += 1;
+                    const int fr = nonsymmetric_solve(h, h->residual, h->step);
+                    rc[i] = fr < 0 ? fr : std::max(rc[i], (int)CALIPSO_WARN_REFINEMENT);
+                }
             } else if (norm[i] <= o.iterative_refinement_tolerance && it[i] >= o.min_iterative_refinement) finished = true;
             if (finished) {
                 rounds[i] = it[i];

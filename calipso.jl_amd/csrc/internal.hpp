@@ -156,6 +156,7 @@ struct calipso_hip_solver {
     std::vector<double> hparams;
     double* multi_rhs = nullptr;  // workspace of the multi-right-hand-side solve of differentiate! (allocated on demand)
     double* dsym_multi = nullptr; // n * np
+    double* Hdense = nullptr; int* lu_ipiv = nullptr;   // fallback.hip: N x N unreduced matrix and pivots (allocated on first use)
     hipEvent_t ev[16];
     hipGraphExec_t graph_ldl = nullptr, graph_trsv = nullptr;   // captured once per handle (fixed launch sequences)
     bool graph_ldl_tried = false, graph_trsv_tried = false, use_graphs = true;
@@ -219,6 +220,9 @@ void gemm(calipso_hip_solver* s, int M, int N, int K, double alpha, const double
 void trsm_multi(calipso_hip_solver* s, double* X, int p, double* U, double* Zm);
 void launch_residual_symmetric_multi(calipso_hip_solver* s, const double* res, int p, double* rsym, double* xbuf, double* t1);
 void launch_recover_multi(calipso_hip_solver* s, const double* res, int p, const double* rsym, const double* xbuf, const double* t2, double* step, double scale);
+// fallback.hip
+int nonsymmetric_solve(calipso_hip_solver* s, const double* res, double* step);   // step = H \\ res (pivoted LU of the unreduced matrix)
+void nonsymmetric_release(calipso_hip_solver* s);
 // qp.hip
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 

@@ -216,6 +216,36 @@ function CALIPSO.linear_solve!(s::HIPLDLSolver, x::Vector{Float64}, A, b::Vector
     return
 end
 
-export HIPSolver, HIPLDLSolver
+# ---- search_direction_nonsymmetric! (src/solver/search_direction.jl:106-119): step = H \ residual on the device ---------------
+function search_direction_nonsymmetric!(hs::HIPSolver)
+    check(hs.handle, ccall((:calipso_hip_search_direction_nonsymmetric, lib), Int32, (Ptr{Cvoid},), hs.handle), "search_direction_nonsymmetric!")
+    return
+end
+
+# ---- groups: many same-shape solvers stepped through the same kernel launches (BASELINE config C4) ------------------------------
+"Up to 16 `HIPSolver`s of one shape on one device; `newton_step!` advances every member by one inner iteration of solve!."
+mutable struct HIPGroup
+    handle::Ptr{Cvoid}
+    members::Vector{HIPSolver}
+end
+function HIPGroup(members::Vector{HIPSolver})
+    hs = Ptr{Cvoid}[m.handle for m in members]
+    g = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:calipso_hip_group_create, lib), Int32, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Ptr{Cvoid}}), hs, length(hs), g)
+    rc == 0 || error("calipso_hip_group_create failed ($rc)")
+    grp = HIPGroup(g[], members)
+    finalizer(x -> ccall((:calipso_hip_group_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), grp)
+    return grp
+end
+"One inner Newton iteration (solve.jl:98-353) for every member (device evaluator attached); returns (info 6 x B, status B)."
+function newton_step!(g::HIPGroup; advance::Bool=true)
+    B = length(g.members)
+    info = zeros(Float64, 6, B); status = zeros(Int32, B)
+    rc = ccall((:calipso_hip_group_newton_step, lib), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Int32}), g.handle, advance ? 1 : 0, info, status)
+    rc < 0 && error("calipso_hip_group_newton_step failed ($rc)")
+    return info, status
+end
+
+export HIPSolver, HIPLDLSolver, HIPGroup, newton_step!, search_direction_nonsymmetric!
 
 end # module

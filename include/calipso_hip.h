@@ -153,6 +153,9 @@ int32_t calipso_hip_iterative_refinement(calipso_hip_solver*, int32_t* rounds, d
 /* search_direction!(solver)  search_direction.jl:1-23 = inertia correction + condensed solve + refinement (+ pivoted
  * dense fallback on the unreduced system when refinement fails, replacing `H \ R` of :113) */
 int32_t calipso_hip_search_direction(calipso_hip_solver*);
+/* search_direction_nonsymmetric!(step, H, residual, ...)  search_direction.jl:106-119 (`step .= H \ residual`): partially pivoted
+ * dense LU of the unreduced N x N matrix (assembled on the device on demand).  "step" <- H^-1 "residual".  Exception path. */
+int32_t calipso_hip_search_direction_nonsymmetric(calipso_hip_solver*);
 /* cone fraction-to-boundary search  solve.jl:190-221 with cone_violation (cones/cone.jl:62-68): writes candidate s, t
  * and returns the two step sizes (2^-k, k = number of halvings).  CALIPSO_ERR_CONE_SEARCH after 25 halvings. */
 int32_t calipso_hip_cone_search(calipso_hip_solver*, double* step_size, double* step_size_cone_slack_dual);

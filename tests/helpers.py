@@ -56,3 +56,18 @@ def make_pair(oracle_mod, prob, pt, lam, kappa=0.17, rho=52.0, ep=0.12, ed=0.21,
     prob.evaluate(pr.ALL_VARIABLE_FLAGS, op["x"], op["y"], op["z"], prob.parameters, o.buf)
     g.evaluate(pr.ALL_VARIABLE_FLAGS, 0)
     return o, g
+
+
+def near_boundary_point(prob, seed):
+    """interior point whose second-order cone slacks / duals sit close to the cone boundary with unrelated directions: the
+    upper-triangle symmetrisation of the condensed SOC blocks is then so coarse that iterative refinement diverges and
+    search_direction! takes its `H \\ residual` fallback (search_direction.jl:22)"""
+    rng = np.random.default_rng(seed)
+    pt, lam = interior_point(prob, seed)
+    for c in prob.second_order_indices:
+        if c:
+            i = np.array(c) - 1
+            u = rng.standard_normal(len(i) - 1); v = rng.standard_normal(len(i) - 1)
+            pt["s"][i[1:]] = u; pt["s"][i[0]] = (1 + 10 ** rng.uniform(-6, -2)) * np.linalg.norm(u)
+            pt["t"][i[1:]] = v; pt["t"][i[0]] = (1 + 10 ** rng.uniform(-6, -2)) * np.linalg.norm(v)
+    return pt, lam
