@@ -52,7 +52,7 @@ def make_instance(pkg, pr, pid, shape, device):
     return prob, pt, lam, w, s
 
 
-def cpu_baseline(shape):
+def cpu_baseline(shape, name="C3"):
     """The oracle (faithful single-thread restatement of the reference's CPU path) on ONE Newton step of the same C3
     problem (problem id 0): search_direction! = assemble + sparse up-looking LDL^T (QDLDL order of operations, constraint-first
     permutation) + solve + refinement, with ONE factorisation per step (the reference re-factorises before every solve —
@@ -76,9 +76,9 @@ def cpu_baseline(shape):
     dt = time.perf_counter() - t0
     st = o.stats()
     return dict(value=1.0 / dt, unit="Newton steps/s", cores=1, kind="port",
-                sample="1 Newton step (evaluate + cone + residual + search_direction: 1 LDL^T factorisation, %d solves) of C3 problem 0, %.1f s; "
+                sample="1 Newton step (evaluate + cone + residual + search_direction: 1 LDL^T factorisation, %d solves) of %s problem 0, %.1f s; "
                        "with the reference's re-factorisation before every solve it would be %dx the factorisation time" % (
-                           1 + st["last_refinement_rounds"], dt, 1 + st["last_refinement_rounds"]),
+                           1 + st["last_refinement_rounds"], name, dt, 1 + st["last_refinement_rounds"]),
                 status=int(rc))
 
 
@@ -244,7 +244,7 @@ def main():
                      "avg_launch_ms_with_%d_units_in_flight" % batch.lanes: sch_ms_concurrent},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(shape)
+        out["cpu_baseline"] = cpu_baseline(shape, args.config)
     else:
         out["cpu_baseline"] = None
     if rank == 0:

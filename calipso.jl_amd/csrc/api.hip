@@ -147,13 +147,11 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     s->icount = reinterpret_cast<int*>(icount_d);
     s->gx = s->Z; s->hx = s->Z + NE; s->g = s->gh; s->hc = s->gh + NE;
     schur_plan(s);
-    rc |= dalloc(s, &s->tile_list, s->h_tile_list.size());
     rc |= dalloc(s, &s->cone.soc_start, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.soc_dim, (size_t)d.n_soc);
     rc |= dalloc(s, &s->cone.soc_woff, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.entry_soc, NC);
     if (rc) return CALIPSO_ERR_HIP;
     CK(hipHostMalloc((void**)&s->hscal, 64 * sizeof(double)));
     CK(hipHostMalloc((void**)&s->hicount, 64 * sizeof(int)));
-    CK(hipMemcpy(s->tile_list, s->h_tile_list.data(), sizeof(int) * s->h_tile_list.size(), hipMemcpyHostToDevice));
     if (d.n_soc) {
         CK(hipMemcpy(s->cone.soc_start, s->h_soc_start.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
         CK(hipMemcpy(s->cone.soc_dim, s->h_soc_dim.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
@@ -190,7 +188,7 @@ int32_t calipso_hip_destroy(H* s) {
     nonsymmetric_release(s);
     double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
     for (double* p : dp) if (p) (void)hipFree(p);
-    int* ip[] = {s->tile_list, s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
+    int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
     for (int* p : ip) if (p) (void)hipFree(p);
     if (s->hscal) (void)hipHostFree(s->hscal);
     if (s->hicount) (void)hipHostFree(s->hicount);

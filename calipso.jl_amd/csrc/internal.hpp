@@ -144,8 +144,7 @@ struct calipso_hip_solver {
     double* Wsoc = nullptr;     // sum d^2: (-B_sym)^-1 per SOC
     double* Bsoc = nullptr;     // sum d^2: the reference's (non-symmetric) K_zz SOC block
     double* socwork = nullptr;  // 2 * sum d^2 scratch
-    int* tile_list = nullptr;   // (row-block, column-block) pairs of the Schur tiles
-    std::vector<int> h_tile_list; int schur_nj = 8;
+    int schur_nj = 8;           // Schur tile = 128 x 16*schur_nj for single-instance launches (schur.hip: schur_plan)
     int* icount = nullptr;      // device ints: [0] pos [1] nonpos [2] zero (constraint part), [3..5] same for S, [6..] cone-search masks
     int* hicount = nullptr;     // pinned host mirror
     double* gemv_partial = nullptr;   // partial sums for column-split mat-vecs
@@ -202,7 +201,7 @@ void launch_cone_weights(calipso_hip_solver* s);
 void launch_scale_rows(calipso_hip_solver* s);
 void launch_schur(calipso_hip_solver* s);
 void launch_symmetrize(calipso_hip_solver* s);          // Lsym from the upper triangle of Lxx (for the covered instances)
-void schur_plan(calipso_hip_solver* s);   // host: choose the tile shape, build the tile list
+void schur_plan(calipso_hip_solver* s);   // host: choose the tile shape of single-instance launches
 // ldl.hip
 void launch_ldl(calipso_hip_solver* s);
 void launch_trsv(calipso_hip_solver* s, double* x);            // x (length NP) <- S^-1 x using L, D

@@ -172,17 +172,32 @@ __device__ __forceinline__ void stage_fetch(double (&r)[SLD], const double* __re
     }
 }
 // registers -> LDS, k fastest: dst[c][k]
-__device__ __forceinline__ void stage_store(double* __restrict__ dst, const double (&r)[SLD], int tid) {
+__device__ __forceinline__ void stage_store(double* dst, const double (&r)[SLD], int tid) {
     const int k = tid % KT, cbase = tid / KT;
 #pragma unroll
     for (int it = 0; it < SLD; ++it) dst[(cbase + it * (SCHUR_THREADS / KT)) * LDK + k] = r[it];
 }
 
+// tile t (row-major over the tiles that intersect { j <= i < nx }) -> (row block, column block)
+__device__ __forceinline__ void schur_tile(int t, int nx, int TJ, int& bi, int& bj) {
+    bi = 0;
+    for (;;) {
+        const int imax = min(nx, (bi + 1) * TILE) - 1;
+        const int c = imax / TJ + 1;
+        if (t < c) break;
+        t -= c; ++bi;
+    }
+    bj = t;
+}
+
+// LDS: two stages of (A tile, B tile), 4 x 128 x LDK doubles = 136 KiB (dynamic).  Stage s+1 is written to the other buffer
+// while the matrix cores work on stage s (its operands were fetched to registers one stage earlier), so a stage costs ONE barrier
+// and neither the global-load nor the LDS-store latency is exposed.
+constexpr size_t SCHUR_LDS_BYTES = 4 * (size_t)TILE * LDK * sizeof(double);
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, const double* __restrict__ Lsym, const double* __restrict__ gx,
                                                           const double* __restrict__ hx, const double* __restrict__ WH, double* __restrict__ S,
-                                                          const int* __restrict__ tile_list, int ntiles, int nj) {
-    __shared__ double As[TILE * LDK];
-    __shared__ double Bs[TILE * LDK];
+                                                          int ntiles, int nj) {
+    extern __shared__ __attribute__((aligned(16))) double schur_lds[];
     inst_shift(bt.b, Lsym, gx, hx, WH, S);
     const Scalars sc = bt.sc[blockIdx.z];
     // XCD-aware remap: block b runs on XCD b % 8 (observed dispatch order; used for speed only): each XCD gets a contiguous
@@ -191,7 +206,9 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
     const int t = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
     if (t >= ntiles) return;
     const int TJ = 16 * nj;
-    const int i0 = tile_list[2 * t] * TILE, j0 = tile_list[2 * t + 1] * TJ;
+    int bi, bj;
+    schur_tile(t, d.nx, TJ, bi, bj);
+    const int i0 = bi * TILE, j0 = bj * TJ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 7;                          // row tile (16 rows) of this wavefront
     const int nlo = (nj + 1) >> 1;
@@ -208,22 +225,28 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
     const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
     const int nst0 = (d.ne + KT - 1) / KT, nst = nst0 + (d.nc + KT - 1) / KT;
     double ra[SLD], rb[SLD];
-    if (nst > 0) {
-        const SchurStage g = schur_stage(0, nst0, d, gx, hx, WH, omega_y);
+    auto fetch = [&](int st) {
+        const SchurStage g = schur_stage(st, nst0, d, gx, hx, WH, omega_y);
         stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, TILE, tid, 1.0);
         stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, TJ, tid, g.bscale);
+    };
+    if (nst > 0) {
+        fetch(0);
+        stage_store(schur_lds, ra, tid);
+        stage_store(schur_lds + TILE * LDK, rb, tid);
+        if (nst > 1) fetch(1);
     }
+    __syncthreads();
 #pragma unroll 1
     for (int st = 0; st < nst; ++st) {
-        __syncthreads();
-        stage_store(As, ra, tid);
-        stage_store(Bs, rb, tid);
-        __syncthreads();
-        if (st + 1 < nst) {   // prefetch the next stage while the matrix cores work on this one
-            const SchurStage g = schur_stage(st + 1, nst0, d, gx, hx, WH, omega_y);
-            stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, TILE, tid, 1.0);
-            stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, TJ, tid, g.bscale);
+        const double* As = schur_lds + (size_t)(st & 1) * 2 * TILE * LDK;
+        const double* Bs = As + TILE * LDK;
+        if (st + 1 < nst) {   // registers hold stage st+1: park it in the other buffer (free since the barrier that ended stage st-1)
+            double* An = schur_lds + (size_t)((st + 1) & 1) * 2 * TILE * LDK;
+            stage_store(An, ra, tid);
+            stage_store(An + TILE * LDK, rb, tid);
         }
+        if (st + 2 < nst) fetch(st + 2);
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
             const double a = As[(wi * 16 + fr) * LDK + kk * 4 + fk];
@@ -234,6 +257,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
             for (int n = 0; n < 4; ++n)
                 if (n < jcnt) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a, acc[n], 0, 0, 0);   // wavefront-uniform
         }
+        __syncthreads();
     }
     // epilogue: + Lxx (through its upper triangle, as triu(K)) + ep on the diagonal; identity in the padding
 #pragma unroll
@@ -300,34 +324,37 @@ void launch_symmetrize(calipso_hip_solver* s) {
     hipLaunchKernelGGL(k_symmetrize_upper, dim3(nt, nt, B.b.n), dim3(32, 8), 0, s->stream, B.b, s->d.nx, s->Lxx, s->Lsym);
 }
 
-// host: tile shape and the list of tiles that intersect { j <= i < nx }, row-major
-void schur_plan(calipso_hip_solver* s) {
-    const int nx = s->d.nx;
-    long best_cost = -1;
-    for (int nj = 4; nj <= 8; ++nj) {
-        const int TJ = 16 * nj;
-        const int nbi = (nx + TILE - 1) / TILE, nbj = (nx + TJ - 1) / TJ;
-        std::vector<int> list;
-        for (int bi = 0; bi < nbi; ++bi) {
-            const int imax = std::min(nx, (bi + 1) * TILE) - 1;
-            for (int bj = 0; bj < nbj; ++bj)
-                if (bj * TJ <= imax) { list.push_back(bi); list.push_back(bj); }
-        }
-        const long cnt = (long)list.size() / 2;
-        const long cost = ((cnt + 255) / 256) * nj;      // rounds over the 256 CUs x per-SIMD MFMA count of a tile
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && nj > s->schur_nj)) { best_cost = cost; s->schur_nj = nj; s->h_tile_list = list; }
-    }
+// host: tile shape for a launch that covers `instances` problem instances.  Tile = 128 x 16 nj; the cost of a launch is the
+// number of rounds over the 256 CUs times the per-SIMD MFMA count of a tile (C3: one instance -> 128 x 112, 249 tiles, one round;
+// groups -> 128 x 128, fewer wasted columns and the per-stage overhead amortised over more matrix work)
+static int schur_tiles(int nx, int nj) {
+    const int TJ = 16 * nj, nbi = (nx + TILE - 1) / TILE;
+    int cnt = 0;
+    for (int bi = 0; bi < nbi; ++bi) cnt += (std::min(nx, (bi + 1) * TILE) - 1) / TJ + 1;
+    return cnt;
 }
+static int schur_choose(int nx, int instances) {
+    long best_cost = -1; int best = 8;
+    for (int nj = 4; nj <= 8; ++nj) {
+        const long cnt = (long)schur_tiles(nx, nj) * instances;
+        const long cost = ((cnt + 255) / 256) * nj;
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = nj; }   // ties: the larger tile
+    }
+    return best;
+}
+void schur_plan(calipso_hip_solver* s) { s->schur_nj = schur_choose(s->d.nx, 1); }
 
 void launch_schur(calipso_hip_solver* s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_LDS_BYTES); attr = true; }
     if (s->hessian_dirty && !s->cur) { launch_symmetrize(s); s->hessian_dirty = false; }   // (a group refreshes its members itself)
-    const int ntiles = (int)s->h_tile_list.size() / 2;
-    const int grid = ((ntiles + 7) / 8) * 8;
     const BatchSc B = batch_of(s);
+    const int nj = B.b.n == 1 ? s->schur_nj : schur_choose(s->d.nx, B.b.n);
+    const int ntiles = schur_tiles(s->d.nx, nj);
+    const int grid = ((ntiles + 7) / 8) * 8;
     if (s->d.NP > s->d.nx)
         hipLaunchKernelGGL(k_pad_identity, dim3((s->d.NP + 255) / 256, s->d.NP - s->d.nx, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->S);
-    hipLaunchKernelGGL(k_schur, dim3(grid, 1, B.b.n), dim3(SCHUR_THREADS), 0, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, s->tile_list, ntiles,
-                       s->schur_nj);
+    hipLaunchKernelGGL(k_schur, dim3(grid, 1, B.b.n), dim3(SCHUR_THREADS), SCHUR_LDS_BYTES, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, ntiles, nj);
 }
 
 }  // namespace calipso
