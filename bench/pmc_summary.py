@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes (one counter per pass, counter_collection.csv) into per-kernel HBM bytes per launch.
 
-usage: pmc_summary.py FETCH_SIZE.csv WRITE_SIZE.csv GRID_Z out.json
+usage: pmc_summary.py FETCH_SIZE.csv WRITE_SIZE.csv GRID_Z out.json [COUNTER:file.csv ...]
+(extra COUNTER passes, e.g. MfmaUtil, SQ_LDS_BANK_CONFLICT, are averaged per kernel and added under that name)
 Only dispatches whose Grid_Size matches the group launch (k_schur: grid.z = GRID_Z instances) are averaged for k_schur; the other
 kernels are averaged over all their dispatches.  FETCH_SIZE is doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950
 rocprofv3 reports half of a wide streaming read); both counters are in KiB."""
@@ -39,6 +40,18 @@ def main():
             e["note"] = ("FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 rocprofv3 reports half of a wide streaming read; 8 B/lane "
                          "loads are uncalibrated, so this is an upper bound); WRITE_SIZE as reported")
         res[k] = e
+    for spec in sys.argv[5:]:
+        name, path = spec.split(":", 1)
+        try:
+            rows = load(path)
+        except OSError:
+            continue
+        for k, v in rows.items():
+            if k in res and v:
+                if k == "calipso::k_schur":
+                    gmax = max(g for g, _ in v)
+                    v = [x for x in v if x[0] == gmax]
+                res[k][name + "_per_launch"] = sum(x for _, x in v) / len(v)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res.get("calipso::k_schur", {})))
 

@@ -260,7 +260,11 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
 #pragma unroll
     for (int r = 0; r < 4; ++r) cS[r] = S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP];
     {
-        const int row = tid & 63, cb = tid >> 6;   // 16 column groups
+        // staging map: a 32-lane half-wave covers 16 rows x 2 columns, so its ds_write_b64 addresses (row * LDT + c, LDT = 66)
+        // fall on 32 distinct bank pairs (a 64-row x 1-column map is a 2-way conflict: rows r and r + 16 share banks), while
+        // every global load is still a full 128-byte run of 16 consecutive rows
+        const int row = (tid & 15) + 16 * ((tid >> 6) & 3);
+        const int cb = ((tid >> 4) & 3) + 4 * (tid >> 8);   // 0..15
         const double* Lp = S + (size_t)k0 * NP;
         double lv[4], yv[4];
 #pragma unroll

@@ -178,16 +178,25 @@ __device__ __forceinline__ void stage_store(double* dst, const double (&r)[SLD],
     for (int it = 0; it < SLD; ++it) dst[(cbase + it * (SCHUR_THREADS / KT)) * LDK + k] = r[it];
 }
 
-// tile t (row-major over the tiles that intersect { j <= i < nx }) -> (row block, column block)
+// tile t -> (row block, column block).  The tiles that intersect { j <= i < nx } are enumerated in SB x SB super-blocks
+// (super-rows outermost, then super-columns, row-major inside): the ~27 consecutive tiles an XCD works on at a time then span
+// about SB row panels and SB column panels of the operands instead of 1 + 27, which is what its 4 MB L2 can share.
+constexpr int SB = 5;
+__device__ __forceinline__ int schur_row_count(int bi, int nx, int TJ) { return (min(nx, (bi + 1) * TILE) - 1) / TJ + 1; }
 __device__ __forceinline__ void schur_tile(int t, int nx, int TJ, int& bi, int& bj) {
-    bi = 0;
-    for (;;) {
-        const int imax = min(nx, (bi + 1) * TILE) - 1;
-        const int c = imax / TJ + 1;
-        if (t < c) break;
-        t -= c; ++bi;
+    const int nbi = (nx + TILE - 1) / TILE;
+    for (int r0 = 0; r0 < nbi; r0 += SB) {
+        const int r1 = min(nbi, r0 + SB);
+        const int cmax = schur_row_count(r1 - 1, nx, TJ);          // widest row of this super-row
+        for (int c0 = 0; c0 < cmax; c0 += SB) {
+            for (int b = r0; b < r1; ++b) {
+                const int c = min(max(schur_row_count(b, nx, TJ) - c0, 0), SB);
+                if (t < c) { bi = b; bj = c0 + t; return; }
+                t -= c;
+            }
+        }
     }
-    bj = t;
+    bi = 0; bj = 0;   // not reached for t < ntiles
 }
 
 // LDS: two stages of (A tile, B tile), 4 x 128 x LDK doubles = 136 KiB (dynamic).  Stage s+1 is written to the other buffer
