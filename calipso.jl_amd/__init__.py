@@ -403,6 +403,17 @@ class Group:
                             factorizations=int(r[3]), merit_candidate=r[4], violation_candidate=r[5]))
         return out
 
+    def solve(self):
+        """solve!(solver) for every member in lockstep (device evaluators attached); returns the per-member results
+        (1 converged, 0 iteration caps reached, negative = error code of that member)"""
+        import ctypes as C
+        B = len(self.solvers)
+        res = (C.c_int32 * B)()
+        rc = self._L.calipso_hip_group_solve(self._g, res)
+        if rc < 0:
+            raise CalipsoHipError("group_solve: %s (%d): %s" % (STATUS_TEXT.get(rc, "error"), rc, self._L.calipso_hip_last_error(self.solvers[0]._h).decode()))
+        return [int(v) for v in res]
+
     def phase_times(self):
         return self.solvers[0].phase_times()
 

@@ -1100,7 +1100,8 @@ static int gb_candidate_merit(G* g, const Set& a, std::vector<double>& Mh, std::
 }
 
 // the body of the inner loop of solve! (solve.jl:98-353) for every member of `a0`, device evaluator attached
-static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, std::vector<int>& rc) {
+static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, std::vector<int>& rc,
+                              const std::vector<double>* eq_violation = nullptr, const std::vector<double>* cp_violation = nullptr) {
     H* s = g->base;
     const Dims& d = s->d;
     const size_t B = g->hs.size();
@@ -1123,7 +1124,9 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
         const double scn = (d.nc > 0) ? std::max(100.0, hs[15] / (double)d.nc) / 100.0 : 1.0;
         f.optimality = std::max(std::max(hs[9] / sd, hs[10]), std::max(hs[11], hs[12] / scn));
         f.slack_violation = std::max(hs[10], hs[11]);
-        // (the benchmark step passes "not converged" violations, so the outer-convergence exit of :138-143 cannot trigger)
+        if (eq_violation && f.residual_violation < o.residual_tolerance && f.slack_violation < o.slack_tolerance &&
+            (*eq_violation)[i] <= o.equality_tolerance && (*cp_violation)[i] <= o.complementarity_tolerance) { f.exit_kind = 1; continue; }   // :138-143
+        // (the benchmark step passes no violations: the outer-convergence exit cannot trigger there)
         if (f.optimality <= std::max(o.central_path_update_tolerance * h->sc.kappa, o.optimality_tolerance)) { f.exit_kind = 2; continue; }   // :165
         a.push_back(i);
     }
@@ -1333,6 +1336,103 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
     (void)hipEventElapsedTime(&ms, s->ev[2], s->ev[3]); s->phase_ms[2] = ms;
     (void)hipEventElapsedTime(&ms, s->ev[3], s->ev[4]); s->phase_ms[5] = ms;
     (void)hipEventElapsedTime(&ms, s->ev[8], s->ev[9]); s->phase_ms[6] = ms;
+    return CALIPSO_OK;
+}
+
+// solve!(solver) (solve.jl:8-377) for every member in lockstep (device evaluators attached): one pass of the inner loop body per
+// round for all members still iterating; members whose inner loop ends (central-path update due, or iteration cap) take their
+// outer update before the next round, converged members drop out.  result[i] = 1 converged, 0 iteration caps reached, < 0 error.
+int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
+    if (!g || !g->base) return CALIPSO_ERR_ARGUMENT;
+    H* s = g->base;
+    const Dims& d = s->d;
+    const size_t B = g->hs.size();
+    CK(hipSetDevice(s->device));
+    Set all;
+    for (size_t i = 0; i < B; ++i) {
+        H* h = g->hs[i];
+        if (!h->qp.attached) { s->err = "calipso_hip_group_solve needs a device evaluator on every member (calipso_hip_qp_attach)"; return CALIPSO_ERR_ARGUMENT; }
+        if (h != s) CK(hipStreamSynchronize(h->stream));
+        all.push_back((int)i);
+    }
+    struct Finally { H* s; ~Finally() { s->cur = nullptr; } } fin{s};
+    {
+        Set dirty;
+        for (int i : all) if (g->hs[i]->hessian_dirty) dirty.push_back(i);
+        if (!dirty.empty()) { g_activate(g, dirty); launch_symmetrize(s); for (int i : dirty) g->hs[i]->hessian_dirty = false; }
+    }
+    const uint32_t eval0 = CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE;
+    Set cold;
+    for (int i : all) { g->hs[i]->stats = Stats(); if (g->hs[i]->opt.warmstart == 0.0) cold.push_back(i); }
+    if (!cold.empty()) {                                                                   // initialize_slacks!/duals! initialize.jl:15-36
+        g_activate(g, cold);
+        launch_qp_evaluate(s, s->solution, eval0);
+        launch_init_point(s);
+    }
+    for (int i : all) {
+        H* h = g->hs[i]; Options& o = h->opt; Scalars& sc = h->sc;
+        sc.kappa = o.central_path_initial; sc.tau = std::max(0.99, 1.0 - sc.kappa);       // initialize.jl:38-42
+        sc.rho = o.penalty_initial;                                                       // :44-48
+        g_activate(g, Set{i});
+        fill_d(s, s->lambda, d.ne, o.dual_initial);
+        filter_reset(h);                                                                  // solve.jl:95
+    }
+    g_activate(g, all);
+    launch_qp_evaluate(s, s->solution, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE);   // :78-83
+    launch_violations(s);
+    if (g_read_d(g, all, 16, 2)) return CALIPSO_ERR_HIP;
+    std::vector<double> ev(B), cv(B);
+    for (int i : all) { ev[i] = g->hs[i]->hscal[16]; cv[i] = g->hs[i]->hscal[17]; }        // :85-86 (cone product read before cone!: reference quirk)
+    launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT | CALIPSO_CONE_TARGET);               // :88-91
+    std::vector<calipso::i64> outer(B, 1), inner(B, 1), total(B, 1);
+    std::vector<int> res(B, 0), worst(B, 0);
+    for (int i : all) g->hs[i]->stats.outer = 1;
+    Set active = all;
+    while (!active.empty()) {
+        std::vector<IterInfo> info(B);
+        std::vector<int> rc(B, 0);
+        const int e = gb_inner_iteration(g, active, info, rc, &ev, &cv);
+        if (e < 0) return e;
+        Set next, upd;
+        for (int i : active) {
+            H* h = g->hs[i]; const Options& o = h->opt;
+            if (rc[i] < 0) { res[i] = rc[i]; continue; }
+            worst[i] = std::max(worst[i], rc[i]);
+            if (info[i].exit_kind == 1) { h->stats.total_iterations = total[i]; res[i] = 1; continue; }   // converged  :138-160
+            bool inner_done = info[i].exit_kind == 2;                                                     // :165
+            if (!inner_done) {
+                ev[i] = h->hscal[16]; cv[i] = h->hscal[17];                                               // :332-333
+                if (h->cb_inner) { SYNC(); h->cb_inner(h->cb_user, h); }
+                total[i] += 1; h->stats.total_iterations = total[i];
+                inner[i] += 1;
+                if (inner[i] > o.max_residual_iterations) inner_done = true;
+            }
+            if (inner_done) upd.push_back(i); else next.push_back(i);
+        }
+        if (!upd.empty()) {                                                                // outer updates  :356-371
+            for (int i : upd) {
+                H* h = g->hs[i]; const Options& o = h->opt; Scalars& sc = h->sc;
+                sc.kappa = std::max(o.residual_tolerance / 10.0, std::min(o.central_path_scaling * sc.kappa, std::pow(sc.kappa, o.central_path_exponent)));
+                sc.tau = std::max(0.99, 1.0 - sc.kappa);
+            }
+            g_activate(g, upd);                                                            // lambda += rho r with the OLD rho (:362-365)
+            launch_lambda_update(s);
+            for (int i : upd) {
+                H* h = g->hs[i]; const Options& o = h->opt; Scalars& sc = h->sc;
+                sc.rho = std::min(std::max(o.penalty_scaling * sc.rho, 1.0 / sc.kappa), o.max_penalty);
+                filter_reset(h);
+                if (h->cb_outer) { SYNC(); h->cb_outer(h->cb_user, h); }
+                outer[i] += 1; inner[i] = 1;
+                if (outer[i] > o.max_outer_iterations) { h->stats.total_iterations = total[i]; res[i] = 0; continue; }
+                h->stats.outer = outer[i];
+                next.push_back(i);
+            }
+            std::sort(next.begin(), next.end());
+        }
+        active.swap(next);
+    }
+    SYNC();
+    if (result) for (size_t i = 0; i < B; ++i) result[i] = res[i];
     return CALIPSO_OK;
 }
 

@@ -90,7 +90,8 @@ void launch_solve_from_b(calipso_hip_solver* s) {
 
 // initialize_slacks! / initialize_duals!  initialize.jl:15-36: r = g(x0); nonnegative slacks/duals = 1;
 // second-order = [1, .1, .1, ...]; y = z = 0  (cones/nonnegative.jl:2-8, second_order.jl:2-10)
-__global__ void k_init_point(Dims d, ConeDev cd, const double* __restrict__ g, double* __restrict__ w) {
+__global__ void k_init_point(Batch bt, Dims d, ConeDev cd, const double* __restrict__ g, double* __restrict__ w) {
+    inst_shift(bt, g, w);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d.ne) { w[d.orr() + i] = g[i]; w[d.oy() + i] = 0.0; }
     if (i < d.nc) {
@@ -105,16 +106,20 @@ __global__ void k_init_point(Dims d, ConeDev cd, const double* __restrict__ g, d
 void launch_init_point(calipso_hip_solver* s) {
     const int n = s->d.ne > s->d.nc ? s->d.ne : s->d.nc;
     if (n == 0) return;
-    hipLaunchKernelGGL(k_init_point, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->d, s->cone, s->g, s->solution);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_init_point, dim3((n + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->cone, s->g, s->solution);
 }
 
-__global__ void k_lambda_update(Dims d, double rho, const double* __restrict__ w, double* __restrict__ lam) {
+__global__ void k_lambda_update(BatchSc bt, Dims d, const double* __restrict__ w, double* __restrict__ lam) {
+    inst_shift(bt.b, w, lam);
+    const double rho = bt.sc[blockIdx.z].rho;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d.ne) lam[i] = lam[i] + rho * w[d.orr() + i];
 }
 void launch_lambda_update(calipso_hip_solver* s) {
     if (s->d.ne == 0) return;
-    hipLaunchKernelGGL(k_lambda_update, dim3((s->d.ne + 255) / 256), dim3(256), 0, s->stream, s->d, s->sc.rho, s->solution, s->lambda);
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_lambda_update, dim3((s->d.ne + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B, s->d, s->solution, s->lambda);
 }
 
 // residual_jacobian_parameters!  residual_jacobian_parameters.jl:1-40: rows x <- Lx_theta, y <- g_theta, z <- h_theta, rest 0

@@ -100,3 +100,50 @@ def test_group_of_one_and_shape_mismatch():
     c = build(pkg, 32, shape=(200, 90, 30, 20, 3))
     with pytest.raises(pkg.CalipsoHipError):
         pkg.Group([a, c])
+
+
+def build_for_solve(pkg, pid, shape=(120, 50, 20, 10, 3), **opts):
+    nx, ne, n_nn, n_soc, dim = shape
+    prob, pt, lam = pr.synthetic_conic_qp(pkg.splitmix_uniform, pid, nx, ne, n_nn, n_soc, dim)
+    s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices,
+                   options=opts)
+    s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
+    s.set("solution", np.concatenate([pt["x"], np.zeros(s.N - nx)]))
+    return prob, s
+
+
+def test_group_solve_is_bitwise_the_single_solves():
+    """solve! (solve.jl:8-377) in lockstep: members converge after different numbers of inner / outer iterations and drop out of the
+    launches one by one; every member ends exactly where its stand-alone solve ends"""
+    pkg = load_pkg()
+    ids = [40, 41, 42, 43, 44]
+    singles = [build_for_solve(pkg, p) for p in ids]
+    members = [build_for_solve(pkg, p) for p in ids]
+    ref = [pkg.solve_b(s) for _, s in singles]
+    g = pkg.Group([s for _, s in members])
+    got = g.solve()
+    assert [int(r) for r in ref] == got and all(ref)
+    its = [s.stats()["total_iterations"] for _, s in singles]
+    assert len(set(its)) > 1                                     # the members do not all take the same path
+    for (prob, s), (_, m) in zip(singles, members):
+        assert s.stats() == m.stats()
+        assert same(s.solution.all, m.solution.all)
+        assert same(s.get("dual", prob.ne), m.get("dual", prob.ne))
+        for name in ("central_path", "penalty", "primal_regularization"):
+            assert s.get(name, 1)[0] == m.get(name, 1)[0], name
+        assert np.abs(prob.A @ m.solution.variables - prob.b).max() < 1e-4
+    g.close()
+
+
+def test_group_solve_with_iteration_caps():
+    """members stopped by max_residual_iterations / max_outer_iterations report 0 like the single solve"""
+    pkg = load_pkg()
+    opts = dict(max_outer_iterations=2, max_residual_iterations=3)
+    singles = [build_for_solve(pkg, p, **opts) for p in (50, 51)]
+    members = [build_for_solve(pkg, p, **opts) for p in (50, 51)]
+    ref = [int(pkg.solve_b(s)) for _, s in singles]
+    g = pkg.Group([s for _, s in members])
+    assert g.solve() == ref and ref == [0, 0]
+    for (_, s), (_, m) in zip(singles, members):
+        assert s.stats() == m.stats() and same(s.solution.all, m.solution.all)
+    g.close()
