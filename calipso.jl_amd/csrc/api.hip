@@ -12,9 +12,9 @@
 
 #include "internal.hpp"
 #include "device_utils.hpp"
+#include "host_logic.hpp"
 
 using namespace calipso;
-typedef calipso_hip_solver H;
 
 namespace calipso {
 int check(H* s, hipError_t e, const char* what) {
@@ -27,7 +27,6 @@ int check(H* s, hipError_t e, const char* what) {
 
 static std::string g_create_err;
 
-#define SYNC() CK(hipStreamSynchronize(s->stream))
 
 template <typename T>
 static int dalloc(H* s, T** p, size_t count) {
@@ -371,8 +370,6 @@ static int do_factorize(H* s, int64_t inertia[3]) {
     return CALIPSO_OK;
 }
 
-static bool inertia_ok(const H* s, const int64_t in[3]) { return in[0] == s->d.nx && in[1] == s->d.ne + s->d.nc && in[2] == 0; }   // inertia.jl:7-11
-
 // inertia.jl:30-80.  Quirk kept: the `primal_regularization_last == 0.0` test of :48 compares a Vector with a Float64 and is
 // always false, so IC-3 always takes max(min_regularization, scaling_regularization_last * eps_last).
 static int do_inertia_correction(H* s, int64_t* nfact) {
@@ -486,44 +483,6 @@ static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t 
     return CALIPSO_OK;
 }
 
-// ---- filter (filter.jl:1-89), host side ------------------------------------------------------------------------------------
-static void filter_reset(H* s) {
-    for (calipso::i64 i = 0; i < s->filter_index; ++i) { s->cache_theta[i] = 1.0e8; s->cache_merit[i] = 1.0e8; }
-    for (calipso::i64 i = 0; i < s->filter_index; ++i) { s->filter_theta[i] = 1.0e8; s->filter_merit[i] = 1.0e8; }
-    s->filter_index = 0;
-}
-static bool check_filter(const H* s, double theta, double merit) {
-    for (size_t i = 0; i < s->filter_theta.size(); ++i)
-        if (!(theta < s->filter_theta[i] || merit < s->filter_merit[i])) return false;
-    return true;
-}
-static void augment_filter(H* s, double theta, double merit) {
-    if (s->filter_index == 0) { s->filter_theta[0] = theta; s->filter_merit[0] = merit; s->filter_index = 1; return; }
-    if (check_filter(s, theta, merit)) {
-        const calipso::i64 nold = s->filter_index;
-        for (calipso::i64 i = 0; i < nold; ++i) { s->cache_theta[i] = s->filter_theta[i]; s->cache_merit[i] = s->filter_merit[i]; }
-        for (calipso::i64 i = 0; i < nold; ++i) { s->filter_theta[i] = 1.0e8; s->filter_merit[i] = 1.0e8; }
-        s->filter_index = 0;
-        s->filter_theta[0] = theta; s->filter_merit[0] = merit; s->filter_index = 1;
-        for (calipso::i64 i = 0; i < nold; ++i)
-            if (!(s->cache_theta[i] >= theta && s->cache_merit[i] >= merit)) {
-                s->filter_theta[s->filter_index] = s->cache_theta[i];
-                s->filter_merit[s->filter_index] = s->cache_merit[i];
-                s->filter_index += 1;
-            }
-    }
-}
-// line_search.jl:2-18 with d = dot(merit_gradient, step.primals) precomputed on the device
-static bool switching_condition(double step_size, double dd, double merit_exponent, double violation, double violation_exponent, double reg) {
-    return dd < 0.0 && step_size * std::pow(-dd, merit_exponent) > reg * std::pow(violation, violation_exponent);
-}
-static bool sufficient_progress(double v, double vc, double m, double mc, double vt, double mt, double mach) {
-    return vc - 10.0 * mach * std::fabs(v) <= (1.0 - vt) * v || mc - 10.0 * mach * std::fabs(m) <= m - mt * v;
-}
-static bool armijo(double m, double mc, double dd, double step_size, double at, double mach) {
-    return mc - m - 10.0 * mach * std::fabs(m) <= at * step_size * dd;
-}
-
 static int candidate_merit(H* s, calipso_eval_fn eval, void* user, double* Mh, double* thetah) {
     int rc = evaluate(s, eval, user, 1, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);   // solve.jl:231-235
     if (rc < 0) return rc;
@@ -534,16 +493,6 @@ static int candidate_merit(H* s, calipso_eval_fn eval, void* user, double* Mh, d
     *Mh = s->hscal[4]; *thetah = s->hscal[5];
     return CALIPSO_OK;
 }
-
-struct IterInfo {
-    double step_size = 1.0, step_size_t = 1.0, M = 0.0, Mh = 0.0, theta = 0.0, thetah = 0.0;
-    int rounds = 0;
-    int64_t nfact = 0;
-    int exit_kind = 0;   // 0 stepped, 1 outer convergence, 2 inner convergence
-    double residual_violation = 0, optimality = 0, slack_violation = 0;
-};
-
-#define EV(i) (void)hipEventRecord(s->ev[i], s->stream)
 
 // one pass of the inner loop body of solve! (solve.jl:98-353)
 static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equality_violation, double cone_product_violation, IterInfo& info,
@@ -915,526 +864,7 @@ int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) {
 
 }  // extern "C"
 
-// =============================================================================================================================
-// Groups: several handles of ONE shape stepped in lockstep through the same launches (BASELINE config C4: many independent
-// problem instances per GPU).  Every kernel takes the instance from blockIdx.z (internal.hpp: Batch), so the latency-bound
-// launches of the step (the pivot chain of the LDL^T, the triangular solves, the O(N) vector kernels) cost the same for B
-// instances as for one.  The host logic below is the per-instance logic of inner_iteration() applied to every member, with
-// the members that need another round (re-factorisation, refinement, back-tracking) forming the next launch's instance list.
-// Results per member are bit-identical to stepping that member alone (tests/test_gpu_group.py).
-// =============================================================================================================================
-struct calipso_hip_group {
-    std::vector<H*> hs;
-    H* base = nullptr;                 // hs[0]: its stream carries every launch, its buffers are the address origin
-    calipso::BatchSc desc;             // instance list of the launches being enqueued (base->cur points here)
-    double *dgather = nullptr, *hgather = nullptr;   // MAX_BATCH x 64 doubles (device, pinned host)
-    int *digather = nullptr, *higather = nullptr;    // MAX_BATCH x 64 ints
-    std::string err;
-};
-typedef calipso_hip_group G;
-typedef std::vector<int> Set;          // member indices
-
-__global__ void k_gather_d(Batch bt, const double* __restrict__ src, int count, double* __restrict__ dst) {
-    inst_shift(bt, src);
-    if ((int)threadIdx.x < count) dst[blockIdx.z * 64 + threadIdx.x] = src[threadIdx.x];
-}
-__global__ void k_gather_i(Batch bt, const int* __restrict__ src, int count, int* __restrict__ dst) {
-    inst_shift_i(bt, src);
-    if ((int)threadIdx.x < count) dst[blockIdx.z * 64 + threadIdx.x] = src[threadIdx.x];
-}
-
-static void g_activate(G* g, const Set& a) {
-    BatchSc& b = g->desc;
-    b.b.n = (int)a.size();
-    for (size_t k = 0; k < a.size(); ++k) {
-        H* h = g->hs[a[k]];
-        b.b.delta[k] = (long long)((reinterpret_cast<intptr_t>(h->slab) - reinterpret_cast<intptr_t>(g->base->slab)) / (intptr_t)sizeof(double));
-        b.sc[k] = h->sc;
-    }
-    g->base->cur = &g->desc;
-}
-// dscal[first .. first+count) of every member of `a` (the active set) -> that member's hscal
-static int g_read_d(G* g, const Set& a, int first, int count) {
-    H* s = g->base;
-    hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + first, count, g->dgather);
-    CK(hipMemcpyAsync(g->hgather, g->dgather, sizeof(double) * 64 * a.size(), hipMemcpyDeviceToHost, s->stream));
-    SYNC();
-    for (size_t k = 0; k < a.size(); ++k)
-        for (int i = 0; i < count; ++i) g->hs[a[k]]->hscal[first + i] = g->hgather[k * 64 + i];
-    return 0;
-}
-static int g_read_i(G* g, const Set& a, int first, int count) {
-    H* s = g->base;
-    hipLaunchKernelGGL(k_gather_i, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->icount + first, count, g->digather);
-    CK(hipMemcpyAsync(g->higather, g->digather, sizeof(int) * 64 * a.size(), hipMemcpyDeviceToHost, s->stream));
-    SYNC();
-    for (size_t k = 0; k < a.size(); ++k)
-        for (int i = 0; i < count; ++i) g->hs[a[k]]->hicount[first + i] = g->higather[k * 64 + i];
-    return 0;
-}
-
-// factorize! + compute_inertia! for the members of `a`
-static int gb_factorize(G* g, const Set& a, std::vector<std::array<int64_t, 3>>& in) {
-    H* s = g->base;
-    g_activate(g, a);
-    (void)hipEventRecord(s->ev[10], s->stream);
-    launch_cone_weights(s);
-    launch_scale_rows(s);
-    (void)hipEventRecord(s->ev[11], s->stream);
-    launch_schur(s);
-    (void)hipEventRecord(s->ev[12], s->stream);
-    launch_ldl(s);
-    (void)hipEventRecord(s->ev[13], s->stream);
-    if (g_read_i(g, a, 0, 6)) return CALIPSO_ERR_HIP;
-    {
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, s->ev[10], s->ev[11]); s->phase_ms[1] = ms;
-        (void)hipEventElapsedTime(&ms, s->ev[11], s->ev[12]); s->phase_ms[7] = ms;
-        (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[13]); s->phase_ms[3] = ms;
-        s->phase_ms[8] += 1.0;
-    }
-    for (int i : a) {
-        H* h = g->hs[i];
-        h->stats.factorizations += 1;
-        const int64_t pos = h->hicount[0] + h->hicount[3], nonpos = h->hicount[1] + h->hicount[4], zero = h->hicount[2] + h->hicount[5];
-        in[i] = {pos, nonpos, zero};
-        if (zero > 0) in[i][0] = -1;
-    }
-    return CALIPSO_OK;
-}
-
-// inertia_correction! (inertia.jl:30-80) for every member of `a`; rc[i] < 0 marks a member that failed
-static int gb_inertia_correction(G* g, const Set& a, std::vector<int>& rc, std::vector<int64_t>& nfact) {
-    std::vector<std::array<int64_t, 3>> in(g->hs.size());
-    for (int i : a) { H* h = g->hs[i]; h->sc.ep = h->opt.primal_regularization_initial; h->sc.ed = h->opt.dual_regularization_initial; nfact[i] = 0; }
-    int e = gb_factorize(g, a, in);                              // IC-1
-    if (e < 0) return e;
-    Set pending;
-    for (int i : a) {
-        H* h = g->hs[i]; nfact[i] += 1;
-        if (inertia_ok(h, in[i].data())) continue;
-        Options& o = h->opt; Scalars& sc = h->sc;
-        if (in[i][2] != 0) sc.ed = o.dual_regularization * std::pow(sc.kappa, o.dual_regularization_exponent);   // IC-2
-        sc.ep = std::max(o.min_regularization, o.scaling_regularization_last * sc.ep_last);                     // IC-3
-        pending.push_back(i);
-    }
-    while (!pending.empty()) {
-        e = gb_factorize(g, pending, in);                        // IC-4
-        if (e < 0) return e;
-        Set next;
-        for (int i : pending) {
-            H* h = g->hs[i]; nfact[i] += 1;
-            Options& o = h->opt; Scalars& sc = h->sc;
-            if (inertia_ok(h, in[i].data())) { sc.ep_last = sc.ep; continue; }
-            if (sc.ep_last == 0.0) sc.ep = o.scaling_regularization_initial * sc.ep;   // IC-5
-            else sc.ep = o.scaling_regularization * sc.ep;
-            if (sc.ep > o.max_regularization) { h->err = "inertia correction failure"; rc[i] = CALIPSO_ERR_INERTIA; continue; }   // IC-6
-            next.push_back(i);
-        }
-        pending.swap(next);
-    }
-    return CALIPSO_OK;
-}
-
-static void gb_sds(G* g, const Set& a, int which, bool accumulate) {
-    H* s = g->base;
-    g_activate(g, a);
-    const double* res = which == 0 ? s->residual : s->residual_error;
-    launch_residual_symmetric(s, res);
-    linear_solve_device(s);
-    launch_recover(s, which == 0 ? s->step : s->step_correction, res, accumulate ? s->step : nullptr);
-}
-
-// iterative_refinement! (iterative_refinement.jl:1-52) for every member of `a`
-static int gb_refinement(G* g, const Set& a, std::vector<int>& rc, std::vector<int>& rounds) {
-    H* s = g->base;
-    const size_t B = g->hs.size();
-    std::vector<double> norm(B, 0.0), norm0(B, 0.0);
-    std::vector<int> it(B, 0);
-    g_activate(g, a);
-    fill_d(s, s->step_correction, s->d.N, 0.0);
-    launch_residual_error(s, s->step);
-    if (g_read_d(g, a, 7, 1)) return CALIPSO_ERR_HIP;
-    for (int i : a) { norm[i] = g->hs[i]->hscal[7]; norm0[i] = norm[i]; }
-    Set run = a;
-    while (!run.empty()) {
-        Set sub;
-        for (int i : run) {
-            H* h = g->hs[i]; const Options& o = h->opt;
-            bool finished = false;
-            if (it[i] > o.max_iterative_refinement) {        // loop exhausted: fail <=> the final error exceeds the initial one
-                finished = true;
-                if (!(norm[i] <= norm0[i])) {           // search_direction.jl:22 -> H \ residual on the member's own stream
-                    h->stats.refine_fail += 1;
-                    const int fr = nonsymmetric_solve(h, h->residual, h->step);
-                    rc[i] = fr < 0 ? fr : std::max(rc[i], (int)CALIPSO_WARN_REFINEMENT);
-                }
-            } else if (norm[i] <= o.iterative_refinement_tolerance && it[i] >= o.min_iterative_refinement) finished = true;
-            if (finished) {
-                rounds[i] = it[i];
-                h->stats.last_refine = it[i]; h->stats.refine_max = std::max<calipso::i64>(h->stats.refine_max, it[i]);
-            } else sub.push_back(i);
-        }
-        if (sub.empty()) break;
-        gb_sds(g, sub, 1, true);
-        launch_residual_error(s, s->step);
-        if (g_read_d(g, sub, 7, 1)) return CALIPSO_ERR_HIP;
-        for (int i : sub) { norm[i] = g->hs[i]->hscal[7]; it[i] += 1; }
-        run.swap(sub);
-    }
-    return CALIPSO_OK;
-}
-
-static Set alive(const Set& a, const std::vector<int>& rc) { Set r; for (int i : a) if (rc[i] >= 0) r.push_back(i); return r; }
-
-static int gb_candidate_merit(G* g, const Set& a, std::vector<double>& Mh, std::vector<double>& thetah) {
-    H* s = g->base;
-    g_activate(g, a);
-    launch_qp_evaluate(s, s->candidate, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);
-    launch_cone(s, s->candidate, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);
-    launch_merit(s, s->candidate);
-    launch_constraint_violation(s, s->candidate);
-    if (g_read_d(g, a, 4, 2)) return CALIPSO_ERR_HIP;
-    for (int i : a) { Mh[i] = g->hs[i]->hscal[4]; thetah[i] = g->hs[i]->hscal[5]; }
-    return CALIPSO_OK;
-}
-
-// the body of the inner loop of solve! (solve.jl:98-353) for every member of `a0`, device evaluator attached
-static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, std::vector<int>& rc,
-                              const std::vector<double>* eq_violation = nullptr, const std::vector<double>* cp_violation = nullptr) {
-    H* s = g->base;
-    const Dims& d = s->d;
-    const size_t B = g->hs.size();
-    g_activate(g, a0);
-    EV(0);
-    launch_qp_evaluate(s, s->solution, CALIPSO_EVAL_OBJECTIVE_GRADIENT | CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT | CALIPSO_EVAL_CONE_DUAL_GRADIENT);
-    launch_cone(s, s->solution, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);
-    launch_merit(s, s->solution);
-    launch_merit_gradient(s);
-    launch_residual(s);
-    launch_violations(s);
-    launch_constraint_violation(s, s->solution);
-    if (g_read_d(g, a0, 4, 14)) return CALIPSO_ERR_HIP;
-    Set a;
-    for (int i : a0) {
-        H* h = g->hs[i]; const Options& o = h->opt; const double* hs = h->hscal; IterInfo& f = info[i];
-        f.M = hs[4]; f.theta = hs[5];
-        f.residual_violation = hs[8] / (double)d.N;
-        const double sd = (d.ne + d.nc > 0) ? std::max(100.0, (hs[13] + hs[14]) / (double)(d.ne + d.nc)) / 100.0 : 1.0;
-        const double scn = (d.nc > 0) ? std::max(100.0, hs[15] / (double)d.nc) / 100.0 : 1.0;
-        f.optimality = std::max(std::max(hs[9] / sd, hs[10]), std::max(hs[11], hs[12] / scn));
-        f.slack_violation = std::max(hs[10], hs[11]);
-        if (eq_violation && f.residual_violation < o.residual_tolerance && f.slack_violation < o.slack_tolerance &&
-            (*eq_violation)[i] <= o.equality_tolerance && (*cp_violation)[i] <= o.complementarity_tolerance) { f.exit_kind = 1; continue; }   // :138-143
-        // (the benchmark step passes no violations: the outer-convergence exit cannot trigger there)
-        if (f.optimality <= std::max(o.central_path_update_tolerance * h->sc.kappa, o.optimality_tolerance)) { f.exit_kind = 2; continue; }   // :165
-        a.push_back(i);
-    }
-    EV(1);
-    if (a.empty()) { EV(2); EV(3); EV(4); return CALIPSO_OK; }
-    // Hessian / Jacobians of a QP are constant (:175-181 is a no-op for the device evaluator)
-    EV(2);
-    std::vector<int64_t> nfact(B, 0);
-    std::vector<int> rounds(B, 0);
-    int e = gb_inertia_correction(g, a, rc, nfact);                                      // :187 search_direction!
-    if (e < 0) return e;
-    a = alive(a, rc);
-    if (!a.empty()) {
-        gb_sds(g, a, 0, false);
-        Set ref;
-        for (int i : a) if (g->hs[i]->opt.iterative_refinement) ref.push_back(i);
-        if (!ref.empty()) { e = gb_refinement(g, ref, rc, rounds); if (e < 0) return e; }
-    }
-    for (int i : a) { info[i].nfact = nfact[i]; info[i].rounds = rounds[i]; }
-    EV(3);
-    if (a.empty()) { EV(4); return CALIPSO_OK; }
-    // cone search (:190-221)
-    std::vector<double> as(B, 1.0), at(B, 1.0), step_size(B, 1.0);
-    g_activate(g, a);
-    if (d.nc) {
-        launch_cone_search(s);
-        if (g_read_i(g, a, 6, 58)) return CALIPSO_ERR_HIP;
-        for (int i : a) {
-            H* h = g->hs[i]; const Options& o = h->opt;
-            const int nk = std::min<int>((int)o.max_cone_line_search + 1, 26);
-            int ks = -1, kt = -1;
-            for (int k = 0; k < nk; ++k) if (h->hicount[6 + k] == 0) { ks = k; break; }
-            for (int k = 0; k < nk; ++k) if (h->hicount[32 + k] == 0) { kt = k; break; }
-            if (ks < 0 || kt < 0) { h->err = "cone search failure"; rc[i] = CALIPSO_ERR_CONE_SEARCH; continue; }
-            for (int k = 0; k < ks; ++k) as[i] = o.scaling_line_search * as[i];
-            for (int k = 0; k < kt; ++k) at[i] = o.scaling_line_search * at[i];
-        }
-        a = alive(a, rc);
-        if (a.empty()) { EV(4); return CALIPSO_OK; }
-        g_activate(g, a);
-        std::vector<double> la, lt;
-        for (int i : a) { la.push_back(as[i]); lt.push_back(at[i]); }
-        launch_cone_candidate_batch(s, la.data(), lt.data());
-    }
-    for (int i : a) { info[i].step_size = as[i]; info[i].step_size_t = at[i]; step_size[i] = as[i]; }
-    {
-        std::vector<double> la;
-        for (int i : a) la.push_back(step_size[i]);
-        launch_axpy_points_batch(s, la.data(), 0);                                         // :224-229
-    }
-    launch_merit_gradient(s);
-    launch_dot_merit(s);
-    std::vector<double> Mh(B, 0.0), thetah(B, 0.0), dd(B, 0.0);
-    e = gb_candidate_merit(g, a, Mh, thetah);                                            // :231-250
-    if (e < 0) return e;
-    if (g_read_d(g, a, 6, 1)) return CALIPSO_ERR_HIP;
-    for (int i : a) dd[i] = g->hs[i]->hscal[6];
-    // residual line search (:254-302): the members still back-tracking form the next launch's instance list
-    std::vector<calipso::i64> ls_it(B, 0);
-    Set run = a;
-    while (!run.empty()) {
-        Set sub;
-        for (int i : run) {
-            H* h = g->hs[i]; const Options& o = h->opt;
-            const double M = info[i].M, theta = info[i].theta;
-            if (!(ls_it[i] < o.max_residual_line_search)) continue;
-            if (check_filter(h, thetah[i], Mh[i])) {
-                if (theta <= o.slack_tolerance && switching_condition(step_size[i], dd[i], o.merit_exponent, theta, o.violation_exponent, 1.0) &&
-                    armijo(M, Mh[i], dd[i], step_size[i], o.armijo_tolerance, o.machine_tolerance)) continue;
-                else if (sufficient_progress(theta, thetah[i], M, Mh[i], o.violation_tolerance, o.merit_tolerance, o.machine_tolerance)) continue;
-            }
-            step_size[i] = o.scaling_line_search * step_size[i];
-            sub.push_back(i);
-        }
-        if (sub.empty()) break;
-        g_activate(g, sub);
-        std::vector<double> la;
-        for (int i : sub) la.push_back(step_size[i]);
-        launch_axpy_points_batch(s, la.data(), 1);                                         // :268-276
-        e = gb_candidate_merit(g, sub, Mh, thetah);                                      // :278-297
-        if (e < 0) return e;
-        for (int i : sub) ls_it[i] += 1;
-        run.swap(sub);
-    }
-    for (int i : a) {
-        H* h = g->hs[i]; const Options& o = h->opt;
-        const double M = info[i].M, theta = info[i].theta;
-        if (ls_it[i] >= o.max_residual_line_search) rc[i] = std::max(rc[i], (int)CALIPSO_WARN_LINE_SEARCH);
-        if (!switching_condition(step_size[i], dd[i], o.merit_exponent, theta, o.violation_exponent, 1.0) ||
-            !armijo(M, Mh[i], dd[i], step_size[i], o.armijo_tolerance, o.machine_tolerance))
-            augment_filter(h, (1.0 - o.violation_tolerance) * theta, M - o.merit_tolerance * theta);   // filter.jl:81-89
-        info[i].step_size = step_size[i]; info[i].Mh = Mh[i]; info[i].thetah = thetah[i];
-        h->stats.newton_steps += 1;
-    }
-    g_activate(g, a);
-    {
-        std::vector<double> la;
-        for (int i : a) la.push_back(step_size[i]);
-        launch_accept_batch(s, la.data());                                                 // :309-326
-    }
-    launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT);                                     // :328-330
-    launch_violations(s);                                                                  // :332-333
-    if (g_read_d(g, a, 16, 2)) return CALIPSO_ERR_HIP;
-    EV(4);
-    return CALIPSO_OK;
-}
-
 extern "C" {
-
-int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, calipso_hip_group** out) {
-    if (!handles || !out || count < 1 || count > MAX_BATCH) return CALIPSO_ERR_ARGUMENT;
-    H* b = handles[0];
-    if (!b) return CALIPSO_ERR_ARGUMENT;
-    for (int i = 0; i < count; ++i) {
-        H* h = handles[i];
-        if (!h) return CALIPSO_ERR_ARGUMENT;
-        const bool same = h->device == b->device && h->slab_doubles == b->slab_doubles && std::memcmp(&h->d, &b->d, sizeof(Dims)) == 0 &&
-                          h->h_soc_start == b->h_soc_start && h->h_soc_dim == b->h_soc_dim && h->h_nonneg == b->h_nonneg;
-        if (!same) { b->err = "calipso_hip_group_create: members must have the same shape, cone layout and device"; return CALIPSO_ERR_ARGUMENT; }
-        for (int j = 0; j < i; ++j) if (handles[j] == h) { b->err = "calipso_hip_group_create: duplicate member"; return CALIPSO_ERR_ARGUMENT; }
-    }
-    G* g = new G();
-    g->hs.assign(handles, handles + count);
-    g->base = b;
-    H* s = b;
-    *out = g;
-    CK(hipSetDevice(b->device));
-    CK(hipMalloc((void**)&g->dgather, sizeof(double) * 64 * MAX_BATCH));
-    CK(hipMalloc((void**)&g->digather, sizeof(int) * 64 * MAX_BATCH));
-    CK(hipHostMalloc((void**)&g->hgather, sizeof(double) * 64 * MAX_BATCH));
-    CK(hipHostMalloc((void**)&g->higather, sizeof(int) * 64 * MAX_BATCH));
-    return CALIPSO_OK;
-}
-
-int32_t calipso_hip_group_destroy(calipso_hip_group* g) {
-    if (!g) return CALIPSO_OK;
-    if (g->base) { (void)hipSetDevice(g->base->device); (void)hipStreamSynchronize(g->base->stream); g->base->cur = nullptr; }
-    if (g->dgather) (void)hipFree(g->dgather);
-    if (g->digather) (void)hipFree(g->digather);
-    if (g->hgather) (void)hipHostFree(g->hgather);
-    if (g->higather) (void)hipHostFree(g->higather);
-    delete g;
-    return CALIPSO_OK;
-}
-
-// calipso_hip_newton_step for every member at once; info = count x 6 (row-major, same fields), status = count entries
-int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, double* info_out, int32_t* status) {
-    if (!g || !g->base) return CALIPSO_ERR_ARGUMENT;
-    H* s = g->base;
-    const Dims& d = s->d;
-    const size_t B = g->hs.size();
-    CK(hipSetDevice(s->device));
-    Set all;
-    for (size_t i = 0; i < B; ++i) {
-        H* h = g->hs[i];
-        if (!h->qp.attached) { s->err = "calipso_hip_group_newton_step needs a device evaluator on every member (calipso_hip_qp_attach)"; return CALIPSO_ERR_ARGUMENT; }
-        if (h != s) CK(hipStreamSynchronize(h->stream));   // uploads made through the member's own stream are complete
-        all.push_back((int)i);
-    }
-    struct Finally { H* s; ~Finally() { s->cur = nullptr; } } fin{s};
-    {   // Lsym of the members whose Hessian changed
-        Set dirty;
-        for (int i : all) if (g->hs[i]->hessian_dirty) dirty.push_back(i);
-        if (!dirty.empty()) { g_activate(g, dirty); launch_symmetrize(s); for (int i : dirty) g->hs[i]->hessian_dirty = false; }
-    }
-    std::vector<Scalars> saved_sc(B);
-    std::vector<std::vector<double>> ft(B), fm(B);
-    std::vector<calipso::i64> fi(B, 0);
-    g_activate(g, all);
-    if (!advance) {
-        copy_d(s, s->saved_point, s->solution, d.N);
-        copy_d(s, s->saved_g, s->g, d.ne);
-        copy_d(s, s->saved_h, s->hc, d.nc);
-        copy_d(s, s->dscal + 32, s->dscal, 2);
-        for (int i : all) { H* h = g->hs[i]; saved_sc[i] = h->sc; ft[i] = h->filter_theta; fm[i] = h->filter_merit; fi[i] = h->filter_index; }
-    }
-    std::vector<IterInfo> info(B);
-    std::vector<int> rc(B, 0);
-    EV(8);
-    int e = gb_inner_iteration(g, all, info, rc);
-    EV(9);
-    if (e < 0) return e;
-    if (!advance) {
-        g_activate(g, all);
-        copy_d(s, s->solution, s->saved_point, d.N);
-        copy_d(s, s->g, s->saved_g, d.ne);
-        copy_d(s, s->hc, s->saved_h, d.nc);
-        copy_d(s, s->dscal, s->dscal + 32, 2);
-        launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT);
-        for (int i : all) {
-            H* h = g->hs[i];
-            h->filter_theta = ft[i]; h->filter_merit = fm[i]; h->filter_index = fi[i];
-            const double keep_ep = h->sc.ep, keep_ed = h->sc.ed;
-            h->sc = saved_sc[i]; h->sc.ep = keep_ep; h->sc.ed = keep_ed;
-        }
-    }
-    SYNC();
-    for (size_t i = 0; i < B; ++i) {
-        if (info_out) {
-            double* o = info_out + 6 * i;
-            o[0] = info[i].step_size; o[1] = info[i].step_size_t; o[2] = info[i].rounds; o[3] = (double)info[i].nfact; o[4] = info[i].Mh; o[5] = info[i].thetah;
-        }
-        if (status) status[i] = rc[i];
-    }
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, s->ev[0], s->ev[1]); s->phase_ms[0] = ms;
-    (void)hipEventElapsedTime(&ms, s->ev[2], s->ev[3]); s->phase_ms[2] = ms;
-    (void)hipEventElapsedTime(&ms, s->ev[3], s->ev[4]); s->phase_ms[5] = ms;
-    (void)hipEventElapsedTime(&ms, s->ev[8], s->ev[9]); s->phase_ms[6] = ms;
-    return CALIPSO_OK;
-}
-
-// solve!(solver) (solve.jl:8-377) for every member in lockstep (device evaluators attached): one pass of the inner loop body per
-// round for all members still iterating; members whose inner loop ends (central-path update due, or iteration cap) take their
-// outer update before the next round, converged members drop out.  result[i] = 1 converged, 0 iteration caps reached, < 0 error.
-int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
-    if (!g || !g->base) return CALIPSO_ERR_ARGUMENT;
-    H* s = g->base;
-    const Dims& d = s->d;
-    const size_t B = g->hs.size();
-    CK(hipSetDevice(s->device));
-    Set all;
-    for (size_t i = 0; i < B; ++i) {
-        H* h = g->hs[i];
-        if (!h->qp.attached) { s->err = "calipso_hip_group_solve needs a device evaluator on every member (calipso_hip_qp_attach)"; return CALIPSO_ERR_ARGUMENT; }
-        if (h != s) CK(hipStreamSynchronize(h->stream));
-        all.push_back((int)i);
-    }
-    struct Finally { H* s; ~Finally() { s->cur = nullptr; } } fin{s};
-    {
-        Set dirty;
-        for (int i : all) if (g->hs[i]->hessian_dirty) dirty.push_back(i);
-        if (!dirty.empty()) { g_activate(g, dirty); launch_symmetrize(s); for (int i : dirty) g->hs[i]->hessian_dirty = false; }
-    }
-    const uint32_t eval0 = CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE;
-    Set cold;
-    for (int i : all) { g->hs[i]->stats = Stats(); if (g->hs[i]->opt.warmstart == 0.0) cold.push_back(i); }
-    if (!cold.empty()) {                                                                   // initialize_slacks!/duals! initialize.jl:15-36
-        g_activate(g, cold);
-        launch_qp_evaluate(s, s->solution, eval0);
-        launch_init_point(s);
-    }
-    for (int i : all) {
-        H* h = g->hs[i]; Options& o = h->opt; Scalars& sc = h->sc;
-        sc.kappa = o.central_path_initial; sc.tau = std::max(0.99, 1.0 - sc.kappa);       // initialize.jl:38-42
-        sc.rho = o.penalty_initial;                                                       // :44-48
-        g_activate(g, Set{i});
-        fill_d(s, s->lambda, d.ne, o.dual_initial);
-        filter_reset(h);                                                                  // solve.jl:95
-    }
-    g_activate(g, all);
-    launch_qp_evaluate(s, s->solution, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE);   // :78-83
-    launch_violations(s);
-    if (g_read_d(g, all, 16, 2)) return CALIPSO_ERR_HIP;
-    std::vector<double> ev(B), cv(B);
-    for (int i : all) { ev[i] = g->hs[i]->hscal[16]; cv[i] = g->hs[i]->hscal[17]; }        // :85-86 (cone product read before cone!: reference quirk)
-    launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT | CALIPSO_CONE_TARGET);               // :88-91
-    std::vector<calipso::i64> outer(B, 1), inner(B, 1), total(B, 1);
-    std::vector<int> res(B, 0), worst(B, 0);
-    for (int i : all) g->hs[i]->stats.outer = 1;
-    Set active = all;
-    while (!active.empty()) {
-        std::vector<IterInfo> info(B);
-        std::vector<int> rc(B, 0);
-        const int e = gb_inner_iteration(g, active, info, rc, &ev, &cv);
-        if (e < 0) return e;
-        Set next, upd;
-        for (int i : active) {
-            H* h = g->hs[i]; const Options& o = h->opt;
-            if (rc[i] < 0) { res[i] = rc[i]; continue; }
-            worst[i] = std::max(worst[i], rc[i]);
-            if (info[i].exit_kind == 1) { h->stats.total_iterations = total[i]; res[i] = 1; continue; }   // converged  :138-160
-            bool inner_done = info[i].exit_kind == 2;                                                     // :165
-            if (!inner_done) {
-                ev[i] = h->hscal[16]; cv[i] = h->hscal[17];                                               // :332-333
-                if (h->cb_inner) { SYNC(); h->cb_inner(h->cb_user, h); }
-                total[i] += 1; h->stats.total_iterations = total[i];
-                inner[i] += 1;
-                if (inner[i] > o.max_residual_iterations) inner_done = true;
-            }
-            if (inner_done) upd.push_back(i); else next.push_back(i);
-        }
-        if (!upd.empty()) {                                                                // outer updates  :356-371
-            for (int i : upd) {
-                H* h = g->hs[i]; const Options& o = h->opt; Scalars& sc = h->sc;
-                sc.kappa = std::max(o.residual_tolerance / 10.0, std::min(o.central_path_scaling * sc.kappa, std::pow(sc.kappa, o.central_path_exponent)));
-                sc.tau = std::max(0.99, 1.0 - sc.kappa);
-            }
-            g_activate(g, upd);                                                            // lambda += rho r with the OLD rho (:362-365)
-            launch_lambda_update(s);
-            for (int i : upd) {
-                H* h = g->hs[i]; const Options& o = h->opt; Scalars& sc = h->sc;
-                sc.rho = std::min(std::max(o.penalty_scaling * sc.rho, 1.0 / sc.kappa), o.max_penalty);
-                filter_reset(h);
-                if (h->cb_outer) { SYNC(); h->cb_outer(h->cb_user, h); }
-                outer[i] += 1; inner[i] = 1;
-                if (outer[i] > o.max_outer_iterations) { h->stats.total_iterations = total[i]; res[i] = 0; continue; }
-                h->stats.outer = outer[i];
-                next.push_back(i);
-            }
-            std::sort(next.begin(), next.end());
-        }
-        active.swap(next);
-    }
-    SYNC();
-    if (result) for (size_t i = 0; i < B; ++i) result[i] = res[i];
-    return CALIPSO_OK;
-}
 
 int32_t calipso_hip_phase_times(H* s, double out[9]) {
     if (!s || !out) return CALIPSO_ERR_ARGUMENT;

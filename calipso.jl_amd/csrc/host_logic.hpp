@@ -1,0 +1,63 @@
+// host_logic.hpp — host-side pieces of the inner iteration shared by the single-handle driver (api.hip) and the group driver
+// (group.hip): inertia test, filter, line-search predicates.  Pure C++ on the handle's host state; nothing here touches the device.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "internal.hpp"
+
+typedef calipso_hip_solver H;
+#define SYNC() CK(hipStreamSynchronize(s->stream))
+
+static inline bool inertia_ok(const H* s, const int64_t in[3]) { return in[0] == s->d.nx && in[1] == s->d.ne + s->d.nc && in[2] == 0; }   // inertia.jl:7-11
+
+
+// ---- filter (filter.jl:1-89), host side ------------------------------------------------------------------------------------
+static inline void filter_reset(H* s) {
+    for (calipso::i64 i = 0; i < s->filter_index; ++i) { s->cache_theta[i] = 1.0e8; s->cache_merit[i] = 1.0e8; }
+    for (calipso::i64 i = 0; i < s->filter_index; ++i) { s->filter_theta[i] = 1.0e8; s->filter_merit[i] = 1.0e8; }
+    s->filter_index = 0;
+}
+static inline bool check_filter(const H* s, double theta, double merit) {
+    for (size_t i = 0; i < s->filter_theta.size(); ++i)
+        if (!(theta < s->filter_theta[i] || merit < s->filter_merit[i])) return false;
+    return true;
+}
+static inline void augment_filter(H* s, double theta, double merit) {
+    if (s->filter_index == 0) { s->filter_theta[0] = theta; s->filter_merit[0] = merit; s->filter_index = 1; return; }
+    if (check_filter(s, theta, merit)) {
+        const calipso::i64 nold = s->filter_index;
+        for (calipso::i64 i = 0; i < nold; ++i) { s->cache_theta[i] = s->filter_theta[i]; s->cache_merit[i] = s->filter_merit[i]; }
+        for (calipso::i64 i = 0; i < nold; ++i) { s->filter_theta[i] = 1.0e8; s->filter_merit[i] = 1.0e8; }
+        s->filter_index = 0;
+        s->filter_theta[0] = theta; s->filter_merit[0] = merit; s->filter_index = 1;
+        for (calipso::i64 i = 0; i < nold; ++i)
+            if (!(s->cache_theta[i] >= theta && s->cache_merit[i] >= merit)) {
+                s->filter_theta[s->filter_index] = s->cache_theta[i];
+                s->filter_merit[s->filter_index] = s->cache_merit[i];
+                s->filter_index += 1;
+            }
+    }
+}
+// line_search.jl:2-18 with d = dot(merit_gradient, step.primals) precomputed on the device
+static inline bool switching_condition(double step_size, double dd, double merit_exponent, double violation, double violation_exponent, double reg) {
+    return dd < 0.0 && step_size * std::pow(-dd, merit_exponent) > reg * std::pow(violation, violation_exponent);
+}
+static inline bool sufficient_progress(double v, double vc, double m, double mc, double vt, double mt, double mach) {
+    return vc - 10.0 * mach * std::fabs(v) <= (1.0 - vt) * v || mc - 10.0 * mach * std::fabs(m) <= m - mt * v;
+}
+static inline bool armijo(double m, double mc, double dd, double step_size, double at, double mach) {
+    return mc - m - 10.0 * mach * std::fabs(m) <= at * step_size * dd;
+}
+
+
+struct IterInfo {
+    double step_size = 1.0, step_size_t = 1.0, M = 0.0, Mh = 0.0, theta = 0.0, thetah = 0.0;
+    int rounds = 0;
+    int64_t nfact = 0;
+    int exit_kind = 0;   // 0 stepped, 1 outer convergence, 2 inner convergence
+    double residual_violation = 0, optimality = 0, slack_violation = 0;
+};
+
+#define EV(i) (void)hipEventRecord(s->ev[i], s->stream)
+
