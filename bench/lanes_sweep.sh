@@ -1,10 +1,11 @@
-for cfg in "3 6 3 4" "3 6 3 8" "1 8 4 8" "1 8 8 8" "3 12 6 8" "2 8 4 8" "1 6 3 4"; do
+# throughput vs stream-priority classes / lanes / HW queues with groups of 8 (C3)
+for cfg in "3 24 3 4" "1 24 3 4" "1 32 4 4" "1 32 4 8" "2 16 2 4" "3 48 6 8" "1 48 6 8"; do
   set -- $cfg
   echo "== classes=$1 batch=$2 lanes=$3 hwq=$4"
-  CALIPSO_HIP_PRIORITY_CLASSES=$1 GPU_MAX_HW_QUEUES=$4 timeout 200 python bench.py --batch $2 --lanes $3 --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | python -c "
+  CALIPSO_HIP_PRIORITY_CLASSES=$1 GPU_MAX_HW_QUEUES=$4 timeout 300 python bench.py --batch $2 --group 8 --lanes $3 --steps 8 --warmup 2 --no-cpu-baseline --no-single 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('value %.1f single %.1f' % (d['value'], d['config']['single_instance_steps_per_s']))
+        d=json.loads(l); print('value %.1f  ms/round %.2f' % (d['value'], d['ms_per_step']))
 "
 done

@@ -82,3 +82,26 @@ def test_advancing_steps_reduce_the_residual_full_size():
     assert v1 <= 10.0 * 0.17 and v1 < 0.05 * v0        # inner-loop exit of solve.jl:165 reached, residual cut > 20x
     sol = s.solution
     assert not s.cone_violation(sol.cone_slack, np.zeros(s.nc), 0.0) and not s.cone_violation(sol.cone_slack_dual, np.zeros(s.nc), 0.0)
+
+
+def test_group_of_full_size_instances_is_bitwise_the_single_step():
+    """two C3 instances stepped as one group (one launch sequence for both) equal their stand-alone steps bit for bit"""
+    pkg = load_pkg()
+    nx, ne, n_nn, n_soc, dim = SHAPES["C3"]
+    fl = pkg.FLAGS
+
+    def make(pid):
+        prob, pt, lam, w, s = build(pkg, pkg.splitmix_uniform, pid, nx, ne, n_nn, n_soc, dim)
+        s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
+        s.cone(product=True, target=True)
+        return s
+
+    singles = [make(1), make(2)]
+    members = [make(1), make(2)]
+    g = pkg.Group(members)
+    ref = [s.newton_step(advance=False) for s in singles]
+    got = g.newton_step(advance=False)
+    for r, q, s, m in zip(ref, got, singles, members):
+        assert r == q and r["status"] == 0
+        assert np.array_equal(s.data("step").all, m.data("step").all)
+    g.close()
