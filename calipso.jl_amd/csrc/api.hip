@@ -128,7 +128,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->Wsoc, (size_t)woff); SL(&s->Bsoc, (size_t)woff); SL(&s->socwork, (size_t)2 * woff);
     SL(&icount_d, 32);                                        // 64 ints
     const size_t maxdim = std::max(std::max(NX, M), NPd);   // rows of the largest mat-vec (the stacked Jacobian has m = ne + nc rows)
-    SL(&s->gemv_partial, 64 * maxdim);
+    SL(&s->gemv_partial, std::max(64 * maxdim, ((NX + 15) / 16) * M + ((M + 1023) / 1024) * NX));   // gemv_n chunks / gemv_both partials
     SL(&s->vtmp, 4 * std::max(N, NPd));
     SL(&s->xbuf, NPd); SL(&s->zf, NPd); SL(&s->t1, M); SL(&s->t2, M);
     SL(&s->lgp, NX * d.np); SL(&s->gp, NE * d.np); SL(&s->hp, NC * d.np);

@@ -84,6 +84,59 @@ __global__ __launch_bounds__(256) void k_gemv_n_reduce(Batch bt, int rows, int n
     }
 }
 
+// Both products with ONE pass over A (rows x cols, column-major):   yt[j] = beta_t*yt[j] + sum_i A[i][j] u[i]   (A' u)
+//                                                                    yn[i] = sum_j A[i][j] x[j]                  (A x)
+// used by the matrix-free H*v of the refinement, where the stacked Jacobian [gx; hx] enters as [gx; hx] v_x and [gx; hx]' v_yz
+// (residual_jacobian_variables.jl:19-47): the block is the largest HBM stream of a refinement round, so it is read once.
+// One wavefront walks BOTH_CW consecutive columns of a row range of 64*BOTH_RQ rows: lanes stride down the column (512-byte
+// loads), the A'u entry of a column is a wave reduction, the A x contributions stay in BOTH_RQ per-lane accumulators and are
+// written once per wavefront as a partial row vector; partials are combined in a fixed order by k_gemv_n_reduce.
+constexpr int BOTH_RQ = 16;   // rows per lane  -> 1024 rows per row range
+constexpr int BOTH_CW = 16;   // columns per wavefront
+__global__ __launch_bounds__(256) void k_gemv_both(Batch bt, int rows, int cols, int cw, const double* __restrict__ A, int ld, const double* __restrict__ x,
+                                                    const double* __restrict__ u, double* __restrict__ part_n, double* __restrict__ part_t) {
+    inst_shift(bt, A, x, u, part_n, part_t);
+    const int lane = threadIdx.x & 63;
+    const int cg = blockIdx.x * 4 + (threadIdx.x >> 6);        // column group of this wavefront
+    const int c0 = cg * cw;
+    if (c0 >= cols) return;
+    const int r0 = blockIdx.y * 64 * BOTH_RQ;
+    double uu[BOTH_RQ], acc[BOTH_RQ];
+#pragma unroll
+    for (int q = 0; q < BOTH_RQ; ++q) { const int i = r0 + lane + 64 * q; uu[q] = i < rows ? u[i] : 0.0; acc[q] = 0.0; }
+    const int c1 = min(cols, c0 + cw);
+    for (int j = c0; j < c1; ++j) {
+        const double* a = A + (size_t)j * ld;
+        double z[BOTH_RQ];
+#pragma unroll
+        for (int q = 0; q < BOTH_RQ; ++q) { const int i = r0 + lane + 64 * q; z[q] = i < rows ? a[i] : 0.0; }   // one batch of loads
+        const double xj = x[j];
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < BOTH_RQ; q += 2) {
+            t0 += z[q] * uu[q]; t1 += z[q + 1] * uu[q + 1];
+            acc[q] += z[q] * xj; acc[q + 1] += z[q + 1] * xj;
+        }
+        const double t = wave_sum(t0 + t1);
+        if (lane == 0) part_t[(size_t)blockIdx.y * cols + j] = t;
+    }
+#pragma unroll
+    for (int q = 0; q < BOTH_RQ; ++q) { const int i = r0 + lane + 64 * q; if (i < rows) part_n[(size_t)cg * rows + i] = acc[q]; }
+}
+
+// yt = A'u + beta_t*yt and yn = A x in one pass over A
+void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t) {
+    if (rows == 0 || cols == 0) return;
+    const BatchSc B = batch_of(s);
+    const int cw = BOTH_CW;   // (8 is 1 % faster for a single cache-resident instance, 16 for groups streaming from HBM)
+    const int ncg = (cols + cw - 1) / cw, nrr = (rows + 64 * BOTH_RQ - 1) / (64 * BOTH_RQ);
+    double* part_n = s->gemv_partial;                       // ncg x rows
+    double* part_t = s->gemv_partial + (size_t)ncg * rows;  // nrr x cols
+    hipLaunchKernelGGL(k_gemv_both, dim3((ncg + 3) / 4, nrr, B.b.n), dim3(256), 0, s->stream, B.b, rows, cols, cw, A, ld, x, u, part_n, part_t);
+    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, rows, ncg, part_n, yn, 1.0, 0.0);
+    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((cols + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, cols, nrr, part_t, yt, 1.0, beta_t);
+}
+
 void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta) {
     if (rows == 0) return;
     // enough workgroups to cover the chip: rows/256 row blocks x nchunk column chunks ~ 1024 workgroups

@@ -196,6 +196,7 @@ void launch_assemble_K(calipso_hip_solver* s);
 // gemv.hip
 void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta);
 void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta);
+void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t);   // yn = A x, yt = A'u + beta_t*yt, one pass over A
 // schur.hip
 void launch_cone_weights(calipso_hip_solver* s);
 void launch_scale_rows(calipso_hip_solver* s);
