@@ -147,3 +147,21 @@ def test_group_solve_with_iteration_caps():
     for (_, s), (_, m) in zip(singles, members):
         assert s.stats() == m.stats() and same(s.solution.all, m.solution.all)
     g.close()
+
+
+def test_group_of_eight_mid_size():
+    """8 x (nx = 1100, three solve blocks): group launches with thousands of trailing-update tiles and the group-sized Schur tile
+    shape (128 x 128 instead of the single handle's choice) produce the bits of the stand-alone steps"""
+    pkg = load_pkg()
+    shape = (1100, 400, 100, 50, 3)
+    ids = list(range(60, 68))
+    singles = [build(pkg, p, shape=shape) for p in ids]
+    members = [build(pkg, p, shape=shape) for p in ids]
+    g = pkg.Group(members)
+    ref = [s.newton_step(advance=True) for s in singles]
+    got = g.newton_step(advance=True)
+    for r, q, s, m in zip(ref, got, singles, members):
+        assert r == q and r["status"] == 0
+        assert same(s.data("step").all, m.data("step").all)
+        assert same(s.solution.all, m.solution.all)
+    g.close()
