@@ -165,3 +165,20 @@ def test_group_of_eight_mid_size():
         assert same(s.data("step").all, m.data("step").all)
         assert same(s.solution.all, m.solution.all)
     g.close()
+
+
+@pytest.mark.parametrize("shape", [(40, 15, 0, 0, 3), (50, 0, 10, 4, 3), (64, 20, 12, 0, 3), (130, 30, 0, 6, 5)])
+def test_group_degenerate_shapes(shape):
+    """no cones / no equalities / no second-order cones / only second-order cones: group == single, bit for bit"""
+    pkg = load_pkg()
+    ids = [70, 71, 72]
+    singles = [build(pkg, p, shape=shape) for p in ids]
+    members = [build(pkg, p, shape=shape) for p in ids]
+    g = pkg.Group(members)
+    for it in range(2):
+        ref = [s.newton_step(advance=True) for s in singles]
+        got = g.newton_step(advance=True)
+        for r, q, s, m in zip(ref, got, singles, members):
+            assert r == q, (it, r, q)
+            assert same(s.solution.all, m.solution.all)
+    g.close()
