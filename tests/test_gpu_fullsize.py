@@ -1,5 +1,6 @@
-"""GPU, BASELINE.json's full sizes (C3: n = 5000 condensed; C4 shape: n = 5234): the oracle needs ~10 s per step there, so the
-checks are size-independent properties of one Newton step computed entirely on the device:
+"""GPU, BASELINE.json's full sizes (C3: n = 5000 condensed; C4 shape: n = 5234): the oracle needs ~10 s per step there, so it is
+run once (test_full_size_step_matches_the_oracle: C3 step / residual / inertia / refinement rounds against the CPU restatement)
+and the other checks are size-independent properties of one Newton step computed entirely on the device:
   * the refined step solves the UNREDUCED Newton system: ||R - H*step||_inf <= 1e-10 (the reference's refinement criterion,
     iterative_refinement.jl:15), with H*v from the matrix-free multiply that test_gpu_parity validates against the oracle;
   * inertia of the regularised condensed matrix = (nx, ne+nc, 0)  (inertia.jl:7-11);
@@ -105,3 +106,31 @@ def test_group_of_full_size_instances_is_bitwise_the_single_step():
         assert r == q and r["status"] == 0
         assert np.array_equal(s.data("step").all, m.data("step").all)
     g.close()
+
+
+def test_full_size_step_matches_the_oracle(oracle_mod):
+    """C3 at BASELINE's full size (n = 5000 condensed, N = 8500): the refined Newton step of the device path against the CPU
+    restatement on the same inputs — the oracle needs ~10 s for this one step (sparse up-looking LDL^T in QDLDL's operation
+    order), which is also what bench.py times as the CPU baseline.  Tolerances of SURVEY.md 8(c): step 1e-8, residual 1e-12."""
+    pkg = load_pkg()
+    nx, ne, n_nn, n_soc, dim = SHAPES["C3"]
+    prob, pt, lam, w, s = build(pkg, pkg.splitmix_uniform, 0, nx, ne, n_nn, n_soc, dim)
+    fl = pkg.FLAGS
+    s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
+    s.cone(product=True, target=True)
+    info = s.newton_step(advance=False)
+    step, R = s.data("step").all, s.data("residual").all
+    o = oracle_mod.OracleSolver(prob.nx, 0, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
+    o.point()["all"][:] = w
+    o.buf("dual")[:] = lam
+    o.buf("central_path")[0] = 0.17; o.buf("penalty")[0] = 52.0
+    o.set_int("linear_solve_refactor", 0)
+    prob.evaluate(pr.ALL_VARIABLE_FLAGS, pt["x"], pt["y"], pt["z"], np.zeros(0), o.buf)
+    o.cone(product=True, jacobian=True, target=True, barrier=True, barrier_gradient=True)
+    o.residual()
+    assert o.search_direction() == 0
+    so, Ro = np.array(o.buf("step")), np.array(o.buf("residual"))
+    assert np.abs(R - Ro).max() <= 1e-12 * max(1.0, np.abs(Ro).max())
+    assert np.abs(step - so).max() <= 1e-8 * max(1.0, np.abs(so).max())
+    assert o.stats()["last_refinement_rounds"] == info["refinement_rounds"]
+    assert tuple(o.compute_inertia()) == (nx, ne + n_nn + n_soc * dim, 0)
