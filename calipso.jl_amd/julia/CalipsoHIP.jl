@@ -246,6 +246,14 @@ function newton_step!(g::HIPGroup; advance::Bool=true)
     return info, status
 end
 
+"solve! (solve.jl:8-377) of every member in lockstep (device evaluators attached); returns the per-member results (1 = converged)."
+function CALIPSO.solve!(g::HIPGroup)
+    res = zeros(Int32, length(g.members))
+    rc = ccall((:calipso_hip_group_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Int32}), g.handle, res)
+    rc < 0 && error("calipso_hip_group_solve failed ($rc)")
+    return res
+end
+
 export HIPSolver, HIPLDLSolver, HIPGroup, newton_step!, search_direction_nonsymmetric!
 
 end # module
