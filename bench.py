@@ -87,10 +87,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=24, help="independent problem instances per GPU; 3 are in flight at a time (one per HIP\n"
+    ap.add_argument("--batch", type=int, default=36, help="independent problem instances per GPU; 3 are in flight at a time (one per HIP\n"
                     "stream-priority class, which the runtime maps to distinct hardware queues), see calipso.jl_amd/batch.py")
     ap.add_argument("--lanes", type=int, default=3, help="host threads / HIP streams driving the units (groups or single instances) concurrently")
-    ap.add_argument("--group", type=int, default=8, help="instances per group: the members of a group are stepped in lockstep through the same\n"
+    ap.add_argument("--group", type=int, default=12, help="instances per group: the members of a group are stepped in lockstep through the same\n"
                     "kernel launches (calipso_hip_group_*); --batch must be a multiple of it")
     ap.add_argument("--config", default="C3", choices=list(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")

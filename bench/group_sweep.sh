@@ -1,12 +1,13 @@
-# throughput vs group size / lanes (C3): python bench.py --batch B --group G --lanes L
-for cfg in "6 1 3" "2 2 1" "4 4 1" "8 8 1" "16 16 1" "12 4 3" "24 8 3" "12 6 2" "16 8 2" "48 16 3"; do
-  set -- $cfg
-  echo "== batch=$1 group=$2 lanes=$3"
-  timeout 600 python bench.py --batch $1 --group $2 --lanes $3 --steps ${STEPS:-8} --warmup 2 --no-cpu-baseline --config ${CONFIG:-C3} 2>&1 | python -c "
+# throughput vs group size / lanes (C3):  bash bench/group_sweep.sh [B:G:L ...]   (python bench.py --batch B --group G --lanes L)
+[ $# -eq 0 ] && set -- 24:8:3 30:10:3 36:12:3 48:16:3 16:8:2 32:16:2
+for cfg in "$@"; do
+  IFS=: read B G L <<< "$cfg"
+  echo "== batch=$B group=$G lanes=$L"
+  timeout 600 python bench.py --batch $B --group $G --lanes $L --steps ${STEPS:-8} --warmup 2 --no-cpu-baseline --no-single --config ${CONFIG:-C3} 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); c=d['config']; print('value %.1f steps/s  ms/round %.2f  single %.1f  schur_ms(concurrent) %.3f' % (d['value'], d['ms_per_step'], c['single_instance_steps_per_s'], list(d['roofline'].values())[-1]))
+        d=json.loads(l); c=d['config']; print('value %.1f steps/s  ms/round %.2f  unit alone %.1f' % (d['value'], d['ms_per_step'], c['one_unit_alone_steps_per_s']))
     elif 'Error' in l or 'error' in l: print(l.strip()[:300])
 "
 done

@@ -3,7 +3,7 @@
 #   1. the default bench line (with the CPU baseline)
 #   2. rocprofv3 --kernel-trace --stats of ONE unit in flight (a group of G instances, one lane): per-kernel averages are uncontended
 #   3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, MfmaUtil, LDS bank conflicts / active cycles) of the same command, summarised by bench/pmc_summary.py
-G=${1:-8}
+G=${1:-12}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/round
 mkdir -p $O
