@@ -5,7 +5,9 @@ A "step" = one inner Newton iteration of solve! (src/solver/solve.jl:98-353) on 
 instances this rank holds: evaluate (QP mat-vecs on the device) -> cone! -> residual! -> inertia-corrected LDL^T of the
 condensed KKT matrix -> condensed solve + step recovery -> >= 1 refinement round against the unreduced system -> cone
 fraction-to-boundary search -> candidate merit / violation -> filter line-search decision.  Inputs are resident in HBM
-before the timed region.  Workload = BASELINE config C3 (synthetic dense conic QP, nx=2500, ne=1500, nc=400 R+ + 200 x SOC3
+before the timed region.  The B instances of a rank are bound into groups of G (default 36 = 3 x 12): a group steps its members
+in lockstep through the same kernel launches (the problem instance is a grid dimension of every kernel), three groups are in
+flight on three HIP streams.  ms_per_step is the time of one such pass over all B instances.  Workload = BASELINE config C3 (synthetic dense conic QP, nx=2500, ne=1500, nc=400 R+ + 200 x SOC3
 => n = 5000 condensed, N = 8500 unreduced), problem ids  rank*B .. rank*B+B-1  (SplitMix64 streams).
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
@@ -87,8 +89,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=36, help="independent problem instances per GPU; 3 are in flight at a time (one per HIP\n"
-                    "stream-priority class, which the runtime maps to distinct hardware queues), see calipso.jl_amd/batch.py")
+    ap.add_argument("--batch", type=int, default=36, help="independent problem instances per GPU (B), arranged in groups of --group members;\n"
+                    "--lanes groups are in flight at a time, see calipso.jl_amd/batch.py")
     ap.add_argument("--lanes", type=int, default=3, help="host threads / HIP streams driving the units (groups or single instances) concurrently")
     ap.add_argument("--group", type=int, default=12, help="instances per group: the members of a group are stepped in lockstep through the same\n"
                     "kernel launches (calipso_hip_group_*); --batch must be a multiple of it")
