@@ -32,7 +32,9 @@ template <typename T>
 static int dalloc(H* s, T** p, size_t count) {
     if (count == 0) count = 1;
     CK(hipMalloc((void**)p, count * sizeof(T)));
-    CK(hipMemset(*p, 0, count * sizeof(T)));
+    // zero-fill ON THE HANDLE'S STREAM: the streams are non-blocking, so a hipMemset on the null stream would not be ordered with
+    // the uploads / kernels that follow on s->stream and could land after them
+    CK(hipMemsetAsync(*p, 0, count * sizeof(T), s->stream));
     return 0;
 }
 
@@ -137,7 +139,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     size_t total = 0;
     for (auto& c : carve) total += (c.second + 31) & ~(size_t)31;
     CK(hipMalloc((void**)&s->slab, total * sizeof(double)));
-    CK(hipMemset(s->slab, 0, total * sizeof(double)));
+    CK(hipMemsetAsync(s->slab, 0, total * sizeof(double), s->stream));   // (on the handle's stream, see dalloc)
     s->slab_doubles = total;
     {
         size_t off = 0;
@@ -151,6 +153,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     if (rc) return CALIPSO_ERR_HIP;
     CK(hipHostMalloc((void**)&s->hscal, 64 * sizeof(double)));
     CK(hipHostMalloc((void**)&s->hicount, 64 * sizeof(int)));
+    CK(hipStreamSynchronize(s->stream));   // the zero-fills above are complete before the (null-stream) index uploads below
     if (d.n_soc) {
         CK(hipMemcpy(s->cone.soc_start, s->h_soc_start.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
         CK(hipMemcpy(s->cone.soc_dim, s->h_soc_dim.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
