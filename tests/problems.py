@@ -335,6 +335,26 @@ def qp_equality_parametric(seed=0, nx=10, ne=5):
     return prob
 
 
+def qp_nonnegative_parametric(seed=0, nx=10, ne=5):
+    """test/solver/qp_nonnegative.jl:2-49: the parametric QP of qp_equality.jl with the cone constraint x >= 0 (nc = nx nonnegative entries)"""
+    base = qp_equality_parametric(seed=seed, nx=nx, ne=ne)
+    theta = base.parameters
+
+    def obj(x, th):
+        return sum(0.5 * th[i] * x[i] ** 2 for i in range(nx)) + sum(th[nx + i] * x[i] for i in range(nx))
+
+    def eq(x, th):
+        return [sum(th[2 * nx + i + j * ne] * x[j] for j in range(nx)) - th[2 * nx + ne * nx + i] for i in range(ne)]
+
+    def cone(x, th):
+        return [x[i] for i in range(nx)]
+
+    prob = SymbolicProblem(nx, obj, eq, cone, np_=theta.size, parameters=theta, x0=np.random.default_rng(seed + 100).standard_normal(nx),
+                           name="qp_nonnegative")
+    prob.Pd, prob.p, prob.A, prob.b = base.Pd, base.p, base.A, base.b
+    return prob
+
+
 def pendulum(T=11, h=0.05, action_guess=None):
     """README.md:123-189 = test/examples/pendulum.jl:3-59 written directly in standard form (BASELINE config C2).
     z = [X1;U1;...;X10;U10;X11]; equality = [d_1..d_10; X1 - 0; X11 - (pi,0)].

@@ -117,3 +117,42 @@ def test_error_paths():
         s.set("no_such_field", [1.0])
     with pytest.raises(pkg.CalipsoHipError):
         s.set("solution", np.zeros(5))
+
+
+@pytest.mark.parametrize("which,expect", [("test2", [2.0 / 3.0, 1.0 / np.sqrt(3.0)]), ("test3", None), ("test4", [-1 / np.sqrt(6), 2 / np.sqrt(6), -1 / np.sqrt(6)])])
+def test_small_nonconvex(oracle_mod, which, expect):
+    """test/solver/test2.jl, test3.jl, test4.jl: the reference's convergence criteria, the known minimisers, and the oracle's answer"""
+    prob = getattr(pr, which)(np.random.default_rng(4).random(3 if which == "test4" else 2))
+    s, ok = run_hip(prob)
+    assert ok
+    criteria(s)
+    if expect is not None:
+        assert np.abs(s.solution.variables - np.array(expect)).max() < 2e-3
+    o, st = run_oracle(oracle_mod, prob)
+    assert st == 1 and np.abs(s.solution.variables - o.point()["x"]).max() < 1e-3
+    assert s.stats()["total_iterations"] == o.stats()["total_iterations"]
+
+
+def test_qp_nonnegative(oracle_mod):
+    """test/solver/qp_nonnegative.jl: parametric QP with x >= 0, differentiate=true; criteria of :52-67 and parity of the solution and
+    of the sensitivities with the oracle"""
+    prob = pr.qp_nonnegative_parametric(seed=3)
+    s, ok = run_hip(prob, differentiate=1)
+    assert ok
+    criteria(s)
+    x = s.solution.variables
+    assert np.all(x > -1e-4) and np.abs(prob.A @ x - prob.b).max() < 1e-4
+    o, st = run_oracle(oracle_mod, prob, differentiate=1)
+    assert st == 1 and s.stats()["total_iterations"] == o.stats()["total_iterations"]
+    assert np.abs(s.solution.all - o.point()["all"]).max() <= 1e-6 * max(1.0, np.abs(o.point()["all"]).max())
+    # dR/dtheta agrees; the sensitivities solve H S = -dR/dtheta at the converged point.  (S itself is NOT compared entry-wise with
+    # the oracle's: with active bounds the slacks are ~1e-5, so iterates that agree to 1e-9 give K_zz entries that differ in the
+    # third digit — the reference comments its own sensitivity asserts out for this problem, qp_nonnegative.jl:122-124.  Entry-wise
+    # parity of differentiate! at a common point is test_gpu_multirhs.py.)
+    J = s.data("jacobian_parameters")
+    assert np.abs(J - o.mat("jacobian_parameters", o.N, prob.np)).max() <= 1e-6
+    S_gpu = s.data("solution_sensitivity")
+    assert np.isfinite(S_gpu).all()
+    for j in (0, prob.nx, prob.np - 1):
+        Hs = s.jacobian_variables_mul(S_gpu[:, j])
+        assert np.abs(Hs + J[:, j]).max() <= 1e-6 * max(1.0, np.abs(J[:, j]).max(), np.abs(S_gpu[:, j]).max())

@@ -114,6 +114,19 @@ def test_random_qp_solves(oracle_mod):
     criteria(o)
 
 
+def test_qp_nonnegative(oracle_mod):
+    """test/solver/qp_nonnegative.jl:52-67: convergence criteria, x >= -1e-4, A x = b (the reference's sensitivity asserts there are
+    commented out, :122-124)"""
+    prob = pr.qp_nonnegative_parametric(seed=3)
+    o, status = run(oracle_mod, prob, differentiate=1)
+    assert status == 1
+    criteria(o)
+    x = o.point()["x"]
+    assert np.all(x > -1e-4) and np.abs(prob.A @ x - prob.b).max() < 1e-4
+    S = o.mat("solution_sensitivity", o.N, prob.np)
+    assert np.isfinite(S).all() and np.abs(S[:prob.nx]).max() > 0
+
+
 def test_qp_equality_sensitivity(oracle_mod):
     """test/solver/qp_equality.jl:37-122: solution sensitivities vs the analytic KKT inverse and vs -H \\ dR/dtheta (1e-2)"""
     prob = pr.qp_equality_parametric(seed=5)
