@@ -409,6 +409,8 @@ class Group:
         import ctypes as C
         B = len(self.solvers)
         res = (C.c_int32 * B)()
+        self._evals = (EVAL_FN * B)(*[s._cb for s in self.solvers])       # host callbacks (used by members without a device evaluator)
+        self._L.calipso_hip_group_set_evaluators(self._g, self._evals, None)
         rc = self._L.calipso_hip_group_solve(self._g, res)
         if rc < 0:
             raise CalipsoHipError("group_solve: %s (%d): %s" % (STATUS_TEXT.get(rc, "error"), rc, self._L.calipso_hip_last_error(self.solvers[0]._h).decode()))

@@ -59,6 +59,7 @@ SYMBOLS = {
     "calipso_hip_group_destroy": (_i32, [_vp]),
     "calipso_hip_group_newton_step": (_i32, [_vp, _i32, _pd, C.POINTER(_i32)]),
     "calipso_hip_group_solve": (_i32, [_vp, C.POINTER(_i32)]),
+    "calipso_hip_group_set_evaluators": (_i32, [_vp, C.POINTER(EVAL_FN), C.POINTER(_vp)]),
     "calipso_hip_synchronize": (_i32, [_vp]),
     "calipso_hip_splitmix_uniform": (_i32, [_u64, _u64, _dbl, _dbl, _i64, _pd]),
 }

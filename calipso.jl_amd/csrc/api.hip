@@ -474,6 +474,8 @@ static int do_cone_search(H* s, double* a_s, double* a_t) {
     return CALIPSO_OK;
 }
 
+static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t flags);
+namespace calipso { int evaluate_point(calipso_hip_solver* s, calipso_eval_fn eval, void* user, int which, uint32_t flags) { return evaluate(s, eval, user, which, flags); } }
 static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t flags) {
     double* pt = point_of(s, which);
     if (s->qp.attached) { launch_qp_evaluate(s, pt, flags); return CALIPSO_OK; }

@@ -24,6 +24,8 @@ struct calipso_hip_group {
     calipso::BatchSc desc;             // instance list of the launches being enqueued (base->cur points here)
     double *dgather = nullptr, *hgather = nullptr;   // MAX_BATCH x 64 doubles (device, pinned host)
     int *digather = nullptr, *higather = nullptr;    // MAX_BATCH x 64 ints
+    std::vector<calipso_eval_fn> evals;              // host evaluation callbacks of the members without a device evaluator
+    std::vector<void*> users;
     std::string err;
 };
 typedef calipso_hip_group G;
@@ -68,9 +70,37 @@ static int g_read_i(G* g, const Set& a, int first, int count) {
     return 0;
 }
 
+// evaluate! for the members of `a` at their current (which = 0) or candidate (1) point: one batched launch sequence for the members
+// with a device evaluator, the host callback (on the member's own stream, after the group's stream has drained) for the others
+static int gb_evaluate(G* g, const Set& a, int which, uint32_t flags) {
+    H* s = g->base;
+    Set dev, host;
+    for (int i : a) (g->hs[i]->qp.attached ? dev : host).push_back(i);
+    if (!dev.empty()) {
+        g_activate(g, dev);
+        launch_qp_evaluate(s, which == 0 ? s->solution : s->candidate, flags);
+    }
+    if (!host.empty()) {
+        SYNC();
+        for (int i : host) {
+            H* h = g->hs[i];
+            const int rc = evaluate_point(h, i < (int)g->evals.size() ? g->evals[i] : nullptr, i < (int)g->users.size() ? g->users[i] : nullptr, which, flags);
+            if (rc < 0) { s->err = "member " + std::to_string(i) + ": " + h->err; return rc; }
+            CK(hipStreamSynchronize(h->stream));      // the callback's uploads are complete before the group's stream goes on
+        }
+    }
+    g_activate(g, a);
+    return CALIPSO_OK;
+}
+
 // factorize! + compute_inertia! for the members of `a`
 static int gb_factorize(G* g, const Set& a, std::vector<std::array<int64_t, 3>>& in) {
     H* s = g->base;
+    {   // Lsym of the members whose Hessian was re-uploaded since the last factorisation
+        Set dirty;
+        for (int i : a) if (g->hs[i]->hessian_dirty) dirty.push_back(i);
+        if (!dirty.empty()) { g_activate(g, dirty); launch_symmetrize(s); for (int i : dirty) g->hs[i]->hessian_dirty = false; }
+    }
     g_activate(g, a);
     (void)hipEventRecord(s->ev[10], s->stream);
     launch_cone_weights(s);
@@ -184,8 +214,8 @@ static Set alive(const Set& a, const std::vector<int>& rc) { Set r; for (int i :
 
 static int gb_candidate_merit(G* g, const Set& a, std::vector<double>& Mh, std::vector<double>& thetah) {
     H* s = g->base;
-    g_activate(g, a);
-    launch_qp_evaluate(s, s->candidate, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);
+    const int e = gb_evaluate(g, a, 1, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);
+    if (e < 0) return e;
     launch_cone(s, s->candidate, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);
     launch_merit(s, s->candidate);
     launch_constraint_violation(s, s->candidate);
@@ -202,7 +232,10 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
     const size_t B = g->hs.size();
     g_activate(g, a0);
     EV(0);
-    launch_qp_evaluate(s, s->solution, CALIPSO_EVAL_OBJECTIVE_GRADIENT | CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT | CALIPSO_EVAL_CONE_DUAL_GRADIENT);
+    {
+        const int e0 = gb_evaluate(g, a0, 0, CALIPSO_EVAL_OBJECTIVE_GRADIENT | CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT | CALIPSO_EVAL_CONE_DUAL_GRADIENT);   // :100-104
+        if (e0 < 0) return e0;
+    }
     launch_cone(s, s->solution, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);
     launch_merit(s, s->solution);
     launch_merit_gradient(s);
@@ -227,7 +260,19 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
     }
     EV(1);
     if (a.empty()) { EV(2); EV(3); EV(4); return CALIPSO_OK; }
-    // Hessian / Jacobians of a QP are constant (:175-181 is a no-op for the device evaluator)
+    {   // :175-181 (a no-op for the device QP evaluator, whose Hessian / Jacobians are constant)
+        Set cb;
+        for (int i : a) if (!g->hs[i]->qp.attached) cb.push_back(i);
+        if (!cb.empty()) {
+            for (int i : cb) {
+                uint32_t fl = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE_JACOBIAN;
+                if (g->hs[i]->opt.constraint_tensor != 0.0) fl |= CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
+                const int e1 = gb_evaluate(g, Set{i}, 0, fl);
+                if (e1 < 0) return e1;
+            }
+            g_activate(g, a);
+        }
+    }
     EV(2);
     std::vector<int64_t> nfact(B, 0);
     std::vector<int> rounds(B, 0);
@@ -356,6 +401,15 @@ int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, ca
     return CALIPSO_OK;
 }
 
+// host evaluation callbacks (calipso_eval_fn, include/calipso_hip.h) of the members that have no device evaluator; entries may be NULL
+int32_t calipso_hip_group_set_evaluators(calipso_hip_group* g, const calipso_eval_fn* evals, void* const* users) {
+    if (!g) return CALIPSO_ERR_ARGUMENT;
+    g->evals.assign(g->hs.size(), nullptr);
+    g->users.assign(g->hs.size(), nullptr);
+    for (size_t i = 0; i < g->hs.size(); ++i) { if (evals) g->evals[i] = evals[i]; if (users) g->users[i] = users[i]; }
+    return CALIPSO_OK;
+}
+
 int32_t calipso_hip_group_destroy(calipso_hip_group* g) {
     if (!g) return CALIPSO_OK;
     if (g->base) { (void)hipSetDevice(g->base->device); (void)hipStreamSynchronize(g->base->stream); g->base->cur = nullptr; }
@@ -446,7 +500,10 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
     Set all;
     for (size_t i = 0; i < B; ++i) {
         H* h = g->hs[i];
-        if (!h->qp.attached) { s->err = "calipso_hip_group_solve needs a device evaluator on every member (calipso_hip_qp_attach)"; return CALIPSO_ERR_ARGUMENT; }
+        if (!h->qp.attached && (i >= g->evals.size() || !g->evals[i])) {
+            s->err = "calipso_hip_group_solve: member without a device evaluator and without a callback (calipso_hip_group_set_evaluators)";
+            return CALIPSO_ERR_ARGUMENT;
+        }
         if (h != s) CK(hipStreamSynchronize(h->stream));
         all.push_back((int)i);
     }
@@ -460,8 +517,8 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
     Set cold;
     for (int i : all) { g->hs[i]->stats = Stats(); if (g->hs[i]->opt.warmstart == 0.0) cold.push_back(i); }
     if (!cold.empty()) {                                                                   // initialize_slacks!/duals! initialize.jl:15-36
-        g_activate(g, cold);
-        launch_qp_evaluate(s, s->solution, eval0);
+        const int e0 = gb_evaluate(g, cold, 0, eval0);
+        if (e0 < 0) return e0;
         launch_init_point(s);
     }
     for (int i : all) {
@@ -472,8 +529,10 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
         fill_d(s, s->lambda, d.ne, o.dual_initial);
         filter_reset(h);                                                                  // solve.jl:95
     }
-    g_activate(g, all);
-    launch_qp_evaluate(s, s->solution, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE);   // :78-83
+    {
+        const int e1 = gb_evaluate(g, all, 0, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE);   // :78-83
+        if (e1 < 0) return e1;
+    }
     launch_violations(s);
     if (g_read_d(g, all, 16, 2)) return CALIPSO_ERR_HIP;
     std::vector<double> ev(B), cv(B);
@@ -493,7 +552,15 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
             H* h = g->hs[i]; const Options& o = h->opt;
             if (rc[i] < 0) { res[i] = rc[i]; continue; }
             worst[i] = std::max(worst[i], rc[i]);
-            if (info[i].exit_kind == 1) { h->stats.total_iterations = total[i]; res[i] = 1; continue; }   // converged  :138-160
+            if (info[i].exit_kind == 1) {                                                                 // converged  :138-160
+                h->stats.total_iterations = total[i]; res[i] = 1;
+                if (o.differentiate != 0.0 && d.np > 0) {                                                 // differentiate! on the member's own stream
+                    SYNC();
+                    const int dr = calipso_hip_differentiate(h, i < (int)g->evals.size() ? g->evals[i] : nullptr, i < (int)g->users.size() ? g->users[i] : nullptr);
+                    if (dr < 0) res[i] = dr;
+                }
+                continue;
+            }
             bool inner_done = info[i].exit_kind == 2;                                                     // :165
             if (!inner_done) {
                 ev[i] = h->hscal[16]; cv[i] = h->hscal[17];                                               // :332-333

@@ -227,6 +227,9 @@ void nonsymmetric_release(calipso_hip_solver* s);
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 
 int check(calipso_hip_solver* s, hipError_t e, const char* what);
+// evaluate!(problem, methods, idx, point, parameters; flags) at the current (which = 0) or candidate (1) point: the attached device
+// evaluator, else the host callback (api.hip)
+int evaluate_point(calipso_hip_solver* s, calipso_eval_fn eval, void* user, int which, uint32_t flags);
 // the batch a launch on `s` covers: the group's active set if a group is driving `s`, else `s` alone with its own scalars
 inline BatchSc batch_of(const calipso_hip_solver* s) {
     if (s->cur) return *s->cur;

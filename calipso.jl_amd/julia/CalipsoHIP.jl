@@ -246,9 +246,13 @@ function newton_step!(g::HIPGroup; advance::Bool=true)
     return info, status
 end
 
-"solve! (solve.jl:8-377) of every member in lockstep (device evaluators attached); returns the per-member results (1 = converged)."
+"solve! (solve.jl:8-377) of every member in lockstep; members are evaluated through `evaluate_callback` (their own CALIPSO.evaluate!)."
 function CALIPSO.solve!(g::HIPGroup)
     res = zeros(Int32, length(g.members))
+    cb = @cfunction(evaluate_callback, Int32, (Ptr{Cvoid}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}))
+    evals = fill(cb, length(g.members))
+    users = Ptr{Cvoid}[pointer_from_objref(m) for m in g.members]
+    ccall((:calipso_hip_group_set_evaluators, lib), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), g.handle, evals, users)
     rc = ccall((:calipso_hip_group_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Int32}), g.handle, res)
     rc < 0 && error("calipso_hip_group_solve failed ($rc)")
     return res

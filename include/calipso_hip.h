@@ -211,8 +211,11 @@ int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, ca
 int32_t calipso_hip_group_destroy(calipso_hip_group*);
 /* calipso_hip_newton_step for every member: info = count x 6 doubles (row per member, fields as above), status = count codes */
 int32_t calipso_hip_group_newton_step(calipso_hip_group*, int32_t advance, double* info, int32_t* status);
-/* solve!(solver) (solve.jl:8-377) for every member in lockstep (device evaluators attached, no parameters): result[i] = 1
- * converged, 0 iteration caps reached, < 0 the member's error code.  Per member identical to calipso_hip_solve. */
+/* solve!(solver) (solve.jl:8-377) for every member in lockstep: result[i] = 1 converged, 0 iteration caps reached, < 0 the
+ * member's error code.  Per member identical to calipso_hip_solve.  Members with a device evaluator are evaluated inside the
+ * group's launches; the others through their host callback (calipso_hip_group_set_evaluators: one calipso_eval_fn / user pointer
+ * per member, NULL where a device evaluator is attached), one member after the other. */
+int32_t calipso_hip_group_set_evaluators(calipso_hip_group*, const calipso_eval_fn* evals, void* const* users);
 int32_t calipso_hip_group_solve(calipso_hip_group*, int32_t* result);
 
 /* timing of the last calipso_hip_newton_step / factorisation, in milliseconds, from HIP events on the handle's stream:

@@ -182,3 +182,32 @@ def test_group_degenerate_shapes(shape):
             assert r == q, (it, r, q)
             assert same(s.solution.all, m.solution.all)
     g.close()
+
+
+def test_group_solve_through_host_callbacks():
+    """members without a device evaluator (the general case: user functions behind the evaluation callback): four pendulum
+    swing-ups (BASELINE config C2 shape, different initial guesses) solved in lockstep end exactly where their stand-alone
+    solves end"""
+    pkg = load_pkg()
+    rng = np.random.default_rng(8)
+    guesses = [np.zeros(10), 0.1 * rng.standard_normal(10), rng.standard_normal(10), 0.5 * np.ones(10)]
+
+    options = [dict(), dict(central_path_initial=0.3), dict(penalty_initial=5.0), dict(residual_tolerance=1e-6, equality_tolerance=1e-6)]
+
+    def make(g, o):
+        prob = pr.pendulum(action_guess=g)
+        s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, options=o)
+        pkg.initialize_b(s, prob.x0)
+        return s
+
+    singles = [make(g, o) for g, o in zip(guesses, options)]
+    members = [make(g, o) for g, o in zip(guesses, options)]
+    ref = [int(pkg.solve_b(s)) for s in singles]
+    grp = pkg.Group(members)
+    got = grp.solve()
+    assert got == ref and all(ref)
+    assert len({s.stats()["total_iterations"] for s in singles}) > 1
+    for s, m in zip(singles, members):
+        assert s.stats() == m.stats()
+        assert same(s.solution.all, m.solution.all)
+    grp.close()
