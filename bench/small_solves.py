@@ -29,3 +29,18 @@ for name, v in (("central_path", 0.17), ("penalty", 52.0), ("primal_regularizati
 s.differentiate()
 t0 = time.perf_counter(); s.differentiate(); dt = time.perf_counter() - t0
 print("parametric conic QP nx=1500 ne=400 nc=250: differentiate p=%d columns wall ms %.2f (includes the python evaluation callback)" % (prob.np, dt * 1e3))
+
+# a batch of C2 problems: one after the other vs one lockstep group (evaluation through the python callbacks either way)
+B = 16
+def mk(k):
+    p = pr.pendulum(action_guess=0.05 * k * np.ones(10))
+    s = pkg.Solver(p, p.nx, p.np, p.ne, p.nc)
+    return p, s
+inst = [mk(k) for k in range(B)]
+grp = pkg.Group([s for _, s in inst])
+for rep in range(2):
+    for p, s in inst: pkg.initialize_b(s, p.x0)
+    t0 = time.perf_counter(); ok1 = [pkg.solve_b(s) for _, s in inst]; t1 = time.perf_counter() - t0
+    for p, s in inst: pkg.initialize_b(s, p.x0)
+    t0 = time.perf_counter(); ok2 = grp.solve(); t2 = time.perf_counter() - t0
+print("%d pendulum (C2) solves: one after the other %.1f ms, lockstep group %.1f ms (python evaluation callbacks in both)" % (B, t1 * 1e3, t2 * 1e3), all(ok1), all(ok2))
