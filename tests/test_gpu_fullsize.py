@@ -16,10 +16,11 @@ from test_gpu_synthetic import build
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = {"C3": (2500, 1500, 400, 200, 3), "C4": (2302, 2208, 244, 240, 2)}
+SHAPES = {"C3": (2500, 1500, 400, 200, 3), "C4": (2302, 2208, 244, 240, 2),
+          "beyond": (4100, 700, 200, 100, 4)}     # nx padded to 4608 = 9 solve blocks: larger than anything in BASELINE.json
 
 
-@pytest.mark.parametrize("cfg", ["C3", "C4"])
+@pytest.mark.parametrize("cfg", ["C3", "C4", "beyond"])
 def test_newton_step_properties_full_size(cfg):
     pkg = load_pkg()
     nx, ne, n_nn, n_soc, dim = SHAPES[cfg]
