@@ -556,6 +556,7 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
                 h->stats.total_iterations = total[i]; res[i] = 1;
                 if (o.differentiate != 0.0 && d.np > 0) {                                                 // differentiate! on the member's own stream
                     SYNC();
+                    s->cur = nullptr;                                                                     // a single-handle call (h may be the base)
                     const int dr = calipso_hip_differentiate(h, i < (int)g->evals.size() ? g->evals[i] : nullptr, i < (int)g->users.size() ? g->users[i] : nullptr);
                     if (dr < 0) res[i] = dr;
                 }
