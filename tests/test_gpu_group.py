@@ -211,3 +211,27 @@ def test_group_solve_through_host_callbacks():
         assert s.stats() == m.stats()
         assert same(s.solution.all, m.solution.all)
     grp.close()
+
+
+def test_group_solve_with_parameters_differentiates_each_member():
+    """differentiate=true and np > 0 (test/solver/qp_equality.jl): the sensitivities of every member of a lockstep solve are those of
+    its stand-alone solve, bit for bit (including the member that is the group's base handle)"""
+    pkg = load_pkg()
+    opts = dict(residual_tolerance=1e-8, equality_tolerance=1e-6, complementarity_tolerance=1e-6, differentiate=1)
+
+    def make(seed):
+        prob = pr.qp_equality_parametric(seed=seed)
+        s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, parameters=prob.parameters, options=opts)
+        pkg.initialize_b(s, prob.x0)
+        return s
+
+    singles = [make(k) for k in (5, 6, 7)]
+    members = [make(k) for k in (5, 6, 7)]
+    ref = [int(pkg.solve_b(s)) for s in singles]
+    grp = pkg.Group(members)
+    assert grp.solve() == ref and all(ref)
+    for s, m in zip(singles, members):
+        assert same(s.solution.all, m.solution.all)
+        S = s.data("solution_sensitivity")
+        assert np.abs(S).max() > 0 and same(S, m.data("solution_sensitivity"))
+    grp.close()
