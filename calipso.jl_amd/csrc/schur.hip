@@ -102,30 +102,34 @@ void launch_cone_weights(calipso_hip_solver* s) {
 }
 
 // WH = Omega_z * hx  (nc x nx): nonnegative rows scaled by -1/K_zz, second-order rows multiplied by the d x d block W
+constexpr int SCALE_COLS = 16;
 __global__ void k_scale_rows(Batch bt, Dims d, ConeDev cd, const double* __restrict__ hx, const double* __restrict__ wz,
                              const double* __restrict__ Wsoc, double* __restrict__ WH) {
     inst_shift(bt, hx, wz, Wsoc, WH);
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int col = blockIdx.y;
     if (c >= d.nc) return;
-    const double* h = hx + (size_t)col * d.m;     // hx is the lower part of the stacked Jacobian (ld = m)
-    double v;
-    if (c < d.q) {
-        v = wz[c] * h[c];
-    } else {
-        const int j = cd.entry_soc[c];
-        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
-        const double* W = Wsoc + cd.soc_woff[j];
-        v = 0.0;
-        for (int b = 0; b < dim; ++b) v += W[(c - st) + b * dim] * h[st + b];
+    int st = 0, dim = 0;
+    const double* W = nullptr;
+    double w0 = 0.0;
+    if (c < d.q) w0 = wz[c];
+    else { const int j = cd.entry_soc[c]; st = cd.soc_start[j]; dim = cd.soc_dim[j]; W = Wsoc + cd.soc_woff[j]; }
+    const int col0 = blockIdx.y * SCALE_COLS, col1 = min(d.nx, col0 + SCALE_COLS);   // a block of columns per workgroup: the cone data is looked up once
+    for (int col = col0; col < col1; ++col) {
+        const double* h = hx + (size_t)col * d.m;     // hx is the lower part of the stacked Jacobian (ld = m)
+        double v;
+        if (c < d.q) v = w0 * h[c];
+        else {
+            v = 0.0;
+            for (int b = 0; b < dim; ++b) v += W[(c - st) + b * dim] * h[st + b];
+        }
+        WH[c + (size_t)col * d.nc] = v;
     }
-    WH[c + (size_t)col * d.nc] = v;
 }
 
 void launch_scale_rows(calipso_hip_solver* s) {
     if (s->d.nc == 0) return;
     const BatchSc B = batch_of(s);
-    hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, s->d.nx, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH);
+    hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, (s->d.nx + SCALE_COLS - 1) / SCALE_COLS, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH);
 }
 
 // ---- Schur complement on the fp64 matrix cores -----------------------------------------------------------------------------
