@@ -366,6 +366,16 @@ class Solver:
         self._L.calipso_hip_phase_times(self._h, _pd(out))
         return out
 
+    def analyze_structure(self):
+        """stage-banded structure from the non-zero pattern of the blocks currently on the device (include/calipso_hip.h); returns
+        dict(half_bandwidth, band_blocks (0 = dense treatment), equality_rows_per_group, cone_rows_per_group)"""
+        out = np.zeros(4, dtype=np.int64)
+        self._check(self._L.calipso_hip_analyze_structure(self._h, _pi(out)), "analyze_structure")
+        return dict(half_bandwidth=int(out[0]), band_blocks=int(out[1]), equality_rows_per_group=int(out[2]), cone_rows_per_group=int(out[3]))
+
+    def clear_structure(self):
+        self._check(self._L.calipso_hip_clear_structure(self._h), "clear_structure")
+
     def synchronize(self):
         self._check(self._L.calipso_hip_synchronize(self._h), "synchronize")
 

@@ -129,6 +129,9 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->wz, NC); SL(&s->kzz, NC);
     SL(&s->Wsoc, (size_t)woff); SL(&s->Bsoc, (size_t)woff); SL(&s->socwork, (size_t)2 * woff);
     SL(&icount_d, 32);                                        // 64 ints
+    double* krange_d = nullptr;
+    const size_t KG = (NX + 15) / 16;                         // 16-column groups (structure.hip)
+    SL(&krange_d, 2 * KG);                                    // 4 ints per group
     const size_t maxdim = std::max(std::max(NX, M), NPd);   // rows of the largest mat-vec (the stacked Jacobian has m = ne + nc rows)
     SL(&s->gemv_partial, std::max(64 * maxdim, ((NX + 15) / 16) * M + ((M + 1023) / 1024) * NX));   // gemv_n chunks / gemv_both partials
     SL(&s->vtmp, 4 * std::max(N, NPd));
@@ -146,6 +149,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
         for (auto& c : carve) { *c.first = s->slab + off; off += (c.second + 31) & ~(size_t)31; }
     }
     s->icount = reinterpret_cast<int*>(icount_d);
+    s->krange = reinterpret_cast<int*>(krange_d);
     s->gx = s->Z; s->hx = s->Z + NE; s->g = s->gh; s->hc = s->gh + NE;
     schur_plan(s);
     rc |= dalloc(s, &s->cone.soc_start, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.soc_dim, (size_t)d.n_soc);
@@ -154,6 +158,11 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     CK(hipHostMalloc((void**)&s->hscal, 64 * sizeof(double)));
     CK(hipHostMalloc((void**)&s->hicount, 64 * sizeof(int)));
     CK(hipStreamSynchronize(s->stream));   // the zero-fills above are complete before the (null-stream) index uploads below
+    {   // dense default of the structure table: every column group visits all constraint rows
+        std::vector<int> kr(4 * KG);
+        for (size_t g = 0; g < KG; ++g) { kr[4 * g] = 0; kr[4 * g + 1] = d.ne; kr[4 * g + 2] = 0; kr[4 * g + 3] = d.nc; }
+        CK(hipMemcpy(s->krange, kr.data(), sizeof(int) * kr.size(), hipMemcpyHostToDevice));
+    }
     if (d.n_soc) {
         CK(hipMemcpy(s->cone.soc_start, s->h_soc_start.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
         CK(hipMemcpy(s->cone.soc_dim, s->h_soc_dim.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));

@@ -26,6 +26,7 @@ struct calipso_hip_group {
     int *digather = nullptr, *higather = nullptr;    // MAX_BATCH x 64 ints
     std::vector<calipso_eval_fn> evals;              // host evaluation callbacks of the members without a device evaluator
     std::vector<void*> users;
+    int saved_band = 0, saved_hb = 0;                // the base handle's own structure while a group call overrides it
     std::string err;
 };
 typedef calipso_hip_group G;
@@ -92,6 +93,17 @@ static int gb_evaluate(G* g, const Set& a, int which, uint32_t flags) {
     g_activate(g, a);
     return CALIPSO_OK;
 }
+
+// the band the group's launches use: the widest of its members' (a launch covers all of them); dense if any member is dense
+static void g_effective_band(G* g) {
+    H* s = g->base;
+    int band = 0, hb = 0;
+    bool dense = false;
+    for (H* h : g->hs) { if (h->band64 == 0) dense = true; band = std::max(band, h->band64); hb = std::max(hb, h->half_bandwidth); }
+    g->saved_band = s->band64; g->saved_hb = s->half_bandwidth;
+    s->band64 = dense ? 0 : band; s->half_bandwidth = dense ? 0 : hb;
+}
+static void g_restore_band(G* g) { g->base->band64 = g->saved_band; g->base->half_bandwidth = g->saved_hb; }
 
 // factorize! + compute_inertia! for the members of `a`
 static int gb_factorize(G* g, const Set& a, std::vector<std::array<int64_t, 3>>& in) {
@@ -435,7 +447,8 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
         if (h != s) CK(hipStreamSynchronize(h->stream));   // uploads made through the member's own stream are complete
         all.push_back((int)i);
     }
-    struct Finally { H* s; ~Finally() { s->cur = nullptr; } } fin{s};
+    g_effective_band(g);
+    struct Finally { G* g; ~Finally() { g->base->cur = nullptr; g_restore_band(g); } } fin{g};
     {   // Lsym of the members whose Hessian changed
         Set dirty;
         for (int i : all) if (g->hs[i]->hessian_dirty) dirty.push_back(i);
@@ -507,7 +520,8 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
         if (h != s) CK(hipStreamSynchronize(h->stream));
         all.push_back((int)i);
     }
-    struct Finally { H* s; ~Finally() { s->cur = nullptr; } } fin{s};
+    g_effective_band(g);
+    struct Finally { G* g; ~Finally() { g->base->cur = nullptr; g_restore_band(g); } } fin{g};
     {
         Set dirty;
         for (int i : all) if (g->hs[i]->hessian_dirty) dirty.push_back(i);

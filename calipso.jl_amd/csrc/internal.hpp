@@ -145,6 +145,9 @@ struct calipso_hip_solver {
     double* Bsoc = nullptr;     // sum d^2: the reference's (non-symmetric) K_zz SOC block
     double* socwork = nullptr;  // 2 * sum d^2 scratch
     int schur_nj = 8;           // Schur tile = 128 x 16*schur_nj for single-instance launches (schur.hip: schur_plan)
+    // stage-banded structure (structure.hip); band64 = 0: dense
+    int half_bandwidth = 0, band64 = 0;
+    int* krange = nullptr;      // (in the slab) per 16-column group: [eq_lo, eq_hi, cone_lo, cone_hi) constraint rows that touch it
     int* icount = nullptr;      // device ints: [0] pos [1] nonpos [2] zero (constraint part), [3..5] same for S, [6..] cone-search masks
     int* hicount = nullptr;     // pinned host mirror
     double* gemv_partial = nullptr;   // partial sums for column-split mat-vecs

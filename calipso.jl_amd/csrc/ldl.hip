@@ -18,6 +18,8 @@
 #include "internal.hpp"
 #include "device_utils.hpp"
 
+#include <algorithm>
+
 namespace calipso {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -374,9 +376,10 @@ static void enqueue_ldl(calipso_hip_solver* s) {
     const Batch bt = batch_of(s).b;
     const unsigned nz = bt.n;
     hipLaunchKernelGGL(k_ldl_diag, dim3(1, 1, nz), dim3(DIAG_THREADS), 0, s->stream, bt, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, s->icount);
+    const int band = s->band64 > 0 ? s->band64 : nblk;     // 64-row blocks below a diagonal block that can be non-zero (structure.hip)
     for (int kb = 0; kb + 1 < nblk; ++kb) {
         const int k0 = kb * NB;
-        const int rows = NP - k0 - NB;
+        const int rows = std::min(NP - k0 - NB, band * NB);  // banded S: the panel and its trailing update stop at the band
         hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64, 1, nz), dim3(1024), 0, s->stream, bt, NP, k0, tb, s->S, s->Dx, s->Tinv, s->Ypanel);
         const int ntr = rows / TT, ntiles = ntr * (ntr + 1) / 2;
         // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
@@ -475,13 +478,13 @@ __global__ __launch_bounds__(256) void k_trsv_block_t(Batch bt, int kb, int tb, 
 }
 
 // z[columns left of block kb] -= L[block kb, columns]' v_k : one wavefront per column
-__global__ __launch_bounds__(256) void k_trsv_update_t(Batch bt, int NP, int kb, const double* __restrict__ S, const double* __restrict__ v, double* __restrict__ z) {
+__global__ __launch_bounds__(256) void k_trsv_update_t(Batch bt, int NP, int kb, int cfirst, const double* __restrict__ S, const double* __restrict__ v, double* __restrict__ z) {
     __shared__ double vs[TB];
     inst_shift(bt, S, v, z);
     const int tid = threadIdx.x, lane = tid & 63, k0 = kb * TB;
     for (int i = tid; i < TB; i += 256) vs[i] = v[k0 + i];
     __syncthreads();
-    const int c = blockIdx.x * 4 + (tid >> 6);     // c < k0
+    const int c = cfirst + blockIdx.x * 4 + (tid >> 6);     // cfirst <= c < k0 (columns further left are outside the band)
     const double* Lc = S + (size_t)c * NP + k0;
     double lv[TB / 64];
 #pragma unroll
@@ -502,12 +505,17 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
     const unsigned nz = bt.n;
     for (int kb = 0; kb < nb; ++kb) {
         hipLaunchKernelGGL(k_trsv_block_n, dim3(tb / 32, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, s->Tinv, x, s->Dx, u, z);
-        const int rest = NP - (kb + 1) * TB;
+        int rest = NP - (kb + 1) * TB;
+        if (s->band64 > 0) rest = std::min(rest, ((s->half_bandwidth + 31) / 32) * 32);      // rows below the block that its columns reach
         if (rest > 0) hipLaunchKernelGGL(k_trsv_update_n, dim3(rest / 32, 1, nz), dim3(256), 0, s->stream, bt, NP, kb, s->S, u, x);
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
         hipLaunchKernelGGL(k_trsv_block_t, dim3(tb / 4, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, s->Tinv, z, x);
-        if (kb > 0) hipLaunchKernelGGL(k_trsv_update_t, dim3(kb * TB / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, kb, s->S, x, z);
+        if (kb > 0) {
+            const int k0 = kb * TB;
+            const int cfirst = s->band64 > 0 ? std::max(0, ((k0 - s->half_bandwidth) / 4) * 4) : 0;   // columns left of the block that reach into it
+            hipLaunchKernelGGL(k_trsv_update_t, dim3((k0 - cfirst) / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, kb, cfirst, s->S, x, z);
+        }
     }
 }
 

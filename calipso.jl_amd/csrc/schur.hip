@@ -157,10 +157,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct SchurStage { const double* MA; const double* MB; int kmax; int k0; double bscale; int lda, ldb; };
 
-__device__ __forceinline__ SchurStage schur_stage(int st, int nst0, const Dims& d, const double* gx, const double* hx, const double* WH, double omega_y) {
+// stage st of a tile: the first nst0 stages walk the equality rows from stage est0 on, the rest the cone rows from stage cst0 on
+// (est0 = cst0 = 0 and all stages for a dense problem; structure.hip narrows the ranges for stage-banded ones)
+__device__ __forceinline__ SchurStage schur_stage(int st, int nst0, int est0, int cst0, const Dims& d, const double* gx, const double* hx, const double* WH,
+                                                  double omega_y) {
     SchurStage g;
-    if (st < nst0) { g.MA = gx; g.MB = gx; g.kmax = d.ne; g.k0 = st * KT; g.bscale = omega_y; g.lda = d.m; g.ldb = d.m; }
-    else { g.MA = hx; g.MB = WH; g.kmax = d.nc; g.k0 = (st - nst0) * KT; g.bscale = 1.0; g.lda = d.m; g.ldb = d.nc; }
+    if (st < nst0) { g.MA = gx; g.MB = gx; g.kmax = d.ne; g.k0 = (est0 + st) * KT; g.bscale = omega_y; g.lda = d.m; g.ldb = d.m; }
+    else { g.MA = hx; g.MB = WH; g.kmax = d.nc; g.k0 = (cst0 + st - nst0) * KT; g.bscale = 1.0; g.lda = d.m; g.ldb = d.nc; }
     return g;
 }
 
@@ -203,15 +206,36 @@ __device__ __forceinline__ void schur_tile(int t, int nx, int TJ, int& bi, int& 
     bi = 0; bj = 0;   // not reached for t < ntiles
 }
 
+// banded S (structure.hip): row-major over the tiles that intersect { j <= i < nx, i - j <= hb }
+__device__ __forceinline__ int schur_band_first(int bi, int TJ, int hb) {     // first column block of row block bi inside the band
+    const int v = bi * TILE - hb - (TJ - 1);
+    return v <= 0 ? 0 : (v + TJ - 1) / TJ;
+}
+__device__ __forceinline__ void schur_tile_banded(int t, int nx, int TJ, int hb, int& bi, int& bj) {
+    const int nbi = (nx + TILE - 1) / TILE;
+    for (bi = 0; bi < nbi; ++bi) {
+        const int first = schur_band_first(bi, TJ, hb), c = schur_row_count(bi, nx, TJ) - first;
+        if (t < c) { bj = first + t; return; }
+        t -= c;
+    }
+    bi = 0; bj = 0;
+}
+// constraint rows a range of columns [c0, c1) visits: union of the per-group ranges of structure.hip (kr: 4 ints per 16 columns)
+__device__ __forceinline__ void schur_rows(const int* __restrict__ kr, int c0, int c1, int which, int& lo, int& hi) {
+    lo = 1 << 30; hi = 0;
+    for (int g = c0 / 16; g <= (c1 - 1) / 16; ++g) { lo = min(lo, kr[4 * g + 2 * which]); hi = max(hi, kr[4 * g + 2 * which + 1]); }
+}
+
 // LDS: two stages of (A tile, B tile), 4 x 128 x LDK doubles = 136 KiB (dynamic).  Stage s+1 is written to the other buffer
 // while the matrix cores work on stage s (its operands were fetched to registers one stage earlier), so a stage costs ONE barrier
 // and neither the global-load nor the LDS-store latency is exposed.
 constexpr size_t SCHUR_LDS_BYTES = 4 * (size_t)TILE * LDK * sizeof(double);
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, const double* __restrict__ Lsym, const double* __restrict__ gx,
                                                           const double* __restrict__ hx, const double* __restrict__ WH, double* __restrict__ S,
-                                                          int ntiles, int nj) {
+                                                          const int* __restrict__ kr, int hb, int ntiles, int nj) {
     extern __shared__ __attribute__((aligned(16))) double schur_lds[];
     inst_shift(bt.b, Lsym, gx, hx, WH, S);
+    inst_shift_i(bt.b, kr);
     const Scalars sc = bt.sc[blockIdx.z];
     // XCD-aware remap: block b runs on XCD b % 8 (observed dispatch order; used for speed only): each XCD gets a contiguous
     // band of the (row-major) tile list, so the operand columns a band needs are shared through that XCD's L2
@@ -220,7 +244,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
     if (t >= ntiles) return;
     const int TJ = 16 * nj;
     int bi, bj;
-    schur_tile(t, d.nx, TJ, bi, bj);
+    if (hb > 0) schur_tile_banded(t, d.nx, TJ, hb, bi, bj);
+    else schur_tile(t, d.nx, TJ, bi, bj);
     const int i0 = bi * TILE, j0 = bj * TJ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 7;                          // row tile (16 rows) of this wavefront
@@ -236,10 +261,21 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
     for (int n = 0; n < 4; ++n) acc[n] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
-    const int nst0 = (d.ne + KT - 1) / KT, nst = nst0 + (d.nc + KT - 1) / KT;
+    // constraint rows that touch both the tile's rows (as columns of the Jacobians) and its columns
+    int est0, nst0, cst0, nst;
+    {
+        int la, ha, lb, hbb;
+        const int i1 = min(d.nx, i0 + TILE), j1 = min(d.nx, j0 + TJ);
+        schur_rows(kr, i0, i1, 0, la, ha); schur_rows(kr, j0, j1, 0, lb, hbb);
+        int lo = max(la, lb), hi = min(ha, hbb);
+        est0 = lo / KT; nst0 = hi > lo ? (hi + KT - 1) / KT - est0 : 0;
+        schur_rows(kr, i0, i1, 1, la, ha); schur_rows(kr, j0, j1, 1, lb, hbb);
+        lo = max(la, lb); hi = min(ha, hbb);
+        cst0 = lo / KT; nst = nst0 + (hi > lo ? (hi + KT - 1) / KT - cst0 : 0);
+    }
     double ra[SLD], rb[SLD];
     auto fetch = [&](int st) {
-        const SchurStage g = schur_stage(st, nst0, d, gx, hx, WH, omega_y);
+        const SchurStage g = schur_stage(st, nst0, est0, cst0, d, gx, hx, WH, omega_y);
         stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, TILE, tid, 1.0);
         stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, TJ, tid, g.bscale);
     };
@@ -340,34 +376,39 @@ void launch_symmetrize(calipso_hip_solver* s) {
 // host: tile shape for a launch that covers `instances` problem instances.  Tile = 128 x 16 nj; the cost of a launch is the
 // number of rounds over the 256 CUs times the per-SIMD MFMA count of a tile (C3: one instance -> 128 x 112, 249 tiles, one round;
 // groups -> 128 x 128, fewer wasted columns and the per-stage overhead amortised over more matrix work)
-static int schur_tiles(int nx, int nj) {
+static int schur_tiles(int nx, int nj, int hb) {
     const int TJ = 16 * nj, nbi = (nx + TILE - 1) / TILE;
     int cnt = 0;
-    for (int bi = 0; bi < nbi; ++bi) cnt += (std::min(nx, (bi + 1) * TILE) - 1) / TJ + 1;
+    for (int bi = 0; bi < nbi; ++bi) {
+        const int v = bi * TILE - hb - (TJ - 1);
+        const int first = (hb <= 0 || v <= 0) ? 0 : (v + TJ - 1) / TJ;
+        cnt += (std::min(nx, (bi + 1) * TILE) - 1) / TJ + 1 - first;
+    }
     return cnt;
 }
-static int schur_choose(int nx, int instances) {
+static int schur_choose(int nx, int instances, int hb) {
     long best_cost = -1; int best = 8;
     for (int nj = 4; nj <= 8; ++nj) {
-        const long cnt = (long)schur_tiles(nx, nj) * instances;
+        const long cnt = (long)schur_tiles(nx, nj, hb) * instances;
         const long cost = ((cnt + 255) / 256) * nj;
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = nj; }   // ties: the larger tile
     }
     return best;
 }
-void schur_plan(calipso_hip_solver* s) { s->schur_nj = schur_choose(s->d.nx, 1); }
+void schur_plan(calipso_hip_solver* s) { s->schur_nj = schur_choose(s->d.nx, 1, 0); }
 
 void launch_schur(calipso_hip_solver* s) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_LDS_BYTES); attr = true; }
     if (s->hessian_dirty && !s->cur) { launch_symmetrize(s); s->hessian_dirty = false; }   // (a group refreshes its members itself)
     const BatchSc B = batch_of(s);
-    const int nj = B.b.n == 1 ? s->schur_nj : schur_choose(s->d.nx, B.b.n);
-    const int ntiles = schur_tiles(s->d.nx, nj);
+    const int hb = s->band64 > 0 ? s->half_bandwidth : 0;       // > 0: only the tiles inside the band (structure.hip)
+    const int nj = (B.b.n == 1 && hb == 0) ? s->schur_nj : schur_choose(s->d.nx, B.b.n, hb);
+    const int ntiles = schur_tiles(s->d.nx, nj, hb);
     const int grid = ((ntiles + 7) / 8) * 8;
     if (s->d.NP > s->d.nx)
         hipLaunchKernelGGL(k_pad_identity, dim3((s->d.NP + 255) / 256, s->d.NP - s->d.nx, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->S);
-    hipLaunchKernelGGL(k_schur, dim3(grid, 1, B.b.n), dim3(SCHUR_THREADS), SCHUR_LDS_BYTES, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, ntiles, nj);
+    hipLaunchKernelGGL(k_schur, dim3(grid, 1, B.b.n), dim3(SCHUR_THREADS), SCHUR_LDS_BYTES, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, s->krange, hb, ntiles, nj);
 }
 
 }  // namespace calipso

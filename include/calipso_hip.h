@@ -218,6 +218,17 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group*, int32_t advance, doubl
 int32_t calipso_hip_group_set_evaluators(calipso_hip_group*, const calipso_eval_fn* evals, void* const* users);
 int32_t calipso_hip_group_solve(calipso_hip_group*, int32_t* result);
 
+/* ---- stage-banded structure -------------------------------------------------------------------------------
+ * Trajectory-optimisation problems order their variables stage by stage (src/trajectory_optimization/indices.jl:41-180), which
+ * makes the Schur complement onto x banded.  calipso_hip_analyze_structure reads the non-zero pattern of the blocks the handle
+ * currently holds (lagrangian_hessian, equality / cone Jacobians) and from then on the factorisation and the triangular solves
+ * skip everything outside the band (the reference obtains the same saving from its sparse LDL^T, qdldl.jl:400-589).  Results are
+ * bit-identical to the dense treatment.  Re-run it (or calipso_hip_clear_structure) if the pattern of the blocks changes.
+ * out[0] = half bandwidth of S, out[1] = 64-row blocks per panel inside the band (0: dense treatment kept),
+ * out[2], out[3] = average number of equality / cone rows a 16-column group visits.  out may be NULL. */
+int32_t calipso_hip_analyze_structure(calipso_hip_solver*, int64_t out[4]);
+int32_t calipso_hip_clear_structure(calipso_hip_solver*);
+
 /* timing of the last calipso_hip_newton_step / factorisation, in milliseconds, from HIP events on the handle's stream:
  * [0] evaluate + cone + residual + reductions   [1] cone pivots + Omega*hx   [2] search_direction! total (factor + solves + refinement)
  * [3] LDL^T of the Schur complement   [5] cone search + line search + accept   [6] whole step

@@ -454,6 +454,60 @@ def synthetic_conic_qp(uniform, problem_id, nx, ne, n_nn, n_soc, soc_dim):
     return prob, pt, lam
 
 
+def staged_conic_qp(uniform, problem_id, T, nv, nd, n_nn_stage, n_soc_stage, soc_dim):
+    """The synthetic conic QP of SURVEY.md 8(d) with the stage structure of a trajectory-optimisation problem (the reference's
+    src/trajectory_optimization layer: variables ordered stage by stage, indices.jl:41-180): T stages of nv variables; the
+    Hessian block (stage, stage) only; nd "dynamics" equality rows per stage pair (t, t+1); per stage n_nn_stage nonnegative rows
+    and n_soc_stage second-order cones of dimension soc_dim on that stage's variables.  Same SplitMix64 streams as
+    synthetic_conic_qp, entries outside the structure set to zero.  Returns (ConicQP, point dict, lam)."""
+    nx, ne = T * nv, (T - 1) * nd
+    n_nn, n_soc = T * n_nn_stage, T * n_soc_stage
+    nc, nonneg, soc = synthetic_layout(nx, ne, n_nn, n_soc, soc_dim)
+    U = lambda name, lo, hi, cnt: uniform(problem_id, STREAMS[name], lo, hi, cnt)
+    stage_of_var = np.arange(nx) // nv
+    B = U("B", -1, 1, nx * nx).reshape(nx, nx).T
+    P = (B + B.T) / (2.0 * np.sqrt(nv))
+    P = P * (stage_of_var[:, None] == stage_of_var[None, :]) + 2.0 * np.eye(nx)
+    q = U("q", -1, 1, nx)
+    A = (U("A", -1, 1, ne * nx) / np.sqrt(2 * nv)).reshape(nx, ne).T
+    if ne:
+        st_row = np.arange(ne) // nd
+        A = A * ((stage_of_var[None, :] == st_row[:, None]) | (stage_of_var[None, :] == st_row[:, None] + 1))
+    G = (U("G", -1, 1, nc * nx) / np.sqrt(nv)).reshape(nx, nc).T
+    st_cone = np.zeros(nc, dtype=int)
+    st_cone[:n_nn] = np.arange(n_nn) // max(1, n_nn_stage)
+    for j, c in enumerate(soc):
+        if c:
+            st_cone[np.array(c) - 1] = j // max(1, n_soc_stage)
+    if nc:
+        G = G * (stage_of_var[None, :] == st_cone[:, None])
+    xbar = U("xbar", -1, 1, nx)
+    b = A @ xbar
+    cp = np.zeros(nc)
+    cp[:n_nn] = U("hpos", 0.5, 1.5, n_nn)
+    tails = U("cone_point_tail", -0.3, 0.3, nc)
+    for c in soc:
+        if c:
+            idx = np.array(c) - 1
+            cp[idx[1:]] = tails[idx[1:]]
+            cp[idx[0]] = 1.0 + np.linalg.norm(cp[idx[1:]])
+    h = G @ xbar + cp
+    prob = ConicQP(P, q, A, b, G, h, nonnegative_indices=nonneg, second_order_indices=soc, name="staged")
+    pt = dict(x=U("x", -1, 1, nx), r=0.1 * U("r", -1, 1, ne), y=U("y", -1, 1, ne), z=U("z", -1, 1, nc))
+    sl = np.zeros(nc); t = np.zeros(nc)
+    sl[:n_nn] = U("s_nn", 0.5, 1.5, n_nn); t[:n_nn] = U("t_nn", 0.5, 1.5, n_nn)
+    stl = U("s_tail", -0.3, 0.3, nc); tt = U("t_tail", -0.3, 0.3, nc)
+    for c in soc:
+        if c:
+            idx = np.array(c) - 1
+            sl[idx[1:]] = stl[idx[1:]]; t[idx[1:]] = tt[idx[1:]]
+            sl[idx[0]] = 1.0 + np.linalg.norm(sl[idx[1:]]); t[idx[0]] = 1.0 + np.linalg.norm(t[idx[1:]])
+    pt["s"], pt["t"] = sl, t
+    lam = U("lam", -1, 1, ne)
+    prob.half_bandwidth = 2 * nv - 1                     # |i - j| of two variables of adjacent stages
+    return prob, pt, lam
+
+
 def cartpole_mpc(horizon=10, h=0.05, perturb=0.05):
     """BASELINE config C5 shape: cart-pole MPC of examples/autotuning/cartpole.jl:85-146 (model examples/autotuning/models/cartpole.jl:2-33):
     H = 10 stages, 4 states, 1 action => nx = 49, ne = 40 (36 explicit-midpoint dynamics + x_1 - x_init), nc = 0, p = 102 parameters

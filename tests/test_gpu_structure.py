@@ -1,0 +1,83 @@
+"""GPU: stage-banded structure (csrc/structure.hip).  Trajectory-optimisation problems order their variables stage
+by stage, the Schur complement onto x is then banded and the device path skips everything outside the band.  The banded
+treatment must give the bits of the dense treatment, and the dense treatment is what the rest of the suite checks against the oracle."""
+import numpy as np
+import pytest
+
+import problems as pr
+from helpers import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def build(pkg, pid, T, nv, nd, nn, nsoc, dim):
+    prob, pt, lam = pr.staged_conic_qp(pkg.splitmix_uniform, pid, T, nv, nd, nn, nsoc, dim)
+    s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices)
+    s.set("solution", np.concatenate([pt[k] for k in "xrsyzt"]))
+    s.set("dual", lam)
+    for name, v in (("central_path", 0.17), ("penalty", 52.0), ("fraction_to_boundary", 0.99)):
+        s.set(name, [v])
+    s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
+    fl = pkg.FLAGS
+    s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
+    s.cone(product=True, target=True)
+    s.synchronize()
+    return prob, s
+
+
+STAGED = [
+    # T, nv, nd, nonnegative rows / stage, second-order cones / stage, cone dimension
+    (24, 30, 20, 4, 2, 3),        # nx = 720 (NP = 1024): band of 1 block
+    (41, 56, 40, 6, 3, 2),        # nx = 2296: the quadruped-gait size of BASELINE config C4, band of 2 blocks
+    (10, 100, 60, 10, 4, 4),      # wide stages: band of 4 blocks
+    (6, 40, 0, 5, 2, 3),          # no dynamics: block-diagonal S
+]
+
+
+@pytest.mark.parametrize("shape", STAGED)
+def test_banded_treatment_is_bitwise_the_dense_one(shape):
+    pkg = load_pkg()
+    prob, dense = build(pkg, 5, *shape)
+    _, banded = build(pkg, 5, *shape)
+    info = banded.analyze_structure()
+    assert info["half_bandwidth"] == (prob.half_bandwidth if shape[2] else shape[1] - 1)
+    NP = ((prob.nx + 511) // 512) * 512
+    assert 0 < info["band_blocks"] < NP // 64 - 1
+    for it in range(3):
+        a = dense.newton_step(advance=True)
+        b = banded.newton_step(advance=True)
+        assert a == b and a["status"] == 0, (it, a, b)
+        assert np.array_equal(dense.data("step").all, banded.data("step").all)
+        assert np.array_equal(dense.solution.all, banded.solution.all)
+    assert dense.factorize() == banded.factorize()
+    # back to the dense treatment
+    banded.clear_structure()
+    assert dense.newton_step(advance=True) == banded.newton_step(advance=True)
+    assert np.array_equal(dense.solution.all, banded.solution.all)
+
+
+def test_dense_problem_has_nothing_to_skip():
+    pkg = load_pkg()
+    import test_gpu_group as tg
+    a, b = tg.build(pkg, 3, shape=(700, 120, 40, 20, 3)), tg.build(pkg, 3, shape=(700, 120, 40, 20, 3))
+    info = b.analyze_structure()
+    assert info["half_bandwidth"] == 699 and (info["band_blocks"] == 0 or info["band_blocks"] * 64 >= 699)
+    assert info["equality_rows_per_group"] == 120 and info["cone_rows_per_group"] == 100
+    assert a.newton_step(advance=True) == b.newton_step(advance=True)
+    assert np.array_equal(a.solution.all, b.solution.all)
+
+
+def test_group_of_banded_members():
+    pkg = load_pkg()
+    shape = STAGED[0]
+    singles = [build(pkg, p, *shape)[1] for p in (7, 8, 9)]
+    members = [build(pkg, p, *shape)[1] for p in (7, 8, 9)]
+    for m in members:
+        m.analyze_structure()
+    g = pkg.Group(members)
+    for it in range(2):
+        ref = [s.newton_step(advance=True) for s in singles]
+        got = g.newton_step(advance=True)
+        for r, q, s, m in zip(ref, got, singles, members):
+            assert r == q and np.array_equal(s.solution.all, m.solution.all)
+    g.close()
