@@ -33,12 +33,22 @@ CONFIGS = {
     "C4": (2302, 2208, 244, 240, 2),
     "small": (600, 300, 100, 50, 3),
 }
+# stage-structured variants (tests/problems.py: staged_conic_qp): name -> (T, nv, nd, nonnegative rows / stage, SOCs / stage, SOC dim).
+# C4T has the size of C4 (nx = 2296, ne = 2160, nc = 738) with the block structure of a 41-stage trajectory problem; the handle
+# analyses the pattern (calipso_hip_analyze_structure) unless --dense-structure is given.
+STAGED = {
+    "C4T": (41, 56, 54, 6, 6, 2),
+    "smallT": (12, 40, 30, 4, 2, 3),
+}
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; bench/mfma_f64_peak.hip measures the achievable ceiling)
 
 
-def make_instance(pkg, pr, pid, shape, device):
+def make_instance(pkg, pr, pid, shape, device, staged=None, analyze=True):
     nx, ne, n_nn, n_soc, dim = shape
-    prob, pt, lam = pr.synthetic_conic_qp(pkg.splitmix_uniform, pid, nx, ne, n_nn, n_soc, dim)
+    if staged is not None:
+        prob, pt, lam = pr.staged_conic_qp(pkg.splitmix_uniform, pid, *staged)
+    else:
+        prob, pt, lam = pr.synthetic_conic_qp(pkg.splitmix_uniform, pid, nx, ne, n_nn, n_soc, dim)
     s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices,
                    second_order_indices=prob.second_order_indices, device=device)
     w = np.concatenate([pt[k] for k in "xrsyzt"])
@@ -47,6 +57,8 @@ def make_instance(pkg, pr, pid, shape, device):
     for name, v in (("central_path", 0.17), ("penalty", 52.0), ("fraction_to_boundary", 0.99)):
         s.set(name, [v])
     s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
+    if staged is not None and analyze:
+        s.analyze_structure()
     fl = pkg.FLAGS
     s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
     s.cone(product=True, target=True)
@@ -54,7 +66,12 @@ def make_instance(pkg, pr, pid, shape, device):
     return prob, pt, lam, w, s
 
 
-def cpu_baseline(shape, name="C3"):
+def staged_shape(st):
+    T, nv, nd, nn, nsoc, dim = st
+    return (T * nv, (T - 1) * nd, T * nn, T * nsoc, dim)
+
+
+def cpu_baseline(shape, name="C3", staged=None):
     """The oracle (faithful single-thread restatement of the reference's CPU path) on ONE Newton step of the same C3
     problem (problem id 0): search_direction! = assemble + sparse up-looking LDL^T (QDLDL order of operations, constraint-first
     permutation) + solve + refinement, with ONE factorisation per step (the reference re-factorises before every solve —
@@ -63,7 +80,10 @@ def cpu_baseline(shape, name="C3"):
     import oracle
     import problems as pr
     nx, ne, n_nn, n_soc, dim = shape
-    prob, pt, lam = pr.synthetic_conic_qp(oracle.splitmix_uniform, 0, nx, ne, n_nn, n_soc, dim)
+    if staged is not None:
+        prob, pt, lam = pr.staged_conic_qp(oracle.splitmix_uniform, 0, *staged)
+    else:
+        prob, pt, lam = pr.synthetic_conic_qp(oracle.splitmix_uniform, 0, nx, ne, n_nn, n_soc, dim)
     o = oracle.OracleSolver(prob.nx, 0, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
     o.point()["all"][:] = np.concatenate([pt[k] for k in "xrsyzt"])
     o.buf("dual")[:] = lam
@@ -77,8 +97,10 @@ def cpu_baseline(shape, name="C3"):
     rc = o.search_direction()
     dt = time.perf_counter() - t0
     st = o.stats()
+    note = "" if staged is None else (" (the port assembles and factors the blocks densely: it does not exploit the stage structure, which the "
+                                      "reference's sparse LDL^T would)")
     return dict(value=1.0 / dt, unit="Newton steps/s", cores=1, kind="port",
-                sample="1 Newton step (evaluate + cone + residual + search_direction: 1 LDL^T factorisation, %d solves) of %s problem 0, %.1f s; "
+                sample=note.strip() + (" " if note else "") + "1 Newton step (evaluate + cone + residual + search_direction: 1 LDL^T factorisation, %d solves) of %s problem 0, %.1f s; "
                        "with the reference's re-factorisation before every solve it would be %dx the factorisation time" % (
                            1 + st["last_refinement_rounds"], name, dt, 1 + st["last_refinement_rounds"]),
                 status=int(rc))
@@ -94,7 +116,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="host threads / HIP streams driving the units (groups or single instances) concurrently")
     ap.add_argument("--group", type=int, default=12, help="instances per group: the members of a group are stepped in lockstep through the same\n"
                     "kernel launches (calipso_hip_group_*); --batch must be a multiple of it")
-    ap.add_argument("--config", default="C3", choices=list(CONFIGS))
+    ap.add_argument("--config", default="C3", choices=list(CONFIGS) + list(STAGED))
+    ap.add_argument("--dense-structure", action="store_true", help="stage-structured configs: keep the dense treatment (no calipso_hip_analyze_structure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the informational single-instance loop (profiling runs: every launch\n"
                     "in the trace then carries a whole group)")
@@ -120,7 +143,8 @@ def main():
     from __graft_entry__ import load_package
     pkg = load_package()
     import problems as pr
-    shape = CONFIGS[args.config]
+    staged = STAGED.get(args.config)
+    shape = staged_shape(staged) if staged else CONFIGS[args.config]
     B = args.batch
     from calipso_jl_amd.batch import BatchSolver, gather_results, shard_range
     G = max(1, args.group)
@@ -129,7 +153,7 @@ def main():
     # creation order: the first member of every unit first, so that the streams that carry the launches get distinct priority
     # classes (handles take class = creation index mod 3, calipso_hip_create)
     order = [k for k in range(B) if k % G == 0] + [k for k in range(B) if k % G != 0]
-    made = {k: make_instance(pkg, pr, ids[k], shape, local_rank) for k in order}
+    made = {k: make_instance(pkg, pr, ids[k], shape, local_rank, staged, not args.dense_structure) for k in order}
     solvers = [made[k][4] for k in range(B)]
     units = [pkg.Group(solvers[k:k + G]) for k in range(0, B, G)] if G > 1 else solvers
     batch = BatchSolver(units, lanes=args.lanes)
@@ -199,7 +223,10 @@ def main():
     # the device to itself; with several units in flight concurrent launches share the CUs and a per-launch time is ill-defined)
     sch_ms = float(np.mean(sch_alone))
     sch_ms_concurrent = float(np.mean(sch))
-    flops1 = float(nx) * (nx + 1) * m
+    # (per constraint row with w non-zero columns: w (w + 1) multiply-add flops of the lower triangle; dense rows: nx (nx + 1) each)
+    prob0 = made[0][0]
+    wrow = np.concatenate([np.count_nonzero(prob0.A, axis=1), np.count_nonzero(prob0.G, axis=1)]).astype(np.float64)
+    flops1 = float(np.sum(wrow * (wrow + 1.0)))
     flops = G * flops1
     achieved = flops / (sch_ms * 1e-3) * 1e-12
     # per-phase rooflines from SURVEY.md 8(d)'s algorithmic figures, one instance in flight (HIP-event phase times of the handle)
@@ -227,12 +254,13 @@ def main():
             traffic = e["hbm_bytes_per_launch"] * G / float(e.get("instances_per_launch", 1))
     except Exception:
         traffic = None
+    kind = ("stage-structured (%d stages, %s treatment) " % (staged[0], "dense" if args.dense_structure else "banded")) if staged else "dense "
     out = {
         "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s synthetic dense conic QP: nx=%d ne=%d nc=%d (%d R+ + %d x SOC%d), n=%d condensed, N=%d unreduced; "
-                               "%d independent instance(s) per GPU; 1 LDL^T factorisation, %d refinement round(s) per step" % (
+        "config": {"workload": ("%s synthetic " + kind + "conic QP: nx=%d ne=%d nc=%d (%d R+ + %d x SOC%d), n=%d condensed, N=%d unreduced; "
+                                "%d independent instance(s) per GPU; 1 LDL^T factorisation, %d refinement round(s) per step") % (
                                    args.config, nx, ne, nc, n_nn, n_soc, dim, nx + m, nx + 2 * ne + 3 * nc, B, info["refinement_rounds"]),
                    "instances_per_gpu": B, "instances_per_group": G, "instances_in_flight": batch.lanes * G, "parallelism": "independent problems per GPU (no data-path collective)",
                    "refinement_rounds": info["refinement_rounds"], "factorizations_per_step": info["factorizations"],
@@ -246,7 +274,7 @@ def main():
                      "avg_launch_ms_with_%d_units_in_flight" % batch.lanes: sch_ms_concurrent},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(shape, args.config)
+        out["cpu_baseline"] = cpu_baseline(shape, args.config, staged)
     else:
         out["cpu_baseline"] = None
     if rank == 0:
