@@ -132,6 +132,8 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     double* krange_d = nullptr;
     const size_t KG = (NX + 15) / 16;                         // 16-column groups (structure.hip)
     SL(&krange_d, 2 * KG);                                    // 4 ints per group
+    double* zrow_d = nullptr;
+    SL(&zrow_d, M);                                           // 2 ints per row of [gx; hx]
     const size_t maxdim = std::max(std::max(NX, M), NPd);   // rows of the largest mat-vec (the stacked Jacobian has m = ne + nc rows)
     SL(&s->gemv_partial, std::max(64 * maxdim, ((NX + 15) / 16) * M + ((M + 1023) / 1024) * NX));   // gemv_n chunks / gemv_both partials
     SL(&s->vtmp, 4 * std::max(N, NPd));
@@ -150,6 +152,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     }
     s->icount = reinterpret_cast<int*>(icount_d);
     s->krange = reinterpret_cast<int*>(krange_d);
+    s->zrow = reinterpret_cast<int*>(zrow_d);
     s->gx = s->Z; s->hx = s->Z + NE; s->g = s->gh; s->hc = s->gh + NE;
     schur_plan(s);
     rc |= dalloc(s, &s->cone.soc_start, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.soc_dim, (size_t)d.n_soc);

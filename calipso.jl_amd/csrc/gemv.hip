@@ -10,19 +10,38 @@
 
 namespace calipso {
 
-__global__ __launch_bounds__(256) void k_gemv_t(Batch bt, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x,
+// 64-row blocks of a column that can hold non-zeros: [b0, b1) and [b2, b3) (empty ranges: b0 >= b1)
+struct BlockRanges { int b0, b1, b2, b3; };
+__device__ __forceinline__ BlockRanges column_blocks(const Sparsity& sp, int col, int rows) {
+    BlockRanges r = {0, (rows + 63) / 64, 0, 0};
+    if (sp.kind == SP_DENSE) return r;
+    if (sp.kind == SP_LXX) { r.b0 = max(0, col - sp.hb) / 64; r.b1 = (min(rows, col + sp.hb + 1) + 63) / 64; return r; }
+    const int* k = sp.kr + 4 * (col / 16);
+    const int elo = k[0], ehi = k[1], clo = k[2], chi = k[3];
+    if (sp.kind == SP_GX) { r.b0 = elo / 64; r.b1 = ehi > elo ? (ehi + 63) / 64 : r.b0; return r; }
+    if (sp.kind == SP_HX) { r.b0 = clo / 64; r.b1 = chi > clo ? (chi + 63) / 64 : r.b0; return r; }
+    r.b0 = elo / 64; r.b1 = ehi > elo ? (ehi + 63) / 64 : r.b0;                       // SP_Z: equality rows, then the cone rows at offset ne
+    r.b2 = (sp.ne + clo) / 64; r.b3 = chi > clo ? (sp.ne + chi + 63) / 64 : r.b2;
+    return r;
+}
+__device__ __forceinline__ bool block_active(const BlockRanges& r, int b) { return (b >= r.b0 && b < r.b1) || (b >= r.b2 && b < r.b3); }
+
+__global__ __launch_bounds__(256) void k_gemv_t(Batch bt, Sparsity sp, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x,
                                                  double* __restrict__ y, double alpha, double beta) {
     inst_shift(bt, A, x, y);
+    if (sp.kr) inst_shift_i(bt, sp.kr);
     const int lane = threadIdx.x & 63;
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= cols) return;
     const double* a = A + (size_t)col * ld;
+    const BlockRanges br = column_blocks(sp, col, rows);
     double acc0 = 0.0, acc1 = 0.0;
     // batches of 24 loads per lane, all issued before the first use (latency-bound otherwise)
     for (int base = 0; base < rows; base += 64 * 24) {
+        if (sp.kind != SP_DENSE && !(base / 64 < max(br.b1, br.b3) && base / 64 + 24 > min(br.b0, br.b2 < br.b3 ? br.b2 : br.b0))) continue;   // nothing of this batch is inside the structure
         double v[24];
 #pragma unroll
-        for (int q = 0; q < 24; ++q) { const int i = base + lane + 64 * q; v[q] = i < rows ? a[i] : 0.0; }
+        for (int q = 0; q < 24; ++q) { const int i = base + lane + 64 * q; v[q] = (i < rows && block_active(br, base / 64 + q)) ? a[i] : 0.0; }
 #pragma unroll
         for (int q = 0; q < 24; q += 2) {
             const int i = base + lane + 64 * q;
@@ -34,28 +53,41 @@ __global__ __launch_bounds__(256) void k_gemv_t(Batch bt, int rows, int cols, co
     if (lane == 0) y[col] = (beta == 0.0) ? alpha * r : alpha * r + beta * y[col];
 }
 
-void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta) {
+// the structure tables of `s` for a block of the given kind (dense unless calipso_hip_analyze_structure found a band)
+static Sparsity sparsity_of(const calipso_hip_solver* s, int kind) {
+    Sparsity sp;
+    if (kind == SP_DENSE || s->band64 == 0) return sp;
+    sp.kind = kind; sp.hb = s->half_bandwidth; sp.ne = s->d.ne; sp.kr = s->krange; sp.rowrange = s->zrow;
+    return sp;
+}
+
+void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind) {
     if (cols == 0) return;
     const BatchSc B = batch_of(s);
-    hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, rows, cols, A, ld, x, y, alpha, beta);
+    hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, A, ld, x, y, alpha, beta);
 }
 
 constexpr int GN_ROWS = 256;    // rows per workgroup
 constexpr int GN_MAXCHUNK = 64; // column chunks
 
-__global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, int rows, int cols, int chunk, const double* __restrict__ A, int ld,
+__global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, Sparsity sp, int row_off, int rows, int cols, int chunk, const double* __restrict__ A, int ld,
                                                              const double* __restrict__ x, double* __restrict__ partial) {
     inst_shift(bt, A, x, partial);
+    if (sp.rowrange) inst_shift_i(bt, sp.rowrange);
     const int i = blockIdx.x * GN_ROWS + threadIdx.x;
     const int c0 = blockIdx.y * chunk;
     const int c1 = min(cols, c0 + chunk);
     if (i >= rows) return;
+    // columns of row i that can be non-zero (loads outside are predicated off; the summation order is that of the dense kernel)
+    int jlo = 0, jhi = cols;
+    if (sp.kind == SP_LXX) { jlo = i - sp.hb; jhi = i + sp.hb + 1; }
+    else if (sp.kind != SP_DENSE) { jlo = sp.rowrange[2 * (row_off + i)]; jhi = sp.rowrange[2 * (row_off + i) + 1]; }
     double acc0 = 0.0, acc1 = 0.0;
     // batches of 24 loads per lane, all issued before the first use
     for (int j0 = c0; j0 < c1; j0 += 24) {
         double v[24];
 #pragma unroll
-        for (int q = 0; q < 24; ++q) v[q] = (j0 + q < c1) ? A[i + (size_t)(j0 + q) * ld] : 0.0;
+        for (int q = 0; q < 24; ++q) { const int j = j0 + q; v[q] = (j < c1 && j >= jlo && j < jhi) ? A[i + (size_t)j * ld] : 0.0; }
 #pragma unroll
         for (int q = 0; q < 24; q += 2) {
             acc0 += v[q] * (j0 + q < c1 ? x[j0 + q] : 0.0);
@@ -93,9 +125,10 @@ __global__ __launch_bounds__(256) void k_gemv_n_reduce(Batch bt, int rows, int n
 // written once per wavefront as a partial row vector; partials are combined in a fixed order by k_gemv_n_reduce.
 constexpr int BOTH_RQ = 16;   // rows per lane  -> 1024 rows per row range
 constexpr int BOTH_CW = 16;   // columns per wavefront
-__global__ __launch_bounds__(256) void k_gemv_both(Batch bt, int rows, int cols, int cw, const double* __restrict__ A, int ld, const double* __restrict__ x,
+__global__ __launch_bounds__(256) void k_gemv_both(Batch bt, Sparsity sp, int rows, int cols, int cw, const double* __restrict__ A, int ld, const double* __restrict__ x,
                                                     const double* __restrict__ u, double* __restrict__ part_n, double* __restrict__ part_t) {
     inst_shift(bt, A, x, u, part_n, part_t);
+    if (sp.kr) inst_shift_i(bt, sp.kr);
     const int lane = threadIdx.x & 63;
     const int cg = blockIdx.x * 4 + (threadIdx.x >> 6);        // column group of this wavefront
     const int c0 = cg * cw;
@@ -105,11 +138,15 @@ __global__ __launch_bounds__(256) void k_gemv_both(Batch bt, int rows, int cols,
 #pragma unroll
     for (int q = 0; q < BOTH_RQ; ++q) { const int i = r0 + lane + 64 * q; uu[q] = i < rows ? u[i] : 0.0; acc[q] = 0.0; }
     const int c1 = min(cols, c0 + cw);
+    const BlockRanges br = column_blocks(sp, c0, rows);        // (a column group of the structure tables is 16 = BOTH_CW columns)
+    unsigned active = 0;
+#pragma unroll
+    for (int q = 0; q < BOTH_RQ; ++q) if (block_active(br, r0 / 64 + q)) active |= 1u << q;
     for (int j = c0; j < c1; ++j) {
         const double* a = A + (size_t)j * ld;
         double z[BOTH_RQ];
 #pragma unroll
-        for (int q = 0; q < BOTH_RQ; ++q) { const int i = r0 + lane + 64 * q; z[q] = i < rows ? a[i] : 0.0; }   // one batch of loads
+        for (int q = 0; q < BOTH_RQ; ++q) { const int i = r0 + lane + 64 * q; z[q] = (i < rows && ((active >> q) & 1u)) ? a[i] : 0.0; }   // one batch of loads
         const double xj = x[j];
         double t0 = 0.0, t1 = 0.0;
 #pragma unroll
@@ -125,19 +162,19 @@ __global__ __launch_bounds__(256) void k_gemv_both(Batch bt, int rows, int cols,
 }
 
 // yt = A'u + beta_t*yt and yn = A x in one pass over A
-void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t) {
+void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t, int kind) {
     if (rows == 0 || cols == 0) return;
     const BatchSc B = batch_of(s);
     const int cw = BOTH_CW;   // (8 is 1 % faster for a single cache-resident instance, 16 for groups streaming from HBM)
     const int ncg = (cols + cw - 1) / cw, nrr = (rows + 64 * BOTH_RQ - 1) / (64 * BOTH_RQ);
     double* part_n = s->gemv_partial;                       // ncg x rows
     double* part_t = s->gemv_partial + (size_t)ncg * rows;  // nrr x cols
-    hipLaunchKernelGGL(k_gemv_both, dim3((ncg + 3) / 4, nrr, B.b.n), dim3(256), 0, s->stream, B.b, rows, cols, cw, A, ld, x, u, part_n, part_t);
+    hipLaunchKernelGGL(k_gemv_both, dim3((ncg + 3) / 4, nrr, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, cw, A, ld, x, u, part_n, part_t);
     hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, rows, ncg, part_n, yn, 1.0, 0.0);
     hipLaunchKernelGGL(k_gemv_n_reduce, dim3((cols + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, cols, nrr, part_t, yt, 1.0, beta_t);
 }
 
-void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta) {
+void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind) {
     if (rows == 0) return;
     // enough workgroups to cover the chip: rows/256 row blocks x nchunk column chunks ~ 1024 workgroups
     const int rb = (rows + GN_ROWS - 1) / GN_ROWS;
@@ -150,7 +187,8 @@ void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, 
     if (cols == 0) nchunk = 0;
     const BatchSc B = batch_of(s);
     if (nchunk > 0)
-        hipLaunchKernelGGL(k_gemv_n_partial, dim3(rb, nchunk, B.b.n), dim3(GN_ROWS), 0, s->stream, B.b, rows, cols, chunk, A, ld, x, s->gemv_partial);
+        hipLaunchKernelGGL(k_gemv_n_partial, dim3(rb, nchunk, B.b.n), dim3(GN_ROWS), 0, s->stream, B.b, sparsity_of(s, kind), kind == SP_HX ? s->d.ne : 0, rows, cols, chunk, A, ld,
+                           x, s->gemv_partial);
     hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, rows, nchunk, s->gemv_partial, y, alpha, beta);
 }
 

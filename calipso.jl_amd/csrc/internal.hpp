@@ -59,6 +59,17 @@ struct BatchSc {                     // + the per-instance scalars
     Scalars sc[MAX_BATCH];
 };
 
+// Structure of the matrix a mat-vec works on (structure.hip): the loads of entries that are structurally zero are predicated off;
+// the arithmetic (which lane adds what, in which order) is that of the dense kernels, so results do not change by a bit.
+enum { SP_DENSE = 0, SP_Z = 1 /* [gx; hx], m rows */, SP_GX = 2 /* gx, ne rows */, SP_HX = 3 /* hx, nc rows */, SP_LXX = 4 /* banded square */ };
+struct Sparsity {
+    int kind = SP_DENSE;
+    int hb = 0;                      // SP_LXX: half bandwidth
+    int ne = 0;                      // SP_Z: offset of the cone rows
+    const int* kr = nullptr;         // per 16-column group: [eq_lo, eq_hi, cone_lo, cone_hi) rows that touch it (per instance, in the slab)
+    const int* rowrange = nullptr;   // per row of [gx; hx]: [first, last + 1) non-zero column (per instance, in the slab)
+};
+
 struct Dims {
     int nx, np, ne, nc, n, N, m;  // m = ne + nc
     int q;                        // number of nonnegative entries (cone-local 0..q-1)
@@ -148,6 +159,7 @@ struct calipso_hip_solver {
     // stage-banded structure (structure.hip); band64 = 0: dense
     int half_bandwidth = 0, band64 = 0;
     int* krange = nullptr;      // (in the slab) per 16-column group: [eq_lo, eq_hi, cone_lo, cone_hi) constraint rows that touch it
+    int* zrow = nullptr;        // (in the slab) per row of [gx; hx]: [first, last + 1) non-zero column
     int* icount = nullptr;      // device ints: [0] pos [1] nonpos [2] zero (constraint part), [3..5] same for S, [6..] cone-search masks
     int* hicount = nullptr;     // pinned host mirror
     double* gemv_partial = nullptr;   // partial sums for column-split mat-vecs
@@ -197,9 +209,11 @@ void launch_residual_error(calipso_hip_solver* s, const double* step);   // resi
 void launch_add(calipso_hip_solver* s, double* y, const double* x, int len);    // y += x
 void launch_assemble_K(calipso_hip_solver* s);
 // gemv.hip
-void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta);
-void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta);
-void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t);   // yn = A x, yt = A'u + beta_t*yt, one pass over A
+void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
+void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
+void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t,
+               int kind = SP_DENSE);   // yn = A x, yt = A'u + beta_t*yt, one pass over A
+// `kind` names the block (SP_Z, SP_GX, SP_HX, SP_LXX) so that a handle with an analysed structure skips its structural zeros
 // schur.hip
 void launch_cone_weights(calipso_hip_solver* s);
 void launch_scale_rows(calipso_hip_solver* s);

@@ -33,7 +33,7 @@ void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t fla
     const Batch bt = batch_of(s).b;
     const unsigned nz = bt.n;
     if (flags & (CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_OBJECTIVE_GRADIENT)) {
-        gemv_t(s, d.nx, d.nx, s->Lxx, d.nx, x, Lx, 1.0, 0.0);   // Lxx is symmetric for the QP
+        gemv_t(s, d.nx, d.nx, s->Lxx, d.nx, x, Lx, 1.0, 0.0, SP_LXX);   // Lxx is symmetric for the QP
         if (flags & CALIPSO_EVAL_OBJECTIVE)
             hipLaunchKernelGGL(k_qp_objective, dim3(1, 1, nz), dim3(1024), 0, s->stream, bt, d.nx, x, Lx, s->qp.q, s->dscal);
         if (flags & CALIPSO_EVAL_OBJECTIVE_GRADIENT)
@@ -41,21 +41,21 @@ void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t fla
     }
     const bool want_g = (flags & CALIPSO_EVAL_EQUALITY) && d.ne, want_h = (flags & CALIPSO_EVAL_CONE) && d.nc;
     if (want_g && want_h) {            // [g; h] = [gx; hx] x + [-b; hvec]  — one pass over the stacked Jacobian
-        gemv_n(s, d.m, d.nx, s->Z, d.m, x, s->gh, 1.0, 0.0);
+        gemv_n(s, d.m, d.nx, s->Z, d.m, x, s->gh, 1.0, 0.0, SP_Z);
         hipLaunchKernelGGL(k_vec_add, dim3((d.m + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.m, s->gh, s->qp.bh, 1.0, s->gh);
     } else if (want_g) {
-        gemv_n(s, d.ne, d.nx, s->gx, d.m, x, s->g, 1.0, 0.0);
+        gemv_n(s, d.ne, d.nx, s->gx, d.m, x, s->g, 1.0, 0.0, SP_GX);
         hipLaunchKernelGGL(k_vec_add, dim3((d.ne + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.ne, s->g, s->qp.bh, 1.0, s->g);
     } else if (want_h) {
-        gemv_n(s, d.nc, d.nx, s->hx, d.m, x, s->hc, 1.0, 0.0);
+        gemv_n(s, d.nc, d.nx, s->hx, d.m, x, s->hc, 1.0, 0.0, SP_HX);
         hipLaunchKernelGGL(k_vec_add, dim3((d.nc + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.nc, s->hc, s->qp.bh + d.ne, 1.0, s->hc);
     }
     if (flags & CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT) {
-        if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.m, y, s->gyx, 1.0, 0.0);
+        if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.m, y, s->gyx, 1.0, 0.0, SP_GX);
         else fill_d(s, s->gyx, d.nx, 0.0);
     }
     if (flags & CALIPSO_EVAL_CONE_DUAL_GRADIENT) {
-        if (d.nc) gemv_t(s, d.nc, d.nx, s->hx, d.m, z, s->hzx, 1.0, 0.0);
+        if (d.nc) gemv_t(s, d.nc, d.nx, s->hx, d.m, z, s->hzx, 1.0, 0.0, SP_HX);
         else fill_d(s, s->hzx, d.nx, 0.0);
     }
     // Hessian / Jacobians are constant for a QP and were installed by calipso_hip_qp_attach

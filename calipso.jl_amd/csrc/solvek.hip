@@ -28,9 +28,9 @@ void launch_negate_copy(calipso_hip_solver* s, const double* src, double* dst, i
 // back-substitution [dy; dz] = -Omega (b_m - t2) is fused into k_recover.
 void linear_solve_device(calipso_hip_solver* s) {
     const Dims& d = s->d;
-    if (d.m) gemv_t(s, d.m, d.nx, s->Z, d.m, s->t1, s->xbuf, 1.0, 1.0);           // b_x + gx'(omega_y b_y) + hx'(Omega_z b_z)
+    if (d.m) gemv_t(s, d.m, d.nx, s->Z, d.m, s->t1, s->xbuf, 1.0, 1.0, SP_Z);           // b_x + gx'(omega_y b_y) + hx'(Omega_z b_z)
     launch_trsv(s, s->xbuf);                                                       // xbuf = S^-1 xbuf
-    if (d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->xbuf, s->t2, 1.0, 0.0);            // t2 = [gx; hx] dx
+    if (d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->xbuf, s->t2, 1.0, 0.0, SP_Z);            // t2 = [gx; hx] dx
 }
 
 // stand-alone linear_solve! on a caller-provided right-hand side b (= "residual_symmetric"): operands, solve, back-substitution

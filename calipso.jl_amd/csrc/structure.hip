@@ -64,6 +64,11 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
     const int band64 = (int)((hb + 63) / 64);                  // 64-row blocks below a diagonal block that can be non-zero
     const int nblk = d.NP / NB;
     CK(hipMemcpy(s->krange, kr.data(), sizeof(int) * kr.size(), hipMemcpyHostToDevice));
+    if (m) {
+        std::vector<int> zr(2 * (size_t)m);
+        for (int k = 0; k < m; ++k) { zr[2 * k] = cmax[k] >= cmin[k] ? cmin[k] : 0; zr[2 * k + 1] = cmax[k] >= cmin[k] ? cmax[k] + 1 : 0; }
+        CK(hipMemcpy(s->zrow, zr.data(), sizeof(int) * zr.size(), hipMemcpyHostToDevice));
+    }
     s->half_bandwidth = (int)hb;
     s->band64 = band64 >= nblk - 1 ? 0 : std::max(1, band64);  // 0: nothing to skip
     // entries of S outside the band are never written in banded mode and must read as zero (the block inverses span whole
