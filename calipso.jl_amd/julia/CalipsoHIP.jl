@@ -222,6 +222,15 @@ function search_direction_nonsymmetric!(hs::HIPSolver)
     return
 end
 
+# ---- stage-banded structure: what the reference gets from its sparsity pattern (src/trajectory_optimization/sparsity.jl) ---------
+"Analyse the non-zero pattern of the blocks currently on the device; afterwards the factorisation and the solves skip everything outside the band of the Schur complement. Returns (half_bandwidth, band_blocks, equality_rows_per_group, cone_rows_per_group)."
+function analyze_structure!(hs::HIPSolver)
+    out = zeros(Int64, 4)
+    check(hs.handle, ccall((:calipso_hip_analyze_structure, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), hs.handle, out), "analyze_structure!")
+    return Tuple(out)
+end
+clear_structure!(hs::HIPSolver) = check(hs.handle, ccall((:calipso_hip_clear_structure, lib), Int32, (Ptr{Cvoid},), hs.handle), "clear_structure!")
+
 # ---- groups: many same-shape solvers stepped through the same kernel launches (BASELINE config C4) ------------------------------
 "Up to 16 `HIPSolver`s of one shape on one device; `newton_step!` advances every member by one inner iteration of solve!."
 mutable struct HIPGroup
@@ -258,6 +267,6 @@ function CALIPSO.solve!(g::HIPGroup)
     return res
 end
 
-export HIPSolver, HIPLDLSolver, HIPGroup, newton_step!, search_direction_nonsymmetric!
+export HIPSolver, HIPLDLSolver, HIPGroup, newton_step!, search_direction_nonsymmetric!, analyze_structure!, clear_structure!
 
 end # module
