@@ -22,8 +22,8 @@ struct calipso_hip_group {
     std::vector<H*> hs;
     H* base = nullptr;                 // hs[0]: its stream carries every launch, its buffers are the address origin
     calipso::BatchSc desc;             // instance list of the launches being enqueued (base->cur points here)
-    double *dgather = nullptr, *hgather = nullptr;   // MAX_BATCH x 64 doubles (device, pinned host)
-    int *digather = nullptr, *higather = nullptr;    // MAX_BATCH x 64 ints
+    double *hgather = nullptr, *hgather_dev = nullptr;   // MAX_BATCH x 64 doubles: pinned host buffer and its device-side address
+    int *higather = nullptr, *higather_dev = nullptr;    // MAX_BATCH x 64 ints
     std::vector<calipso_eval_fn> evals;              // host evaluation callbacks of the members without a device evaluator
     std::vector<void*> users;
     int saved_band = 0, saved_hb = 0;                // the base handle's own structure while a group call overrides it
@@ -54,8 +54,8 @@ static void g_activate(G* g, const Set& a) {
 // dscal[first .. first+count) of every member of `a` (the active set) -> that member's hscal
 static int g_read_d(G* g, const Set& a, int first, int count) {
     H* s = g->base;
-    hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + first, count, g->dgather);
-    CK(hipMemcpyAsync(g->hgather, g->dgather, sizeof(double) * 64 * a.size(), hipMemcpyDeviceToHost, s->stream));
+    // the gather kernel stores straight into pinned host memory (one launch, no separate copy)
+    hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + first, count, g->hgather_dev);
     SYNC();
     for (size_t k = 0; k < a.size(); ++k)
         for (int i = 0; i < count; ++i) g->hs[a[k]]->hscal[first + i] = g->hgather[k * 64 + i];
@@ -63,8 +63,7 @@ static int g_read_d(G* g, const Set& a, int first, int count) {
 }
 static int g_read_i(G* g, const Set& a, int first, int count) {
     H* s = g->base;
-    hipLaunchKernelGGL(k_gather_i, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->icount + first, count, g->digather);
-    CK(hipMemcpyAsync(g->higather, g->digather, sizeof(int) * 64 * a.size(), hipMemcpyDeviceToHost, s->stream));
+    hipLaunchKernelGGL(k_gather_i, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->icount + first, count, g->higather_dev);
     SYNC();
     for (size_t k = 0; k < a.size(); ++k)
         for (int i = 0; i < count; ++i) g->hs[a[k]]->hicount[first + i] = g->higather[k * 64 + i];
@@ -406,10 +405,10 @@ int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, ca
     H* s = b;
     *out = g;
     CK(hipSetDevice(b->device));
-    CK(hipMalloc((void**)&g->dgather, sizeof(double) * 64 * MAX_BATCH));
-    CK(hipMalloc((void**)&g->digather, sizeof(int) * 64 * MAX_BATCH));
-    CK(hipHostMalloc((void**)&g->hgather, sizeof(double) * 64 * MAX_BATCH));
-    CK(hipHostMalloc((void**)&g->higather, sizeof(int) * 64 * MAX_BATCH));
+    CK(hipHostMalloc((void**)&g->hgather, sizeof(double) * 64 * MAX_BATCH, hipHostMallocMapped));
+    CK(hipHostMalloc((void**)&g->higather, sizeof(int) * 64 * MAX_BATCH, hipHostMallocMapped));
+    CK(hipHostGetDevicePointer((void**)&g->hgather_dev, g->hgather, 0));
+    CK(hipHostGetDevicePointer((void**)&g->higather_dev, g->higather, 0));
     return CALIPSO_OK;
 }
 
@@ -425,8 +424,6 @@ int32_t calipso_hip_group_set_evaluators(calipso_hip_group* g, const calipso_eva
 int32_t calipso_hip_group_destroy(calipso_hip_group* g) {
     if (!g) return CALIPSO_OK;
     if (g->base) { (void)hipSetDevice(g->base->device); (void)hipStreamSynchronize(g->base->stream); g->base->cur = nullptr; }
-    if (g->dgather) (void)hipFree(g->dgather);
-    if (g->digather) (void)hipFree(g->digather);
     if (g->hgather) (void)hipHostFree(g->hgather);
     if (g->higather) (void)hipHostFree(g->higather);
     delete g;
