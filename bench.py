@@ -153,7 +153,14 @@ def main():
     # creation order: the first member of every unit first, so that the streams that carry the launches get distinct priority
     # classes (handles take class = creation index mod 3, calipso_hip_create)
     order = [k for k in range(B) if k % G == 0] + [k for k in range(B) if k % G != 0]
-    made = {k: make_instance(pkg, pr, ids[k], shape, local_rank, staged, not args.dense_structure) for k in order}
+    made = {}
+    for k in order:
+        inst = make_instance(pkg, pr, ids[k], shape, local_rank, staged, not args.dense_structure)
+        # the dense host copies of the problem data (~100 MB per C3 instance) are only needed until they are on the device
+        made[k] = inst if k == 0 else (None, None, None, None, inst[4])
+        if k != 0:
+            inst[4].problem = None
+            inst[4].methods = None
     solvers = [made[k][4] for k in range(B)]
     units = [pkg.Group(solvers[k:k + G]) for k in range(0, B, G)] if G > 1 else solvers
     batch = BatchSolver(units, lanes=args.lanes)
