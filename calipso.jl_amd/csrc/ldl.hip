@@ -240,67 +240,95 @@ constexpr int FUSED_LDS_DOUBLES = TR_LDS_DOUBLES > DIAG_LDS_DOUBLES ? TR_LDS_DOU
 // Tile 0 of the trailing update IS the next diagonal block: its workgroup keeps going and factors that block (diag_block),
 // so the 64-column pivot chain of panel k+1 runs inside this launch, overlapped with the other tiles, and a panel step is two
 // launches (this kernel, then the panel GEMM) instead of three.
-__global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, int nx, int k0, int tb, double* __restrict__ S, const double* __restrict__ Y,
+// Workgroups are persistent: workgroup 0 takes tile 0 (and then the diagonal block), workgroup w >= 1 walks the tiles w, w + stride, ...
+// and fetches the operands of its next tile into registers while the matrix cores work on the current one, so that the
+// global-load latency of a tile (several microseconds under load, as long as its 16 MFMAs per wavefront) is hidden.
+__device__ __forceinline__ void trailing_tile_index(int t, int& ti, int& tj) {
+    ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    tj = t - ti * (ti + 1) / 2;
+}
+__global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, int nx, int k0, int ntiles, int tb, double* __restrict__ S, const double* __restrict__ Y,
                                                              double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount) {
     __shared__ double smem[FUSED_LDS_DOUBLES];
     inst_shift(bt, S, Y, Dx, Tinv);
     inst_shift_i(bt, icount);
     double* Ls = smem;                    // Ls[i][k]: rows of the i block of L21
     double* Ys = smem + TT * LDT;         // Ys[j][k]: rows of the j block of Y21
-    const int t = blockIdx.x;
-    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int tj = t - ti * (ti + 1) / 2;
     const int r0 = k0 + NB;
-    const int i0 = r0 + ti * TT, j0 = r0 + tj * TT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fk = lane >> 4;
-    // the entries of S this lane updates: loads issued first so their latency hides behind the staging and the MFMAs
-    double cS[4];
+    // staging map: a 32-lane half-wave covers 16 rows x 2 columns, so its ds_write_b64 addresses (row * LDT + c, LDT = 66)
+    // fall on 32 distinct bank pairs (a 64-row x 1-column map is a 2-way conflict: rows r and r + 16 share banks), while
+    // every global load is still a full 128-byte run of 16 consecutive rows
+    const int row = (tid & 15) + 16 * ((tid >> 6) & 3);
+    const int cb = ((tid >> 4) & 3) + 4 * (tid >> 8);   // 0..15
+    const double* Lp = S + (size_t)k0 * NP;
+    const int stride = (int)gridDim.x - 1;
+    int t = blockIdx.x;
+    int ti, tj;
+    trailing_tile_index(t, ti, tj);
+    int i0 = r0 + ti * TT, j0 = r0 + tj * TT;
+    double cS[4], lv[4], yv[4];           // operands of the current tile: the entries of S this lane updates, its share of the panels
 #pragma unroll
     for (int r = 0; r < 4; ++r) cS[r] = S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP];
-    {
-        // staging map: a 32-lane half-wave covers 16 rows x 2 columns, so its ds_write_b64 addresses (row * LDT + c, LDT = 66)
-        // fall on 32 distinct bank pairs (a 64-row x 1-column map is a 2-way conflict: rows r and r + 16 share banks), while
-        // every global load is still a full 128-byte run of 16 consecutive rows
-        const int row = (tid & 15) + 16 * ((tid >> 6) & 3);
-        const int cb = ((tid >> 4) & 3) + 4 * (tid >> 8);   // 0..15
-        const double* Lp = S + (size_t)k0 * NP;
-        double lv[4], yv[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = cb + it * 16;
-            lv[it] = Lp[(i0 + row) + (size_t)c * NP];
-            yv[it] = Y[(j0 + row) + (size_t)c * NP];
-        }
+    for (int it = 0; it < 4; ++it) {
+        const int c = cb + it * 16;
+        lv[it] = Lp[(i0 + row) + (size_t)c * NP];
+        yv[it] = Y[(j0 + row) + (size_t)c * NP];
+    }
+    for (;;) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int c = cb + it * 16;
             Ls[row * LDT + c] = lv[it];
             Ys[row * LDT + c] = yv[it];
         }
-    }
-    __syncthreads();
-    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        __syncthreads();
+        // next tile of this workgroup: its operands travel while the matrix cores work
+        const int tn = (t == 0 || stride <= 0) ? ntiles : t + stride;
+        int in0 = 0, jn0 = 0;
+        double cN[4];
+        if (tn < ntiles) {
+            int a, b;
+            trailing_tile_index(tn, a, b);
+            in0 = r0 + a * TT; jn0 = r0 + b * TT;
 #pragma unroll
-    for (int kk = 0; kk < NB / 4; ++kk) {
-        const double la = Ls[(wr * 16 + fr) * LDT + kk * 4 + fk];
-        const double yb = Ys[(wc * 16 + fr) * LDT + kk * 4 + fk];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yb, la, acc, 0, 0, 0);
-    }
-    if (t != 0) {
+            for (int r = 0; r < 4; ++r) cN[r] = S[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int c = cb + it * 16;
+                lv[it] = Lp[(in0 + row) + (size_t)c * NP];
+                yv[it] = Y[(jn0 + row) + (size_t)c * NP];
+            }
+        }
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; ++kk) {
+            const double la = Ls[(wr * 16 + fr) * LDT + kk * 4 + fk];
+            const double yb = Ys[(wc * 16 + fr) * LDT + kk * 4 + fk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yb, la, acc, 0, 0, 0);
+        }
+        if (t == 0) {
+            // tile 0 = the diagonal block of the next panel: hand it over through LDS (row-major, stride LDD) and factor it
+            __syncthreads();                      // all MFMA operand reads of Ls/Ys are done
+#pragma unroll
+            for (int r = 0; r < 4; ++r) smem[(wr * 16 + fr) * LDD + (wc * 16 + fk + 4 * r)] = cS[r] - acc[r];
+            __syncthreads();
+            diag_block<true>(smem, NP, nx, r0, tb, S, Dx, Tinv, icount);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP] = cS[r] - acc[r];
-        return;
-    }
-    // tile 0 = the diagonal block of the next panel: hand it over through LDS (row-major, stride LDD) and factor it
-    __syncthreads();                      // all MFMA operand reads of Ls/Ys are done
+        if (tn >= ntiles) return;
+        t = tn; i0 = in0; j0 = jn0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) smem[(wr * 16 + fr) * LDD + (wc * 16 + fk + 4 * r)] = cS[r] - acc[r];
-    __syncthreads();
-    diag_block<true>(smem, NP, nx, r0, tb, S, Dx, Tinv, icount);
+        for (int r = 0; r < 4; ++r) cS[r] = cN[r];
+        __syncthreads();                          // the operand reads of this tile are done before LDS is refilled
+    }
 }
 
 // ---- inverses of the 256 x 256 diagonal blocks from the 64 x 64 ones -----------------------------------------------------------
@@ -383,7 +411,10 @@ static void enqueue_ldl(calipso_hip_solver* s) {
         hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64, 1, nz), dim3(1024), 0, s->stream, bt, NP, k0, tb, s->S, s->Dx, s->Tinv, s->Ypanel);
         const int ntr = rows / TT, ntiles = ntr * (ntr + 1) / 2;
         // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
-        hipLaunchKernelGGL(k_ldl_trailing, dim3(ntiles, 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, tb, s->S, s->Ypanel, s->Dx, s->Tinv, s->icount);
+        // persistent workgroups: two fit a CU (LDS, wave slots), so at most 512 are resident; more would only queue
+        const int resident = std::max(2, 512 / (int)nz);
+        const int nwg = ntiles <= resident ? ntiles : resident;
+        hipLaunchKernelGGL(k_ldl_trailing, dim3(nwg, 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S, s->Ypanel, s->Dx, s->Tinv, s->icount);
     }
     const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
     for (int level = 1; level <= 3; ++level) {
