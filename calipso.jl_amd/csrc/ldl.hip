@@ -283,9 +283,9 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
     for (;;) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int c = cb + it * 16;
-            Ls[row * LDT + c] = lv[it];
-            Ys[row * LDT + c] = yv[it];
+            const int c = cb + it * 16;                      // panel column k; stored at (k % 4) * 16 + k / 4: per-lane fragments contiguous
+            Ls[row * LDT + (c & 3) * 16 + (c >> 2)] = lv[it];
+            Ys[row * LDT + (c & 3) * 16 + (c >> 2)] = yv[it];
         }
         __syncthreads();
         // next tile of this workgroup: its operands travel while the matrix cores work
@@ -306,12 +306,13 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
             }
         }
         v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        // a lane's 16 fragment values (k = 4 kk + fk) are contiguous in LDS (see the staging): 128-bit reads, and the 16 lanes of a
+        // pass cover 64 distinct banks.  (With k stored in natural order the compiler pairs the kk and kk + 1 fragments into
+        // ds_read2_b64, whose second element lands on the banks of the lane two rows down: a 2-way conflict on every read.)
+        const double* Lv = Ls + (wr * 16 + fr) * LDT + fk * 16;
+        const double* Yv = Ys + (wc * 16 + fr) * LDT + fk * 16;
 #pragma unroll
-        for (int kk = 0; kk < NB / 4; ++kk) {
-            const double la = Ls[(wr * 16 + fr) * LDT + kk * 4 + fk];
-            const double yb = Ys[(wc * 16 + fr) * LDT + kk * 4 + fk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yb, la, acc, 0, 0, 0);
-        }
+        for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Yv[kk], Lv[kk], acc, 0, 0, 0);
         if (t == 0) {
             // tile 0 = the diagonal block of the next panel: hand it over through LDS (row-major, stride LDD) and factor it
             __syncthreads();                      // all MFMA operand reads of Ls/Ys are done
