@@ -197,6 +197,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
 
 int32_t calipso_hip_destroy(H* s) {
     if (!s) return CALIPSO_OK;
+    if (s->owner) calipso::group_member_destroyed(s->owner, s);   // a live group must never touch this handle again (group.hip)
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     nonsymmetric_release(s);
@@ -282,9 +283,21 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
     if (!s || !name || (!data && len > 0)) return CALIPSO_ERR_ARGUMENT;
     Field f;
     if (!find_field(s, name, f)) return fail_arg(s, std::string("unknown field: ") + name);
-    if (f.len == -1) { if (len != 1) return fail_arg(s, "scalar expected"); *(calipso::i64*)f.host = (calipso::i64)llround(data[0]); return CALIPSO_OK; }
+    const std::string nm = name;
+    if (f.len == -1) {
+        if (len != 1) return fail_arg(s, "scalar expected");
+        const calipso::i64 v = (calipso::i64)llround(data[0]);
+        if (nm == "opt.max_cone_line_search" && (v < 0 || v + 1 > CONE_MASK_TRIALS)) return fail_arg(s, "opt.max_cone_line_search must be in 0..831");
+        *(calipso::i64*)f.host = v;
+        return CALIPSO_OK;
+    }
     if (len != f.len) return fail_arg(s, std::string("wrong length for field ") + name);
-    if (f.host) { *f.host = data[0]; return CALIPSO_OK; }
+    if (f.host) {
+        if (nm == "opt.scaling_line_search" && !(data[0] > 0.0 && data[0] < 1.0)) return fail_arg(s, "opt.scaling_line_search must be in (0, 1)");
+        if (nm == "opt.max_filter") { if (!(data[0] >= 1.0)) return fail_arg(s, "opt.max_filter must be >= 1"); filter_resize(s, (calipso::i64)data[0]); }   // filter.jl:7-13 sizes it from the option
+        *f.host = data[0];
+        return CALIPSO_OK;
+    }
     if (!f.dev) return fail_arg(s, std::string("field not allocated: ") + name);
     if (len == 0) return CALIPSO_OK;
     CK(hipSetDevice(s->device));
@@ -292,9 +305,15 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
         CK(hipMemcpy2DAsync(f.dev, sizeof(double) * f.ld, data, sizeof(double) * f.rows, sizeof(double) * f.rows, len / f.rows, hipMemcpyHostToDevice, s->stream));
     else
         CK(hipMemcpyAsync(f.dev, data, sizeof(double) * len, hipMemcpyHostToDevice, s->stream));
+    if (nm == "parameters") s->hparams.assign(data, data + len);
+    if (nm == "lagrangian_hessian") s->hessian_dirty = true;
+    // an analysed stage-banded structure (structure.hip) is a promise about where these three blocks are non-zero: re-check it
+    // on the device against what was just uploaded; a block that breaks it sends the handle back to the dense treatment
+    if (s->band64 > 0 && (nm == "lagrangian_hessian" || nm == "equality_jacobian_variables" || nm == "cone_jacobian_variables")) {
+        const int rc = structure_validate(s, nm == "lagrangian_hessian" ? 0 : (nm == "equality_jacobian_variables" ? 1 : 2));
+        if (rc < 0) return rc;
+    }
     SYNC();
-    if (std::string(name) == "parameters") s->hparams.assign(data, data + len);
-    if (std::string(name) == "lagrangian_hessian") s->hessian_dirty = true;
     return CALIPSO_OK;
 }
 
@@ -472,12 +491,9 @@ static int do_cone_search(H* s, double* a_s, double* a_t) {
     launch_cone_search(s);
     CK(hipMemcpyAsync(s->hicount + 6, s->icount + 6, sizeof(int) * 58, hipMemcpyDeviceToHost, s->stream));
     SYNC();
-    const int nk = std::min<int>((int)o.max_cone_line_search + 1, 26);
-    int ks = -1, kt = -1;
-    for (int k = 0; k < nk; ++k) if (s->hicount[6 + k] == 0) { ks = k; break; }
-    for (int k = 0; k < nk; ++k) if (s->hicount[32 + k] == 0) { kt = k; break; }
+    const int ks = first_feasible_trial(s->hicount + 6, o.max_cone_line_search), kt = first_feasible_trial(s->hicount + 32, o.max_cone_line_search);
     if (ks < 0 || kt < 0) { s->err = "cone search failure"; return CALIPSO_ERR_CONE_SEARCH; }   // solve.jl:210,220
-    // step sizes as the reference forms them: repeated multiplication by scaling_line_search (= 0.5: exact powers of two)
+    // step sizes as the reference forms them: repeated multiplication by scaling_line_search (the kernel tested exactly these)
     double as = 1.0, at = 1.0;
     for (int k = 0; k < ks; ++k) as = o.scaling_line_search * as;
     for (int k = 0; k < kt; ++k) at = o.scaling_line_search * at;
@@ -807,6 +823,7 @@ int32_t calipso_hip_qp_attach(H* s, const double* P, const double* q, const doub
     const Dims& d = s->d;
     if ((d.ne && (!A || !b)) || (d.nc && (!G || !h))) return CALIPSO_ERR_ARGUMENT;
     CK(hipSetDevice(s->device));
+    if (s->band64 > 0) { const int rc = calipso_hip_clear_structure(s); if (rc < 0) return rc; }   // new blocks: any analysed structure is void
     const size_t nx = d.nx;
     // Lxx = 2c P ; gx = A ; hx = -G   (constant Hessian / Jacobians of the QP); bh = [-b; h]
     CK(hipMemcpyAsync(s->S, P, sizeof(double) * nx * nx, hipMemcpyHostToDevice, s->stream));   // S is free before the first factorisation

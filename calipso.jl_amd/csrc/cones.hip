@@ -93,44 +93,45 @@ void launch_cone(calipso_hip_solver* s, const double* point, int flags) {
                        s->cone_target, s->barrier_gradient, s->dscal);
 }
 
-// cone_violation(xhat, x, tau)  cones/cone.jl:62-68, nonnegative.jl:29-34, second_order.jl:45-47 evaluated for all 26
-// candidate step sizes alpha_k = 2^-k at once:  xhat = x - alpha_k * dx.  mask[k] != 0  <=>  violation at alpha_k.
-// The sequential halving of solve.jl:204-221 stops at the first k without violation, which is what the host picks.
-// xhat is formed exactly as the reference does (x - alpha*dx with alpha a power of two).
+// cone_violation(xhat, x, tau)  cones/cone.jl:62-68, nonnegative.jl:29-34, second_order.jl:45-47 evaluated for all the
+// candidate step sizes alpha_k = scaling_line_search^k (k = 0 .. max_cone_line_search) at once:  xhat = x - alpha_k * dx.
+// Bit k & 31 of mask[k >> 5] is set  <=>  violation at alpha_k (CONE_MASK_WORDS words: up to 832 trial step sizes).
+// The sequential shrinking of solve.jl:204-221 stops at the first k without violation, which is what the host picks.
+// alpha_k is formed exactly as the reference does: alpha <- scaling_line_search * alpha, starting from 1.
 __device__ __forceinline__ void violation_masks(const Dims& d, const ConeDev& cd, const double* __restrict__ x,
-                                                const double* __restrict__ dx, double tau, int nk, int* __restrict__ mask) {
+                                                const double* __restrict__ dx, double tau, double sls, int nk, int* __restrict__ mask) {
     const int tid = threadIdx.x;
     const double omt = 1.0 - tau;
     for (int i = tid; i < d.q; i += blockDim.x) {
         const double xi = x[i], dxi = dx[i];
         double a = 1.0;
-        for (int k = 0; k < nk; ++k, a *= 0.5) {
-            if (xi - a * dxi <= omt * xi) atomicOr(&mask[k], 1);
+        for (int k = 0; k < nk; ++k, a = sls * a) {
+            if (xi - a * dxi <= omt * xi) atomicOr(&mask[k >> 5], 1 << (k & 31));
         }
     }
     for (int j = tid; j < d.n_soc; j += blockDim.x) {
         const int st = cd.soc_start[j], dim = cd.soc_dim[j];
         double a = 1.0;
-        for (int k = 0; k < nk; ++k, a *= 0.5) {
+        for (int k = 0; k < nk; ++k, a = sls * a) {
             double nrm = 0.0;
             for (int e = 1; e < dim; ++e) {
                 const double df = (x[st + e] - a * dx[st + e]) - omt * x[st + e];
                 nrm += df * df;
             }
-            if ((x[st] - a * dx[st]) - omt * x[st] <= sqrt(nrm)) atomicOr(&mask[k], 1);
+            if ((x[st] - a * dx[st]) - omt * x[st] <= sqrt(nrm)) atomicOr(&mask[k >> 5], 1 << (k & 31));
         }
     }
 }
 
 __global__ __launch_bounds__(CONE_THREADS) void k_cone_search(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ sol,
-                                                               const double* __restrict__ step, int nk,
+                                                               const double* __restrict__ step, double sls, int nk,
                                                                int* __restrict__ icount) {
     inst_shift(bt.b, sol, step);
     inst_shift_i(bt.b, icount);
     const double tau = bt.sc[blockIdx.z].tau;
     // block 0: slack s with Delta s ; block 1: slack dual t with Delta t   (separate step sizes, solve.jl:190-221)
     const int off = blockIdx.x == 0 ? d.os() : d.ot();
-    violation_masks(d, cd, sol + off, step + off, tau, nk, icount + (blockIdx.x == 0 ? 6 : 32));
+    violation_masks(d, cd, sol + off, step + off, tau, sls, nk, icount + (blockIdx.x == 0 ? 6 : 32));
 }
 
 void launch_cone_search(calipso_hip_solver* s) {
@@ -139,7 +140,7 @@ void launch_cone_search(calipso_hip_solver* s) {
     const int nk = (int)s->opt.max_cone_line_search + 1;
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_cone_search, dim3(2, 1, B.b.n), dim3(CONE_THREADS), 0, s->stream, B, s->d, s->cone, s->solution, s->step,
-                       nk > 26 ? 26 : nk, s->icount);
+                       s->opt.scaling_line_search, nk > CONE_MASK_TRIALS ? CONE_MASK_TRIALS : nk, s->icount);
 }
 
 // candidate s, t for the chosen step sizes (solve.jl:206-208, 216-218)

@@ -27,6 +27,7 @@ struct calipso_hip_group {
     std::vector<calipso_eval_fn> evals;              // host evaluation callbacks of the members without a device evaluator
     std::vector<void*> users;
     int saved_band = 0, saved_hb = 0;                // the base handle's own structure while a group call overrides it
+    bool dead = false;                               // a member was destroyed: every further call fails (no dangling handle is touched)
     std::string err;
 };
 typedef calipso_hip_group G;
@@ -307,10 +308,7 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
         if (g_read_i(g, a, 6, 58)) return CALIPSO_ERR_HIP;
         for (int i : a) {
             H* h = g->hs[i]; const Options& o = h->opt;
-            const int nk = std::min<int>((int)o.max_cone_line_search + 1, 26);
-            int ks = -1, kt = -1;
-            for (int k = 0; k < nk; ++k) if (h->hicount[6 + k] == 0) { ks = k; break; }
-            for (int k = 0; k < nk; ++k) if (h->hicount[32 + k] == 0) { kt = k; break; }
+            const int ks = first_feasible_trial(h->hicount + 6, o.max_cone_line_search), kt = first_feasible_trial(h->hicount + 32, o.max_cone_line_search);
             if (ks < 0 || kt < 0) { h->err = "cone search failure"; rc[i] = CALIPSO_ERR_CONE_SEARCH; continue; }
             for (int k = 0; k < ks; ++k) as[i] = o.scaling_line_search * as[i];
             for (int k = 0; k < kt; ++k) at[i] = o.scaling_line_search * at[i];
@@ -385,6 +383,34 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
     return CALIPSO_OK;
 }
 
+namespace calipso {
+// Finalisers (Julia, Python) run in unspecified order: a member may be destroyed before its group.  The group then drops every
+// handle pointer; its remaining entry points return CALIPSO_ERR_ARGUMENT and calipso_hip_group_destroy only frees its own memory.
+void group_member_destroyed(calipso_hip_group* g, calipso_hip_solver* dying) {
+    if (!g) return;
+    for (H* h : g->hs) {
+        if (h == g->base && h->stream) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); }
+        h->cur = nullptr;
+        h->owner = nullptr;
+    }
+    (void)dying;
+    g->hs.clear();
+    g->base = nullptr;
+    g->dead = true;
+}
+}  // namespace calipso
+
+// members of a group share one cone-search launch: the options that launch takes by value must agree
+static int g_check_options(G* g) {
+    const Options& o = g->base->opt;
+    for (H* h : g->hs)
+        if (h->opt.scaling_line_search != o.scaling_line_search || h->opt.max_cone_line_search != o.max_cone_line_search) {
+            g->base->err = "group members must share opt.scaling_line_search and opt.max_cone_line_search";
+            return CALIPSO_ERR_ARGUMENT;
+        }
+    return CALIPSO_OK;
+}
+
 extern "C" {
 
 int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, calipso_hip_group** out) {
@@ -398,10 +424,12 @@ int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, ca
                           h->h_soc_start == b->h_soc_start && h->h_soc_dim == b->h_soc_dim && h->h_nonneg == b->h_nonneg;
         if (!same) { b->err = "calipso_hip_group_create: members must have the same shape, cone layout and device"; return CALIPSO_ERR_ARGUMENT; }
         for (int j = 0; j < i; ++j) if (handles[j] == h) { b->err = "calipso_hip_group_create: duplicate member"; return CALIPSO_ERR_ARGUMENT; }
+        if (h->owner) { b->err = "calipso_hip_group_create: a handle can be a member of one group at a time"; return CALIPSO_ERR_ARGUMENT; }
     }
     G* g = new G();
     g->hs.assign(handles, handles + count);
     g->base = b;
+    for (H* h : g->hs) h->owner = g;
     H* s = b;
     *out = g;
     CK(hipSetDevice(b->device));
@@ -414,7 +442,7 @@ int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, ca
 
 // host evaluation callbacks (calipso_eval_fn, include/calipso_hip.h) of the members that have no device evaluator; entries may be NULL
 int32_t calipso_hip_group_set_evaluators(calipso_hip_group* g, const calipso_eval_fn* evals, void* const* users) {
-    if (!g) return CALIPSO_ERR_ARGUMENT;
+    if (!g || g->dead) return CALIPSO_ERR_ARGUMENT;
     g->evals.assign(g->hs.size(), nullptr);
     g->users.assign(g->hs.size(), nullptr);
     for (size_t i = 0; i < g->hs.size(); ++i) { if (evals) g->evals[i] = evals[i]; if (users) g->users[i] = users[i]; }
@@ -424,6 +452,7 @@ int32_t calipso_hip_group_set_evaluators(calipso_hip_group* g, const calipso_eva
 int32_t calipso_hip_group_destroy(calipso_hip_group* g) {
     if (!g) return CALIPSO_OK;
     if (g->base) { (void)hipSetDevice(g->base->device); (void)hipStreamSynchronize(g->base->stream); g->base->cur = nullptr; }
+    for (H* h : g->hs) h->owner = nullptr;
     if (g->hgather) (void)hipHostFree(g->hgather);
     if (g->higather) (void)hipHostFree(g->higather);
     delete g;
@@ -432,11 +461,12 @@ int32_t calipso_hip_group_destroy(calipso_hip_group* g) {
 
 // calipso_hip_newton_step for every member at once; info = count x 6 (row-major, same fields), status = count entries
 int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, double* info_out, int32_t* status) {
-    if (!g || !g->base) return CALIPSO_ERR_ARGUMENT;
+    if (!g || !g->base || g->dead) return CALIPSO_ERR_ARGUMENT;
     H* s = g->base;
     const Dims& d = s->d;
     const size_t B = g->hs.size();
     CK(hipSetDevice(s->device));
+    { const int oc = g_check_options(g); if (oc < 0) return oc; }
     Set all;
     for (size_t i = 0; i < B; ++i) {
         H* h = g->hs[i];
@@ -502,11 +532,12 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
 // round for all members still iterating; members whose inner loop ends (central-path update due, or iteration cap) take their
 // outer update before the next round, converged members drop out.  result[i] = 1 converged, 0 iteration caps reached, < 0 error.
 int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
-    if (!g || !g->base) return CALIPSO_ERR_ARGUMENT;
+    if (!g || !g->base || g->dead) return CALIPSO_ERR_ARGUMENT;
     H* s = g->base;
     const Dims& d = s->d;
     const size_t B = g->hs.size();
     CK(hipSetDevice(s->device));
+    { const int oc = g_check_options(g); if (oc < 0) return oc; }
     Set all;
     for (size_t i = 0; i < B; ++i) {
         H* h = g->hs[i];

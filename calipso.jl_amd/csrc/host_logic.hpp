@@ -1,6 +1,7 @@
 // host_logic.hpp — host-side pieces of the inner iteration shared by the single-handle driver (api.hip) and the group driver
 // (group.hip): inertia test, filter, line-search predicates.  Pure C++ on the handle's host state; nothing here touches the device.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 
@@ -11,6 +12,14 @@ typedef calipso_hip_solver H;
 
 static inline bool inertia_ok(const H* s, const int64_t in[3]) { return in[0] == s->d.nx && in[1] == s->d.ne + s->d.nc && in[2] == 0; }   // inertia.jl:7-11
 
+
+// first trial index k in 0..max_cone_line_search whose violation bit is clear (cones.hip: violation_masks), -1 if none: the
+// reference raises "cone search failure" once cone_iteration exceeds max_cone_line_search (solve.jl:204-221)
+static inline int first_feasible_trial(const int* mask, calipso::i64 max_cone_line_search) {
+    const int nk = (int)std::min<calipso::i64>(max_cone_line_search + 1, calipso::CONE_MASK_TRIALS);
+    for (int k = 0; k < nk; ++k) if (!(mask[k >> 5] & (1 << (k & 31)))) return k;
+    return -1;
+}
 
 // ---- filter (filter.jl:1-89), host side ------------------------------------------------------------------------------------
 static inline void filter_reset(H* s) {
@@ -23,8 +32,19 @@ static inline bool check_filter(const H* s, double theta, double merit) {
         if (!(theta < s->filter_theta[i] || merit < s->filter_merit[i])) return false;
     return true;
 }
-static inline void augment_filter(H* s, double theta, double merit) {
-    if (s->filter_index == 0) { s->filter_theta[0] = theta; s->filter_merit[0] = merit; s->filter_index = 1; return; }
+static inline void filter_resize(H* s, calipso::i64 n) {
+    if (n < 1) n = 1;
+    s->filter_theta.resize((size_t)n, 1.0e8); s->filter_merit.resize((size_t)n, 1.0e8);
+    s->cache_theta.resize((size_t)n, 1.0e8); s->cache_merit.resize((size_t)n, 1.0e8);
+    if (s->filter_index > n) s->filter_index = n;
+}
+// returns false when the filter is full (the reference raises a BoundsError there: filter.jl:52-79 has no overflow guard)
+static inline bool augment_filter(H* s, double theta, double merit) {
+    if (s->filter_index >= (calipso::i64)s->filter_theta.size() && check_filter(s, theta, merit)) {
+        // every kept pair plus the new one must fit: grow instead of writing past the end
+        filter_resize(s, 2 * (calipso::i64)s->filter_theta.size());
+    }
+    if (s->filter_index == 0) { s->filter_theta[0] = theta; s->filter_merit[0] = merit; s->filter_index = 1; return true; }
     if (check_filter(s, theta, merit)) {
         const calipso::i64 nold = s->filter_index;
         for (calipso::i64 i = 0; i < nold; ++i) { s->cache_theta[i] = s->filter_theta[i]; s->cache_merit[i] = s->filter_merit[i]; }
@@ -38,6 +58,7 @@ static inline void augment_filter(H* s, double theta, double merit) {
                 s->filter_index += 1;
             }
     }
+    return true;
 }
 // line_search.jl:2-18 with d = dot(merit_gradient, step.primals) precomputed on the device
 static inline bool switching_condition(double step_size, double dd, double merit_exponent, double violation, double violation_exponent, double reg) {

@@ -17,6 +17,8 @@ typedef int64_t i64;
 constexpr int TILE = 128;   // Schur-complement (SYRK) workgroup tile
 constexpr int NB = 64;      // LDL^T panel width
 constexpr int MAX_SOC_DIM = 64;
+constexpr int CONE_MASK_WORDS = 26;                     // icount[6..31] (slack) and icount[32..57] (slack dual): one bit per trial step size
+constexpr int CONE_MASK_TRIALS = 32 * CONE_MASK_WORDS;  // => max_cone_line_search <= 831
 
 // options.jl:6-59 (hot-path relevant subset + the rest for API parity)
 struct Options {
@@ -111,6 +113,7 @@ struct calipso_hip_solver {
     calipso::ConeDev cone;
     calipso::QpEval qp;
     calipso::Stats stats;
+    struct calipso_hip_group* owner = nullptr;   // the group this handle is a member of (group.hip), if any
     const calipso::BatchSc* cur = nullptr;   // set by the group driver on its base handle: launches cover these instances
     double* slab = nullptr; size_t slab_doubles = 0;   // all per-instance device buffers live here (see calipso::Batch)
     int device = 0;
@@ -158,6 +161,7 @@ struct calipso_hip_solver {
     int schur_nj = 8;           // Schur tile = 128 x 16*schur_nj for single-instance launches (schur.hip: schur_plan)
     // stage-banded structure (structure.hip); band64 = 0: dense
     int half_bandwidth = 0, band64 = 0;
+    calipso::i64 structure_resets = 0;   // uploads that broke an analysed structure (the handle went back to dense)
     int* krange = nullptr;      // (in the slab) per 16-column group: [eq_lo, eq_hi, cone_lo, cone_hi) constraint rows that touch it
     int* zrow = nullptr;        // (in the slab) per row of [gx; hx]: [first, last + 1) non-zero column
     int* icount = nullptr;      // device ints: [0] pos [1] nonpos [2] zero (constraint part), [3..5] same for S, [6..] cone-search masks
@@ -187,7 +191,7 @@ namespace calipso {
 // ---- launchers (each enqueues on s->stream; no host synchronisation unless stated) -------------------------------
 // cones.hip
 void launch_cone(calipso_hip_solver* s, const double* point, int flags);
-void launch_cone_search(calipso_hip_solver* s);                 // fills icount[6..] violation masks for alpha = 2^-k
+void launch_cone_search(calipso_hip_solver* s);                 // fills icount[6..] violation bit masks for alpha = scaling_line_search^k
 void launch_cone_candidate(calipso_hip_solver* s, double a_s, double a_t);
 void launch_cone_candidate_batch(calipso_hip_solver* s, const double* a_s, const double* a_t);   // one pair per covered instance
 void launch_cone_violation_host(calipso_hip_solver* s, const double* xhat_dev, const double* x_dev, double tau);
@@ -240,6 +244,10 @@ void launch_recover_multi(calipso_hip_solver* s, const double* res, int p, const
 // fallback.hip
 int nonsymmetric_solve(calipso_hip_solver* s, const double* res, double* step);   // step = H \\ res (pivoted LU of the unreduced matrix)
 void nonsymmetric_release(calipso_hip_solver* s);
+// group.hip
+void group_member_destroyed(struct calipso_hip_group* g, calipso_hip_solver* s);   // called by calipso_hip_destroy on a member of a live group
+// structure.hip
+int structure_validate(calipso_hip_solver* s, int which);      // which: 0 Lxx, 1 gx, 2 hx; clears the structure when the block breaks it
 // qp.hip
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 

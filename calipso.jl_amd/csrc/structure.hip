@@ -16,6 +16,61 @@
 
 using namespace calipso;
 
+// ---- re-validation of uploads against an analysed structure ---------------------------------------------------------------------
+// flag[0] != 0  <=>  the block holds a non-zero entry where the structure promises a zero
+__global__ void k_check_band(int nx, int hb, const double* __restrict__ L, int* __restrict__ flag) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)nx * nx) return;
+    const int i = (int)(idx % nx), j = (int)(idx / nx);
+    const int dist = i > j ? i - j : j - i;
+    if (dist > hb && L[idx] != 0.0) atomicOr(flag, 1);
+}
+__global__ void k_check_rows(int rows, int row0, int m, int nx, const double* __restrict__ Z, const int* __restrict__ zrow, int* __restrict__ flag) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * nx) return;
+    const int k = row0 + (int)(idx % rows), j = (int)(idx / rows);
+    if ((j < zrow[2 * k] || j >= zrow[2 * k + 1]) && Z[k + (size_t)j * m] != 0.0) atomicOr(flag, 1);
+}
+
+static int structure_clear(calipso_hip_solver* s) {
+    s->band64 = 0; s->half_bandwidth = 0;
+    const Dims& d = s->d;
+    const size_t G = ((size_t)d.nx + 15) / 16;
+    std::vector<int> kr(4 * G);
+    for (size_t g = 0; g < G; ++g) { kr[4 * g] = 0; kr[4 * g + 1] = d.ne; kr[4 * g + 2] = 0; kr[4 * g + 3] = d.nc; }
+    CK(hipSetDevice(s->device));
+    CK(hipStreamSynchronize(s->stream));
+    CK(hipMemcpy(s->krange, kr.data(), sizeof(int) * kr.size(), hipMemcpyHostToDevice));
+    if (s->graph_ldl) { (void)hipGraphExecDestroy(s->graph_ldl); s->graph_ldl = nullptr; }      // the launch sequences change with the band
+    if (s->graph_trsv) { (void)hipGraphExecDestroy(s->graph_trsv); s->graph_trsv = nullptr; }
+    s->graph_ldl_tried = false; s->graph_trsv_tried = false;
+    return CALIPSO_OK;
+}
+
+namespace calipso {
+int structure_validate(calipso_hip_solver* s, int which) {
+    const Dims& d = s->d;
+    int* flag = s->icount + 60;
+    CK(hipMemsetAsync(flag, 0, sizeof(int), s->stream));
+    if (which == 0) {
+        const size_t n = (size_t)d.nx * d.nx;
+        hipLaunchKernelGGL(k_check_band, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d.nx, s->half_bandwidth, s->Lxx, flag);
+    } else {
+        const int rows = which == 1 ? d.ne : d.nc, row0 = which == 1 ? 0 : d.ne;
+        const size_t n = (size_t)rows * d.nx;
+        if (n) hipLaunchKernelGGL(k_check_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, rows, row0, d.m, d.nx, s->Z, s->zrow, flag);
+    }
+    CK(hipMemcpyAsync(s->hicount + 60, flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    CK(hipStreamSynchronize(s->stream));
+    if (s->hicount[60] != 0) {
+        s->structure_resets += 1;
+        s->err = "uploaded block has non-zeros outside the analysed structure: the handle is back to the dense treatment";
+        return structure_clear(s);
+    }
+    return CALIPSO_OK;
+}
+}  // namespace calipso
+
 extern "C" {
 
 // out[0] = half bandwidth hb of S, out[1] = 64-wide blocks per panel inside the band (0 = treated as dense),
@@ -86,20 +141,7 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
 // back to the dense treatment (e.g. before uploading blocks with a different pattern)
 int32_t calipso_hip_clear_structure(calipso_hip_solver* s) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
-    s->band64 = 0; s->half_bandwidth = 0;
-    {
-        const Dims& d = s->d;
-        const size_t G = ((size_t)d.nx + 15) / 16;
-        std::vector<int> kr(4 * G);
-        for (size_t g = 0; g < G; ++g) { kr[4 * g] = 0; kr[4 * g + 1] = d.ne; kr[4 * g + 2] = 0; kr[4 * g + 3] = d.nc; }
-        CK(hipSetDevice(s->device));
-        CK(hipStreamSynchronize(s->stream));
-        CK(hipMemcpy(s->krange, kr.data(), sizeof(int) * kr.size(), hipMemcpyHostToDevice));
-    }
-    if (s->graph_ldl) { (void)hipGraphExecDestroy(s->graph_ldl); s->graph_ldl = nullptr; }
-    if (s->graph_trsv) { (void)hipGraphExecDestroy(s->graph_trsv); s->graph_trsv = nullptr; }
-    s->graph_ldl_tried = false; s->graph_trsv_tried = false;
-    return CALIPSO_OK;
+    return structure_clear(s);
 }
 
 }  // extern "C"

@@ -355,11 +355,43 @@ def qp_nonnegative_parametric(seed=0, nx=10, ne=5):
     return prob
 
 
-def pendulum(T=11, h=0.05, action_guess=None):
+class TrajectoryProblem(SymbolicProblem):
+    """A SymbolicProblem whose equality-dual Hessian (g'y)xx is scattered the way the reference's trajectory layer does it
+    (SURVEY.md quirk B-11): every dynamics stage t emits the structurally non-zero entries of the Hessian of y_t'd_t(X_t, U_t, X_t+1)
+    at GLOBAL (i, j) tuples (src/trajectory_optimization/dynamics.jl:81-101,245-260), the per-stage lists are concatenated without
+    de-duplication (methods.jl:24-27) and the core scatter ASSIGNS  problem.equality_dual_jacobian_variables_variables[idx...] =
+    cache[i]  (src/solver/evaluate.jl:75-77): where consecutive stages share (X_t+1, X_t+1) entries the LAST writer wins (stage
+    order 1..T-1).  hessian_mode = "sum" gives the exact Hessian instead (what the reference's own unit test checks with +=,
+    test/trajectory_optimization/hessian_lagrangian.jl:297-303)."""
+
+    def set_stages(self, stage_hessian, stage_slices, stage_dual_slices, hessian_mode):
+        self._stage_hessian = stage_hessian            # (x, u, y, lam) -> local Hessian of lam'd wrt [x; u; y], and its structural pattern
+        self._stage_slices = stage_slices              # per stage: global indices of [x; u; y]
+        self._stage_dual_slices = stage_dual_slices    # per stage: slice of the equality duals of its dynamics rows
+        self.hessian_mode = hessian_mode
+
+    def evaluate(self, flags, x, y, z, theta, out):
+        SymbolicProblem.evaluate(self, flags & ~EQUALITY_DUAL_HESSIAN, x, y, z, theta, out)
+        if flags & EQUALITY_DUAL_HESSIAN:
+            fn, pattern = self._stage_hessian
+            H = np.zeros((self.nx, self.nx))
+            xv, yv = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+            for idx, dsl in zip(self._stage_slices, self._stage_dual_slices):
+                loc = np.asarray(fn(*xv[idx], *yv[dsl]), dtype=np.float64).reshape(len(idx), len(idx))
+                for (i, j) in pattern:
+                    if self.hessian_mode == "sum":
+                        H[idx[i], idx[j]] += loc[i, j]
+                    else:
+                        H[idx[i], idx[j]] = loc[i, j]       # last writer wins
+            _put(out, "equality_dual_jacobian_variables_variables", H)
+
+
+def pendulum(T=11, h=0.05, action_guess=None, hessian_mode="last_writer"):
     """README.md:123-189 = test/examples/pendulum.jl:3-59 written directly in standard form (BASELINE config C2).
     z = [X1;U1;...;X10;U10;X11]; equality = [d_1..d_10; X1 - 0; X11 - (pi,0)].
-    The Lagrangian Hessian here is the exact sum (the reference's trajectory layer overwrites overlapping
-    entries; iterates therefore differ, the converged answer does not)."""
+    hessian_mode = "last_writer" (default) reproduces the reference's scatter of the dynamics Hessians (quirk B-11, see
+    TrajectoryProblem): at the shared (X_t+1, X_t+1) entries only the later stage's contribution survives; "sum" is the exact
+    Lagrangian Hessian.  The converged answer is the same, the iterate path is not."""
     import sympy as sp
     nxs, nu = 2, 1
     nz = nxs * T + nu * (T - 1)
@@ -374,6 +406,11 @@ def pendulum(T=11, h=0.05, action_guess=None):
     def f(mid, u):
         return [mid[1], u[0] / (m_ * l_ * l_) - g_ * sp.sin(mid[0]) / l_ - c_ * mid[1] / (m_ * l_ * l_)]
 
+    def dyn(X, U, Y):
+        mid = [0.5 * (X[0] + Y[0]), 0.5 * (X[1] + Y[1])]
+        fm = f(mid, U)
+        return [Y[0] - (X[0] + h * fm[0]), Y[1] - (X[1] + h * fm[1])]
+
     def objective(z):
         J = 0
         for t in range(T - 1):
@@ -385,10 +422,7 @@ def pendulum(T=11, h=0.05, action_guess=None):
     def equality(z):
         e = []
         for t in range(T - 1):
-            X, U, Y = xs(z, t), us(z, t), xs(z, t + 1)
-            mid = [0.5 * (X[0] + Y[0]), 0.5 * (X[1] + Y[1])]
-            fm = f(mid, U)
-            e += [Y[0] - (X[0] + h * fm[0]), Y[1] - (X[1] + h * fm[1])]
+            e += dyn(xs(z, t), us(z, t), xs(z, t + 1))
         X1, XT = xs(z, 0), xs(z, T - 1)
         e += [X1[0] - 0.0, X1[1] - 0.0, XT[0] - sp.pi, XT[1] - 0.0]
         return e
@@ -399,8 +433,19 @@ def pendulum(T=11, h=0.05, action_guess=None):
     if action_guess is not None:
         for t in range(T - 1):
             x0[t * (nxs + nu) + nxs] = action_guess[t]
-    prob = SymbolicProblem(nz, objective, equality, None, x0=x0, name="pendulum")
+    prob = TrajectoryProblem(nz, objective, equality, None, x0=x0, name="pendulum")
     prob.T = T
+    # per-stage Hessian of lam'd(y, x, u) wrt [x; u; y] (dynamics.jl:81-101) and its structural non-zeros
+    lx, lu, ly, ll = sp.symbols("a0:2"), sp.symbols("b0:1"), sp.symbols("c0:2"), sp.symbols("l0:2")
+    d = dyn(list(lx), list(lu), list(ly))
+    dl = sum(li * di for li, di in zip(ll, d))
+    loc = list(lx) + list(lu) + list(ly)
+    Hs = sp.hessian(dl, loc)
+    pattern = [(i, j) for j in range(len(loc)) for i in range(len(loc)) if Hs[i, j] != 0]     # column-major, like findnz
+    fn = sp.lambdify(loc + list(ll), Hs, "numpy")
+    stage_idx = [list(range(t * (nxs + nu), t * (nxs + nu) + nxs + nu + nxs)) for t in range(T - 1)]
+    stage_dual = [slice(nxs * t, nxs * t + nxs) for t in range(T - 1)]
+    prob.set_stages((fn, pattern), stage_idx, stage_dual, hessian_mode)
     return prob
 
 

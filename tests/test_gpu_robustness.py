@@ -1,0 +1,162 @@
+"""GPU tests (-m gpu) of the option / lifetime edge cases around the hot path:
+  * cone search with options.scaling_line_search != 0.5 and max_cone_line_search > 25 (solve.jl:204-221),
+  * uploads that break an analysed stage-banded structure (structure.hip) send the handle back to the dense treatment,
+  * the filter is re-sized from options.max_filter (filter.jl:7-13) and never written past its end,
+  * a group survives its members being destroyed first (finaliser order is unspecified in Julia and Python).
+"""
+import numpy as np
+import pytest
+
+import problems as pr
+from helpers import interior_point, load_pkg, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(1.0, np.abs(np.asarray(b)).max())
+
+
+@pytest.mark.parametrize("sls", [0.5, 0.7, 0.3, 0.93])
+def test_cone_search_uses_scaling_line_search(oracle_mod, sls):
+    """the accepted step sizes are exactly the ones whose feasibility was tested: alpha <- sls * alpha from 1 (solve.jl:204-221)"""
+    prob = pr.random_qp(20, 4, 14, seed=5, nonnegative_indices=[1, 2], second_order_indices=[list(range(3, 9)), list(range(9, 15))])
+    pt, lam = interior_point(prob, seed=3)
+    o, g = make_pair(oracle_mod, prob, pt, lam)
+    g.set_option("scaling_line_search", sls)
+    g.set_option("max_cone_line_search", 200)
+    o.cone(product=True, jacobian=True, target=True); g.cone(product=True, target=True)
+    o.residual(); g.residual()
+    assert o.search_direction() == 0 and g.search_direction() == 0
+    # make the step long so that several shrinkings are needed
+    step = 40.0 * o.buf("step").copy()
+    g.set("step", step)
+    a_s, a_t = g.cone_search()
+    s, t = o.point()["s"], o.point()["t"]
+    Ds, Dt = step[o.index("cone_slack") - 1], step[o.index("cone_slack_dual") - 1]
+    for vec, dv, a_g in ((s, Ds, a_s), (t, Dt, a_t)):
+        a, it = 1.0, 0
+        while o.cone_violation(vec - a * dv, vec, 0.99):
+            a = sls * a
+            it += 1
+        assert it >= 1
+        assert a == a_g
+    # candidate slack written with those step sizes is inside the cone
+    cand = g.candidate
+    assert not o.cone_violation(cand.cone_slack, s, 0.99)
+    assert not o.cone_violation(cand.cone_slack_dual, t, 0.99)
+
+
+def test_cone_search_failure_and_option_limits(oracle_mod):
+    prob = pr.random_qp(10, 5, 5, seed=3)
+    pt, lam = interior_point(prob, seed=1)
+    o, g = make_pair(oracle_mod, prob, pt, lam)
+    pkg = load_pkg()
+    with pytest.raises(pkg.CalipsoHipError):
+        g.set_option("max_cone_line_search", 832)
+    with pytest.raises(pkg.CalipsoHipError):
+        g.set_option("scaling_line_search", 1.0)
+    g.set_option("max_cone_line_search", 3)
+    g.set_option("scaling_line_search", 0.9)
+    g.cone(product=True, target=True); g.residual()
+    assert g.search_direction() == 0
+    step = g.data("step").all * 1.0e6
+    g.set("step", step)
+    with pytest.raises(pkg.CalipsoHipError, match="cone search failure"):
+        g.cone_search()
+
+
+def _staged(pkg, analyze=True):
+    prob, pt, lam = pr.staged_conic_qp(pkg.splitmix_uniform, 5, 12, 40, 30, 4, 2, 3)
+    s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices)
+    s.set("solution", np.concatenate([pt[k] for k in "xrsyzt"]))
+    s.set("dual", lam)
+    for name, v in (("central_path", 0.17), ("penalty", 52.0), ("fraction_to_boundary", 0.99)):
+        s.set(name, [v])
+    s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
+    if analyze:
+        s.analyze_structure()
+    return prob, s
+
+
+def test_upload_outside_the_analysed_structure_falls_back_to_dense(oracle_mod):
+    """an entry that was zero when the structure was analysed and is non-zero later must not be dropped from the factorisation"""
+    pkg = load_pkg()
+    prob, s = _staged(pkg, analyze=True)
+    _, ref = _staged(pkg, analyze=False)
+    nx, ne, nc = prob.nx, prob.ne, prob.nc
+    # a Hessian with a far off-band entry (both triangles) and an equality Jacobian row that couples the first and last stage
+    H = (prob.P + prob.P.T) * 0.5
+    H = 2 * 0.5 * H.copy()
+    H[0, nx - 1] += 0.37; H[nx - 1, 0] += 0.37
+    A = prob.A.copy()
+    A[0, nx - 1] = 0.5
+    colmajor = lambda M: np.ascontiguousarray(M.T).reshape(-1)
+    for h in (s, ref):
+        h.set("lagrangian_hessian", colmajor(H))
+        h.set("equality_jacobian_variables", colmajor(A))
+    fl = pkg.FLAGS
+    for h in (s, ref):
+        h.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"] | fl["objective_gradient_variables"] |
+                      fl["equality_dual_jacobian_variables"] | fl["cone_dual_jacobian_variables"], 0)
+        h.cone(product=True, target=True, barrier=True, barrier_gradient=True)
+        h.residual()
+        assert h.search_direction() in (0, 2)
+    a, b = s.data("step").all, ref.data("step").all
+    assert np.array_equal(a, b)          # same (dense) launches on both handles
+    # and the step solves the system that contains the new entries
+    R = ref.data("residual").all
+    Hv = ref.jacobian_variables_mul(b)
+    assert np.abs(R - Hv).max() <= 1e-8 * max(1.0, np.abs(R).max())
+    # an upload that respects the structure keeps it
+    _, s2 = _staged(pkg, analyze=True)
+    info0 = s2.analyze_structure()
+    s2.set("lagrangian_hessian", colmajor(2 * 0.5 * (prob.P + prob.P.T) * 0.5))
+    s2.set("equality_jacobian_variables", colmajor(prob.A))
+    assert s2.analyze_structure() == info0
+
+
+def test_filter_follows_max_filter(oracle_mod):
+    """max_filter set after creation re-sizes the filter; more pairs than slots grow it instead of writing past the end"""
+    pkg = load_pkg()
+    prob = pr.wachter()
+    g = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, options=dict(max_filter=2))
+    pkg.initialize_b(g, prob.x0)
+    assert pkg.solve_b(g)
+    assert np.abs(g.solution.variables - np.array([1.0, 0.0, 0.5])).max() <= 1e-3
+    g2 = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc)
+    g2.set_option("max_filter", 5000)
+    pkg.initialize_b(g2, prob.x0)
+    assert pkg.solve_b(g2)
+    assert np.array_equal(g2.solution.all, g.solution.all)
+
+
+def test_group_outlives_its_members():
+    pkg = load_pkg()
+    prob = pr.random_qp(40, 10, 12, seed=2)
+    sol = []
+    for k in range(3):
+        pt, lam = interior_point(prob, seed=k)
+        s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc)
+        s.set("solution", np.concatenate([pt[k2] for k2 in "xrsyzt"])); s.set("dual", lam)
+        s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
+        sol.append(s)
+    grp = pkg.Group(sol)
+    out = grp.newton_step(advance=False)
+    assert all(i["status"] >= 0 for i in out)
+    # destroy the base member first, then the others, then use / destroy the group
+    for s in sol:
+        s._L.calipso_hip_destroy(s._h)
+        import ctypes as C
+        s._h = C.c_void_p()
+    with pytest.raises(pkg.CalipsoHipError):
+        grp.newton_step(advance=False)
+    grp.close()
+    # a handle can be grouped again after its group is gone
+    s1 = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc); s2 = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc)
+    g1 = pkg.Group([s1, s2])
+    with pytest.raises(pkg.CalipsoHipError):
+        pkg.Group([s1, s2])
+    g1.close()
+    g2 = pkg.Group([s1, s2])
+    g2.close()
