@@ -12,7 +12,8 @@ import numpy as np
 
 from ._lib import CALLBACK_FN, EVAL_FN, CalipsoHipError, lib
 
-__all__ = ["Solver", "Group", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform"]
+__all__ = ["Solver", "Group", "LDLSolver", "Comm", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform",
+           "mfma_f64_peak"]
 
 # evaluate! flags (include/calipso_hip.h)
 FLAGS = dict(
@@ -442,6 +443,127 @@ class Group:
             self.close()
         except Exception:
             pass
+
+
+class LDLSolver:
+    """LDLSolver / ldl_solver(A) of src/solver/linear_solver.jl:1-60 on the device: factorize!(s, A), compute_inertia!(s),
+    linear_solve!(s, x, A, b).  A is a scipy.sparse CSC matrix (or anything scipy can convert); only triu(A) is read."""
+
+    def __init__(self, n, device=0):
+        self._L = lib()
+        self.n = int(n)
+        h = C.c_void_p()
+        rc = self._L.calipso_hip_ldl_create(self.n, device, C.byref(h))
+        if rc != 0:
+            raise CalipsoHipError("calipso_hip_ldl_create failed (%d): %s" % (rc, self._L.calipso_hip_last_error(h if h.value else None).decode()))
+        self._h = h
+        self.inertia = (0, 0, 0)          # Inertia(positive, negative, zero)  inertia.jl:1-5
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise CalipsoHipError("%s: %s (%d): %s" % (what, STATUS_TEXT.get(rc, "error"), rc, self._L.calipso_hip_last_error(self._h).decode()))
+        return rc
+
+    def factorize(self, A):
+        """factorize!(s, A; update) + compute_inertia!(s); returns the warning status (1 = zero pivot met)"""
+        import scipy.sparse as sp
+        A = sp.csc_matrix(A)
+        A.sort_indices()
+        colptr = np.ascontiguousarray(A.indptr, dtype=np.int64) + 1      # Julia's 1-based SparseMatrixCSC
+        rowval = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
+        nzval = np.ascontiguousarray(A.data, dtype=np.float64)
+        out = np.zeros(3, dtype=np.int64)
+        rc = self._check(self._L.calipso_hip_ldl_factorize_csc(self._h, self.n, _pi(colptr), _pi(rowval), _pd(nzval), _pi(out)), "factorize!")
+        self.inertia = tuple(int(v) for v in out)
+        return rc
+
+    def compute_inertia(self):
+        out = np.zeros(3, dtype=np.int64)
+        self._check(self._L.calipso_hip_ldl_inertia(self._h, _pi(out)), "compute_inertia!")
+        self.inertia = tuple(int(v) for v in out)
+        return self.inertia
+
+    def linear_solve(self, b, A=None, fact=False):
+        """linear_solve!(s, x, A, b; fact): b is a vector (n) or a matrix (n x nrhs); returns x"""
+        if fact:
+            self.factorize(A)
+        b = np.asarray(b, dtype=np.float64)
+        nrhs = 1 if b.ndim == 1 else b.shape[1]
+        bf = np.ascontiguousarray(b.reshape(self.n, nrhs).T).reshape(-1)          # column-major
+        x = np.zeros_like(bf)
+        self._check(self._L.calipso_hip_ldl_solve(self._h, self.n, nrhs, _pd(bf), _pd(x)), "linear_solve!")
+        return x if b.ndim == 1 else x.reshape(nrhs, self.n).T
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.calipso_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator of the batched path (include/calipso_hip.h, "multi-GPU exchange"): one process per GPU; the only
+    collectives are the post-round all-gather of per-problem status rows and the all-reduce of counters."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = lib().calipso_hip_comm_unique_id(buf)
+        if rc != 0:
+            raise CalipsoHipError("comm_unique_id failed (%d): %s" % (rc, lib().calipso_hip_comm_last_error(None).decode()))
+        return bytes(buf)
+
+    def __init__(self, rank, nranks, unique_id, device=0):
+        self._L = lib()
+        self.rank, self.nranks = int(rank), int(nranks)
+        buf = (C.c_uint8 * 128)(*unique_id)
+        h = C.c_void_p()
+        rc = self._L.calipso_hip_comm_init(self.rank, self.nranks, buf, device, C.byref(h))
+        if rc != 0:
+            raise CalipsoHipError("comm_init failed (%d): %s" % (rc, self._L.calipso_hip_comm_last_error(h if h.value else None).decode()))
+        self._c = h
+
+    def gather_status(self, rows, capacity):
+        rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+        out = np.zeros((int(capacity), 4), dtype=np.int32)
+        counts = np.zeros(self.nranks, dtype=np.int64)
+        p32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        n = self._L.calipso_hip_comm_gather_status(self._c, p32(rows), rows.shape[0], p32(out), out.shape[0], _pi(counts))
+        if n < 0:
+            raise CalipsoHipError("comm_gather_status failed (%d): %s" % (n, self._L.calipso_hip_comm_last_error(self._c).decode()))
+        return out[:n], counts
+
+    def allreduce_sum(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        rc = self._L.calipso_hip_comm_allreduce_sum(self._c, _pd(v), v.size)
+        if rc < 0:
+            raise CalipsoHipError("comm_allreduce_sum failed (%d): %s" % (rc, self._L.calipso_hip_comm_last_error(self._c).decode()))
+        return v
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self._L.calipso_hip_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mfma_f64_peak(device=0):
+    """measured fp64 matrix-core ceiling of the device in TFLOP/s (calipso_hip_mfma_f64_peak)"""
+    t = C.c_double(0.0)
+    rc = lib().calipso_hip_mfma_f64_peak(device, C.byref(t))
+    if rc != 0:
+        raise CalipsoHipError("mfma_f64_peak failed (%d)" % rc)
+    return float(t.value)
 
 
 def initialize_b(solver, guess):

@@ -62,6 +62,17 @@ SYMBOLS = {
     "calipso_hip_group_newton_step": (_i32, [_vp, _i32, _pd, C.POINTER(_i32)]),
     "calipso_hip_group_solve": (_i32, [_vp, C.POINTER(_i32)]),
     "calipso_hip_group_set_evaluators": (_i32, [_vp, C.POINTER(EVAL_FN), C.POINTER(_vp)]),
+    "calipso_hip_ldl_create": (_i32, [_i64, _i32, C.POINTER(_vp)]),
+    "calipso_hip_ldl_factorize_csc": (_i32, [_vp, _i64, _pi64, _pi64, _pd, _pi64]),
+    "calipso_hip_ldl_inertia": (_i32, [_vp, _pi64]),
+    "calipso_hip_ldl_solve": (_i32, [_vp, _i64, _i64, _pd, _pd]),
+    "calipso_hip_comm_unique_id": (_i32, [C.POINTER(C.c_uint8)]),
+    "calipso_hip_comm_init": (_i32, [_i32, _i32, C.POINTER(C.c_uint8), _i32, C.POINTER(_vp)]),
+    "calipso_hip_comm_destroy": (_i32, [_vp]),
+    "calipso_hip_comm_last_error": (C.c_char_p, [_vp]),
+    "calipso_hip_comm_gather_status": (_i64, [_vp, _pi32, _i64, _pi32, _i64, _pi64]),
+    "calipso_hip_comm_allreduce_sum": (_i32, [_vp, _pd, _i64]),
+    "calipso_hip_mfma_f64_peak": (_i32, [_i32, _pd]),
     "calipso_hip_synchronize": (_i32, [_vp]),
     "calipso_hip_splitmix_uniform": (_i32, [_u64, _u64, _dbl, _dbl, _i64, _pd]),
 }

@@ -174,6 +174,7 @@ struct calipso_hip_solver {
     std::vector<double> hparams;
     double* multi_rhs = nullptr;  // workspace of the multi-right-hand-side solve of differentiate! (allocated on demand)
     double* dsym_multi = nullptr; // n * np
+    void* ldl_aux = nullptr;      // ldlsolver.hip: staging of the caller's CSC matrix (handles made by calipso_hip_ldl_create)
     double* Hdense = nullptr; int* lu_ipiv = nullptr;   // fallback.hip: N x N unreduced matrix and pivots (allocated on first use)
     hipEvent_t ev[16];
     hipGraphExec_t graph_ldl = nullptr, graph_trsv = nullptr;   // captured once per handle (fixed launch sequences)
@@ -246,6 +247,8 @@ int nonsymmetric_solve(calipso_hip_solver* s, const double* res, double* step); 
 void nonsymmetric_release(calipso_hip_solver* s);
 // group.hip
 void group_member_destroyed(struct calipso_hip_group* g, calipso_hip_solver* s);   // called by calipso_hip_destroy on a member of a live group
+// ldlsolver.hip
+void ldlsolver_release(calipso_hip_solver* s);
 // structure.hip
 int structure_validate(calipso_hip_solver* s, int which);      // which: 0 Lxx, 1 gx, 2 hx; clears the structure when the block breaks it
 // qp.hip

@@ -1,0 +1,148 @@
+// ldlsolver.hip — the LinearSolver seam of the reference (src/solver/linear_solver.jl:1-60) as a stand-alone device solver:
+//   ldl_solver(A) / factorize!(s, A; update) / compute_inertia!(s) / linear_solve!(s, x, A, b; fact, update)
+// for ANY sparse symmetric quasi-definite matrix the caller assembled itself (the reference hands its condensed K,
+// `solver.data.jacobian_variables_symmetric`, to these functions from search_direction.jl:34, iterative_refinement.jl:25,
+// differentiate.jl:19,45 and inertia.jl:23).  With this seam the reference's own unmodified search_direction! /
+// iterative_refinement! / differentiate! run on top of the GPU factorisation: nothing but A's CSC arrays and the right-hand
+// sides cross the boundary.
+//
+// As the reference's QDLDL (qdldl.jl:134-188): only triu(A) is read; no pivoting; D = diagonal of the LDL^T; the inertia is
+// (#D > 0, #D <= 0, #D == 0); an exact zero pivot makes `positive` = -1.  The elimination order is the natural one (the x-block
+// first): for a quasi-definite matrix every symmetric permutation has an LDL^T, and the dense fill does not depend on the order.
+// The matrix is factored densely by the blocked LDL^T of ldl.hip (fp64 matrix cores) — a handle created for nx = n, ne = nc = 0
+// carries exactly the buffers that needs (S, Dx, panel scratch, the 512-wide inverse blocks of the triangular solves).
+#include <algorithm>
+#include <vector>
+
+#include "internal.hpp"
+#include "device_utils.hpp"
+#include "host_logic.hpp"
+
+using namespace calipso;
+
+// one workgroup per column c (1-based CSC as Julia's SparseMatrixCSC): entries (r, c) with r <= c go to the lower triangle of the
+// column-major S at (c, r); entries below the diagonal are ignored (triu!, linear_solver.jl:23)
+__global__ __launch_bounds__(256) void k_scatter_csc_upper(int n, int NP, const long long* __restrict__ colptr, const long long* __restrict__ rowval,
+                                                           const double* __restrict__ nzval, double* __restrict__ S) {
+    const int c = blockIdx.x;
+    const long long p0 = colptr[c] - 1, p1 = colptr[c + 1] - 1;
+    for (long long p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const long long r = rowval[p] - 1;
+        if (r <= c && r >= 0 && r < n) S[(size_t)c + (size_t)r * NP] = nzval[p];
+    }
+}
+// identity in the padding [n, NP)
+__global__ void k_pad_diag(int n, int NP, double* __restrict__ S) {
+    const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NP) S[(size_t)i + (size_t)i * NP] = 1.0;
+}
+__global__ void k_pad_vec(const double* __restrict__ b, int n, int NP, double* __restrict__ x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NP) x[i] = i < n ? b[i] : 0.0;
+}
+
+struct LdlAux {   // device staging of the caller's CSC arrays (grown on demand), kept in the handle's side table
+    long long* colptr = nullptr; long long* rowval = nullptr; double* nzval = nullptr; double* rhs = nullptr;
+    size_t cap_nz = 0, cap_rhs = 0;
+    int64_t inertia[3] = {0, 0, 0};
+    bool factored = false;
+};
+static LdlAux* aux_of(calipso_hip_solver* s, bool create) {
+    if (!s->ldl_aux && create) s->ldl_aux = new LdlAux();
+    return static_cast<LdlAux*>(s->ldl_aux);
+}
+
+namespace calipso {
+void ldlsolver_release(calipso_hip_solver* s) {
+    LdlAux* a = aux_of(s, false);
+    if (!a) return;
+    if (a->colptr) (void)hipFree(a->colptr);
+    if (a->rowval) (void)hipFree(a->rowval);
+    if (a->nzval) (void)hipFree(a->nzval);
+    if (a->rhs) (void)hipFree(a->rhs);
+    delete a;
+    s->ldl_aux = nullptr;
+}
+}  // namespace calipso
+
+extern "C" {
+
+// ldl_solver(A)  linear_solver.jl:46-50 — a solver for n x n matrices on `device`
+int32_t calipso_hip_ldl_create(int64_t n, int32_t device, calipso_hip_solver** out) {
+    const int64_t none = 0;
+    const int64_t ptr0[1] = {0};
+    return calipso_hip_create(n, 0, 0, 0, 0, &none, 0, ptr0, &none, device, out);
+}
+
+// factorize!(s, A; update) + compute_inertia!(s)  linear_solver.jl:19-44
+int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver* s, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                                      int64_t inertia[3]) {
+    if (!s || !colptr || (!rowval && colptr[n] > 1) || (!nzval && colptr[n] > 1)) return CALIPSO_ERR_ARGUMENT;
+    const Dims& d = s->d;
+    if (n != d.nx || d.ne != 0 || d.nc != 0) { s->err = "calipso_hip_ldl_factorize_csc: the handle was not created by calipso_hip_ldl_create for this n"; return CALIPSO_ERR_ARGUMENT; }
+    if (colptr[0] != 1) { s->err = "colptr must be 1-based (Julia SparseMatrixCSC)"; return CALIPSO_ERR_ARGUMENT; }
+    CK(hipSetDevice(s->device));
+    LdlAux& a = *aux_of(s, true);
+    const size_t nnz = (size_t)(colptr[n] - 1);
+    if (nnz > a.cap_nz || !a.colptr) {
+        if (a.rowval) (void)hipFree(a.rowval);
+        if (a.nzval) (void)hipFree(a.nzval);
+        if (!a.colptr) CK(hipMalloc((void**)&a.colptr, sizeof(long long) * (size_t)(n + 1)));
+        a.cap_nz = std::max<size_t>(nnz, 1);
+        CK(hipMalloc((void**)&a.rowval, sizeof(long long) * a.cap_nz));
+        CK(hipMalloc((void**)&a.nzval, sizeof(double) * a.cap_nz));
+    }
+    CK(hipMemcpyAsync(a.colptr, colptr, sizeof(long long) * (size_t)(n + 1), hipMemcpyHostToDevice, s->stream));
+    if (nnz) {
+        CK(hipMemcpyAsync(a.rowval, rowval, sizeof(long long) * nnz, hipMemcpyHostToDevice, s->stream));
+        CK(hipMemcpyAsync(a.nzval, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice, s->stream));
+    }
+    CK(hipMemsetAsync(s->S, 0, sizeof(double) * (size_t)d.NP * d.NP, s->stream));
+    hipLaunchKernelGGL(k_scatter_csc_upper, dim3((unsigned)n), dim3(256), 0, s->stream, (int)n, d.NP, a.colptr, a.rowval, a.nzval, s->S);
+    if (d.NP > n) hipLaunchKernelGGL(k_pad_diag, dim3((d.NP - (int)n + 255) / 256), dim3(256), 0, s->stream, (int)n, d.NP, s->S);
+    fill_i(s, s->icount, 6, 0);
+    launch_ldl(s);
+    CK(hipMemcpyAsync(s->hicount, s->icount, sizeof(int) * 6, hipMemcpyDeviceToHost, s->stream));
+    SYNC();
+    s->stats.factorizations += 1;
+    a.inertia[0] = s->hicount[3]; a.inertia[1] = s->hicount[4]; a.inertia[2] = s->hicount[5];
+    a.factored = true;
+    int rc = CALIPSO_OK;
+    if (a.inertia[2] > 0) { a.inertia[0] = -1; rc = CALIPSO_WARN_ZERO_PIVOT; }     // qdldl.jl:456,579
+    if (inertia) { inertia[0] = a.inertia[0]; inertia[1] = a.inertia[1]; inertia[2] = a.inertia[2]; }
+    return rc;
+}
+
+// compute_inertia!(s)  linear_solver.jl:33-44 (of the last factorisation)
+int32_t calipso_hip_ldl_inertia(calipso_hip_solver* s, int64_t inertia[3]) {
+    if (!s || !inertia) return CALIPSO_ERR_ARGUMENT;
+    const LdlAux* a = aux_of(s, false);
+    if (!a || !a->factored) { s->err = "no factorisation yet"; return CALIPSO_ERR_ARGUMENT; }
+    for (int k = 0; k < 3; ++k) inertia[k] = a->inertia[k];
+    return CALIPSO_OK;
+}
+
+// linear_solve!(s, x, A, b; fact = false)  linear_solver.jl:52-60 / solve!(F, x) qdldl.jl:330-351 for nrhs right-hand sides
+// (column-major n x nrhs; the Matrix method of linear_solver.jl:82-99 loops over the columns the same way)
+int32_t calipso_hip_ldl_solve(calipso_hip_solver* s, int64_t n, int64_t nrhs, const double* b, double* x) {
+    if (!s || !b || !x || nrhs < 0) return CALIPSO_ERR_ARGUMENT;
+    const Dims& d = s->d;
+    LdlAux* ap = aux_of(s, false);
+    if (n != d.nx || !ap || !ap->factored) { s->err = "calipso_hip_ldl_solve: factorize first"; return CALIPSO_ERR_ARGUMENT; }
+    LdlAux& a = *ap;
+    CK(hipSetDevice(s->device));
+    const size_t need = (size_t)n * (size_t)std::max<int64_t>(nrhs, 1);
+    if (need > a.cap_rhs) { if (a.rhs) (void)hipFree(a.rhs); a.cap_rhs = need; CK(hipMalloc((void**)&a.rhs, sizeof(double) * need)); }
+    if (nrhs == 0) return CALIPSO_OK;
+    CK(hipMemcpyAsync(a.rhs, b, sizeof(double) * (size_t)n * nrhs, hipMemcpyHostToDevice, s->stream));
+    for (int64_t j = 0; j < nrhs; ++j) {
+        hipLaunchKernelGGL(k_pad_vec, dim3((d.NP + 255) / 256), dim3(256), 0, s->stream, a.rhs + (size_t)j * n, (int)n, d.NP, s->xbuf);
+        launch_trsv(s, s->xbuf);
+        CK(hipMemcpyAsync(a.rhs + (size_t)j * n, s->xbuf, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s->stream));
+    }
+    CK(hipMemcpyAsync(x, a.rhs, sizeof(double) * (size_t)n * nrhs, hipMemcpyDeviceToHost, s->stream));
+    SYNC();
+    return CALIPSO_OK;
+}
+
+}  // extern "C"

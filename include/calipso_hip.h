@@ -157,7 +157,8 @@ int32_t calipso_hip_search_direction(calipso_hip_solver*);
  * dense LU of the unreduced N x N matrix (assembled on the device on demand).  "step" <- H^-1 "residual".  Exception path. */
 int32_t calipso_hip_search_direction_nonsymmetric(calipso_hip_solver*);
 /* cone fraction-to-boundary search  solve.jl:190-221 with cone_violation (cones/cone.jl:62-68): writes candidate s, t
- * and returns the two step sizes (2^-k, k = number of halvings).  CALIPSO_ERR_CONE_SEARCH after 25 halvings. */
+ * and returns the two step sizes (opt.scaling_line_search^k, k = number of shrinkings).  CALIPSO_ERR_CONE_SEARCH once k would exceed
+ * opt.max_cone_line_search (<= 831). */
 int32_t calipso_hip_cone_search(calipso_hip_solver*, double* step_size, double* step_size_cone_slack_dual);
 /* cone_violation(xhat, x, tau, ...)  cones/cone.jl:62-68 on host vectors of length nc; *violated = 0/1 */
 int32_t calipso_hip_cone_violation(calipso_hip_solver*, const double* xhat, const double* x, double tau, int32_t* violated);
@@ -228,6 +229,42 @@ int32_t calipso_hip_group_solve(calipso_hip_group*, int32_t* result);
  * out[2], out[3] = average number of equality / cone rows a 16-column group visits.  out may be NULL. */
 int32_t calipso_hip_analyze_structure(calipso_hip_solver*, int64_t out[4]);
 int32_t calipso_hip_clear_structure(calipso_hip_solver*);
+
+/* ---- LinearSolver seam (src/solver/linear_solver.jl:1-60) ----------------------------------------------------------------------
+ * A stand-alone device LDL^T for ANY sparse symmetric quasi-definite matrix the caller assembled itself, so that the reference's own
+ * search_direction! / iterative_refinement! / differentiate! / inertia_correction! (which hand `data.jacobian_variables_symmetric`
+ * to `solver.linear_solver`) run unmodified on the GPU factorisation: `HIPLDLSolver <: LinearSolver` in julia/CalipsoHIP.jl.
+ *   calipso_hip_ldl_create         = ldl_solver(A)                               linear_solver.jl:46-50  (destroy: calipso_hip_destroy)
+ *   calipso_hip_ldl_factorize_csc  = factorize!(s, A; update) + compute_inertia! linear_solver.jl:19-44, qdldl.jl:134-188,269-317
+ *   calipso_hip_ldl_inertia        = compute_inertia!(s) of the last factorisation
+ *   calipso_hip_ldl_solve          = linear_solve!(s, x, A, b; fact=false)       linear_solver.jl:52-60,82-99, qdldl.jl:330-351
+ * A is Julia's SparseMatrixCSC: colptr[n+1], rowval[nnz] 1-based Int64, nzval[nnz]; only triu(A) is read (linear_solver.jl:23);
+ * no pivoting; inertia = (#D>0, #D<=0, #D==0), positive = -1 and CALIPSO_WARN_ZERO_PIVOT on an exact zero pivot (qdldl.jl:456,579).
+ * b, x: column-major n x nrhs host arrays (may alias). */
+int32_t calipso_hip_ldl_create(int64_t n, int32_t device, calipso_hip_solver** out);
+int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver*, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
+                                      int64_t inertia[3]);
+int32_t calipso_hip_ldl_inertia(calipso_hip_solver*, int64_t inertia[3]);
+int32_t calipso_hip_ldl_solve(calipso_hip_solver*, int64_t n, int64_t nrhs, const double* b, double* x);
+
+/* ---- multi-GPU exchange of the batched path: RCCL over xGMI, one process per GPU ---------------------------------
+ * Problem instances are sharded block-contiguously over ranks and never interact (the reference's `Solver`s are independent); the
+ * only exchange is after a batch round: all-gather of per-problem status rows, all-reduce of counters.  RCCL is dlopen'ed on first
+ * use.  calipso_hip_comm_unique_id = ncclGetUniqueId (one rank), calipso_hip_comm_init = ncclCommInitRank (all ranks, same id). */
+typedef struct calipso_hip_comm calipso_hip_comm;
+int32_t calipso_hip_comm_unique_id(uint8_t id[128]);
+int32_t calipso_hip_comm_init(int32_t rank, int32_t nranks, const uint8_t id[128], int32_t device, calipso_hip_comm** out);
+int32_t calipso_hip_comm_destroy(calipso_hip_comm*);
+const char* calipso_hip_comm_last_error(calipso_hip_comm*);
+/* rows: n_rows x 4 int32 of this rank (row counts may differ between ranks); all_rows: capacity cap_rows rows, filled in global
+ * problem-id order; counts_out[nranks] (may be NULL) = rows per rank.  Returns the total row count or a negative status. */
+int64_t calipso_hip_comm_gather_status(calipso_hip_comm*, const int32_t* rows, int64_t n_rows, int32_t* all_rows, int64_t cap_rows,
+                                       int64_t* counts_out);
+int32_t calipso_hip_comm_allreduce_sum(calipso_hip_comm*, double* values, int64_t count);
+
+/* measured fp64 matrix-core ceiling (TFLOP/s) of `device`: back-to-back independent v_mfma_f64_16x16x4_f64, 8 wavefronts per SIMD
+ * (a few milliseconds).  bench.py reports it as roofline.peak_measured next to the datasheet peak. */
+int32_t calipso_hip_mfma_f64_peak(int32_t device, double* tflops);
 
 /* timing of the last calipso_hip_newton_step / factorisation, in milliseconds, from HIP events on the handle's stream:
  * [0] evaluate + cone + residual + reductions   [1] cone pivots + Omega*hx   [2] search_direction! total (factor + solves + refinement)
