@@ -100,15 +100,26 @@ int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver* s, int64_t n, const in
     CK(hipMemsetAsync(s->S, 0, sizeof(double) * (size_t)d.NP * d.NP, s->stream));
     hipLaunchKernelGGL(k_scatter_csc_upper, dim3((unsigned)n), dim3(256), 0, s->stream, (int)n, d.NP, a.colptr, a.rowval, a.nzval, s->S);
     if (d.NP > n) hipLaunchKernelGGL(k_pad_diag, dim3((d.NP - (int)n + 255) / 256), dim3(256), 0, s->stream, (int)n, d.NP, s->S);
-    fill_i(s, s->icount, 6, 0);
+    fill_i(s, s->icount, 6, 0);       // (the device-side sign counters of ldl.hip are not used here)
     launch_ldl(s);
-    CK(hipMemcpyAsync(s->hicount, s->icount, sizeof(int) * 6, hipMemcpyDeviceToHost, s->stream));
+    // compute_inertia! on the host from D, exactly as linear_solver.jl:33-44 sees it: QDLDL_factor! stops at the first exact zero
+    // pivot (qdldl.jl:456,579: positive_inertia = -1) and leaves the rest of D at the zeros it was reset to (qdldl.jl:444)
+    s->hstage.resize((size_t)n);
+    CK(hipMemcpyAsync(s->hstage.data(), s->Dx, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
     SYNC();
     s->stats.factorizations += 1;
-    a.inertia[0] = s->hicount[3]; a.inertia[1] = s->hicount[4]; a.inertia[2] = s->hicount[5];
-    a.factored = true;
     int rc = CALIPSO_OK;
-    if (a.inertia[2] > 0) { a.inertia[0] = -1; rc = CALIPSO_WARN_ZERO_PIVOT; }     // qdldl.jl:456,579
+    {
+        int64_t pos = 0, nonpos = 0, zero = 0, k = 0;
+        for (; k < n; ++k) {
+            const double dk = s->hstage[(size_t)k];
+            if (dk == 0.0) break;
+            pos += dk > 0.0; nonpos += dk <= 0.0;
+        }
+        if (k < n) { zero = n - k; nonpos += n - k; pos = -1; rc = CALIPSO_WARN_ZERO_PIVOT; }
+        a.inertia[0] = pos; a.inertia[1] = nonpos; a.inertia[2] = zero;
+    }
+    a.factored = true;
     if (inertia) { inertia[0] = a.inertia[0]; inertia[1] = a.inertia[1]; inertia[2] = a.inertia[2]; }
     return rc;
 }

@@ -6,7 +6,8 @@
 #     initialize!(hs, x0)            src/solver/initialize.jl:9-13
 #     solve!(hs)::Bool               src/solver/solve.jl:8-377   — the whole loop runs in the library; Julia only evaluates the
 #                                                                  user functions (evaluate!) when the library calls back
-#     HIPLDLSolver <: LinearSolver   src/solver/linear_solver.jl:1-60 seam: factorize!, compute_inertia!, linear_solve!
+#     HIPLDLSolver <: LinearSolver   src/solver/linear_solver.jl:1-60 seam: factorize!(s, A), compute_inertia!(s), linear_solve!(s, x, A, b) on
+#                                    the device for the sparse K the reference assembles itself (calipso_hip_ldl_*)
 #
 # NOTE: Julia is not installed in the build container of this repository, so this file has not been executed there; it is the
 # binding a maintainer adds (see INTEGRATION.md).  The same C ABI is exercised end-to-end by the Python ctypes mirror
@@ -15,6 +16,7 @@ module CalipsoHIP
 
 using CALIPSO
 using LinearAlgebra
+using SparseArrays
 
 const lib = get(ENV, "CALIPSO_HIP_LIB", joinpath(@__DIR__, "..", "libcalipso_hip.so"))
 
@@ -100,16 +102,19 @@ function HIPSolver(solver::CALIPSO.Solver; device::Integer=0)
     return hs
 end
 
-const ACTIVE = Ref{Union{Nothing,HIPSolver}}(nothing)   # the solver being driven by solve! (one per thread of control)
+const ACTIVE = Ref{Union{Nothing,HIPSolver}}(nothing)   # fallback for callers that pass user = C_NULL to the C drivers
 
 # evaluate!(problem, methods, idx, point, parameters; <flags>)  (src/solver/evaluate.jl:1-124) at the point the library hands
 # over, then upload of the flagged ProblemData fields (the three Hessian terms as one summed "lagrangian_hessian",
 # src/solver/residual_jacobian_variables.jl:10-16).
 function evaluate_callback(user::Ptr{Cvoid}, flags::UInt32, px::Ptr{Float64}, py::Ptr{Float64}, pz::Ptr{Float64}, pth::Ptr{Float64})::Int32
-    hs = ACTIVE[]
-    s = hs.solver
-    d = s.dimensions
+    # No exception may unwind through the @cfunction frame into C: everything, including the lookup of the solver, is inside `try`.
     try
+        # `user` = pointer_from_objref(hs) as passed to calipso_hip_solve / calipso_hip_group_set_evaluators (the caller keeps `hs`
+        # rooted with GC.@preserve for the duration of the ccall); ACTIVE[] serves callers that passed C_NULL
+        hs = user != C_NULL ? (unsafe_pointer_to_objref(user)::HIPSolver) : (ACTIVE[]::HIPSolver)
+        s = hs.solver
+        d = s.dimensions
         pt = s.candidate                      # scratch Point the generated functions read from
         pt.variables .= unsafe_wrap(Array, px, d.variables)
         d.equality_dual > 0 && (pt.equality_dual .= unsafe_wrap(Array, py, d.equality_dual))
@@ -170,10 +175,14 @@ end
 
 "solve!(solver)::Bool  src/solver/solve.jl:8-377 — results are copied back into the wrapped Solver's fields"
 function CALIPSO.solve!(hs::HIPSolver)
-    ACTIVE[] = hs
-    rc = ccall((:calipso_hip_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), hs.handle, hs.eval_cfunction, C_NULL)
-    ACTIVE[] = nothing
+    rc = GC.@preserve hs ccall((:calipso_hip_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), hs.handle, hs.eval_cfunction, pointer_from_objref(hs))
     check(hs.handle, rc, "solve!")
+    copy_back!(hs)
+    return rc == 1
+end
+
+"copy the results of the device handle into the wrapped reference Solver's own fields (what tests and examples read)"
+function copy_back!(hs::HIPSolver)
     s = hs.solver
     d = s.dimensions
     s.solution.all .= get_field(hs.handle, "solution", d.total)
@@ -189,26 +198,108 @@ function CALIPSO.solve!(hs::HIPSolver)
     if s.options.differentiate && d.parameters > 0
         s.data.solution_sensitivity .= reshape(get_field(hs.handle, "solution_sensitivity", d.total * d.parameters), d.total, d.parameters)
     end
-    return rc == 1
+    return
 end
 
 # ---- linear-solver seam (src/solver/linear_solver.jl:1-60) -------------------------------------------------------------------
-"Drop-in for LDLSolver: the factorisation works from the blocks already on the device, `A` is accepted for signature parity."
+"""
+    HIPLDLSolver(A::SparseMatrixCSC) / hip_ldl_solver(A)
+
+Drop-in for `LDLSolver` (linear_solver.jl:3-17,46-50): a device LDL^T for the sparse symmetric quasi-definite matrix the
+reference assembles itself.  `factorize!(s, A)` ships A's CSC arrays (colptr / rowval / nzval, 1-based as Julia stores them; only
+triu(A) is read, linear_solver.jl:23) to the device and factors there; `compute_inertia!` / `linear_solve!` have the reference's
+signatures and semantics, so the reference's own `search_direction!` (search_direction.jl:1-23), `iterative_refinement!`
+(iterative_refinement.jl:20-26), `inertia_correction!` (inertia.jl:17-28) and `differentiate!` (differentiate.jl:19-46) run
+unmodified with `solver.linear_solver = hip_ldl_solver(solver.data.jacobian_variables_symmetric)`.
+(One-line change in the reference for that assignment: the field is declared `linear_solver::LDLSolver{T,Int}` in
+solver.jl:14 — widen it to `linear_solver::LinearSolver`.)
+"""
 mutable struct HIPLDLSolver <: CALIPSO.LinearSolver
+    handle::Ptr{Cvoid}
+    n::Int
+    inertia::CALIPSO.Inertia
+end
+
+function HIPLDLSolver(n::Integer; device::Integer=0)
+    href = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:calipso_hip_ldl_create, lib), Int32, (Int64, Int32, Ptr{Ptr{Cvoid}}), n, device, href)
+    rc != 0 && throw(HIPError(rc, "calipso_hip_ldl_create: $(last_error(href[]))"))
+    s = HIPLDLSolver(href[], n, CALIPSO.Inertia(0, 0, 0))
+    finalizer(x -> ccall((:calipso_hip_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), s)
+    return s
+end
+
+"ldl_solver(A)  linear_solver.jl:46-50 (factors once at construction, as `qdldl(A)` does there)"
+function hip_ldl_solver(A::SparseMatrixCSC{Float64,Int}; device::Integer=0)
+    s = HIPLDLSolver(size(A, 1); device=device)
+    CALIPSO.factorize!(s, A)
+    return s
+end
+hip_ldl_solver(A::Matrix{Float64}; kw...) = hip_ldl_solver(sparse(A); kw...)
+
+"factorize!(s, A; update)  linear_solver.jl:19-31.  `update` only selects between value update and symbolic re-analysis in QDLDL; the dense device factorisation has no symbolic phase, so both take the same path.  Like the reference with update=true, only triu(A) matters (A itself is not mutated here)."
+function CALIPSO.factorize!(s::HIPLDLSolver, A::SparseMatrixCSC{Float64,Int}; update=false)
+    out = zeros(Int64, 3)
+    rc = ccall((:calipso_hip_ldl_factorize_csc, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}),
+               s.handle, s.n, A.colptr, A.rowval, A.nzval, out)
+    rc < 0 && throw(HIPError(rc, "factorize!: $(last_error(s.handle))"))
+    rc == 1 && @warn "Zero entry in D (matrix is not quasidefinite)"     # qdldl.jl:309-311
+    s.inertia.positive, s.inertia.negative, s.inertia.zero = out
+    return nothing
+end
+
+"compute_inertia!(s)  linear_solver.jl:33-44"
+function CALIPSO.compute_inertia!(s::HIPLDLSolver)
+    out = zeros(Int64, 3)
+    check(s.handle, ccall((:calipso_hip_ldl_inertia, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), s.handle, out), "compute_inertia!")
+    s.inertia.positive, s.inertia.negative, s.inertia.zero = out
+    return nothing
+end
+
+"linear_solve!(s, x, A, b; fact, update)  linear_solver.jl:52-60"
+function CALIPSO.linear_solve!(s::HIPLDLSolver, x::Vector{Float64}, A::SparseMatrixCSC{Float64,Int}, b::Vector{Float64}; fact=true, update=true)
+    fact && CALIPSO.factorize!(s, A; update=update)
+    check(s.handle, ccall((:calipso_hip_ldl_solve, lib), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}), s.handle, s.n, 1, b, x), "linear_solve!")
+    return
+end
+
+"linear_solve!(s, X, A, B; fact, update) for matrices  linear_solver.jl:82-99: all columns through one factorisation"
+function CALIPSO.linear_solve!(s::HIPLDLSolver, x::Matrix{Float64}, A::SparseMatrixCSC{Float64,Int}, b::Matrix{Float64}; fact=true, update=true)
+    fact && CALIPSO.factorize!(s, A; update=update)
+    check(s.handle, ccall((:calipso_hip_ldl_solve, lib), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}), s.handle, s.n, size(b, 2), b, x), "linear_solve!")
+    return
+end
+
+# The handle-resident variant: the KKT blocks are already on the device (uploaded by the evaluation callback or by set_field!), the
+# condensed matrix is never formed on the host.  factorize! = calipso_hip_factorize on those blocks with the handle's kappa / rho /
+# regularisation scalars (which the caller syncs with sync_scalars!); `A` is accepted for signature parity only.
+mutable struct HIPKKTSolver <: CALIPSO.LinearSolver
     hs::HIPSolver
     inertia::CALIPSO.Inertia
 end
-HIPLDLSolver(hs::HIPSolver) = HIPLDLSolver(hs, CALIPSO.Inertia(0, 0, 0))
+HIPKKTSolver(hs::HIPSolver) = HIPKKTSolver(hs, CALIPSO.Inertia(0, 0, 0))
 
-function CALIPSO.factorize!(s::HIPLDLSolver, A=nothing; update=true)
+"push the reference Solver's iterate and scalars (solver.jl:81-127) to the handle before factorize!/linear_solve! in HIPKKTSolver mode"
+function sync_scalars!(hs::HIPSolver)
+    s = hs.solver
+    set_field!(hs.handle, "solution", s.solution.all)
+    for (name, ref) in (("central_path", s.central_path), ("penalty", s.penalty), ("fraction_to_boundary", s.fraction_to_boundary),
+                        ("primal_regularization", s.primal_regularization), ("dual_regularization", s.dual_regularization))
+        set_field!(hs.handle, name, ref[1])
+    end
+    return
+end
+
+function CALIPSO.factorize!(s::HIPKKTSolver, A=nothing; update=true)
+    sync_scalars!(s.hs)
     out = zeros(Int64, 3)
     check(s.hs.handle, ccall((:calipso_hip_factorize, lib), Int32, (Ptr{Cvoid}, Ptr{Int64}), s.hs.handle, out), "factorize!")
     s.inertia.positive, s.inertia.negative, s.inertia.zero = out
     return nothing
 end
-CALIPSO.compute_inertia!(s::HIPLDLSolver) = nothing      # filled by factorize! (one device pass counts the pivot signs)
+CALIPSO.compute_inertia!(s::HIPKKTSolver) = nothing      # filled by factorize! (one device pass counts the pivot signs)
 
-function CALIPSO.linear_solve!(s::HIPLDLSolver, x::Vector{Float64}, A, b::Vector{Float64}; fact=true, update=true)
+function CALIPSO.linear_solve!(s::HIPKKTSolver, x::Vector{Float64}, A, b::Vector{Float64}; fact=true, update=true)
     fact && CALIPSO.factorize!(s, A; update=update)
     set_field!(s.hs.handle, "residual_symmetric", b)
     check(s.hs.handle, ccall((:calipso_hip_linear_solve, lib), Int32, (Ptr{Cvoid},), s.hs.handle), "linear_solve!")
@@ -255,18 +346,60 @@ function newton_step!(g::HIPGroup; advance::Bool=true)
     return info, status
 end
 
-"solve! (solve.jl:8-377) of every member in lockstep; members are evaluated through `evaluate_callback` (their own CALIPSO.evaluate!)."
+"solve! (solve.jl:8-377) of every member in lockstep; members are evaluated through `evaluate_callback` (their own CALIPSO.evaluate!), which finds its solver through the per-member `user` pointer.  Returns the per-member results (1 converged, 0 caps reached, < 0 error code)."
 function CALIPSO.solve!(g::HIPGroup)
-    res = zeros(Int32, length(g.members))
+    members = g.members
+    res = zeros(Int32, length(members))
     cb = @cfunction(evaluate_callback, Int32, (Ptr{Cvoid}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}))
-    evals = fill(cb, length(g.members))
-    users = Ptr{Cvoid}[pointer_from_objref(m) for m in g.members]
-    ccall((:calipso_hip_group_set_evaluators, lib), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), g.handle, evals, users)
-    rc = ccall((:calipso_hip_group_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Int32}), g.handle, res)
-    rc < 0 && error("calipso_hip_group_solve failed ($rc)")
+    evals = fill(cb, length(members))
+    GC.@preserve members begin
+        users = Ptr{Cvoid}[pointer_from_objref(m) for m in members]
+        rc = ccall((:calipso_hip_group_set_evaluators, lib), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}), g.handle, evals, users)
+        rc < 0 && error("calipso_hip_group_set_evaluators failed ($rc)")
+        rc = ccall((:calipso_hip_group_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Int32}), g.handle, res)
+        rc < 0 && error("calipso_hip_group_solve failed ($rc): $(last_error(members[1].handle))")
+    end
+    for (m, r) in zip(members, res)
+        r >= 0 && copy_back!(m)
+    end
     return res
 end
 
-export HIPSolver, HIPLDLSolver, HIPGroup, newton_step!, search_direction_nonsymmetric!, analyze_structure!, clear_structure!
+# ---- multi-GPU exchange (include/calipso_hip.h: calipso_hip_comm_*): RCCL over xGMI, one process per GPU -------------------------
+"RCCL communicator: `id = comm_unique_id()` on one rank, distributed by the launcher (file / MPI / Distributed.jl), then `HIPComm(rank, nranks, id; device)` on every rank."
+mutable struct HIPComm
+    handle::Ptr{Cvoid}
+    rank::Int
+    nranks::Int
+end
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    rc = ccall((:calipso_hip_comm_unique_id, lib), Int32, (Ptr{UInt8},), id)
+    rc == 0 || error("calipso_hip_comm_unique_id failed ($rc)")
+    return id
+end
+function HIPComm(rank::Integer, nranks::Integer, id::Vector{UInt8}; device::Integer=0)
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:calipso_hip_comm_init, lib), Int32, (Int32, Int32, Ptr{UInt8}, Int32, Ptr{Ptr{Cvoid}}), rank, nranks, id, device, c)
+    rc == 0 || error("calipso_hip_comm_init failed ($rc)")
+    comm = HIPComm(c[], rank, nranks)
+    finalizer(x -> ccall((:calipso_hip_comm_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), comm)
+    return comm
+end
+"all-gather of the per-problem status rows (4 x k Int32 per rank, k may differ) in global problem-id order; `capacity` = total rows"
+function gather_status(c::HIPComm, rows::Matrix{Int32}, capacity::Integer)
+    out = zeros(Int32, 4, capacity); counts = zeros(Int64, c.nranks)
+    n = ccall((:calipso_hip_comm_gather_status, lib), Int64, (Ptr{Cvoid}, Ptr{Int32}, Int64, Ptr{Int32}, Int64, Ptr{Int64}), c.handle, rows, size(rows, 2), out, capacity, counts)
+    n < 0 && error("calipso_hip_comm_gather_status failed ($n)")
+    return out[:, 1:n], counts
+end
+function allreduce_sum!(c::HIPComm, v::Vector{Float64})
+    rc = ccall((:calipso_hip_comm_allreduce_sum, lib), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64), c.handle, v, length(v))
+    rc == 0 || error("calipso_hip_comm_allreduce_sum failed ($rc)")
+    return v
+end
+
+export HIPSolver, HIPLDLSolver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPComm, comm_unique_id, gather_status, allreduce_sum!, newton_step!,
+       search_direction_nonsymmetric!, analyze_structure!, clear_structure!, sync_scalars!, copy_back!
 
 end # module

@@ -61,6 +61,24 @@ def kat(name, prob, seed):
     out["merit_gradient"] = o.buf("merit_gradient").copy()
     out["optimality_error"] = np.array([o.optimality_error()])
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    # the same inputs as plain text for bench/ref_fixtures.jl (Julia, the reference itself): "name rows cols" + column-major values
+    with open(os.path.join(HERE, name + "_inputs.txt"), "w") as fh:
+        def rec(key, arr):
+            a = np.atleast_2d(np.asarray(arr, dtype=np.float64))
+            if a.shape[0] == 1 and np.asarray(arr).ndim <= 1:
+                a = a.T
+            fh.write("%s %d %d\n" % (key, a.shape[0], a.shape[1]))
+            for v in a.T.reshape(-1):
+                fh.write(repr(float(v)) + "\n")
+        for key in ("P", "q", "A", "b", "G", "h", "w"):
+            rec(key, out[key])
+        rec("dual", lam)
+        rec("objective_scale", [prob.c])
+        rec("nonnegative_indices", prob.nonnegative_indices)
+        rec("second_order_ptr", out["soc_ptr"])
+        rec("second_order_indices", out["soc"])
+        for key, v in (("central_path", 0.17), ("penalty", 52.0), ("primal_regularization", 0.12), ("dual_regularization", 0.21), ("fraction_to_boundary", 0.99)):
+            rec(key, [v])
     print(name, "inertia", out["inertia"], "alpha", out["alpha"])
 
 
