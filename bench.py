@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — Newton steps/s of the CALIPSO KKT hot path on MI355X (BASELINE.json metric).
 
-A "step" = one inner Newton iteration of solve! (src/solver/solve.jl:98-353) on each of the B independent problem
-instances this rank holds: evaluate (QP mat-vecs on the device) -> cone! -> residual! -> inertia-corrected LDL^T of the
-condensed KKT matrix -> condensed solve + step recovery -> >= 1 refinement round against the unreduced system -> cone
-fraction-to-boundary search -> candidate merit / violation -> filter line-search decision.  Inputs are resident in HBM
-before the timed region.  The B instances of a rank are bound into groups of G (default 36 = 3 x 12): a group steps its members
-in lockstep through the same kernel launches (the problem instance is a grid dimension of every kernel), three groups are in
-flight on three HIP streams.  ms_per_step is the time of one such pass over all B instances.  Workload = BASELINE config C3 (synthetic dense conic QP, nx=2500, ne=1500, nc=400 R+ + 200 x SOC3
-=> n = 5000 condensed, N = 8500 unreduced), problem ids  rank*B .. rank*B+B-1  (SplitMix64 streams).
+Headline (`value`): ONE n = 5000 KKT system per GPU stepped sequentially — "Newton steps/sec (n~5k KKT) at 1 GPU".
+A "step" = one inner Newton iteration of solve! (src/solver/solve.jl:98-353): evaluate (QP mat-vecs on the device) -> cone! ->
+residual! -> inertia-corrected LDL^T of the condensed KKT matrix -> condensed solve + step recovery -> >= 1 refinement round
+against the unreduced system -> cone fraction-to-boundary search -> candidate merit / violation -> filter line-search decision.
+Inputs are resident in HBM before the timed region.  Workload = BASELINE config C3 (synthetic dense conic QP, nx=2500, ne=1500,
+nc=400 R+ + 200 x SOC3 => n = 5000 condensed, N = 8500 unreduced; SplitMix64 streams); problem id = rank.
+
+Batched figure (`config.batched`, BASELINE's "batched problems/sec"): B independent instances per GPU (default 36 = 3 groups of 12;
+a group steps its members in lockstep through the same kernel launches, three groups in flight on three HIP streams), measured in
+a second timed region of the same run; aggregated over ranks.
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Multi-GPU: problems are independent => ranks share nothing on the data path (weak scaling); torch.distributed (RCCL) is
-used only for the barrier and the max-over-ranks time.  Prints ONE JSON line on rank 0.
+Multi-GPU: problems are independent => ranks share nothing on the data path (a single system is "replicas only", the batched path
+is sharded block-contiguously: weak scaling); torch.distributed (RCCL) is used for the barrier, the max-over-ranks time and the
+post-round gather of status rows / counters.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -40,7 +43,7 @@ STAGED = {
     "C4T": (41, 56, 54, 6, 6, 2),
     "smallT": (12, 40, 30, 4, 2, 3),
 }
-FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet; bench/mfma_f64_peak.hip measures the achievable ceiling)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet); the measured ceiling is reported beside it (calipso_hip_mfma_f64_peak)
 
 
 def make_instance(pkg, pr, pid, shape, device, staged=None, analyze=True):
@@ -71,11 +74,14 @@ def staged_shape(st):
     return (T * nv, (T - 1) * nd, T * nn, T * nsoc, dim)
 
 
-def cpu_baseline(shape, name="C3", staged=None):
-    """The oracle (faithful single-thread restatement of the reference's CPU path) on ONE Newton step of the same C3
-    problem (problem id 0): search_direction! = assemble + sparse up-looking LDL^T (QDLDL order of operations, constraint-first
-    permutation) + solve + refinement, with ONE factorisation per step (the reference re-factorises before every solve —
-    linear_solver.jl:53 — so this is favourable to it)."""
+def cpu_baseline(shape, name="C3", staged=None, samples=3, full=False):
+    """CPU rows of SURVEY.md 8(d) on the GPU box's host, same C3 problem 0 (ONE Newton step each):
+      B0(i)   the oracle (faithful single-thread restatement of the reference's CPU path: assemble + sparse up-looking LDL^T in QDLDL's
+              operation order + solves + refinement) with ONE factorisation per step — favourable to the reference; `value`, 3 samples
+      B0(ii)  the reference's real behaviour: every linear_solve! re-factorises (linear_solver.jl:52-57, fact=true): 1 + (1 + n_r)
+              factorisations per step.  Default: B0(i) + (1 + n_r) x the separately timed factorisation; --cpu-baseline-full runs it
+      B1      NOT the reference: LAPACK dsytrf/dsytrs (Bunch-Kaufman) of the dense condensed K on all host cores — the strongest CPU
+              baseline the box offers for the factor + solves part."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     import problems as pr
@@ -84,26 +90,75 @@ def cpu_baseline(shape, name="C3", staged=None):
         prob, pt, lam = pr.staged_conic_qp(oracle.splitmix_uniform, 0, *staged)
     else:
         prob, pt, lam = pr.synthetic_conic_qp(oracle.splitmix_uniform, 0, nx, ne, n_nn, n_soc, dim)
-    o = oracle.OracleSolver(prob.nx, 0, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
-    o.point()["all"][:] = np.concatenate([pt[k] for k in "xrsyzt"])
-    o.buf("dual")[:] = lam
-    o.buf("central_path")[0] = 0.17
-    o.buf("penalty")[0] = 52.0
-    o.set_int("linear_solve_refactor", 0)
-    t0 = time.perf_counter()
-    prob.evaluate(pr.ALL_VARIABLE_FLAGS, pt["x"], pt["y"], pt["z"], np.zeros(0), o.buf)
-    o.cone(product=True, jacobian=True, target=True, barrier=True, barrier_gradient=True)
-    o.residual()
-    rc = o.search_direction()
-    dt = time.perf_counter() - t0
+
+    def fresh(refactor):
+        o = oracle.OracleSolver(prob.nx, 0, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
+        o.point()["all"][:] = np.concatenate([pt[k] for k in "xrsyzt"])
+        o.buf("dual")[:] = lam
+        o.buf("central_path")[0] = 0.17
+        o.buf("penalty")[0] = 52.0
+        o.set_int("linear_solve_refactor", refactor)
+        return o
+
+    def one_step(o):
+        t0 = time.perf_counter()
+        prob.evaluate(pr.ALL_VARIABLE_FLAGS, pt["x"], pt["y"], pt["z"], np.zeros(0), o.buf)
+        o.cone(product=True, jacobian=True, target=True, barrier=True, barrier_gradient=True)
+        o.residual()
+        rc = o.search_direction()
+        return time.perf_counter() - t0, rc
+
+    o = fresh(0)
+    times, rc = [], 0
+    for _ in range(max(1, samples)):
+        dt, rc = one_step(o)
+        times.append(dt)
     st = o.stats()
-    note = "" if staged is None else (" (the port assembles and factors the blocks densely: it does not exploit the stage structure, which the "
-                                      "reference's sparse LDL^T would)")
-    return dict(value=1.0 / dt, unit="Newton steps/s", cores=1, kind="port",
-                sample=note.strip() + (" " if note else "") + "1 Newton step (evaluate + cone + residual + search_direction: 1 LDL^T factorisation, %d solves) of %s problem 0, %.1f s; "
-                       "with the reference's re-factorisation before every solve it would be %dx the factorisation time" % (
-                           1 + st["last_refinement_rounds"], name, dt, 1 + st["last_refinement_rounds"]),
-                status=int(rc))
+    n_r = st["last_refinement_rounds"]
+    t0 = time.perf_counter()
+    o.factorize(update=True)                       # one more factorisation of the same matrix, timed alone
+    t_fact = time.perf_counter() - t0
+    t_i = float(np.median(times))
+    extra = 1 + n_r                                # hidden re-factorisations: one per linear_solve! (first solve + n_r refinement solves)
+    b0ii = dict(value=1.0 / (t_i + extra * t_fact), unit="Newton steps/s", cores=1, factorizations_per_step=1 + extra, measured=False,
+                how="B0(i) median + %d x one separately timed factorisation (%.2f s)" % (extra, t_fact))
+    if full:
+        of = fresh(1)
+        dt, _ = one_step(of)
+        b0ii = dict(value=1.0 / dt, unit="Newton steps/s", cores=1, factorizations_per_step=int(of.stats()["factorizations"]), measured=True,
+                    how="one full step with linear_solve_refactor = 1 (%.1f s)" % dt)
+    # B1: LAPACK on all cores, factor + (1 + n_r) solves of the dense condensed K (upper triangle symmetrised, as QDLDL sees it)
+    b1 = None
+    try:
+        from scipy.linalg import lapack
+        o.residual_jacobian_variables(); o.residual_jacobian_variables_symmetric()
+        K = np.array(o.K_dense(), order="F")
+        K = np.triu(K) + np.triu(K, 1).T
+        b = np.array(o.buf("residual_symmetric"))
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ldu, ipiv, info = lapack.dsytrf(K, lower=0)
+            for _k in range(1 + n_r):
+                x, info2 = lapack.dsytrs(ldu, ipiv, b, lower=0)
+            ts.append(time.perf_counter() - t0)
+        try:
+            import threadpoolctl
+            thr = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"] or [os.cpu_count()])
+        except Exception:
+            thr = os.cpu_count()
+        b1 = dict(value=1.0 / float(np.median(ts)), unit="factor+solves/s", cores=int(thr), kind="lapack dsytrf/dsytrs (not the reference)",
+                  sample="dense K n=%d, 1 dsytrf + %d dsytrs, median of 3: %.3f s; excludes assembly / residuals / refinement mat-vecs" % (
+                      K.shape[0], 1 + n_r, float(np.median(ts))))
+    except Exception as e:   # pragma: no cover
+        b1 = dict(error=repr(e))
+    note = "" if staged is None else ("(the port assembles and factors the blocks densely: it does not exploit the stage structure, which the "
+                                      "reference's sparse LDL^T would) ")
+    return dict(value=1.0 / t_i, unit="Newton steps/s", cores=1, kind="port",
+                sample=note + "B0(i): %d sample(s) of 1 Newton step (evaluate + cone + residual + search_direction: 1 LDL^T factorisation, %d solves) of "
+                       "%s problem 0, median %.1f s, all %s s" % (len(times), 1 + n_r, name, t_i, ["%.1f" % t for t in times]),
+                samples_s=times, status=int(rc), host_cores=os.cpu_count(),
+                B0_ii_reference_refactorisation=b0ii, B1_lapack_all_cores=b1)
 
 
 def main():
@@ -111,16 +166,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=36, help="independent problem instances per GPU (B), arranged in groups of --group members;\n"
-                    "--lanes groups are in flight at a time, see calipso.jl_amd/batch.py")
+    ap.add_argument("--batch", type=int, default=36, help="batched region: independent problem instances per GPU (B), arranged in groups of --group\n"
+                    "members; --lanes groups are in flight at a time, see calipso.jl_amd/batch.py.  0 skips the batched region")
     ap.add_argument("--lanes", type=int, default=3, help="host threads / HIP streams driving the units (groups or single instances) concurrently")
     ap.add_argument("--group", type=int, default=12, help="instances per group: the members of a group are stepped in lockstep through the same\n"
                     "kernel launches (calipso_hip_group_*); --batch must be a multiple of it")
+    ap.add_argument("--batched-passes", type=int, default=10, help="passes over all B instances in the batched timed region")
     ap.add_argument("--config", default="C3", choices=list(CONFIGS) + list(STAGED))
     ap.add_argument("--dense-structure", action="store_true", help="stage-structured configs: keep the dense treatment (no calipso_hip_analyze_structure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single", action="store_true", help="skip the informational single-instance loop (profiling runs: every launch\n"
-                    "in the trace then carries a whole group)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="measure B0(ii) (re-factorisation before every solve) instead of deriving it (~1 min more)")
+    ap.add_argument("--cpu-samples", type=int, default=3)
+    ap.add_argument("--no-single", action="store_true", help="profiling runs: skip the single-system region (every launch in the trace then carries a\n"
+                    "whole group); the headline then falls back to the batched rate")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets two ranks share one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="testing only: every rank uses this device ordinal")
     args = ap.parse_args()
@@ -145,14 +203,15 @@ def main():
     import problems as pr
     staged = STAGED.get(args.config)
     shape = staged_shape(staged) if staged else CONFIGS[args.config]
-    B = args.batch
+    B = max(0, args.batch)
     from calipso_jl_amd.batch import BatchSolver, gather_results, shard_range
     G = max(1, args.group)
     assert B % G == 0, "--batch must be a multiple of --group"
-    ids = list(shard_range(world * B, rank, world))          # block-contiguous problem ids of this rank
+    nb = max(B, 1)
+    ids = list(shard_range(world * nb, rank, world))          # block-contiguous problem ids of this rank
     # creation order: the first member of every unit first, so that the streams that carry the launches get distinct priority
     # classes (handles take class = creation index mod 3, calipso_hip_create)
-    order = [k for k in range(B) if k % G == 0] + [k for k in range(B) if k % G != 0]
+    order = [k for k in range(nb) if k % G == 0] + [k for k in range(nb) if k % G != 0]
     made = {}
     for k in order:
         inst = make_instance(pkg, pr, ids[k], shape, local_rank, staged, not args.dense_structure)
@@ -161,9 +220,10 @@ def main():
         if k != 0:
             inst[4].problem = None
             inst[4].methods = None
-    solvers = [made[k][4] for k in range(B)]
-    units = [pkg.Group(solvers[k:k + G]) for k in range(0, B, G)] if G > 1 else solvers
-    batch = BatchSolver(units, lanes=args.lanes)
+    solvers = [made[k][4] for k in range(nb)]
+    single = solvers[0]                                       # the headline system of this rank (problem id = first of its shard)
+    units = ([pkg.Group(solvers[k:k + G]) for k in range(0, B, G)] if G > 1 else solvers[:B]) if B else []
+    batch = BatchSolver(units, lanes=args.lanes) if units else None
 
     def barrier():
         if dist is not None:
@@ -172,116 +232,159 @@ def main():
         for s in solvers:
             s.synchronize()
 
-    def one_step():
-        out = batch.newton_step(advance=False)              # units run concurrently, one HIP stream each
+    def max_over_ranks(t):
+        if dist is None:
+            return t
+        tt = torch.tensor([t], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def batched_pass():
+        out = batch.newton_step(advance=False)               # units run concurrently, one HIP stream each
         return [i for u in out for i in u] if G > 1 else out
 
+    # ---- warm-up: W steps of the single system (captures its launch graphs) and of the batched pass ----------------------------
     for _ in range(args.warmup):
-        one_step()
-    # single-instance latency rate (informational): instance 0 alone, same step
-    barrier()
-    n_single = max(3, min(10, args.steps))
-    single_rate = None
+        if not args.no_single:
+            single.newton_step(advance=False)
+        if batch is not None:
+            batched_pass()
+    peak_measured = pkg.mfma_f64_peak(local_rank) if rank == 0 else None
+
+    # ---- timed region 1 (headline): K sequential Newton steps of ONE system per GPU ------------------------------------------------
+    K = args.steps
+    single_elapsed, single_infos, sch_single, ldl_single, sd_single, tot_single = None, [], [], [], [], []
     if not args.no_single:
-        for _ in range(2):
-            solvers[0].newton_step(advance=False)            # (first single-handle call captures its launch graphs)
-        solvers[0].synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            single_infos.append(single.newton_step(advance=False))
+            pt_ = single.phase_times()
+            sch_single.append(pt_[7]); ldl_single.append(pt_[3]); sd_single.append(pt_[2]); tot_single.append(pt_[6])
+        barrier()
+        single_elapsed = max_over_ranks(time.perf_counter() - t0)
+        assert all(i["status"] >= 0 for i in single_infos), "a Newton step of the timed region failed"
+
+    # ---- unit 0 alone (one group of G instances): its launches have the device to themselves => clean per-launch figures ------------
+    alone, unit_rate = [], None
+    if batch is not None:
+        barrier()
+        n_alone = max(3, min(10, K))
         ts = time.perf_counter()
-        for _ in range(n_single):
-            solvers[0].newton_step(advance=False)
-        solvers[0].synchronize()
-        single_rate = n_single / (time.perf_counter() - ts)
-    # unit 0 alone (one group of G instances, or one instance): its launches have the device to themselves, so the HIP-event
-    # durations of its kernels are clean per-launch figures (the roofline below uses them)
-    barrier()
-    ts = time.perf_counter()
-    sch_alone, alone = [], []
-    for _ in range(n_single):
-        units[0].newton_step(advance=False)
-        alone.append(units[0].phase_times())
-        sch_alone.append(alone[-1][7])
-    units[0].synchronize()
-    unit_rate = G * n_single / (time.perf_counter() - ts)
-    barrier()
-    t0 = time.perf_counter()
-    sch, ldl, tot, sd = [], [], [], []
-    for _ in range(args.steps):
-        infos = one_step()
-        pt = solvers[0].phase_times()
-        sch.append(pt[7]); ldl.append(pt[3]); tot.append(pt[6]); sd.append(pt[2])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    # post-round exchange (outside the data path): per-problem status rows all-gathered, step counters all-reduced
-    status = [[int(i["status"] >= 0), args.steps, i["refinement_rounds"], i["factorizations"]] for i in infos]
-    all_status, counters = gather_results(status, [float(len(solvers) * args.steps)])
-    assert all_status.shape[0] == world * B and int(counters[0]) == world * B * args.steps
-    info = infos[0]
+        for _ in range(n_alone):
+            units[0].newton_step(advance=False)
+            alone.append(units[0].phase_times())
+        units[0].synchronize()
+        unit_rate = G * n_alone / (time.perf_counter() - ts)
+
+    # ---- timed region 2 (batched): P passes over all B instances of the rank ------------------------------------------------------
+    P = max(1, args.batched_passes)
+    batched_elapsed, infos, sch_conc = None, None, []
+    if batch is not None:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(P):
+            infos = batched_pass()
+            sch_conc.append(solvers[0].phase_times()[7])
+        barrier()
+        batched_elapsed = max_over_ranks(time.perf_counter() - t0)
+        assert all(i["status"] >= 0 for i in infos), "a Newton step of the batched region failed"
+        # post-round exchange (outside the data path): per-problem status rows all-gathered, step counters all-reduced
+        status = [[int(i["status"] >= 0), P, i["refinement_rounds"], i["factorizations"]] for i in infos]
+        all_status, counters = gather_results(status, [float(len(infos) * P)])
+        assert all_status.shape[0] == world * B and int(counters[0]) == world * B * P
+        assert all_status[:, 0].all(), "failed Newton steps must not count towards the reported rate"
+
+    info = single_infos[-1] if single_infos else infos[0]
     nx, ne, n_nn, n_soc, dim = shape
     nc = n_nn + n_soc * dim
     m = ne + nc
-    value = world * B * args.steps / elapsed
-    # dominant kernel: the Schur-complement update S = Lxx + ep*I + Z' Omega Z on the fp64 matrix cores (k_schur); one launch
-    # covers the G instances of a group.  algorithmic flops per launch = G x multiply-adds of the lower triangle incl. diagonal,
-    # nx (nx+1) m each.  Its launch duration is taken from HIP events on the stream while ONE unit is in flight (the kernel has
-    # the device to itself; with several units in flight concurrent launches share the CUs and a per-launch time is ill-defined)
-    sch_ms = float(np.mean(sch_alone))
-    sch_ms_concurrent = float(np.mean(sch))
-    # (per constraint row with w non-zero columns: w (w + 1) multiply-add flops of the lower triangle; dense rows: nx (nx + 1) each)
+    if single_elapsed is not None:
+        value, elapsed, steps_timed = world * K / single_elapsed, single_elapsed, K
+    else:                                                     # --no-single (profiling): the batched rate stands in
+        value, elapsed, steps_timed = world * B * P / batched_elapsed, batched_elapsed, P
+    # dominant kernel (by flops): the Schur-complement update S = Lxx + ep*I + Z' Omega Z on the fp64 matrix cores (k_schur).
+    # algorithmic flops per instance = multiply-adds of the lower triangle incl. diagonal: per constraint row with w non-zero columns
+    # w (w + 1); dense rows: nx (nx + 1).  Launch duration: HIP events on the stream the kernel runs on (phase_times[7]), averaged over
+    # the launches of the TIMED region (one instance per launch there); the group launch (G instances) is reported beside it.
     prob0 = made[0][0]
     wrow = np.concatenate([np.count_nonzero(prob0.A, axis=1), np.count_nonzero(prob0.G, axis=1)]).astype(np.float64)
     flops1 = float(np.sum(wrow * (wrow + 1.0)))
-    flops = G * flops1
-    achieved = flops / (sch_ms * 1e-3) * 1e-12
-    # per-phase rooflines from SURVEY.md 8(d)'s algorithmic figures, one instance in flight (HIP-event phase times of the handle)
-    al = np.mean(np.asarray(alone), axis=0)
+    roof = {"kernel": "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "peak_measured": peak_measured,
+            "peak_note": "peak = datasheet fp64 matrix rate (not tabulated in MI355X_MICROARCH.md); peak_measured = calipso_hip_mfma_f64_peak in this run"}
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+    except Exception:
+        pmc = {}
+    if sch_single:
+        ms1 = float(np.mean(sch_single))
+        roof.update(achieved=flops1 / (ms1 * 1e-3) * 1e-12, flops_per_launch=flops1, instances_per_launch=1, avg_launch_ms=ms1)
+        e = pmc.get("single", {}).get("calipso::k_schur") if args.config == "C3" else None
+        roof["traffic"] = e["hbm_bytes_per_launch"] if e else None
+    if alone:
+        msg = float(np.mean([a[7] for a in alone]))
+        grp = dict(achieved=G * flops1 / (msg * 1e-3) * 1e-12, flops_per_launch=G * flops1, instances_per_launch=G, avg_launch_ms=msg,
+                   avg_launch_ms_with_all_units_in_flight=float(np.mean(sch_conc)) if sch_conc else None)
+        e = pmc.get("group", {}).get("calipso::k_schur") if args.config == "C3" else None
+        grp["traffic"] = e["hbm_bytes_per_launch"] * G / float(e.get("instances_per_launch", G)) if e else None
+        grp["frac"] = grp["achieved"] / FP64_MFMA_PEAK_TFLOPS
+        if "achieved" not in roof:
+            roof.update({k: v for k, v in grp.items()})
+        roof["group_launch"] = grp
+    roof["frac"] = roof["achieved"] / FP64_MFMA_PEAK_TFLOPS
+    roof.setdefault("traffic", None)
+
+    # per-phase rooflines from SURVEY.md 8(d)'s algorithmic figures (HIP-event phase times of the handle)
     n_cond = nx + m
     n_r = int(info["refinement_rounds"])
-    t_factor = float(al[1] + al[7] + al[3])                       # cone pivots + Schur complement + LDL^T of S (G instances)
-    t_solve = float(al[2]) - t_factor                              # condensed solves + recovery + refinement residuals
-    f_survey = G * n_cond ** 3 / 3.0                               # dense n^3/3 of 8(d), per instance
-    f_exec = G * (flops1 + nx ** 3 / 3.0)                          # what the constraint-first order executes
-    b_solves = G * (1 + n_r) * 2 * 8 * n_cond * (n_cond + 1) / 2   # 8(d): each solve reads the factor twice
-    b_resid = G * (1 + n_r) * 8.0 * (nx * nx + ne * nx + nc * nx)  # 8(d): matrix-free R - H*step per refinement residual
-    phases = {
-        "factor": {"ms": t_factor, "bound": "mfma", "flops_survey_n3_over_3": f_survey, "flops_executed": f_exec,
-                   "achieved_TFLOPs_survey": f_survey / t_factor * 1e-9, "achieved_TFLOPs_executed": f_exec / t_factor * 1e-9,
-                   "frac_survey": f_survey / t_factor * 1e-9 / FP64_MFMA_PEAK_TFLOPS, "frac_executed": f_exec / t_factor * 1e-9 / FP64_MFMA_PEAK_TFLOPS},
-        "solve_and_refine": {"ms": t_solve, "bound": "hbm", "bytes_survey": b_solves + b_resid, "solves": 1 + n_r,
-                             "achieved_GBs_survey": (b_solves + b_resid) / t_solve * 1e-6, "frac_survey": (b_solves + b_resid) / t_solve * 1e-6 / 8000.0},
-        "whole_step_ms": float(al[6]),
-    }
-    traffic = None
-    try:   # HBM bytes per launch of k_schur from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C3 shape only)
-        if args.config == "C3":
-            e = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["calipso::k_schur"]
-            traffic = e["hbm_bytes_per_launch"] * G / float(e.get("instances_per_launch", 1))
-    except Exception:
-        traffic = None
+
+    def phases(al, inst):
+        t_factor = float(al[1] + al[7] + al[3])                       # cone pivots + Schur complement + LDL^T of S
+        t_solve = float(al[2]) - t_factor                              # condensed solves + recovery + refinement residuals
+        f_survey = inst * n_cond ** 3 / 3.0                            # dense n^3/3 of 8(d)
+        f_exec = inst * (flops1 + nx ** 3 / 3.0)                       # what the constraint-first order executes
+        b_solves = inst * (1 + n_r) * 2 * 8 * n_cond * (n_cond + 1) / 2
+        b_resid = inst * (1 + n_r) * 8.0 * (nx * nx + ne * nx + nc * nx)
+        return {"instances": inst, "whole_step_ms": float(al[6]),
+                "factor": {"ms": t_factor, "schur_ms": float(al[7]), "ldl_ms": float(al[3]), "bound": "mfma", "flops_survey_n3_over_3": f_survey,
+                           "flops_executed": f_exec, "achieved_TFLOPs_survey": f_survey / t_factor * 1e-9,
+                           "achieved_TFLOPs_executed": f_exec / t_factor * 1e-9, "frac_executed": f_exec / t_factor * 1e-9 / FP64_MFMA_PEAK_TFLOPS},
+                "solve_and_refine": {"ms": t_solve, "bound": "hbm", "bytes_survey": b_solves + b_resid, "solves": 1 + n_r,
+                                     "achieved_GBs_survey": (b_solves + b_resid) / t_solve * 1e-6,
+                                     "frac_survey": (b_solves + b_resid) / t_solve * 1e-6 / 8000.0}}
+    cfg_phases = {}
+    if tot_single:
+        al1 = np.zeros(9); al1[7] = np.mean(sch_single); al1[3] = np.mean(ldl_single); al1[2] = np.mean(sd_single); al1[6] = np.mean(tot_single)
+        al1[1] = single.phase_times()[1]
+        cfg_phases["single_system"] = phases(al1, 1)
+    if alone:
+        cfg_phases["one_group_alone"] = phases(np.mean(np.asarray(alone), axis=0), G)
+
     kind = ("stage-structured (%d stages, %s treatment) " % (staged[0], "dense" if args.dense_structure else "banded")) if staged else "dense "
+    batched = None
+    if batched_elapsed is not None:
+        brate = world * B * P / batched_elapsed
+        batched = {"newton_steps_per_s": brate, "problems_per_s_of_10_steps": brate / 10.0, "instances_per_gpu": B, "instances_per_group": G,
+                   "groups_in_flight": batch.lanes, "passes": P, "ms_per_pass": 1e3 * batched_elapsed / P, "one_group_alone_steps_per_s": unit_rate,
+                   "scaling": "weak (instances sharded block-contiguously over ranks, no data-path collective)"}
     out = {
-        "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": steps_timed,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps_timed, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("%s synthetic " + kind + "conic QP: nx=%d ne=%d nc=%d (%d R+ + %d x SOC%d), n=%d condensed, N=%d unreduced; "
-                                "%d independent instance(s) per GPU; 1 LDL^T factorisation, %d refinement round(s) per step") % (
-                                   args.config, nx, ne, nc, n_nn, n_soc, dim, nx + m, nx + 2 * ne + 3 * nc, B, info["refinement_rounds"]),
-                   "instances_per_gpu": B, "instances_per_group": G, "instances_in_flight": batch.lanes * G, "parallelism": "independent problems per GPU (no data-path collective)",
+                                "%s; 1 LDL^T factorisation, %d refinement round(s) per step") % (
+                                   args.config, nx, ne, nc, n_nn, n_soc, dim, nx + m, nx + 2 * ne + 3 * nc,
+                                   "ONE system per GPU stepped sequentially (replicas at N > 1)" if single_elapsed is not None
+                                   else "%d independent instances per GPU (batched rate, --no-single)" % B, info["refinement_rounds"]),
+                   "parallelism": "one system per GPU: replicas only; batched: independent problems per GPU (no data-path collective)",
                    "refinement_rounds": info["refinement_rounds"], "factorizations_per_step": info["factorizations"],
-                   "single_instance_steps_per_s": single_rate, "one_unit_alone_steps_per_s": unit_rate,
-                   "problems_per_s_of_10_steps": value / 10.0, "roofline_phases_one_unit_alone": phases,
-                   "phase_ms": {"whole_step_gpu": float(np.mean(tot)), "search_direction": float(np.mean(sd)), "schur_mfma": sch_ms,
-                                "ldl_of_schur_complement": float(np.mean(ldl))}},
-        "roofline": {"kernel": "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
-                     "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "flops_per_launch": flops, "instances_per_launch": G, "avg_launch_ms": sch_ms,
-                     "avg_launch_ms_with_%d_units_in_flight" % batch.lanes: sch_ms_concurrent},
+                   "batched": batched, "roofline_phases": cfg_phases},
+        "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(shape, args.config, staged)
+        out["cpu_baseline"] = cpu_baseline(shape, args.config, staged, samples=args.cpu_samples, full=args.cpu_baseline_full)
     else:
         out["cpu_baseline"] = None
     if rank == 0:

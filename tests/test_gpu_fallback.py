@@ -42,7 +42,7 @@ def test_refinement_failure_takes_the_fallback(oracle_mod, seed):
     rc = g.search_direction()
     assert rc == 2 and g.stats()["fallbacks"] == 1
     so, sg = np.array(o.buf("step")), g.data("step").all
-    assert np.abs(so - sg).max() <= 1e-7 * max(1.0, np.abs(so).max())
+    assert np.abs(so - sg).max() <= 1e-8 * max(1.0, np.abs(so).max())
     Hs = g.jacobian_variables_mul(sg)
     R = g.data("residual").all
     assert np.abs(Hs - R).max() <= 1e-8 * max(1.0, np.abs(R).max())

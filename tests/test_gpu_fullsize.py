@@ -109,12 +109,14 @@ def test_group_of_full_size_instances_is_bitwise_the_single_step():
     g.close()
 
 
-def test_full_size_step_matches_the_oracle(oracle_mod):
-    """C3 at BASELINE's full size (n = 5000 condensed, N = 8500): the refined Newton step of the device path against the CPU
-    restatement on the same inputs — the oracle needs ~10 s for this one step (sparse up-looking LDL^T in QDLDL's operation
-    order), which is also what bench.py times as the CPU baseline.  Tolerances of SURVEY.md 8(c): step 1e-8, residual 1e-12."""
+@pytest.mark.parametrize("cfg", ["C3", "C4"])
+def test_full_size_step_matches_the_oracle(oracle_mod, cfg):
+    """C3 (n = 5000 condensed, N = 8500) and one instance of C4's shape (n = 5234, N = 8890) at BASELINE's full sizes: the refined
+    Newton step of the device path against the CPU restatement on the same inputs — the oracle needs ~10 s for one such step
+    (sparse up-looking LDL^T in QDLDL's operation order), which is also what bench.py times as the CPU baseline.  Tolerances of
+    SURVEY.md 8(c): step 1e-8, residual 1e-12."""
     pkg = load_pkg()
-    nx, ne, n_nn, n_soc, dim = SHAPES["C3"]
+    nx, ne, n_nn, n_soc, dim = SHAPES[cfg]
     prob, pt, lam, w, s = build(pkg, pkg.splitmix_uniform, 0, nx, ne, n_nn, n_soc, dim)
     fl = pkg.FLAGS
     s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
@@ -135,3 +137,30 @@ def test_full_size_step_matches_the_oracle(oracle_mod):
     assert np.abs(step - so).max() <= 1e-8 * max(1.0, np.abs(so).max())
     assert o.stats()["last_refinement_rounds"] == info["refinement_rounds"]
     assert tuple(o.compute_inertia()) == (nx, ne + n_nn + n_soc * dim, 0)
+
+
+def test_group_of_twelve_c4_instances_is_bitwise_the_single_steps():
+    """BASELINE config C4's per-GPU unit: a group of 12 instances of C4's shape (nx = 2302, ne = 2208, nc = 244 R+ + 240 x SOC2) stepped
+    through one launch sequence equals the 12 stand-alone steps bit for bit (each stand-alone step being oracle-checked at this shape
+    by test_full_size_step_matches_the_oracle[C4])"""
+    pkg = load_pkg()
+    nx, ne, n_nn, n_soc, dim = SHAPES["C4"]
+    fl = pkg.FLAGS
+    members = []
+    for pid in range(12):
+        prob, pt, lam, w, s = build(pkg, pkg.splitmix_uniform, pid, nx, ne, n_nn, n_soc, dim)
+        s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
+        s.cone(product=True, target=True)
+        s.problem = None; s.methods = None
+        del prob
+        members.append(s)
+    ref, steps = [], []
+    for s in members:                                  # stand-alone (benchmark mode restores the iterate)
+        ref.append(s.newton_step(advance=False))
+        steps.append(s.data("step").all)
+    g = pkg.Group(members)
+    got = g.newton_step(advance=False)
+    for r, q, st, m in zip(ref, got, steps, members):
+        assert r == q and r["status"] == 0 and r["factorizations"] == 1
+        assert np.array_equal(st, m.data("step").all)
+    g.close()

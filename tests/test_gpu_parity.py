@@ -112,7 +112,7 @@ def test_search_direction_with_inertia_correction(oracle_mod):
     assert g.scalar("primal_regularization") == o.buf("primal_regularization")[0] > 1e-7
     assert g.scalar("primal_regularization_last") == o.buf("primal_regularization_last")[0]
     assert g.scalar("dual_regularization") == o.buf("dual_regularization")[0]
-    assert rel(g.data("step").all, o.buf("step")) <= 1e-7
+    assert rel(g.data("step").all, o.buf("step")) <= 1e-8
 
 
 def test_cone_violation_api(oracle_mod):
