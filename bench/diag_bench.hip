@@ -419,6 +419,134 @@ __global__ __launch_bounds__(1024) void k_diag_v4(int ld, double* __restrict__ S
     }
 }
 
+
+// v6: two-level blocking.  The 64 columns are four 16-column sub-panels.  ONE wavefront factors a sub-panel without any barrier: lane = row
+// (64 rows x 16 columns, 16 registers per lane), the pivot row travels by v_readlane; the rank-16 update of the columns to the right is
+// done by all 16 wavefronts out of LDS.  8 workgroup barriers per 64 columns instead of 64.  X = L^-1 as in v4 (16 x 16 inversions + merges).
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(1024) void k_diag_v6(int ld, double* __restrict__ S, double* __restrict__ Dx, double* __restrict__ Xout) {
+    constexpr int WAVES = 16, CPW = 4, SP = 16;
+    __shared__ double As[NB * LDD3];    // working matrix, row-major As[i][k]; ends as L (strictly lower) with the pivots in dd
+    __shared__ double Xs[NB * LDD3];
+    __shared__ double Ts[32 * 33];
+    __shared__ double dd[NB];
+    const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        As[i * LDD3 + k] = (i >= k) ? S[i + (size_t)k * ld] : 0.0;
+        Xs[i * LDD3 + k] = 0.0;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < NB / SP; ++p) {
+        const int c0 = SP * p;
+        if (cg == 0) {
+            // lane i = row i (rows >= c0 take part); a[k] = A[i][c0 + k]; the 16 x 16 diagonal sub-block is held with BOTH triangles
+            double a[SP];
+#pragma unroll
+            for (int k = 0; k < SP; ++k) {
+                const int col = c0 + k;
+                a[k] = (i >= col) ? As[i * LDD3 + col] : ((i >= c0) ? As[col * LDD3 + i] : 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < SP; ++j) {
+                const int r = c0 + j;
+                const double d = readlane_d(a[j], r);
+                const double rinv = fast_rcp(d);
+                const double li = a[j] * rinv;
+#pragma unroll
+                for (int k = j + 1; k < SP; ++k) {
+                    const double yk = readlane_d(a[k], r);       // A[r][c0 + k] (symmetric sub-block) = unscaled pivot-column entry of row c0 + k
+                    a[k] -= li * yk;                             // rows <= r collect garbage that is never read
+                }
+                a[j] = (i > r) ? li : a[j];                      // L below the pivot, the pivot itself stays in lane r
+            }
+#pragma unroll
+            for (int k = 0; k < SP; ++k) {
+                const int col = c0 + k;
+                if (i > col) As[i * LDD3 + col] = a[k];
+                if (i == col) dd[col] = a[k];
+            }
+        }
+        __syncthreads();
+        // rank-16 update of the square to the right / below: A[i][k] -= sum_q L[i][q] d_q L[k][q]   (i >= k >= c0 + 16)
+        const int m = NB - c0 - SP;
+        for (int e = tid; e < m * m; e += 1024) {
+            const int ii = c0 + SP + e / m, kk = c0 + SP + e % m;
+            if (ii >= kk) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < SP; ++q) acc += As[ii * LDD3 + c0 + q] * (As[kk * LDD3 + c0 + q] * dd[c0 + q]);
+                As[ii * LDD3 + kk] -= acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < NB) Dx[tid] = dd[tid];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        if (i > k) S[i + (size_t)k * ld] = As[i * LDD3 + k];
+    }
+    // (a) the four 16 x 16 diagonal blocks of X
+    if (cg < 4 && i < 16) {
+        const int o = 16 * cg;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = (r == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < r; ++k) acc -= As[(o + r) * LDD3 + o + k] * x[k];
+            x[r] = (r >= i) ? acc : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Xs[(o + r) * LDD3 + o + i] = x[r];
+    }
+    __syncthreads();
+    {
+        const int p = tid >> 8, ii = (tid >> 4) & 15, jj2 = tid & 15, o = 32 * p;
+        double t = 0.0;
+        if (tid < 512) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += As[(o + 16 + ii) * LDD3 + o + k] * Xs[(o + k) * LDD3 + o + jj2];
+            Ts[(p * 16 + ii) * 33 + jj2] = t;
+        }
+        __syncthreads();
+        if (tid < 512) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v -= Xs[(o + 16 + ii) * LDD3 + o + 16 + k] * Ts[(p * 16 + k) * 33 + jj2];
+            Xs[(o + 16 + ii) * LDD3 + o + jj2] = v;
+        }
+        __syncthreads();
+    }
+    {
+        const int ii = tid >> 5, jj2 = tid & 31;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += As[(32 + ii) * LDD3 + k] * Xs[k * LDD3 + jj2];
+        Ts[ii * 33 + jj2] = t;
+        __syncthreads();
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v -= Xs[(32 + ii) * LDD3 + 32 + k] * Ts[k * 33 + jj2];
+        __syncthreads();
+        Xs[(32 + ii) * LDD3 + jj2] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        Xout[i + k * NB] = Xs[i * LDD3 + k];
+    }
+}
+
 // v5 = v4 templated on the number of wavefronts (v3 + unmasked column updates, finished columns stashed in LDS, per-lane reciprocal vector): LDL^T loop without the inverse; X = L^-1 afterwards by 16 x 16 wave-synchronous inversions + two merge levels in LDS
 
 template <int WAVES>
@@ -605,6 +733,7 @@ int main() {
     run("skeleton  1 wave + rcp", k_skeleton<1,1>, 64, A, false);
     run("v3: LDL loop + blocked inverse", k_diag_v3, 1024, A, true);
     run("v4: v3 + unmasked/stash/rcp-vector", k_diag_v4, 1024, A, true);
+    run("v6: 16-col sub-panels in one wave (readlane)", k_diag_v6, 1024, A, true);
     run("v5 16 waves", k_diag_v5<16>, 1024, A, true);
     run("v5  8 waves", k_diag_v5<8>, 512, A, true);
     run("v5  4 waves", k_diag_v5<4>, 256, A, true);

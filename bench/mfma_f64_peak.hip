@@ -24,6 +24,42 @@ __global__ __launch_bounds__(256) void k(int iters, double* out, long long* clk)
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
 }
 
+// the 4x4x4 (4 blocks) form: 512 flop per instruction, one accumulator double per lane
+template <int NACC>
+__global__ __launch_bounds__(256) void k4(int iters, double* out, long long* clk) {
+    double acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    double a = threadIdx.x * 1e-3, b = blockIdx.x * 1e-3 + 1.0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = 0; clk[1] = 0; }
+}
+template <int NACC>
+void run4(int blocks_per_cu, int iters) {
+    const int blocks = 256 * blocks_per_cu;
+    double* out; long long* clk;
+    hipMalloc(&out, sizeof(double) * blocks * 256);
+    hipMalloc(&clk, 16);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k4<NACC><<<blocks, 256>>>(iters, out, clk);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k4<NACC><<<blocks, 256>>>(iters, out, clk);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 2.0 * 4 * 4 * 4 * 4 * (double)NACC * iters * 4.0 * blocks;
+    printf("4x4x4: acc=%2d waves/SIMD=%d iters=%d: %8.3f ms  %6.2f TFLOP/s\n", NACC, blocks_per_cu, iters, ms, flop / ms * 1e-9);
+    hipFree(out); hipFree(clk);
+}
+
 template <int NACC>
 void run(int blocks_per_cu, int iters) {
     const int blocks = 256 * blocks_per_cu;
@@ -53,5 +89,6 @@ int main() {
     printf("%s  CUs=%d  clockRate=%d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
     run<1>(1, 20000); run<4>(1, 20000); run<8>(1, 20000); run<16>(1, 10000);
     run<4>(2, 20000); run<8>(2, 20000); run<4>(4, 10000); run<4>(8, 5000);
+    run4<4>(1, 40000); run4<16>(1, 20000); run4<8>(2, 20000); run4<8>(4, 20000); run4<16>(4, 10000); run4<8>(8, 10000);
     return 0;
 }
