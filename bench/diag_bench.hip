@@ -429,6 +429,8 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
 }
+__device__ long long g_ts[32];
+#define TS(n) do { if (tid == 0) g_ts[n] = wall_clock64(); } while (0)
 __global__ __launch_bounds__(1024) void k_diag_v6(int ld, double* __restrict__ S, double* __restrict__ Dx, double* __restrict__ Xout) {
     constexpr int WAVES = 16, CPW = 4, SP = 16;
     __shared__ double As[NB * LDD3];    // working matrix, row-major As[i][k]; ends as L (strictly lower) with the pivots in dd
@@ -442,10 +444,13 @@ __global__ __launch_bounds__(1024) void k_diag_v6(int ld, double* __restrict__ S
         As[i * LDD3 + k] = (i >= k) ? S[i + (size_t)k * ld] : 0.0;
         Xs[i * LDD3 + k] = 0.0;
     }
+    TS(0);
     __syncthreads();
+    TS(1);
 #pragma unroll 1
     for (int p = 0; p < NB / SP; ++p) {
         const int c0 = SP * p;
+        TS(2 + 3 * p);
         if (cg == 0) {
             // lane i = row i (rows >= c0 take part); a[k] = A[i][c0 + k]; the 16 x 16 diagonal sub-block is held with BOTH triangles
             double a[SP];
@@ -474,7 +479,9 @@ __global__ __launch_bounds__(1024) void k_diag_v6(int ld, double* __restrict__ S
                 if (i == col) dd[col] = a[k];
             }
         }
+        TS(3 + 3 * p);
         __syncthreads();
+        TS(4 + 3 * p);
         // rank-16 update of the square to the right / below: A[i][k] -= sum_q L[i][q] d_q L[k][q]   (i >= k >= c0 + 16)
         const int m = NB - c0 - SP;
         for (int e = tid; e < m * m; e += 1024) {
@@ -488,12 +495,14 @@ __global__ __launch_bounds__(1024) void k_diag_v6(int ld, double* __restrict__ S
         }
         __syncthreads();
     }
+    TS(14);
     if (tid < NB) Dx[tid] = dd[tid];
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
         const int k = cg + WAVES * c;
         if (i > k) S[i + (size_t)k * ld] = As[i * LDD3 + k];
     }
+    TS(15);
     // (a) the four 16 x 16 diagonal blocks of X
     if (cg < 4 && i < 16) {
         const int o = 16 * cg;
@@ -540,11 +549,186 @@ __global__ __launch_bounds__(1024) void k_diag_v6(int ld, double* __restrict__ S
         Xs[(32 + ii) * LDD3 + jj2] = v;
     }
     __syncthreads();
+    TS(16);
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
         const int k = cg + WAVES * c;
         Xout[i + k * NB] = Xs[i * LDD3 + k];
     }
+    TS(17);
+}
+
+
+// v7: recursion at 16 columns with the pivot row broadcast by DPP.  Per 16-column stage:
+//   (A) wavefront 0 factors the 16 x 16 diagonal sub-block: lane & 15 = row, both triangles in 16 registers, the pivot row of every
+//       step reaches the other lanes of the 16-lane DPP row by row_newbcast (plain VALU, no SGPR round trip, no barrier);
+//   (B) the same wavefront then solves the rows below (lane = row): Y21 = A21 L11^-T, L21 = Y21 D^-1, with the L11 entries read from LDS
+//       as broadcasts;
+//   (C) all wavefronts apply the rank-16 update to the rest of the block on the matrix cores (one 16 x 16 tile per wavefront).
+// Two workgroup barriers per 16 columns.  The 16 x 16 inverses of X = L^-1 are formed by wavefront 1 while wavefront 0 works on the next stage.
+typedef double v4d_ __attribute__((ext_vector_type(4)));
+template <int N> __device__ __forceinline__ double bcast16(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + N, 0xf, 0xf, false);    // row_newbcast:N
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int J> struct Step16 {
+    static __device__ __forceinline__ void run(double (&a)[16], int r16) {
+        const double d = bcast16<J>(a[J]);
+        const double rinv = fast_rcp(d);
+        const double li = a[J] * rinv;
+        step_cols<J + 1>(a, li);
+        a[J] = (r16 > J) ? li : a[J];
+        Step16<J + 1>::run(a, r16);
+    }
+    template <int K> static __device__ __forceinline__ void step_cols(double (&a)[16], double li) {
+        if constexpr (K < 16) { a[K] -= li * bcast16<J>(a[K]); step_cols<K + 1>(a, li); }
+    }
+};
+template <> struct Step16<16> { static __device__ __forceinline__ void run(double (&)[16], int) {} };
+
+// inverse of the unit-lower 16 x 16 block at (o, o) of L (row-major, ld LDD3): lane c < 16 builds column c by forward substitution
+__device__ __forceinline__ void inv16(const double* __restrict__ Lm, double* __restrict__ Xm, int o, int c) {
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        double acc = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) acc -= Lm[(o + r) * LDD3 + o + k] * x[k];
+        x[r] = (r >= c) ? acc : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Xm[(o + r) * LDD3 + o + c] = x[r];
+}
+
+__global__ __launch_bounds__(1024) void k_diag_v7(int ld, double* __restrict__ S, double* __restrict__ Dx, double* __restrict__ Xout) {
+    constexpr int WAVES = 16, CPW = 4, SP = 16;
+    __shared__ double As[NB * LDD3];    // working matrix, row-major As[i][k]; ends as L (strictly lower)
+    __shared__ double Xs[NB * LDD3];
+    __shared__ double Ts[32 * 33];      // Y panel (48 x 16, ld 17) during the stages, merge scratch afterwards
+    __shared__ double dd[NB], rd[NB];
+    const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
+    const int fr = i & 15, fk = i >> 4;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        As[i * LDD3 + k] = (i >= k) ? S[i + (size_t)k * ld] : 0.0;
+        Xs[i * LDD3 + k] = 0.0;
+    }
+    TS(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < NB / SP; ++p) {
+        const int c0 = SP * p;
+        const int m = NB - c0 - SP;                  // rows / columns to the right of this stage
+        TS(1 + 3 * p);
+        if (cg == 0) {
+            // (A) diagonal sub-block
+            const int row = c0 + fr;
+            double a[SP];
+#pragma unroll
+            for (int k = 0; k < SP; ++k) a[k] = (fr >= k) ? As[row * LDD3 + c0 + k] : As[(c0 + k) * LDD3 + row];
+            Step16<0>::run(a, fr);
+            if (i < SP) {
+#pragma unroll
+                for (int k = 0; k < SP; ++k) {
+                    if (fr > k) As[row * LDD3 + c0 + k] = a[k];
+                    if (fr == k) { dd[row] = a[k]; rd[row] = fast_rcp(a[k]); }
+                }
+            }
+            // (B) rows below: lane = row c0 + 16 + i
+            const int rb = c0 + SP + i;
+            if (i < m) {
+                double y[SP];
+#pragma unroll
+                for (int k = 0; k < SP; ++k) y[k] = As[rb * LDD3 + c0 + k];
+#pragma unroll
+                for (int k = 1; k < SP; ++k) {
+#pragma unroll
+                    for (int q = 0; q < k; ++q) y[k] -= y[q] * As[(c0 + k) * LDD3 + c0 + q];     // uniform address: LDS broadcast
+                }
+#pragma unroll
+                for (int k = 0; k < SP; ++k) { Ts[i * 17 + k] = y[k]; As[rb * LDD3 + c0 + k] = y[k] * rd[c0 + k]; }
+            }
+        } else if (cg == 1 && p > 0 && i < 16) {
+            inv16(As, Xs, c0 - SP, i);               // inverse of the previous diagonal sub-block (final since the last barrier)
+        }
+        TS(2 + 3 * p);
+        __syncthreads();
+        // (C) A22 -= L21 Y21' on the matrix cores: lower tiles (ti >= tj) of the (m/16)^2 tiling, one per wavefront
+        {
+            const int nt = m / 16;
+            int ti = 0, tj = 0, t = cg;
+            bool have = false;
+            for (int a_ = 0; a_ < nt && !have; ++a_) { if (t <= a_) { ti = a_; tj = t; have = true; } else t -= a_ + 1; }
+            if (have) {
+                const int r0 = c0 + SP + 16 * ti, j0 = c0 + SP + 16 * tj;
+                v4d_ acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = As[(r0 + fk + 4 * r) * LDD3 + j0 + fr];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double av = -As[(r0 + fr) * LDD3 + c0 + 4 * kk + fk];                  // A[i = fr][k = fk] = -L
+                    const double bv = Ts[(16 * tj + fr) * 17 + 4 * kk + fk];                     // B[k = fk][j = fr] = Y[j][k]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) As[(r0 + fk + 4 * r) * LDD3 + j0 + fr] = acc[r];
+            }
+        }
+        TS(3 + 3 * p);
+        __syncthreads();
+    }
+    TS(13);
+    if (tid < NB) Dx[tid] = dd[tid];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        if (i > k) S[i + (size_t)k * ld] = As[i * LDD3 + k];
+    }
+    if (cg == 1 && i < 16) inv16(As, Xs, 48, i);
+    TS(14);
+    __syncthreads();
+    {
+        const int p = tid >> 8, ii = (tid >> 4) & 15, jj2 = tid & 15, o = 32 * p;
+        double t = 0.0;
+        if (tid < 512) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += As[(o + 16 + ii) * LDD3 + o + k] * Xs[(o + k) * LDD3 + o + jj2];
+            Ts[(p * 16 + ii) * 33 + jj2] = t;
+        }
+        __syncthreads();
+        if (tid < 512) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v -= Xs[(o + 16 + ii) * LDD3 + o + 16 + k] * Ts[(p * 16 + k) * 33 + jj2];
+            Xs[(o + 16 + ii) * LDD3 + o + jj2] = v;
+        }
+        __syncthreads();
+    }
+    TS(15);
+    {
+        const int ii = tid >> 5, jj2 = tid & 31;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += As[(32 + ii) * LDD3 + k] * Xs[k * LDD3 + jj2];
+        Ts[ii * 33 + jj2] = t;
+        __syncthreads();
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v -= Xs[(32 + ii) * LDD3 + 32 + k] * Ts[k * 33 + jj2];
+        __syncthreads();
+        Xs[(32 + ii) * LDD3 + jj2] = v;
+    }
+    __syncthreads();
+    TS(16);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int k = cg + WAVES * c;
+        Xout[i + k * NB] = Xs[i * LDD3 + k];
+    }
+    TS(17);
 }
 
 // v5 = v4 templated on the number of wavefronts (v3 + unmasked column updates, finished columns stashed in LDS, per-lane reciprocal vector): LDL^T loop without the inverse; X = L^-1 afterwards by 16 x 16 wave-synchronous inversions + two merge levels in LDS
@@ -734,6 +918,9 @@ int main() {
     run("v3: LDL loop + blocked inverse", k_diag_v3, 1024, A, true);
     run("v4: v3 + unmasked/stash/rcp-vector", k_diag_v4, 1024, A, true);
     run("v6: 16-col sub-panels in one wave (readlane)", k_diag_v6, 1024, A, true);
+    { long long h[32]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts), sizeof(h)); printf("v6 timeline (10 ns ticks from start):"); for (int q = 0; q < 18; ++q) printf(" [%d]%lld", q, h[q] - h[0]); printf("\n"); }
+    run("v7: 16-col stages, DPP pivot broadcast, MFMA update", k_diag_v7, 1024, A, true);
+    { long long h[32]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts), sizeof(h)); printf("v7 timeline (10 ns ticks from start):"); for (int q = 0; q < 18; ++q) printf(" [%d]%lld", q, h[q] - h[0]); printf("\n"); }
     run("v5 16 waves", k_diag_v5<16>, 1024, A, true);
     run("v5  8 waves", k_diag_v5<8>, 512, A, true);
     run("v5  4 waves", k_diag_v5<4>, 256, A, true);

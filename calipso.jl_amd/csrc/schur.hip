@@ -142,13 +142,18 @@ void launch_scale_rows(calipso_hip_solver* s) {
 //                            D: lane l, register r holds D[row = (l>>4) + 4r][col = l&15].
 // blockIdx -> tile is XCD-aware: the 8 XCDs each get a contiguous band of tile rows, so the operand columns a band
 // needs are shared through that XCD's L2 instead of being fetched by all eight.
-// fp64 MFMA on gfx950 needs >= 4 wavefronts per SIMD to keep the matrix pipe busy (bench/mfma_f64_peak.hip: one wave per
-// SIMD reaches 36 TFLOP/s, four reach 47-49), so the workgroup is 1024 threads = 16 wavefronts.
-// Tile = 128 rows x TJ columns of the lower triangle, TJ = 16 nj with nj in 4..8 chosen on the host so that the tiles that
-// intersect the triangle fill the 256 CUs in as few, as small rounds as possible (C3: 128 x 112 -> 249 tiles, one round;
-// 128 x 128 would be 210 tiles at 8/7 the tile time).  The 8 x nj MFMA tiles of a workgroup are dealt so that every SIMD gets
-// 2 nj of them: wavefront w < 8 owns row-tile w and the first ceil(nj/2) column tiles, wavefront w >= 8 owns row-tile w-8 and
-// the rest (consecutive groups of four wavefronts sit on the four SIMDs).
+// The matrix-core instruction is v_mfma_f64_4x4x4_f64 (four independent 4 x 4 x 4 blocks per instruction), NOT the 16 x 16 x 4 form:
+// back-to-back independent 4x4x4 instructions sustain 76 TFLOP/s on this chip (97 % of the 78.6 datasheet rate) where the
+// 16x16x4 form tops out at 47-49 (bench/mfma_f64_peak.hip, profiles/r02_mfma_f64_peak.txt).  Lane layout (found with
+// bench/mfma_f64_4x4x4_probe.hip; the guides only give the 16x16x4 one): lane l = 16 k + 4 b + x,
+//     A operand: A_b[i = x][k]        B operand: B_b[k][j = x]        D: lane 16 i + 4 b + j holds D_b[i][j]     (b = block 0..3)
+// A 16 x 16 x 4 product is four such instructions: instruction r takes rows 4r..4r+3 of the first operand REPLICATED over the four
+// blocks (lanes that differ only in b read the same LDS address: a broadcast) and the second operand in the standard "lane & 15 =
+// column, lane >> 4 = k" layout, so that block b yields columns 4b..4b+3; its result register then maps exactly as register r of
+// the 16x16x4 form (row = (lane >> 4) + 4 r, col = lane & 15).
+// Workgroup = 1024 threads = 16 wavefronts (>= 4 per SIMD keep the matrix pipe busy).  Tile = 128 rows x TJ columns of the lower
+// triangle, TJ = 16 nj, nj <= 8.  Wavefront w owns column tile w % nj and the four row tiles 4 (w / nj) .. + 3 (w / nj < 2): the one
+// operand that has to be fetched in the 4-register replicated form is then shared by 16 instructions per k-step.
 constexpr int KT = 32;
 constexpr int LDK = KT + 2;
 constexpr int SCHUR_THREADS = 1024;
@@ -248,17 +253,18 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
     else schur_tile(t, d.nx, TJ, bi, bj);
     const int i0 = bi * TILE, j0 = bj * TJ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave & 7;                          // row tile (16 rows) of this wavefront
-    const int nlo = (nj + 1) >> 1;
-    const int jt0 = wave < 8 ? 0 : nlo;               // first column tile
-    const int jcnt = wave < 8 ? nlo : nj - nlo;       // number of column tiles (<= 4)
-    const int fr = lane & 15, fk = lane >> 4;
+    const int cj = wave % nj;                         // column tile (16 columns of S) of this wavefront
+    const int rg = wave / nj;                         // its row tiles: 4 rg .. 4 rg + 3   (wavefronts with rg >= 2 only help with the loads)
+    const bool mma = rg < 2;
+    const int fr = lane & 15, fk = lane >> 4, fx = lane & 3;
 
-    // acc[n]: MFMA row index <-> column j of S, MFMA column index (the 16-lane fast index) <-> row i of S, so that the
-    // epilogue's stores are 128-byte contiguous runs of the column-major S
-    v4d acc[4];
+    // acc[m][r]: row tile m, register r.  MFMA row index <-> column j of S (= 4 r + (lane >> 4) inside the column tile), MFMA column
+    // index (the 16-lane fast index) <-> row i of S, so that the epilogue's stores are 128-byte contiguous runs of the column-major S
+    double acc[4][4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int m_ = 0; m_ < 4; ++m_)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m_][r] = 0.0;
 
     const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
     // constraint rows that touch both the tile's rows (as columns of the Jacobians) and its columns
@@ -296,30 +302,34 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
             stage_store(An + TILE * LDK, rb, tid);
         }
         if (st + 2 < nst) fetch(st + 2);
+        if (mma) {
 #pragma unroll
-        for (int kk = 0; kk < KT / 4; ++kk) {
-            const double a = As[(wi * 16 + fr) * LDK + kk * 4 + fk];
-            double b[4];
+            for (int kk = 0; kk < KT / 4; ++kk) {
+                double bq[4], a[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = Bs[((jt0 + n) * 16 + fr) * LDK + kk * 4 + fk];   // rows beyond the tile are zero-filled
+                for (int r = 0; r < 4; ++r) bq[r] = Bs[(cj * 16 + 4 * r + fx) * LDK + kk * 4 + fk];     // replicated form (columns beyond the tile are zero-filled)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                if (n < jcnt) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a, acc[n], 0, 0, 0);   // wavefront-uniform
+                for (int m_ = 0; m_ < 4; ++m_) a[m_] = As[((4 * rg + m_) * 16 + fr) * LDK + kk * 4 + fk];
+#pragma unroll
+                for (int m_ = 0; m_ < 4; ++m_)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[m_][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bq[r], a[m_], acc[m_][r], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
     // epilogue: + Lxx (through its upper triangle, as triu(K)) + ep on the diagonal; identity in the padding
+    if (!mma) return;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        if (n >= jcnt) break;
+    for (int m_ = 0; m_ < 4; ++m_) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int gj = j0 + (jt0 + n) * 16 + fk + 4 * r;   // MFMA row
-            const int gi = i0 + wi * 16 + fr;                  // MFMA column: contiguous rows of S
+            const int gj = j0 + cj * 16 + fk + 4 * r;            // MFMA row
+            const int gi = i0 + (4 * rg + m_) * 16 + fr;         // MFMA column: contiguous rows of S
             if (gi >= d.NP || gj >= d.NP) continue;
             double v;
             if (gi < d.nx && gj < d.nx) {
-                v = acc[n][r] + Lsym[gi + (size_t)gj * d.nx];   // = Lxx[min, max]: triu(K) mirrored (k_symmetrize_upper)
+                v = acc[m_][r] + Lsym[gi + (size_t)gj * d.nx];   // = Lxx[min, max]: triu(K) mirrored (k_symmetrize_upper)
                 if (gi == gj) v += sc.ep;
             } else {
                 v = (gi == gj) ? 1.0 : 0.0;
@@ -374,8 +384,8 @@ void launch_symmetrize(calipso_hip_solver* s) {
 }
 
 // host: tile shape for a launch that covers `instances` problem instances.  Tile = 128 x 16 nj; the cost of a launch is the
-// number of rounds over the 256 CUs times the per-SIMD MFMA count of a tile (C3: one instance -> 128 x 112, 249 tiles, one round;
-// groups -> 128 x 128, fewer wasted columns and the per-stage overhead amortised over more matrix work)
+// number of rounds over the 256 CUs times the matrix-core time of a tile, which is set by the busiest SIMD: 2 nj wavefronts issue
+// 16 instructions per k-step each and are spread round-robin over the 4 SIMDs => ceil(nj / 2) wavefronts on the busiest one
 static int schur_tiles(int nx, int nj, int hb) {
     const int TJ = 16 * nj, nbi = (nx + TILE - 1) / TILE;
     int cnt = 0;
@@ -390,7 +400,7 @@ static int schur_choose(int nx, int instances, int hb) {
     long best_cost = -1; int best = 8;
     for (int nj = 4; nj <= 8; ++nj) {
         const long cnt = (long)schur_tiles(nx, nj, hb) * instances;
-        const long cost = ((cnt + 255) / 256) * nj;
+        const long cost = ((cnt + 255) / 256) * ((nj + 1) / 2);
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = nj; }   // ties: the larger tile
     }
     return best;
