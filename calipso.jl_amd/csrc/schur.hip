@@ -142,18 +142,16 @@ void launch_scale_rows(calipso_hip_solver* s) {
 //                            D: lane l, register r holds D[row = (l>>4) + 4r][col = l&15].
 // blockIdx -> tile is XCD-aware: the 8 XCDs each get a contiguous band of tile rows, so the operand columns a band
 // needs are shared through that XCD's L2 instead of being fetched by all eight.
-// The matrix-core instruction is v_mfma_f64_4x4x4_f64 (four independent 4 x 4 x 4 blocks per instruction), NOT the 16 x 16 x 4 form:
-// back-to-back independent 4x4x4 instructions sustain 76 TFLOP/s on this chip (97 % of the 78.6 datasheet rate) where the
-// 16x16x4 form tops out at 47-49 (bench/mfma_f64_peak.hip, profiles/r02_mfma_f64_peak.txt).  Lane layout (found with
-// bench/mfma_f64_4x4x4_probe.hip; the guides only give the 16x16x4 one): lane l = 16 k + 4 b + x,
-//     A operand: A_b[i = x][k]        B operand: B_b[k][j = x]        D: lane 16 i + 4 b + j holds D_b[i][j]     (b = block 0..3)
-// A 16 x 16 x 4 product is four such instructions: instruction r takes rows 4r..4r+3 of the first operand REPLICATED over the four
-// blocks (lanes that differ only in b read the same LDS address: a broadcast) and the second operand in the standard "lane & 15 =
-// column, lane >> 4 = k" layout, so that block b yields columns 4b..4b+3; its result register then maps exactly as register r of
-// the 16x16x4 form (row = (lane >> 4) + 4 r, col = lane & 15).
-// Workgroup = 1024 threads = 16 wavefronts (>= 4 per SIMD keep the matrix pipe busy).  Tile = 128 rows x TJ columns of the lower
-// triangle, TJ = 16 nj, nj <= 8.  Wavefront w owns column tile w % nj and the four row tiles 4 (w / nj) .. + 3 (w / nj < 2): the one
-// operand that has to be fetched in the 4-register replicated form is then shared by 16 instructions per k-step.
+// Workgroup = 1024 threads = 16 wavefronts.  Tile = 128 rows x TJ columns of the lower triangle, TJ = 16 nj <= 128.  Wavefront w owns
+// row tile w & 7 and the four column tiles 4 (w >> 3) .. + 3: EVERY wavefront runs the same branch-free instruction stream
+// (5 ds_read_b64 + 4 MFMAs per k-step); column tiles beyond the tile width are zero-filled in LDS and dropped in the epilogue.
+// (Round 1 dealt the column tiles by `if (n < jcnt)`: wave-uniform, but the compiler turned every MFMA into its own exec-masked basic
+// block with an s_waitcnt lgkmcnt(0) in front, which serialised LDS reads and matrix instructions — 36 TFLOP/s; the stage loop of this
+// kernel in isolation, bench/schur_loop_bench.hip, sustains 61.)  Global addresses are a wave-uniform base (scalar registers,
+// advanced per stage by scalar adds) plus a per-thread 32-bit offset that is constant over the stages, and the bounds predicates are
+// only evaluated for the stages / tiles that touch an edge: the vector ALU work per stage is a handful of instructions.
+// fp64 matrix-core ceiling: bench/mfma444_loop.hip — 75 TFLOP/s for back-to-back v_mfma_f64_16x16x4_f64 with distinct operands
+// (the 47-49 of bench/mfma_f64_peak.hip comes from issuing the SAME source registers back to back), 76 for the 4x4x4 form.
 constexpr int KT = 32;
 constexpr int LDK = KT + 2;
 constexpr int SCHUR_THREADS = 1024;
@@ -182,6 +180,12 @@ __device__ __forceinline__ void stage_fetch(double (&r)[SLD], const double* __re
         const int gk = k0 + k, gc = c0 + c;
         r[it] = (gk < kmax && gc < ncols && c < width) ? scale * M[gk + (size_t)gc * ldm] : 0.0;
     }
+}
+// the same block when it lies entirely inside the matrix: base = M + k0 + c0 * ldm is wave-uniform, off[it] (in doubles) is the thread's
+// constant offset of its it-th element
+__device__ __forceinline__ void stage_fetch_full(double (&r)[SLD], const double* __restrict__ base, const unsigned (&off)[SLD], double scale) {
+#pragma unroll
+    for (int it = 0; it < SLD; ++it) r[it] = scale * base[off[it]];
 }
 // registers -> LDS, k fastest: dst[c][k]
 __device__ __forceinline__ void stage_store(double* dst, const double (&r)[SLD], int tid) {
@@ -253,18 +257,15 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
     else schur_tile(t, d.nx, TJ, bi, bj);
     const int i0 = bi * TILE, j0 = bj * TJ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cj = wave % nj;                         // column tile (16 columns of S) of this wavefront
-    const int rg = wave / nj;                         // its row tiles: 4 rg .. 4 rg + 3   (wavefronts with rg >= 2 only help with the loads)
-    const bool mma = rg < 2;
-    const int fr = lane & 15, fk = lane >> 4, fx = lane & 3;
+    const int wi = wave & 7;                          // row tile (16 rows) of this wavefront
+    const int jt0 = (wave >> 3) * 4;                  // its column tiles jt0 .. jt0 + 3 (those >= nj hold zeros and are dropped at the end)
+    const int fr = lane & 15, fk = lane >> 4;
 
-    // acc[m][r]: row tile m, register r.  MFMA row index <-> column j of S (= 4 r + (lane >> 4) inside the column tile), MFMA column
-    // index (the 16-lane fast index) <-> row i of S, so that the epilogue's stores are 128-byte contiguous runs of the column-major S
-    double acc[4][4];
+    // acc[n]: MFMA row index <-> column j of S, MFMA column index (the 16-lane fast index) <-> row i of S, so that the
+    // epilogue's stores are 128-byte contiguous runs of the column-major S
+    v4d acc[4];
 #pragma unroll
-    for (int m_ = 0; m_ < 4; ++m_)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[m_][r] = 0.0;
+    for (int n = 0; n < 4; ++n) acc[n] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
     // constraint rows that touch both the tile's rows (as columns of the Jacobians) and its columns
@@ -280,10 +281,27 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
         cst0 = lo / KT; nst = nst0 + (hi > lo ? (hi + KT - 1) / KT - cst0 : 0);
     }
     double ra[SLD], rb[SLD];
+    // per-thread offsets (doubles) of its SLD elements inside a stage block, for the two leading dimensions in use (m for gx / hx, nc for WH)
+    unsigned offm[SLD], offc[SLD];
+    {
+        const int k = tid % KT, cbase = tid / KT;
+#pragma unroll
+        for (int it = 0; it < SLD; ++it) {
+            const unsigned c = (unsigned)(cbase + it * (SCHUR_THREADS / KT));
+            offm[it] = (unsigned)k + c * (unsigned)d.m;
+            offc[it] = (unsigned)k + c * (unsigned)d.nc;
+        }
+    }
+    const bool rows_full = i0 + TILE <= d.nx, cols_full = (TJ == TILE) && j0 + TJ <= d.nx;      // the tile's operand columns all exist
     auto fetch = [&](int st) {
         const SchurStage g = schur_stage(st, nst0, est0, cst0, d, gx, hx, WH, omega_y);
-        stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, TILE, tid, 1.0);
-        stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, TJ, tid, g.bscale);
+        const bool kfull = g.k0 + KT <= g.kmax;                                                  // wave-uniform
+        if (kfull && rows_full) stage_fetch_full(ra, g.MA + g.k0 + (size_t)i0 * g.lda, offm, 1.0);
+        else stage_fetch(ra, g.MA, g.lda, g.kmax, d.nx, g.k0, i0, TILE, tid, 1.0);
+        if (kfull && cols_full) {
+            if (g.ldb == d.m) stage_fetch_full(rb, g.MB + g.k0 + (size_t)j0 * g.ldb, offm, g.bscale);
+            else stage_fetch_full(rb, g.MB + g.k0 + (size_t)j0 * g.ldb, offc, g.bscale);
+        } else stage_fetch(rb, g.MB, g.ldb, g.kmax, d.nx, g.k0, j0, TJ, tid, g.bscale);
     };
     if (nst > 0) {
         fetch(0);
@@ -302,34 +320,29 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
             stage_store(An + TILE * LDK, rb, tid);
         }
         if (st + 2 < nst) fetch(st + 2);
-        if (mma) {
 #pragma unroll
-            for (int kk = 0; kk < KT / 4; ++kk) {
-                double bq[4], a[4];
+        for (int kk = 0; kk < KT / 4; ++kk) {
+            const double a = As[(wi * 16 + fr) * LDK + kk * 4 + fk];
+            double b[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bq[r] = Bs[(cj * 16 + 4 * r + fx) * LDK + kk * 4 + fk];     // replicated form (columns beyond the tile are zero-filled)
+            for (int n = 0; n < 4; ++n) b[n] = Bs[((jt0 + n) * 16 + fr) * LDK + kk * 4 + fk];   // rows beyond the tile are zero-filled
 #pragma unroll
-                for (int m_ = 0; m_ < 4; ++m_) a[m_] = As[((4 * rg + m_) * 16 + fr) * LDK + kk * 4 + fk];
-#pragma unroll
-                for (int m_ = 0; m_ < 4; ++m_)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[m_][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bq[r], a[m_], acc[m_][r], 0, 0, 0);
-            }
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a, acc[n], 0, 0, 0);
         }
         __syncthreads();
     }
     // epilogue: + Lxx (through its upper triangle, as triu(K)) + ep on the diagonal; identity in the padding
-    if (!mma) return;
 #pragma unroll
-    for (int m_ = 0; m_ < 4; ++m_) {
+    for (int n = 0; n < 4; ++n) {
+        if (jt0 + n >= nj) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int gj = j0 + cj * 16 + fk + 4 * r;            // MFMA row
-            const int gi = i0 + (4 * rg + m_) * 16 + fr;         // MFMA column: contiguous rows of S
+            const int gj = j0 + (jt0 + n) * 16 + fk + 4 * r;   // MFMA row
+            const int gi = i0 + wi * 16 + fr;                  // MFMA column: contiguous rows of S
             if (gi >= d.NP || gj >= d.NP) continue;
             double v;
             if (gi < d.nx && gj < d.nx) {
-                v = acc[m_][r] + Lsym[gi + (size_t)gj * d.nx];   // = Lxx[min, max]: triu(K) mirrored (k_symmetrize_upper)
+                v = acc[n][r] + Lsym[gi + (size_t)gj * d.nx];   // = Lxx[min, max]: triu(K) mirrored (k_symmetrize_upper)
                 if (gi == gj) v += sc.ep;
             } else {
                 v = (gi == gj) ? 1.0 : 0.0;
@@ -383,9 +396,9 @@ void launch_symmetrize(calipso_hip_solver* s) {
     hipLaunchKernelGGL(k_symmetrize_upper, dim3(nt, nt, B.b.n), dim3(32, 8), 0, s->stream, B.b, s->d.nx, s->Lxx, s->Lsym);
 }
 
-// host: tile shape for a launch that covers `instances` problem instances.  Tile = 128 x 16 nj; the cost of a launch is the
-// number of rounds over the 256 CUs times the matrix-core time of a tile, which is set by the busiest SIMD: 2 nj wavefronts issue
-// 16 instructions per k-step each and are spread round-robin over the 4 SIMDs => ceil(nj / 2) wavefronts on the busiest one
+// host: tile shape for a launch that covers `instances` problem instances.  Tile = 128 x 16 nj.  Every wavefront issues the same
+// instruction stream whatever nj is, so a tile costs the same for every nj > 4 (two column-tile groups) and half for nj <= 4 (one group
+// does nothing useful but the other still paces the workgroup): the cost of a launch is rounds over the 256 CUs x that.
 static int schur_tiles(int nx, int nj, int hb) {
     const int TJ = 16 * nj, nbi = (nx + TILE - 1) / TILE;
     int cnt = 0;
@@ -400,7 +413,7 @@ static int schur_choose(int nx, int instances, int hb) {
     long best_cost = -1; int best = 8;
     for (int nj = 4; nj <= 8; ++nj) {
         const long cnt = (long)schur_tiles(nx, nj, hb) * instances;
-        const long cost = ((cnt + 255) / 256) * ((nj + 1) / 2);
+        const long cost = ((cnt + 255) / 256) * 8;
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = nj; }   // ties: the larger tile
     }
     return best;
