@@ -4,6 +4,7 @@
 //   loads per thread per stage (register prefetch two stages ahead), as in calipso.jl_amd/csrc/schur.hip.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int LDK = 34, TILE = 128;
 template <bool BAR, bool WR, bool GL, int ACCS>
@@ -67,6 +68,17 @@ template <bool BAR, bool WR, bool GL, int ACCS> void run(const char* name, const
 int main() {
     const int ldg = 2500;
     double* G; hipMalloc(&G, sizeof(double) * (size_t)ldg * (128 * 256 + 256)); hipMemset(G, 0, sizeof(double) * (size_t)ldg * (128 * 256 + 256));
+    run<true, true, true, 4>("k_schur's loop, operands all zero", G, ldg);
+    {   // random operands: fp64 matrix-core power (and with it the sustained clock) depends on the data
+        const size_t n = (size_t)ldg * (128 * 256 + 256);
+        double* h = (double*)malloc(n * sizeof(double));
+        unsigned long long s = 88172645463325252ull;
+        for (size_t i = 0; i < n; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (double)(s >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+        hipMemcpy(G, h, n * sizeof(double), hipMemcpyHostToDevice);
+        free(h);
+    }
+    run<true, true, true, 4>("k_schur's loop, random operands", G, ldg);
+    run<true, true, true, 4>("k_schur's loop, random operands (again)", G, ldg);
     run<false, false, false, 4>("MFMA + 5 ds_read_b64 per k-step", G, ldg);
     run<true, false, false, 4>("+ barrier per stage", G, ldg);
     run<true, true, false, 4>("+ barrier + LDS stores", G, ldg);

@@ -320,14 +320,35 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
             stage_store(An + TILE * LDK, rb, tid);
         }
         if (st + 2 < nst) fetch(st + 2);
+        {
+            // operand fragments by explicit ds_read_b64: the compiler pairs plain loads of consecutive k-steps into ds_read2_b64, which
+            // is banked modulo 32 and conflicts on this layout (45 % of the LDS cycles were conflict replays, rocprofv3 SQ_LDS_BANK_CONFLICT);
+            // ds_read_b64 is conflict-free here.  The loads run one k-step ahead of the matrix instructions; lgkmcnt is tracked by hand
+            // (LDS returns in order) and the wait takes the fragments as in/out operands so that their uses cannot move above it.
+            const unsigned ab = (unsigned)(uintptr_t)(As + (wi * 16 + fr) * LDK + fk);
+            const unsigned bb = (unsigned)(uintptr_t)(Bs + (jt0 * 16 + fr) * LDK + fk);
+            double fa[2], fb[2][4];
+            auto issue = [&](int kk, int buf) {
+                const unsigned ao = ab + kk * 32u, bo = bb + kk * 32u;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(fa[buf]) : "v"(ao) : "memory");
+                asm volatile("ds_read_b64 %0, %1" : "=v"(fb[buf][0]) : "v"(bo) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[buf][1]) : "v"(bo), "n"(16 * LDK * 8) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[buf][2]) : "v"(bo), "n"(32 * LDK * 8) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[buf][3]) : "v"(bo), "n"(48 * LDK * 8) : "memory");
+            };
+            issue(0, 0);
 #pragma unroll
-        for (int kk = 0; kk < KT / 4; ++kk) {
-            const double a = As[(wi * 16 + fr) * LDK + kk * 4 + fk];
-            double b[4];
+            for (int kk = 0; kk < KT / 4; ++kk) {
+                const int cur = kk & 1;
+                if (kk + 1 < KT / 4) {
+                    issue(kk + 1, cur ^ 1);
+                    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa[cur]), "+v"(fb[cur][0]), "+v"(fb[cur][1]), "+v"(fb[cur][2]), "+v"(fb[cur][3]) :: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[cur]), "+v"(fb[cur][0]), "+v"(fb[cur][1]), "+v"(fb[cur][2]), "+v"(fb[cur][3]) :: "memory");
+                }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = Bs[((jt0 + n) * 16 + fr) * LDK + kk * 4 + fk];   // rows beyond the tile are zero-filled
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[n], a, acc[n], 0, 0, 0);
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[cur][n], fa[cur], acc[n], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
