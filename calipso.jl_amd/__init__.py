@@ -12,7 +12,7 @@ import numpy as np
 
 from ._lib import CALLBACK_FN, EVAL_FN, CalipsoHipError, lib
 
-__all__ = ["Solver", "Group", "LDLSolver", "Comm", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform",
+__all__ = ["Solver", "Group", "LDLSolver", "SmallBatch", "Comm", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform",
            "mfma_f64_peak"]
 
 # evaluate! flags (include/calipso_hip.h)
@@ -497,6 +497,62 @@ class LDLSolver:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.calipso_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SmallBatch:
+    """`batch` independent small systems (n <= 128) factored and solved for `nrhs` right-hand sides each in ONE launch, every system
+    resident in the LDS of one workgroup (include/calipso_hip.h, "batched small systems"): the sensitivity solves of differentiate!
+    (src/solver/differentiate.jl:29-58) for many MPC steps at once."""
+
+    def __init__(self, n, nrhs, batch, device=0):
+        self._L = lib()
+        self.n, self.nrhs, self.batch = int(n), int(nrhs), int(batch)
+        h = C.c_void_p()
+        rc = self._L.calipso_hip_small_create(self.n, self.nrhs, self.batch, device, C.byref(h))
+        if rc != 0:
+            msg = self._L.calipso_hip_small_last_error(h if h.value else None).decode()
+            if h.value:
+                self._L.calipso_hip_small_destroy(h)
+            raise CalipsoHipError("calipso_hip_small_create failed (%d): %s" % (rc, msg))
+        self._h = h
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise CalipsoHipError("%s failed (%d): %s" % (what, rc, self._L.calipso_hip_small_last_error(self._h).decode()))
+        return rc
+
+    def set(self, K=None, B=None):
+        """K: (batch, n, n) matrices (only the upper triangles are read); B: (batch, n, nrhs) right-hand sides"""
+        kk = bb = None
+        if K is not None:
+            kk = np.ascontiguousarray(np.transpose(np.asarray(K, dtype=np.float64).reshape(self.batch, self.n, self.n), (0, 2, 1))).reshape(-1)
+        if B is not None:
+            bb = np.ascontiguousarray(np.transpose(np.asarray(B, dtype=np.float64).reshape(self.batch, self.n, self.nrhs), (0, 2, 1))).reshape(-1)
+        self._check(self._L.calipso_hip_small_set(self._h, _pd(kk) if kk is not None else None, _pd(bb) if bb is not None else None), "small_set")
+
+    def solve(self):
+        """factor + solve every instance (one launch); returns the launch duration in milliseconds"""
+        ms = C.c_double(0.0)
+        self._check(self._L.calipso_hip_small_solve(self._h, C.byref(ms)), "small_solve")
+        return float(ms.value)
+
+    def get(self):
+        """(X (batch, n, nrhs), inertia (batch, 3), number of instances that met an exact zero pivot)"""
+        x = np.zeros(self.batch * self.n * self.nrhs)
+        inr = np.zeros(3 * self.batch, dtype=np.int64)
+        bad = self._check(self._L.calipso_hip_small_get(self._h, _pd(x), _pi(inr)), "small_get")
+        return np.transpose(x.reshape(self.batch, self.nrhs, self.n), (0, 2, 1)), inr.reshape(self.batch, 3), bad
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.calipso_hip_small_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

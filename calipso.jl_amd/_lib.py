@@ -66,6 +66,12 @@ SYMBOLS = {
     "calipso_hip_ldl_factorize_csc": (_i32, [_vp, _i64, _pi64, _pi64, _pd, _pi64]),
     "calipso_hip_ldl_inertia": (_i32, [_vp, _pi64]),
     "calipso_hip_ldl_solve": (_i32, [_vp, _i64, _i64, _pd, _pd]),
+    "calipso_hip_small_create": (_i32, [_i64, _i64, _i64, _i32, C.POINTER(_vp)]),
+    "calipso_hip_small_destroy": (_i32, [_vp]),
+    "calipso_hip_small_last_error": (C.c_char_p, [_vp]),
+    "calipso_hip_small_set": (_i32, [_vp, _pd, _pd]),
+    "calipso_hip_small_solve": (_i32, [_vp, _pd]),
+    "calipso_hip_small_get": (_i32, [_vp, _pd, _pi64]),
     "calipso_hip_comm_unique_id": (_i32, [C.POINTER(C.c_uint8)]),
     "calipso_hip_comm_init": (_i32, [_i32, _i32, C.POINTER(C.c_uint8), _i32, C.POINTER(_vp)]),
     "calipso_hip_comm_destroy": (_i32, [_vp]),

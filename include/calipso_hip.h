@@ -247,6 +247,21 @@ int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver*, int64_t n, const int6
 int32_t calipso_hip_ldl_inertia(calipso_hip_solver*, int64_t inertia[3]);
 int32_t calipso_hip_ldl_solve(calipso_hip_solver*, int64_t n, int64_t nrhs, const double* b, double* x);
 
+/* ---- batched small systems (BASELINE config C5): LDS-resident LDL^T + multi-right-hand-side solve, one workgroup per
+ * instance, one launch for the whole batch.  The sensitivity solves of the reference's MPC auto-tuning loop
+ * (examples/autotuning/cartpole.jl:179-227 -> differentiate.jl:29-58: n = 89, 102 parameter columns per step) for thousands of
+ * independent steps at once; semantics of the LinearSolver seam above (only triu(K) read, no pivoting, natural order).
+ *   create(n <= 128, nrhs, batch, device)   set(K[batch][n*n], B[batch][n*nrhs]) column-major host arrays (NULL = keep what is resident)
+ *   solve(&ms)   one launch, inputs resident; ms = its HIP-event duration   get(X[batch][n*nrhs], inertia[batch][3]) -> number of
+ *   instances with an exact zero pivot (inertia as compute_inertia!, linear_solver.jl:33-44) or a negative status */
+typedef struct calipso_hip_small calipso_hip_small;
+int32_t calipso_hip_small_create(int64_t n, int64_t nrhs, int64_t batch, int32_t device, calipso_hip_small** out);
+int32_t calipso_hip_small_destroy(calipso_hip_small*);
+const char* calipso_hip_small_last_error(calipso_hip_small*);
+int32_t calipso_hip_small_set(calipso_hip_small*, const double* K, const double* B);
+int32_t calipso_hip_small_solve(calipso_hip_small*, double* ms);
+int32_t calipso_hip_small_get(calipso_hip_small*, double* X, int64_t* inertia);
+
 /* ---- multi-GPU exchange of the batched path: RCCL over xGMI, one process per GPU ---------------------------------
  * Problem instances are sharded block-contiguously over ranks and never interact (the reference's `Solver`s are independent); the
  * only exchange is after a batch round: all-gather of per-problem status rows, all-reduce of counters.  RCCL is dlopen'ed on first
