@@ -331,6 +331,15 @@ class Solver:
     def differentiate(self):
         self._check(self._L.calipso_hip_differentiate(self._h, self._cb, None), "differentiate")
 
+    def set_device_evaluator(self, fn_ptr, user=None):
+        """install a device-side evaluator (calipso_device_eval_fn, include/calipso_hip.h): `fn_ptr` is the C function's address (e.g.
+        ctypes.cast(lib.sym, c_void_p)), `user` its opaque pointer; solve_b / differentiate then never call back into Python"""
+        self._check(self._L.calipso_hip_set_device_evaluator(self._h, fn_ptr, user), "set_device_evaluator")
+        self._device_eval = fn_ptr is not None
+
+    def device_evaluate(self, flags, which=0):
+        self._check(self._L.calipso_hip_device_evaluate(self._h, which, int(flags)), "device_evaluate")
+
     def set_callbacks(self, inner=None, outer=None):
         """callback_inner(custom, solver) / callback_outer(custom, solver) (src/solver/solver.jl:183,193): python callables taking the Solver"""
         self._cbi = CALLBACK_FN(lambda u, h: inner(self)) if inner else None

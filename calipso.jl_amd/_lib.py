@@ -12,6 +12,7 @@ EVAL_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_double), 
                       C.POINTER(C.c_double))
 
 CALLBACK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+DEVICE_EVAL_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 
 # every symbol include/calipso_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _u32, _u64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
@@ -49,6 +50,8 @@ SYMBOLS = {
     "calipso_hip_initialize": (_i32, [_vp, _pd]),
     "calipso_hip_solve": (_i32, [_vp, EVAL_FN, _vp]),
     "calipso_hip_differentiate": (_i32, [_vp, EVAL_FN, _vp]),
+    "calipso_hip_set_device_evaluator": (_i32, [_vp, C.c_void_p, _vp]),
+    "calipso_hip_device_evaluate": (_i32, [_vp, _i32, _u32]),
     "calipso_hip_set_callbacks": (_i32, [_vp, C.c_void_p, C.c_void_p, _vp]),
     "calipso_hip_stats": (_i32, [_vp, _pi64]),
     "calipso_hip_qp_attach": (_i32, [_vp, _pd, _pd, _pd, _pd, _pd, _pd, _dbl]),

@@ -503,11 +503,41 @@ static int do_cone_search(H* s, double* a_s, double* a_t) {
     return CALIPSO_OK;
 }
 
+// user evaluation on the device: hand the evaluator the device addresses of the point and of the ProblemData fields; it enqueues its
+// kernels on the handle's stream (the launches that follow are ordered behind them) — no download of the point, no upload of blocks
+static int device_evaluate(H* s, const double* pt, uint32_t flags) {
+    const Dims& d = s->d;
+    calipso_device_problem_data o;
+    o.objective = s->dscal + 0;
+    o.objective_gradient_variables = s->fx;
+    o.equality_constraint = d.ne ? s->g : nullptr;
+    o.cone_constraint = d.nc ? s->hc : nullptr;
+    o.equality_dual_jacobian_variables = s->gyx;
+    o.cone_dual_jacobian_variables = s->hzx;
+    o.lagrangian_hessian = s->Lxx;
+    o.equality_jacobian_variables = d.ne ? s->gx : nullptr;
+    o.cone_jacobian_variables = d.nc ? s->hx : nullptr;
+    o.jacobian_ld = d.m;
+    o.lagrangian_gradient_parameters = d.np ? s->lgp : nullptr;
+    o.equality_jacobian_parameters = (d.np && d.ne) ? s->gp : nullptr;
+    o.cone_jacobian_parameters = (d.np && d.nc) ? s->hp : nullptr;
+    o.nx = d.nx; o.np = d.np; o.ne = d.ne; o.nc = d.nc;
+    const int rc = s->dev_eval(s->dev_eval_user, flags, pt, pt + d.oy(), pt + d.oz(), s->parameters, &o, (void*)s->stream);
+    if (rc != 0) { s->err = "device evaluator failed"; return CALIPSO_ERR_CALLBACK; }
+    const uint32_t hess = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
+    if (flags & hess) s->hessian_dirty = true;
+    // blocks written behind our back: an analysed stage-banded structure has to be re-checked against them (as set_field does)
+    if (s->band64 > 0 && (flags & hess)) { const int v = structure_validate(s, 0); if (v < 0) return v; }
+    if (s->band64 > 0 && (flags & CALIPSO_EVAL_EQUALITY_JACOBIAN) && d.ne) { const int v = structure_validate(s, 1); if (v < 0) return v; }
+    if (s->band64 > 0 && (flags & CALIPSO_EVAL_CONE_JACOBIAN) && d.nc) { const int v = structure_validate(s, 2); if (v < 0) return v; }
+    return CALIPSO_OK;
+}
 static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t flags);
 namespace calipso { int evaluate_point(calipso_hip_solver* s, calipso_eval_fn eval, void* user, int which, uint32_t flags) { return evaluate(s, eval, user, which, flags); } }
 static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t flags) {
     double* pt = point_of(s, which);
     if (s->qp.attached) { launch_qp_evaluate(s, pt, flags); return CALIPSO_OK; }
+    if (s->dev_eval) return device_evaluate(s, pt, flags);
     if (!eval) { s->err = "no evaluation callback and no device evaluator attached"; return CALIPSO_ERR_ARGUMENT; }
     CK(hipMemcpyAsync(s->hpoint.data(), pt, sizeof(double) * s->d.N, hipMemcpyDeviceToHost, s->stream));
     SYNC();
@@ -696,6 +726,19 @@ int32_t calipso_hip_initialize(H* s, const double* guess) {
     return CALIPSO_OK;
 }
 
+int32_t calipso_hip_set_device_evaluator(H* s, calipso_device_eval_fn fn, void* user) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    s->dev_eval = fn; s->dev_eval_user = user;
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_device_evaluate(H* s, int32_t which, uint32_t flags) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    if (!s->dev_eval) { s->err = "no device evaluator installed (calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
+    CK(hipSetDevice(s->device));
+    return device_evaluate(s, point_of(s, which), flags);
+}
+
 int32_t calipso_hip_set_callbacks(H* s, calipso_callback_fn inner, calipso_callback_fn outer, void* user) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
     s->cb_inner = inner; s->cb_outer = outer; s->cb_user = user;
@@ -855,7 +898,7 @@ int32_t calipso_hip_qp_evaluate(H* s, int32_t which, uint32_t flags) {
 
 int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
-    if (!s->qp.attached) { s->err = "calipso_hip_newton_step needs a device evaluator (calipso_hip_qp_attach)"; return CALIPSO_ERR_ARGUMENT; }
+    if (!s->qp.attached && !s->dev_eval) { s->err = "calipso_hip_newton_step needs a device evaluator (calipso_hip_qp_attach or calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
     const Dims& d = s->d;
     const Scalars saved_sc = s->sc;
     std::vector<double> ft, fm; calipso::i64 fi = 0;

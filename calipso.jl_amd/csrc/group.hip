@@ -75,11 +75,21 @@ static int g_read_i(G* g, const Set& a, int first, int count) {
 // with a device evaluator, the host callback (on the member's own stream, after the group's stream has drained) for the others
 static int gb_evaluate(G* g, const Set& a, int which, uint32_t flags) {
     H* s = g->base;
-    Set dev, host;
-    for (int i : a) (g->hs[i]->qp.attached ? dev : host).push_back(i);
+    Set dev, user_dev, host;
+    for (int i : a) (g->hs[i]->qp.attached ? dev : (g->hs[i]->dev_eval ? user_dev : host)).push_back(i);
     if (!dev.empty()) {
         g_activate(g, dev);
         launch_qp_evaluate(s, which == 0 ? s->solution : s->candidate, flags);
+    }
+    // members with a user device evaluator: their kernels are enqueued on the GROUP's stream (the member's handle borrows it for the
+    // call), one member after the other, without leaving the device
+    for (int i : user_dev) {
+        H* h = g->hs[i];
+        hipStream_t own = h->stream;
+        h->stream = s->stream;
+        const int rc = evaluate_point(h, nullptr, nullptr, which, flags);
+        h->stream = own;
+        if (rc < 0) { s->err = "member " + std::to_string(i) + ": " + h->err; return rc; }
     }
     if (!host.empty()) {
         SYNC();
@@ -274,7 +284,7 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
     if (a.empty()) { EV(2); EV(3); EV(4); return CALIPSO_OK; }
     {   // :175-181 (a no-op for the device QP evaluator, whose Hessian / Jacobians are constant)
         Set cb;
-        for (int i : a) if (!g->hs[i]->qp.attached) cb.push_back(i);
+        for (int i : a) if (!g->hs[i]->qp.attached) cb.push_back(i);     // (host callbacks and user device evaluators alike)
         if (!cb.empty()) {
             for (int i : cb) {
                 uint32_t fl = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE_JACOBIAN;
@@ -470,7 +480,7 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
     Set all;
     for (size_t i = 0; i < B; ++i) {
         H* h = g->hs[i];
-        if (!h->qp.attached) { s->err = "calipso_hip_group_newton_step needs a device evaluator on every member (calipso_hip_qp_attach)"; return CALIPSO_ERR_ARGUMENT; }
+        if (!h->qp.attached && !h->dev_eval) { s->err = "calipso_hip_group_newton_step needs a device evaluator on every member (calipso_hip_qp_attach or calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
         if (h != s) CK(hipStreamSynchronize(h->stream));   // uploads made through the member's own stream are complete
         all.push_back((int)i);
     }
@@ -541,7 +551,7 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
     Set all;
     for (size_t i = 0; i < B; ++i) {
         H* h = g->hs[i];
-        if (!h->qp.attached && (i >= g->evals.size() || !g->evals[i])) {
+        if (!h->qp.attached && !h->dev_eval && (i >= g->evals.size() || !g->evals[i])) {
             s->err = "calipso_hip_group_solve: member without a device evaluator and without a callback (calipso_hip_group_set_evaluators)";
             return CALIPSO_ERR_ARGUMENT;
         }

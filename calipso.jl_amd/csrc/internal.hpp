@@ -121,6 +121,8 @@ struct calipso_hip_solver {
     std::string err;
     calipso_callback_fn cb_inner = nullptr, cb_outer = nullptr;   // options.callback_inner / callback_outer (solver.jl:183,193)
     void* cb_user = nullptr;
+    calipso_device_eval_fn dev_eval = nullptr;   // user evaluation on the device (include/calipso_hip.h): enqueues on `stream`, never syncs
+    void* dev_eval_user = nullptr;
     std::map<std::string, double*> optd;
     // host copies of the layout
     std::vector<int> h_soc_start, h_soc_dim, h_soc_woff;

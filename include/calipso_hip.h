@@ -83,6 +83,32 @@ enum {
 typedef int32_t (*calipso_eval_fn)(void* user, uint32_t flags, const double* x, const double* y, const double* z,
                                    const double* theta);
 
+/* DEVICE-side user evaluation: the same contract as calipso_eval_fn, but every pointer is a DEVICE pointer into the
+ * handle's own memory and the function only ENQUEUES work (HIP kernels, hipMemcpyAsync, hipBLAS ...) on the given stream — it must not
+ * synchronise.  x, y, z point into the current / candidate point, theta to the parameters; `out` names where each flagged ProblemData
+ * field has to be written (fields that do not exist for the shape are NULL).  With such an evaluator a whole solve! — including the
+ * up to 25 backtracking re-evaluations of the residual line search, solve.jl:254-302 — runs without the point ever visiting the host
+ * and without a block upload.  Return 0 on success. */
+typedef struct calipso_device_problem_data {
+    double* objective;                        /* [1] */
+    double* objective_gradient_variables;     /* [nx] */
+    double* equality_constraint;              /* [ne] */
+    double* cone_constraint;                  /* [nc] */
+    double* equality_dual_jacobian_variables; /* [nx]  (g'y)_x */
+    double* cone_dual_jacobian_variables;     /* [nx]  (h'z)_x */
+    double* lagrangian_hessian;               /* [nx*nx] column-major: objective Hessian + (g'y)_xx + (h'z)_xx summed (the latter two iff
+                                                 options.constraint_tensor, residual_jacobian_variables.jl:10-16) */
+    double* equality_jacobian_variables;      /* ne x nx column-major with leading dimension jacobian_ld */
+    double* cone_jacobian_variables;          /* nc x nx column-major with leading dimension jacobian_ld */
+    int64_t jacobian_ld;                      /* = ne + nc: the two Jacobians are stacked in one matrix on the device */
+    double* lagrangian_gradient_parameters;   /* [nx*np] objective + equality-dual + cone-dual terms summed (residual_jacobian_parameters.jl:8-14) */
+    double* equality_jacobian_parameters;     /* [ne*np] */
+    double* cone_jacobian_parameters;         /* [nc*np] */
+    int64_t nx, np, ne, nc;
+} calipso_device_problem_data;
+typedef int32_t (*calipso_device_eval_fn)(void* user, uint32_t flags, const double* x, const double* y, const double* z, const double* theta,
+                                          const calipso_device_problem_data* out, void* hip_stream);
+
 /* callback_inner(custom, solver) / callback_outer(custom, solver)  (solver.jl:183,193; called at solve.jl:350,371) */
 typedef void (*calipso_callback_fn)(void* user, calipso_hip_solver* solver);
 
@@ -184,6 +210,10 @@ int32_t calipso_hip_solve(calipso_hip_solver*, calipso_eval_fn eval, void* user)
 /* differentiate!(solver)  differentiate.jl:1-61: dR/dtheta assembled on the device, one factorisation, then one condensed
  * solve + recovery per parameter column (as differentiate.jl:29-58, without its per-column re-factorisation) */
 int32_t calipso_hip_differentiate(calipso_hip_solver*, calipso_eval_fn eval, void* user);
+/* install a device-side evaluator (NULL removes it): calipso_hip_solve / calipso_hip_differentiate / the group drivers then call it instead
+ * of the host callback (their `eval` argument may be NULL), and calipso_hip_device_evaluate runs it on point `which` (0 solution, 1 candidate) */
+int32_t calipso_hip_set_device_evaluator(calipso_hip_solver*, calipso_device_eval_fn fn, void* user);
+int32_t calipso_hip_device_evaluate(calipso_hip_solver*, int32_t which, uint32_t flags);
 /* install the per-inner-iteration / per-outer-update callbacks (NULL disables; options.callback_inner/outer) */
 int32_t calipso_hip_set_callbacks(calipso_hip_solver*, calipso_callback_fn inner, calipso_callback_fn outer, void* user);
 /* statistics of the last solve: [total_iterations, outer, factorizations, refinement_failures, max_refinement_rounds,

@@ -1,0 +1,128 @@
+"""GPU (-m gpu): user evaluation on the DEVICE (include/calipso_hip.h: calipso_device_eval_fn).  The fixture
+tests/device_eval/libuser_device_eval.so plays the user: its evaluators enqueue kernels on the solver's stream and write f, g, h and
+their derivatives straight into the solver's device buffers, so that solve! — including every backtracking re-evaluation of the residual
+line search (solve.jl:254-302) — never downloads the point, never uploads a block and never calls back into the host language."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import problems as pr
+from helpers import ROOT, load_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def user_lib():
+    L = C.CDLL(os.path.join(ROOT, "tests", "device_eval", "libuser_device_eval.so"))
+    L.qp_user_create.restype = C.c_void_p
+    L.qp_user_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double] + [C.POINTER(C.c_double)] * 6
+    L.qp_user_destroy.argtypes = [C.c_void_p]
+    return L
+
+
+def fnptr(f):
+    return C.cast(f, C.c_void_p)
+
+
+class CountingProblem:
+    """wraps a problem and counts host evaluations"""
+
+    def __init__(self, prob):
+        self.prob, self.calls = prob, 0
+
+    def evaluate(self, *a):
+        self.calls += 1
+        return self.prob.evaluate(*a)
+
+
+def test_wachter_solved_without_a_single_host_evaluation(oracle_mod):
+    pkg, UL = load_pkg(), user_lib()
+    prob = pr.wachter()
+    host = pkg.Solver(prob, 3, 0, 2, 2)
+    pkg.initialize_b(host, prob.x0)
+    assert pkg.solve_b(host)
+    counted = CountingProblem(prob)
+    dev = pkg.Solver(counted, 3, 0, 2, 2)
+    dev.set_device_evaluator(fnptr(UL.wachter_device_eval))
+    pkg.initialize_b(dev, prob.x0)
+    assert pkg.solve_b(dev)
+    assert counted.calls == 0                                              # the loop never left the device
+    assert dev.stats()["total_iterations"] == host.stats()["total_iterations"]
+    assert np.abs(dev.solution.all - host.solution.all).max() <= 1e-9
+    assert np.abs(dev.solution.variables - np.array([1.0, 0.0, 0.5])).max() <= 1e-3       # test/solver/wachter.jl:47
+    # and the oracle agrees
+    o = oracle_mod.OracleSolver(3, 0, 2, 2)
+    o.point()["x"][:] = prob.x0
+    assert o.solve(prob) == 1
+    assert np.abs(dev.solution.all - o.point()["all"]).max() <= 1e-8
+
+
+def make_qp_user(UL, prob):
+    f = lambda M: np.ascontiguousarray(np.asarray(M, dtype=np.float64)).reshape(-1)          # row-major, as the fixture expects
+    pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    arrs = [f(prob.P), f(prob.q), f(prob.A), f(prob.b), f(prob.G), f(prob.h)]
+    return UL.qp_user_create(prob.nx, prob.ne, prob.nc, prob.c, *[pd(a) for a in arrs])
+
+
+def test_user_qp_evaluator_fields_and_solve(oracle_mod):
+    pkg, UL = load_pkg(), user_lib()
+    prob = pr.random_qp(40, 10, 12, seed=4, nonnegative_indices=[1, 2, 3, 4], second_order_indices=[[5, 6, 7, 8], [9, 10, 11, 12]])
+    user = make_qp_user(UL, prob)
+    counted = CountingProblem(prob)
+    dev = pkg.Solver(counted, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices)
+    dev.set_device_evaluator(fnptr(UL.qp_device_eval), user)
+    host = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices)
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal(dev.N)
+    for s in (dev, host):
+        s.set("solution", w)
+    dev.device_evaluate(pr.ALL_VARIABLE_FLAGS, 0)
+    host.evaluate(pr.ALL_VARIABLE_FLAGS, 0)
+    for name, ln in (("objective", 1), ("objective_gradient_variables", prob.nx), ("equality_constraint", prob.ne), ("cone_constraint", prob.nc),
+                     ("equality_dual_jacobian_variables", prob.nx), ("cone_dual_jacobian_variables", prob.nx), ("lagrangian_hessian", prob.nx ** 2),
+                     ("equality_jacobian_variables", prob.ne * prob.nx), ("cone_jacobian_variables", prob.nc * prob.nx)):
+        a, b = dev.get(name, ln), host.get(name, ln)
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), name
+    assert counted.calls == 0
+    # full solves: device-evaluated vs host-callback vs oracle
+    x0 = np.zeros(prob.nx)
+    for s in (dev, host):
+        pkg.initialize_b(s, x0)
+    assert pkg.solve_b(dev) and pkg.solve_b(host)
+    assert counted.calls == 0
+    assert dev.stats()["total_iterations"] == host.stats()["total_iterations"]
+    assert np.abs(dev.solution.all - host.solution.all).max() <= 1e-8 * max(1.0, np.abs(host.solution.all).max())
+    o = oracle_mod.OracleSolver(prob.nx, 0, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
+    o.point()["x"][:] = x0
+    assert o.solve(prob) == 1
+    assert np.abs(dev.solution.variables - o.point()["x"]).max() <= 1e-6
+    UL.qp_user_destroy(user)
+
+
+def test_group_members_with_user_device_evaluators():
+    """a group whose members are evaluated by user kernels on the group's stream: same results as solving the members one by one"""
+    pkg, UL = load_pkg(), user_lib()
+    probs = [pr.random_qp(30, 8, 6, seed=10 + k) for k in range(3)]
+    users = [make_qp_user(UL, p) for p in probs]
+
+    def make(k):
+        s = pkg.Solver(CountingProblem(probs[k]), probs[k].nx, 0, probs[k].ne, probs[k].nc)
+        s.set_device_evaluator(fnptr(UL.qp_device_eval), users[k])
+        pkg.initialize_b(s, np.zeros(probs[k].nx))
+        return s
+
+    singles = [make(k) for k in range(3)]
+    for s in singles:
+        assert pkg.solve_b(s)
+    members = [make(k) for k in range(3)]
+    g = pkg.Group(members)
+    assert g.solve() == [1, 1, 1]
+    for s, m in zip(singles, members):
+        assert m.methods.calls == 0
+        assert m.stats()["total_iterations"] == s.stats()["total_iterations"]
+        assert np.array_equal(m.solution.all, s.solution.all)
+    g.close()
+    for u in users:
+        UL.qp_user_destroy(u)
