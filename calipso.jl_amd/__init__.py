@@ -12,7 +12,7 @@ import numpy as np
 
 from ._lib import CALLBACK_FN, EVAL_FN, CalipsoHipError, lib
 
-__all__ = ["Solver", "Group", "LDLSolver", "SmallBatch", "Comm", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform",
+__all__ = ["Solver", "Group", "LDLSolver", "SmallBatch", "Comm", "ordering", "symbolic", "Options", "initialize_b", "solve_b", "CalipsoHipError", "FLAGS", "splitmix_uniform",
            "mfma_f64_peak"]
 
 # evaluate! flags (include/calipso_hip.h)
@@ -454,6 +454,42 @@ class Group:
             pass
 
 
+def _csc_1based(A):
+    import scipy.sparse as sp
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    return (A, np.ascontiguousarray(A.indptr, dtype=np.int64) + 1, np.ascontiguousarray(A.indices, dtype=np.int64) + 1,
+            np.ascontiguousarray(A.data, dtype=np.float64))
+
+
+ORDERINGS = dict(natural=0, rcm=1, minimum_degree=2)
+
+
+def ordering(A, method="rcm"):
+    """elimination order (1-based, perm[k] = vertex eliminated k-th) of the symmetric pattern of A: "natural", "rcm", "minimum_degree"
+    (calipso_hip_ordering; the reference takes perm = amd(A), qdldl.jl:135).  Host function: needs no device."""
+    A, colptr, rowval, _ = _csc_1based(A)
+    n = A.shape[0]
+    perm = np.zeros(n, dtype=np.int64)
+    rc = lib().calipso_hip_ordering(n, _pi(colptr), _pi(rowval), ORDERINGS[method], _pi(perm))
+    if rc != 0:
+        raise CalipsoHipError("calipso_hip_ordering failed (%d)" % rc)
+    return perm
+
+
+def symbolic(A, perm=None):
+    """permute_symmetric + QDLDL_etree! of triu(A) under perm (qdldl.jl:358-395,642-742): dict(Pp, Pi, AtoPAPt, etree, Lnz, nnzL, half_bandwidth)"""
+    A, colptr, rowval, _ = _csc_1based(A)
+    n, nnz = A.shape[0], A.nnz
+    Pp, Pi, mp = np.zeros(n + 1, dtype=np.int64), np.zeros(max(nnz, 1), dtype=np.int64), np.zeros(max(nnz, 1), dtype=np.int64)
+    et, lnz, info = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64), np.zeros(2, dtype=np.int64)
+    pp = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+    tot = lib().calipso_hip_symbolic(n, _pi(colptr), _pi(rowval), _pi(pp) if pp is not None else None, _pi(Pp), _pi(Pi), _pi(mp), _pi(et), _pi(lnz), _pi(info))
+    if tot < -1:
+        raise CalipsoHipError("calipso_hip_symbolic failed (%d)" % tot)
+    return dict(Pp=Pp, Pi=Pi[:int(info[1])], AtoPAPt=mp[:nnz], etree=et, Lnz=lnz, nnzL=int(tot), half_bandwidth=int(info[0]))
+
+
 class LDLSolver:
     """LDLSolver / ldl_solver(A) of src/solver/linear_solver.jl:1-60 on the device: factorize!(s, A), compute_inertia!(s),
     linear_solve!(s, x, A, b).  A is a scipy.sparse CSC matrix (or anything scipy can convert); only triu(A) is read."""
@@ -473,14 +509,19 @@ class LDLSolver:
             raise CalipsoHipError("%s: %s (%d): %s" % (what, STATUS_TEXT.get(rc, "error"), rc, self._L.calipso_hip_last_error(self._h).decode()))
         return rc
 
+    def analyze(self, A, method="rcm", perm=None):
+        """install the elimination order of the following factorisations ("natural", "rcm", "minimum_degree", or perm=<1-based order>);
+        returns (perm, dict(half_bandwidth, band_blocks (0 = dense treatment), nnzL, nnz_upper))"""
+        A, colptr, rowval, _ = _csc_1based(A)
+        p = np.zeros(self.n, dtype=np.int64) if perm is None else np.ascontiguousarray(perm, dtype=np.int64).copy()
+        info = np.zeros(4, dtype=np.int64)
+        m = 3 if perm is not None else ORDERINGS[method]
+        self._check(self._L.calipso_hip_ldl_analyze_csc(self._h, self.n, _pi(colptr), _pi(rowval), m, _pi(p), _pi(info)), "analyze")
+        return p, dict(half_bandwidth=int(info[0]), band_blocks=int(info[1]), nnzL=int(info[2]), nnz_upper=int(info[3]))
+
     def factorize(self, A):
         """factorize!(s, A; update) + compute_inertia!(s); returns the warning status (1 = zero pivot met)"""
-        import scipy.sparse as sp
-        A = sp.csc_matrix(A)
-        A.sort_indices()
-        colptr = np.ascontiguousarray(A.indptr, dtype=np.int64) + 1      # Julia's 1-based SparseMatrixCSC
-        rowval = np.ascontiguousarray(A.indices, dtype=np.int64) + 1
-        nzval = np.ascontiguousarray(A.data, dtype=np.float64)
+        A, colptr, rowval, nzval = _csc_1based(A)
         out = np.zeros(3, dtype=np.int64)
         rc = self._check(self._L.calipso_hip_ldl_factorize_csc(self._h, self.n, _pi(colptr), _pi(rowval), _pd(nzval), _pi(out)), "factorize!")
         self.inertia = tuple(int(v) for v in out)

@@ -68,6 +68,9 @@ SYMBOLS = {
     "calipso_hip_ldl_create": (_i32, [_i64, _i32, C.POINTER(_vp)]),
     "calipso_hip_ldl_factorize_csc": (_i32, [_vp, _i64, _pi64, _pi64, _pd, _pi64]),
     "calipso_hip_ldl_inertia": (_i32, [_vp, _pi64]),
+    "calipso_hip_ordering": (_i32, [_i64, _pi64, _pi64, _i32, _pi64]),
+    "calipso_hip_symbolic": (_i64, [_i64, _pi64, _pi64, _pi64, _pi64, _pi64, _pi64, _pi64, _pi64, _pi64]),
+    "calipso_hip_ldl_analyze_csc": (_i32, [_vp, _i64, _pi64, _pi64, _i32, _pi64, _pi64]),
     "calipso_hip_ldl_solve": (_i32, [_vp, _i64, _i64, _pd, _pd]),
     "calipso_hip_small_create": (_i32, [_i64, _i64, _i64, _i32, C.POINTER(_vp)]),
     "calipso_hip_small_destroy": (_i32, [_vp]),

@@ -275,6 +275,21 @@ int32_t calipso_hip_ldl_create(int64_t n, int32_t device, calipso_hip_solver** o
 int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver*, int64_t n, const int64_t* colptr, const int64_t* rowval, const double* nzval,
                                       int64_t inertia[3]);
 int32_t calipso_hip_ldl_inertia(calipso_hip_solver*, int64_t inertia[3]);
+/* Ordering / symbolic service (qdldl.jl:134-188,358-395,642-742).  Host-side integer work, 1-based Int64 like the reference.
+ *   calipso_hip_ordering: elimination order of a sparse symmetric pattern (CSC, any triangle(s)): method 0 natural, 1 reverse Cuthill-McKee
+ *     (minimum bandwidth: what the device factorisation exploits), 2 minimum degree on the quotient graph (AMD's order class; AMD.jl's exact
+ *     output, qdldl.jl:135, is third-party and unpinned).  perm[k] = vertex eliminated k-th.
+ *   calipso_hip_symbolic: permute_symmetric + QDLDL_etree! for triu(A) under perm (NULL = natural): Pp[n+1], Pi[nnz triu], AtoPAPt[nnz A] (0 below
+ *     the diagonal), etree[n] (-1 = root), Lnz[n]; returns nnz(L) (-1 in the reference's failure cases); info = [half bandwidth of PAP', nnz triu].
+ *     Bit-exact against the oracle's restatement for the same perm.  Outputs may be NULL.
+ *   calipso_hip_ldl_analyze_csc: installs the order on a calipso_hip_ldl_create handle (method 3 = the caller's perm); the following
+ *     calipso_hip_ldl_factorize_csc calls factor P A P' and, if it is banded, only inside the band; calipso_hip_ldl_solve permutes the right-hand
+ *     sides (qdldl.jl:330-351).  info = [half bandwidth, band blocks used (0 = dense treatment), nnz(L) symbolic, nnz triu]. */
+int32_t calipso_hip_ordering(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, int64_t* perm);
+int64_t calipso_hip_symbolic(int64_t n, const int64_t* colptr, const int64_t* rowval, const int64_t* perm, int64_t* Pp, int64_t* Pi, int64_t* AtoPAPt,
+                             int64_t* etree, int64_t* Lnz, int64_t info[2]);
+int32_t calipso_hip_ldl_analyze_csc(calipso_hip_solver*, int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, int64_t* perm,
+                                    int64_t info[4]);
 int32_t calipso_hip_ldl_solve(calipso_hip_solver*, int64_t n, int64_t nrhs, const double* b, double* x);
 
 /* ---- batched small systems (BASELINE config C5): LDS-resident LDL^T + multi-right-hand-side solve, one workgroup per

@@ -100,3 +100,49 @@ def test_handle_linear_solve_sequence_of_the_julia_wrapper(oracle_mod):
         g.linear_solve()
         x = g.get("step_symmetric", o.n)
         assert rel(x, o.linear_solve(b, fact=False)) <= 1e-8
+
+
+@pytest.mark.parametrize("method", ["rcm", "minimum_degree", "natural"])
+def test_seam_with_an_elimination_order(oracle_mod, method):
+    """ldl_solver(A) with perm = ordering(A) (the reference: perm = amd(A), qdldl.jl:135): the K of a stage-structured problem, which in the
+    natural [x | y | z] order couples everything with everything, becomes banded under reverse Cuthill-McKee and the device factorisation only
+    visits the band; the solution does not depend on the order (to rounding)."""
+    pkg = load_pkg()
+    prob, pt, lam = pr.staged_conic_qp(pkg.splitmix_uniform, 3, 16, 24, 16, 3, 2, 3)      # nx = 384, ne = 240, nc = 144: n = 768
+    o = oracle_mod.OracleSolver(prob.nx, 0, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
+    o.point()["all"][:] = np.concatenate([pt[k] for k in "xrsyzt"])
+    o.buf("dual")[:] = lam
+    o.buf("central_path")[0] = 0.17; o.buf("penalty")[0] = 52.0
+    o.buf("primal_regularization")[0] = 1e-7; o.buf("dual_regularization")[0] = 1e-7
+    op = o.point()
+    prob.evaluate(pr.ALL_VARIABLE_FLAGS, op["x"], op["y"], op["z"], np.zeros(0), o.buf)
+    o.cone(product=True, jacobian=True, target=True)
+    o.residual_jacobian_variables(); o.residual_jacobian_variables_symmetric()
+    K = np.array(o.K_dense())
+    o.factorize(update=False)
+    n = o.n
+    A = sp.csc_matrix(K)
+    ls = pkg.LDLSolver(n)
+    perm, info = ls.analyze(A, method=method)
+    assert sorted(perm) == list(range(1, n + 1)) and info["nnz_upper"] == sp.triu(A).nnz
+    nblk = 1024 // 64
+    if method == "rcm":
+        assert 0 < info["band_blocks"] < nblk - 1 and info["half_bandwidth"] < n // 3      # the band is found and used
+    if method == "natural":
+        assert info["band_blocks"] == 0                                                     # [x | y | z]: y couples the first and the last stage
+    assert ls.factorize(A) == 0
+    assert ls.compute_inertia() == o.compute_inertia() == (prob.nx, prob.ne + prob.nc, 0)     # Sylvester: the same for every order
+    rng = np.random.default_rng(7)
+    B = rng.standard_normal((n, 5))
+    X = ls.linear_solve(B)
+    for j in range(5):
+        assert rel(X[:, j], o.linear_solve(B[:, j], fact=False)) <= 1e-8
+    # a caller-supplied order (method 3) reproduces the same solver state
+    ls2 = pkg.LDLSolver(n)
+    perm2, info2 = ls2.analyze(A, perm=perm)
+    assert np.array_equal(perm2, perm) and info2 == info
+    ls2.factorize(A)
+    assert np.array_equal(ls2.linear_solve(B), X)
+    # the symbolic factor the reference would build for this order (nnz(L)) is reported
+    assert info["nnzL"] == pkg.symbolic(sp.triu(A), perm)["nnzL"] > 0
+    ls.close(); ls2.close()
