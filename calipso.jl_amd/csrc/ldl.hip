@@ -260,11 +260,12 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fk = lane >> 4;
-    // staging map: a 32-lane half-wave covers 16 rows x 2 columns, so its ds_write_b64 addresses (row * LDT + c, LDT = 66)
-    // fall on 32 distinct bank pairs (a 64-row x 1-column map is a 2-way conflict: rows r and r + 16 share banks), while
-    // every global load is still a full 128-byte run of 16 consecutive rows
-    const int row = (tid & 15) + 16 * ((tid >> 6) & 3);
-    const int cb = ((tid >> 4) & 3) + 4 * (tid >> 8);   // 0..15
+    // staging map: every contiguous 16-lane group (the unit ds_write_b64 is banked over, modulo 32 dwords) covers 8 rows x 2 ADJACENT
+    // panel columns: with the row stride LDT = 66 doubles (132 dwords = 4 mod 32) its 16 stores fall on 16 distinct bank pairs (16 rows of
+    // one column, the round-1 map, put rows r and r + 8 on the same pair: a 2-way conflict on every store); a wave's global load is
+    // still 4 columns x 16 consecutive rows = four full 128-byte runs
+    const int row = (lane & 7) + 8 * ((lane >> 4) & 1) + 16 * (wave & 3);
+    const int cb = ((lane >> 3) & 1) + 2 * ((lane >> 5) & 1) + 4 * (wave >> 2);   // 0..15
     const double* Lp = S + (size_t)k0 * NP;
     const int stride = (int)gridDim.x - 1;
     int t = blockIdx.x;
@@ -283,9 +284,9 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
     for (;;) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int c = cb + it * 16;                      // panel column k; stored at (k % 4) * 16 + k / 4: per-lane fragments contiguous
-            Ls[row * LDT + (c & 3) * 16 + (c >> 2)] = lv[it];
-            Ys[row * LDT + (c & 3) * 16 + (c >> 2)] = yv[it];
+            const int c = cb + it * 16;                      // panel column k, natural order
+            Ls[row * LDT + c] = lv[it];
+            Ys[row * LDT + c] = yv[it];
         }
         __syncthreads();
         // next tile of this workgroup: its operands travel while the matrix cores work
@@ -306,13 +307,25 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
             }
         }
         v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-        // a lane's 16 fragment values (k = 4 kk + fk) are contiguous in LDS (see the staging): 128-bit reads, and the 16 lanes of a
-        // pass cover 64 distinct banks.  (With k stored in natural order the compiler pairs the kk and kk + 1 fragments into
-        // ds_read2_b64, whose second element lands on the banks of the lane two rows down: a 2-way conflict on every read.)
-        const double* Lv = Ls + (wr * 16 + fr) * LDT + fk * 16;
-        const double* Yv = Ys + (wc * 16 + fr) * LDT + fk * 16;
+        // MFMA fragments by explicit ds_read_b64 (lane (fr, fk) reads row fr, k = 4 kk + fk: dword address 132 fr + 2 fk + 8 kk — the 32
+        // lanes of a half-wave hit 32 distinct bank pairs modulo 64).  Plain loads would be paired by the compiler into ds_read2_b64 /
+        // ds_read_b128, whose lane groups conflict 2-way on this layout (round 1: 48 % of the LDS cycles were conflict replays).  All 32
+        // loads of a tile are issued up front; the waits release them to the matrix cores in order (LDS returns in order).
+        {
+            const unsigned lb = (unsigned)(uintptr_t)(Ls + (wr * 16 + fr) * LDT + fk);
+            const unsigned yb = (unsigned)(uintptr_t)(Ys + (wc * 16 + fr) * LDT + fk);
+            double fl[NB / 4], fy[NB / 4];
 #pragma unroll
-        for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Yv[kk], Lv[kk], acc, 0, 0, 0);
+            for (int kk = 0; kk < NB / 4; ++kk) {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fl[kk]) : "v"(lb), "n"(kk * 32) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fy[kk]) : "v"(yb), "n"(kk * 32) : "memory");
+            }
+#define TR_WAIT(N, A, B) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fl[A]), "+v"(fy[A]), "+v"(fl[B]), "+v"(fy[B]) :: "memory")
+            TR_WAIT(15, 0, 1); TR_WAIT(15, 2, 3); TR_WAIT(15, 4, 5); TR_WAIT(12, 6, 7); TR_WAIT(8, 8, 9); TR_WAIT(4, 10, 11); TR_WAIT(0, 12, 13); TR_WAIT(0, 14, 15);
+#undef TR_WAIT
+#pragma unroll
+            for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fy[kk], fl[kk], acc, 0, 0, 0);
+        }
         if (t == 0) {
             // tile 0 = the diagonal block of the next panel: hand it over through LDS (row-major, stride LDD) and factor it
             __syncthreads();                      // all MFMA operand reads of Ls/Ys are done
