@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <vector>
+#include <type_traits>
 constexpr int NB = 64;
 
 __device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton steps (no div_scale/fixup: pivots are normal numbers)
@@ -731,6 +732,133 @@ __global__ __launch_bounds__(1024) void k_diag_v7(int ld, double* __restrict__ S
     TS(17);
 }
 
+
+// v8: 4-column mini-panels.  Wavefront cg owns the four CONSECUTIVE columns 4 cg .. 4 cg + 3 (lane = row).  Per mini-panel the owner wave
+// factors its four columns alone (pivot entries by v_readlane inside the wave, no barrier), publishes the unscaled columns + reciprocals to a
+// double-buffered LDS panel, ONE workgroup barrier, and every later wave applies the rank-4 update to its own four columns.  16 barriers per
+// 64 columns instead of 64; the critical wave executes ~50 + ~40 instructions per four columns instead of 4 x 30.
+__device__ __forceinline__ double fast_rcp1(double v) {   // v_rcp_f64 + 1 Newton step
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+template <int P> struct MiniPanel {
+    // a[0..3]: this lane's row of the owner's four columns (global columns 4P..4P+3); returns y (unscaled), l (scaled below the pivot), rinv
+    static __device__ __forceinline__ void run(double (&a)[4], int i, double (&y)[4], double (&rinv)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * P + j;
+            const double d = readlane_d(a[j], r);
+            rinv[j] = fast_rcp1(d);
+            y[j] = a[j];
+            const double li = a[j] * rinv[j];
+#pragma unroll
+            for (int k = j + 1; k < 4; ++k) a[k] -= li * readlane_d(a[j], 4 * P + k);     // A[4P+k][r]: the symmetric partner of row r's entry
+        }
+    }
+};
+__global__ __launch_bounds__(1024) void k_diag_v8(int ld, double* __restrict__ S, double* __restrict__ Dx, double* __restrict__ Xout) {
+    constexpr int WAVES = 16;
+    __shared__ double Ls[NB * LDD3];
+    __shared__ double Xs[NB * LDD3];
+    __shared__ double Ts[32 * 33];
+    __shared__ double ypan[2][4][NB];       // unscaled pivot columns of the current mini-panel
+    __shared__ double rpan[2][4];           // their reciprocals
+    const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
+    double a[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = 4 * cg + c;
+        a[c] = (i >= k) ? S[i + (size_t)k * ld] : 0.0;
+    }
+    TS(0);
+    auto panel = [&](auto Ptag) {
+        constexpr int P = decltype(Ptag)::value;
+        const int buf = P & 1;
+        if (cg == P) {
+            double y[4], rinv[4];
+            MiniPanel<P>::run(a, i, y, rinv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ypan[buf][j][i] = y[j];
+                Ls[i * LDD3 + 4 * P + j] = (i > 4 * P + j) ? y[j] * rinv[j] : ((i == 4 * P + j) ? y[j] : 0.0);    // L below, the pivot on the diagonal
+            }
+            if (i < 4) rpan[buf][i] = rinv[i];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        if (cg > P) {
+            double l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) l[j] = (i > 4 * P + j) ? ypan[buf][j][i] * rpan[buf][j] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = 4 * cg + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[c] -= l[j] * ypan[buf][j][k];
+            }
+        }
+    };
+    panel(std::integral_constant<int, 0>{}); panel(std::integral_constant<int, 1>{}); panel(std::integral_constant<int, 2>{}); panel(std::integral_constant<int, 3>{});
+    panel(std::integral_constant<int, 4>{}); panel(std::integral_constant<int, 5>{}); panel(std::integral_constant<int, 6>{}); panel(std::integral_constant<int, 7>{});
+    panel(std::integral_constant<int, 8>{}); panel(std::integral_constant<int, 9>{}); panel(std::integral_constant<int, 10>{}); panel(std::integral_constant<int, 11>{});
+    panel(std::integral_constant<int, 12>{}); panel(std::integral_constant<int, 13>{}); panel(std::integral_constant<int, 14>{}); panel(std::integral_constant<int, 15>{});
+    __syncthreads();
+    TS(1);
+    if (tid < NB) Dx[tid] = Ls[tid * LDD3 + tid];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = 4 * cg + c;
+        if (i > k) S[i + (size_t)k * ld] = Ls[i * LDD3 + k];
+        if (i <= k) Ls[i * LDD3 + k] = 0.0;           // the inverse below reads L only: clear the diagonal / upper part
+        Xs[i * LDD3 + k] = 0.0;
+    }
+    __syncthreads();
+    TS(2);
+    if (cg < 4 && i < 16) inv16(Ls, Xs, 16 * cg, i);
+    __syncthreads();
+    {
+        const int p = tid >> 8, ii = (tid >> 4) & 15, jj2 = tid & 15, o = 32 * p;
+        double t = 0.0;
+        if (tid < 512) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += Ls[(o + 16 + ii) * LDD3 + o + k] * Xs[(o + k) * LDD3 + o + jj2];
+            Ts[(p * 16 + ii) * 33 + jj2] = t;
+        }
+        __syncthreads();
+        if (tid < 512) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v -= Xs[(o + 16 + ii) * LDD3 + o + 16 + k] * Ts[(p * 16 + k) * 33 + jj2];
+            Xs[(o + 16 + ii) * LDD3 + o + jj2] = v;
+        }
+        __syncthreads();
+    }
+    {
+        const int ii = tid >> 5, jj2 = tid & 31;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += Ls[(32 + ii) * LDD3 + k] * Xs[k * LDD3 + jj2];
+        Ts[ii * 33 + jj2] = t;
+        __syncthreads();
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v -= Xs[(32 + ii) * LDD3 + 32 + k] * Ts[k * 33 + jj2];
+        __syncthreads();
+        Xs[(32 + ii) * LDD3 + jj2] = v;
+    }
+    __syncthreads();
+    TS(3);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = 4 * cg + c;
+        Xout[i + k * NB] = Xs[i * LDD3 + k];
+    }
+    TS(4);
+}
+
 // v5 = v4 templated on the number of wavefronts (v3 + unmasked column updates, finished columns stashed in LDS, per-lane reciprocal vector): LDL^T loop without the inverse; X = L^-1 afterwards by 16 x 16 wave-synchronous inversions + two merge levels in LDS
 
 template <int WAVES>
@@ -921,6 +1049,8 @@ int main() {
     { long long h[32]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts), sizeof(h)); printf("v6 timeline (10 ns ticks from start):"); for (int q = 0; q < 18; ++q) printf(" [%d]%lld", q, h[q] - h[0]); printf("\n"); }
     run("v7: 16-col stages, DPP pivot broadcast, MFMA update", k_diag_v7, 1024, A, true);
     { long long h[32]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts), sizeof(h)); printf("v7 timeline (10 ns ticks from start):"); for (int q = 0; q < 18; ++q) printf(" [%d]%lld", q, h[q] - h[0]); printf("\n"); }
+    run("v8: 4-column mini-panels (readlane inside the owner wave)", k_diag_v8, 1024, A, true);
+    { long long h[32]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts), sizeof(h)); printf("v8 timeline (10 ns ticks from start):"); for (int q = 0; q < 5; ++q) printf(" [%d]%lld", q, h[q] - h[0]); printf("\n"); }
     run("v5 16 waves", k_diag_v5<16>, 1024, A, true);
     run("v5  8 waves", k_diag_v5<8>, 512, A, true);
     run("v5  4 waves", k_diag_v5<4>, 256, A, true);
