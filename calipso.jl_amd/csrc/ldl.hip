@@ -28,11 +28,14 @@ constexpr int LDT = NB + 2;        // LDS leading dimension of a k-fastest 64-de
 
 // ---- diagonal block ---------------------------------------------------------------------------------------------------------
 // The 2500 sequential pivots of S are the critical path of the factorisation; this kernel is tuned with the stand-alone
-// harness bench/diag_bench.hip (variant v4).  1024 threads: lane i = tid & 63 is a ROW of the block, wavefront
-// cg = tid >> 6 owns the columns k = cg + 16 c (c = 0..3) in registers.
-//   phase 1  LDL^T: per column j ONE barrier; the unscaled pivot column y (y_i = l_i d_j) and a vector of reciprocals travel
-//            through LDS; the update a[c] -= l_i y_k is unmasked (a finished column was stashed in LDS when it was
-//            published, rows at/above the pivot only collect garbage that is never read) -> 4 FMAs per lane per column.
+// harness bench/diag_bench.hip (variant v8; profiles/r02_diag_bench.txt has the timelines of the alternatives).  1024 threads: lane
+// i = tid & 63 is a ROW of the block, wavefront cg = tid >> 6 owns the four CONSECUTIVE columns 4 cg .. 4 cg + 3 in registers.
+//   phase 1  LDL^T in 16 mini-panels of four columns: the owner wavefront factors its four columns alone — the pivot entries it needs
+//            from other rows are in its own lanes and travel by v_readlane, no barrier — publishes the four unscaled columns and their
+//            reciprocal pivots to a double-buffered LDS panel, ONE workgroup barrier, and every later wavefront applies the rank-4 update
+//            to its own columns.  16 barriers per block instead of 64 (one per column in round 1); a single wavefront issues one dependent
+//            instruction every ~13 cycles, so what counts on the critical path is the instruction count of the wave that holds the
+//            next pivot: ~50 (mini-panel) + ~40 (update) per four columns instead of 4 x 30 + 4 barriers.  10.6 us instead of 15.
 //   phase 2  X = L11^-1 (needed by the panel GEMM and by the triangular solves): the four 16 x 16 diagonal blocks by
 //            wave-synchronous forward substitution in registers, then two merge levels inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1, C^-1]
 //            as small dense products out of LDS.
@@ -47,9 +50,16 @@ __device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton
     return r;
 }
 
-// LDS carve (doubles): Ls | Xs | Ts | colbuf | rinvvec.  When the block arrives through LDS (fused with the trailing update) it
+// LDS carve (doubles): Ls | Xs | Ts | ypan[2][4][NB] | rpan[2][4].  When the block arrives through LDS (fused with the trailing update) it
 // sits in the Ls region and is consumed into registers before Ls is first written.
-constexpr int DIAG_LDS_DOUBLES = 2 * NB * LDD + 32 * 33 + 4 * NB;
+constexpr int DIAG_LDS_DOUBLES = 2 * NB * LDD + 32 * 33 + 8 * NB + 8;
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {     // lane: wave-uniform
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
 template <bool FROM_LDS>
 __device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
                                            double* __restrict__ Tinv, int* __restrict__ icount) {
@@ -57,52 +67,53 @@ __device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, in
     double* Ls = smem;
     double* Xs = Ls + NB * LDD;
     double* Ts = Xs + NB * LDD;
-    double (*colbuf)[NB] = reinterpret_cast<double (*)[NB]>(Ts + 32 * 33);
-    double (*rinvvec)[NB] = reinterpret_cast<double (*)[NB]>(Ts + 32 * 33 + 2 * NB);
+    double (*ypan)[4][NB] = reinterpret_cast<double (*)[4][NB]>(Ts + 32 * 33);     // [2][4][NB] unscaled pivot columns of a mini-panel
+    double (*rpan)[4] = reinterpret_cast<double (*)[4]>(Ts + 32 * 33 + 8 * NB);    // [2][4] their reciprocal pivots
     const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
     double a[CPW];
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
-        const int k = cg + WAVES * c;
+        const int k = 4 * cg + c;
         if (FROM_LDS) a[c] = (i >= k) ? Ls[i * LDD + k] : 0.0;
         else a[c] = (i >= k) ? S[(k0 + i) + (size_t)(k0 + k) * NP] : 0.0;
     }
     if (FROM_LDS) __syncthreads();   // every lane has its entries before the Ls region is reused
-    if (cg == 0) {
-        colbuf[0][i] = a[0];
-        rinvvec[0][i] = fast_rcp(a[0]);
-        Ls[i * LDD + 0] = a[0];
-    }
 #pragma unroll 1
-    for (int jb = 0; jb < NB; jb += WAVES)
+    for (int P = 0; P < WAVES; ++P) {
+        const int buf = P & 1;
+        if (cg == P) {
+            // the owner's four columns, alone: rows <= the pivot only collect garbage that is never read
+            double y[4], rinv[4];
 #pragma unroll
-    for (int jj = 0; jj < WAVES; ++jj) {
-        const int j = jb + jj;
-        const int cur = jj & 1, nxt = cur ^ 1;
+            for (int j = 0; j < 4; ++j) {
+                const double d = readlane_d(a[j], 4 * P + j);
+                rinv[j] = fast_rcp(d);
+                y[j] = a[j];
+                const double li = a[j] * rinv[j];
+#pragma unroll
+                for (int k = j + 1; k < 4; ++k) a[k] -= li * readlane_d(a[j], 4 * P + k);    // A[4P+k][4P+j]: the symmetric partner of the pivot row's entry
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ypan[buf][j][i] = y[j];
+                Ls[i * LDD + 4 * P + j] = (i > 4 * P + j) ? y[j] * rinv[j] : y[j];              // L below the pivot, the pivot on the diagonal
+            }
+            if (i == 0) { rpan[buf][0] = rinv[0]; rpan[buf][1] = rinv[1]; rpan[buf][2] = rinv[2]; rpan[buf][3] = rinv[3]; }
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only LDS traffic is outstanding here
         __builtin_amdgcn_s_barrier();
-        const double yi = colbuf[cur][i];
-        const double rinv = rinvvec[cur][j];
-        double yk[CPW];
+        if (cg > P) {
+            double l[4];
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) yk[c] = colbuf[cur][cg + WAVES * c];
-        const double li = (i > j) ? yi * rinv : 0.0;
+            for (int j = 0; j < 4; ++j) l[j] = (i > 4 * P + j) ? ypan[buf][j][i] * rpan[buf][j] : 0.0;
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) a[c] -= li * yk[c];
-        if (j + 1 < NB && cg == (jj + 1) % WAVES) {      // the wavefront that owns column j+1 publishes and stashes it
-            const int cs = (j + 1) / WAVES;
-            double v = a[0];
+            for (int c = 0; c < CPW; ++c) {
 #pragma unroll
-            for (int c = 1; c < CPW; ++c) v = (cs == c) ? a[c] : v;
-            colbuf[nxt][i] = v;
-            rinvvec[nxt][i] = fast_rcp(v);               // every lane; readers pick entry j+1 (no divergent single-lane path)
-            Ls[i * LDD + j + 1] = v;                     // unscaled column j+1, pivot on the diagonal
+                for (int j = 0; j < 4; ++j) a[c] -= l[j] * ypan[buf][j][4 * cg + c];
+            }
         }
     }
     __syncthreads();
-    double dk[CPW];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) dk[c] = Ls[(cg + WAVES * c) * LDD + cg + WAVES * c];
     if (tid < NB) {
         const double d = Ls[tid * LDD + tid];
         Dx[k0 + tid] = d;
@@ -115,8 +126,8 @@ __device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, in
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
         const int k = cg + WAVES * c;
-        const double lv = (i > k) ? Ls[i * LDD + k] * (1.0 / dk[c]) : 0.0;
-        Ls[i * LDD + k] = lv;
+        const double lv = (i > k) ? Ls[i * LDD + k] : 0.0;
+        Ls[i * LDD + k] = lv;                 // strictly lower L (the pivots and what the garbage rows left above them go)
         Xs[i * LDD + k] = 0.0;
         if (i > k) S[(k0 + i) + (size_t)(k0 + k) * NP] = lv;
     }
