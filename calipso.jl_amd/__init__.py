@@ -179,6 +179,23 @@ class Solver:
                ("cone_jacobian_variables", "cone_jacobian_variables"), ("cone_dual_jacobian_variables", "cone_dual_jacobian_variables"),
                ("equality_jacobian_parameters", "equality_jacobian_parameters"), ("cone_jacobian_parameters", "cone_jacobian_parameters")]
 
+    # ---- sparse scatter of evaluate! (evaluate.jl:37-121): value caches + registered index lists instead of dense blocks ---------------
+    def set_sparsity(self, field, rows, cols):
+        """methods.<field>_sparsity: 1-based (row, col) lists in cache order; duplicates allowed (the last writer wins)"""
+        r = np.ascontiguousarray(rows, dtype=np.int64); c = np.ascontiguousarray(cols, dtype=np.int64)
+        self._check(self._L.calipso_hip_set_sparsity(self._h, field.encode(), r.size, _pi(r), _pi(c)), "set_sparsity(%s)" % field)
+
+    def scatter_field(self, field, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self._L.calipso_hip_scatter_field(self._h, field.encode(), _pd(v), v.size), "scatter_field(%s)" % field)
+
+    def scatter_hessian(self, objective=None, equality_dual=None, cone_dual=None):
+        a = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in (objective, equality_dual, cone_dual)]
+        args = []
+        for v in a:
+            args += [_pd(v) if v is not None else None, 0 if v is None else v.size]
+        self._check(self._L.calipso_hip_scatter_hessian(self._h, *args), "scatter_hessian")
+
     def upload(self, flags):
         """hand the flagged ProblemData fields to the device (the tail of evaluate!, src/solver/evaluate.jl:37-121)"""
         p = self.problem

@@ -25,6 +25,9 @@ SYMBOLS = {
     "calipso_hip_device_count": (_i32, []),
     "calipso_hip_set_field": (_i32, [_vp, C.c_char_p, _pd, _i64]),
     "calipso_hip_get_field": (_i32, [_vp, C.c_char_p, _pd, _i64]),
+    "calipso_hip_set_sparsity": (_i32, [_vp, C.c_char_p, _i64, _pi64, _pi64]),
+    "calipso_hip_scatter_field": (_i32, [_vp, C.c_char_p, _pd, _i64]),
+    "calipso_hip_scatter_hessian": (_i32, [_vp, _pd, _i64, _pd, _i64, _pd, _i64]),
     "calipso_hip_get_index": (_i64, [_vp, C.c_char_p, _pi64, _i64]),
     "calipso_hip_cone": (_i32, [_vp, _i32, _i32]),
     "calipso_hip_residual": (_i32, [_vp]),

@@ -202,6 +202,7 @@ int32_t calipso_hip_destroy(H* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     nonsymmetric_release(s);
     ldlsolver_release(s);
+    scatter_release(s);
     double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
     for (double* p : dp) if (p) (void)hipFree(p);
     int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};

@@ -176,6 +176,7 @@ struct calipso_hip_solver {
     std::vector<double> hparams;
     double* multi_rhs = nullptr;  // workspace of the multi-right-hand-side solve of differentiate! (allocated on demand)
     double* dsym_multi = nullptr; // n * np
+    void* scatter_aux = nullptr;  // scatter.hip: registered sparsity patterns of the evaluate! scatter
     void* ldl_aux = nullptr;      // ldlsolver.hip: staging of the caller's CSC matrix (handles made by calipso_hip_ldl_create)
     double* Hdense = nullptr; int* lu_ipiv = nullptr;   // fallback.hip: N x N unreduced matrix and pivots (allocated on first use)
     hipEvent_t ev[16];
@@ -249,6 +250,8 @@ int nonsymmetric_solve(calipso_hip_solver* s, const double* res, double* step); 
 void nonsymmetric_release(calipso_hip_solver* s);
 // group.hip
 void group_member_destroyed(struct calipso_hip_group* g, calipso_hip_solver* s);   // called by calipso_hip_destroy on a member of a live group
+// scatter.hip
+void scatter_release(calipso_hip_solver* s);
 // ldlsolver.hip
 void ldlsolver_release(calipso_hip_solver* s);
 // structure.hip

@@ -140,6 +140,17 @@ int32_t calipso_hip_device_count(void);
  *   "primal_regularization_last" "dual_regularization";  options (options.jl:6-59): "opt.<field>" (as double). */
 int32_t calipso_hip_set_field(calipso_hip_solver*, const char* name, const double* data, int64_t len);
 int32_t calipso_hip_get_field(calipso_hip_solver*, const char* name, double* data, int64_t len);
+/* The scatter of evaluate! on the device (evaluate.jl:37-121): register `methods.<field>_sparsity` once — `count` (row, col)
+ * pairs, 1-based, in cache order, duplicates allowed — then hand over only the value caches of an evaluation: O(nnz) over PCIe instead of the
+ * dense blocks.  Semantics of the reference: plain assignment in list order, so the LAST writer of a repeated entry wins (the trajectory layer
+ * repeats entries across stages); the three Hessian matrices are assigned separately and summed into "lagrangian_hessian"
+ * (residual_jacobian_variables.jl:10-16).  Fields: "objective_jacobian_variables_variables", "equality_dual_jacobian_variables_variables",
+ * "cone_dual_jacobian_variables_variables" (calipso_hip_scatter_hessian; NULL skips a part), "equality_jacobian_variables",
+ * "cone_jacobian_variables" (calipso_hip_scatter_field). */
+int32_t calipso_hip_set_sparsity(calipso_hip_solver*, const char* field, int64_t count, const int64_t* rows, const int64_t* cols);
+int32_t calipso_hip_scatter_field(calipso_hip_solver*, const char* field, const double* values, int64_t count);
+int32_t calipso_hip_scatter_hessian(calipso_hip_solver*, const double* objective_values, int64_t n_objective, const double* equality_dual_values,
+                                    int64_t n_equality_dual, const double* cone_dual_values, int64_t n_cone_dual);
 /* Indices (indices.jl:1-63) as the handle computed them, 1-based; returns the length or a negative status */
 int64_t calipso_hip_get_index(calipso_hip_solver*, const char* name, int64_t* out, int64_t cap);
 
