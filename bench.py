@@ -152,13 +152,24 @@ def cpu_baseline(shape, name="C3", staged=None, samples=3, full=False):
                       K.shape[0], 1 + n_r, float(np.median(ts))))
     except Exception as e:   # pragma: no cover
         b1 = dict(error=repr(e))
+    # B2: the reference itself, only where a julia with CALIPSO's dependencies exists (none in this project's containers)
+    import shutil
+    import subprocess
+    b2 = "julia unavailable"
+    if staged is None and shutil.which("julia") and os.environ.get("CALIPSO_JL_PROJECT"):
+        try:
+            r = subprocess.run(["julia", "--project=" + os.environ["CALIPSO_JL_PROJECT"], os.path.join(ROOT, "bench", "ref_julia.jl")] + [str(v) for v in shape],
+                               capture_output=True, text=True, timeout=3600)
+            b2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:   # pragma: no cover
+            b2 = "julia run failed: %r" % (e,)
     note = "" if staged is None else ("(the port assembles and factors the blocks densely: it does not exploit the stage structure, which the "
                                       "reference's sparse LDL^T would) ")
     return dict(value=1.0 / t_i, unit="Newton steps/s", cores=1, kind="port",
                 sample=note + "B0(i): %d sample(s) of 1 Newton step (evaluate + cone + residual + search_direction: 1 LDL^T factorisation, %d solves) of "
                        "%s problem 0, median %.1f s, all %s s" % (len(times), 1 + n_r, name, t_i, ["%.1f" % t for t in times]),
                 samples_s=times, status=int(rc), host_cores=os.cpu_count(),
-                B0_ii_reference_refactorisation=b0ii, B1_lapack_all_cores=b1)
+                B0_ii_reference_refactorisation=b0ii, B1_lapack_all_cores=b1, B2_julia_reference=b2)
 
 
 def main():
