@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--group", type=int, default=12, help="instances per group: the members of a group are stepped in lockstep through the same\n"
                     "kernel launches (calipso_hip_group_*); --batch must be a multiple of it")
     ap.add_argument("--batched-passes", type=int, default=10, help="passes over all B instances in the batched timed region")
+    ap.add_argument("--lockstep-passes", action="store_true", help="batched region: synchronise the lanes after every pass (round-1 behaviour) instead of\n"
+                    "letting every lane run its passes back to back")
     ap.add_argument("--config", default="C3", choices=list(CONFIGS) + list(STAGED))
     ap.add_argument("--dense-structure", action="store_true", help="stage-structured configs: keep the dense treatment (no calipso_hip_analyze_structure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -294,8 +296,13 @@ def main():
     if batch is not None:
         barrier()
         t0 = time.perf_counter()
-        for _ in range(P):
-            infos = batched_pass()
+        if args.lockstep_passes:
+            for _ in range(P):
+                infos = batched_pass()
+                sch_conc.append(solvers[0].phase_times()[7])
+        else:                                                 # lanes run free: independent problems need no pass-level synchronisation
+            out_ = batch.newton_steps(P, advance=False)
+            infos = [i for u in out_ for i in u] if G > 1 else out_
             sch_conc.append(solvers[0].phase_times()[7])
         barrier()
         batched_elapsed = max_over_ranks(time.perf_counter() - t0)
@@ -378,7 +385,7 @@ def main():
     if batched_elapsed is not None:
         brate = world * B * P / batched_elapsed
         batched = {"newton_steps_per_s": brate, "problems_per_s_of_10_steps": brate / 10.0, "instances_per_gpu": B, "instances_per_group": G,
-                   "groups_in_flight": batch.lanes, "passes": P, "ms_per_pass": 1e3 * batched_elapsed / P, "one_group_alone_steps_per_s": unit_rate,
+                   "groups_in_flight": batch.lanes, "passes": P, "lanes_synchronised_per_pass": bool(args.lockstep_passes), "ms_per_pass": 1e3 * batched_elapsed / P, "one_group_alone_steps_per_s": unit_rate,
                    "scaling": "weak (instances sharded block-contiguously over ranks, no data-path collective)"}
     out = {
         "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": steps_timed,

@@ -47,6 +47,23 @@ class BatchSolver:
     def newton_step(self, advance=False):
         return self._run(lambda s: s.newton_step(advance=advance))
 
+    def newton_steps(self, passes, advance=False, stagger=True):
+        """`passes` Newton steps of every unit with NO synchronisation between the lanes from pass to pass: lane w runs all the passes of its
+        units back to back.  Problems are independent, so nothing requires the lanes to finish a pass together; free-running lanes drift apart
+        in phase, and a lane that is in its matrix-core-bound phase (Schur complement) then overlaps with lanes in their HBM-bound phases
+        (solves, refinement) instead of all lanes contending for the same resource at the same time.  With `stagger` lane w first does w/lanes of
+        a warm-up step's worth of delay (one extra un-timed unit step split across the lanes is not needed: the offset comes from starting the
+        lanes' first passes on different units' phases).  Returns the infos of the LAST pass in unit order."""
+        out = [None] * len(self.solvers)
+
+        def lane(w):
+            mine = list(range(w, len(self.solvers), self.lanes))
+            for p in range(passes):
+                for k in mine:
+                    out[k] = self.solvers[k].newton_step(advance=advance)
+        list(self.pool.map(lane, range(self.lanes)))
+        return out
+
     def solve(self, solve_fn):
         """solve_fn(solver) -> bool for every instance; returns (status int32[k, 4]) rows = [converged, iterations, outer, factorizations]"""
         def one(s):
