@@ -138,6 +138,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->gemv_partial, std::max(64 * maxdim, ((NX + 15) / 16) * M + ((M + 1023) / 1024) * NX));   // gemv_n chunks / gemv_both partials
     SL(&s->vtmp, 4 * std::max(N, NPd));
     SL(&s->xbuf, NPd); SL(&s->zf, NPd); SL(&s->t1, M); SL(&s->t2, M);
+    SL(&s->zsx, M); SL(&s->w1, NX); SL(&s->w2, NX); SL(&s->lxv, NX);
     SL(&s->lgp, NX * d.np); SL(&s->gp, NE * d.np); SL(&s->hp, NC * d.np);
     SL(&s->jacobian_parameters, N * d.np); SL(&s->solution_sensitivity, N * d.np);
     SL(&s->qp.q, NX); SL(&s->qp.bh, M);
@@ -437,14 +438,33 @@ static void do_sds(H* s, int which, double* accumulate = nullptr) {
     double* st = which == 0 ? s->step : s->step_correction;
     launch_residual_symmetric(s, res);     // b, and the first operands of the condensed solve (xbuf, t1)
     linear_solve_device(s);                // dx = S^-1(...) in xbuf, t2 = [gx; hx] dx
-    launch_recover(s, st, res, accumulate);   // dy, dz back-substitution + dr, ds, dt recovery (+ step += correction)
+    // dy, dz back-substitution + dr, ds, dt recovery (+ step += correction); which = 0 also leaves zsx = [gx; hx] step_x = t2 for the refinement
+    launch_recover(s, st, res, accumulate, which == 0 ? 1 : 0);
 }
 
-// iterative_refinement.jl:1-52
-static int do_refinement(H* s, int* rounds, double* final_norm) {
-    const Options& o = s->opt;
+// residual_error = residual - H step and its inf-norm (dscal[7]), computed so that the operands of the NEXT condensed solve fall out of the same
+// passes (vectors.hip: k_refine_local / k_refine_x): needs zsx = [gx; hx] step_x
+static void refine_residual(H* s) {
+    const Dims& d = s->d;
+    launch_refine_local(s);
+    if (d.m) gemv_t2(s, d.m, d.nx, s->Z, d.m, s->step + d.oy(), s->t1, s->w1, s->w2, SP_Z);
+    gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, s->step, s->lxv, 1.0, 0.0, SP_LXX);
+    launch_refine_x(s);
+}
+// the condensed solve for the operands refine_residual left (xbuf, residual_symmetric); step += correction, zsx += [gx; hx] dx
+static void refine_solve(H* s) {
+    const Dims& d = s->d;
+    launch_trsv(s, s->xbuf);
+    if (d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->xbuf, s->t2, 1.0, 0.0, SP_Z);
+    launch_recover(s, s->step_correction, s->residual_error, s->step, 2);
+}
+
+// iterative_refinement.jl:1-52.  zsx_valid: zsx already holds [gx; hx] step_x (it does right after do_sds(s, 0))
+static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid = false) {
+    const Options& o = s->opt; const Dims& d = s->d;
     fill_d(s, s->step_correction, s->d.N, 0.0);
-    launch_residual_error(s, s->step);
+    if (!zsx_valid && d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->step, s->zsx, 1.0, 0.0, SP_Z);
+    refine_residual(s);
     if (read_scalars(s, 7, 1)) return CALIPSO_ERR_HIP;
     double norm = s->hscal[7];
     const double norm0 = norm;
@@ -456,8 +476,8 @@ static int do_refinement(H* s, int* rounds, double* final_norm) {
             s->stats.last_refine = it; s->stats.refine_max = std::max<calipso::i64>(s->stats.refine_max, it);
             return CALIPSO_OK;
         }
-        do_sds(s, 1, s->step);             // step += step_correction fused into the recovery kernel
-        launch_residual_error(s, s->step);
+        refine_solve(s);                   // step += step_correction fused into the recovery kernel
+        refine_residual(s);
         if (read_scalars(s, 7, 1)) return CALIPSO_ERR_HIP;
         norm = s->hscal[7];
         it += 1;
@@ -475,7 +495,7 @@ static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
     if (rc < 0) return rc;
     do_sds(s, 0);
     if (s->opt.iterative_refinement) {
-        rc = do_refinement(s, rounds, nullptr);
+        rc = do_refinement(s, rounds, nullptr, true);
         if (rc < 0) return rc;
         if (rc == CALIPSO_WARN_REFINEMENT) {
             // the reference falls back to `H \ residual` on the unreduced system (search_direction.jl:22,113): fallback.hip

@@ -53,6 +53,36 @@ __global__ __launch_bounds__(256) void k_gemv_t(Batch bt, Sparsity sp, int rows,
     if (lane == 0) y[col] = (beta == 0.0) ? alpha * r : alpha * r + beta * y[col];
 }
 
+// y1 = A'x1 and y2 = A'x2 with ONE pass over A: the refinement residual needs [gx; hx]'(step_y; step_z) and the condensed solve that follows
+// needs [gx; hx]'(Omega b_m) — both input vectors are known at the same time (vectors.hip: k_refine_local), so the largest block of a
+// refinement round is read once for the two.  Same lane / summation layout as k_gemv_t.
+__global__ __launch_bounds__(256) void k_gemv_t2(Batch bt, Sparsity sp, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x1,
+                                                  const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2) {
+    inst_shift(bt, A, x1, x2, y1, y2);
+    if (sp.kr) inst_shift_i(bt, sp.kr);
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= cols) return;
+    const double* a = A + (size_t)col * ld;
+    const BlockRanges br = column_blocks(sp, col, rows);
+    double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
+    for (int base = 0; base < rows; base += 64 * 24) {
+        if (sp.kind != SP_DENSE && !(base / 64 < max(br.b1, br.b3) && base / 64 + 24 > min(br.b0, br.b2 < br.b3 ? br.b2 : br.b0))) continue;
+        double v[24];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) { const int i = base + lane + 64 * q; v[q] = (i < rows && block_active(br, base / 64 + q)) ? a[i] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 24; q += 2) {
+            const int i = base + lane + 64 * q;
+            const bool in0 = i < rows, in1 = i + 64 < rows;
+            p0 += v[q] * (in0 ? x1[i] : 0.0); p1 += v[q + 1] * (in1 ? x1[i + 64] : 0.0);
+            q0 += v[q] * (in0 ? x2[i] : 0.0); q1 += v[q + 1] * (in1 ? x2[i + 64] : 0.0);
+        }
+    }
+    const double r1 = wave_sum(p0 + p1), r2 = wave_sum(q0 + q1);
+    if (lane == 0) { y1[col] = r1; y2[col] = r2; }
+}
+
 // the structure tables of `s` for a block of the given kind (dense unless calipso_hip_analyze_structure found a band)
 static Sparsity sparsity_of(const calipso_hip_solver* s, int kind) {
     Sparsity sp;
@@ -65,6 +95,12 @@ void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, 
     if (cols == 0) return;
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, A, ld, x, y, alpha, beta);
+}
+
+void gemv_t2(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x1, const double* x2, double* y1, double* y2, int kind) {
+    if (cols == 0) return;
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_gemv_t2, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, A, ld, x1, x2, y1, y2);
 }
 
 constexpr int GN_ROWS = 256;    // rows per workgroup

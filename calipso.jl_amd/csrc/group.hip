@@ -189,10 +189,24 @@ static void gb_sds(G* g, const Set& a, int which, bool accumulate) {
     const double* res = which == 0 ? s->residual : s->residual_error;
     launch_residual_symmetric(s, res);
     linear_solve_device(s);
-    launch_recover(s, which == 0 ? s->step : s->step_correction, res, accumulate ? s->step : nullptr);
+    launch_recover(s, which == 0 ? s->step : s->step_correction, res, accumulate ? s->step : nullptr, which == 0 ? 1 : 0);   // which = 0: zsx = [gx; hx] step_x
+}
+// the two halves of a refinement round for the active members (api.hip: refine_residual / refine_solve)
+static void gb_refine_residual(G* g) {
+    H* s = g->base; const Dims& d = s->d;
+    launch_refine_local(s);
+    if (d.m) gemv_t2(s, d.m, d.nx, s->Z, d.m, s->step + d.oy(), s->t1, s->w1, s->w2, SP_Z);
+    gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, s->step, s->lxv, 1.0, 0.0, SP_LXX);
+    launch_refine_x(s);
+}
+static void gb_refine_solve(G* g) {
+    H* s = g->base; const Dims& d = s->d;
+    launch_trsv(s, s->xbuf);
+    if (d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->xbuf, s->t2, 1.0, 0.0, SP_Z);
+    launch_recover(s, s->step_correction, s->residual_error, s->step, 2);
 }
 
-// iterative_refinement! (iterative_refinement.jl:1-52) for every member of `a`
+// iterative_refinement! (iterative_refinement.jl:1-52) for every member of `a` (called right after gb_sds(g, a, 0, ...): zsx is valid)
 static int gb_refinement(G* g, const Set& a, std::vector<int>& rc, std::vector<int>& rounds) {
     H* s = g->base;
     const size_t B = g->hs.size();
@@ -200,7 +214,7 @@ static int gb_refinement(G* g, const Set& a, std::vector<int>& rc, std::vector<i
     std::vector<int> it(B, 0);
     g_activate(g, a);
     fill_d(s, s->step_correction, s->d.N, 0.0);
-    launch_residual_error(s, s->step);
+    gb_refine_residual(g);
     if (g_read_d(g, a, 7, 1)) return CALIPSO_ERR_HIP;
     for (int i : a) { norm[i] = g->hs[i]->hscal[7]; norm0[i] = norm[i]; }
     Set run = a;
@@ -223,8 +237,9 @@ static int gb_refinement(G* g, const Set& a, std::vector<int>& rc, std::vector<i
             } else sub.push_back(i);
         }
         if (sub.empty()) break;
-        gb_sds(g, sub, 1, true);
-        launch_residual_error(s, s->step);
+        g_activate(g, sub);
+        gb_refine_solve(g);
+        gb_refine_residual(g);
         if (g_read_d(g, sub, 7, 1)) return CALIPSO_ERR_HIP;
         for (int i : sub) { norm[i] = g->hs[i]->hscal[7]; it[i] += 1; }
         run.swap(sub);

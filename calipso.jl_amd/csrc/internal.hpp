@@ -171,6 +171,8 @@ struct calipso_hip_solver {
     double* gemv_partial = nullptr;   // partial sums for column-split mat-vecs
     double* vtmp = nullptr;     // 4*N scratch vectors
     double *xbuf = nullptr, *zf = nullptr, *t1 = nullptr, *t2 = nullptr;   // NP, NP, m, m: work vectors of the condensed solve
+    double *zsx = nullptr;                                                  // m: [gx; hx] step_x, kept up to date across refinement rounds (vectors.hip)
+    double *w1 = nullptr, *w2 = nullptr, *lxv = nullptr;                    // nx each: [gx; hx]'step_yz, [gx; hx]'(Omega b_m), Lxx step_x
     double *saved_g = nullptr, *saved_h = nullptr;                          // ne, nc (benchmark-mode restore)
     double *lgp = nullptr, *gp = nullptr, *hp = nullptr;                    // nx*np, ne*np, nc*np parameter Jacobians
     std::vector<double> hparams;
@@ -203,7 +205,12 @@ void launch_cone_violation_host(calipso_hip_solver* s, const double* xhat_dev, c
 void launch_residual(calipso_hip_solver* s);
 void launch_violations(calipso_hip_solver* s);                  // -> dscal[8..]
 void launch_residual_symmetric(calipso_hip_solver* s, const double* res);   // also fills xbuf (b_x, zero padded) and t1 = Omega b_m
-void launch_recover(calipso_hip_solver* s, double* step, const double* res, double* accumulate);   // back-substitution + recovery (+ accumulate += step)
+// back-substitution + recovery (+ accumulate += step); zsx_mode 0: leave zsx, 1: zsx = [gx; hx] dx (= t2), 2: zsx += t2
+void launch_recover(calipso_hip_solver* s, double* step, const double* res, double* accumulate, int zsx_mode = 0);
+// one refinement residual in two kernels around the mat-vecs (see vectors.hip): rows r, s, y, z, t of residual_error = residual - H step from
+// zsx, the condensed b_m and t1 = Omega b_m, partial norm -> dscal[18]; then the x rows, dscal[7] = ||residual_error||_inf, xbuf = [b_x + w2; 0]
+void launch_refine_local(calipso_hip_solver* s);
+void launch_refine_x(calipso_hip_solver* s);
 void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s);
 void launch_accept(calipso_hip_solver* s, double step_size);
 void launch_axpy_points_batch(calipso_hip_solver* s, const double* step_size, int with_s);
@@ -219,6 +226,7 @@ void launch_assemble_K(calipso_hip_solver* s);
 // gemv.hip
 void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
 void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
+void gemv_t2(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x1, const double* x2, double* y1, double* y2, int kind = SP_DENSE);   // y1 = A'x1, y2 = A'x2, one pass
 void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t,
                int kind = SP_DENSE);   // yn = A x, yt = A'u + beta_t*yt, one pass over A
 // `kind` names the block (SP_Z, SP_GX, SP_HX, SP_LXX) so that a handle with an analysed structure skips its structural zeros

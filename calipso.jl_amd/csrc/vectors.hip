@@ -172,9 +172,10 @@ void launch_residual_symmetric_multi(calipso_hip_solver* s, const double* res, i
 __global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res_,
                           const double* __restrict__ b_, const double* __restrict__ dx_, const double* __restrict__ t2_,
                           const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ dsym_,
-                          double* __restrict__ step_, double* __restrict__ accum) {
+                          double* __restrict__ step_, double* __restrict__ accum, double* __restrict__ zsx, int zsx_mode) {
     inst_shift(bt.b, w, res_, b_, dx_, t2_, wz, Wsoc, dsym_, step_);
     if (accum) inst_shift(bt.b, accum);
+    if (zsx_mode) inst_shift(bt.b, zsx);
     const Scalars sc = bt.sc[blockIdx.z];
     // blockIdx.y = right-hand-side column (see k_residual_symmetric); dsym_ may be null for the multi-column use
     const double* res = res_ + (size_t)blockIdx.y * d.N;
@@ -194,6 +195,7 @@ __global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restri
         const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
         const double dy = -1.0 * omega_y * (b[d.nx + k] - t2[k]);
         dsym[d.nx + k] = dy;
+        if (zsx_mode) zsx[k] = zsx_mode == 1 ? t2[k] : zsx[k] + t2[k];         // [gx; hx] step_x follows the step
         const double dr = (res[d.orr() + k] + dy) / Hrr;
         step[d.oy() + k] = dy;
         step[d.orr() + k] = dr;
@@ -202,6 +204,7 @@ __global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restri
         const int k = i - d.nx - d.ne;
         const double dz = -1.0 * wz[k] * (b[d.nx + d.ne + k] - t2[d.ne + k]);
         dsym[d.nx + d.ne + k] = dz;
+        if (zsx_mode) zsx[d.ne + k] = zsx_mode == 1 ? t2[d.ne + k] : zsx[d.ne + k] + t2[d.ne + k];
         const double Sb = w[d.os() + k] - sc.ed, Ti = w[d.ot() + k], Pi = Hss;
         const double rt = res[d.ot() + k], rs = res[d.os() + k];
         const double ds = (rt + Sb * (rs + dz)) / (Ti + Sb * Pi);
@@ -216,6 +219,7 @@ __global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restri
         const double* rs = res + d.os() + st; const double* rt = res + d.ot() + st;
         const double* W = Wsoc + cd.soc_woff[j];
         for (int a = 0; a < dim; ++a) o[a] = b[d.nx + d.ne + st + a] - t2[d.ne + st + a];
+        if (zsx_mode) for (int a = 0; a < dim; ++a) zsx[d.ne + st + a] = zsx_mode == 1 ? t2[d.ne + st + a] : zsx[d.ne + st + a] + t2[d.ne + st + a];
         for (int a = 0; a < dim; ++a) {
             double s = 0.0;
             for (int c = 0; c < dim; ++c) s += W[a + c * dim] * o[c];
@@ -246,11 +250,11 @@ __global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restri
     }
 }
 
-void launch_recover(calipso_hip_solver* s, double* step, const double* res, double* accumulate) {
+void launch_recover(calipso_hip_solver* s, double* step, const double* res, double* accumulate, int zsx_mode) {
     const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128, 1, B.b.n), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
-                       s->residual_symmetric, s->xbuf, s->t2, s->wz, s->Wsoc, s->step_symmetric, step, accumulate);
+                       s->residual_symmetric, s->xbuf, s->t2, s->wz, s->Wsoc, s->step_symmetric, step, accumulate, s->zsx, zsx_mode);
 }
 __global__ void k_scale_inplace(size_t n, double* __restrict__ x, double a) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -261,7 +265,7 @@ void launch_recover_multi(calipso_hip_solver* s, const double* res, int p, const
     const int work = s->d.nx + s->d.ne + s->d.q + s->d.n_soc;
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128, p, 1), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
-                       rsym, xbuf, t2, s->wz, s->Wsoc, s->dsym_multi, step, (double*)nullptr);
+                       rsym, xbuf, t2, s->wz, s->Wsoc, s->dsym_multi, step, (double*)nullptr, (double*)nullptr, 0);
     if (scale != 1.0) {
         const size_t n = (size_t)s->d.N * p;
         hipLaunchKernelGGL(k_scale_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, step, scale);
@@ -484,6 +488,127 @@ void launch_residual_error(calipso_hip_solver* s, const double* step) {
     hmul_matvecs(s, step, s->residual_error);
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_Hmul_err, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->cone, s->solution, step, s->residual, s->residual_error, s->dscal + 7);
+}
+
+// ---- one refinement residual, split around its mat-vecs (iterative_refinement.jl:8-12,38-41 + residual.jl:53-101) ------------------------------
+// residual_error = residual - H step needs [gx; hx] step_x (rows y, z), [gx; hx]'(step_y; step_z) and Lxx step_x (rows x).  zsx = [gx; hx] step_x
+// is kept up to date by k_recover (step += correction  =>  zsx += [gx; hx] dx, which the condensed solve has just computed as t2), so the rows
+// r, s, y, z, t of the residual need no mat-vec at all — and with them the whole condensed right-hand side b_m of the NEXT solve and its first
+// operand t1 = Omega b_m.  k_refine_local does that; then ONE pass over [gx; hx] yields both transposed products (gemv_t2), one pass over Lxx
+// the Hessian product, and k_refine_x finishes the x rows, the norm and the solve operand xbuf = b_x + [gx; hx]' Omega b_m.
+// A round thus reads [gx; hx] twice (here and for t2 = [gx; hx] dx in the solve) instead of three times.
+__global__ __launch_bounds__(RT) void k_refine_local(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
+                                                      const double* __restrict__ res, const double* __restrict__ zsx, const double* __restrict__ wz,
+                                                      const double* __restrict__ Wsoc, double* __restrict__ e, double* __restrict__ rsym,
+                                                      double* __restrict__ t1, double* __restrict__ dscal) {
+    __shared__ double sm[RT / 64];
+    inst_shift(bt.b, w, v, res, zsx, wz, Wsoc, e, rsym, t1, dscal);
+    const Scalars sc = bt.sc[blockIdx.z];
+    const double* sl = w + d.os(); const double* t = w + d.ot();
+    const double* vs = v + d.os(); const double* vt = v + d.ot();
+    double m = 0.0;
+    for (int i = d.nx + threadIdx.x; i < d.N; i += RT) {
+        double hv;
+        if (i < d.os()) hv = (sc.rho + sc.ep) * v[i] - v[d.oy() + i - d.orr()];
+        else if (i < d.oy()) { const int k = i - d.os(); hv = (0.0 + sc.ep) * v[i] - v[d.oz() + k] - v[d.ot() + k]; }
+        else if (i < d.oz()) hv = zsx[i - d.oy()] + (-v[d.orr() + i - d.oy()] + (0.0 - sc.ed) * v[i]);
+        else if (i < d.ot()) hv = zsx[d.ne + i - d.oz()] + (-v[d.os() + i - d.oz()] + (0.0 - sc.ed) * v[i]);
+        else {
+            const int k = i - d.ot();
+            const int j = cd.entry_soc[k];
+            if (j < 0) hv = t[k] * vs[k] + (sl[k] - sc.ed) * vt[k];
+            else {
+                const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+                if (k == st) {
+                    hv = t[st] * vs[st] + (sl[st] - sc.ed) * vt[st];
+                    for (int q = 1; q < dim; ++q) hv += t[st + q] * vs[st + q] + sl[st + q] * vt[st + q];
+                } else {
+                    hv = t[k] * vs[st] + sl[k] * vt[st];
+                    hv += t[st] * vs[k] + (sl[st] - sc.ed) * vt[k];
+                }
+            }
+        }
+        const double r = res[i] - hv;
+        e[i] = r;
+        m = fmax(m, fabs(r));
+    }
+    const double mr = block_max(m, sm);
+    if (threadIdx.x == 0) dscal[18] = mr;
+    __threadfence_block();
+    __syncthreads();                           // the rows written above are read below by other lanes of this (single) workgroup
+    // condensed right-hand side of the constraint rows and t1 = Omega b_m  (= the constraint part of k_residual_symmetric on residual_error)
+    const double Hrr = sc.rho + sc.ep, Hss = 0.0 + sc.ep;
+    for (int ee = threadIdx.x; ee < d.ne + d.q + d.n_soc; ee += RT) {
+        if (ee < d.ne) {
+            double b = e[d.oy() + ee];
+            b += e[d.orr() + ee] / Hrr;
+            rsym[d.nx + ee] = b;
+            const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+            t1[ee] = omega_y * b;
+        } else if (ee < d.ne + d.q) {
+            const int k = ee - d.ne;
+            const double Sb = w[d.os() + k] - sc.ed, Ti = w[d.ot() + k], Pi = Hss;
+            double b = e[d.oz() + k];
+            b += (e[d.ot() + k] + Sb * e[d.os() + k]) / (Ti + Sb * Pi);
+            rsym[d.nx + d.ne + k] = b;
+            t1[d.ne + k] = wz[k] * b;
+        } else {
+            const int j = ee - d.ne - d.q;
+            const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+            double u[MAX_SOC_DIM], vv[MAX_SOC_DIM], o[MAX_SOC_DIM];
+            const double* slj = w + d.os() + st; const double* tj = w + d.ot() + st;
+            const double* rs = e + d.os() + st; const double* rt = e + d.ot() + st;
+            const double sb1 = slj[0] - sc.ed;
+            u[0] = tj[0] + sb1 * Hss;
+            for (int k = 1; k < dim; ++k) u[k] = tj[k] + slj[k] * Hss;
+            double acc = sb1 * rs[0];
+            for (int k = 1; k < dim; ++k) acc += slj[k] * rs[k];
+            vv[0] = acc + rt[0];
+            for (int k = 1; k < dim; ++k) vv[k] = (slj[k] * rs[0] + sb1 * rs[k]) + rt[k];
+            arrow_inverse(dim, u, vv, o);
+            for (int k = 0; k < dim; ++k) { o[k] = e[d.oz() + st + k] + o[k]; rsym[d.nx + d.ne + st + k] = o[k]; }
+            const double* W = Wsoc + cd.soc_woff[j];
+            for (int a = 0; a < dim; ++a) {
+                double ss = 0.0;
+                for (int b = 0; b < dim; ++b) ss += W[a + b * dim] * o[b];
+                t1[d.ne + st + a] = ss;
+            }
+        }
+    }
+}
+
+// x rows: residual_error_x = residual_x - ((Lxx step_x + [gx; hx]' step_yz) + ep step_x); dscal[7] = ||residual_error||_inf (with the partial norm of
+// k_refine_local); condensed b_x = residual_error_x; xbuf = [b_x + [gx; hx]' Omega b_m; 0]
+__global__ __launch_bounds__(RT) void k_refine_x(BatchSc bt, Dims d, int have_m, const double* __restrict__ v, const double* __restrict__ res,
+                                                  const double* __restrict__ lxv, const double* __restrict__ w1, const double* __restrict__ w2,
+                                                  double* __restrict__ e, double* __restrict__ rsym, double* __restrict__ xbuf, double* __restrict__ dscal) {
+    __shared__ double sm[RT / 64];
+    inst_shift(bt.b, v, res, lxv, w1, w2, e, rsym, xbuf, dscal);
+    const Scalars sc = bt.sc[blockIdx.z];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < d.NP; i += RT) {
+        if (i < d.nx) {
+            const double hv = (lxv[i] + (have_m ? w1[i] : 0.0)) + sc.ep * v[i];
+            const double r = res[i] - hv;
+            e[i] = r;
+            rsym[i] = r;
+            xbuf[i] = have_m ? r + w2[i] : r;
+            m = fmax(m, fabs(r));
+        } else xbuf[i] = 0.0;
+    }
+    const double mr = block_max(m, sm);
+    if (threadIdx.x == 0) dscal[7] = fmax(mr, dscal[18]);
+}
+
+void launch_refine_local(calipso_hip_solver* s) {
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_refine_local, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->cone, s->solution, s->step, s->residual, s->zsx, s->wz, s->Wsoc,
+                       s->residual_error, s->residual_symmetric, s->t1, s->dscal);
+}
+void launch_refine_x(calipso_hip_solver* s) {
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_refine_x, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->d.m > 0 ? 1 : 0, s->step, s->residual, s->lxv, s->w1, s->w2, s->residual_error,
+                       s->residual_symmetric, s->xbuf, s->dscal);
 }
 
 __global__ void k_add(Batch bt, int n, double* __restrict__ y, const double* __restrict__ x) {
