@@ -335,6 +335,60 @@ def qp_equality_parametric(seed=0, nx=10, ne=5):
     return prob
 
 
+def double_integrator(horizon=5, action_guess=None):
+    """test/examples/double_integrator.jl:1-90 written in standard form: z = [X1;U1;...;X_{T-1};U_{T-1};X_T] (X in R^2, U in R), equality rows
+    [dynamics d_1..d_{T-1}; X1 - x_init; X_T - x_goal] (src/trajectory_optimization/indices.jl:63-80), parameters theta = [theta_1; theta_t...;
+    theta_T] with theta_1 = [vec(A); B; diag(Q); R; x_init] (11), theta_t = [vec(A); B; diag(Q); R] (9), theta_T = [diag(Q_T); x_goal] (4).
+    The reference draws the action guess with randn (:81); fix it."""
+    T = horizon
+    nz = 2 * T + (T - 1)
+    A = np.array([[1.0, 1.0], [0.0, 1.0]]); B = np.array([0.0, 1.0])
+    th1 = np.concatenate([A.T.reshape(-1), B, [1.0, 1.0], [0.1], [0.0, 0.0]])
+    tht = np.concatenate([A.T.reshape(-1), B, [1.0, 1.0], [0.1]])
+    thT = np.array([10.0, 10.0, 1.0, 0.0])
+    theta = np.concatenate([th1] + [tht] * (T - 2) + [thT])
+    off = [0]
+    for t in range(T):
+        off.append(off[-1] + (11 if t == 0 else (9 if t < T - 1 else 4)))
+
+    def X(z, t):
+        return z[3 * t: 3 * t + 2]
+
+    def U(z, t):
+        return z[3 * t + 2: 3 * t + 3]
+
+    def W(th, t):
+        return th[off[t]: off[t + 1]]
+
+    def objective(z, th):
+        J = 0
+        for t in range(T - 1):
+            w = W(th, t)
+            J += 0.5 * (w[6] * X(z, t)[0] ** 2 + w[7] * X(z, t)[1] ** 2) + 0.5 * w[8] * U(z, t)[0] ** 2
+        w = W(th, T - 1)
+        return J + 0.5 * (w[0] * X(z, T - 1)[0] ** 2 + w[1] * X(z, T - 1)[1] ** 2)
+
+    def equality(z, th):
+        e = []
+        for t in range(T - 1):
+            w = W(th, t)                       # A = reshape(w[1:4], 2, 2) column-major, B = w[5:6]
+            x, u, y = X(z, t), U(z, t), X(z, t + 1)
+            e += [y[0] - (w[0] * x[0] + w[2] * x[1] + w[4] * u[0]), y[1] - (w[1] * x[0] + w[3] * x[1] + w[5] * u[0])]
+        w1, wT = W(th, 0), W(th, T - 1)
+        e += [X(z, 0)[0] - w1[9], X(z, 0)[1] - w1[10], X(z, T - 1)[0] - wT[2], X(z, T - 1)[1] - wT[3]]
+        return e
+
+    x0 = np.zeros(nz)
+    for t in range(T):                         # linear_interpolation(state_initial, state_goal, horizon)
+        x0[3 * t: 3 * t + 2] = np.array([1.0, 0.0]) * t / (T - 1)
+    if action_guess is not None:
+        for t in range(T - 1):
+            x0[3 * t + 2] = action_guess[t]
+    prob = SymbolicProblem(nz, objective, equality, None, np_=theta.size, parameters=theta, x0=x0, name="double_integrator")
+    prob.horizon = T
+    return prob
+
+
 def qp_nonnegative_parametric(seed=0, nx=10, ne=5):
     """test/solver/qp_nonnegative.jl:2-49: the parametric QP of qp_equality.jl with the cone constraint x >= 0 (nc = nx nonnegative entries)"""
     base = qp_equality_parametric(seed=seed, nx=nx, ne=ne)

@@ -156,3 +156,23 @@ def test_qp_nonnegative(oracle_mod):
     for j in (0, prob.nx, prob.np - 1):
         Hs = s.jacobian_variables_mul(S_gpu[:, j])
         assert np.abs(Hs + J[:, j]).max() <= 1e-6 * max(1.0, np.abs(J[:, j]).max(), np.abs(S_gpu[:, j]).max())
+
+
+def test_double_integrator_sensitivities_on_the_device(oracle_mod):
+    """test/examples/double_integrator.jl:3-164 through the HIP path: same iterations as the oracle, sensitivities of the variables within the
+    reference's 1e-3 of the analytic -L_zz \\ L_z,theta and within 1e-6 of the oracle's"""
+    from test_oracle_solve import analytic_sensitivity, run
+    pkg = load_pkg()
+    prob = pr.double_integrator(action_guess=[0.3, -0.2, 0.1, 0.05])
+    opts = dict(residual_tolerance=1e-12, equality_tolerance=1e-8, complementarity_tolerance=1e-8, differentiate=1)
+    s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, parameters=prob.parameters, options=opts)
+    pkg.initialize_b(s, prob.x0)
+    assert pkg.solve_b(s)
+    o, st = run(oracle_mod, prob, **opts)
+    assert st == 1 and s.stats()["total_iterations"] == o.stats()["total_iterations"]
+    S_gpu = s.data("solution_sensitivity")
+    S_cpu = o.mat("solution_sensitivity", o.N, prob.np)
+    assert np.abs(S_gpu - S_cpu).max() <= 1e-6 * max(1.0, np.abs(S_cpu).max())
+    sol = s.solution
+    sens = analytic_sensitivity(prob, sol.variables, sol.equality_dual)
+    assert np.abs(sens[:prob.nx] - S_gpu[:prob.nx]).max() < 1e-3

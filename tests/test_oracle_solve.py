@@ -160,3 +160,45 @@ def test_pendulum_swing_up(oracle_mod):
     criteria(o)
     x = o.point()["x"]
     assert np.abs(x[-2:] - np.array([np.pi, 0.0])).max() < 1e-3 and np.abs(x[:2]).max() < 1e-3
+
+
+def analytic_sensitivity(prob, x, y):
+    """-L_zz \\ L_z,theta of the Lagrangian in (x, y) at the solution (test/examples/double_integrator.jl:111-158), by finite-difference-free
+    evaluation of the problem's own second derivatives: L_zz = [[f_xx + (g'y)_xx, g_x'], [g_x, 0]], L_z,theta = [[f_x,theta + (g'y)_x,theta], [g_theta]]"""
+    nx, ne, npar = prob.nx, prob.ne, prob.np
+    bufs = {}
+    size = dict(objective=1, objective_gradient_variables=nx, equality_constraint=ne, cone_constraint=0, equality_dual_jacobian_variables=nx,
+                cone_dual_jacobian_variables=nx, objective_jacobian_variables_variables=nx * nx, equality_dual_jacobian_variables_variables=nx * nx,
+                cone_dual_jacobian_variables_variables=nx * nx, equality_jacobian_variables=ne * nx, cone_jacobian_variables=0,
+                objective_jacobian_variables_parameters=nx * npar, equality_jacobian_parameters=ne * npar,
+                equality_dual_jacobian_variables_parameters=nx * npar, cone_jacobian_parameters=0, cone_dual_jacobian_variables_parameters=nx * npar)
+    prob.evaluate((1 << 16) - 1, x, y, np.zeros(0), prob.parameters, lambda nm: bufs.setdefault(nm, np.zeros(size[nm])))
+    cm = lambda nm, r, c: bufs[nm].reshape(c, r).T
+    Lxx = cm("objective_jacobian_variables_variables", nx, nx) + cm("equality_dual_jacobian_variables_variables", nx, nx)
+    gx = cm("equality_jacobian_variables", ne, nx)
+    Lzz = np.block([[Lxx, gx.T], [gx, np.zeros((ne, ne))]])
+    Lzth = np.vstack([cm("objective_jacobian_variables_parameters", nx, npar) + cm("equality_dual_jacobian_variables_parameters", nx, npar),
+                      cm("equality_jacobian_parameters", ne, npar)])
+    return -np.linalg.solve(Lzz, Lzth)
+
+
+def test_double_integrator_sensitivities(oracle_mod):
+    """test/examples/double_integrator.jl:3-164: horizon 5, 42 parameters; solve to the example's tolerances with differentiate = true and compare
+    the solver's sensitivities of the variables with the analytic -L_zz \\ L_z,theta (the reference asserts 1e-3, :162-164)"""
+    prob = pr.double_integrator(action_guess=[0.3, -0.2, 0.1, 0.05])
+    assert (prob.nx, prob.ne, prob.nc, prob.np) == (14, 12, 0, 42)
+    o, status = run(oracle_mod, prob, residual_tolerance=1e-12, equality_tolerance=1e-8, complementarity_tolerance=1e-8, differentiate=1)
+    assert status == 1
+    res = o.buf("residual")
+    assert np.abs(res[o.index("variables") - 1]).max() < 1e-4 and np.abs(res[o.index("equality_dual") - 1]).max() < 1e-4   # :97-108
+    assert np.abs(o.buf("equality_constraint")).max() <= 1e-8
+    x, y = o.point()["x"].copy(), o.point()["y"].copy()
+    assert np.abs(x[:2]).max() < 1e-8 and np.abs(x[-2:] - np.array([1.0, 0.0])).max() < 1e-8       # initial / goal state constraints
+    sens = analytic_sensitivity(prob, x, y)
+    S = o.mat("solution_sensitivity", o.N, prob.np)
+    assert np.abs(sens[:prob.nx] - S[:prob.nx]).max() < 1e-3                      # the reference's assertion (the regularised H of the last iterate
+                                                                                   # differs from the exact KKT matrix by O(1e-4) here)
+    # dR/dtheta rows as the reference checks them (:160-161, 1e-5)
+    Jp = o.mat("jacobian_parameters", o.N, prob.np)
+    bufs_gp = o.mat("equality_jacobian_parameters", prob.ne, prob.np)
+    assert np.abs(Jp[o.index("equality_dual") - 1] - bufs_gp).max() < 1e-12
