@@ -19,6 +19,7 @@
 #include "device_utils.hpp"
 
 #include <algorithm>
+#include <mutex>
 
 namespace calipso {
 
@@ -579,11 +580,8 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
 // they are captured once per handle into hipGraphs and replayed, so the host issues one graph launch instead of queueing every
 // kernel (the GPU otherwise waits on the host between the many few-microsecond kernels).
 void ldl_set_attributes() {
-    static bool done = false;
-    if (!done) {   // > 64 KiB of dynamic LDS must be requested explicitly
-        (void)hipFuncSetAttribute((const void*)k_tinv_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 64 * (128 + 2) * sizeof(double)));
-        done = true;
-    }
+    static std::once_flag done;      // > 64 KiB of dynamic LDS must be requested explicitly; host lanes may arrive here concurrently
+    std::call_once(done, [] { (void)hipFuncSetAttribute((const void*)k_tinv_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 64 * (128 + 2) * sizeof(double))); });
 }
 
 template <typename F>

@@ -13,6 +13,7 @@
 #include "device_utils.hpp"
 
 #include <algorithm>
+#include <mutex>
 
 namespace calipso {
 
@@ -442,8 +443,8 @@ static int schur_choose(int nx, int instances, int hb) {
 void schur_plan(calipso_hip_solver* s) { s->schur_nj = schur_choose(s->d.nx, 1, 0); }
 
 void launch_schur(calipso_hip_solver* s) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_LDS_BYTES); attr = true; }
+    static std::once_flag attr;      // (several host lanes launch concurrently: one of them sets the attribute, the others wait for it)
+    std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_LDS_BYTES); });
     if (s->hessian_dirty && !s->cur) { launch_symmetrize(s); s->hessian_dirty = false; }   // (a group refreshes its members itself)
     const BatchSc B = batch_of(s);
     const int hb = s->band64 > 0 ? s->half_bandwidth : 0;       // > 0: only the tiles inside the band (structure.hip)
