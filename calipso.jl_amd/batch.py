@@ -47,13 +47,11 @@ class BatchSolver:
     def newton_step(self, advance=False):
         return self._run(lambda s: s.newton_step(advance=advance))
 
-    def newton_steps(self, passes, advance=False, stagger=True):
+    def newton_steps(self, passes, advance=False):
         """`passes` Newton steps of every unit with NO synchronisation between the lanes from pass to pass: lane w runs all the passes of its
         units back to back.  Problems are independent, so nothing requires the lanes to finish a pass together; free-running lanes drift apart
-        in phase, and a lane that is in its matrix-core-bound phase (Schur complement) then overlaps with lanes in their HBM-bound phases
-        (solves, refinement) instead of all lanes contending for the same resource at the same time.  With `stagger` lane w first does w/lanes of
-        a warm-up step's worth of delay (one extra un-timed unit step split across the lanes is not needed: the offset comes from starting the
-        lanes' first passes on different units' phases).  Returns the infos of the LAST pass in unit order."""
+        in phase, so a lane in its matrix-core-bound phase (Schur complement) can overlap lanes in their HBM-bound phases (solves, refinement).
+        Measured on C4 this is within noise of lock-step passes.  Returns the infos of the LAST pass in unit order."""
         out = [None] * len(self.solvers)
 
         def lane(w):
