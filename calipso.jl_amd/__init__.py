@@ -479,7 +479,7 @@ def _csc_1based(A):
             np.ascontiguousarray(A.data, dtype=np.float64))
 
 
-ORDERINGS = dict(natural=0, rcm=1, minimum_degree=2)
+ORDERINGS = dict(natural=0, rcm=1, minimum_degree=2, nested_dissection=4)
 
 
 def ordering(A, method="rcm"):
@@ -564,6 +564,89 @@ class LDLSolver:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.calipso_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SparseLDL:
+    """Sparse LDL^T on the device (include/calipso_hip.h, "sparse LDL^T on the device"): qdldl(A; perm) / QDLDL_factor! / solve! of
+    src/solver/qdldl.jl for a scipy.sparse matrix A (only triu(A) is read), memory O(nnz(L)), level-scheduled over the elimination tree.
+    method: "natural", "rcm", "minimum_degree", "nested_dissection", or perm=<1-based order>."""
+
+    def __init__(self, A, method="nested_dissection", perm=None, device=0):
+        self._L = lib()
+        A, colptr, rowval, _ = _csc_1based(A)
+        self.n, self.nnz = A.shape[0], A.nnz
+        pp = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+        h = C.c_void_p()
+        rc = self._L.calipso_hip_sparse_create(self.n, _pi(colptr), _pi(rowval), 3 if pp is not None else ORDERINGS[method], _pi(pp) if pp is not None else None,
+                                               device, C.byref(h))
+        if rc != 0:
+            msg = self._L.calipso_hip_sparse_last_error(h if h.value else None).decode()
+            if h.value:
+                self._L.calipso_hip_sparse_destroy(h)
+            raise CalipsoHipError("calipso_hip_sparse_create failed (%d): %s" % (rc, msg))
+        self._h = h
+        info = np.zeros(8, dtype=np.int64)
+        self._check(self._L.calipso_hip_sparse_info(self._h, _pi(info)), "sparse_info")
+        self.info = dict(n=int(info[0]), nnz_upper=int(info[1]), nnzL=int(info[2]), levels=int(info[3]), launches=int(info[4]), widest_level=int(info[5]),
+                         multiply_adds=int(info[6]), lds_accumulator=bool(info[7]))
+        self.inertia = (0, 0, 0)
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise CalipsoHipError("%s failed (%d): %s" % (what, rc, self._L.calipso_hip_sparse_last_error(self._h).decode()))
+        return rc
+
+    def factorize(self, A):
+        """numeric factorisation of A (same pattern as analysed; a scipy.sparse matrix or the nnz values in CSC order); returns the warning
+        status (1 = exact zero pivot met, inertia[0] = -1)"""
+        if hasattr(A, "shape") and len(getattr(A, "shape")) == 2:
+            A, _, _, vals = _csc_1based(A)
+            if A.nnz != self.nnz:
+                raise CalipsoHipError("SparseLDL.factorize: the pattern differs from the analysed one")
+        else:
+            vals = np.ascontiguousarray(A, dtype=np.float64)
+        inr = np.zeros(3, dtype=np.int64)
+        rc = self._check(self._L.calipso_hip_sparse_factorize(self._h, _pd(vals), _pi(inr)), "sparse_factorize")
+        self.inertia = tuple(int(v) for v in inr)
+        return rc
+
+    def solve(self, b):
+        """x = A^-1 b for a vector or an (n, nrhs) matrix"""
+        b = np.asarray(b, dtype=np.float64)
+        one = b.ndim == 1
+        B = np.ascontiguousarray(b.reshape(self.n, -1).T).reshape(-1)          # column-major n x nrhs
+        nrhs = B.size // self.n
+        X = np.zeros_like(B)
+        self._check(self._L.calipso_hip_sparse_solve(self._h, nrhs, _pd(B), _pd(X)), "sparse_solve")
+        X = X.reshape(nrhs, self.n).T
+        return X[:, 0].copy() if one else X.copy()
+
+    def factor(self):
+        """(perm (1-based), L as a scipy.sparse CSC unit-lower matrix, D)"""
+        import scipy.sparse as sp
+        nl = self.info["nnzL"]
+        perm, Lp, Li = np.zeros(self.n, dtype=np.int64), np.zeros(self.n + 1, dtype=np.int64), np.zeros(max(nl, 1), dtype=np.int64)
+        Lx, D = np.zeros(max(nl, 1)), np.zeros(self.n)
+        self._check(self._L.calipso_hip_sparse_get_factor(self._h, _pi(perm), _pi(Lp), _pi(Li), _pd(Lx), _pd(D)), "sparse_get_factor")
+        Lm = sp.csc_matrix((Lx[:nl], Li[:nl] - 1, Lp - 1), shape=(self.n, self.n)) + sp.identity(self.n, format="csc")
+        return perm, Lm, D
+
+    def timing(self):
+        """(device milliseconds of the last factorisation, of the last solve)"""
+        ms = np.zeros(2)
+        self._check(self._L.calipso_hip_sparse_timing(self._h, _pd(ms)), "sparse_timing")
+        return float(ms[0]), float(ms[1])
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.calipso_hip_sparse_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

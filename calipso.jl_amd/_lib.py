@@ -75,6 +75,14 @@ SYMBOLS = {
     "calipso_hip_symbolic": (_i64, [_i64, _pi64, _pi64, _pi64, _pi64, _pi64, _pi64, _pi64, _pi64, _pi64]),
     "calipso_hip_ldl_analyze_csc": (_i32, [_vp, _i64, _pi64, _pi64, _i32, _pi64, _pi64]),
     "calipso_hip_ldl_solve": (_i32, [_vp, _i64, _i64, _pd, _pd]),
+    "calipso_hip_sparse_create": (_i32, [_i64, _pi64, _pi64, _i32, _pi64, _i32, C.POINTER(_vp)]),
+    "calipso_hip_sparse_destroy": (_i32, [_vp]),
+    "calipso_hip_sparse_last_error": (C.c_char_p, [_vp]),
+    "calipso_hip_sparse_info": (_i32, [_vp, _pi64]),
+    "calipso_hip_sparse_factorize": (_i32, [_vp, _pd, _pi64]),
+    "calipso_hip_sparse_solve": (_i32, [_vp, _i64, _pd, _pd]),
+    "calipso_hip_sparse_get_factor": (_i32, [_vp, _pi64, _pi64, _pi64, _pd, _pd]),
+    "calipso_hip_sparse_timing": (_i32, [_vp, _pd]),
     "calipso_hip_small_create": (_i32, [_i64, _i64, _i64, _i32, C.POINTER(_vp)]),
     "calipso_hip_small_destroy": (_i32, [_vp]),
     "calipso_hip_small_last_error": (C.c_char_p, [_vp]),

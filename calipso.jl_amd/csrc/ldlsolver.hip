@@ -140,13 +140,13 @@ int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver* s, int64_t n, const in
 }
 
 // Choose the elimination order of the following factorisations (qdldl.jl:134-143: perm = amd(A), iperm = invperm(perm)).
-//   method 0 natural, 1 reverse Cuthill-McKee, 2 minimum degree (ordering.hip), 3 the caller's `perm` (1-based, perm[k] = vertex eliminated k-th).
+//   method 0 natural, 1 reverse Cuthill-McKee, 2 minimum degree, 4 nested dissection (ordering.hip), 3 the caller's `perm` (1-based, perm[k] = vertex eliminated k-th).
 // perm (may be NULL for methods 0-2) receives / supplies the order.  info (may be NULL): [0] half bandwidth of P A P', [1] 64-row blocks per
 // panel the device factorisation visits (0 = all: dense treatment), [2] nnz(L) of the sparse symbolic factor (-1: QDLDL_etree! failure),
 // [3] nnz(triu A).  When the permuted matrix is banded the blocked LDL^T and the triangular solves skip everything outside the band.
 int32_t calipso_hip_ldl_analyze_csc(calipso_hip_solver* s, int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, int64_t* perm,
                                     int64_t info[4]) {
-    if (!s || !colptr || (!rowval && colptr[n] > 1) || method < 0 || method > 3 || (method == 3 && !perm)) return CALIPSO_ERR_ARGUMENT;
+    if (!s || !colptr || (!rowval && colptr[n] > 1) || method < 0 || method > 4 || (method == 3 && !perm)) return CALIPSO_ERR_ARGUMENT;
     const Dims& d = s->d;
     if (n != d.nx || d.ne != 0 || d.nc != 0) { s->err = "calipso_hip_ldl_analyze_csc: the handle was not created by calipso_hip_ldl_create for this n"; return CALIPSO_ERR_ARGUMENT; }
     std::vector<int64_t> p((size_t)n);

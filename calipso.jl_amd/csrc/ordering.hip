@@ -130,6 +130,95 @@ std::vector<i64> minimum_degree(const std::vector<std::vector<int>>& adj0) {
     return perm;
 }
 
+// nested dissection: the graph is cut by a vertex separator taken from the breadth-first level structure of a pseudo-peripheral vertex (the
+// level that halves the vertex count, thinned to the vertices that really touch the far side), the two halves are ordered recursively and the
+// separator is eliminated LAST.  The two halves are then independent sub-trees of the elimination tree — for the stage-chained KKT systems of
+// trajectory problems (trajectory_optimization/sparsity.jl:28-129) the tree height drops from O(T) stages to O(log T), which is what the
+// level-scheduled device factorisation of sparse.hip turns into parallelism (stage-parallel elimination).  Leaves (<= 48
+// vertices, or pieces the level structure cannot split) are ordered by minimum degree.
+void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& verts, std::vector<int>& local, std::vector<int>& level, std::vector<i64>& out) {
+    const int m = (int)verts.size();
+    auto leaf = [&]() {
+        // minimum degree on the induced subgraph
+        for (int a = 0; a < m; ++a) local[verts[a]] = a;
+        std::vector<std::vector<int>> sub((size_t)m);
+        for (int a = 0; a < m; ++a) for (int u : adj[verts[a]]) if (local[u] >= 0) sub[(size_t)a].push_back(local[u]);
+        for (int a = 0; a < m; ++a) local[verts[a]] = -1;
+        for (i64 k : minimum_degree(sub)) out.push_back(verts[(size_t)k - 1] + 1);
+    };
+    if (m <= 48) { leaf(); return; }
+    for (int a = 0; a < m; ++a) local[verts[a]] = a;          // membership of the current piece
+    // connected components of the piece: independent, no separator needed
+    {
+        std::vector<int> comp_of((size_t)m, -1); int ncomp = 0;
+        std::vector<int> stack;
+        for (int a = 0; a < m; ++a) {
+            if (comp_of[(size_t)a] >= 0) continue;
+            comp_of[(size_t)a] = ncomp; stack.push_back(a);
+            while (!stack.empty()) { const int v = stack.back(); stack.pop_back(); for (int u : adj[verts[v]]) { const int lu = local[u]; if (lu >= 0 && comp_of[(size_t)lu] < 0) { comp_of[(size_t)lu] = ncomp; stack.push_back(lu); } } }
+            ++ncomp;
+        }
+        if (ncomp > 1) {
+            std::vector<std::vector<int>> parts((size_t)ncomp);
+            for (int a = 0; a < m; ++a) parts[(size_t)comp_of[(size_t)a]].push_back(verts[a]);
+            for (int a = 0; a < m; ++a) local[verts[a]] = -1;
+            for (auto& part : parts) nd_recurse(adj, part, local, level, out);
+            return;
+        }
+    }
+    auto bfs = [&](int root, std::vector<int>& order) {       // level structure of the (connected) piece from root; returns the depth
+        for (int v : verts) level[v] = -1;
+        order.clear(); order.push_back(root); level[root] = 0;
+        for (size_t h = 0; h < order.size(); ++h) { const int v = order[h]; for (int u : adj[v]) if (local[u] >= 0 && level[u] < 0) { level[u] = level[v] + 1; order.push_back(u); } }
+        return level[order.back()];
+    };
+    std::vector<int> order, tmp;
+    int root = verts[0], depth = bfs(root, order);
+    for (int iter = 0; iter < 6; ++iter) {                    // pseudo-peripheral root: the deepest level structure found
+        int best = order.back();
+        for (int v : order) if (level[v] == depth && adj[v].size() < adj[best].size()) best = v;
+        const int d2 = bfs(best, tmp);
+        if (d2 <= depth) { bfs(root, order); break; }
+        root = best; depth = d2; order.swap(tmp);
+    }
+    if (depth < 2) { for (int a = 0; a < m; ++a) local[verts[a]] = -1; leaf(); return; }
+    // the level at which half of the vertices have been passed (never the first or the last level)
+    std::vector<int> count((size_t)depth + 1, 0);
+    for (int v : order) count[(size_t)level[v]] += 1;
+    int cut = 1, acc = count[0];
+    while (cut < depth - 1 && acc + count[(size_t)cut] < m / 2) { acc += count[(size_t)cut]; ++cut; }
+    std::vector<int> A, B, Sep;
+    for (int v : order) {
+        if (level[v] < cut) A.push_back(v);
+        else if (level[v] > cut) B.push_back(v);
+        else {
+            bool far = false;
+            for (int u : adj[v]) if (local[u] >= 0 && level[u] == cut + 1) { far = true; break; }
+            (far ? Sep : A).push_back(v);                     // a cut-level vertex without a neighbour beyond the cut belongs to the near half
+        }
+    }
+    for (int a = 0; a < m; ++a) local[verts[a]] = -1;
+    if (A.empty() || B.empty()) { leaf(); return; }
+    nd_recurse(adj, A, local, level, out);
+    nd_recurse(adj, B, local, level, out);
+    if (!Sep.empty()) {                                       // the separator's own order: minimum degree of its induced subgraph
+        const int ms = (int)Sep.size();
+        for (int a = 0; a < ms; ++a) local[Sep[a]] = a;
+        std::vector<std::vector<int>> sub((size_t)ms);
+        for (int a = 0; a < ms; ++a) for (int u : adj[Sep[a]]) if (local[u] >= 0) sub[(size_t)a].push_back(local[u]);
+        for (int a = 0; a < ms; ++a) local[Sep[a]] = -1;
+        for (i64 k : minimum_degree(sub)) out.push_back(Sep[(size_t)k - 1] + 1);
+    }
+}
+std::vector<i64> nested_dissection(const std::vector<std::vector<int>>& adj) {
+    const int n = (int)adj.size();
+    std::vector<int> verts((size_t)n), local((size_t)n, -1), level((size_t)n, -1);
+    std::iota(verts.begin(), verts.end(), 0);
+    std::vector<i64> out; out.reserve((size_t)n);
+    nd_recurse(adj, verts, local, level, out);
+    return out;
+}
+
 // permuted upper triangle in the reference's placement order (qdldl.jl:675-737): entries are taken column by column of A and appended to the
 // column max(P row, P col) of the result, which leaves the rows inside a column unsorted — the factorisation's operation order follows it
 void permute_upper(i64 n, const i64* Ap, const i64* Ai, const i64* iperm, std::vector<i64>& Pp, std::vector<i64>& Pi, std::vector<i64>& map) {
@@ -195,12 +284,12 @@ bool is_permutation(i64 n, const i64* perm) {
 
 extern "C" {
 
-// method 0: natural (1..n), 1: reverse Cuthill-McKee, 2: minimum degree.  Pattern: CSC, 1-based, any triangle(s).  perm[k] = the vertex eliminated k-th.
+// method 0: natural (1..n), 1: reverse Cuthill-McKee, 2: minimum degree, 4: nested dissection (3 is "the caller's order" in the analyse calls).  Pattern: CSC, 1-based, any triangle(s).  perm[k] = the vertex eliminated k-th.
 int32_t calipso_hip_ordering(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, int64_t* perm) {
-    if (n < 0 || !colptr || !perm || (!rowval && colptr[n] > 1) || method < 0 || method > 2) return CALIPSO_ERR_ARGUMENT;
+    if (n < 0 || !colptr || !perm || (!rowval && colptr[n] > 1) || method < 0 || method > 4 || method == 3) return CALIPSO_ERR_ARGUMENT;
     if (method == 0) { for (i64 k = 0; k < n; ++k) perm[k] = k + 1; return CALIPSO_OK; }
     const auto adj = adjacency(n, colptr, rowval);
-    const std::vector<i64> p = method == 1 ? rcm(adj) : minimum_degree(adj);
+    const std::vector<i64> p = method == 1 ? rcm(adj) : method == 2 ? minimum_degree(adj) : nested_dissection(adj);
     std::copy(p.begin(), p.end(), perm);
     return CALIPSO_OK;
 }

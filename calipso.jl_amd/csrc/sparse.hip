@@ -1,0 +1,460 @@
+// sparse.hip — sparse LDL^T on the device for the LinearSolver seam: what the reference does with its vendored QDLDL
+// (src/solver/qdldl.jl:134-188 analyse, :400-589 factor, :330-351,592-640 solve) for a sparse symmetric quasi-definite matrix, WITHOUT the dense
+// n x n storage of ldlsolver.hip: memory is O(nnz(L)).
+//
+//   analyse (host, once per pattern)   order (ordering.hip: natural / RCM / minimum degree / nested dissection / the caller's), P A P' as a
+//                                      LOWER CSC with a gather map from the caller's nzval, elimination tree, the row-sorted pattern of L, its
+//                                      row view (which columns k < j update column j), and the LEVELS of the tree: level(j) = 1 + max level of
+//                                      j's children.  Every column that updates column j lies in j's subtree, hence on a lower level.
+//   factor  (device)                   left-looking by levels: one launch per level, one workgroup per column.  Column j is gathered into a
+//                                      dense accumulator in LDS (n <= 20 000; global scratch beyond), the updates  w -= L(:,k) D_k L(j,k)  are
+//                                      applied in ascending k (a fixed order: no atomics, bit-reproducible), then D_j = w_j, L(:,j) = w / D_j.
+//                                      Runs of levels that hold a single column (the separators of a nested dissection, a dense tail) are
+//                                      merged into ONE single-workgroup launch that walks the chain.  No pivoting (quasi-definite: any symmetric
+//                                      order has an LDL^T, qdldl.jl:134-143); inertia from the signs of D, an exact zero pivot as qdldl.jl:456,579.
+//   solve   (device)                   L y = b by levels (one wavefront per row, pull form over the row view), x = L^-T (y ./ D) by levels in
+//                                      reverse (one wavefront per column); all right-hand sides of a call in the same launches.
+// QDLDL is up-looking (row by row); the factor is unique, the summation order differs, so L and D agree with the oracle's restatement to
+// rounding (tests/test_gpu_sparse.py: 1e-11 relative), not bit for bit.
+#include <algorithm>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+#include "device_utils.hpp"
+
+using calipso::i64;
+
+namespace {
+
+constexpr int SP_THREADS = 256;
+constexpr int SP_REC = 256;                // update records staged in LDS at a time
+constexpr int SP_LDS_MAX_N = 19400;        // 155 200 B of the CU's 160 KiB LDS for the accumulator (4 KiB of record stage beside it)
+
+struct SpDev {
+    int n;
+    const int* order;                      // columns sorted by (level, index)
+    const int *Alp, *Ali, *Asrc;           // P A P' lower CSC (diagonal included), Asrc = index into the caller's nzval
+    const double* Aval;                    // the caller's nzval on the device
+    const int *Lp, *Li;                    // strictly lower pattern of L, rows ascending
+    double *Lx, *D;
+    const int *Rp, *Rk, *Rpos, *Rend;      // row view: for row j the columns k < j with L(j,k) != 0 (ascending), the slot of L(j,k), the end of column k
+    double* work;                          // global accumulators (gridDim.x x n) when n > SP_LDS_MAX_N
+};
+
+// barrier that orders the accumulator only: LDS traffic when the accumulator is in LDS (outstanding global PREFETCHES must not be waited for),
+// everything otherwise
+template <bool LDSW>
+__device__ __forceinline__ void acc_barrier() {
+    if (LDSW) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); }   // lgkmcnt(0)
+    else __syncthreads();
+}
+
+template <bool LDSW>
+__global__ __launch_bounds__(SP_THREADS) void k_sp_factor(SpDev d, int first, int ncols) {
+    extern __shared__ __attribute__((aligned(16))) double wl[];
+    __shared__ int rpos[SP_REC], rend[SP_REC];
+    __shared__ double rf[SP_REC];
+    double* w = LDSW ? wl : d.work + (size_t)blockIdx.x * d.n;
+    const int tid = threadIdx.x;
+    for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
+        const int j = d.order[first + c];
+        const int l0 = d.Lp[j], l1 = d.Lp[j + 1];
+        for (int p = l0 + tid; p < l1; p += SP_THREADS) w[d.Li[p]] = 0.0;
+        if (tid == 0) w[j] = 0.0;
+        __syncthreads();
+        for (int p = d.Alp[j] + tid; p < d.Alp[j + 1]; p += SP_THREADS) w[d.Ali[p]] = d.Aval[d.Asrc[p]];
+        const int r0 = d.Rp[j], r1 = d.Rp[j + 1];
+        __syncthreads();
+        // The updates of column j are a dependent chain (they all touch w_j), one barrier each.  What must NOT be on that chain is global-memory
+        // latency: the records (column k, slot of L(j,k), end of column k) and the factors L(j,k) D_k of up to SP_REC updates are staged in LDS
+        // with one parallel load, and the first 256 (row, value) pairs of update q + 4 travel while update q is applied.
+        for (int qc = r0; qc < r1; qc += SP_REC) {
+            const int m = min(SP_REC, r1 - qc);
+            if (tid < m) {
+                const int k = d.Rk[qc + tid], pos = d.Rpos[qc + tid];
+                rpos[tid] = pos; rend[tid] = d.Rend[qc + tid];
+                rf[tid] = d.Lx[pos] * d.D[k];
+            }
+            __syncthreads();
+            int li[4]; double lx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                li[u] = 0; lx[u] = 0.0;
+                if (u < m) { const int p = rpos[u] + tid; if (p < rend[u]) { li[u] = d.Li[p]; lx[u] = d.Lx[p]; } }
+            }
+            for (int q = 0; q < m; q += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (q + u < m) {                                                        // (wave-uniform)
+                        const int pos = rpos[q + u], end = rend[q + u];
+                        const double f = rf[q + u];
+                        const int cli = li[u]; const double clx = lx[u];
+                        if (q + u + 4 < m) { const int p = rpos[q + u + 4] + tid; if (p < rend[q + u + 4]) { li[u] = d.Li[p]; lx[u] = d.Lx[p]; } }
+                        if (pos + tid < end) w[cli] -= clx * f;                             // rows >= j of column k (the slot of L(j,k) is the first of them)
+                        for (int p = pos + tid + SP_THREADS; p < end; p += SP_THREADS) w[d.Li[p]] -= d.Lx[p] * f;
+                        acc_barrier<LDSW>();
+                    }
+                }
+            }
+            __syncthreads();                                                                // the record stage is refilled
+        }
+        const double dj = w[j];
+        const double dinv = 1.0 / dj;                                               // L = y * Dinv as qdldl.jl:560-566
+        for (int p = l0 + tid; p < l1; p += SP_THREADS) d.Lx[p] = w[d.Li[p]] * dinv;
+        if (tid == 0) d.D[j] = dj;
+        __syncthreads();                                                            // a chain's next column reads what this one wrote
+    }
+}
+
+// forward substitution, rows of one level (or a chain, sequentially): x_j -= sum_k L(j,k) x_k.  One wavefront per row; blockIdx.y = right-hand side.
+__global__ __launch_bounds__(64) void k_sp_forward(SpDev d, int first, int ncols, double* __restrict__ X) {
+    double* x = X + (size_t)blockIdx.y * d.n;
+    const int lane = threadIdx.x;
+    for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
+        const int j = d.order[first + c];
+        double acc = 0.0;
+        for (int q = d.Rp[j] + lane; q < d.Rp[j + 1]; q += 64) acc += d.Lx[d.Rpos[q]] * x[d.Rk[q]];
+        acc = calipso::wave_sum(acc);
+        if (lane == 0) x[j] -= acc;
+        __syncthreads();
+    }
+}
+// backward substitution with the diagonal scaling folded in: x_j = y_j / D_j - sum_i L(i,j) x_i, levels (and chains) in reverse
+__global__ __launch_bounds__(64) void k_sp_backward(SpDev d, int first, int ncols, double* __restrict__ X) {
+    double* x = X + (size_t)blockIdx.y * d.n;
+    const int lane = threadIdx.x;
+    for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
+        const int j = d.order[first + ncols - 1 - c];
+        double acc = 0.0;
+        for (int p = d.Lp[j] + lane; p < d.Lp[j + 1]; p += 64) acc += d.Lx[p] * x[d.Li[p]];
+        acc = calipso::wave_sum(acc);
+        if (lane == 0) x[j] = x[j] / d.D[j] - acc;
+        __syncthreads();
+    }
+}
+__global__ void k_sp_permute_in(const double* __restrict__ b, const int* __restrict__ perm, int n, double* __restrict__ x) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[(size_t)blockIdx.y * n + i] = b[(size_t)blockIdx.y * n + perm[i]];          // permute!(x, perm)  qdldl.jl:333
+}
+__global__ void k_sp_permute_out(const double* __restrict__ x, const int* __restrict__ perm, int n, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[(size_t)blockIdx.y * n + perm[i]] = x[(size_t)blockIdx.y * n + i];        // ipermute!(x, perm) qdldl.jl:349
+}
+
+struct Segment { int first, count; bool chain; };
+
+}  // namespace
+
+struct calipso_hip_sparse {
+    int n = 0, device = 0;
+    i64 nnzA = 0, nnzU = 0, nnzL = 0, flops = 0;
+    int levels = 0, widest = 0;
+    bool lds_acc = true;
+    std::vector<i64> perm;                       // 1-based, perm[k] = vertex eliminated k-th
+    std::vector<int> hLp, hLi;                   // host copy of the pattern (get_factor)
+    std::vector<Segment> plan;
+    std::vector<void*> dev;                      // every device allocation
+    SpDev d{};
+    int* d_perm = nullptr;
+    double *d_Aval = nullptr, *d_rhs = nullptr, *d_x = nullptr;
+    size_t cap_rhs = 0;
+    int work_slots = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipGraphExec_t graph_factor = nullptr;
+    bool graph_tried = false, factored = false;
+    i64 inertia[3] = {0, 0, 0};
+    double ms_factor = 0.0, ms_solve = 0.0;
+    std::string err;
+};
+
+static thread_local std::string g_sparse_err;
+#define PK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (s ? s->err : g_sparse_err) = std::string(#call) + ": " + hipGetErrorString(e__); return CALIPSO_ERR_HIP; } } while (0)
+
+namespace {
+
+template <typename T>
+int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
+    T* p = nullptr;
+    PK(hipMalloc((void**)&p, sizeof(T) * std::max<size_t>(h.size(), 1)));
+    s->dev.push_back(p);
+    if (!h.empty()) PK(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    *out = p;
+    return CALIPSO_OK;
+}
+
+void enqueue_factor(calipso_hip_sparse* s) {
+    const size_t lds = s->lds_acc ? sizeof(double) * (size_t)s->n : 0;
+    for (const Segment& g : s->plan) {
+        const int grid = g.chain ? 1 : std::min(g.count, s->work_slots);
+        if (s->lds_acc) hipLaunchKernelGGL(k_sp_factor<true>, dim3(grid), dim3(SP_THREADS), lds, s->stream, s->d, g.first, g.count);
+        else hipLaunchKernelGGL(k_sp_factor<false>, dim3(grid), dim3(SP_THREADS), 0, s->stream, s->d, g.first, g.count);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* calipso_hip_sparse_last_error(calipso_hip_sparse* s) { return s ? s->err.c_str() : g_sparse_err.c_str(); }
+
+int32_t calipso_hip_sparse_destroy(calipso_hip_sparse* s) {
+    if (!s) return CALIPSO_OK;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->graph_factor) (void)hipGraphExecDestroy(s->graph_factor);
+    for (void* p : s->dev) if (p) (void)hipFree(p);
+    if (s->d_rhs) (void)hipFree(s->d_rhs);
+    if (s->d_x) (void)hipFree(s->d_x);
+    if (s->e0) (void)hipEventDestroy(s->e0);
+    if (s->e1) (void)hipEventDestroy(s->e1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return CALIPSO_OK;
+}
+
+// QDLDL(A; perm) analyse phase (qdldl.jl:134-188): order, P A P', etree, pattern of L — plus the level schedule of the device factorisation.
+// colptr / rowval: Julia SparseMatrixCSC pattern (1-based); only the upper triangle is read (triu!, linear_solver.jl:23).
+// method: 0 natural, 1 RCM, 2 minimum degree, 4 nested dissection, 3 = `perm` (1-based, perm[k] = vertex eliminated k-th).
+int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, const int64_t* perm, int32_t device,
+                                  calipso_hip_sparse** out) {
+    calipso_hip_sparse* s = nullptr;
+    if (!out) return CALIPSO_ERR_ARGUMENT;
+    *out = nullptr;
+    if (n < 1 || n > 0x3fffffff || !colptr || (!rowval && colptr[n] > 1) || method < 0 || method > 4 || (method == 3 && !perm)) {
+        g_sparse_err = "calipso_hip_sparse_create: bad arguments"; return CALIPSO_ERR_ARGUMENT;
+    }
+    if (colptr[0] != 1) { g_sparse_err = "colptr must be 1-based (Julia SparseMatrixCSC)"; return CALIPSO_ERR_ARGUMENT; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_sparse_err = "no HIP device available (libcalipso_hip has no CPU path)"; return CALIPSO_ERR_HIP; }
+    if (device < 0 || device >= ndev) { g_sparse_err = "device ordinal out of range"; return CALIPSO_ERR_ARGUMENT; }
+    // ---- order
+    std::vector<i64> p((size_t)n);
+    if (method == 3) {
+        std::vector<char> seen((size_t)n, 0);
+        for (i64 k = 0; k < n; ++k) { const i64 v = perm[k]; if (v < 1 || v > n || seen[(size_t)v - 1]) { g_sparse_err = "perm is not a permutation of 1:n"; return CALIPSO_ERR_ARGUMENT; } seen[(size_t)v - 1] = 1; p[(size_t)k] = v; }
+    } else {
+        const int rc = calipso_hip_ordering(n, colptr, rowval, method, p.data());
+        if (rc < 0) { g_sparse_err = "calipso_hip_ordering failed"; return rc; }
+    }
+    std::vector<int> ip((size_t)n);
+    for (i64 k = 0; k < n; ++k) ip[(size_t)p[(size_t)k] - 1] = (int)k;
+    // ---- P A P' as a lower CSC (rows ascending), with the gather map from the caller's nzval
+    const i64 nnzA = colptr[n] - 1;
+    std::vector<std::vector<std::pair<int, int>>> col((size_t)n);       // (row, source index)
+    i64 nnzU = 0;
+    for (i64 c = 0; c < n; ++c)
+        for (i64 q = colptr[c] - 1; q < colptr[c + 1] - 1; ++q) {
+            const i64 r = rowval[q] - 1;
+            if (r < 0 || r >= n) { g_sparse_err = "row index out of range"; return CALIPSO_ERR_ARGUMENT; }
+            if (r > c) continue;
+            const int pr = ip[(size_t)r], pc = ip[(size_t)c];
+            col[(size_t)std::min(pr, pc)].push_back({std::max(pr, pc), (int)q});
+            ++nnzU;
+        }
+    std::vector<int> Alp((size_t)n + 1, 0), Ali, Asrc;
+    Ali.reserve((size_t)nnzU); Asrc.reserve((size_t)nnzU);
+    std::vector<std::vector<int>> lowrow((size_t)n);                    // row view of the strictly lower part: columns i < j of row j
+    for (int j = 0; j < (int)n; ++j) {
+        auto& cj = col[(size_t)j];
+        std::sort(cj.begin(), cj.end());
+        for (size_t a = 1; a < cj.size(); ++a) if (cj[a].first == cj[a - 1].first) { g_sparse_err = "duplicate entry in the CSC pattern"; return CALIPSO_ERR_ARGUMENT; }
+        for (auto& e : cj) { Ali.push_back(e.first); Asrc.push_back(e.second); if (e.first > j) lowrow[(size_t)e.first].push_back(j); }
+        Alp[(size_t)j + 1] = (int)Ali.size();
+    }
+    // QDLDL_etree! refuses a matrix with an empty column of the upper triangle (qdldl.jl:366-371): column j of triu(P A P') = row j of the lower part + diagonal
+    for (int j = 0; j < (int)n; ++j) {
+        const bool diag = Alp[(size_t)j] < Alp[(size_t)j + 1] && Ali[(size_t)Alp[(size_t)j]] == j;
+        if (!diag && lowrow[(size_t)j].empty()) { g_sparse_err = "empty column in triu(A): QDLDL_etree! fails on this matrix (qdldl.jl:366-371)"; return CALIPSO_ERR_ARGUMENT; }
+    }
+    // ---- elimination tree (Liu, path compression)
+    std::vector<int> parent((size_t)n, -1), anc((size_t)n, -1);
+    for (int j = 0; j < (int)n; ++j)
+        for (int i0 : lowrow[(size_t)j]) {
+            int i = i0;
+            while (i != -1 && i < j) { const int nxt = anc[(size_t)i]; anc[(size_t)i] = j; if (nxt == -1) parent[(size_t)i] = j; i = nxt; }
+        }
+    // ---- pattern of L: struct(L_j) = struct(A_j below the diagonal) U (struct(L_c) \ {j}) over the children c of j
+    std::vector<std::vector<int>> children((size_t)n);
+    for (int j = 0; j < (int)n; ++j) if (parent[(size_t)j] >= 0) children[(size_t)parent[(size_t)j]].push_back(j);
+    std::vector<std::vector<int>> Lcol((size_t)n);
+    std::vector<int> mark((size_t)n, -1);
+    i64 nnzL = 0, flops = 0;
+    for (int j = 0; j < (int)n; ++j) {
+        std::vector<int>& lj = Lcol[(size_t)j];
+        mark[(size_t)j] = j;
+        for (int q = Alp[(size_t)j]; q < Alp[(size_t)j + 1]; ++q) { const int r = Ali[(size_t)q]; if (r > j && mark[(size_t)r] != j) { mark[(size_t)r] = j; lj.push_back(r); } }
+        for (int c : children[(size_t)j]) for (int r : Lcol[(size_t)c]) if (r != j && mark[(size_t)r] != j) { mark[(size_t)r] = j; lj.push_back(r); }
+        std::sort(lj.begin(), lj.end());
+        nnzL += (i64)lj.size();
+        if (nnzL > 0x7fffffff) { g_sparse_err = "nnz(L) exceeds 2^31 - 1"; return CALIPSO_ERR_ARGUMENT; }
+    }
+    std::vector<int> Lp((size_t)n + 1, 0), Li; Li.reserve((size_t)nnzL);
+    for (int j = 0; j < (int)n; ++j) { Li.insert(Li.end(), Lcol[(size_t)j].begin(), Lcol[(size_t)j].end()); Lp[(size_t)j + 1] = (int)Li.size(); }
+    // ---- row view
+    std::vector<int> Rp((size_t)n + 1, 0);
+    for (int v : Li) Rp[(size_t)v + 1] += 1;
+    for (int j = 0; j < (int)n; ++j) Rp[(size_t)j + 1] += Rp[(size_t)j];
+    std::vector<int> Rk((size_t)nnzL), Rpos((size_t)nnzL), Rend((size_t)nnzL), nextr(Rp.begin(), Rp.end() - 1);
+    for (int k = 0; k < (int)n; ++k)
+        for (int q = Lp[(size_t)k]; q < Lp[(size_t)k + 1]; ++q) {
+            const int at = nextr[(size_t)Li[(size_t)q]]++;
+            Rk[(size_t)at] = k; Rpos[(size_t)at] = q; Rend[(size_t)at] = Lp[(size_t)k + 1];
+            flops += (i64)(Lp[(size_t)k + 1] - q);
+        }
+    // ---- levels and the launch plan
+    std::vector<int> level((size_t)n, 0);
+    int height = 0;
+    for (int j = 0; j < (int)n; ++j) {          // children have smaller indices: one ascending pass
+        if (parent[(size_t)j] >= 0) level[(size_t)parent[(size_t)j]] = std::max(level[(size_t)parent[(size_t)j]], level[(size_t)j] + 1);
+        height = std::max(height, level[(size_t)j] + 1);
+    }
+    std::vector<int> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[(size_t)a] < level[(size_t)b]; });
+    std::vector<Segment> plan;
+    int widest = 0;
+    for (int a = 0; a < (int)n;) {
+        int b = a;
+        while (b < (int)n && level[(size_t)order[(size_t)b]] == level[(size_t)order[(size_t)a]]) ++b;
+        const int cnt = b - a;
+        widest = std::max(widest, cnt);
+        if (cnt == 1 && !plan.empty() && plan.back().chain) plan.back().count += 1;        // extend the chain of single-column levels
+        else plan.push_back({a, cnt, cnt == 1});
+        a = b;
+    }
+    // ---- the handle and its device side
+    s = new calipso_hip_sparse();
+    *out = s;
+    s->n = (int)n; s->device = device; s->nnzA = nnzA; s->nnzU = nnzU; s->nnzL = nnzL; s->flops = flops;
+    s->levels = height; s->widest = widest; s->perm = p; s->plan = plan; s->hLp = Lp; s->hLi = Li;
+    s->lds_acc = n <= SP_LDS_MAX_N;
+    PK(hipSetDevice(device));
+    PK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    PK(hipEventCreate(&s->e0)); PK(hipEventCreate(&s->e1));
+    s->d.n = (int)n;
+    int rc;
+    std::vector<int> hperm((size_t)n);
+    for (i64 k = 0; k < n; ++k) hperm[(size_t)k] = (int)(p[(size_t)k] - 1);
+    const int* cperm = nullptr;
+    if ((rc = upload(s, order, &s->d.order)) || (rc = upload(s, Alp, &s->d.Alp)) || (rc = upload(s, Ali, &s->d.Ali)) || (rc = upload(s, Asrc, &s->d.Asrc)) ||
+        (rc = upload(s, Lp, &s->d.Lp)) || (rc = upload(s, Li, &s->d.Li)) || (rc = upload(s, Rp, &s->d.Rp)) || (rc = upload(s, Rk, &s->d.Rk)) ||
+        (rc = upload(s, Rpos, &s->d.Rpos)) || (rc = upload(s, Rend, &s->d.Rend)) || (rc = upload(s, hperm, &cperm))) return rc;
+    s->d_perm = const_cast<int*>(cperm);
+    PK(hipMalloc((void**)&s->d.Lx, sizeof(double) * std::max<size_t>((size_t)nnzL, 1))); s->dev.push_back(s->d.Lx);
+    PK(hipMalloc((void**)&s->d.D, sizeof(double) * (size_t)n)); s->dev.push_back(s->d.D);
+    PK(hipMalloc((void**)&s->d_Aval, sizeof(double) * std::max<size_t>((size_t)nnzA, 1))); s->dev.push_back(s->d_Aval);
+    s->d.Aval = s->d_Aval;
+    s->work_slots = std::min(widest, 2048);
+    if (s->lds_acc) {
+        PK(hipFuncSetAttribute((const void*)k_sp_factor<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * SP_LDS_MAX_N)));
+    } else {
+        s->work_slots = std::min(s->work_slots, 512);
+        PK(hipMalloc((void**)&s->d.work, sizeof(double) * (size_t)s->work_slots * (size_t)n)); s->dev.push_back(s->d.work);
+    }
+    return CALIPSO_OK;
+}
+
+// info = [n, nnz(triu A), nnz(L), levels of the elimination tree, launches per factorisation, widest level, multiply-adds per factorisation,
+//         1 if the column accumulator lives in LDS]
+int32_t calipso_hip_sparse_info(calipso_hip_sparse* s, int64_t info[8]) {
+    if (!s || !info) return CALIPSO_ERR_ARGUMENT;
+    info[0] = s->n; info[1] = s->nnzU; info[2] = s->nnzL; info[3] = s->levels; info[4] = (i64)s->plan.size(); info[5] = s->widest; info[6] = s->flops; info[7] = s->lds_acc;
+    return CALIPSO_OK;
+}
+
+// QDLDL_factor! + compute_inertia! (qdldl.jl:400-589, linear_solver.jl:19-44) for new values on the analysed pattern.
+// nzval: the nnz(A) values in the caller's CSC order (host).  Returns CALIPSO_WARN_ZERO_PIVOT with inertia[0] = -1 on an exact zero pivot.
+int32_t calipso_hip_sparse_factorize(calipso_hip_sparse* s, const double* nzval, int64_t inertia[3]) {
+    if (!s || (!nzval && s->nnzA > 0)) return CALIPSO_ERR_ARGUMENT;
+    PK(hipSetDevice(s->device));
+    if (s->nnzA) PK(hipMemcpyAsync(s->d_Aval, nzval, sizeof(double) * (size_t)s->nnzA, hipMemcpyHostToDevice, s->stream));
+    PK(hipEventRecord(s->e0, s->stream));
+    if (!s->graph_tried) {          // the level schedule is a fixed launch sequence with fixed arguments: captured once, replayed afterwards
+        s->graph_tried = true;
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            enqueue_factor(s);
+            if (hipStreamEndCapture(s->stream, &g) == hipSuccess && g) {
+                if (hipGraphInstantiate(&s->graph_factor, g, nullptr, nullptr, 0) != hipSuccess) s->graph_factor = nullptr;
+                (void)hipGraphDestroy(g);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    if (s->graph_factor) PK(hipGraphLaunch(s->graph_factor, s->stream));
+    else enqueue_factor(s);
+    PK(hipEventRecord(s->e1, s->stream));
+    std::vector<double> D((size_t)s->n);
+    PK(hipMemcpyAsync(D.data(), s->d.D, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost, s->stream));
+    PK(hipStreamSynchronize(s->stream));
+    PK(hipGetLastError());
+    float ms = 0.f; PK(hipEventElapsedTime(&ms, s->e0, s->e1)); s->ms_factor = ms;
+    // compute_inertia! as the reference sees it: the up-looking factorisation stops at the first exact zero pivot in elimination order and the
+    // rest of D stays at the zeros it was reset to (qdldl.jl:444,456,579)
+    int rc = CALIPSO_OK;
+    i64 pos = 0, nonpos = 0, zero = 0; int k = 0;
+    for (; k < s->n; ++k) { const double dk = D[(size_t)k]; if (dk == 0.0) break; pos += dk > 0.0; nonpos += dk <= 0.0; }
+    if (k < s->n) { zero = s->n - k; nonpos += s->n - k; pos = -1; rc = CALIPSO_WARN_ZERO_PIVOT; }
+    s->inertia[0] = pos; s->inertia[1] = nonpos; s->inertia[2] = zero;
+    s->factored = true;
+    if (inertia) { inertia[0] = pos; inertia[1] = nonpos; inertia[2] = zero; }
+    return rc;
+}
+
+// solve!(F, b) (qdldl.jl:330-351) for nrhs right-hand sides: b, x column-major n x nrhs host arrays (may alias)
+int32_t calipso_hip_sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const double* b, double* x) {
+    if (!s || nrhs < 0 || (nrhs > 0 && (!b || !x)) || nrhs > 65535) return CALIPSO_ERR_ARGUMENT;
+    if (!s->factored) { s->err = "calipso_hip_sparse_solve: factorize first"; return CALIPSO_ERR_ARGUMENT; }
+    if (nrhs == 0) return CALIPSO_OK;
+    PK(hipSetDevice(s->device));
+    const size_t need = (size_t)s->n * (size_t)nrhs;
+    if (need > s->cap_rhs) {
+        if (s->d_rhs) (void)hipFree(s->d_rhs);
+        if (s->d_x) (void)hipFree(s->d_x);
+        s->d_rhs = s->d_x = nullptr; s->cap_rhs = 0;
+        PK(hipMalloc((void**)&s->d_rhs, sizeof(double) * need)); PK(hipMalloc((void**)&s->d_x, sizeof(double) * need));
+        s->cap_rhs = need;
+    }
+    PK(hipMemcpyAsync(s->d_rhs, b, sizeof(double) * need, hipMemcpyHostToDevice, s->stream));
+    PK(hipEventRecord(s->e0, s->stream));
+    const unsigned gx = (unsigned)((s->n + 255) / 256), ny = (unsigned)nrhs;
+    hipLaunchKernelGGL(k_sp_permute_in, dim3(gx, ny), dim3(256), 0, s->stream, s->d_rhs, s->d_perm, s->n, s->d_x);
+    for (const Segment& g : s->plan)
+        hipLaunchKernelGGL(k_sp_forward, dim3(g.chain ? 1 : (unsigned)std::min(g.count, 4096), ny), dim3(64), 0, s->stream, s->d, g.first, g.count, s->d_x);
+    for (auto g = s->plan.rbegin(); g != s->plan.rend(); ++g)
+        hipLaunchKernelGGL(k_sp_backward, dim3(g->chain ? 1 : (unsigned)std::min(g->count, 4096), ny), dim3(64), 0, s->stream, s->d, g->first, g->count, s->d_x);
+    hipLaunchKernelGGL(k_sp_permute_out, dim3(gx, ny), dim3(256), 0, s->stream, s->d_x, s->d_perm, s->n, s->d_rhs);
+    PK(hipEventRecord(s->e1, s->stream));
+    PK(hipMemcpyAsync(x, s->d_rhs, sizeof(double) * need, hipMemcpyDeviceToHost, s->stream));
+    PK(hipStreamSynchronize(s->stream));
+    PK(hipGetLastError());
+    float ms = 0.f; PK(hipEventElapsedTime(&ms, s->e0, s->e1)); s->ms_solve = ms;
+    return CALIPSO_OK;
+}
+
+// the factor for inspection: perm[n] (1-based), Lp[n+1], Li[nnz(L)] (1-based, strictly lower, rows ascending — F.L of qdldl.jl:160-166 without the
+// unit diagonal), Lx[nnz(L)], D[n]; any output may be NULL
+int32_t calipso_hip_sparse_get_factor(calipso_hip_sparse* s, int64_t* perm, int64_t* Lp, int64_t* Li, double* Lx, double* D) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    if ((Lx || D) && !s->factored) { s->err = "calipso_hip_sparse_get_factor: factorize first"; return CALIPSO_ERR_ARGUMENT; }
+    PK(hipSetDevice(s->device));
+    if (perm) std::copy(s->perm.begin(), s->perm.end(), perm);
+    if (Lp) for (size_t k = 0; k < s->hLp.size(); ++k) Lp[k] = (i64)s->hLp[k] + 1;
+    if (Li) for (size_t k = 0; k < s->hLi.size(); ++k) Li[k] = (i64)s->hLi[k] + 1;
+    if (Lx && s->nnzL) PK(hipMemcpyAsync(Lx, s->d.Lx, sizeof(double) * (size_t)s->nnzL, hipMemcpyDeviceToHost, s->stream));
+    if (D) PK(hipMemcpyAsync(D, s->d.D, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost, s->stream));
+    PK(hipStreamSynchronize(s->stream));
+    return CALIPSO_OK;
+}
+
+// ms[0] = device time of the last factorisation (all level launches), ms[1] = of the last solve call; HIP events on the handle's stream
+int32_t calipso_hip_sparse_timing(calipso_hip_sparse* s, double ms[2]) {
+    if (!s || !ms) return CALIPSO_ERR_ARGUMENT;
+    ms[0] = s->ms_factor; ms[1] = s->ms_solve;
+    return CALIPSO_OK;
+}
+
+}  // extern "C"

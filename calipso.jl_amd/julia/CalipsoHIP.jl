@@ -270,6 +270,60 @@ function CALIPSO.linear_solve!(s::HIPLDLSolver, x::Matrix{Float64}, A::SparseMat
     return
 end
 
+# ---- sparse variant: qdldl(A; perm) on the device without dense storage (csrc/sparse.hip) ---------------------------------------------------
+"""
+    HIPSparseLDLSolver(A::SparseMatrixCSC; method=:nested_dissection, perm=nothing) / hip_sparse_ldl_solver(A)
+
+`LDLSolver` (linear_solver.jl:1-60) with the analyse phase of `qdldl(A; perm)` (qdldl.jl:134-188) at construction and the numeric
+factorisation / triangular solves level-scheduled on the device; memory O(nnz(L)).  The pattern of `A` is fixed at construction
+(as `update=true` assumes in linear_solver.jl:24-27); `factorize!` sends only `A.nzval`.
+"""
+mutable struct HIPSparseLDLSolver <: CALIPSO.LinearSolver
+    handle::Ptr{Cvoid}
+    n::Int
+    nnz::Int
+    inertia::CALIPSO.Inertia
+end
+const SPARSE_METHODS = Dict(:natural => 0, :rcm => 1, :minimum_degree => 2, :nested_dissection => 4)
+sparse_last_error(h) = unsafe_string(ccall((:calipso_hip_sparse_last_error, lib), Cstring, (Ptr{Cvoid},), h))
+
+function HIPSparseLDLSolver(A::SparseMatrixCSC{Float64,Int}; method::Symbol=:nested_dissection, perm::Union{Nothing,Vector{Int}}=nothing, device::Integer=0)
+    href = Ref{Ptr{Cvoid}}(C_NULL)
+    m = perm === nothing ? SPARSE_METHODS[method] : 3
+    rc = ccall((:calipso_hip_sparse_create, lib), Int32, (Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ptr{Int64}, Int32, Ptr{Ptr{Cvoid}}),
+               size(A, 1), A.colptr, A.rowval, m, perm === nothing ? C_NULL : perm, device, href)
+    if rc != 0
+        msg = sparse_last_error(href[])
+        href[] != C_NULL && ccall((:calipso_hip_sparse_destroy, lib), Int32, (Ptr{Cvoid},), href[])
+        throw(HIPError(rc, "calipso_hip_sparse_create: $msg"))
+    end
+    s = HIPSparseLDLSolver(href[], size(A, 1), nnz(A), CALIPSO.Inertia(0, 0, 0))
+    finalizer(x -> ccall((:calipso_hip_sparse_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), s)
+    return s
+end
+function hip_sparse_ldl_solver(A::SparseMatrixCSC{Float64,Int}; kw...)
+    s = HIPSparseLDLSolver(A; kw...)
+    CALIPSO.factorize!(s, A)
+    return s
+end
+
+function CALIPSO.factorize!(s::HIPSparseLDLSolver, A::SparseMatrixCSC{Float64,Int}; update=false)
+    nnz(A) == s.nnz || throw(HIPError(-1, "factorize!: the pattern of A differs from the analysed one (build a new HIPSparseLDLSolver)"))
+    out = zeros(Int64, 3)
+    rc = ccall((:calipso_hip_sparse_factorize, lib), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}), s.handle, A.nzval, out)
+    rc < 0 && throw(HIPError(rc, "factorize!: $(sparse_last_error(s.handle))"))
+    rc == 1 && @warn "Zero entry in D (matrix is not quasidefinite)"     # qdldl.jl:309-311
+    s.inertia.positive, s.inertia.negative, s.inertia.zero = out
+    return nothing
+end
+CALIPSO.compute_inertia!(s::HIPSparseLDLSolver) = nothing      # (set by factorize!, as the values of linear_solver.jl:33-44 only change there)
+function CALIPSO.linear_solve!(s::HIPSparseLDLSolver, x::VecOrMat{Float64}, A::SparseMatrixCSC{Float64,Int}, b::VecOrMat{Float64}; fact=true, update=true)
+    fact && CALIPSO.factorize!(s, A; update=update)
+    rc = ccall((:calipso_hip_sparse_solve, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}), s.handle, size(b, 2), b, x)
+    rc < 0 && throw(HIPError(rc, "linear_solve!: $(sparse_last_error(s.handle))"))
+    return
+end
+
 # The handle-resident variant: the KKT blocks are already on the device (uploaded by the evaluation callback or by set_field!), the
 # condensed matrix is never formed on the host.  factorize! = calipso_hip_factorize on those blocks with the handle's kappa / rho /
 # regularisation scalars (which the caller syncs with sync_scalars!); `A` is accepted for signature parity only.
@@ -399,7 +453,7 @@ function allreduce_sum!(c::HIPComm, v::Vector{Float64})
     return v
 end
 
-export HIPSolver, HIPLDLSolver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPComm, comm_unique_id, gather_status, allreduce_sum!, newton_step!,
+export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPComm, comm_unique_id, gather_status, allreduce_sum!, newton_step!,
        search_direction_nonsymmetric!, analyze_structure!, clear_structure!, sync_scalars!, copy_back!
 
 end # module

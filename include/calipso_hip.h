@@ -288,7 +288,8 @@ int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver*, int64_t n, const int6
 int32_t calipso_hip_ldl_inertia(calipso_hip_solver*, int64_t inertia[3]);
 /* Ordering / symbolic service (qdldl.jl:134-188,358-395,642-742).  Host-side integer work, 1-based Int64 like the reference.
  *   calipso_hip_ordering: elimination order of a sparse symmetric pattern (CSC, any triangle(s)): method 0 natural, 1 reverse Cuthill-McKee
- *     (minimum bandwidth: what the device factorisation exploits), 2 minimum degree on the quotient graph (AMD's order class; AMD.jl's exact
+ *     (minimum bandwidth: what the dense device factorisation exploits), 4 nested dissection (level-structure separators: minimum tree height, what
+ *     the sparse device factorisation exploits), 2 minimum degree on the quotient graph (AMD's order class; AMD.jl's exact
  *     output, qdldl.jl:135, is third-party and unpinned).  perm[k] = vertex eliminated k-th.
  *   calipso_hip_symbolic: permute_symmetric + QDLDL_etree! for triu(A) under perm (NULL = natural): Pp[n+1], Pi[nnz triu], AtoPAPt[nnz A] (0 below
  *     the diagonal), etree[n] (-1 = root), Lnz[n]; returns nnz(L) (-1 in the reference's failure cases); info = [half bandwidth of PAP', nnz triu].
@@ -302,6 +303,30 @@ int64_t calipso_hip_symbolic(int64_t n, const int64_t* colptr, const int64_t* ro
 int32_t calipso_hip_ldl_analyze_csc(calipso_hip_solver*, int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, int64_t* perm,
                                     int64_t info[4]);
 int32_t calipso_hip_ldl_solve(calipso_hip_solver*, int64_t n, int64_t nrhs, const double* b, double* x);
+
+/* ---- sparse LDL^T on the device (src/solver/qdldl.jl:134-188 analyse, :400-589 factor, :330-351,592-640 solve) --------
+ * The LinearSolver seam WITHOUT dense n x n storage: memory O(nnz(L)).  The analyse phase (host) orders the matrix (method 0 natural, 1 RCM,
+ * 2 minimum degree, 4 nested dissection, 3 = the caller's 1-based `perm`), builds P A P', the elimination tree, the pattern of L and the LEVEL
+ * schedule; the numeric phase is a left-looking factorisation by tree levels (one launch per level, one workgroup per column, single-column levels
+ * merged into chains) and level-scheduled triangular solves.  With a nested-dissection order the stages of a trajectory problem
+ * (trajectory_optimization/sparsity.jl:28-129) are eliminated in parallel: the number of levels is the sequential depth.  No pivoting; inertia and
+ * zero-pivot behaviour as calipso_hip_ldl_factorize_csc.  L and D agree with QDLDL's to rounding (the summation order differs).
+ *   calipso_hip_sparse_create      = QDLDL analyse of qdldl(A; perm)          qdldl.jl:134-188, 358-395, 642-742  (pattern only: colptr, rowval 1-based)
+ *   calipso_hip_sparse_factorize   = QDLDL_factor! + compute_inertia!         qdldl.jl:400-589, linear_solver.jl:19-44  (nzval in the pattern's order, host)
+ *   calipso_hip_sparse_solve       = solve!(F, b) for nrhs columns            qdldl.jl:330-351
+ *   calipso_hip_sparse_get_factor  = F.perm, F.L (strictly lower, 1-based CSC), F.D   qdldl.jl:160-166
+ *   calipso_hip_sparse_info        info[8] = n, nnz(triu A), nnz(L), tree levels, launches per factorisation, widest level, multiply-adds, LDS accumulator?
+ *   calipso_hip_sparse_timing      ms[2] = device time of the last factorisation / solve (HIP events on the handle's stream) */
+typedef struct calipso_hip_sparse calipso_hip_sparse;
+int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, const int64_t* perm, int32_t device,
+                                  calipso_hip_sparse** out);
+int32_t calipso_hip_sparse_destroy(calipso_hip_sparse*);
+const char* calipso_hip_sparse_last_error(calipso_hip_sparse*);
+int32_t calipso_hip_sparse_info(calipso_hip_sparse*, int64_t info[8]);
+int32_t calipso_hip_sparse_factorize(calipso_hip_sparse*, const double* nzval, int64_t inertia[3]);
+int32_t calipso_hip_sparse_solve(calipso_hip_sparse*, int64_t nrhs, const double* b, double* x);
+int32_t calipso_hip_sparse_get_factor(calipso_hip_sparse*, int64_t* perm, int64_t* Lp, int64_t* Li, double* Lx, double* D);
+int32_t calipso_hip_sparse_timing(calipso_hip_sparse*, double ms[2]);
 
 /* ---- batched small systems (BASELINE config C5): LDS-resident LDL^T + multi-right-hand-side solve, one workgroup per
  * instance, one launch for the whole batch.  The sensitivity solves of the reference's MPC auto-tuning loop

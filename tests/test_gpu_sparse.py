@@ -1,0 +1,183 @@
+"""Sparse LDL^T on the device (csrc/sparse.hip; SURVEY.md 8(f4) sparse factorisation, 8(f1) stage-parallel elimination) against the oracle's
+restatement of the vendored QDLDL (oracle_qdldl_factor / _solve, src/solver/qdldl.jl:400-640) for the SAME permutation: the factor of a
+quasi-definite matrix is unique, so L and D must agree to rounding (the summation order differs: left-looking by levels vs up-looking)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import load_pkg
+from test_oracle_qdldl import quasidefinite
+from test_ordering_symbolic import csc1, kkt_matrices, staged_kkt, tree_height
+
+pytestmark = pytest.mark.gpu
+
+
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def oracle_factor(oracle_mod, K, perm):
+    """QDLDL of triu(K) under perm by the oracle: dense unit-lower L, D, and a solve closure"""
+    L = oracle_mod.lib()
+    n = K.shape[0]
+    Ap, Ai, Ax = csc1(sp.triu(sp.csc_matrix(K)))
+    nnz = len(Ai)
+    iperm = np.zeros(n, dtype=np.int64); iperm[perm - 1] = np.arange(1, n + 1)
+    Pp, Pi, Px, mp = np.zeros(n + 1, dtype=np.int64), np.zeros(nnz, dtype=np.int64), np.zeros(nnz), np.zeros(nnz, dtype=np.int64)
+    L.oracle_qdldl_permute_symmetric(n, _pi(Ap), _pi(Ai), _pd(Ax), _pi(iperm), _pi(Pp), _pi(Pi), _pd(Px), _pi(mp))
+    work, Lnz, et = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    tot = L.oracle_qdldl_etree(n, _pi(Pp), _pi(Pi), _pi(work), _pi(Lnz), _pi(et))
+    assert tot >= 0
+    Lp, Li, Lx = np.zeros(n + 1, dtype=np.int64), np.zeros(max(tot, 1), dtype=np.int64), np.zeros(max(tot, 1))
+    D, Dinv = np.zeros(n), np.zeros(n)
+    pos = L.oracle_qdldl_factor(n, _pi(Pp), _pi(Pi), _pd(Px), _pi(Lp), _pi(Li), _pd(Lx), _pd(D), _pd(Dinv), _pi(Lnz), _pi(et))
+    Lm = sp.csc_matrix((Lx[:tot], Li[:tot] - 1, Lp - 1), shape=(n, n)) + sp.identity(n, format="csc")
+
+    def solve(b):
+        tmp = b[perm - 1].copy()
+        L.oracle_qdldl_solve(n, _pi(Lp), _pi(Li), _pd(Lx), _pd(Dinv), _pd(tmp))
+        x = np.empty(n); x[perm - 1] = tmp
+        return x
+    return dict(L=Lm, D=D, positive=int(pos), nnzL=int(tot), solve=solve)
+
+
+def cases():
+    rng = np.random.default_rng(11)
+    out = dict(kkt_matrices())
+    out["quasidefinite_60"] = quasidefinite(40, 20, rng, density=0.15)
+    out["staged_12x(4+2)"] = staged_kkt(12, 4, 2, rng).toarray()
+    return out
+
+
+@pytest.mark.parametrize("name", ["quasidefinite_15", "pendulum", "conic_qp", "quasidefinite_60", "staged_12x(4+2)"])
+@pytest.mark.parametrize("method", ["natural", "rcm", "minimum_degree", "nested_dissection", "random"])
+def test_factor_and_solve_match_the_oracle(oracle_mod, name, method):
+    pkg = load_pkg()
+    K = cases()[name]
+    n = K.shape[0]
+    A = sp.csc_matrix(sp.triu(sp.csc_matrix(K)))
+    rng = np.random.default_rng(3)
+    if method == "random":
+        S = pkg.SparseLDL(A, perm=rng.permutation(n) + 1)
+    else:
+        S = pkg.SparseLDL(A, method=method)
+    rc = S.factorize(A)
+    perm, Lm, D = S.factor()
+    assert sorted(perm.tolist()) == list(range(1, n + 1))
+    ref = oracle_factor(oracle_mod, K, perm)
+    assert rc == 0 and S.info["nnzL"] == ref["nnzL"]
+    assert S.inertia == (ref["positive"], int((ref["D"] <= 0).sum()), 0)
+    scale = max(1.0, np.abs(ref["L"].toarray()).max())
+    assert np.array_equal((Lm != 0).toarray() | (ref["L"].toarray() != 0), (ref["L"] != 0).toarray() | (Lm.toarray() != 0))
+    assert np.abs(Lm.toarray() - ref["L"].toarray()).max() <= 1e-11 * scale
+    assert np.abs(D - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
+    PK = K[np.ix_(perm - 1, perm - 1)]
+    assert np.allclose(Lm.toarray() @ np.diag(D) @ Lm.toarray().T, PK, atol=1e-10 * np.abs(K).max())
+    B = rng.standard_normal((n, 3))
+    X = S.solve(B)
+    for c in range(3):
+        xo = ref["solve"](B[:, c].copy())
+        assert np.abs(X[:, c] - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
+    assert np.abs(S.solve(B[:, 0]) - X[:, 0]).max() == 0.0           # same launches, same order: bit-reproducible
+    S.close()
+
+
+def test_refactorisation_with_new_values_and_reproducibility(oracle_mod):
+    pkg = load_pkg()
+    rng = np.random.default_rng(5)
+    K0 = staged_kkt(10, 3, 2, rng)
+    S = pkg.SparseLDL(sp.triu(K0).tocsc(), method="nested_dissection")
+    for trial in range(3):
+        K = K0.copy()
+        K.data = K.data * (1.0 + 0.1 * rng.random(K.data.size))
+        K = ((K + K.T) * 0.5).tocsc()
+        A = sp.triu(K).tocsc()
+        assert S.factorize(A) == 0
+        perm, Lm, D = S.factor()
+        ref = oracle_factor(oracle_mod, K.toarray(), perm)
+        assert np.abs(D - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
+        S.factorize(A)
+        _, Lm2, D2 = S.factor()
+        assert np.array_equal(D, D2) and np.array_equal(Lm.toarray(), Lm2.toarray())      # no atomics, fixed summation order
+    S.close()
+
+
+def test_zero_pivot_is_reported_like_qdldl(oracle_mod):
+    pkg = load_pkg()
+    K = np.array([[1.0, 1.0, 0.0], [1.0, 1.0, 0.0], [0.0, 0.0, 2.0]])      # second pivot exactly zero (qdldl.jl:456,579)
+    S = pkg.SparseLDL(sp.triu(sp.csc_matrix(K)).tocsc(), method="natural")
+    assert S.factorize(sp.triu(sp.csc_matrix(K)).tocsc()) == 1
+    assert S.inertia == (-1, 2, 2)
+    S.close()
+    with pytest.raises(pkg.CalipsoHipError):
+        pkg.SparseLDL(sp.csc_matrix(np.array([[0.0, 0.0], [0.0, 1.0]])), method="natural")   # empty column: QDLDL_etree! fails (qdldl.jl:366-371)
+
+
+def test_nested_dissection_eliminates_the_stages_in_parallel(oracle_mod):
+    """a T-stage trajectory KKT system.  In the natural (stage-by-stage) order the elimination tree is a chain through all the
+    stages; under nested dissection the two halves of the horizon are independent sub-trees, recursively: the sequential depth (levels) grows
+    like log T, and the factorisation / solves still match the oracle and a dense solve."""
+    pkg = load_pkg()
+    rng = np.random.default_rng(9)
+    T, ns, nu = 64, 6, 2
+    K = staged_kkt(T, ns, nu, rng)
+    n = K.shape[0]
+    A = sp.triu(K).tocsc()
+    nat = pkg.SparseLDL(A, method="natural")
+    nd = pkg.SparseLDL(A, method="nested_dissection")
+    assert nat.info["levels"] > 0.3 * n                       # a chain through the horizon
+    assert nd.info["levels"] < 0.2 * nat.info["levels"]       # parallel sub-trees
+    assert nd.info["widest_level"] >= T // 2
+    assert nd.factorize(A) == 0 and nat.factorize(A) == 0
+    assert nd.inertia == nat.inertia == (T * (ns + nu) + ns, T * ns, 0)
+    b = rng.standard_normal(n)
+    x_nd, x_nat = nd.solve(b), nat.solve(b)
+    xd = np.linalg.solve(K.toarray(), b)
+    assert np.abs(x_nd - xd).max() <= 1e-9 * np.abs(xd).max() and np.abs(x_nat - xd).max() <= 1e-9 * np.abs(xd).max()
+    perm, Lm, D = nd.factor()
+    ref = oracle_factor(oracle_mod, K.toarray(), perm)
+    assert np.abs(D - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
+    assert tree_height(pkg.symbolic(A, perm)["etree"]) == nd.info["levels"]
+    nat.close(); nd.close()
+
+
+def test_rate_report_on_trajectory_kkt_systems(oracle_mod):
+    """Timings (device events) of the level-scheduled factorisation / solve on stage-structured KKT systems, natural order vs nested dissection,
+    next to the oracle's QDLDL on one host core for the same permutation; written to gpurun_out/sparse_ldl_rate.json (copied to profiles/).
+    Asserts only correctness and that nested dissection shortens the device factorisation."""
+    import json, os, time
+    pkg = load_pkg()
+    rng = np.random.default_rng(2)
+    rows = []
+    for T, ns, nu in ((256, 6, 2), (512, 12, 4)):
+        K = staged_kkt(T, ns, nu, rng)
+        n = K.shape[0]
+        A = sp.triu(K).tocsc()
+        b = rng.standard_normal(n)
+        row = dict(T=T, state=ns, control=nu, n=n, nnz_upper=int(A.nnz))
+        for method in ("natural", "nested_dissection"):
+            S = pkg.SparseLDL(A, method=method)
+            S.factorize(A); S.solve(b)                       # warm-up (graph capture, allocations)
+            f, s = [], []
+            for _ in range(5):
+                assert S.factorize(A) == 0
+                x = S.solve(b)
+                tf, ts = S.timing(); f.append(tf); s.append(ts)
+            assert np.abs(K @ x - b).max() <= 1e-8 * max(1.0, np.abs(b).max()) * max(1.0, np.abs(x).max())
+            perm, _, D = S.factor()
+            t0 = time.perf_counter(); ref = oracle_factor(oracle_mod, K, perm); t_cpu = time.perf_counter() - t0
+            assert np.abs(D - ref["D"]).max() <= 1e-10 * np.abs(ref["D"]).max()
+            row[method] = dict(S.info, factor_ms=min(f), solve_ms=min(s), oracle_qdldl_analyse_plus_factor_ms_1core=1e3 * t_cpu)
+            S.close()
+        assert row["nested_dissection"]["factor_ms"] < row["natural"]["factor_ms"]
+        rows.append(row)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/sparse_ldl_rate.json", "w") as fh:
+        json.dump(rows, fh, indent=1)
+    print(json.dumps(rows))

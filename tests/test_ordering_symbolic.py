@@ -117,3 +117,52 @@ def test_orderings_are_permutations_and_do_their_job():
     # the trajectory-structured K of the pendulum: natural order [x | y] couples the first and last block, RCM interleaves them into a band
     K = kkt_matrices()["pendulum"]
     assert pkg.symbolic(K, pkg.ordering(K, "rcm"))["half_bandwidth"] < 0.5 * pkg.symbolic(K)["half_bandwidth"]
+
+
+def staged_kkt(T, ns, nu, rng, delta=1e-2):
+    """KKT matrix [H G'; G -delta I] of a T-stage trajectory problem in the reference's variable order (trajectory_optimization/indices.jl:41-180):
+    variables (x_1,u_1,...,x_T,u_T,x_{T+1}), H block-diagonal per stage, dynamics rows x_{t+1} = A_t x_t + B_t u_t coupling neighbouring stages"""
+    nv = T * (ns + nu) + ns
+    H = sp.lil_matrix((nv, nv))
+    for t in range(T + 1):
+        w = ns + nu if t < T else ns
+        M = rng.standard_normal((w, w))
+        o = t * (ns + nu)
+        H[o:o + w, o:o + w] = M @ M.T + w * np.eye(w)
+    G = sp.lil_matrix((T * ns, nv))
+    for t in range(T):
+        o = t * (ns + nu)
+        G[t * ns:(t + 1) * ns, o:o + ns + nu] = rng.standard_normal((ns, ns + nu))
+        G[t * ns:(t + 1) * ns, o + ns + nu:o + ns + nu + ns] = -np.eye(ns)
+    K = sp.bmat([[H, G.T], [G, -delta * sp.identity(T * ns)]], format="csc")
+    K.sort_indices()
+    return K
+
+
+def tree_height(etree):
+    """levels of the elimination tree (1-based parents, -1 = root)"""
+    n = len(etree)
+    lev = np.zeros(n, dtype=np.int64)
+    for j in range(n):
+        p = int(etree[j])
+        if p > 0:
+            lev[p - 1] = max(lev[p - 1], lev[j] + 1)
+    return int(lev.max()) + 1
+
+
+def test_nested_dissection_is_a_permutation_and_flattens_the_tree():
+    pkg = load_pkg()
+    rng = np.random.default_rng(4)
+    for T, ns, nu, ratio in ((16, 3, 1, 0.5), (64, 6, 2, 0.15), (256, 6, 2, 0.05)):
+        K = staged_kkt(T, ns, nu, rng)
+        n = K.shape[0]
+        perm = pkg.ordering(K, "nested_dissection")
+        assert sorted(perm.tolist()) == list(range(1, n + 1))
+        h_nd = tree_height(pkg.symbolic(sp.triu(K).tocsc(), perm)["etree"])
+        h_nat = tree_height(pkg.symbolic(sp.triu(K).tocsc(), None)["etree"])
+        h_md = tree_height(pkg.symbolic(sp.triu(K).tocsc(), pkg.ordering(K, "minimum_degree"))["etree"])
+        assert h_nd < ratio * h_nat and h_nd < ratio * h_md, (h_nd, h_nat, h_md)       # O(log T) separators instead of a chain through the horizon
+    # pieces the level structure cannot split (a clique, disconnected vertices) still give a valid order
+    for M in (np.ones((70, 70)), np.eye(100), sp.block_diag([np.ones((60, 60)), np.eye(30)]).toarray()):
+        perm = pkg.ordering(sp.csc_matrix(M), "nested_dissection")
+        assert sorted(perm.tolist()) == list(range(1, M.shape[0] + 1))
