@@ -124,7 +124,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->residual, N); SL(&s->residual_error, N); SL(&s->step, N); SL(&s->step_correction, N);
     SL(&s->saved_point, N); SL(&s->saved_g, NE); SL(&s->saved_h, NC);
     SL(&s->residual_symmetric, n); SL(&s->step_symmetric, n); SL(&s->merit_gradient, n);
-    SL(&s->S, NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, NPd * NB);
+    SL(&s->S, NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, 2 * NPd * NB);
     SL(&s->Tinv, NPd < 512 ? NPd * NPd : (NPd / 512) * 512 * 512); SL(&s->Ttmp, NPd * 128); SL(&s->zf2, NPd); SL(&s->WH, NC * NX);
     SL(&s->wz, NC); SL(&s->kzz, NC);
     SL(&s->Wsoc, (size_t)woff); SL(&s->Bsoc, (size_t)woff); SL(&s->socwork, (size_t)2 * woff);

@@ -150,7 +150,7 @@ struct calipso_hip_solver {
     // factorisation
     double* S = nullptr;        // NP*NP: Schur complement onto x, then L (unit lower) in place
     double* Dx = nullptr;       // NP: pivots of S
-    double* Ypanel = nullptr;   // NP*NB: L21*D of the current panel
+    double* Ypanel = nullptr;   // 2 x NP*NB: L21*D of the current panel (and of the next one in the pair schedule of ldl.hip)
     double* Tinv = nullptr;     // (NP/512) * 512*512: inverses of the unit-lower 512 x 512 diagonal blocks of L
     double* Ttmp = nullptr;     // NP*128 scratch of the inverse assembly
     double* zf2 = nullptr;      // NP

@@ -261,14 +261,22 @@ __device__ __forceinline__ void trailing_tile_index(int t, int& ti, int& tj) {
     while (ti * (ti + 1) / 2 > t) --ti;
     tj = t - ti * (ti + 1) / 2;
 }
+// MODE 0: one panel (columns k0 .. k0 + 63), every tile of the trailing matrix.
+// MODE 1: one panel, only the FIRST tile column (tiles (i, 0)): what the next panel needs.
+// MODE 2: the two panels k0 and k0 + 64 (second one in the second half of Y) applied in ONE pass over the tiles from block k0 + 128 on: every
+//         entry of the trailing matrix is read and written once per 128 pivots instead of once per 64 — the early, HBM-bound updates of a
+//         group move half the bytes.  The arithmetic is that of two MODE 0 passes, operation for operation (a separate accumulator per
+//         panel, subtracted in panel order), so the pair schedule (MODE 1 + MODE 2) and the plain one (MODE 0 twice) give the same bits.
+template <int MODE>
 __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, int nx, int k0, int ntiles, int tb, double* __restrict__ S, const double* __restrict__ Y,
                                                              double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount) {
     __shared__ double smem[FUSED_LDS_DOUBLES];
     inst_shift(bt, S, Y, Dx, Tinv);
     inst_shift_i(bt, icount);
+    constexpr int NH = MODE == 2 ? 2 : 1;   // panels per pass
     double* Ls = smem;                    // Ls[i][k]: rows of the i block of L21
     double* Ys = smem + TT * LDT;         // Ys[j][k]: rows of the j block of Y21
-    const int r0 = k0 + NB;
+    const int r0 = k0 + NB * NH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fk = lane >> 4;
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
     const int stride = (int)gridDim.x - 1;
     int t = blockIdx.x;
     int ti, tj;
-    trailing_tile_index(t, ti, tj);
+    if (MODE == 1) { ti = t; tj = 0; } else trailing_tile_index(t, ti, tj);
     int i0 = r0 + ti * TT, j0 = r0 + tj * TT;
     double cS[4], lv[4], yv[4];           // operands of the current tile: the entries of S this lane updates, its share of the panels
 #pragma unroll
@@ -294,61 +302,75 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
         yv[it] = Y[(j0 + row) + (size_t)c * NP];
     }
     for (;;) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = cb + it * 16;                      // panel column k, natural order
-            Ls[row * LDT + c] = lv[it];
-            Ys[row * LDT + c] = yv[it];
-        }
-        __syncthreads();
         // next tile of this workgroup: its operands travel while the matrix cores work
         const int tn = (t == 0 || stride <= 0) ? ntiles : t + stride;
         int in0 = 0, jn0 = 0;
         double cN[4];
-        if (tn < ntiles) {
-            int a, b;
-            trailing_tile_index(tn, a, b);
-            in0 = r0 + a * TT; jn0 = r0 + b * TT;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cN[r] = S[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
+        for (int h = 0; h < NH; ++h) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int c = cb + it * 16;
-                lv[it] = Lp[(in0 + row) + (size_t)c * NP];
-                yv[it] = Y[(jn0 + row) + (size_t)c * NP];
+                const int c = cb + it * 16;                      // panel column k, natural order
+                Ls[row * LDT + c] = lv[it];
+                Ys[row * LDT + c] = yv[it];
             }
-        }
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-        // MFMA fragments by explicit ds_read_b64 (lane (fr, fk) reads row fr, k = 4 kk + fk: dword address 132 fr + 2 fk + 8 kk — the 32
-        // lanes of a half-wave hit 32 distinct bank pairs modulo 64).  Plain loads would be paired by the compiler into ds_read2_b64 /
-        // ds_read_b128, whose lane groups conflict 2-way on this layout (round 1: 48 % of the LDS cycles were conflict replays).  All 32
-        // loads of a tile are issued up front; the waits release them to the matrix cores in order (LDS returns in order).
-        {
-            const unsigned lb = (unsigned)(uintptr_t)(Ls + (wr * 16 + fr) * LDT + fk);
-            const unsigned yb = (unsigned)(uintptr_t)(Ys + (wc * 16 + fr) * LDT + fk);
-            double fl[NB / 4], fy[NB / 4];
+            __syncthreads();
+            if (h + 1 < NH) {
+                // the second panel of the same tile
 #pragma unroll
-            for (int kk = 0; kk < NB / 4; ++kk) {
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fl[kk]) : "v"(lb), "n"(kk * 32) : "memory");
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fy[kk]) : "v"(yb), "n"(kk * 32) : "memory");
+                for (int it = 0; it < 4; ++it) {
+                    const int c = NB + cb + it * 16;
+                    lv[it] = Lp[(i0 + row) + (size_t)c * NP];
+                    yv[it] = Y[(j0 + row) + (size_t)c * NP];
+                }
+            } else if (tn < ntiles) {
+                int a, b;
+                if (MODE == 1) { a = tn; b = 0; } else trailing_tile_index(tn, a, b);
+                in0 = r0 + a * TT; jn0 = r0 + b * TT;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cN[r] = S[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int c = cb + it * 16;
+                    lv[it] = Lp[(in0 + row) + (size_t)c * NP];
+                    yv[it] = Y[(jn0 + row) + (size_t)c * NP];
+                }
             }
+            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+            // MFMA fragments by explicit ds_read_b64 (lane (fr, fk) reads row fr, k = 4 kk + fk: dword address 132 fr + 2 fk + 8 kk — the 32
+            // lanes of a half-wave hit 32 distinct bank pairs modulo 64).  Plain loads would be paired by the compiler into ds_read2_b64 /
+            // ds_read_b128, whose lane groups conflict 2-way on this layout (round 1: 48 % of the LDS cycles were conflict replays).  All 32
+            // loads of a tile are issued up front; the waits release them to the matrix cores in order (LDS returns in order).
+            {
+                const unsigned lb = (unsigned)(uintptr_t)(Ls + (wr * 16 + fr) * LDT + fk);
+                const unsigned yb = (unsigned)(uintptr_t)(Ys + (wc * 16 + fr) * LDT + fk);
+                double fl[NB / 4], fy[NB / 4];
+#pragma unroll
+                for (int kk = 0; kk < NB / 4; ++kk) {
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fl[kk]) : "v"(lb), "n"(kk * 32) : "memory");
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fy[kk]) : "v"(yb), "n"(kk * 32) : "memory");
+                }
 #define TR_WAIT(N, A, B) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fl[A]), "+v"(fy[A]), "+v"(fl[B]), "+v"(fy[B]) :: "memory")
-            TR_WAIT(15, 0, 1); TR_WAIT(15, 2, 3); TR_WAIT(15, 4, 5); TR_WAIT(12, 6, 7); TR_WAIT(8, 8, 9); TR_WAIT(4, 10, 11); TR_WAIT(0, 12, 13); TR_WAIT(0, 14, 15);
+                TR_WAIT(15, 0, 1); TR_WAIT(15, 2, 3); TR_WAIT(15, 4, 5); TR_WAIT(12, 6, 7); TR_WAIT(8, 8, 9); TR_WAIT(4, 10, 11); TR_WAIT(0, 12, 13); TR_WAIT(0, 14, 15);
 #undef TR_WAIT
 #pragma unroll
-            for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fy[kk], fl[kk], acc, 0, 0, 0);
+                for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fy[kk], fl[kk], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cS[r] -= acc[r];
+            if (h + 1 < NH) __syncthreads();          // the operand reads of the first panel are done before LDS is refilled
         }
         if (t == 0) {
             // tile 0 = the diagonal block of the next panel: hand it over through LDS (row-major, stride LDD) and factor it
             __syncthreads();                      // all MFMA operand reads of Ls/Ys are done
 #pragma unroll
-            for (int r = 0; r < 4; ++r) smem[(wr * 16 + fr) * LDD + (wc * 16 + fk + 4 * r)] = cS[r] - acc[r];
+            for (int r = 0; r < 4; ++r) smem[(wr * 16 + fr) * LDD + (wc * 16 + fk + 4 * r)] = cS[r];
             __syncthreads();
             diag_block<true>(smem, NP, nx, r0, tb, S, Dx, Tinv, icount);
             return;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP] = cS[r] - acc[r];
+        for (int r = 0; r < 4; ++r) S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP] = cS[r];
         if (tn >= ntiles) return;
         t = tn; i0 = in0; j0 = jn0;
 #pragma unroll
@@ -431,16 +453,34 @@ static void enqueue_ldl(calipso_hip_solver* s) {
     const unsigned nz = bt.n;
     hipLaunchKernelGGL(k_ldl_diag, dim3(1, 1, nz), dim3(DIAG_THREADS), 0, s->stream, bt, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, s->icount);
     const int band = s->band64 > 0 ? s->band64 : nblk;     // 64-row blocks below a diagonal block that can be non-zero (structure.hip)
-    for (int kb = 0; kb + 1 < nblk; ++kb) {
+    // persistent workgroups: two fit a CU (LDS, wave slots), so at most 512 are resident; more would only queue
+    const int resident = std::max(2, 512 / (int)nz);
+    // Pair schedule (dense S, several instances per launch): panel k, the first tile column of its update (whose tile 0 factors diagonal block
+    // k + 1), panel k + 1, then BOTH panels in one pass over the rest.  Same arithmetic as the plain schedule (k_ldl_trailing, MODE 2), half
+    // the read-modify-write traffic on the trailing matrix; one instance alone is bound by the pivot chain, not by traffic, and keeps the
+    // plain schedule (two launches per panel).
+    static const int pairs_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_PAIRS"); return e ? atoi(e) : -1; }();
+    const bool pairs = s->band64 == 0 && (pairs_env >= 0 ? pairs_env != 0 : nz >= 4);
+    for (int kb = 0; kb + 1 < nblk;) {
         const int k0 = kb * NB;
         const int rows = std::min(NP - k0 - NB, band * NB);  // banded S: the panel and its trailing update stop at the band
         hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64, 1, nz), dim3(1024), 0, s->stream, bt, NP, k0, tb, s->S, s->Dx, s->Tinv, s->Ypanel);
-        const int ntr = rows / TT, ntiles = ntr * (ntr + 1) / 2;
-        // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
-        // persistent workgroups: two fit a CU (LDS, wave slots), so at most 512 are resident; more would only queue
-        const int resident = std::max(2, 512 / (int)nz);
-        const int nwg = ntiles <= resident ? ntiles : resident;
-        hipLaunchKernelGGL(k_ldl_trailing, dim3(nwg, 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S, s->Ypanel, s->Dx, s->Tinv, s->icount);
+        const int ntr = rows / TT;
+        if (pairs && kb + 2 < nblk) {
+            hipLaunchKernelGGL(k_ldl_trailing<1>, dim3(std::min(ntr, resident), 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntr, tb, s->S, s->Ypanel, s->Dx,
+                               s->Tinv, s->icount);
+            hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64 - 1, 1, nz), dim3(1024), 0, s->stream, bt, NP, k0 + NB, tb, s->S, s->Dx, s->Tinv, s->Ypanel + (size_t)NP * NB);
+            const int ntr2 = ntr - 1, ntiles2 = ntr2 * (ntr2 + 1) / 2;
+            hipLaunchKernelGGL(k_ldl_trailing<2>, dim3(std::min(ntiles2, resident), 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles2, tb, s->S, s->Ypanel,
+                               s->Dx, s->Tinv, s->icount);
+            kb += 2;
+        } else {
+            const int ntiles = ntr * (ntr + 1) / 2;
+            // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
+            hipLaunchKernelGGL(k_ldl_trailing<0>, dim3(std::min(ntiles, resident), 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S, s->Ypanel,
+                               s->Dx, s->Tinv, s->icount);
+            kb += 1;
+        }
     }
     const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
     for (int level = 1; level <= 3; ++level) {
