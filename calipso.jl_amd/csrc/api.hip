@@ -159,8 +159,13 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     rc |= dalloc(s, &s->cone.soc_start, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.soc_dim, (size_t)d.n_soc);
     rc |= dalloc(s, &s->cone.soc_woff, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.entry_soc, NC);
     if (rc) return CALIPSO_ERR_HIP;
-    CK(hipHostMalloc((void**)&s->hscal, 64 * sizeof(double)));
-    CK(hipHostMalloc((void**)&s->hicount, 64 * sizeof(int)));
+    CK(hipHostMalloc((void**)&s->hscal, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    CK(hipHostMalloc((void**)&s->hicount, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    CK(hipHostMalloc((void**)&s->hseq, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    CK(hipHostGetDevicePointer((void**)&s->hscal_dev, s->hscal, 0));
+    CK(hipHostGetDevicePointer((void**)&s->hicount_dev, s->hicount, 0));
+    CK(hipHostGetDevicePointer((void**)&s->hseq_dev, s->hseq, 0));
+    s->hseq[0] = 0;
     CK(hipStreamSynchronize(s->stream));   // the zero-fills above are complete before the (null-stream) index uploads below
     {   // dense default of the structure table: every column group visits all constraint rows
         std::vector<int> kr(4 * KG);
@@ -210,6 +215,7 @@ int32_t calipso_hip_destroy(H* s) {
     for (int* p : ip) if (p) (void)hipFree(p);
     if (s->hscal) (void)hipHostFree(s->hscal);
     if (s->hicount) (void)hipHostFree(s->hicount);
+    if (s->hseq) (void)hipHostFree(s->hseq);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     if (s->graph_ldl) (void)hipGraphExecDestroy(s->graph_ldl);
     if (s->graph_trsv) (void)hipGraphExecDestroy(s->graph_trsv);
@@ -375,11 +381,33 @@ int32_t calipso_hip_synchronize(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; SYN
 }  // extern "C"
 
 // ---- internal helpers -------------------------------------------------------------------------------------------------------
-static int read_scalars(H* s, int first, int count) {
-    CK(hipMemcpyAsync(s->hscal + first, s->dscal + first, sizeof(double) * count, hipMemcpyDeviceToHost, s->stream));
-    SYNC();
+// Scalar read-backs (refinement norms, merit / step-length decisions, cone-search masks: ~14 per Newton step).  A hipMemcpyAsync to pinned
+// memory + hipStreamSynchronize costs 11.4 us between two dependent kernels on this system; a one-workgroup kernel that stores the words
+// straight into mapped pinned host memory, then (system-scope release) a sequence number the host spins on, costs 6.4 us
+// (bench/readback_latency.hip, profiles/r02_readback_latency.txt).  Everything queued before the publish kernel has completed when the
+// sequence number arrives (in-order stream).
+__global__ __launch_bounds__(128) void k_publish_words(const unsigned* __restrict__ src, int words, unsigned* __restrict__ hdst, unsigned long long* __restrict__ hseq,
+                                                        unsigned long long seq) {
+    if ((int)threadIdx.x < words) hdst[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static int publish_and_wait(H* s, const void* dsrc, void* hdst_dev, int words) {
+    const unsigned long long seq = ++s->pub_seq;
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, s->stream, static_cast<const unsigned*>(dsrc), words, static_cast<unsigned*>(hdst_dev), s->hseq_dev, seq);
+    unsigned spins = 0;
+    while (__atomic_load_n(s->hseq, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0x3ffffu) == 0) {                      // a faulted queue would never publish: look at the stream now and then
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return calipso::check(s, q, "publish_and_wait");
+            if (q == hipSuccess && __atomic_load_n(s->hseq, __ATOMIC_ACQUIRE) != seq) { s->err = "scalar read-back did not arrive"; return CALIPSO_ERR_HIP; }
+        }
+    }
     return 0;
 }
+static int read_scalars(H* s, int first, int count) { return publish_and_wait(s, s->dscal + first, s->hscal_dev + first, 2 * count); }
+static int read_icount(H* s, int first, int count) { return publish_and_wait(s, s->icount + first, s->hicount_dev + first, count); }
 static double* point_of(H* s, int which) { return which == 0 ? s->solution : s->candidate; }
 
 static int do_factorize(H* s, int64_t inertia[3]) {
@@ -511,8 +539,7 @@ static int do_cone_search(H* s, double* a_s, double* a_t) {
     const Options& o = s->opt;
     if (s->d.nc == 0) { *a_s = 1.0; *a_t = 1.0; return CALIPSO_OK; }
     launch_cone_search(s);
-    CK(hipMemcpyAsync(s->hicount + 6, s->icount + 6, sizeof(int) * 58, hipMemcpyDeviceToHost, s->stream));
-    SYNC();
+    if (read_icount(s, 6, 58)) return CALIPSO_ERR_HIP;
     const int ks = first_feasible_trial(s->hicount + 6, o.max_cone_line_search), kt = first_feasible_trial(s->hicount + 32, o.max_cone_line_search);
     if (ks < 0 || kt < 0) { s->err = "cone search failure"; return CALIPSO_ERR_CONE_SEARCH; }   // solve.jl:210,220
     // step sizes as the reference forms them: repeated multiplication by scaling_line_search (the kernel tested exactly these)

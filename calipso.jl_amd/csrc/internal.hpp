@@ -141,6 +141,10 @@ struct calipso_hip_solver {
     double *cone_product = nullptr, *cone_target = nullptr, *barrier_gradient = nullptr;  // nc
     double* dscal = nullptr;   // device scalars: [0] objective [1] barrier  [2..] reduction outputs (see kernels)
     double* hscal = nullptr;   // pinned host mirror of dscal
+    double* hscal_dev = nullptr;            // its device-side address (the publish kernel of api.hip stores into it)
+    unsigned long long* hseq = nullptr;     // pinned: sequence number the publish kernel writes after the values
+    unsigned long long* hseq_dev = nullptr;
+    unsigned long long pub_seq = 0;
     double *jacobian_parameters = nullptr, *solution_sensitivity = nullptr;   // N*np
     // points
     double *solution = nullptr, *candidate = nullptr, *lambda = nullptr, *parameters = nullptr;
@@ -168,6 +172,7 @@ struct calipso_hip_solver {
     int* zrow = nullptr;        // (in the slab) per row of [gx; hx]: [first, last + 1) non-zero column
     int* icount = nullptr;      // device ints: [0] pos [1] nonpos [2] zero (constraint part), [3..5] same for S, [6..] cone-search masks
     int* hicount = nullptr;     // pinned host mirror
+    int* hicount_dev = nullptr;
     double* gemv_partial = nullptr;   // partial sums for column-split mat-vecs
     double* vtmp = nullptr;     // 4*N scratch vectors
     double *xbuf = nullptr, *zf = nullptr, *t1 = nullptr, *t2 = nullptr;   // NP, NP, m, m: work vectors of the condensed solve

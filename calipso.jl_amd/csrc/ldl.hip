@@ -267,6 +267,13 @@ __device__ __forceinline__ void trailing_tile_index(int t, int& ti, int& tj) {
 //         entry of the trailing matrix is read and written once per 128 pivots instead of once per 64 — the early, HBM-bound updates of a
 //         group move half the bytes.  The arithmetic is that of two MODE 0 passes, operation for operation (a separate accumulator per
 //         panel, subtracted in panel order), so the pair schedule (MODE 1 + MODE 2) and the plain one (MODE 0 twice) give the same bits.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wave (vmcnt(0)): in the
+// tile loop below that would put the write latency of the tile just stored, and the arrival of the operands prefetched for the next one, on
+// the critical path of every tile.  Tiles are disjoint in global memory; only the LDS panels are shared between the waves.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+}
 template <int MODE>
 __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, int nx, int k0, int ntiles, int tb, double* __restrict__ S, const double* __restrict__ Y,
                                                              double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount) {
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
                 Ls[row * LDT + c] = lv[it];
                 Ys[row * LDT + c] = yv[it];
             }
-            __syncthreads();
+            lds_barrier();
             if (h + 1 < NH) {
                 // the second panel of the same tile
 #pragma unroll
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) cS[r] -= acc[r];
-            if (h + 1 < NH) __syncthreads();          // the operand reads of the first panel are done before LDS is refilled
+            if (h + 1 < NH) lds_barrier();            // the operand reads of the first panel are done before LDS is refilled
         }
         if (t == 0) {
             // tile 0 = the diagonal block of the next panel: hand it over through LDS (row-major, stride LDD) and factor it
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
         t = tn; i0 = in0; j0 = jn0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) cS[r] = cN[r];
-        __syncthreads();                          // the operand reads of this tile are done before LDS is refilled
+        lds_barrier();                            // the operand reads of this tile are done before LDS is refilled
     }
 }
 
@@ -454,7 +461,8 @@ static void enqueue_ldl(calipso_hip_solver* s) {
     hipLaunchKernelGGL(k_ldl_diag, dim3(1, 1, nz), dim3(DIAG_THREADS), 0, s->stream, bt, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, s->icount);
     const int band = s->band64 > 0 ? s->band64 : nblk;     // 64-row blocks below a diagonal block that can be non-zero (structure.hip)
     // persistent workgroups: two fit a CU (LDS, wave slots), so at most 512 are resident; more would only queue
-    const int resident = std::max(2, 512 / (int)nz);
+    static const int resident_total = [] { const char* e = getenv("CALIPSO_HIP_LDL_RESIDENT"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    const int resident = std::max(2, resident_total / (int)nz);
     // Pair schedule (dense S, several instances per launch): panel k, the first tile column of its update (whose tile 0 factors diagonal block
     // k + 1), panel k + 1, then BOTH panels in one pass over the rest.  Same arithmetic as the plain schedule (k_ldl_trailing, MODE 2), half
     // the read-modify-write traffic on the trailing matrix; one instance alone is bound by the pivot chain, not by traffic, and keeps the
