@@ -16,7 +16,10 @@ def load(path):
     rows = defaultdict(list)
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows[r["Kernel_Name"].split("(")[0]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+            name = r["Kernel_Name"].split("(")[0]
+            if name.startswith("void "):          # template instantiations are printed with their return type
+                name = name[5:]
+            rows[name].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     return rows
 
 
