@@ -181,3 +181,26 @@ def test_rate_report_on_trajectory_kkt_systems(oracle_mod):
     with open("gpurun_out/sparse_ldl_rate.json", "w") as fh:
         json.dump(rows, fh, indent=1)
     print(json.dumps(rows))
+
+
+def test_global_accumulator_path_beyond_the_lds_limit(oracle_mod):
+    """n above what one CU's LDS can hold as a column accumulator (19 400 doubles): the accumulators live in global scratch, one per resident
+    workgroup; same parity bar"""
+    pkg = load_pkg()
+    rng = np.random.default_rng(21)
+    K = staged_kkt(700, 12, 4, rng)
+    n = K.shape[0]
+    assert n > 19400
+    A = sp.triu(K).tocsc()
+    S = pkg.SparseLDL(A, method="nested_dissection")
+    assert not S.info["lds_accumulator"] and S.info["levels"] < 200
+    assert S.factorize(A) == 0
+    assert S.inertia == (700 * 16 + 12, 700 * 12, 0)
+    perm, Lm, D = S.factor()
+    ref = oracle_factor(oracle_mod, K, perm)
+    assert np.abs(D - ref["D"]).max() <= 1e-10 * np.abs(ref["D"]).max()
+    assert abs(Lm - ref["L"]).max() <= 1e-10 * max(1.0, abs(ref["L"]).max())
+    b = rng.standard_normal((n, 2))
+    x = S.solve(b)
+    assert np.abs(K @ x - b).max() <= 1e-8 * max(1.0, np.abs(x).max())
+    S.close()
