@@ -480,6 +480,7 @@ def _csc_1based(A):
 
 
 ORDERINGS = dict(natural=0, rcm=1, minimum_degree=2, nested_dissection=4)
+SPARSE_METHODS = dict(ORDERINGS, nested_dissection_columns=5)     # 5: nested-dissection order with the column-level numeric phase (no fronts)
 
 
 def ordering(A, method="rcm"):
@@ -576,7 +577,8 @@ class LDLSolver:
 class SparseLDL:
     """Sparse LDL^T on the device (include/calipso_hip.h, "sparse LDL^T on the device"): qdldl(A; perm) / QDLDL_factor! / solve! of
     src/solver/qdldl.jl for a scipy.sparse matrix A (only triu(A) is read), memory O(nnz(L)), level-scheduled over the elimination tree.
-    method: "natural", "rcm", "minimum_degree", "nested_dissection", or perm=<1-based order>."""
+    method: "natural", "rcm", "minimum_degree", "nested_dissection" (multifrontal over the dissection tree when every front fits one CU's LDS,
+    else as "nested_dissection_columns": the same order with the column-level numeric phase), or perm=<1-based order>."""
 
     def __init__(self, A, method="nested_dissection", perm=None, device=0):
         self._L = lib()
@@ -584,7 +586,7 @@ class SparseLDL:
         self.n, self.nnz = A.shape[0], A.nnz
         pp = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
         h = C.c_void_p()
-        rc = self._L.calipso_hip_sparse_create(self.n, _pi(colptr), _pi(rowval), 3 if pp is not None else ORDERINGS[method], _pi(pp) if pp is not None else None,
+        rc = self._L.calipso_hip_sparse_create(self.n, _pi(colptr), _pi(rowval), 3 if pp is not None else SPARSE_METHODS[method], _pi(pp) if pp is not None else None,
                                                device, C.byref(h))
         if rc != 0:
             msg = self._L.calipso_hip_sparse_last_error(h if h.value else None).decode()
@@ -595,7 +597,8 @@ class SparseLDL:
         info = np.zeros(8, dtype=np.int64)
         self._check(self._L.calipso_hip_sparse_info(self._h, _pi(info)), "sparse_info")
         self.info = dict(n=int(info[0]), nnz_upper=int(info[1]), nnzL=int(info[2]), levels=int(info[3]), launches=int(info[4]), widest_level=int(info[5]),
-                         multiply_adds=int(info[6]), lds_accumulator=bool(info[7]))
+                         multiply_adds=int(info[6]), lds_accumulator=int(info[7]) == 1,
+                         numeric={0: "columns_global_accumulator", 1: "columns_lds_accumulator", 2: "multifrontal"}[int(info[7])])
         self.inertia = (0, 0, 0)
 
     def _check(self, rc, what):

@@ -284,6 +284,7 @@ inline BatchSc batch_of(const calipso_hip_solver* s) {
     return b;
 }
 // batched fills / copies (vectors.hip) — replace hipMemsetAsync / hipMemcpyAsync on the hot path so that groups are covered
+int nested_dissection_pieces(i64 n, const i64* colptr, const i64* rowval, i64* perm, std::vector<std::pair<int, int>>& pieces);   // ordering.hip
 void fill_d(calipso_hip_solver* s, double* p, size_t n, double v);
 void fill_i(calipso_hip_solver* s, int* p, size_t n, int v);
 void copy_d(calipso_hip_solver* s, double* dst, const double* src, size_t n);

@@ -136,7 +136,8 @@ std::vector<i64> minimum_degree(const std::vector<std::vector<int>>& adj0) {
 // trajectory problems (trajectory_optimization/sparsity.jl:28-129) the tree height drops from O(T) stages to O(log T), which is what the
 // level-scheduled device factorisation of sparse.hip turns into parallelism (stage-parallel elimination).  Leaves (<= 48
 // vertices, or pieces the level structure cannot split) are ordered by minimum degree.
-void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& verts, std::vector<int>& local, std::vector<int>& level, std::vector<i64>& out) {
+typedef std::vector<std::pair<int, int>> Pieces;     // (first position, count) of every leaf piece / separator, in elimination order
+void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& verts, std::vector<int>& local, std::vector<int>& level, std::vector<i64>& out, Pieces* pieces) {
     const int m = (int)verts.size();
     auto leaf = [&]() {
         // minimum degree on the induced subgraph
@@ -144,6 +145,7 @@ void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& vert
         std::vector<std::vector<int>> sub((size_t)m);
         for (int a = 0; a < m; ++a) for (int u : adj[verts[a]]) if (local[u] >= 0) sub[(size_t)a].push_back(local[u]);
         for (int a = 0; a < m; ++a) local[verts[a]] = -1;
+        if (pieces) pieces->push_back({(int)out.size(), m});
         for (i64 k : minimum_degree(sub)) out.push_back(verts[(size_t)k - 1] + 1);
     };
     if (m <= 48) { leaf(); return; }
@@ -162,7 +164,7 @@ void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& vert
             std::vector<std::vector<int>> parts((size_t)ncomp);
             for (int a = 0; a < m; ++a) parts[(size_t)comp_of[(size_t)a]].push_back(verts[a]);
             for (int a = 0; a < m; ++a) local[verts[a]] = -1;
-            for (auto& part : parts) nd_recurse(adj, part, local, level, out);
+            for (auto& part : parts) nd_recurse(adj, part, local, level, out, pieces);
             return;
         }
     }
@@ -199,23 +201,24 @@ void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& vert
     }
     for (int a = 0; a < m; ++a) local[verts[a]] = -1;
     if (A.empty() || B.empty()) { leaf(); return; }
-    nd_recurse(adj, A, local, level, out);
-    nd_recurse(adj, B, local, level, out);
+    nd_recurse(adj, A, local, level, out, pieces);
+    nd_recurse(adj, B, local, level, out, pieces);
     if (!Sep.empty()) {                                       // the separator's own order: minimum degree of its induced subgraph
         const int ms = (int)Sep.size();
         for (int a = 0; a < ms; ++a) local[Sep[a]] = a;
         std::vector<std::vector<int>> sub((size_t)ms);
         for (int a = 0; a < ms; ++a) for (int u : adj[Sep[a]]) if (local[u] >= 0) sub[(size_t)a].push_back(local[u]);
         for (int a = 0; a < ms; ++a) local[Sep[a]] = -1;
+        if (pieces) pieces->push_back({(int)out.size(), ms});
         for (i64 k : minimum_degree(sub)) out.push_back(Sep[(size_t)k - 1] + 1);
     }
 }
-std::vector<i64> nested_dissection(const std::vector<std::vector<int>>& adj) {
+std::vector<i64> nested_dissection(const std::vector<std::vector<int>>& adj, Pieces* pieces = nullptr) {
     const int n = (int)adj.size();
     std::vector<int> verts((size_t)n), local((size_t)n, -1), level((size_t)n, -1);
     std::iota(verts.begin(), verts.end(), 0);
     std::vector<i64> out; out.reserve((size_t)n);
-    nd_recurse(adj, verts, local, level, out);
+    nd_recurse(adj, verts, local, level, out, pieces);
     return out;
 }
 
@@ -281,6 +284,18 @@ bool is_permutation(i64 n, const i64* perm) {
 }
 
 }  // namespace
+
+namespace calipso {
+// nested dissection with its pieces (leaf pieces <= 48 vertices and separators, each contiguous in the order): the supernodes of the multifrontal
+// factorisation of sparse.hip.  perm: 1-based, n entries; pieces: (first position 0-based, count)
+int nested_dissection_pieces(i64 n, const i64* colptr, const i64* rowval, i64* perm, std::vector<std::pair<int, int>>& pieces) {
+    if (n < 0 || !colptr || !perm || (!rowval && colptr[n] > 1)) return CALIPSO_ERR_ARGUMENT;
+    pieces.clear();
+    const std::vector<i64> p = nested_dissection(adjacency(n, colptr, rowval), &pieces);
+    std::copy(p.begin(), p.end(), perm);
+    return CALIPSO_OK;
+}
+}  // namespace calipso
 
 extern "C" {
 

@@ -143,6 +143,136 @@ __global__ void k_sp_permute_out(const double* __restrict__ x, const int* __rest
     if (i < n) out[(size_t)blockIdx.y * n + perm[i]] = x[(size_t)blockIdx.y * n + i];        // ipermute!(x, perm) qdldl.jl:349
 }
 
+
+// ---- multifrontal path (nested-dissection orders) ---------------------------------------------------------------------------------------------
+// The pieces of the dissection (leaf pieces of <= 48 vertices, separators) are the SUPERNODES: node s owns the contiguous columns
+// [first, first + c) and the rows R_s below them (r of them); its frontal matrix F_s (m = c + r) is assembled in the LDS of one workgroup from
+// the entries of A in its columns and the update matrices U of its children (extend-add through precomputed relative indices, children in
+// ascending order: fixed summation order), the first c columns are eliminated by a dense LDL^T in LDS (one barrier per pivot column), the
+// m x c panel of L goes to global memory and U_s = F_s[c.., c..] to the node's slot of the update pool.  One launch per LEVEL of the node tree:
+// for a T-stage trajectory problem that is ~log2 T launches for the whole factorisation — the stages are eliminated in parallel, level by level.
+struct MfDev {
+    int nnodes;
+    const int* order;                         // nodes sorted by level
+    const int *nfirst, *ncols, *nrows;        // per node: first column, c, r
+    const int *rowptr, *rows;                 // R_s (global, permuted row indices), ascending
+    const int* rel;                           // per node, aligned with rows: local index of R_s[k] in the PARENT's front
+    const int *childptr, *children;
+    const long long *panel_off, *upd_off, *u_off;
+    const int* Aloc;                          // per entry of the permuted lower CSC: offset inside its node's front (row * (m + 1) + column)
+    const int *Alp, *Asrc;
+    const double* Aval;
+    double *panel, *upd, *D, *uvec;
+};
+
+constexpr int MF_THREADS = 256;
+constexpr int MF_MAX_FRONT = 136;             // (m (m + 1) + 2 m) doubles <= 160 KiB
+
+__global__ __launch_bounds__(MF_THREADS) void k_mf_factor(MfDev d, int first) {
+    extern __shared__ __attribute__((aligned(16))) double F[];
+    const int s = d.order[first + blockIdx.x];
+    const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r, ld = m + 1;
+    double* ycol = F + (size_t)m * ld;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < m * ld; e += MF_THREADS) F[e] = 0.0;
+    __syncthreads();
+    for (int p = d.Alp[f] + tid; p < d.Alp[f + c]; p += MF_THREADS) F[d.Aloc[p]] = d.Aval[d.Asrc[p]];
+    __syncthreads();
+    for (int q = d.childptr[s]; q < d.childptr[s + 1]; ++q) {                 // extend-add, children in ascending order
+        const int ch = d.children[q];
+        const int rc = d.nrows[ch];
+        const double* U = d.upd + d.upd_off[ch];
+        const int* rel = d.rel + d.rowptr[ch];
+        for (int e = tid; e < rc * rc; e += MF_THREADS) {
+            const int a = e / rc, b = e - a * rc;
+            if (a >= b) F[rel[a] * ld + rel[b]] += U[e];                       // rel is increasing: the lower triangle lands in the lower triangle
+        }
+        __syncthreads();
+    }
+    // partial dense LDL^T: the pivot column travels (unscaled) through a double-buffered LDS vector, one barrier per column
+    if (tid < m) ycol[tid] = F[tid * ld];
+    const int ti = tid >> 4, tk = tid & 15;
+    for (int j = 0; j < c; ++j) {
+        __syncthreads();
+        const double* y = ycol + (j & 1) * m;
+        double* yn = ycol + ((j + 1) & 1) * m;
+        const double dj = y[j];
+        const double rinv = 1.0 / dj;
+        if (tid == 0) d.D[f + j] = dj;
+        for (int i = j + 1 + ti; i < m; i += 16) {
+            const double li = y[i] * rinv;
+            for (int k = j + 1 + tk; k <= i; k += 16) {
+                const double v = F[i * ld + k] - li * y[k];
+                F[i * ld + k] = v;
+                if (k == j + 1) { yn[i] = v; F[i * ld + j] = li; }
+            }
+        }
+    }
+    __syncthreads();
+    double* P = d.panel + d.panel_off[s];                                      // column-major m x c: column k contiguous over the rows
+    for (int e = tid; e < m * c; e += MF_THREADS) { const int i = e % m, k = e / m; P[e] = i > k ? F[i * ld + k] : 0.0; }
+    double* U = d.upd + d.upd_off[s];
+    for (int e = tid; e < r * r; e += MF_THREADS) { const int a = e / r, b = e - a * r; if (a >= b) U[e] = F[(c + a) * ld + c + b]; }
+}
+
+// forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors
+__global__ __launch_bounds__(MF_THREADS) void k_mf_forward(MfDev d, int first, int n, long long usum, double* __restrict__ X) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int s = d.order[first + blockIdx.x];
+    const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
+    double* Ps = sm; double* v = sm + (size_t)m * c;
+    double* x = X + (size_t)blockIdx.y * n;
+    double* ubase = d.uvec + (size_t)blockIdx.y * usum;
+    const int tid = threadIdx.x;
+    const double* P = d.panel + d.panel_off[s];
+    for (int e = tid; e < m * c; e += MF_THREADS) Ps[e] = P[e];
+    for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] : 0.0;
+    __syncthreads();
+    for (int q = d.childptr[s]; q < d.childptr[s + 1]; ++q) {
+        const int ch = d.children[q];
+        const int rc = d.nrows[ch];
+        const double* u = ubase + d.u_off[ch];
+        const int* rel = d.rel + d.rowptr[ch];
+        for (int a = tid; a < rc; a += MF_THREADS) v[rel[a]] += u[a];
+        __syncthreads();
+    }
+    for (int k = 0; k < c; ++k) {
+        const double yk = v[k];
+        for (int i = k + 1 + tid; i < m; i += MF_THREADS) v[i] -= Ps[i + k * m] * yk;
+        __syncthreads();
+    }
+    for (int i = tid; i < c; i += MF_THREADS) x[f + i] = v[i];
+    double* u = ubase + d.u_off[s];
+    for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a];
+}
+// backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C
+__global__ __launch_bounds__(MF_THREADS) void k_mf_backward(MfDev d, int first, int n, double* __restrict__ X) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int s = d.order[first + blockIdx.x];
+    const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
+    double* Ps = sm; double* v = sm + (size_t)m * c;
+    double* x = X + (size_t)blockIdx.y * n;
+    const int tid = threadIdx.x;
+    const double* P = d.panel + d.panel_off[s];
+    const int* R = d.rows + d.rowptr[s];
+    for (int e = tid; e < m * c; e += MF_THREADS) Ps[e] = P[e];
+    for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] / d.D[f + i] : x[R[i - c]];
+    __syncthreads();
+    double z = 0.0;
+    if (tid < c) { z = v[tid]; for (int a = 0; a < r; ++a) z -= Ps[(c + a) + tid * m] * v[c + a]; }
+    __syncthreads();
+    if (tid < c) v[tid] = z;
+    __syncthreads();
+    for (int k = c - 1; k >= 0; --k) {
+        const double xk = v[k];
+        for (int j = tid; j < k; j += MF_THREADS) v[j] -= Ps[k + j * m] * xk;
+        __syncthreads();
+    }
+    for (int i = tid; i < c; i += MF_THREADS) x[f + i] = v[i];
+}
+
+struct MfSeg { int first, count; size_t lds_factor, lds_solve; };
+
 struct Segment { int first, count; bool chain; };
 
 }  // namespace
@@ -155,6 +285,14 @@ struct calipso_hip_sparse {
     std::vector<i64> perm;                       // 1-based, perm[k] = vertex eliminated k-th
     std::vector<int> hLp, hLi;                   // host copy of the pattern (get_factor)
     std::vector<Segment> plan;
+    bool mf = false;                             // multifrontal numeric phase (nested-dissection orders whose fronts fit the LDS)
+    MfDev md{};
+    std::vector<MfSeg> mplan;
+    std::vector<int> h_nfirst, h_ncols, h_nrows, h_rowptr, h_rows;
+    std::vector<long long> h_panel_off;
+    long long panel_total = 0, usum = 0;
+    size_t cap_uvec = 0;
+    int max_front = 0, nnodes = 0;
     std::vector<void*> dev;                      // every device allocation
     SpDev d{};
     int* d_perm = nullptr;
@@ -186,6 +324,10 @@ int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
 }
 
 void enqueue_factor(calipso_hip_sparse* s) {
+    if (s->mf) {
+        for (const MfSeg& g : s->mplan) hipLaunchKernelGGL(k_mf_factor, dim3((unsigned)g.count), dim3(MF_THREADS), g.lds_factor, s->stream, s->md, g.first);
+        return;
+    }
     const size_t lds = s->lds_acc ? sizeof(double) * (size_t)s->n : 0;
     for (const Segment& g : s->plan) {
         const int grid = g.chain ? 1 : std::min(g.count, s->work_slots);
@@ -208,6 +350,7 @@ int32_t calipso_hip_sparse_destroy(calipso_hip_sparse* s) {
     for (void* p : s->dev) if (p) (void)hipFree(p);
     if (s->d_rhs) (void)hipFree(s->d_rhs);
     if (s->d_x) (void)hipFree(s->d_x);
+    if (s->md.uvec) (void)hipFree(s->md.uvec);
     if (s->e0) (void)hipEventDestroy(s->e0);
     if (s->e1) (void)hipEventDestroy(s->e1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -223,7 +366,7 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
     calipso_hip_sparse* s = nullptr;
     if (!out) return CALIPSO_ERR_ARGUMENT;
     *out = nullptr;
-    if (n < 1 || n > 0x3fffffff || !colptr || (!rowval && colptr[n] > 1) || method < 0 || method > 4 || (method == 3 && !perm)) {
+    if (n < 1 || n > 0x3fffffff || !colptr || (!rowval && colptr[n] > 1) || method < 0 || method > 5 || (method == 3 && !perm)) {
         g_sparse_err = "calipso_hip_sparse_create: bad arguments"; return CALIPSO_ERR_ARGUMENT;
     }
     if (colptr[0] != 1) { g_sparse_err = "colptr must be 1-based (Julia SparseMatrixCSC)"; return CALIPSO_ERR_ARGUMENT; }
@@ -232,9 +375,13 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
     if (device < 0 || device >= ndev) { g_sparse_err = "device ordinal out of range"; return CALIPSO_ERR_ARGUMENT; }
     // ---- order
     std::vector<i64> p((size_t)n);
+    std::vector<std::pair<int, int>> pieces;        // nested dissection: (first position, count) of every leaf piece / separator
     if (method == 3) {
         std::vector<char> seen((size_t)n, 0);
         for (i64 k = 0; k < n; ++k) { const i64 v = perm[k]; if (v < 1 || v > n || seen[(size_t)v - 1]) { g_sparse_err = "perm is not a permutation of 1:n"; return CALIPSO_ERR_ARGUMENT; } seen[(size_t)v - 1] = 1; p[(size_t)k] = v; }
+    } else if (method >= 4) {
+        const int rc = calipso::nested_dissection_pieces(n, colptr, rowval, p.data(), pieces);
+        if (rc < 0) { g_sparse_err = "nested dissection failed"; return rc; }
     } else {
         const int rc = calipso_hip_ordering(n, colptr, rowval, method, p.data());
         if (rc < 0) { g_sparse_err = "calipso_hip_ordering failed"; return rc; }
@@ -325,6 +472,97 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
         else plan.push_back({a, cnt, cnt == 1});
         a = b;
     }
+    // ---- multifrontal symbolic phase (method 4): the dissection pieces as supernodes
+    bool use_mf = method == 4 && !pieces.empty();
+    const int NN = (int)pieces.size();
+    std::vector<int> m_first, m_cols, m_rows, m_parent, m_rowptr, m_rowsv, m_rel, m_childptr, m_children, m_order, m_Aloc;
+    std::vector<long long> m_panel_off, m_upd_off, m_u_off;
+    std::vector<MfSeg> mplan;
+    long long panel_total = 0, upd_total = 0, usum = 0;
+    int max_front = 0, mf_levels = 0, mf_widest = 0;
+    if (use_mf) {
+        std::vector<int> node_of((size_t)n, -1);
+        for (int t = 0; t < NN; ++t) for (int q = 0; q < pieces[(size_t)t].second; ++q) node_of[(size_t)(pieces[(size_t)t].first + q)] = t;
+        for (int j = 0; j < (int)n; ++j) if (node_of[(size_t)j] < 0) use_mf = false;
+        std::vector<std::vector<int>> R((size_t)NN);
+        m_parent.assign((size_t)NN, -1);
+        std::vector<int> stamp((size_t)n, -1);
+        for (int t = 0; t < NN && use_mf; ++t) {
+            // rows below the node reached from any of its columns, plus what the children passed up (already in R[t])
+            const int f = pieces[(size_t)t].first, c = pieces[(size_t)t].second, last = f + c - 1;
+            std::vector<int>& rt = R[(size_t)t];
+            for (int v : rt) stamp[(size_t)v] = t;
+            for (int j = f; j <= last; ++j) for (int i : Lcol[(size_t)j]) if (i > last && stamp[(size_t)i] != t) { stamp[(size_t)i] = t; rt.push_back(i); }
+            std::sort(rt.begin(), rt.end());
+            max_front = std::max(max_front, c + (int)rt.size());
+            if (!rt.empty()) {
+                const int par = node_of[(size_t)rt[0]];
+                m_parent[(size_t)t] = par;
+                const int pl = pieces[(size_t)par].first + pieces[(size_t)par].second - 1;
+                std::vector<int>& rp = R[(size_t)par];                  // closure: what the parent does not own it must carry on
+                for (int v : rt) if (v > pl) rp.push_back(v);
+                std::sort(rp.begin(), rp.end()); rp.erase(std::unique(rp.begin(), rp.end()), rp.end());
+            }
+        }
+        if (max_front > MF_MAX_FRONT) use_mf = false;                   // a front that does not fit one CU's LDS: column method
+        if (use_mf) {
+            m_first.resize((size_t)NN); m_cols.resize((size_t)NN); m_rows.resize((size_t)NN); m_rowptr.assign((size_t)NN + 1, 0);
+            m_panel_off.resize((size_t)NN); m_upd_off.resize((size_t)NN); m_u_off.resize((size_t)NN);
+            for (int t = 0; t < NN; ++t) {
+                const int c = pieces[(size_t)t].second, r = (int)R[(size_t)t].size();
+                m_first[(size_t)t] = pieces[(size_t)t].first; m_cols[(size_t)t] = c; m_rows[(size_t)t] = r;
+                m_rowptr[(size_t)t + 1] = m_rowptr[(size_t)t] + r;
+                m_panel_off[(size_t)t] = panel_total; panel_total += (long long)(c + r) * c;
+                m_upd_off[(size_t)t] = upd_total; upd_total += (long long)r * r;
+                m_u_off[(size_t)t] = usum; usum += r;
+                m_rowsv.insert(m_rowsv.end(), R[(size_t)t].begin(), R[(size_t)t].end());
+            }
+            // relative indices into the parent's front, children lists, levels
+            m_rel.assign(m_rowsv.size(), 0);
+            std::vector<std::vector<int>> kids((size_t)NN);
+            std::vector<int> lev((size_t)NN, 0);
+            for (int t = 0; t < NN; ++t) {
+                const int par = m_parent[(size_t)t];
+                if (par < 0) continue;
+                kids[(size_t)par].push_back(t);
+                lev[(size_t)par] = std::max(lev[(size_t)par], lev[(size_t)t] + 1);      // children precede parents in position order
+                const int pf = m_first[(size_t)par], pc = m_cols[(size_t)par];
+                const std::vector<int>& rp = R[(size_t)par];
+                for (int k = 0; k < m_rows[(size_t)t]; ++k) {
+                    const int v = R[(size_t)t][(size_t)k];
+                    m_rel[(size_t)m_rowptr[(size_t)t] + (size_t)k] = v < pf + pc ? v - pf : pc + (int)(std::lower_bound(rp.begin(), rp.end(), v) - rp.begin());
+                }
+            }
+            m_childptr.assign((size_t)NN + 1, 0);
+            for (int t = 0; t < NN; ++t) { m_childptr[(size_t)t + 1] = m_childptr[(size_t)t] + (int)kids[(size_t)t].size(); m_children.insert(m_children.end(), kids[(size_t)t].begin(), kids[(size_t)t].end()); }
+            // where each entry of the permuted lower CSC lands in its node's front
+            m_Aloc.assign(Ali.size(), 0);
+            for (int j = 0; j < (int)n; ++j) {
+                const int t = node_of[(size_t)j], f = m_first[(size_t)t], c = m_cols[(size_t)t], ld = c + m_rows[(size_t)t] + 1;
+                const std::vector<int>& rt = R[(size_t)t];
+                for (int q = Alp[(size_t)j]; q < Alp[(size_t)j + 1]; ++q) {
+                    const int i = Ali[(size_t)q];
+                    const int lr = i < f + c ? i - f : c + (int)(std::lower_bound(rt.begin(), rt.end(), i) - rt.begin());
+                    m_Aloc[(size_t)q] = lr * ld + (j - f);
+                }
+            }
+            m_order.resize((size_t)NN);
+            std::iota(m_order.begin(), m_order.end(), 0);
+            std::stable_sort(m_order.begin(), m_order.end(), [&](int a, int b) { return lev[(size_t)a] < lev[(size_t)b]; });
+            for (int a = 0; a < NN;) {
+                int b = a; size_t lf = 0, ls = 0;
+                while (b < NN && lev[(size_t)m_order[(size_t)b]] == lev[(size_t)m_order[(size_t)a]]) {
+                    const int t = m_order[(size_t)b]; const size_t m = (size_t)(m_cols[(size_t)t] + m_rows[(size_t)t]);
+                    lf = std::max(lf, sizeof(double) * (m * (m + 1) + 2 * m)); ls = std::max(ls, sizeof(double) * (m * (size_t)m_cols[(size_t)t] + m));
+                    ++b;
+                }
+                mplan.push_back({a, b - a, lf, ls});
+                mf_widest = std::max(mf_widest, b - a);
+                a = b;
+            }
+            mf_levels = (int)mplan.size();
+        }
+    }
     // ---- the handle and its device side
     s = new calipso_hip_sparse();
     *out = s;
@@ -347,6 +585,23 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
     PK(hipMalloc((void**)&s->d.D, sizeof(double) * (size_t)n)); s->dev.push_back(s->d.D);
     PK(hipMalloc((void**)&s->d_Aval, sizeof(double) * std::max<size_t>((size_t)nnzA, 1))); s->dev.push_back(s->d_Aval);
     s->d.Aval = s->d_Aval;
+    if (use_mf) {
+        s->mf = true; s->mplan = mplan; s->nnodes = NN; s->max_front = max_front; s->panel_total = panel_total; s->usum = usum;
+        s->h_nfirst = m_first; s->h_ncols = m_cols; s->h_nrows = m_rows; s->h_rowptr = m_rowptr; s->h_rows = m_rowsv; s->h_panel_off = m_panel_off;
+        s->levels = mf_levels; s->widest = mf_widest;
+        MfDev& md = s->md;
+        md.nnodes = NN;
+        if ((rc = upload(s, m_order, &md.order)) || (rc = upload(s, m_first, &md.nfirst)) || (rc = upload(s, m_cols, &md.ncols)) || (rc = upload(s, m_rows, &md.nrows)) ||
+            (rc = upload(s, m_rowptr, &md.rowptr)) || (rc = upload(s, m_rowsv, &md.rows)) || (rc = upload(s, m_rel, &md.rel)) || (rc = upload(s, m_childptr, &md.childptr)) ||
+            (rc = upload(s, m_children, &md.children)) || (rc = upload(s, m_panel_off, &md.panel_off)) || (rc = upload(s, m_upd_off, &md.upd_off)) ||
+            (rc = upload(s, m_u_off, &md.u_off)) || (rc = upload(s, m_Aloc, &md.Aloc))) return rc;
+        md.Alp = s->d.Alp; md.Asrc = s->d.Asrc; md.Aval = s->d_Aval; md.D = s->d.D;
+        PK(hipMalloc((void**)&md.panel, sizeof(double) * std::max<size_t>((size_t)panel_total, 1))); s->dev.push_back(md.panel);
+        PK(hipMalloc((void**)&md.upd, sizeof(double) * std::max<size_t>((size_t)upd_total, 1))); s->dev.push_back(md.upd);
+        PK(hipFuncSetAttribute((const void*)k_mf_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PK(hipFuncSetAttribute((const void*)k_mf_forward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PK(hipFuncSetAttribute((const void*)k_mf_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     s->work_slots = std::min(widest, 2048);
     if (s->lds_acc) {
         PK(hipFuncSetAttribute((const void*)k_sp_factor<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * SP_LDS_MAX_N)));
@@ -361,7 +616,7 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
 //         1 if the column accumulator lives in LDS]
 int32_t calipso_hip_sparse_info(calipso_hip_sparse* s, int64_t info[8]) {
     if (!s || !info) return CALIPSO_ERR_ARGUMENT;
-    info[0] = s->n; info[1] = s->nnzU; info[2] = s->nnzL; info[3] = s->levels; info[4] = (i64)s->plan.size(); info[5] = s->widest; info[6] = s->flops; info[7] = s->lds_acc;
+    info[0] = s->n; info[1] = s->nnzU; info[2] = s->nnzL; info[3] = s->levels; info[4] = s->mf ? (i64)s->mplan.size() : (i64)s->plan.size(); info[5] = s->widest; info[6] = s->flops; info[7] = s->mf ? 2 : (s->lds_acc ? 1 : 0);
     return CALIPSO_OK;
 }
 
@@ -422,10 +677,24 @@ int32_t calipso_hip_sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const doub
     PK(hipEventRecord(s->e0, s->stream));
     const unsigned gx = (unsigned)((s->n + 255) / 256), ny = (unsigned)nrhs;
     hipLaunchKernelGGL(k_sp_permute_in, dim3(gx, ny), dim3(256), 0, s->stream, s->d_rhs, s->d_perm, s->n, s->d_x);
+    if (s->mf) {
+        const size_t need_u = (size_t)std::max<long long>(s->usum, 1) * (size_t)nrhs;
+        if (need_u > s->cap_uvec) {
+            if (s->md.uvec) (void)hipFree(s->md.uvec);
+            s->md.uvec = nullptr; s->cap_uvec = 0;
+            PK(hipMalloc((void**)&s->md.uvec, sizeof(double) * need_u));
+            s->cap_uvec = need_u;
+        }
+        for (const MfSeg& g : s->mplan)
+            hipLaunchKernelGGL(k_mf_forward, dim3((unsigned)g.count, ny), dim3(MF_THREADS), g.lds_solve, s->stream, s->md, g.first, s->n, s->usum, s->d_x);
+        for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g)
+            hipLaunchKernelGGL(k_mf_backward, dim3((unsigned)g->count, ny), dim3(MF_THREADS), g->lds_solve, s->stream, s->md, g->first, s->n, s->d_x);
+    } else {
     for (const Segment& g : s->plan)
         hipLaunchKernelGGL(k_sp_forward, dim3(g.chain ? 1 : (unsigned)std::min(g.count, 4096), ny), dim3(64), 0, s->stream, s->d, g.first, g.count, s->d_x);
     for (auto g = s->plan.rbegin(); g != s->plan.rend(); ++g)
         hipLaunchKernelGGL(k_sp_backward, dim3(g->chain ? 1 : (unsigned)std::min(g->count, 4096), ny), dim3(64), 0, s->stream, s->d, g->first, g->count, s->d_x);
+    }
     hipLaunchKernelGGL(k_sp_permute_out, dim3(gx, ny), dim3(256), 0, s->stream, s->d_x, s->d_perm, s->n, s->d_rhs);
     PK(hipEventRecord(s->e1, s->stream));
     PK(hipMemcpyAsync(x, s->d_rhs, sizeof(double) * need, hipMemcpyDeviceToHost, s->stream));
@@ -444,6 +713,23 @@ int32_t calipso_hip_sparse_get_factor(calipso_hip_sparse* s, int64_t* perm, int6
     if (perm) std::copy(s->perm.begin(), s->perm.end(), perm);
     if (Lp) for (size_t k = 0; k < s->hLp.size(); ++k) Lp[k] = (i64)s->hLp[k] + 1;
     if (Li) for (size_t k = 0; k < s->hLi.size(); ++k) Li[k] = (i64)s->hLi[k] + 1;
+    if (Lx && s->nnzL && s->mf) {
+        // multifrontal storage: dense m x c panels per node; pick the entries of the exact pattern out of them
+        std::vector<double> panel((size_t)s->panel_total);
+        PK(hipMemcpyAsync(panel.data(), s->md.panel, sizeof(double) * panel.size(), hipMemcpyDeviceToHost, s->stream));
+        PK(hipStreamSynchronize(s->stream));
+        for (int t = 0; t < s->nnodes; ++t) {
+            const int f = s->h_nfirst[(size_t)t], c = s->h_ncols[(size_t)t], m = c + s->h_nrows[(size_t)t];
+            const int* Rb = s->h_rows.data() + s->h_rowptr[(size_t)t]; const int* Re = Rb + s->h_nrows[(size_t)t];
+            const double* Pn = panel.data() + s->h_panel_off[(size_t)t];
+            for (int j = f; j < f + c; ++j)
+                for (int q = s->hLp[(size_t)j]; q < s->hLp[(size_t)j + 1]; ++q) {
+                    const int i = s->hLi[(size_t)q];
+                    const int lr = i < f + c ? i - f : c + (int)(std::lower_bound(Rb, Re, i) - Rb);
+                    Lx[q] = Pn[(size_t)lr + (size_t)(j - f) * m];
+                }
+        }
+    } else
     if (Lx && s->nnzL) PK(hipMemcpyAsync(Lx, s->d.Lx, sizeof(double) * (size_t)s->nnzL, hipMemcpyDeviceToHost, s->stream));
     if (D) PK(hipMemcpyAsync(D, s->d.D, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost, s->stream));
     PK(hipStreamSynchronize(s->stream));

@@ -56,7 +56,7 @@ def cases():
 
 
 @pytest.mark.parametrize("name", ["quasidefinite_15", "pendulum", "conic_qp", "quasidefinite_60", "staged_12x(4+2)"])
-@pytest.mark.parametrize("method", ["natural", "rcm", "minimum_degree", "nested_dissection", "random"])
+@pytest.mark.parametrize("method", ["natural", "rcm", "minimum_degree", "nested_dissection", "nested_dissection_columns", "random"])
 def test_factor_and_solve_match_the_oracle(oracle_mod, name, method):
     pkg = load_pkg()
     K = cases()[name]
@@ -130,21 +130,27 @@ def test_nested_dissection_eliminates_the_stages_in_parallel(oracle_mod):
     n = K.shape[0]
     A = sp.triu(K).tocsc()
     nat = pkg.SparseLDL(A, method="natural")
-    nd = pkg.SparseLDL(A, method="nested_dissection")
+    nd = pkg.SparseLDL(A, method="nested_dissection_columns")
+    mf = pkg.SparseLDL(A, method="nested_dissection")
     assert nat.info["levels"] > 0.3 * n                       # a chain through the horizon
     assert nd.info["levels"] < 0.2 * nat.info["levels"]       # parallel sub-trees
     assert nd.info["widest_level"] >= T // 2
-    assert nd.factorize(A) == 0 and nat.factorize(A) == 0
-    assert nd.inertia == nat.inertia == (T * (ns + nu) + ns, T * ns, 0)
+    assert mf.info["numeric"] == "multifrontal" and mf.info["levels"] <= 12 and mf.info["launches"] == mf.info["levels"]   # ~log2 T levels of fronts
     b = rng.standard_normal(n)
-    x_nd, x_nat = nd.solve(b), nat.solve(b)
     xd = np.linalg.solve(K.toarray(), b)
-    assert np.abs(x_nd - xd).max() <= 1e-9 * np.abs(xd).max() and np.abs(x_nat - xd).max() <= 1e-9 * np.abs(xd).max()
-    perm, Lm, D = nd.factor()
-    ref = oracle_factor(oracle_mod, K.toarray(), perm)
-    assert np.abs(D - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
+    for S in (nat, nd, mf):
+        assert S.factorize(A) == 0
+        assert S.inertia == (T * (ns + nu) + ns, T * ns, 0)
+        x = S.solve(b)
+        assert np.abs(x - xd).max() <= 1e-9 * np.abs(xd).max()
+    for S in (nd, mf):
+        perm, Lm, D = S.factor()
+        ref = oracle_factor(oracle_mod, K.toarray(), perm)
+        assert np.abs(D - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
+        assert abs(Lm - ref["L"]).max() <= 1e-11 * max(1.0, abs(ref["L"]).max())
+    perm, _, _ = nd.factor()
     assert tree_height(pkg.symbolic(A, perm)["etree"]) == nd.info["levels"]
-    nat.close(); nd.close()
+    nat.close(); nd.close(); mf.close()
 
 
 def test_rate_report_on_trajectory_kkt_systems(oracle_mod):
@@ -161,7 +167,7 @@ def test_rate_report_on_trajectory_kkt_systems(oracle_mod):
         A = sp.triu(K).tocsc()
         b = rng.standard_normal(n)
         row = dict(T=T, state=ns, control=nu, n=n, nnz_upper=int(A.nnz))
-        for method in ("natural", "nested_dissection"):
+        for method in ("natural", "nested_dissection_columns", "nested_dissection"):
             S = pkg.SparseLDL(A, method=method)
             S.factorize(A); S.solve(b)                       # warm-up (graph capture, allocations)
             f, s = [], []
@@ -175,7 +181,8 @@ def test_rate_report_on_trajectory_kkt_systems(oracle_mod):
             assert np.abs(D - ref["D"]).max() <= 1e-10 * np.abs(ref["D"]).max()
             row[method] = dict(S.info, factor_ms=min(f), solve_ms=min(s), oracle_qdldl_analyse_plus_factor_ms_1core=1e3 * t_cpu)
             S.close()
-        assert row["nested_dissection"]["factor_ms"] < row["natural"]["factor_ms"]
+        assert row["nested_dissection_columns"]["factor_ms"] < row["natural"]["factor_ms"]
+        assert row["nested_dissection"]["numeric"] == "multifrontal" and row["nested_dissection"]["factor_ms"] < row["nested_dissection_columns"]["factor_ms"]
         rows.append(row)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/sparse_ldl_rate.json", "w") as fh:
@@ -192,8 +199,8 @@ def test_global_accumulator_path_beyond_the_lds_limit(oracle_mod):
     n = K.shape[0]
     assert n > 19400
     A = sp.triu(K).tocsc()
-    S = pkg.SparseLDL(A, method="nested_dissection")
-    assert not S.info["lds_accumulator"] and S.info["levels"] < 200
+    S = pkg.SparseLDL(A, method="nested_dissection_columns")
+    assert S.info["numeric"] == "columns_global_accumulator" and S.info["levels"] < 200
     assert S.factorize(A) == 0
     assert S.inertia == (700 * 16 + 12, 700 * 12, 0)
     perm, Lm, D = S.factor()
