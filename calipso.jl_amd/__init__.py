@@ -606,30 +606,52 @@ class SparseLDL:
             raise CalipsoHipError("%s failed (%d): %s" % (what, rc, self._L.calipso_hip_sparse_last_error(self._h).decode()))
         return rc
 
+    def set_batch(self, batch):
+        """treat `batch` matrices of the analysed pattern per factorize / solve call (values (batch, nnz), right-hand sides (batch, n[, nrhs]))"""
+        self._check(self._L.calipso_hip_sparse_set_batch(self._h, int(batch)), "sparse_set_batch")
+        self.batch = int(batch)
+
     def factorize(self, A):
-        """numeric factorisation of A (same pattern as analysed; a scipy.sparse matrix or the nnz values in CSC order); returns the warning
-        status (1 = exact zero pivot met, inertia[0] = -1)"""
-        if hasattr(A, "shape") and len(getattr(A, "shape")) == 2:
+        """numeric factorisation of A (same pattern as analysed; a scipy.sparse matrix, or the nnz values in CSC order — (batch, nnz) after
+        set_batch); returns the warning status (1 = an exact zero pivot was met, inertia[0] = -1 for that matrix)"""
+        B = getattr(self, "batch", 1)
+        if hasattr(A, "shape") and len(getattr(A, "shape")) == 2 and not isinstance(A, np.ndarray):
             A, _, _, vals = _csc_1based(A)
             if A.nnz != self.nnz:
                 raise CalipsoHipError("SparseLDL.factorize: the pattern differs from the analysed one")
         else:
-            vals = np.ascontiguousarray(A, dtype=np.float64)
-        inr = np.zeros(3, dtype=np.int64)
+            vals = np.ascontiguousarray(A, dtype=np.float64).reshape(-1)
+        if vals.size != B * self.nnz:
+            raise CalipsoHipError("SparseLDL.factorize: expected %d x %d values" % (B, self.nnz))
+        inr = np.zeros(3 * B, dtype=np.int64)
         rc = self._check(self._L.calipso_hip_sparse_factorize(self._h, _pd(vals), _pi(inr)), "sparse_factorize")
-        self.inertia = tuple(int(v) for v in inr)
+        self.inertia = tuple(int(v) for v in inr[:3])
+        self.inertia_all = inr.reshape(B, 3)
         return rc
 
     def solve(self, b):
-        """x = A^-1 b for a vector or an (n, nrhs) matrix"""
+        """x = A^-1 b for a vector or an (n, nrhs) matrix; after set_batch: b of shape (batch, n) or (batch, n, nrhs)"""
         b = np.asarray(b, dtype=np.float64)
+        B = getattr(self, "batch", 1)
+        if B > 1:
+            b3 = b.reshape(B, self.n, -1)
+            nrhs = b3.shape[2]
+            flat = np.ascontiguousarray(np.transpose(b3, (0, 2, 1))).reshape(-1)     # per matrix column-major n x nrhs
+            X = np.zeros_like(flat)
+            self._check(self._L.calipso_hip_sparse_solve(self._h, nrhs, _pd(flat), _pd(X)), "sparse_solve")
+            X = np.transpose(X.reshape(B, nrhs, self.n), (0, 2, 1))
+            return X[:, :, 0].copy() if b.ndim == 2 else X.copy()
         one = b.ndim == 1
-        B = np.ascontiguousarray(b.reshape(self.n, -1).T).reshape(-1)          # column-major n x nrhs
-        nrhs = B.size // self.n
-        X = np.zeros_like(B)
-        self._check(self._L.calipso_hip_sparse_solve(self._h, nrhs, _pd(B), _pd(X)), "sparse_solve")
+        Bm = np.ascontiguousarray(b.reshape(self.n, -1).T).reshape(-1)          # column-major n x nrhs
+        nrhs = Bm.size // self.n
+        X = np.zeros_like(Bm)
+        self._check(self._L.calipso_hip_sparse_solve(self._h, nrhs, _pd(Bm), _pd(X)), "sparse_solve")
         X = X.reshape(nrhs, self.n).T
         return X[:, 0].copy() if one else X.copy()
+
+    def select(self, instance):
+        """which matrix of the batch factor() reads"""
+        self._check(self._L.calipso_hip_sparse_select(self._h, int(instance)), "sparse_select")
 
     def factor(self):
         """(perm (1-based), L as a scipy.sparse CSC unit-lower matrix, D)"""

@@ -79,6 +79,8 @@ SYMBOLS = {
     "calipso_hip_sparse_destroy": (_i32, [_vp]),
     "calipso_hip_sparse_last_error": (C.c_char_p, [_vp]),
     "calipso_hip_sparse_info": (_i32, [_vp, _pi64]),
+    "calipso_hip_sparse_set_batch": (_i32, [_vp, _i64]),
+    "calipso_hip_sparse_select": (_i32, [_vp, _i64]),
     "calipso_hip_sparse_factorize": (_i32, [_vp, _pd, _pi64]),
     "calipso_hip_sparse_solve": (_i32, [_vp, _i64, _pd, _pd]),
     "calipso_hip_sparse_get_factor": (_i32, [_vp, _pi64, _pi64, _pi64, _pd, _pd]),

@@ -163,6 +163,7 @@ struct MfDev {
     const int *Alp, *Asrc;
     const double* Aval;
     double *panel, *upd, *D, *uvec;
+    long long sA, sPanel, sUpd, sD;           // instance strides (batched factorisation of matrices with one pattern)
 };
 
 constexpr int MF_THREADS = 256;
@@ -174,6 +175,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(MfDev d, int first) {
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r, ld = m + 1;
     double* ycol = F + (size_t)m * ld;
     const int tid = threadIdx.x;
+    const size_t z = blockIdx.y;                                               // instance of the batch
+    d.Aval += z * d.sA; d.upd += z * d.sUpd; d.panel += z * d.sPanel; d.D += z * d.sD;
     for (int e = tid; e < m * ld; e += MF_THREADS) F[e] = 0.0;
     __syncthreads();
     for (int p = d.Alp[f] + tid; p < d.Alp[f + c]; p += MF_THREADS) F[d.Aloc[p]] = d.Aval[d.Asrc[p]];
@@ -216,13 +219,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(MfDev d, int first) {
 }
 
 // forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors
-__global__ __launch_bounds__(MF_THREADS) void k_mf_forward(MfDev d, int first, int n, long long usum, double* __restrict__ X) {
+__global__ __launch_bounds__(MF_THREADS) void k_mf_forward(MfDev d, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
     double* Ps = sm; double* v = sm + (size_t)m * c;
-    double* x = X + (size_t)blockIdx.y * n;
+    double* x = X + (size_t)blockIdx.y * n;                                    // blockIdx.y = instance * nrhs + right-hand side
     double* ubase = d.uvec + (size_t)blockIdx.y * usum;
+    d.panel += (size_t)(blockIdx.y / nrhs) * d.sPanel;
     const int tid = threadIdx.x;
     const double* P = d.panel + d.panel_off[s];
     for (int e = tid; e < m * c; e += MF_THREADS) Ps[e] = P[e];
@@ -246,12 +250,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(MfDev d, int first, i
     for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a];
 }
 // backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C
-__global__ __launch_bounds__(MF_THREADS) void k_mf_backward(MfDev d, int first, int n, double* __restrict__ X) {
+__global__ __launch_bounds__(MF_THREADS) void k_mf_backward(MfDev d, int first, int n, int nrhs, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
     double* Ps = sm; double* v = sm + (size_t)m * c;
     double* x = X + (size_t)blockIdx.y * n;
+    d.panel += (size_t)(blockIdx.y / nrhs) * d.sPanel; d.D += (size_t)(blockIdx.y / nrhs) * d.sD;
     const int tid = threadIdx.x;
     const double* P = d.panel + d.panel_off[s];
     const int* R = d.rows + d.rowptr[s];
@@ -293,6 +298,9 @@ struct calipso_hip_sparse {
     long long panel_total = 0, usum = 0;
     size_t cap_uvec = 0;
     int max_front = 0, nnodes = 0;
+    int batch = 1, selected = 0;                 // matrices of this pattern factored together / the one get_factor reads
+    long long upd_total = 0;
+    std::vector<i64> inertia_all;                // batch x 3
     std::vector<void*> dev;                      // every device allocation
     SpDev d{};
     int* d_perm = nullptr;
@@ -313,6 +321,26 @@ static thread_local std::string g_sparse_err;
 
 namespace {
 
+// (re)allocate everything that holds VALUES, for `batch` matrices of the analysed pattern: instance-major
+int alloc_values(calipso_hip_sparse* s, int batch) {
+    const size_t B = (size_t)batch;
+    for (double** pp : {&s->d_Aval, &s->d.Lx, &s->d.D, &s->md.panel, &s->md.upd}) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+    PK(hipMalloc((void**)&s->d_Aval, sizeof(double) * B * std::max<size_t>((size_t)s->nnzA, 1)));
+    PK(hipMalloc((void**)&s->d.D, sizeof(double) * B * (size_t)s->n));
+    if (s->mf) {
+        PK(hipMalloc((void**)&s->md.panel, sizeof(double) * B * std::max<size_t>((size_t)s->panel_total, 1)));
+        PK(hipMalloc((void**)&s->md.upd, sizeof(double) * B * std::max<size_t>((size_t)s->upd_total, 1)));
+    } else {
+        PK(hipMalloc((void**)&s->d.Lx, sizeof(double) * B * std::max<size_t>((size_t)s->nnzL, 1)));
+    }
+    s->d.Aval = s->d_Aval;
+    s->md.Aval = s->d_Aval; s->md.D = s->d.D;
+    s->md.sA = s->nnzA; s->md.sPanel = s->panel_total; s->md.sUpd = s->upd_total; s->md.sD = s->n;
+    s->batch = batch; s->selected = 0; s->factored = false;
+    s->inertia_all.assign(3 * B, 0);
+    return CALIPSO_OK;
+}
+
 template <typename T>
 int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
     T* p = nullptr;
@@ -325,14 +353,19 @@ int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
 
 void enqueue_factor(calipso_hip_sparse* s) {
     if (s->mf) {
-        for (const MfSeg& g : s->mplan) hipLaunchKernelGGL(k_mf_factor, dim3((unsigned)g.count), dim3(MF_THREADS), g.lds_factor, s->stream, s->md, g.first);
+        for (const MfSeg& g : s->mplan)
+            hipLaunchKernelGGL(k_mf_factor, dim3((unsigned)g.count, (unsigned)s->batch), dim3(MF_THREADS), g.lds_factor, s->stream, s->md, g.first);
         return;
     }
     const size_t lds = s->lds_acc ? sizeof(double) * (size_t)s->n : 0;
-    for (const Segment& g : s->plan) {
-        const int grid = g.chain ? 1 : std::min(g.count, s->work_slots);
-        if (s->lds_acc) hipLaunchKernelGGL(k_sp_factor<true>, dim3(grid), dim3(SP_THREADS), lds, s->stream, s->d, g.first, g.count);
-        else hipLaunchKernelGGL(k_sp_factor<false>, dim3(grid), dim3(SP_THREADS), 0, s->stream, s->d, g.first, g.count);
+    for (int z = 0; z < s->batch; ++z) {                    // the column method takes the matrices of a batch one after the other
+        SpDev d = s->d;
+        d.Aval += (size_t)z * (size_t)s->nnzA; d.Lx += (size_t)z * (size_t)s->nnzL; d.D += (size_t)z * (size_t)s->n;
+        for (const Segment& g : s->plan) {
+            const int grid = g.chain ? 1 : std::min(g.count, s->work_slots);
+            if (s->lds_acc) hipLaunchKernelGGL(k_sp_factor<true>, dim3(grid), dim3(SP_THREADS), lds, s->stream, d, g.first, g.count);
+            else hipLaunchKernelGGL(k_sp_factor<false>, dim3(grid), dim3(SP_THREADS), 0, s->stream, d, g.first, g.count);
+        }
     }
 }
 
@@ -348,6 +381,7 @@ int32_t calipso_hip_sparse_destroy(calipso_hip_sparse* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->graph_factor) (void)hipGraphExecDestroy(s->graph_factor);
     for (void* p : s->dev) if (p) (void)hipFree(p);
+    for (double* p : {s->d_Aval, s->d.Lx, s->d.D, s->md.panel, s->md.upd}) if (p) (void)hipFree(p);
     if (s->d_rhs) (void)hipFree(s->d_rhs);
     if (s->d_x) (void)hipFree(s->d_x);
     if (s->md.uvec) (void)hipFree(s->md.uvec);
@@ -581,12 +615,11 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
         (rc = upload(s, Lp, &s->d.Lp)) || (rc = upload(s, Li, &s->d.Li)) || (rc = upload(s, Rp, &s->d.Rp)) || (rc = upload(s, Rk, &s->d.Rk)) ||
         (rc = upload(s, Rpos, &s->d.Rpos)) || (rc = upload(s, Rend, &s->d.Rend)) || (rc = upload(s, hperm, &cperm))) return rc;
     s->d_perm = const_cast<int*>(cperm);
-    PK(hipMalloc((void**)&s->d.Lx, sizeof(double) * std::max<size_t>((size_t)nnzL, 1))); s->dev.push_back(s->d.Lx);
-    PK(hipMalloc((void**)&s->d.D, sizeof(double) * (size_t)n)); s->dev.push_back(s->d.D);
-    PK(hipMalloc((void**)&s->d_Aval, sizeof(double) * std::max<size_t>((size_t)nnzA, 1))); s->dev.push_back(s->d_Aval);
-    s->d.Aval = s->d_Aval;
+    s->upd_total = use_mf ? upd_total : 0; s->panel_total = use_mf ? panel_total : 0;
+    s->mf = use_mf;
+    if ((rc = alloc_values(s, 1))) return rc;
     if (use_mf) {
-        s->mf = true; s->mplan = mplan; s->nnodes = NN; s->max_front = max_front; s->panel_total = panel_total; s->usum = usum;
+        s->mplan = mplan; s->nnodes = NN; s->max_front = max_front; s->panel_total = panel_total; s->usum = usum;
         s->h_nfirst = m_first; s->h_ncols = m_cols; s->h_nrows = m_rows; s->h_rowptr = m_rowptr; s->h_rows = m_rowsv; s->h_panel_off = m_panel_off;
         s->levels = mf_levels; s->widest = mf_widest;
         MfDev& md = s->md;
@@ -595,9 +628,7 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
             (rc = upload(s, m_rowptr, &md.rowptr)) || (rc = upload(s, m_rowsv, &md.rows)) || (rc = upload(s, m_rel, &md.rel)) || (rc = upload(s, m_childptr, &md.childptr)) ||
             (rc = upload(s, m_children, &md.children)) || (rc = upload(s, m_panel_off, &md.panel_off)) || (rc = upload(s, m_upd_off, &md.upd_off)) ||
             (rc = upload(s, m_u_off, &md.u_off)) || (rc = upload(s, m_Aloc, &md.Aloc))) return rc;
-        md.Alp = s->d.Alp; md.Asrc = s->d.Asrc; md.Aval = s->d_Aval; md.D = s->d.D;
-        PK(hipMalloc((void**)&md.panel, sizeof(double) * std::max<size_t>((size_t)panel_total, 1))); s->dev.push_back(md.panel);
-        PK(hipMalloc((void**)&md.upd, sizeof(double) * std::max<size_t>((size_t)upd_total, 1))); s->dev.push_back(md.upd);
+        md.Alp = s->d.Alp; md.Asrc = s->d.Asrc;
         PK(hipFuncSetAttribute((const void*)k_mf_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PK(hipFuncSetAttribute((const void*)k_mf_forward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PK(hipFuncSetAttribute((const void*)k_mf_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -620,12 +651,32 @@ int32_t calipso_hip_sparse_info(calipso_hip_sparse* s, int64_t info[8]) {
     return CALIPSO_OK;
 }
 
+// Number of matrices (same pattern, different values) the following calls treat together: nzval = batch x nnz, inertia = batch x 3,
+// b / x = batch x (n x nrhs).  The multifrontal path factors the whole batch in the same launches (one workgroup per front and matrix);
+// the column method takes them one after the other.  Invalidates the current factorisation.
+int32_t calipso_hip_sparse_set_batch(calipso_hip_sparse* s, int64_t batch) {
+    if (!s || batch < 1 || batch > 65535) return CALIPSO_ERR_ARGUMENT;
+    PK(hipSetDevice(s->device));
+    PK(hipStreamSynchronize(s->stream));
+    if (s->graph_factor) { (void)hipGraphExecDestroy(s->graph_factor); s->graph_factor = nullptr; }
+    s->graph_tried = false;
+    return alloc_values(s, (int)batch);
+}
+// which matrix of the batch calipso_hip_sparse_get_factor reads (default 0)
+int32_t calipso_hip_sparse_select(calipso_hip_sparse* s, int64_t instance) {
+    if (!s || instance < 0 || instance >= s->batch) return CALIPSO_ERR_ARGUMENT;
+    s->selected = (int)instance;
+    return CALIPSO_OK;
+}
+
 // QDLDL_factor! + compute_inertia! (qdldl.jl:400-589, linear_solver.jl:19-44) for new values on the analysed pattern.
-// nzval: the nnz(A) values in the caller's CSC order (host).  Returns CALIPSO_WARN_ZERO_PIVOT with inertia[0] = -1 on an exact zero pivot.
-int32_t calipso_hip_sparse_factorize(calipso_hip_sparse* s, const double* nzval, int64_t inertia[3]) {
+// nzval: batch x nnz(A) values in the caller's CSC order (host).  inertia: batch x 3 (may be NULL).  Returns CALIPSO_WARN_ZERO_PIVOT if any
+// matrix met an exact zero pivot (its inertia[0] = -1).
+int32_t calipso_hip_sparse_factorize(calipso_hip_sparse* s, const double* nzval, int64_t* inertia) {
     if (!s || (!nzval && s->nnzA > 0)) return CALIPSO_ERR_ARGUMENT;
     PK(hipSetDevice(s->device));
-    if (s->nnzA) PK(hipMemcpyAsync(s->d_Aval, nzval, sizeof(double) * (size_t)s->nnzA, hipMemcpyHostToDevice, s->stream));
+    const size_t B = (size_t)s->batch;
+    if (s->nnzA) PK(hipMemcpyAsync(s->d_Aval, nzval, sizeof(double) * B * (size_t)s->nnzA, hipMemcpyHostToDevice, s->stream));
     PK(hipEventRecord(s->e0, s->stream));
     if (!s->graph_tried) {          // the level schedule is a fixed launch sequence with fixed arguments: captured once, replayed afterwards
         s->graph_tried = true;
@@ -642,30 +693,34 @@ int32_t calipso_hip_sparse_factorize(calipso_hip_sparse* s, const double* nzval,
     if (s->graph_factor) PK(hipGraphLaunch(s->graph_factor, s->stream));
     else enqueue_factor(s);
     PK(hipEventRecord(s->e1, s->stream));
-    std::vector<double> D((size_t)s->n);
-    PK(hipMemcpyAsync(D.data(), s->d.D, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost, s->stream));
+    std::vector<double> D(B * (size_t)s->n);
+    PK(hipMemcpyAsync(D.data(), s->d.D, sizeof(double) * D.size(), hipMemcpyDeviceToHost, s->stream));
     PK(hipStreamSynchronize(s->stream));
     PK(hipGetLastError());
     float ms = 0.f; PK(hipEventElapsedTime(&ms, s->e0, s->e1)); s->ms_factor = ms;
     // compute_inertia! as the reference sees it: the up-looking factorisation stops at the first exact zero pivot in elimination order and the
     // rest of D stays at the zeros it was reset to (qdldl.jl:444,456,579)
     int rc = CALIPSO_OK;
-    i64 pos = 0, nonpos = 0, zero = 0; int k = 0;
-    for (; k < s->n; ++k) { const double dk = D[(size_t)k]; if (dk == 0.0) break; pos += dk > 0.0; nonpos += dk <= 0.0; }
-    if (k < s->n) { zero = s->n - k; nonpos += s->n - k; pos = -1; rc = CALIPSO_WARN_ZERO_PIVOT; }
-    s->inertia[0] = pos; s->inertia[1] = nonpos; s->inertia[2] = zero;
+    for (size_t z = 0; z < B; ++z) {
+        const double* Dz = D.data() + z * (size_t)s->n;
+        i64 pos = 0, nonpos = 0, zero = 0; int k = 0;
+        for (; k < s->n; ++k) { const double dk = Dz[k]; if (dk == 0.0) break; pos += dk > 0.0; nonpos += dk <= 0.0; }
+        if (k < s->n) { zero = s->n - k; nonpos += s->n - k; pos = -1; rc = CALIPSO_WARN_ZERO_PIVOT; }
+        s->inertia_all[3 * z] = pos; s->inertia_all[3 * z + 1] = nonpos; s->inertia_all[3 * z + 2] = zero;
+    }
     s->factored = true;
-    if (inertia) { inertia[0] = pos; inertia[1] = nonpos; inertia[2] = zero; }
+    if (inertia) std::copy(s->inertia_all.begin(), s->inertia_all.end(), inertia);
     return rc;
 }
 
-// solve!(F, b) (qdldl.jl:330-351) for nrhs right-hand sides: b, x column-major n x nrhs host arrays (may alias)
+// solve!(F, b) (qdldl.jl:330-351) for nrhs right-hand sides per matrix: b, x = batch x (column-major n x nrhs) host arrays (may alias)
 int32_t calipso_hip_sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const double* b, double* x) {
-    if (!s || nrhs < 0 || (nrhs > 0 && (!b || !x)) || nrhs > 65535) return CALIPSO_ERR_ARGUMENT;
+    if (!s || nrhs < 0 || (nrhs > 0 && (!b || !x)) || nrhs * (int64_t)(s ? s->batch : 1) > 65535) return CALIPSO_ERR_ARGUMENT;
     if (!s->factored) { s->err = "calipso_hip_sparse_solve: factorize first"; return CALIPSO_ERR_ARGUMENT; }
     if (nrhs == 0) return CALIPSO_OK;
     PK(hipSetDevice(s->device));
-    const size_t need = (size_t)s->n * (size_t)nrhs;
+    const size_t cols = (size_t)nrhs * (size_t)s->batch;
+    const size_t need = (size_t)s->n * cols;
     if (need > s->cap_rhs) {
         if (s->d_rhs) (void)hipFree(s->d_rhs);
         if (s->d_x) (void)hipFree(s->d_x);
@@ -675,10 +730,10 @@ int32_t calipso_hip_sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const doub
     }
     PK(hipMemcpyAsync(s->d_rhs, b, sizeof(double) * need, hipMemcpyHostToDevice, s->stream));
     PK(hipEventRecord(s->e0, s->stream));
-    const unsigned gx = (unsigned)((s->n + 255) / 256), ny = (unsigned)nrhs;
+    const unsigned gx = (unsigned)((s->n + 255) / 256), ny = (unsigned)cols;
     hipLaunchKernelGGL(k_sp_permute_in, dim3(gx, ny), dim3(256), 0, s->stream, s->d_rhs, s->d_perm, s->n, s->d_x);
     if (s->mf) {
-        const size_t need_u = (size_t)std::max<long long>(s->usum, 1) * (size_t)nrhs;
+        const size_t need_u = (size_t)std::max<long long>(s->usum, 1) * cols;
         if (need_u > s->cap_uvec) {
             if (s->md.uvec) (void)hipFree(s->md.uvec);
             s->md.uvec = nullptr; s->cap_uvec = 0;
@@ -686,14 +741,19 @@ int32_t calipso_hip_sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const doub
             s->cap_uvec = need_u;
         }
         for (const MfSeg& g : s->mplan)
-            hipLaunchKernelGGL(k_mf_forward, dim3((unsigned)g.count, ny), dim3(MF_THREADS), g.lds_solve, s->stream, s->md, g.first, s->n, s->usum, s->d_x);
+            hipLaunchKernelGGL(k_mf_forward, dim3((unsigned)g.count, ny), dim3(MF_THREADS), g.lds_solve, s->stream, s->md, g.first, s->n, (int)nrhs, s->usum, s->d_x);
         for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g)
-            hipLaunchKernelGGL(k_mf_backward, dim3((unsigned)g->count, ny), dim3(MF_THREADS), g->lds_solve, s->stream, s->md, g->first, s->n, s->d_x);
+            hipLaunchKernelGGL(k_mf_backward, dim3((unsigned)g->count, ny), dim3(MF_THREADS), g->lds_solve, s->stream, s->md, g->first, s->n, (int)nrhs, s->d_x);
     } else {
-    for (const Segment& g : s->plan)
-        hipLaunchKernelGGL(k_sp_forward, dim3(g.chain ? 1 : (unsigned)std::min(g.count, 4096), ny), dim3(64), 0, s->stream, s->d, g.first, g.count, s->d_x);
-    for (auto g = s->plan.rbegin(); g != s->plan.rend(); ++g)
-        hipLaunchKernelGGL(k_sp_backward, dim3(g->chain ? 1 : (unsigned)std::min(g->count, 4096), ny), dim3(64), 0, s->stream, s->d, g->first, g->count, s->d_x);
+        for (int z = 0; z < s->batch; ++z) {
+            SpDev d = s->d;
+            d.Lx += (size_t)z * (size_t)s->nnzL; d.D += (size_t)z * (size_t)s->n;
+            double* xz = s->d_x + (size_t)z * (size_t)nrhs * (size_t)s->n;
+            for (const Segment& g : s->plan)
+                hipLaunchKernelGGL(k_sp_forward, dim3(g.chain ? 1 : (unsigned)std::min(g.count, 4096), (unsigned)nrhs), dim3(64), 0, s->stream, d, g.first, g.count, xz);
+            for (auto g = s->plan.rbegin(); g != s->plan.rend(); ++g)
+                hipLaunchKernelGGL(k_sp_backward, dim3(g->chain ? 1 : (unsigned)std::min(g->count, 4096), (unsigned)nrhs), dim3(64), 0, s->stream, d, g->first, g->count, xz);
+        }
     }
     hipLaunchKernelGGL(k_sp_permute_out, dim3(gx, ny), dim3(256), 0, s->stream, s->d_x, s->d_perm, s->n, s->d_rhs);
     PK(hipEventRecord(s->e1, s->stream));
@@ -716,7 +776,7 @@ int32_t calipso_hip_sparse_get_factor(calipso_hip_sparse* s, int64_t* perm, int6
     if (Lx && s->nnzL && s->mf) {
         // multifrontal storage: dense m x c panels per node; pick the entries of the exact pattern out of them
         std::vector<double> panel((size_t)s->panel_total);
-        PK(hipMemcpyAsync(panel.data(), s->md.panel, sizeof(double) * panel.size(), hipMemcpyDeviceToHost, s->stream));
+        PK(hipMemcpyAsync(panel.data(), s->md.panel + (size_t)s->selected * (size_t)s->panel_total, sizeof(double) * panel.size(), hipMemcpyDeviceToHost, s->stream));
         PK(hipStreamSynchronize(s->stream));
         for (int t = 0; t < s->nnodes; ++t) {
             const int f = s->h_nfirst[(size_t)t], c = s->h_ncols[(size_t)t], m = c + s->h_nrows[(size_t)t];
@@ -730,8 +790,8 @@ int32_t calipso_hip_sparse_get_factor(calipso_hip_sparse* s, int64_t* perm, int6
                 }
         }
     } else
-    if (Lx && s->nnzL) PK(hipMemcpyAsync(Lx, s->d.Lx, sizeof(double) * (size_t)s->nnzL, hipMemcpyDeviceToHost, s->stream));
-    if (D) PK(hipMemcpyAsync(D, s->d.D, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost, s->stream));
+    if (Lx && s->nnzL) PK(hipMemcpyAsync(Lx, s->d.Lx + (size_t)s->selected * (size_t)s->nnzL, sizeof(double) * (size_t)s->nnzL, hipMemcpyDeviceToHost, s->stream));
+    if (D) PK(hipMemcpyAsync(D, s->d.D + (size_t)s->selected * (size_t)s->n, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost, s->stream));
     PK(hipStreamSynchronize(s->stream));
     return CALIPSO_OK;
 }

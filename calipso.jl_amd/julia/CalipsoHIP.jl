@@ -284,7 +284,7 @@ mutable struct HIPSparseLDLSolver <: CALIPSO.LinearSolver
     nnz::Int
     inertia::CALIPSO.Inertia
 end
-const SPARSE_METHODS = Dict(:natural => 0, :rcm => 1, :minimum_degree => 2, :nested_dissection => 4)
+const SPARSE_METHODS = Dict(:natural => 0, :rcm => 1, :minimum_degree => 2, :nested_dissection => 4, :nested_dissection_columns => 5)
 sparse_last_error(h) = unsafe_string(ccall((:calipso_hip_sparse_last_error, lib), Cstring, (Ptr{Cvoid},), h))
 
 function HIPSparseLDLSolver(A::SparseMatrixCSC{Float64,Int}; method::Symbol=:nested_dissection, perm::Union{Nothing,Vector{Int}}=nothing, device::Integer=0)

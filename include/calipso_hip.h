@@ -315,15 +315,24 @@ int32_t calipso_hip_ldl_solve(calipso_hip_solver*, int64_t n, int64_t nrhs, cons
  *   calipso_hip_sparse_factorize   = QDLDL_factor! + compute_inertia!         qdldl.jl:400-589, linear_solver.jl:19-44  (nzval in the pattern's order, host)
  *   calipso_hip_sparse_solve       = solve!(F, b) for nrhs columns            qdldl.jl:330-351
  *   calipso_hip_sparse_get_factor  = F.perm, F.L (strictly lower, 1-based CSC), F.D   qdldl.jl:160-166
- *   calipso_hip_sparse_info        info[8] = n, nnz(triu A), nnz(L), tree levels, launches per factorisation, widest level, multiply-adds, LDS accumulator?
- *   calipso_hip_sparse_timing      ms[2] = device time of the last factorisation / solve (HIP events on the handle's stream) */
+ *   calipso_hip_sparse_info        info[8] = n, nnz(triu A), nnz(L), tree levels, launches per factorisation, widest level, multiply-adds,
+ *                                  numeric phase (0 columns / global accumulator, 1 columns / LDS accumulator, 2 multifrontal)
+ *   calipso_hip_sparse_timing      ms[2] = device time of the last factorisation / solve (HIP events on the handle's stream)
+ *   calipso_hip_sparse_set_batch   `batch` matrices of the analysed pattern per call (BASELINE config C4: many independent problems of one structure):
+ *                                  nzval = batch x nnz, inertia = batch x 3, b / x = batch x (n x nrhs); the multifrontal path factors them in the
+ *                                  same launches.  calipso_hip_sparse_select picks the matrix calipso_hip_sparse_get_factor reads.
+ * Numeric phase: with method 4 (nested dissection) and every front <= 136 rows the factorisation is MULTIFRONTAL over the dissection tree — the
+ * pieces of the dissection are the supernodes, each front is assembled and partially factored in the LDS of one workgroup, one launch per tree level
+ * (~log2 T launches for a T-stage problem); otherwise (and with method 5 = nested-dissection order, column method) the left-looking column method. */
 typedef struct calipso_hip_sparse calipso_hip_sparse;
 int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, const int64_t* perm, int32_t device,
                                   calipso_hip_sparse** out);
 int32_t calipso_hip_sparse_destroy(calipso_hip_sparse*);
 const char* calipso_hip_sparse_last_error(calipso_hip_sparse*);
 int32_t calipso_hip_sparse_info(calipso_hip_sparse*, int64_t info[8]);
-int32_t calipso_hip_sparse_factorize(calipso_hip_sparse*, const double* nzval, int64_t inertia[3]);
+int32_t calipso_hip_sparse_set_batch(calipso_hip_sparse*, int64_t batch);
+int32_t calipso_hip_sparse_select(calipso_hip_sparse*, int64_t instance);
+int32_t calipso_hip_sparse_factorize(calipso_hip_sparse*, const double* nzval, int64_t* inertia);
 int32_t calipso_hip_sparse_solve(calipso_hip_sparse*, int64_t nrhs, const double* b, double* x);
 int32_t calipso_hip_sparse_get_factor(calipso_hip_sparse*, int64_t* perm, int64_t* Lp, int64_t* Li, double* Lx, double* D);
 int32_t calipso_hip_sparse_timing(calipso_hip_sparse*, double ms[2]);

@@ -161,13 +161,13 @@ def test_rate_report_on_trajectory_kkt_systems(oracle_mod):
     pkg = load_pkg()
     rng = np.random.default_rng(2)
     rows = []
-    for T, ns, nu in ((256, 6, 2), (512, 12, 4)):
+    for T, ns, nu in ((256, 6, 2), (512, 12, 4), (2048, 12, 4)):
         K = staged_kkt(T, ns, nu, rng)
         n = K.shape[0]
         A = sp.triu(K).tocsc()
         b = rng.standard_normal(n)
         row = dict(T=T, state=ns, control=nu, n=n, nnz_upper=int(A.nnz))
-        for method in ("natural", "nested_dissection_columns", "nested_dissection"):
+        for method in (("natural", "nested_dissection_columns", "nested_dissection") if T <= 512 else ("nested_dissection_columns", "nested_dissection")):
             S = pkg.SparseLDL(A, method=method)
             S.factorize(A); S.solve(b)                       # warm-up (graph capture, allocations)
             f, s = [], []
@@ -181,9 +181,30 @@ def test_rate_report_on_trajectory_kkt_systems(oracle_mod):
             assert np.abs(D - ref["D"]).max() <= 1e-10 * np.abs(ref["D"]).max()
             row[method] = dict(S.info, factor_ms=min(f), solve_ms=min(s), oracle_qdldl_analyse_plus_factor_ms_1core=1e3 * t_cpu)
             S.close()
-        assert row["nested_dissection_columns"]["factor_ms"] < row["natural"]["factor_ms"]
+        assert T > 512 or row["nested_dissection_columns"]["factor_ms"] < row["natural"]["factor_ms"]
         assert row["nested_dissection"]["numeric"] == "multifrontal" and row["nested_dissection"]["factor_ms"] < row["nested_dissection_columns"]["factor_ms"]
         rows.append(row)
+    # a batch of independent systems of one structure (BASELINE config C4's shape of work), multifrontal: all matrices in the same launches
+    for T, ns, nu, Bn in ((64, 6, 2, 256), (256, 6, 2, 64), (41, 14, 14, 256)):
+        K = staged_kkt(T, ns, nu, rng)
+        n = K.shape[0]
+        A = sp.triu(K).tocsc(); A.sort_indices()
+        S = pkg.SparseLDL(A, method="nested_dissection")
+        vals = A.data[None, :] * (1.0 + 0.05 * rng.random((Bn, A.nnz)))
+        S.set_batch(Bn)
+        bb = rng.standard_normal((Bn, n))
+        S.factorize(vals); S.solve(bb)
+        f, sv = [], []
+        for _ in range(5):
+            assert S.factorize(vals) == 0
+            x = S.solve(bb)
+            tf, ts = S.timing(); f.append(tf); sv.append(ts)
+        z = Bn - 1
+        Kz = sp.csc_matrix((vals[z], A.indices, A.indptr), shape=A.shape); Kz = Kz + sp.triu(Kz, 1).T
+        assert np.abs(Kz @ x[z] - bb[z]).max() <= 1e-8 * max(1.0, np.abs(x[z]).max())
+        rows.append(dict(T=T, state=ns, control=nu, n=n, batch=Bn, numeric=S.info["numeric"], levels=S.info["levels"], factor_ms_whole_batch=min(f),
+                         solve_ms_whole_batch=min(sv), factorisations_per_s=Bn / (1e-3 * min(f)), solves_per_s=Bn / (1e-3 * min(sv))))
+        S.close()
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/sparse_ldl_rate.json", "w") as fh:
         json.dump(rows, fh, indent=1)
@@ -210,4 +231,68 @@ def test_global_accumulator_path_beyond_the_lds_limit(oracle_mod):
     b = rng.standard_normal((n, 2))
     x = S.solve(b)
     assert np.abs(K @ x - b).max() <= 1e-8 * max(1.0, np.abs(x).max())
+    S.close()
+
+
+def test_fronts_that_do_not_fit_fall_back_to_the_column_method(oracle_mod):
+    """a 2-D grid has separators of ~sqrt(n) vertices: the top fronts exceed one CU's LDS, so the nested-dissection order keeps the column-level
+    numeric phase — same answers"""
+    pkg = load_pkg()
+    g = 120
+    I = sp.identity(g, format="csc")
+    T1 = sp.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(g, g), format="csc")
+    K = (sp.kron(I, T1) + sp.kron(T1, I)).tocsc()                # SPD (hence quasi-definite), n = 14 400
+    K.sort_indices()
+    A = sp.triu(K).tocsc()
+    S = pkg.SparseLDL(A, method="nested_dissection")
+    assert S.info["numeric"] == "columns_lds_accumulator"
+    assert S.factorize(A) == 0 and S.inertia == (g * g, 0, 0)
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(g * g)
+    x = S.solve(b)
+    assert np.abs(K @ x - b).max() <= 1e-9 * max(1.0, np.abs(x).max())
+    perm, Lm, D = S.factor()
+    ref = oracle_factor(oracle_mod, K, perm)
+    assert np.abs(D - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
+    S.close()
+
+
+@pytest.mark.parametrize("method", ["nested_dissection", "nested_dissection_columns"])
+def test_a_batch_of_matrices_with_one_pattern(oracle_mod, method):
+    """BASELINE config C4's shape of work for the LinearSolver seam: many independent KKT systems of ONE structure.  The multifrontal path factors
+    the whole batch in the same launches; every matrix gets the bits it gets alone."""
+    pkg = load_pkg()
+    rng = np.random.default_rng(13)
+    K0 = staged_kkt(24, 5, 2, rng)
+    n, nnz = K0.shape[0], sp.triu(K0).nnz
+    A0 = sp.triu(K0).tocsc(); A0.sort_indices()
+    Bn = 7
+    mats, vals = [], np.zeros((Bn, A0.nnz))
+    for z in range(Bn):
+        K = K0.copy(); K.data = K.data * (1.0 + 0.2 * rng.random(K.data.size)); K = ((K + K.T) * 0.5).tocsc(); K.sort_indices()
+        mats.append(K)
+        Az = sp.triu(K).tocsc(); Az.sort_indices()
+        assert np.array_equal(Az.indices, A0.indices)
+        vals[z] = Az.data
+    vals[3] = vals[3] * 1.0
+    S = pkg.SparseLDL(A0, method=method)
+    alone = []
+    for z in range(Bn):
+        assert S.factorize(vals[z]) == 0
+        perm, Lm, D = S.factor()
+        alone.append((Lm.toarray(), D, S.solve(np.arange(1.0, n + 1.0))))
+    S.set_batch(Bn)
+    assert S.factorize(vals) == 0
+    assert np.array_equal(S.inertia_all, np.tile(np.array(S.inertia_all[0]), (Bn, 1))) and S.inertia_all[0][0] == 24 * 7 + 5
+    rhs = np.tile(np.arange(1.0, n + 1.0), (Bn, 1))
+    X = S.solve(rhs)
+    X3 = S.solve(np.stack([rhs, 2.0 * rhs], axis=2))
+    for z in range(Bn):
+        S.select(z)
+        perm, Lm, D = S.factor()
+        assert np.array_equal(Lm.toarray(), alone[z][0]) and np.array_equal(D, alone[z][1])      # same bits as alone
+        assert np.array_equal(X[z], alone[z][2]) and np.array_equal(X3[z, :, 0], alone[z][2])
+        assert np.abs(mats[z] @ X3[z, :, 1] - 2.0 * rhs[z]).max() <= 1e-8 * np.abs(X3[z]).max()
+        ref = oracle_factor(oracle_mod, mats[z].toarray(), perm)
+        assert np.abs(D - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
     S.close()
