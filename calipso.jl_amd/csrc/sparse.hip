@@ -159,7 +159,7 @@ struct MfDev {
     const int* rel;                           // per node, aligned with rows: local index of R_s[k] in the PARENT's front
     const int *childptr, *children;
     const long long *panel_off, *upd_off, *u_off;
-    const int* Aloc;                          // per entry of the permuted lower CSC: offset inside its node's front (row * (m + 1) + column)
+    const int* Aloc;                          // per entry of the permuted lower CSC: offset inside its node's packed front (row (row + 1) / 2 + column)
     const int *Alp, *Asrc;
     const double* Aval;
     double *panel, *upd, *D, *uvec;
@@ -167,17 +167,21 @@ struct MfDev {
 };
 
 constexpr int MF_THREADS = 256;
-constexpr int MF_MAX_FRONT = 136;             // (m (m + 1) + 2 m) doubles <= 160 KiB
+constexpr int MF_MAX_FRONT = 196;             // (m (m + 1) / 2 + 2 m) doubles <= 160 KiB: the front's lower triangle, packed, + the pivot-column buffers
+
+// The front is symmetric: only its lower triangle is held, packed row by row (row i starts at i (i + 1) / 2), which lets fronts of up to 196 rows
+// fit the 160 KiB of LDS (a full square would stop at 141).
+__device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }     // i >= k
 
 __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(MfDev d, int first) {
     extern __shared__ __attribute__((aligned(16))) double F[];
     const int s = d.order[first + blockIdx.x];
-    const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r, ld = m + 1;
-    double* ycol = F + (size_t)m * ld;
+    const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r, nt = m * (m + 1) / 2;
+    double* ycol = F + nt;
     const int tid = threadIdx.x;
     const size_t z = blockIdx.y;                                               // instance of the batch
     d.Aval += z * d.sA; d.upd += z * d.sUpd; d.panel += z * d.sPanel; d.D += z * d.sD;
-    for (int e = tid; e < m * ld; e += MF_THREADS) F[e] = 0.0;
+    for (int e = tid; e < nt; e += MF_THREADS) F[e] = 0.0;
     __syncthreads();
     for (int p = d.Alp[f] + tid; p < d.Alp[f + c]; p += MF_THREADS) F[d.Aloc[p]] = d.Aval[d.Asrc[p]];
     __syncthreads();
@@ -188,12 +192,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(MfDev d, int first) {
         const int* rel = d.rel + d.rowptr[ch];
         for (int e = tid; e < rc * rc; e += MF_THREADS) {
             const int a = e / rc, b = e - a * rc;
-            if (a >= b) F[rel[a] * ld + rel[b]] += U[e];                       // rel is increasing: the lower triangle lands in the lower triangle
+            if (a >= b) F[tri(rel[a], rel[b])] += U[e];                        // rel is increasing: the lower triangle lands in the lower triangle
         }
         __syncthreads();
     }
     // partial dense LDL^T: the pivot column travels (unscaled) through a double-buffered LDS vector, one barrier per column
-    if (tid < m) ycol[tid] = F[tid * ld];
+    if (tid < m) ycol[tid] = F[tri(tid, 0)];
     const int ti = tid >> 4, tk = tid & 15;
     for (int j = 0; j < c; ++j) {
         __syncthreads();
@@ -204,18 +208,19 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(MfDev d, int first) {
         if (tid == 0) d.D[f + j] = dj;
         for (int i = j + 1 + ti; i < m; i += 16) {
             const double li = y[i] * rinv;
+            double* Fi = F + i * (i + 1) / 2;
             for (int k = j + 1 + tk; k <= i; k += 16) {
-                const double v = F[i * ld + k] - li * y[k];
-                F[i * ld + k] = v;
-                if (k == j + 1) { yn[i] = v; F[i * ld + j] = li; }
+                const double v = Fi[k] - li * y[k];
+                Fi[k] = v;
+                if (k == j + 1) { yn[i] = v; Fi[j] = li; }
             }
         }
     }
     __syncthreads();
     double* P = d.panel + d.panel_off[s];                                      // column-major m x c: column k contiguous over the rows
-    for (int e = tid; e < m * c; e += MF_THREADS) { const int i = e % m, k = e / m; P[e] = i > k ? F[i * ld + k] : 0.0; }
+    for (int e = tid; e < m * c; e += MF_THREADS) { const int i = e % m, k = e / m; P[e] = i > k ? F[tri(i, k)] : 0.0; }
     double* U = d.upd + d.upd_off[s];
-    for (int e = tid; e < r * r; e += MF_THREADS) { const int a = e / r, b = e - a * r; if (a >= b) U[e] = F[(c + a) * ld + c + b]; }
+    for (int e = tid; e < r * r; e += MF_THREADS) { const int a = e / r, b = e - a * r; if (a >= b) U[e] = F[tri(c + a, c + b)]; }
 }
 
 // forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors
@@ -572,12 +577,12 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
             // where each entry of the permuted lower CSC lands in its node's front
             m_Aloc.assign(Ali.size(), 0);
             for (int j = 0; j < (int)n; ++j) {
-                const int t = node_of[(size_t)j], f = m_first[(size_t)t], c = m_cols[(size_t)t], ld = c + m_rows[(size_t)t] + 1;
+                const int t = node_of[(size_t)j], f = m_first[(size_t)t], c = m_cols[(size_t)t];
                 const std::vector<int>& rt = R[(size_t)t];
                 for (int q = Alp[(size_t)j]; q < Alp[(size_t)j + 1]; ++q) {
                     const int i = Ali[(size_t)q];
                     const int lr = i < f + c ? i - f : c + (int)(std::lower_bound(rt.begin(), rt.end(), i) - rt.begin());
-                    m_Aloc[(size_t)q] = lr * ld + (j - f);
+                    m_Aloc[(size_t)q] = lr * (lr + 1) / 2 + (j - f);          // packed lower triangle (k_mf_factor: tri)
                 }
             }
             m_order.resize((size_t)NN);
@@ -587,7 +592,7 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
                 int b = a; size_t lf = 0, ls = 0;
                 while (b < NN && lev[(size_t)m_order[(size_t)b]] == lev[(size_t)m_order[(size_t)a]]) {
                     const int t = m_order[(size_t)b]; const size_t m = (size_t)(m_cols[(size_t)t] + m_rows[(size_t)t]);
-                    lf = std::max(lf, sizeof(double) * (m * (m + 1) + 2 * m)); ls = std::max(ls, sizeof(double) * (m * (size_t)m_cols[(size_t)t] + m));
+                    lf = std::max(lf, sizeof(double) * (m * (m + 1) / 2 + 2 * m)); ls = std::max(ls, sizeof(double) * (m * (size_t)m_cols[(size_t)t] + m));
                     ++b;
                 }
                 mplan.push_back({a, b - a, lf, ls});

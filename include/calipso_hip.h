@@ -321,7 +321,7 @@ int32_t calipso_hip_ldl_solve(calipso_hip_solver*, int64_t n, int64_t nrhs, cons
  *   calipso_hip_sparse_set_batch   `batch` matrices of the analysed pattern per call (BASELINE config C4: many independent problems of one structure):
  *                                  nzval = batch x nnz, inertia = batch x 3, b / x = batch x (n x nrhs); the multifrontal path factors them in the
  *                                  same launches.  calipso_hip_sparse_select picks the matrix calipso_hip_sparse_get_factor reads.
- * Numeric phase: with method 4 (nested dissection) and every front <= 136 rows the factorisation is MULTIFRONTAL over the dissection tree — the
+ * Numeric phase: with method 4 (nested dissection) and every front <= 196 rows the factorisation is MULTIFRONTAL over the dissection tree — the
  * pieces of the dissection are the supernodes, each front is assembled and partially factored in the LDS of one workgroup, one launch per tree level
  * (~log2 T launches for a T-stage problem); otherwise (and with method 5 = nested-dissection order, column method) the left-looking column method. */
 typedef struct calipso_hip_sparse calipso_hip_sparse;

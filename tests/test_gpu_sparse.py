@@ -238,14 +238,14 @@ def test_fronts_that_do_not_fit_fall_back_to_the_column_method(oracle_mod):
     """a 2-D grid has separators of ~sqrt(n) vertices: the top fronts exceed one CU's LDS, so the nested-dissection order keeps the column-level
     numeric phase — same answers"""
     pkg = load_pkg()
-    g = 120
+    g = 180
     I = sp.identity(g, format="csc")
     T1 = sp.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(g, g), format="csc")
-    K = (sp.kron(I, T1) + sp.kron(T1, I)).tocsc()                # SPD (hence quasi-definite), n = 14 400
+    K = (sp.kron(I, T1) + sp.kron(T1, I)).tocsc()                # SPD (hence quasi-definite), n = 32 400
     K.sort_indices()
     A = sp.triu(K).tocsc()
     S = pkg.SparseLDL(A, method="nested_dissection")
-    assert S.info["numeric"] == "columns_lds_accumulator"
+    assert S.info["numeric"].startswith("columns")
     assert S.factorize(A) == 0 and S.inertia == (g * g, 0, 0)
     rng = np.random.default_rng(1)
     b = rng.standard_normal(g * g)
