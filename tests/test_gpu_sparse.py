@@ -296,3 +296,17 @@ def test_a_batch_of_matrices_with_one_pattern(oracle_mod, method):
         ref = oracle_factor(oracle_mod, mats[z].toarray(), perm)
         assert np.abs(D - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
     S.close()
+
+
+def test_zero_pivot_in_the_multifrontal_path():
+    """60 decoupled 2 x 2 blocks [[1, 1], [1, 1]]: every second pivot is exactly zero.  QDLDL stops at the first one in elimination order
+    (positive = -1, the rest of D counted as zeros, qdldl.jl:444,456,579); the fronts do not stop, the reported inertia is the same"""
+    pkg = load_pkg()
+    K = sp.block_diag([np.ones((2, 2))] * 60, format="csc")
+    S = pkg.SparseLDL(sp.triu(K).tocsc(), method="nested_dissection")
+    assert S.info["numeric"] == "multifrontal"
+    assert S.factorize(sp.triu(K).tocsc()) == 1
+    perm, _, D = S.factor()
+    first_zero = int(np.argmax(D == 0.0))
+    assert D[first_zero] == 0.0 and S.inertia == (-1, 120 - first_zero, 120 - first_zero)
+    S.close()
