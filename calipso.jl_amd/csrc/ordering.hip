@@ -137,6 +137,12 @@ std::vector<i64> minimum_degree(const std::vector<std::vector<int>>& adj0) {
 // level-scheduled device factorisation of sparse.hip turns into parallelism (stage-parallel elimination).  Leaves (<= 48
 // vertices, or pieces the level structure cannot split) are ordered by minimum degree.
 typedef std::vector<std::pair<int, int>> Pieces;     // (first position, count) of every leaf piece / separator, in elimination order
+// a piece the level structure could not split further (a clique-like stage block) or a wide separator goes out as a chain of chunks of <= 64
+// columns: the multifrontal factorisation of sparse.hip holds a front of (chunk + its rows below) in one CU's LDS
+inline void push_pieces(Pieces* pieces, int first, int count) {
+    if (!pieces) return;
+    for (int o = 0; o < count; o += 64) pieces->push_back({first + o, std::min(64, count - o)});
+}
 void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& verts, std::vector<int>& local, std::vector<int>& level, std::vector<i64>& out, Pieces* pieces) {
     const int m = (int)verts.size();
     auto leaf = [&]() {
@@ -145,7 +151,7 @@ void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& vert
         std::vector<std::vector<int>> sub((size_t)m);
         for (int a = 0; a < m; ++a) for (int u : adj[verts[a]]) if (local[u] >= 0) sub[(size_t)a].push_back(local[u]);
         for (int a = 0; a < m; ++a) local[verts[a]] = -1;
-        if (pieces) pieces->push_back({(int)out.size(), m});
+        push_pieces(pieces, (int)out.size(), m);
         for (i64 k : minimum_degree(sub)) out.push_back(verts[(size_t)k - 1] + 1);
     };
     if (m <= 48) { leaf(); return; }
@@ -209,7 +215,7 @@ void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& vert
         std::vector<std::vector<int>> sub((size_t)ms);
         for (int a = 0; a < ms; ++a) for (int u : adj[Sep[a]]) if (local[u] >= 0) sub[(size_t)a].push_back(local[u]);
         for (int a = 0; a < ms; ++a) local[Sep[a]] = -1;
-        if (pieces) pieces->push_back({(int)out.size(), ms});
+        push_pieces(pieces, (int)out.size(), ms);
         for (i64 k : minimum_degree(sub)) out.push_back(Sep[(size_t)k - 1] + 1);
     }
 }
