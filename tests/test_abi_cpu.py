@@ -59,6 +59,12 @@ def test_no_cpu_fallback():
     with pytest.raises(pkg.CalipsoHipError) as e:
         pkg.Solver(None, 3, 0, 2, 2)
     assert "no HIP device" in str(e.value)
+    # every other handle type of the ABI as well: the LinearSolver seam (dense and sparse), the batched small systems
+    import scipy.sparse as sp
+    for make in (lambda: pkg.LDLSolver(4), lambda: pkg.SparseLDL(sp.identity(4, format="csc")), lambda: pkg.SmallBatch(4, 1, 2)):
+        with pytest.raises(pkg.CalipsoHipError) as e:
+            make()
+        assert "no HIP device" in str(e.value)
 
 
 def test_product_does_not_reference_oracle():
