@@ -649,6 +649,27 @@ class SparseLDL:
         X = X.reshape(nrhs, self.n).T
         return X[:, 0].copy() if one else X.copy()
 
+    def factorize_device(self, values):
+        """factorize with the values already on the device: a float64 CUDA/HIP torch tensor of batch x nnz entries (CSC order)"""
+        B = getattr(self, "batch", 1)
+        assert values.is_cuda and values.is_contiguous() and values.numel() == B * self.nnz and values.element_size() == 8
+        inr = np.zeros(3 * B, dtype=np.int64)
+        rc = self._check(self._L.calipso_hip_sparse_factorize_device(self._h, C.c_void_p(values.data_ptr()), _pi(inr)), "sparse_factorize_device")
+        self.inertia = tuple(int(v) for v in inr[:3])
+        self.inertia_all = inr.reshape(B, 3)
+        return rc
+
+    def solve_device(self, b, out=None):
+        """solve with device-resident right-hand sides: float64 torch tensor laid out batch x nrhs x n (each right-hand side contiguous);
+        returns a tensor of the same layout (or writes `out`)"""
+        B = getattr(self, "batch", 1)
+        assert b.is_cuda and b.is_contiguous() and b.element_size() == 8 and b.numel() % (B * self.n) == 0
+        nrhs = b.numel() // (B * self.n)
+        if out is None:
+            out = b.new_empty(b.shape)
+        self._check(self._L.calipso_hip_sparse_solve_device(self._h, nrhs, C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr())), "sparse_solve_device")
+        return out
+
     def select(self, instance):
         """which matrix of the batch factor() reads"""
         self._check(self._L.calipso_hip_sparse_select(self._h, int(instance)), "sparse_select")

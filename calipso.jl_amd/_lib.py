@@ -83,6 +83,8 @@ SYMBOLS = {
     "calipso_hip_sparse_select": (_i32, [_vp, _i64]),
     "calipso_hip_sparse_factorize": (_i32, [_vp, _pd, _pi64]),
     "calipso_hip_sparse_solve": (_i32, [_vp, _i64, _pd, _pd]),
+    "calipso_hip_sparse_factorize_device": (_i32, [_vp, _vp, _pi64]),
+    "calipso_hip_sparse_solve_device": (_i32, [_vp, _i64, _vp, _vp]),
     "calipso_hip_sparse_get_factor": (_i32, [_vp, _pi64, _pi64, _pi64, _pd, _pd]),
     "calipso_hip_sparse_timing": (_i32, [_vp, _pd]),
     "calipso_hip_small_create": (_i32, [_i64, _i64, _i64, _i32, C.POINTER(_vp)]),

@@ -677,11 +677,11 @@ int32_t calipso_hip_sparse_select(calipso_hip_sparse* s, int64_t instance) {
 // QDLDL_factor! + compute_inertia! (qdldl.jl:400-589, linear_solver.jl:19-44) for new values on the analysed pattern.
 // nzval: batch x nnz(A) values in the caller's CSC order (host).  inertia: batch x 3 (may be NULL).  Returns CALIPSO_WARN_ZERO_PIVOT if any
 // matrix met an exact zero pivot (its inertia[0] = -1).
-int32_t calipso_hip_sparse_factorize(calipso_hip_sparse* s, const double* nzval, int64_t* inertia) {
+static int32_t sparse_factorize(calipso_hip_sparse* s, const double* nzval, int64_t* inertia, hipMemcpyKind kind) {
     if (!s || (!nzval && s->nnzA > 0)) return CALIPSO_ERR_ARGUMENT;
     PK(hipSetDevice(s->device));
     const size_t B = (size_t)s->batch;
-    if (s->nnzA) PK(hipMemcpyAsync(s->d_Aval, nzval, sizeof(double) * B * (size_t)s->nnzA, hipMemcpyHostToDevice, s->stream));
+    if (s->nnzA) PK(hipMemcpyAsync(s->d_Aval, nzval, sizeof(double) * B * (size_t)s->nnzA, kind, s->stream));
     PK(hipEventRecord(s->e0, s->stream));
     if (!s->graph_tried) {          // the level schedule is a fixed launch sequence with fixed arguments: captured once, replayed afterwards
         s->graph_tried = true;
@@ -717,9 +717,12 @@ int32_t calipso_hip_sparse_factorize(calipso_hip_sparse* s, const double* nzval,
     if (inertia) std::copy(s->inertia_all.begin(), s->inertia_all.end(), inertia);
     return rc;
 }
+int32_t calipso_hip_sparse_factorize(calipso_hip_sparse* s, const double* nzval, int64_t* inertia) { return sparse_factorize(s, nzval, inertia, hipMemcpyHostToDevice); }
+// the same with the values already resident on the handle's device (d_nzval: device pointer, batch x nnz)
+int32_t calipso_hip_sparse_factorize_device(calipso_hip_sparse* s, const double* d_nzval, int64_t* inertia) { return sparse_factorize(s, d_nzval, inertia, hipMemcpyDeviceToDevice); }
 
 // solve!(F, b) (qdldl.jl:330-351) for nrhs right-hand sides per matrix: b, x = batch x (column-major n x nrhs) host arrays (may alias)
-int32_t calipso_hip_sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const double* b, double* x) {
+static int32_t sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const double* b, double* x, hipMemcpyKind kin, hipMemcpyKind kout) {
     if (!s || nrhs < 0 || (nrhs > 0 && (!b || !x)) || nrhs * (int64_t)(s ? s->batch : 1) > 65535) return CALIPSO_ERR_ARGUMENT;
     if (!s->factored) { s->err = "calipso_hip_sparse_solve: factorize first"; return CALIPSO_ERR_ARGUMENT; }
     if (nrhs == 0) return CALIPSO_OK;
@@ -733,7 +736,7 @@ int32_t calipso_hip_sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const doub
         PK(hipMalloc((void**)&s->d_rhs, sizeof(double) * need)); PK(hipMalloc((void**)&s->d_x, sizeof(double) * need));
         s->cap_rhs = need;
     }
-    PK(hipMemcpyAsync(s->d_rhs, b, sizeof(double) * need, hipMemcpyHostToDevice, s->stream));
+    PK(hipMemcpyAsync(s->d_rhs, b, sizeof(double) * need, kin, s->stream));
     PK(hipEventRecord(s->e0, s->stream));
     const unsigned gx = (unsigned)((s->n + 255) / 256), ny = (unsigned)cols;
     hipLaunchKernelGGL(k_sp_permute_in, dim3(gx, ny), dim3(256), 0, s->stream, s->d_rhs, s->d_perm, s->n, s->d_x);
@@ -762,12 +765,15 @@ int32_t calipso_hip_sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const doub
     }
     hipLaunchKernelGGL(k_sp_permute_out, dim3(gx, ny), dim3(256), 0, s->stream, s->d_x, s->d_perm, s->n, s->d_rhs);
     PK(hipEventRecord(s->e1, s->stream));
-    PK(hipMemcpyAsync(x, s->d_rhs, sizeof(double) * need, hipMemcpyDeviceToHost, s->stream));
+    PK(hipMemcpyAsync(x, s->d_rhs, sizeof(double) * need, kout, s->stream));
     PK(hipStreamSynchronize(s->stream));
     PK(hipGetLastError());
     float ms = 0.f; PK(hipEventElapsedTime(&ms, s->e0, s->e1)); s->ms_solve = ms;
     return CALIPSO_OK;
 }
+int32_t calipso_hip_sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const double* b, double* x) { return sparse_solve(s, nrhs, b, x, hipMemcpyHostToDevice, hipMemcpyDeviceToHost); }
+// the same with right-hand sides and solutions resident on the handle's device (device pointers; may alias)
+int32_t calipso_hip_sparse_solve_device(calipso_hip_sparse* s, int64_t nrhs, const double* d_b, double* d_x) { return sparse_solve(s, nrhs, d_b, d_x, hipMemcpyDeviceToDevice, hipMemcpyDeviceToDevice); }
 
 // the factor for inspection: perm[n] (1-based), Lp[n+1], Li[nnz(L)] (1-based, strictly lower, rows ascending — F.L of qdldl.jl:160-166 without the
 // unit diagonal), Lx[nnz(L)], D[n]; any output may be NULL

@@ -334,6 +334,9 @@ int32_t calipso_hip_sparse_set_batch(calipso_hip_sparse*, int64_t batch);
 int32_t calipso_hip_sparse_select(calipso_hip_sparse*, int64_t instance);
 int32_t calipso_hip_sparse_factorize(calipso_hip_sparse*, const double* nzval, int64_t* inertia);
 int32_t calipso_hip_sparse_solve(calipso_hip_sparse*, int64_t nrhs, const double* b, double* x);
+/* the same with values / right-hand sides / solutions already resident on the handle's device (device pointers) */
+int32_t calipso_hip_sparse_factorize_device(calipso_hip_sparse*, const double* d_nzval, int64_t* inertia);
+int32_t calipso_hip_sparse_solve_device(calipso_hip_sparse*, int64_t nrhs, const double* d_b, double* d_x);
 int32_t calipso_hip_sparse_get_factor(calipso_hip_sparse*, int64_t* perm, int64_t* Lp, int64_t* Li, double* Lx, double* D);
 int32_t calipso_hip_sparse_timing(calipso_hip_sparse*, double ms[2]);
 

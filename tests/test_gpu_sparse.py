@@ -7,6 +7,11 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+try:                       # before libcalipso_hip.so is loaded: torch brings its own HIP runtime, and one process should hold only one
+    import torch
+except ImportError:        # (the device-pointer test is skipped without it)
+    torch = None
+
 from helpers import load_pkg
 from test_oracle_qdldl import quasidefinite
 from test_ordering_symbolic import csc1, kkt_matrices, staged_kkt, tree_height
@@ -309,4 +314,28 @@ def test_zero_pivot_in_the_multifrontal_path():
     perm, _, D = S.factor()
     first_zero = int(np.argmax(D == 0.0))
     assert D[first_zero] == 0.0 and S.inertia == (-1, 120 - first_zero, 120 - first_zero)
+    S.close()
+
+
+def test_device_resident_values_and_right_hand_sides():
+    """calipso_hip_sparse_factorize_device / _solve_device: nothing but pointers crosses the boundary; same bits as the host-array calls"""
+    if torch is None:
+        pytest.skip("torch not installed")
+    pkg = load_pkg()
+    rng = np.random.default_rng(17)
+    K = staged_kkt(32, 5, 2, rng)
+    A = sp.triu(K).tocsc(); A.sort_indices()
+    n = K.shape[0]
+    S = pkg.SparseLDL(A, method="nested_dissection")
+    S.set_batch(3)
+    vals = A.data[None, :] * (1.0 + 0.1 * rng.random((3, A.nnz)))
+    b = rng.standard_normal((3, n))
+    S.factorize(vals)
+    x_host = S.solve(b)
+    tv = torch.from_numpy(vals).to("cuda:0")
+    tb = torch.from_numpy(b.reshape(3, 1, n).copy()).to("cuda:0")
+    assert S.factorize_device(tv) == 0
+    tx = S.solve_device(tb)
+    torch.cuda.synchronize()
+    assert np.array_equal(tx.cpu().numpy().reshape(3, n), x_host)
     S.close()
