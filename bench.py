@@ -187,6 +187,7 @@ def main():
                     "letting every lane run its passes back to back")
     ap.add_argument("--config", default="C3", choices=list(CONFIGS) + list(STAGED))
     ap.add_argument("--dense-structure", action="store_true", help="stage-structured configs: keep the dense treatment (no calipso_hip_analyze_structure)")
+    ap.add_argument("--no-stage-parallel", action="store_true", help="stage-structured configs: keep the blocked banded LDL^T of S (no calipso_hip_set_stage_parallel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="measure B0(ii) (re-factorisation before every solve) instead of deriving it (~1 min more)")
     ap.add_argument("--cpu-samples", type=int, default=3)
@@ -234,6 +235,15 @@ def main():
             inst[4].problem = None
             inst[4].methods = None
     solvers = [made[k][4] for k in range(nb)]
+    stage_parallel = None
+    if staged is not None and not args.dense_structure and not args.no_stage_parallel:
+        # the Schur complement through the multifrontal sparse LDL^T over a nested dissection of its pattern (calipso_hip_set_stage_parallel):
+        # on the handle that leads each unit (its storage covers the unit's G members)
+        try:
+            for k in range(0, nb, max(G, 1)):
+                stage_parallel = solvers[k].set_stage_parallel(True, batch=max(G, 1))
+        except pkg.CalipsoHipError as e:                      # a front exceeds one CU's LDS: the blocked factorisation stays
+            stage_parallel = dict(refused=str(e))
     single = solvers[0]                                       # the headline system of this rank (problem id = first of its shard)
     units = ([pkg.Group(solvers[k:k + G]) for k in range(0, B, G)] if G > 1 else solvers[:B]) if B else []
     batch = BatchSolver(units, lanes=args.lanes) if units else None
@@ -380,7 +390,8 @@ def main():
     if alone:
         cfg_phases["one_group_alone"] = phases(np.mean(np.asarray(alone), axis=0), G)
 
-    kind = ("stage-structured (%d stages, %s treatment) " % (staged[0], "dense" if args.dense_structure else "banded")) if staged else "dense "
+    kind = ("stage-structured (%d stages, %s treatment) " % (staged[0], "dense" if args.dense_structure else ("banded, stage-parallel multifrontal LDL^T of S"
+            if stage_parallel and "levels" in stage_parallel else "banded"))) if staged else "dense "
     batched = None
     if batched_elapsed is not None:
         brate = world * B * P / batched_elapsed

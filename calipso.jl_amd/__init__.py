@@ -403,6 +403,14 @@ class Solver:
     def clear_structure(self):
         self._check(self._L.calipso_hip_clear_structure(self._h), "clear_structure")
 
+    def set_stage_parallel(self, on=True, batch=1):
+        """after analyze_structure: factor the Schur complement by the multifrontal sparse LDL^T over a nested dissection of its pattern (for a
+        trajectory problem log2(stages) launches instead of the chain of nx pivots); batch >= the largest group this handle leads.
+        Returns dict(levels, largest_front, nnz_upper)."""
+        out = np.zeros(4, dtype=np.int64)
+        self._check(self._L.calipso_hip_set_stage_parallel(self._h, 1 if on else 0, int(batch), _pi(out)), "set_stage_parallel")
+        return dict(levels=int(out[0]), largest_front=int(out[1]), nnz_upper=int(out[2]))
+
     def synchronize(self):
         self._check(self._L.calipso_hip_synchronize(self._h), "synchronize")
 

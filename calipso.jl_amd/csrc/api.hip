@@ -209,6 +209,8 @@ int32_t calipso_hip_destroy(H* s) {
     nonsymmetric_release(s);
     ldlsolver_release(s);
     scatter_release(s);
+    if (s->spS) { (void)calipso_hip_sparse_destroy(s->spS); s->spS = nullptr; }
+    if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
     double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
     for (double* p : dp) if (p) (void)hipFree(p);
     int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};

@@ -48,6 +48,7 @@ static void g_activate(G* g, const Set& a) {
     for (size_t k = 0; k < a.size(); ++k) {
         H* h = g->hs[a[k]];
         b.b.delta[k] = (long long)((reinterpret_cast<intptr_t>(h->slab) - reinterpret_cast<intptr_t>(g->base->slab)) / (intptr_t)sizeof(double));
+        b.b.slot[k] = (int)a[k];
         b.sc[k] = h->sc;
     }
     g->base->cur = &g->desc;

@@ -55,6 +55,7 @@ constexpr int MAX_BATCH = 16;
 struct Batch {
     int n = 1;                       // gridDim.z
     long long delta[MAX_BATCH] = {0};
+    int slot[MAX_BATCH] = {0};       // the member's index in its group (0 for a handle stepped alone): addresses per-member storage outside the slabs
 };
 struct BatchSc {                     // + the per-instance scalars
     Batch b;
@@ -167,6 +168,12 @@ struct calipso_hip_solver {
     int schur_nj = 8;           // Schur tile = 128 x 16*schur_nj for single-instance launches (schur.hip: schur_plan)
     // stage-banded structure (structure.hip); band64 = 0: dense
     int half_bandwidth = 0, band64 = 0;
+    // stage-parallel factorisation of S (calipso_hip_set_stage_parallel): the skyline pattern of S found by the structure analysis, a multifrontal
+    // sparse LDL^T over its nested-dissection tree (sparse.hip) instead of the blocked LDL^T of ldl.hip, for this handle or the group it leads
+    std::vector<int> h_reach;                 // per column j of S: last row that can be non-zero (analysis)
+    calipso_hip_sparse* spS = nullptr;
+    long long* spS_src = nullptr;             // device: offset (row + col * NP) in S of every pattern entry
+    bool stage_parallel = false;
     calipso::i64 structure_resets = 0;   // uploads that broke an analysed structure (the handle went back to dense)
     int* krange = nullptr;      // (in the slab) per 16-column group: [eq_lo, eq_hi, cone_lo, cone_hi) constraint rows that touch it
     int* zrow = nullptr;        // (in the slab) per row of [gx; hx]: [first, last + 1) non-zero column
@@ -284,6 +291,13 @@ inline BatchSc batch_of(const calipso_hip_solver* s) {
     return b;
 }
 // batched fills / copies (vectors.hip) — replace hipMemsetAsync / hipMemcpyAsync on the hot path so that groups are covered
+// sparse.hip hooks used by ldl.hip when a handle factors S through the multifrontal path
+bool sparse_is_multifrontal(const calipso_hip_sparse* sp);
+int sparse_batch(const calipso_hip_sparse* sp);
+int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, const double* S, const long long* src, int* icount);
+int sparse_solve_inplace(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, double* x);
+int sparse_reserve_solve(calipso_hip_sparse* sp, int batch);
+void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]);
 int nested_dissection_pieces(i64 n, const i64* colptr, const i64* rowval, i64* perm, std::vector<std::pair<int, int>>& pieces);   // ordering.hip
 void fill_d(calipso_hip_solver* s, double* p, size_t n, double v);
 void fill_i(calipso_hip_solver* s, int* p, size_t n, int v);

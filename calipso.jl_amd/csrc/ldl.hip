@@ -648,12 +648,18 @@ static bool replay_or_capture(calipso_hip_solver* s, hipGraphExec_t& exec, bool&
 }
 
 void launch_ldl(calipso_hip_solver* s) {
+    if (s->stage_parallel && s->spS) {        // stage-parallel: multifrontal LDL^T of S over its nested-dissection tree (sparse.hip)
+        const Batch bt = batch_of(s).b;
+        if (sparse_factor_from_dense(s->spS, s->stream, bt, s->S, s->spS_src, s->icount) == CALIPSO_OK) return;
+        s->stage_parallel = false;            // (a group larger than the reserved batch: back to the blocked factorisation)
+    }
     ldl_set_attributes();
     // (a group launch covers a changing set of instances: its kernel arguments differ from call to call, so no graph there)
     if (s->cur || !s->use_graphs || !replay_or_capture(s, s->graph_ldl, s->graph_ldl_tried, [&] { enqueue_ldl(s); })) enqueue_ldl(s);
 }
 
 void launch_trsv(calipso_hip_solver* s, double* x) {
+    if (s->stage_parallel && s->spS) { (void)sparse_solve_inplace(s->spS, s->stream, batch_of(s).b, x); return; }
     if (s->cur || x != s->xbuf || !s->use_graphs || !replay_or_capture(s, s->graph_trsv, s->graph_trsv_tried, [&] { enqueue_trsv(s, s->xbuf); })) enqueue_trsv(s, x);
 }
 

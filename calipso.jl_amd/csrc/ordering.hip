@@ -137,12 +137,7 @@ std::vector<i64> minimum_degree(const std::vector<std::vector<int>>& adj0) {
 // level-scheduled device factorisation of sparse.hip turns into parallelism (stage-parallel elimination).  Leaves (<= 48
 // vertices, or pieces the level structure cannot split) are ordered by minimum degree.
 typedef std::vector<std::pair<int, int>> Pieces;     // (first position, count) of every leaf piece / separator, in elimination order
-// a piece the level structure could not split further (a clique-like stage block) or a wide separator goes out as a chain of chunks of <= 64
-// columns: the multifrontal factorisation of sparse.hip holds a front of (chunk + its rows below) in one CU's LDS
-inline void push_pieces(Pieces* pieces, int first, int count) {
-    if (!pieces) return;
-    for (int o = 0; o < count; o += 64) pieces->push_back({first + o, std::min(64, count - o)});
-}
+inline void push_pieces(Pieces* pieces, int first, int count) { if (pieces) pieces->push_back({first, count}); }
 void nd_recurse(const std::vector<std::vector<int>>& adj, std::vector<int>& verts, std::vector<int>& local, std::vector<int>& level, std::vector<i64>& out, Pieces* pieces) {
     const int m = (int)verts.size();
     auto leaf = [&]() {

@@ -165,7 +165,11 @@ struct MfDev {
     double *panel, *upd, *D, *uvec;
     long long sA, sPanel, sUpd, sD;           // instance strides (batched factorisation of matrices with one pattern)
 };
+// storage slot of launch instance z: z itself, or — for the members of a group's (shrinking) active set — slot[z].  A separate read-only kernel
+// argument: indexing an array inside a struct the kernel also modifies would push the whole struct to scratch memory.
+struct MfSlots { int use; int slot[calipso::MAX_BATCH]; };
 
+typedef double calipso_v4d __attribute__((ext_vector_type(4)));
 constexpr int MF_THREADS = 256;
 constexpr int MF_MAX_FRONT = 196;             // (m (m + 1) / 2 + 2 m) doubles <= 160 KiB: the front's lower triangle, packed, + the pivot-column buffers
 
@@ -173,22 +177,23 @@ constexpr int MF_MAX_FRONT = 196;             // (m (m + 1) / 2 + 2 m) doubles <
 // fit the 160 KiB of LDS (a full square would stop at 141).
 __device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }     // i >= k
 
-__global__ __launch_bounds__(MF_THREADS) void k_mf_factor(MfDev d, int first) {
+__global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first) {
     extern __shared__ __attribute__((aligned(16))) double F[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r, nt = m * (m + 1) / 2;
     double* ycol = F + nt;
     const int tid = threadIdx.x;
-    const size_t z = blockIdx.y;                                               // instance of the batch
-    d.Aval += z * d.sA; d.upd += z * d.sUpd; d.panel += z * d.sPanel; d.D += z * d.sD;
+    const size_t z = sl.use ? (size_t)sl.slot[blockIdx.y] : (size_t)blockIdx.y;   // storage slot of this instance of the batch
+    const double* Aval = d.Aval + z * d.sA;
+    double* upd = d.upd + z * d.sUpd; double* panel = d.panel + z * d.sPanel; double* Dg = d.D + z * d.sD;
     for (int e = tid; e < nt; e += MF_THREADS) F[e] = 0.0;
     __syncthreads();
-    for (int p = d.Alp[f] + tid; p < d.Alp[f + c]; p += MF_THREADS) F[d.Aloc[p]] = d.Aval[d.Asrc[p]];
+    for (int p = d.Alp[f] + tid; p < d.Alp[f + c]; p += MF_THREADS) F[d.Aloc[p]] = Aval[d.Asrc[p]];
     __syncthreads();
     for (int q = d.childptr[s]; q < d.childptr[s + 1]; ++q) {                 // extend-add, children in ascending order
         const int ch = d.children[q];
         const int rc = d.nrows[ch];
-        const double* U = d.upd + d.upd_off[ch];
+        const double* U = upd + d.upd_off[ch];
         const int* rel = d.rel + d.rowptr[ch];
         for (int e = tid; e < rc * rc; e += MF_THREADS) {
             const int a = e / rc, b = e - a * rc;
@@ -196,44 +201,73 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(MfDev d, int first) {
         }
         __syncthreads();
     }
-    // partial dense LDL^T: the pivot column travels (unscaled) through a double-buffered LDS vector, one barrier per column
-    if (tid < m) ycol[tid] = F[tri(tid, 0)];
-    const int ti = tid >> 4, tk = tid & 15;
-    for (int j = 0; j < c; ++j) {
+    // Partial dense LDL^T of the first c columns, blocked: panels of 16 columns.
+    //   panel   column j is left UNSCALED in F (y_ij = l_ij d_j; nothing overwrites what the other rows still read, so ONE barrier per column);
+    //           256 threads as 16 row classes x 16 panel columns apply  F[i][k] -= y_ij (y_kj / d_j)  to the panel columns k > j, rows i >= k.
+    //   update  F[i][j] -= sum_k (y_ik / d_k) y_jk over the panel, for every 16 x 16 tile of the trailing lower triangle on the fp64 matrix cores
+    //           (v_mfma_f64_16x16x4: first operand = scaled rows of the i tile, second = rows of the j tile, K = 16 = one panel).
+    double* rinv = ycol;                                                       // c reciprocal pivots (the 2 m doubles behind the front)
+    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    for (int kb = 0; kb < c; kb += 16) {
+        const int pe = min(kb + 16, c);
+        for (int j = kb; j < pe; ++j) {
+            __syncthreads();
+            const double dj = F[tri(j, j)];
+            const double rj = 1.0 / dj;
+            if (tid == 0) { Dg[f + j] = dj; rinv[j] = rj; }
+            const int k = j + 1 + (tid & 15);                                  // 16 x 16 threads over (row, panel column)
+            if (k < pe) {
+                const double ykj = F[tri(k, j)] * rj;
+                int i = j + 1 + (tid >> 4);                                      // rows i >= k of this thread's residue class
+                if (i < k) i += ((k - i + 15) >> 4) << 4;
+                for (; i < m; i += 16) {
+                    double* Fi = F + i * (i + 1) / 2;
+                    Fi[k] -= Fi[j] * ykj;
+                }
+            }
+        }
         __syncthreads();
-        const double* y = ycol + (j & 1) * m;
-        double* yn = ycol + ((j + 1) & 1) * m;
-        const double dj = y[j];
-        const double rinv = 1.0 / dj;
-        if (tid == 0) d.D[f + j] = dj;
-        for (int i = j + 1 + ti; i < m; i += 16) {
-            const double li = y[i] * rinv;
-            double* Fi = F + i * (i + 1) / 2;
-            for (int k = j + 1 + tk; k <= i; k += 16) {
-                const double v = Fi[k] - li * y[k];
-                Fi[k] = v;
-                if (k == j + 1) { yn[i] = v; Fi[j] = li; }
+        const int nt = (m - pe + 15) / 16;                                     // 16-row tiles of the trailing part
+        for (int t = wave; t < nt * (nt + 1) / 2; t += MF_THREADS / 64) {
+            int tb_i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while ((tb_i + 1) * (tb_i + 2) / 2 <= t) ++tb_i;
+            while (tb_i * (tb_i + 1) / 2 > t) --tb_i;
+            const int tb_j = t - tb_i * (tb_i + 1) / 2;
+            const int ia = pe + 16 * tb_i + fr, jbr = pe + 16 * tb_j + fr;    // the row this lane feeds to the first / second operand
+            calipso_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = kb + 4 * kk + fk;
+                const bool kin = k < pe;
+                const double av = (kin && ia < m) ? F[tri(ia, k)] * rinv[k] : 0.0;
+                const double bv = (kin && jbr < m) ? F[tri(jbr, k)] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = pe + 16 * tb_i + fk + 4 * r, j = pe + 16 * tb_j + fr;   // result row (first operand's tile), column (second's)
+                if (i < m && j <= i) F[tri(i, j)] -= acc[r];
             }
         }
     }
     __syncthreads();
-    double* P = d.panel + d.panel_off[s];                                      // column-major m x c: column k contiguous over the rows
-    for (int e = tid; e < m * c; e += MF_THREADS) { const int i = e % m, k = e / m; P[e] = i > k ? F[tri(i, k)] : 0.0; }
-    double* U = d.upd + d.upd_off[s];
+    double* P = panel + d.panel_off[s];                                        // column-major m x c: column k contiguous over the rows
+    for (int e = tid; e < m * c; e += MF_THREADS) { const int i = e % m, k = e / m; P[e] = i > k ? F[tri(i, k)] * rinv[k] : 0.0; }
+    double* U = upd + d.upd_off[s];
     for (int e = tid; e < r * r; e += MF_THREADS) { const int a = e / r, b = e - a * r; if (a >= b) U[e] = F[tri(c + a, c + b)]; }
 }
 
 // forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors
-__global__ __launch_bounds__(MF_THREADS) void k_mf_forward(MfDev d, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
+__global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
     double* Ps = sm; double* v = sm + (size_t)m * c;
     double* x = X + (size_t)blockIdx.y * n;                                    // blockIdx.y = instance * nrhs + right-hand side
     double* ubase = d.uvec + (size_t)blockIdx.y * usum;
-    d.panel += (size_t)(blockIdx.y / nrhs) * d.sPanel;
+    const double* panel = d.panel + (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)) * d.sPanel;
     const int tid = threadIdx.x;
-    const double* P = d.panel + d.panel_off[s];
+    const double* P = panel + d.panel_off[s];
     for (int e = tid; e < m * c; e += MF_THREADS) Ps[e] = P[e];
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] : 0.0;
     __syncthreads();
@@ -255,18 +289,19 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(MfDev d, int first, i
     for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a];
 }
 // backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C
-__global__ __launch_bounds__(MF_THREADS) void k_mf_backward(MfDev d, int first, int n, int nrhs, double* __restrict__ X) {
+__global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
     double* Ps = sm; double* v = sm + (size_t)m * c;
     double* x = X + (size_t)blockIdx.y * n;
-    d.panel += (size_t)(blockIdx.y / nrhs) * d.sPanel; d.D += (size_t)(blockIdx.y / nrhs) * d.sD;
+    const size_t zs = (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs));
+    const double* panel = d.panel + zs * d.sPanel; const double* Dg = d.D + zs * d.sD;
     const int tid = threadIdx.x;
-    const double* P = d.panel + d.panel_off[s];
+    const double* P = panel + d.panel_off[s];
     const int* R = d.rows + d.rowptr[s];
     for (int e = tid; e < m * c; e += MF_THREADS) Ps[e] = P[e];
-    for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] / d.D[f + i] : x[R[i - c]];
+    for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] / Dg[f + i] : x[R[i - c]];
     __syncthreads();
     double z = 0.0;
     if (tid < c) { z = v[tid]; for (int a = 0; a < r; ++a) z -= Ps[(c + a) + tid * m] * v[c + a]; }
@@ -359,7 +394,7 @@ int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
 void enqueue_factor(calipso_hip_sparse* s) {
     if (s->mf) {
         for (const MfSeg& g : s->mplan)
-            hipLaunchKernelGGL(k_mf_factor, dim3((unsigned)g.count, (unsigned)s->batch), dim3(MF_THREADS), g.lds_factor, s->stream, s->md, g.first);
+            hipLaunchKernelGGL(k_mf_factor, dim3((unsigned)g.count, (unsigned)s->batch), dim3(MF_THREADS), g.lds_factor, s->stream, s->md, MfSlots{}, g.first);
         return;
     }
     const size_t lds = s->lds_acc ? sizeof(double) * (size_t)s->n : 0;
@@ -375,6 +410,99 @@ void enqueue_factor(calipso_hip_sparse* s) {
 }
 
 }  // namespace
+
+
+// ---- hooks for the Newton handle (ldl.hip): the Schur complement S of a stage-structured problem through the multifrontal path -----------------
+// S lives densely (column-major, leading dimension NP) in every instance's slab; `src` holds, for each entry of the analysed pattern, its offset
+// row + col * NP.  Everything is enqueued on the CALLER's stream; nothing synchronises.
+namespace {
+__global__ void k_gather_dense(calipso::Batch bt, const double* __restrict__ S, const long long* __restrict__ src, long long nnz, double* __restrict__ Aval) {
+    calipso::inst_shift(bt, S);
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nnz) Aval[(size_t)bt.slot[blockIdx.z] * (size_t)nnz + (size_t)q] = S[src[q]];
+}
+__global__ void k_permute_in_slab(calipso::Batch bt, const double* __restrict__ x, const int* __restrict__ perm, int n, double* __restrict__ dx) {
+    calipso::inst_shift(bt, x);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[(size_t)blockIdx.z * n + i] = x[perm[i]];
+}
+__global__ void k_permute_out_slab(calipso::Batch bt, const double* __restrict__ dx, const int* __restrict__ perm, int n, double* __restrict__ x) {
+    calipso::inst_shift(bt, x);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[perm[i]] = dx[(size_t)blockIdx.z * n + i];
+}
+// compute_inertia! (linear_solver.jl:33-44) of the S block: signs of its n pivots added to the handle's counters (icount[3..5] = positive, non-positive, zero)
+__global__ __launch_bounds__(256) void k_count_signs(calipso::Batch bt, const double* __restrict__ D, int n, int* __restrict__ icount) {
+    calipso::inst_shift_i(bt, icount);
+    __shared__ int sh[3][4];
+    const double* Dz = D + (size_t)bt.slot[blockIdx.z] * n;
+    int pos = 0, nonpos = 0, zero = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { const double v = Dz[i]; pos += v > 0.0; nonpos += !(v > 0.0); zero += v == 0.0; }
+    pos = calipso::wave_sum_i(pos); nonpos = calipso::wave_sum_i(nonpos); zero = calipso::wave_sum_i(zero);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = pos; sh[1][threadIdx.x >> 6] = nonpos; sh[2][threadIdx.x >> 6] = zero; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        icount[3] += sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        icount[4] += sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        icount[5] += sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+    }
+}
+}  // namespace
+
+namespace calipso {
+bool sparse_is_multifrontal(const calipso_hip_sparse* sp) { return sp && sp->mf; }
+int sparse_batch(const calipso_hip_sparse* sp) { return sp ? sp->batch : 0; }
+// gather the pattern's entries from the dense S of every instance of `bt`, factor, add the pivot signs to the instances' counters
+int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, const double* S, const long long* src, int* icount) {
+    if (!sp || !sp->mf || bt.n > sp->batch) return CALIPSO_ERR_ARGUMENT;
+    for (int k = 0; k < bt.n; ++k) if (bt.slot[k] >= sp->batch) return CALIPSO_ERR_ARGUMENT;
+    const unsigned nz = (unsigned)bt.n;
+    hipLaunchKernelGGL(k_gather_dense, dim3((unsigned)((sp->nnzA + 255) / 256), 1, nz), dim3(256), 0, st, bt, S, src, (long long)sp->nnzA, sp->d_Aval);
+    MfSlots sl{};
+    sl.use = 1;
+    for (int k = 0; k < bt.n; ++k) sl.slot[k] = bt.slot[k];
+    for (const MfSeg& g : sp->mplan) hipLaunchKernelGGL(k_mf_factor, dim3((unsigned)g.count, nz), dim3(MF_THREADS), g.lds_factor, st, sp->md, sl, g.first);
+    hipLaunchKernelGGL(k_count_signs, dim3(1, 1, nz), dim3(256), 0, st, bt, sp->d.D, sp->n, icount);
+    sp->factored = true;
+    return CALIPSO_OK;
+}
+// x <- S^-1 x for the first n entries of every instance's x (a slab buffer)
+int sparse_solve_inplace(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, double* x) {
+    if (!sp || !sp->mf || bt.n > sp->batch) return CALIPSO_ERR_ARGUMENT;
+    const unsigned nz = (unsigned)bt.n, gx = (unsigned)((sp->n + 255) / 256);
+    MfSlots sl{};
+    sl.use = 1;
+    for (int k = 0; k < bt.n; ++k) { if (bt.slot[k] >= sp->batch) return CALIPSO_ERR_ARGUMENT; sl.slot[k] = bt.slot[k]; }
+    hipLaunchKernelGGL(k_permute_in_slab, dim3(gx, 1, nz), dim3(256), 0, st, bt, x, sp->d_perm, sp->n, sp->d_x);
+    for (const MfSeg& g : sp->mplan)
+        hipLaunchKernelGGL(k_mf_forward, dim3((unsigned)g.count, nz), dim3(MF_THREADS), g.lds_solve, st, sp->md, sl, g.first, sp->n, 1, sp->usum, sp->d_x);
+    for (auto g = sp->mplan.rbegin(); g != sp->mplan.rend(); ++g)
+        hipLaunchKernelGGL(k_mf_backward, dim3((unsigned)g->count, nz), dim3(MF_THREADS), g->lds_solve, st, sp->md, sl, g->first, sp->n, 1, sp->d_x);
+    hipLaunchKernelGGL(k_permute_out_slab, dim3(gx, 1, nz), dim3(256), 0, st, bt, sp->d_x, sp->d_perm, sp->n, x);
+    return CALIPSO_OK;
+}
+// buffers for in-place solves of `batch` instances with one right-hand side each (sparse_solve_inplace allocates nothing)
+int sparse_reserve_solve(calipso_hip_sparse* s, int batch) {
+    PK(hipSetDevice(s->device));
+    const size_t need = (size_t)s->n * (size_t)batch;
+    if (need > s->cap_rhs) {
+        if (s->d_rhs) (void)hipFree(s->d_rhs);
+        if (s->d_x) (void)hipFree(s->d_x);
+        s->d_rhs = s->d_x = nullptr; s->cap_rhs = 0;
+        PK(hipMalloc((void**)&s->d_rhs, sizeof(double) * need)); PK(hipMalloc((void**)&s->d_x, sizeof(double) * need));
+        s->cap_rhs = need;
+    }
+    const size_t need_u = (size_t)std::max<long long>(s->usum, 1) * (size_t)batch;
+    if (need_u > s->cap_uvec) {
+        if (s->md.uvec) (void)hipFree(s->md.uvec);
+        s->md.uvec = nullptr; s->cap_uvec = 0;
+        PK(hipMalloc((void**)&s->md.uvec, sizeof(double) * need_u));
+        s->cap_uvec = need_u;
+    }
+    return CALIPSO_OK;
+}
+void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]) { out[0] = sp->levels; out[1] = sp->max_front; out[2] = sp->nnzU; out[3] = sp->mf ? 2 : (sp->lds_acc ? 1 : 0); }
+}  // namespace calipso
 
 extern "C" {
 
@@ -512,14 +640,26 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
         a = b;
     }
     // ---- multifrontal symbolic phase (method 4): the dissection pieces as supernodes
-    bool use_mf = method == 4 && !pieces.empty();
-    const int NN = (int)pieces.size();
+    // A piece the level structure could not split (a clique-like stage block) or a wide separator is cut into a chain of chunks of <= w columns;
+    // w is lowered until every front (chunk + its rows below) fits one CU's LDS — e.g. 56 for stages of 56 variables, where chunks that straddle
+    // two stages would carry both stages' neighbours.
+    bool use_mf = false;
+    const std::vector<std::pair<int, int>> base_pieces = pieces;
+    int NN = 0;
     std::vector<int> m_first, m_cols, m_rows, m_parent, m_rowptr, m_rowsv, m_rel, m_childptr, m_children, m_order, m_Aloc;
     std::vector<long long> m_panel_off, m_upd_off, m_u_off;
     std::vector<MfSeg> mplan;
     long long panel_total = 0, upd_total = 0, usum = 0;
     int max_front = 0, mf_levels = 0, mf_widest = 0;
-    if (use_mf) {
+    for (int width : {64, 56, 48, 40, 32, 24, 16}) {
+        if (method != 4 || base_pieces.empty() || use_mf) break;
+        pieces.clear();
+        for (const auto& bp : base_pieces) for (int o = 0; o < bp.second; o += width) pieces.push_back({bp.first + o, std::min(width, bp.second - o)});
+        NN = (int)pieces.size();
+        use_mf = true;
+        max_front = 0;
+        m_rowsv.clear(); m_children.clear(); mplan.clear(); panel_total = upd_total = usum = 0; mf_widest = 0;
+        {
         std::vector<int> node_of((size_t)n, -1);
         for (int t = 0; t < NN; ++t) for (int q = 0; q < pieces[(size_t)t].second; ++q) node_of[(size_t)(pieces[(size_t)t].first + q)] = t;
         for (int j = 0; j < (int)n; ++j) if (node_of[(size_t)j] < 0) use_mf = false;
@@ -601,6 +741,7 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
             }
             mf_levels = (int)mplan.size();
         }
+    }
     }
     // ---- the handle and its device side
     s = new calipso_hip_sparse();
@@ -749,9 +890,9 @@ static int32_t sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const double* b
             s->cap_uvec = need_u;
         }
         for (const MfSeg& g : s->mplan)
-            hipLaunchKernelGGL(k_mf_forward, dim3((unsigned)g.count, ny), dim3(MF_THREADS), g.lds_solve, s->stream, s->md, g.first, s->n, (int)nrhs, s->usum, s->d_x);
+            hipLaunchKernelGGL(k_mf_forward, dim3((unsigned)g.count, ny), dim3(MF_THREADS), g.lds_solve, s->stream, s->md, MfSlots{}, g.first, s->n, (int)nrhs, s->usum, s->d_x);
         for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g)
-            hipLaunchKernelGGL(k_mf_backward, dim3((unsigned)g->count, ny), dim3(MF_THREADS), g->lds_solve, s->stream, s->md, g->first, s->n, (int)nrhs, s->d_x);
+            hipLaunchKernelGGL(k_mf_backward, dim3((unsigned)g->count, ny), dim3(MF_THREADS), g->lds_solve, s->stream, s->md, MfSlots{}, g->first, s->n, (int)nrhs, s->d_x);
     } else {
         for (int z = 0; z < s->batch; ++z) {
             SpDev d = s->d;

@@ -10,6 +10,7 @@
 // The structure is taken from the non-zero pattern of the blocks currently held by the handle (calipso_hip_analyze_structure):
 // the reference gets the same information from its sparsity pattern + AMD ordering (qdldl.jl:134-188).  Default = dense.
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "internal.hpp"
@@ -34,6 +35,7 @@ __global__ void k_check_rows(int rows, int row0, int m, int nx, const double* __
 
 static int structure_clear(calipso_hip_solver* s) {
     s->band64 = 0; s->half_bandwidth = 0;
+    s->stage_parallel = false; s->h_reach.clear();
     const Dims& d = s->d;
     const size_t G = ((size_t)d.nx + 15) / 16;
     std::vector<int> kr(4 * G);
@@ -101,6 +103,20 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
         for (int k = st; k < st + dim; ++k) { cmin[k] = lo; cmax[k] = hi; }
     }
     for (int k = 0; k < m; ++k) if (cmax[k] >= cmin[k]) hb = std::max<long>(hb, cmax[k] - cmin[k]);
+    // skyline of S (column j of the lower triangle reaches down to row reach[j]): S = Lxx + sum over constraint rows of an outer product over the
+    // row's column range, so j is coupled to everything up to the furthest end of a range that contains it (and to its Lxx neighbours)
+    {
+        std::vector<int>& reach = s->h_reach;
+        reach.assign((size_t)nx, 0);
+        for (int j = 0; j < nx; ++j) reach[(size_t)j] = j;
+        for (int j = 0; j < nx; ++j)
+            for (int i = 0; i < nx; ++i)
+                if (L[i + (size_t)j * nx] != 0.0) { const int lo = std::min(i, j), hi = std::max(i, j); reach[(size_t)lo] = std::max(reach[(size_t)lo], hi); }
+        std::vector<int> ext((size_t)nx, -1);                 // furthest range end among the ranges STARTING at a column
+        for (int k = 0; k < m; ++k) if (cmax[k] >= cmin[k]) ext[(size_t)cmin[k]] = std::max(ext[(size_t)cmin[k]], cmax[k]);
+        int run = -1;                                         // furthest end among the ranges that started at or before j
+        for (int j = 0; j < nx; ++j) { run = std::max(run, ext[(size_t)j]); if (run >= j) reach[(size_t)j] = std::max(reach[(size_t)j], run); }
+    }
     // per 16-column group: the range of equality rows / cone rows whose column range overlaps the group
     const int G = (nx + 15) / 16;
     std::vector<int> kr(4 * (size_t)G);
@@ -142,6 +158,56 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
 int32_t calipso_hip_clear_structure(calipso_hip_solver* s) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
     return structure_clear(s);
+}
+
+
+// Stage-parallel factorisation of the Schur complement.  After calipso_hip_analyze_structure: S is treated as the sparse matrix
+// its skyline describes, ordered by nested dissection — for a trajectory problem the separators are single stages — and factored by the
+// multifrontal LDL^T of sparse.hip: log2(stages) launches instead of the chain of nx pivots of the blocked factorisation; the triangular solves
+// run over the same tree.  `batch` >= the largest group this handle will lead (1 for a handle stepped alone).  Pivot signs (inertia) are those of
+// the blocked factorisation (Sylvester); values agree to rounding, not bitwise (another elimination order).  on = 0 switches back.
+// info (may be NULL) = [tree levels, rows of the largest front, nnz of the pattern of S (upper triangle), numeric phase (2 = multifrontal)].
+int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_t batch, int64_t info[4]) {
+    if (!s || batch < 1 || batch > MAX_BATCH) return CALIPSO_ERR_ARGUMENT;
+    CK(hipSetDevice(s->device));
+    CK(hipStreamSynchronize(s->stream));
+    if (s->spS) { (void)calipso_hip_sparse_destroy(s->spS); s->spS = nullptr; }
+    if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
+    s->stage_parallel = false;
+    if (!on) return CALIPSO_OK;
+    const int nx = s->d.nx, NP = s->d.NP;
+    if ((int)s->h_reach.size() != nx) { s->err = "calipso_hip_set_stage_parallel: call calipso_hip_analyze_structure first"; return CALIPSO_ERR_ARGUMENT; }
+    // upper-triangular CSC pattern (1-based) of the skyline: entry (r, c), r <= c, iff reach[r] >= c
+    std::vector<int64_t> colptr((size_t)nx + 1, 0), rowval;
+    for (int r = 0; r < nx; ++r) for (int c = r; c <= s->h_reach[(size_t)r]; ++c) colptr[(size_t)c + 1] += 1;
+    colptr[0] = 1;
+    for (int c = 0; c < nx; ++c) colptr[(size_t)c + 1] += colptr[(size_t)c];
+    rowval.resize((size_t)(colptr[(size_t)nx] - 1));
+    std::vector<long long> src(rowval.size());
+    {
+        std::vector<int64_t> next(colptr.begin(), colptr.end() - 1);
+        for (int r = 0; r < nx; ++r)                                   // ascending r => rows sorted inside every column
+            for (int c = r; c <= s->h_reach[(size_t)r]; ++c) {
+                const int64_t at = next[(size_t)c]++ - 1;
+                rowval[(size_t)at] = r + 1;
+                src[(size_t)at] = (long long)c + (long long)r * NP;   // S holds its lower triangle: entry (row c, column r)
+            }
+    }
+    calipso_hip_sparse* sp = nullptr;
+    int rc = calipso_hip_sparse_create(nx, colptr.data(), rowval.data(), 4, nullptr, s->device, &sp);
+    if (rc != CALIPSO_OK || !sparse_is_multifrontal(sp)) {
+        s->err = rc != CALIPSO_OK ? std::string("calipso_hip_set_stage_parallel: ") + calipso_hip_sparse_last_error(sp)
+                                  : std::string("calipso_hip_set_stage_parallel: a front of the dissection of S exceeds one CU's LDS (196 rows): the blocked factorisation stays");
+        if (sp) (void)calipso_hip_sparse_destroy(sp);
+        return rc != CALIPSO_OK ? rc : CALIPSO_ERR_ARGUMENT;
+    }
+    if (batch > 1 && (rc = calipso_hip_sparse_set_batch(sp, batch)) != CALIPSO_OK) { (void)calipso_hip_sparse_destroy(sp); return rc; }
+    if ((rc = sparse_reserve_solve(sp, batch)) != CALIPSO_OK) { (void)calipso_hip_sparse_destroy(sp); return rc; }
+    CK(hipMalloc((void**)&s->spS_src, sizeof(long long) * std::max<size_t>(src.size(), 1)));
+    CK(hipMemcpy(s->spS_src, src.data(), sizeof(long long) * src.size(), hipMemcpyHostToDevice));
+    s->spS = sp; s->stage_parallel = true;
+    if (info) sparse_describe(sp, info);
+    return CALIPSO_OK;
 }
 
 }  // extern "C"

@@ -270,6 +270,13 @@ int32_t calipso_hip_group_solve(calipso_hip_group*, int32_t* result);
  * out[2], out[3] = average number of equality / cone rows a 16-column group visits.  out may be NULL. */
 int32_t calipso_hip_analyze_structure(calipso_hip_solver*, int64_t out[4]);
 int32_t calipso_hip_clear_structure(calipso_hip_solver*);
+/* Stage-parallel factorisation of the Schur complement (the reference gets its parallel-free equivalent from AMD + sparse QDLDL,
+ * qdldl.jl:134-188,400-589): after calipso_hip_analyze_structure, S is factored by the multifrontal sparse LDL^T over a nested dissection of its
+ * skyline pattern (for a trajectory problem: log2(stages) launches instead of the chain of nx pivots) and solved over the same tree.  `batch` >= the
+ * largest group this handle will lead (1 for a handle stepped alone).  Same inertia as the blocked factorisation; values agree to rounding.
+ * info (may be NULL) = [tree levels, rows of the largest front, nnz(triu) of the pattern of S, 2].  on = 0 switches back.  Fails (and keeps the
+ * blocked factorisation) when a front would exceed one CU's LDS (196 rows). */
+int32_t calipso_hip_set_stage_parallel(calipso_hip_solver*, int32_t on, int32_t batch, int64_t info[4]);
 
 /* ---- LinearSolver seam (src/solver/linear_solver.jl:1-60) ----------------------------------------------------------------------
  * A stand-alone device LDL^T for ANY sparse symmetric quasi-definite matrix the caller assembled itself, so that the reference's own

@@ -83,8 +83,9 @@ def test_group_of_banded_members():
     g.close()
 
 
+@pytest.mark.parametrize("stage_parallel", [False, True])
 @pytest.mark.parametrize("shape", [STAGED[0], STAGED[2], (12, 40, 30, 4, 2, 3)])
-def test_banded_step_matches_the_oracle(oracle_mod, shape):
+def test_banded_step_matches_the_oracle(oracle_mod, shape, stage_parallel):
     """f1 against the ORACLE (not against the dense device path): one inner Newton iteration of a stage-structured problem with the
     banded treatment on — step, residual, inertia, refinement rounds, cone step sizes — equals the CPU restatement, whose sparse
     up-looking LDL^T (qdldl.jl:400-589 restated) factors the same structured K.  Tolerances of SURVEY.md 8(c)."""
@@ -92,6 +93,12 @@ def test_banded_step_matches_the_oracle(oracle_mod, shape):
     prob, s = build(pkg, 11, *shape)
     info = s.analyze_structure()
     assert info["band_blocks"] > 0
+    if stage_parallel:                      # S through the multifrontal sparse LDL^T over a nested dissection of its pattern
+        if shape == STAGED[2]:
+            with pytest.raises(pkg.CalipsoHipError):      # stages of 100 variables: fronts of 300 rows do not fit one CU's LDS — refused, blocked path stays
+                s.set_stage_parallel(True)
+        else:
+            assert s.set_stage_parallel(True)["largest_front"] <= 196
     w = s.get("solution", s.N)
     lam = s.get("dual", s.ne)
     step_info = s.newton_step(advance=False)
@@ -131,3 +138,53 @@ def test_banded_step_matches_the_oracle(oracle_mod, shape):
     s.set("residual_symmetric", b)
     s.linear_solve()
     assert np.abs(s.get("step_symmetric", o.n) - o.linear_solve(b, fact=False)).max() <= 1e-8 * max(1.0, np.abs(o.linear_solve(b, fact=False)).max())
+
+
+@pytest.mark.parametrize("shape", [STAGED[0], STAGED[1], (16, 24, 16, 3, 1, 3)])
+def test_stage_parallel_factorisation_matches_the_blocked_one(shape):
+    """calipso_hip_set_stage_parallel: S factored by the multifrontal sparse LDL^T over a nested dissection of its pattern (log2(stages) launches) instead
+    of the blocked LDL^T.  Another elimination order: same inertia and decisions, values to rounding."""
+    pkg = load_pkg()
+    prob, ref = build(pkg, 5, *shape)
+    _, par = build(pkg, 5, *shape)
+    ref.analyze_structure()
+    par.analyze_structure()
+    info = par.set_stage_parallel(True)
+    T = shape[0]
+    assert info["levels"] <= int(np.ceil(np.log2(T))) + 4 and info["largest_front"] <= 196
+    assert ref.factorize() == par.factorize()                        # (inertia, regularisation path)
+    for it in range(3):
+        a = ref.newton_step(advance=True)
+        b = par.newton_step(advance=True)
+        for key in ("status", "factorizations", "refinement_rounds", "cone_halvings_s", "cone_halvings_t", "line_search_iterations"):
+            if key in a:
+                assert a[key] == b[key], (it, key, a, b)
+        sa, sb = ref.data("step").all, par.data("step").all
+        assert np.abs(sa - sb).max() <= 1e-9 * max(1.0, np.abs(sa).max())
+        assert np.abs(ref.solution.all - par.solution.all).max() <= 1e-9 * max(1.0, np.abs(ref.solution.all).max())
+    # and back: the blocked factorisation again, bit for bit
+    par.set_stage_parallel(False)
+    par.set("solution", ref.solution.all); par.set("dual", ref.get("dual", ref.ne))
+    par.qp_evaluate(pkg.FLAGS["objective"] | pkg.FLAGS["equality_constraint"] | pkg.FLAGS["cone_constraint"], 0)
+    a, b = ref.newton_step(advance=False), par.newton_step(advance=False)
+    assert a["status"] == b["status"] == 0
+
+
+def test_group_led_by_a_stage_parallel_handle():
+    pkg = load_pkg()
+    shape = STAGED[0]
+    singles = [build(pkg, p, *shape)[1] for p in (7, 8, 9)]
+    members = [build(pkg, p, *shape)[1] for p in (7, 8, 9)]
+    for m in singles + members:
+        m.analyze_structure()
+    for s in singles:
+        s.set_stage_parallel(True)
+    members[0].set_stage_parallel(True, batch=3)
+    g = pkg.Group(members)
+    for it in range(2):
+        ref = [s.newton_step(advance=True) for s in singles]
+        got = g.newton_step(advance=True)
+        for a, b, s, m in zip(ref, got, singles, members):
+            assert a == b and a["status"] == 0
+            assert np.array_equal(s.solution.all, m.solution.all)        # a member gets the bits of the same handle stepped alone
+    g.close() if hasattr(g, "close") else None
