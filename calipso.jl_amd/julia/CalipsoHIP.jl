@@ -375,6 +375,12 @@ function analyze_structure!(hs::HIPSolver)
     return Tuple(out)
 end
 clear_structure!(hs::HIPSolver) = check(hs.handle, ccall((:calipso_hip_clear_structure, lib), Int32, (Ptr{Cvoid},), hs.handle), "clear_structure!")
+"After `analyze_structure!`: factor the Schur complement by the multifrontal sparse LDL' over a nested dissection of its pattern (log2(stages) launches instead of the chain of nx pivots); `batch` >= the largest group this solver leads. Returns (tree levels, largest front, nnz of the pattern, 2)."
+function set_stage_parallel!(hs::HIPSolver, on::Bool=true; batch::Integer=1)
+    out = zeros(Int64, 4)
+    check(hs.handle, ccall((:calipso_hip_set_stage_parallel, lib), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Int64}), hs.handle, on ? 1 : 0, batch, out), "set_stage_parallel!")
+    return Tuple(out)
+end
 
 # ---- groups: many same-shape solvers stepped through the same kernel launches (BASELINE config C4) ------------------------------
 "Up to 16 `HIPSolver`s of one shape on one device; `newton_step!` advances every member by one inner iteration of solve!."
@@ -454,6 +460,6 @@ function allreduce_sum!(c::HIPComm, v::Vector{Float64})
 end
 
 export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPComm, comm_unique_id, gather_status, allreduce_sum!, newton_step!,
-       search_direction_nonsymmetric!, analyze_structure!, clear_structure!, sync_scalars!, copy_back!
+       search_direction_nonsymmetric!, analyze_structure!, clear_structure!, set_stage_parallel!, sync_scalars!, copy_back!
 
 end # module
