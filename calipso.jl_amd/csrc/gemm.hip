@@ -69,6 +69,10 @@ __global__ void k_scale_rows_by_dinv(int NP, int p, const double* __restrict__ D
 // Z = D^-1 U ; backward  V_k = Tinv_k' Z_k ; Z_above -= L[k,above]' V_k.  U and Z are NP x p scratch.
 void trsm_multi(calipso_hip_solver* s, double* X, int p, double* U, double* Zm) {
     const int NP = s->d.NP, tb = NP < 512 ? NP : 512, nb = NP / tb;
+    if (s->stage_parallel && s->spS) {        // the factor lives in the fronts of sparse.hip (calipso_hip_set_stage_parallel): column by column over the tree
+        for (int j = 0; j < p; ++j) launch_trsv(s, X + (size_t)j * NP);
+        return;
+    }
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = kb * tb;
         gemm(s, tb, p, tb, 1.0, s->Tinv + (size_t)kb * tb * tb, tb, false, X + k0, NP, 0.0, U + k0, NP);

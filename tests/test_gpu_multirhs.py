@@ -30,3 +30,24 @@ def test_sensitivities_all_columns_match_oracle(oracle_mod, shape):
         for j in (0, prob.np // 2, prob.np - 1):
             Hs = g.jacobian_variables_mul(S_gpu[:, j])
             assert np.abs(Hs + J[:, j]).max() <= 1e-7 * max(1.0, np.abs(J[:, j]).max(), np.abs(S_gpu[:, j]).max())
+
+
+@pytest.mark.parametrize("shape", [(70, 20, 6, 5, 3), (150, 60, 20, 8, 4)])
+def test_sensitivities_with_the_stage_parallel_factorisation(oracle_mod, shape):
+    """differentiate! when S is held by the multifrontal factorisation (calipso_hip_set_stage_parallel): the block triangular solves of gemm.hip have no
+    dense factor to read, the right-hand sides go through the tree instead — same sensitivities"""
+    nx, ne, n_nn, n_soc, dim = shape
+    prob = pr.parametric_conic_qp(nx, ne, n_nn, n_soc, dim, seed=nx)
+    pt, lam = interior_point(prob, 3)
+    o, g = make_pair(oracle_mod, prob, pt, lam, ep=1e-5, ed=1e-5)
+    o.cone(product=True, jacobian=True, target=True)
+    g.cone(product=True, jacobian=True, target=True)
+    g.analyze_structure()
+    info = g.set_stage_parallel(True)           # a dense S of this size is one chain of <= 64-column fronts
+    assert info["largest_front"] <= 196
+    assert o.differentiate(prob) >= 0
+    g.differentiate()
+    S_cpu = o.mat("solution_sensitivity", o.N, prob.np)
+    S_gpu = g.data("solution_sensitivity")
+    scale = max(1.0, np.abs(S_cpu).max())
+    assert np.abs(S_gpu - S_cpu).max() <= 1e-8 * scale, (np.abs(S_gpu - S_cpu).max(), scale)
