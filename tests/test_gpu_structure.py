@@ -188,3 +188,23 @@ def test_group_led_by_a_stage_parallel_handle():
             assert a == b and a["status"] == 0
             assert np.array_equal(s.solution.all, m.solution.all)        # a member gets the bits of the same handle stepped alone
     g.close() if hasattr(g, "close") else None
+
+
+def test_whole_solve_with_the_three_treatments():
+    """solve! (src/solver/solve.jl:8-377) of a stage-structured conic QP evaluated on the device: dense treatment, stage-banded blocked factorisation,
+    stage-parallel multifrontal factorisation — the same iteration counts and the same solution (bitwise for the first two)"""
+    pkg = load_pkg()
+    shape = (16, 24, 16, 3, 1, 3)
+    sols, stats = [], []
+    for mode in ("dense", "banded", "stage_parallel"):
+        prob, s = build(pkg, 21, *shape)
+        if mode != "dense":
+            s.analyze_structure()
+        if mode == "stage_parallel":
+            s.set_stage_parallel(True)
+        assert pkg.solve_b(s)
+        st = s.stats()
+        sols.append(s.solution.all.copy()); stats.append((st["total_iterations"], st["outer"]))
+    assert stats[0] == stats[1] == stats[2], stats
+    assert np.array_equal(sols[0], sols[1])
+    assert np.abs(sols[2] - sols[0]).max() <= 1e-7 * max(1.0, np.abs(sols[0]).max())
