@@ -170,14 +170,18 @@ struct MfDev {
 struct MfSlots { int use; int slot[calipso::MAX_BATCH]; };
 
 typedef double calipso_v4d __attribute__((ext_vector_type(4)));
-constexpr int MF_THREADS = 256;
+// threads per front: 256 for small fronts (several workgroups share a CU), 512 for fronts of more than MF_BIG rows (one front fills the CU's LDS
+// anyway; more waves shorten the panel, assembly and matrix-core phases)
+constexpr int MF_BIG = 96;
 constexpr int MF_MAX_FRONT = 196;             // (m (m + 1) / 2 + 2 m) doubles <= 160 KiB: the front's lower triangle, packed, + the pivot-column buffers
 
 // The front is symmetric: only its lower triangle is held, packed row by row (row i starts at i (i + 1) / 2), which lets fronts of up to 196 rows
 // fit the 160 KiB of LDS (a full square would stop at 141).
 __device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }     // i >= k
 
+template <int MF_THREADS>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first) {
+    constexpr int MF_RC = MF_THREADS / 16;        // row classes of the panel step (16 panel columns x MF_RC rows at a time)
     extern __shared__ __attribute__((aligned(16))) double F[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r, nt = m * (m + 1) / 2;
@@ -215,12 +219,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
             const double dj = F[tri(j, j)];
             const double rj = 1.0 / dj;
             if (tid == 0) { Dg[f + j] = dj; rinv[j] = rj; }
-            const int k = j + 1 + (tid & 15);                                  // 16 x 16 threads over (row, panel column)
+            const int k = j + 1 + (tid & 15);                                  // MF_RC x 16 threads over (row, panel column)
             if (k < pe) {
                 const double ykj = F[tri(k, j)] * rj;
                 int i = j + 1 + (tid >> 4);                                      // rows i >= k of this thread's residue class
-                if (i < k) i += ((k - i + 15) >> 4) << 4;
-                for (; i < m; i += 16) {
+                if (i < k) i += ((k - i + MF_RC - 1) / MF_RC) * MF_RC;
+                for (; i < m; i += MF_RC) {
                     double* Fi = F + i * (i + 1) / 2;
                     Fi[k] -= Fi[j] * ykj;
                 }
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
 }
 
 // forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors
+template <int MF_THREADS>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
@@ -289,6 +294,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
     for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a];
 }
 // backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C
+template <int MF_THREADS>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
@@ -316,7 +322,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
     for (int i = tid; i < c; i += MF_THREADS) x[f + i] = v[i];
 }
 
-struct MfSeg { int first, count; size_t lds_factor, lds_solve; };
+struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; };
+// launch helpers: the thread count of a level is fixed by the analyse phase (MfSeg::threads)
+#define MF_LAUNCH(KERNEL, G, GRID, LDS, STREAM, ...)                                                                              \
+    do {                                                                                                                          \
+        if ((G).threads == 512) hipLaunchKernelGGL(KERNEL<512>, GRID, dim3(512), LDS, STREAM, __VA_ARGS__);                       \
+        else hipLaunchKernelGGL(KERNEL<256>, GRID, dim3(256), LDS, STREAM, __VA_ARGS__);                                         \
+    } while (0)
+
 
 struct Segment { int first, count; bool chain; };
 
@@ -394,7 +407,7 @@ int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
 void enqueue_factor(calipso_hip_sparse* s) {
     if (s->mf) {
         for (const MfSeg& g : s->mplan)
-            hipLaunchKernelGGL(k_mf_factor, dim3((unsigned)g.count, (unsigned)s->batch), dim3(MF_THREADS), g.lds_factor, s->stream, s->md, MfSlots{}, g.first);
+            MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, (unsigned)s->batch), g.lds_factor, s->stream, s->md, MfSlots{}, g.first);
         return;
     }
     const size_t lds = s->lds_acc ? sizeof(double) * (size_t)s->n : 0;
@@ -461,7 +474,7 @@ int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch
     MfSlots sl{};
     sl.use = 1;
     for (int k = 0; k < bt.n; ++k) sl.slot[k] = bt.slot[k];
-    for (const MfSeg& g : sp->mplan) hipLaunchKernelGGL(k_mf_factor, dim3((unsigned)g.count, nz), dim3(MF_THREADS), g.lds_factor, st, sp->md, sl, g.first);
+    for (const MfSeg& g : sp->mplan) MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, nz), g.lds_factor, st, sp->md, sl, g.first);
     hipLaunchKernelGGL(k_count_signs, dim3(1, 1, nz), dim3(256), 0, st, bt, sp->d.D, sp->n, icount);
     sp->factored = true;
     return CALIPSO_OK;
@@ -475,9 +488,9 @@ int sparse_solve_inplace(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt
     for (int k = 0; k < bt.n; ++k) { if (bt.slot[k] >= sp->batch) return CALIPSO_ERR_ARGUMENT; sl.slot[k] = bt.slot[k]; }
     hipLaunchKernelGGL(k_permute_in_slab, dim3(gx, 1, nz), dim3(256), 0, st, bt, x, sp->d_perm, sp->n, sp->d_x);
     for (const MfSeg& g : sp->mplan)
-        hipLaunchKernelGGL(k_mf_forward, dim3((unsigned)g.count, nz), dim3(MF_THREADS), g.lds_solve, st, sp->md, sl, g.first, sp->n, 1, sp->usum, sp->d_x);
+        MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, nz), g.lds_solve, st, sp->md, sl, g.first, sp->n, 1, sp->usum, sp->d_x);
     for (auto g = sp->mplan.rbegin(); g != sp->mplan.rend(); ++g)
-        hipLaunchKernelGGL(k_mf_backward, dim3((unsigned)g->count, nz), dim3(MF_THREADS), g->lds_solve, st, sp->md, sl, g->first, sp->n, 1, sp->d_x);
+        MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, nz), g->lds_solve, st, sp->md, sl, g->first, sp->n, 1, sp->d_x);
     hipLaunchKernelGGL(k_permute_out_slab, dim3(gx, 1, nz), dim3(256), 0, st, bt, sp->d_x, sp->d_perm, sp->n, x);
     return CALIPSO_OK;
 }
@@ -729,13 +742,14 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
             std::iota(m_order.begin(), m_order.end(), 0);
             std::stable_sort(m_order.begin(), m_order.end(), [&](int a, int b) { return lev[(size_t)a] < lev[(size_t)b]; });
             for (int a = 0; a < NN;) {
-                int b = a; size_t lf = 0, ls = 0;
+                int b = a; size_t lf = 0, ls = 0, mmax = 0;
                 while (b < NN && lev[(size_t)m_order[(size_t)b]] == lev[(size_t)m_order[(size_t)a]]) {
                     const int t = m_order[(size_t)b]; const size_t m = (size_t)(m_cols[(size_t)t] + m_rows[(size_t)t]);
                     lf = std::max(lf, sizeof(double) * (m * (m + 1) / 2 + 2 * m)); ls = std::max(ls, sizeof(double) * (m * (size_t)m_cols[(size_t)t] + m));
+                    mmax = std::max(mmax, m);
                     ++b;
                 }
-                mplan.push_back({a, b - a, lf, ls});
+                mplan.push_back({a, b - a, lf, ls, mmax > (size_t)MF_BIG ? 512 : 256});
                 mf_widest = std::max(mf_widest, b - a);
                 a = b;
             }
@@ -775,9 +789,9 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
             (rc = upload(s, m_children, &md.children)) || (rc = upload(s, m_panel_off, &md.panel_off)) || (rc = upload(s, m_upd_off, &md.upd_off)) ||
             (rc = upload(s, m_u_off, &md.u_off)) || (rc = upload(s, m_Aloc, &md.Aloc))) return rc;
         md.Alp = s->d.Alp; md.Asrc = s->d.Asrc;
-        PK(hipFuncSetAttribute((const void*)k_mf_factor, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PK(hipFuncSetAttribute((const void*)k_mf_forward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PK(hipFuncSetAttribute((const void*)k_mf_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (const void* fn : {(const void*)k_mf_factor<256>, (const void*)k_mf_factor<512>, (const void*)k_mf_forward<256>, (const void*)k_mf_forward<512>,
+                               (const void*)k_mf_backward<256>, (const void*)k_mf_backward<512>})
+            PK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     s->work_slots = std::min(widest, 2048);
     if (s->lds_acc) {
@@ -890,9 +904,9 @@ static int32_t sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const double* b
             s->cap_uvec = need_u;
         }
         for (const MfSeg& g : s->mplan)
-            hipLaunchKernelGGL(k_mf_forward, dim3((unsigned)g.count, ny), dim3(MF_THREADS), g.lds_solve, s->stream, s->md, MfSlots{}, g.first, s->n, (int)nrhs, s->usum, s->d_x);
+            MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, s->stream, s->md, MfSlots{}, g.first, s->n, (int)nrhs, s->usum, s->d_x);
         for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g)
-            hipLaunchKernelGGL(k_mf_backward, dim3((unsigned)g->count, ny), dim3(MF_THREADS), g->lds_solve, s->stream, s->md, MfSlots{}, g->first, s->n, (int)nrhs, s->d_x);
+            MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, s->stream, s->md, MfSlots{}, g->first, s->n, (int)nrhs, s->d_x);
     } else {
         for (int z = 0; z < s->batch; ++z) {
             SpDev d = s->d;
