@@ -83,6 +83,7 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
     const int nx = d.nx, ne = d.ne, nc = d.nc, m = d.m;
     CK(hipSetDevice(s->device));
     CK(hipStreamSynchronize(s->stream));
+    s->stage_parallel = false;             // a new analysis: the multifrontal plan of an earlier pattern no longer applies (calipso_hip_set_stage_parallel again)
     std::vector<double> L((size_t)nx * nx), Z((size_t)std::max(1, m) * nx);
     CK(hipMemcpy(L.data(), s->Lxx, sizeof(double) * L.size(), hipMemcpyDeviceToHost));
     if (m) CK(hipMemcpy(Z.data(), s->Z, sizeof(double) * (size_t)m * nx, hipMemcpyDeviceToHost));
