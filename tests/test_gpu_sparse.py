@@ -190,7 +190,7 @@ def test_rate_report_on_trajectory_kkt_systems(oracle_mod):
         assert row["nested_dissection"]["numeric"] == "multifrontal" and row["nested_dissection"]["factor_ms"] < row["nested_dissection_columns"]["factor_ms"]
         rows.append(row)
     # a batch of independent systems of one structure (BASELINE config C4's shape of work), multifrontal: all matrices in the same launches
-    for T, ns, nu, Bn in ((64, 6, 2, 256), (256, 6, 2, 64), (41, 14, 14, 256)):
+    for T, ns, nu, Bn in ((64, 6, 2, 256), (256, 6, 2, 64), (41, 14, 14, 256), (41, 28, 28, 64)):
         K = staged_kkt(T, ns, nu, rng)
         n = K.shape[0]
         A = sp.triu(K).tocsc(); A.sort_indices()
