@@ -10,8 +10,11 @@
 //                   the panel step and by the triangular solves), counts pivot signs (compute_inertia!,
 //                   linear_solver.jl:33-44) and flags exact zeros (qdldl.jl:579).
 //   k_ldl_panel     Y21 = A21 * L11^-T and L21 = Y21 * D^-1 as a small GEMM with the inverse on the fp64 matrix cores
-//   k_ldl_trailing  A22 -= L21 * Y21'  on the matrix cores: 128 x 128 tiles of the lower triangle, 1024 threads (16
-//                   wavefronts, fp64 MFMA needs >= 4 waves per SIMD), both 128 x 64 operand panels staged in LDS once.
+//   k_ldl_trailing  A22 -= L21 * Y21'  on the matrix cores: 64 x 64 tiles of the lower triangle, 1024 threads (16 wavefronts, one
+//                   16 x 16 MFMA tile each), persistent workgroups, both 64 x 64 operand panels staged in LDS; tile 0 goes on to factor the
+//                   next diagonal block.  <1> / <2>: the pair schedule of groups (two panels applied in one pass).
+// A handle whose S is stage-structured can bypass all of this: calipso_hip_set_stage_parallel routes launch_ldl / launch_trsv to the multifrontal
+// sparse LDL^T of sparse.hip over a nested dissection of S.
 // Triangular solves work on 512-wide blocks: the inverses of the 512 x 512 unit-lower diagonal blocks of L are assembled
 // from the 64 x 64 inverses by three levels of small matrix-core GEMMs (k_tinv_*), so a solve is 2 launches per block
 // instead of a 256-long dependent chain.
@@ -242,8 +245,8 @@ __global__ __launch_bounds__(1024) void k_ldl_panel(Batch bt, int NP, int k0, in
 }
 
 // ---- trailing update A22 -= L21 * Y21' -------------------------------------------------------------------------------------------
-// 64 x 64 tile of the lower triangle per workgroup of 1024 threads (16 wavefronts, one 16 x 16 MFMA tile each; two
-// workgroups fit a CU => 8 wavefronts per SIMD, which fp64 MFMA needs).  Small tiles keep all 256 CUs busy on the shrinking
+// 64 x 64 tile of the lower triangle per workgroup of 1024 threads (16 wavefronts, one 16 x 16 MFMA tile each).  The kernel needs
+// 124-128 VGPRs, so ONE workgroup is resident per CU (4 wavefronts per SIMD; the LDS would admit two).  Small tiles keep all 256 CUs busy on the shrinking
 // trailing matrix.  The tile is computed transposed (MFMA row <-> column j of S) so result stores are 128-byte runs.
 constexpr int TR_THREADS = 1024;
 constexpr int TT = 64;
@@ -460,7 +463,7 @@ static void enqueue_ldl(calipso_hip_solver* s) {
     const unsigned nz = bt.n;
     hipLaunchKernelGGL(k_ldl_diag, dim3(1, 1, nz), dim3(DIAG_THREADS), 0, s->stream, bt, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, s->icount);
     const int band = s->band64 > 0 ? s->band64 : nblk;     // 64-row blocks below a diagonal block that can be non-zero (structure.hip)
-    // persistent workgroups: two fit a CU (LDS, wave slots), so at most 512 are resident; more would only queue
+    // persistent workgroups: one is resident per CU (registers); 256, 512 and 768 launched workgroups time the same (profiles/README.md), 512 is kept
     static const int resident_total = [] { const char* e = getenv("CALIPSO_HIP_LDL_RESIDENT"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
     const int resident = std::max(2, resident_total / (int)nz);
     // Pair schedule (dense S, several instances per launch): panel k, the first tile column of its update (whose tile 0 factors diagonal block
