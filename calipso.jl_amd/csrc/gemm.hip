@@ -69,7 +69,9 @@ __global__ void k_scale_rows_by_dinv(int NP, int p, const double* __restrict__ D
 // Z = D^-1 U ; backward  V_k = Tinv_k' Z_k ; Z_above -= L[k,above]' V_k.  U and Z are NP x p scratch.
 void trsm_multi(calipso_hip_solver* s, double* X, int p, double* U, double* Zm) {
     const int NP = s->d.NP, tb = NP < 512 ? NP : 512, nb = NP / tb;
-    if (s->stage_parallel && s->spS) {        // the factor lives in the fronts of sparse.hip (calipso_hip_set_stage_parallel): column by column over the tree
+    if (s->stage_parallel && s->spS) {        // the factor lives in the fronts of sparse.hip (calipso_hip_set_stage_parallel): all columns through the tree together
+        const BatchSc bsc = batch_of(s);
+        if (bsc.b.n == 1 && sparse_solve_inplace_multi(s->spS, s->stream, bsc.b.slot[0], X + bsc.b.delta[0], NP, p) == CALIPSO_OK) return;
         for (int j = 0; j < p; ++j) launch_trsv(s, X + (size_t)j * NP);
         return;
     }

@@ -297,6 +297,7 @@ int sparse_batch(const calipso_hip_sparse* sp);
 int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, const double* S, const long long* src, int* icount);
 int sparse_solve_inplace(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, double* x);
 int sparse_reserve_solve(calipso_hip_sparse* sp, int batch);
+int sparse_solve_inplace_multi(calipso_hip_sparse* sp, hipStream_t st, int slot, double* X, long long ld, int p);
 void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]);
 int nested_dissection_pieces(i64 n, const i64* colptr, const i64* rowval, i64* perm, std::vector<std::pair<int, int>>& pieces);   // ordering.hip
 void fill_d(calipso_hip_solver* s, double* p, size_t n, double v);

@@ -444,6 +444,15 @@ __global__ void k_permute_out_slab(calipso::Batch bt, const double* __restrict__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[perm[i]] = dx[(size_t)blockIdx.z * n + i];
 }
+// the p columns of X (leading dimension ld) of ONE instance: blockIdx.y = column
+__global__ void k_permute_in_cols(const double* __restrict__ X, long long ld, const int* __restrict__ perm, int n, double* __restrict__ dx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[(size_t)blockIdx.y * n + i] = X[(size_t)blockIdx.y * ld + perm[i]];
+}
+__global__ void k_permute_out_cols(const double* __restrict__ dx, const int* __restrict__ perm, int n, double* __restrict__ X, long long ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) X[(size_t)blockIdx.y * ld + perm[i]] = dx[(size_t)blockIdx.y * n + i];
+}
 // compute_inertia! (linear_solver.jl:33-44) of the S block: signs of its n pivots added to the handle's counters (icount[3..5] = positive, non-positive, zero)
 __global__ __launch_bounds__(256) void k_count_signs(calipso::Batch bt, const double* __restrict__ D, int n, int* __restrict__ icount) {
     calipso::inst_shift_i(bt, icount);
@@ -463,6 +472,7 @@ __global__ __launch_bounds__(256) void k_count_signs(calipso::Batch bt, const do
 }  // namespace
 
 namespace calipso {
+int sparse_reserve_solve(calipso_hip_sparse* s, int batch);
 bool sparse_is_multifrontal(const calipso_hip_sparse* sp) { return sp && sp->mf; }
 int sparse_batch(const calipso_hip_sparse* sp) { return sp ? sp->batch : 0; }
 // gather the pattern's entries from the dense S of every instance of `bt`, factor, add the pivot signs to the instances' counters
@@ -492,6 +502,24 @@ int sparse_solve_inplace(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt
     for (auto g = sp->mplan.rbegin(); g != sp->mplan.rend(); ++g)
         MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, nz), g->lds_solve, st, sp->md, sl, g->first, sp->n, 1, sp->d_x);
     hipLaunchKernelGGL(k_permute_out_slab, dim3(gx, 1, nz), dim3(256), 0, st, bt, sp->d_x, sp->d_perm, sp->n, x);
+    return CALIPSO_OK;
+}
+// X (ld x p, column-major, in the slab of the single instance `slot`) <- S^-1 X: all p right-hand sides through the tree in the same launches
+int sparse_solve_inplace_multi(calipso_hip_sparse* s, hipStream_t st, int slot, double* X, long long ld, int p) {
+    if (!s || !s->mf || slot < 0 || slot >= s->batch || p < 1 || p > 65535) return CALIPSO_ERR_ARGUMENT;
+    const int rc = sparse_reserve_solve(s, p);
+    if (rc != CALIPSO_OK) return rc;
+    MfSlots sl{};
+    sl.use = 1;
+    // every column of the launch belongs to the same factor: with nrhs = p the kernels take slot[blockIdx.y / p] = slot[0]
+    sl.slot[0] = slot;
+    const unsigned gx = (unsigned)((s->n + 255) / 256), ny = (unsigned)p;
+    hipLaunchKernelGGL(k_permute_in_cols, dim3(gx, ny), dim3(256), 0, st, X, ld, s->d_perm, s->n, s->d_x);
+    for (const MfSeg& g : s->mplan)
+        MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, st, s->md, sl, g.first, s->n, p, s->usum, s->d_x);
+    for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g)
+        MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, st, s->md, sl, g->first, s->n, p, s->d_x);
+    hipLaunchKernelGGL(k_permute_out_cols, dim3(gx, ny), dim3(256), 0, st, s->d_x, s->d_perm, s->n, X, ld);
     return CALIPSO_OK;
 }
 // buffers for in-place solves of `batch` instances with one right-hand side each (sparse_solve_inplace allocates nothing)
