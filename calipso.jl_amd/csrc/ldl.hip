@@ -303,6 +303,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
     if (MODE == 1) { ti = t; tj = 0; } else trailing_tile_index(t, ti, tj);
     int i0 = r0 + ti * TT, j0 = r0 + tj * TT;
     double cS[4], lv[4], yv[4];           // operands of the current tile: the entries of S this lane updates, its share of the panels
+    double lv2[4], yv2[4];                // MODE 2: its share of the SECOND panel — each panel's operands are fetched a whole tile ahead
 #pragma unroll
     for (int r = 0; r < 4; ++r) cS[r] = S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP];
 #pragma unroll
@@ -310,40 +311,41 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
         const int c = cb + it * 16;
         lv[it] = Lp[(i0 + row) + (size_t)c * NP];
         yv[it] = Y[(j0 + row) + (size_t)c * NP];
+        if (MODE == 2) {
+            lv2[it] = Lp[(i0 + row) + (size_t)(NB + c) * NP];
+            yv2[it] = Y[(j0 + row) + (size_t)(NB + c) * NP];
+        }
     }
     for (;;) {
         // next tile of this workgroup: its operands travel while the matrix cores work
         const int tn = (t == 0 || stride <= 0) ? ntiles : t + stride;
         int in0 = 0, jn0 = 0;
         double cN[4];
+        if (tn < ntiles) {
+            int a, b;
+            if (MODE == 1) { a = tn; b = 0; } else trailing_tile_index(tn, a, b);
+            in0 = r0 + a * TT; jn0 = r0 + b * TT;
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int c = cb + it * 16;                      // panel column k, natural order
-                Ls[row * LDT + c] = lv[it];
-                Ys[row * LDT + c] = yv[it];
+                Ls[row * LDT + c] = h == 0 ? lv[it] : lv2[it];
+                Ys[row * LDT + c] = h == 0 ? yv[it] : yv2[it];
             }
             lds_barrier();
-            if (h + 1 < NH) {
-                // the second panel of the same tile
+            // the registers just staged are free: fetch the SAME panel's share of the next tile into them (one tile = NH units ahead)
+            if (tn < ntiles) {
+                if (h + 1 == NH) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int c = NB + cb + it * 16;
-                    lv[it] = Lp[(i0 + row) + (size_t)c * NP];
-                    yv[it] = Y[(j0 + row) + (size_t)c * NP];
+                    for (int r = 0; r < 4; ++r) cN[r] = S[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
                 }
-            } else if (tn < ntiles) {
-                int a, b;
-                if (MODE == 1) { a = tn; b = 0; } else trailing_tile_index(tn, a, b);
-                in0 = r0 + a * TT; jn0 = r0 + b * TT;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cN[r] = S[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const int c = cb + it * 16;
-                    lv[it] = Lp[(in0 + row) + (size_t)c * NP];
-                    yv[it] = Y[(jn0 + row) + (size_t)c * NP];
+                    const int c = h * NB + cb + it * 16;
+                    if (h == 0) { lv[it] = Lp[(in0 + row) + (size_t)c * NP]; yv[it] = Y[(jn0 + row) + (size_t)c * NP]; }
+                    else { lv2[it] = Lp[(in0 + row) + (size_t)c * NP]; yv2[it] = Y[(jn0 + row) + (size_t)c * NP]; }
                 }
             }
             v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -354,17 +356,29 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
             {
                 const unsigned lb = (unsigned)(uintptr_t)(Ls + (wr * 16 + fr) * LDT + fk);
                 const unsigned yb = (unsigned)(uintptr_t)(Ys + (wc * 16 + fr) * LDT + fk);
-                double fl[NB / 4], fy[NB / 4];
-#pragma unroll
-                for (int kk = 0; kk < NB / 4; ++kk) {
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fl[kk]) : "v"(lb), "n"(kk * 32) : "memory");
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fy[kk]) : "v"(yb), "n"(kk * 32) : "memory");
+                // a ring of two register groups of four k-steps: the reads of group g + 2 are issued as soon as the MFMAs of group g have taken
+                // their operands, so 16 doubles hold the fragments instead of 32 (the registers freed carry the second operand set above)
+                double fl[8], fy[8];
+#define TR_READ(G, KK0)                                                                                                                    \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                          \
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fl[(G) * 4 + q]) : "v"(lb), "n"(((KK0) + q) * 32) : "memory");     \
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fy[(G) * 4 + q]) : "v"(yb), "n"(((KK0) + q) * 32) : "memory");     \
                 }
-#define TR_WAIT(N, A, B) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fl[A]), "+v"(fy[A]), "+v"(fl[B]), "+v"(fy[B]) :: "memory")
-                TR_WAIT(15, 0, 1); TR_WAIT(15, 2, 3); TR_WAIT(15, 4, 5); TR_WAIT(12, 6, 7); TR_WAIT(8, 8, 9); TR_WAIT(4, 10, 11); TR_WAIT(0, 12, 13); TR_WAIT(0, 14, 15);
+#define TR_WAIT(N, G)                                                                                                                      \
+                asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fl[(G) * 4]), "+v"(fy[(G) * 4]), "+v"(fl[(G) * 4 + 1]), "+v"(fy[(G) * 4 + 1]),   \
+                             "+v"(fl[(G) * 4 + 2]), "+v"(fy[(G) * 4 + 2]), "+v"(fl[(G) * 4 + 3]), "+v"(fy[(G) * 4 + 3]) :: "memory")
+#define TR_MFMA(G)                                                                                                                         \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fy[(G) * 4 + q], fl[(G) * 4 + q], acc, 0, 0, 0);
+                TR_READ(0, 0) TR_READ(1, 4)
+                TR_WAIT(8, 0); TR_MFMA(0)
+                TR_READ(0, 8)
+                TR_WAIT(8, 1); TR_MFMA(1)
+                TR_READ(1, 12)
+                TR_WAIT(8, 0); TR_MFMA(0)
+                TR_WAIT(0, 1); TR_MFMA(1)
+#undef TR_READ
 #undef TR_WAIT
-#pragma unroll
-                for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fy[kk], fl[kk], acc, 0, 0, 0);
+#undef TR_MFMA
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) cS[r] -= acc[r];
