@@ -277,12 +277,16 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), vmcnt / expcnt untouched
     __builtin_amdgcn_s_barrier();
 }
-template <int MODE>
+// FLAT (groups): ONE grid dimension over all instances.  Workgroup w runs on XCD w % 8 (dispatch order; used for speed only); the first bt.n
+// workgroups take tile 0 of one instance each (and then its diagonal block), the others share the remaining (instance, tile) pairs so that every XCD
+// owns a CONTIGUOUS eighth of the instance-major, tile-row-major list: what runs concurrently on an XCD then touches the panels of one or two
+// instances and neighbouring tile rows — they stay in that XCD's 4 MB L2 (with blockIdx.z = instance every XCD saw the panels of all the
+// instances in flight: TCC hit rate 33 %).
+template <int MODE, bool FLAT>
 __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, int nx, int k0, int ntiles, int tb, double* __restrict__ S, const double* __restrict__ Y,
                                                              double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount) {
     __shared__ double smem[FUSED_LDS_DOUBLES];
-    inst_shift(bt, S, Y, Dx, Tinv);
-    inst_shift_i(bt, icount);
+    if (!FLAT) { inst_shift(bt, S, Y, Dx, Tinv); inst_shift_i(bt, icount); }
     constexpr int NH = MODE == 2 ? 2 : 1;   // panels per pass
     double* Ls = smem;                    // Ls[i][k]: rows of the i block of L21
     double* Ys = smem + TT * LDT;         // Ys[j][k]: rows of the j block of Y21
@@ -296,9 +300,25 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
     // still 4 columns x 16 consecutive rows = four full 128-byte runs
     const int row = (lane & 7) + 8 * ((lane >> 4) & 1) + 16 * (wave & 3);
     const int cb = ((lane >> 3) & 1) + 2 * ((lane >> 5) & 1) + 4 * (wave >> 2);   // 0..15
-    const double* Lp = S + (size_t)k0 * NP;
     const int stride = (int)gridDim.x - 1;
     int t = blockIdx.x;
+    long long item = 0, item_end = 0, off = 0;        // FLAT: position in this XCD's share of the (instance, tile) list; slab offset of the instance
+    int istep = 1;
+    if (FLAT) {
+        const int nz = bt.n, W = (int)gridDim.x, lin = (int)blockIdx.x;
+        if (lin < nz) { t = 0; off = bt.delta[lin]; }
+        else {
+            const int k = lin & 7;
+            const int first = nz + ((k - (nz & 7) + 8) & 7);              // first worker of this XCD
+            const int u = (lin - first) >> 3, Uk = first < W ? (W - 1 - first) / 8 + 1 : 0;
+            const long long G = (long long)nz * (ntiles - 1);
+            item = (long long)k * G / 8 + u; item_end = (long long)(k + 1) * G / 8; istep = Uk;
+            if (item >= item_end) return;
+            t = 1 + (int)(item % (ntiles - 1)); off = bt.delta[item / (ntiles - 1)];
+        }
+        S += off; Y += off;
+    }
+    const double* Lp = S + (size_t)k0 * NP;
     int ti, tj;
     if (MODE == 1) { ti = t; tj = 0; } else trailing_tile_index(t, ti, tj);
     int i0 = r0 + ti * TT, j0 = r0 + tj * TT;
@@ -318,7 +338,16 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
     }
     for (;;) {
         // next tile of this workgroup: its operands travel while the matrix cores work
-        const int tn = (t == 0 || stride <= 0) ? ntiles : t + stride;
+        int tn = (t == 0 || stride <= 0) ? ntiles : t + stride;
+        long long doff = 0;                                   // FLAT: slab offset of the next tile's instance relative to the current one
+        if (FLAT) {
+            tn = ntiles;
+            if (t != 0 && item + istep < item_end) {
+                const long long nxt = item + istep;
+                tn = 1 + (int)(nxt % (ntiles - 1));
+                doff = bt.delta[nxt / (ntiles - 1)] - off;
+            }
+        }
         int in0 = 0, jn0 = 0;
         double cN[4];
         if (tn < ntiles) {
@@ -326,6 +355,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
             if (MODE == 1) { a = tn; b = 0; } else trailing_tile_index(tn, a, b);
             in0 = r0 + a * TT; jn0 = r0 + b * TT;
         }
+        const double* Sn = S + doff; const double* Yn = Y + doff; const double* Lpn = Lp + doff;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
 #pragma unroll
@@ -339,13 +369,13 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
             if (tn < ntiles) {
                 if (h + 1 == NH) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) cN[r] = S[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
+                    for (int r = 0; r < 4; ++r) cN[r] = Sn[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
                 }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int c = h * NB + cb + it * 16;
-                    if (h == 0) { lv[it] = Lp[(in0 + row) + (size_t)c * NP]; yv[it] = Y[(jn0 + row) + (size_t)c * NP]; }
-                    else { lv2[it] = Lp[(in0 + row) + (size_t)c * NP]; yv2[it] = Y[(jn0 + row) + (size_t)c * NP]; }
+                    if (h == 0) { lv[it] = Lpn[(in0 + row) + (size_t)c * NP]; yv[it] = Yn[(jn0 + row) + (size_t)c * NP]; }
+                    else { lv2[it] = Lpn[(in0 + row) + (size_t)c * NP]; yv2[it] = Yn[(jn0 + row) + (size_t)c * NP]; }
                 }
             }
             v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -390,6 +420,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) smem[(wr * 16 + fr) * LDD + (wc * 16 + fk + 4 * r)] = cS[r];
             __syncthreads();
+            if (FLAT) { Dx += off; Tinv += off; icount += 2 * off; }
             diag_block<true>(smem, NP, nx, r0, tb, S, Dx, Tinv, icount);
             return;
         }
@@ -397,6 +428,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_trailing(Batch bt, int NP, i
         for (int r = 0; r < 4; ++r) S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP] = cS[r];
         if (tn >= ntiles) return;
         t = tn; i0 = in0; j0 = jn0;
+        if (FLAT) { item += istep; off += doff; S += doff; Y += doff; Lp += doff; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) cS[r] = cN[r];
         lds_barrier();                            // the operand reads of this tile are done before LDS is refilled
@@ -492,18 +524,20 @@ static void enqueue_ldl(calipso_hip_solver* s) {
         hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64, 1, nz), dim3(1024), 0, s->stream, bt, NP, k0, tb, s->S, s->Dx, s->Tinv, s->Ypanel);
         const int ntr = rows / TT;
         if (pairs && kb + 2 < nblk) {
-            hipLaunchKernelGGL(k_ldl_trailing<1>, dim3(std::min(ntr, resident), 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntr, tb, s->S, s->Ypanel, s->Dx,
+            hipLaunchKernelGGL((k_ldl_trailing<1, true>), dim3(std::min(ntr, resident) * nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntr, tb, s->S, s->Ypanel, s->Dx,
                                s->Tinv, s->icount);
             hipLaunchKernelGGL(k_ldl_panel, dim3(rows / 64 - 1, 1, nz), dim3(1024), 0, s->stream, bt, NP, k0 + NB, tb, s->S, s->Dx, s->Tinv, s->Ypanel + (size_t)NP * NB);
             const int ntr2 = ntr - 1, ntiles2 = ntr2 * (ntr2 + 1) / 2;
-            hipLaunchKernelGGL(k_ldl_trailing<2>, dim3(std::min(ntiles2, resident), 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles2, tb, s->S, s->Ypanel,
+            hipLaunchKernelGGL((k_ldl_trailing<2, true>), dim3(std::min(ntiles2, resident) * nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles2, tb, s->S, s->Ypanel,
                                s->Dx, s->Tinv, s->icount);
             kb += 2;
         } else {
             const int ntiles = ntr * (ntr + 1) / 2;
             // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
-            hipLaunchKernelGGL(k_ldl_trailing<0>, dim3(std::min(ntiles, resident), 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S, s->Ypanel,
-                               s->Dx, s->Tinv, s->icount);
+            if (pairs) hipLaunchKernelGGL((k_ldl_trailing<0, true>), dim3(std::min(ntiles, resident) * nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S,
+                                          s->Ypanel, s->Dx, s->Tinv, s->icount);
+            else hipLaunchKernelGGL((k_ldl_trailing<0, false>), dim3(std::min(ntiles, resident), 1, nz), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S,
+                                    s->Ypanel, s->Dx, s->Tinv, s->icount);
             kb += 1;
         }
     }
