@@ -242,16 +242,29 @@ __device__ __forceinline__ void schur_rows(const int* __restrict__ kr, int c0, i
 constexpr size_t SCHUR_LDS_BYTES = 4 * (size_t)TILE * LDK * sizeof(double);
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, const double* __restrict__ Lsym, const double* __restrict__ gx,
                                                           const double* __restrict__ hx, const double* __restrict__ WH, double* __restrict__ S,
-                                                          const int* __restrict__ kr, int hb, int ntiles, int nj) {
+                                                          const int* __restrict__ kr, int hb, int ntiles, int nj, int flat) {
     extern __shared__ __attribute__((aligned(16))) double schur_lds[];
-    inst_shift(bt.b, Lsym, gx, hx, WH, S);
-    inst_shift_i(bt.b, kr);
-    const Scalars sc = bt.sc[blockIdx.z];
-    // XCD-aware remap: block b runs on XCD b % 8 (observed dispatch order; used for speed only): each XCD gets a contiguous
-    // band of the (row-major) tile list, so the operand columns a band needs are shared through that XCD's L2
-    const int chunk = (gridDim.x + 7) / 8;
-    const int t = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
-    if (t >= ntiles) return;
+    // XCD-aware remap over ONE flattened grid: block b runs on XCD b % 8 (observed dispatch order; used for speed only) and every XCD owns a
+    // contiguous eighth of the instance-major, tile-row-major list of (instance, tile) pairs: the tiles an XCD works on at a time belong to one
+    // instance and to neighbouring tile rows, so the operand columns they need are shared through that XCD's L2 (with blockIdx.z = instance
+    // every XCD saw the operands of all the instances in flight).
+    int z, t;
+    if (flat) {
+        const long long G = (long long)bt.b.n * ntiles;
+        const int xk = blockIdx.x & 7;
+        const long long item = (long long)xk * G / 8 + (blockIdx.x >> 3);
+        if (item >= (long long)(xk + 1) * G / 8) return;
+        z = (int)(item / ntiles); t = (int)(item % ntiles);
+    } else {                      // one grid row per instance (blockIdx.z): every XCD gets a contiguous band of each instance's tile list
+        const int chunk = (gridDim.x + 7) / 8;
+        z = blockIdx.z; t = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+        if (t >= ntiles) return;
+    }
+    {
+        const long long o = bt.b.delta[z];
+        Lsym += o; gx += o; hx += o; WH += o; S += o; kr += 2 * o;
+    }
+    const Scalars sc = bt.sc[z];
     const int TJ = 16 * nj;
     int bi, bj;
     if (hb > 0) schur_tile_banded(t, d.nx, TJ, hb, bi, bj);
@@ -450,10 +463,13 @@ void launch_schur(calipso_hip_solver* s) {
     const int hb = s->band64 > 0 ? s->half_bandwidth : 0;       // > 0: only the tiles inside the band (structure.hip)
     const int nj = (B.b.n == 1 && hb == 0) ? s->schur_nj : schur_choose(s->d.nx, B.b.n, hb);
     const int ntiles = schur_tiles(s->d.nx, nj, hb);
-    const int grid = ((ntiles + 7) / 8) * 8;
+    // every XCD gets ceil(n ntiles / 8) workgroups: enough for its share [k G / 8, (k + 1) G / 8) of the list
+    static const int flat_env = [] { const char* e = getenv("CALIPSO_HIP_SCHUR_FLAT"); return e ? atoi(e) : -1; }();
+    const int flat = flat_env >= 0 ? flat_env : 1;
+    const int grid = flat ? (int)(((long long)B.b.n * ntiles + 7) / 8 + 1) * 8 : ((ntiles + 7) / 8) * 8;
     if (s->d.NP > s->d.nx)
         hipLaunchKernelGGL(k_pad_identity, dim3((s->d.NP + 255) / 256, s->d.NP - s->d.nx, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->S);
-    hipLaunchKernelGGL(k_schur, dim3(grid, 1, B.b.n), dim3(SCHUR_THREADS), SCHUR_LDS_BYTES, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, s->krange, hb, ntiles, nj);
+    hipLaunchKernelGGL(k_schur, dim3(grid, 1, flat ? 1 : B.b.n), dim3(SCHUR_THREADS), SCHUR_LDS_BYTES, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, s->krange, hb, ntiles, nj, flat);
 }
 
 }  // namespace calipso
