@@ -235,3 +235,23 @@ def test_group_solve_with_parameters_differentiates_each_member():
         S = s.data("solution_sensitivity")
         assert np.abs(S).max() > 0 and same(S, m.data("solution_sensitivity"))
     grp.close()
+
+
+@pytest.mark.parametrize("n", [5, 7, 13, 16])
+def test_group_sizes_on_the_flattened_grids(n):
+    """the group launches of the Schur complement and of the trailing updates run on ONE flattened grid whose workgroups are dealt to the
+    XCDs by (instance, tile) ranges (schur.hip, ldl.hip): sizes that are not multiples of 8, and the largest group, give the stand-alone bits"""
+    pkg = load_pkg()
+    shape = (700, 250, 60, 30, 3)
+    ids = list(range(200, 200 + n))
+    singles = [build(pkg, p, shape=shape) for p in ids]
+    members = [build(pkg, p, shape=shape) for p in ids]
+    g = pkg.Group(members)
+    for it in range(2):
+        ref = [s.newton_step(advance=True) for s in singles]
+        got = g.newton_step(advance=True)
+        for r, q, s, m in zip(ref, got, singles, members):
+            assert r == q and r["status"] == 0, (it, r, q)
+            assert same(s.data("step").all, m.data("step").all)
+            assert same(s.solution.all, m.solution.all)
+    g.close()
