@@ -176,3 +176,25 @@ def test_double_integrator_sensitivities_on_the_device(oracle_mod):
     sol = s.solution
     sens = analytic_sensitivity(prob, sol.variables, sol.equality_dual)
     assert np.abs(sens[:prob.nx] - S_gpu[:prob.nx]).max() < 1e-3
+
+
+def test_pendulum_c2_with_the_stage_parallel_factorisation(oracle_mod):
+    """C2 again, host-callback evaluated, with the structure analysed after the first evaluate! and the Schur complement factored by the multifrontal
+    path.  Whatever the later iterates do to the pattern (an upload outside the analysed structure puts the handle back on the dense treatment,
+    structure.hip), the solve must end at the reference's solution with the reference's criteria."""
+    pkg = load_pkg()
+    prob = pr.pendulum(action_guess=np.zeros(10))
+    s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, parameters=prob.parameters, nonnegative_indices=prob.nonnegative_indices,
+                   second_order_indices=prob.second_order_indices)
+    pkg.initialize_b(s, prob.x0)
+    s.evaluate(pkg.ALL_VARIABLE_FLAGS if hasattr(pkg, "ALL_VARIABLE_FLAGS") else pr.ALL_VARIABLE_FLAGS, 0)
+    info = s.analyze_structure()
+    sp = s.set_stage_parallel(True)
+    assert sp["largest_front"] <= 196
+    assert pkg.solve_b(s)
+    criteria(s)
+    x = s.solution.variables
+    assert np.abs(x[-2:] - np.array([np.pi, 0.0])).max() < 1e-3 and np.abs(x[:2]).max() < 1e-3
+    o, st = run_oracle(oracle_mod, prob)
+    assert st == 1 and np.abs(x - o.point()["x"]).max() < 1e-3
+    assert abs(s.stats()["total_iterations"] - o.stats()["total_iterations"]) <= 2
