@@ -183,6 +183,7 @@ template <int MF_THREADS>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first) {
     constexpr int MF_RC = MF_THREADS / 16;        // row classes of the panel step (16 panel columns x MF_RC rows at a time)
     extern __shared__ __attribute__((aligned(16))) double F[];
+    __shared__ int relS[256];                                                  // relative indices of the child being extend-added
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r, nt = m * (m + 1) / 2;
     double* ycol = F + nt;
@@ -199,9 +200,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
         const int rc = d.nrows[ch];
         const double* U = upd + d.upd_off[ch];
         const int* rel = d.rel + d.rowptr[ch];
-        for (int e = tid; e < rc * rc; e += MF_THREADS) {
-            const int a = e / rc, b = e - a * rc;
-            if (a >= b) F[tri(rel[a], rel[b])] += U[e];                        // rel is increasing: the lower triangle lands in the lower triangle
+        for (int a = tid; a < rc; a += MF_THREADS) relS[a] = rel[a];
+        __syncthreads();
+        for (int a = tid >> 5; a < rc; a += MF_THREADS / 32) {                 // a row of the child's update matrix per 32 lanes, coalesced along b
+            const int ra = relS[a] * (relS[a] + 1) / 2;                        // rel is increasing: the lower triangle lands in the lower triangle
+            const double* Ua = U + (size_t)a * rc;
+            for (int b = tid & 31; b <= a; b += 32) F[ra + relS[b]] += Ua[b];
         }
         __syncthreads();
     }
@@ -231,26 +235,30 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
             }
         }
         __syncthreads();
-        const int nt = (m - pe + 15) / 16;                                     // 16-row tiles of the trailing part
-        for (int t = wave; t < nt * (nt + 1) / 2; t += MF_THREADS / 64) {
-            int tb_i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-            while ((tb_i + 1) * (tb_i + 2) / 2 <= t) ++tb_i;
-            while (tb_i * (tb_i + 1) / 2 > t) --tb_i;
-            const int tb_j = t - tb_i * (tb_i + 1) / 2;
-            const int ia = pe + 16 * tb_i + fr, jbr = pe + 16 * tb_j + fr;    // the row this lane feeds to the first / second operand
-            calipso_v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const int ntl = (m - pe + 15) / 16;                                    // 16-row tiles of the trailing part
+        // a wave takes whole tile rows (largest first): the first operand's fragments are read once per row and reused for every tile of the row
+        for (int q = wave; q < ntl; q += MF_THREADS / 64) {
+            const int bi = ntl - 1 - q;
+            const int ia = pe + 16 * bi + fr;                                  // the row this lane feeds to the first operand
+            const int ra = ia * (ia + 1) / 2;
+            double av[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int k = kb + 4 * kk + fk;
-                const bool kin = k < pe;
-                const double av = (kin && ia < m) ? F[tri(ia, k)] * rinv[k] : 0.0;
-                const double bv = (kin && jbr < m) ? F[tri(jbr, k)] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
+            for (int kk = 0; kk < 4; ++kk) { const int k = kb + 4 * kk + fk; av[kk] = (k < pe && ia < m) ? F[ra + k] * rinv[k] : 0.0; }
+            for (int bj = 0; bj <= bi; ++bj) {
+                const int jbr = pe + 16 * bj + fr;                              // ... to the second operand
+                const int rb = jbr * (jbr + 1) / 2;
+                calipso_v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = pe + 16 * tb_i + fk + 4 * r, j = pe + 16 * tb_j + fr;   // result row (first operand's tile), column (second's)
-                if (i < m && j <= i) F[tri(i, j)] -= acc[r];
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = kb + 4 * kk + fk;
+                    const double bv = (k < pe && jbr < m) ? F[rb + k] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int i = pe + 16 * bi + fk + 4 * rr, j = pe + 16 * bj + fr;   // result row (first operand's tile), column (second's)
+                    if (i < m && j <= i) F[tri(i, j)] -= acc[rr];
+                }
             }
         }
     }
@@ -819,7 +827,7 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
         md.Alp = s->d.Alp; md.Asrc = s->d.Asrc;
         for (const void* fn : {(const void*)k_mf_factor<256>, (const void*)k_mf_factor<512>, (const void*)k_mf_forward<256>, (const void*)k_mf_forward<512>,
                                (const void*)k_mf_backward<256>, (const void*)k_mf_backward<512>})
-            PK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));     // (k_mf_factor also holds 1 KiB of static LDS)
     }
     s->work_slots = std::min(widest, 2048);
     if (s->lds_acc) {
