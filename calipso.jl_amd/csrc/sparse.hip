@@ -163,6 +163,9 @@ struct MfDev {
     const int *Alp, *Asrc;
     const double* Aval;
     double *panel, *upd, *D, *uvec;
+    double* fpool;                            // global-memory fronts (levels whose fronts exceed the LDS): packed lower triangles, per instance
+    const long long* foff;                    // per node: offset of its front in fpool (levels reuse the pool)
+    long long sPool;
     long long sA, sPanel, sUpd, sD;           // instance strides (batched factorisation of matrices with one pattern)
 };
 // storage slot of launch instance z: z itself, or — for the members of a group's (shrinking) active set — slot[z].  A separate read-only kernel
@@ -174,21 +177,25 @@ typedef double calipso_v4d __attribute__((ext_vector_type(4)));
 // anyway; more waves shorten the panel, assembly and matrix-core phases)
 constexpr int MF_BIG = 96;
 constexpr int MF_MAX_FRONT = 196;             // (m (m + 1) / 2 + 2 m) doubles <= 160 KiB: the front's lower triangle, packed, + the pivot-column buffers
+constexpr int MF_MAX_FRONT_GLOBAL = 1024;     // larger fronts live in global memory (L2): same algorithm, every access a memory access — slower, but
+                                              // still tree-parallel; beyond this the column method takes over
 
 // The front is symmetric: only its lower triangle is held, packed row by row (row i starts at i (i + 1) / 2), which lets fronts of up to 196 rows
 // fit the 160 KiB of LDS (a full square would stop at 141).
 __device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }     // i >= k
 
-template <int MF_THREADS>
+template <int MF_THREADS, bool GF>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first) {
     constexpr int MF_RC = MF_THREADS / 16;        // row classes of the panel step (16 panel columns x MF_RC rows at a time)
-    extern __shared__ __attribute__((aligned(16))) double F[];
-    __shared__ int relS[256];                                                  // relative indices of the child being extend-added
+    extern __shared__ __attribute__((aligned(16))) double Flds[];
+    __shared__ int relS[256];                                                  // relative indices of the child being extend-added (LDS fronts: r <= 196)
+    __shared__ double rinvS[64];                                               // GF: reciprocal pivots (a node has at most 64 columns)
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r, nt = m * (m + 1) / 2;
-    double* ycol = F + nt;
     const int tid = threadIdx.x;
     const size_t z = sl.use ? (size_t)sl.slot[blockIdx.y] : (size_t)blockIdx.y;   // storage slot of this instance of the batch
+    double* F = GF ? d.fpool + z * d.sPool + d.foff[s] : Flds;                  // GF: the front lives in global memory (L2-resident)
+    double* ycol = GF ? rinvS : F + nt;
     const double* Aval = d.Aval + z * d.sA;
     double* upd = d.upd + z * d.sUpd; double* panel = d.panel + z * d.sPanel; double* Dg = d.D + z * d.sD;
     for (int e = tid; e < nt; e += MF_THREADS) F[e] = 0.0;
@@ -200,12 +207,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
         const int rc = d.nrows[ch];
         const double* U = upd + d.upd_off[ch];
         const int* rel = d.rel + d.rowptr[ch];
-        for (int a = tid; a < rc; a += MF_THREADS) relS[a] = rel[a];
+        if (!GF) { for (int a = tid; a < rc; a += MF_THREADS) relS[a] = rel[a]; }
         __syncthreads();
         for (int a = tid >> 5; a < rc; a += MF_THREADS / 32) {                 // a row of the child's update matrix per 32 lanes, coalesced along b
-            const int ra = relS[a] * (relS[a] + 1) / 2;                        // rel is increasing: the lower triangle lands in the lower triangle
+            const int rla = GF ? rel[a] : relS[a];
+            const int ra = rla * (rla + 1) / 2;                                // rel is increasing: the lower triangle lands in the lower triangle
             const double* Ua = U + (size_t)a * rc;
-            for (int b = tid & 31; b <= a; b += 32) F[ra + relS[b]] += Ua[b];
+            for (int b = tid & 31; b <= a; b += 32) F[ra + (GF ? rel[b] : relS[b])] += Ua[b];
         }
         __syncthreads();
     }
@@ -270,18 +278,19 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
 }
 
 // forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors
-template <int MF_THREADS>
+template <int MF_THREADS, bool GP>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
-    double* Ps = sm; double* v = sm + (size_t)m * c;
+    double* v = GP ? sm : sm + (size_t)m * c;                                  // GP: the panel is too large for the LDS and is read in place
     double* x = X + (size_t)blockIdx.y * n;                                    // blockIdx.y = instance * nrhs + right-hand side
     double* ubase = d.uvec + (size_t)blockIdx.y * usum;
     const double* panel = d.panel + (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)) * d.sPanel;
     const int tid = threadIdx.x;
     const double* P = panel + d.panel_off[s];
-    for (int e = tid; e < m * c; e += MF_THREADS) Ps[e] = P[e];
+    const double* Ps = GP ? P : sm;
+    if (!GP) { for (int e = tid; e < m * c; e += MF_THREADS) sm[e] = P[e]; }
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] : 0.0;
     __syncthreads();
     for (int q = d.childptr[s]; q < d.childptr[s + 1]; ++q) {
@@ -302,19 +311,20 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
     for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a];
 }
 // backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C
-template <int MF_THREADS>
+template <int MF_THREADS, bool GP>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
-    double* Ps = sm; double* v = sm + (size_t)m * c;
+    double* v = GP ? sm : sm + (size_t)m * c;
     double* x = X + (size_t)blockIdx.y * n;
     const size_t zs = (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs));
     const double* panel = d.panel + zs * d.sPanel; const double* Dg = d.D + zs * d.sD;
     const int tid = threadIdx.x;
     const double* P = panel + d.panel_off[s];
     const int* R = d.rows + d.rowptr[s];
-    for (int e = tid; e < m * c; e += MF_THREADS) Ps[e] = P[e];
+    const double* Ps = GP ? P : sm;
+    if (!GP) { for (int e = tid; e < m * c; e += MF_THREADS) sm[e] = P[e]; }
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] / Dg[f + i] : x[R[i - c]];
     __syncthreads();
     double z = 0.0;
@@ -330,12 +340,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
     for (int i = tid; i < c; i += MF_THREADS) x[f + i] = v[i];
 }
 
-struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; };
+struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; bool global; };
 // launch helpers: the thread count of a level is fixed by the analyse phase (MfSeg::threads)
 #define MF_LAUNCH(KERNEL, G, GRID, LDS, STREAM, ...)                                                                              \
     do {                                                                                                                          \
-        if ((G).threads == 512) hipLaunchKernelGGL(KERNEL<512>, GRID, dim3(512), LDS, STREAM, __VA_ARGS__);                       \
-        else hipLaunchKernelGGL(KERNEL<256>, GRID, dim3(256), LDS, STREAM, __VA_ARGS__);                                         \
+        if ((G).global) hipLaunchKernelGGL((KERNEL<512, true>), GRID, dim3(512), LDS, STREAM, __VA_ARGS__);                       \
+        else if ((G).threads == 512) hipLaunchKernelGGL((KERNEL<512, false>), GRID, dim3(512), LDS, STREAM, __VA_ARGS__);         \
+        else hipLaunchKernelGGL((KERNEL<256, false>), GRID, dim3(256), LDS, STREAM, __VA_ARGS__);                                \
     } while (0)
 
 
@@ -360,7 +371,7 @@ struct calipso_hip_sparse {
     size_t cap_uvec = 0;
     int max_front = 0, nnodes = 0;
     int batch = 1, selected = 0;                 // matrices of this pattern factored together / the one get_factor reads
-    long long upd_total = 0;
+    long long upd_total = 0, pool_total = 0;
     std::vector<i64> inertia_all;                // batch x 3
     std::vector<void*> dev;                      // every device allocation
     SpDev d{};
@@ -385,18 +396,19 @@ namespace {
 // (re)allocate everything that holds VALUES, for `batch` matrices of the analysed pattern: instance-major
 int alloc_values(calipso_hip_sparse* s, int batch) {
     const size_t B = (size_t)batch;
-    for (double** pp : {&s->d_Aval, &s->d.Lx, &s->d.D, &s->md.panel, &s->md.upd}) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+    for (double** pp : {&s->d_Aval, &s->d.Lx, &s->d.D, &s->md.panel, &s->md.upd, &s->md.fpool}) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
     PK(hipMalloc((void**)&s->d_Aval, sizeof(double) * B * std::max<size_t>((size_t)s->nnzA, 1)));
     PK(hipMalloc((void**)&s->d.D, sizeof(double) * B * (size_t)s->n));
     if (s->mf) {
         PK(hipMalloc((void**)&s->md.panel, sizeof(double) * B * std::max<size_t>((size_t)s->panel_total, 1)));
         PK(hipMalloc((void**)&s->md.upd, sizeof(double) * B * std::max<size_t>((size_t)s->upd_total, 1)));
+        if (s->pool_total) PK(hipMalloc((void**)&s->md.fpool, sizeof(double) * B * (size_t)s->pool_total));
     } else {
         PK(hipMalloc((void**)&s->d.Lx, sizeof(double) * B * std::max<size_t>((size_t)s->nnzL, 1)));
     }
     s->d.Aval = s->d_Aval;
     s->md.Aval = s->d_Aval; s->md.D = s->d.D;
-    s->md.sA = s->nnzA; s->md.sPanel = s->panel_total; s->md.sUpd = s->upd_total; s->md.sD = s->n;
+    s->md.sA = s->nnzA; s->md.sPanel = s->panel_total; s->md.sUpd = s->upd_total; s->md.sD = s->n; s->md.sPool = s->pool_total;
     s->batch = batch; s->selected = 0; s->factored = false;
     s->inertia_all.assign(3 * B, 0);
     return CALIPSO_OK;
@@ -563,7 +575,7 @@ int32_t calipso_hip_sparse_destroy(calipso_hip_sparse* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->graph_factor) (void)hipGraphExecDestroy(s->graph_factor);
     for (void* p : s->dev) if (p) (void)hipFree(p);
-    for (double* p : {s->d_Aval, s->d.Lx, s->d.D, s->md.panel, s->md.upd}) if (p) (void)hipFree(p);
+    for (double* p : {s->d_Aval, s->d.Lx, s->d.D, s->md.panel, s->md.upd, s->md.fpool}) if (p) (void)hipFree(p);
     if (s->d_rhs) (void)hipFree(s->d_rhs);
     if (s->d_x) (void)hipFree(s->d_x);
     if (s->md.uvec) (void)hipFree(s->md.uvec);
@@ -700,7 +712,12 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
     std::vector<MfSeg> mplan;
     long long panel_total = 0, upd_total = 0, usum = 0;
     int max_front = 0, mf_levels = 0, mf_widest = 0;
-    for (int width : {64, 56, 48, 40, 32, 24, 16}) {
+    // last resort: chunks of 64 columns with the oversized fronts in global memory (MF_MAX_FRONT_GLOBAL)
+    std::vector<long long> m_foff;
+    long long pool_total = 0;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const int width = attempt < 7 ? (int[]){64, 56, 48, 40, 32, 24, 16}[attempt] : 64;
+        const int front_limit = attempt < 7 ? MF_MAX_FRONT : MF_MAX_FRONT_GLOBAL;
         if (method != 4 || base_pieces.empty() || use_mf) break;
         pieces.clear();
         for (const auto& bp : base_pieces) for (int o = 0; o < bp.second; o += width) pieces.push_back({bp.first + o, std::min(width, bp.second - o)});
@@ -732,7 +749,7 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
                 std::sort(rp.begin(), rp.end()); rp.erase(std::unique(rp.begin(), rp.end()), rp.end());
             }
         }
-        if (max_front > MF_MAX_FRONT) use_mf = false;                   // a front that does not fit one CU's LDS: column method
+        if (max_front > front_limit) use_mf = false;                    // a front that does not fit: next chunk width / global fronts / column method
         if (use_mf) {
             m_first.resize((size_t)NN); m_cols.resize((size_t)NN); m_rows.resize((size_t)NN); m_rowptr.assign((size_t)NN + 1, 0);
             m_panel_off.resize((size_t)NN); m_upd_off.resize((size_t)NN); m_u_off.resize((size_t)NN);
@@ -775,6 +792,7 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
                 }
             }
             m_order.resize((size_t)NN);
+            m_foff.assign((size_t)NN, 0); pool_total = 0;
             std::iota(m_order.begin(), m_order.end(), 0);
             std::stable_sort(m_order.begin(), m_order.end(), [&](int a, int b) { return lev[(size_t)a] < lev[(size_t)b]; });
             for (int a = 0; a < NN;) {
@@ -785,7 +803,14 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
                     mmax = std::max(mmax, m);
                     ++b;
                 }
-                mplan.push_back({a, b - a, lf, ls, mmax > (size_t)MF_BIG ? 512 : 256});
+                const bool glob = mmax > (size_t)MF_MAX_FRONT;
+                if (glob) {                                               // the level's fronts in the (reused) global pool; the solves keep only v in LDS
+                    long long off = 0;
+                    for (int q = a; q < b; ++q) { const int t = m_order[(size_t)q]; const long long mm = m_cols[(size_t)t] + m_rows[(size_t)t]; m_foff[(size_t)t] = off; off += mm * (mm + 1) / 2; }
+                    pool_total = std::max(pool_total, off);
+                    lf = 0; ls = sizeof(double) * mmax;
+                }
+                mplan.push_back({a, b - a, lf, ls, mmax > (size_t)MF_BIG ? 512 : 256, glob});
                 mf_widest = std::max(mf_widest, b - a);
                 a = b;
             }
@@ -823,10 +848,12 @@ int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_
         if ((rc = upload(s, m_order, &md.order)) || (rc = upload(s, m_first, &md.nfirst)) || (rc = upload(s, m_cols, &md.ncols)) || (rc = upload(s, m_rows, &md.nrows)) ||
             (rc = upload(s, m_rowptr, &md.rowptr)) || (rc = upload(s, m_rowsv, &md.rows)) || (rc = upload(s, m_rel, &md.rel)) || (rc = upload(s, m_childptr, &md.childptr)) ||
             (rc = upload(s, m_children, &md.children)) || (rc = upload(s, m_panel_off, &md.panel_off)) || (rc = upload(s, m_upd_off, &md.upd_off)) ||
-            (rc = upload(s, m_u_off, &md.u_off)) || (rc = upload(s, m_Aloc, &md.Aloc))) return rc;
+            (rc = upload(s, m_u_off, &md.u_off)) || (rc = upload(s, m_Aloc, &md.Aloc)) || (rc = upload(s, m_foff, &md.foff))) return rc;
+        s->pool_total = pool_total;
+        if ((rc = alloc_values(s, 1))) return rc;      // (again: now with the pool of the global-memory fronts)
         md.Alp = s->d.Alp; md.Asrc = s->d.Asrc;
-        for (const void* fn : {(const void*)k_mf_factor<256>, (const void*)k_mf_factor<512>, (const void*)k_mf_forward<256>, (const void*)k_mf_forward<512>,
-                               (const void*)k_mf_backward<256>, (const void*)k_mf_backward<512>})
+        for (const void* fn : {(const void*)k_mf_factor<256, false>, (const void*)k_mf_factor<512, false>, (const void*)k_mf_forward<256, false>,
+                               (const void*)k_mf_forward<512, false>, (const void*)k_mf_backward<256, false>, (const void*)k_mf_backward<512, false>})
             PK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));     // (k_mf_factor also holds 1 KiB of static LDS)
     }
     s->work_slots = std::min(widest, 2048);

@@ -196,7 +196,9 @@ int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_
     }
     calipso_hip_sparse* sp = nullptr;
     int rc = calipso_hip_sparse_create(nx, colptr.data(), rowval.data(), 4, nullptr, s->device, &sp);
-    if (rc != CALIPSO_OK || !sparse_is_multifrontal(sp)) {
+    int64_t desc[4] = {0, 0, 0, 0};
+    if (rc == CALIPSO_OK && sp) sparse_describe(sp, desc);
+    if (rc != CALIPSO_OK || !sparse_is_multifrontal(sp) || desc[1] > 196) {          // (fronts in global memory would be slower than the blocked factorisation)
         s->err = rc != CALIPSO_OK ? std::string("calipso_hip_set_stage_parallel: ") + calipso_hip_sparse_last_error(sp)
                                   : std::string("calipso_hip_set_stage_parallel: a front of the dissection of S exceeds one CU's LDS (196 rows): the blocked factorisation stays");
         if (sp) (void)calipso_hip_sparse_destroy(sp);

@@ -328,9 +328,10 @@ int32_t calipso_hip_ldl_solve(calipso_hip_solver*, int64_t n, int64_t nrhs, cons
  *   calipso_hip_sparse_set_batch   `batch` matrices of the analysed pattern per call (BASELINE config C4: many independent problems of one structure):
  *                                  nzval = batch x nnz, inertia = batch x 3, b / x = batch x (n x nrhs); the multifrontal path factors them in the
  *                                  same launches.  calipso_hip_sparse_select picks the matrix calipso_hip_sparse_get_factor reads.
- * Numeric phase: with method 4 (nested dissection) and every front <= 196 rows the factorisation is MULTIFRONTAL over the dissection tree — the
- * pieces of the dissection are the supernodes, each front is assembled and partially factored in the LDS of one workgroup, one launch per tree level
- * (~log2 T launches for a T-stage problem); otherwise (and with method 5 = nested-dissection order, column method) the left-looking column method. */
+ * Numeric phase: with method 4 (nested dissection) the factorisation is MULTIFRONTAL over the dissection tree — the pieces of the dissection (cut into
+ * chains of <= 64 columns) are the supernodes, each front is assembled and partially factored by one workgroup, in its LDS when the front has <= 196
+ * rows, in global memory up to 1024 rows; one launch per tree level (~log2 T launches for a T-stage problem).  Larger fronts, every other order
+ * and method 5 (nested-dissection order, column method) take the left-looking column method. */
 typedef struct calipso_hip_sparse calipso_hip_sparse;
 int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, const int64_t* perm, int32_t device,
                                   calipso_hip_sparse** out);

@@ -166,7 +166,7 @@ def test_rate_report_on_trajectory_kkt_systems(oracle_mod):
     pkg = load_pkg()
     rng = np.random.default_rng(2)
     rows = []
-    for T, ns, nu in ((256, 6, 2), (512, 12, 4), (2048, 12, 4), (41, 28, 28)):          # the last: BASELINE C4's size, 41 stages of 56 variables
+    for T, ns, nu in ((256, 6, 2), (512, 12, 4), (2048, 12, 4), (41, 28, 28), (41, 50, 50)):   # (41, 28, 28): BASELINE C4's size, 41 stages of 56 variables; (41, 50, 50): stages of 100 variables, fronts of 300 rows in global memory
         K = staged_kkt(T, ns, nu, rng)
         n = K.shape[0]
         A = sp.triu(K).tocsc()
@@ -239,9 +239,9 @@ def test_global_accumulator_path_beyond_the_lds_limit(oracle_mod):
     S.close()
 
 
-def test_fronts_that_do_not_fit_fall_back_to_the_column_method(oracle_mod):
-    """a 2-D grid has separators of ~sqrt(n) vertices: the top fronts exceed one CU's LDS, so the nested-dissection order keeps the column-level
-    numeric phase — same answers"""
+def test_fronts_larger_than_the_lds_live_in_global_memory(oracle_mod):
+    """a 2-D grid has separators of ~sqrt(n) vertices: the top fronts (hundreds of rows) exceed one CU's LDS and are factored in global memory by
+    the same kernels; a front beyond 1024 rows (one dense block) sends the whole matrix to the column method — same answers either way"""
     pkg = load_pkg()
     g = 180
     I = sp.identity(g, format="csc")
@@ -250,16 +250,30 @@ def test_fronts_that_do_not_fit_fall_back_to_the_column_method(oracle_mod):
     K.sort_indices()
     A = sp.triu(K).tocsc()
     S = pkg.SparseLDL(A, method="nested_dissection")
-    assert S.info["numeric"].startswith("columns")
+    assert S.info["numeric"] == "multifrontal"
     assert S.factorize(A) == 0 and S.inertia == (g * g, 0, 0)
     rng = np.random.default_rng(1)
-    b = rng.standard_normal(g * g)
+    b = rng.standard_normal((g * g, 2))
     x = S.solve(b)
     assert np.abs(K @ x - b).max() <= 1e-9 * max(1.0, np.abs(x).max())
     perm, Lm, D = S.factor()
     ref = oracle_factor(oracle_mod, K, perm)
     assert np.abs(D - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
-    S.close()
+    assert abs(Lm - ref["L"]).max() <= 1e-10 * max(1.0, abs(ref["L"]).max())
+    tf, ts = S.timing()
+    C = pkg.SparseLDL(A, method="nested_dissection_columns")
+    C.factorize(A); C.factorize(A)
+    assert tf < C.timing()[0]                                    # the tree-parallel fronts beat the column method on this matrix
+    S.close(); C.close()
+    # one dense block of 1500: its first front would have 1500 rows
+    M = rng.standard_normal((1500, 1500)); Kd = M @ M.T + 1500 * np.eye(1500)
+    Ad = sp.csc_matrix(np.triu(Kd))
+    Sd = pkg.SparseLDL(Ad, method="nested_dissection")
+    assert Sd.info["numeric"].startswith("columns")
+    assert Sd.factorize(Ad) == 0
+    bd = rng.standard_normal(1500)
+    assert np.abs(Kd @ Sd.solve(bd) - bd).max() <= 1e-8 * np.abs(bd).max() * 10
+    Sd.close()
 
 
 @pytest.mark.parametrize("method", ["nested_dissection", "nested_dissection_columns"])
