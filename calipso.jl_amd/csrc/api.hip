@@ -953,10 +953,12 @@ int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) {
     const Scalars saved_sc = s->sc;
     std::vector<double> ft, fm; calipso::i64 fi = 0;
     if (!advance) {
-        copy_d(s, s->saved_point, s->solution, d.N);
-        copy_d(s, s->saved_g, s->g, d.ne);
-        copy_d(s, s->saved_h, s->hc, d.nc);
-        copy_d(s, s->dscal + 32, s->dscal, 2);
+        {
+            double* const dst[4] = {s->saved_point, s->saved_g, s->saved_h, s->dscal + 32};
+            const double* const src[4] = {s->solution, s->g, s->hc, s->dscal};
+            const size_t n[4] = {(size_t)d.N, (size_t)d.ne, (size_t)d.nc, 2};
+            copy4_d(s, dst, src, n);
+        }
         ft = s->filter_theta; fm = s->filter_merit; fi = s->filter_index;
     }
     IterInfo info;
@@ -966,10 +968,12 @@ int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) {
     EV(9);
     if (rc < 0) return rc;
     if (!advance) {
-        copy_d(s, s->solution, s->saved_point, d.N);
-        copy_d(s, s->g, s->saved_g, d.ne);
-        copy_d(s, s->hc, s->saved_h, d.nc);
-        copy_d(s, s->dscal, s->dscal + 32, 2);
+        {
+            double* const dst[4] = {s->solution, s->g, s->hc, s->dscal};
+            const double* const src[4] = {s->saved_point, s->saved_g, s->saved_h, s->dscal + 32};
+            const size_t n[4] = {(size_t)d.N, (size_t)d.ne, (size_t)d.nc, 2};
+            copy4_d(s, dst, src, n);
+        }
         launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT);
         s->filter_theta = ft; s->filter_merit = fm; s->filter_index = fi;
         const double keep_ep = s->sc.ep, keep_ed = s->sc.ed;

@@ -303,6 +303,7 @@ int nested_dissection_pieces(i64 n, const i64* colptr, const i64* rowval, i64* p
 void fill_d(calipso_hip_solver* s, double* p, size_t n, double v);
 void fill_i(calipso_hip_solver* s, int* p, size_t n, int v);
 void copy_d(calipso_hip_solver* s, double* dst, const double* src, size_t n);
+void copy4_d(calipso_hip_solver* s, double* const dst[4], const double* const src[4], const size_t n[4]);   // four copies, one launch
 }  // namespace calipso
 
 #define CK(call)                                                        \

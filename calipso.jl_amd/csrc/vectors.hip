@@ -2,6 +2,7 @@
 // candidate/accept updates, the vector part of the matrix-free H*v, dense K materialisation.
 // N is ~10^4: elementwise kernels are a handful of workgroups; every reduction is ONE workgroup with a fixed
 // summation order (deterministic), its result written to the device scalar block `dscal`.
+#include <algorithm>
 #include "internal.hpp"
 #include "device_utils.hpp"
 
@@ -646,6 +647,22 @@ void fill_i(calipso_hip_solver* s, int* p, size_t n, int v) {
     if (!n) return;
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_fill_i, dim3((unsigned)((n + 255) / 256), 1, B.b.n), dim3(256), 0, s->stream, B.b, p, n, v);
+}
+// four copies in one launch (the save / restore of the benchmark step): blockIdx.y selects the pair
+struct Copy4 { double* dst[4]; const double* src[4]; unsigned long long n[4]; };
+__global__ void k_copy4_d(Batch bt, Copy4 c) {
+    const int q = blockIdx.y;
+    double* dst = c.dst[q]; const double* src = c.src[q];
+    inst_shift(bt, dst, src);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c.n[q]) dst[i] = src[i];
+}
+void copy4_d(calipso_hip_solver* s, double* const dst[4], const double* const src[4], const size_t n[4]) {
+    Copy4 c; size_t nmax = 0;
+    for (int q = 0; q < 4; ++q) { c.dst[q] = dst[q]; c.src[q] = src[q]; c.n[q] = n[q]; nmax = std::max(nmax, n[q]); }
+    if (!nmax) return;
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_copy4_d, dim3((unsigned)((nmax + 255) / 256), 4, B.b.n), dim3(256), 0, s->stream, B.b, c);
 }
 void copy_d(calipso_hip_solver* s, double* dst, const double* src, size_t n) {
     if (!n) return;
