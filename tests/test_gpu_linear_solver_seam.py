@@ -146,3 +146,44 @@ def test_seam_with_an_elimination_order(oracle_mod, method):
     # the symbolic factor the reference would build for this order (nnz(L)) is reported
     assert info["nnzL"] == pkg.symbolic(sp.triu(A), perm)["nnzL"] > 0
     ls.close(); ls2.close()
+
+
+@pytest.mark.parametrize("case", ["qp_soc_6_3_9", "qp_mixed_300_120_130", "pendulum"])
+@pytest.mark.parametrize("method", ["nested_dissection", "minimum_degree"])
+def test_reference_search_direction_on_the_sparse_device_solver(oracle_mod, case, method):
+    """the same seam with the SPARSE device solver (calipso_hip_sparse_*: what `HIPSparseLDLSolver <: LinearSolver` binds): the caller's condensed K
+    — here also the genuinely sparse K of the pendulum trajectory problem (BASELINE config C2) — analysed once, factored and solved on the device;
+    a second factorisation with new values on the same pattern (update = true in linear_solver.jl:24-27)"""
+    pkg = load_pkg()
+    prob = pr.pendulum(action_guess=np.zeros(10)) if case == "pendulum" else CASES[case]()
+    pt, lam = interior_point(prob, seed=1)
+    o, g = make_pair(oracle_mod, prob, pt, lam)
+    n = o.n
+    o.cone(barrier=True, barrier_gradient=True, product=True, jacobian=True, target=True)
+    o.residual()
+    o.residual_jacobian_variables(); o.residual_jacobian_variables_symmetric()
+    K = o.K_dense().copy()
+    o.residual_symmetric(0)
+    b = o.buf("residual_symmetric").copy()
+    A = sp.csc_matrix(np.triu(K)); A.sort_indices()
+    ls = pkg.SparseLDL(A, method=method)
+    assert ls.factorize(A) == 0
+    o.factorize(update=False)
+    assert ls.inertia == tuple(o.compute_inertia()) == (o.nx, o.ne + o.nc, 0)
+    x = ls.solve(b)
+    x_o = o.linear_solve(b, fact=False)
+    assert rel(x, x_o) <= 1e-8
+    B = np.random.default_rng(2).standard_normal((n, 5))
+    X = ls.solve(B)
+    for j in range(5):
+        assert rel(X[:, j], o.linear_solve(B[:, j], fact=False)) <= 1e-8
+    # new values, same pattern: the regularised K of the next inertia-correction try (inertia.jl:23-26)
+    K2 = K.copy(); K2[np.arange(o.nx), np.arange(o.nx)] += 1e-3
+    rows, cols = A.nonzero()
+    A2 = sp.csc_matrix((np.asarray(K2[rows, cols]).ravel(), (rows, cols)), shape=A.shape)      # the values of K2 on the analysed pattern
+    A2.sort_indices()
+    assert np.array_equal(A2.indices, A.indices) and np.array_equal(A2.indptr, A.indptr)
+    assert ls.factorize(A2) == 0
+    Ksym2 = np.triu(K2) + np.triu(K2, 1).T
+    assert np.abs(Ksym2 @ ls.solve(b) - b).max() <= 1e-8 * max(1.0, np.abs(b).max())
+    ls.close()
