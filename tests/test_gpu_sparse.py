@@ -353,3 +353,29 @@ def test_device_resident_values_and_right_hand_sides():
     torch.cuda.synchronize()
     assert np.array_equal(tx.cpu().numpy().reshape(3, n), x_host)
     S.close()
+
+
+def test_batch_with_fronts_in_global_memory():
+    """a batch of matrices whose fronts (stages of 100 variables: 300-row fronts) live in the global-memory pool: every matrix has its own pool slice"""
+    pkg = load_pkg()
+    rng = np.random.default_rng(23)
+    K0 = staged_kkt(9, 50, 50, rng)
+    A0 = sp.triu(K0).tocsc(); A0.sort_indices()
+    n = K0.shape[0]
+    S = pkg.SparseLDL(A0, method="nested_dissection")
+    assert S.info["numeric"] == "multifrontal"
+    Bn = 3
+    vals = A0.data[None, :] * (1.0 + 0.05 * rng.random((Bn, A0.nnz)))
+    alone = []
+    b = rng.standard_normal(n)
+    for z in range(Bn):
+        assert S.factorize(vals[z]) == 0
+        alone.append(S.solve(b))
+    S.set_batch(Bn)
+    assert S.factorize(vals) == 0
+    X = S.solve(np.tile(b, (Bn, 1)))
+    for z in range(Bn):
+        assert np.array_equal(X[z], alone[z])
+        Kz = sp.csc_matrix((vals[z], A0.indices, A0.indptr), shape=A0.shape); Kz = Kz + sp.triu(Kz, 1).T
+        assert np.abs(Kz @ X[z] - b).max() <= 1e-8 * max(1.0, np.abs(X[z]).max())
+    S.close()
