@@ -379,3 +379,36 @@ def test_batch_with_fronts_in_global_memory():
         Kz = sp.csc_matrix((vals[z], A0.indices, A0.indptr), shape=A0.shape); Kz = Kz + sp.triu(Kz, 1).T
         assert np.abs(Kz @ X[z] - b).max() <= 1e-8 * max(1.0, np.abs(X[z]).max())
     S.close()
+
+
+def test_error_paths_of_the_sparse_handle():
+    """the reference raises on these (DimensionMismatch / BoundsError / "factorize first" has no counterpart); here: a negative status with a message"""
+    pkg = load_pkg()
+    rng = np.random.default_rng(3)
+    K = staged_kkt(6, 3, 2, rng)
+    A = sp.triu(K).tocsc(); A.sort_indices()
+    n = K.shape[0]
+    with pytest.raises(pkg.CalipsoHipError):
+        pkg.SparseLDL(A, perm=np.arange(n))                       # 0-based: not a permutation of 1:n
+    with pytest.raises(pkg.CalipsoHipError):
+        pkg.SparseLDL(A, perm=np.r_[np.arange(1, n), n - 1])      # a repeated vertex
+    S = pkg.SparseLDL(A, method="nested_dissection")
+    with pytest.raises(pkg.CalipsoHipError):
+        S.solve(np.ones(n))                                       # no factorisation yet
+    with pytest.raises(pkg.CalipsoHipError):
+        S.factorize(np.ones(A.nnz - 1))                           # wrong number of values
+    with pytest.raises(pkg.CalipsoHipError):
+        S.factorize(sp.triu(staged_kkt(6, 3, 3, rng)).tocsc())    # another pattern
+    assert S.factorize(A) == 0
+    with pytest.raises(pkg.CalipsoHipError):
+        S.select(1)                                               # only one matrix in the batch
+    with pytest.raises(pkg.CalipsoHipError):
+        S.set_batch(0)
+    S.set_batch(2)
+    with pytest.raises(pkg.CalipsoHipError):
+        S.solve(np.ones((2, n)))                                  # set_batch invalidated the factorisation
+    assert S.factorize(np.stack([A.data, 2.0 * A.data])) == 0
+    X = S.solve(np.ones((2, n)))
+    assert np.abs(2.0 * X[1] - X[0]).max() <= 1e-12 * np.abs(X[0]).max()
+    S.close()
+    S.close()                                                     # idempotent
