@@ -105,8 +105,9 @@ void launch_cone_weights(calipso_hip_solver* s) {
 // WH = Omega_z * hx  (nc x nx): nonnegative rows scaled by -1/K_zz, second-order rows multiplied by the d x d block W
 constexpr int SCALE_COLS = 16;
 __global__ void k_scale_rows(Batch bt, Dims d, ConeDev cd, const double* __restrict__ hx, const double* __restrict__ wz,
-                             const double* __restrict__ Wsoc, double* __restrict__ WH) {
+                             const double* __restrict__ Wsoc, double* __restrict__ WH, const int* __restrict__ zrow) {
     inst_shift(bt, hx, wz, Wsoc, WH);
+    if (zrow) inst_shift_i(bt, zrow);
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nc) return;
     int st = 0, dim = 0;
@@ -114,7 +115,11 @@ __global__ void k_scale_rows(Batch bt, Dims d, ConeDev cd, const double* __restr
     double w0 = 0.0;
     if (c < d.q) w0 = wz[c];
     else { const int j = cd.entry_soc[c]; st = cd.soc_start[j]; dim = cd.soc_dim[j]; W = Wsoc + cd.soc_woff[j]; }
-    const int col0 = blockIdx.y * SCALE_COLS, col1 = min(d.nx, col0 + SCALE_COLS);   // a block of columns per workgroup: the cone data is looked up once
+    int col0 = blockIdx.y * SCALE_COLS, col1 = min(d.nx, col0 + SCALE_COLS);   // a block of columns per workgroup: the cone data is looked up once
+    if (zrow) {                          // analysed structure (structure.hip): the row is zero outside its column range — in hx, hence in WH (never written there)
+        const int k = d.ne + c;
+        col0 = max(col0, zrow[2 * k]); col1 = min(col1, zrow[2 * k + 1]);
+    }
     for (int col = col0; col < col1; ++col) {
         const double* h = hx + (size_t)col * d.m;     // hx is the lower part of the stacked Jacobian (ld = m)
         double v;
@@ -130,7 +135,7 @@ __global__ void k_scale_rows(Batch bt, Dims d, ConeDev cd, const double* __restr
 void launch_scale_rows(calipso_hip_solver* s) {
     if (s->d.nc == 0) return;
     const BatchSc B = batch_of(s);
-    hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, (s->d.nx + SCALE_COLS - 1) / SCALE_COLS, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH);
+    hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, (s->d.nx + SCALE_COLS - 1) / SCALE_COLS, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH, s->band64 > 0 ? s->zrow : nullptr);
 }
 
 // ---- Schur complement on the fp64 matrix cores -----------------------------------------------------------------------------
@@ -467,7 +472,7 @@ void launch_schur(calipso_hip_solver* s) {
     static const int flat_env = [] { const char* e = getenv("CALIPSO_HIP_SCHUR_FLAT"); return e ? atoi(e) : -1; }();
     const int flat = flat_env >= 0 ? flat_env : 1;
     const int grid = flat ? (int)(((long long)B.b.n * ntiles + 7) / 8 + 1) * 8 : ((ntiles + 7) / 8) * 8;
-    if (s->d.NP > s->d.nx)
+    if (s->d.NP > s->d.nx && !(s->stage_parallel && s->spS))      // (the multifrontal path reads S only inside its nx x nx pattern)
         hipLaunchKernelGGL(k_pad_identity, dim3((s->d.NP + 255) / 256, s->d.NP - s->d.nx, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->S);
     hipLaunchKernelGGL(k_schur, dim3(grid, 1, flat ? 1 : B.b.n), dim3(SCHUR_THREADS), SCHUR_LDS_BYTES, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, s->krange, hb, ntiles, nj, flat);
 }
