@@ -26,6 +26,35 @@ __device__ __forceinline__ BlockRanges column_blocks(const Sparsity& sp, int col
 }
 __device__ __forceinline__ bool block_active(const BlockRanges& r, int b) { return (b >= r.b0 && b < r.b1) || (b >= r.b2 && b < r.b3); }
 
+// Structured column (analysed structure): only the 64-row blocks that can hold non-zeros are visited, 16 candidate blocks per round (all loads
+// issued before the first use).  The terms go to the two accumulators exactly as the dense loop deals them (block b of a batch of 24 -> acc0 for even,
+// acc1 for odd positions), in ascending order, so dropping the blocks that hold structural zeros does not change a bit of the result.
+template <int NV>
+__device__ __forceinline__ void structured_column(const BlockRanges& br, int rows, int lane, const double* __restrict__ a, const double* const (&x)[NV],
+                                                  double (&acc0)[NV], double (&acc1)[NV]) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int lo = pass ? max(br.b2, br.b1) : br.b0, hi = pass ? br.b3 : br.b1;
+        for (int w0 = lo; w0 < hi; w0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const int b = w0 + q, i = b * 64 + lane; v[q] = (b < hi && i < rows) ? a[i] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int b = w0 + q, i = b * 64 + lane;
+                const bool in = b < hi && i < rows;
+                const bool odd = ((b % 24) & 1) != 0;
+#pragma unroll
+                for (int n = 0; n < NV; ++n) {
+                    const double xv = in ? x[n][i] : 0.0;
+                    acc0[n] = odd ? acc0[n] : fma(v[q], xv, acc0[n]);         // (fused, as the dense loop is)
+                    acc1[n] = odd ? fma(v[q], xv, acc1[n]) : acc1[n];
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gemv_t(Batch bt, Sparsity sp, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x,
                                                  double* __restrict__ y, double alpha, double beta) {
     inst_shift(bt, A, x, y);
@@ -36,6 +65,12 @@ __global__ __launch_bounds__(256) void k_gemv_t(Batch bt, Sparsity sp, int rows,
     const double* a = A + (size_t)col * ld;
     const BlockRanges br = column_blocks(sp, col, rows);
     double acc0 = 0.0, acc1 = 0.0;
+    if (sp.kind != SP_DENSE) {
+        const double* const xs[1] = {x};
+        double a0[1] = {0.0}, a1[1] = {0.0};
+        structured_column<1>(br, rows, lane, a, xs, a0, a1);
+        acc0 = a0[0]; acc1 = a1[0];
+    } else
     // batches of 24 loads per lane, all issued before the first use (latency-bound otherwise)
     for (int base = 0; base < rows; base += 64 * 24) {
         if (sp.kind != SP_DENSE && !(base / 64 < max(br.b1, br.b3) && base / 64 + 24 > min(br.b0, br.b2 < br.b3 ? br.b2 : br.b0))) continue;   // nothing of this batch is inside the structure
@@ -45,8 +80,8 @@ __global__ __launch_bounds__(256) void k_gemv_t(Batch bt, Sparsity sp, int rows,
 #pragma unroll
         for (int q = 0; q < 24; q += 2) {
             const int i = base + lane + 64 * q;
-            acc0 += v[q] * (i < rows ? x[i] : 0.0);
-            acc1 += v[q + 1] * (i + 64 < rows ? x[i + 64] : 0.0);
+            acc0 = fma(v[q], i < rows ? x[i] : 0.0, acc0);
+            acc1 = fma(v[q + 1], i + 64 < rows ? x[i + 64] : 0.0, acc1);
         }
     }
     const double r = wave_sum(acc0 + acc1);
@@ -66,6 +101,12 @@ __global__ __launch_bounds__(256) void k_gemv_t2(Batch bt, Sparsity sp, int rows
     const double* a = A + (size_t)col * ld;
     const BlockRanges br = column_blocks(sp, col, rows);
     double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
+    if (sp.kind != SP_DENSE) {
+        const double* const xs[2] = {x1, x2};
+        double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
+        structured_column<2>(br, rows, lane, a, xs, a0, a1);
+        p0 = a0[0]; p1 = a1[0]; q0 = a0[1]; q1 = a1[1];
+    } else
     for (int base = 0; base < rows; base += 64 * 24) {
         if (sp.kind != SP_DENSE && !(base / 64 < max(br.b1, br.b3) && base / 64 + 24 > min(br.b0, br.b2 < br.b3 ? br.b2 : br.b0))) continue;
         double v[24];
@@ -75,8 +116,8 @@ __global__ __launch_bounds__(256) void k_gemv_t2(Batch bt, Sparsity sp, int rows
         for (int q = 0; q < 24; q += 2) {
             const int i = base + lane + 64 * q;
             const bool in0 = i < rows, in1 = i + 64 < rows;
-            p0 += v[q] * (in0 ? x1[i] : 0.0); p1 += v[q + 1] * (in1 ? x1[i + 64] : 0.0);
-            q0 += v[q] * (in0 ? x2[i] : 0.0); q1 += v[q + 1] * (in1 ? x2[i + 64] : 0.0);
+            p0 = fma(v[q], in0 ? x1[i] : 0.0, p0); p1 = fma(v[q + 1], in1 ? x1[i + 64] : 0.0, p1);
+            q0 = fma(v[q], in0 ? x2[i] : 0.0, q0); q1 = fma(v[q + 1], in1 ? x2[i + 64] : 0.0, q1);
         }
     }
     const double r1 = wave_sum(p0 + p1), r2 = wave_sum(q0 + q1);
@@ -119,8 +160,10 @@ __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, Sparsity s
     if (sp.kind == SP_LXX) { jlo = i - sp.hb; jhi = i + sp.hb + 1; }
     else if (sp.kind != SP_DENSE) { jlo = sp.rowrange[2 * (row_off + i)]; jhi = sp.rowrange[2 * (row_off + i) + 1]; }
     double acc0 = 0.0, acc1 = 0.0;
+    if (sp.kind != SP_DENSE && (c1 <= jlo || c0 >= jhi)) { partial[(size_t)blockIdx.y * rows + i] = 0.0; return; }   // nothing of this chunk is inside the row's range
     // batches of 24 loads per lane, all issued before the first use
     for (int j0 = c0; j0 < c1; j0 += 24) {
+        if (sp.kind != SP_DENSE && (j0 + 24 <= jlo || j0 >= jhi)) continue;                                             // (a batch of exact zeros)
         double v[24];
 #pragma unroll
         for (int q = 0; q < 24; ++q) { const int j = j0 + q; v[q] = (j < c1 && j >= jlo && j < jhi) ? A[i + (size_t)j * ld] : 0.0; }
