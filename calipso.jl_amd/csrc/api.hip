@@ -119,7 +119,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->Lxx, NX * NX); SL(&s->Lsym, NX * NX); SL(&s->Z, M * NX);
     SL(&s->fx, NX); SL(&s->gyx, NX); SL(&s->hzx, NX); SL(&s->gh, M);
     SL(&s->cone_product, NC); SL(&s->cone_target, NC); SL(&s->barrier_gradient, NC);
-    SL(&s->dscal, 64);
+    SL(&s->dscal, 64); SL(&s->refpart, (NE + NC + 255) / 256 + 1);
     SL(&s->solution, N); SL(&s->candidate, N); SL(&s->lambda, NE); SL(&s->parameters, (size_t)d.np);
     SL(&s->residual, N); SL(&s->residual_error, N); SL(&s->step, N); SL(&s->step_correction, N);
     SL(&s->saved_point, N); SL(&s->saved_g, NE); SL(&s->saved_h, NC);

@@ -155,6 +155,7 @@ struct calipso_hip_solver {
     // factorisation
     double* S = nullptr;        // NP*NP: Schur complement onto x, then L (unit lower) in place
     double* Dx = nullptr;       // NP: pivots of S
+    double* refpart = nullptr;  // per workgroup of k_refine_local: its part of ||residual_error||_inf
     double* Ypanel = nullptr;   // 2 x NP*NB: L21*D of the current panel (and of the next one in the pair schedule of ldl.hip)
     double* Tinv = nullptr;     // (NP/512) * 512*512: inverses of the unit-lower 512 x 512 diagonal blocks of L
     double* Ttmp = nullptr;     // NP*128 scratch of the inverse assembly

@@ -498,95 +498,107 @@ void launch_residual_error(calipso_hip_solver* s, const double* step) {
 // operand t1 = Omega b_m.  k_refine_local does that; then ONE pass over [gx; hx] yields both transposed products (gemv_t2), one pass over Lxx
 // the Hessian product, and k_refine_x finishes the x rows, the norm and the solve operand xbuf = b_x + [gx; hx]' Omega b_m.
 // A round thus reads [gx; hx] twice (here and for t2 = [gx; hx] dx in the solve) instead of three times.
-__global__ __launch_bounds__(RT) void k_refine_local(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
-                                                      const double* __restrict__ res, const double* __restrict__ zsx, const double* __restrict__ wz,
-                                                      const double* __restrict__ Wsoc, double* __restrict__ e, double* __restrict__ rsym,
-                                                      double* __restrict__ t1, double* __restrict__ dscal) {
-    __shared__ double sm[RT / 64];
-    inst_shift(bt.b, w, v, res, zsx, wz, Wsoc, e, rsym, t1, dscal);
+// One work item per CONSTRAINT (equality row, nonnegative entry, second-order cone): the item forms the rows of residual_error that belong to it
+// (r, y for an equality; s, z, t for a cone) and, from them, its entries of the condensed right-hand side and of t1 — nothing crosses items, so the
+// kernel runs on as many workgroups as the constraints fill; every workgroup leaves its part of the infinity norm in part[blockIdx.x] (k_refine_x
+// combines them: a maximum, exact in any order).
+constexpr int RL_THREADS = 256;
+__global__ __launch_bounds__(RL_THREADS) void k_refine_local(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
+                                                              const double* __restrict__ res, const double* __restrict__ zsx, const double* __restrict__ wz,
+                                                              const double* __restrict__ Wsoc, double* __restrict__ e, double* __restrict__ rsym,
+                                                              double* __restrict__ t1, double* __restrict__ part) {
+    __shared__ double sm[RL_THREADS / 64];
+    inst_shift(bt.b, w, v, res, zsx, wz, Wsoc, e, rsym, t1, part);
     const Scalars sc = bt.sc[blockIdx.z];
     const double* sl = w + d.os(); const double* t = w + d.ot();
     const double* vs = v + d.os(); const double* vt = v + d.ot();
+    const double Hrr = sc.rho + sc.ep, Hss = 0.0 + sc.ep;
     double m = 0.0;
-    for (int i = d.nx + threadIdx.x; i < d.N; i += RT) {
-        double hv;
-        if (i < d.os()) hv = (sc.rho + sc.ep) * v[i] - v[d.oy() + i - d.orr()];
-        else if (i < d.oy()) { const int k = i - d.os(); hv = (0.0 + sc.ep) * v[i] - v[d.oz() + k] - v[d.ot() + k]; }
-        else if (i < d.oz()) hv = zsx[i - d.oy()] + (-v[d.orr() + i - d.oy()] + (0.0 - sc.ed) * v[i]);
-        else if (i < d.ot()) hv = zsx[d.ne + i - d.oz()] + (-v[d.os() + i - d.oz()] + (0.0 - sc.ed) * v[i]);
-        else {
-            const int k = i - d.ot();
-            const int j = cd.entry_soc[k];
-            if (j < 0) hv = t[k] * vs[k] + (sl[k] - sc.ed) * vt[k];
-            else {
-                const int st = cd.soc_start[j], dim = cd.soc_dim[j];
-                if (k == st) {
-                    hv = t[st] * vs[st] + (sl[st] - sc.ed) * vt[st];
-                    for (int q = 1; q < dim; ++q) hv += t[st + q] * vs[st + q] + sl[st + q] * vt[st + q];
-                } else {
-                    hv = t[k] * vs[st] + sl[k] * vt[st];
-                    hv += t[st] * vs[k] + (sl[st] - sc.ed) * vt[k];
-                }
+    const int ee = blockIdx.x * RL_THREADS + threadIdx.x;
+    if (ee < d.ne) {
+        const int ir = d.orr() + ee, iy = d.oy() + ee;
+        const double hr = (sc.rho + sc.ep) * v[ir] - v[d.oy() + ir - d.orr()];
+        const double er = res[ir] - hr;
+        const double hy = zsx[iy - d.oy()] + (-v[d.orr() + iy - d.oy()] + (0.0 - sc.ed) * v[iy]);
+        const double ey = res[iy] - hy;
+        e[ir] = er; e[iy] = ey;
+        m = fmax(fabs(er), fabs(ey));
+        double b = ey;
+        b += er / Hrr;
+        rsym[d.nx + ee] = b;
+        const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+        t1[ee] = omega_y * b;
+    } else if (ee < d.ne + d.q) {
+        const int k = ee - d.ne;
+        const int is = d.os() + k, iz = d.oz() + k, it = d.ot() + k;
+        const double hs = (0.0 + sc.ep) * v[is] - v[d.oz() + k] - v[d.ot() + k];
+        const double es = res[is] - hs;
+        const double hz = zsx[d.ne + iz - d.oz()] + (-v[d.os() + iz - d.oz()] + (0.0 - sc.ed) * v[iz]);
+        const double ez = res[iz] - hz;
+        const double ht = t[k] * vs[k] + (sl[k] - sc.ed) * vt[k];
+        const double et = res[it] - ht;
+        e[is] = es; e[iz] = ez; e[it] = et;
+        m = fmax(fmax(fabs(es), fabs(ez)), fabs(et));
+        const double Sb = w[d.os() + k] - sc.ed, Ti = w[d.ot() + k], Pi = Hss;
+        double b = ez;
+        b += (et + Sb * es) / (Ti + Sb * Pi);
+        rsym[d.nx + d.ne + k] = b;
+        t1[d.ne + k] = wz[k] * b;
+    } else if (ee < d.ne + d.q + d.n_soc) {
+        const int j = ee - d.ne - d.q;
+        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        double rs[MAX_SOC_DIM], rt[MAX_SOC_DIM], rz[MAX_SOC_DIM];
+        for (int a = 0; a < dim; ++a) {
+            const int k = st + a;
+            const int is = d.os() + k, iz = d.oz() + k, it = d.ot() + k;
+            const double hs = (0.0 + sc.ep) * v[is] - v[d.oz() + k] - v[d.ot() + k];
+            rs[a] = res[is] - hs;
+            const double hz = zsx[d.ne + iz - d.oz()] + (-v[d.os() + iz - d.oz()] + (0.0 - sc.ed) * v[iz]);
+            rz[a] = res[iz] - hz;
+            double ht;
+            if (a == 0) {
+                ht = t[st] * vs[st] + (sl[st] - sc.ed) * vt[st];
+                for (int q = 1; q < dim; ++q) ht += t[st + q] * vs[st + q] + sl[st + q] * vt[st + q];
+            } else {
+                ht = t[k] * vs[st] + sl[k] * vt[st];
+                ht += t[st] * vs[k] + (sl[st] - sc.ed) * vt[k];
             }
+            rt[a] = res[it] - ht;
+            e[is] = rs[a]; e[iz] = rz[a]; e[it] = rt[a];
+            m = fmax(m, fmax(fmax(fabs(rs[a]), fabs(rz[a])), fabs(rt[a])));
         }
-        const double r = res[i] - hv;
-        e[i] = r;
-        m = fmax(m, fabs(r));
+        double u[MAX_SOC_DIM], vv[MAX_SOC_DIM], o[MAX_SOC_DIM];
+        const double* slj = w + d.os() + st; const double* tj = w + d.ot() + st;
+        const double sb1 = slj[0] - sc.ed;
+        u[0] = tj[0] + sb1 * Hss;
+        for (int k = 1; k < dim; ++k) u[k] = tj[k] + slj[k] * Hss;
+        double acc = sb1 * rs[0];
+        for (int k = 1; k < dim; ++k) acc += slj[k] * rs[k];
+        vv[0] = acc + rt[0];
+        for (int k = 1; k < dim; ++k) vv[k] = (slj[k] * rs[0] + sb1 * rs[k]) + rt[k];
+        arrow_inverse(dim, u, vv, o);
+        for (int k = 0; k < dim; ++k) { o[k] = rz[k] + o[k]; rsym[d.nx + d.ne + st + k] = o[k]; }
+        const double* W = Wsoc + cd.soc_woff[j];
+        for (int a = 0; a < dim; ++a) {
+            double ss = 0.0;
+            for (int b = 0; b < dim; ++b) ss += W[a + b * dim] * o[b];
+            t1[d.ne + st + a] = ss;
+        }
     }
     const double mr = block_max(m, sm);
-    if (threadIdx.x == 0) dscal[18] = mr;
-    __threadfence_block();
-    __syncthreads();                           // the rows written above are read below by other lanes of this (single) workgroup
-    // condensed right-hand side of the constraint rows and t1 = Omega b_m  (= the constraint part of k_residual_symmetric on residual_error)
-    const double Hrr = sc.rho + sc.ep, Hss = 0.0 + sc.ep;
-    for (int ee = threadIdx.x; ee < d.ne + d.q + d.n_soc; ee += RT) {
-        if (ee < d.ne) {
-            double b = e[d.oy() + ee];
-            b += e[d.orr() + ee] / Hrr;
-            rsym[d.nx + ee] = b;
-            const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
-            t1[ee] = omega_y * b;
-        } else if (ee < d.ne + d.q) {
-            const int k = ee - d.ne;
-            const double Sb = w[d.os() + k] - sc.ed, Ti = w[d.ot() + k], Pi = Hss;
-            double b = e[d.oz() + k];
-            b += (e[d.ot() + k] + Sb * e[d.os() + k]) / (Ti + Sb * Pi);
-            rsym[d.nx + d.ne + k] = b;
-            t1[d.ne + k] = wz[k] * b;
-        } else {
-            const int j = ee - d.ne - d.q;
-            const int st = cd.soc_start[j], dim = cd.soc_dim[j];
-            double u[MAX_SOC_DIM], vv[MAX_SOC_DIM], o[MAX_SOC_DIM];
-            const double* slj = w + d.os() + st; const double* tj = w + d.ot() + st;
-            const double* rs = e + d.os() + st; const double* rt = e + d.ot() + st;
-            const double sb1 = slj[0] - sc.ed;
-            u[0] = tj[0] + sb1 * Hss;
-            for (int k = 1; k < dim; ++k) u[k] = tj[k] + slj[k] * Hss;
-            double acc = sb1 * rs[0];
-            for (int k = 1; k < dim; ++k) acc += slj[k] * rs[k];
-            vv[0] = acc + rt[0];
-            for (int k = 1; k < dim; ++k) vv[k] = (slj[k] * rs[0] + sb1 * rs[k]) + rt[k];
-            arrow_inverse(dim, u, vv, o);
-            for (int k = 0; k < dim; ++k) { o[k] = e[d.oz() + st + k] + o[k]; rsym[d.nx + d.ne + st + k] = o[k]; }
-            const double* W = Wsoc + cd.soc_woff[j];
-            for (int a = 0; a < dim; ++a) {
-                double ss = 0.0;
-                for (int b = 0; b < dim; ++b) ss += W[a + b * dim] * o[b];
-                t1[d.ne + st + a] = ss;
-            }
-        }
-    }
+    if (threadIdx.x == 0) part[blockIdx.x] = mr;
 }
 
 // x rows: residual_error_x = residual_x - ((Lxx step_x + [gx; hx]' step_yz) + ep step_x); dscal[7] = ||residual_error||_inf (with the partial norm of
 // k_refine_local); condensed b_x = residual_error_x; xbuf = [b_x + [gx; hx]' Omega b_m; 0]
 __global__ __launch_bounds__(RT) void k_refine_x(BatchSc bt, Dims d, int have_m, const double* __restrict__ v, const double* __restrict__ res,
                                                   const double* __restrict__ lxv, const double* __restrict__ w1, const double* __restrict__ w2,
-                                                  double* __restrict__ e, double* __restrict__ rsym, double* __restrict__ xbuf, double* __restrict__ dscal) {
+                                                  double* __restrict__ e, double* __restrict__ rsym, double* __restrict__ xbuf, double* __restrict__ dscal, const double* __restrict__ part, int nparts) {
     __shared__ double sm[RT / 64];
-    inst_shift(bt.b, v, res, lxv, w1, w2, e, rsym, xbuf, dscal);
+    inst_shift(bt.b, v, res, lxv, w1, w2, e, rsym, xbuf, dscal, part);
     const Scalars sc = bt.sc[blockIdx.z];
     double m = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += RT) m = fmax(m, part[i]);     // the other rows' part of the norm (k_refine_local)
     for (int i = threadIdx.x; i < d.NP; i += RT) {
         if (i < d.nx) {
             const double hv = (lxv[i] + (have_m ? w1[i] : 0.0)) + sc.ep * v[i];
@@ -598,18 +610,21 @@ __global__ __launch_bounds__(RT) void k_refine_x(BatchSc bt, Dims d, int have_m,
         } else xbuf[i] = 0.0;
     }
     const double mr = block_max(m, sm);
-    if (threadIdx.x == 0) dscal[7] = fmax(mr, dscal[18]);
+    if (threadIdx.x == 0) dscal[7] = mr;
 }
 
 void launch_refine_local(calipso_hip_solver* s) {
     const BatchSc B = batch_of(s);
-    hipLaunchKernelGGL(k_refine_local, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->cone, s->solution, s->step, s->residual, s->zsx, s->wz, s->Wsoc,
-                       s->residual_error, s->residual_symmetric, s->t1, s->dscal);
+    const int items = s->d.ne + s->d.q + s->d.n_soc;
+    if (items == 0) return;
+    hipLaunchKernelGGL(k_refine_local, dim3((items + RL_THREADS - 1) / RL_THREADS, 1, B.b.n), dim3(RL_THREADS), 0, s->stream, B, s->d, s->cone, s->solution, s->step,
+                       s->residual, s->zsx, s->wz, s->Wsoc, s->residual_error, s->residual_symmetric, s->t1, s->refpart);
 }
 void launch_refine_x(calipso_hip_solver* s) {
     const BatchSc B = batch_of(s);
+    const int items = s->d.ne + s->d.q + s->d.n_soc;
     hipLaunchKernelGGL(k_refine_x, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->d.m > 0 ? 1 : 0, s->step, s->residual, s->lxv, s->w1, s->w2, s->residual_error,
-                       s->residual_symmetric, s->xbuf, s->dscal);
+                       s->residual_symmetric, s->xbuf, s->dscal, s->refpart, (items + RL_THREADS - 1) / RL_THREADS);
 }
 
 __global__ void k_add(Batch bt, int n, double* __restrict__ y, const double* __restrict__ x) {
