@@ -76,4 +76,31 @@ __device__ __forceinline__ void arrow_inverse(int n, const double* u, const doub
     for (int i = 1; i < n; ++i) out[i] = 1.0 / u[0] * out[i];
 }
 
+
+// arrow_inverse for cones of dimension <= MAXD with every loop unrolled to constant indices (the arrays stay in registers): the operations and
+// their order are those of arrow_inverse, so the result is the same to the bit
+template <int MAXD>
+__device__ __forceinline__ void arrow_inverse_small(int n, const double (&u)[MAXD], const double (&x)[MAXD], double (&out)[MAXD]) {
+    double uu = 0.0;
+#pragma unroll
+    for (int i = 1; i < MAXD; ++i) if (i < n) uu += u[i] * u[i];
+    const double alpha = -1.0 / (u[0] * u[0]) * uu;
+    const double beta = 1.0 / (1.0 + alpha);
+    double d0 = 0.0;
+#pragma unroll
+    for (int i = 1; i < MAXD; ++i) if (i < n) d0 += (u[i] / u[0]) * x[i];
+    const double x0_1 = x[0] - d0;
+    double d1 = 0.0;
+#pragma unroll
+    for (int i = 1; i < MAXD; ++i) if (i < n) {
+        const double v = x[i] - beta * ((u[i] / u[0]) * x0_1);
+        out[i] = v;
+        d1 += (u[i] / u[0]) * v;
+    }
+    const double x2_1 = x[0] - d1;
+    out[0] = 1.0 / u[0] * x2_1;
+#pragma unroll
+    for (int i = 1; i < MAXD; ++i) if (i < n) out[i] = 1.0 / u[0] * out[i];
+}
+
 }  // namespace calipso

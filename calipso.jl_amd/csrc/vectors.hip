@@ -215,6 +215,69 @@ __global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restri
     } else if (i < d.nx + d.ne + d.q + d.n_soc) {
         const int j = i - d.nx - d.ne - d.q;
         const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        if (dim <= 4) {
+            // small cones (friction cones, SOC2 / SOC3): everything the cone needs is fetched in ONE round of independent loads into registers and the
+            // loops are unrolled to constant indices; the operations and their order are those of the general branch below
+            constexpr int MD = 4;
+            double sl[MD], t[MD], rs[MD], rt[MD], bb[MD], tt[MD], zz[MD], W[MD * MD];
+            const int woff = cd.soc_woff[j];
+#pragma unroll
+            for (int a = 0; a < MD; ++a) {
+                const bool in = a < dim;
+                sl[a] = in ? w[d.os() + st + a] : 0.0; t[a] = in ? w[d.ot() + st + a] : 0.0;
+                rs[a] = in ? res[d.os() + st + a] : 0.0; rt[a] = in ? res[d.ot() + st + a] : 0.0;
+                bb[a] = in ? b[d.nx + d.ne + st + a] : 0.0; tt[a] = in ? t2[d.ne + st + a] : 0.0;
+                zz[a] = (in && zsx_mode == 2) ? zsx[d.ne + st + a] : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < MD * MD; ++e) W[e] = 0.0;
+#pragma unroll
+            for (int c = 0; c < MD; ++c)
+#pragma unroll
+                for (int a = 0; a < MD; ++a) if (a < dim && c < dim) W[a + c * MD] = Wsoc[woff + a + c * dim];
+            double u[MD], v[MD], ds[MD], o[MD], dz[MD];
+#pragma unroll
+            for (int a = 0; a < MD; ++a) { o[a] = bb[a] - tt[a]; u[a] = 0.0; v[a] = 0.0; ds[a] = 0.0; dz[a] = 0.0; }
+            if (zsx_mode) {
+#pragma unroll
+                for (int a = 0; a < MD; ++a) if (a < dim) zsx[d.ne + st + a] = zsx_mode == 1 ? tt[a] : zz[a] + tt[a];
+            }
+#pragma unroll
+            for (int a = 0; a < MD; ++a) if (a < dim) {
+                double s = 0.0;
+#pragma unroll
+                for (int c = 0; c < MD; ++c) if (c < dim) s += W[a + c * MD] * o[c];
+                dz[a] = -1.0 * s;
+                dsym[d.nx + d.ne + st + a] = dz[a];
+            }
+            const double sb1 = sl[0] - sc.ed;
+            u[0] = t[0] + sb1 * Hss;
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) u[k] = t[k] + sl[k] * Hss;
+            double acc = sb1 * (rs[0] + dz[0]);
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) acc += sl[k] * (rs[k] + dz[k]);
+            v[0] = rt[0] + acc;
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) v[k] = rt[k] + (sl[k] * (rs[0] + dz[0]) + sb1 * (rs[k] + dz[k]));
+            arrow_inverse_small<MD>(dim, u, v, ds);
+            acc = t[0] * ds[0];
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) acc += t[k] * ds[k];
+            v[0] = rt[0] - acc;
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) v[k] = rt[k] - (t[k] * ds[0] + t[0] * ds[k]);
+            u[0] = sb1;
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) u[k] = sl[k];
+            arrow_inverse_small<MD>(dim, u, v, o);
+#pragma unroll
+            for (int k = 0; k < MD; ++k) if (k < dim) {
+                step[d.oz() + st + k] = dz[k]; step[d.os() + st + k] = ds[k]; step[d.ot() + st + k] = o[k];
+                if (accum) { accum[d.oz() + st + k] += dz[k]; accum[d.os() + st + k] += ds[k]; accum[d.ot() + st + k] += o[k]; }
+            }
+            return;
+        }
         double u[MAX_SOC_DIM], v[MAX_SOC_DIM], ds[MAX_SOC_DIM], o[MAX_SOC_DIM], dz[MAX_SOC_DIM];
         const double* sl = w + d.os() + st; const double* t = w + d.ot() + st;
         const double* rs = res + d.os() + st; const double* rt = res + d.ot() + st;
