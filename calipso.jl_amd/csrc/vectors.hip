@@ -610,6 +610,73 @@ __global__ __launch_bounds__(RL_THREADS) void k_refine_local(BatchSc bt, Dims d,
     } else if (ee < d.ne + d.q + d.n_soc) {
         const int j = ee - d.ne - d.q;
         const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+        if (dim <= 4) {
+            // small cones: one round of independent loads into registers, loops unrolled to constant indices, operations and order of the general branch
+            constexpr int MD = 4;
+            double lsl[MD], lt[MD], lvs[MD], lvt[MD], lvz[MD], lres_s[MD], lres_z[MD], lres_t[MD], lzsx[MD], W[MD * MD];
+            const int woff = cd.soc_woff[j];
+#pragma unroll
+            for (int a = 0; a < MD; ++a) {
+                const bool in = a < dim;
+                const int k = st + a;
+                lsl[a] = in ? sl[k] : 0.0; lt[a] = in ? t[k] : 0.0; lvs[a] = in ? vs[k] : 0.0; lvt[a] = in ? vt[k] : 0.0;
+                lvz[a] = in ? v[d.oz() + k] : 0.0;
+                lres_s[a] = in ? res[d.os() + k] : 0.0; lres_z[a] = in ? res[d.oz() + k] : 0.0; lres_t[a] = in ? res[d.ot() + k] : 0.0;
+                lzsx[a] = in ? zsx[d.ne + k] : 0.0;
+            }
+#pragma unroll
+            for (int e2 = 0; e2 < MD * MD; ++e2) W[e2] = 0.0;
+#pragma unroll
+            for (int c = 0; c < MD; ++c)
+#pragma unroll
+                for (int a = 0; a < MD; ++a) if (a < dim && c < dim) W[a + c * MD] = Wsoc[woff + a + c * dim];
+            double rs[MD], rt[MD], rz[MD];
+#pragma unroll
+            for (int a = 0; a < MD; ++a) { rs[a] = 0.0; rt[a] = 0.0; rz[a] = 0.0; }
+#pragma unroll
+            for (int a = 0; a < MD; ++a) if (a < dim) {
+                const int k = st + a;
+                const double hs = (0.0 + sc.ep) * lvs[a] - lvz[a] - lvt[a];
+                rs[a] = lres_s[a] - hs;
+                const double hz = lzsx[a] + (-lvs[a] + (0.0 - sc.ed) * lvz[a]);
+                rz[a] = lres_z[a] - hz;
+                double ht;
+                if (a == 0) {
+                    ht = lt[0] * lvs[0] + (lsl[0] - sc.ed) * lvt[0];
+#pragma unroll
+                    for (int q = 1; q < MD; ++q) if (q < dim) ht += lt[q] * lvs[q] + lsl[q] * lvt[q];
+                } else {
+                    ht = lt[a] * lvs[0] + lsl[a] * lvt[0];
+                    ht += lt[0] * lvs[a] + (lsl[0] - sc.ed) * lvt[a];
+                }
+                rt[a] = lres_t[a] - ht;
+                e[d.os() + k] = rs[a]; e[d.oz() + k] = rz[a]; e[d.ot() + k] = rt[a];
+                m = fmax(m, fmax(fmax(fabs(rs[a]), fabs(rz[a])), fabs(rt[a])));
+            }
+            double u[MD], vv[MD], o[MD];
+#pragma unroll
+            for (int a = 0; a < MD; ++a) { u[a] = 0.0; vv[a] = 0.0; o[a] = 0.0; }
+            const double sb1 = lsl[0] - sc.ed;
+            u[0] = lt[0] + sb1 * Hss;
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) u[k] = lt[k] + lsl[k] * Hss;
+            double acc = sb1 * rs[0];
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) acc += lsl[k] * rs[k];
+            vv[0] = acc + rt[0];
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) vv[k] = (lsl[k] * rs[0] + sb1 * rs[k]) + rt[k];
+            arrow_inverse_small<MD>(dim, u, vv, o);
+#pragma unroll
+            for (int k = 0; k < MD; ++k) if (k < dim) { o[k] = rz[k] + o[k]; rsym[d.nx + d.ne + st + k] = o[k]; }
+#pragma unroll
+            for (int a = 0; a < MD; ++a) if (a < dim) {
+                double ss = 0.0;
+#pragma unroll
+                for (int b2 = 0; b2 < MD; ++b2) if (b2 < dim) ss += W[a + b2 * MD] * o[b2];
+                t1[d.ne + st + a] = ss;
+            }
+        } else {
         double rs[MAX_SOC_DIM], rt[MAX_SOC_DIM], rz[MAX_SOC_DIM];
         for (int a = 0; a < dim; ++a) {
             const int k = st + a;
@@ -646,6 +713,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_refine_local(BatchSc bt, Dims d,
             double ss = 0.0;
             for (int b = 0; b < dim; ++b) ss += W[a + b * dim] * o[b];
             t1[d.ne + st + a] = ss;
+        }
         }
     }
     const double mr = block_max(m, sm);
