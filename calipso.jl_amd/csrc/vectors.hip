@@ -57,7 +57,6 @@ __device__ __forceinline__ double pnorm_term(double v, int ptype) { return ptype
 __global__ __launch_bounds__(RT) void k_violations(Batch bt, Dims d, int ptype, const double* __restrict__ res, const double* __restrict__ w,
                                                     const double* __restrict__ g, const double* __restrict__ prod,
                                                     double* __restrict__ dscal) {
-    __shared__ double sm[RT / 64];
     inst_shift(bt, res, w, g, prod, dscal);
     const int tid = threadIdx.x;
     double rp = 0.0, rprim = 0.0, ry = 0.0, rz = 0.0, rt = 0.0, y1 = 0.0, z1 = 0.0, t1 = 0.0, ginf = 0.0, pinf = 0.0;
@@ -72,17 +71,24 @@ __global__ __launch_bounds__(RT) void k_violations(Batch bt, Dims d, int ptype, 
     }
     for (int i = tid; i < d.ne; i += RT) { y1 += fabs(w[d.oy() + i]); ginf = fmax(ginf, fabs(g[i])); }
     for (int i = tid; i < d.nc; i += RT) { z1 += fabs(w[d.oz() + i]); t1 += fabs(w[d.ot() + i]); pinf = fmax(pinf, fabs(prod[i])); }
-    double r;
-    r = (ptype == 0) ? block_max(rp, sm) : block_sum(rp, sm); if (tid == 0) dscal[8] = (ptype == 2) ? sqrt(r) : r;
-    r = block_max(rprim, sm); if (tid == 0) dscal[9] = r;
-    r = block_max(ry, sm);    if (tid == 0) dscal[10] = r;
-    r = block_max(rz, sm);    if (tid == 0) dscal[11] = r;
-    r = block_max(rt, sm);    if (tid == 0) dscal[12] = r;
-    r = block_sum(y1, sm);    if (tid == 0) dscal[13] = r;
-    r = block_sum(z1, sm);    if (tid == 0) dscal[14] = r;
-    r = block_sum(t1, sm);    if (tid == 0) dscal[15] = r;
-    r = block_max(ginf, sm);  if (tid == 0) dscal[16] = r;
-    r = block_max(pinf, sm);  if (tid == 0) dscal[17] = r;
+    // the ten reductions share ONE barrier round: every wavefront reduces its ten values by shuffles, lane 0 parks them in LDS, and after the barrier
+    // thread q combines the per-wave values of quantity q in wave order — the operations and their order are those of ten block_sum / block_max calls
+    __shared__ double red[10][RT / 64];
+    const int lane = tid & 63, wv = tid >> 6;
+    const double w0 = (ptype == 0) ? wave_max(rp) : wave_sum(rp);
+    const double w1 = wave_max(rprim), w2 = wave_max(ry), w3 = wave_max(rz), w4 = wave_max(rt);
+    const double w5 = wave_sum(y1), w6 = wave_sum(z1), w7 = wave_sum(t1), w8 = wave_max(ginf), w9 = wave_max(pinf);
+    if (lane == 0) {
+        red[0][wv] = w0; red[1][wv] = w1; red[2][wv] = w2; red[3][wv] = w3; red[4][wv] = w4;
+        red[5][wv] = w5; red[6][wv] = w6; red[7][wv] = w7; red[8][wv] = w8; red[9][wv] = w9;
+    }
+    __syncthreads();
+    if (tid < 10) {
+        const bool is_max = tid == 0 ? ptype == 0 : (tid <= 4 || tid >= 8);
+        double r = 0.0;
+        for (int i = 0; i < RT / 64; ++i) r = is_max ? fmax(r, red[tid][i]) : r + red[tid][i];
+        dscal[8 + tid] = (tid == 0 && ptype == 2) ? sqrt(r) : r;
+    }
 }
 
 static int norm_type(double p) { return p == 1.0 ? 1 : (p == 2.0 ? 2 : 0); }
