@@ -395,9 +395,14 @@ __global__ __launch_bounds__(128) void k_publish_words(const unsigned* __restric
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+static int wait_published(H* s, unsigned long long seq);
 static int publish_and_wait(H* s, const void* dsrc, void* hdst_dev, int words) {
     const unsigned long long seq = ++s->pub_seq;
     hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, s->stream, static_cast<const unsigned*>(dsrc), words, static_cast<unsigned*>(hdst_dev), s->hseq_dev, seq);
+    return wait_published(s, seq);
+}
+// spin until the sequence number `seq` (written by a publish kernel or by a producer kernel itself) has arrived
+static int wait_published(H* s, unsigned long long seq) {
     unsigned spins = 0;
     while (__atomic_load_n(s->hseq, __ATOMIC_ACQUIRE) != seq) {
         if ((++spins & 0x3ffffu) == 0) {                      // a faulted queue would never publish: look at the stream now and then
@@ -474,12 +479,12 @@ static void do_sds(H* s, int which, double* accumulate = nullptr) {
 
 // residual_error = residual - H step and its inf-norm (dscal[7]), computed so that the operands of the NEXT condensed solve fall out of the same
 // passes (vectors.hip: k_refine_local / k_refine_x): needs zsx = [gx; hx] step_x
-static void refine_residual(H* s) {
+static void refine_residual(H* s, bool publish = false) {
     const Dims& d = s->d;
     launch_refine_local(s);
     if (d.m) gemv_t2(s, d.m, d.nx, s->Z, d.m, s->step + d.oy(), s->t1, s->w1, s->w2, SP_Z);
     gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, s->step, s->lxv, 1.0, 0.0, SP_LXX);
-    launch_refine_x(s);
+    launch_refine_x(s, publish);
 }
 // the condensed solve for the operands refine_residual left (xbuf, residual_symmetric); step += correction, zsx += [gx; hx] dx
 static void refine_solve(H* s) {
@@ -494,8 +499,8 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
     const Options& o = s->opt; const Dims& d = s->d;
     fill_d(s, s->step_correction, s->d.N, 0.0);
     if (!zsx_valid && d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->step, s->zsx, 1.0, 0.0, SP_Z);
-    refine_residual(s);
-    if (read_scalars(s, 7, 1)) return CALIPSO_ERR_HIP;
+    refine_residual(s, true);                  // (k_refine_x itself publishes the norm: no separate read-back launch)
+    if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
     double norm = s->hscal[7];
     const double norm0 = norm;
     int it = 0;
@@ -507,8 +512,8 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
             return CALIPSO_OK;
         }
         refine_solve(s);                   // step += step_correction fused into the recovery kernel
-        refine_residual(s);
-        if (read_scalars(s, 7, 1)) return CALIPSO_ERR_HIP;
+        refine_residual(s, true);
+        if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
         norm = s->hscal[7];
         it += 1;
     }

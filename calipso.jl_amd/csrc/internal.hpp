@@ -223,7 +223,7 @@ void launch_recover(calipso_hip_solver* s, double* step, const double* res, doub
 // one refinement residual in two kernels around the mat-vecs (see vectors.hip): rows r, s, y, z, t of residual_error = residual - H step from
 // zsx, the condensed b_m and t1 = Omega b_m, partial norm -> dscal[18]; then the x rows, dscal[7] = ||residual_error||_inf, xbuf = [b_x + w2; 0]
 void launch_refine_local(calipso_hip_solver* s);
-void launch_refine_x(calipso_hip_solver* s);
+void launch_refine_x(calipso_hip_solver* s, bool publish = false);   // publish: dscal[7] also to the handle's mapped host mirror + sequence number
 void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s);
 void launch_accept(calipso_hip_solver* s, double step_size);
 void launch_axpy_points_batch(calipso_hip_solver* s, const double* step_size, int with_s);

@@ -730,7 +730,8 @@ __global__ __launch_bounds__(RL_THREADS) void k_refine_local(BatchSc bt, Dims d,
 // k_refine_local); condensed b_x = residual_error_x; xbuf = [b_x + [gx; hx]' Omega b_m; 0]
 __global__ __launch_bounds__(RT) void k_refine_x(BatchSc bt, Dims d, int have_m, const double* __restrict__ v, const double* __restrict__ res,
                                                   const double* __restrict__ lxv, const double* __restrict__ w1, const double* __restrict__ w2,
-                                                  double* __restrict__ e, double* __restrict__ rsym, double* __restrict__ xbuf, double* __restrict__ dscal, const double* __restrict__ part, int nparts) {
+                                                  double* __restrict__ e, double* __restrict__ rsym, double* __restrict__ xbuf, double* __restrict__ dscal, const double* __restrict__ part, int nparts,
+                                                  double* __restrict__ hpub, unsigned long long* __restrict__ hseq, unsigned long long seq) {
     __shared__ double sm[RT / 64];
     inst_shift(bt.b, v, res, lxv, w1, w2, e, rsym, xbuf, dscal, part);
     const Scalars sc = bt.sc[blockIdx.z];
@@ -747,7 +748,14 @@ __global__ __launch_bounds__(RT) void k_refine_x(BatchSc bt, Dims d, int have_m,
         } else xbuf[i] = 0.0;
     }
     const double mr = block_max(m, sm);
-    if (threadIdx.x == 0) dscal[7] = mr;
+    if (threadIdx.x == 0) {
+        dscal[7] = mr;
+        if (hpub) {                        // a single handle: the norm goes straight to mapped host memory, then the sequence number the host spins on
+            hpub[7] = mr;
+            __threadfence_system();
+            __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 void launch_refine_local(calipso_hip_solver* s) {
@@ -757,11 +765,12 @@ void launch_refine_local(calipso_hip_solver* s) {
     hipLaunchKernelGGL(k_refine_local, dim3((items + RL_THREADS - 1) / RL_THREADS, 1, B.b.n), dim3(RL_THREADS), 0, s->stream, B, s->d, s->cone, s->solution, s->step,
                        s->residual, s->zsx, s->wz, s->Wsoc, s->residual_error, s->residual_symmetric, s->t1, s->refpart);
 }
-void launch_refine_x(calipso_hip_solver* s) {
+void launch_refine_x(calipso_hip_solver* s, bool publish) {
     const BatchSc B = batch_of(s);
     const int items = s->d.ne + s->d.q + s->d.n_soc;
     hipLaunchKernelGGL(k_refine_x, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->d.m > 0 ? 1 : 0, s->step, s->residual, s->lxv, s->w1, s->w2, s->residual_error,
-                       s->residual_symmetric, s->xbuf, s->dscal, s->refpart, (items + RL_THREADS - 1) / RL_THREADS);
+                       s->residual_symmetric, s->xbuf, s->dscal, s->refpart, (items + RL_THREADS - 1) / RL_THREADS,
+                       publish ? s->hscal_dev : (double*)nullptr, publish ? s->hseq_dev : (unsigned long long*)nullptr, publish ? ++s->pub_seq : 0ULL);
 }
 
 __global__ void k_add(Batch bt, int n, double* __restrict__ y, const double* __restrict__ x) {
