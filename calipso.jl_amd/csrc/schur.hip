@@ -45,6 +45,72 @@ __global__ __launch_bounds__(1024) void k_cone_weights(BatchSc bt, Dims d, ConeD
         const int st = cd.soc_start[j], dim = cd.soc_dim[j], off = cd.soc_woff[j];
         double* B = Bsoc + off;
         double* W = Wsoc + off;
+        if (dim <= 4) {
+            // small cones: the d x d blocks live in registers (loops unrolled to constant indices); the operations and their order are those of the
+            // general branch below
+            constexpr int MD = 4;
+            double ls[MD], lt[MD], u[MD], c[MD], o[MD], Bm[MD * MD], M[MD * MD];
+#pragma unroll
+            for (int a = 0; a < MD; ++a) { ls[a] = a < dim ? sl[st + a] : 0.0; lt[a] = a < dim ? t[st + a] : 0.0; u[a] = 0.0; c[a] = 0.0; o[a] = 0.0; }
+#pragma unroll
+            for (int e = 0; e < MD * MD; ++e) { Bm[e] = 0.0; M[e] = 0.0; }
+            const double sb1 = ls[0] - sc.ed;
+            u[0] = lt[0] + sb1 * Hss;
+#pragma unroll
+            for (int k = 1; k < MD; ++k) if (k < dim) u[k] = lt[k] + ls[k] * Hss;
+#pragma unroll
+            for (int col = 0; col < MD; ++col) if (col < dim) {
+#pragma unroll
+                for (int a = 0; a < MD; ++a) if (a < dim) c[a] = (a == col) ? sb1 : (col == 0 ? ls[a] : (a == 0 ? ls[col] : 0.0));
+                arrow_inverse_small<MD>(dim, u, c, o);
+#pragma unroll
+                for (int a = 0; a < MD; ++a) if (a < dim) Bm[a + col * MD] = 0.0 - o[a];
+            }
+#pragma unroll
+            for (int a = 0; a < MD; ++a) if (a < dim) Bm[a + a * MD] += (0.0 - sc.ed);
+#pragma unroll
+            for (int b = 0; b < MD; ++b)
+#pragma unroll
+                for (int a = 0; a < MD; ++a) if (a < dim && b < dim) { B[a + b * dim] = Bm[a + b * MD]; M[a + b * MD] = (a <= b) ? Bm[a + b * MD] : Bm[b + a * MD]; }
+#pragma unroll
+            for (int jj = 0; jj < MD; ++jj) if (jj < dim) {
+                const double dj = M[jj + jj * MD];
+                pos += dj > 0.0; nonpos += dj <= 0.0; zero += dj == 0.0;
+#pragma unroll
+                for (int i = jj + 1; i < MD; ++i) if (i < dim) {
+                    const double yij = M[i + jj * MD];
+                    const double l = yij / dj;
+#pragma unroll
+                    for (int k = jj + 1; k < MD; ++k) if (k <= i) M[i + k * MD] -= l * (k == i ? yij : M[jj + k * MD]);
+                    M[i + jj * MD] = l;
+                    M[jj + i * MD] = yij;
+                }
+            }
+#pragma unroll
+            for (int col = 0; col < MD; ++col) if (col < dim) {
+#pragma unroll
+                for (int a = 0; a < MD; ++a) o[a] = (a == col) ? 1.0 : 0.0;
+#pragma unroll
+                for (int a = 0; a < MD; ++a) if (a < dim) {
+                    double x = o[a];
+#pragma unroll
+                    for (int k = 0; k < MD; ++k) if (k < a) x -= M[a + k * MD] * o[k];
+                    o[a] = x;
+                }
+#pragma unroll
+                for (int a = 0; a < MD; ++a) if (a < dim) o[a] /= M[a + a * MD];
+#pragma unroll
+                for (int a = MD - 1; a >= 0; --a) if (a < dim) {
+                    double x = o[a];
+#pragma unroll
+                    for (int k = 0; k < MD; ++k) if (k > a && k < dim) x -= M[k + a * MD] * o[k];
+                    o[a] = x;
+                }
+#pragma unroll
+                for (int a = 0; a < MD; ++a) if (a < dim) W[a + col * dim] = -o[a];
+            }
+            continue;
+        }
         double* M = work + 2 * off;          // LDL' of the symmetrised block
         double u[MAX_SOC_DIM], c[MAX_SOC_DIM], o[MAX_SOC_DIM];
         const double sb1 = sl[st] - sc.ed;
