@@ -172,9 +172,144 @@ def cpu_baseline(shape, name="C3", staged=None, samples=3, full=False):
                 B0_ii_reference_refactorisation=b0ii, B1_lapack_all_cores=b1, B2_julia_reference=b2)
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_command(n, argv):
+    """the launch `python bench.py --gpus N` turns itself into when it is not already a rank of a torch.distributed job"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: re-exec under torch.distributed.run, one rank per GPU (RCCL over xGMI),
+    so that the plain command really runs N ranks and prints n_gpus = N.  Under torchrun (RANK / WORLD_SIZE set) this is a no-op."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    if args.force_device < 0 and not args.spawn_check:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d asked for, %d HIP device(s) visible" % (args.gpus, have))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = spawn_command(args.gpus, sys.argv[1:])
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+class Exchange:
+    """The post-round exchange (outside the data path): per-problem status rows all-gathered in global problem-id order, step counters
+    all-reduced.  With RCCL ranks (and with one rank) it goes through the PRODUCT's C entry points calipso_hip_comm_* (csrc/comm.hip:
+    ncclAllGather / ncclAllReduce); with the gloo backend (CPU-side tests: two ranks sharing one GPU cannot form an RCCL communicator)
+    through torch.distributed (calipso.jl_amd/batch.py: gather_results)."""
+
+    def __init__(self, pkg, dist, backend, rank, world, device):
+        self.pkg, self.dist, self.rank, self.world = pkg, dist, rank, world
+        self.comm, self.path = None, "torch.distributed (%s)" % backend
+        if world == 1 or backend == "nccl":
+            uid = [pkg.Comm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            self.comm = pkg.Comm(rank, world, uid[0], device=device)
+            self.path = "calipso_hip_comm_gather_status / calipso_hip_comm_allreduce_sum (RCCL ncclAllGather / ncclAllReduce, csrc/comm.hip)"
+
+    def gather(self, status, counters):
+        status = np.ascontiguousarray(status, dtype=np.int32).reshape(-1, 4)
+        if self.comm is not None:
+            rows, counts = self.comm.gather_status(status, self.world * max(1, status.shape[0]) + 16)
+            return rows, self.comm.allreduce_sum(counters), counts
+        from calipso_jl_amd.batch import gather_results
+        rows, tot = gather_results(status, counters)
+        return rows, tot, None
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
+class Workload:
+    """B independent instances of one configuration on this rank's GPU.  Instance 0 is the rank's single system (headline region); the B
+    instances form B / G groups of G (the members of a group are stepped in lockstep through the same launches), `lanes` groups in flight."""
+
+    def __init__(self, pkg, pr, name, rank, world, device, B, G, lanes, dense_structure=False, no_stage_parallel=False):
+        from calipso_jl_amd.batch import BatchSolver, shard_range
+        self.pkg, self.name, self.B, self.G, self.world = pkg, name, max(0, B), max(1, G), world
+        self.staged = STAGED.get(name)
+        self.shape = staged_shape(self.staged) if self.staged else CONFIGS[name]
+        assert self.B % self.G == 0, "--batch must be a multiple of --group"
+        nb = max(self.B, 1)
+        self.ids = list(shard_range(world * nb, rank, world))      # block-contiguous problem ids of this rank
+        # creation order: the first member of every unit first, so that the streams that carry the launches get distinct priority
+        # classes (handles take class = creation index mod 3, calipso_hip_create)
+        G_ = self.G
+        order = [k for k in range(nb) if k % G_ == 0] + [k for k in range(nb) if k % G_ != 0]
+        made = {}
+        for k in order:
+            inst = make_instance(pkg, pr, self.ids[k], self.shape, device, self.staged, not dense_structure)
+            # the dense host copies of the problem data (~100 MB per C3 instance) are only needed until they are on the device
+            made[k] = inst if k == 0 else (None, None, None, None, inst[4])
+            if k != 0:
+                inst[4].problem = None
+                inst[4].methods = None
+        self.prob0 = made[0][0]
+        self.solvers = [made[k][4] for k in range(nb)]
+        self.stage_parallel = None
+        if self.staged is not None and not dense_structure and not no_stage_parallel:
+            # the Schur complement through the multifrontal sparse LDL^T over a nested dissection of its pattern (calipso_hip_set_stage_parallel):
+            # on the handle that leads each unit (its storage covers the unit's G members)
+            try:
+                for k in range(0, nb, G_):
+                    self.stage_parallel = self.solvers[k].set_stage_parallel(True, batch=G_)
+            except pkg.CalipsoHipError as e:                      # a front exceeds one CU's LDS: the blocked factorisation stays
+                self.stage_parallel = dict(refused=str(e))
+        self.single = self.solvers[0]
+        self.units = ([pkg.Group(self.solvers[k:k + G_]) for k in range(0, self.B, G_)] if G_ > 1 else self.solvers[:self.B]) if self.B else []
+        self.batch = BatchSolver(self.units, lanes=lanes) if self.units else None
+
+    def sync(self):
+        for s in self.solvers:
+            s.synchronize()
+
+    def batched_pass(self):
+        out = self.batch.newton_step(advance=False)               # units run concurrently, one HIP stream each
+        return [i for u in out for i in u] if self.G > 1 else out
+
+    def batched_passes(self, P):
+        out = self.batch.newton_steps(P, advance=False)           # lanes run free: independent problems need no pass-level synchronisation
+        return [i for u in out for i in u] if self.G > 1 else out
+
+    def kind(self, dense_structure):
+        st = self.staged
+        if not st:
+            return "dense "
+        return "stage-structured (%d stages, %s treatment) " % (st[0], "dense" if dense_structure else (
+            "banded, stage-parallel multifrontal LDL^T of S" if self.stage_parallel and "levels" in self.stage_parallel else "banded"))
+
+    def describe(self):
+        nx, ne, n_nn, n_soc, dim = self.shape
+        nc = n_nn + n_soc * dim
+        return "nx=%d ne=%d nc=%d (%d R+ + %d x SOC%d), n=%d condensed, N=%d unreduced" % (nx, ne, nc, n_nn, n_soc, dim, nx + ne + nc, nx + 2 * ne + 3 * nc)
+
+    def close(self):
+        if self.batch is not None:
+            self.batch.close()
+        for u in self.units:
+            if hasattr(u, "close"):
+                u.close()
+        self.units, self.batch, self.single = [], None, None
+        for s in self.solvers:
+            s.__del__()
+        self.solvers = []
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 outside torch.distributed.run: bench.py re-launches itself as N ranks (one per GPU)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=36, help="batched region: independent problem instances per GPU (B), arranged in groups of --group\n"
@@ -193,9 +328,17 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=3)
     ap.add_argument("--no-single", action="store_true", help="profiling runs: skip the single-system region (every launch in the trace then carries a\n"
                     "whole group); the headline then falls back to the batched rate")
+    ap.add_argument("--no-c4", action="store_true", help="skip the config.c4 block (BASELINE config 4: C4 dense and C4T stage-structured, 32 instances per GPU\n"
+                    "in groups of 16); it only runs with --config C3")
+    ap.add_argument("--c4-batch", type=int, default=32, help="config.c4: instances per GPU (BASELINE config 4: 256 problems over 8 GPUs)")
+    ap.add_argument("--c4-group", type=int, default=16)
+    ap.add_argument("--c4-configs", default=None, help="the configurations of the config.c4 block (default: C4,C4T with --config C3, none otherwise)")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets two ranks share one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="testing only: every rank uses this device ordinal")
+    ap.add_argument("--spawn-check", action="store_true", help="testing only (runs without a GPU): start the ranks, all-gather their ids and print\n"
+                    "{\"spawn_check\": true, \"n_gpus\": N, \"ranks\": [...]} instead of benchmarking")
     args = ap.parse_args()
+    spawn_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -204,6 +347,18 @@ def main():
     dist = None
     if args.force_device >= 0:
         local_rank = args.force_device
+    if args.spawn_check:
+        ranks = [rank]
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+            ranks = [None] * world
+            dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "0"))))
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"spawn_check": True, "n_gpus": world, "gpus_argument": args.gpus, "ranks": ranks,
+                              "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"}))
+        return
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
@@ -215,45 +370,13 @@ def main():
     from __graft_entry__ import load_package
     pkg = load_package()
     import problems as pr
-    staged = STAGED.get(args.config)
-    shape = staged_shape(staged) if staged else CONFIGS[args.config]
-    B = max(0, args.batch)
-    from calipso_jl_amd.batch import BatchSolver, gather_results, shard_range
-    G = max(1, args.group)
-    assert B % G == 0, "--batch must be a multiple of --group"
-    nb = max(B, 1)
-    ids = list(shard_range(world * nb, rank, world))          # block-contiguous problem ids of this rank
-    # creation order: the first member of every unit first, so that the streams that carry the launches get distinct priority
-    # classes (handles take class = creation index mod 3, calipso_hip_create)
-    order = [k for k in range(nb) if k % G == 0] + [k for k in range(nb) if k % G != 0]
-    made = {}
-    for k in order:
-        inst = make_instance(pkg, pr, ids[k], shape, local_rank, staged, not args.dense_structure)
-        # the dense host copies of the problem data (~100 MB per C3 instance) are only needed until they are on the device
-        made[k] = inst if k == 0 else (None, None, None, None, inst[4])
-        if k != 0:
-            inst[4].problem = None
-            inst[4].methods = None
-    solvers = [made[k][4] for k in range(nb)]
-    stage_parallel = None
-    if staged is not None and not args.dense_structure and not args.no_stage_parallel:
-        # the Schur complement through the multifrontal sparse LDL^T over a nested dissection of its pattern (calipso_hip_set_stage_parallel):
-        # on the handle that leads each unit (its storage covers the unit's G members)
-        try:
-            for k in range(0, nb, max(G, 1)):
-                stage_parallel = solvers[k].set_stage_parallel(True, batch=max(G, 1))
-        except pkg.CalipsoHipError as e:                      # a front exceeds one CU's LDS: the blocked factorisation stays
-            stage_parallel = dict(refused=str(e))
-    single = solvers[0]                                       # the headline system of this rank (problem id = first of its shard)
-    units = ([pkg.Group(solvers[k:k + G]) for k in range(0, B, G)] if G > 1 else solvers[:B]) if B else []
-    batch = BatchSolver(units, lanes=args.lanes) if units else None
+    exchange = Exchange(pkg, dist, args.dist_backend, rank, world, local_rank)
 
-    def barrier():
+    def barrier(wl):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        for s in solvers:
-            s.synchronize()
+        wl.sync()
 
     def max_over_ranks(t):
         if dist is None:
@@ -262,109 +385,154 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    def batched_pass():
-        out = batch.newton_step(advance=False)               # units run concurrently, one HIP stream each
-        return [i for u in out for i in u] if G > 1 else out
+    def run_batched(wl, P, lockstep=False):
+        """timed region over P passes of all B instances of the rank + the post-round exchange; returns (elapsed, infos, k_schur ms samples)"""
+        sch = []
+        barrier(wl)
+        t0 = time.perf_counter()
+        if lockstep:
+            for _ in range(P):
+                infos = wl.batched_pass()
+                sch.append(wl.solvers[0].phase_times()[7])
+        else:
+            infos = wl.batched_passes(P)
+            sch.append(wl.solvers[0].phase_times()[7])
+        barrier(wl)
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        assert all(i["status"] >= 0 for i in infos), "a Newton step of the batched region failed"
+        status = [[int(i["status"] >= 0), P, i["refinement_rounds"], i["factorizations"]] for i in infos]
+        all_status, counters, counts = exchange.gather(status, [float(len(infos) * P)])
+        assert all_status.shape[0] == world * wl.B and int(round(float(counters[0]))) == world * wl.B * P
+        assert all_status[:, 0].all(), "failed Newton steps must not count towards the reported rate"
+        return elapsed, infos, sch
 
+    def run_single(wl, K):
+        infos, sch, ldl, chain, sd, tot = [], [], [], [], [], []
+        barrier(wl)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            infos.append(wl.single.newton_step(advance=False))
+            pt_ = wl.single.phase_times()
+            sch.append(pt_[7]); ldl.append(pt_[3]); sd.append(pt_[2]); tot.append(pt_[6])
+            chain.append(wl.single.kernel_times()[0])
+        barrier(wl)
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        assert all(i["status"] >= 0 for i in infos), "a Newton step of the timed region failed"
+        return elapsed, infos, dict(schur=sch, ldl=ldl, chain=chain, sd=sd, total=tot)
+
+    # =================================================================== headline workload ======================================
+    wl = Workload(pkg, pr, args.config, rank, world, local_rank, args.batch, args.group, args.lanes, args.dense_structure, args.no_stage_parallel)
+    B, G = wl.B, wl.G
+    shape, staged = wl.shape, wl.staged
     # ---- warm-up: W steps of the single system (captures its launch graphs) and of the batched pass ----------------------------
     for _ in range(args.warmup):
         if not args.no_single:
-            single.newton_step(advance=False)
-        if batch is not None:
-            batched_pass()
+            wl.single.newton_step(advance=False)
+        if wl.batch is not None:
+            wl.batched_pass()
     peak_measured = pkg.mfma_f64_peak(local_rank) if rank == 0 else None
 
     # ---- timed region 1 (headline): K sequential Newton steps of ONE system per GPU ------------------------------------------------
     K = args.steps
-    single_elapsed, single_infos, sch_single, ldl_single, sd_single, tot_single = None, [], [], [], [], []
+    single_elapsed, single_infos, ph = None, [], None
     if not args.no_single:
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            single_infos.append(single.newton_step(advance=False))
-            pt_ = single.phase_times()
-            sch_single.append(pt_[7]); ldl_single.append(pt_[3]); sd_single.append(pt_[2]); tot_single.append(pt_[6])
-        barrier()
-        single_elapsed = max_over_ranks(time.perf_counter() - t0)
-        assert all(i["status"] >= 0 for i in single_infos), "a Newton step of the timed region failed"
+        single_elapsed, single_infos, ph = run_single(wl, K)
 
     # ---- unit 0 alone (one group of G instances): its launches have the device to themselves => clean per-launch figures ------------
-    alone, unit_rate = [], None
-    if batch is not None:
-        barrier()
+    alone, alone_chain, unit_rate = [], [], None
+    if wl.batch is not None:
+        barrier(wl)
         n_alone = max(3, min(10, K))
         ts = time.perf_counter()
         for _ in range(n_alone):
-            units[0].newton_step(advance=False)
-            alone.append(units[0].phase_times())
-        units[0].synchronize()
+            wl.units[0].newton_step(advance=False)
+            alone.append(wl.units[0].phase_times())
+            alone_chain.append(wl.solvers[0].kernel_times()[0])
+        wl.units[0].synchronize()
         unit_rate = G * n_alone / (time.perf_counter() - ts)
 
     # ---- timed region 2 (batched): P passes over all B instances of the rank ------------------------------------------------------
     P = max(1, args.batched_passes)
     batched_elapsed, infos, sch_conc = None, None, []
-    if batch is not None:
-        barrier()
-        t0 = time.perf_counter()
-        if args.lockstep_passes:
-            for _ in range(P):
-                infos = batched_pass()
-                sch_conc.append(solvers[0].phase_times()[7])
-        else:                                                 # lanes run free: independent problems need no pass-level synchronisation
-            out_ = batch.newton_steps(P, advance=False)
-            infos = [i for u in out_ for i in u] if G > 1 else out_
-            sch_conc.append(solvers[0].phase_times()[7])
-        barrier()
-        batched_elapsed = max_over_ranks(time.perf_counter() - t0)
-        assert all(i["status"] >= 0 for i in infos), "a Newton step of the batched region failed"
-        # post-round exchange (outside the data path): per-problem status rows all-gathered, step counters all-reduced
-        status = [[int(i["status"] >= 0), P, i["refinement_rounds"], i["factorizations"]] for i in infos]
-        all_status, counters = gather_results(status, [float(len(infos) * P)])
-        assert all_status.shape[0] == world * B and int(counters[0]) == world * B * P
-        assert all_status[:, 0].all(), "failed Newton steps must not count towards the reported rate"
+    if wl.batch is not None:
+        batched_elapsed, infos, sch_conc = run_batched(wl, P, args.lockstep_passes)
 
     info = single_infos[-1] if single_infos else infos[0]
     nx, ne, n_nn, n_soc, dim = shape
     nc = n_nn + n_soc * dim
     m = ne + nc
+    NP = wl.single.padded_nx()
     if single_elapsed is not None:
         value, elapsed, steps_timed = world * K / single_elapsed, single_elapsed, K
     else:                                                     # --no-single (profiling): the batched rate stands in
         value, elapsed, steps_timed = world * B * P / batched_elapsed, batched_elapsed, P
-    # dominant kernel (by flops): the Schur-complement update S = Lxx + ep*I + Z' Omega Z on the fp64 matrix cores (k_schur).
-    # algorithmic flops per instance = multiply-adds of the lower triangle incl. diagonal: per constraint row with w non-zero columns
-    # w (w + 1); dense rows: nx (nx + 1).  Launch duration: HIP events on the stream the kernel runs on (phase_times[7]), averaged over
-    # the launches of the TIMED region (one instance per launch there); the group launch (G instances) is reported beside it.
-    prob0 = made[0][0]
-    wrow = np.concatenate([np.count_nonzero(prob0.A, axis=1), np.count_nonzero(prob0.G, axis=1)]).astype(np.float64)
-    flops1 = float(np.sum(wrow * (wrow + 1.0)))
-    roof = {"kernel": "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)", "bound": "mfma",
-            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "peak_measured": peak_measured,
-            "peak_note": "peak = datasheet fp64 matrix rate (not tabulated in MI355X_MICROARCH.md); peak_measured = calipso_hip_mfma_f64_peak in this run"}
-    pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-    except Exception:
-        pmc = {}
-    if sch_single:
-        ms1 = float(np.mean(sch_single))
-        roof.update(achieved=flops1 / (ms1 * 1e-3) * 1e-12, flops_per_launch=flops1, instances_per_launch=1, avg_launch_ms=ms1)
-        e = pmc.get("single", {}).get("calipso::k_schur") if args.config == "C3" else None
-        roof["traffic"] = e["hbm_bytes_per_launch"] if e else None
-    if alone:
-        msg = float(np.mean([a[7] for a in alone]))
-        grp = dict(achieved=G * flops1 / (msg * 1e-3) * 1e-12, flops_per_launch=G * flops1, instances_per_launch=G, avg_launch_ms=msg,
-                   avg_launch_ms_with_all_units_in_flight=float(np.mean(sch_conc)) if sch_conc else None)
-        e = pmc.get("group", {}).get("calipso::k_schur") if args.config == "C3" else None
-        grp["traffic"] = e["hbm_bytes_per_launch"] * G / float(e.get("instances_per_launch", G)) if e else None
-        grp["frac"] = grp["achieved"] / FP64_MFMA_PEAK_TFLOPS
-        if "achieved" not in roof:
-            roof.update({k: v for k, v in grp.items()})
-        roof["group_launch"] = grp
-    roof["frac"] = roof["achieved"] / FP64_MFMA_PEAK_TFLOPS
-    roof.setdefault("traffic", None)
 
-    # per-phase rooflines from SURVEY.md 8(d)'s algorithmic figures (HIP-event phase times of the handle)
+    # ---- roofline of the DOMINANT kernel = the kernel with the largest share of the headline step -----------------------------------
+    # Two candidates carry matrix-core work (everything else is a few microseconds per launch): the panel-step kernel of the LDL^T of S
+    # (k_ldl_step: one launch per 64 pivots; its first workgroup carries the sequential pivot chain) and the Schur-complement kernel k_schur.
+    # Both are timed live with HIP events on the handle's stream (calipso_hip_kernel_times / phase_times) over the launches of the TIMED
+    # region; whichever takes the larger share of the step is `roofline`, the other goes to roofline.secondary.  Algorithmic flops:
+    #   k_ldl_step  nx^3 / 3 per factorisation (SURVEY 8(d): a dense LDL^T of the nx x nx Schur complement), spread over its NP / 64 - 1 launches
+    #   k_schur     multiply-adds of the lower triangle of S incl. diagonal: per constraint row with w non-zero columns w (w + 1); dense: nx (nx + 1)
+    prob0 = wl.prob0
+    wrow = np.concatenate([np.count_nonzero(prob0.A, axis=1), np.count_nonzero(prob0.G, axis=1)]).astype(np.float64)
+    flops_schur = float(np.sum(wrow * (wrow + 1.0)))
+    flops_ldl = nx ** 3 / 3.0
+    n_ldl_launch = max(1, NP // 64 - 1)
+    pmc = {}
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            pmc["_file"] = "profiles/" + name
+            break
+        except Exception:
+            pmc = {}
+
+    def pmc_traffic(section, kernel_prefix, scale=1.0):
+        if args.config != "C3":
+            return None
+        for kname, e in pmc.get(section, {}).items():
+            if kname.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
+                return e["hbm_bytes_per_launch"] * scale
+        return None
+
+    def entry(kernel, flops_per_factor, launches, ms_total, inst, section, prefix, step_ms):
+        ms_launch = ms_total / launches
+        e = {"kernel": kernel, "bound": "mfma", "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "achieved": inst * flops_per_factor / (ms_total * 1e-3) * 1e-12, "flops_per_launch": inst * flops_per_factor / launches,
+             "launches_per_step": launches, "instances_per_launch": inst, "avg_launch_ms": ms_launch, "ms_per_step": ms_total,
+             "share_of_step": ms_total / step_ms if step_ms else None, "traffic": pmc_traffic(section, prefix)}
+        e["frac"] = e["achieved"] / FP64_MFMA_PEAK_TFLOPS
+        return e
+    K_LDL = "k_ldl_step (LDL^T of the nx x nx Schur complement S, one launch per 64 pivots: trailing update on v_mfma_f64_16x16x4_f64, its first workgroup factors the next diagonal block)"
+    K_SCH = "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)"
+    cands = []
+    if ph is not None:
+        step_ms = float(np.mean(ph["total"]))
+        cands = [entry(K_LDL, flops_ldl, n_ldl_launch, float(np.mean(ph["chain"])), 1, "single", "void calipso::k_ldl_step", step_ms),
+                 entry(K_SCH, flops_schur, 1, float(np.mean(ph["schur"])), 1, "single", "calipso::k_schur", step_ms)]
+    grp = None
+    if alone:
+        al = np.mean(np.asarray(alone), axis=0)
+        grp = [entry(K_LDL, flops_ldl, n_ldl_launch, float(np.mean(alone_chain)), G, "group", "void calipso::k_ldl_step", float(al[6])),
+               entry(K_SCH, flops_schur, 1, float(al[7]), G, "group", "calipso::k_schur", float(al[6]))]
+        grp[1]["avg_launch_ms_with_all_units_in_flight"] = float(np.mean(sch_conc)) if sch_conc else None
+        if not cands:
+            cands = grp
+    if staged is not None:                                    # stage-structured: the LDL^T is the multifrontal path, k_ldl_step does not run
+        cands = [c for c in cands if c["ms_per_step"] > 0] or cands
+    cands.sort(key=lambda c: -c["ms_per_step"])
+    roof = dict(cands[0])
+    roof["secondary"] = cands[1:]
+    roof["dominance"] = ("the kernel with the largest share of the headline step among all kernels (profiles/r03_kernel_stats_single.csv lists every kernel); "
+                         "HIP-event durations of this run")
+    roof["peak_measured"] = peak_measured
+    roof["peak_note"] = ("peak = datasheet fp64 matrix rate (not tabulated in MI355X_MICROARCH.md); peak_measured = calipso_hip_mfma_f64_peak in this run; "
+                         "traffic = (2 FETCH_SIZE + WRITE_SIZE) KiB of %s (separate rocprofv3 --pmc passes of the same command), null when no counter file covers the kernel" % pmc.get("_file", "profiles/"))
+    if grp:
+        roof["group_launch"] = {g["kernel"].split(" ")[0]: g for g in grp}
+
+    # per-phase rooflines: SURVEY.md 8(d)'s algorithmic figures AND the bytes / flops the constraint-first path really executes
     n_cond = nx + m
     n_r = int(info["refinement_rounds"])
 
@@ -372,46 +540,78 @@ def main():
         t_factor = float(al[1] + al[7] + al[3])                       # cone pivots + Schur complement + LDL^T of S
         t_solve = float(al[2]) - t_factor                              # condensed solves + recovery + refinement residuals
         f_survey = inst * n_cond ** 3 / 3.0                            # dense n^3/3 of 8(d)
-        f_exec = inst * (flops1 + nx ** 3 / 3.0)                       # what the constraint-first order executes
-        b_solves = inst * (1 + n_r) * 2 * 8 * n_cond * (n_cond + 1) / 2
-        b_resid = inst * (1 + n_r) * 8.0 * (nx * nx + ne * nx + nc * nx)
+        f_exec = inst * (flops_schur + flops_ldl)                      # what the constraint-first order executes
+        b_survey = inst * (1 + n_r) * (2 * 8 * n_cond * (n_cond + 1) / 2 + 8.0 * (nx * nx + ne * nx + nc * nx))
+        # executed: every solve reads the factor of S twice (L forward, L' backward: NP^2 / 2 doubles each); [gx; hx] is passed over
+        # 2 (first solve) + n_r (correction solves) + n_r + 1 (refinement residuals) times, Lxx n_r + 1 times
+        b_exec = inst * 8.0 * ((1 + n_r) * NP * NP + (2 * n_r + 3) * m * nx + (n_r + 1) * nx * nx)
         return {"instances": inst, "whole_step_ms": float(al[6]),
                 "factor": {"ms": t_factor, "schur_ms": float(al[7]), "ldl_ms": float(al[3]), "bound": "mfma", "flops_survey_n3_over_3": f_survey,
                            "flops_executed": f_exec, "achieved_TFLOPs_survey": f_survey / t_factor * 1e-9,
                            "achieved_TFLOPs_executed": f_exec / t_factor * 1e-9, "frac_executed": f_exec / t_factor * 1e-9 / FP64_MFMA_PEAK_TFLOPS},
-                "solve_and_refine": {"ms": t_solve, "bound": "hbm", "bytes_survey": b_solves + b_resid, "solves": 1 + n_r,
-                                     "achieved_GBs_survey": (b_solves + b_resid) / t_solve * 1e-6,
-                                     "frac_survey": (b_solves + b_resid) / t_solve * 1e-6 / 8000.0}}
+                "solve_and_refine": {"ms": t_solve, "bound": "hbm", "solves": 1 + n_r, "bytes_executed": b_exec, "achieved_GBs_executed": b_exec / t_solve * 1e-6,
+                                     "frac_executed": b_exec / t_solve * 1e-6 / 8000.0, "bytes_survey": b_survey,
+                                     "note": "priced with the bytes the executed path moves (factor of the NP x NP Schur complement, [gx; hx], Lxx); bytes_survey = the "
+                                             "n = nx + ne + nc triangular-solve figure of SURVEY 8(d), kept for reference only"}}
     cfg_phases = {}
-    if tot_single:
-        al1 = np.zeros(9); al1[7] = np.mean(sch_single); al1[3] = np.mean(ldl_single); al1[2] = np.mean(sd_single); al1[6] = np.mean(tot_single)
-        al1[1] = single.phase_times()[1]
+    if ph is not None:
+        al1 = np.zeros(9); al1[7] = np.mean(ph["schur"]); al1[3] = np.mean(ph["ldl"]); al1[2] = np.mean(ph["sd"]); al1[6] = np.mean(ph["total"])
+        al1[1] = wl.single.phase_times()[1]
         cfg_phases["single_system"] = phases(al1, 1)
+        cfg_phases["single_system"]["launches_per_step"] = wl.single.kernel_times()[1]
     if alone:
         cfg_phases["one_group_alone"] = phases(np.mean(np.asarray(alone), axis=0), G)
 
-    kind = ("stage-structured (%d stages, %s treatment) " % (staged[0], "dense" if args.dense_structure else ("banded, stage-parallel multifrontal LDL^T of S"
-            if stage_parallel and "levels" in stage_parallel else "banded"))) if staged else "dense "
     batched = None
     if batched_elapsed is not None:
         brate = world * B * P / batched_elapsed
         batched = {"newton_steps_per_s": brate, "problems_per_s_of_10_steps": brate / 10.0, "instances_per_gpu": B, "instances_per_group": G,
-                   "groups_in_flight": batch.lanes, "passes": P, "lanes_synchronised_per_pass": bool(args.lockstep_passes), "ms_per_pass": 1e3 * batched_elapsed / P, "one_group_alone_steps_per_s": unit_rate,
-                   "scaling": "weak (instances sharded block-contiguously over ranks, no data-path collective)"}
+                   "groups_in_flight": wl.batch.lanes, "passes": P, "lanes_synchronised_per_pass": bool(args.lockstep_passes), "ms_per_pass": 1e3 * batched_elapsed / P, "one_group_alone_steps_per_s": unit_rate,
+                   "scaling": "weak (instances sharded block-contiguously over ranks, no data-path collective)", "post_round_exchange": exchange.path}
+    workload = ("%s synthetic " + wl.kind(args.dense_structure) + "conic QP: %s; %s; 1 LDL^T factorisation, %d refinement round(s) per step") % (
+        args.config, wl.describe(), "ONE system per GPU stepped sequentially (replicas at N > 1)" if single_elapsed is not None
+        else "%d independent instances per GPU (batched rate, --no-single)" % B, info["refinement_rounds"])
+    refinement_rounds, factorizations = info["refinement_rounds"], info["factorizations"]
+    wl.close()
+    del wl
+
+    # =================================================================== config.c4: BASELINE config 4 ===========================
+    # 256 quadruped-gait-sized problems sharded over 8 GPUs = 32 instances per GPU, here in groups of 16, two groups in flight: C4 (the dense
+    # treatment of that size) and C4T (the same size with the stage structure of a 41-stage trajectory problem: band-limited Schur complement,
+    # stage-parallel multifrontal LDL^T).  Same timed-region rules as above; no CPU baseline.
+    c4 = None
+    c4_configs = args.c4_configs if args.c4_configs is not None else ("C4,C4T" if args.config == "C3" else "")
+    if c4_configs and not args.no_c4 and args.c4_batch > 0:
+        c4 = {"instances_per_gpu": args.c4_batch, "instances_per_group": args.c4_group, "problems_total": world * args.c4_batch,
+              "problem": "10 Newton steps of one instance (SURVEY 8(d))"}
+        for cname in [c for c in c4_configs.split(",") if c]:
+            w4 = Workload(pkg, pr, cname, rank, world, local_rank, args.c4_batch, args.c4_group, 2)
+            for _ in range(max(1, min(args.warmup, 2))):
+                w4.single.newton_step(advance=False)
+                w4.batched_pass()
+            K4 = max(3, min(K, 10))
+            e1, i1, _ = run_single(w4, K4)
+            P4 = max(1, min(P, 10))
+            e2, i2, _ = run_batched(w4, P4)
+            r2 = world * w4.B * P4 / e2
+            c4[cname] = {"workload": cname + " " + w4.kind(False) + w4.describe(), "single_system_steps_per_s": world * K4 / e1, "single_ms_per_step": 1e3 * e1 / K4,
+                         "batched_newton_steps_per_s": r2, "batched_problems_per_s_of_10_steps": r2 / 10.0, "ms_per_pass": 1e3 * e2 / P4, "passes": P4,
+                         "refinement_rounds": int(i2[0]["refinement_rounds"]), "stage_parallel": w4.stage_parallel,
+                         "device_bytes_per_instance": w4.single.device_bytes()}
+            w4.close()
+            del w4
+
     out = {
         "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": steps_timed,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps_timed, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": ("%s synthetic " + kind + "conic QP: nx=%d ne=%d nc=%d (%d R+ + %d x SOC%d), n=%d condensed, N=%d unreduced; "
-                                "%s; 1 LDL^T factorisation, %d refinement round(s) per step") % (
-                                   args.config, nx, ne, nc, n_nn, n_soc, dim, nx + m, nx + 2 * ne + 3 * nc,
-                                   "ONE system per GPU stepped sequentially (replicas at N > 1)" if single_elapsed is not None
-                                   else "%d independent instances per GPU (batched rate, --no-single)" % B, info["refinement_rounds"]),
+        "config": {"workload": workload,
                    "parallelism": "one system per GPU: replicas only; batched: independent problems per GPU (no data-path collective)",
-                   "refinement_rounds": info["refinement_rounds"], "factorizations_per_step": info["factorizations"],
-                   "batched": batched, "roofline_phases": cfg_phases},
+                   "refinement_rounds": refinement_rounds, "factorizations_per_step": factorizations,
+                   "batched": batched, "c4": c4, "roofline_phases": cfg_phases},
         "roofline": roof,
     }
+    exchange.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(shape, args.config, staged, samples=args.cpu_samples, full=args.cpu_baseline_full)
     else:

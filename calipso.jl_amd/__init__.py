@@ -393,6 +393,18 @@ class Solver:
         self._L.calipso_hip_phase_times(self._h, _pd(out))
         return out
 
+    def kernel_times(self):
+        """[0] ms of the panel-step launches of the last LDL^T (the pivot chain), [1] their number, [2] NP, [3] bytes of the device slab"""
+        out = np.zeros(8)
+        self._L.calipso_hip_kernel_times(self._h, _pd(out))
+        return out
+
+    def padded_nx(self):
+        return int(self.kernel_times()[2])
+
+    def device_bytes(self):
+        return int(self.kernel_times()[3])
+
     def analyze_structure(self):
         """stage-banded structure from the non-zero pattern of the blocks currently on the device (include/calipso_hip.h); returns
         dict(half_bandwidth, band_blocks (0 = dense treatment), equality_rows_per_group, cone_rows_per_group)"""

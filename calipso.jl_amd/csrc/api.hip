@@ -124,8 +124,8 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->residual, N); SL(&s->residual_error, N); SL(&s->step, N); SL(&s->step_correction, N);
     SL(&s->saved_point, N); SL(&s->saved_g, NE); SL(&s->saved_h, NC);
     SL(&s->residual_symmetric, n); SL(&s->step_symmetric, n); SL(&s->merit_gradient, n);
-    SL(&s->S, NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, 2 * NPd * NB);
-    SL(&s->Tinv, NPd < 512 ? NPd * NPd : (NPd / 512) * 512 * 512); SL(&s->Ttmp, NPd * 128); SL(&s->zf2, NPd); SL(&s->WH, NC * NX);
+    SL(&s->S, NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, NPd * NB);
+    SL(&s->Tinv, calipso::tinv_doubles(d.NP)); SL(&s->Ttmp, NPd * 256); SL(&s->zf2, NPd); SL(&s->WH, NC * NX);
     SL(&s->wz, NC); SL(&s->kzz, NC);
     SL(&s->Wsoc, (size_t)woff); SL(&s->Bsoc, (size_t)woff); SL(&s->socwork, (size_t)2 * woff);
     SL(&icount_d, 32);                                        // 64 ints
@@ -219,8 +219,7 @@ int32_t calipso_hip_destroy(H* s) {
     if (s->hicount) (void)hipHostFree(s->hicount);
     if (s->hseq) (void)hipHostFree(s->hseq);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
-    if (s->graph_ldl) (void)hipGraphExecDestroy(s->graph_ldl);
-    if (s->graph_trsv) (void)hipGraphExecDestroy(s->graph_trsv);
+    calipso::ldl_drop_graphs(s);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return CALIPSO_OK;
@@ -433,7 +432,8 @@ static int do_factorize(H* s, int64_t inertia[3]) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, s->ev[10], s->ev[11]); s->phase_ms[1] = ms;   // cone pivots + Omega*hx
         (void)hipEventElapsedTime(&ms, s->ev[11], s->ev[12]); s->phase_ms[7] = ms;   // Schur complement (MFMA kernel), one launch
-        (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[13]); s->phase_ms[3] = ms;   // LDL^T of S
+        (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[13]); s->phase_ms[3] = ms;
+        (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[14]); s->kernel_ms[0] = ms;   // of which the panel steps (the pivot chain)   // LDL^T of S
         s->phase_ms[8] += 1.0;
     }
     const int64_t pos = s->hicount[0] + s->hicount[3], nonpos = s->hicount[1] + s->hicount[4], zero = s->hicount[2] + s->hicount[5];
@@ -1006,6 +1006,16 @@ extern "C" {
 int32_t calipso_hip_phase_times(H* s, double out[9]) {
     if (!s || !out) return CALIPSO_ERR_ARGUMENT;
     for (int i = 0; i < 9; ++i) out[i] = s->phase_ms[i];
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_kernel_times(H* s, double out[8]) {
+    if (!s || !out) return CALIPSO_ERR_ARGUMENT;
+    for (int i = 0; i < 8; ++i) out[i] = 0.0;
+    out[0] = s->kernel_ms[0];
+    out[1] = (double)(s->d.NP / calipso::NB);
+    out[2] = (double)s->d.NP;
+    out[3] = (double)(s->slab_doubles * sizeof(double));
     return CALIPSO_OK;
 }
 

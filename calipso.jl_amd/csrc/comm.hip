@@ -110,8 +110,9 @@ int64_t calipso_hip_comm_gather_status(calipso_hip_comm* c, const int32_t* rows,
     Rccl& R = rccl();
     HC(hipSetDevice(c->device));
     const int W = c->nranks;
-    long long* d_cnt = nullptr;
-    HC(hipMalloc((void**)&d_cnt, sizeof(long long) * (size_t)(W + 1)));
+    struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } } cntb, rowb;     // freed on every exit
+    HC(hipMalloc(&cntb.p, sizeof(long long) * (size_t)(W + 1)));
+    long long* d_cnt = static_cast<long long*>(cntb.p);
     long long mine = n_rows;
     HC(hipMemcpyAsync(d_cnt + W, &mine, sizeof(long long), hipMemcpyHostToDevice, c->stream));
     NC(R.AllGather(d_cnt + W, d_cnt, 1, ncclInt64, c->comm, c->stream));
@@ -121,19 +122,21 @@ int64_t calipso_hip_comm_gather_status(calipso_hip_comm* c, const int32_t* rows,
     long long kmax = 0, total = 0;
     for (long long k : cnt) { kmax = k > kmax ? k : kmax; total += k; }
     if (counts_out) for (int r = 0; r < W; ++r) counts_out[r] = cnt[(size_t)r];
-    if (total > cap_rows) { (void)hipFree(d_cnt); return fail(c, "calipso_hip_comm_gather_status: all_rows too small"); }
-    int32_t* d_rows = nullptr;
+    // A rank whose all_rows is too small must still take part in the second all-gather (capacities are per rank: leaving here would
+    // hang the others inside the collective); it reports the error afterwards.
+    const bool fits = total <= cap_rows;
     const size_t slot = (size_t)(kmax > 0 ? kmax : 1) * 4;
-    HC(hipMalloc((void**)&d_rows, sizeof(int32_t) * slot * (size_t)(W + 1)));
+    HC(hipMalloc(&rowb.p, sizeof(int32_t) * slot * (size_t)(W + 1)));
+    int32_t* d_rows = static_cast<int32_t*>(rowb.p);
     HC(hipMemsetAsync(d_rows + slot * (size_t)W, 0xff, sizeof(int32_t) * slot, c->stream));     // padding rows = -1
     if (n_rows) HC(hipMemcpyAsync(d_rows + slot * (size_t)W, rows, sizeof(int32_t) * 4 * (size_t)n_rows, hipMemcpyHostToDevice, c->stream));
     NC(R.AllGather(d_rows + slot * (size_t)W, d_rows, slot, ncclInt32, c->comm, c->stream));
     std::vector<int32_t> h(slot * (size_t)W);
     HC(hipMemcpyAsync(h.data(), d_rows, sizeof(int32_t) * slot * (size_t)W, hipMemcpyDeviceToHost, c->stream));
     HC(hipStreamSynchronize(c->stream));
+    if (!fits) return fail(c, "calipso_hip_comm_gather_status: all_rows too small");
     size_t o = 0;
     for (int r = 0; r < W; ++r) { std::memcpy(all_rows + 4 * o, h.data() + slot * (size_t)r, sizeof(int32_t) * 4 * (size_t)cnt[(size_t)r]); o += (size_t)cnt[(size_t)r]; }
-    (void)hipFree(d_cnt); (void)hipFree(d_rows);
     return total;
 }
 
@@ -143,13 +146,13 @@ int32_t calipso_hip_comm_allreduce_sum(calipso_hip_comm* c, double* values, int6
     if (count == 0) return CALIPSO_OK;
     Rccl& R = rccl();
     HC(hipSetDevice(c->device));
-    double* d = nullptr;
-    HC(hipMalloc((void**)&d, sizeof(double) * (size_t)count));
+    struct DevBuf { void* p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } } buf;
+    HC(hipMalloc(&buf.p, sizeof(double) * (size_t)count));
+    double* d = static_cast<double*>(buf.p);
     HC(hipMemcpyAsync(d, values, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c->stream));
     NC(R.AllReduce(d, d, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream));
     HC(hipMemcpyAsync(values, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     HC(hipStreamSynchronize(c->stream));
-    (void)hipFree(d);
     return CALIPSO_OK;
 }
 

@@ -4,6 +4,8 @@
 //     C(M x N) = alpha * op(A)(M x K) * B(K x N) + beta * C          op(A) = A or A', everything column-major
 // 64 x 64 tile per workgroup of 1024 threads (16 wavefronts, one 16 x 16 MFMA tile each), K staged through LDS in chunks of 32.
 #include "internal.hpp"
+
+#include <algorithm>
 #include "device_utils.hpp"
 
 namespace calipso {
@@ -68,7 +70,7 @@ __global__ void k_scale_rows_by_dinv(int NP, int p, const double* __restrict__ D
 // X (NP x p, ld NP) <- S^-1 X with the block factors of ldl.hip: forward  U_k = Tinv_k B_k ; B_rest -= L[rest,k] U_k ;
 // Z = D^-1 U ; backward  V_k = Tinv_k' Z_k ; Z_above -= L[k,above]' V_k.  U and Z are NP x p scratch.
 void trsm_multi(calipso_hip_solver* s, double* X, int p, double* U, double* Zm) {
-    const int NP = s->d.NP, tb = NP < 512 ? NP : 512, nb = NP / tb;
+    const int NP = s->d.NP, tb = trsv_block(NP), nb = (NP + tb - 1) / tb;      // the last block may be narrower (NP = 2560: 1024 + 1024 + 512)
     if (s->stage_parallel && s->spS) {        // the factor lives in the fronts of sparse.hip (calipso_hip_set_stage_parallel): all columns through the tree together
         const BatchSc bsc = batch_of(s);
         if (bsc.b.n == 1 && sparse_solve_inplace_multi(s->spS, s->stream, bsc.b.slot[0], X + bsc.b.delta[0], NP, p) == CALIPSO_OK) return;
@@ -76,16 +78,16 @@ void trsm_multi(calipso_hip_solver* s, double* X, int p, double* U, double* Zm) 
         return;
     }
     for (int kb = 0; kb < nb; ++kb) {
-        const int k0 = kb * tb;
-        gemm(s, tb, p, tb, 1.0, s->Tinv + (size_t)kb * tb * tb, tb, false, X + k0, NP, 0.0, U + k0, NP);
-        const int rest = NP - k0 - tb;
-        if (rest > 0) gemm(s, rest, p, tb, -1.0, s->S + (k0 + tb) + (size_t)k0 * NP, NP, false, U + k0, NP, 1.0, X + k0 + tb, NP);
+        const int k0 = kb * tb, w = std::min(tb, NP - k0);
+        gemm(s, w, p, w, 1.0, s->Tinv + (size_t)kb * tb * tb, tb, false, X + k0, NP, 0.0, U + k0, NP);
+        const int rest = NP - k0 - w;
+        if (rest > 0) gemm(s, rest, p, w, -1.0, s->S + (k0 + w) + (size_t)k0 * NP, NP, false, U + k0, NP, 1.0, X + k0 + w, NP);
     }
     hipLaunchKernelGGL(k_scale_rows_by_dinv, dim3((NP + 255) / 256, p), dim3(256), 0, s->stream, NP, p, s->Dx, U, Zm);
     for (int kb = nb - 1; kb >= 0; --kb) {
-        const int k0 = kb * tb;
-        gemm(s, tb, p, tb, 1.0, s->Tinv + (size_t)kb * tb * tb, tb, true, Zm + k0, NP, 0.0, X + k0, NP);
-        if (k0 > 0) gemm(s, k0, p, tb, -1.0, s->S + k0, NP, true, X + k0, NP, 1.0, Zm, NP);
+        const int k0 = kb * tb, w = std::min(tb, NP - k0);
+        gemm(s, w, p, w, 1.0, s->Tinv + (size_t)kb * tb * tb, tb, true, Zm + k0, NP, 0.0, X + k0, NP);
+        if (k0 > 0) gemm(s, k0, p, w, -1.0, s->S + k0, NP, true, X + k0, NP, 1.0, Zm, NP);
     }
 }
 

@@ -139,6 +139,7 @@ static int gb_factorize(G* g, const Set& a, std::vector<std::array<int64_t, 3>>&
         (void)hipEventElapsedTime(&ms, s->ev[10], s->ev[11]); s->phase_ms[1] = ms;
         (void)hipEventElapsedTime(&ms, s->ev[11], s->ev[12]); s->phase_ms[7] = ms;
         (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[13]); s->phase_ms[3] = ms;
+        (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[14]); s->kernel_ms[0] = ms;   // of which the panel steps (the pivot chain)
         s->phase_ms[8] += 1.0;
     }
     for (int i : a) {

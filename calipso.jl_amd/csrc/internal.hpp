@@ -17,6 +17,9 @@ typedef int64_t i64;
 constexpr int TILE = 128;   // Schur-complement (SYRK) workgroup tile
 constexpr int NB = 64;      // LDL^T panel width
 constexpr int MAX_SOC_DIM = 64;
+constexpr int TRSV_BLOCK = 1024;   // widest diagonal block of L whose inverse is assembled for the triangular solves (ldl.hip)
+inline int trsv_block(int NP) { return NP < TRSV_BLOCK ? NP : TRSV_BLOCK; }
+inline size_t tinv_doubles(int NP) { const size_t tb = (size_t)trsv_block(NP); return ((size_t)NP + tb - 1) / tb * tb * tb; }   // every block stored with leading dimension tb
 constexpr int CONE_MASK_WORDS = 26;                     // icount[6..31] (slack) and icount[32..57] (slack dual): one bit per trial step size
 constexpr int CONE_MASK_TRIALS = 32 * CONE_MASK_WORDS;  // => max_cone_line_search <= 831
 
@@ -156,9 +159,9 @@ struct calipso_hip_solver {
     double* S = nullptr;        // NP*NP: Schur complement onto x, then L (unit lower) in place
     double* Dx = nullptr;       // NP: pivots of S
     double* refpart = nullptr;  // per workgroup of k_refine_local: its part of ||residual_error||_inf
-    double* Ypanel = nullptr;   // 2 x NP*NB: L21*D of the current panel (and of the next one in the pair schedule of ldl.hip)
-    double* Tinv = nullptr;     // (NP/512) * 512*512: inverses of the unit-lower 512 x 512 diagonal blocks of L
-    double* Ttmp = nullptr;     // NP*128 scratch of the inverse assembly
+    double* Ypanel = nullptr;   // NP*NB: M_k = (L_kk D_k L_kk')^-1 of every 64-column panel (ldl.hip: what the trailing update multiplies the raw panel with)
+    double* Tinv = nullptr;     // tinv_doubles(NP): inverses of the unit-lower diagonal blocks of L (up to 1024 x 1024, the last one may be 512 wide)
+    double* Ttmp = nullptr;     // NP*256 scratch of the inverse assembly
     double* zf2 = nullptr;      // NP
     double* WH = nullptr;       // nc*nx: Omega_z * hx
     double* wz = nullptr;       // nc: Omega for nonnegative entries (-1/K_zz)
@@ -195,8 +198,9 @@ struct calipso_hip_solver {
     void* ldl_aux = nullptr;      // ldlsolver.hip: staging of the caller's CSC matrix (handles made by calipso_hip_ldl_create)
     double* Hdense = nullptr; int* lu_ipiv = nullptr;   // fallback.hip: N x N unreduced matrix and pivots (allocated on first use)
     hipEvent_t ev[16];
-    hipGraphExec_t graph_ldl = nullptr, graph_trsv = nullptr;   // captured once per handle (fixed launch sequences)
-    bool graph_ldl_tried = false, graph_trsv_tried = false, use_graphs = true;
+    hipGraphExec_t graph_ldl = nullptr, graph_ldl_fin = nullptr, graph_trsv = nullptr;   // captured once per handle (fixed launch sequences): panel steps, factor columns + block inverses, one triangular solve
+    bool graph_ldl_tried = false, graph_ldl_fin_tried = false, graph_trsv_tried = false, use_graphs = true;
+    double kernel_ms[4] = {0};   // [0] the panel-step launches (k_ldl_diag + k_ldl_step) of the last factorisation
     double phase_ms[9] = {0};
     // filter (filter.jl:1-13), host side
     std::vector<double> filter_theta, filter_merit, cache_theta, cache_merit;
@@ -250,7 +254,9 @@ void launch_schur(calipso_hip_solver* s);
 void launch_symmetrize(calipso_hip_solver* s);          // Lsym from the upper triangle of Lxx (for the covered instances)
 void schur_plan(calipso_hip_solver* s);   // host: choose the tile shape of single-instance launches
 // ldl.hip
+void launch_pad_identity(calipso_hip_solver* s);
 void launch_ldl(calipso_hip_solver* s);
+void ldl_drop_graphs(calipso_hip_solver* s);
 void launch_trsv(calipso_hip_solver* s, double* x);            // x (length NP) <- S^-1 x using L, D
 // solvek.hip
 void launch_copy_pad(calipso_hip_solver* s, const double* src, int n, double* dst, int npad);

@@ -175,13 +175,11 @@ int32_t calipso_hip_ldl_analyze_csc(calipso_hip_solver* s, int64_t n, const int6
     const int band64 = (hb + 63) / 64;
     const int new_band = band64 >= nblk - 1 ? 0 : std::max(1, band64);
     if (new_band != s->band64 || (new_band > 0 && hb != s->half_bandwidth)) {     // the launch sequences change with the band
-        if (s->graph_ldl) { (void)hipGraphExecDestroy(s->graph_ldl); s->graph_ldl = nullptr; }
-        if (s->graph_trsv) { (void)hipGraphExecDestroy(s->graph_trsv); s->graph_trsv = nullptr; }
-        s->graph_ldl_tried = false; s->graph_trsv_tried = false;
+        ldl_drop_graphs(s);
     }
     s->band64 = new_band; s->half_bandwidth = new_band > 0 ? hb : 0;
     // the block inverses of the triangular solves span whole diagonal blocks: what lies outside the band must read as zero
-    CK(hipMemsetAsync(s->Tinv, 0, sizeof(double) * (d.NP < 512 ? (size_t)d.NP * d.NP : (size_t)(d.NP / 512) * 512 * 512), s->stream));
+    CK(hipMemsetAsync(s->Tinv, 0, sizeof(double) * tinv_doubles(d.NP), s->stream));
     CK(hipStreamSynchronize(s->stream));
     a.factored = false;
     if (perm) std::copy(p.begin(), p.end(), perm);

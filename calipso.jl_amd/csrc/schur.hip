@@ -526,6 +526,13 @@ static int schur_choose(int nx, int instances, int hb) {
 }
 void schur_plan(calipso_hip_solver* s) { s->schur_nj = schur_choose(s->d.nx, 1, 0); }
 
+// unit pivots in the padded rows of S (what the blocked LDL^T of ldl.hip factors beyond row nx)
+void launch_pad_identity(calipso_hip_solver* s) {
+    if (s->d.NP <= s->d.nx) return;
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_pad_identity, dim3((s->d.NP + 255) / 256, s->d.NP - s->d.nx, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->S);
+}
+
 void launch_schur(calipso_hip_solver* s) {
     static std::once_flag attr;      // (several host lanes launch concurrently: one of them sets the attribute, the others wait for it)
     std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_LDS_BYTES); });
@@ -538,8 +545,7 @@ void launch_schur(calipso_hip_solver* s) {
     static const int flat_env = [] { const char* e = getenv("CALIPSO_HIP_SCHUR_FLAT"); return e ? atoi(e) : -1; }();
     const int flat = flat_env >= 0 ? flat_env : 1;
     const int grid = flat ? (int)(((long long)B.b.n * ntiles + 7) / 8 + 1) * 8 : ((ntiles + 7) / 8) * 8;
-    if (s->d.NP > s->d.nx && !(s->stage_parallel && s->spS))      // (the multifrontal path reads S only inside its nx x nx pattern)
-        hipLaunchKernelGGL(k_pad_identity, dim3((s->d.NP + 255) / 256, s->d.NP - s->d.nx, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->S);
+    if (!(s->stage_parallel && s->spS)) launch_pad_identity(s);   // (the multifrontal path reads S only inside its nx x nx pattern)
     hipLaunchKernelGGL(k_schur, dim3(grid, 1, flat ? 1 : B.b.n), dim3(SCHUR_THREADS), SCHUR_LDS_BYTES, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, s->krange, hb, ntiles, nj, flat);
 }
 

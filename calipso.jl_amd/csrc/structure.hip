@@ -43,9 +43,7 @@ static int structure_clear(calipso_hip_solver* s) {
     CK(hipSetDevice(s->device));
     CK(hipStreamSynchronize(s->stream));
     CK(hipMemcpy(s->krange, kr.data(), sizeof(int) * kr.size(), hipMemcpyHostToDevice));
-    if (s->graph_ldl) { (void)hipGraphExecDestroy(s->graph_ldl); s->graph_ldl = nullptr; }      // the launch sequences change with the band
-    if (s->graph_trsv) { (void)hipGraphExecDestroy(s->graph_trsv); s->graph_trsv = nullptr; }
-    s->graph_ldl_tried = false; s->graph_trsv_tried = false;
+    ldl_drop_graphs(s);      // the launch sequences change with the band
     return CALIPSO_OK;
 }
 
@@ -144,13 +142,11 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
     s->half_bandwidth = (int)hb;
     s->band64 = band64 >= nblk - 1 ? 0 : std::max(1, band64);  // 0: nothing to skip
     // entries of S outside the band are never written in banded mode and must read as zero (the block inverses span whole
-    // 512 x 512 diagonal blocks): clear what an earlier dense factorisation may have left there
+    // diagonal blocks): clear what an earlier dense factorisation may have left there
     CK(hipMemsetAsync(s->S, 0, sizeof(double) * (size_t)d.NP * d.NP, s->stream));
-    CK(hipMemsetAsync(s->Tinv, 0, sizeof(double) * (d.NP < 512 ? (size_t)d.NP * d.NP : (size_t)(d.NP / 512) * 512 * 512), s->stream));
+    CK(hipMemsetAsync(s->Tinv, 0, sizeof(double) * tinv_doubles(d.NP), s->stream));
     CK(hipStreamSynchronize(s->stream));
-    if (s->graph_ldl) { (void)hipGraphExecDestroy(s->graph_ldl); s->graph_ldl = nullptr; }      // the launch sequences change with the band
-    if (s->graph_trsv) { (void)hipGraphExecDestroy(s->graph_trsv); s->graph_trsv = nullptr; }
-    s->graph_ldl_tried = false; s->graph_trsv_tried = false;
+    ldl_drop_graphs(s);      // the launch sequences change with the band
     if (out) { out[0] = hb; out[1] = s->band64; out[2] = G ? (int64_t)(ve / G) : 0; out[3] = G ? (int64_t)(vc / G) : 0; }
     return CALIPSO_OK;
 }

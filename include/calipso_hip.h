@@ -387,6 +387,11 @@ int32_t calipso_hip_mfma_f64_peak(int32_t device, double* tflops);
  * [3] LDL^T of the Schur complement   [5] cone search + line search + accept   [6] whole step
  * [7] the Schur-complement MFMA kernel (k_schur), last launch   [8] number of factorisations timed so far */
 int32_t calipso_hip_phase_times(calipso_hip_solver*, double out[9]);
+/* per-kernel figures of the last factorisation and the handle's layout (bench.py: the live launch durations behind `roofline`):
+ * [0] ms of the panel-step launches of the LDL^T of the Schur complement (k_ldl_diag + k_ldl_step: the pivot chain, one launch per 64
+ *     pivots; HIP events around exactly these launches; the rest of [3] above is the parallel finish: factor columns + block inverses)
+ * [1] number of those launches   [2] NP = padded order of the Schur complement   [3] bytes of the handle's device slab   [4..7] reserved (0) */
+int32_t calipso_hip_kernel_times(calipso_hip_solver*, double out[8]);
 int32_t calipso_hip_synchronize(calipso_hip_solver*);
 
 /* SplitMix64 uniform stream of SURVEY.md 8(d): seed = 0xCA11B50000000000 + 4096*problem_id + stream_id,

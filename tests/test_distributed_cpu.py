@@ -82,3 +82,39 @@ def test_batch_lanes_keep_priority_classes_apart():
     for lane in range(3):
         assert len({f.thread for f in fakes[lane::3]}) == 1          # one host thread per lane
     b.close()
+
+
+def test_bench_spawns_its_ranks():
+    """`python bench.py --gpus N` (the driver's plain command form, no torch.distributed.run around it) must start N ranks itself.
+    --spawn-check stops every rank before it touches a GPU, so the launch path is covered here: the ranks report in through a gloo
+    all-gather and rank 0 prints one JSON line."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["spawn_check"] is True and d["n_gpus"] == 2 and d["gpus_argument"] == 2 and d["launched_by"] == "torch.distributed.run"
+    assert sorted(tuple(r) for r in d["ranks"]) == [(0, 0), (1, 1)]           # (RANK, LOCAL_RANK) of every process
+    # one GPU: nothing is spawned
+    out1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn-check"], capture_output=True, text=True, timeout=600, env=env)
+    d1 = json.loads([l for l in out1.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["launched_by"] == "direct"
+
+
+def test_c4_sharding_of_256_instances():
+    """BASELINE config 4: 256 problems over 8 GPUs = 32 block-contiguous ids per rank, in two groups of 16; gathered rows come back in
+    global problem-id order with every id exactly once"""
+    load_pkg()
+    from calipso_jl_amd.batch import shard_range
+    seen = []
+    for rank in range(8):
+        ids = list(shard_range(8 * 32, rank, 8))
+        assert ids == list(range(32 * rank, 32 * rank + 32))
+        groups = [ids[k:k + 16] for k in range(0, 32, 16)]
+        assert [len(g) for g in groups] == [16, 16] and groups[0][0] == 32 * rank and groups[1][0] == 32 * rank + 16
+        seen += ids
+    assert seen == list(range(256))

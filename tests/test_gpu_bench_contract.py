@@ -1,5 +1,7 @@
 """GPU: the one-line JSON contract of bench.py (metric / value / ms_per_step / roofline / cpu_baseline ...) on a small configuration,
-single rank and two ranks (torch.distributed.run, gloo, both ranks on device 0: the multi-rank path of bench.py on one GPU)."""
+single rank and two ranks (both ranks on device 0 with the gloo backend: the multi-rank path of bench.py on one GPU), started both ways:
+under torch.distributed.run and by `python bench.py --gpus 2` alone (bench.py then spawns the ranks itself).  Structural asserts only: rates
+are reported, never compared (a wall-clock ratio does not belong in a correctness suite)."""
 import json
 import os
 import socket
@@ -25,20 +27,33 @@ def run_bench(*extra):
     return parse(out)
 
 
-def run_bench_2ranks(*extra):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+def run_bench_2ranks(*extra, torchrun=True):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "small", "--steps", "3",
-                          "--warmup", "1", "--dist-backend", "gloo", "--force-device", "0", *extra],
-                         capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "small", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo",
+            "--force-device", "0", *extra]
+    if torchrun:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args                                # the driver's plain command form: bench.py starts the ranks itself
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
     return parse(out)
 
 
+def check_roofline_entry(e, inst):
+    assert e["bound"] == "mfma" and e["unit"] == "TFLOP/s" and e["peak"] > 0 and abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-12
+    assert e["achieved"] > 0 and "traffic" in e and e["instances_per_launch"] == inst and e["launches_per_step"] >= 1
+    assert abs(e["avg_launch_ms"] * e["launches_per_step"] - e["ms_per_step"]) <= 1e-9 * e["ms_per_step"]
+    assert abs(e["achieved"] - e["flops_per_launch"] * e["launches_per_step"] / (e["ms_per_step"] * 1e-3) * 1e-12) <= 1e-9 * e["achieved"]
+
+
 def test_bench_line_contract():
-    d = run_bench("--batch", "4", "--group", "2", "--lanes", "2", "--batched-passes", "3", "--cpu-samples", "2")
+    d = run_bench("--batch", "4", "--group", "2", "--lanes", "2", "--batched-passes", "3", "--cpu-samples", "2",
+                  "--c4-configs", "smallT", "--c4-batch", "4", "--c4-group", "2")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -51,34 +66,47 @@ def test_bench_line_contract():
     assert b["instances_per_gpu"] == 4 and b["instances_per_group"] == 2 and b["passes"] == 3
     assert abs(b["newton_steps_per_s"] - 4 * 3 / (b["ms_per_pass"] * 3e-3)) <= 1e-6 * b["newton_steps_per_s"]
     assert abs(b["problems_per_s_of_10_steps"] - b["newton_steps_per_s"] / 10.0) < 1e-9
+    assert "calipso_hip_comm" in b["post_round_exchange"]              # one rank: the gather goes through the product's RCCL entry points
+    # roofline = the kernel with the largest share of the step; the other matrix-core kernel is listed under `secondary`
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["achieved"] > 0 and "traffic" in r and r["instances_per_launch"] == 1
+    check_roofline_entry(r, 1)
+    assert len(r["secondary"]) == 1
+    check_roofline_entry(r["secondary"][0], 1)
+    assert r["ms_per_step"] >= r["secondary"][0]["ms_per_step"]
+    assert {r["kernel"].split(" ")[0], r["secondary"][0]["kernel"].split(" ")[0]} == {"k_ldl_step", "k_schur"}
     assert 10.0 < r["peak_measured"] < r["peak"]                      # the measured fp64 MFMA ceiling of this chip
-    assert r["group_launch"]["instances_per_launch"] == 2 and r["group_launch"]["achieved"] > 0
+    for name in ("k_ldl_step", "k_schur"):
+        check_roofline_entry(r["group_launch"][name], 2)
+    ph = d["config"]["roofline_phases"]["single_system"]
+    assert ph["solve_and_refine"]["bytes_executed"] > 0 and ph["solve_and_refine"]["frac_executed"] > 0 and ph["factor"]["frac_executed"] > 0
+    # config.c4: the batched figures of BASELINE config 4 ride in the same line (here: a small stage-structured stand-in)
+    c4 = d["config"]["c4"]
+    assert c4["instances_per_gpu"] == 4 and c4["instances_per_group"] == 2
+    e = c4["smallT"]
+    assert e["batched_newton_steps_per_s"] > 0 and e["single_system_steps_per_s"] > 0 and e["device_bytes_per_instance"] > 0
+    assert abs(e["batched_problems_per_s_of_10_steps"] - e["batched_newton_steps_per_s"] / 10.0) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and isinstance(c["sample"], str)
     assert len(c["samples_s"]) == 2
     assert 0 < c["B0_ii_reference_refactorisation"]["value"] < c["value"] and c["B0_ii_reference_refactorisation"]["factorizations_per_step"] >= 3
     assert c["B1_lapack_all_cores"]["value"] > 0 and c["B1_lapack_all_cores"]["cores"] >= 1
-    assert d["value"] > c["value"]                                   # the device path is faster than the single-core port
 
 
 def test_bench_single_units_and_no_baseline():
     d = run_bench("--batch", "2", "--group", "1", "--lanes", "2", "--no-cpu-baseline", "--batched-passes", "2")
-    assert d["cpu_baseline"] is None and d["config"]["batched"]["instances_per_group"] == 1 and d["value"] > 0
+    assert d["cpu_baseline"] is None and d["config"]["batched"]["instances_per_group"] == 1 and d["value"] > 0 and d["config"]["c4"] is None
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("torchrun", [True, False], ids=["under-torchrun", "self-spawned"])
+def test_bench_two_ranks_on_one_gpu(torchrun):
     """the multi-rank path of bench.py (barrier, max-over-ranks time, gather of status rows, all-reduce of counters) on ONE GPU: two
-    ranks under torch.distributed.run with the gloo backend, both on device 0.  value = sum over ranks; the two ranks share the GPU,
-    so the aggregate is between 1x and ~2x the single-rank figure (sharing penalty), never more"""
-    one = run_bench("--batch", "4", "--group", "2", "--lanes", "2", "--no-cpu-baseline", "--batched-passes", "3")
-    two = run_bench_2ranks("--batch", "4", "--group", "2", "--lanes", "2", "--batched-passes", "3")
+    ranks with the gloo backend, both on device 0 — once launched by torch.distributed.run, once by `python bench.py --gpus 2` alone.
+    value = sum over ranks of the steps over the max time (bench.py itself asserts that the gathered status table has 2 x B rows, all ok,
+    and that the counters sum to 2 B P)."""
+    two = run_bench_2ranks("--batch", "4", "--group", "2", "--lanes", "2", "--batched-passes", "3", torchrun=torchrun)
     assert two["n_gpus"] == 2 and two["cpu_baseline"] is None and two["steps"] == 3
     assert abs(two["value"] - 2 * 3 / (two["ms_per_step"] * 3e-3)) <= 1e-6 * two["value"]         # both ranks' steps over the max time
-    b1, b2 = one["config"]["batched"], two["config"]["batched"]
+    b2 = two["config"]["batched"]
     assert b2["instances_per_gpu"] == 4 and abs(b2["newton_steps_per_s"] - 2 * 4 * 3 / (b2["ms_per_pass"] * 3e-3)) <= 1e-6 * b2["newton_steps_per_s"]
-    # (bench.py itself asserts that the gathered status table has 2 x B rows, all ok, and that the counters sum to 2 B P)
-    assert 0.2 * b1["newton_steps_per_s"] <= b2["newton_steps_per_s"] <= 2.3 * b1["newton_steps_per_s"]      # (a timing ratio: loose, the box may be shared with other test processes)
-    assert 0.5 * one["value"] <= two["value"] <= 2.3 * one["value"]
+    assert "torch.distributed (gloo)" in b2["post_round_exchange"]
+    print("two ranks on one GPU (%s): %.1f steps/s single, %.1f batched" % ("torchrun" if torchrun else "self-spawned", two["value"], b2["newton_steps_per_s"]))
