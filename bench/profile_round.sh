@@ -10,8 +10,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/round
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-SINGLE="python $R/bench.py --batch 0 --steps 10 --warmup 2 --no-cpu-baseline"
-GROUP="python $R/bench.py --batch $G --group $G --lanes 1 --steps 10 --warmup 2 --batched-passes 10 --no-cpu-baseline --no-single"
+SINGLE="python $R/bench.py --batch 0 --steps 10 --warmup 2 --no-cpu-baseline --no-c4"
+GROUP="python $R/bench.py --batch $G --group $G --lanes 1 --steps 10 --warmup 2 --batched-passes 10 --no-cpu-baseline --no-single --no-c4"
 timeout 900 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err < /dev/null
 for mode in single group; do
   if [ $mode = single ]; then CMD=$SINGLE; Z=1; else CMD=$GROUP; Z=$G; fi
@@ -21,7 +21,7 @@ for mode in single group; do
   for c in FETCH_SIZE WRITE_SIZE MfmaUtil SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do
     timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${mode}_$c -- $CMD --steps 2 --warmup 1 --batched-passes 2 > $O/pmc_${mode}_$c.log 2>&1 < /dev/null
     f=$(find $O/pmc_${mode}_$c -name "*counter_collection.csv" | head -1)
-    if [ -n "$f" ]; then grep -E "Correlation_Id|k_schur|k_ldl_trailing|k_gemv_t|k_gemv_both" "$f" | head -200 > $O/pmc_${mode}_$c.csv; fi
+    if [ -n "$f" ]; then grep -E "Correlation_Id|k_schur|k_ldl_step|k_ldl_scale|k_gemv_t|k_gemv_both" "$f" | head -200 > $O/pmc_${mode}_$c.csv; fi
     rm -rf $O/pmc_${mode}_$c
   done
   if [ -s $O/pmc_${mode}_FETCH_SIZE.csv ] && [ -s $O/pmc_${mode}_WRITE_SIZE.csv ]; then

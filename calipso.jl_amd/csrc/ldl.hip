@@ -45,12 +45,23 @@ constexpr int LDT = NB + 2;        // LDS leading dimension of a k-fastest 64-de
 //            to its own columns.  16 barriers per block instead of 64 (one per column in round 1); a single wavefront issues one dependent
 //            instruction every ~13 cycles, so what counts on the critical path is the instruction count of the wave that holds the
 //            next pivot: ~50 (mini-panel) + ~40 (update) per four columns instead of 4 x 30 + 4 barriers.  10.6 us instead of 15.
-//   phase 2  X = L11^-1 (needed by the panel GEMM and by the triangular solves): the four 16 x 16 diagonal blocks by
-//            wave-synchronous forward substitution in registers, then two merge levels inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1, C^-1]
-//            as small dense products out of LDS.
-// Nothing is written to global memory inside the column loop (a pending store would make every barrier wait on memory).
+//            Round 3: the wavefronts that are done with the LDL^T (cg <= P) apply G_P^-1 to their columns of X = L11^-1 in the same step
+//            (v_readlane inside the wave), so the inverse is complete when the last pivot is (round 2: a separate phase 2, 7 us per block).
+//   phase 2  M = X' D^-1 X on the matrix cores (what the next panel step multiplies the raw panel with), then ALL global stores: D, L, X, M.
+// Nothing is written to global memory before the last barrier (a pending store would make a barrier wait on memory).
 constexpr int DIAG_THREADS = 1024;
-constexpr int LDD = NB + 1;
+constexpr int LDD = NB + 1;        // stride of the 64 x 64 tile handed to the diagonal block through LDS
+
+// Optional timeline of the pivot chain (build with -DCALIPSO_LDL_TRACE; bench/ldl_trace.py reads it through calipso_hip_debug_ldl_trace):
+// 100 MHz wall-clock stamps of the workgroup that carries tile 0 + the diagonal block, instance 0, per panel step.
+#ifdef CALIPSO_LDL_TRACE
+__device__ long long g_ldl_trace[64 * 16];
+#define LDL_STAMP(step, slot) do { if (threadIdx.x == 0 && (step) < 64) g_ldl_trace[(step) * 16 + (slot)] = wall_clock64(); } while (0)
+#define LDL_STAMP_IF(cond, step, slot) do { if ((cond) && (step) < 64) g_ldl_trace[(step) * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define LDL_STAMP(step, slot) do { } while (0)
+#define LDL_STAMP_IF(cond, step, slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton steps (pivots are normal numbers; 0 -> inf as 1/0)
     double r = __builtin_amdgcn_rcp(v);
@@ -59,163 +70,153 @@ __device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton
     return r;
 }
 
-// LDS carve (doubles): Ls | Xs | Ts | ypan[2][4][NB] | rpan[2][4].  When the block arrives through LDS (fused with the trailing update) it
-// sits in the Ls region and is consumed into registers before Ls is first written.
-constexpr int DIAG_LDS_DOUBLES = 2 * NB * LDD + 32 * 33 + 8 * NB + 8;
+// LDS carve (doubles): XT | XTs | ypan[2][4][NB] | rpan[2][4] | dpiv[NB] | dinv[NB].  When the block arrives through LDS (fused with the trailing update)
+// it sits at the start (row-major, stride LDD) and is consumed into registers before anything is written.
+constexpr int DIAG_LDS_DOUBLES = 2 * NB * LDT + 2 * 4 * NB + 8 + 2 * NB;
 
+__device__ __forceinline__ void lds_barrier_all() {                  // workgroup barrier that orders LDS traffic only (global stores stay in flight)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+}
 __device__ __forceinline__ double readlane_d(double v, int lane) {     // lane: wave-uniform
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, lane);
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
 }
+typedef double v2d __attribute__((ext_vector_type(2)));
 template <bool FROM_LDS>
 __device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
                                            double* __restrict__ Tinv, double* __restrict__ Minv, int* __restrict__ icount) {
     constexpr int WAVES = 16, CPW = 4;
-    double* Ls = smem;
-    double* Xs = Ls + NB * LDD;
-    double* Ts = Xs + NB * LDD;
-    double (*ypan)[4][NB] = reinterpret_cast<double (*)[4][NB]>(Ts + 32 * 33);     // [2][4][NB] unscaled pivot columns of a mini-panel
-    double (*rpan)[4] = reinterpret_cast<double (*)[4]>(Ts + 32 * 33 + 8 * NB);    // [2][4] their reciprocal pivots
+    double* XT = smem;                       // XT[a][r] = X[r][a], stride LDT: the matrix-core fragments of M read it without bank conflicts
+    double* XTs = XT + NB * LDT;             // XT scaled by the reciprocal pivot of row r
+    double (*ypan)[4][NB] = reinterpret_cast<double (*)[4][NB]>(XTs + NB * LDT);   // [2][4][NB] unscaled pivot columns of a mini-panel
+    double (*rpan)[4] = reinterpret_cast<double (*)[4]>(XTs + NB * LDT + 8 * NB);  // [2][4] their reciprocal pivots
+    double* dpiv = XTs + NB * LDT + 8 * NB + 8;                                     // the 64 pivots
+    double* dinv = dpiv + NB;                                                       // and their reciprocals
     const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
     double a[CPW];
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
         const int k = 4 * cg + c;
-        if (FROM_LDS) a[c] = (i >= k) ? Ls[i * LDD + k] : 0.0;
+        if (FROM_LDS) a[c] = (i >= k) ? smem[i * LDD + k] : 0.0;
         else a[c] = (i >= k) ? S[(k0 + i) + (size_t)(k0 + k) * NP] : 0.0;
     }
-    if (FROM_LDS) __syncthreads();   // every lane has its entries before the Ls region is reused
+    if (FROM_LDS) __syncthreads();   // every lane has its entries before the region is reused
+    LDL_STAMP(k0 / NB, 2);
+    // X = L11^-1 grows alongside: L = G_0 G_1 ... G_15 (G_P = identity + the four columns of mini-panel P), so X = G_15^-1 ... G_0^-1 and
+    // G_P^-1 is applied from the left as soon as mini-panel P is published:  X[i][:] -= L[i][4P+j] X[4P+j][:]  for j = 0..3 in turn, i > 4P+j.
+    // Wavefront cg holds columns 4 cg .. 4 cg + 3 of X (lane = row, like A); row 4P+j of its columns sits in its own lane 4P+j (v_readlane).
+    // Only columns <= 4P+3 are touched by G_P^-1, i.e. wavefronts cg <= P — exactly the ones with nothing left to do in the LDL^T — so the
+    // inverse costs the pivot chain nothing (round 2 formed it afterwards: 16 x 16 forward substitutions + two merge levels, 7 us per block).
+    double x[CPW], lfin[CPW];                 // lfin: the finished columns of L of this wavefront (they go to global memory at the very end)
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) { x[c] = (i == 4 * cg + c) ? 1.0 : 0.0; lfin[c] = 0.0; }
 #pragma unroll 1
     for (int P = 0; P < WAVES; ++P) {
         const int buf = P & 1;
         if (cg == P) {
             // the owner's four columns, alone: rows <= the pivot only collect garbage that is never read
-            double y[4], rinv[4];
+            double y[4], rinv[4], dv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const double d = readlane_d(a[j], 4 * P + j);
-                rinv[j] = fast_rcp(d);
+                dv[j] = readlane_d(a[j], 4 * P + j);
+                rinv[j] = fast_rcp(dv[j]);
                 y[j] = a[j];
                 const double li = a[j] * rinv[j];
+                lfin[j] = li;
 #pragma unroll
                 for (int k = j + 1; k < 4; ++k) a[k] -= li * readlane_d(a[j], 4 * P + k);    // A[4P+k][4P+j]: the symmetric partner of the pivot row's entry
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ypan[buf][j][i] = y[j];
-                Ls[i * LDD + 4 * P + j] = (i > 4 * P + j) ? y[j] * rinv[j] : y[j];              // L below the pivot, the pivot on the diagonal
+            for (int j = 0; j < 4; ++j) ypan[buf][j][i] = y[j];
+            if (i < 4) {
+                const double dd = i == 0 ? dv[0] : i == 1 ? dv[1] : i == 2 ? dv[2] : dv[3], rr = i == 0 ? rinv[0] : i == 1 ? rinv[1] : i == 2 ? rinv[2] : rinv[3];
+                dpiv[4 * P + i] = dd; dinv[4 * P + i] = rr; rpan[buf][i] = rr;
             }
-            if (i == 0) { rpan[buf][0] = rinv[0]; rpan[buf][1] = rinv[1]; rpan[buf][2] = rinv[2]; rpan[buf][3] = rinv[3]; }
+            LDL_STAMP_IF(i == 0 && cg == 9, k0 / NB, 10);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only LDS traffic is outstanding here
         __builtin_amdgcn_s_barrier();
+        LDL_STAMP_IF(i == 0 && cg == 9 && P == 8, k0 / NB, 8);
+        LDL_STAMP_IF(i == 0 && cg == 9 && P == 9, k0 / NB, 11);
+        // (every load is issued before any is used: a load inside the `i > pivot` conditional turns into exec-masked blocks with an LDS round
+        // trip each).  Measured alternatives (bench/diag_bench2.hip, profiles/r03_diag_bench2.txt): 16-byte (y, l) pairs, pivot-row entries by
+        // v_readlane instead of broadcast reads, s_sleep for the non-critical wavefronts, s_setprio — all slower.
+        double yl[4], rp[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { yl[j] = ypan[buf][j][i]; rp[j] = rpan[buf][j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double v = yl[j] * rp[j]; l[j] = (i > 4 * P + j) ? v : 0.0; }
         if (cg > P) {
-            double l[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) l[j] = (i > 4 * P + j) ? ypan[buf][j][i] * rpan[buf][j] : 0.0;
+            for (int j = 0; j < 4; ++j) {
+                double yr[CPW];
 #pragma unroll
-            for (int c = 0; c < CPW; ++c) {
+                for (int c = 0; c < CPW; ++c) yr[c] = ypan[buf][j][4 * cg + c];                   // Y[4cg+c][4P+j] (broadcast reads)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[c] -= l[j] * ypan[buf][j][4 * cg + c];
+                for (int c = 0; c < CPW; ++c) a[c] -= l[j] * yr[c];
+            }
+            LDL_STAMP_IF(i == 0 && cg == 9 && P == 8 && a[0] != 1.2345e300, k0 / NB, 9);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                 // (j outermost: the four columns are independent chains)
+                double xs[CPW];
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) xs[c] = readlane_d(x[c], 4 * P + j);
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) x[c] -= l[j] * xs[c];                               // (l[j] = 0 for the rows i <= 4P+j)
             }
         }
     }
-    __syncthreads();
-    double* dinv = &ypan[0][0][0];          // (the mini-panel buffers are free from here on) reciprocal pivots for M
-    if (tid < NB) {
-        const double d = Ls[tid * LDD + tid];
-        Dx[k0 + tid] = d;
-        dinv[tid] = 1.0 / d;
-        int pos = 0, nonpos = 0, zero = 0;
-        if (k0 + tid < nx) { pos = d > 0.0; nonpos = d <= 0.0; zero = d == 0.0; }
-        pos = wave_sum_i(pos); nonpos = wave_sum_i(nonpos); zero = wave_sum_i(zero);
-        if (tid == 0) { atomicAdd(&icount[3], pos); atomicAdd(&icount[4], nonpos); atomicAdd(&icount[5], zero); }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        const int k = cg + WAVES * c;
-        const double lv = (i > k) ? Ls[i * LDD + k] : 0.0;
-        Ls[i * LDD + k] = lv;                 // strictly lower L (the pivots and what the garbage rows left above them go)
-        Xs[i * LDD + k] = 0.0;
-        if (i > k) S[(k0 + i) + (size_t)(k0 + k) * NP] = lv;
-    }
-    __syncthreads();
-    // (a) the four 16 x 16 diagonal blocks of X: wavefront w < 4, lane c < 16 builds column c by forward substitution
-    if (cg < 4 && i < 16) {
-        const int o = 16 * cg;
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            double acc = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < r; ++k) acc -= Ls[(o + r) * LDD + o + k] * x[k];
-            x[r] = (r >= i) ? acc : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Xs[(o + r) * LDD + o + i] = x[r];
-    }
-    __syncthreads();
-    // (b) level 1: X21 = -X22 (L21 X11) inside each 32-block; 512 threads, one output each
+    LDL_STAMP(k0 / NB, 3);
+    // X' to LDS for the matrix cores, plain and scaled by the reciprocal pivot of its row (the last mini-panel's pivots are visible: barrier 15)
     {
-        const int p = tid >> 8, ii = (tid >> 4) & 15, jc = tid & 15, o = 32 * p;
-        if (tid < 512) {
-            double t = 0.0;
+        const double di = dinv[i];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t += Ls[(o + 16 + ii) * LDD + o + k] * Xs[(o + k) * LDD + o + jc];
-            Ts[(p * 16 + ii) * 33 + jc] = t;
-        }
-        __syncthreads();
-        if (tid < 512) {
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v -= Xs[(o + 16 + ii) * LDD + o + 16 + k] * Ts[(p * 16 + k) * 33 + jc];
-            Xs[(o + 16 + ii) * LDD + o + jc] = v;
-        }
-        __syncthreads();
+        for (int c = 0; c < CPW; ++c) { XT[(4 * cg + c) * LDT + i] = x[c]; XTs[(4 * cg + c) * LDT + i] = x[c] * di; }
     }
-    // (c) level 2: X21 (32 x 32) = -X22 (L21 X11); 1024 threads, one output each
-    {
-        const int ii = tid >> 5, jc = tid & 31;
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) t += Ls[(32 + ii) * LDD + k] * Xs[k * LDD + jc];
-        Ts[ii * 33 + jc] = t;
-        __syncthreads();
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) v -= Xs[(32 + ii) * LDD + 32 + k] * Ts[k * 33 + jc];
-        __syncthreads();
-        Xs[(32 + ii) * LDD + jc] = v;
-    }
-    __syncthreads();
-    {
-        const int q = k0 / tb, o = k0 % tb;
-        double* T = Tinv + (size_t)q * tb * tb;
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-            const int k = cg + WAVES * c;
-            T[(o + i) + (size_t)(o + k) * tb] = Xs[i * LDD + k];     // X = L11^-1 on the diagonal of the inverse block (zeros above)
-        }
-    }
+    lds_barrier_all();
+    LDL_STAMP(k0 / NB, 4);
     // M = X' D^-1 X = (L11 D L11')^-1: what the NEXT launch multiplies the raw panel with.  M[a][b] = sum_r X[r][a] X[r][b] / d[r] on the matrix
     // cores: wavefront (wa, wb) forms the 16 x 16 tile (rows a, columns b); both operand fragments are "row a (b), k index r" reads of X'.
     {
         const int wa = cg >> 2, wb = cg & 3, fr = i & 15, fk = i >> 4;
         v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < NB / 4; ++kk) {
-            const int r = 4 * kk + fk;
-            const double xa = Xs[r * LDD + wa * 16 + fr] * dinv[r];
-            const double xb = Xs[r * LDD + wb * 16 + fr];
+        // X[r][a] = 0 for r < a: the k blocks above the later of the two tile origins contribute exact zeros and are skipped (the workgroup's 256
+        // MFMAs shrink to 120; the matrix cores of one CU are what bounds this product)
+        for (int kk = 4 * (wa > wb ? wa : wb); kk < NB / 4; ++kk) {
+            const double xa = XTs[(wa * 16 + fr) * LDT + 4 * kk + fk];
+            const double xb = XT[(wb * 16 + fr) * LDT + 4 * kk + fk];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, acc, 0, 0, 0);
         }
         double* Mo = Minv + (size_t)(k0 / NB) * NB * NB;
+        LDL_STAMP(k0 / NB, 6);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Mo[(wa * 16 + fk + 4 * q) + (size_t)(wb * 16 + fr) * NB] = acc[q];   // lane holds M(a = fk + 4 q, b = fr)
+        for (int q = 0; q < 4; ++q) Mo[(wb * 16 + fr) + (size_t)(wa * 16 + fk + 4 * q) * NB] = acc[q];   // lane holds M(a = fk + 4 q, b = fr) = M(b, a): 128-byte runs along fr
     }
+    // everything that goes to global memory leaves here, after the last barrier: D and the inertia counts (compute_inertia!), the strictly
+    // lower L of the block (from the registers of the wavefront that factored the column), X = L11^-1 on the diagonal of the triangular-solve
+    // inverse block (zeros above)
+    if (tid < NB) {
+        const double d = dpiv[tid];
+        Dx[k0 + tid] = d;
+        const bool real = k0 + tid < nx;                                  // (padding rows carry unit pivots that are not counted)
+        const int pos = __popcll(__ballot(real && d > 0.0)), nonpos = __popcll(__ballot(real && d <= 0.0)), zero = __popcll(__ballot(real && d == 0.0));
+        if (tid == 0) { atomicAdd(&icount[3], pos); atomicAdd(&icount[4], nonpos); atomicAdd(&icount[5], zero); }
+    }
+    {
+        const int q = k0 / tb, o = k0 % tb;
+        double* T = Tinv + (size_t)q * tb * tb;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int k = 4 * cg + c;
+            T[(o + i) + (size_t)(o + k) * tb] = x[c];
+            if (i > k) S[(k0 + i) + (size_t)(k0 + k) * NP] = lfin[c];
+        }
+    }
+    LDL_STAMP(k0 / NB, 5);
 }
 
 __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(Batch bt, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(1024) void k_ldl_scale(Batch bt, int NP, int tb, in
 // column j of S) so result stores are 128-byte runs.
 constexpr int TR_THREADS = 1024;
 constexpr int TT = 64;
-constexpr int step_lds_doubles(int nh) { return (nh + 1) * TT * LDT > DIAG_LDS_DOUBLES ? (nh + 1) * TT * LDT : DIAG_LDS_DOUBLES; }
+constexpr int step_lds_doubles(int nh) { return (nh + 2) * TT * LDT > DIAG_LDS_DOUBLES ? (nh + 2) * TT * LDT : DIAG_LDS_DOUBLES; }   // Zs[nh] | Ys | Ms
 // Tile 0 of the trailing update IS the next diagonal block: its workgroup keeps going and factors that block (diag_block),
 // so the 64-column pivot chain of panel k+1 runs inside this launch, overlapped with the other tiles, and a panel step is ONE launch.
 // Workgroups are persistent: workgroup 0 takes tile 0 (and then the diagonal block), workgroup w >= 1 walks a CONTIGUOUS run of the
@@ -302,34 +303,32 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 // Z = A(i, panel) M into Zs (LDS, [row i][c fastest], ld LDT): on a change of tile row.  The raw rows travel through `stage` (the buffer the
-// column operand uses afterwards); the fragments of M (symmetric, 32 KB, in L2 for every workgroup of the launch) come straight from global
-// memory: lane (fr, fk) of wavefront (wr, wc) needs M[16 wc + fr][4 kk + fk].
-__device__ __forceinline__ void form_Z(const double* __restrict__ Ap, int NP, const double* __restrict__ Mk, double* __restrict__ stage, double* __restrict__ Zs,
-                                       int row, int cb, int wr, int wc, int fr, int fk) {
-    double av[4], mf[NB / 8];
+// column operand uses afterwards) and M (symmetric, 32 KB, in L2 for every workgroup of the launch) through `Ms`, both fetched in ONE batch of
+// global loads (the workgroup that carries the pivot chain pays one memory round trip here, not two).
+__device__ __forceinline__ void form_Z(const double* __restrict__ Ap, int NP, const double* __restrict__ Mk, double* __restrict__ stage, double* __restrict__ Ms,
+                                       double* __restrict__ Zs, int row, int cb, int wr, int wc, int fr, int fk) {
+    double av[4], mv[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) av[it] = Ap[row + (size_t)(cb + it * 16) * NP];
+    for (int it = 0; it < 4; ++it) {
+        av[it] = Ap[row + (size_t)(cb + it * 16) * NP];
+        mv[it] = Mk[row + (size_t)(cb + it * 16) * NB];
+    }
 #pragma unroll
-    for (int kk = 0; kk < NB / 8; ++kk) mf[kk] = Mk[(wc * 16 + fr) + (size_t)(4 * kk + fk) * NB];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) stage[row * LDT + cb + it * 16] = av[it];
+    for (int it = 0; it < 4; ++it) {
+        stage[row * LDT + cb + it * 16] = av[it];
+        Ms[row * LDT + cb + it * 16] = mv[it];           // Ms[c][k] = M[c][k]
+    }
     lds_barrier();
     v4d z = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {          // the fragments of M in two batches of eight (registers)
-#pragma unroll
-        for (int kk = 0; kk < NB / 8; ++kk) {
-            const double a = stage[(wr * 16 + fr) * LDT + 4 * (kk + half * (NB / 8)) + fk];
-            z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, mf[kk], z, 0, 0, 0);    // D[row i][col c]: lane holds Z(i = fk + 4 r, c = fr)
-        }
-        if (half == 0) {
-#pragma unroll
-            for (int kk = 0; kk < NB / 8; ++kk) mf[kk] = Mk[(wc * 16 + fr) + (size_t)(4 * (kk + NB / 8) + fk) * NB];
-        }
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const double a = stage[(wr * 16 + fr) * LDT + 4 * kk + fk];
+        const double m = Ms[(wc * 16 + fr) * LDT + 4 * kk + fk];
+        z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, m, z, 0, 0, 0);    // D[row i][col c]: lane holds Z(i = fk + 4 r, c = fr)
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) Zs[(wr * 16 + fk + 4 * r) * LDT + wc * 16 + fr] = z[r];
-    lds_barrier();                        // Z visible; every read of `stage` is done (it is refilled with the column operand next)
+    lds_barrier();                        // Z visible; every read of `stage` / Ms is done (they are refilled next)
 }
 // ONE grid dimension over all instances of the launch.  Workgroup w runs on XCD w % 8 (dispatch order; used for speed only); the first bt.n
 // workgroups take tile 0 of one instance each (and then its diagonal block), the others share the remaining (instance, tile) pairs so that every XCD
@@ -342,6 +341,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
     __shared__ double smem[step_lds_doubles(NH)];
     double* Zs = smem;                    // Zs[h][i][c]: Z = A(i, panel h) M_h of the current tile row
     double* Ys = smem + NH * TT * LDT;    // Ys[j][k]: rows of the j block of the raw panel (and the staging buffer of form_Z)
+    double* Ms = Ys + TT * LDT;           // M of the panel whose Z is being formed
     const int r0 = k0 + NB * NH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
     if (MODE == 1) { ti = t; tj = 0; } else trailing_tile_index(t, ti, tj);
     int i0 = r0 + ti * TT, j0 = r0 + tj * TT;
     bool newrow = true;
+    if (t == 0) LDL_STAMP(r0 / NB, 0);
     double cS[4], yv[NH][4];              // operands of the current tile: the entries of S this lane updates, its share of the raw column panels
 #pragma unroll
     for (int r = 0; r < 4; ++r) cS[r] = S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP];
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
         if (newrow) {
 #pragma unroll
             for (int h = 0; h < NH; ++h)
-                form_Z(S + i0 + (size_t)(k0 + h * NB) * NP, NP, Mk + (size_t)h * NB * NB, Ys, Zs + h * TT * LDT, row, cb, wr, wc, fr, fk);
+                form_Z(S + i0 + (size_t)(k0 + h * NB) * NP, NP, Mk + (size_t)h * NB * NB, Ys, Ms, Zs + h * TT * LDT, row, cb, wr, wc, fr, fk);
+            if (t == 0) LDL_STAMP(r0 / NB, 1);
         }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
@@ -764,6 +766,12 @@ static bool replay_or_capture(calipso_hip_solver* s, hipGraphExec_t& exec, bool&
     if (!ok) { exec = nullptr; return false; }
     return hipGraphLaunch(exec, s->stream) == hipSuccess;
 }
+
+#ifdef CALIPSO_LDL_TRACE
+}  // namespace calipso
+extern "C" int32_t calipso_hip_debug_ldl_trace(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(calipso::g_ldl_trace), sizeof(long long) * 64 * 16) == hipSuccess ? 0 : -1; }
+namespace calipso {
+#endif
 
 void ldl_drop_graphs(calipso_hip_solver* s) {       // the captured launch sequences depend on the band / the block sizes
     if (s->graph_ldl) { (void)hipGraphExecDestroy(s->graph_ldl); s->graph_ldl = nullptr; }
