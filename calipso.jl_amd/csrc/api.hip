@@ -211,6 +211,7 @@ int32_t calipso_hip_destroy(H* s) {
     scatter_release(s);
     if (s->spS) { (void)calipso_hip_sparse_destroy(s->spS); s->spS = nullptr; }
     if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
+    if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
     double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
     for (double* p : dp) if (p) (void)hipFree(p);
     int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
@@ -319,7 +320,7 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
     if (nm == "lagrangian_hessian") s->hessian_dirty = true;
     // an analysed stage-banded structure (structure.hip) is a promise about where these three blocks are non-zero: re-check it
     // on the device against what was just uploaded; a block that breaks it sends the handle back to the dense treatment
-    if (s->band64 > 0 && (nm == "lagrangian_hessian" || nm == "equality_jacobian_variables" || nm == "cone_jacobian_variables")) {
+    if (structure_active(s) && (nm == "lagrangian_hessian" || nm == "equality_jacobian_variables" || nm == "cone_jacobian_variables")) {
         const int rc = structure_validate(s, nm == "lagrangian_hessian" ? 0 : (nm == "equality_jacobian_variables" ? 1 : 2));
         if (rc < 0) return rc;
     }
@@ -582,9 +583,9 @@ static int device_evaluate(H* s, const double* pt, uint32_t flags) {
     const uint32_t hess = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
     if (flags & hess) s->hessian_dirty = true;
     // blocks written behind our back: an analysed stage-banded structure has to be re-checked against them (as set_field does)
-    if (s->band64 > 0 && (flags & hess)) { const int v = structure_validate(s, 0); if (v < 0) return v; }
-    if (s->band64 > 0 && (flags & CALIPSO_EVAL_EQUALITY_JACOBIAN) && d.ne) { const int v = structure_validate(s, 1); if (v < 0) return v; }
-    if (s->band64 > 0 && (flags & CALIPSO_EVAL_CONE_JACOBIAN) && d.nc) { const int v = structure_validate(s, 2); if (v < 0) return v; }
+    if (structure_active(s) && (flags & hess)) { const int v = structure_validate(s, 0); if (v < 0) return v; }
+    if (structure_active(s) && (flags & CALIPSO_EVAL_EQUALITY_JACOBIAN) && d.ne) { const int v = structure_validate(s, 1); if (v < 0) return v; }
+    if (structure_active(s) && (flags & CALIPSO_EVAL_CONE_JACOBIAN) && d.nc) { const int v = structure_validate(s, 2); if (v < 0) return v; }
     return CALIPSO_OK;
 }
 static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t flags);
@@ -922,7 +923,7 @@ int32_t calipso_hip_qp_attach(H* s, const double* P, const double* q, const doub
     const Dims& d = s->d;
     if ((d.ne && (!A || !b)) || (d.nc && (!G || !h))) return CALIPSO_ERR_ARGUMENT;
     CK(hipSetDevice(s->device));
-    if (s->band64 > 0) { const int rc = calipso_hip_clear_structure(s); if (rc < 0) return rc; }   // new blocks: any analysed structure is void
+    if (structure_active(s)) { const int rc = calipso_hip_clear_structure(s); if (rc < 0) return rc; }   // new blocks: any analysed structure is void
     const size_t nx = d.nx;
     // Lxx = 2c P ; gx = A ; hx = -G   (constant Hessian / Jacobians of the QP); bh = [-b; h]
     CK(hipMemcpyAsync(s->S, P, sizeof(double) * nx * nx, hipMemcpyHostToDevice, s->stream));   // S is free before the first factorisation

@@ -177,6 +177,7 @@ struct calipso_hip_solver {
     std::vector<int> h_reach;                 // per column j of S: last row that can be non-zero (analysis)
     calipso_hip_sparse* spS = nullptr;
     long long* spS_src = nullptr;             // device: offset (row + col * NP) in S of every pattern entry
+    int* d_reach = nullptr;                   // device copy of h_reach while the stage-parallel factorisation is on: uploads are re-checked against the skyline
     bool stage_parallel = false;
     calipso::i64 structure_resets = 0;   // uploads that broke an analysed structure (the handle went back to dense)
     int* krange = nullptr;      // (in the slab) per 16-column group: [eq_lo, eq_hi, cone_lo, cone_hi) constraint rows that touch it
@@ -282,7 +283,8 @@ void scatter_release(calipso_hip_solver* s);
 // ldlsolver.hip
 void ldlsolver_release(calipso_hip_solver* s);
 // structure.hip
-int structure_validate(calipso_hip_solver* s, int which);      // which: 0 Lxx, 1 gx, 2 hx; clears the structure when the block breaks it
+int structure_validate(calipso_hip_solver* s, int which);
+inline bool structure_active(const calipso_hip_solver* s) { return s->band64 > 0 || s->stage_parallel; }   // an analysed pattern that uploads must respect      // which: 0 Lxx, 1 gx, 2 hx; clears the structure when the block breaks it
 // qp.hip
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 

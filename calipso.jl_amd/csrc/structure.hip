@@ -33,6 +33,15 @@ __global__ void k_check_rows(int rows, int row0, int m, int nx, const double* __
     if ((j < zrow[2 * k] || j >= zrow[2 * k + 1]) && Z[k + (size_t)j * m] != 0.0) atomicOr(flag, 1);
 }
 
+// stage-parallel mode factors S only inside its skyline: a Hessian entry (i, j) must satisfy max(i, j) <= reach[min(i, j)]
+__global__ void k_check_reach(int nx, const int* __restrict__ reach, const double* __restrict__ L, int* __restrict__ flag) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)nx * nx) return;
+    const int i = (int)(idx % nx), j = (int)(idx / nx);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    if (hi > reach[lo] && L[idx] != 0.0) atomicOr(flag, 1);
+}
+
 static int structure_clear(calipso_hip_solver* s) {
     s->band64 = 0; s->half_bandwidth = 0;
     s->stage_parallel = false; s->h_reach.clear();
@@ -54,7 +63,9 @@ int structure_validate(calipso_hip_solver* s, int which) {
     CK(hipMemsetAsync(flag, 0, sizeof(int), s->stream));
     if (which == 0) {
         const size_t n = (size_t)d.nx * d.nx;
-        hipLaunchKernelGGL(k_check_band, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d.nx, s->half_bandwidth, s->Lxx, flag);
+        if (s->band64 > 0) hipLaunchKernelGGL(k_check_band, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d.nx, s->half_bandwidth, s->Lxx, flag);
+        // the multifrontal factorisation gathers S through the skyline only (finer than the band, and in force even when the band covers everything)
+        if (s->stage_parallel && s->d_reach) hipLaunchKernelGGL(k_check_reach, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d.nx, s->d_reach, s->Lxx, flag);
     } else {
         const int rows = which == 1 ? d.ne : d.nc, row0 = which == 1 ? 0 : d.ne;
         const size_t n = (size_t)rows * d.nx;
@@ -170,6 +181,7 @@ int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_
     CK(hipStreamSynchronize(s->stream));
     if (s->spS) { (void)calipso_hip_sparse_destroy(s->spS); s->spS = nullptr; }
     if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
+    if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
     s->stage_parallel = false;
     if (!on) return CALIPSO_OK;
     const int nx = s->d.nx, NP = s->d.NP;
@@ -203,8 +215,18 @@ int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_
     }
     if (batch > 1 && (rc = calipso_hip_sparse_set_batch(sp, batch)) != CALIPSO_OK) { (void)calipso_hip_sparse_destroy(sp); return rc; }
     if ((rc = sparse_reserve_solve(sp, batch)) != CALIPSO_OK) { (void)calipso_hip_sparse_destroy(sp); return rc; }
-    CK(hipMalloc((void**)&s->spS_src, sizeof(long long) * std::max<size_t>(src.size(), 1)));
-    CK(hipMemcpy(s->spS_src, src.data(), sizeof(long long) * src.size(), hipMemcpyHostToDevice));
+    {
+        hipError_t e = hipMalloc((void**)&s->spS_src, sizeof(long long) * std::max<size_t>(src.size(), 1));
+        if (e == hipSuccess) e = hipMemcpy(s->spS_src, src.data(), sizeof(long long) * src.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&s->d_reach, sizeof(int) * (size_t)std::max(nx, 1));
+        if (e == hipSuccess) e = hipMemcpy(s->d_reach, s->h_reach.data(), sizeof(int) * (size_t)nx, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {                                          // nothing half-built stays behind
+            (void)calipso_hip_sparse_destroy(sp);
+            if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
+            if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
+            return calipso::check(s, e, "calipso_hip_set_stage_parallel");
+        }
+    }
     s->spS = sp; s->stage_parallel = true;
     if (info) sparse_describe(sp, info);
     return CALIPSO_OK;

@@ -208,3 +208,56 @@ def test_whole_solve_with_the_three_treatments():
     assert stats[0] == stats[1] == stats[2], stats
     assert np.array_equal(sols[0], sols[1])
     assert np.abs(sols[2] - sols[0]).max() <= 1e-7 * max(1.0, np.abs(sols[0]).max())
+
+
+def test_stage_parallel_upload_outside_the_skyline_is_caught_even_without_a_band():
+    """A handle small enough that the band covers everything (band_blocks == 0: one 64-wide block) still factors S through its SKYLINE once the
+    stage-parallel mode is on; an upload with an entry outside that skyline (zero at analysis time, non-zero later) must send the handle back to
+    the dense treatment instead of being dropped from the factorisation."""
+    pkg = load_pkg()
+    shape = (4, 14, 8, 2, 1, 3)                   # nx = 56: NP = 64, a single block
+    prob, s = build(pkg, 11, *shape)
+    _, ref = build(pkg, 11, *shape)
+    info = s.analyze_structure()
+    assert info["band_blocks"] == 0               # nothing for the band treatment to skip ...
+    s.set_stage_parallel(True)                    # ... but the multifrontal plan reads S through the skyline only
+    nx = prob.nx
+    colmajor = lambda M: np.ascontiguousarray(M.T).reshape(-1)
+    H = 0.5 * (prob.P + prob.P.T)
+    # an upload INSIDE the skyline keeps the mode: same result as the dense handle to rounding
+    for h in (s, ref):
+        h.set("lagrangian_hessian", colmajor(H))
+    a, b = s.newton_step(advance=False), ref.newton_step(advance=False)
+    assert a["status"] == b["status"] == 0 and a["factorizations"] == b["factorizations"]
+    assert np.abs(s.data("step").all - ref.data("step").all).max() <= 1e-9 * max(1.0, np.abs(ref.data("step").all).max())
+    assert s.set_stage_parallel(True)["levels"] >= 1
+    # first and last stage coupled: outside the skyline
+    H2 = H.copy()
+    H2[0, nx - 1] += 0.41; H2[nx - 1, 0] += 0.41
+    for h in (s, ref):
+        h.set("lagrangian_hessian", colmajor(H2))
+    a, b = s.newton_step(advance=False), ref.newton_step(advance=False)
+    assert a == b and a["status"] == 0
+    assert np.array_equal(s.data("step").all, ref.data("step").all)          # both handles ran the dense launches
+    R = ref.data("residual").all
+    assert np.abs(R - ref.jacobian_variables_mul(ref.data("step").all)).max() <= 1e-8 * max(1.0, np.abs(R).max())   # the new entries are in the system that was solved
+
+
+def test_group_larger_than_the_reserved_stage_parallel_batch_falls_back_to_the_blocked_factorisation():
+    """calipso_hip_set_stage_parallel(batch = 1) on the leader of a group of three: the multifrontal storage covers one member, so the group step
+    falls back to the blocked LDL^T — whose padded rows need their unit pivots although the Schur kernel skipped them for the multifrontal path
+    (round-2 defect: NaN steps).  The fallback gives the bits of the banded blocked treatment."""
+    pkg = load_pkg()
+    shape = (24, 30, 20, 4, 2, 3)                 # nx = 720, NP = 1024: 304 padded rows
+    ref = [build(pkg, p, *shape)[1] for p in (3, 4, 5)]
+    members = [build(pkg, p, *shape)[1] for p in (3, 4, 5)]
+    for m in ref + members:
+        m.analyze_structure()
+    members[0].set_stage_parallel(True, batch=1)  # too small for the group of three
+    g, gref = pkg.Group(members), pkg.Group(ref)
+    for it in range(2):
+        a, b = gref.newton_step(advance=True), g.newton_step(advance=True)
+        for x, y, r, m in zip(a, b, ref, members):
+            assert x == y and x["status"] == 0, (it, x, y)
+            assert np.all(np.isfinite(m.solution.all)) and np.array_equal(r.solution.all, m.solution.all)
+    g.close(); gref.close()
