@@ -284,6 +284,7 @@ void scatter_release(calipso_hip_solver* s);
 void ldlsolver_release(calipso_hip_solver* s);
 // structure.hip
 int structure_validate(calipso_hip_solver* s, int which);
+bool csc_pattern_ok(i64 n, const i64* colptr, const i64* rowval);   // ordering.hip: colptr[0] == 1, monotone, nnz < 2^31, rows in 1..n
 inline bool structure_active(const calipso_hip_solver* s) { return s->band64 > 0 || s->stage_parallel; }   // an analysed pattern that uploads must respect      // which: 0 Lxx, 1 gx, 2 hx; clears the structure when the block breaks it
 // qp.hip
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);

@@ -95,17 +95,21 @@ int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver* s, int64_t n, const in
     if (!s || !colptr || (!rowval && colptr[n] > 1) || (!nzval && colptr[n] > 1)) return CALIPSO_ERR_ARGUMENT;
     const Dims& d = s->d;
     if (n != d.nx || d.ne != 0 || d.nc != 0) { s->err = "calipso_hip_ldl_factorize_csc: the handle was not created by calipso_hip_ldl_create for this n"; return CALIPSO_ERR_ARGUMENT; }
-    if (colptr[0] != 1) { s->err = "colptr must be 1-based (Julia SparseMatrixCSC)"; return CALIPSO_ERR_ARGUMENT; }
+    if (!csc_pattern_ok(n, colptr, rowval)) { s->err = "calipso_hip_ldl_factorize_csc: colptr must be 1-based (Julia SparseMatrixCSC) and non-decreasing, rowval in 1..n"; return CALIPSO_ERR_ARGUMENT; }
     CK(hipSetDevice(s->device));
     LdlAux& a = *aux_of(s, true);
     const size_t nnz = (size_t)(colptr[n] - 1);
     if (nnz > a.cap_nz || !a.colptr) {
-        if (a.rowval) (void)hipFree(a.rowval);
-        if (a.nzval) (void)hipFree(a.nzval);
+        // pointers are cleared as soon as they are freed and the capacity is raised only once both buffers exist: an allocation failure
+        // in between leaves the staging empty, not dangling (ldlsolver_release frees whatever is non-null)
+        if (a.rowval) { (void)hipFree(a.rowval); a.rowval = nullptr; }
+        if (a.nzval) { (void)hipFree(a.nzval); a.nzval = nullptr; }
+        a.cap_nz = 0;
         if (!a.colptr) CK(hipMalloc((void**)&a.colptr, sizeof(long long) * (size_t)(n + 1)));
-        a.cap_nz = std::max<size_t>(nnz, 1);
-        CK(hipMalloc((void**)&a.rowval, sizeof(long long) * a.cap_nz));
-        CK(hipMalloc((void**)&a.nzval, sizeof(double) * a.cap_nz));
+        const size_t cap = std::max<size_t>(nnz, 1);
+        CK(hipMalloc((void**)&a.rowval, sizeof(long long) * cap));
+        CK(hipMalloc((void**)&a.nzval, sizeof(double) * cap));
+        a.cap_nz = cap;
     }
     CK(hipMemcpyAsync(a.colptr, colptr, sizeof(long long) * (size_t)(n + 1), hipMemcpyHostToDevice, s->stream));
     if (nnz) {
@@ -146,7 +150,8 @@ int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver* s, int64_t n, const in
 // [3] nnz(triu A).  When the permuted matrix is banded the blocked LDL^T and the triangular solves skip everything outside the band.
 int32_t calipso_hip_ldl_analyze_csc(calipso_hip_solver* s, int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, int64_t* perm,
                                     int64_t info[4]) {
-    if (!s || !colptr || (!rowval && colptr[n] > 1) || method < 0 || method > 4 || (method == 3 && !perm)) return CALIPSO_ERR_ARGUMENT;
+    if (!s || !colptr || method < 0 || method > 4 || (method == 3 && !perm)) return CALIPSO_ERR_ARGUMENT;
+    if (!csc_pattern_ok(n, colptr, rowval)) { s->err = "calipso_hip_ldl_analyze_csc: colptr must start at 1 and be non-decreasing, rowval in 1..n"; return CALIPSO_ERR_ARGUMENT; }
     const Dims& d = s->d;
     if (n != d.nx || d.ne != 0 || d.nc != 0) { s->err = "calipso_hip_ldl_analyze_csc: the handle was not created by calipso_hip_ldl_create for this n"; return CALIPSO_ERR_ARGUMENT; }
     std::vector<int64_t> p((size_t)n);
@@ -206,7 +211,12 @@ int32_t calipso_hip_ldl_solve(calipso_hip_solver* s, int64_t n, int64_t nrhs, co
     LdlAux& a = *ap;
     CK(hipSetDevice(s->device));
     const size_t need = (size_t)n * (size_t)std::max<int64_t>(nrhs, 1);
-    if (need > a.cap_rhs) { if (a.rhs) (void)hipFree(a.rhs); a.cap_rhs = need; CK(hipMalloc((void**)&a.rhs, sizeof(double) * need)); }
+    if (need > a.cap_rhs) {
+        if (a.rhs) { (void)hipFree(a.rhs); a.rhs = nullptr; }
+        a.cap_rhs = 0;
+        CK(hipMalloc((void**)&a.rhs, sizeof(double) * need));
+        a.cap_rhs = need;                       // only after the allocation succeeded
+    }
     if (nrhs == 0) return CALIPSO_OK;
     CK(hipMemcpyAsync(a.rhs, b, sizeof(double) * (size_t)n * nrhs, hipMemcpyHostToDevice, s->stream));
     for (int64_t j = 0; j < nrhs; ++j) {

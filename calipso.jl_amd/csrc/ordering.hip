@@ -296,13 +296,22 @@ int nested_dissection_pieces(i64 n, const i64* colptr, const i64* rowval, i64* p
     std::copy(p.begin(), p.end(), perm);
     return CALIPSO_OK;
 }
+// one gate for every entry point that walks a caller's CSC pattern: colptr[0] == 1, non-decreasing, fewer than 2^31 entries, 1 <= rowval <= n
+bool csc_pattern_ok(i64 n, const i64* colptr, const i64* rowval) {
+    if (n < 0 || !colptr || colptr[0] != 1) return false;
+    for (i64 c = 0; c < n; ++c) if (colptr[c + 1] < colptr[c]) return false;
+    const i64 nnz = colptr[n] - 1;
+    if (nnz < 0 || nnz >= ((i64)1 << 31) || (nnz > 0 && !rowval)) return false;
+    for (i64 p = 0; p < nnz; ++p) if (rowval[p] < 1 || rowval[p] > n) return false;
+    return true;
+}
 }  // namespace calipso
 
 extern "C" {
 
 // method 0: natural (1..n), 1: reverse Cuthill-McKee, 2: minimum degree, 4: nested dissection (3 is "the caller's order" in the analyse calls).  Pattern: CSC, 1-based, any triangle(s).  perm[k] = the vertex eliminated k-th.
 int32_t calipso_hip_ordering(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, int64_t* perm) {
-    if (n < 0 || !colptr || !perm || (!rowval && colptr[n] > 1) || method < 0 || method > 4 || method == 3) return CALIPSO_ERR_ARGUMENT;
+    if (n < 0 || !colptr || !perm || method < 0 || method > 4 || method == 3 || !calipso::csc_pattern_ok(n, colptr, rowval)) return CALIPSO_ERR_ARGUMENT;
     if (method == 0) { for (i64 k = 0; k < n; ++k) perm[k] = k + 1; return CALIPSO_OK; }
     const auto adj = adjacency(n, colptr, rowval);
     const std::vector<i64> p = method == 1 ? rcm(adj) : method == 2 ? minimum_degree(adj) : nested_dissection(adj);
@@ -315,7 +324,7 @@ int32_t calipso_hip_ordering(int64_t n, const int64_t* colptr, const int64_t* ro
 // status < -1.  info (may be NULL): [0] half bandwidth of P A P', [1] nnz(triu A).
 int64_t calipso_hip_symbolic(int64_t n, const int64_t* colptr, const int64_t* rowval, const int64_t* perm, int64_t* Pp, int64_t* Pi, int64_t* AtoPAPt,
                              int64_t* etree, int64_t* Lnz, int64_t info[2]) {
-    if (n < 1 || !colptr || (!rowval && colptr[n] > 1)) return CALIPSO_ERR_ARGUMENT;
+    if (n < 1 || !calipso::csc_pattern_ok(n, colptr, rowval)) return CALIPSO_ERR_ARGUMENT;
     std::vector<i64> iperm((size_t)n);
     if (perm) { if (!is_permutation(n, perm)) return CALIPSO_ERR_ARGUMENT; for (i64 k = 0; k < n; ++k) iperm[(size_t)perm[k] - 1] = k + 1; }   // invperm (qdldl.jl:143)
     else for (i64 k = 0; k < n; ++k) iperm[(size_t)k] = k + 1;

@@ -30,7 +30,8 @@ struct Pattern {
     int64_t winners = 0;             // entries that survive the assignment order
     int* src = nullptr;              // device: index into the cache of winner w
     long long* dst = nullptr;        // device: offset (doubles) into the destination matrix of winner w
-    double* vals = nullptr;          // device staging of the cache
+    double* vals = nullptr;          // device staging of the cache (kept: the last values of a part are re-used when a later call does not pass it)
+    bool loaded = false;             // vals holds values of an earlier scatter
 };
 struct ScatterAux { std::map<std::string, Pattern> pat; };
 
@@ -122,8 +123,10 @@ int32_t calipso_hip_scatter_field(calipso_hip_solver* s, const char* field, cons
     return CALIPSO_OK;
 }
 
-// Lagrangian Hessian = assign(objective part) + assign(equality-dual part) + assign(cone-dual part); a NULL cache skips that part (e.g. the
-// tensor parts when options.constraint_tensor is off, or a part without registered sparsity).  counts as registered.
+// Lagrangian Hessian = assign(objective part) + assign(equality-dual part) + assign(cone-dual part).  A NULL cache means "not part of this
+// evaluate! call": as in the reference, where each of the three stored matrices keeps its previous values when its flag is not set
+// (evaluate.jl:37-42) and residual_jacobian_variables.jl:10-16 always sums all three, the part's LAST uploaded values are added again from the
+// device-resident cache; a part that has never been scattered (or has no registered sparsity) contributes zeros.  counts as registered.
 int32_t calipso_hip_scatter_hessian(calipso_hip_solver* s, const double* objective_values, int64_t n_objective, const double* equality_dual_values,
                                     int64_t n_equality_dual, const double* cone_dual_values, int64_t n_cone_dual) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
@@ -139,9 +142,10 @@ int32_t calipso_hip_scatter_hessian(calipso_hip_solver* s, const double* objecti
     CK(hipSetDevice(s->device));
     CK(hipMemsetAsync(s->Lxx, 0, sizeof(double) * (size_t)d.nx * d.nx, s->stream));     // the three dense matrices of the reference are zero outside their lists
     for (int k = 0; k < 3; ++k) {
-        if (!vals[k]) continue;
+        if (!a || !a->pat.count(HESSIAN_PARTS[k])) continue;
         Pattern& pat = a->pat[HESSIAN_PARTS[k]];
-        CK(hipMemcpyAsync(pat.vals, vals[k], sizeof(double) * (size_t)cnt[k], hipMemcpyHostToDevice, s->stream));
+        if (vals[k]) { CK(hipMemcpyAsync(pat.vals, vals[k], sizeof(double) * (size_t)cnt[k], hipMemcpyHostToDevice, s->stream)); pat.loaded = true; }
+        if (!pat.loaded || pat.winners == 0) continue;
         hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)((pat.winners + 255) / 256)), dim3(256), 0, s->stream, pat.winners, pat.src, pat.dst, pat.vals, s->Lxx);
     }
     s->hessian_dirty = true;

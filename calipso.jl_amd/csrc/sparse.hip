@@ -589,15 +589,27 @@ int32_t calipso_hip_sparse_destroy(calipso_hip_sparse* s) {
 // QDLDL(A; perm) analyse phase (qdldl.jl:134-188): order, P A P', etree, pattern of L — plus the level schedule of the device factorisation.
 // colptr / rowval: Julia SparseMatrixCSC pattern (1-based); only the upper triangle is read (triu!, linear_solver.jl:23).
 // method: 0 natural, 1 RCM, 2 minimum degree, 4 nested dissection, 3 = `perm` (1-based, perm[k] = vertex eliminated k-th).
+static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, const int64_t* perm, int32_t device,
+                                  calipso_hip_sparse** out);
 int32_t calipso_hip_sparse_create(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, const int64_t* perm, int32_t device,
                                   calipso_hip_sparse** out) {
-    calipso_hip_sparse* s = nullptr;
     if (!out) return CALIPSO_ERR_ARGUMENT;
     *out = nullptr;
-    if (n < 1 || n > 0x3fffffff || !colptr || (!rowval && colptr[n] > 1) || method < 0 || method > 5 || (method == 3 && !perm)) {
+    const int32_t rc = sparse_create_impl(n, colptr, rowval, method, perm, device, out);
+    if (rc != CALIPSO_OK && *out) {             // a failure after the handle was made (stream, uploads, allocations): no half-built handle leaves here
+        g_sparse_err = (*out)->err;
+        (void)calipso_hip_sparse_destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_t* rowval, int32_t method, const int64_t* perm, int32_t device,
+                                  calipso_hip_sparse** out) {
+    calipso_hip_sparse* s = nullptr;
+    if (n < 1 || n > 0x3fffffff || !colptr || method < 0 || method > 5 || (method == 3 && !perm)) {
         g_sparse_err = "calipso_hip_sparse_create: bad arguments"; return CALIPSO_ERR_ARGUMENT;
     }
-    if (colptr[0] != 1) { g_sparse_err = "colptr must be 1-based (Julia SparseMatrixCSC)"; return CALIPSO_ERR_ARGUMENT; }
+    if (!calipso::csc_pattern_ok(n, colptr, rowval)) { g_sparse_err = "colptr must be 1-based (Julia SparseMatrixCSC) and non-decreasing, rowval in 1..n, nnz < 2^31"; return CALIPSO_ERR_ARGUMENT; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_sparse_err = "no HIP device available (libcalipso_hip has no CPU path)"; return CALIPSO_ERR_HIP; }
     if (device < 0 || device >= ndev) { g_sparse_err = "device ordinal out of range"; return CALIPSO_ERR_ARGUMENT; }

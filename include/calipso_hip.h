@@ -145,8 +145,9 @@ int32_t calipso_hip_get_field(calipso_hip_solver*, const char* name, double* dat
  * dense blocks.  Semantics of the reference: plain assignment in list order, so the LAST writer of a repeated entry wins (the trajectory layer
  * repeats entries across stages); the three Hessian matrices are assigned separately and summed into "lagrangian_hessian"
  * (residual_jacobian_variables.jl:10-16).  Fields: "objective_jacobian_variables_variables", "equality_dual_jacobian_variables_variables",
- * "cone_dual_jacobian_variables_variables" (calipso_hip_scatter_hessian; NULL skips a part), "equality_jacobian_variables",
- * "cone_jacobian_variables" (calipso_hip_scatter_field). */
+ * "cone_dual_jacobian_variables_variables" (calipso_hip_scatter_hessian; a NULL part is "not re-evaluated in this call": as in evaluate.jl:37-42
+ * it keeps the values of its last scatter — zeros if it never had one; count = 0 in calipso_hip_set_sparsity drops a part),
+ * "equality_jacobian_variables", "cone_jacobian_variables" (calipso_hip_scatter_field). */
 int32_t calipso_hip_set_sparsity(calipso_hip_solver*, const char* field, int64_t count, const int64_t* rows, const int64_t* cols);
 int32_t calipso_hip_scatter_field(calipso_hip_solver*, const char* field, const double* values, int64_t count);
 int32_t calipso_hip_scatter_hessian(calipso_hip_solver*, const double* objective_values, int64_t n_objective, const double* equality_dual_values,

@@ -62,9 +62,20 @@ def test_scatter_reproduces_the_last_writer_wins_hessian_bit_for_bit():
     fxx2, gyxx2 = dense(prob, x2, y2, ["objective_jacobian_variables_variables", "equality_dual_jacobian_variables_variables"])
     s.scatter_hessian(objective=np.diag(fxx2.reshape(prob.nx, prob.nx)).copy(), equality_dual=trajectory_caches(prob, x2, y2)[2])
     assert np.array_equal(s.get("lagrangian_hessian", prob.nx ** 2), fxx2 + gyxx2)
-    # constraint_tensor = false: only the objective part
+    # a PARTIAL re-evaluation (evaluate.jl:37-42: only the flagged matrices are rewritten, residual_jacobian_variables.jl:10-16 sums all three):
+    # the part that is not passed keeps the values of its last scatter
+    hv3 = trajectory_caches(prob, x, y2)[2]
+    gyxx3, = dense(prob, x, y2, ["equality_dual_jacobian_variables_variables"])
+    s.scatter_hessian(equality_dual=hv3)                           # e.g. after a dual update: the objective part is NOT re-evaluated
+    assert np.array_equal(s.get("lagrangian_hessian", prob.nx ** 2), fxx2 + gyxx3)
+    s.scatter_hessian(objective=np.diag(fxx.reshape(prob.nx, prob.nx)).copy())
+    assert np.array_equal(s.get("lagrangian_hessian", prob.nx ** 2), fxx + gyxx3)
+    # constraint_tensor = false: the tensor parts are never evaluated, so they contribute nothing (a part never scattered is zero; an
+    # earlier one is dropped by un-registering its list)
+    s.set_sparsity("equality_dual_jacobian_variables_variables", [], [])
     s.scatter_hessian(objective=np.diag(fxx2.reshape(prob.nx, prob.nx)).copy())
     assert np.array_equal(s.get("lagrangian_hessian", prob.nx ** 2), fxx2)
+    s.set_sparsity("equality_dual_jacobian_variables_variables", hr, hc)
     with pytest.raises(pkg.CalipsoHipError):
         s.scatter_hessian(equality_dual=hv[:-1])                  # cache length must match the registered list
     with pytest.raises(pkg.CalipsoHipError):

@@ -166,3 +166,28 @@ def test_nested_dissection_is_a_permutation_and_flattens_the_tree():
     for M in (np.ones((70, 70)), np.eye(100), sp.block_diag([np.ones((60, 60)), np.eye(30)]).toarray()):
         perm = pkg.ordering(sp.csc_matrix(M), "nested_dissection")
         assert sorted(perm.tolist()) == list(range(1, M.shape[0] + 1))
+
+
+def test_malformed_csc_patterns_are_rejected_before_any_indexing():
+    """calipso_hip_ordering / calipso_hip_symbolic walk the caller's colptr / rowval: a row index outside 1..n, a colptr that does not start at 1
+    or decreases must come back as CALIPSO_ERR_ARGUMENT (-4), not index past the arrays (host functions: no device needed)"""
+    import ctypes as C
+    pkg = load_pkg()
+    from calipso_jl_amd._lib import lib
+    L = lib()
+    pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    n = 4
+    good_ptr = np.array([1, 2, 4, 6, 8], dtype=np.int64)
+    good_row = np.array([1, 1, 2, 2, 3, 3, 4], dtype=np.int64)
+    perm = np.zeros(n, dtype=np.int64)
+    info = np.zeros(2, dtype=np.int64)
+    assert L.calipso_hip_ordering(n, pi(good_ptr), pi(good_row), 1, pi(perm)) == 0 and sorted(perm.tolist()) == [1, 2, 3, 4]
+    assert L.calipso_hip_symbolic(n, pi(good_ptr), pi(good_row), None, None, None, None, None, None, pi(info)) >= 0
+    for bad_ptr, bad_row in (
+            (good_ptr, np.array([1, 0, 2, 2, 3, 3, 4], dtype=np.int64)),        # row 0
+            (good_ptr, np.array([1, 1, 2, 2, 3, 9, 4], dtype=np.int64)),        # row > n
+            (good_ptr, np.array([1, -3, 2, 2, 3, 3, 4], dtype=np.int64)),       # negative row
+            (np.array([0, 1, 3, 5, 7], dtype=np.int64), good_row),              # 0-based colptr
+            (np.array([1, 4, 2, 6, 8], dtype=np.int64), good_row)):             # decreasing colptr
+        assert L.calipso_hip_ordering(n, pi(bad_ptr), pi(bad_row), 2, pi(perm)) == -4
+        assert L.calipso_hip_symbolic(n, pi(bad_ptr), pi(bad_row), None, None, None, None, None, None, pi(info)) == -4
