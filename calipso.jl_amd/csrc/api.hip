@@ -90,6 +90,8 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     d.N = d.nx + 2 * d.ne + 3 * d.nc;         // dimensions.jl:22-23
     d.m = d.ne + d.nc;
     d.q = (int)n_nonneg; d.n_soc = (int)s->h_soc_start.size(); d.max_dim = maxd;
+    d.n_wide = 0;
+    for (int dim_j : s->h_soc_dim) d.n_wide += dim_j > 4;
     // nx padded: a power-of-two multiple of 64 up to 512 (small systems: one solve block), multiples of 512 above
     if (d.nx <= 512) { d.NP = 64; while (d.NP < d.nx) d.NP *= 2; } else d.NP = ((d.nx + 511) / 512) * 512;   // multiple of the triangular-solve block (and of TILE, NB)
     s->device = device;
@@ -119,7 +121,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->Lxx, NX * NX); SL(&s->Lsym, NX * NX); SL(&s->Z, M * NX);
     SL(&s->fx, NX); SL(&s->gyx, NX); SL(&s->hzx, NX); SL(&s->gh, M);
     SL(&s->cone_product, NC); SL(&s->cone_target, NC); SL(&s->barrier_gradient, NC);
-    SL(&s->dscal, 64); SL(&s->refpart, (NE + NC + 255) / 256 + 1);
+    SL(&s->dscal, 64); SL(&s->refpart, (NE + NC + 255) / 256 + 1 + (size_t)d.n_wide);
     SL(&s->solution, N); SL(&s->candidate, N); SL(&s->lambda, NE); SL(&s->parameters, (size_t)d.np);
     SL(&s->residual, N); SL(&s->residual_error, N); SL(&s->step, N); SL(&s->step_correction, N);
     SL(&s->saved_point, N); SL(&s->saved_g, NE); SL(&s->saved_h, NC);
@@ -158,6 +160,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     schur_plan(s);
     rc |= dalloc(s, &s->cone.soc_start, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.soc_dim, (size_t)d.n_soc);
     rc |= dalloc(s, &s->cone.soc_woff, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.entry_soc, NC);
+    rc |= dalloc(s, &s->cone.wide, (size_t)d.n_wide);
     if (rc) return CALIPSO_ERR_HIP;
     CK(hipHostMalloc((void**)&s->hscal, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     CK(hipHostMalloc((void**)&s->hicount, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
@@ -176,6 +179,11 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
         CK(hipMemcpy(s->cone.soc_start, s->h_soc_start.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
         CK(hipMemcpy(s->cone.soc_dim, s->h_soc_dim.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
         CK(hipMemcpy(s->cone.soc_woff, s->h_soc_woff.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
+    }
+    if (d.n_wide) {
+        std::vector<int> wide;
+        for (int j = 0; j < d.n_soc; ++j) if (s->h_soc_dim[j] > 4) wide.push_back(j);
+        CK(hipMemcpy(s->cone.wide, wide.data(), sizeof(int) * wide.size(), hipMemcpyHostToDevice));
     }
     std::vector<int> es((size_t)std::max(1, d.nc), -1);
     for (int j = 0; j < d.n_soc; ++j)
@@ -214,7 +222,7 @@ int32_t calipso_hip_destroy(H* s) {
     if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
     double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
     for (double* p : dp) if (p) (void)hipFree(p);
-    int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc};
+    int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc, s->cone.wide};
     for (int* p : ip) if (p) (void)hipFree(p);
     if (s->hscal) (void)hipHostFree(s->hscal);
     if (s->hicount) (void)hipHostFree(s->hicount);

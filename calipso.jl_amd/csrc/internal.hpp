@@ -81,6 +81,7 @@ struct Dims {
     int q;                        // number of nonnegative entries (cone-local 0..q-1)
     int n_soc;                    // number of (non-empty) second-order cones
     int max_dim;                  // largest SOC dimension
+    int n_wide;                   // second-order cones of dimension > 4
     int NP;                       // nx padded to a multiple of TILE
     // offsets into a Point (point.jl:13-22)
     __host__ __device__ int orr() const { return nx; }
@@ -96,6 +97,7 @@ struct ConeDev {
     int* soc_dim = nullptr;     // [n_soc]
     int* soc_woff = nullptr;    // [n_soc] offset of its d x d weight block in Wsoc
     int* entry_soc = nullptr;   // [nc] SOC id of an entry, -1 for nonnegative entries
+    int* wide = nullptr;        // [n_wide] ids of the cones of dimension > 4 (soc_wide.hip: one wavefront per cone)
 };
 
 struct QpEval {
@@ -250,6 +252,11 @@ void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int l
 // `kind` names the block (SP_Z, SP_GX, SP_HX, SP_LXX) so that a handle with an analysed structure skips its structural zeros
 // schur.hip
 void launch_cone_weights(calipso_hip_solver* s);
+// soc_wide.hip: cones of dimension > 4, one wavefront per cone (no-ops on handles without such cones)
+void launch_cone_weights_wide(calipso_hip_solver* s);
+void launch_residual_symmetric_wide(calipso_hip_solver* s, const double* res, int p, double* rsym, double* t1);
+void launch_recover_wide(calipso_hip_solver* s, const double* res, int p, const double* rsym, const double* t2, double* dsym, double* step, double* accumulate, int zsx_mode);
+void launch_refine_local_wide(calipso_hip_solver* s, int part0);
 void launch_scale_rows(calipso_hip_solver* s);
 void launch_schur(calipso_hip_solver* s);
 void launch_symmetrize(calipso_hip_solver* s);          // Lsym from the upper triangle of Lxx (for the covered instances)

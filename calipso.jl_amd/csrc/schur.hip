@@ -45,9 +45,10 @@ __global__ __launch_bounds__(1024) void k_cone_weights(BatchSc bt, Dims d, ConeD
         const int st = cd.soc_start[j], dim = cd.soc_dim[j], off = cd.soc_woff[j];
         double* B = Bsoc + off;
         double* W = Wsoc + off;
-        if (dim <= 4) {
+        if (dim > 4) continue;
+        {
             // small cones: the d x d blocks live in registers (loops unrolled to constant indices); the operations and their order are those of the
-            // general branch below
+            // sequential formulation (oracle: oracle_residual_jacobian_variables_symmetric)
             constexpr int MD = 4;
             double ls[MD], lt[MD], u[MD], c[MD], o[MD], Bm[MD * MD], M[MD * MD];
 #pragma unroll
@@ -109,41 +110,8 @@ __global__ __launch_bounds__(1024) void k_cone_weights(BatchSc bt, Dims d, ConeD
 #pragma unroll
                 for (int a = 0; a < MD; ++a) if (a < dim) W[a + col * dim] = -o[a];
             }
-            continue;
         }
-        double* M = work + 2 * off;          // LDL' of the symmetrised block
-        double u[MAX_SOC_DIM], c[MAX_SOC_DIM], o[MAX_SOC_DIM];
-        const double sb1 = sl[st] - sc.ed;
-        u[0] = t[st] + sb1 * Hss;
-        for (int k = 1; k < dim; ++k) u[k] = t[st + k] + sl[st + k] * Hss;
-        for (int col = 0; col < dim; ++col) {
-            for (int a = 0; a < dim; ++a) c[a] = (a == col) ? sb1 : (col == 0 ? sl[st + a] : (a == 0 ? sl[st + col] : 0.0));
-            arrow_inverse(dim, u, c, o);
-            for (int a = 0; a < dim; ++a) B[a + col * dim] = 0.0 - o[a];
-        }
-        for (int a = 0; a < dim; ++a) B[a + a * dim] += (0.0 - sc.ed);
-        // symmetrise from the upper triangle (what a triu-only factorisation sees) and factor without pivoting
-        for (int a = 0; a < dim; ++a)
-            for (int b = 0; b < dim; ++b) M[a + b * dim] = (a <= b) ? B[a + b * dim] : B[b + a * dim];
-        for (int jj = 0; jj < dim; ++jj) {
-            const double dj = M[jj + jj * dim];
-            pos += dj > 0.0; nonpos += dj <= 0.0; zero += dj == 0.0;
-            for (int i = jj + 1; i < dim; ++i) {
-                const double yij = M[i + jj * dim];
-                const double l = yij / dj;
-                for (int k = jj + 1; k <= i; ++k) M[i + k * dim] -= l * (k == i ? yij : M[jj + k * dim]);   // y_k = unscaled column entry
-                M[i + jj * dim] = l;
-                M[jj + i * dim] = yij;   // keep the unscaled column in the upper part for the update above
-            }
-        }
-        // W = -(B_sym)^-1 : solve L D L' x = e_c
-        for (int col = 0; col < dim; ++col) {
-            for (int a = 0; a < dim; ++a) o[a] = (a == col) ? 1.0 : 0.0;
-            for (int a = 0; a < dim; ++a) { double x = o[a]; for (int k = 0; k < a; ++k) x -= M[a + k * dim] * o[k]; o[a] = x; }
-            for (int a = 0; a < dim; ++a) o[a] /= M[a + a * dim];
-            for (int a = dim - 1; a >= 0; --a) { double x = o[a]; for (int k = a + 1; k < dim; ++k) x -= M[k + a * dim] * o[k]; o[a] = x; }
-            for (int a = 0; a < dim; ++a) W[a + col * dim] = -o[a];
-        }
+        // (cones of dimension > 4 are the business of k_cone_weights_wide, soc_wide.hip: one wavefront per cone)
     }
     if (tid == 0 && d.ne > 0) {
         const double ky = -1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed);
@@ -166,6 +134,7 @@ void launch_cone_weights(calipso_hip_solver* s) {
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_cone_weights, dim3(1, 1, B.b.n), dim3(1024), 0, s->stream, B, s->d, s->cone, s->solution, s->kzz, s->wz, s->Bsoc,
                        s->Wsoc, s->socwork, s->icount);
+    launch_cone_weights_wide(s);          // cones of dimension > 4 (adds their pivot signs to the counts the kernel above has just written)
 }
 
 // WH = Omega_z * hx  (nc x nx): nonnegative rows scaled by -1/K_zz, second-order rows multiplied by the d x d block W

@@ -135,26 +135,46 @@ __global__ void k_residual_symmetric(BatchSc bt, Dims d, ConeDev cd, const doubl
         rsym[d.nx + d.ne + k] = v;
         t1[d.ne + k] = wz[k] * v;
     } else if (e < d.ne + d.q + d.n_soc) {
-        // one lane per second-order cone:  b_z[soc] = r_z + U^-1 (Cbar_t r_s + r_t),  U = Cs + Cbar_t P
+        // one lane per second-order cone of dimension <= 4:  b_z[soc] = r_z + U^-1 (Cbar_t r_s + r_t),  U = Cs + Cbar_t P  (registers, loops unrolled
+        // to constant indices); wider cones: k_residual_symmetric_wide (soc_wide.hip), one wavefront per cone
         const int j = e - d.ne - d.q;
         const int st = cd.soc_start[j], dim = cd.soc_dim[j];
-        double u[MAX_SOC_DIM], v[MAX_SOC_DIM], o[MAX_SOC_DIM];
-        const double* sl = w + d.os() + st; const double* t = w + d.ot() + st;
-        const double* rs = res + d.os() + st; const double* rt = res + d.ot() + st;
+        if (dim > 4) return;
+        constexpr int MD = 4;
+        double sl[MD], t[MD], rs[MD], rt[MD], rz[MD], u[MD], v[MD], o[MD], W[MD * MD];
+        const int woff = cd.soc_woff[j];
+#pragma unroll
+        for (int a = 0; a < MD; ++a) {
+            const bool in = a < dim;
+            sl[a] = in ? w[d.os() + st + a] : 0.0; t[a] = in ? w[d.ot() + st + a] : 0.0;
+            rs[a] = in ? res[d.os() + st + a] : 0.0; rt[a] = in ? res[d.ot() + st + a] : 0.0; rz[a] = in ? res[d.oz() + st + a] : 0.0;
+            u[a] = 0.0; v[a] = 0.0; o[a] = 0.0;
+        }
+#pragma unroll
+        for (int e2 = 0; e2 < MD * MD; ++e2) W[e2] = 0.0;
+#pragma unroll
+        for (int c = 0; c < MD; ++c)
+#pragma unroll
+            for (int a = 0; a < MD; ++a) if (a < dim && c < dim) W[a + c * MD] = Wsoc[woff + a + c * dim];
         const double sb1 = sl[0] - sc.ed;
         u[0] = t[0] + sb1 * Hss;
-        for (int k = 1; k < dim; ++k) u[k] = t[k] + sl[k] * Hss;
+#pragma unroll
+        for (int k = 1; k < MD; ++k) if (k < dim) u[k] = t[k] + sl[k] * Hss;
         double acc = sb1 * rs[0];
-        for (int k = 1; k < dim; ++k) acc += sl[k] * rs[k];
+#pragma unroll
+        for (int k = 1; k < MD; ++k) if (k < dim) acc += sl[k] * rs[k];
         v[0] = acc + rt[0];
-        for (int k = 1; k < dim; ++k) v[k] = (sl[k] * rs[0] + sb1 * rs[k]) + rt[k];
-        arrow_inverse(dim, u, v, o);
-        for (int k = 0; k < dim; ++k) { o[k] = res[d.oz() + st + k] + o[k]; rsym[d.nx + d.ne + st + k] = o[k]; }
-        const double* W = Wsoc + cd.soc_woff[j];
-        for (int a = 0; a < dim; ++a) {
-            double s = 0.0;
-            for (int b = 0; b < dim; ++b) s += W[a + b * dim] * o[b];
-            t1[d.ne + st + a] = s;
+#pragma unroll
+        for (int k = 1; k < MD; ++k) if (k < dim) v[k] = (sl[k] * rs[0] + sb1 * rs[k]) + rt[k];
+        arrow_inverse_small<MD>(dim, u, v, o);
+#pragma unroll
+        for (int k = 0; k < MD; ++k) if (k < dim) { o[k] = rz[k] + o[k]; rsym[d.nx + d.ne + st + k] = o[k]; }
+#pragma unroll
+        for (int a = 0; a < MD; ++a) if (a < dim) {
+            double ss = 0.0;
+#pragma unroll
+            for (int b2 = 0; b2 < MD; ++b2) if (b2 < dim) ss += W[a + b2 * MD] * o[b2];
+            t1[d.ne + st + a] = ss;
         }
     }
 }
@@ -164,12 +184,14 @@ void launch_residual_symmetric(calipso_hip_solver* s, const double* res) {
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128, 1, B.b.n), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
                        s->wz, s->Wsoc, s->residual_symmetric, s->xbuf, s->t1);
+    launch_residual_symmetric_wide(s, res, 1, s->residual_symmetric, s->t1);
 }
 void launch_residual_symmetric_multi(calipso_hip_solver* s, const double* res, int p, double* rsym, double* xbuf, double* t1) {
     const int work = s->d.NP + s->d.ne + s->d.q + s->d.n_soc;
     const BatchSc B = batch_of(s);   // (the multi-column path is single-instance)
     hipLaunchKernelGGL(k_residual_symmetric, dim3((work + 127) / 128, p, 1), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
                        s->wz, s->Wsoc, rsym, xbuf, t1);
+    launch_residual_symmetric_wide(s, res, p, rsym, t1);
 }
 
 // Tail of the condensed solve + search_direction_symmetric! (search_direction.jl:38-101) in one kernel:
@@ -223,7 +245,7 @@ __global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restri
         const int st = cd.soc_start[j], dim = cd.soc_dim[j];
         if (dim <= 4) {
             // small cones (friction cones, SOC2 / SOC3): everything the cone needs is fetched in ONE round of independent loads into registers and the
-            // loops are unrolled to constant indices; the operations and their order are those of the general branch below
+            // loops are unrolled to constant indices; the operations and their order are those of the sequential formulation (search_direction.jl:83-101)
             constexpr int MD = 4;
             double sl[MD], t[MD], rs[MD], rt[MD], bb[MD], tt[MD], zz[MD], W[MD * MD];
             const int woff = cd.soc_woff[j];
@@ -284,39 +306,7 @@ __global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restri
             }
             return;
         }
-        double u[MAX_SOC_DIM], v[MAX_SOC_DIM], ds[MAX_SOC_DIM], o[MAX_SOC_DIM], dz[MAX_SOC_DIM];
-        const double* sl = w + d.os() + st; const double* t = w + d.ot() + st;
-        const double* rs = res + d.os() + st; const double* rt = res + d.ot() + st;
-        const double* W = Wsoc + cd.soc_woff[j];
-        for (int a = 0; a < dim; ++a) o[a] = b[d.nx + d.ne + st + a] - t2[d.ne + st + a];
-        if (zsx_mode) for (int a = 0; a < dim; ++a) zsx[d.ne + st + a] = zsx_mode == 1 ? t2[d.ne + st + a] : zsx[d.ne + st + a] + t2[d.ne + st + a];
-        for (int a = 0; a < dim; ++a) {
-            double s = 0.0;
-            for (int c = 0; c < dim; ++c) s += W[a + c * dim] * o[c];
-            dz[a] = -1.0 * s;
-            dsym[d.nx + d.ne + st + a] = dz[a];
-        }
-        const double sb1 = sl[0] - sc.ed;
-        u[0] = t[0] + sb1 * Hss;
-        for (int k = 1; k < dim; ++k) u[k] = t[k] + sl[k] * Hss;
-        // ds = U^-1 (r_t + Cbar_t (r_s + dz))
-        double acc = sb1 * (rs[0] + dz[0]);
-        for (int k = 1; k < dim; ++k) acc += sl[k] * (rs[k] + dz[k]);
-        v[0] = rt[0] + acc;
-        for (int k = 1; k < dim; ++k) v[k] = rt[k] + (sl[k] * (rs[0] + dz[0]) + sb1 * (rs[k] + dz[k]));
-        arrow_inverse(dim, u, v, ds);
-        // dt = Cbar_t^-1 (r_t - Cs ds),  Cs = arrow(t)
-        acc = t[0] * ds[0];
-        for (int k = 1; k < dim; ++k) acc += t[k] * ds[k];
-        v[0] = rt[0] - acc;
-        for (int k = 1; k < dim; ++k) v[k] = rt[k] - (t[k] * ds[0] + t[0] * ds[k]);
-        u[0] = sb1;
-        for (int k = 1; k < dim; ++k) u[k] = sl[k];
-        arrow_inverse(dim, u, v, o);
-        for (int k = 0; k < dim; ++k) {
-            step[d.oz() + st + k] = dz[k]; step[d.os() + st + k] = ds[k]; step[d.ot() + st + k] = o[k];
-            if (accum) { accum[d.oz() + st + k] += dz[k]; accum[d.os() + st + k] += ds[k]; accum[d.ot() + st + k] += o[k]; }
-        }
+        // (dimension > 4: k_recover_wide, soc_wide.hip)
     }
 }
 
@@ -325,6 +315,7 @@ void launch_recover(calipso_hip_solver* s, double* step, const double* res, doub
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128, 1, B.b.n), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
                        s->residual_symmetric, s->xbuf, s->t2, s->wz, s->Wsoc, s->step_symmetric, step, accumulate, s->zsx, zsx_mode);
+    launch_recover_wide(s, res, 1, s->residual_symmetric, s->t2, s->step_symmetric, step, accumulate, zsx_mode);
 }
 __global__ void k_scale_inplace(size_t n, double* __restrict__ x, double a) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,6 +327,7 @@ void launch_recover_multi(calipso_hip_solver* s, const double* res, int p, const
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_recover, dim3((work + 127) / 128, p, 1), dim3(128), 0, s->stream, B, s->d, s->cone, s->solution, res,
                        rsym, xbuf, t2, s->wz, s->Wsoc, s->dsym_multi, step, (double*)nullptr, (double*)nullptr, 0);
+    launch_recover_wide(s, res, p, rsym, t2, s->dsym_multi, step, nullptr, 0);
     if (scale != 1.0) {
         const size_t n = (size_t)s->d.N * p;
         hipLaunchKernelGGL(k_scale_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, n, step, scale);
@@ -682,45 +674,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_refine_local(BatchSc bt, Dims d,
                 for (int b2 = 0; b2 < MD; ++b2) if (b2 < dim) ss += W[a + b2 * MD] * o[b2];
                 t1[d.ne + st + a] = ss;
             }
-        } else {
-        double rs[MAX_SOC_DIM], rt[MAX_SOC_DIM], rz[MAX_SOC_DIM];
-        for (int a = 0; a < dim; ++a) {
-            const int k = st + a;
-            const int is = d.os() + k, iz = d.oz() + k, it = d.ot() + k;
-            const double hs = (0.0 + sc.ep) * v[is] - v[d.oz() + k] - v[d.ot() + k];
-            rs[a] = res[is] - hs;
-            const double hz = zsx[d.ne + iz - d.oz()] + (-v[d.os() + iz - d.oz()] + (0.0 - sc.ed) * v[iz]);
-            rz[a] = res[iz] - hz;
-            double ht;
-            if (a == 0) {
-                ht = t[st] * vs[st] + (sl[st] - sc.ed) * vt[st];
-                for (int q = 1; q < dim; ++q) ht += t[st + q] * vs[st + q] + sl[st + q] * vt[st + q];
-            } else {
-                ht = t[k] * vs[st] + sl[k] * vt[st];
-                ht += t[st] * vs[k] + (sl[st] - sc.ed) * vt[k];
-            }
-            rt[a] = res[it] - ht;
-            e[is] = rs[a]; e[iz] = rz[a]; e[it] = rt[a];
-            m = fmax(m, fmax(fmax(fabs(rs[a]), fabs(rz[a])), fabs(rt[a])));
-        }
-        double u[MAX_SOC_DIM], vv[MAX_SOC_DIM], o[MAX_SOC_DIM];
-        const double* slj = w + d.os() + st; const double* tj = w + d.ot() + st;
-        const double sb1 = slj[0] - sc.ed;
-        u[0] = tj[0] + sb1 * Hss;
-        for (int k = 1; k < dim; ++k) u[k] = tj[k] + slj[k] * Hss;
-        double acc = sb1 * rs[0];
-        for (int k = 1; k < dim; ++k) acc += slj[k] * rs[k];
-        vv[0] = acc + rt[0];
-        for (int k = 1; k < dim; ++k) vv[k] = (slj[k] * rs[0] + sb1 * rs[k]) + rt[k];
-        arrow_inverse(dim, u, vv, o);
-        for (int k = 0; k < dim; ++k) { o[k] = rz[k] + o[k]; rsym[d.nx + d.ne + st + k] = o[k]; }
-        const double* W = Wsoc + cd.soc_woff[j];
-        for (int a = 0; a < dim; ++a) {
-            double ss = 0.0;
-            for (int b = 0; b < dim; ++b) ss += W[a + b * dim] * o[b];
-            t1[d.ne + st + a] = ss;
-        }
-        }
+        }   // (dimension > 4: k_refine_local_wide, soc_wide.hip)
     }
     const double mr = block_max(m, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = mr;
@@ -764,12 +718,13 @@ void launch_refine_local(calipso_hip_solver* s) {
     if (items == 0) return;
     hipLaunchKernelGGL(k_refine_local, dim3((items + RL_THREADS - 1) / RL_THREADS, 1, B.b.n), dim3(RL_THREADS), 0, s->stream, B, s->d, s->cone, s->solution, s->step,
                        s->residual, s->zsx, s->wz, s->Wsoc, s->residual_error, s->residual_symmetric, s->t1, s->refpart);
+    launch_refine_local_wide(s, (items + RL_THREADS - 1) / RL_THREADS);      // their partial norms follow the ones of the kernel above in refpart
 }
 void launch_refine_x(calipso_hip_solver* s, bool publish) {
     const BatchSc B = batch_of(s);
     const int items = s->d.ne + s->d.q + s->d.n_soc;
     hipLaunchKernelGGL(k_refine_x, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->d.m > 0 ? 1 : 0, s->step, s->residual, s->lxv, s->w1, s->w2, s->residual_error,
-                       s->residual_symmetric, s->xbuf, s->dscal, s->refpart, (items + RL_THREADS - 1) / RL_THREADS,
+                       s->residual_symmetric, s->xbuf, s->dscal, s->refpart, (items + RL_THREADS - 1) / RL_THREADS + s->d.n_wide,
                        publish ? s->hscal_dev : (double*)nullptr, publish ? s->hseq_dev : (unsigned long long*)nullptr, publish ? ++s->pub_seq : 0ULL);
 }
 

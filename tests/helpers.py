@@ -20,15 +20,17 @@ def load_pkg():
     return m
 
 
-def interior_point(prob, seed):
+def interior_point(prob, seed, tail=0.3):
+    """tail: scale of the second-order cone tails (head = 1 + |tail|): wide cones need a smaller one to stay as far inside the cone, relatively,
+    as the small ones (the upper-triangle symmetrisation of the reference, quirk B-3, is the coarser the closer to the boundary)"""
     rng = np.random.default_rng(seed)
     pt = dict(x=rng.standard_normal(prob.nx), r=rng.random(prob.ne), s=0.5 + rng.random(prob.nc), y=rng.standard_normal(prob.ne),
               z=rng.standard_normal(prob.nc), t=0.5 + rng.random(prob.nc))
     for c in prob.second_order_indices:
         if c:
             i = np.array(c) - 1
-            pt["s"][i[1:]] = 0.3 * rng.standard_normal(len(i) - 1)
-            pt["t"][i[1:]] = 0.3 * rng.standard_normal(len(i) - 1)
+            pt["s"][i[1:]] = tail * rng.standard_normal(len(i) - 1)
+            pt["t"][i[1:]] = tail * rng.standard_normal(len(i) - 1)
             pt["s"][i[0]] = 1.0 + np.linalg.norm(pt["s"][i[1:]])
             pt["t"][i[0]] = 1.0 + np.linalg.norm(pt["t"][i[1:]])
     lam = rng.standard_normal(prob.ne)

@@ -255,3 +255,21 @@ def test_group_sizes_on_the_flattened_grids(n):
             assert same(s.data("step").all, m.data("step").all)
             assert same(s.solution.all, m.solution.all)
     g.close()
+
+
+def test_group_with_wide_second_order_cones_is_bitwise_the_single_step():
+    """cones of dimension 12 (the reference's portfolio size) take the wave-per-cone kernels of csrc/soc_wide.hip: also per member of a group"""
+    pkg = load_pkg()
+    shape = (200, 60, 24, 6, 12)          # 24 nonnegative rows + 6 cones of dimension 12
+    ids = [21, 22, 23]
+    singles = [build(pkg, p, shape) for p in ids]
+    members = [build(pkg, p, shape) for p in ids]
+    g = pkg.Group(members)
+    for it in range(2):
+        ref = [s.newton_step(advance=True) for s in singles]
+        got = g.newton_step(advance=True)
+        for r, q, s, m in zip(ref, got, singles, members):
+            assert r == q and r["status"] >= 0, (it, r, q)
+            assert same(s.data("step").all, m.data("step").all)
+            assert same(s.solution.all, m.solution.all)
+    g.close()

@@ -18,6 +18,10 @@ CASES = {
     "qp_nonneg_10_5_5": lambda: pr.random_qp(10, 5, 5, seed=3),
     "qp_soc_6_3_9": lambda: pr.random_qp(6, 3, 9, seed=10, nonnegative_indices=[1, 2], second_order_indices=[[3, 4, 5], [6, 7, 8, 9]]),
     "qp_soc12_20_4_14": lambda: pr.random_qp(20, 4, 14, seed=5, nonnegative_indices=[1, 2], second_order_indices=[list(range(3, 15))]),
+    # wide cones (dimension > 4) run one wavefront per cone (csrc/soc_wide.hip): the largest supported dimension, and wide + small + nonnegative mixed
+    "qp_soc64_70_5_66": lambda: pr.random_qp(70, 5, 66, seed=12, nonnegative_indices=[1, 2], second_order_indices=[list(range(3, 67))]),
+    "qp_soc_mixed_widths_40_6_35": lambda: pr.random_qp(40, 6, 35, seed=13, nonnegative_indices=[1, 2, 3],
+                                                          second_order_indices=[[4, 5, 6], list(range(7, 19)), [19, 20], list(range(21, 30)), [], list(range(30, 36))]),
     "qp_noeq_7_0_4": lambda: pr.random_qp(7, 0, 4, seed=6),
     "qp_nocone_9_4_0": lambda: pr.random_qp(9, 4, 0, seed=7),
     "qp_mixed_300_120_130": lambda: pr.random_qp(300, 120, 130, seed=8, nonnegative_indices=list(range(1, 41)),
@@ -28,7 +32,7 @@ CASES = {
 @pytest.mark.parametrize("case", list(CASES))
 def test_newton_step_parity(oracle_mod, case):
     prob = CASES[case]()
-    pt, lam = interior_point(prob, seed=1)
+    pt, lam = interior_point(prob, seed=1, tail=0.05 if "soc64" in case else 0.3)
     o, g = make_pair(oracle_mod, prob, pt, lam)
     nx, ne, nc, N, n = o.nx, o.ne, o.nc, o.N, o.n
     # a1: Indices — bit-exact integer work

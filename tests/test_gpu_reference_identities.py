@@ -47,7 +47,7 @@ def cone_blocks(prob, u):
 
 def device_solver(prob, seed):
     pkg = load_pkg()
-    pt, lam = interior_point(prob, seed=seed)
+    pt, lam = interior_point(prob, seed=seed, tail=0.05 if max([len(c) for c in prob.second_order_indices] + [0]) > 16 else 0.3)
     g = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, parameters=prob.parameters, nonnegative_indices=prob.nonnegative_indices,
                    second_order_indices=prob.second_order_indices)
     w = np.concatenate([pt[k] for k in "xrsyzt"])
@@ -110,6 +110,7 @@ CASES = {
     "problem_jl_10_5_5_nonnegative": lambda: pr.random_qp(10, 5, 5, seed=3),
     "soc3_soc4_6_3_9": lambda: pr.random_qp(6, 3, 9, seed=10, nonnegative_indices=[1, 2], second_order_indices=[[3, 4, 5], [6, 7, 8, 9]]),
     "soc12_portfolio_size_20_4_14": lambda: pr.random_qp(20, 4, 14, seed=5, nonnegative_indices=[1, 2], second_order_indices=[list(range(3, 15))]),
+    "soc64_largest_dimension_70_5_66": lambda: pr.random_qp(70, 5, 66, seed=12, nonnegative_indices=[1, 2], second_order_indices=[list(range(3, 67))]),
     "mixed_120_50_64": lambda: pr.random_qp(120, 50, 64, seed=8, nonnegative_indices=list(range(1, 17)),
                                              second_order_indices=[list(range(17 + 3 * k, 20 + 3 * k)) for k in range(16)]),
 }
