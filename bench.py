@@ -492,7 +492,7 @@ def main():
         if args.config != "C3":
             return None
         for kname, e in pmc.get(section, {}).items():
-            if kname.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
+            if kname.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e and (section != "single" or "<0>" in kname or "k_ldl_step" not in kname):
                 return e["hbm_bytes_per_launch"] * scale
         return None
 
@@ -509,12 +509,12 @@ def main():
     cands = []
     if ph is not None:
         step_ms = float(np.mean(ph["total"]))
-        cands = [entry(K_LDL, flops_ldl, n_ldl_launch, float(np.mean(ph["chain"])), 1, "single", "void calipso::k_ldl_step", step_ms),
+        cands = [entry(K_LDL, flops_ldl, n_ldl_launch, float(np.mean(ph["chain"])), 1, "single", "calipso::k_ldl_step", step_ms),
                  entry(K_SCH, flops_schur, 1, float(np.mean(ph["schur"])), 1, "single", "calipso::k_schur", step_ms)]
     grp = None
     if alone:
         al = np.mean(np.asarray(alone), axis=0)
-        grp = [entry(K_LDL, flops_ldl, n_ldl_launch, float(np.mean(alone_chain)), G, "group", "void calipso::k_ldl_step", float(al[6])),
+        grp = [entry(K_LDL, flops_ldl, n_ldl_launch, float(np.mean(alone_chain)), G, "group", "calipso::k_ldl_step", float(al[6])),
                entry(K_SCH, flops_schur, 1, float(al[7]), G, "group", "calipso::k_schur", float(al[6]))]
         grp[1]["avg_launch_ms_with_all_units_in_flight"] = float(np.mean(sch_conc)) if sch_conc else None
         if not cands:

@@ -4,7 +4,8 @@
 usage: pmc_summary.py FETCH_SIZE.csv WRITE_SIZE.csv GRID_Z out.json [COUNTER:file.csv ...]
 (extra COUNTER passes, e.g. MfmaUtil, SQ_LDS_BANK_CONFLICT, are averaged per kernel and added under that name)
 Only dispatches whose Grid_Size matches the group launch (k_schur: grid.z = GRID_Z instances) are averaged for k_schur; the other
-kernels are averaged over all their dispatches.  FETCH_SIZE is doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950
+kernels are averaged over all their dispatches (k_ldl_step: over the NP / 64 - 1 panel steps of a factorisation, early and late ones alike —
+the same average bench.py's roofline uses).  FETCH_SIZE is doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950
 rocprofv3 reports half of a wide streaming read); both counters are in KiB."""
 import csv
 import json
@@ -37,9 +38,9 @@ def main():
         e = {"launches_sampled": len(f),
              "FETCH_SIZE_KiB_per_launch": sum(v for _, v in f) / max(1, len(f)),
              "WRITE_SIZE_KiB_per_launch": sum(v for _, v in w) / max(1, len(w))}
+        e["instances_per_launch"] = gz
+        e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KiB_per_launch"] + e["WRITE_SIZE_KiB_per_launch"]) * 1024.0
         if k == "calipso::k_schur":
-            e["instances_per_launch"] = gz
-            e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KiB_per_launch"] + e["WRITE_SIZE_KiB_per_launch"]) * 1024.0
             e["note"] = ("FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 rocprofv3 reports half of a wide streaming read; 8 B/lane "
                          "loads are uncalibrated, so this is an upper bound); WRITE_SIZE as reported")
         res[k] = e

@@ -302,6 +302,38 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), vmcnt / expcnt untouched
     __builtin_amdgcn_s_barrier();
 }
+// acc[r] = sum_k Y[16 wc + fk + 4 r][k] L[16 wr + fr][k] for one wavefront: 16 v_mfma_f64_16x16x4_f64 on fragments of two k-fastest LDS panels (row stride
+// LDT), lb / yb = LDS byte addresses of this lane's row of the B / A operand panel at k = fk.  MFMA fragments by explicit ds_read_b64 (lane
+// (fr, fk) reads row fr, k = 4 kk + fk: dword address 132 fr + 2 fk + 8 kk — the 32 lanes of a half-wave hit 32 distinct bank pairs modulo 64).
+// Plain loads would be paired by the compiler into ds_read2_b64 / ds_read_b128, whose lane groups conflict 2-way on this layout.  A ring of two
+// register groups of four k-steps: the reads of group g + 2 are issued as soon as the MFMAs of group g have taken their operands, so 16 doubles
+// hold the fragments instead of 32; the waits release the loads to the matrix cores in order (LDS returns in order).
+__device__ __forceinline__ v4d frag_product(const unsigned lb, const unsigned yb) {
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    double fl[8], fy[8];
+#define TR_READ(G, KK0)                                                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                                      \
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fl[(G) * 4 + q]) : "v"(lb), "n"(((KK0) + q) * 32) : "memory");                 \
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fy[(G) * 4 + q]) : "v"(yb), "n"(((KK0) + q) * 32) : "memory");                 \
+    }
+#define TR_WAIT(N, G)                                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fl[(G) * 4]), "+v"(fy[(G) * 4]), "+v"(fl[(G) * 4 + 1]), "+v"(fy[(G) * 4 + 1]),               \
+                 "+v"(fl[(G) * 4 + 2]), "+v"(fy[(G) * 4 + 2]), "+v"(fl[(G) * 4 + 3]), "+v"(fy[(G) * 4 + 3]) :: "memory")
+#define TR_MFMA(G)                                                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fy[(G) * 4 + q], fl[(G) * 4 + q], acc, 0, 0, 0);
+    TR_READ(0, 0) TR_READ(1, 4)
+    TR_WAIT(8, 0); TR_MFMA(0)
+    TR_READ(0, 8)
+    TR_WAIT(8, 1); TR_MFMA(1)
+    TR_READ(1, 12)
+    TR_WAIT(8, 0); TR_MFMA(0)
+    TR_WAIT(0, 1); TR_MFMA(1)
+#undef TR_READ
+#undef TR_WAIT
+#undef TR_MFMA
+    return acc;
+}
+
 // Z = A(i, panel) M into Zs (LDS, [row i][c fastest], ld LDT): on a change of tile row.  The raw rows travel through `stage` (the buffer the
 // column operand uses afterwards) and M (symmetric, 32 KB, in L2 for every workgroup of the launch) through `Ms`, both fetched in ONE batch of
 // global loads (the workgroup that carries the pivot chain pays one memory round trip here, not two).
@@ -319,15 +351,11 @@ __device__ __forceinline__ void form_Z(const double* __restrict__ Ap, int NP, co
         Ms[row * LDT + cb + it * 16] = mv[it];           // Ms[c][k] = M[c][k]
     }
     lds_barrier();
-    v4d z = (v4d){0.0, 0.0, 0.0, 0.0};
+    // Z[i][c] = sum_k A[i][k] M[c][k]: the fragment sequence of the tile product with (Ms, stage) in the places of (Ys, Zs); this lane receives
+    // Z(i = 16 wr + fr, c = 16 wc + fk + 4 r)
+    const v4d z = frag_product((unsigned)(uintptr_t)(stage + (wr * 16 + fr) * LDT + fk), (unsigned)(uintptr_t)(Ms + (wc * 16 + fr) * LDT + fk));
 #pragma unroll
-    for (int kk = 0; kk < NB / 4; ++kk) {
-        const double a = stage[(wr * 16 + fr) * LDT + 4 * kk + fk];
-        const double m = Ms[(wc * 16 + fr) * LDT + 4 * kk + fk];
-        z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, m, z, 0, 0, 0);    // D[row i][col c]: lane holds Z(i = fk + 4 r, c = fr)
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Zs[(wr * 16 + fk + 4 * r) * LDT + wc * 16 + fr] = z[r];
+    for (int r = 0; r < 4; ++r) Zs[(wr * 16 + fr) * LDT + wc * 16 + fk + 4 * r] = z[r];
     lds_barrier();                        // Z visible; every read of `stage` / Ms is done (they are refilled next)
 }
 // ONE grid dimension over all instances of the launch.  Workgroup w runs on XCD w % 8 (dispatch order; used for speed only); the first bt.n
@@ -425,37 +453,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
 #pragma unroll
                 for (int it = 0; it < 4; ++it) yv[h][it] = Sn[(jn0 + row) + (size_t)(k0 + h * NB + cb + it * 16) * NP];
             }
-            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-            // MFMA fragments by explicit ds_read_b64 (lane (fr, fk) reads row fr, k = 4 kk + fk: dword address 132 fr + 2 fk + 8 kk — the 32
-            // lanes of a half-wave hit 32 distinct bank pairs modulo 64).  Plain loads would be paired by the compiler into ds_read2_b64 /
-            // ds_read_b128, whose lane groups conflict 2-way on this layout.  The waits release the loads to the matrix cores in order.
-            {
-                const unsigned lb = (unsigned)(uintptr_t)(Zs + h * TT * LDT + (wr * 16 + fr) * LDT + fk);
-                const unsigned yb = (unsigned)(uintptr_t)(Ys + (wc * 16 + fr) * LDT + fk);
-                // a ring of two register groups of four k-steps: the reads of group g + 2 are issued as soon as the MFMAs of group g have taken
-                // their operands, so 16 doubles hold the fragments instead of 32
-                double fl[8], fy[8];
-#define TR_READ(G, KK0)                                                                                                                    \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                          \
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fl[(G) * 4 + q]) : "v"(lb), "n"(((KK0) + q) * 32) : "memory");     \
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fy[(G) * 4 + q]) : "v"(yb), "n"(((KK0) + q) * 32) : "memory");     \
-                }
-#define TR_WAIT(N, G)                                                                                                                      \
-                asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fl[(G) * 4]), "+v"(fy[(G) * 4]), "+v"(fl[(G) * 4 + 1]), "+v"(fy[(G) * 4 + 1]),   \
-                             "+v"(fl[(G) * 4 + 2]), "+v"(fy[(G) * 4 + 2]), "+v"(fl[(G) * 4 + 3]), "+v"(fy[(G) * 4 + 3]) :: "memory")
-#define TR_MFMA(G)                                                                                                                         \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fy[(G) * 4 + q], fl[(G) * 4 + q], acc, 0, 0, 0);
-                TR_READ(0, 0) TR_READ(1, 4)
-                TR_WAIT(8, 0); TR_MFMA(0)
-                TR_READ(0, 8)
-                TR_WAIT(8, 1); TR_MFMA(1)
-                TR_READ(1, 12)
-                TR_WAIT(8, 0); TR_MFMA(0)
-                TR_WAIT(0, 1); TR_MFMA(1)
-#undef TR_READ
-#undef TR_WAIT
-#undef TR_MFMA
-            }
+            const v4d acc = frag_product((unsigned)(uintptr_t)(Zs + h * TT * LDT + (wr * 16 + fr) * LDT + fk), (unsigned)(uintptr_t)(Ys + (wc * 16 + fr) * LDT + fk));
 #pragma unroll
             for (int r = 0; r < 4; ++r) cS[r] -= acc[r];
             if (h + 1 < NH) lds_barrier();            // the operand reads of the first panel are done before Ys is refilled
