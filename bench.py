@@ -236,7 +236,7 @@ class Workload:
     """B independent instances of one configuration on this rank's GPU.  Instance 0 is the rank's single system (headline region); the B
     instances form B / G groups of G (the members of a group are stepped in lockstep through the same launches), `lanes` groups in flight."""
 
-    def __init__(self, pkg, pr, name, rank, world, device, B, G, lanes, dense_structure=False, no_stage_parallel=False):
+    def __init__(self, pkg, pr, name, rank, world, device, B, G, lanes, dense_structure=False, no_stage_parallel=False, no_stage_blocks=False):
         from calipso_jl_amd.batch import BatchSolver, shard_range
         self.pkg, self.name, self.B, self.G, self.world = pkg, name, max(0, B), max(1, G), world
         self.staged = STAGED.get(name)
@@ -267,6 +267,14 @@ class Workload:
                     self.stage_parallel = self.solvers[k].set_stage_parallel(True, batch=G_)
             except pkg.CalipsoHipError as e:                      # a front exceeds one CU's LDS: the blocked factorisation stays
                 self.stage_parallel = dict(refused=str(e))
+        self.stage_blocks = None
+        if self.staged is not None and not dense_structure and not no_stage_blocks:
+            # stage blocks (calipso_hip_set_stage_blocks): packed blocks of [gx; hx] / Lxx, block mat-vecs, Schur complement by segment pairs
+            try:
+                for sv in self.solvers:
+                    self.stage_blocks = sv.set_stage_blocks(True)
+            except pkg.CalipsoHipError as e:
+                self.stage_blocks = dict(refused=str(e))
         self.single = self.solvers[0]
         self.units = ([pkg.Group(self.solvers[k:k + G_]) for k in range(0, self.B, G_)] if G_ > 1 else self.solvers[:self.B]) if self.B else []
         self.batch = BatchSolver(self.units, lanes=lanes) if self.units else None
@@ -288,7 +296,8 @@ class Workload:
         if not st:
             return "dense "
         return "stage-structured (%d stages, %s treatment) " % (st[0], "dense" if dense_structure else (
-            "banded, stage-parallel multifrontal LDL^T of S" if self.stage_parallel and "levels" in self.stage_parallel else "banded"))
+            ("stage blocks, " if self.stage_blocks and "z_blocks" in self.stage_blocks else "banded, ") +
+            ("stage-parallel multifrontal LDL^T of S" if self.stage_parallel and "levels" in self.stage_parallel else "blocked LDL^T of S")))
 
     def describe(self):
         nx, ne, n_nn, n_soc, dim = self.shape
@@ -323,6 +332,7 @@ def main():
     ap.add_argument("--config", default="C3", choices=list(CONFIGS) + list(STAGED))
     ap.add_argument("--dense-structure", action="store_true", help="stage-structured configs: keep the dense treatment (no calipso_hip_analyze_structure)")
     ap.add_argument("--no-stage-parallel", action="store_true", help="stage-structured configs: keep the blocked banded LDL^T of S (no calipso_hip_set_stage_parallel)")
+    ap.add_argument("--no-stage-blocks", action="store_true", help="stage-structured configs: keep the dense-layout mat-vecs and Schur kernel (no calipso_hip_set_stage_blocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="measure B0(ii) (re-factorisation before every solve) instead of deriving it (~1 min more)")
     ap.add_argument("--cpu-samples", type=int, default=3)
@@ -421,7 +431,7 @@ def main():
         return elapsed, infos, dict(schur=sch, ldl=ldl, chain=chain, sd=sd, total=tot)
 
     # =================================================================== headline workload ======================================
-    wl = Workload(pkg, pr, args.config, rank, world, local_rank, args.batch, args.group, args.lanes, args.dense_structure, args.no_stage_parallel)
+    wl = Workload(pkg, pr, args.config, rank, world, local_rank, args.batch, args.group, args.lanes, args.dense_structure, args.no_stage_parallel, args.no_stage_blocks)
     B, G = wl.B, wl.G
     shape, staged = wl.shape, wl.staged
     # ---- warm-up: W steps of the single system (captures its launch graphs) and of the batched pass ----------------------------
@@ -596,7 +606,7 @@ def main():
             r2 = world * w4.B * P4 / e2
             c4[cname] = {"workload": cname + " " + w4.kind(False) + w4.describe(), "single_system_steps_per_s": world * K4 / e1, "single_ms_per_step": 1e3 * e1 / K4,
                          "batched_newton_steps_per_s": r2, "batched_problems_per_s_of_10_steps": r2 / 10.0, "ms_per_pass": 1e3 * e2 / P4, "passes": P4,
-                         "refinement_rounds": int(i2[0]["refinement_rounds"]), "stage_parallel": w4.stage_parallel,
+                         "refinement_rounds": int(i2[0]["refinement_rounds"]), "stage_parallel": w4.stage_parallel, "stage_blocks": w4.stage_blocks,
                          "device_bytes_per_instance": w4.single.device_bytes()}
             w4.close()
             del w4

@@ -423,6 +423,13 @@ class Solver:
         self._check(self._L.calipso_hip_set_stage_parallel(self._h, 1 if on else 0, int(batch), _pi(out)), "set_stage_parallel")
         return dict(levels=int(out[0]), largest_front=int(out[1]), nnz_upper=int(out[2]))
 
+    def set_stage_blocks(self, on=True):
+        """after analyze_structure: pack the blocks of [gx; hx] and of the Lagrangian Hessian and run the mat-vecs / the Schur complement on them
+        (csrc/blocks.hip).  Returns dict(z_blocks, hessian_blocks, segments, packed_doubles)."""
+        out = np.zeros(4, dtype=np.int64)
+        self._check(self._L.calipso_hip_set_stage_blocks(self._h, 1 if on else 0, _pi(out)), "set_stage_blocks")
+        return dict(z_blocks=int(out[0]), hessian_blocks=int(out[1]), segments=int(out[2]), packed_doubles=int(out[3]))
+
     def synchronize(self):
         self._check(self._L.calipso_hip_synchronize(self._h), "synchronize")
 

@@ -65,6 +65,7 @@ SYMBOLS = {
     "calipso_hip_analyze_structure": (_i32, [_vp, _pi64]),
     "calipso_hip_clear_structure": (_i32, [_vp]),
     "calipso_hip_set_stage_parallel": (_i32, [_vp, _i32, _i32, _pi64]),
+    "calipso_hip_set_stage_blocks": (_i32, [_vp, _i32, _pi64]),
     "calipso_hip_group_create": (_i32, [C.POINTER(_vp), _i32, C.POINTER(_vp)]),
     "calipso_hip_group_destroy": (_i32, [_vp]),
     "calipso_hip_group_newton_step": (_i32, [_vp, _i32, _pd, C.POINTER(_i32)]),

@@ -220,6 +220,7 @@ int32_t calipso_hip_destroy(H* s) {
     if (s->spS) { (void)calipso_hip_sparse_destroy(s->spS); s->spS = nullptr; }
     if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
     if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
+    calipso::blocks_release(s);
     double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
     for (double* p : dp) if (p) (void)hipFree(p);
     int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc, s->cone.wide};
@@ -331,6 +332,7 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
     if (structure_active(s) && (nm == "lagrangian_hessian" || nm == "equality_jacobian_variables" || nm == "cone_jacobian_variables")) {
         const int rc = structure_validate(s, nm == "lagrangian_hessian" ? 0 : (nm == "equality_jacobian_variables" ? 1 : 2));
         if (rc < 0) return rc;
+        blocks_pack(s, nm != "lagrangian_hessian", nm == "lagrangian_hessian");     // stage blocks (if still on): the packed copies follow the upload
     }
     SYNC();
     return CALIPSO_OK;
@@ -594,6 +596,7 @@ static int device_evaluate(H* s, const double* pt, uint32_t flags) {
     if (structure_active(s) && (flags & hess)) { const int v = structure_validate(s, 0); if (v < 0) return v; }
     if (structure_active(s) && (flags & CALIPSO_EVAL_EQUALITY_JACOBIAN) && d.ne) { const int v = structure_validate(s, 1); if (v < 0) return v; }
     if (structure_active(s) && (flags & CALIPSO_EVAL_CONE_JACOBIAN) && d.nc) { const int v = structure_validate(s, 2); if (v < 0) return v; }
+    blocks_pack(s, (flags & (CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE_JACOBIAN)) != 0, (flags & hess) != 0);
     return CALIPSO_OK;
 }
 static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t flags);

@@ -1,0 +1,415 @@
+// blocks.hip — stage blocks: packed storage and block kernels for stage-structured problems (the reference keeps such problems
+// sparse end to end: src/trajectory_optimization/sparsity.jl:28-129, indices.jl:41-180, the nz -> dense copy of src/solver/evaluate.jl:37-121).
+//
+// calipso_hip_analyze_structure finds, per row of the stacked Jacobian [gx; hx], the range of columns that can be non-zero, and the reach of
+// every column of the Lagrangian Hessian.  calipso_hip_set_stage_blocks turns that into
+//   Z blocks   maximal runs of consecutive constraint rows with the SAME column range (a dynamics constraint between stages t and t + 1: nd rows x
+//              (n_t + n_t+1) columns; the cone rows of a stage: rows x n_t columns), each stored twice, contiguously: column-major (for Z x: lanes
+//              along the rows) and row-major (for Z'u: lanes along the columns);
+//   L blocks   the diagonal blocks of Lxx (columns that no Hessian entry couples to an earlier block start a new one), both orientations;
+//   segments   the partition of the columns by all block boundaries (at most 64 wide): the tiles of the Schur complement
+// and from then on the mat-vecs of the Newton step and the Schur-complement kernel work on the packed blocks:
+//   k_bgemv_n / k_bgemv_t   one workgroup per block / per segment, every load a full 512-byte run of the packed data, no reductions across lanes
+//   k_schur_blocks          one workgroup per pair of segments that some block couples: S[a][b] = Lsym[a][b] + ep I + sum over the blocks that cover
+//                           both of B[:, a]' Omega B[:, b] on the fp64 matrix cores, the blocks in ascending order; Omega (omega_y, the nonnegative
+//                           weights, the W block of a second-order cone) is applied while the operand is staged, so WH = Omega hx is never formed
+// instead of the dense-layout kernels with predicated loads (gemv.hip, schur.hip), which spend their time on the zeros between the blocks: the
+// 128 x 128 tiles of k_schur do 14x the useful flops at BASELINE config C4's trajectory structure (41 stages of 56 variables).
+// The dense buffers stay the interchange format of the uploads (set_field, scatter, device evaluators write them as before; a pack kernel refreshes the
+// blocks on the same stream right behind every such write).  The packed values live in the slab region of Lsym (unused in this mode: the Schur kernel
+// symmetrises from the packed Hessian blocks itself), so a group addresses them like every other per-instance buffer.  Results agree with the dense
+// treatment to rounding, not bitwise (the sums run block by block): the mode is opt-in and a member of a group gets the bits of the same handle alone.
+#include <algorithm>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "internal.hpp"
+#include "device_utils.hpp"
+
+namespace calipso {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ---- pack --------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blocks_pack_z(Batch bt, const ZBlock* __restrict__ blk, int m, const double* __restrict__ Z, double* __restrict__ pk) {
+    inst_shift(bt, Z, pk);
+    const ZBlock b = blk[blockIdx.x];
+    const int total = b.nrows * b.ncols;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int i = idx % b.nrows, j = idx / b.nrows;
+        const double v = Z[(size_t)(b.row0 + i) + (size_t)(b.col0 + j) * m];
+        pk[b.off_c + idx] = v;                                 // column-major, ld = nrows
+        pk[b.off_r + (size_t)i * b.ncols + j] = v;             // row-major, ld = ncols
+    }
+}
+__global__ __launch_bounds__(256) void k_blocks_pack_l(Batch bt, const LBlock* __restrict__ blk, int nx, const double* __restrict__ L, double* __restrict__ pk) {
+    inst_shift(bt, L, pk);
+    const LBlock b = blk[blockIdx.x];
+    const int total = b.n * b.n;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int i = idx % b.n, j = idx / b.n;
+        const double v = L[(size_t)(b.c0 + i) + (size_t)(b.c0 + j) * nx];
+        pk[b.off_c + idx] = v;
+        pk[b.off_r + (size_t)i * b.n + j] = v;
+    }
+}
+
+// ---- y[rows of a block] = B x[columns of the block]: one workgroup per block, lanes along the rows, four column parts ---------------------------
+// rows [rlo, rhi) of the stacked Jacobian take part (gx only, hx only, or both); vectors indexed from row rlo
+__global__ __launch_bounds__(256) void k_bgemv_n(Batch bt, const ZBlock* __restrict__ blk, int rlo, int rhi, const double* __restrict__ pk, const double* __restrict__ x,
+                                                  double* __restrict__ y) {
+    __shared__ double part[4][64];
+    inst_shift(bt, pk, x, y);
+    const ZBlock b = blk[blockIdx.x];
+    if (b.row0 < rlo || b.row0 >= rhi) return;
+    const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < b.nrows; i0 += 64) {
+        const int i = i0 + lane;
+        double acc = 0.0;
+        if (i < b.nrows) {
+            const double* a = pk + b.off_c + i;
+            for (int j = p; j < b.ncols; j += 4) acc += a[(size_t)j * b.nrows] * x[b.col0 + j];
+        }
+        part[p][lane] = acc;
+        __syncthreads();
+        if (p == 0 && i < b.nrows) y[b.row0 - rlo + i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        __syncthreads();
+    }
+}
+// y[columns of a segment] = alpha * sum over the covering blocks (ascending) of B[:, segment]' u[rows of the block] + beta y: lanes along the columns
+template <int NV>
+__global__ __launch_bounds__(256) void k_bgemv_t(Batch bt, const Segment* __restrict__ seg, const int* __restrict__ segblk, const ZBlock* __restrict__ blk, int rlo, int rhi,
+                                                  const double* __restrict__ pk, const double* __restrict__ u1, const double* __restrict__ u2, double* __restrict__ y1,
+                                                  double* __restrict__ y2, double alpha, double beta) {
+    __shared__ double part[NV][4][64];
+    inst_shift(bt, pk, u1, y1);
+    if (NV == 2) inst_shift(bt, u2, y2);
+    const Segment sg = seg[blockIdx.x];
+    const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
+    double a1 = 0.0, a2 = 0.0;
+    if (lane < sg.nc) {
+        for (int q = 0; q < sg.count; ++q) {
+            const ZBlock b = blk[segblk[sg.first + q]];
+            if (b.row0 < rlo || b.row0 >= rhi) continue;
+            const double* a = pk + b.off_r + (sg.c0 - b.col0) + lane;
+            const double* v1 = u1 + (b.row0 - rlo);
+            const double* v2 = NV == 2 ? u2 + (b.row0 - rlo) : nullptr;
+            for (int i = p; i < b.nrows; i += 4) {
+                const double e = a[(size_t)i * b.ncols];
+                a1 += e * v1[i];
+                if (NV == 2) a2 += e * v2[i];
+            }
+        }
+    }
+    part[0][p][lane] = a1;
+    if (NV == 2) part[1][p][lane] = a2;
+    __syncthreads();
+    if (p == 0 && lane < sg.nc) {
+        const double r1 = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+        const int j = sg.c0 + lane;
+        y1[j] = beta == 0.0 ? alpha * r1 : alpha * r1 + beta * y1[j];
+        if (NV == 2) { const double r2 = (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]); y2[j] = r2; }
+    }
+}
+// y = Lxx x (trans = 0) or Lxx' x (1) over the diagonal blocks: one workgroup per block and 64 rows of it
+__global__ __launch_bounds__(256) void k_bgemv_l(Batch bt, const LBlock* __restrict__ blk, int trans, const double* __restrict__ pk, const double* __restrict__ x,
+                                                  double* __restrict__ y, double alpha, double beta) {
+    __shared__ double part[4][64];
+    inst_shift(bt, pk, x, y);
+    const LBlock b = blk[blockIdx.x];
+    const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int i = blockIdx.y * 64 + lane;
+    if ((int)blockIdx.y * 64 >= b.n) return;
+    double acc = 0.0;
+    if (i < b.n) {
+        const double* a = pk + (trans ? b.off_r : b.off_c) + i;        // row-major copy read "down the rows" = the transpose
+        for (int j = p; j < b.n; j += 4) acc += a[(size_t)j * b.n] * x[b.c0 + j];
+    }
+    part[p][lane] = acc;
+    __syncthreads();
+    if (p == 0 && i < b.n) {
+        const double r = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        y[b.c0 + i] = beta == 0.0 ? alpha * r : alpha * r + beta * y[b.c0 + i];
+    }
+}
+
+// ---- Schur complement by segment pairs ---------------------------------------------------------------------------------------------------------
+// S[a][b] (na x nb <= 64 x 64) = Lsym[a][b] + ep I + sum over the blocks covering both segments of B[:, a]' Omega B[:, b].  256 threads: wavefront w forms
+// rows 16 w .. 16 w + 15 of the tile (four 16 x 16 MFMA tiles).  Rows of a block are taken in chunks of at most SB_KC that never split a second-order
+// cone.  LDS panels are k-fastest with stride SB_KC + 2 (the conflict-free fragment layout of schur.hip / ldl.hip).
+constexpr int SB_KC = 64, SB_LD = SB_KC + 2;
+__global__ __launch_bounds__(256) void k_schur_blocks(BatchSc bt, Dims d, ConeDev cd, const SegPair* __restrict__ pairs, const int* __restrict__ pairblk, const Segment* __restrict__ seg,
+                                                       const ZBlock* __restrict__ blk, const LBlock* __restrict__ lblk, const double* __restrict__ pk, const double* __restrict__ wz,
+                                                       const double* __restrict__ Wsoc, double* __restrict__ S) {
+    __shared__ double As[64 * SB_LD];      // As[i][k] = B[k][a-column i]
+    __shared__ double Bs[64 * SB_LD];      // Bs[j][k] = (Omega B)[k][b-column j]
+    __shared__ double Rs[64 * SB_LD];      // raw rows of a second-order cone before its W block is applied
+    inst_shift(bt.b, pk, wz, Wsoc, S);
+    const Scalars sc = bt.sc[blockIdx.z];
+    const SegPair pr = pairs[blockIdx.x];
+    const Segment sa = seg[pr.a], sb = seg[pr.b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+    v4d acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < pr.count; ++q) {
+        const ZBlock b = blk[pairblk[pr.first + q]];
+        const int oa = sa.c0 - b.col0, ob = sb.c0 - b.col0;
+        for (int k0 = 0; k0 < b.nrows;) {
+            // chunk [k0, k1): at most SB_KC rows, cones whole
+            int k1 = min(b.nrows, k0 + SB_KC);
+            if (k1 < b.nrows && b.row0 + k1 >= d.ne + d.q) {
+                const int e = b.row0 + k1 - d.ne;                        // cone-local index of the first row after the chunk
+                const int j = cd.entry_soc[e];
+                if (j >= 0 && cd.soc_start[j] < e) k1 = d.ne + cd.soc_start[j] - b.row0;   // the cone that would be split goes to the next chunk
+            }
+            const int kn = k1 - k0;
+            __syncthreads();
+            for (int idx = tid; idx < 64 * SB_KC; idx += 256) {
+                const int k = idx % SB_KC, i = idx / SB_KC;
+                double va = 0.0, vb = 0.0, vr = 0.0;
+                if (k < kn) {
+                    const int row = b.row0 + k0 + k;                     // row of the stacked Jacobian
+                    if (i < sa.nc) va = pk[b.off_c + (size_t)(oa + i) * b.nrows + k0 + k];
+                    if (i < sb.nc) {
+                        const double raw = pk[b.off_c + (size_t)(ob + i) * b.nrows + k0 + k];
+                        if (row < d.ne) vb = omega_y * raw;
+                        else if (row < d.ne + d.q) vb = wz[row - d.ne] * raw;
+                        else vr = raw;                                    // a second-order cone row: W is applied below
+                    }
+                }
+                As[i * SB_LD + k] = va; Bs[i * SB_LD + k] = vb; Rs[i * SB_LD + k] = vr;
+            }
+            __syncthreads();
+            if (b.row0 + k1 > d.ne + d.q) {                              // (Omega_z B)[k][j] = sum_k' W[k][k'] B[k'][j] inside every cone of the chunk
+                for (int idx = tid; idx < 64 * SB_KC; idx += 256) {
+                    const int k = idx % SB_KC, i = idx / SB_KC;
+                    const int row = b.row0 + k0 + k;
+                    if (k < kn && i < sb.nc && row >= d.ne + d.q) {
+                        const int e = row - d.ne, j = cd.entry_soc[e];
+                        const int st = cd.soc_start[j], dim = cd.soc_dim[j];
+                        const double* W = Wsoc + cd.soc_woff[j];
+                        const int kc = d.ne + st - b.row0 - k0;          // chunk-local index of the cone's first row
+                        double s = 0.0;
+                        for (int c = 0; c < dim; ++c) s += W[(e - st) + c * dim] * Rs[i * SB_LD + kc + c];
+                        Bs[i * SB_LD + k] = s;
+                    }
+                }
+                __syncthreads();
+            }
+            for (int kk = 0; kk < (kn + 3) / 4; ++kk) {
+                const double a = As[(wave * 16 + fr) * SB_LD + 4 * kk + fk];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double bb = Bs[(t * 16 + fr) * SB_LD + 4 * kk + fk];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[t], 0, 0, 0);    // D[row i][col j]: lane holds (i = fk + 4 r, j = fr)
+                }
+            }
+            k0 = k1;
+        }
+    }
+    // epilogue: + Lsym (the Hessian as a triu-only factorisation sees it: entry (i, j) = Lxx[min][max], qdldl.jl:145-147) + ep on the diagonal
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = wave * 16 + fk + 4 * r, j = t * 16 + fr;
+            if (i < sa.nc && j < sb.nc) {
+                const int gi = sa.c0 + i, gj = sb.c0 + j;
+                double v = acc[t][r];
+                if (pr.lblock >= 0) {
+                    const LBlock lb = lblk[pr.lblock];
+                    const int li = gi - lb.c0, lj = gj - lb.c0;
+                    v += pk[lb.off_c + (size_t)min(li, lj) + (size_t)max(li, lj) * lb.n];
+                }
+                if (gi == gj) v += sc.ep;
+                S[(size_t)gi + (size_t)gj * d.NP] = v;
+            }
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------------------
+void blocks_release(calipso_hip_solver* s) {
+    StageBlocks& B = s->blocks;
+    for (void* p : {(void*)B.d_blk, (void*)B.d_lblk, (void*)B.d_seg, (void*)B.d_segblk, (void*)B.d_pairs, (void*)B.d_pairblk, (void*)B.d_colrange}) if (p) (void)hipFree(p);
+    B = StageBlocks();
+}
+
+// refresh the packed copies from the dense buffers (on the handle's stream, right behind whatever wrote them)
+void blocks_pack(calipso_hip_solver* s, bool z, bool l) {
+    StageBlocks& B = s->blocks;
+    if (!B.on) return;
+    const Batch one;                                                    // the handle itself (uploads are per handle, also for members of a group)
+    if (z && B.nblk) hipLaunchKernelGGL(k_blocks_pack_z, dim3(B.nblk), dim3(256), 0, s->stream, one, B.d_blk, s->d.m, s->Z, s->Lsym);
+    if (l && B.nlb) hipLaunchKernelGGL(k_blocks_pack_l, dim3(B.nlb), dim3(256), 0, s->stream, one, B.d_lblk, s->d.nx, s->Lxx, s->Lsym);
+}
+
+static bool blocks_usable(const calipso_hip_solver* s) { return s->blocks.on && s->blocks_effective; }
+
+bool blocks_gemv_n(calipso_hip_solver* s, int kind, const double* x, double* y, double alpha, double beta) {
+    if (!blocks_usable(s) || alpha != 1.0 || beta != 0.0) return false;
+    const StageBlocks& B = s->blocks;
+    const BatchSc bs = batch_of(s);
+    const Dims& d = s->d;
+    if (kind == SP_LXX) {
+        hipLaunchKernelGGL(k_bgemv_l, dim3(B.nlb, (B.max_lb + 63) / 64, bs.b.n), dim3(256), 0, s->stream, bs.b, B.d_lblk, 0, s->Lsym, x, y, alpha, beta);
+        return true;
+    }
+    const int rlo = kind == SP_HX ? d.ne : 0, rhi = kind == SP_GX ? d.ne : d.m;
+    if (kind != SP_Z && kind != SP_GX && kind != SP_HX) return false;
+    hipLaunchKernelGGL(k_bgemv_n, dim3(B.nblk, 1, bs.b.n), dim3(256), 0, s->stream, bs.b, B.d_blk, rlo, rhi, s->Lsym, x, y);
+    return true;
+}
+bool blocks_gemv_t(calipso_hip_solver* s, int kind, const double* u1, const double* u2, double* y1, double* y2, double alpha, double beta) {
+    if (!blocks_usable(s)) return false;
+    const StageBlocks& B = s->blocks;
+    const BatchSc bs = batch_of(s);
+    const Dims& d = s->d;
+    if (kind == SP_LXX) {
+        if (u2) return false;
+        hipLaunchKernelGGL(k_bgemv_l, dim3(B.nlb, (B.max_lb + 63) / 64, bs.b.n), dim3(256), 0, s->stream, bs.b, B.d_lblk, 1, s->Lsym, u1, y1, alpha, beta);
+        return true;
+    }
+    if (kind != SP_Z && kind != SP_GX && kind != SP_HX) return false;
+    const int rlo = kind == SP_HX ? d.ne : 0, rhi = kind == SP_GX ? d.ne : d.m;
+    if (u2) hipLaunchKernelGGL(k_bgemv_t<2>, dim3(B.nseg, 1, bs.b.n), dim3(256), 0, s->stream, bs.b, B.d_seg, B.d_segblk, B.d_blk, rlo, rhi, s->Lsym, u1, u2, y1, y2, 1.0, 0.0);
+    else hipLaunchKernelGGL(k_bgemv_t<1>, dim3(B.nseg, 1, bs.b.n), dim3(256), 0, s->stream, bs.b, B.d_seg, B.d_segblk, B.d_blk, rlo, rhi, s->Lsym, u1, (const double*)nullptr, y1, (double*)nullptr, alpha, beta);
+    return true;
+}
+bool blocks_schur(calipso_hip_solver* s) {
+    if (!blocks_usable(s)) return false;
+    const StageBlocks& B = s->blocks;
+    const BatchSc bs = batch_of(s);
+    if (!(s->stage_parallel && s->spS)) {
+        // the blocked LDL^T factors S in place: what it left between the pair tiles (fill-in) must read as zero again, and the padded rows as identity
+        // (the multifrontal path gathers S into storage of its own and needs neither)
+        for (int k = 0; k < bs.b.n; ++k) (void)hipMemsetAsync(s->S + bs.b.delta[k], 0, sizeof(double) * (size_t)s->d.NP * s->d.NP, s->stream);
+        launch_pad_identity(s);
+    }
+    hipLaunchKernelGGL(k_schur_blocks, dim3(B.npairs, 1, bs.b.n), dim3(256), 0, s->stream, bs, s->d, s->cone, B.d_pairs, B.d_pairblk, B.d_seg, B.d_blk, B.d_lblk, s->Lsym, s->wz,
+                       s->Wsoc, s->S);
+    return true;
+}
+
+}  // namespace calipso
+
+using namespace calipso;
+
+extern "C" {
+
+// After calipso_hip_analyze_structure: derive the blocks, pack the current contents of the dense buffers and route the mat-vecs and the Schur complement
+// of this handle through them (on = 0: back to the dense-layout kernels).  Refused (CALIPSO_ERR_ARGUMENT, the handle stays as it was) when the
+// structure has no blocks to speak of (fewer than two Hessian blocks) or the packed data would not fit the slab region it borrows.
+// info (may be NULL) = [Z blocks, Hessian blocks, column segments, packed doubles per instance (both orientations)].
+int32_t calipso_hip_set_stage_blocks(calipso_hip_solver* s, int32_t on, int64_t info[4]) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    CK(hipSetDevice(s->device));
+    CK(hipStreamSynchronize(s->stream));
+    blocks_release(s);
+    if (!on) { s->hessian_dirty = true; return CALIPSO_OK; }           // (Lsym was borrowed: the dense Schur kernel needs it rebuilt)
+    const Dims& d = s->d;
+    const int nx = d.nx, m = d.m, ne = d.ne;
+    if ((int)s->h_zrow.size() != 2 * m || (int)s->h_lreach.size() != nx) { s->err = "calipso_hip_set_stage_blocks: call calipso_hip_analyze_structure first"; return CALIPSO_ERR_ARGUMENT; }
+    // Hessian blocks: a new block starts at column p when no entry of columns < p reaches p or beyond
+    std::vector<LBlock> lb;
+    {
+        int start = 0, reach = -1;
+        for (int j = 0; j < nx; ++j) {
+            if (j > start && reach < j) { lb.push_back({start, j - start, 0, 0}); start = j; }
+            reach = std::max(reach, std::max(j, s->h_lreach[(size_t)j]));
+        }
+        lb.push_back({start, nx - start, 0, 0});
+    }
+    // Z blocks: runs of consecutive rows with one column range (never across the equality / cone boundary)
+    std::vector<ZBlock> zb;
+    for (int k = 0; k < m;) {
+        const int lo = s->h_zrow[2 * (size_t)k], hi = s->h_zrow[2 * (size_t)k + 1];
+        int e = k + 1;
+        while (e < m && e != ne && s->h_zrow[2 * (size_t)e] == lo && s->h_zrow[2 * (size_t)e + 1] == hi) ++e;
+        zb.push_back({k, e - k, hi > lo ? lo : 0, hi > lo ? hi - lo : 0, 0, 0});
+        k = e;
+    }
+    if (lb.size() < 2 || zb.size() > (size_t)std::max(64, m / 2)) { s->err = "calipso_hip_set_stage_blocks: no block structure to exploit (one Hessian block, or a column range per row)"; return CALIPSO_ERR_ARGUMENT; }
+    // packed offsets inside the Lsym region
+    size_t off = 0;
+    int max_lb = 0;
+    for (ZBlock& b : zb) { const size_t n = (size_t)b.nrows * b.ncols; b.off_c = (long long)off; b.off_r = (long long)(off + n); off += 2 * n; }
+    for (LBlock& b : lb) { const size_t n = (size_t)b.n * b.n; b.off_c = (long long)off; b.off_r = (long long)(off + n); off += 2 * n; max_lb = std::max(max_lb, b.n); }
+    if (off > (size_t)nx * nx) { s->err = "calipso_hip_set_stage_blocks: the packed blocks exceed the slab region they borrow"; return CALIPSO_ERR_ARGUMENT; }
+    // segments: every block boundary, at most 64 columns each
+    std::vector<int> cut = {0, nx};
+    for (const ZBlock& b : zb) if (b.ncols) { cut.push_back(b.col0); cut.push_back(b.col0 + b.ncols); }
+    for (const LBlock& b : lb) { cut.push_back(b.c0); cut.push_back(b.c0 + b.n); }
+    std::sort(cut.begin(), cut.end());
+    cut.erase(std::unique(cut.begin(), cut.end()), cut.end());
+    std::vector<Segment> seg;
+    for (size_t c = 0; c + 1 < cut.size(); ++c)
+        for (int a = cut[c]; a < cut[c + 1]; a += 64) seg.push_back({a, std::min(64, cut[c + 1] - a), 0, 0});
+    std::vector<int> segblk;
+    std::vector<int> seg_of_col((size_t)nx, 0);
+    for (size_t g = 0; g < seg.size(); ++g) {
+        for (int c = seg[g].c0; c < seg[g].c0 + seg[g].nc; ++c) seg_of_col[(size_t)c] = (int)g;
+        seg[g].first = (int)segblk.size();
+        for (size_t q = 0; q < zb.size(); ++q) if (zb[q].ncols && zb[q].col0 <= seg[g].c0 && seg[g].c0 + seg[g].nc <= zb[q].col0 + zb[q].ncols) segblk.push_back((int)q);
+        seg[g].count = (int)segblk.size() - seg[g].first;
+    }
+    // pairs of segments (a >= b) that a Z block or a Hessian block couples
+    std::map<std::pair<int, int>, std::pair<std::vector<int>, int>> pm;
+    for (size_t q = 0; q < zb.size(); ++q) {
+        if (!zb[q].ncols) continue;
+        const int g0 = seg_of_col[(size_t)zb[q].col0], g1 = seg_of_col[(size_t)(zb[q].col0 + zb[q].ncols - 1)];
+        for (int a = g0; a <= g1; ++a) for (int b2 = g0; b2 <= a; ++b2) { auto& e = pm[{a, b2}]; if (e.first.empty() && e.second == 0) e.second = -1; e.first.push_back((int)q); }
+    }
+    for (size_t q = 0; q < lb.size(); ++q) {
+        const int g0 = seg_of_col[(size_t)lb[q].c0], g1 = seg_of_col[(size_t)(lb[q].c0 + lb[q].n - 1)];
+        for (int a = g0; a <= g1; ++a) for (int b2 = g0; b2 <= a; ++b2) { auto it = pm.find({a, b2}); if (it == pm.end()) pm[{a, b2}] = {{}, (int)q}; else it->second.second = (int)q; }
+    }
+    std::vector<SegPair> pairs;
+    std::vector<int> pairblk;
+    for (auto& kv : pm) {
+        SegPair p{kv.first.first, kv.first.second, (int)pairblk.size(), (int)kv.second.first.size(), kv.second.second};
+        pairblk.insert(pairblk.end(), kv.second.first.begin(), kv.second.first.end());
+        pairs.push_back(p);
+    }
+    StageBlocks& B = s->blocks;
+    auto up = [&](auto& vec, auto** dptr) -> hipError_t {
+        typedef typename std::remove_reference<decltype(vec)>::type V;
+        typedef typename V::value_type T;
+        hipError_t e = hipMalloc((void**)dptr, sizeof(T) * std::max<size_t>(vec.size(), 1));
+        if (e == hipSuccess && !vec.empty()) e = hipMemcpy(*dptr, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(zb, &B.d_blk);
+    if (e == hipSuccess) e = up(lb, &B.d_lblk);
+    if (e == hipSuccess) e = up(seg, &B.d_seg);
+    if (e == hipSuccess) e = up(segblk, &B.d_segblk);
+    if (e == hipSuccess) e = up(pairs, &B.d_pairs);
+    if (e == hipSuccess) e = up(pairblk, &B.d_pairblk);
+    std::vector<int> colrange(2 * (size_t)nx);
+    for (const LBlock& b : lb) for (int c = b.c0; c < b.c0 + b.n; ++c) { colrange[2 * (size_t)c] = b.c0; colrange[2 * (size_t)c + 1] = b.c0 + b.n; }
+    if (e == hipSuccess) e = up(colrange, &B.d_colrange);
+    if (e != hipSuccess) { blocks_release(s); s->hessian_dirty = true; return calipso::check(s, e, "calipso_hip_set_stage_blocks"); }
+    B.nblk = (int)zb.size(); B.nlb = (int)lb.size(); B.nseg = (int)seg.size(); B.npairs = (int)pairs.size(); B.max_lb = max_lb; B.packed = off;
+    // structure signature: members of a group must share it for the group's launches to use the blocks
+    {
+        unsigned long long h = 1469598103934665603ULL;
+        auto mix = [&](long long v) { h ^= (unsigned long long)v; h *= 1099511628211ULL; };
+        for (const ZBlock& b : zb) { mix(b.row0); mix(b.nrows); mix(b.col0); mix(b.ncols); }
+        for (const LBlock& b : lb) { mix(b.c0); mix(b.n); }
+        B.signature = h;
+    }
+    B.on = true;
+    CK(hipMemsetAsync(s->S, 0, sizeof(double) * (size_t)d.NP * d.NP, s->stream));     // what no pair covers must read as zero
+    launch_pad_identity(s);
+    blocks_pack(s, true, true);
+    CK(hipStreamSynchronize(s->stream));
+    if (info) { info[0] = B.nblk; info[1] = B.nlb; info[2] = B.nseg; info[3] = (int64_t)off; }
+    return CALIPSO_OK;
+}
+
+}  // extern "C"

@@ -114,7 +114,17 @@ static void g_effective_band(G* g) {
     g->saved_band = s->band64; g->saved_hb = s->half_bandwidth;
     s->band64 = dense ? 0 : band; s->half_bandwidth = dense ? 0 : hb;
 }
-static void g_restore_band(G* g) { g->base->band64 = g->saved_band; g->base->half_bandwidth = g->saved_hb; }
+static void g_restore_band(G* g) { g->base->band64 = g->saved_band; g->base->half_bandwidth = g->saved_hb; g->base->blocks_effective = true; }
+// stage blocks (blocks.hip): the group's launches walk the block tables of the base handle, so either every member uses blocks of the same structure
+// or none does.  A mixed group is an error (the slab region of Lsym means different things on its members).
+static int g_effective_blocks(G* g) {
+    H* s = g->base;
+    bool any = false, all = true;
+    for (H* h : g->hs) { any = any || h->blocks.on; all = all && h->blocks.on && h->blocks.signature == s->blocks.signature; }
+    if (any && !all) { s->err = "the members of a group must agree on calipso_hip_set_stage_blocks (all on with one block structure, or all off)"; return CALIPSO_ERR_ARGUMENT; }
+    s->blocks_effective = true;
+    return CALIPSO_OK;
+}
 
 // factorize! + compute_inertia! for the members of `a`
 static int gb_factorize(G* g, const Set& a, std::vector<std::array<int64_t, 3>>& in) {
@@ -502,6 +512,7 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
         all.push_back((int)i);
     }
     g_effective_band(g);
+    { const int brc = g_effective_blocks(g); if (brc < 0) { g_restore_band(g); return brc; } }
     struct Finally { G* g; ~Finally() { g->base->cur = nullptr; g_restore_band(g); } } fin{g};
     {   // Lsym of the members whose Hessian changed
         Set dirty;
@@ -576,6 +587,7 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
         all.push_back((int)i);
     }
     g_effective_band(g);
+    { const int brc = g_effective_blocks(g); if (brc < 0) { g_restore_band(g); return brc; } }
     struct Finally { G* g; ~Finally() { g->base->cur = nullptr; g_restore_band(g); } } fin{g};
     {
         Set dirty;

@@ -100,6 +100,21 @@ struct ConeDev {
     int* wide = nullptr;        // [n_wide] ids of the cones of dimension > 4 (soc_wide.hip: one wavefront per cone)
 };
 
+// Stage blocks (blocks.hip): packed copies of the blocks of [gx; hx] and Lxx of a stage-structured problem, and the tables the block kernels walk.
+// Offsets are in doubles from the start of the slab region of Lsym (unused in this mode), the same for every handle of one structure.
+struct ZBlock { int row0, nrows, col0, ncols; long long off_c, off_r; };   // rows [row0, row0 + nrows) x columns [col0, col0 + ncols): column-major (ld nrows) and row-major (ld ncols) copies
+struct LBlock { int c0, n; long long off_c, off_r; };                      // diagonal block of Lxx
+struct Segment { int c0, nc, first, count; };                              // <= 64 columns; covering Z blocks: segblk[first .. first + count), ascending
+struct SegPair { int a, b, first, count, lblock; };                        // tile (segment a >= segment b) of S: the Z blocks covering both, the Hessian block containing both (-1: none)
+struct StageBlocks {
+    bool on = false;
+    int nblk = 0, nlb = 0, nseg = 0, npairs = 0, max_lb = 0;
+    size_t packed = 0;                  // doubles per instance
+    unsigned long long signature = 0;   // of the block structure (members of a group must share it)
+    ZBlock* d_blk = nullptr; LBlock* d_lblk = nullptr; Segment* d_seg = nullptr; int* d_segblk = nullptr; SegPair* d_pairs = nullptr; int* d_pairblk = nullptr;
+    int* d_colrange = nullptr;          // per column of Lxx: [first, last + 1) row of its Hessian block (uploads are re-checked against it)
+};
+
 struct QpEval {
     bool attached = false;
     double scale = 0.5;
@@ -177,6 +192,9 @@ struct calipso_hip_solver {
     // stage-parallel factorisation of S (calipso_hip_set_stage_parallel): the skyline pattern of S found by the structure analysis, a multifrontal
     // sparse LDL^T over its nested-dissection tree (sparse.hip) instead of the blocked LDL^T of ldl.hip, for this handle or the group it leads
     std::vector<int> h_reach;                 // per column j of S: last row that can be non-zero (analysis)
+    std::vector<int> h_zrow, h_lreach;        // analysis, host copies: per row of [gx; hx] its [first, last + 1) column; per column of Lxx the last row its entries reach
+    calipso::StageBlocks blocks;              // calipso_hip_set_stage_blocks (blocks.hip)
+    bool blocks_effective = true;             // false while a group launch covers members whose block structures differ
     calipso_hip_sparse* spS = nullptr;
     long long* spS_src = nullptr;             // device: offset (row + col * NP) in S of every pattern entry
     int* d_reach = nullptr;                   // device copy of h_reach while the stage-parallel factorisation is on: uploads are re-checked against the skyline
@@ -263,6 +281,13 @@ void launch_symmetrize(calipso_hip_solver* s);          // Lsym from the upper t
 void schur_plan(calipso_hip_solver* s);   // host: choose the tile shape of single-instance launches
 // ldl.hip
 void launch_pad_identity(calipso_hip_solver* s);
+// blocks.hip: stage blocks.  The blocks_* launchers return false when the handle (or the group launch in progress) does not use blocks: the caller
+// then takes the dense-layout kernel.
+void blocks_release(calipso_hip_solver* s);
+void blocks_pack(calipso_hip_solver* s, bool z, bool l);
+bool blocks_gemv_n(calipso_hip_solver* s, int kind, const double* x, double* y, double alpha, double beta);
+bool blocks_gemv_t(calipso_hip_solver* s, int kind, const double* u1, const double* u2, double* y1, double* y2, double alpha, double beta);
+bool blocks_schur(calipso_hip_solver* s);
 void launch_ldl(calipso_hip_solver* s);
 void ldl_drop_graphs(calipso_hip_solver* s);
 void launch_trsv(calipso_hip_solver* s, double* x);            // x (length NP) <- S^-1 x using L, D
@@ -292,7 +317,7 @@ void ldlsolver_release(calipso_hip_solver* s);
 // structure.hip
 int structure_validate(calipso_hip_solver* s, int which);
 bool csc_pattern_ok(i64 n, const i64* colptr, const i64* rowval);   // ordering.hip: colptr[0] == 1, monotone, nnz < 2^31, rows in 1..n
-inline bool structure_active(const calipso_hip_solver* s) { return s->band64 > 0 || s->stage_parallel; }   // an analysed pattern that uploads must respect      // which: 0 Lxx, 1 gx, 2 hx; clears the structure when the block breaks it
+inline bool structure_active(const calipso_hip_solver* s) { return s->band64 > 0 || s->stage_parallel || s->blocks.on; }   // an analysed pattern that uploads must respect      // which: 0 Lxx, 1 gx, 2 hx; clears the structure when the block breaks it
 // qp.hip
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 

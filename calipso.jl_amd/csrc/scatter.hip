@@ -119,6 +119,7 @@ int32_t calipso_hip_scatter_field(calipso_hip_solver* s, const char* field, cons
     CK(hipMemcpyAsync(pat.vals, values, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(k_scatter_assign, dim3((unsigned)((pat.winners + 255) / 256)), dim3(256), 0, s->stream, pat.winners, pat.src, pat.dst, pat.vals, s->Z);
     if (structure_active(s)) { const int rc = structure_validate(s, f == "equality_jacobian_variables" ? 1 : 2); if (rc < 0) return rc; }
+    blocks_pack(s, true, false);
     SYNC();      // `values` may be reused by the caller
     return CALIPSO_OK;
 }
@@ -150,6 +151,7 @@ int32_t calipso_hip_scatter_hessian(calipso_hip_solver* s, const double* objecti
     }
     s->hessian_dirty = true;
     if (structure_active(s)) { const int rc = structure_validate(s, 0); if (rc < 0) return rc; }
+    blocks_pack(s, false, true);
     SYNC();
     return CALIPSO_OK;
 }

@@ -169,6 +169,7 @@ __global__ void k_scale_rows(Batch bt, Dims d, ConeDev cd, const double* __restr
 
 void launch_scale_rows(calipso_hip_solver* s) {
     if (s->d.nc == 0) return;
+    if (s->blocks.on && s->blocks_effective) return;      // stage blocks: Omega is applied while k_schur_blocks stages its operand, WH is not formed
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, (s->d.nx + SCALE_COLS - 1) / SCALE_COLS, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH, s->band64 > 0 ? s->zrow : nullptr);
 }
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(256) void k_symmetrize_upper(Batch bt, int nx, cons
 }
 
 void launch_symmetrize(calipso_hip_solver* s) {
+    if (s->blocks.on) return;             // stage blocks: the slab region of Lsym holds the packed blocks; k_schur_blocks mirrors the upper triangle itself
     const int nt = (s->d.nx + 31) / 32;
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_symmetrize_upper, dim3(nt, nt, B.b.n), dim3(32, 8), 0, s->stream, B.b, s->d.nx, s->Lxx, s->Lsym);
@@ -505,6 +507,7 @@ void launch_pad_identity(calipso_hip_solver* s) {
 void launch_schur(calipso_hip_solver* s) {
     static std::once_flag attr;      // (several host lanes launch concurrently: one of them sets the attribute, the others wait for it)
     std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_LDS_BYTES); });
+    if (blocks_schur(s)) return;          // stage blocks: S by segment pairs from the packed blocks (blocks.hip)
     if (s->hessian_dirty && !s->cur) { launch_symmetrize(s); s->hessian_dirty = false; }   // (a group refreshes its members itself)
     const BatchSc B = batch_of(s);
     const int hb = s->band64 > 0 ? s->half_bandwidth : 0;       // > 0: only the tiles inside the band (structure.hip)

@@ -42,9 +42,19 @@ __global__ void k_check_reach(int nx, const int* __restrict__ reach, const doubl
     if (hi > reach[lo] && L[idx] != 0.0) atomicOr(flag, 1);
 }
 
+// stage blocks: entry (i, j) of the Hessian must lie inside the diagonal block of column j
+__global__ void k_check_colrange(int nx, const int* __restrict__ range, const double* __restrict__ L, int* __restrict__ flag) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)nx * nx) return;
+    const int i = (int)(idx % nx), j = (int)(idx / nx);
+    if ((i < range[2 * j] || i >= range[2 * j + 1]) && L[idx] != 0.0) atomicOr(flag, 1);
+}
+
 static int structure_clear(calipso_hip_solver* s) {
     s->band64 = 0; s->half_bandwidth = 0;
     s->stage_parallel = false; s->h_reach.clear();
+    if (s->blocks.on) { blocks_release(s); s->hessian_dirty = true; }      // (the dense Schur kernel needs Lsym, which the blocks had borrowed, rebuilt)
+    s->h_zrow.clear(); s->h_lreach.clear();
     const Dims& d = s->d;
     const size_t G = ((size_t)d.nx + 15) / 16;
     std::vector<int> kr(4 * G);
@@ -65,6 +75,7 @@ int structure_validate(calipso_hip_solver* s, int which) {
         const size_t n = (size_t)d.nx * d.nx;
         if (s->band64 > 0) hipLaunchKernelGGL(k_check_band, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d.nx, s->half_bandwidth, s->Lxx, flag);
         // the multifrontal factorisation gathers S through the skyline only (finer than the band, and in force even when the band covers everything)
+        if (s->blocks.on && s->blocks.d_colrange) hipLaunchKernelGGL(k_check_colrange, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d.nx, s->blocks.d_colrange, s->Lxx, flag);
         if (s->stage_parallel && s->d_reach) hipLaunchKernelGGL(k_check_reach, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d.nx, s->d_reach, s->Lxx, flag);
     } else {
         const int rows = which == 1 ? d.ne : d.nc, row0 = which == 1 ? 0 : d.ne;
@@ -93,6 +104,7 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
     CK(hipSetDevice(s->device));
     CK(hipStreamSynchronize(s->stream));
     s->stage_parallel = false;             // a new analysis: the multifrontal plan of an earlier pattern no longer applies (calipso_hip_set_stage_parallel again)
+    if (s->blocks.on) { blocks_release(s); s->hessian_dirty = true; }      // ... nor do the stage blocks (calipso_hip_set_stage_blocks again)
     std::vector<double> L((size_t)nx * nx), Z((size_t)std::max(1, m) * nx);
     CK(hipMemcpy(L.data(), s->Lxx, sizeof(double) * L.size(), hipMemcpyDeviceToHost));
     if (m) CK(hipMemcpy(Z.data(), s->Z, sizeof(double) * (size_t)m * nx, hipMemcpyDeviceToHost));
@@ -122,6 +134,7 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
         for (int j = 0; j < nx; ++j)
             for (int i = 0; i < nx; ++i)
                 if (L[i + (size_t)j * nx] != 0.0) { const int lo = std::min(i, j), hi = std::max(i, j); reach[(size_t)lo] = std::max(reach[(size_t)lo], hi); }
+        s->h_lreach = reach;                                   // the Hessian alone: its diagonal blocks (calipso_hip_set_stage_blocks)
         std::vector<int> ext((size_t)nx, -1);                 // furthest range end among the ranges STARTING at a column
         for (int k = 0; k < m; ++k) if (cmax[k] >= cmin[k]) ext[(size_t)cmin[k]] = std::max(ext[(size_t)cmin[k]], cmax[k]);
         int run = -1;                                         // furthest end among the ranges that started at or before j
@@ -149,7 +162,8 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
         std::vector<int> zr(2 * (size_t)m);
         for (int k = 0; k < m; ++k) { zr[2 * k] = cmax[k] >= cmin[k] ? cmin[k] : 0; zr[2 * k + 1] = cmax[k] >= cmin[k] ? cmax[k] + 1 : 0; }
         CK(hipMemcpy(s->zrow, zr.data(), sizeof(int) * zr.size(), hipMemcpyHostToDevice));
-    }
+        s->h_zrow = zr;
+    } else s->h_zrow.clear();
     s->half_bandwidth = (int)hb;
     s->band64 = band64 >= nblk - 1 ? 0 : std::max(1, band64);  // 0: nothing to skip
     // entries of S outside the band are never written in banded mode and must read as zero (the block inverses span whole

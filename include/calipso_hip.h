@@ -278,6 +278,14 @@ int32_t calipso_hip_clear_structure(calipso_hip_solver*);
  * info (may be NULL) = [tree levels, rows of the largest front, nnz(triu) of the pattern of S, 2].  on = 0 switches back.  Fails (and keeps the
  * blocked factorisation) when a front would exceed one CU's LDS (196 rows). */
 int32_t calipso_hip_set_stage_parallel(calipso_hip_solver*, int32_t on, int32_t batch, int64_t info[4]);
+/* Stage blocks (after calipso_hip_analyze_structure; SURVEY.md 8(f1): the reference keeps stage-structured problems sparse end to end,
+ * src/trajectory_optimization/sparsity.jl:28-129, src/solver/evaluate.jl:37-121): the runs of constraint rows with one column range and the diagonal
+ * blocks of the Lagrangian Hessian are packed contiguously and the mat-vecs of the Newton step and the Schur-complement kernel work on the packed
+ * blocks (one workgroup per block / per pair of column segments) instead of the dense-layout kernels.  The dense buffers stay the interchange format of
+ * the uploads; a pack kernel follows every upload on the handle's stream.  Results agree with the dense treatment to rounding (not bitwise).  on = 0
+ * switches back.  Refused when the structure has fewer than two Hessian blocks.  Members of a group must agree (all on with one structure, or all off).
+ * info (may be NULL) = [Z blocks, Hessian blocks, column segments, packed doubles per instance]. */
+int32_t calipso_hip_set_stage_blocks(calipso_hip_solver*, int32_t on, int64_t info[4]);
 
 /* ---- LinearSolver seam (src/solver/linear_solver.jl:1-60) ----------------------------------------------------------------------
  * A stand-alone device LDL^T for ANY sparse symmetric quasi-definite matrix the caller assembled itself, so that the reference's own
