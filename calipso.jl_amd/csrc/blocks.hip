@@ -139,10 +139,12 @@ __global__ __launch_bounds__(256) void k_bgemv_l(Batch bt, const LBlock* __restr
 // S[a][b] (na x nb <= 64 x 64) = Lsym[a][b] + ep I + sum over the blocks covering both segments of B[:, a]' Omega B[:, b].  256 threads: wavefront w forms
 // rows 16 w .. 16 w + 15 of the tile (four 16 x 16 MFMA tiles).  Rows of a block are taken in chunks of at most SB_KC that never split a second-order
 // cone.  LDS panels are k-fastest with stride SB_KC + 2 (the conflict-free fragment layout of schur.hip / ldl.hip).
-constexpr int SB_KC = 64, SB_LD = SB_KC + 2;
+// SB_KC = 32 (3 panels x 64 x 34 doubles = 51 KB of LDS: three workgroups per CU) unless a cone is wider than that (then 64: one workgroup per CU)
+template <int SB_KC>
 __global__ __launch_bounds__(256) void k_schur_blocks(BatchSc bt, Dims d, ConeDev cd, const SegPair* __restrict__ pairs, const int* __restrict__ pairblk, const Segment* __restrict__ seg,
                                                        const ZBlock* __restrict__ blk, const LBlock* __restrict__ lblk, const double* __restrict__ pk, const double* __restrict__ wz,
                                                        const double* __restrict__ Wsoc, double* __restrict__ S) {
+    constexpr int SB_LD = SB_KC + 2;
     __shared__ double As[64 * SB_LD];      // As[i][k] = B[k][a-column i]
     __shared__ double Bs[64 * SB_LD];      // Bs[j][k] = (Omega B)[k][b-column j]
     __shared__ double Rs[64 * SB_LD];      // raw rows of a second-order cone before its W block is applied
@@ -291,8 +293,10 @@ bool blocks_schur(calipso_hip_solver* s) {
         for (int k = 0; k < bs.b.n; ++k) (void)hipMemsetAsync(s->S + bs.b.delta[k], 0, sizeof(double) * (size_t)s->d.NP * s->d.NP, s->stream);
         launch_pad_identity(s);
     }
-    hipLaunchKernelGGL(k_schur_blocks, dim3(B.npairs, 1, bs.b.n), dim3(256), 0, s->stream, bs, s->d, s->cone, B.d_pairs, B.d_pairblk, B.d_seg, B.d_blk, B.d_lblk, s->Lsym, s->wz,
-                       s->Wsoc, s->S);
+    if (s->d.max_dim <= 32) hipLaunchKernelGGL(k_schur_blocks<32>, dim3(B.npairs, 1, bs.b.n), dim3(256), 0, s->stream, bs, s->d, s->cone, B.d_pairs, B.d_pairblk, B.d_seg, B.d_blk, B.d_lblk,
+                                               s->Lsym, s->wz, s->Wsoc, s->S);
+    else hipLaunchKernelGGL(k_schur_blocks<64>, dim3(B.npairs, 1, bs.b.n), dim3(256), 0, s->stream, bs, s->d, s->cone, B.d_pairs, B.d_pairblk, B.d_seg, B.d_blk, B.d_lblk, s->Lsym, s->wz,
+                            s->Wsoc, s->S);
     return true;
 }
 
