@@ -375,6 +375,21 @@ function analyze_structure!(hs::HIPSolver)
     return Tuple(out)
 end
 clear_structure!(hs::HIPSolver) = check(hs.handle, ccall((:calipso_hip_clear_structure, lib), Int32, (Ptr{Cvoid},), hs.handle), "clear_structure!")
+# calipso_hip_set_stage_blocks (after analyze_structure!): packed blocks of [gx; hx] / the Lagrangian Hessian, block mat-vecs, Schur complement by
+# segment pairs (csrc/blocks.hip).  Returns (z_blocks, hessian_blocks, segments, packed_doubles).
+function set_stage_blocks!(hs::HIPSolver, on::Bool=true)
+    out = zeros(Int64, 4)
+    check(hs.handle, ccall((:calipso_hip_set_stage_blocks, lib), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}), hs.handle, on ? 1 : 0, out), "set_stage_blocks!")
+    return (z_blocks = out[1], hessian_blocks = out[2], segments = out[3], packed_doubles = out[4])
+end
+
+# calipso_hip_kernel_times: [1] ms of the panel-step launches of the last LDL^T of S, [2] their number, [3] NP, [4] bytes of the device slab
+function kernel_times(hs::HIPSolver)
+    out = zeros(Float64, 8)
+    ccall((:calipso_hip_kernel_times, lib), Int32, (Ptr{Cvoid}, Ptr{Float64}), hs.handle, out)
+    return out
+end
+
 "After `analyze_structure!`: factor the Schur complement by the multifrontal sparse LDL' over a nested dissection of its pattern (log2(stages) launches instead of the chain of nx pivots); `batch` >= the largest group this solver leads. Returns (tree levels, largest front, nnz of the pattern, 2)."
 function set_stage_parallel!(hs::HIPSolver, on::Bool=true; batch::Integer=1)
     out = zeros(Int64, 4)
@@ -460,6 +475,6 @@ function allreduce_sum!(c::HIPComm, v::Vector{Float64})
 end
 
 export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPComm, comm_unique_id, gather_status, allreduce_sum!, newton_step!,
-       search_direction_nonsymmetric!, analyze_structure!, clear_structure!, set_stage_parallel!, sync_scalars!, copy_back!
+       search_direction_nonsymmetric!, analyze_structure!, clear_structure!, set_stage_parallel!, set_stage_blocks!, kernel_times, sync_scalars!, copy_back!
 
 end # module
