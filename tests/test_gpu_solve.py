@@ -198,3 +198,27 @@ def test_pendulum_c2_with_the_stage_parallel_factorisation(oracle_mod):
     o, st = run_oracle(oracle_mod, prob)
     assert st == 1 and np.abs(x - o.point()["x"]).max() < 1e-3
     assert abs(s.stats()["total_iterations"] - o.stats()["total_iterations"]) <= 2
+
+
+def test_pendulum_c2_with_stage_blocks(oracle_mod):
+    """C2 once more, host-callback evaluated (every evaluate! uploads the dense blocks: the pack kernels of csrc/blocks.hip follow each upload), with the
+    stage blocks on top of the stage-parallel factorisation: a REAL trajectory problem (3 x 3 stages of state + action, dynamics rows over two stages) through
+    the block mat-vecs and the Schur complement by segment pairs.  An iterate whose pattern leaves the blocks puts the handle back on the dense treatment;
+    either way the solve ends at the reference's solution with the reference's criteria."""
+    pkg = load_pkg()
+    prob = pr.pendulum(action_guess=np.zeros(10))
+    s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, parameters=prob.parameters, nonnegative_indices=prob.nonnegative_indices,
+                   second_order_indices=prob.second_order_indices)
+    pkg.initialize_b(s, prob.x0)
+    s.evaluate(pr.ALL_VARIABLE_FLAGS, 0)
+    s.analyze_structure()
+    s.set_stage_parallel(True)
+    info = s.set_stage_blocks(True)
+    assert info["hessian_blocks"] >= 2 and info["z_blocks"] >= 2
+    assert pkg.solve_b(s)
+    criteria(s)
+    x = s.solution.variables
+    assert np.abs(x[-2:] - np.array([np.pi, 0.0])).max() < 1e-3 and np.abs(x[:2]).max() < 1e-3
+    o, st = run_oracle(oracle_mod, prob)
+    assert st == 1 and np.abs(x - o.point()["x"]).max() < 1e-3
+    assert abs(s.stats()["total_iterations"] - o.stats()["total_iterations"]) <= 2

@@ -196,18 +196,21 @@ def test_whole_solve_with_the_three_treatments():
     pkg = load_pkg()
     shape = (16, 24, 16, 3, 1, 3)
     sols, stats = [], []
-    for mode in ("dense", "banded", "stage_parallel"):
+    for mode in ("dense", "banded", "stage_parallel", "stage_blocks"):
         prob, s = build(pkg, 21, *shape)
         if mode != "dense":
             s.analyze_structure()
-        if mode == "stage_parallel":
+        if mode in ("stage_parallel", "stage_blocks"):
             s.set_stage_parallel(True)
+        if mode == "stage_blocks":              # packed blocks, block mat-vecs, Schur complement by segment pairs (csrc/blocks.hip)
+            assert s.set_stage_blocks(True)["hessian_blocks"] == shape[0]
         assert pkg.solve_b(s)
         st = s.stats()
         sols.append(s.solution.all.copy()); stats.append((st["total_iterations"], st["outer"]))
-    assert stats[0] == stats[1] == stats[2], stats
+    assert stats[0] == stats[1] == stats[2] == stats[3], stats
     assert np.array_equal(sols[0], sols[1])
     assert np.abs(sols[2] - sols[0]).max() <= 1e-7 * max(1.0, np.abs(sols[0]).max())
+    assert np.abs(sols[3] - sols[0]).max() <= 1e-7 * max(1.0, np.abs(sols[0]).max())
 
 
 def test_stage_parallel_upload_outside_the_skyline_is_caught_even_without_a_band():
