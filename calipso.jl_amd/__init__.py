@@ -79,7 +79,9 @@ class Solver:
     evaluate(flags, x, y, z, theta, out) writing the requested ProblemData fields through out(name)."""
 
     def __init__(self, methods, num_variables, num_parameters, num_equality, num_cone, parameters=None,
-                 nonnegative_indices=None, second_order_indices=None, options=None, device=0):
+                 nonnegative_indices=None, second_order_indices=None, options=None, device=0, structure=None):
+        """structure = dict(row_first, row_last, hessian_block_start) (1-based) makes a STRUCTURED handle (calipso_hip_create_structured): only the
+        stage blocks live on the device"""
         L = lib()
         self._L = L
         nx, npar, ne, nc = int(num_variables), int(num_parameters), int(num_equality), int(num_cone)
@@ -95,7 +97,15 @@ class Solver:
             ptr[k + 1] = len(flat)
         flat = np.asarray(flat, dtype=np.int64)
         h = C.c_void_p()
-        rc = L.calipso_hip_create(nx, npar, ne, nc, len(nn), _pi(nn), len(second_order_indices), _pi(ptr), _pi(flat), device, C.byref(h))
+        self.structure = structure
+        if structure is not None:
+            rf = np.ascontiguousarray(structure["row_first"], dtype=np.int64); rl = np.ascontiguousarray(structure["row_last"], dtype=np.int64)
+            hb = np.ascontiguousarray(structure["hessian_block_start"], dtype=np.int64)
+            assert rf.size == ne + nc and rl.size == ne + nc
+            rc = L.calipso_hip_create_structured(nx, npar, ne, nc, len(nn), _pi(nn), len(second_order_indices), _pi(ptr), _pi(flat), device, _pi(rf), _pi(rl),
+                                                 hb.size, _pi(hb), C.byref(h))
+        else:
+            rc = L.calipso_hip_create(nx, npar, ne, nc, len(nn), _pi(nn), len(second_order_indices), _pi(ptr), _pi(flat), device, C.byref(h))
         if rc != 0:
             msg = L.calipso_hip_last_error(h if h.value else None).decode()
             if h.value:

@@ -19,6 +19,7 @@ _vp, _i32, _i64, _u32, _u64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
 _pd, _pi64, _pi32 = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
 SYMBOLS = {
     "calipso_hip_create": (_i32, [_i64, _i64, _i64, _i64, _i64, _pi64, _i64, _pi64, _pi64, _i32, C.POINTER(_vp)]),
+    "calipso_hip_create_structured": (_i32, [_i64, _i64, _i64, _i64, _i64, _pi64, _i64, _pi64, _pi64, _i32, _pi64, _pi64, _i64, _pi64, C.POINTER(_vp)]),
     "calipso_hip_destroy": (_i32, [_vp]),
     "calipso_hip_last_error": (C.c_char_p, [_vp]),
     "calipso_hip_version": (C.c_char_p, []),

@@ -52,8 +52,11 @@ int32_t calipso_hip_device_count(void) {
 
 const char* calipso_hip_last_error(H* s) { return s ? s->err.c_str() : g_create_err.c_str(); }
 
-int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx, int64_t n_soc,
-                           const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device, H** out) {
+// the declared structure of a structured handle (calipso_hip_create_structured): 1-based, as the caller's sparsity lists are
+struct StructureSpec { const int64_t* row_first; const int64_t* row_last; int64_t n_blocks; const int64_t* block_start; };
+
+static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx, int64_t n_soc,
+                           const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device, const StructureSpec* spec, H** out) {
     if (!out) return CALIPSO_ERR_ARGUMENT;
     *out = nullptr;
     if (nx < 1 || np < 0 || ne < 0 || nc < 0 || n_nonneg < 0 || n_soc < 0) { g_create_err = "negative or empty dimension"; return CALIPSO_ERR_ARGUMENT; }
@@ -112,13 +115,47 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     for (auto& e : s->ev) CK(hipEventCreate(&e));
     const size_t NX = d.nx, NE = d.ne, NC = d.nc, N = d.N, NPd = d.NP, M = d.m, n = d.n;
     int rc = 0;
+    // Structured handle: the block tables come first (host work only), because the slab is sized from them — no dense Lxx / [gx; hx] / S / Tinv exist
+    calipso::BlockPlan plan;
+    if (spec) {
+        std::vector<int> zr(2 * (size_t)d.m, 0), lr((size_t)d.nx, 0);
+        for (int k = 0; k < d.m; ++k) {
+            const int64_t f = spec->row_first[k], l = spec->row_last[k];
+            if (l >= f && (f < 1 || l > nx)) { s->err = "calipso_hip_create_structured: column range of a constraint row outside 1..nx"; return CALIPSO_ERR_ARGUMENT; }
+            zr[2 * (size_t)k] = l >= f ? (int)(f - 1) : 0; zr[2 * (size_t)k + 1] = l >= f ? (int)l : 0;
+        }
+        for (int j = 0; j < d.n_soc; ++j) {          // the rows of a second-order cone are coupled through its weight block: they share the union of their ranges
+            const int st = d.ne + s->h_soc_start[j], dim = s->h_soc_dim[j];
+            int lo = d.nx, hi = 0;
+            for (int k = st; k < st + dim; ++k) if (zr[2 * (size_t)k + 1] > zr[2 * (size_t)k]) { lo = std::min(lo, zr[2 * (size_t)k]); hi = std::max(hi, zr[2 * (size_t)k + 1]); }
+            for (int k = st; k < st + dim; ++k) { zr[2 * (size_t)k] = hi > lo ? lo : 0; zr[2 * (size_t)k + 1] = hi > lo ? hi : 0; }
+        }
+        if (spec->n_blocks < 1 || spec->block_start[0] != 1) { s->err = "calipso_hip_create_structured: hessian_block_start must begin with 1"; return CALIPSO_ERR_ARGUMENT; }
+        for (int64_t b = 0; b < spec->n_blocks; ++b) {
+            const int64_t c0 = spec->block_start[b], c1 = b + 1 < spec->n_blocks ? spec->block_start[b + 1] : nx + 1;
+            if (c1 <= c0 || c1 > nx + 1) { s->err = "calipso_hip_create_structured: hessian_block_start must be increasing within 1..nx"; return CALIPSO_ERR_ARGUMENT; }
+            for (int64_t c = c0; c < c1; ++c) lr[(size_t)c - 1] = (int)c1 - 2;
+        }
+        s->h_zrow = zr; s->h_lreach = lr;
+        // skyline of S (as calipso_hip_analyze_structure derives it from a numeric pattern)
+        std::vector<int>& reach = s->h_reach;
+        reach = lr;
+        std::vector<int> ext((size_t)d.nx, -1);
+        for (int k = 0; k < d.m; ++k) if (zr[2 * (size_t)k + 1] > zr[2 * (size_t)k]) ext[(size_t)zr[2 * (size_t)k]] = std::max(ext[(size_t)zr[2 * (size_t)k]], zr[2 * (size_t)k + 1] - 1);
+        int run = -1;
+        for (int j = 0; j < d.nx; ++j) { run = std::max(run, ext[(size_t)j]); if (run >= j) reach[(size_t)j] = std::max(reach[(size_t)j], run); }
+        if (!calipso::blocks_plan(d, zr, lr, plan, s->err)) return CALIPSO_ERR_ARGUMENT;
+        s->compact = true;
+        s->blocks_zero_cell = plan.spacked - 1;
+    }
+    const bool cp = s->compact;
     // Every per-instance buffer is carved out of ONE slab (256-byte aligned pieces, same order for every handle of a shape), so
     // that two handles of the same shape differ by a single pointer offset — what lets a group step them through the same
     // launches (internal.hpp: Batch).  Shape-only data (tile list, cone index arrays) is outside the slab.
     std::vector<std::pair<double**, size_t>> carve;
     auto SL = [&](double** pp, size_t count) { carve.push_back({pp, count ? count : 1}); };
     double* icount_d = nullptr;
-    SL(&s->Lxx, NX * NX); SL(&s->Lsym, NX * NX); SL(&s->Z, M * NX);
+    SL(&s->Lxx, cp ? 1 : NX * NX); SL(&s->Lsym, cp ? plan.packed : NX * NX); SL(&s->Z, cp ? 1 : M * NX);     // structured: Lsym is the region of the packed blocks
     SL(&s->fx, NX); SL(&s->gyx, NX); SL(&s->hzx, NX); SL(&s->gh, M);
     SL(&s->cone_product, NC); SL(&s->cone_target, NC); SL(&s->barrier_gradient, NC);
     SL(&s->dscal, 64); SL(&s->refpart, (NE + NC + 255) / 256 + 1 + (size_t)d.n_wide);
@@ -126,8 +163,8 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->residual, N); SL(&s->residual_error, N); SL(&s->step, N); SL(&s->step_correction, N);
     SL(&s->saved_point, N); SL(&s->saved_g, NE); SL(&s->saved_h, NC);
     SL(&s->residual_symmetric, n); SL(&s->step_symmetric, n); SL(&s->merit_gradient, n);
-    SL(&s->S, NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, NPd * NB);
-    SL(&s->Tinv, calipso::tinv_doubles(d.NP)); SL(&s->Ttmp, NPd * 256); SL(&s->zf2, NPd); SL(&s->WH, NC * NX);
+    SL(&s->S, cp ? plan.spacked : NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, cp ? 1 : NPd * NB);                     // structured: S = the tiles of the segment pairs, contiguous
+    SL(&s->Tinv, cp ? 1 : calipso::tinv_doubles(d.NP)); SL(&s->Ttmp, cp ? 1 : NPd * 256); SL(&s->zf2, NPd); SL(&s->WH, cp ? 1 : NC * NX);
     SL(&s->wz, NC); SL(&s->kzz, NC);
     SL(&s->Wsoc, (size_t)woff); SL(&s->Bsoc, (size_t)woff); SL(&s->socwork, (size_t)2 * woff);
     SL(&icount_d, 32);                                        // 64 ints
@@ -137,7 +174,7 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     double* zrow_d = nullptr;
     SL(&zrow_d, M);                                           // 2 ints per row of [gx; hx]
     const size_t maxdim = std::max(std::max(NX, M), NPd);   // rows of the largest mat-vec (the stacked Jacobian has m = ne + nc rows)
-    SL(&s->gemv_partial, std::max(64 * maxdim, ((NX + 15) / 16) * M + ((M + 1023) / 1024) * NX));   // gemv_n chunks / gemv_both partials
+    SL(&s->gemv_partial, cp ? 1 : std::max(64 * maxdim, ((NX + 15) / 16) * M + ((M + 1023) / 1024) * NX));   // gemv_n chunks / gemv_both partials (the block mat-vecs need none)
     SL(&s->vtmp, 4 * std::max(N, NPd));
     SL(&s->xbuf, NPd); SL(&s->zf, NPd); SL(&s->t1, M); SL(&s->t2, M);
     SL(&s->zsx, M); SL(&s->w1, NX); SL(&s->w2, NX); SL(&s->lxv, NX);
@@ -206,7 +243,37 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     const int mf = (int)o.max_filter;
     s->filter_theta.assign(mf, 1.0e8); s->filter_merit.assign(mf, 1.0e8);
     s->cache_theta.assign(mf, 1.0e8); s->cache_merit.assign(mf, 1.0e8);
+    if (cp) {
+        // the blocks and the multifrontal plan of the Schur complement are part of the handle from the start (there is no dense path to fall back to)
+        CK(hipStreamSynchronize(s->stream));
+        int brc = calipso::blocks_install(s, plan);
+        if (brc < 0) return brc;
+        brc = calipso_hip_set_stage_parallel(s, 1, 1, nullptr);
+        if (brc < 0) return brc;
+    }
     return CALIPSO_OK;
+}
+
+int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx, int64_t n_soc,
+                           const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device, H** out) {
+    return create_impl(nx, np, ne, nc, n_nonneg, nonneg_idx, n_soc, soc_ptr, soc_idx, device, nullptr, out);
+}
+
+// Solver(...) for a stage-structured problem whose sparsity is known up front (the reference's methods.*_sparsity lists, src/trajectory_optimization/
+// sparsity.jl:28-129): constraint row k of [equality; cone] touches columns row_first[k]..row_last[k] (1-based, inclusive; first > last: an empty row),
+// the Lagrangian Hessian is block diagonal with blocks starting at columns hessian_block_start[0] = 1 < ... .  The handle holds ONLY the blocks (packed,
+// both orientations), the tiles of the Schur complement that the blocks couple, and the multifrontal factor: O(stages x block^2) device memory instead of the
+// dense nx^2 / m nx / NP^2 buffers.  Uploads: calipso_hip_set_field with the dense host arrays (packed on the host, entries outside the declared structure
+// are an error), calipso_hip_set_sparsity + calipso_hip_scatter_* (straight into the blocks), calipso_hip_qp_attach.  Not available on such a handle:
+// device evaluators, differentiate!, calipso_hip_analyze_structure / clear_structure (the structure is fixed).
+int32_t calipso_hip_create_structured(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx, int64_t n_soc,
+                                      const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device, const int64_t* row_first, const int64_t* row_last,
+                                      int64_t n_hessian_blocks, const int64_t* hessian_block_start, H** out) {
+    if (((ne + nc) > 0 && (!row_first || !row_last)) || !hessian_block_start || n_hessian_blocks < 1) { g_create_err = "calipso_hip_create_structured: structure arrays missing"; return CALIPSO_ERR_ARGUMENT; }
+    const StructureSpec spec{row_first, row_last, n_hessian_blocks, hessian_block_start};
+    const int32_t rc = create_impl(nx, np, ne, nc, n_nonneg, nonneg_idx, n_soc, soc_ptr, soc_idx, device, &spec, out);
+    if (rc != CALIPSO_OK && out && *out) { g_create_err = (*out)->err; (void)calipso_hip_destroy(*out); *out = nullptr; }
+    return rc;
 }
 
 int32_t calipso_hip_destroy(H* s) {
@@ -321,6 +388,8 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
     if (!f.dev) return fail_arg(s, std::string("field not allocated: ") + name);
     if (len == 0) return CALIPSO_OK;
     CK(hipSetDevice(s->device));
+    if (s->compact && (nm == "lagrangian_hessian" || nm == "equality_jacobian_variables" || nm == "cone_jacobian_variables"))      // structured handle: the dense host array goes into the blocks
+        return blocks_upload_dense(s, nm == "lagrangian_hessian" ? 0 : (nm == "equality_jacobian_variables" ? 1 : 2), data, 1.0);
     if (f.ld)
         CK(hipMemcpy2DAsync(f.dev, sizeof(double) * f.ld, data, sizeof(double) * f.rows, sizeof(double) * f.rows, len / f.rows, hipMemcpyHostToDevice, s->stream));
     else
@@ -348,6 +417,11 @@ int32_t calipso_hip_get_field(H* s, const char* name, double* data, int64_t len)
     if (!f.dev) return fail_arg(s, std::string("field not computed yet: ") + name);
     if (len == 0) return CALIPSO_OK;
     CK(hipSetDevice(s->device));
+    {
+        const std::string nm = name;
+        if (s->compact && (nm == "lagrangian_hessian" || nm == "equality_jacobian_variables" || nm == "cone_jacobian_variables"))
+            return blocks_download_dense(s, nm == "lagrangian_hessian" ? 0 : (nm == "equality_jacobian_variables" ? 1 : 2), data);
+    }
     if (f.ld)
         CK(hipMemcpy2DAsync(data, sizeof(double) * f.rows, f.dev, sizeof(double) * f.ld, sizeof(double) * f.rows, len / f.rows, hipMemcpyDeviceToHost, s->stream));
     else
@@ -735,6 +809,14 @@ int32_t calipso_hip_residual_jacobian_variables_symmetric(H* s) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
     if (!s->Kdense) { if (dalloc(s, &s->Kdense, (size_t)s->d.n * s->d.n)) return CALIPSO_ERR_HIP; }
     launch_cone_weights(s);
+    if (s->compact) {                        // inspection only: dense temporaries of the blocks for the dense assembly kernel
+        double *L = nullptr, *Z = nullptr;
+        const int rc = blocks_unpack_dense(s, &L, &Z);
+        if (rc == CALIPSO_OK) { double* kl = s->Lxx; double* kz = s->Z; s->Lxx = L; s->Z = Z; s->gx = Z; s->hx = Z + s->d.ne; launch_assemble_K(s); (void)hipStreamSynchronize(s->stream); s->Lxx = kl; s->Z = kz; s->gx = kz; s->hx = kz; }
+        if (L) (void)hipFree(L);
+        if (Z) (void)hipFree(Z);
+        return rc;
+    }
     launch_assemble_K(s);
     return CALIPSO_OK;
 }
@@ -795,6 +877,7 @@ int32_t calipso_hip_initialize(H* s, const double* guess) {
 
 int32_t calipso_hip_set_device_evaluator(H* s, calipso_device_eval_fn fn, void* user) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
+    if (s->compact && fn) { s->err = "device evaluators write the dense ProblemData layout, which a structured handle does not hold"; return CALIPSO_ERR_ARGUMENT; }
     s->dev_eval = fn; s->dev_eval_user = user;
     return CALIPSO_OK;
 }
@@ -825,6 +908,7 @@ int32_t calipso_hip_differentiate(H* s, calipso_eval_fn eval, void* user) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
     const Dims& d = s->d;
     if (d.np == 0) return CALIPSO_OK;
+    if (s->compact) { s->err = "calipso_hip_differentiate is not available on a structured handle"; return CALIPSO_ERR_ARGUMENT; }
     int rc = evaluate(s, eval, user, 0, CALIPSO_EVAL_OBJECTIVE_JACOBIAN_PARAMETERS | CALIPSO_EVAL_EQUALITY_JACOBIAN_PARAMETERS |
                                            CALIPSO_EVAL_EQUALITY_DUAL_JACOBIAN_PARAMETERS | CALIPSO_EVAL_CONE_JACOBIAN_PARAMETERS |
                                            CALIPSO_EVAL_CONE_DUAL_JACOBIAN_PARAMETERS);
@@ -934,6 +1018,21 @@ int32_t calipso_hip_qp_attach(H* s, const double* P, const double* q, const doub
     const Dims& d = s->d;
     if ((d.ne && (!A || !b)) || (d.nc && (!G || !h))) return CALIPSO_ERR_ARGUMENT;
     CK(hipSetDevice(s->device));
+    if (s->compact) {
+        // structured handle: Lxx = 2c P, gx = A, hx = -G straight into the blocks (packed on the host; entries outside the declared structure are an error)
+        int rc = blocks_upload_dense(s, 0, P, 2.0 * objective_scale);
+        if (rc == CALIPSO_OK && d.ne) rc = blocks_upload_dense(s, 1, A, 1.0);
+        if (rc == CALIPSO_OK && d.nc) rc = blocks_upload_dense(s, 2, G, -1.0);
+        if (rc < 0) return rc;
+        std::vector<double> bh((size_t)d.m);
+        for (int k = 0; k < d.ne; ++k) bh[(size_t)k] = -b[k];
+        for (int k = 0; k < d.nc; ++k) bh[(size_t)d.ne + k] = h[k];
+        CK(hipMemcpyAsync(s->qp.q, q, sizeof(double) * d.nx, hipMemcpyHostToDevice, s->stream));
+        if (d.m) CK(hipMemcpyAsync(s->qp.bh, bh.data(), sizeof(double) * d.m, hipMemcpyHostToDevice, s->stream));
+        SYNC();
+        s->qp.attached = true; s->qp.scale = objective_scale;
+        return CALIPSO_OK;
+    }
     if (structure_active(s)) { const int rc = calipso_hip_clear_structure(s); if (rc < 0) return rc; }   // new blocks: any analysed structure is void
     const size_t nx = d.nx;
     // Lxx = 2c P ; gx = A ; hx = -G   (constant Hessian / Jacobians of the QP); bh = [-b; h]

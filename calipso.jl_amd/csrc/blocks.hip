@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_bgemv_l(Batch bt, const LBlock* __restr
 template <int SB_KC>
 __global__ __launch_bounds__(256) void k_schur_blocks(BatchSc bt, Dims d, ConeDev cd, const SegPair* __restrict__ pairs, const int* __restrict__ pairblk, const Segment* __restrict__ seg,
                                                        const ZBlock* __restrict__ blk, const LBlock* __restrict__ lblk, const double* __restrict__ pk, const double* __restrict__ wz,
-                                                       const double* __restrict__ Wsoc, double* __restrict__ S) {
+                                                       const double* __restrict__ Wsoc, double* __restrict__ S, int packed_S) {
     constexpr int SB_LD = SB_KC + 2;
     __shared__ double As[64 * SB_LD];      // As[i][k] = B[k][a-column i]
     __shared__ double Bs[64 * SB_LD];      // Bs[j][k] = (Omega B)[k][b-column j]
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void k_schur_blocks(BatchSc bt, Dims d, ConeDe
                     v += pk[lb.off_c + (size_t)min(li, lj) + (size_t)max(li, lj) * lb.n];
                 }
                 if (gi == gj) v += sc.ep;
-                S[(size_t)gi + (size_t)gj * d.NP] = v;
+                if (packed_S) S[pr.soff + i + (size_t)j * sa.nc] = v;          // structured handles: the tile, contiguous (column-major, ld = rows of segment a)
+                else S[(size_t)gi + (size_t)gj * d.NP] = v;
             }
         }
     }
@@ -287,17 +288,235 @@ bool blocks_schur(calipso_hip_solver* s) {
     if (!blocks_usable(s)) return false;
     const StageBlocks& B = s->blocks;
     const BatchSc bs = batch_of(s);
-    if (!(s->stage_parallel && s->spS)) {
+    if (!s->compact && !(s->stage_parallel && s->spS)) {
         // the blocked LDL^T factors S in place: what it left between the pair tiles (fill-in) must read as zero again, and the padded rows as identity
         // (the multifrontal path gathers S into storage of its own and needs neither)
         for (int k = 0; k < bs.b.n; ++k) (void)hipMemsetAsync(s->S + bs.b.delta[k], 0, sizeof(double) * (size_t)s->d.NP * s->d.NP, s->stream);
         launch_pad_identity(s);
     }
     if (s->d.max_dim <= 32) hipLaunchKernelGGL(k_schur_blocks<32>, dim3(B.npairs, 1, bs.b.n), dim3(256), 0, s->stream, bs, s->d, s->cone, B.d_pairs, B.d_pairblk, B.d_seg, B.d_blk, B.d_lblk,
-                                               s->Lsym, s->wz, s->Wsoc, s->S);
+                                               s->Lsym, s->wz, s->Wsoc, s->S, s->compact ? 1 : 0);
     else hipLaunchKernelGGL(k_schur_blocks<64>, dim3(B.npairs, 1, bs.b.n), dim3(256), 0, s->stream, bs, s->d, s->cone, B.d_pairs, B.d_pairblk, B.d_seg, B.d_blk, B.d_lblk, s->Lsym, s->wz,
-                            s->Wsoc, s->S);
+                            s->Wsoc, s->S, s->compact ? 1 : 0);
     return true;
+}
+
+}  // namespace calipso
+
+namespace calipso {
+
+// unpack the blocks into dense column-major matrices (structured handles only hold the blocks: the rare dense consumers — the pivoted LU fallback, the
+// dense K for inspection — get temporaries)
+__global__ __launch_bounds__(256) void k_blocks_unpack_z(const ZBlock* __restrict__ blk, int m, const double* __restrict__ pk, double* __restrict__ Z) {
+    const ZBlock b = blk[blockIdx.x];
+    const int total = b.nrows * b.ncols;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int i = idx % b.nrows, j = idx / b.nrows;
+        Z[(size_t)(b.row0 + i) + (size_t)(b.col0 + j) * m] = pk[b.off_c + idx];
+    }
+}
+__global__ __launch_bounds__(256) void k_blocks_unpack_l(const LBlock* __restrict__ blk, int nx, const double* __restrict__ pk, double* __restrict__ L) {
+    const LBlock b = blk[blockIdx.x];
+    const int total = b.n * b.n;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int i = idx % b.n, j = idx / b.n;
+        L[(size_t)(b.c0 + i) + (size_t)(b.c0 + j) * nx] = pk[b.off_c + idx];
+    }
+}
+// Lxx (nx x nx) and [gx; hx] (m x nx, ld m) of a structured handle as dense temporaries (zero outside the blocks); the caller frees them
+int blocks_unpack_dense(calipso_hip_solver* s, double** Lxx, double** Z) {
+    const Dims& d = s->d;
+    const StageBlocks& B = s->blocks;
+    *Lxx = nullptr; *Z = nullptr;
+    CK(hipMalloc((void**)Lxx, sizeof(double) * (size_t)d.nx * d.nx));
+    CK(hipMalloc((void**)Z, sizeof(double) * std::max<size_t>((size_t)d.m * d.nx, 1)));
+    CK(hipMemsetAsync(*Lxx, 0, sizeof(double) * (size_t)d.nx * d.nx, s->stream));
+    CK(hipMemsetAsync(*Z, 0, sizeof(double) * std::max<size_t>((size_t)d.m * d.nx, 1), s->stream));
+    if (B.nlb) hipLaunchKernelGGL(k_blocks_unpack_l, dim3(B.nlb), dim3(256), 0, s->stream, B.d_lblk, d.nx, s->Lsym, *Lxx);
+    if (B.nblk) hipLaunchKernelGGL(k_blocks_unpack_z, dim3(B.nblk), dim3(256), 0, s->stream, B.d_blk, d.m, s->Lsym, *Z);
+    return CALIPSO_OK;
+}
+
+// The block tables of a structure: zrow = per row of [gx; hx] its [first, last + 1) column (0-based), lreach = per column of Lxx the last row/column its
+// entries reach.  Pure host work (no device): structured handles size their slab from it before anything is allocated.
+bool blocks_plan(const Dims& d, const std::vector<int>& zrow, const std::vector<int>& lreach, BlockPlan& P, std::string& err) {
+    const int nx = d.nx, m = d.m, ne = d.ne;
+    if ((int)zrow.size() != 2 * m || (int)lreach.size() != nx) { err = "calipso_hip_set_stage_blocks: call calipso_hip_analyze_structure first"; return false; }
+    std::vector<LBlock>& lb = P.lb; std::vector<ZBlock>& zb = P.zb;
+    lb.clear(); zb.clear();
+    {   // Hessian blocks: a new block starts at column p when no entry of columns < p reaches p or beyond
+        int start = 0, reach = -1;
+        for (int j = 0; j < nx; ++j) {
+            if (j > start && reach < j) { lb.push_back({start, j - start, 0, 0}); start = j; }
+            reach = std::max(reach, std::max(j, lreach[(size_t)j]));
+        }
+        lb.push_back({start, nx - start, 0, 0});
+    }
+    for (int k = 0; k < m;) {    // Z blocks: runs of consecutive rows with one column range (never across the equality / cone boundary)
+        const int lo = zrow[2 * (size_t)k], hi = zrow[2 * (size_t)k + 1];
+        int e = k + 1;
+        while (e < m && e != ne && zrow[2 * (size_t)e] == lo && zrow[2 * (size_t)e + 1] == hi) ++e;
+        zb.push_back({k, e - k, hi > lo ? lo : 0, hi > lo ? hi - lo : 0, 0, 0});
+        k = e;
+    }
+    if (lb.size() < 2 || zb.size() > (size_t)std::max(64, m / 2)) { err = "calipso_hip_set_stage_blocks: no block structure to exploit (one Hessian block, or a column range per row)"; return false; }
+    size_t off = 0;
+    P.max_lb = 0;
+    for (ZBlock& b : zb) { const size_t n = (size_t)b.nrows * b.ncols; b.off_c = (long long)off; b.off_r = (long long)(off + n); off += 2 * n; }
+    for (LBlock& b : lb) { const size_t n = (size_t)b.n * b.n; b.off_c = (long long)off; b.off_r = (long long)(off + n); off += 2 * n; P.max_lb = std::max(P.max_lb, b.n); }
+    P.packed = off;
+    // segments: every block boundary, at most 64 columns each
+    std::vector<int> cut = {0, nx};
+    for (const ZBlock& b : zb) if (b.ncols) { cut.push_back(b.col0); cut.push_back(b.col0 + b.ncols); }
+    for (const LBlock& b : lb) { cut.push_back(b.c0); cut.push_back(b.c0 + b.n); }
+    std::sort(cut.begin(), cut.end());
+    cut.erase(std::unique(cut.begin(), cut.end()), cut.end());
+    std::vector<Segment>& seg = P.seg; seg.clear(); P.segblk.clear();
+    for (size_t c = 0; c + 1 < cut.size(); ++c)
+        for (int a = cut[c]; a < cut[c + 1]; a += 64) seg.push_back({a, std::min(64, cut[c + 1] - a), 0, 0});
+    P.seg_of_col.assign((size_t)nx, 0);
+    for (size_t g = 0; g < seg.size(); ++g) {
+        for (int c = seg[g].c0; c < seg[g].c0 + seg[g].nc; ++c) P.seg_of_col[(size_t)c] = (int)g;
+        seg[g].first = (int)P.segblk.size();
+        for (size_t q = 0; q < zb.size(); ++q) if (zb[q].ncols && zb[q].col0 <= seg[g].c0 && seg[g].c0 + seg[g].nc <= zb[q].col0 + zb[q].ncols) P.segblk.push_back((int)q);
+        seg[g].count = (int)P.segblk.size() - seg[g].first;
+    }
+    // pairs of segments (a >= b) that a Z block or a Hessian block couples
+    std::map<std::pair<int, int>, std::pair<std::vector<int>, int>> pm;
+    for (size_t q = 0; q < zb.size(); ++q) {
+        if (!zb[q].ncols) continue;
+        const int g0 = P.seg_of_col[(size_t)zb[q].col0], g1 = P.seg_of_col[(size_t)(zb[q].col0 + zb[q].ncols - 1)];
+        for (int a = g0; a <= g1; ++a) for (int b2 = g0; b2 <= a; ++b2) { auto it = pm.find({a, b2}); if (it == pm.end()) it = pm.insert({{a, b2}, {{}, -1}}).first; it->second.first.push_back((int)q); }
+    }
+    for (size_t q = 0; q < lb.size(); ++q) {
+        const int g0 = P.seg_of_col[(size_t)lb[q].c0], g1 = P.seg_of_col[(size_t)(lb[q].c0 + lb[q].n - 1)];
+        for (int a = g0; a <= g1; ++a) for (int b2 = g0; b2 <= a; ++b2) { auto it = pm.find({a, b2}); if (it == pm.end()) pm.insert({{a, b2}, {{}, (int)q}}); else it->second.second = (int)q; }
+    }
+    P.pairs.clear(); P.pairblk.clear();
+    size_t soff = 0;
+    for (auto& kv : pm) {
+        SegPair p{kv.first.first, kv.first.second, (int)P.pairblk.size(), (int)kv.second.first.size(), kv.second.second, (long long)soff};
+        soff += (size_t)seg[(size_t)p.a].nc * seg[(size_t)p.b].nc;
+        P.pairblk.insert(P.pairblk.end(), kv.second.first.begin(), kv.second.first.end());
+        P.pairs.push_back(p);
+    }
+    P.spacked = soff + 32;                        // (+ a cell that stays zero: what the skyline holds between the tiles points there)
+    P.colrange.assign(2 * (size_t)nx, 0);
+    for (const LBlock& b : lb) for (int c = b.c0; c < b.c0 + b.n; ++c) { P.colrange[2 * (size_t)c] = b.c0; P.colrange[2 * (size_t)c + 1] = b.c0 + b.n; }
+    unsigned long long h = 1469598103934665603ULL;
+    auto mix = [&](long long v) { h ^= (unsigned long long)v; h *= 1099511628211ULL; };
+    for (const ZBlock& b : zb) { mix(b.row0); mix(b.nrows); mix(b.col0); mix(b.ncols); }
+    for (const LBlock& b : lb) { mix(b.c0); mix(b.n); }
+    P.signature = h;
+    return true;
+}
+
+// the device side of a plan
+int blocks_install(calipso_hip_solver* s, const BlockPlan& P) {
+    StageBlocks& B = s->blocks;
+    auto up = [&](const auto& vec, auto** dptr) -> hipError_t {
+        typedef typename std::remove_const<typename std::remove_reference<decltype(vec)>::type>::type V;
+        typedef typename V::value_type T;
+        hipError_t e = hipMalloc((void**)dptr, sizeof(T) * std::max<size_t>(vec.size(), 1));
+        if (e == hipSuccess && !vec.empty()) e = hipMemcpy(*dptr, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(P.zb, &B.d_blk);
+    if (e == hipSuccess) e = up(P.lb, &B.d_lblk);
+    if (e == hipSuccess) e = up(P.seg, &B.d_seg);
+    if (e == hipSuccess) e = up(P.segblk, &B.d_segblk);
+    if (e == hipSuccess) e = up(P.pairs, &B.d_pairs);
+    if (e == hipSuccess) e = up(P.pairblk, &B.d_pairblk);
+    if (e == hipSuccess) e = up(P.colrange, &B.d_colrange);
+    if (e != hipSuccess) { blocks_release(s); return calipso::check(s, e, "stage blocks: device tables"); }
+    B.nblk = (int)P.zb.size(); B.nlb = (int)P.lb.size(); B.nseg = (int)P.seg.size(); B.npairs = (int)P.pairs.size(); B.max_lb = P.max_lb; B.packed = P.packed;
+    B.signature = P.signature;
+    B.h_blk = P.zb; B.h_lblk = P.lb; B.h_pairs = P.pairs; B.h_seg = P.seg; B.h_seg_of_col = P.seg_of_col;
+    B.on = true;
+    return CALIPSO_OK;
+}
+
+// ---- structured handles: the dense HOST arrays of the reference's ProblemData <-> the packed blocks ---------------------------------------------
+// which: 0 = lagrangian_hessian (nx x nx), 1 = equality_jacobian_variables (ne x nx), 2 = cone_jacobian_variables (nc x nx), all column-major.
+// Entries outside the declared structure must be zero (there is nowhere to put them): CALIPSO_ERR_ARGUMENT otherwise.
+int blocks_upload_dense(calipso_hip_solver* s, int which, const double* data, double scale) {
+    const Dims& d = s->d;
+    const StageBlocks& B = s->blocks;
+    std::vector<double>& hb = s->hstage;
+    long long lo = -1, hi = -1;                 // the region of the packed buffer this field owns
+    auto claim = [&](long long a, long long b) { if (lo < 0 || a < lo) lo = a; if (b > hi) hi = b; };
+    if (which == 0) for (const LBlock& b : B.h_lblk) claim(b.off_c, b.off_r + (long long)b.n * b.n);
+    else for (const ZBlock& b : B.h_blk) if ((which == 1) == (b.row0 < d.ne)) claim(b.off_c, b.off_r + (long long)b.nrows * b.ncols);
+    if (lo < 0) return CALIPSO_OK;
+    hb.assign((size_t)(hi - lo), 0.0);
+    if (which == 0) {
+        const size_t nx = (size_t)d.nx;
+        size_t inside = 0, total = 0;
+        for (size_t q = 0; q < nx * nx; ++q) total += data[q] != 0.0;
+        for (const LBlock& b : B.h_lblk)
+            for (int j = 0; j < b.n; ++j) for (int i = 0; i < b.n; ++i) {
+                const double v = data[(size_t)(b.c0 + i) + (size_t)(b.c0 + j) * nx];
+                inside += v != 0.0;
+                hb[(size_t)(b.off_c - lo) + i + (size_t)j * b.n] = scale * v;
+                hb[(size_t)(b.off_r - lo) + (size_t)i * b.n + j] = scale * v;
+            }
+        if (inside != total) { s->err = "lagrangian_hessian has non-zero entries outside the Hessian blocks declared at calipso_hip_create_structured"; return CALIPSO_ERR_ARGUMENT; }
+    } else {
+        const int r0 = which == 1 ? 0 : d.ne, rows = which == 1 ? d.ne : d.nc;
+        size_t inside = 0, total = 0;
+        for (size_t q = 0; q < (size_t)rows * d.nx; ++q) total += data[q] != 0.0;
+        for (const ZBlock& b : B.h_blk) {
+            if ((which == 1) != (b.row0 < d.ne)) continue;
+            for (int j = 0; j < b.ncols; ++j) for (int i = 0; i < b.nrows; ++i) {
+                const double v = data[(size_t)(b.row0 - r0 + i) + (size_t)(b.col0 + j) * rows];
+                inside += v != 0.0;
+                hb[(size_t)(b.off_c - lo) + i + (size_t)j * b.nrows] = scale * v;
+                hb[(size_t)(b.off_r - lo) + (size_t)i * b.ncols + j] = scale * v;
+            }
+        }
+        if (inside != total) { s->err = "a constraint Jacobian has non-zero entries outside the column ranges declared at calipso_hip_create_structured"; return CALIPSO_ERR_ARGUMENT; }
+    }
+    CK(hipMemcpyAsync(s->Lsym + lo, hb.data(), sizeof(double) * hb.size(), hipMemcpyHostToDevice, s->stream));
+    CK(hipStreamSynchronize(s->stream));        // (hstage is reused)
+    return CALIPSO_OK;
+}
+int blocks_download_dense(calipso_hip_solver* s, int which, double* data) {
+    const Dims& d = s->d;
+    const StageBlocks& B = s->blocks;
+    std::vector<double> hb(B.packed);
+    CK(hipMemcpyAsync(hb.data(), s->Lsym, sizeof(double) * B.packed, hipMemcpyDeviceToHost, s->stream));
+    CK(hipStreamSynchronize(s->stream));
+    if (which == 0) {
+        std::fill(data, data + (size_t)d.nx * d.nx, 0.0);
+        for (const LBlock& b : B.h_lblk) for (int j = 0; j < b.n; ++j) for (int i = 0; i < b.n; ++i) data[(size_t)(b.c0 + i) + (size_t)(b.c0 + j) * d.nx] = hb[(size_t)b.off_c + i + (size_t)j * b.n];
+    } else {
+        const int r0 = which == 1 ? 0 : d.ne, rows = which == 1 ? d.ne : d.nc;
+        std::fill(data, data + (size_t)rows * d.nx, 0.0);
+        for (const ZBlock& b : B.h_blk) {
+            if ((which == 1) != (b.row0 < d.ne)) continue;
+            for (int j = 0; j < b.ncols; ++j) for (int i = 0; i < b.nrows; ++i) data[(size_t)(b.row0 - r0 + i) + (size_t)(b.col0 + j) * rows] = hb[(size_t)b.off_c + i + (size_t)j * b.nrows];
+        }
+    }
+    return CALIPSO_OK;
+}
+// packed offsets (column-major copy, row-major copy) of entry (row, col) — 0-based; row: of the stacked Jacobian (field 1 / 2) or of Lxx (field 0);
+// false if the entry lies outside the structure
+bool blocks_entry_offsets(const calipso_hip_solver* s, int which, int row, int col, long long* off_c, long long* off_r) {
+    const StageBlocks& B = s->blocks;
+    if (which == 0) {
+        for (const LBlock& b : B.h_lblk) if (col >= b.c0 && col < b.c0 + b.n) {
+            if (row < b.c0 || row >= b.c0 + b.n) return false;
+            *off_c = b.off_c + (row - b.c0) + (long long)(col - b.c0) * b.n; *off_r = b.off_r + (long long)(row - b.c0) * b.n + (col - b.c0);
+            return true;
+        }
+        return false;
+    }
+    for (const ZBlock& b : B.h_blk) if (row >= b.row0 && row < b.row0 + b.nrows) {
+        if (col < b.col0 || col >= b.col0 + b.ncols) return false;
+        *off_c = b.off_c + (row - b.row0) + (long long)(col - b.col0) * b.nrows; *off_r = b.off_r + (long long)(row - b.row0) * b.ncols + (col - b.col0);
+        return true;
+    }
+    return false;
 }
 
 }  // namespace calipso
@@ -312,107 +531,22 @@ extern "C" {
 // info (may be NULL) = [Z blocks, Hessian blocks, column segments, packed doubles per instance (both orientations)].
 int32_t calipso_hip_set_stage_blocks(calipso_hip_solver* s, int32_t on, int64_t info[4]) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
+    if (s->compact) { s->err = "calipso_hip_set_stage_blocks: a structured handle always works on its blocks"; return on ? CALIPSO_OK : CALIPSO_ERR_ARGUMENT; }
     CK(hipSetDevice(s->device));
     CK(hipStreamSynchronize(s->stream));
     blocks_release(s);
     if (!on) { s->hessian_dirty = true; return CALIPSO_OK; }           // (Lsym was borrowed: the dense Schur kernel needs it rebuilt)
     const Dims& d = s->d;
-    const int nx = d.nx, m = d.m, ne = d.ne;
-    if ((int)s->h_zrow.size() != 2 * m || (int)s->h_lreach.size() != nx) { s->err = "calipso_hip_set_stage_blocks: call calipso_hip_analyze_structure first"; return CALIPSO_ERR_ARGUMENT; }
-    // Hessian blocks: a new block starts at column p when no entry of columns < p reaches p or beyond
-    std::vector<LBlock> lb;
-    {
-        int start = 0, reach = -1;
-        for (int j = 0; j < nx; ++j) {
-            if (j > start && reach < j) { lb.push_back({start, j - start, 0, 0}); start = j; }
-            reach = std::max(reach, std::max(j, s->h_lreach[(size_t)j]));
-        }
-        lb.push_back({start, nx - start, 0, 0});
-    }
-    // Z blocks: runs of consecutive rows with one column range (never across the equality / cone boundary)
-    std::vector<ZBlock> zb;
-    for (int k = 0; k < m;) {
-        const int lo = s->h_zrow[2 * (size_t)k], hi = s->h_zrow[2 * (size_t)k + 1];
-        int e = k + 1;
-        while (e < m && e != ne && s->h_zrow[2 * (size_t)e] == lo && s->h_zrow[2 * (size_t)e + 1] == hi) ++e;
-        zb.push_back({k, e - k, hi > lo ? lo : 0, hi > lo ? hi - lo : 0, 0, 0});
-        k = e;
-    }
-    if (lb.size() < 2 || zb.size() > (size_t)std::max(64, m / 2)) { s->err = "calipso_hip_set_stage_blocks: no block structure to exploit (one Hessian block, or a column range per row)"; return CALIPSO_ERR_ARGUMENT; }
-    // packed offsets inside the Lsym region
-    size_t off = 0;
-    int max_lb = 0;
-    for (ZBlock& b : zb) { const size_t n = (size_t)b.nrows * b.ncols; b.off_c = (long long)off; b.off_r = (long long)(off + n); off += 2 * n; }
-    for (LBlock& b : lb) { const size_t n = (size_t)b.n * b.n; b.off_c = (long long)off; b.off_r = (long long)(off + n); off += 2 * n; max_lb = std::max(max_lb, b.n); }
-    if (off > (size_t)nx * nx) { s->err = "calipso_hip_set_stage_blocks: the packed blocks exceed the slab region they borrow"; return CALIPSO_ERR_ARGUMENT; }
-    // segments: every block boundary, at most 64 columns each
-    std::vector<int> cut = {0, nx};
-    for (const ZBlock& b : zb) if (b.ncols) { cut.push_back(b.col0); cut.push_back(b.col0 + b.ncols); }
-    for (const LBlock& b : lb) { cut.push_back(b.c0); cut.push_back(b.c0 + b.n); }
-    std::sort(cut.begin(), cut.end());
-    cut.erase(std::unique(cut.begin(), cut.end()), cut.end());
-    std::vector<Segment> seg;
-    for (size_t c = 0; c + 1 < cut.size(); ++c)
-        for (int a = cut[c]; a < cut[c + 1]; a += 64) seg.push_back({a, std::min(64, cut[c + 1] - a), 0, 0});
-    std::vector<int> segblk;
-    std::vector<int> seg_of_col((size_t)nx, 0);
-    for (size_t g = 0; g < seg.size(); ++g) {
-        for (int c = seg[g].c0; c < seg[g].c0 + seg[g].nc; ++c) seg_of_col[(size_t)c] = (int)g;
-        seg[g].first = (int)segblk.size();
-        for (size_t q = 0; q < zb.size(); ++q) if (zb[q].ncols && zb[q].col0 <= seg[g].c0 && seg[g].c0 + seg[g].nc <= zb[q].col0 + zb[q].ncols) segblk.push_back((int)q);
-        seg[g].count = (int)segblk.size() - seg[g].first;
-    }
-    // pairs of segments (a >= b) that a Z block or a Hessian block couples
-    std::map<std::pair<int, int>, std::pair<std::vector<int>, int>> pm;
-    for (size_t q = 0; q < zb.size(); ++q) {
-        if (!zb[q].ncols) continue;
-        const int g0 = seg_of_col[(size_t)zb[q].col0], g1 = seg_of_col[(size_t)(zb[q].col0 + zb[q].ncols - 1)];
-        for (int a = g0; a <= g1; ++a) for (int b2 = g0; b2 <= a; ++b2) { auto& e = pm[{a, b2}]; if (e.first.empty() && e.second == 0) e.second = -1; e.first.push_back((int)q); }
-    }
-    for (size_t q = 0; q < lb.size(); ++q) {
-        const int g0 = seg_of_col[(size_t)lb[q].c0], g1 = seg_of_col[(size_t)(lb[q].c0 + lb[q].n - 1)];
-        for (int a = g0; a <= g1; ++a) for (int b2 = g0; b2 <= a; ++b2) { auto it = pm.find({a, b2}); if (it == pm.end()) pm[{a, b2}] = {{}, (int)q}; else it->second.second = (int)q; }
-    }
-    std::vector<SegPair> pairs;
-    std::vector<int> pairblk;
-    for (auto& kv : pm) {
-        SegPair p{kv.first.first, kv.first.second, (int)pairblk.size(), (int)kv.second.first.size(), kv.second.second};
-        pairblk.insert(pairblk.end(), kv.second.first.begin(), kv.second.first.end());
-        pairs.push_back(p);
-    }
-    StageBlocks& B = s->blocks;
-    auto up = [&](auto& vec, auto** dptr) -> hipError_t {
-        typedef typename std::remove_reference<decltype(vec)>::type V;
-        typedef typename V::value_type T;
-        hipError_t e = hipMalloc((void**)dptr, sizeof(T) * std::max<size_t>(vec.size(), 1));
-        if (e == hipSuccess && !vec.empty()) e = hipMemcpy(*dptr, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice);
-        return e;
-    };
-    hipError_t e = up(zb, &B.d_blk);
-    if (e == hipSuccess) e = up(lb, &B.d_lblk);
-    if (e == hipSuccess) e = up(seg, &B.d_seg);
-    if (e == hipSuccess) e = up(segblk, &B.d_segblk);
-    if (e == hipSuccess) e = up(pairs, &B.d_pairs);
-    if (e == hipSuccess) e = up(pairblk, &B.d_pairblk);
-    std::vector<int> colrange(2 * (size_t)nx);
-    for (const LBlock& b : lb) for (int c = b.c0; c < b.c0 + b.n; ++c) { colrange[2 * (size_t)c] = b.c0; colrange[2 * (size_t)c + 1] = b.c0 + b.n; }
-    if (e == hipSuccess) e = up(colrange, &B.d_colrange);
-    if (e != hipSuccess) { blocks_release(s); s->hessian_dirty = true; return calipso::check(s, e, "calipso_hip_set_stage_blocks"); }
-    B.nblk = (int)zb.size(); B.nlb = (int)lb.size(); B.nseg = (int)seg.size(); B.npairs = (int)pairs.size(); B.max_lb = max_lb; B.packed = off;
-    // structure signature: members of a group must share it for the group's launches to use the blocks
-    {
-        unsigned long long h = 1469598103934665603ULL;
-        auto mix = [&](long long v) { h ^= (unsigned long long)v; h *= 1099511628211ULL; };
-        for (const ZBlock& b : zb) { mix(b.row0); mix(b.nrows); mix(b.col0); mix(b.ncols); }
-        for (const LBlock& b : lb) { mix(b.c0); mix(b.n); }
-        B.signature = h;
-    }
-    B.on = true;
+    BlockPlan P;
+    if (!blocks_plan(d, s->h_zrow, s->h_lreach, P, s->err)) return CALIPSO_ERR_ARGUMENT;
+    if (P.packed > (size_t)d.nx * d.nx) { s->err = "calipso_hip_set_stage_blocks: the packed blocks exceed the slab region they borrow"; return CALIPSO_ERR_ARGUMENT; }
+    const int rc = blocks_install(s, P);
+    if (rc < 0) { s->hessian_dirty = true; return rc; }
     CK(hipMemsetAsync(s->S, 0, sizeof(double) * (size_t)d.NP * d.NP, s->stream));     // what no pair covers must read as zero
     launch_pad_identity(s);
     blocks_pack(s, true, true);
     CK(hipStreamSynchronize(s->stream));
-    if (info) { info[0] = B.nblk; info[1] = B.nlb; info[2] = B.nseg; info[3] = (int64_t)off; }
+    if (info) { info[0] = s->blocks.nblk; info[1] = s->blocks.nlb; info[2] = s->blocks.nseg; info[3] = (int64_t)P.packed; }
     return CALIPSO_OK;
 }
 

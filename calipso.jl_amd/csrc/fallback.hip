@@ -193,8 +193,11 @@ int nonsymmetric_solve(calipso_hip_solver* s, const double* res, double* step) {
     const calipso::BatchSc* group = s->cur;
     s->cur = nullptr;                                   // this path works on the handle alone (gemm() consults batch_of)
     double* A = s->Hdense;
-    hipLaunchKernelGGL(k_assemble_H, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, s->stream, d, s->sc, s->cone, s->Lxx, s->Z,
+    double *Ltmp = nullptr, *Ztmp = nullptr;           // structured handle: dense temporaries of the blocks for the (rare) pivoted fallback
+    if (s->compact) { const int urc = blocks_unpack_dense(s, &Ltmp, &Ztmp); if (urc < 0) { s->cur = group; if (Ltmp) (void)hipFree(Ltmp); if (Ztmp) (void)hipFree(Ztmp); return urc; } }
+    hipLaunchKernelGGL(k_assemble_H, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, s->stream, d, s->sc, s->cone, s->compact ? Ltmp : s->Lxx, s->compact ? Ztmp : s->Z,
                        s->solution, A);
+    if (s->compact) { (void)hipStreamSynchronize(s->stream); (void)hipFree(Ltmp); (void)hipFree(Ztmp); }
     if (step != res) (void)hipMemcpyAsync(step, res, sizeof(double) * N, hipMemcpyDeviceToDevice, s->stream);
     int* info = s->lu_ipiv + N;
     (void)hipMemsetAsync(info, 0, sizeof(int), s->stream);

@@ -462,6 +462,11 @@ int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, ca
         if (!same) { b->err = "calipso_hip_group_create: members must have the same shape, cone layout and device"; return CALIPSO_ERR_ARGUMENT; }
         for (int j = 0; j < i; ++j) if (handles[j] == h) { b->err = "calipso_hip_group_create: duplicate member"; return CALIPSO_ERR_ARGUMENT; }
         if (h->owner) { b->err = "calipso_hip_group_create: a handle can be a member of one group at a time"; return CALIPSO_ERR_ARGUMENT; }
+        if (h->compact != b->compact || (h->compact && h->blocks.signature != b->blocks.signature)) { b->err = "calipso_hip_group_create: structured members must share one structure"; return CALIPSO_ERR_ARGUMENT; }
+    }
+    if (b->compact && count > 1) {           // the multifrontal storage of the leader covers the whole group (a structured handle has no blocked path to fall back to)
+        const int rc = calipso_hip_set_stage_parallel(b, 1, count, nullptr);
+        if (rc < 0) return rc;
     }
     G* g = new G();
     g->hs.assign(handles, handles + count);

@@ -105,7 +105,7 @@ struct ConeDev {
 struct ZBlock { int row0, nrows, col0, ncols; long long off_c, off_r; };   // rows [row0, row0 + nrows) x columns [col0, col0 + ncols): column-major (ld nrows) and row-major (ld ncols) copies
 struct LBlock { int c0, n; long long off_c, off_r; };                      // diagonal block of Lxx
 struct Segment { int c0, nc, first, count; };                              // <= 64 columns; covering Z blocks: segblk[first .. first + count), ascending
-struct SegPair { int a, b, first, count, lblock; };                        // tile (segment a >= segment b) of S: the Z blocks covering both, the Hessian block containing both (-1: none)
+struct SegPair { int a, b, first, count, lblock; long long soff; };        // tile (segment a >= segment b) of S: the Z blocks covering both, the Hessian block containing both (-1: none); its offset in the packed S of a structured handle
 struct StageBlocks {
     bool on = false;
     int nblk = 0, nlb = 0, nseg = 0, npairs = 0, max_lb = 0;
@@ -113,6 +113,11 @@ struct StageBlocks {
     unsigned long long signature = 0;   // of the block structure (members of a group must share it)
     ZBlock* d_blk = nullptr; LBlock* d_lblk = nullptr; Segment* d_seg = nullptr; int* d_segblk = nullptr; SegPair* d_pairs = nullptr; int* d_pairblk = nullptr;
     int* d_colrange = nullptr;          // per column of Lxx: [first, last + 1) row of its Hessian block (uploads are re-checked against it)
+    std::vector<ZBlock> h_blk; std::vector<LBlock> h_lblk; std::vector<SegPair> h_pairs; std::vector<Segment> h_seg; std::vector<int> h_seg_of_col;   // host copies (uploads of structured handles are packed on the host)
+};
+struct BlockPlan {                      // blocks.hip: blocks_plan (host only)
+    std::vector<ZBlock> zb; std::vector<LBlock> lb; std::vector<Segment> seg; std::vector<int> segblk, pairblk, colrange, seg_of_col; std::vector<SegPair> pairs;
+    size_t packed = 0, spacked = 0; int max_lb = 0; unsigned long long signature = 0;
 };
 
 struct QpEval {
@@ -195,6 +200,8 @@ struct calipso_hip_solver {
     std::vector<int> h_zrow, h_lreach;        // analysis, host copies: per row of [gx; hx] its [first, last + 1) column; per column of Lxx the last row its entries reach
     calipso::StageBlocks blocks;              // calipso_hip_set_stage_blocks (blocks.hip)
     bool blocks_effective = true;             // false while a group launch covers members whose block structures differ
+    size_t blocks_zero_cell = 0;              // structured handle: offset (doubles, in S) of a cell that stays zero
+    bool compact = false;                     // structured handle (calipso_hip_create_structured): no dense Lxx / [gx; hx] / S / Tinv exist, only the blocks
     calipso_hip_sparse* spS = nullptr;
     long long* spS_src = nullptr;             // device: offset (row + col * NP) in S of every pattern entry
     int* d_reach = nullptr;                   // device copy of h_reach while the stage-parallel factorisation is on: uploads are re-checked against the skyline
@@ -288,6 +295,12 @@ void blocks_pack(calipso_hip_solver* s, bool z, bool l);
 bool blocks_gemv_n(calipso_hip_solver* s, int kind, const double* x, double* y, double alpha, double beta);
 bool blocks_gemv_t(calipso_hip_solver* s, int kind, const double* u1, const double* u2, double* y1, double* y2, double alpha, double beta);
 bool blocks_schur(calipso_hip_solver* s);
+bool blocks_plan(const Dims& d, const std::vector<int>& zrow, const std::vector<int>& lreach, BlockPlan& P, std::string& err);
+int blocks_install(calipso_hip_solver* s, const BlockPlan& P);
+int blocks_unpack_dense(calipso_hip_solver* s, double** Lxx, double** Z);
+int blocks_upload_dense(calipso_hip_solver* s, int which, const double* data, double scale);        // structured handles: dense host array -> packed blocks
+int blocks_download_dense(calipso_hip_solver* s, int which, double* data);
+bool blocks_entry_offsets(const calipso_hip_solver* s, int which, int row, int col, long long* off_c, long long* off_r);
 void launch_ldl(calipso_hip_solver* s);
 void ldl_drop_graphs(calipso_hip_solver* s);
 void launch_trsv(calipso_hip_solver* s, double* x);            // x (length NP) <- S^-1 x using L, D

@@ -784,6 +784,7 @@ void launch_ldl(calipso_hip_solver* s) {
     if (s->stage_parallel && s->spS) {        // stage-parallel: multifrontal LDL^T of S over its nested-dissection tree (sparse.hip)
         const Batch bt = batch_of(s).b;
         if (sparse_factor_from_dense(s->spS, s->stream, bt, s->S, s->spS_src, s->icount) == CALIPSO_OK) { (void)hipEventRecord(s->ev[14], s->stream); return; }
+        if (s->compact) { s->err = "structured handle: the multifrontal factorisation was refused and there is no blocked one to fall back to"; (void)hipEventRecord(s->ev[14], s->stream); return; }
         s->stage_parallel = false;            // (a group larger than the reserved batch: back to the blocked factorisation)
         launch_pad_identity(s);               // launch_schur skipped the padding of S for the multifrontal path: the blocked one needs its unit pivots
     }

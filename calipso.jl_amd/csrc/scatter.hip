@@ -30,6 +30,7 @@ struct Pattern {
     int64_t winners = 0;             // entries that survive the assignment order
     int* src = nullptr;              // device: index into the cache of winner w
     long long* dst = nullptr;        // device: offset (doubles) into the destination matrix of winner w
+    long long* dst2 = nullptr;       // structured handles: the same entry in the row-major copy of its block (dst: the column-major copy)
     double* vals = nullptr;          // device staging of the cache (kept: the last values of a part are re-used when a later call does not pass it)
     bool loaded = false;             // vals holds values of an earlier scatter
 };
@@ -55,6 +56,7 @@ const char* const HESSIAN_PARTS[3] = {"objective_jacobian_variables_variables", 
 void free_pattern(Pattern& p) {
     if (p.src) (void)hipFree(p.src);
     if (p.dst) (void)hipFree(p.dst);
+    if (p.dst2) (void)hipFree(p.dst2);
     if (p.vals) (void)hipFree(p.vals);
     p = Pattern();
 }
@@ -95,10 +97,26 @@ int32_t calipso_hip_set_sparsity(calipso_hip_solver* s, const char* field, int64
     // winners: for every distinct (row, col) the LAST position in the list (assignment order of evaluate.jl:40-42 etc.)
     std::map<std::pair<int64_t, int64_t>, int64_t> last;
     for (int64_t p = 0; p < count; ++p) last[{rows[p], cols[p]}] = p;
-    std::vector<int> src; std::vector<long long> dst;
+    std::vector<int> src; std::vector<long long> dst, dst2;
     src.reserve(last.size()); dst.reserve(last.size());
-    for (const auto& kv : last) { src.push_back((int)kv.second); dst.push_back((long long)(off + kv.first.first - 1) + (long long)(kv.first.second - 1) * ld); }
+    for (const auto& kv : last) {
+        src.push_back((int)kv.second);
+        if (s->compact) {       // structured handle: straight into the two packed copies of the entry's block
+            long long oc = 0, orr = 0;
+            const int which = f == "equality_jacobian_variables" ? 1 : (f == "cone_jacobian_variables" ? 2 : 0);
+            if (!blocks_entry_offsets(s, which, (int)(off + kv.first.first - 1), (int)(kv.first.second - 1), &oc, &orr)) {
+                a->pat.erase(f);
+                s->err = "calipso_hip_set_sparsity: an entry lies outside the structure declared at calipso_hip_create_structured";
+                return CALIPSO_ERR_ARGUMENT;
+            }
+            dst.push_back(oc); dst2.push_back(orr);
+        } else dst.push_back((long long)(off + kv.first.first - 1) + (long long)(kv.first.second - 1) * ld);
+    }
     pat.count = count; pat.winners = (int64_t)src.size();
+    if (s->compact) {
+        CK(hipMalloc((void**)&pat.dst2, sizeof(long long) * dst2.size()));
+        CK(hipMemcpy(pat.dst2, dst2.data(), sizeof(long long) * dst2.size(), hipMemcpyHostToDevice));
+    }
     CK(hipMalloc((void**)&pat.src, sizeof(int) * src.size()));
     CK(hipMalloc((void**)&pat.dst, sizeof(long long) * dst.size()));
     CK(hipMalloc((void**)&pat.vals, sizeof(double) * (size_t)count));
@@ -117,6 +135,10 @@ int32_t calipso_hip_scatter_field(calipso_hip_solver* s, const char* field, cons
     Pattern& pat = a->pat[f];
     CK(hipSetDevice(s->device));
     CK(hipMemcpyAsync(pat.vals, values, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s->stream));
+    if (s->compact) {
+        hipLaunchKernelGGL(k_scatter_assign, dim3((unsigned)((pat.winners + 255) / 256)), dim3(256), 0, s->stream, pat.winners, pat.src, pat.dst, pat.vals, s->Lsym);
+        hipLaunchKernelGGL(k_scatter_assign, dim3((unsigned)((pat.winners + 255) / 256)), dim3(256), 0, s->stream, pat.winners, pat.src, pat.dst2, pat.vals, s->Lsym);
+    } else
     hipLaunchKernelGGL(k_scatter_assign, dim3((unsigned)((pat.winners + 255) / 256)), dim3(256), 0, s->stream, pat.winners, pat.src, pat.dst, pat.vals, s->Z);
     if (structure_active(s)) { const int rc = structure_validate(s, f == "equality_jacobian_variables" ? 1 : 2); if (rc < 0) return rc; }
     blocks_pack(s, true, false);
@@ -141,12 +163,21 @@ int32_t calipso_hip_scatter_hessian(calipso_hip_solver* s, const double* objecti
         }
     const Dims& d = s->d;
     CK(hipSetDevice(s->device));
+    if (s->compact) {           // the Hessian blocks (contiguous behind the Z blocks in the packed region)
+        const StageBlocks& B = s->blocks;
+        const long long lo = B.h_lblk.front().off_c, hi = B.h_lblk.back().off_r + (long long)B.h_lblk.back().n * B.h_lblk.back().n;
+        CK(hipMemsetAsync(s->Lsym + lo, 0, sizeof(double) * (size_t)(hi - lo), s->stream));
+    } else
     CK(hipMemsetAsync(s->Lxx, 0, sizeof(double) * (size_t)d.nx * d.nx, s->stream));     // the three dense matrices of the reference are zero outside their lists
     for (int k = 0; k < 3; ++k) {
         if (!a || !a->pat.count(HESSIAN_PARTS[k])) continue;
         Pattern& pat = a->pat[HESSIAN_PARTS[k]];
         if (vals[k]) { CK(hipMemcpyAsync(pat.vals, vals[k], sizeof(double) * (size_t)cnt[k], hipMemcpyHostToDevice, s->stream)); pat.loaded = true; }
         if (!pat.loaded || pat.winners == 0) continue;
+        if (s->compact) {
+            hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)((pat.winners + 255) / 256)), dim3(256), 0, s->stream, pat.winners, pat.src, pat.dst, pat.vals, s->Lsym);
+            hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)((pat.winners + 255) / 256)), dim3(256), 0, s->stream, pat.winners, pat.src, pat.dst2, pat.vals, s->Lsym);
+        } else
         hipLaunchKernelGGL(k_scatter_add, dim3((unsigned)((pat.winners + 255) / 256)), dim3(256), 0, s->stream, pat.winners, pat.src, pat.dst, pat.vals, s->Lxx);
     }
     s->hessian_dirty = true;

@@ -10,6 +10,7 @@
 // The structure is taken from the non-zero pattern of the blocks currently held by the handle (calipso_hip_analyze_structure):
 // the reference gets the same information from its sparsity pattern + AMD ordering (qdldl.jl:134-188).  Default = dense.
 #include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,7 @@ static int structure_clear(calipso_hip_solver* s) {
 
 namespace calipso {
 int structure_validate(calipso_hip_solver* s, int which) {
+    if (s->compact) return CALIPSO_OK;      // uploads of a structured handle are packed against the declared structure on the host
     const Dims& d = s->d;
     int* flag = s->icount + 60;
     CK(hipMemsetAsync(flag, 0, sizeof(int), s->stream));
@@ -99,6 +101,7 @@ extern "C" {
 // out[2], out[3] = average number of equality / cone rows a 16-column group has to visit (of ne / nc)
 int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
+    if (s->compact) { s->err = "calipso_hip_analyze_structure: the structure of a structured handle is fixed at creation"; return CALIPSO_ERR_ARGUMENT; }
     const Dims& d = s->d;
     const int nx = d.nx, ne = d.ne, nc = d.nc, m = d.m;
     CK(hipSetDevice(s->device));
@@ -179,6 +182,7 @@ int32_t calipso_hip_analyze_structure(calipso_hip_solver* s, int64_t out[4]) {
 // back to the dense treatment (e.g. before uploading blocks with a different pattern)
 int32_t calipso_hip_clear_structure(calipso_hip_solver* s) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
+    if (s->compact) { s->err = "calipso_hip_clear_structure: a structured handle has no dense treatment to go back to"; return CALIPSO_ERR_ARGUMENT; }
     return structure_clear(s);
 }
 
@@ -197,8 +201,20 @@ int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_
     if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
     if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
     s->stage_parallel = false;
-    if (!on) return CALIPSO_OK;
+    if (!on) { if (s->compact) { s->err = "calipso_hip_set_stage_parallel: a structured handle always factors through the multifrontal path"; return CALIPSO_ERR_ARGUMENT; } return CALIPSO_OK; }
     const int nx = s->d.nx, NP = s->d.NP;
+    // where entry (row c >= column r) of the lower triangle of S lives: the dense S, or — structured handle — the tile of its segment pair (what
+    // the skyline holds between the tiles is structurally zero: it points at the spare zero cell behind the last tile)
+    std::map<std::pair<int, int>, const calipso::SegPair*> pair_of;
+    if (s->compact) for (const calipso::SegPair& p : s->blocks.h_pairs) pair_of[{p.a, p.b}] = &p;
+    auto s_offset = [&](int c, int r) -> long long {
+        if (!s->compact) return (long long)c + (long long)r * NP;
+        const int a = s->blocks.h_seg_of_col[(size_t)c], b = s->blocks.h_seg_of_col[(size_t)r];
+        auto it = pair_of.find({a, b});
+        if (it == pair_of.end()) return (long long)s->blocks_zero_cell;
+        const calipso::Segment& sa = s->blocks.h_seg[(size_t)a]; const calipso::Segment& sb = s->blocks.h_seg[(size_t)b];
+        return it->second->soff + (c - sa.c0) + (long long)(r - sb.c0) * sa.nc;
+    };
     if ((int)s->h_reach.size() != nx) { s->err = "calipso_hip_set_stage_parallel: call calipso_hip_analyze_structure first"; return CALIPSO_ERR_ARGUMENT; }
     // upper-triangular CSC pattern (1-based) of the skyline: entry (r, c), r <= c, iff reach[r] >= c
     std::vector<int64_t> colptr((size_t)nx + 1, 0), rowval;
@@ -213,7 +229,7 @@ int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_
             for (int c = r; c <= s->h_reach[(size_t)r]; ++c) {
                 const int64_t at = next[(size_t)c]++ - 1;
                 rowval[(size_t)at] = r + 1;
-                src[(size_t)at] = (long long)c + (long long)r * NP;   // S holds its lower triangle: entry (row c, column r)
+                src[(size_t)at] = s_offset(c, r);                     // S holds its lower triangle: entry (row c, column r)
             }
     }
     calipso_hip_sparse* sp = nullptr;

@@ -495,6 +495,11 @@ __global__ void k_Hmul_vec(BatchSc bt, Dims d, ConeDev cd, const double* __restr
 
 static void hmul_matvecs(calipso_hip_solver* s, const double* v, double* out) {
     const Dims& d = s->d;
+    if (s->compact) {       // structured handle: the same three products on the packed blocks
+        gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, v, out, 1.0, 0.0, SP_LXX);
+        if (d.m) { gemv_t(s, d.m, d.nx, s->Z, d.m, v + d.oy(), out, 1.0, 1.0, SP_Z); gemv_n(s, d.m, d.nx, s->Z, d.m, v, out + d.oy(), 1.0, 0.0, SP_Z); }
+        return;
+    }
     gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, v, out, 1.0, 0.0, SP_LXX);
     // out_x += gx'v_y + hx'v_z (y and z are adjacent in a Point) and out_yz = [gx; hx] v_x with one pass over the stacked Jacobian
     if (d.m) gemv_both(s, d.m, d.nx, s->Z, d.m, v, v + d.oy(), out + d.oy(), out, 1.0, SP_Z);

@@ -120,6 +120,18 @@ typedef void (*calipso_callback_fn)(void* user, calipso_hip_solver* solver);
 int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx,
                            int64_t n_soc, const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device,
                            calipso_hip_solver** out);
+/* Solver(...) for a stage-structured problem whose sparsity is known up front — as the reference's are (methods.*_sparsity, src/trajectory_optimization/
+ * sparsity.jl:28-129): constraint row k of [equality; cone] touches columns row_first[k]..row_last[k] (1-based, inclusive; first > last: an empty row; the
+ * rows of a second-order cone share the union of their ranges), the Lagrangian Hessian is block diagonal with blocks starting at hessian_block_start[0] = 1 <
+ * hessian_block_start[1] < ... .  The handle holds ONLY the blocks (packed contiguously, both orientations), the tiles of the Schur complement that the
+ * blocks couple, and the multifrontal factor of the Schur complement: O(stages x block^2) device memory — none of the dense nx^2 / (ne + nc) nx / NP^2 buffers of
+ * calipso_hip_create exist.  Uploads: calipso_hip_set_field with the dense host arrays of ProblemData (packed on the host; a non-zero outside the declared
+ * structure is an error), calipso_hip_set_sparsity + calipso_hip_scatter_field / _hessian (straight into the blocks), calipso_hip_qp_attach.  Everything
+ * else of this header works as on a dense handle, except: no device evaluators, no calipso_hip_differentiate, no calipso_hip_analyze_structure /
+ * clear_structure / set_stage_parallel(off) / set_stage_blocks(off) (the structure is fixed); members of a group must share one structure. */
+int32_t calipso_hip_create_structured(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx, int64_t n_soc,
+                                      const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device, const int64_t* row_first, const int64_t* row_last,
+                                      int64_t n_hessian_blocks, const int64_t* hessian_block_start, calipso_hip_solver** out);
 int32_t calipso_hip_destroy(calipso_hip_solver*);
 const char* calipso_hip_last_error(calipso_hip_solver*); /* never NULL */
 const char* calipso_hip_version(void);

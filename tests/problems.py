@@ -681,3 +681,28 @@ def cartpole_mpc(horizon=10, h=0.05, perturb=0.05):
     prob = SymbolicProblem(nz, objective, equality, None, np_=npar, parameters=theta, x0=x0, name="cartpole_mpc")
     prob.horizon = T
     return prob
+
+
+def declared_structure(prob):
+    """what a caller who knows the sparsity of the problem up front (the reference's methods.*_sparsity lists) hands to calipso_hip_create_structured:
+    per row of [equality; cone] its first / last non-zero column (1-based, inclusive; first > last for an empty row) and the first columns of the
+    diagonal blocks of the Lagrangian Hessian — here read off the QP data"""
+    rows = []
+    if prob.ne:
+        rows.append(np.asarray(prob.A) != 0.0)
+    if prob.nc:
+        rows.append(np.asarray(prob.G) != 0.0)
+    Zp = np.vstack(rows) if rows else np.zeros((0, prob.nx), dtype=bool)
+    first = np.ones(Zp.shape[0], dtype=np.int64); last = np.zeros(Zp.shape[0], dtype=np.int64)
+    for k in range(Zp.shape[0]):
+        nz = np.nonzero(Zp[k])[0]
+        if nz.size:
+            first[k], last[k] = nz[0] + 1, nz[-1] + 1
+    Hp = (np.asarray(prob.P) != 0.0) | (np.asarray(prob.P).T != 0.0)
+    starts, reach = [1], -1
+    for j in range(prob.nx):
+        if j > starts[-1] - 1 and reach < j:
+            starts.append(j + 1)
+        nz = np.nonzero(Hp[:, j])[0]
+        reach = max(reach, j, int(nz.max()) if nz.size else j)
+    return dict(row_first=first, row_last=last, hessian_block_start=np.array(starts, dtype=np.int64))

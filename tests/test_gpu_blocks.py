@@ -187,3 +187,75 @@ def test_a_dense_problem_has_no_blocks():
     s.analyze_structure()
     with pytest.raises(pkg.CalipsoHipError, match="no block structure"):
         s.set_stage_blocks(True)
+
+
+def build_structured(pkg, pid, T, nv, nd, nn, nsoc, dim):
+    """a STRUCTURED handle (calipso_hip_create_structured): no dense Lxx / [gx; hx] / S on the device at all"""
+    prob, pt, lam = pr.staged_conic_qp(pkg.splitmix_uniform, pid, T, nv, nd, nn, nsoc, dim)
+    s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices,
+                   structure=pr.declared_structure(prob))
+    s.set("solution", np.concatenate([pt[k] for k in "xrsyzt"]))
+    s.set("dual", lam)
+    for name, v in (("central_path", 0.17), ("penalty", 52.0), ("fraction_to_boundary", 0.99)):
+        s.set(name, [v])
+    s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
+    fl = pkg.FLAGS
+    s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"] | fl["objective_gradient_variables"] |
+                  fl["equality_dual_jacobian_variables"] | fl["cone_dual_jacobian_variables"], 0)
+    s.cone(product=True, target=True)
+    s.synchronize()
+    return prob, s
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[2], SHAPES[4]])
+def test_structured_handle_gets_the_bits_of_the_blocks_on_a_dense_handle_in_a_fraction_of_the_memory(shape):
+    pkg = load_pkg()
+    prob, ref = build(pkg, 5, *shape, blocks=True)
+    _, s = build_structured(pkg, 5, *shape)
+    assert s.device_bytes() * 8 < ref.device_bytes()                       # (C4T's size: 240 MB -> a few MB)
+    # the blocks round-trip through the dense host layout of ProblemData
+    cm = lambda M: np.ascontiguousarray(M.T).reshape(-1)
+    assert np.array_equal(s.get("lagrangian_hessian", prob.nx ** 2), cm(prob.P))          # Lxx = 2 c P with c = 1/2
+    if prob.ne:
+        assert np.array_equal(s.get("equality_jacobian_variables", prob.ne * prob.nx), cm(prob.A))
+    assert np.array_equal(s.get("cone_jacobian_variables", prob.nc * prob.nx), cm(-prob.G))
+    for it in range(3):
+        a, b = ref.newton_step(advance=True), s.newton_step(advance=True)
+        assert a == b and a["status"] == 0, (it, a, b)
+        assert np.array_equal(ref.data("step").all, s.data("step").all)
+        assert np.array_equal(ref.solution.all, s.solution.all)
+    assert ref.factorize() == s.factorize()
+    # H v through the blocks, the dense K for inspection through temporaries
+    v = np.random.default_rng(3).standard_normal(s.N)
+    assert close(s.jacobian_variables_mul(v), ref.jacobian_variables_mul(v), 1e-12)
+    assert close(s.jacobian_variables_symmetric(), ref.jacobian_variables_symmetric(), 1e-12)
+    # what a structured handle refuses
+    with pytest.raises(pkg.CalipsoHipError):
+        s.analyze_structure()
+    with pytest.raises(pkg.CalipsoHipError):
+        s.clear_structure()
+    H = 0.5 * (prob.P + prob.P.T); H[0, prob.nx - 1] = 0.3; H[prob.nx - 1, 0] = 0.3
+    with pytest.raises(pkg.CalipsoHipError, match="outside the Hessian blocks"):
+        s.set("lagrangian_hessian", cm(H))
+
+
+def test_structured_group_and_whole_solve():
+    pkg = load_pkg()
+    shape = SHAPES[1]
+    singles = [build_structured(pkg, p, *shape)[1] for p in (7, 8, 9)]
+    members = [build_structured(pkg, p, *shape)[1] for p in (7, 8, 9)]
+    g = pkg.Group(members)
+    for it in range(2):
+        ref = [x.newton_step(advance=True) for x in singles]
+        got = g.newton_step(advance=True)
+        for a, b, x, m in zip(ref, got, singles, members):
+            assert a == b and a["status"] == 0
+            assert np.array_equal(x.solution.all, m.solution.all)
+    g.close()
+    # solve! to the end on a structured handle: the iteration counts and the solution of the dense treatment
+    shape = (16, 24, 16, 3, 1, 3)
+    prob, dense = build(pkg, 21, *shape)
+    _, s = build_structured(pkg, 21, *shape)
+    assert pkg.solve_b(dense) and pkg.solve_b(s)
+    assert (dense.stats()["total_iterations"], dense.stats()["outer"]) == (s.stats()["total_iterations"], s.stats()["outer"])
+    assert close(s.solution.all, dense.solution.all, 1e-7)
