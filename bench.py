@@ -46,21 +46,22 @@ STAGED = {
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet); the measured ceiling is reported beside it (calipso_hip_mfma_f64_peak)
 
 
-def make_instance(pkg, pr, pid, shape, device, staged=None, analyze=True):
+def make_instance(pkg, pr, pid, shape, device, staged=None, analyze=True, structured=False):
     nx, ne, n_nn, n_soc, dim = shape
     if staged is not None:
         prob, pt, lam = pr.staged_conic_qp(pkg.splitmix_uniform, pid, *staged)
     else:
         prob, pt, lam = pr.synthetic_conic_qp(pkg.splitmix_uniform, pid, nx, ne, n_nn, n_soc, dim)
+    # structured handle (calipso_hip_create_structured): the sparsity is declared up front, only the stage blocks live on the device
     s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices,
-                   second_order_indices=prob.second_order_indices, device=device)
+                   second_order_indices=prob.second_order_indices, device=device, structure=pr.declared_structure(prob) if structured else None)
     w = np.concatenate([pt[k] for k in "xrsyzt"])
     s.set("solution", w)
     s.set("dual", lam)
     for name, v in (("central_path", 0.17), ("penalty", 52.0), ("fraction_to_boundary", 0.99)):
         s.set(name, [v])
     s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
-    if staged is not None and analyze:
+    if staged is not None and analyze and not structured:
         s.analyze_structure()
     fl = pkg.FLAGS
     s.qp_evaluate(fl["objective"] | fl["equality_constraint"] | fl["cone_constraint"], 0)
@@ -236,7 +237,7 @@ class Workload:
     """B independent instances of one configuration on this rank's GPU.  Instance 0 is the rank's single system (headline region); the B
     instances form B / G groups of G (the members of a group are stepped in lockstep through the same launches), `lanes` groups in flight."""
 
-    def __init__(self, pkg, pr, name, rank, world, device, B, G, lanes, dense_structure=False, no_stage_parallel=False, no_stage_blocks=False):
+    def __init__(self, pkg, pr, name, rank, world, device, B, G, lanes, dense_structure=False, no_stage_parallel=False, no_stage_blocks=False, dense_buffers=False):
         from calipso_jl_amd.batch import BatchSolver, shard_range
         self.pkg, self.name, self.B, self.G, self.world = pkg, name, max(0, B), max(1, G), world
         self.staged = STAGED.get(name)
@@ -249,8 +250,9 @@ class Workload:
         G_ = self.G
         order = [k for k in range(nb) if k % G_ == 0] + [k for k in range(nb) if k % G_ != 0]
         made = {}
+        self.structured = self.staged is not None and not (dense_structure or no_stage_parallel or no_stage_blocks or dense_buffers)
         for k in order:
-            inst = make_instance(pkg, pr, self.ids[k], self.shape, device, self.staged, not dense_structure)
+            inst = make_instance(pkg, pr, self.ids[k], self.shape, device, self.staged, not dense_structure, self.structured)
             # the dense host copies of the problem data (~100 MB per C3 instance) are only needed until they are on the device
             made[k] = inst if k == 0 else (None, None, None, None, inst[4])
             if k != 0:
@@ -259,7 +261,9 @@ class Workload:
         self.prob0 = made[0][0]
         self.solvers = [made[k][4] for k in range(nb)]
         self.stage_parallel = None
-        if self.staged is not None and not dense_structure and not no_stage_parallel:
+        if self.structured:
+            self.stage_parallel = dict(structured_handle=True)
+        elif self.staged is not None and not dense_structure and not no_stage_parallel:
             # the Schur complement through the multifrontal sparse LDL^T over a nested dissection of its pattern (calipso_hip_set_stage_parallel):
             # on the handle that leads each unit (its storage covers the unit's G members)
             try:
@@ -268,7 +272,9 @@ class Workload:
             except pkg.CalipsoHipError as e:                      # a front exceeds one CU's LDS: the blocked factorisation stays
                 self.stage_parallel = dict(refused=str(e))
         self.stage_blocks = None
-        if self.staged is not None and not dense_structure and not no_stage_blocks:
+        if self.structured:
+            self.stage_blocks = dict(structured_handle=True)
+        elif self.staged is not None and not dense_structure and not no_stage_blocks:
             # stage blocks (calipso_hip_set_stage_blocks): packed blocks of [gx; hx] / Lxx, block mat-vecs, Schur complement by segment pairs
             try:
                 for sv in self.solvers:
@@ -296,6 +302,7 @@ class Workload:
         if not st:
             return "dense "
         return "stage-structured (%d stages, %s treatment) " % (st[0], "dense" if dense_structure else (
+            "structured handle: stage blocks only, multifrontal LDL^T of S" if self.structured else
             ("stage blocks, " if self.stage_blocks and "z_blocks" in self.stage_blocks else "banded, ") +
             ("stage-parallel multifrontal LDL^T of S" if self.stage_parallel and "levels" in self.stage_parallel else "blocked LDL^T of S")))
 
@@ -333,6 +340,8 @@ def main():
     ap.add_argument("--dense-structure", action="store_true", help="stage-structured configs: keep the dense treatment (no calipso_hip_analyze_structure)")
     ap.add_argument("--no-stage-parallel", action="store_true", help="stage-structured configs: keep the blocked banded LDL^T of S (no calipso_hip_set_stage_parallel)")
     ap.add_argument("--no-stage-blocks", action="store_true", help="stage-structured configs: keep the dense-layout mat-vecs and Schur kernel (no calipso_hip_set_stage_blocks)")
+    ap.add_argument("--dense-buffers", action="store_true", help="stage-structured configs: handles made by calipso_hip_create + analyze_structure + set_stage_parallel + set_stage_blocks\n"
+                    "(the dense Lxx / [gx; hx] / S buffers exist beside the blocks) instead of structured handles (calipso_hip_create_structured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="measure B0(ii) (re-factorisation before every solve) instead of deriving it (~1 min more)")
     ap.add_argument("--cpu-samples", type=int, default=3)
@@ -431,7 +440,7 @@ def main():
         return elapsed, infos, dict(schur=sch, ldl=ldl, chain=chain, sd=sd, total=tot)
 
     # =================================================================== headline workload ======================================
-    wl = Workload(pkg, pr, args.config, rank, world, local_rank, args.batch, args.group, args.lanes, args.dense_structure, args.no_stage_parallel, args.no_stage_blocks)
+    wl = Workload(pkg, pr, args.config, rank, world, local_rank, args.batch, args.group, args.lanes, args.dense_structure, args.no_stage_parallel, args.no_stage_blocks, args.dense_buffers)
     B, G = wl.B, wl.G
     shape, staged = wl.shape, wl.staged
     # ---- warm-up: W steps of the single system (captures its launch graphs) and of the batched pass ----------------------------

@@ -348,6 +348,7 @@ inline BatchSc batch_of(const calipso_hip_solver* s) {
 // batched fills / copies (vectors.hip) — replace hipMemsetAsync / hipMemcpyAsync on the hot path so that groups are covered
 // sparse.hip hooks used by ldl.hip when a handle factors S through the multifrontal path
 bool sparse_is_multifrontal(const calipso_hip_sparse* sp);
+void sparse_borrow_stream(calipso_hip_sparse* sp, hipStream_t st);
 int sparse_batch(const calipso_hip_sparse* sp);
 int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, const double* S, const long long* src, int* icount);
 int sparse_solve_inplace(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, double* x);

@@ -380,6 +380,7 @@ struct calipso_hip_sparse {
     size_t cap_rhs = 0;
     int work_slots = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;      // false once a solver handle lent its own stream (sparse_borrow_stream): a stream per plan would only crowd the hardware queues
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipGraphExec_t graph_factor = nullptr;
     bool graph_tried = false, factored = false;
@@ -494,6 +495,12 @@ __global__ __launch_bounds__(256) void k_count_signs(calipso::Batch bt, const do
 namespace calipso {
 int sparse_reserve_solve(calipso_hip_sparse* s, int batch);
 bool sparse_is_multifrontal(const calipso_hip_sparse* sp) { return sp && sp->mf; }
+// a plan owned by a solver handle is only ever driven on that handle's stream: give the plan's own stream back
+void sparse_borrow_stream(calipso_hip_sparse* sp, hipStream_t st) {
+    if (!sp) return;
+    if (sp->owns_stream && sp->stream) { (void)hipStreamSynchronize(sp->stream); (void)hipStreamDestroy(sp->stream); }
+    sp->stream = st; sp->owns_stream = false;
+}
 int sparse_batch(const calipso_hip_sparse* sp) { return sp ? sp->batch : 0; }
 // gather the pattern's entries from the dense S of every instance of `bt`, factor, add the pivot signs to the instances' counters
 int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, const double* S, const long long* src, int* icount) {
@@ -572,7 +579,7 @@ const char* calipso_hip_sparse_last_error(calipso_hip_sparse* s) { return s ? s-
 int32_t calipso_hip_sparse_destroy(calipso_hip_sparse* s) {
     if (!s) return CALIPSO_OK;
     (void)hipSetDevice(s->device);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->stream && s->owns_stream) (void)hipStreamSynchronize(s->stream);
     if (s->graph_factor) (void)hipGraphExecDestroy(s->graph_factor);
     for (void* p : s->dev) if (p) (void)hipFree(p);
     for (double* p : {s->d_Aval, s->d.Lx, s->d.D, s->md.panel, s->md.upd, s->md.fpool}) if (p) (void)hipFree(p);
@@ -581,7 +588,7 @@ int32_t calipso_hip_sparse_destroy(calipso_hip_sparse* s) {
     if (s->md.uvec) (void)hipFree(s->md.uvec);
     if (s->e0) (void)hipEventDestroy(s->e0);
     if (s->e1) (void)hipEventDestroy(s->e1);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->stream && s->owns_stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return CALIPSO_OK;
 }

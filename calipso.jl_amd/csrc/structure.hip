@@ -257,6 +257,7 @@ int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_
             return calipso::check(s, e, "calipso_hip_set_stage_parallel");
         }
     }
+    sparse_borrow_stream(sp, s->stream);
     s->spS = sp; s->stage_parallel = true;
     if (info) sparse_describe(sp, info);
     return CALIPSO_OK;
