@@ -75,7 +75,9 @@ end
 Create the device handle for an existing reference `Solver` (src/solver/solver.jl:46-150).  Index sets are passed 1-based,
 exactly as `solver.indices` holds them.
 """
-function HIPSolver(solver::CALIPSO.Solver; device::Integer=0)
+# structure = (row_first, row_last, hessian_block_start) (1-based Int vectors) makes a STRUCTURED handle (calipso_hip_create_structured): only the stage
+# blocks of the problem live on the device.  `declared_structure(solver)` reads it off the methods' sparsity lists.
+function HIPSolver(solver::CALIPSO.Solver; device::Integer=0, structure=nothing)
     d = solver.dimensions
     idx = solver.indices
     nn = Vector{Int64}(idx.cone_nonnegative)
@@ -87,9 +89,16 @@ function HIPSolver(solver::CALIPSO.Solver; device::Integer=0)
         push!(ptr, length(flat))
     end
     href = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = ccall((:calipso_hip_create, lib), Int32,
-        (Int64, Int64, Int64, Int64, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ptr{Ptr{Cvoid}}),
-        d.variables, d.parameters, d.equality_dual, d.cone_dual, length(nn), nn, length(soc), ptr, flat, device, href)
+    rc = if structure === nothing
+        ccall((:calipso_hip_create, lib), Int32,
+            (Int64, Int64, Int64, Int64, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ptr{Ptr{Cvoid}}),
+            d.variables, d.parameters, d.equality_dual, d.cone_dual, length(nn), nn, length(soc), ptr, flat, device, href)
+    else
+        rf, rl, hb = Vector{Int64}(structure[1]), Vector{Int64}(structure[2]), Vector{Int64}(structure[3])
+        ccall((:calipso_hip_create_structured, lib), Int32,
+            (Int64, Int64, Int64, Int64, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}),
+            d.variables, d.parameters, d.equality_dual, d.cone_dual, length(nn), nn, length(soc), ptr, flat, device, rf, rl, length(hb), hb, href)
+    end
     rc != 0 && throw(HIPError(rc, "calipso_hip_create: $(last_error(href[]))"))
     hs = HIPSolver(href[], solver, @cfunction($(evaluate_callback), Int32, (Ptr{Cvoid}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64})))
     finalizer(x -> ccall((:calipso_hip_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), hs)
@@ -100,6 +109,28 @@ function HIPSolver(solver::CALIPSO.Solver; device::Integer=0)
     end
     length(solver.parameters) > 0 && set_field!(hs.handle, "parameters", solver.parameters)
     return hs
+end
+
+# The structure of a solver whose methods carry sparsity lists (src/solver/methods.jl; every trajectory problem): per row of [equality; cone] the extrema of
+# the columns in the Jacobian lists, and the diagonal blocks of the three Hessian lists (a new block starts where no listed entry couples to an earlier column).
+function declared_structure(solver::CALIPSO.Solver)
+    d = solver.dimensions; m = solver.methods
+    ne, nc, nx = d.equality_dual, d.cone_dual, d.variables
+    rf = fill(1, ne + nc); rl = fill(0, ne + nc); seen = falses(ne + nc)
+    for (off, list) in ((0, m.equality_jacobian_variables_sparsity), (ne, m.cone_jacobian_variables_sparsity)), (i, j) in list
+        k = off + i
+        rf[k] = seen[k] ? min(rf[k], j) : j; rl[k] = seen[k] ? max(rl[k], j) : j; seen[k] = true
+    end
+    reach = collect(1:nx)
+    for list in (m.objective_jacobian_variables_variables_sparsity, m.equality_dual_jacobian_variables_variables_sparsity, m.cone_dual_jacobian_variables_variables_sparsity), (i, j) in list
+        lo, hi = minmax(i, j); reach[lo] = max(reach[lo], hi)
+    end
+    starts = Int64[1]; r = 0
+    for j in 1:nx
+        j > starts[end] && r < j && push!(starts, j)
+        r = max(r, reach[j])
+    end
+    return (rf, rl, starts)
 end
 
 const ACTIVE = Ref{Union{Nothing,HIPSolver}}(nothing)   # fallback for callers that pass user = C_NULL to the C drivers
@@ -475,6 +506,6 @@ function allreduce_sum!(c::HIPComm, v::Vector{Float64})
 end
 
 export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPComm, comm_unique_id, gather_status, allreduce_sum!, newton_step!,
-       search_direction_nonsymmetric!, analyze_structure!, clear_structure!, set_stage_parallel!, set_stage_blocks!, kernel_times, sync_scalars!, copy_back!
+       search_direction_nonsymmetric!, analyze_structure!, clear_structure!, set_stage_parallel!, set_stage_blocks!, declared_structure, kernel_times, sync_scalars!, copy_back!
 
 end # module
