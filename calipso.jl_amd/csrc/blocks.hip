@@ -246,7 +246,7 @@ void blocks_release(calipso_hip_solver* s) {
 // refresh the packed copies from the dense buffers (on the handle's stream, right behind whatever wrote them)
 void blocks_pack(calipso_hip_solver* s, bool z, bool l) {
     StageBlocks& B = s->blocks;
-    if (!B.on) return;
+    if (!B.on || s->compact) return;                                    // (a structured handle has no dense buffers to pack from: its uploads go into the blocks directly)
     const Batch one;                                                    // the handle itself (uploads are per handle, also for members of a group)
     if (z && B.nblk) hipLaunchKernelGGL(k_blocks_pack_z, dim3(B.nblk), dim3(256), 0, s->stream, one, B.d_blk, s->d.m, s->Z, s->Lsym);
     if (l && B.nlb) hipLaunchKernelGGL(k_blocks_pack_l, dim3(B.nlb), dim3(256), 0, s->stream, one, B.d_lblk, s->d.nx, s->Lxx, s->Lsym);

@@ -94,7 +94,7 @@ int32_t calipso_hip_ldl_factorize_csc(calipso_hip_solver* s, int64_t n, const in
                                       int64_t inertia[3]) {
     if (!s || !colptr || (!rowval && colptr[n] > 1) || (!nzval && colptr[n] > 1)) return CALIPSO_ERR_ARGUMENT;
     const Dims& d = s->d;
-    if (n != d.nx || d.ne != 0 || d.nc != 0) { s->err = "calipso_hip_ldl_factorize_csc: the handle was not created by calipso_hip_ldl_create for this n"; return CALIPSO_ERR_ARGUMENT; }
+    if (n != d.nx || d.ne != 0 || d.nc != 0 || s->compact) { s->err = "calipso_hip_ldl_factorize_csc: the handle was not created by calipso_hip_ldl_create for this n"; return CALIPSO_ERR_ARGUMENT; }
     if (!csc_pattern_ok(n, colptr, rowval)) { s->err = "calipso_hip_ldl_factorize_csc: colptr must be 1-based (Julia SparseMatrixCSC) and non-decreasing, rowval in 1..n"; return CALIPSO_ERR_ARGUMENT; }
     CK(hipSetDevice(s->device));
     LdlAux& a = *aux_of(s, true);
@@ -153,7 +153,7 @@ int32_t calipso_hip_ldl_analyze_csc(calipso_hip_solver* s, int64_t n, const int6
     if (!s || !colptr || method < 0 || method > 4 || (method == 3 && !perm)) return CALIPSO_ERR_ARGUMENT;
     if (!csc_pattern_ok(n, colptr, rowval)) { s->err = "calipso_hip_ldl_analyze_csc: colptr must start at 1 and be non-decreasing, rowval in 1..n"; return CALIPSO_ERR_ARGUMENT; }
     const Dims& d = s->d;
-    if (n != d.nx || d.ne != 0 || d.nc != 0) { s->err = "calipso_hip_ldl_analyze_csc: the handle was not created by calipso_hip_ldl_create for this n"; return CALIPSO_ERR_ARGUMENT; }
+    if (n != d.nx || d.ne != 0 || d.nc != 0 || s->compact) { s->err = "calipso_hip_ldl_analyze_csc: the handle was not created by calipso_hip_ldl_create for this n"; return CALIPSO_ERR_ARGUMENT; }
     std::vector<int64_t> p((size_t)n);
     if (method == 3) std::copy(perm, perm + n, p.begin());
     else { const int rc = calipso_hip_ordering(n, colptr, rowval, method, p.data()); if (rc < 0) return rc; }

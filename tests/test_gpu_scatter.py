@@ -127,3 +127,34 @@ def test_solve_through_the_sparse_scatter_equals_the_dense_upload():
     assert pkg.solve_b(sp_s)
     assert sp_s.stats()["total_iterations"] == dense_s.stats()["total_iterations"]
     assert np.array_equal(sp_s.solution.all, dense_s.solution.all)
+    # the same solve on a STRUCTURED handle (calipso_hip_create_structured): the structure declared from the lists, the caches scattered straight into the
+    # packed blocks (no dense Lxx / [gx; hx] / S on the device); the block kernels sum in another order than the dense ones, so: same iteration count, same
+    # solution to rounding
+    first = np.ones(prob.ne, dtype=np.int64); last = np.zeros(prob.ne, dtype=np.int64)
+    for k in range(prob.ne):
+        cols = sp_s._jc[sp_s._jr == k]
+        if cols.size:
+            first[k], last[k] = cols.min() + 1, cols.max() + 1
+    reach = np.arange(prob.nx)
+    for i, j in list(zip(dg - 1, dg - 1)) + list(zip(hr - 1, hc - 1)):
+        lo, hi = min(i, j), max(i, j)
+        reach[lo] = max(reach[lo], hi)
+    starts, r = [1], -1
+    for j in range(prob.nx):
+        if j > starts[-1] - 1 and r < j:
+            starts.append(j + 1)
+        r = max(r, reach[j])
+    assert len(starts) >= 2
+    st_s = SparseSolver(prob, prob.nx, 0, prob.ne, 0, structure=dict(row_first=first, row_last=last, hessian_block_start=np.array(starts)))
+    st_s._next_which = None
+    st_s._jr, st_s._jc = sp_s._jr, sp_s._jc
+    st_s.set_sparsity("objective_jacobian_variables_variables", dg, dg)
+    st_s.set_sparsity("equality_dual_jacobian_variables_variables", hr, hc)
+    st_s.set_sparsity("equality_jacobian_variables", st_s._jr + 1, st_s._jc + 1)
+    assert st_s.device_bytes() < dense_s.device_bytes()
+    pkg.initialize_b(st_s, prob.x0)
+    assert pkg.solve_b(st_s)
+    assert st_s.stats()["total_iterations"] == dense_s.stats()["total_iterations"]
+    assert np.abs(st_s.solution.all - dense_s.solution.all).max() <= 1e-7 * max(1.0, np.abs(dense_s.solution.all).max())
+    with pytest.raises(pkg.CalipsoHipError, match="outside the structure"):
+        st_s.set_sparsity("equality_jacobian_variables", [1], [prob.nx])          # row 1 does not reach the last column
