@@ -443,12 +443,19 @@ def main():
     wl = Workload(pkg, pr, args.config, rank, world, local_rank, args.batch, args.group, args.lanes, args.dense_structure, args.no_stage_parallel, args.no_stage_blocks, args.dense_buffers)
     B, G = wl.B, wl.G
     shape, staged = wl.shape, wl.staged
-    # ---- warm-up: W steps of the single system (captures its launch graphs) and of the batched pass ----------------------------
+    # "opt.solve_block" (a tuning knob of the device factorisation, not an option of the reference): the widest diagonal block of L whose inverse
+    # is assembled for the triangular solves.  ONE system wants 1024 (10 instead of 18 dependent launches per solve); a GROUP wants 512 (its solves are
+    # bandwidth-bound and the extra assembly level costs it 0.5 ms per step).  The leader's setting governs a group's launches; a member stepped alone
+    # with the same setting gets the same bits.
+    def solve_block(handles, value):
+        if staged is None:
+            for h in handles:
+                h.set_option("solve_block", value)
+    # ---- warm-up: W steps of the single system (captures its launch graphs) ---------------------------------------------------
+    solve_block([wl.single], 1024)
     for _ in range(args.warmup):
         if not args.no_single:
             wl.single.newton_step(advance=False)
-        if wl.batch is not None:
-            wl.batched_pass()
     peak_measured = pkg.mfma_f64_peak(local_rank) if rank == 0 else None
 
     # ---- timed region 1 (headline): K sequential Newton steps of ONE system per GPU ------------------------------------------------
@@ -457,9 +464,12 @@ def main():
     if not args.no_single:
         single_elapsed, single_infos, ph = run_single(wl, K)
 
-    # ---- unit 0 alone (one group of G instances): its launches have the device to themselves => clean per-launch figures ------------
+    # ---- warm-up of the batched pass; unit 0 alone (one group of G instances): its launches have the device to themselves => clean per-launch figures --
     alone, alone_chain, unit_rate = [], [], None
     if wl.batch is not None:
+        solve_block([wl.solvers[k] for k in range(0, B, G)] if G > 1 else [], 512)
+        for _ in range(args.warmup):
+            wl.batched_pass()
         barrier(wl)
         n_alone = max(3, min(10, K))
         ts = time.perf_counter()
@@ -607,9 +617,13 @@ def main():
             w4 = Workload(pkg, pr, cname, rank, world, local_rank, args.c4_batch, args.c4_group, 2)
             for _ in range(max(1, min(args.warmup, 2))):
                 w4.single.newton_step(advance=False)
-                w4.batched_pass()
             K4 = max(3, min(K, 10))
             e1, i1, _ = run_single(w4, K4)
+            if w4.staged is None and w4.G > 1:
+                for k in range(0, w4.B, w4.G):
+                    w4.solvers[k].set_option("solve_block", 512)
+            for _ in range(max(1, min(args.warmup, 2))):
+                w4.batched_pass()
             P4 = max(1, min(P, 10))
             e2, i2, _ = run_batched(w4, P4)
             r2 = world * w4.B * P4 / e2

@@ -358,7 +358,7 @@ static bool find_field(H* s, const std::string& name, Field& f) {
     IO ios[] = {{"opt.max_outer_iterations", &o.max_outer_iterations}, {"opt.max_residual_iterations", &o.max_residual_iterations},
                 {"opt.max_residual_line_search", &o.max_residual_line_search}, {"opt.max_cone_line_search", &o.max_cone_line_search},
                 {"opt.iterative_refinement", &o.iterative_refinement}, {"opt.max_iterative_refinement", &o.max_iterative_refinement},
-                {"opt.min_iterative_refinement", &o.min_iterative_refinement}};
+                {"opt.min_iterative_refinement", &o.min_iterative_refinement}, {"opt.solve_block", &s->solve_block}};
     for (auto& io : ios)
         if (name == io.n) { f.host = (double*)io.p; f.len = -1; return true; }   // len -1 marks an int64 slot
     return false;
@@ -375,6 +375,14 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
         if (len != 1) return fail_arg(s, "scalar expected");
         const calipso::i64 v = (calipso::i64)llround(data[0]);
         if (nm == "opt.max_cone_line_search" && (v < 0 || v + 1 > CONE_MASK_TRIALS)) return fail_arg(s, "opt.max_cone_line_search must be in 0..831");
+        if (nm == "opt.solve_block") {            // not an option of the reference: a tuning knob of the device factorisation (ldl.hip)
+            if (v != 512 && v != 1024) return fail_arg(s, "opt.solve_block must be 512 or 1024");
+            if (v != s->solve_block) {            // the captured launch sequences and the layout of the inverse blocks change with it
+                CK(hipSetDevice(s->device)); CK(hipStreamSynchronize(s->stream));
+                calipso::ldl_drop_graphs(s);
+                if (!s->compact) { CK(hipMemsetAsync(s->Tinv, 0, sizeof(double) * calipso::tinv_doubles(s->d.NP), s->stream)); CK(hipStreamSynchronize(s->stream)); }
+            }
+        }
         *(calipso::i64*)f.host = v;
         return CALIPSO_OK;
     }

@@ -70,7 +70,7 @@ __global__ void k_scale_rows_by_dinv(int NP, int p, const double* __restrict__ D
 // X (NP x p, ld NP) <- S^-1 X with the block factors of ldl.hip: forward  U_k = Tinv_k B_k ; B_rest -= L[rest,k] U_k ;
 // Z = D^-1 U ; backward  V_k = Tinv_k' Z_k ; Z_above -= L[k,above]' V_k.  U and Z are NP x p scratch.
 void trsm_multi(calipso_hip_solver* s, double* X, int p, double* U, double* Zm) {
-    const int NP = s->d.NP, tb = trsv_block(NP), nb = (NP + tb - 1) / tb;      // the last block may be narrower (NP = 2560: 1024 + 1024 + 512)
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), nb = (NP + tb - 1) / tb;      // the last block may be narrower (NP = 2560: 1024 + 1024 + 512)
     if (s->stage_parallel && s->spS) {        // the factor lives in the fronts of sparse.hip (calipso_hip_set_stage_parallel): all columns through the tree together
         const BatchSc bsc = batch_of(s);
         if (bsc.b.n == 1 && sparse_solve_inplace_multi(s->spS, s->stream, bsc.b.slot[0], X + bsc.b.delta[0], NP, p) == CALIPSO_OK) return;

@@ -18,8 +18,8 @@ constexpr int TILE = 128;   // Schur-complement (SYRK) workgroup tile
 constexpr int NB = 64;      // LDL^T panel width
 constexpr int MAX_SOC_DIM = 64;
 constexpr int TRSV_BLOCK = 1024;   // widest diagonal block of L whose inverse is assembled for the triangular solves (ldl.hip)
-inline int trsv_block(int NP) { return NP < TRSV_BLOCK ? NP : TRSV_BLOCK; }
-inline size_t tinv_doubles(int NP) { const size_t tb = (size_t)trsv_block(NP); return ((size_t)NP + tb - 1) / tb * tb * tb; }   // every block stored with leading dimension tb
+inline int trsv_block(int NP, int limit = TRSV_BLOCK) { return NP < limit ? NP : limit; }   // limit: the handle's "opt.solve_block" (512 or 1024)
+inline size_t tinv_doubles(int NP) { const size_t tb = (size_t)trsv_block(NP); return ((size_t)NP + tb - 1) / tb * tb * tb; }   // every block stored with leading dimension tb (sized for the widest block: the 512-wide layout is smaller)
 constexpr int CONE_MASK_WORDS = 26;                     // icount[6..31] (slack) and icount[32..57] (slack dual): one bit per trial step size
 constexpr int CONE_MASK_TRIALS = 32 * CONE_MASK_WORDS;  // => max_cone_line_search <= 831
 
@@ -228,6 +228,8 @@ struct calipso_hip_solver {
     hipEvent_t ev[16];
     hipGraphExec_t graph_ldl = nullptr, graph_ldl_fin = nullptr, graph_trsv = nullptr;   // captured once per handle (fixed launch sequences): panel steps, factor columns + block inverses, one triangular solve
     bool graph_ldl_tried = false, graph_ldl_fin_tried = false, graph_trsv_tried = false, use_graphs = true;
+    calipso::i64 solve_block = calipso::TRSV_BLOCK;   // "opt.solve_block": widest diagonal block of L whose inverse is assembled (1024: fewest launches per solve, what one system wants; 512: a quarter of the
+                                                        // inverse-assembly flops, what a group wants — its solves are bandwidth-bound).  Members of a group use the leader's.
     double kernel_ms[4] = {0};   // [0] the panel-step launches (k_ldl_diag + k_ldl_step) of the last factorisation
     double phase_ms[9] = {0};
     // filter (filter.jl:1-13), host side

@@ -550,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_tinv_merge(Batch bt, int NP, int tb, i
 
 // the panel steps (the pivot chain): NP / 64 launches
 static void enqueue_ldl_steps(calipso_hip_solver* s) {
-    const int NP = s->d.NP, nblk = NP / NB, tb = NP < TB ? NP : TB;
+    const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
     const Batch bt = batch_of(s).b;
     const unsigned nz = bt.n;
     double* Minv = s->Ypanel;           // NP x 64: M_k of every panel (the buffer held round 2's unscaled panels)
@@ -590,7 +590,7 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
 
 // what follows the chain, fully parallel: the factor columns L = A X' D^-1 of every panel, then the inverses of the triangular-solve blocks
 static void enqueue_ldl_finish(calipso_hip_solver* s) {
-    const int NP = s->d.NP, nblk = NP / NB, tb = NP < TB ? NP : TB;
+    const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
     const Batch bt = batch_of(s).b;
     const unsigned nz = bt.n;
     const int band = s->band64 > 0 ? s->band64 : nblk;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void k_trsv_update_t(Batch bt, int NP, int k0,
 
 // x (length NP, padded entries zero) <- S^-1 x
 static void enqueue_trsv(calipso_hip_solver* s, double* x) {
-    const int NP = s->d.NP, tb = NP < TB ? NP : TB, nb = (NP + tb - 1) / tb;
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), nb = (NP + tb - 1) / tb;
     double* u = s->zf;         // forward result (unscaled), consumed by the updates
     double* z = s->zf2;        // D^-1 u, then overwritten block by block with v
     const Batch bt = batch_of(s).b;

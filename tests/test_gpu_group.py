@@ -273,3 +273,27 @@ def test_group_with_wide_second_order_cones_is_bitwise_the_single_step():
             assert same(s.data("step").all, m.data("step").all)
             assert same(s.solution.all, m.solution.all)
     g.close()
+
+
+def test_solve_block_option_keeps_group_and_single_bitwise_and_agrees_across_settings():
+    """"opt.solve_block" (512 / 1024: the widest diagonal block of L whose inverse is assembled for the triangular solves) — for each setting a member of
+    a group gets the bits of the same handle stepped alone; the two settings agree to rounding; anything else is refused"""
+    pkg = load_pkg()
+    shape = (1300, 300, 40, 20, 3)                     # NP = 1536: blocks 1024 + 512, or three of 512
+    steps = {}
+    for blockw in (1024, 512):
+        singles = [build(pkg, p, shape) for p in (31, 32)]
+        members = [build(pkg, p, shape) for p in (31, 32)]
+        for h in singles + members:
+            h.set_option("solve_block", blockw)
+        g = pkg.Group(members)
+        ref = [s.newton_step(advance=False) for s in singles]
+        got = g.newton_step(advance=False)
+        for r, q, s, m in zip(ref, got, singles, members):
+            assert r == q and r["status"] == 0
+            assert same(s.data("step").all, m.data("step").all)
+        steps[blockw] = singles[0].data("step").all.copy()
+        g.close()
+    assert np.abs(steps[512] - steps[1024]).max() <= 1e-9 * max(1.0, np.abs(steps[1024]).max())
+    with pytest.raises(pkg.CalipsoHipError, match="512 or 1024"):
+        singles[0].set_option("solve_block", 256)
