@@ -445,8 +445,8 @@ def main():
     shape, staged = wl.shape, wl.staged
     # "opt.solve_block" (a tuning knob of the device factorisation, not an option of the reference): the widest diagonal block of L whose inverse
     # is assembled for the triangular solves.  ONE system wants 1024 (10 instead of 18 dependent launches per solve); a GROUP wants 512 (its solves are
-    # bandwidth-bound and the extra assembly level costs it 0.5 ms per step).  The leader's setting governs a group's launches; a member stepped alone
-    # with the same setting gets the same bits.
+    # bandwidth-bound and the extra assembly level costs it 0.5 ms per step).  Set on every member: the first member's setting governs a group's launches, and a
+    # member stepped alone with the same setting gets the same bits.
     def solve_block(handles, value):
         if staged is None:
             for h in handles:
@@ -467,7 +467,7 @@ def main():
     # ---- warm-up of the batched pass; unit 0 alone (one group of G instances): its launches have the device to themselves => clean per-launch figures --
     alone, alone_chain, unit_rate = [], [], None
     if wl.batch is not None:
-        solve_block([wl.solvers[k] for k in range(0, B, G)] if G > 1 else [], 512)
+        solve_block(wl.solvers if G > 1 else [], 512)
         for _ in range(args.warmup):
             wl.batched_pass()
         barrier(wl)
@@ -620,8 +620,8 @@ def main():
             K4 = max(3, min(K, 10))
             e1, i1, _ = run_single(w4, K4)
             if w4.staged is None and w4.G > 1:
-                for k in range(0, w4.B, w4.G):
-                    w4.solvers[k].set_option("solve_block", 512)
+                for h4 in w4.solvers:
+                    h4.set_option("solve_block", 512)
             for _ in range(max(1, min(args.warmup, 2))):
                 w4.batched_pass()
             P4 = max(1, min(P, 10))
