@@ -1,0 +1,550 @@
+// diag_bench3.hip — harness for the 64 x 64 diagonal block of ldl.hip, 16-column rounds: one wavefront factors 16 columns in its registers
+// (lane = row, pivot-row entries by v_readlane, no LDS, no barrier inside the round), the rank-16 update of the rest runs on the matrix cores
+// (every lower 16 x 16 tile of the block lives in the MFMA accumulators of one wavefront for the whole factorisation), then X = L^-1 is
+// assembled from the 16 x 16 diagonal inverses (in-wave) by block products on the matrix cores, and M = X' D^-1 X as in diag_bench2.
+// Checked: L D L' = A, X L = I, M A = I.  Compare with profiles/r03_diag_bench2.txt ("e0 ... X": 18.3 us per launch, 13.6 us in the pivot loop).
+//   hipcc -O3 --offload-arch=gfx950 bench/diag_bench3.hip -o /tmp/diag_bench3 && /tmp/diag_bench3
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+constexpr int NB = 64, LDT = NB + 2;
+constexpr int YS = 18;          // row stride of the 16-column panel of unscaled pivot columns (k fastest)
+constexpr int CPS = NB;         // column stride of the column block handed to the next owner
+typedef double v4d __attribute__((ext_vector_type(4)));
+__device__ long long g_ts[16];
+__device__ long long g_tb[16];
+#define TB(k) do { if (threadIdx.x == 64) g_tb[k] = wall_clock64(); } while (0)
+#define TS(k) do { if (threadIdx.x == 0) g_ts[k] = wall_clock64(); } while (0)
+
+__device__ __forceinline__ double fast_rcp(double v) {
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ void lds_barrier() { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); }
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// DPP64 helpers: row_newbcast:K hands lane K of every 16-lane row to all lanes of that row, inside the multiply-add (one instruction
+// per update instead of two v_readlane + one v_fma, and no SGPR traffic)
+template <int K> __device__ __forceinline__ double bcast16(double v) {
+    double m;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(m) : "v"(v), "n"(K));
+    return m;
+}
+// software pipeline, instruction order fixed by hand (every statement is a volatile asm): the updates of pivot J on column J + 1, the broadcast of
+// the NEXT pivot, then its reciprocal chain (v_rcp_f64 + two Newton steps) threaded through the remaining updates of pivot J, which do not depend on it
+#define DPP_UPD(K)                                                                                                                      \
+    if constexpr ((K) < 16) asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                      \
+                                         "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"                           \
+                                         : "+v"(a[(K) & 15]), "+v"(g[(K) & 15]) : "v"(g[J]), "v"(nl), "v"(nlg), "n"((K) & 15))
+__device__ long long g_cyc[8];
+template <int J> struct Piv {
+    // on entry: rinv = reciprocal of pivot J
+    static __device__ __forceinline__ void run(double (&a)[16], double (&g)[16], int i, int r, double* Yk, double* Lk, double rinv) {
+        const int p = 16 * r + J;
+        if constexpr ((J & 3) == 0) { if (r == 1) { const long long c = __builtin_readcyclecounter(); if (i == 0) g_cyc[1 + J / 4] = c; } }
+        const double y = a[J];
+        const double nl = a[J] * -rinv, nlg = g[J] * -rinv;
+        if constexpr (J + 1 < 16) {
+            double dn, rn, t;
+            DPP_UPD(J + 1);
+            asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(dn) : "v"(g[J + 1]), "n"(J + 1));
+            asm volatile("s_nop 0\n\tv_rcp_f64 %0, %1" : "=v"(rn) : "v"(dn));
+            DPP_UPD(J + 2); DPP_UPD(J + 3);
+            asm volatile("s_nop 0\n\tv_fma_f64 %0, -%1, %2, 1.0" : "=v"(t) : "v"(dn), "v"(rn));
+            DPP_UPD(J + 4);
+            asm volatile("v_fmac_f64 %0, %1, %0" : "+v"(rn) : "v"(t));
+            DPP_UPD(J + 5);
+            asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(t) : "v"(dn), "v"(rn));
+            DPP_UPD(J + 6);
+            asm volatile("v_fmac_f64 %0, %1, %0" : "+v"(rn) : "v"(t));
+            DPP_UPD(J + 7); DPP_UPD(J + 8); DPP_UPD(J + 9); DPP_UPD(J + 10); DPP_UPD(J + 11); DPP_UPD(J + 12); DPP_UPD(J + 13); DPP_UPD(J + 14); DPP_UPD(J + 15);
+            Yk[i * YS + J] = y;
+            Lk[i * LDT + p] = -nl;
+            a[J] = -nl;
+            Piv<J + 1>::run(a, g, i, r, Yk, Lk, rn);
+        } else {
+            Yk[i * YS + J] = y;
+            Lk[i * LDT + p] = -nl;
+            a[J] = -nl;
+        }
+    }
+};
+
+// OWN = 2: no duplicate rows.  The pivot column is published to LDS as soon as it is final (it has to go there anyway, for the matrix-core update) and
+// read back as "its rows of the diagonal 16 x 16 block, replicated in every 16-lane row" (one ds_read_b64; the LDS queue of a wavefront is in order), which
+// is what the row-local DPP broadcast needs; the round trip hides behind the reciprocal chain of the same pivot (whose operand travels by v_readlane).
+#define DPP_UPD1(K)                                                                                                                     \
+    if constexpr ((K) < 16) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"                             \
+                                         : "+v"(a[(K) & 15]) : "v"(yrep), "v"(nl), "n"((K) & 15))
+template <int J> struct Piv2 {
+    // on entry: rinv = reciprocal of pivot J; yrep (lane 16 m + k) = entry (16 r + k, p) of column p = 16 r + J
+    static __device__ __forceinline__ void run(double (&a)[16], unsigned yk_own, unsigned yk_rep, double* Lrow, int lane0, double rinv, double yrep) {
+        const double nl = a[J] * -rinv;
+        Lrow[J] = -nl;
+        if constexpr (J + 1 < 16) {
+            double rn, t, yn;
+            DPP_UPD1(J + 1);
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(yk_own), "v"(a[J + 1]), "n"((J + 1) * 8) : "memory");
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(yn) : "v"(yk_rep), "n"((J + 1) * 8) : "memory");
+            int dlo, dhi;
+            asm volatile("s_nop 0\n\tv_readlane_b32 %0, %2, %4\n\tv_readlane_b32 %1, %3, %4" : "=&s"(dlo), "=&s"(dhi)
+                         : "v"(__double2loint(a[J + 1])), "v"(__double2hiint(a[J + 1])), "s"(lane0 + J + 1));
+            const double dn = __hiloint2double(dhi, dlo);
+            asm volatile("v_rcp_f64 %0, %1" : "=v"(rn) : "s"(dn));
+            DPP_UPD1(J + 2); DPP_UPD1(J + 3);
+            asm volatile("s_nop 0\n\tv_fma_f64 %0, -%1, %2, 1.0" : "=v"(t) : "s"(dn), "v"(rn));
+            DPP_UPD1(J + 4);
+            asm volatile("v_fmac_f64 %0, %1, %0" : "+v"(rn) : "v"(t));
+            DPP_UPD1(J + 5);
+            asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(t) : "s"(dn), "v"(rn));
+            DPP_UPD1(J + 6);
+            asm volatile("v_fmac_f64 %0, %1, %0" : "+v"(rn) : "v"(t));
+            DPP_UPD1(J + 7); DPP_UPD1(J + 8); DPP_UPD1(J + 9); DPP_UPD1(J + 10); DPP_UPD1(J + 11); DPP_UPD1(J + 12); DPP_UPD1(J + 13); DPP_UPD1(J + 14); DPP_UPD1(J + 15);
+            a[J] = -nl;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn) :: "memory");
+            Piv2<J + 1>::run(a, yk_own, yk_rep, Lrow, lane0, rn, yn);
+        } else {
+            a[J] = -nl;
+        }
+    }
+};
+
+// OWN = 3: OWN = 1 with the dependent chain of a pivot cut from ~8 to 5 operations: (1) the update of the NEXT pivot column is written as
+// fma(-(y y'), 1/d, a) with the product y y' formed one pivot earlier, so only one fma separates 1/d from the next pivot; (2) v_rcp_f64 reads the pivot
+// through DPP itself (no separate broadcast in front of it); (3) the two Newton steps as r0 (1 + e)(1 + e^2), e = 1 - d r0: fma, {fma, mul}, fma.
+// A wavefront issues in order, so the independent updates of the other columns are placed by hand into the latency gaps of that chain.
+#define DPP_UPD3(K)                                                                                                                     \
+    if constexpr ((K) < 16) asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                      \
+                                         "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"                           \
+                                         : "+v"(a[(K) & 15]), "+v"(g[(K) & 15]) : "v"(gJ), "v"(nl), "v"(nlg), "n"((K) & 15))
+template <int J> struct Piv3 {
+    // on entry: rinv = 1 / pivot J;  qa, qg = (entry (16 r + J, p - 1) of the previous pivot column) x (that column), i.e. what the previous pivot
+    // subtracts from column J once multiplied by its reciprocal — already applied by the caller: a[J], g[J] are final
+    static __device__ __forceinline__ void run(double (&a)[16], double (&g)[16], unsigned yk_own, double* Lrow, double rinv, double qa, double qg) {
+        // qa, qg here: products for column J + 1 from pivot column J (formed by the caller as soon as column J was final)
+        const double gJ = g[J];
+        double nl, nlg;
+        if constexpr (J + 1 < 16) {
+            double r0, dn, e, a1, e2, rn, qa2 = 0.0, qg2 = 0.0;
+            asm volatile("v_fma_f64 %0, -%1, %2, %0" : "+v"(g[J + 1]) : "v"(qg), "v"(rinv));                                   // chain 1
+            asm volatile("v_mul_f64 %0, %2, -%4\n\tv_mul_f64 %1, %3, -%4" : "=&v"(nl), "=&v"(nlg) : "v"(a[J]), "v"(gJ), "v"(rinv));
+            asm volatile("v_fma_f64 %0, -%1, %2, %0" : "+v"(a[J + 1]) : "v"(qa), "v"(rinv));
+            asm volatile("v_rcp_f64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r0) : "v"(g[J + 1]), "n"(J + 1));   // chain 2
+            asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(dn) : "v"(g[J + 1]), "n"(J + 1));
+            DPP_UPD3(J + 2);
+            if constexpr (J + 2 < 16) {
+                asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                             "v_fmac_f64_dpp %1, %2, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                             : "+v"(qa2), "+v"(qg2) : "v"(g[J + 1]), "v"(a[J + 1]), "n"((J + 2) & 15));
+            }
+            asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(dn), "v"(r0));                                            // chain 3
+            DPP_UPD3(J + 3); DPP_UPD3(J + 4);
+            asm volatile("v_fma_f64 %0, %2, %3, %2\n\tv_mul_f64 %1, %3, %3" : "=&v"(a1), "=&v"(e2) : "v"(r0), "v"(e));           // chain 4
+            DPP_UPD3(J + 5); DPP_UPD3(J + 6);
+            asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(rn) : "v"(a1), "v"(e2));                                               // chain 5
+            DPP_UPD3(J + 7); DPP_UPD3(J + 8); DPP_UPD3(J + 9); DPP_UPD3(J + 10); DPP_UPD3(J + 11); DPP_UPD3(J + 12); DPP_UPD3(J + 13); DPP_UPD3(J + 14); DPP_UPD3(J + 15);
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(yk_own), "v"(a[J]), "n"(J * 8) : "memory");
+            Lrow[J] = -nl;
+            a[J] = -nl;
+            Piv3<J + 1>::run(a, g, yk_own, Lrow, rn, qa2, qg2);
+        } else {
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(yk_own), "v"(a[J]), "n"(J * 8) : "memory");
+            nl = a[J] * -rinv;
+            Lrow[J] = -nl;
+            a[J] = -nl;
+        }
+    }
+};
+
+// ---- X = L^-1 assembled while the pivots run (XM = 2) ----------------------------------------------------------------------------------------
+// diagonal 16 x 16 inverse, in-wave by DPP: helper wavefront hq grows columns 4 hq .. 4 hq + 3 (lane & 15 = row; the four 16-lane rows compute the same)
+template <int J> __device__ __forceinline__ void xrr_steps(double (&x)[4], const double (&nl)[15]) {
+    if constexpr (J < 15) {
+        asm volatile("v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "v"(nl[J]), "n"(J));
+        xrr_steps<J + 1>(x, nl);
+    }
+}
+__device__ __forceinline__ void xrr_helper(int r, int hq, int i, const double* Lk, const double* dinv, double* XT, double* XTs) {
+    const int ii = i & 15;
+    double nl[15], x[4];
+    const double* Lrow = Lk + (16 * r + ii) * LDT + 16 * r;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) nl[j] = Lrow[j];                       // (all loads in flight before the first use)
+#pragma unroll
+    for (int j = 0; j < 15; ++j) nl[j] = (ii > j) ? -nl[j] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = (ii == 4 * hq + c) ? 1.0 : 0.0;
+    asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    xrr_steps<0>(x, nl);
+    if (i < 16) {
+        const double di = dinv[16 * r + ii];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { XT[(16 * r + 4 * hq + c) * LDT + 16 * r + ii] = x[c]; XTs[(16 * r + 4 * hq + c) * LDT + 16 * r + ii] = x[c] * di; }
+    }
+}
+// t += L_RK X_KC (16 x 16 blocks): lane (fr, fk) holds t[q] = (row 16 R + fk + 4 q, column 16 C + fr)
+__device__ __forceinline__ v4d blk_LX(v4d t, int Rr, int K, int Cc, const double* Lk, const double* XT, int fr, int fk) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double f = Lk[(16 * Rr + fr) * LDT + 16 * K + 4 * kk + fk];
+        const double s = XT[(16 * Cc + fr) * LDT + 16 * K + 4 * kk + fk];
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(f, s, t, 0, 0, 0);
+    }
+    return t;
+}
+__device__ __forceinline__ void blk_storeW(v4d t, int Rr, int Cc, double* XT, int fr, int fk) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) XT[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = t[q];
+}
+// X_RC = -X_RR W_RC with W still in the accumulator registers of the wavefront that formed it (t[q] = W(16 R + fk + 4 q, 16 C + fr)): the matrix
+// cores sum over k in any order, so k-step kk takes k = fk + 4 kk — lane (fr, fk) then supplies t[kk] as it stands, and the X_RR operand is read to match
+__device__ __forceinline__ void blk_XW(v4d t, int Rr, int Cc, double* XT, double* XTs, const double* dinv, int fr, int fk) {
+    v4d x = (v4d){0.0, 0.0, 0.0, 0.0};
+    double f[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f[kk] = XT[(16 * Rr + fk + 4 * kk) * LDT + 16 * Rr + fr];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(-f[kk], t[kk], x, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        XT[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = x[q];
+        XTs[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = x[q] * dinv[16 * Rr + fk + 4 * q];
+    }
+}
+// one column of a diagonal 16 x 16 inverse per wavefront (the tail: every wavefront is free)
+template <int J> __device__ __forceinline__ void xrr1_steps(double& x, const double (&nl)[15]) {
+    if constexpr (J < 15) {
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(nl[J]), "n"(J));
+        xrr1_steps<J + 1>(x, nl);
+    }
+}
+__device__ __forceinline__ void xrr_column(int r, int c, int i, const double* Lk, const double* dinv, double* XT, double* XTs) {
+    const int ii = i & 15;
+    double nl[15];
+    const double* Lrow = Lk + (16 * r + ii) * LDT + 16 * r;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) nl[j] = Lrow[j];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) nl[j] = (ii > j) ? -nl[j] : 0.0;
+    double x = (ii == c) ? 1.0 : 0.0;
+    xrr1_steps<0>(x, nl);
+    if (i < 16) { XT[(16 * r + c) * LDT + 16 * r + ii] = x; XTs[(16 * r + c) * LDT + 16 * r + ii] = x * dinv[16 * r + ii]; }
+}
+
+// XM: 0 = L and D only, 1 = + X and M.  OWN: 0 = pivot-row entries by v_readlane, 1 = by DPP row broadcast (each lane also carries the row of the
+// diagonal 16 x 16 block that sits at its position within its 16-lane row, so that every broadcast is row-local)
+template <int XM, int OWN>
+__global__ __launch_bounds__(1024) void k_diag16(int ld, double* __restrict__ S, double* __restrict__ Dx, double* __restrict__ Xout, double* __restrict__ Mout) {
+    __shared__ double Lk[NB * LDT];        // Lk[i][k] = L[i][k] (k fastest): operand panels of the matrix cores
+    __shared__ double Yk[NB * YS];         // Yk[i][j] = unscaled column 16 r + j of the current round
+    __shared__ double cp[16 * CPS];        // cp[c][i]: column block r + 1 after the update, for its owner
+    __shared__ double XT[NB * LDT];        // XT[a][r] = X[r][a]
+    __shared__ double XTs[NB * LDT];       // ... scaled by 1 / d[r]
+    __shared__ double Tw[32 * 34];         // level-2 intermediate of the inverse
+    __shared__ double dpiv[NB], dinv[NB];
+    const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
+    const int R = w >> 2, C = w & 3, fr = i & 15, fk = i >> 4;
+    // tile (R, C) of the block in accumulator layout: acc[q] = A[16 R + fr][16 C + fk + 4 q]
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (R >= C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = S[(16 * R + fr) + (size_t)(16 * C + fk + 4 * q) * ld];
+    }
+    v4d xacc = (v4d){0.0, 0.0, 0.0, 0.0};     // (XM = 2) a block product of the inverse carried across phases
+    TS(0);
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        if (C == r && R >= r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cp[(fk + 4 * q) * CPS + 16 * R + fr] = acc[q];
+        }
+        lds_barrier();
+        TB(2 * r);
+        if (r == 1 && tid == 5 * 64) g_ts[5] = wall_clock64();
+        if (w == 5 * r && OWN == 1) {
+            double a[16], g[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { a[c] = cp[c * CPS + i]; g[c] = cp[c * CPS + 16 * r + (i & 15)]; }
+            { const double d0 = bcast16<0>(g[0]); Piv<0>::run(a, g, i, r, Yk, Lk, fast_rcp(d0)); }
+            if (r == 1) { const long long c = __builtin_readcyclecounter(); if (i == 0) g_cyc[5] = c; }
+        }
+        if (w == 5 * r && OWN == 2) {
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = cp[c * CPS + i];
+            const double y0 = cp[16 * r + (i & 15)];
+            Yk[i * YS] = a[0];
+            const double d0 = readlane_d(a[0], 16 * r);
+            Piv2<0>::run(a, (unsigned)(uintptr_t)(Yk + i * YS), (unsigned)(uintptr_t)(Yk + (16 * r + (i & 15)) * YS), Lk + i * LDT + 16 * r, 16 * r, fast_rcp(d0), y0);
+        }
+        if (w == 5 * r && OWN == 3) {
+            double a[16], g[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { a[c] = cp[c * CPS + i]; g[c] = cp[c * CPS + 16 * r + (i & 15)]; }
+            const double d0 = bcast16<0>(g[0]);
+            double qa = 0.0, qg = 0.0;
+            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %2, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "+v"(qa), "+v"(qg) : "v"(g[0]), "v"(a[0]));
+            Piv3<0>::run(a, g, (unsigned)(uintptr_t)(Yk + i * YS), Lk + i * LDT + 16 * r, fast_rcp(d0), qa, qg);
+        }
+        if (w == 5 * r && OWN == 0) {
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = cp[c * CPS + i];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int p = 16 * r + j;
+                const double d = readlane_d(a[j], p);
+                const double rinv = fast_rcp(d);
+                Yk[i * YS + j] = a[j];
+                const double l = a[j] * rinv;
+                Lk[i * LDT + p] = l;
+#pragma unroll
+                for (int k = j + 1; k < 16; ++k) a[k] -= l * readlane_d(a[j], 16 * r + k);
+                a[j] = l;
+                if (i == 0) { dpiv[p] = d; dinv[p] = rinv; }
+            }
+        }
+        if (OWN != 0 && w == 5 * r && i < 16) { const double d = Yk[(16 * r + i) * YS + i]; dpiv[16 * r + i] = d; dinv[16 * r + i] = fast_rcp(d); }
+        if (XM == 2) {
+            // phase a of round r (the owner, wavefront 5 r, runs on SIMD r: nothing else is put there): the diagonal inverse of the previous round and the
+            // block products whose operands are visible
+            if (r == 1) { const int hq = w == 2 ? 0 : w == 3 ? 1 : w == 6 ? 2 : w == 7 ? 3 : -1; if (hq >= 0) xrr_helper(0, hq, i, Lk, dinv, XT, XTs); }
+            if (r == 2) { const int hq = w == 1 ? 0 : w == 3 ? 1 : w == 4 ? 2 : w == 8 ? 3 : -1; if (hq >= 0) xrr_helper(1, hq, i, Lk, dinv, XT, XTs); }
+            if (r == 3) {
+                const int hq = w == 1 ? 0 : w == 2 ? 1 : w == 6 ? 2 : w == 4 ? 3 : -1;
+                if (hq >= 0) xrr_helper(2, hq, i, Lk, dinv, XT, XTs);
+                if (w == 9) xacc = blk_LX(xacc, 2, 1, 0, Lk, XT, fr, fk);                                                                              // W_20 += L_21 X_10
+                if (w == 8) { xacc = blk_LX(xacc, 3, 0, 0, Lk, XT, fr, fk); xacc = blk_LX(xacc, 3, 1, 0, Lk, XT, fr, fk); }                           // W_30' = L_30 X_00 + L_31 X_10
+                if (w == 12) xacc = blk_LX(xacc, 3, 1, 1, Lk, XT, fr, fk);                                                                            // W_31' = L_31 X_11
+            }
+        }
+        if (r == 1 && tid == 5 * 64) g_ts[6] = wall_clock64();
+        lds_barrier();
+        TB(2 * r + 1);
+        if (r == 1 && tid == 10 * 64) g_ts[7] = wall_clock64();
+        if (R >= C && C > r) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double yf = Yk[(16 * C + fr) * YS + 4 * kk + fk];
+                const double lf = Lk[(16 * R + fr) * LDT + 16 * r + 4 * kk + fk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-yf, lf, acc, 0, 0, 0);
+            }
+        }
+        if (XM == 2) {
+            // phase b of round r (the tile wavefronts update)
+            if (r == 2) {
+                if (w == 7) { v4d t = blk_LX((v4d){0.0, 0.0, 0.0, 0.0}, 1, 0, 0, Lk, XT, fr, fk); blk_XW(t, 1, 0, XT, XTs, dinv, fr, fk); }               // X_10 = -X_11 (L_10 X_00)
+                if (w == 9) xacc = blk_LX(xacc, 2, 0, 0, Lk, XT, fr, fk);                                                                             // W_20' = L_20 X_00
+                if (w == 4) xacc = blk_LX(xacc, 2, 1, 1, Lk, XT, fr, fk);                                                                             // W_21 = L_21 X_11
+            }
+        }
+        if (r == 1 && tid == 10 * 64 && acc[0] != 1.234e300) g_ts[8] = wall_clock64();
+    }
+    TS(1);
+    if (XM == 2) {
+        if (w != 9 && w != 4 && w != 7) xrr_column(3, w, i, Lk, dinv, XT, XTs);
+        if (w == 0) xrr_column(3, 9, i, Lk, dinv, XT, XTs);
+        if (w == 1) xrr_column(3, 4, i, Lk, dinv, XT, XTs);
+        if (w == 2) xrr_column(3, 7, i, Lk, dinv, XT, XTs);
+        if (w == 9) blk_XW(xacc, 2, 0, XT, XTs, dinv, fr, fk);
+        if (w == 4) blk_XW(xacc, 2, 1, XT, XTs, dinv, fr, fk);
+        if (w == 7) xacc = blk_LX(xacc, 3, 2, 2, Lk, XT, fr, fk);                                                                                     // W_32 = L_32 X_22
+        lds_barrier();
+        TB(8);
+        if (w == 8) { xacc = blk_LX(xacc, 3, 2, 0, Lk, XT, fr, fk); blk_XW(xacc, 3, 0, XT, XTs, dinv, fr, fk); }
+        if (w == 12) { xacc = blk_LX(xacc, 3, 2, 1, Lk, XT, fr, fk); blk_XW(xacc, 3, 1, XT, XTs, dinv, fr, fk); }
+        if (w == 7) blk_XW(xacc, 3, 2, XT, XTs, dinv, fr, fk);
+        lds_barrier();
+        TB(9);
+    }
+    if (XM == 1) {
+        // the four 16 x 16 diagonal inverses, in-wave: wavefront (r = R, hq = C) grows columns 4 hq .. 4 hq + 3 of X_rr (lanes 0..15 = rows)
+        {
+            const int r = R, hq = C, ii = i & 15;
+            double lj[16], x[4];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) lj[j] = Lk[(16 * r + ii) * LDT + 16 * r + j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = (ii == 4 * hq + c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < 15; ++j) {
+                const double l = (ii > j) ? lj[j] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] -= l * readlane_d(x[c], j);
+            }
+            if (i < 16) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) XT[(16 * r + 4 * hq + c) * LDT + 16 * r + ii] = x[c];
+            }
+            lds_barrier();           // (also: the last round's reciprocal pivots are visible)
+            if (i < 16) {
+                const double di = dinv[16 * r + ii];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) XTs[(16 * r + 4 * hq + c) * LDT + 16 * r + ii] = x[c] * di;
+            }
+        }
+        // level 1: W_10 = L_10 X_00, W_32 = L_32 X_22 (left in the places of X_10, X_32), then X = -X_RR W
+        if (w == 0 || w == 1) {
+            const int Rr = w == 0 ? 1 : 3, Cc = Rr - 1;
+            v4d t = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double f = Lk[(16 * Rr + fr) * LDT + 16 * Cc + 4 * kk + fk];
+                const double s = XT[(16 * Cc + fr) * LDT + 16 * Cc + 4 * kk + fk];
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(f, s, t, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) XT[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = t[q];
+        }
+        lds_barrier();
+        if (w == 0 || w == 1) {
+            const int Rr = w == 0 ? 1 : 3, Cc = Rr - 1;
+            v4d t = (v4d){0.0, 0.0, 0.0, 0.0};
+            double f[4], s[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                f[kk] = XT[(16 * Rr + 4 * kk + fk) * LDT + 16 * Rr + fr];
+                s[kk] = XT[(16 * Cc + fr) * LDT + 16 * Rr + 4 * kk + fk];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(-f[kk], s[kk], t, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                XT[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = t[q];
+                XTs[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = t[q] * dinv[16 * Rr + fk + 4 * q];
+            }
+        }
+        lds_barrier();
+        // level 2: T = L_[23][01] X_[01][01] (four tiles, Tw[c][k]: c = column 0..31, k = row - 32), then X_[23][01] = -X_[23][23] T
+        if (w < 4) {
+            const int Rr = 2 + (w >> 1), Cc = w & 1;
+            v4d t = (v4d){0.0, 0.0, 0.0, 0.0};
+            for (int K = Cc; K < 2; ++K) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double f = Lk[(16 * Rr + fr) * LDT + 16 * K + 4 * kk + fk];
+                    const double s = XT[(16 * Cc + fr) * LDT + 16 * K + 4 * kk + fk];
+                    t = __builtin_amdgcn_mfma_f64_16x16x4f64(f, s, t, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Tw[(16 * Cc + fr) * 34 + 16 * (Rr - 2) + fk + 4 * q] = t[q];
+        }
+        lds_barrier();
+        if (w < 4) {
+            const int Rr = 2 + (w >> 1), Cc = w & 1;
+            v4d t = (v4d){0.0, 0.0, 0.0, 0.0};
+            for (int K = 2; K <= Rr; ++K) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double f = XT[(16 * K + 4 * kk + fk) * LDT + 16 * Rr + fr];
+                    const double s = Tw[(16 * Cc + fr) * 34 + 16 * (K - 2) + 4 * kk + fk];
+                    t = __builtin_amdgcn_mfma_f64_16x16x4f64(-f, s, t, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                XT[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = t[q];
+                XTs[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = t[q] * dinv[16 * Rr + fk + 4 * q];
+            }
+        }
+        lds_barrier();
+    }
+    TS(2);
+    if (XM) {
+        const int wa = R, wb = C;
+        v4d m = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int kk = 4 * (wa > wb ? wa : wb); kk < NB / 4; ++kk) {
+            const double xa = XTs[(wa * 16 + fr) * LDT + 4 * kk + fk];
+            const double xb = XT[(wb * 16 + fr) * LDT + 4 * kk + fk];
+            m = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, m, 0, 0, 0);
+        }
+        TS(3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Mout[(wb * 16 + fr) + (size_t)(wa * 16 + fk + 4 * q) * NB] = m[q];
+        // X to global: thread (i, w) stores rows i of columns 4 w .. 4 w + 3 (zeros above the diagonal)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * w + c;
+            Xout[i + (size_t)k * NB] = (i >= k) ? XT[k * LDT + i] : 0.0;
+        }
+    }
+    if (tid < NB) Dx[tid] = dpiv[tid];
+    // the strictly lower L of the block from its LDS copy: thread (i, w) stores rows i of columns 4 w .. 4 w + 3
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int k = 4 * w + c; if (i > k) S[i + (size_t)k * ld] = Lk[i * LDT + k]; }
+    TS(4);
+}
+
+template <typename K>
+void run(const char* name, K kern, const std::vector<double>& A0, bool with_x) {
+    const int ld = NB, reps = 200;
+    double *S, *D, *X, *M;
+    hipMalloc(&S, sizeof(double) * NB * NB); hipMalloc(&D, sizeof(double) * NB); hipMalloc(&X, sizeof(double) * NB * NB); hipMalloc(&M, sizeof(double) * NB * NB);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipMemcpy(S, A0.data(), sizeof(double) * NB * NB, hipMemcpyHostToDevice);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(1), dim3(1024), 0, 0, ld, S, D, X, M);   // (repeats refactor garbage: timing only)
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    hipMemcpy(S, A0.data(), sizeof(double) * NB * NB, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), 0, 0, ld, S, D, X, M);
+    std::vector<double> L(NB * NB), d(NB), Xh(NB * NB), Mh(NB * NB);
+    hipMemcpy(L.data(), S, sizeof(double) * NB * NB, hipMemcpyDeviceToHost);
+    hipMemcpy(d.data(), D, sizeof(double) * NB, hipMemcpyDeviceToHost);
+    hipMemcpy(Xh.data(), X, sizeof(double) * NB * NB, hipMemcpyDeviceToHost);
+    hipMemcpy(Mh.data(), M, sizeof(double) * NB * NB, hipMemcpyDeviceToHost);
+    long long h[16]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts), sizeof(h));
+    double err = 0, errx = 0, errm = 0;
+    for (int i = 0; i < NB; ++i) for (int j = 0; j <= i; ++j) {
+        double s = 0;
+        for (int k = 0; k <= j; ++k) s += (i == k ? 1.0 : L[i + k * NB]) * d[k] * (j == k ? 1.0 : L[j + k * NB]);
+        err = fmax(err, fabs(s - A0[i + j * NB]));
+        if (with_x) { double t = 0; for (int k = j; k <= i; ++k) t += Xh[i + k * NB] * (k == j ? 1.0 : L[k + j * NB]); errx = fmax(errx, fabs(t - (i == j ? 1.0 : 0.0))); }
+    }
+    if (with_x) for (int i = 0; i < NB; ++i) for (int j = 0; j < NB; ++j) { double t = 0; for (int k = 0; k < NB; ++k) t += Mh[i + k * NB] * A0[k + j * NB]; errm = fmax(errm, fabs(t - (i == j ? 1.0 : 0.0))); }
+    printf("%-58s %6.2f us/launch | pivots %5.2f  X %4.2f  M %4.2f  stores %4.2f us | |LDL'-A| %.1e |XL-I| %.1e |MA-I| %.1e\n", name, best * 1e3 / reps,
+           (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0, err, errx, errm);
+    { long long b[16]; hipMemcpyFromSymbol(b, HIP_SYMBOL(g_tb), sizeof(b));
+      printf("        barriers (us since the first):"); for (int k = 1; k < 10; ++k) printf(" %.2f", (b[k] - b[0]) / 100.0); printf("\n"); }
+    { long long c[8]; hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cyc), sizeof(c));
+      printf("        owner (OWN = 1) cycles: loads %lld, pivots 0-3 %lld, 4-7 %lld, 8-11 %lld, 12-15 %lld\n", c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4]); }
+    printf("        round 1: barrier 1 -> owner done %.2f us, -> barrier 2 released %.2f us, -> tile (2,2) updated %.2f us\n", (h[6] - h[5]) / 100.0, (h[7] - h[6]) / 100.0, (h[8] - h[7]) / 100.0);
+    hipFree(S); hipFree(D); hipFree(X); hipFree(M);
+}
+
+int main() {
+    std::vector<double> A(NB * NB);
+    unsigned s = 12345;
+    for (int i = 0; i < NB; ++i) for (int j = 0; j <= i; ++j) {
+        s = s * 1664525u + 1013904223u;
+        double v = ((s >> 8) & 0xffff) / 65536.0 - 0.5;
+        A[i + j * NB] = A[j + i * NB] = (i == j) ? 8.0 + v : v * 0.2;
+    }
+    run("r16: 16-column rounds, matrix-core update, L and D only", k_diag16<0, 0>, A, false);
+    run("r16: + X by block products, M", k_diag16<1, 0>, A, true);
+    run("r16 dpp, rows replicated through LDS: L and D only", k_diag16<0, 2>, A, false);
+    run("r16 dpp, rows replicated through LDS: + X, M", k_diag16<1, 2>, A, true);
+    run("r16 dpp, short chain: L and D only", k_diag16<0, 3>, A, false);
+    run("r16 dpp, short chain: + X, M", k_diag16<1, 3>, A, true);
+    run("r16 dpp: L and D only", k_diag16<0, 1>, A, false);
+    run("r16 dpp: + X assembled alongside, M", k_diag16<2, 1>, A, true);
+    run("r16 dpp: + X by block products, M", k_diag16<1, 1>, A, true);
+    return 0;
+}

@@ -4,8 +4,8 @@ tile 0 + the diagonal block (csrc/ldl.hip built with -DCALIPSO_LDL_TRACE into li
   gap     end of the previous launch's chain workgroup -> entry of this launch's   (kernel boundary)
   formZ   entry -> Z = A(k+1,k) M_k in LDS (one global round trip + 16 MFMAs)
   tile    -> tile (k+1,k+1) updated and handed to the diagonal block
-  ldl     -> the 64 pivots (16 four-column mini-panels)
-  inv     -> pivots counted, L stored, X = L^-1 (blocked inversion)
+  ldl     -> the 64 pivots (four rounds of 16 columns; most of X = L^-1 is assembled meanwhile)
+  inv     -> the last blocks of X = L^-1 (two short phases)
   M       -> M = X' D^-1 X on the matrix cores
   stores  -> D, inertia counts, L, X, M issued to global memory"""
 import ctypes as C
@@ -45,7 +45,4 @@ for k in range(1, nb):
         print("%4d " % k + " ".join("%7.2f" % v for v in rows[-1]))
 m = np.mean(np.array(rows), axis=0)
 print("mean " + " ".join("%7.2f" % v for v in m))
-w = t[1:nb, :].astype(float)
-print("wavefront 9 around mini-panel 9 (mean over blocks): barrier 8 -> its update done %.2f us, -> its four pivots factored and published %.2f us, -> barrier 9 released %.2f us" % (
-    np.mean(w[:, 9] - w[:, 8]) / 100.0, np.mean(w[:, 10] - w[:, 9]) / 100.0, np.mean(w[:, 11] - w[:, 10]) / 100.0))
 print("chain: block 0 start .. last block end = %.1f us over %d panel steps; sum of means per step %.2f us" % (us(t[nb - 1, 5], t[0, 2]), nb - 1, float(np.sum(m[:7]))))

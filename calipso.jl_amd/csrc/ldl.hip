@@ -36,31 +36,36 @@ constexpr int TB = 1024;           // largest triangular-solve block; the block 
 constexpr int LDT = NB + 2;        // LDS leading dimension of a k-fastest 64-deep operand panel
 
 // ---- diagonal block ---------------------------------------------------------------------------------------------------------
-// The 2500 sequential pivots of S are the critical path of the factorisation; this kernel is tuned with the stand-alone
-// harness bench/diag_bench.hip (variant v8; profiles/r02_diag_bench.txt has the timelines of the alternatives).  1024 threads: lane
-// i = tid & 63 is a ROW of the block, wavefront cg = tid >> 6 owns the four CONSECUTIVE columns 4 cg .. 4 cg + 3 in registers.
-//   phase 1  LDL^T in 16 mini-panels of four columns: the owner wavefront factors its four columns alone — the pivot entries it needs
-//            from other rows are in its own lanes and travel by v_readlane, no barrier — publishes the four unscaled columns and their
-//            reciprocal pivots to a double-buffered LDS panel, ONE workgroup barrier, and every later wavefront applies the rank-4 update
-//            to its own columns.  16 barriers per block instead of 64 (one per column in round 1); a single wavefront issues one dependent
-//            instruction every ~13 cycles, so what counts on the critical path is the instruction count of the wave that holds the
-//            next pivot: ~50 (mini-panel) + ~40 (update) per four columns instead of 4 x 30 + 4 barriers.  10.6 us instead of 15.
-//            Round 3: the wavefronts that are done with the LDL^T (cg <= P) apply G_P^-1 to their columns of X = L11^-1 in the same step
-//            (v_readlane inside the wave), so the inverse is complete when the last pivot is (round 2: a separate phase 2, 7 us per block).
-//   phase 2  M = X' D^-1 X on the matrix cores (what the next panel step multiplies the raw panel with), then ALL global stores: D, L, X, M.
+// The 2500 sequential pivots of S are the critical path of the factorisation; this block is tuned with the stand-alone harnesses
+// bench/diag_bench3.hip (this design; profiles/r03_diag_bench3.txt) and bench/diag_bench2.hip / diag_bench.hip (its predecessors: four-column
+// mini-panels exchanged through LDS, one barrier each; 13.5 us in the pivot loop).  1024 threads = 16 wavefronts; wavefront (R, C) = (w >> 2, w & 3)
+// holds the 16 x 16 tile (R, C) of the block in the accumulator layout of v_mfma_f64_16x16x4 for the whole factorisation (exactly what the
+// trailing update of k_ldl_step leaves in its registers: no hand-over).  Four ROUNDS of 16 columns:
+//   [A] the tiles of column block r go to LDS (cp), barrier;
+//   [owner] wavefront (r, r) takes the 16 columns with lane = row and factors them alone, in registers: no LDS traffic and no barrier between
+//       pivots.  The pivot-row entry a rank-1 update needs is fused into the multiply-add by DPP (v_fmac_f64_dpp row_newbcast: lane K of
+//       every 16-lane row to all lanes of that row) — for that, the pivot column is read back from LDS, where it goes anyway, as "its rows of
+//       the diagonal 16 x 16 block, replicated in every 16-lane row".  The reciprocal chain of the next pivot (v_rcp_f64 + two Newton steps)
+//       is threaded by hand through the updates of the current one (a wavefront issues in order).  Unscaled columns (Yk), L (Lk) and the
+//       pivots go to LDS, barrier;
+//   [C] the tiles right of the block take the rank-16 update on the matrix cores (4 MFMAs per tile).
+// X = L11^-1 is assembled meanwhile by the wavefronts that have nothing to do: the 16 x 16 diagonal inverses in-wave by DPP (four helper
+// wavefronts, kept off the SIMD of the owner), the blocks below by products on the matrix cores, X_RC = -X_RR (sum_K L_RK X_KC), with the
+// inner sum handed from one MFMA chain to the next in registers (the k order of an MFMA is free).  Two short phases remain after the last
+// pivot; then M = X' D^-1 X on the matrix cores (what the next panel step multiplies the raw panel with) and ALL global stores: D, L, X, M.
 // Nothing is written to global memory before the last barrier (a pending store would make a barrier wait on memory).
+// Measured (bench/diag_bench3.hip, one block alone): 14.3 us per launch against 18.2 for the four-column design.
 constexpr int DIAG_THREADS = 1024;
-constexpr int LDD = NB + 1;        // stride of the 64 x 64 tile handed to the diagonal block through LDS
+constexpr int YS = 18;             // row stride of the 16-column panel of unscaled pivot columns (k fastest; 36 dwords: conflict-free fragment reads)
+constexpr int CPS = NB;            // column stride of the column block handed to the next owner
 
 // Optional timeline of the pivot chain (build with -DCALIPSO_LDL_TRACE; bench/ldl_trace.py reads it through calipso_hip_debug_ldl_trace):
 // 100 MHz wall-clock stamps of the workgroup that carries tile 0 + the diagonal block, instance 0, per panel step.
 #ifdef CALIPSO_LDL_TRACE
 __device__ long long g_ldl_trace[64 * 16];
 #define LDL_STAMP(step, slot) do { if (threadIdx.x == 0 && (step) < 64) g_ldl_trace[(step) * 16 + (slot)] = wall_clock64(); } while (0)
-#define LDL_STAMP_IF(cond, step, slot) do { if ((cond) && (step) < 64) g_ldl_trace[(step) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define LDL_STAMP(step, slot) do { } while (0)
-#define LDL_STAMP_IF(cond, step, slot) do { } while (0)
 #endif
 
 __device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton steps (pivots are normal numbers; 0 -> inf as 1/0)
@@ -70,135 +75,227 @@ __device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton
     return r;
 }
 
-// LDS carve (doubles): XT | XTs | ypan[2][4][NB] | rpan[2][4] | dpiv[NB] | dinv[NB].  When the block arrives through LDS (fused with the trailing update)
-// it sits at the start (row-major, stride LDD) and is consumed into registers before anything is written.
-constexpr int DIAG_LDS_DOUBLES = 2 * NB * LDT + 2 * 4 * NB + 8 + 2 * NB;
+// LDS carve (doubles): Lk | Yk | cp | XT | XTs | dpiv | dinv
+constexpr int DIAG_LDS_DOUBLES = 3 * NB * LDT + NB * YS + 16 * CPS + 2 * NB;
 
 __device__ __forceinline__ void lds_barrier_all() {                  // workgroup barrier that orders LDS traffic only (global stores stay in flight)
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
 }
-__device__ __forceinline__ double readlane_d(double v, int lane) {     // lane: wave-uniform
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
+// -- the owner of a round: 16 columns in registers.  Every statement is a volatile asm, so the order below IS the issue order: the updates of pivot J
+// on column J + 1, the broadcast of the NEXT pivot, then its reciprocal chain threaded through the remaining updates of pivot J.  DPP reads of a VGPR
+// need two wait states after a VALU write of it: only the pivot broadcast follows its producer that closely (s_nop 1 inside its string).
+template <int K> __device__ __forceinline__ double bcast16(double v) {
+    double m;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(m) : "v"(v), "n"(K));
+    return m;
 }
-typedef double v2d __attribute__((ext_vector_type(2)));
-template <bool FROM_LDS>
-__device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
-                                           double* __restrict__ Tinv, double* __restrict__ Minv, int* __restrict__ icount) {
-    constexpr int WAVES = 16, CPW = 4;
-    double* XT = smem;                       // XT[a][r] = X[r][a], stride LDT: the matrix-core fragments of M read it without bank conflicts
-    double* XTs = XT + NB * LDT;             // XT scaled by the reciprocal pivot of row r
-    double (*ypan)[4][NB] = reinterpret_cast<double (*)[4][NB]>(XTs + NB * LDT);   // [2][4][NB] unscaled pivot columns of a mini-panel
-    double (*rpan)[4] = reinterpret_cast<double (*)[4]>(XTs + NB * LDT + 8 * NB);  // [2][4] their reciprocal pivots
-    double* dpiv = XTs + NB * LDT + 8 * NB + 8;                                     // the 64 pivots
-    double* dinv = dpiv + NB;                                                       // and their reciprocals
-    const int tid = threadIdx.x, i = tid & 63, cg = tid >> 6;
-    double a[CPW];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        const int k = 4 * cg + c;
-        if (FROM_LDS) a[c] = (i >= k) ? smem[i * LDD + k] : 0.0;
-        else a[c] = (i >= k) ? S[(k0 + i) + (size_t)(k0 + k) * NP] : 0.0;
-    }
-    if (FROM_LDS) __syncthreads();   // every lane has its entries before the region is reused
-    LDL_STAMP(k0 / NB, 2);
-    // X = L11^-1 grows alongside: L = G_0 G_1 ... G_15 (G_P = identity + the four columns of mini-panel P), so X = G_15^-1 ... G_0^-1 and
-    // G_P^-1 is applied from the left as soon as mini-panel P is published:  X[i][:] -= L[i][4P+j] X[4P+j][:]  for j = 0..3 in turn, i > 4P+j.
-    // Wavefront cg holds columns 4 cg .. 4 cg + 3 of X (lane = row, like A); row 4P+j of its columns sits in its own lane 4P+j (v_readlane).
-    // Only columns <= 4P+3 are touched by G_P^-1, i.e. wavefronts cg <= P — exactly the ones with nothing left to do in the LDL^T — so the
-    // inverse costs the pivot chain nothing (round 2 formed it afterwards: 16 x 16 forward substitutions + two merge levels, 7 us per block).
-    double x[CPW], lfin[CPW];                 // lfin: the finished columns of L of this wavefront (they go to global memory at the very end)
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) { x[c] = (i == 4 * cg + c) ? 1.0 : 0.0; lfin[c] = 0.0; }
-#pragma unroll 1
-    for (int P = 0; P < WAVES; ++P) {
-        const int buf = P & 1;
-        if (cg == P) {
-            // the owner's four columns, alone: rows <= the pivot only collect garbage that is never read
-            double y[4], rinv[4], dv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dv[j] = readlane_d(a[j], 4 * P + j);
-                rinv[j] = fast_rcp(dv[j]);
-                y[j] = a[j];
-                const double li = a[j] * rinv[j];
-                lfin[j] = li;
-#pragma unroll
-                for (int k = j + 1; k < 4; ++k) a[k] -= li * readlane_d(a[j], 4 * P + k);    // A[4P+k][4P+j]: the symmetric partner of the pivot row's entry
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ypan[buf][j][i] = y[j];
-            if (i < 4) {
-                const double dd = i == 0 ? dv[0] : i == 1 ? dv[1] : i == 2 ? dv[2] : dv[3], rr = i == 0 ? rinv[0] : i == 1 ? rinv[1] : i == 2 ? rinv[2] : rinv[3];
-                dpiv[4 * P + i] = dd; dinv[4 * P + i] = rr; rpan[buf][i] = rr;
-            }
-            LDL_STAMP_IF(i == 0 && cg == 9, k0 / NB, 10);
+#define DPP_UPD(K)                                                                                                                      \
+    if constexpr ((K) < 16) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"                             \
+                                         : "+v"(a[(K) & 15]) : "v"(yrep), "v"(nl), "n"((K) & 15))
+template <int J> struct Pivot {
+    // on entry: rinv = reciprocal of pivot J; yrep (lane 16 m + k) = entry (16 r + k, p) of the pivot column p = 16 r + J — its rows of the diagonal
+    // 16 x 16 block, replicated in every 16-lane row: what the row-local broadcast needs
+    static __device__ __forceinline__ void run(double (&a)[16], unsigned yk_own, unsigned yk_rep, double* __restrict__ Lrow, int lane0, double rinv, double yrep) {
+        const double nl = a[J] * -rinv;
+        Lrow[J] = -nl;
+        if constexpr (J + 1 < 16) {
+            double rn, t, yn;
+            int dlo, dhi;
+            DPP_UPD(J + 1);
+            // column J + 1 is final: publish it (the matrix-core update reads it from LDS anyway) and read it back replicated (one ds_read_b64; the LDS
+            // queue of a wavefront is in order); the round trip hides behind the reciprocal chain, whose operand travels by v_readlane
+            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(yk_own), "v"(a[J + 1]), "n"((J + 1) * 8) : "memory");
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(yn) : "v"(yk_rep), "n"((J + 1) * 8) : "memory");
+            asm volatile("s_nop 0\n\tv_readlane_b32 %0, %2, %4\n\tv_readlane_b32 %1, %3, %4" : "=&s"(dlo), "=&s"(dhi)
+                         : "v"(__double2loint(a[J + 1])), "v"(__double2hiint(a[J + 1])), "s"(lane0 + J + 1));
+            const double dn = __hiloint2double(dhi, dlo);
+            asm volatile("v_rcp_f64 %0, %1" : "=v"(rn) : "s"(dn));
+            DPP_UPD(J + 2); DPP_UPD(J + 3);
+            asm volatile("s_nop 0\n\tv_fma_f64 %0, -%1, %2, 1.0" : "=v"(t) : "s"(dn), "v"(rn));
+            DPP_UPD(J + 4);
+            asm volatile("v_fmac_f64 %0, %1, %0" : "+v"(rn) : "v"(t));
+            DPP_UPD(J + 5);
+            asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(t) : "s"(dn), "v"(rn));
+            DPP_UPD(J + 6);
+            asm volatile("v_fmac_f64 %0, %1, %0" : "+v"(rn) : "v"(t));
+            DPP_UPD(J + 7); DPP_UPD(J + 8); DPP_UPD(J + 9); DPP_UPD(J + 10); DPP_UPD(J + 11); DPP_UPD(J + 12); DPP_UPD(J + 13); DPP_UPD(J + 14); DPP_UPD(J + 15);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn) :: "memory");
+            Pivot<J + 1>::run(a, yk_own, yk_rep, Lrow, lane0, rn, yn);
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): only LDS traffic is outstanding here
-        __builtin_amdgcn_s_barrier();
-        LDL_STAMP_IF(i == 0 && cg == 9 && P == 8, k0 / NB, 8);
-        LDL_STAMP_IF(i == 0 && cg == 9 && P == 9, k0 / NB, 11);
-        // (every load is issued before any is used: a load inside the `i > pivot` conditional turns into exec-masked blocks with an LDS round
-        // trip each).  Measured alternatives (bench/diag_bench2.hip, profiles/r03_diag_bench2.txt): 16-byte (y, l) pairs, pivot-row entries by
-        // v_readlane instead of broadcast reads, s_sleep for the non-critical wavefronts, s_setprio — all slower.
-        double yl[4], rp[4], l[4];
+    }
+};
+#undef DPP_UPD
+// -- diagonal 16 x 16 inverse, in-wave by DPP: a helper wavefront grows columns 4 hq .. 4 hq + 3 (lane & 15 = row; the four 16-lane rows compute the
+// same).  X = G_14^-1 ... G_0^-1 applied to the identity: x[i] -= L[i][j] x[j] for i > j, j = 0 .. 14 in turn (x[j] by the row broadcast)
+template <int J> __device__ __forceinline__ void xrr_steps(double (&x)[4], const double (&nl)[15]) {
+    if constexpr (J < 15) {
+        asm volatile("v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "v"(nl[J]), "n"(J));      // (three instructions between a write of x[c] and its next DPP read)
+        xrr_steps<J + 1>(x, nl);
+    }
+}
+__device__ __forceinline__ void xrr_helper(int r, int hq, int i, const double* __restrict__ Lk, const double* __restrict__ dinv, double* __restrict__ XT,
+                                           double* __restrict__ XTs) {
+    const int ii = i & 15;
+    double nl[15], x[4];
+    const double* Lrow = Lk + (16 * r + ii) * LDT + 16 * r;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { yl[j] = ypan[buf][j][i]; rp[j] = rpan[buf][j]; }
+    for (int j = 0; j < 15; ++j) nl[j] = Lrow[j];                       // (all loads in flight before the first use)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const double v = yl[j] * rp[j]; l[j] = (i > 4 * P + j) ? v : 0.0; }
-        if (cg > P) {
+    for (int j = 0; j < 15; ++j) nl[j] = (ii > j) ? -nl[j] : 0.0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double yr[CPW];
+    for (int c = 0; c < 4; ++c) x[c] = (ii == 4 * hq + c) ? 1.0 : 0.0;
+    asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    xrr_steps<0>(x, nl);
+    if (i < 16) {
+        const double di = dinv[16 * r + ii];
 #pragma unroll
-                for (int c = 0; c < CPW; ++c) yr[c] = ypan[buf][j][4 * cg + c];                   // Y[4cg+c][4P+j] (broadcast reads)
+        for (int c = 0; c < 4; ++c) { XT[(16 * r + 4 * hq + c) * LDT + 16 * r + ii] = x[c]; XTs[(16 * r + 4 * hq + c) * LDT + 16 * r + ii] = x[c] * di; }
+    }
+}
+// one column of a diagonal inverse per wavefront (after the last pivot every wavefront is free)
+template <int J> __device__ __forceinline__ void xrr1_steps(double& x, const double (&nl)[15]) {
+    if constexpr (J < 15) {
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(nl[J]), "n"(J));
+        xrr1_steps<J + 1>(x, nl);
+    }
+}
+__device__ __forceinline__ void xrr_column(int r, int c, int i, const double* __restrict__ Lk, const double* __restrict__ dinv, double* __restrict__ XT,
+                                           double* __restrict__ XTs) {
+    const int ii = i & 15;
+    double nl[15];
+    const double* Lrow = Lk + (16 * r + ii) * LDT + 16 * r;
 #pragma unroll
-                for (int c = 0; c < CPW; ++c) a[c] -= l[j] * yr[c];
+    for (int j = 0; j < 15; ++j) nl[j] = Lrow[j];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) nl[j] = (ii > j) ? -nl[j] : 0.0;
+    double x = (ii == c) ? 1.0 : 0.0;
+    xrr1_steps<0>(x, nl);
+    if (i < 16) { XT[(16 * r + c) * LDT + 16 * r + ii] = x; XTs[(16 * r + c) * LDT + 16 * r + ii] = x * dinv[16 * r + ii]; }
+}
+// t += L_RK X_KC (16 x 16 blocks): lane (fr, fk) holds t[q] = (row 16 R + fk + 4 q, column 16 C + fr).  XT[a][r] = X[r][a], Lk[i][k] = L[i][k], both
+// k-fastest with stride LDT: the fragment reads of a 32-lane half hit 32 distinct bank pairs
+__device__ __forceinline__ v4d blk_LX(v4d t, int Rr, int K, int Cc, const double* __restrict__ Lk, const double* __restrict__ XT, int fr, int fk) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double f = Lk[(16 * Rr + fr) * LDT + 16 * K + 4 * kk + fk];
+        const double s = XT[(16 * Cc + fr) * LDT + 16 * K + 4 * kk + fk];
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(f, s, t, 0, 0, 0);
+    }
+    return t;
+}
+// X_RC = -X_RR W_RC with W still in the accumulator registers of the wavefront that formed it (t[q] = W(16 R + fk + 4 q, 16 C + fr)): the matrix
+// cores sum over k in any order, so k-step kk takes k = fk + 4 kk — lane (fr, fk) then supplies t[kk] as it stands, and the X_RR operand is read to match
+__device__ __forceinline__ void blk_XW(v4d t, int Rr, int Cc, double* __restrict__ XT, double* __restrict__ XTs, const double* __restrict__ dinv, int fr, int fk) {
+    v4d x = (v4d){0.0, 0.0, 0.0, 0.0};
+    double f[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f[kk] = XT[(16 * Rr + fk + 4 * kk) * LDT + 16 * Rr + fr];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(-f[kk], t[kk], x, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        XT[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = x[q];
+        XTs[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = x[q] * dinv[16 * Rr + fk + 4 * q];
+    }
+}
+
+// acc: tile (R, C) = (w >> 2, w & 3) of the block, acc[q] = A(16 R + fr, 16 C + fk + 4 q) with fr = lane & 15, fk = lane >> 4 (tiles above the diagonal are
+// ignored).  smem: DIAG_LDS_DOUBLES doubles that no wavefront of the workgroup still reads (the caller has a barrier behind its last LDS read).
+__device__ __forceinline__ void diag_block(double* __restrict__ smem, v4d acc, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
+                                           double* __restrict__ Tinv, double* __restrict__ Minv, int* __restrict__ icount) {
+    double* Lk = smem;                       // Lk[i][k] = L[i][k] (k fastest)
+    double* XT = Lk + NB * LDT;              // XT[a][r] = X[r][a]
+    double* XTs = XT + NB * LDT;             // ... scaled by the reciprocal pivot of row r
+    double* Yk = XTs + NB * LDT;             // Yk[i][j] = unscaled column 16 r + j of the current round
+    double* cp = Yk + NB * YS;               // cp[c][i]: column block r after the updates of the rounds before, for its owner
+    double* dpiv = cp + 16 * CPS;            // the 64 pivots
+    double* dinv = dpiv + NB;                // and their reciprocals
+    const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
+    const int R = w >> 2, C = w & 3, fr = i & 15, fk = i >> 4;
+    v4d xacc = (v4d){0.0, 0.0, 0.0, 0.0};   // a block product of the inverse carried from one phase to the next
+    LDL_STAMP(k0 / NB, 2);
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        if (C == r && R >= r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cp[(fk + 4 * q) * CPS + 16 * R + fr] = acc[q];
+        }
+        lds_barrier_all();
+        if (w == 5 * r) {
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = cp[c * CPS + i];
+            const double y0 = cp[16 * r + (i & 15)];
+            Yk[i * YS] = a[0];
+            const int lo = __builtin_amdgcn_readlane(__double2loint(a[0]), 16 * r), hi = __builtin_amdgcn_readlane(__double2hiint(a[0]), 16 * r);
+            Pivot<0>::run(a, (unsigned)(uintptr_t)(Yk + i * YS), (unsigned)(uintptr_t)(Yk + (16 * r + (i & 15)) * YS), Lk + i * LDT + 16 * r, 16 * r,
+                          fast_rcp(__hiloint2double(hi, lo)), y0);
+            if (i < 16) { const double d = Yk[(16 * r + i) * YS + i]; dpiv[16 * r + i] = d; dinv[16 * r + i] = fast_rcp(d); }   // (its own stores: the LDS queue of a wavefront is in order)
+        }
+        // while the owner (wavefront 5 r, SIMD r) is busy — nothing else is put on its SIMD: the diagonal inverse of the previous round and the block
+        // products whose operands are visible
+        if (r == 1) { const int hq = w == 2 ? 0 : w == 3 ? 1 : w == 6 ? 2 : w == 7 ? 3 : -1; if (hq >= 0) xrr_helper(0, hq, i, Lk, dinv, XT, XTs); }
+        if (r == 2) { const int hq = w == 1 ? 0 : w == 3 ? 1 : w == 4 ? 2 : w == 8 ? 3 : -1; if (hq >= 0) xrr_helper(1, hq, i, Lk, dinv, XT, XTs); }
+        if (r == 3) {
+            const int hq = w == 1 ? 0 : w == 2 ? 1 : w == 6 ? 2 : w == 4 ? 3 : -1;
+            if (hq >= 0) xrr_helper(2, hq, i, Lk, dinv, XT, XTs);
+            if (w == 9) xacc = blk_LX(xacc, 2, 1, 0, Lk, XT, fr, fk);                                                                  // W_20 += L_21 X_10
+            if (w == 8) { xacc = blk_LX(xacc, 3, 0, 0, Lk, XT, fr, fk); xacc = blk_LX(xacc, 3, 1, 0, Lk, XT, fr, fk); }               // W_30' = L_30 X_00 + L_31 X_10
+            if (w == 12) xacc = blk_LX(xacc, 3, 1, 1, Lk, XT, fr, fk);                                                                // W_31' = L_31 X_11
+        }
+        lds_barrier_all();
+        if (R >= C && C > r) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double yf = Yk[(16 * C + fr) * YS + 4 * kk + fk];
+                const double lf = Lk[(16 * R + fr) * LDT + 16 * r + 4 * kk + fk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-yf, lf, acc, 0, 0, 0);
             }
-            LDL_STAMP_IF(i == 0 && cg == 9 && P == 8 && a[0] != 1.2345e300, k0 / NB, 9);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {                 // (j outermost: the four columns are independent chains)
-                double xs[CPW];
-#pragma unroll
-                for (int c = 0; c < CPW; ++c) xs[c] = readlane_d(x[c], 4 * P + j);
-#pragma unroll
-                for (int c = 0; c < CPW; ++c) x[c] -= l[j] * xs[c];                               // (l[j] = 0 for the rows i <= 4P+j)
-            }
+        }
+        if (r == 2) {
+            if (w == 7) { const v4d t = blk_LX((v4d){0.0, 0.0, 0.0, 0.0}, 1, 0, 0, Lk, XT, fr, fk); blk_XW(t, 1, 0, XT, XTs, dinv, fr, fk); }   // X_10 = -X_11 (L_10 X_00)
+            if (w == 9) xacc = blk_LX(xacc, 2, 0, 0, Lk, XT, fr, fk);                                                                 // W_20' = L_20 X_00
+            if (w == 4) xacc = blk_LX(xacc, 2, 1, 1, Lk, XT, fr, fk);                                                                 // W_21 = L_21 X_11
         }
     }
     LDL_STAMP(k0 / NB, 3);
-    // X' to LDS for the matrix cores, plain and scaled by the reciprocal pivot of its row (the last mini-panel's pivots are visible: barrier 15)
-    {
-        const double di = dinv[i];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) { XT[(4 * cg + c) * LDT + i] = x[c]; XTs[(4 * cg + c) * LDT + i] = x[c] * di; }
-    }
+    // after the last pivot: X_33 (one column per wavefront), X_20, X_21, W_32; then X_30, X_31, X_32
+    if (w != 9 && w != 4 && w != 7) xrr_column(3, w, i, Lk, dinv, XT, XTs);
+    if (w == 0) xrr_column(3, 9, i, Lk, dinv, XT, XTs);
+    if (w == 1) xrr_column(3, 4, i, Lk, dinv, XT, XTs);
+    if (w == 2) xrr_column(3, 7, i, Lk, dinv, XT, XTs);
+    if (w == 9) blk_XW(xacc, 2, 0, XT, XTs, dinv, fr, fk);
+    if (w == 4) blk_XW(xacc, 2, 1, XT, XTs, dinv, fr, fk);
+    if (w == 7) xacc = blk_LX(xacc, 3, 2, 2, Lk, XT, fr, fk);                                                                             // W_32 = L_32 X_22
+    lds_barrier_all();
+    if (w == 8) { xacc = blk_LX(xacc, 3, 2, 0, Lk, XT, fr, fk); blk_XW(xacc, 3, 0, XT, XTs, dinv, fr, fk); }
+    if (w == 12) { xacc = blk_LX(xacc, 3, 2, 1, Lk, XT, fr, fk); blk_XW(xacc, 3, 1, XT, XTs, dinv, fr, fk); }
+    if (w == 7) blk_XW(xacc, 3, 2, XT, XTs, dinv, fr, fk);
     lds_barrier_all();
     LDL_STAMP(k0 / NB, 4);
     // M = X' D^-1 X = (L11 D L11')^-1: what the NEXT launch multiplies the raw panel with.  M[a][b] = sum_r X[r][a] X[r][b] / d[r] on the matrix
     // cores: wavefront (wa, wb) forms the 16 x 16 tile (rows a, columns b); both operand fragments are "row a (b), k index r" reads of X'.
     {
-        const int wa = cg >> 2, wb = cg & 3, fr = i & 15, fk = i >> 4;
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        const int wa = R, wb = C;
+        v4d m = (v4d){0.0, 0.0, 0.0, 0.0};
         // X[r][a] = 0 for r < a: the k blocks above the later of the two tile origins contribute exact zeros and are skipped (the workgroup's 256
         // MFMAs shrink to 120; the matrix cores of one CU are what bounds this product)
         for (int kk = 4 * (wa > wb ? wa : wb); kk < NB / 4; ++kk) {
             const double xa = XTs[(wa * 16 + fr) * LDT + 4 * kk + fk];
             const double xb = XT[(wb * 16 + fr) * LDT + 4 * kk + fk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, acc, 0, 0, 0);
+            m = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, m, 0, 0, 0);
         }
         double* Mo = Minv + (size_t)(k0 / NB) * NB * NB;
         LDL_STAMP(k0 / NB, 6);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Mo[(wb * 16 + fr) + (size_t)(wa * 16 + fk + 4 * q) * NB] = acc[q];   // lane holds M(a = fk + 4 q, b = fr) = M(b, a): 128-byte runs along fr
+        for (int q = 0; q < 4; ++q) Mo[(wb * 16 + fr) + (size_t)(wa * 16 + fk + 4 * q) * NB] = m[q];   // lane holds M(a = fk + 4 q, b = fr) = M(b, a): 128-byte runs along fr
     }
     // everything that goes to global memory leaves here, after the last barrier: D and the inertia counts (compute_inertia!), the strictly
-    // lower L of the block (from the registers of the wavefront that factored the column), X = L11^-1 on the diagonal of the triangular-solve
-    // inverse block (zeros above)
+    // lower L of the block and X = L11^-1 on the diagonal of the triangular-solve inverse block (zeros above), both from their LDS copies:
+    // thread (i, w) stores row i of columns 4 w .. 4 w + 3
     if (tid < NB) {
         const double d = dpiv[tid];
         Dx[k0 + tid] = d;
@@ -210,10 +307,10 @@ __device__ __forceinline__ void diag_block(double* __restrict__ smem, int NP, in
         const int q = k0 / tb, o = k0 % tb;
         double* T = Tinv + (size_t)q * tb * tb;
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-            const int k = 4 * cg + c;
-            T[(o + i) + (size_t)(o + k) * tb] = x[c];
-            if (i > k) S[(k0 + i) + (size_t)(k0 + k) * NP] = lfin[c];
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * w + c;
+            T[(o + i) + (size_t)(o + k) * tb] = (i >= k) ? XT[k * LDT + i] : 0.0;
+            if (i > k) S[(k0 + i) + (size_t)(k0 + k) * NP] = Lk[i * LDT + k];
         }
     }
     LDL_STAMP(k0 / NB, 5);
@@ -224,7 +321,13 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(Batch bt, int NP, int
     __shared__ double smem[DIAG_LDS_DOUBLES];
     inst_shift(bt, S, Dx, Tinv, Minv);
     inst_shift_i(bt, icount);
-    diag_block<false>(smem, NP, nx, k0, tb, S, Dx, Tinv, Minv, icount);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, R = w >> 2, C = w & 3, fr = lane & 15, fk = lane >> 4;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (R >= C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = S[(k0 + 16 * R + fr) + (size_t)(k0 + 16 * C + fk + 4 * q) * NP];
+    }
+    diag_block(smem, acc, NP, nx, k0, tb, S, Dx, Tinv, Minv, icount);
 }
 
 // ---- factor columns: L21 = A21 X' D^-1 for every panel in one launch -------------------------------------------------------------
@@ -459,13 +562,11 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
             if (h + 1 < NH) lds_barrier();            // the operand reads of the first panel are done before Ys is refilled
         }
         if (t == 0) {
-            // tile 0 = the diagonal block of the next panel: hand it over through LDS (row-major, stride LDD) and factor it
-            __syncthreads();                      // all MFMA operand reads of Zs/Ys are done
-#pragma unroll
-            for (int r = 0; r < 4; ++r) smem[(wr * 16 + fr) * LDD + (wc * 16 + fk + 4 * r)] = cS[r];
-            __syncthreads();
+            // tile 0 = the diagonal block of the next panel: its 16 x 16 tiles are already where the diagonal block wants them (accumulator layout,
+            // wavefront (wr, wc)); one barrier: every operand read of Zs / Ys is done before the block reuses the LDS
+            lds_barrier();
             Dx += off; Tinv += off; icount += 2 * off;
-            diag_block<true>(smem, NP, nx, r0, tb, S, Dx, Tinv, Minv, icount);
+            diag_block(smem, (v4d){cS[0], cS[1], cS[2], cS[3]}, NP, nx, r0, tb, S, Dx, Tinv, Minv, icount);
             return;
         }
 #pragma unroll
@@ -556,8 +657,11 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     double* Minv = s->Ypanel;           // NP x 64: M_k of every panel (the buffer held round 2's unscaled panels)
     hipLaunchKernelGGL(k_ldl_diag, dim3(1, 1, nz), dim3(DIAG_THREADS), 0, s->stream, bt, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, Minv, s->icount);
     const int band = s->band64 > 0 ? s->band64 : nblk;     // 64-row blocks below a diagonal block that can be non-zero (structure.hip)
-    // persistent workgroups: one is resident per CU (registers); 256, 512 and 768 launched workgroups time the same (profiles/README.md), 512 is kept
-    static const int resident_total = [] { const char* e = getenv("CALIPSO_HIP_LDL_RESIDENT"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    // persistent workgroups: one is resident per CU (registers, LDS).  ONE instance: 248 workers + the workgroup that carries the diagonal block =
+    // 31 + 1 per XCD at most, everything resident at once — since round 3's diagonal block (19 us) the early launches are bound by the trailing
+    // update, and a second wave of workgroups costs 5 us per launch (21.5 against 26.4 us at 512).  Groups keep 512 (they are throughput-bound).
+    static const int resident_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_RESIDENT"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    const int resident_total = resident_env ? resident_env : nz == 1 ? 248 : 512;
     const int resident = std::max(2, resident_total / (int)nz);
     // Pair schedule (dense S, several instances per launch): the first tile column of panel k's update (whose tile 0 factors diagonal block
     // k + 1), then BOTH panels in one pass over the rest.  Same arithmetic as the plain schedule (k_ldl_step, MODE 2), half

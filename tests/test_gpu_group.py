@@ -297,3 +297,8 @@ def test_solve_block_option_keeps_group_and_single_bitwise_and_agrees_across_set
     assert np.abs(steps[512] - steps[1024]).max() <= 1e-9 * max(1.0, np.abs(steps[1024]).max())
     with pytest.raises(pkg.CalipsoHipError, match="512 or 1024"):
         singles[0].set_option("solve_block", 256)
+    members[1].set_option("solve_block", 1024)            # members[0] stays at 512
+    g = pkg.Group(members)
+    with pytest.raises(pkg.CalipsoHipError, match="agree on opt.solve_block"):
+        g.newton_step(advance=False)
+    g.close()
