@@ -1,12 +1,17 @@
 // diag_bench3.hip — harness for the 64 x 64 diagonal block of ldl.hip, 16-column rounds: one wavefront factors 16 columns in its registers
-// (lane = row, pivot-row entries by v_readlane, no LDS, no barrier inside the round), the rank-16 update of the rest runs on the matrix cores
-// (every lower 16 x 16 tile of the block lives in the MFMA accumulators of one wavefront for the whole factorisation), then X = L^-1 is
-// assembled from the 16 x 16 diagonal inverses (in-wave) by block products on the matrix cores, and M = X' D^-1 X as in diag_bench2.
+// (lane = row, no barrier inside the round), the rank-16 update of the rest runs on the matrix cores (every lower 16 x 16 tile of the block lives
+// in the MFMA accumulators of one wavefront for the whole factorisation), X = L^-1 is assembled from the 16 x 16 diagonal inverses (in-wave) by
+// block products on the matrix cores — after the pivots (XM = 1) or meanwhile, by the idle wavefronts (XM = 2) — and M = X' D^-1 X as in diag_bench2.
+// Variants of the owner (OWN): pivot-row entries by v_readlane (0), by DPP row broadcasts with a duplicate of the diagonal-block rows in every
+// 16-lane row (1), by DPP with the pivot column read back from LDS replicated (2: what csrc/ldl.hip uses — as fast as 1 with half the registers).
 // Checked: L D L' = A, X L = I, M A = I.  Compare with profiles/r03_diag_bench2.txt ("e0 ... X": 18.3 us per launch, 13.6 us in the pivot loop).
+// Also tried and dropped (no gain): a shorter reciprocal chain, two wavefronts per round (diagonal block / panel rows,
+// tags in LDS): the 16 x 16 pivot chain alone already takes the 2400 cycles of the whole round (bench/lat_bench4.hip).
 //   hipcc -O3 --offload-arch=gfx950 bench/diag_bench3.hip -o /tmp/diag_bench3 && /tmp/diag_bench3
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 constexpr int NB = 64, LDT = NB + 2;
 constexpr int YS = 18;          // row stride of the 16-column panel of unscaled pivot columns (k fastest)
@@ -112,53 +117,6 @@ template <int J> struct Piv2 {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn) :: "memory");
             Piv2<J + 1>::run(a, yk_own, yk_rep, Lrow, lane0, rn, yn);
         } else {
-            a[J] = -nl;
-        }
-    }
-};
-
-// OWN = 3: OWN = 1 with the dependent chain of a pivot cut from ~8 to 5 operations: (1) the update of the NEXT pivot column is written as
-// fma(-(y y'), 1/d, a) with the product y y' formed one pivot earlier, so only one fma separates 1/d from the next pivot; (2) v_rcp_f64 reads the pivot
-// through DPP itself (no separate broadcast in front of it); (3) the two Newton steps as r0 (1 + e)(1 + e^2), e = 1 - d r0: fma, {fma, mul}, fma.
-// A wavefront issues in order, so the independent updates of the other columns are placed by hand into the latency gaps of that chain.
-#define DPP_UPD3(K)                                                                                                                     \
-    if constexpr ((K) < 16) asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                      \
-                                         "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"                           \
-                                         : "+v"(a[(K) & 15]), "+v"(g[(K) & 15]) : "v"(gJ), "v"(nl), "v"(nlg), "n"((K) & 15))
-template <int J> struct Piv3 {
-    // on entry: rinv = 1 / pivot J;  qa, qg = (entry (16 r + J, p - 1) of the previous pivot column) x (that column), i.e. what the previous pivot
-    // subtracts from column J once multiplied by its reciprocal — already applied by the caller: a[J], g[J] are final
-    static __device__ __forceinline__ void run(double (&a)[16], double (&g)[16], unsigned yk_own, double* Lrow, double rinv, double qa, double qg) {
-        // qa, qg here: products for column J + 1 from pivot column J (formed by the caller as soon as column J was final)
-        const double gJ = g[J];
-        double nl, nlg;
-        if constexpr (J + 1 < 16) {
-            double r0, dn, e, a1, e2, rn, qa2 = 0.0, qg2 = 0.0;
-            asm volatile("v_fma_f64 %0, -%1, %2, %0" : "+v"(g[J + 1]) : "v"(qg), "v"(rinv));                                   // chain 1
-            asm volatile("v_mul_f64 %0, %2, -%4\n\tv_mul_f64 %1, %3, -%4" : "=&v"(nl), "=&v"(nlg) : "v"(a[J]), "v"(gJ), "v"(rinv));
-            asm volatile("v_fma_f64 %0, -%1, %2, %0" : "+v"(a[J + 1]) : "v"(qa), "v"(rinv));
-            asm volatile("v_rcp_f64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r0) : "v"(g[J + 1]), "n"(J + 1));   // chain 2
-            asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(dn) : "v"(g[J + 1]), "n"(J + 1));
-            DPP_UPD3(J + 2);
-            if constexpr (J + 2 < 16) {
-                asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
-                             "v_fmac_f64_dpp %1, %2, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
-                             : "+v"(qa2), "+v"(qg2) : "v"(g[J + 1]), "v"(a[J + 1]), "n"((J + 2) & 15));
-            }
-            asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "v"(dn), "v"(r0));                                            // chain 3
-            DPP_UPD3(J + 3); DPP_UPD3(J + 4);
-            asm volatile("v_fma_f64 %0, %2, %3, %2\n\tv_mul_f64 %1, %3, %3" : "=&v"(a1), "=&v"(e2) : "v"(r0), "v"(e));           // chain 4
-            DPP_UPD3(J + 5); DPP_UPD3(J + 6);
-            asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(rn) : "v"(a1), "v"(e2));                                               // chain 5
-            DPP_UPD3(J + 7); DPP_UPD3(J + 8); DPP_UPD3(J + 9); DPP_UPD3(J + 10); DPP_UPD3(J + 11); DPP_UPD3(J + 12); DPP_UPD3(J + 13); DPP_UPD3(J + 14); DPP_UPD3(J + 15);
-            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(yk_own), "v"(a[J]), "n"(J * 8) : "memory");
-            Lrow[J] = -nl;
-            a[J] = -nl;
-            Piv3<J + 1>::run(a, g, yk_own, Lrow, rn, qa2, qg2);
-        } else {
-            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(yk_own), "v"(a[J]), "n"(J * 8) : "memory");
-            nl = a[J] * -rinv;
-            Lrow[J] = -nl;
             a[J] = -nl;
         }
     }
@@ -286,16 +244,6 @@ __global__ __launch_bounds__(1024) void k_diag16(int ld, double* __restrict__ S,
             Yk[i * YS] = a[0];
             const double d0 = readlane_d(a[0], 16 * r);
             Piv2<0>::run(a, (unsigned)(uintptr_t)(Yk + i * YS), (unsigned)(uintptr_t)(Yk + (16 * r + (i & 15)) * YS), Lk + i * LDT + 16 * r, 16 * r, fast_rcp(d0), y0);
-        }
-        if (w == 5 * r && OWN == 3) {
-            double a[16], g[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { a[c] = cp[c * CPS + i]; g[c] = cp[c * CPS + 16 * r + (i & 15)]; }
-            const double d0 = bcast16<0>(g[0]);
-            double qa = 0.0, qg = 0.0;
-            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "v_fmac_f64_dpp %1, %2, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "+v"(qa), "+v"(qg) : "v"(g[0]), "v"(a[0]));
-            Piv3<0>::run(a, g, (unsigned)(uintptr_t)(Yk + i * YS), Lk + i * LDT + 16 * r, fast_rcp(d0), qa, qg);
         }
         if (w == 5 * r && OWN == 0) {
             double a[16];
@@ -503,6 +451,12 @@ void run(const char* name, K kern, const std::vector<double>& A0, bool with_x) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best;
     }
+    if (getenv("WARM")) {      // every CU runs the kernel once (instruction caches warm), then the measured launch
+        double* S2; hipMalloc(&S2, sizeof(double) * NB * NB * 512);
+        for (int b = 0; b < 512; ++b) hipMemcpy(S2 + (size_t)b * NB * NB, A0.data(), sizeof(double) * NB * NB, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(kern, dim3(512), dim3(1024), 0, 0, ld, S2, D, X, M);      // (all blocks factor block 0's copy... outputs race with equal values)
+        hipDeviceSynchronize(); hipFree(S2);
+    }
     hipMemcpy(S, A0.data(), sizeof(double) * NB * NB, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(kern, dim3(1), dim3(1024), 0, 0, ld, S, D, X, M);
     std::vector<double> L(NB * NB), d(NB), Xh(NB * NB), Mh(NB * NB);
@@ -524,7 +478,7 @@ void run(const char* name, K kern, const std::vector<double>& A0, bool with_x) {
     { long long b[16]; hipMemcpyFromSymbol(b, HIP_SYMBOL(g_tb), sizeof(b));
       printf("        barriers (us since the first):"); for (int k = 1; k < 10; ++k) printf(" %.2f", (b[k] - b[0]) / 100.0); printf("\n"); }
     { long long c[8]; hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cyc), sizeof(c));
-      printf("        owner (OWN = 1) cycles: loads %lld, pivots 0-3 %lld, 4-7 %lld, 8-11 %lld, 12-15 %lld\n", c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4]); }
+      if (c[5] > c[1] && c[5] - c[1] < 100000) printf("        owner (OWN = 1) cycles: pivots 0-3 %lld, 4-7 %lld, 8-11 %lld, 12-15 %lld\n", c[2] - c[1], c[3] - c[2], c[4] - c[3], c[5] - c[4]); }
     printf("        round 1: barrier 1 -> owner done %.2f us, -> barrier 2 released %.2f us, -> tile (2,2) updated %.2f us\n", (h[6] - h[5]) / 100.0, (h[7] - h[6]) / 100.0, (h[8] - h[7]) / 100.0);
     hipFree(S); hipFree(D); hipFree(X); hipFree(M);
 }
@@ -541,8 +495,7 @@ int main() {
     run("r16: + X by block products, M", k_diag16<1, 0>, A, true);
     run("r16 dpp, rows replicated through LDS: L and D only", k_diag16<0, 2>, A, false);
     run("r16 dpp, rows replicated through LDS: + X, M", k_diag16<1, 2>, A, true);
-    run("r16 dpp, short chain: L and D only", k_diag16<0, 3>, A, false);
-    run("r16 dpp, short chain: + X, M", k_diag16<1, 3>, A, true);
+    run("r16 dpp, rows replicated through LDS: + X assembled alongside, M   [csrc/ldl.hip]", k_diag16<2, 2>, A, true);
     run("r16 dpp: L and D only", k_diag16<0, 1>, A, false);
     run("r16 dpp: + X assembled alongside, M", k_diag16<2, 1>, A, true);
     run("r16 dpp: + X by block products, M", k_diag16<1, 1>, A, true);
