@@ -452,7 +452,7 @@ def main():
             for h in handles:
                 h.set_option("solve_block", value)
     # ---- warm-up: W steps of the single system (captures its launch graphs) ---------------------------------------------------
-    solve_block([wl.single], 1024)
+    solve_block([wl.single], int(os.environ.get("CALIPSO_BENCH_SOLVE_BLOCK", "1024")))
     for _ in range(args.warmup):
         if not args.no_single:
             wl.single.newton_step(advance=False)

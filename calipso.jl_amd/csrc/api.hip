@@ -164,7 +164,7 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->saved_point, N); SL(&s->saved_g, NE); SL(&s->saved_h, NC);
     SL(&s->residual_symmetric, n); SL(&s->step_symmetric, n); SL(&s->merit_gradient, n);
     SL(&s->S, cp ? plan.spacked : NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, cp ? 1 : NPd * NB);                     // structured: S = the tiles of the segment pairs, contiguous
-    SL(&s->Tinv, cp ? 1 : calipso::tinv_doubles(d.NP)); SL(&s->Ttmp, cp ? 1 : NPd * 256); SL(&s->zf2, NPd); SL(&s->WH, cp ? 1 : NC * NX);
+    SL(&s->Tinv, cp ? 1 : calipso::tinv_doubles(d.NP)); SL(&s->Ttmp, cp ? 1 : NPd * 512); SL(&s->zf2, NPd); SL(&s->WH, cp ? 1 : NC * NX);
     SL(&s->wz, NC); SL(&s->kzz, NC);
     SL(&s->Wsoc, (size_t)woff); SL(&s->Bsoc, (size_t)woff); SL(&s->socwork, (size_t)2 * woff);
     SL(&icount_d, 32);                                        // 64 ints
@@ -376,7 +376,7 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
         const calipso::i64 v = (calipso::i64)llround(data[0]);
         if (nm == "opt.max_cone_line_search" && (v < 0 || v + 1 > CONE_MASK_TRIALS)) return fail_arg(s, "opt.max_cone_line_search must be in 0..831");
         if (nm == "opt.solve_block") {            // not an option of the reference: a tuning knob of the device factorisation (ldl.hip)
-            if (v != 512 && v != 1024) return fail_arg(s, "opt.solve_block must be 512 or 1024");
+            if (v != 512 && v != 1024 && v != 2048) return fail_arg(s, "opt.solve_block must be 512, 1024 or 2048");
             if (v != s->solve_block) {            // the captured launch sequences and the layout of the inverse blocks change with it
                 CK(hipSetDevice(s->device)); CK(hipStreamSynchronize(s->stream));
                 calipso::ldl_drop_graphs(s);

@@ -17,9 +17,21 @@ typedef int64_t i64;
 constexpr int TILE = 128;   // Schur-complement (SYRK) workgroup tile
 constexpr int NB = 64;      // LDL^T panel width
 constexpr int MAX_SOC_DIM = 64;
-constexpr int TRSV_BLOCK = 1024;   // widest diagonal block of L whose inverse is assembled for the triangular solves (ldl.hip)
-inline int trsv_block(int NP, int limit = TRSV_BLOCK) { return NP < limit ? NP : limit; }   // limit: the handle's "opt.solve_block" (512 or 1024)
-inline size_t tinv_doubles(int NP) { const size_t tb = (size_t)trsv_block(NP); return ((size_t)NP + tb - 1) / tb * tb * tb; }   // every block stored with leading dimension tb (sized for the widest block: the 512-wide layout is smaller)
+constexpr int TRSV_BLOCK = 2048;   // widest diagonal block of L whose inverse is assembled for the triangular solves (ldl.hip)
+// limit: the handle's "opt.solve_block" (512, 1024 or 2048).  NP is a power of two up to 512 and a multiple of 512 beyond; the inverse of a block is assembled
+// by pairwise merges of equal halves, so every block of the layout — the last, narrower one included — must be 64 * 2^k wide: the widest power of two
+// <= min(limit, NP) whose remainder NP mod tb is one as well (NP = 1536: 1024 + 512 also under limit 2048; NP = 2560: 2048 + 512).
+inline int trsv_block(int NP, int limit = TRSV_BLOCK) {
+    if (NP <= 512) return NP;
+    int tb = 512;
+    while (2 * tb <= limit && 2 * tb <= NP) tb *= 2;
+    for (;; tb /= 2) { const int rem = NP % tb; if (tb == 512 || (rem & (rem - 1)) == 0) return tb; }
+}
+inline size_t tinv_doubles(int NP) {      // every block is stored with the leading dimension tb of its layout; sized for the largest of the three layouts
+    size_t most = 0;
+    for (int limit : {512, 1024, 2048}) { const size_t tb = (size_t)trsv_block(NP, limit); const size_t n = ((size_t)NP + tb - 1) / tb * tb * tb; most = n > most ? n : most; }
+    return most;
+}
 constexpr int CONE_MASK_WORDS = 26;                     // icount[6..31] (slack) and icount[32..57] (slack dual): one bit per trial step size
 constexpr int CONE_MASK_TRIALS = 32 * CONE_MASK_WORDS;  // => max_cone_line_search <= 831
 
@@ -183,7 +195,7 @@ struct calipso_hip_solver {
     double* refpart = nullptr;  // per workgroup of k_refine_local: its part of ||residual_error||_inf
     double* Ypanel = nullptr;   // NP*NB: M_k = (L_kk D_k L_kk')^-1 of every 64-column panel (ldl.hip: what the trailing update multiplies the raw panel with)
     double* Tinv = nullptr;     // tinv_doubles(NP): inverses of the unit-lower diagonal blocks of L (up to 1024 x 1024, the last one may be 512 wide)
-    double* Ttmp = nullptr;     // NP*256 scratch of the inverse assembly
+    double* Ttmp = nullptr;     // NP*512 scratch of the inverse assembly (one 1024 x 1024 product at the top level)
     double* zf2 = nullptr;      // NP
     double* WH = nullptr;       // nc*nx: Omega_z * hx
     double* wz = nullptr;       // nc: Omega for nonnegative entries (-1/K_zz)
@@ -228,7 +240,7 @@ struct calipso_hip_solver {
     hipEvent_t ev[16];
     hipGraphExec_t graph_ldl = nullptr, graph_ldl_fin = nullptr, graph_trsv = nullptr;   // captured once per handle (fixed launch sequences): panel steps, factor columns + block inverses, one triangular solve
     bool graph_ldl_tried = false, graph_ldl_fin_tried = false, graph_trsv_tried = false, use_graphs = true;
-    calipso::i64 solve_block = calipso::TRSV_BLOCK;   // "opt.solve_block": widest diagonal block of L whose inverse is assembled (1024: fewest launches per solve, what one system wants; 512: a quarter of the
+    calipso::i64 solve_block = 1024;   // "opt.solve_block": widest diagonal block of L whose inverse is assembled (1024: fewest launches per solve, what one system wants; 512: a quarter of the
                                                         // inverse-assembly flops, what a group wants — its solves are bandwidth-bound).  Members of a group use the leader's.
     double kernel_ms[4] = {0};   // [0] the panel-step launches (k_ldl_diag + k_ldl_step) of the last factorisation
     double phase_ms[9] = {0};

@@ -32,7 +32,7 @@
 namespace calipso {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int TB = 1024;           // largest triangular-solve block; the block actually used is tb = min(TB, NP); the last block of a solve may be narrower
+constexpr int TB = 2048;           // largest triangular-solve block; the block actually used is tb = min(opt.solve_block, NP); the last block of a solve may be narrower
 constexpr int LDT = NB + 2;        // LDS leading dimension of a k-fastest 64-deep operand panel
 
 // ---- diagonal block ---------------------------------------------------------------------------------------------------------
@@ -622,7 +622,7 @@ __device__ __forceinline__ void gemm_tile64(const GemmDesc g, int kbeg, int kend
     }
 }
 
-// level 1, 2, 3, 4: half = 64, 128, 256, 512; phase 0: T = L21 * X11 ; phase 1: X21 = -X22 * T
+// level 1 .. 5: half = 64, 128, 256, 512, 1024; phase 0: T = L21 * X11 ; phase 1: X21 = -X22 * T
 __global__ __launch_bounds__(1024) void k_tinv_merge(Batch bt, int NP, int tb, int half, int phase, const double* __restrict__ S, double* __restrict__ Tinv,
                                                       double* __restrict__ Ttmp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -703,7 +703,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
         hipLaunchKernelGGL(k_ldl_scale, dim3(maxrows / 64, nblk - 1, nz), dim3(1024), 0, s->stream, bt, NP, tb, band * NB, s->S, s->Dx, s->Tinv);
     }
     const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
-    for (int level = 1; level <= 4; ++level) {
+    for (int level = 1; level <= 5; ++level) {
         const int half = 32 << level, tiles = half / 64, pairs = NP / (2 * half);
         if (2 * half > tb) break;
         for (int phase = 0; phase < 2; ++phase)
@@ -723,7 +723,8 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
 template <int PARTS>
 __global__ __launch_bounds__(32 * PARTS) void k_trsv_block_n(Batch bt, int kb, int tb, int w, const double* __restrict__ Tinv, const double* __restrict__ b,
                                                               const double* __restrict__ Dx, double* __restrict__ u, double* __restrict__ z) {
-    __shared__ double bs[64 * PARTS];
+    constexpr int W = 64 * PARTS;                 // columns per pass (a 2048-wide block takes two passes of 1024; the rows of its upper half only the first)
+    __shared__ double bs[W];
     __shared__ double part[PARTS][32];
     inst_shift(bt, Tinv, b, Dx, u, z);
     const int tid = threadIdx.x, k0 = kb * tb;
@@ -731,14 +732,17 @@ __global__ __launch_bounds__(32 * PARTS) void k_trsv_block_n(Batch bt, int kb, i
     const int row = blockIdx.x * 32 + r;
     const double* T = Tinv + (size_t)kb * tb * tb + row;
     const int cend = blockIdx.x * 32 + 32;         // lower triangular: columns beyond the workgroup's last row are zero
-    double v[64];
-#pragma unroll
-    for (int q = 0; q < 64; ++q) { const int c = p + PARTS * q; v[q] = (c < cend) ? T[(size_t)c * tb] : 0.0; }
-    for (int i = tid; i < 64 * PARTS; i += 32 * PARTS) bs[i] = i < w ? b[k0 + i] : 0.0;
-    __syncthreads();
     double acc = 0.0;
+    for (int c0 = 0; c0 < cend; c0 += W) {
+        double v[64];
 #pragma unroll
-    for (int q = 0; q < 64; ++q) acc += v[q] * bs[p + PARTS * q];
+        for (int q = 0; q < 64; ++q) { const int c = c0 + p + PARTS * q; v[q] = (c < cend) ? T[(size_t)c * tb] : 0.0; }
+        if (c0) __syncthreads();                  // the previous pass has read bs
+        for (int i = tid; i < W; i += 32 * PARTS) bs[i] = c0 + i < w ? b[k0 + c0 + i] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 64; ++q) acc += v[q] * bs[p + PARTS * q];
+    }
     part[p][r] = acc;
     __syncthreads();
     if (tid < 32) {
@@ -751,69 +755,74 @@ __global__ __launch_bounds__(32 * PARTS) void k_trsv_block_n(Batch bt, int kb, i
     }
 }
 
-// b[rows below block kb] -= L[rows, block kb] * u_k      (32 rows per workgroup, 64 PARTS = tb columns, one load batch)
+// b[rows below block kb] -= L[rows, block kb] * u_k      (32 rows per workgroup, passes of 64 PARTS columns over the w columns of the block)
 template <int PARTS>
-__global__ __launch_bounds__(32 * PARTS) void k_trsv_update_n(Batch bt, int NP, int k0, const double* __restrict__ S, const double* __restrict__ u, double* __restrict__ b) {
-    __shared__ double us[64 * PARTS];
+__global__ __launch_bounds__(32 * PARTS) void k_trsv_update_n(Batch bt, int NP, int k0, int w, const double* __restrict__ S, const double* __restrict__ u, double* __restrict__ b) {
+    constexpr int W = 64 * PARTS;
+    __shared__ double us[W];
     __shared__ double part[PARTS][32];
     inst_shift(bt, S, u, b);
-    constexpr int W = 64 * PARTS;
     const int tid = threadIdx.x;
     const int r = tid & 31, p = tid >> 5;
-    const int row = k0 + W + blockIdx.x * 32 + r;
-    const double* Sp = S + row + (size_t)k0 * NP;
-    double v[64];
-#pragma unroll
-    for (int q = 0; q < 64; ++q) v[q] = Sp[(size_t)(p + PARTS * q) * NP];
-    for (int i = tid; i < W; i += 32 * PARTS) us[i] = u[k0 + i];
-    __syncthreads();
+    const int row = k0 + w + blockIdx.x * 32 + r;
     double acc = 0.0;
+    for (int c0 = 0; c0 < w; c0 += W) {
+        const double* Sp = S + row + (size_t)(k0 + c0) * NP;
+        double v[64];
 #pragma unroll
-    for (int q = 0; q < 64; ++q) acc += v[q] * us[p + PARTS * q];
+        for (int q = 0; q < 64; ++q) v[q] = Sp[(size_t)(p + PARTS * q) * NP];
+        if (c0) __syncthreads();
+        for (int i = tid; i < W; i += 32 * PARTS) us[i] = u[k0 + c0 + i];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 64; ++q) acc += v[q] * us[p + PARTS * q];
+    }
     part[p][r] = acc;
     __syncthreads();
     if (tid < 32) {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < PARTS; ++q) s += part[q][tid];
-        b[k0 + W + blockIdx.x * 32 + tid] -= s;
+        b[k0 + w + blockIdx.x * 32 + tid] -= s;
     }
 }
 
-// v_k = Tinv_k' z_k : one wavefront per column (4 columns per workgroup), lanes stride down the column
+// v_k = Tinv_k' z_k : one wavefront per column (4 columns per workgroup), lanes stride down the column.  TBW = widest block of the layout (1024 or 2048)
+template <int TBW>
 __global__ __launch_bounds__(256) void k_trsv_block_t(Batch bt, int kb, int tb, int w, const double* __restrict__ Tinv, const double* __restrict__ z, double* __restrict__ v) {
-    __shared__ double zs[TB];
+    __shared__ double zs[TBW];
     inst_shift(bt, Tinv, z, v);
     const int tid = threadIdx.x, lane = tid & 63, k0 = kb * tb;
-    for (int i = tid; i < TB; i += 256) zs[i] = i < w ? z[k0 + i] : 0.0;
+    for (int i = tid; i < TBW; i += 256) zs[i] = i < w ? z[k0 + i] : 0.0;
     __syncthreads();
     const int c = blockIdx.x * 4 + (tid >> 6);
     const double* T = Tinv + (size_t)kb * tb * tb + (size_t)c * tb;
-    double tv[TB / 64];
+    double tv[TBW / 64];
 #pragma unroll
-    for (int q = 0; q < TB / 64; ++q) { const int r = lane + 64 * q; tv[q] = (r >= (c & ~63) && r < w) ? T[r] : 0.0; }   // column c is zero above row c
+    for (int q = 0; q < TBW / 64; ++q) { const int r = lane + 64 * q; tv[q] = (r >= (c & ~63) && r < w) ? T[r] : 0.0; }   // column c is zero above row c
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < TB / 64; ++q) acc += tv[q] * zs[lane + 64 * q];
+    for (int q = 0; q < TBW / 64; ++q) acc += tv[q] * zs[lane + 64 * q];
     acc = wave_sum(acc);
     if (lane == 0) v[k0 + c] = acc;
 }
 
 // z[columns left of block kb] -= L[block kb, columns]' v_k : one wavefront per column
+template <int TBW>
 __global__ __launch_bounds__(256) void k_trsv_update_t(Batch bt, int NP, int k0, int w, int cfirst, const double* __restrict__ S, const double* __restrict__ v, double* __restrict__ z) {
-    __shared__ double vs[TB];
+    __shared__ double vs[TBW];
     inst_shift(bt, S, v, z);
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < TB; i += 256) vs[i] = i < w ? v[k0 + i] : 0.0;
+    for (int i = tid; i < TBW; i += 256) vs[i] = i < w ? v[k0 + i] : 0.0;
     __syncthreads();
     const int c = cfirst + blockIdx.x * 4 + (tid >> 6);     // cfirst <= c < k0 (columns further left are outside the band)
     const double* Lc = S + (size_t)c * NP + k0;
-    double lv[TB / 64];
+    double lv[TBW / 64];
 #pragma unroll
-    for (int q = 0; q < TB / 64; ++q) lv[q] = (lane + 64 * q < w) ? Lc[lane + 64 * q] : 0.0;
+    for (int q = 0; q < TBW / 64; ++q) lv[q] = (lane + 64 * q < w) ? Lc[lane + 64 * q] : 0.0;
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < TB / 64; ++q) acc += lv[q] * vs[lane + 64 * q];
+    for (int q = 0; q < TBW / 64; ++q) acc += lv[q] * vs[lane + 64 * q];
     acc = wave_sum(acc);
     if (lane == 0) z[c] -= acc;
 }
@@ -831,17 +840,19 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
         else hipLaunchKernelGGL(k_trsv_block_n<8>, dim3(w / 32, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, s->Tinv, x, s->Dx, u, z);
         int rest = NP - (k0 + w);
         if (s->band64 > 0) rest = std::min(rest, ((s->half_bandwidth + 31) / 32) * 32);      // rows below the block that its columns reach
-        if (rest > 0) {                                                                       // (a block with rows below it is tb = 512 or 1024 wide)
-            if (w > 512) hipLaunchKernelGGL(k_trsv_update_n<16>, dim3(rest / 32, 1, nz), dim3(512), 0, s->stream, bt, NP, k0, s->S, u, x);
-            else hipLaunchKernelGGL(k_trsv_update_n<8>, dim3(rest / 32, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, s->S, u, x);
+        if (rest > 0) {                                                                       // (a block with rows below it is tb = 512, 1024 or 2048 wide)
+            if (w > 512) hipLaunchKernelGGL(k_trsv_update_n<16>, dim3(rest / 32, 1, nz), dim3(512), 0, s->stream, bt, NP, k0, w, s->S, u, x);
+            else hipLaunchKernelGGL(k_trsv_update_n<8>, dim3(rest / 32, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, s->S, u, x);
         }
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
         const int k0 = kb * tb, w = std::min(tb, NP - k0);
-        hipLaunchKernelGGL(k_trsv_block_t, dim3(w / 4, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, s->Tinv, z, x);
+        if (w > 1024) hipLaunchKernelGGL(k_trsv_block_t<2048>, dim3(w / 4, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, s->Tinv, z, x);
+        else hipLaunchKernelGGL(k_trsv_block_t<1024>, dim3(w / 4, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, s->Tinv, z, x);
         if (kb > 0) {
             const int cfirst = s->band64 > 0 ? std::max(0, ((k0 - s->half_bandwidth) / 4) * 4) : 0;   // columns left of the block that reach into it
-            hipLaunchKernelGGL(k_trsv_update_t, dim3((k0 - cfirst) / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, cfirst, s->S, x, z);
+            if (w > 1024) hipLaunchKernelGGL(k_trsv_update_t<2048>, dim3((k0 - cfirst) / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, cfirst, s->S, x, z);
+            else hipLaunchKernelGGL(k_trsv_update_t<1024>, dim3((k0 - cfirst) / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, cfirst, s->S, x, z);
         }
     }
 }

@@ -150,9 +150,10 @@ int32_t calipso_hip_device_count(void);
  *   "solution_sensitivity"[N*np] "parameters"[np] "dual"[ne]
  * Scalars (solver.jl:81-127): "central_path" "fraction_to_boundary" "penalty" "primal_regularization"
  *   "primal_regularization_last" "dual_regularization";  options (options.jl:6-59): "opt.<field>" (as double).  One option has no counterpart in
- *   the reference: "opt.solve_block" (512 or 1024, default 1024) — the widest diagonal block of the factor of S whose inverse is assembled for the
+ *   the reference: "opt.solve_block" (512, 1024 or 2048, default 1024) — the widest diagonal block of the factor of S whose inverse is assembled for the
  *   triangular solves.  It changes the summation order of the solves (not the factor): 1024 suits one system (fewer dependent launches), 512 suits
- *   a group (one merge level less; its solves are bandwidth-bound).  Set it on every member of a group (the first member's value governs the group's launches). */
+ *   a group (one merge level less; its solves are bandwidth-bound); 2048 is there for larger systems (at nx = 2432 its extra merge level costs 0.15 ms
+ *   and saves 0.07).  Set it on every member of a group (the first member's value governs the group's launches). */
 int32_t calipso_hip_set_field(calipso_hip_solver*, const char* name, const double* data, int64_t len);
 int32_t calipso_hip_get_field(calipso_hip_solver*, const char* name, double* data, int64_t len);
 /* The scatter of evaluate! on the device (evaluate.jl:37-121): register `methods.<field>_sparsity` once — `count` (row, col)

@@ -279,9 +279,9 @@ def test_solve_block_option_keeps_group_and_single_bitwise_and_agrees_across_set
     """"opt.solve_block" (512 / 1024: the widest diagonal block of L whose inverse is assembled for the triangular solves) — for each setting a member of
     a group gets the bits of the same handle stepped alone; the two settings agree to rounding; anything else is refused"""
     pkg = load_pkg()
-    shape = (1300, 300, 40, 20, 3)                     # NP = 1536: blocks 1024 + 512, or three of 512
+    shape = (1700, 300, 40, 20, 3)                     # NP = 2048: one block of 2048, two of 1024, or four of 512
     steps = {}
-    for blockw in (1024, 512):
+    for blockw in (2048, 1024, 512):
         singles = [build(pkg, p, shape) for p in (31, 32)]
         members = [build(pkg, p, shape) for p in (31, 32)]
         for h in singles + members:
@@ -295,7 +295,8 @@ def test_solve_block_option_keeps_group_and_single_bitwise_and_agrees_across_set
         steps[blockw] = singles[0].data("step").all.copy()
         g.close()
     assert np.abs(steps[512] - steps[1024]).max() <= 1e-9 * max(1.0, np.abs(steps[1024]).max())
-    with pytest.raises(pkg.CalipsoHipError, match="512 or 1024"):
+    assert np.abs(steps[2048] - steps[1024]).max() <= 1e-9 * max(1.0, np.abs(steps[1024]).max())
+    with pytest.raises(pkg.CalipsoHipError, match="512, 1024 or 2048"):
         singles[0].set_option("solve_block", 256)
     members[1].set_option("solve_block", 1024)            # members[0] stays at 512
     g = pkg.Group(members)
