@@ -649,6 +649,68 @@ __global__ __launch_bounds__(1024) void k_tinv_merge(Batch bt, int NP, int tb, i
     }
 }
 
+// The same merge with 32 x 32 output tiles and 256 threads (4 wavefronts, one 16 x 16 MFMA tile each).  A 64 x 64 tile keeps ONE CU's matrix cores busy
+// for 64 cycles per k (13.6 us at K = 512) and the levels have 20 .. 128 such tiles: the launch lasts as long as its longest tile.  Four times as many
+// tiles of a quarter of the work spread over four times as many CUs, and eight 256-thread workgroups per CU hide each other's load latency (the K loop
+// is load -> barrier -> MFMA -> barrier, no double buffering).  Same k order per output entry as the 64 x 64 version (the skipped k ranges are exact zeros).
+__global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, int half, int phase, const double* __restrict__ S, double* __restrict__ Tinv,
+                                                       double* __restrict__ Ttmp) {
+    constexpr int KC = 32, ldk = KC + 2;
+    __shared__ double As[32 * ldk];       // As[i][k]
+    __shared__ double Bs[32 * ldk];       // Bs[j][k]
+    inst_shift(bt, S, Tinv, Ttmp);
+    const int tiles = half / 32;
+    const int pair = blockIdx.x / (tiles * tiles);
+    const int tt = blockIdx.x % (tiles * tiles);
+    const int tiy = tt / tiles, tjx = tt % tiles;
+    const int g0 = pair * 2 * half;
+    const int q = g0 / tb, o = g0 % tb;
+    double* T = Tinv + (size_t)q * tb * tb;
+    double* tmp = Ttmp + (size_t)pair * half * half;
+    const double* A; const double* B; double* Cc; int lda, ldb, ldc, kbeg, kend; double alpha;
+    if (phase == 0) {        // tmp(half x half) = L21 * X11
+        A = S + (g0 + half + tiy * 32) + (size_t)g0 * NP; lda = NP;
+        B = T + o + (size_t)(o + tjx * 32) * tb; ldb = tb;
+        Cc = tmp + tiy * 32 + (size_t)(tjx * 32) * half; ldc = half;
+        kbeg = tjx * 32; kend = half; alpha = 1.0;           // X11 is lower triangular: rows k < 32 tjx of its column tile are zero
+    } else {                 // X21 = -X22 * tmp
+        A = T + (o + half + tiy * 32) + (size_t)(o + half) * tb; lda = tb;
+        B = tmp + (size_t)(tjx * 32) * half; ldb = half;
+        Cc = T + (o + half + tiy * 32) + (size_t)(o + tjx * 32) * tb; ldc = tb;
+        kbeg = 0; kend = (tiy + 1) * 32; alpha = -1.0;       // X22 is lower triangular: columns k >= 32 (tiy + 1) of its row tile are zero
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int fr = lane & 15, fk = lane >> 4;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int kc = kbeg; kc < kend; kc += KC) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            av[it] = A[(tid & 31) + (size_t)(kc + (tid >> 5) + 8 * it) * lda];          // lanes along i
+            bv[it] = B[(kc + (tid & 31)) + (size_t)((tid >> 5) + 8 * it) * ldb];        // lanes along k
+        }
+        __syncthreads();                                                                 // the previous chunk's fragments are read
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            As[(tid & 31) * ldk + (tid >> 5) + 8 * it] = av[it];
+            Bs[((tid >> 5) + 8 * it) * ldk + (tid & 31)] = bv[it];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC / 4; ++kk) {
+            const double a = As[(wi * 16 + fr) * ldk + kk * 4 + fk];
+            const double b = Bs[(wj * 16 + fr) * ldk + kk * 4 + fk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);   // transposed: row <-> j, col <-> i
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = wj * 16 + fk + 4 * r, i = wi * 16 + fr;
+        Cc[i + (size_t)j * ldc] = alpha * acc[r];
+    }
+}
+
 // the panel steps (the pivot chain): NP / 64 launches
 static void enqueue_ldl_steps(calipso_hip_solver* s) {
     const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
@@ -706,8 +768,11 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
     for (int level = 1; level <= 5; ++level) {
         const int half = 32 << level, tiles = half / 64, pairs = NP / (2 * half);
         if (2 * half > tb) break;
-        for (int phase = 0; phase < 2; ++phase)
-            hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles, 1, nz), dim3(1024), mg_lds, s->stream, bt, NP, tb, half, phase, s->S, s->Tinv, s->Ttmp);
+        static const bool merge64 = [] { const char* e = getenv("CALIPSO_HIP_MERGE64"); return e && atoi(e) != 0; }();
+        for (int phase = 0; phase < 2; ++phase) {
+            if (merge64) hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles, 1, nz), dim3(1024), mg_lds, s->stream, bt, NP, tb, half, phase, s->S, s->Tinv, s->Ttmp);
+            else hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles * 4, 1, nz), dim3(256), 0, s->stream, bt, NP, tb, half, phase, s->S, s->Tinv, s->Ttmp);
+        }
     }
 }
 
