@@ -780,75 +780,75 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
 // forward:  L u = b.   kernel B_k: u_k = Tinv_k b_k ;  kernel A_k: b_rest -= L[rest, k] u_k
 // backward: L' v = z.  kernel B'_k: v_k = Tinv_k' z_k ; kernel A'_k: z_above -= L[k, above]' v_k
 // Each output entry is a dot product of a matrix row/column with a block-wide vector; the vector sits in LDS.  Block kb covers columns
-// k0 = kb tb .. k0 + w - 1 with w = min(tb, NP - k0): NP = 2560 is 1024 + 1024 + 512.  PARTS = column parts per row (8 for blocks of up to
-// 512 columns, 16 for 1024): 32 PARTS threads per workgroup, 64 columns per thread.
+// k0 = kb tb .. k0 + w - 1 with w = min(tb, NP - k0): NP = 2560 is 1024 + 1024 + 512.  ROWS rows per workgroup, PARTS column parts per row,
+// CPT columns per thread and pass: ROWS * PARTS threads cover PARTS * CPT columns per pass (16 x 32 x 32 for blocks wider than 512, 16 x 16 x 32 otherwise).
 
-// u_k = Tinv_k b_k (lower-triangular mat-vec, lanes along rows); also z_k = u_k / D.  32 rows per workgroup; each lane issues ALL its
+// u_k = Tinv_k b_k (lower-triangular mat-vec, lanes along rows); also z_k = u_k / D.  Each lane issues ALL its
 // loads before using any (these kernels are latency-bound: one round trip, not four).
-template <int PARTS>
-__global__ __launch_bounds__(32 * PARTS) void k_trsv_block_n(Batch bt, int kb, int tb, int w, const double* __restrict__ Tinv, const double* __restrict__ b,
-                                                              const double* __restrict__ Dx, double* __restrict__ u, double* __restrict__ z) {
-    constexpr int W = 64 * PARTS;                 // columns per pass (a 2048-wide block takes two passes of 1024; the rows of its upper half only the first)
+template <int ROWS, int PARTS, int CPT>
+__global__ __launch_bounds__(ROWS * PARTS) void k_trsv_block_n(Batch bt, int kb, int tb, int w, const double* __restrict__ Tinv, const double* __restrict__ b,
+                                                                const double* __restrict__ Dx, double* __restrict__ u, double* __restrict__ z) {
+    constexpr int W = PARTS * CPT;                // columns per pass (a 2048-wide block takes two passes of 1024; the rows of its upper half only the first)
     __shared__ double bs[W];
-    __shared__ double part[PARTS][32];
+    __shared__ double part[PARTS][ROWS];
     inst_shift(bt, Tinv, b, Dx, u, z);
     const int tid = threadIdx.x, k0 = kb * tb;
-    const int r = tid & 31, p = tid >> 5;
-    const int row = blockIdx.x * 32 + r;
+    const int r = tid % ROWS, p = tid / ROWS;
+    const int row = blockIdx.x * ROWS + r;
     const double* T = Tinv + (size_t)kb * tb * tb + row;
-    const int cend = blockIdx.x * 32 + 32;         // lower triangular: columns beyond the workgroup's last row are zero
+    const int cend = blockIdx.x * ROWS + ROWS;     // lower triangular: columns beyond the workgroup's last row are zero
     double acc = 0.0;
     for (int c0 = 0; c0 < cend; c0 += W) {
-        double v[64];
+        double v[CPT];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) { const int c = c0 + p + PARTS * q; v[q] = (c < cend) ? T[(size_t)c * tb] : 0.0; }
+        for (int q = 0; q < CPT; ++q) { const int c = c0 + p + PARTS * q; v[q] = (c < cend) ? T[(size_t)c * tb] : 0.0; }
         if (c0) __syncthreads();                  // the previous pass has read bs
-        for (int i = tid; i < W; i += 32 * PARTS) bs[i] = c0 + i < w ? b[k0 + c0 + i] : 0.0;
+        for (int i = tid; i < W; i += ROWS * PARTS) bs[i] = c0 + i < w ? b[k0 + c0 + i] : 0.0;
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 64; ++q) acc += v[q] * bs[p + PARTS * q];
+        for (int q = 0; q < CPT; ++q) acc += v[q] * bs[p + PARTS * q];
     }
     part[p][r] = acc;
     __syncthreads();
-    if (tid < 32) {
+    if (tid < ROWS) {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < PARTS; ++q) s += part[q][tid];
-        const int gi = k0 + blockIdx.x * 32 + tid;
+        const int gi = k0 + blockIdx.x * ROWS + tid;
         u[gi] = s;
         z[gi] = s / Dx[gi];
     }
 }
 
-// b[rows below block kb] -= L[rows, block kb] * u_k      (32 rows per workgroup, passes of 64 PARTS columns over the w columns of the block)
-template <int PARTS>
-__global__ __launch_bounds__(32 * PARTS) void k_trsv_update_n(Batch bt, int NP, int k0, int w, const double* __restrict__ S, const double* __restrict__ u, double* __restrict__ b) {
-    constexpr int W = 64 * PARTS;
+// b[rows below block kb] -= L[rows, block kb] * u_k      (ROWS rows per workgroup, passes of PARTS * CPT columns over the w columns of the block)
+template <int ROWS, int PARTS, int CPT>
+__global__ __launch_bounds__(ROWS * PARTS) void k_trsv_update_n(Batch bt, int NP, int k0, int w, const double* __restrict__ S, const double* __restrict__ u, double* __restrict__ b) {
+    constexpr int W = PARTS * CPT;
     __shared__ double us[W];
-    __shared__ double part[PARTS][32];
+    __shared__ double part[PARTS][ROWS];
     inst_shift(bt, S, u, b);
     const int tid = threadIdx.x;
-    const int r = tid & 31, p = tid >> 5;
-    const int row = k0 + w + blockIdx.x * 32 + r;
+    const int r = tid % ROWS, p = tid / ROWS;
+    const int row = k0 + w + blockIdx.x * ROWS + r;
     double acc = 0.0;
     for (int c0 = 0; c0 < w; c0 += W) {
         const double* Sp = S + row + (size_t)(k0 + c0) * NP;
-        double v[64];
+        double v[CPT];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) v[q] = Sp[(size_t)(p + PARTS * q) * NP];
+        for (int q = 0; q < CPT; ++q) v[q] = Sp[(size_t)(p + PARTS * q) * NP];
         if (c0) __syncthreads();
-        for (int i = tid; i < W; i += 32 * PARTS) us[i] = u[k0 + c0 + i];
+        for (int i = tid; i < W; i += ROWS * PARTS) us[i] = u[k0 + c0 + i];
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 64; ++q) acc += v[q] * us[p + PARTS * q];
+        for (int q = 0; q < CPT; ++q) acc += v[q] * us[p + PARTS * q];
     }
     part[p][r] = acc;
     __syncthreads();
-    if (tid < 32) {
+    if (tid < ROWS) {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < PARTS; ++q) s += part[q][tid];
-        b[k0 + w + blockIdx.x * 32 + tid] -= s;
+        b[k0 + w + blockIdx.x * ROWS + tid] -= s;
     }
 }
 
@@ -901,13 +901,17 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
     const unsigned nz = bt.n;
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = kb * tb, w = std::min(tb, NP - k0);
-        if (w > 512) hipLaunchKernelGGL(k_trsv_block_n<16>, dim3(w / 32, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, s->Tinv, x, s->Dx, u, z);
-        else hipLaunchKernelGGL(k_trsv_block_n<8>, dim3(w / 32, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, s->Tinv, x, s->Dx, u, z);
         int rest = NP - (k0 + w);
         if (s->band64 > 0) rest = std::min(rest, ((s->half_bandwidth + 31) / 32) * 32);      // rows below the block that its columns reach
-        if (rest > 0) {                                                                       // (a block with rows below it is tb = 512, 1024 or 2048 wide)
-            if (w > 512) hipLaunchKernelGGL(k_trsv_update_n<16>, dim3(rest / 32, 1, nz), dim3(512), 0, s->stream, bt, NP, k0, w, s->S, u, x);
-            else hipLaunchKernelGGL(k_trsv_update_n<8>, dim3(rest / 32, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, s->S, u, x);
+        // 16 rows per workgroup (128-byte runs down a column), 32 columns per thread in one batch of loads: 64 workgroups per 1024-wide block.  Measured
+        // at C3 (7 solves per step): 0.71 ms for the solve + refinement phase against 0.82 with 32 rows x 64 columns per thread (32 workgroups per block)
+        // and 0.73 - 0.75 with 8 rows or 16 / 64 columns per thread.
+        if (w > 512) {                                                                        // (a block with rows below it is tb = 512, 1024 or 2048 wide)
+            hipLaunchKernelGGL((k_trsv_block_n<16, 32, 32>), dim3(w / 16, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, s->Tinv, x, s->Dx, u, z);
+            if (rest > 0) hipLaunchKernelGGL((k_trsv_update_n<16, 32, 32>), dim3(rest / 16, 1, nz), dim3(512), 0, s->stream, bt, NP, k0, w, s->S, u, x);
+        } else {
+            hipLaunchKernelGGL((k_trsv_block_n<16, 16, 32>), dim3(w / 16, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, s->Tinv, x, s->Dx, u, z);
+            if (rest > 0) hipLaunchKernelGGL((k_trsv_update_n<16, 16, 32>), dim3(rest / 16, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, s->S, u, x);
         }
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
