@@ -550,6 +550,10 @@ def main():
             cands = grp
     if staged is not None:                                    # stage-structured: the LDL^T is the multifrontal path, k_ldl_step does not run
         cands = [c for c in cands if c["ms_per_step"] > 0] or cands
+        for c in cands + (grp or []):
+            if c["kernel"] == K_LDL:                          # (the dense nx^3 / 3 does not price a factorisation over the stage tree: time only)
+                c.update(kernel="multifrontal LDL^T of S over the nested-dissection tree of the stages (sparse.hip), timed as a whole", achieved=None, frac=None,
+                         flops_per_launch=None, launches_per_step=None, avg_launch_ms=None)
     cands.sort(key=lambda c: -c["ms_per_step"])
     roof = dict(cands[0])
     roof["secondary"] = cands[1:]

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Everything profiles/ cites for a round, in one call on the GPU box (bash bench/evidence_round.sh): output under gpurun_out/round/.
+#   profile_round.sh (default bench line, kernel stats and PMC passes of the single system and of one group), the per-launch durations of the
+#   LDL^T chain (single / group), the C4 and C4T bench lines and the kernel stats of one C4T group, the chain timeline, the block harnesses.
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/round; mkdir -p $O
+cd $R
+bash bench/profile_round.sh 12 > $O/profile_round.log 2>&1
+bash bench/ldl_step_times.sh 0 0 > /dev/null 2>&1; cp gpurun_out/ldlsteps_0_0/steps.txt $O/ldl_steps_single.txt
+bash bench/ldl_step_times.sh 12 1 > /dev/null 2>&1; cp gpurun_out/ldlsteps_12_1/steps.txt $O/ldl_steps_group12_pairs.txt
+for c in C4 C4T; do
+  timeout 600 python bench.py --config $c --batch 32 --group 16 --lanes 2 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err < /dev/null
+done
+timeout 600 python bench.py --config C4T --batch 48 --group 16 --lanes 3 --no-cpu-baseline --no-single > $O/bench_C4T_48.json 2> /dev/null < /dev/null
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4t -- python $R/bench.py --config C4T --batch 16 --group 16 --lanes 1 --steps 10 --warmup 2 --batched-passes 10 --no-cpu-baseline --no-single > $O/bench_c4t_group_under_rocprof.json 2> /dev/null < /dev/null)
+f=$(find $O/stats_c4t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_c4t_group.csv; rm -rf $O/stats_c4t
+timeout 300 python bench/ldl_trace.py > $O/ldl_chain_timeline.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 bench/diag_bench3.hip -o /tmp/d3 2>/dev/null && timeout 60 /tmp/d3 > $O/diag_bench3.txt
+ls -la $O | head -60
