@@ -542,6 +542,31 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
                 form_Z(S + i0 + (size_t)(k0 + h * NB) * NP, NP, Mk + (size_t)h * NB * NB, Ys, Ms, Zs + h * TT * LDT, row, cb, wr, wc, fr, fk);
             if (t == 0) LDL_STAMP(r0 / NB, 1);
         }
+        if constexpr (NH == 2) {
+            // both column panels are staged at once (the second one in the buffer form_Z uses for M: free between two changes of tile row): two
+            // barriers per tile instead of four, and the two products run back to back on the matrix cores.  Same arithmetic, same order.
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) (h ? Ms : Ys)[row * LDT + cb + it * 16] = yv[h][it];
+            }
+            lds_barrier();
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cN[r] = Sn[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) yv[h][it] = Sn[(jn0 + row) + (size_t)(k0 + h * NB + cb + it * 16) * NP];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const v4d acc = frag_product((unsigned)(uintptr_t)(Zs + h * TT * LDT + (wr * 16 + fr) * LDT + fk), (unsigned)(uintptr_t)((h ? Ms : Ys) + (wc * 16 + fr) * LDT + fk));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cS[r] -= acc[r];
+            }
+        } else {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
 #pragma unroll
@@ -560,6 +585,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
 #pragma unroll
             for (int r = 0; r < 4; ++r) cS[r] -= acc[r];
             if (h + 1 < NH) lds_barrier();            // the operand reads of the first panel are done before Ys is refilled
+        }
         }
         if (t == 0) {
             // tile 0 = the diagonal block of the next panel: its 16 x 16 tiles are already where the diagonal block wants them (accumulator layout,
