@@ -508,13 +508,16 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
     int i0 = r0 + ti * TT, j0 = r0 + tj * TT;
     bool newrow = true;
     if (t == 0) LDL_STAMP(r0 / NB, 0);
+    // lane offsets inside a tile as 32-bit integers (NP^2 < 2^31), tile origins as wave-uniform pointers: scalar base + vector offset addressing,
+    // half the address registers
+    const int offC = (wr * 16 + fr) + (wc * 16 + fk) * NP, offY = row + cb * NP;
     double cS[4], yv[NH][4];              // operands of the current tile: the entries of S this lane updates, its share of the raw column panels
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cS[r] = S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP];
+    for (int r = 0; r < 4; ++r) cS[r] = (S + (i0 + (size_t)j0 * NP))[offC + 4 * r * NP];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) yv[h][it] = S[(j0 + row) + (size_t)(k0 + h * NB + cb + it * 16) * NP];
+        for (int it = 0; it < 4; ++it) yv[h][it] = (S + (j0 + (size_t)(k0 + h * NB) * NP))[offY + it * 16 * NP];
     }
     for (;;) {
         // next tile of this workgroup: its operands travel while the matrix cores work
@@ -553,11 +556,11 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
             lds_barrier();
             if (more) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cN[r] = Sn[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
+                for (int r = 0; r < 4; ++r) cN[r] = (Sn + (in0 + (size_t)jn0 * NP))[offC + 4 * r * NP];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) yv[h][it] = Sn[(jn0 + row) + (size_t)(k0 + h * NB + cb + it * 16) * NP];
+                    for (int it = 0; it < 4; ++it) yv[h][it] = (Sn + (jn0 + (size_t)(k0 + h * NB) * NP))[offY + it * 16 * NP];
                 }
             }
 #pragma unroll
@@ -576,10 +579,10 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
             if (more) {
                 if (h + 1 == NH) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) cN[r] = Sn[(in0 + wr * 16 + fr) + (size_t)(jn0 + wc * 16 + fk + 4 * r) * NP];
+                    for (int r = 0; r < 4; ++r) cN[r] = (Sn + (in0 + (size_t)jn0 * NP))[offC + 4 * r * NP];
                 }
 #pragma unroll
-                for (int it = 0; it < 4; ++it) yv[h][it] = Sn[(jn0 + row) + (size_t)(k0 + h * NB + cb + it * 16) * NP];
+                for (int it = 0; it < 4; ++it) yv[h][it] = (Sn + (jn0 + (size_t)(k0 + h * NB) * NP))[offY + it * 16 * NP];
             }
             const v4d acc = frag_product((unsigned)(uintptr_t)(Zs + h * TT * LDT + (wr * 16 + fr) * LDT + fk), (unsigned)(uintptr_t)(Ys + (wc * 16 + fr) * LDT + fk));
 #pragma unroll
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
             return;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S[(i0 + wr * 16 + fr) + (size_t)(j0 + wc * 16 + fk + 4 * r) * NP] = cS[r];
+        for (int r = 0; r < 4; ++r) (S + (i0 + (size_t)j0 * NP))[offC + 4 * r * NP] = cS[r];
         if (!more) return;
         t = tn; i0 = in0; j0 = jn0; newrow = nextrow;
         item += 1; off += doff; S += doff; Minv += doff; Mk += doff;
