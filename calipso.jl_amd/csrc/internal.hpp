@@ -66,7 +66,7 @@ struct Scalars {
 // "buffer X of instance k" = "buffer X of the base handle" + delta[k] doubles, for every X.  Kernels take this by value, use
 // blockIdx.z as the instance slot and shift their pointers (device_utils.hpp: inst_shift).  A single handle is a batch of one
 // with delta 0; a group (group.hip) steps several same-shape handles in lockstep through the same launches.
-constexpr int MAX_BATCH = 16;
+constexpr int MAX_BATCH = 32;
 struct Batch {
     int n = 1;                       // gridDim.z
     long long delta[MAX_BATCH] = {0};

@@ -261,7 +261,7 @@ int32_t calipso_hip_qp_evaluate(calipso_hip_solver*, int32_t which, uint32_t fla
 int32_t calipso_hip_newton_step(calipso_hip_solver*, int32_t advance, double info[6]);
 /* ---- groups: several handles of one shape stepped in lockstep through the same kernel launches ------------------------------
  * The reference has no batching: distinct `Solver`s are simply independent; BASELINE config C4 runs many of them
- * per GPU.  A group covers up to 16 handles created with identical dimensions and cone layout on one device; every launch of a
+ * per GPU.  A group covers up to 32 handles created with identical dimensions and cone layout on one device; every launch of a
  * group step carries all members (the instance is a grid dimension), so the latency-bound parts of the step cost the same for
  * the whole group as for one handle.  Per member the arithmetic is exactly that of calipso_hip_newton_step.  Members stay
  * usable through the single-handle entry points between group calls (not concurrently with them). */

@@ -237,12 +237,12 @@ def test_group_solve_with_parameters_differentiates_each_member():
     grp.close()
 
 
-@pytest.mark.parametrize("n", [5, 7, 13, 16])
+@pytest.mark.parametrize("n", [5, 7, 13, 16, 27, 32])
 def test_group_sizes_on_the_flattened_grids(n):
     """the group launches of the Schur complement and of the trailing updates run on ONE flattened grid whose workgroups are dealt to the
     XCDs by (instance, tile) ranges (schur.hip, ldl.hip): sizes that are not multiples of 8, and the largest group, give the stand-alone bits"""
     pkg = load_pkg()
-    shape = (700, 250, 60, 30, 3)
+    shape = (700, 250, 60, 30, 3) if n <= 16 else (300, 140, 40, 20, 3)
     ids = list(range(200, 200 + n))
     singles = [build(pkg, p, shape=shape) for p in ids]
     members = [build(pkg, p, shape=shape) for p in ids]
@@ -255,6 +255,10 @@ def test_group_sizes_on_the_flattened_grids(n):
             assert same(s.data("step").all, m.data("step").all)
             assert same(s.solution.all, m.solution.all)
     g.close()
+    if n == 32:                                            # the largest group (MAX_BATCH of internal.hpp): one more member is refused
+        extra = build(pkg, 999, shape=shape)
+        with pytest.raises(pkg.CalipsoHipError):
+            pkg.Group(members + [extra])
 
 
 def test_group_with_wide_second_order_cones_is_bitwise_the_single_step():
