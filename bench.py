@@ -215,8 +215,21 @@ class Exchange:
             uid = [pkg.Comm.unique_id() if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(uid, src=0)
-            self.comm = pkg.Comm(rank, world, uid[0], device=device)
-            self.path = "calipso_hip_comm_gather_status / calipso_hip_comm_allreduce_sum (RCCL ncclAllGather / ncclAllReduce, csrc/comm.hip)"
+            ok, why = 1, ""
+            try:
+                self.comm = pkg.Comm(rank, world, uid[0], device=device)
+            except Exception as e:                                    # (the exchange is outside the data path: never let it take the measurement down)
+                ok, why = 0, str(e)
+            if world > 1:                                             # every rank takes the same path
+                import torch
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda:%d" % device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
+                self.path = "calipso_hip_comm_gather_status / calipso_hip_comm_allreduce_sum (RCCL ncclAllGather / ncclAllReduce, csrc/comm.hip)"
+            else:
+                self.close()
+                self.path += "; the product's communicator could not be created on every rank (%s)" % (why or "another rank failed")
 
     def gather(self, status, counters):
         status = np.ascontiguousarray(status, dtype=np.int32).reshape(-1, 4)
