@@ -696,13 +696,13 @@ static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t 
     return CALIPSO_OK;
 }
 
-static int candidate_merit(H* s, calipso_eval_fn eval, void* user, double* Mh, double* thetah) {
+static int candidate_merit(H* s, calipso_eval_fn eval, void* user, double* Mh, double* thetah, bool with_dd = false) {   // with_dd: dscal[6] (launch_dot_merit, queued before) travels along
     int rc = evaluate(s, eval, user, 1, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);   // solve.jl:231-235
     if (rc < 0) return rc;
     launch_cone(s, s->candidate, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);                         // :237-240
     launch_merit(s, s->candidate);
-    launch_constraint_violation(s, s->candidate);
-    if (read_scalars(s, 4, 2)) return CALIPSO_ERR_HIP;
+    launch_constraint_violation(s, s->candidate, 4, with_dd ? 3 : 2);                                           // (the kernel publishes: no read-back launch)
+    if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
     *Mh = s->hscal[4]; *thetah = s->hscal[5];
     return CALIPSO_OK;
 }
@@ -720,8 +720,8 @@ static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equali
     launch_merit_gradient(s);                                                           // :118-124
     launch_residual(s);                                                                 // :127
     launch_violations(s);                                                               // :130-135
-    launch_constraint_violation(s, s->solution);                                        // :170-172 (computed early: one readback)
-    if (read_scalars(s, 4, 14)) return CALIPSO_ERR_HIP;
+    launch_constraint_violation(s, s->solution, 4, 14);                                 // :170-172 (computed early: one read-back, published by the kernel itself)
+    if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
     const double* hs = s->hscal;
     info.M = hs[4]; info.theta = hs[5];
     info.residual_violation = hs[8] / (double)d.N;
@@ -755,9 +755,8 @@ static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equali
     launch_merit_gradient(s);   // (unchanged; kept resident)
     launch_dot_merit(s);
     double Mh, thetah;
-    rc = candidate_merit(s, eval, user, &Mh, &thetah);                                  // :231-250
+    rc = candidate_merit(s, eval, user, &Mh, &thetah, true);                            // :231-250
     if (rc < 0) return rc;
-    if (read_scalars(s, 6, 1)) return CALIPSO_ERR_HIP;
     const double dd = s->hscal[6];
     const double M = info.M, theta = info.theta;
     calipso::i64 residual_iteration = 0;
@@ -783,8 +782,8 @@ static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equali
         augment_filter(s, (1.0 - o.violation_tolerance) * theta, M - o.merit_tolerance * theta);
     launch_accept(s, step_size);                                                        // :309-326
     launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT);                                  // :328-330
-    launch_violations(s);                                                               // ||g||inf, ||s o t||inf  :332-333
-    if (read_scalars(s, 16, 2)) return CALIPSO_ERR_HIP;
+    launch_violations(s, 16, 2);                                                        // ||g||inf, ||s o t||inf  :332-333
+    if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
     *eq_viol_out = s->hscal[16]; *cp_viol_out = s->hscal[17];
     EV(4);
     info.step_size = step_size; info.Mh = Mh; info.thetah = thetah;

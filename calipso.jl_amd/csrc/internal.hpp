@@ -262,7 +262,7 @@ void launch_cone_candidate_batch(calipso_hip_solver* s, const double* a_s, const
 void launch_cone_violation_host(calipso_hip_solver* s, const double* xhat_dev, const double* x_dev, double tau);
 // vectors.hip
 void launch_residual(calipso_hip_solver* s);
-void launch_violations(calipso_hip_solver* s);                  // -> dscal[8..]
+void launch_violations(calipso_hip_solver* s, int pub_first = 0, int pub_count = 0);   // pub_count > 0 (single handle): the kernel also publishes dscal[pub_first ..) for the read-back behind it                  // -> dscal[8..]
 void launch_residual_symmetric(calipso_hip_solver* s, const double* res);   // also fills xbuf (b_x, zero padded) and t1 = Omega b_m
 // back-substitution + recovery (+ accumulate += step); zsx_mode 0: leave zsx, 1: zsx = [gx; hx] dx (= t2), 2: zsx += t2
 void launch_recover(calipso_hip_solver* s, double* step, const double* res, double* accumulate, int zsx_mode = 0);
@@ -276,7 +276,7 @@ void launch_axpy_points_batch(calipso_hip_solver* s, const double* step_size, in
 void launch_accept_batch(calipso_hip_solver* s, const double* step_size);
 void launch_merit(calipso_hip_solver* s, const double* point);  // -> dscal[4] (M), uses dscal[0], dscal[1]
 void launch_merit_gradient(calipso_hip_solver* s);
-void launch_constraint_violation(calipso_hip_solver* s, const double* point);   // -> dscal[5]
+void launch_constraint_violation(calipso_hip_solver* s, const double* point, int pub_first = 0, int pub_count = 0);   // -> dscal[5]
 void launch_dot_merit(calipso_hip_solver* s);                   // -> dscal[6]
 void launch_Hmul(calipso_hip_solver* s, const double* v, double* out);   // out = H v
 void launch_residual_error(calipso_hip_solver* s, const double* step);   // residual_error = residual - H step ; dscal[7] = inf-norm

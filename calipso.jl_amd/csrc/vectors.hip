@@ -53,10 +53,23 @@ void launch_residual(calipso_hip_solver* s) {
 
 __device__ __forceinline__ double pnorm_term(double v, int ptype) { return ptype == 2 ? v * v : fabs(v); }
 
+// A read-back without a launch of its own: the LAST kernel in front of a scalar read-back (one workgroup, a single handle) copies dscal[first .. first +
+// count) — its own results and those of the kernels before it on the stream — to the handle's mapped host mirror and then stores the sequence number the
+// host spins on (api.hip: wait_published), as k_publish_words would.  hpub = nullptr: nothing (groups gather by their own kernels).
+__device__ __forceinline__ void publish_tail(const double* dscal, int first, int count, double* hpub, unsigned long long* hseq, unsigned long long seq) {
+    if (!hpub) return;
+    __syncthreads();                                             // this kernel's own stores to dscal are done (they are re-read past the L1 below)
+    if ((int)threadIdx.x < count) hpub[first + threadIdx.x] = __hip_atomic_load(dscal + first + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // the reductions of solve.jl:130-135,332-333 and optimality_error.jl:1-27 -> dscal[8..17]
 __global__ __launch_bounds__(RT) void k_violations(Batch bt, Dims d, int ptype, const double* __restrict__ res, const double* __restrict__ w,
                                                     const double* __restrict__ g, const double* __restrict__ prod,
-                                                    double* __restrict__ dscal) {
+                                                    double* __restrict__ dscal, int pub_first, int pub_count, double* __restrict__ hpub,
+                                                    unsigned long long* __restrict__ hseq, unsigned long long seq) {
     inst_shift(bt, res, w, g, prod, dscal);
     const int tid = threadIdx.x;
     double rp = 0.0, rprim = 0.0, ry = 0.0, rz = 0.0, rt = 0.0, y1 = 0.0, z1 = 0.0, t1 = 0.0, ginf = 0.0, pinf = 0.0;
@@ -89,14 +102,17 @@ __global__ __launch_bounds__(RT) void k_violations(Batch bt, Dims d, int ptype, 
         for (int i = 0; i < RT / 64; ++i) r = is_max ? fmax(r, red[tid][i]) : r + red[tid][i];
         dscal[8 + tid] = (tid == 0 && ptype == 2) ? sqrt(r) : r;
     }
+    publish_tail(dscal, pub_first, pub_count, hpub, hseq, seq);
 }
 
 static int norm_type(double p) { return p == 1.0 ? 1 : (p == 2.0 ? 2 : 0); }
 
-void launch_violations(calipso_hip_solver* s) {
+void launch_violations(calipso_hip_solver* s, int pub_first, int pub_count) {
     const BatchSc B = batch_of(s);
+    const bool pub = pub_count > 0 && !s->cur;               // a single handle: the kernel publishes the scalars of the read-back that follows it
     hipLaunchKernelGGL(k_violations, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B.b, s->d, norm_type(s->opt.residual_norm), s->residual, s->solution,
-                       s->g, s->cone_product, s->dscal);
+                       s->g, s->cone_product, s->dscal, pub_first, pub_count, pub ? s->hscal_dev : (double*)nullptr,
+                       pub ? s->hseq_dev : (unsigned long long*)nullptr, pub ? ++s->pub_seq : 0ULL);
 }
 
 // residual_symmetric!   residual.jl:53-101 (condensed right-hand side b).  The same kernel also emits the first operands of
@@ -415,7 +431,8 @@ void launch_merit_gradient(calipso_hip_solver* s) {
 // constraint_violation!   constraint_violation.jl:1-13 -> dscal[5]
 __global__ __launch_bounds__(RT) void k_constraint_violation(Batch bt, Dims d, int ptype, const double* __restrict__ point,
                                                               const double* __restrict__ g, const double* __restrict__ hc,
-                                                              double* __restrict__ dscal) {
+                                                              double* __restrict__ dscal, int pub_first, int pub_count, double* __restrict__ hpub,
+                                                              unsigned long long* __restrict__ hseq, unsigned long long seq) {
     __shared__ double sm[RT / 64];
     inst_shift(bt, point, g, hc, dscal);
     double acc = 0.0;
@@ -428,11 +445,14 @@ __global__ __launch_bounds__(RT) void k_constraint_violation(Batch bt, Dims d, i
         if (ptype == 2) r = sqrt(r);
         dscal[5] = r / (double)(d.ne + d.nc);
     }
+    publish_tail(dscal, pub_first, pub_count, hpub, hseq, seq);
 }
-void launch_constraint_violation(calipso_hip_solver* s, const double* point) {
+void launch_constraint_violation(calipso_hip_solver* s, const double* point, int pub_first, int pub_count) {
     const BatchSc B = batch_of(s);
+    const bool pub = pub_count > 0 && !s->cur;
     hipLaunchKernelGGL(k_constraint_violation, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B.b, s->d, norm_type(s->opt.constraint_norm), point, s->g,
-                       s->hc, s->dscal);
+                       s->hc, s->dscal, pub_first, pub_count, pub ? s->hscal_dev : (double*)nullptr, pub ? s->hseq_dev : (unsigned long long*)nullptr,
+                       pub ? ++s->pub_seq : 0ULL);
 }
 
 // d = dot(merit_gradient, step.primals)   line_search.jl:3,16 -> dscal[6]
