@@ -480,7 +480,7 @@ def main():
     # ---- warm-up of the batched pass; unit 0 alone (one group of G instances): its launches have the device to themselves => clean per-launch figures --
     alone, alone_chain, unit_rate = [], [], None
     if wl.batch is not None:
-        solve_block(wl.solvers if G > 1 else [], 512)
+        solve_block(wl.solvers if G > 1 else [], int(os.environ.get("CALIPSO_BENCH_GROUP_SOLVE_BLOCK", "512")))
         for _ in range(args.warmup):
             wl.batched_pass()
         barrier(wl)
