@@ -1,3 +1,4 @@
+# reads bench.py JSON lines from stdin and prints the headline, the roofline entry and the batched figures on one line (used by the sweeps in DESIGN 5.0)
 import json, sys
 for line in sys.stdin:
     if line.startswith('{"metric'):

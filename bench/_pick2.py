@@ -1,3 +1,4 @@
+# reads bench.py JSON lines from stdin: ms per step and the phase split of the single system (LDL^T, Schur complement, solve + refinement)
 import json, sys
 for line in sys.stdin:
     if line.startswith('{"metric'):

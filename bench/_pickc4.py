@@ -1,3 +1,4 @@
+# reads bench.py JSON lines from stdin: the config.c4 block (single / batched rates per configuration)
 import json, sys
 for l in sys.stdin:
     if l.startswith('{"metric'):

@@ -1,3 +1,4 @@
+# wall-clock time of repeated Newton steps of ONE C3 system (no phase queries in the loop): python bench/_steptime.py
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
