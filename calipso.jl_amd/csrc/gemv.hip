@@ -91,12 +91,12 @@ __global__ __launch_bounds__(256) void k_gemv_t(Batch bt, Sparsity sp, int rows,
 // y1 = A'x1 and y2 = A'x2 with ONE pass over A: the refinement residual needs [gx; hx]'(step_y; step_z) and the condensed solve that follows
 // needs [gx; hx]'(Omega b_m) — both input vectors are known at the same time (vectors.hip: k_refine_local), so the largest block of a
 // refinement round is read once for the two.  Same lane / summation layout as k_gemv_t.
-__global__ __launch_bounds__(256) void k_gemv_t2(Batch bt, Sparsity sp, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x1,
-                                                  const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2) {
+__device__ __forceinline__ void gemv_t2_body(Batch bt, Sparsity sp, int bx, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x1,
+                                             const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2) {
     inst_shift(bt, A, x1, x2, y1, y2);
     if (sp.kr) inst_shift_i(bt, sp.kr);
     const int lane = threadIdx.x & 63;
-    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int col = bx * 4 + (threadIdx.x >> 6);
     if (col >= cols) return;
     const double* a = A + (size_t)col * ld;
     const BlockRanges br = column_blocks(sp, col, rows);
@@ -122,6 +122,10 @@ __global__ __launch_bounds__(256) void k_gemv_t2(Batch bt, Sparsity sp, int rows
     }
     const double r1 = wave_sum(p0 + p1), r2 = wave_sum(q0 + q1);
     if (lane == 0) { y1[col] = r1; y2[col] = r2; }
+}
+__global__ __launch_bounds__(256) void k_gemv_t2(Batch bt, Sparsity sp, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x1,
+                                                  const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2) {
+    gemv_t2_body(bt, sp, blockIdx.x, rows, cols, A, ld, x1, x2, y1, y2);
 }
 
 // the structure tables of `s` for a block of the given kind (dense unless calipso_hip_analyze_structure found a band)
@@ -151,12 +155,12 @@ void gemv_t2(calipso_hip_solver* s, int rows, int cols, const double* A, int ld,
 constexpr int GN_ROWS = 256;    // rows per workgroup
 constexpr int GN_MAXCHUNK = 64; // column chunks
 
-__global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, Sparsity sp, int row_off, int rows, int cols, int chunk, const double* __restrict__ A, int ld,
-                                                             const double* __restrict__ x, double* __restrict__ partial) {
+__device__ __forceinline__ void gemv_n_partial_body(Batch bt, Sparsity sp, int bx, int by, int row_off, int rows, int cols, int chunk, const double* __restrict__ A, int ld,
+                                                    const double* __restrict__ x, double* __restrict__ partial) {
     inst_shift(bt, A, x, partial);
     if (sp.rowrange) inst_shift_i(bt, sp.rowrange);
-    const int i = blockIdx.x * GN_ROWS + threadIdx.x;
-    const int c0 = blockIdx.y * chunk;
+    const int i = bx * GN_ROWS + threadIdx.x;
+    const int c0 = by * chunk;
     const int c1 = min(cols, c0 + chunk);
     if (i >= rows) return;
     // columns of row i that can be non-zero (loads outside are predicated off; the summation order is that of the dense kernel)
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, Sparsity s
     if (sp.kind == SP_LXX) { jlo = i - sp.hb; jhi = i + sp.hb + 1; }
     else if (sp.kind != SP_DENSE) { jlo = sp.rowrange[2 * (row_off + i)]; jhi = sp.rowrange[2 * (row_off + i) + 1]; }
     double acc0 = 0.0, acc1 = 0.0;
-    if (sp.kind != SP_DENSE && (c1 <= jlo || c0 >= jhi)) { partial[(size_t)blockIdx.y * rows + i] = 0.0; return; }   // nothing of this chunk is inside the row's range
+    if (sp.kind != SP_DENSE && (c1 <= jlo || c0 >= jhi)) { partial[(size_t)by * rows + i] = 0.0; return; }   // nothing of this chunk is inside the row's range
     // batches of 24 loads per lane, all issued before the first use
     for (int j0 = c0; j0 < c1; j0 += 24) {
         if (sp.kind != SP_DENSE && (j0 + 24 <= jlo || j0 >= jhi)) continue;                                             // (a batch of exact zeros)
@@ -177,7 +181,23 @@ __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, Sparsity s
             acc1 += v[q + 1] * (j0 + q + 1 < c1 ? x[j0 + q + 1] : 0.0);
         }
     }
-    partial[(size_t)blockIdx.y * rows + i] = acc0 + acc1;
+    partial[(size_t)by * rows + i] = acc0 + acc1;
+}
+__global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, Sparsity sp, int row_off, int rows, int cols, int chunk, const double* __restrict__ A, int ld,
+                                                             const double* __restrict__ x, double* __restrict__ partial) {
+    gemv_n_partial_body(bt, sp, blockIdx.x, blockIdx.y, row_off, rows, cols, chunk, A, ld, x, partial);
+}
+// The two mat-vecs a refinement residual needs are independent of each other — [gx; hx]'(v_y; v_z) and [gx; hx]'(Omega b_m) in one pass (gemv_t2), Lxx v_x
+// (gemv_n) — and each is a 12 - 16 us kernel that does not fill the device for long: ONE launch runs both (the first nt2 workgroups take the columns of the
+// transposed product, the others the (row block, column chunk) pairs of the plain one), the same code and the same sums as the two kernels.
+__global__ __launch_bounds__(256) void k_gemv_t2_and_n(Batch bt, Sparsity spz, int rowsz, int colsz, const double* __restrict__ Z, int ldz, const double* __restrict__ x1,
+                                                        const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2, int nt2, Sparsity spl, int rb,
+                                                        int rowsl, int colsl, int chunk, const double* __restrict__ L, int ldl, const double* __restrict__ xl,
+                                                        double* __restrict__ partial) {
+    static_assert(GN_ROWS == 256, "one block size for both bodies");
+    const int b = blockIdx.x;
+    if (b < nt2) gemv_t2_body(bt, spz, b, rowsz, colsz, Z, ldz, x1, x2, y1, y2);
+    else gemv_n_partial_body(bt, spl, (b - nt2) % rb, (b - nt2) / rb, 0, rowsl, colsl, chunk, L, ldl, xl, partial);
 }
 
 // y = alpha * sum_chunks partial + beta*y: 64 rows per workgroup, 4 lanes per row each summing every 4th chunk in a fixed order
@@ -258,19 +278,41 @@ void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int l
     hipLaunchKernelGGL(k_gemv_n_reduce, dim3((cols + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, cols, nrr, part_t, yt, 1.0, beta_t);
 }
 
+static void gemv_n_chunks(int rows, int cols, int& rb, int& nchunk, int& chunk) {
+    // enough workgroups to cover the chip: rows/256 row blocks x nchunk column chunks ~ 1024 workgroups
+    rb = (rows + GN_ROWS - 1) / GN_ROWS;
+    nchunk = (768 + rb - 1) / rb;
+    if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
+    if (nchunk > (cols + 15) / 16) nchunk = (cols + 15) / 16;
+    if (nchunk < 1) nchunk = 1;
+    chunk = (cols + nchunk - 1) / nchunk;
+    nchunk = (cols + chunk - 1) / chunk;
+    if (cols == 0) nchunk = 0;
+}
+
+// y1 = Z'x1, y2 = Z'x2 (Z = [gx; hx], m x nx) and yl = Lxx xl in one launch + the reduction of the second (api.hip: refine_residual)
+void gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2, double* y1, double* y2, const double* xl, double* yl) {
+    const Dims& d = s->d;
+    if (d.m == 0 || s->blocks.on || s->compact) {              // no constraints, or the block kernels (blocks.hip): the two calls as they were
+        if (d.m) gemv_t2(s, d.m, d.nx, s->Z, d.m, x1, x2, y1, y2, SP_Z);
+        gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, xl, yl, 1.0, 0.0, SP_LXX);
+        return;
+    }
+    int rb, nchunk, chunk;
+    gemv_n_chunks(d.nx, d.nx, rb, nchunk, chunk);
+    const int nt2 = (d.nx + 3) / 4;
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_gemv_t2_and_n, dim3(nt2 + rb * nchunk, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, SP_Z), d.m, d.nx, s->Z, d.m, x1, x2, y1, y2, nt2,
+                       sparsity_of(s, SP_LXX), rb, d.nx, d.nx, chunk, s->Lxx, d.nx, xl, s->gemv_partial);
+    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((d.nx + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, d.nx, nchunk, s->gemv_partial, yl, 1.0, 0.0);
+}
+
 void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind) {
     if (rows == 0) return;
     if (blocks_gemv_n(s, kind, x, y, alpha, beta)) return;
     if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; return; }
-    // enough workgroups to cover the chip: rows/256 row blocks x nchunk column chunks ~ 1024 workgroups
-    const int rb = (rows + GN_ROWS - 1) / GN_ROWS;
-    int nchunk = (768 + rb - 1) / rb;
-    if (nchunk > GN_MAXCHUNK) nchunk = GN_MAXCHUNK;
-    if (nchunk > (cols + 15) / 16) nchunk = (cols + 15) / 16;
-    if (nchunk < 1) nchunk = 1;
-    const int chunk = (cols + nchunk - 1) / nchunk;
-    nchunk = (cols + chunk - 1) / chunk;
-    if (cols == 0) nchunk = 0;
+    int rb, nchunk, chunk;
+    gemv_n_chunks(rows, cols, rb, nchunk, chunk);
     const BatchSc B = batch_of(s);
     if (nchunk > 0)
         hipLaunchKernelGGL(k_gemv_n_partial, dim3(rb, nchunk, B.b.n), dim3(GN_ROWS), 0, s->stream, B.b, sparsity_of(s, kind), kind == SP_HX ? s->d.ne : 0, rows, cols, chunk, A, ld,

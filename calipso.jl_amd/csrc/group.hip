@@ -209,8 +209,7 @@ static void gb_sds(G* g, const Set& a, int which, bool accumulate) {
 static void gb_refine_residual(G* g) {
     H* s = g->base; const Dims& d = s->d;
     launch_refine_local(s);
-    if (d.m) gemv_t2(s, d.m, d.nx, s->Z, d.m, s->step + d.oy(), s->t1, s->w1, s->w2, SP_Z);
-    gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, s->step, s->lxv, 1.0, 0.0, SP_LXX);
+    gemv_refine_pair(s, s->step + d.oy(), s->t1, s->w1, s->w2, s->step, s->lxv);      // [gx; hx]'(two vectors) and Lxx step_x: one launch (gemv.hip)
     launch_refine_x(s);
 }
 static void gb_refine_solve(G* g) {

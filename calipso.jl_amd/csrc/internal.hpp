@@ -286,6 +286,7 @@ void launch_assemble_K(calipso_hip_solver* s);
 void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
 void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
 void gemv_t2(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x1, const double* x2, double* y1, double* y2, int kind = SP_DENSE);   // y1 = A'x1, y2 = A'x2, one pass
+void gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2, double* y1, double* y2, const double* xl, double* yl);   // gemv_t2 on [gx; hx] and gemv_n on Lxx in one launch
 void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t,
                int kind = SP_DENSE);   // yn = A x, yt = A'u + beta_t*yt, one pass over A
 // `kind` names the block (SP_Z, SP_GX, SP_HX, SP_LXX) so that a handle with an analysed structure skips its structural zeros
