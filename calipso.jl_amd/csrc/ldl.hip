@@ -748,11 +748,11 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     double* Minv = s->Ypanel;           // NP x 64: M_k of every panel (the buffer held round 2's unscaled panels)
     hipLaunchKernelGGL(k_ldl_diag, dim3(1, 1, nz), dim3(DIAG_THREADS), 0, s->stream, bt, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, Minv, s->icount);
     const int band = s->band64 > 0 ? s->band64 : nblk;     // 64-row blocks below a diagonal block that can be non-zero (structure.hip)
-    // persistent workgroups: one is resident per CU (registers, LDS).  ONE instance: 248 workers + the workgroup that carries the diagonal block =
-    // 31 + 1 per XCD at most, everything resident at once — since round 3's diagonal block (19 us) the early launches are bound by the trailing
-    // update, and a second wave of workgroups costs 5 us per launch (21.5 against 26.4 us at 512).  Groups keep 512 (they are throughput-bound).
+    // persistent workgroups: one is resident per CU (registers, LDS): 248 workers + the workgroups that carry the diagonal blocks = everything resident
+    // at once, 31 + 1 per XCD for one instance.  Since round 3's diagonal block (19 us) the early launches of ONE instance are bound by the trailing update,
+    // and a second wave of workgroups costs 5 us per launch (21.5 against 26.4 us at 512); a group of 12 gains 2 % (2.50 against 2.56 ms per factorisation).
     static const int resident_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_RESIDENT"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
-    const int resident_total = resident_env ? resident_env : nz == 1 ? 248 : 512;
+    const int resident_total = resident_env ? resident_env : 248;
     const int resident = std::max(2, resident_total / (int)nz);
     // Pair schedule (dense S, several instances per launch): the first tile column of panel k's update (whose tile 0 factors diagonal block
     // k + 1), then BOTH panels in one pass over the rest.  Same arithmetic as the plain schedule (k_ldl_step, MODE 2), half
