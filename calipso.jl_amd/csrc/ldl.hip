@@ -25,6 +25,7 @@
 // (10 launches for NP = 2560) instead of a 2560-long dependent chain.
 #include "internal.hpp"
 #include "device_utils.hpp"
+#include "pivot16.hpp"
 
 #include <algorithm>
 #include <mutex>
@@ -68,12 +69,6 @@ __device__ long long g_ldl_trace[64 * 16];
 #define LDL_STAMP(step, slot) do { } while (0)
 #endif
 
-__device__ __forceinline__ double fast_rcp(double v) {   // v_rcp_f64 + 2 Newton steps (pivots are normal numbers; 0 -> inf as 1/0)
-    double r = __builtin_amdgcn_rcp(v);
-    r = fma(fma(-v, r, 1.0), r, r);
-    r = fma(fma(-v, r, 1.0), r, r);
-    return r;
-}
 
 // LDS carve (doubles): Lk | Yk | cp | XT | XTs | dpiv | dinv
 constexpr int DIAG_LDS_DOUBLES = 3 * NB * LDT + NB * YS + 16 * CPS + 2 * NB;
@@ -82,50 +77,6 @@ __device__ __forceinline__ void lds_barrier_all() {                  // workgrou
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
 }
-// -- the owner of a round: 16 columns in registers.  Every statement is a volatile asm, so the order below IS the issue order: the updates of pivot J
-// on column J + 1, the broadcast of the NEXT pivot, then its reciprocal chain threaded through the remaining updates of pivot J.  DPP reads of a VGPR
-// need two wait states after a VALU write of it: only the pivot broadcast follows its producer that closely (s_nop 1 inside its string).
-template <int K> __device__ __forceinline__ double bcast16(double v) {
-    double m;
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(m) : "v"(v), "n"(K));
-    return m;
-}
-#define DPP_UPD(K)                                                                                                                      \
-    if constexpr ((K) < 16) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"                             \
-                                         : "+v"(a[(K) & 15]) : "v"(yrep), "v"(nl), "n"((K) & 15))
-template <int J> struct Pivot {
-    // on entry: rinv = reciprocal of pivot J; yrep (lane 16 m + k) = entry (16 r + k, p) of the pivot column p = 16 r + J — its rows of the diagonal
-    // 16 x 16 block, replicated in every 16-lane row: what the row-local broadcast needs
-    static __device__ __forceinline__ void run(double (&a)[16], unsigned yk_own, unsigned yk_rep, double* __restrict__ Lrow, int lane0, double rinv, double yrep) {
-        const double nl = a[J] * -rinv;
-        Lrow[J] = -nl;
-        if constexpr (J + 1 < 16) {
-            double rn, t, yn;
-            int dlo, dhi;
-            DPP_UPD(J + 1);
-            // column J + 1 is final: publish it (the matrix-core update reads it from LDS anyway) and read it back replicated (one ds_read_b64; the LDS
-            // queue of a wavefront is in order); the round trip hides behind the reciprocal chain, whose operand travels by v_readlane
-            asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(yk_own), "v"(a[J + 1]), "n"((J + 1) * 8) : "memory");
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(yn) : "v"(yk_rep), "n"((J + 1) * 8) : "memory");
-            asm volatile("s_nop 0\n\tv_readlane_b32 %0, %2, %4\n\tv_readlane_b32 %1, %3, %4" : "=&s"(dlo), "=&s"(dhi)
-                         : "v"(__double2loint(a[J + 1])), "v"(__double2hiint(a[J + 1])), "s"(lane0 + J + 1));
-            const double dn = __hiloint2double(dhi, dlo);
-            asm volatile("v_rcp_f64 %0, %1" : "=v"(rn) : "s"(dn));
-            DPP_UPD(J + 2); DPP_UPD(J + 3);
-            asm volatile("s_nop 0\n\tv_fma_f64 %0, -%1, %2, 1.0" : "=v"(t) : "s"(dn), "v"(rn));
-            DPP_UPD(J + 4);
-            asm volatile("v_fmac_f64 %0, %1, %0" : "+v"(rn) : "v"(t));
-            DPP_UPD(J + 5);
-            asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(t) : "s"(dn), "v"(rn));
-            DPP_UPD(J + 6);
-            asm volatile("v_fmac_f64 %0, %1, %0" : "+v"(rn) : "v"(t));
-            DPP_UPD(J + 7); DPP_UPD(J + 8); DPP_UPD(J + 9); DPP_UPD(J + 10); DPP_UPD(J + 11); DPP_UPD(J + 12); DPP_UPD(J + 13); DPP_UPD(J + 14); DPP_UPD(J + 15);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn) :: "memory");
-            Pivot<J + 1>::run(a, yk_own, yk_rep, Lrow, lane0, rn, yn);
-        }
-    }
-};
-#undef DPP_UPD
 // -- diagonal 16 x 16 inverse, in-wave by DPP: a helper wavefront grows columns 4 hq .. 4 hq + 3 (lane & 15 = row; the four 16-lane rows compute the
 // same).  X = G_14^-1 ... G_0^-1 applied to the identity: x[i] -= L[i][j] x[j] for i > j, j = 0 .. 14 in turn (x[j] by the row broadcast)
 template <int J> __device__ __forceinline__ void xrr_steps(double (&x)[4], const double (&nl)[15]) {
@@ -231,7 +182,7 @@ __device__ __forceinline__ void diag_block(double* __restrict__ smem, v4d acc, i
             const double y0 = cp[16 * r + (i & 15)];
             Yk[i * YS] = a[0];
             const int lo = __builtin_amdgcn_readlane(__double2loint(a[0]), 16 * r), hi = __builtin_amdgcn_readlane(__double2hiint(a[0]), 16 * r);
-            Pivot<0>::run(a, (unsigned)(uintptr_t)(Yk + i * YS), (unsigned)(uintptr_t)(Yk + (16 * r + (i & 15)) * YS), Lk + i * LDT + 16 * r, 16 * r,
+            Pivot<0, true>::run(a, (unsigned)(uintptr_t)(Yk + i * YS), (unsigned)(uintptr_t)(Yk + (16 * r + (i & 15)) * YS), Lk + i * LDT + 16 * r, 16 * r,
                           fast_rcp(__hiloint2double(hi, lo)), y0);
             if (i < 16) { const double d = Yk[(16 * r + i) * YS + i]; dpiv[16 * r + i] = d; dinv[16 * r + i] = fast_rcp(d); }   // (its own stores: the LDS queue of a wavefront is in order)
         }

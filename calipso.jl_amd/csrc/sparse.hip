@@ -23,6 +23,7 @@
 
 #include "internal.hpp"
 #include "device_utils.hpp"
+#include "pivot16.hpp"
 
 using calipso::i64;
 
@@ -177,6 +178,7 @@ typedef double calipso_v4d __attribute__((ext_vector_type(4)));
 // anyway; more waves shorten the panel, assembly and matrix-core phases)
 constexpr int MF_BIG = 96;
 constexpr int MF_MAX_FRONT = 196;             // (m (m + 1) / 2 + 2 m) doubles <= 160 KiB: the front's lower triangle, packed, + the pivot-column buffers
+constexpr int MF_PY = 18;                     // row stride of the exchange rows of an in-register panel (pivot16.hpp)
 constexpr int MF_MAX_FRONT_GLOBAL = 1024;     // larger fronts live in global memory (L2): same algorithm, every access a memory access — slower, but
                                               // still tree-parallel; beyond this the column method takes over
 
@@ -184,8 +186,22 @@ constexpr int MF_MAX_FRONT_GLOBAL = 1024;     // larger fronts live in global me
 // fit the 160 KiB of LDS (a full square would stop at 141).
 __device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }     // i >= k
 
+// rows of a front below the 64 its owner wavefront took (pivot16.hpp): the same rank-1 updates with the pivots already known — the pivot column's rows of the
+// diagonal 16 x 16 block (unscaled, replicated in every 16-lane row) and the reciprocal pivots come from LDS
+template <int J> __device__ __forceinline__ void mf_follow(double (&a)[16], const double (&yrep)[16], const double (&nrinv)[16]) {
+    if constexpr (J < 15) {
+        const double nl = a[J] * nrinv[J];
+        asm volatile("s_nop 1" :: "v"(nl));
+#define MF_UPD(K) if constexpr ((K) < 16) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a[(K) & 15]) : "v"(yrep[J]), "v"(nl), "n"((K) & 15))
+        MF_UPD(J + 1); MF_UPD(J + 2); MF_UPD(J + 3); MF_UPD(J + 4); MF_UPD(J + 5); MF_UPD(J + 6); MF_UPD(J + 7); MF_UPD(J + 8);
+        MF_UPD(J + 9); MF_UPD(J + 10); MF_UPD(J + 11); MF_UPD(J + 12); MF_UPD(J + 13); MF_UPD(J + 14); MF_UPD(J + 15);
+#undef MF_UPD
+        mf_follow<J + 1>(a, yrep, nrinv);
+    }
+}
+
 template <int MF_THREADS, bool GF>
-__global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first) {
+__global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first, int ypan) {
     constexpr int MF_RC = MF_THREADS / 16;        // row classes of the panel step (16 panel columns x MF_RC rows at a time)
     extern __shared__ __attribute__((aligned(16))) double Flds[];
     __shared__ int relS[256];                                                  // relative indices of the child being extend-added (LDS fronts: r <= 196)
@@ -226,6 +242,53 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
     for (int kb = 0; kb < c; kb += 16) {
         const int pe = min(kb + 16, c);
+        if (!GF && ypan && pe - kb == 16 && m >= 32) {
+            // A full panel through registers (pivot16.hpp; ldl.hip: diag_block has the design notes): wavefront 0 takes rows kb .. kb + 63 with lane = row and
+            // factors the 16 columns alone — no barrier between pivots —; the wavefronts behind it apply the same updates to the rows further down once the
+            // pivots are known.  Three barriers per panel instead of sixteen; the columns stay UNSCALED in the front, as the loop below leaves them.
+            double* Yp = F + nt + 2 * m;                                       // 64 exchange rows of MF_PY doubles (the owner's pivot columns, read back replicated)
+            __syncthreads();
+            if (wave == 0) {
+                const int row = kb + lane;
+                const bool in = row < m;
+                const int trow = in ? row * (row + 1) / 2 + kb : 0;
+                double a[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = (in && lane >= q) ? F[trow + q] : 0.0;
+                const int drow = kb + (lane & 15);
+                const double y0 = F[drow * (drow + 1) / 2 + kb];
+                const int lo = __builtin_amdgcn_readlane(__double2loint(a[0]), 0), hi = __builtin_amdgcn_readlane(__double2hiint(a[0]), 0);
+                calipso::Pivot<0, false>::run(a, (unsigned)(uintptr_t)(Yp + lane * MF_PY), (unsigned)(uintptr_t)(Yp + (lane & 15) * MF_PY), nullptr, 0,
+                                              calipso::fast_rcp(__hiloint2double(hi, lo)), y0);
+                if (in) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) if (lane >= q) F[trow + q] = a[q];
+                }
+                if (lane < 16) {
+                    double dd = a[0];
+#pragma unroll
+                    for (int q = 1; q < 16; ++q) dd = (lane == q) ? a[q] : dd;
+                    rinv[kb + lane] = calipso::fast_rcp(dd);
+                    Dg[f + kb + lane] = dd;
+                }
+            }
+            __syncthreads();
+            for (int base = kb + 64 * wave; wave >= 1 && base < m; base += 64 * (MF_THREADS / 64 - 1)) {
+                const int row = base + lane;
+                const bool in = row < m;
+                const int trow = in ? row * (row + 1) / 2 + kb : 0;
+                const int drow = kb + (lane & 15);
+                const double* Fd = F + drow * (drow + 1) / 2 + kb;
+                double a[16], yrep[16], nrinv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { a[q] = in ? F[trow + q] : 0.0; yrep[q] = Fd[q]; nrinv[q] = -rinv[kb + q]; }
+                mf_follow<0>(a, yrep, nrinv);
+                if (in) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) F[trow + q] = a[q];
+                }
+            }
+        } else
         for (int j = kb; j < pe; ++j) {
             __syncthreads();
             const double dj = F[tri(j, j)];
@@ -340,7 +403,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
     for (int i = tid; i < c; i += MF_THREADS) x[f + i] = v[i];
 }
 
-struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; bool global; };
+struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; bool global; int ypan; };   // ypan: room for the 64 x MF_PY exchange rows of the in-register panels
 // launch helpers: the thread count of a level is fixed by the analyse phase (MfSeg::threads)
 #define MF_LAUNCH(KERNEL, G, GRID, LDS, STREAM, ...)                                                                              \
     do {                                                                                                                          \
@@ -428,7 +491,7 @@ int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
 void enqueue_factor(calipso_hip_sparse* s) {
     if (s->mf) {
         for (const MfSeg& g : s->mplan)
-            MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, (unsigned)s->batch), g.lds_factor, s->stream, s->md, MfSlots{}, g.first);
+            MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, (unsigned)s->batch), g.lds_factor, s->stream, s->md, MfSlots{}, g.first, g.ypan);
         return;
     }
     const size_t lds = s->lds_acc ? sizeof(double) * (size_t)s->n : 0;
@@ -511,7 +574,7 @@ int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch
     MfSlots sl{};
     sl.use = 1;
     for (int k = 0; k < bt.n; ++k) sl.slot[k] = bt.slot[k];
-    for (const MfSeg& g : sp->mplan) MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, nz), g.lds_factor, st, sp->md, sl, g.first);
+    for (const MfSeg& g : sp->mplan) MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, nz), g.lds_factor, st, sp->md, sl, g.first, g.ypan);
     hipLaunchKernelGGL(k_count_signs, dim3(1, 1, nz), dim3(256), 0, st, bt, sp->d.D, sp->n, icount);
     sp->factored = true;
     return CALIPSO_OK;
@@ -829,7 +892,9 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                     pool_total = std::max(pool_total, off);
                     lf = 0; ls = sizeof(double) * mmax;
                 }
-                mplan.push_back({a, b - a, lf, ls, mmax > (size_t)MF_BIG ? 512 : 256, glob});
+                int ypan = 0;                                             // full 16-column panels of fronts with >= 32 rows go through registers (pivot16.hpp) when the LDS has room for the exchange rows
+                if (!glob && mmax >= 32 && lf + sizeof(double) * 64 * MF_PY <= (size_t)(160 * 1024 - 2048)) { ypan = 1; lf += sizeof(double) * 64 * MF_PY; }
+                mplan.push_back({a, b - a, lf, ls, mmax > (size_t)MF_BIG ? 512 : 256, glob, ypan});
                 mf_widest = std::max(mf_widest, b - a);
                 a = b;
             }
