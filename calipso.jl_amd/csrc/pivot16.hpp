@@ -22,15 +22,15 @@ template <int K> __device__ __forceinline__ double bcast16(double v) {
     return m;
 }
 #define DPP_UPD(K)                                                                                                                      \
-    if constexpr ((K) < 16) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"                             \
+    if constexpr ((K) < NC) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"                             \
                                          : "+v"(a[(K) & 15]) : "v"(yrep), "v"(nl), "n"((K) & 15))
-template <int J, bool STORE_L> struct Pivot {
+template <int J, bool STORE_L, int NC = 16> struct Pivot {     // NC: columns of the panel (16, or 8 for a half panel)
     // on entry: rinv = reciprocal of pivot J; yrep (lane 16 m + k) = entry (16 r + k, p) of the pivot column p = 16 r + J — its rows of the diagonal
     // 16 x 16 block, replicated in every 16-lane row: what the row-local broadcast needs
     static __device__ __forceinline__ void run(double (&a)[16], unsigned yk_own, unsigned yk_rep, double* __restrict__ Lrow, int lane0, double rinv, double yrep) {
         const double nl = a[J] * -rinv;
         if constexpr (STORE_L) Lrow[J] = -nl;
-        if constexpr (J + 1 < 16) {
+        if constexpr (J + 1 < NC) {
             double rn, t, yn;
             int dlo, dhi;
             DPP_UPD(J + 1);
@@ -52,7 +52,7 @@ template <int J, bool STORE_L> struct Pivot {
             asm volatile("v_fmac_f64 %0, %1, %0" : "+v"(rn) : "v"(t));
             DPP_UPD(J + 7); DPP_UPD(J + 8); DPP_UPD(J + 9); DPP_UPD(J + 10); DPP_UPD(J + 11); DPP_UPD(J + 12); DPP_UPD(J + 13); DPP_UPD(J + 14); DPP_UPD(J + 15);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yn) :: "memory");
-            Pivot<J + 1, STORE_L>::run(a, yk_own, yk_rep, Lrow, lane0, rn, yn);
+            Pivot<J + 1, STORE_L, NC>::run(a, yk_own, yk_rep, Lrow, lane0, rn, yn);
         }
     }
 };

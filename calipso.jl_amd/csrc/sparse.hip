@@ -188,15 +188,15 @@ __device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }
 
 // rows of a front below the 64 its owner wavefront took (pivot16.hpp): the same rank-1 updates with the pivots already known — the pivot column's rows of the
 // diagonal 16 x 16 block (unscaled, replicated in every 16-lane row) and the reciprocal pivots come from LDS
-template <int J> __device__ __forceinline__ void mf_follow(double (&a)[16], const double (&yrep)[16], const double (&nrinv)[16]) {
-    if constexpr (J < 15) {
+template <int J, int NC> __device__ __forceinline__ void mf_follow(double (&a)[16], const double (&yrep)[16], const double (&nrinv)[16]) {
+    if constexpr (J + 1 < NC) {
         const double nl = a[J] * nrinv[J];
         asm volatile("s_nop 1" :: "v"(nl));
-#define MF_UPD(K) if constexpr ((K) < 16) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a[(K) & 15]) : "v"(yrep[J]), "v"(nl), "n"((K) & 15))
+#define MF_UPD(K) if constexpr ((K) < NC) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a[(K) & 15]) : "v"(yrep[J]), "v"(nl), "n"((K) & 15))
         MF_UPD(J + 1); MF_UPD(J + 2); MF_UPD(J + 3); MF_UPD(J + 4); MF_UPD(J + 5); MF_UPD(J + 6); MF_UPD(J + 7); MF_UPD(J + 8);
         MF_UPD(J + 9); MF_UPD(J + 10); MF_UPD(J + 11); MF_UPD(J + 12); MF_UPD(J + 13); MF_UPD(J + 14); MF_UPD(J + 15);
 #undef MF_UPD
-        mf_follow<J + 1>(a, yrep, nrinv);
+        mf_follow<J + 1, NC>(a, yrep, nrinv);
     }
 }
 
@@ -242,11 +242,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
     for (int kb = 0; kb < c; kb += 16) {
         const int pe = min(kb + 16, c);
-        if (!GF && ypan && pe - kb == 16 && m >= 32) {
+        if (!GF && ypan && (pe - kb == 16 || pe - kb == 8) && m >= 32) {
             // A full panel through registers (pivot16.hpp; ldl.hip: diag_block has the design notes): wavefront 0 takes rows kb .. kb + 63 with lane = row and
             // factors the 16 columns alone — no barrier between pivots —; the wavefronts behind it apply the same updates to the rows further down once the
             // pivots are known.  Three barriers per panel instead of sixteen; the columns stay UNSCALED in the front, as the loop below leaves them.
             double* Yp = F + nt + 2 * m;                                       // 64 exchange rows of MF_PY doubles (the owner's pivot columns, read back replicated)
+            const bool half = pe - kb == 8;                                    // (a node of 56 columns ends in a half panel)
             __syncthreads();
             if (wave == 0) {
                 const int row = kb + lane;
@@ -254,17 +255,19 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
                 const int trow = in ? row * (row + 1) / 2 + kb : 0;
                 double a[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = (in && lane >= q) ? F[trow + q] : 0.0;
-                const int drow = kb + (lane & 15);
+                for (int q = 0; q < 16; ++q) a[q] = (in && lane >= q && (q < 8 || !half)) ? F[trow + q] : 0.0;
+                const int drow = min(kb + (lane & 15), m - 1);
                 const double y0 = F[drow * (drow + 1) / 2 + kb];
                 const int lo = __builtin_amdgcn_readlane(__double2loint(a[0]), 0), hi = __builtin_amdgcn_readlane(__double2hiint(a[0]), 0);
-                calipso::Pivot<0, false>::run(a, (unsigned)(uintptr_t)(Yp + lane * MF_PY), (unsigned)(uintptr_t)(Yp + (lane & 15) * MF_PY), nullptr, 0,
-                                              calipso::fast_rcp(__hiloint2double(hi, lo)), y0);
+                if (half) calipso::Pivot<0, false, 8>::run(a, (unsigned)(uintptr_t)(Yp + lane * MF_PY), (unsigned)(uintptr_t)(Yp + (lane & 15) * MF_PY), nullptr, 0,
+                                                           calipso::fast_rcp(__hiloint2double(hi, lo)), y0);
+                else calipso::Pivot<0, false, 16>::run(a, (unsigned)(uintptr_t)(Yp + lane * MF_PY), (unsigned)(uintptr_t)(Yp + (lane & 15) * MF_PY), nullptr, 0,
+                                                       calipso::fast_rcp(__hiloint2double(hi, lo)), y0);
                 if (in) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) if (lane >= q) F[trow + q] = a[q];
+                    for (int q = 0; q < 16; ++q) if (lane >= q && (q < 8 || !half)) F[trow + q] = a[q];
                 }
-                if (lane < 16) {
+                if (lane < (half ? 8 : 16)) {
                     double dd = a[0];
 #pragma unroll
                     for (int q = 1; q < 16; ++q) dd = (lane == q) ? a[q] : dd;
@@ -277,15 +280,15 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
                 const int row = base + lane;
                 const bool in = row < m;
                 const int trow = in ? row * (row + 1) / 2 + kb : 0;
-                const int drow = kb + (lane & 15);
+                const int drow = min(kb + (lane & 15), m - 1);
                 const double* Fd = F + drow * (drow + 1) / 2 + kb;
                 double a[16], yrep[16], nrinv[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { a[q] = in ? F[trow + q] : 0.0; yrep[q] = Fd[q]; nrinv[q] = -rinv[kb + q]; }
-                mf_follow<0>(a, yrep, nrinv);
+                for (int q = 0; q < 16; ++q) { const bool u = q < 8 || !half; a[q] = (in && u) ? F[trow + q] : 0.0; yrep[q] = u ? Fd[q] : 0.0; nrinv[q] = u ? -rinv[kb + q] : 0.0; }
+                if (half) mf_follow<0, 8>(a, yrep, nrinv); else mf_follow<0, 16>(a, yrep, nrinv);
                 if (in) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) F[trow + q] = a[q];
+                    for (int q = 0; q < 16; ++q) if (q < 8 || !half) F[trow + q] = a[q];
                 }
             }
         } else
@@ -340,20 +343,28 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     for (int e = tid; e < r * r; e += MF_THREADS) { const int a = e / r, b = e - a * r; if (a >= b) U[e] = F[tri(c + a, c + b)]; }
 }
 
-// forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors
+// forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors.
+// The c <= 64 dependent steps of the triangular solve run in ONE wavefront (lane = row, y_k by v_readlane, no barrier: ~20 cycles per step instead of a
+// workgroup barrier); the product with L21 is spread over all threads (four k-slices per row, combined in a fixed order).  The panel is read where it
+// lies (every entry is used once): the LDS holds only the vector.  (GP, the former "panel too large for the LDS" variant, is the same code now.)
+__device__ __forceinline__ double mf_readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
 template <int MF_THREADS, bool GP>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
-    double* v = GP ? sm : sm + (size_t)m * c;                                  // GP: the panel is too large for the LDS and is read in place
+    double* v = sm;                                                            // m
+    double* part = sm + m;                                                     // 4 r
     double* x = X + (size_t)blockIdx.y * n;                                    // blockIdx.y = instance * nrhs + right-hand side
     double* ubase = d.uvec + (size_t)blockIdx.y * usum;
     const double* panel = d.panel + (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)) * d.sPanel;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* P = panel + d.panel_off[s];
-    const double* Ps = GP ? P : sm;
-    if (!GP) { for (int e = tid; e < m * c; e += MF_THREADS) sm[e] = P[e]; }
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] : 0.0;
     __syncthreads();
     for (int q = d.childptr[s]; q < d.childptr[s + 1]; ++q) {
@@ -364,43 +375,65 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
         for (int a = tid; a < rc; a += MF_THREADS) v[rel[a]] += u[a];
         __syncthreads();
     }
-    for (int k = 0; k < c; ++k) {
-        const double yk = v[k];
-        for (int i = k + 1 + tid; i < m; i += MF_THREADS) v[i] -= Ps[i + k * m] * yk;
-        __syncthreads();
+    if (wave == 0) {
+        double vi = lane < c ? v[lane] : 0.0;
+        for (int k0 = 0; k0 < c; k0 += 8) {
+            double pl[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int k = k0 + q; pl[q] = (k < c && lane > k && lane < c) ? P[lane + (size_t)k * m] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int k = k0 + q; if (k < c) vi = fma(-pl[q], mf_readlane_d(vi, k), vi); }
+        }
+        if (lane < c) { v[lane] = vi; x[f + lane] = vi; }
     }
-    for (int i = tid; i < c; i += MF_THREADS) x[f + i] = v[i];
+    __syncthreads();
+    const int cs = (c + 3) / 4;
+    for (int idx = tid; idx < 4 * r; idx += MF_THREADS) {
+        const int a = idx % r, q = idx / r, kbeg = q * cs, kend = min(c, kbeg + cs);
+        const double* Pi = P + (c + a);
+        double acc = 0.0;
+        for (int k = kbeg; k < kend; ++k) acc += Pi[(size_t)k * m] * v[k];
+        part[idx] = acc;
+    }
+    __syncthreads();
     double* u = ubase + d.u_off[s];
-    for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a];
+    for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a] - ((part[a] + part[r + a]) + (part[2 * r + a] + part[3 * r + a]));
 }
-// backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C
+// backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C.  One wavefront per column for the product with L21'
+// (lanes along the rows, contiguous), then the c dependent steps in one wavefront (lane = column, x_i by v_readlane).
 template <int MF_THREADS, bool GP>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = d.order[first + blockIdx.x];
     const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
-    double* v = GP ? sm : sm + (size_t)m * c;
+    double* v = sm;
     double* x = X + (size_t)blockIdx.y * n;
     const size_t zs = (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs));
     const double* panel = d.panel + zs * d.sPanel; const double* Dg = d.D + zs * d.sD;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* P = panel + d.panel_off[s];
     const int* R = d.rows + d.rowptr[s];
-    const double* Ps = GP ? P : sm;
-    if (!GP) { for (int e = tid; e < m * c; e += MF_THREADS) sm[e] = P[e]; }
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] / Dg[f + i] : x[R[i - c]];
     __syncthreads();
-    double z = 0.0;
-    if (tid < c) { z = v[tid]; for (int a = 0; a < r; ++a) z -= Ps[(c + a) + tid * m] * v[c + a]; }
-    __syncthreads();
-    if (tid < c) v[tid] = z;
-    __syncthreads();
-    for (int k = c - 1; k >= 0; --k) {
-        const double xk = v[k];
-        for (int j = tid; j < k; j += MF_THREADS) v[j] -= Ps[k + j * m] * xk;
-        __syncthreads();
+    for (int k = wave; k < c; k += MF_THREADS / 64) {
+        const double* Pk = P + c + (size_t)k * m;
+        double acc = 0.0;
+        for (int a = lane; a < r; a += 64) acc += Pk[a] * v[c + a];
+        acc = calipso::wave_sum(acc);
+        if (lane == 0) v[k] -= acc;
     }
-    for (int i = tid; i < c; i += MF_THREADS) x[f + i] = v[i];
+    __syncthreads();
+    if (wave == 0) {
+        double zk = lane < c ? v[lane] : 0.0;
+        for (int i0 = c - 1; i0 >= 1; i0 -= 8) {
+            double pl[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int i = i0 - q; pl[q] = (i >= 1 && lane < i) ? P[i + (size_t)lane * m] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int i = i0 - q; if (i >= 1) zk = fma(-pl[q], mf_readlane_d(zk, i), zk); }
+        }
+        if (lane < c) x[f + lane] = zk;
+    }
 }
 
 struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; bool global; int ypan; };   // ypan: room for the 64 x MF_PY exchange rows of the in-register panels
@@ -881,7 +914,7 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                 int b = a; size_t lf = 0, ls = 0, mmax = 0;
                 while (b < NN && lev[(size_t)m_order[(size_t)b]] == lev[(size_t)m_order[(size_t)a]]) {
                     const int t = m_order[(size_t)b]; const size_t m = (size_t)(m_cols[(size_t)t] + m_rows[(size_t)t]);
-                    lf = std::max(lf, sizeof(double) * (m * (m + 1) / 2 + 2 * m)); ls = std::max(ls, sizeof(double) * (m * (size_t)m_cols[(size_t)t] + m));
+                    lf = std::max(lf, sizeof(double) * (m * (m + 1) / 2 + 2 * m)); ls = std::max(ls, sizeof(double) * 5 * m);   // the vector + four slices of partial sums per row
                     mmax = std::max(mmax, m);
                     ++b;
                 }
@@ -890,7 +923,7 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                     long long off = 0;
                     for (int q = a; q < b; ++q) { const int t = m_order[(size_t)q]; const long long mm = m_cols[(size_t)t] + m_rows[(size_t)t]; m_foff[(size_t)t] = off; off += mm * (mm + 1) / 2; }
                     pool_total = std::max(pool_total, off);
-                    lf = 0; ls = sizeof(double) * mmax;
+                    lf = 0;
                 }
                 int ypan = 0;                                             // full 16-column panels of fronts with >= 32 rows go through registers (pivot16.hpp) when the LDS has room for the exchange rows
                 if (!glob && mmax >= 32 && lf + sizeof(double) * 64 * MF_PY <= (size_t)(160 * 1024 - 2048)) { ypan = 1; lf += sizeof(double) * 64 * MF_PY; }
