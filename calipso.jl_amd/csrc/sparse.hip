@@ -377,12 +377,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
     }
     if (wave == 0) {
         double vi = lane < c ? v[lane] : 0.0;
-        for (int k0 = 0; k0 < c; k0 += 8) {
-            double pl[8];
+        // the whole lower triangle of L11 travels before the first step (two batches of 32 columns: every load of a batch is in flight at once; a batch
+        // per 8 columns would expose one memory round trip per batch)
+        for (int k0 = 0; k0 < c; k0 += 32) {
+            double pl[32];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int k = k0 + q; pl[q] = (k < c && lane > k && lane < c) ? P[lane + (size_t)k * m] : 0.0; }
+            for (int q = 0; q < 32; ++q) { const int k = k0 + q; pl[q] = (k < c && lane > k && lane < c) ? P[lane + (size_t)k * m] : 0.0; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int k = k0 + q; if (k < c) vi = fma(-pl[q], mf_readlane_d(vi, k), vi); }
+            for (int q = 0; q < 32; ++q) { const int k = k0 + q; if (k < c) vi = fma(-pl[q], mf_readlane_d(vi, k), vi); }
         }
         if (lane < c) { v[lane] = vi; x[f + lane] = vi; }
     }
@@ -392,7 +394,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
         const int a = idx % r, q = idx / r, kbeg = q * cs, kend = min(c, kbeg + cs);
         const double* Pi = P + (c + a);
         double acc = 0.0;
-        for (int k = kbeg; k < kend; ++k) acc += Pi[(size_t)k * m] * v[k];
+        for (int k = kbeg; k < kend; k += 8) {                                 // (eight loads in flight)
+            double pv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pv[q] = k + q < kend ? Pi[(size_t)(k + q) * m] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += pv[q] * (k + q < kend ? v[k + q] : 0.0);
+        }
         part[idx] = acc;
     }
     __syncthreads();
@@ -415,22 +423,36 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
     const int* R = d.rows + d.rowptr[s];
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] / Dg[f + i] : x[R[i - c]];
     __syncthreads();
-    for (int k = wave; k < c; k += MF_THREADS / 64) {
-        const double* Pk = P + c + (size_t)k * m;
-        double acc = 0.0;
-        for (int a = lane; a < r; a += 64) acc += Pk[a] * v[c + a];
-        acc = calipso::wave_sum(acc);
-        if (lane == 0) v[k] -= acc;
+    {
+        constexpr int NW = MF_THREADS / 64, CPW = 64 / NW;                     // columns per wavefront: k = wave + NW q (c <= 64); their loads travel together
+        double acc[CPW];
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) acc[q] = 0.0;
+        for (int a0 = 0; a0 < r; a0 += 64) {
+            const int a = a0 + lane;
+            const double va = a < r ? v[c + a] : 0.0;
+            double pv[CPW];
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) { const int k = wave + NW * q; pv[q] = (k < c && a < r) ? P[(c + a) + (size_t)k * m] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) acc[q] += pv[q] * va;
+        }
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const int k = wave + NW * q;
+            const double t = calipso::wave_sum(acc[q]);
+            if (lane == 0 && k < c) v[k] -= t;
+        }
     }
     __syncthreads();
     if (wave == 0) {
         double zk = lane < c ? v[lane] : 0.0;
-        for (int i0 = c - 1; i0 >= 1; i0 -= 8) {
-            double pl[8];
+        for (int i0 = c - 1; i0 >= 1; i0 -= 32) {
+            double pl[32];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int i = i0 - q; pl[q] = (i >= 1 && lane < i) ? P[i + (size_t)lane * m] : 0.0; }
+            for (int q = 0; q < 32; ++q) { const int i = i0 - q; pl[q] = (i >= 1 && lane < i) ? P[i + (size_t)lane * m] : 0.0; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int i = i0 - q; if (i >= 1) zk = fma(-pl[q], mf_readlane_d(zk, i), zk); }
+            for (int q = 0; q < 32; ++q) { const int i = i0 - q; if (i >= 1) zk = fma(-pl[q], mf_readlane_d(zk, i), zk); }
         }
         if (lane < c) x[f + lane] = zk;
     }
