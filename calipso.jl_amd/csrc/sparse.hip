@@ -310,37 +310,51 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
         }
         __syncthreads();
         const int ntl = (m - pe + 15) / 16;                                    // 16-row tiles of the trailing part
-        // a wave takes whole tile rows (largest first): the first operand's fragments are read once per row and reused for every tile of the row
-        for (int q = wave; q < ntl; q += MF_THREADS / 64) {
-            const int bi = ntl - 1 - q;
+        // the tiles of the lower triangle (bi >= bj), row-major, dealt round-robin to the wavefronts: every wavefront gets the same number of tiles to within
+        // one (whole tile rows per wavefront left the one with the longest rows 1.7 x the average).  Two accumulator chains per tile (a dependent
+        // v_mfma_f64_16x16x4 issues every 64 cycles).
+        const int ntile = ntl * (ntl + 1) / 2;
+        for (int t = wave; t < ntile; t += MF_THREADS / 64) {
+            int bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+            while (bi * (bi + 1) / 2 > t) --bi;
+            const int bj = t - bi * (bi + 1) / 2;
             const int ia = pe + 16 * bi + fr;                                  // the row this lane feeds to the first operand
             const int ra = ia * (ia + 1) / 2;
-            double av[4];
+            const int jbr = pe + 16 * bj + fr;                                  // ... to the second operand
+            const int rb = jbr * (jbr + 1) / 2;
+            double av[4], bv[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { const int k = kb + 4 * kk + fk; av[kk] = (k < pe && ia < m) ? F[ra + k] * rinv[k] : 0.0; }
-            for (int bj = 0; bj <= bi; ++bj) {
-                const int jbr = pe + 16 * bj + fr;                              // ... to the second operand
-                const int rb = jbr * (jbr + 1) / 2;
-                calipso_v4d acc = {0.0, 0.0, 0.0, 0.0};
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = kb + 4 * kk + fk;
+                av[kk] = (k < pe && ia < m) ? F[ra + k] * rinv[k] : 0.0;
+                bv[kk] = (k < pe && jbr < m) ? F[rb + k] : 0.0;
+            }
+            calipso_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+            const int j = pe + 16 * bj + fr;                                    // result column (second operand's tile)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = kb + 4 * kk + fk;
-                    const double bv = (k < pe && jbr < m) ? F[rb + k] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int i = pe + 16 * bi + fk + 4 * rr, j = pe + 16 * bj + fr;   // result row (first operand's tile), column (second's)
-                    if (i < m && j <= i) F[tri(i, j)] -= acc[rr];
-                }
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = pe + 16 * bi + fk + 4 * rr;                       // result row (first operand's tile)
+                if (i < m && j <= i) F[i * (i + 1) / 2 + j] -= acc[rr] + acc2[rr];
             }
         }
     }
     __syncthreads();
     double* P = panel + d.panel_off[s];                                        // column-major m x c: column k contiguous over the rows
-    for (int e = tid; e < m * c; e += MF_THREADS) { const int i = e % m, k = e / m; P[e] = i > k ? F[tri(i, k)] * rinv[k] : 0.0; }
+    // write-out: a wavefront per column of the panel (lanes along the rows: contiguous stores) / per row of the update matrix (lanes along the columns)
+    for (int k = wave; k < c; k += MF_THREADS / 64) {
+        const double rk = rinv[k];
+        for (int i = lane; i < m; i += 64) P[i + (size_t)k * m] = i > k ? F[i * (i + 1) / 2 + k] * rk : 0.0;
+    }
     double* U = upd + d.upd_off[s];
-    for (int e = tid; e < r * r; e += MF_THREADS) { const int a = e / r, b = e - a * r; if (a >= b) U[e] = F[tri(c + a, c + b)]; }
+    for (int a = wave; a < r; a += MF_THREADS / 64) {
+        const double* Fa = F + (c + a) * (c + a + 1) / 2 + c;
+        for (int b = lane; b <= a; b += 64) U[(size_t)a * r + b] = Fa[b];
+    }
 }
 
 // forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors.
