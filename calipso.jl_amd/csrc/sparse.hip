@@ -200,8 +200,26 @@ template <int J, int NC> __device__ __forceinline__ void mf_follow(double (&a)[1
     }
 }
 
+// Optional timeline of one front per level (build with -DCALIPSO_LDL_TRACE: `make trace`; bench/mf_trace.py reads it through calipso_hip_debug_mf_trace):
+// 100 MHz wall-clock stamps of workgroup (0, 0) of every k_mf_factor launch, keyed by the launch's `first` node index.
+#ifdef CALIPSO_LDL_TRACE
+__device__ long long g_mf_trace[64 * 12];
+__device__ int g_mf_trace_n;
+#define MF_STAMP(slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_mf_trace[(mf_tr & 63) * 12 + (slot)] = wall_clock64(); } while (0)
+#else
+#define MF_STAMP(slot) do { } while (0)
+#endif
+
 template <int MF_THREADS, bool GF>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first, int ypan) {
+#ifdef CALIPSO_LDL_TRACE
+    __shared__ int mf_tr_s;
+    if (threadIdx.x == 0) mf_tr_s = (blockIdx.x == 0 && blockIdx.y == 0) ? atomicAdd(&g_mf_trace_n, 1) : 0;
+    __syncthreads();
+    const int mf_tr = mf_tr_s;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_mf_trace[(mf_tr & 63) * 12 + 10] = d.ncols[d.order[first]]; g_mf_trace[(mf_tr & 63) * 12 + 11] = d.ncols[d.order[first]] + d.nrows[d.order[first]]; }
+#endif
+    MF_STAMP(0);
     constexpr int MF_RC = MF_THREADS / 16;        // row classes of the panel step (16 panel columns x MF_RC rows at a time)
     extern __shared__ __attribute__((aligned(16))) double Flds[];
     __shared__ int relS[256];                                                  // relative indices of the child being extend-added (LDS fronts: r <= 196)
@@ -216,8 +234,10 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     double* upd = d.upd + z * d.sUpd; double* panel = d.panel + z * d.sPanel; double* Dg = d.D + z * d.sD;
     for (int e = tid; e < nt; e += MF_THREADS) F[e] = 0.0;
     __syncthreads();
+    MF_STAMP(1);
     for (int p = d.Alp[f] + tid; p < d.Alp[f + c]; p += MF_THREADS) F[d.Aloc[p]] = Aval[d.Asrc[p]];
     __syncthreads();
+    MF_STAMP(2);
     for (int q = d.childptr[s]; q < d.childptr[s + 1]; ++q) {                 // extend-add, children in ascending order
         const int ch = d.children[q];
         const int rc = d.nrows[ch];
@@ -229,7 +249,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
             const int rla = GF ? rel[a] : relS[a];
             const int ra = rla * (rla + 1) / 2;                                // rel is increasing: the lower triangle lands in the lower triangle
             const double* Ua = U + (size_t)a * rc;
-            for (int b = tid & 31; b <= a; b += 32) F[ra + (GF ? rel[b] : relS[b])] += Ua[b];
+            if (GF) { for (int b = tid & 31; b <= a; b += 32) F[ra + rel[b]] += Ua[b]; }
+            else {
+                double uv[7];                                                  // (rc <= 196: at most seven chunks of 32) all loads of the row in flight, then the LDS updates
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { const int b = (tid & 31) + 32 * q; uv[q] = b <= a ? Ua[b] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { const int b = (tid & 31) + 32 * q; if (b <= a) F[ra + relS[b]] += uv[q]; }
+            }
         }
         __syncthreads();
     }
@@ -240,8 +267,15 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     //           (v_mfma_f64_16x16x4: first operand = scaled rows of the i tile, second = rows of the j tile, K = 16 = one panel).
     double* rinv = ycol;                                                       // c reciprocal pivots (the 2 m doubles behind the front)
     const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    MF_STAMP(3);
+#ifdef CALIPSO_LDL_TRACE
+    long long mf_pan = 0, mf_upd = 0, mf_t0 = 0;
+#endif
     for (int kb = 0; kb < c; kb += 16) {
         const int pe = min(kb + 16, c);
+#ifdef CALIPSO_LDL_TRACE
+        mf_t0 = wall_clock64();
+#endif
         if (!GF && ypan && (pe - kb == 16 || pe - kb == 8) && m >= 32) {
             // A full panel through registers (pivot16.hpp; ldl.hip: diag_block has the design notes): wavefront 0 takes rows kb .. kb + 63 with lane = row and
             // factors the 16 columns alone — no barrier between pivots —; the wavefronts behind it apply the same updates to the rows further down once the
@@ -252,10 +286,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
             if (wave == 0) {
                 const int row = kb + lane;
                 const bool in = row < m;
-                const int trow = in ? row * (row + 1) / 2 + kb : 0;
+                const int rowc = min(row, m - 1);
+                const int trow = rowc * (rowc + 1) / 2 + kb;                   // (loads unconditional from a valid address, then selected: no exec-masked blocks)
                 double a[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = (in && lane >= q && (q < 8 || !half)) ? F[trow + q] : 0.0;
+                for (int q = 0; q < 16; ++q) a[q] = F[trow + min(q, rowc - kb)];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = (in && lane >= q && (q < 8 || !half)) ? a[q] : 0.0;
                 const int drow = min(kb + (lane & 15), m - 1);
                 const double y0 = F[drow * (drow + 1) / 2 + kb];
                 const int lo = __builtin_amdgcn_readlane(__double2loint(a[0]), 0), hi = __builtin_amdgcn_readlane(__double2hiint(a[0]), 0);
@@ -279,12 +316,15 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
             for (int base = kb + 64 * wave; wave >= 1 && base < m; base += 64 * (MF_THREADS / 64 - 1)) {
                 const int row = base + lane;
                 const bool in = row < m;
-                const int trow = in ? row * (row + 1) / 2 + kb : 0;
+                const int rowc = min(row, m - 1);
+                const int trow = rowc * (rowc + 1) / 2 + kb;
                 const int drow = min(kb + (lane & 15), m - 1);
                 const double* Fd = F + drow * (drow + 1) / 2 + kb;
                 double a[16], yrep[16], nrinv[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { const bool u = q < 8 || !half; a[q] = (in && u) ? F[trow + q] : 0.0; yrep[q] = u ? Fd[q] : 0.0; nrinv[q] = u ? -rinv[kb + q] : 0.0; }
+                for (int q = 0; q < 16; ++q) { a[q] = F[trow + q]; yrep[q] = Fd[q]; nrinv[q] = rinv[min(kb + q, pe - 1)]; }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { const bool u = q < 8 || !half; a[q] = (in && u) ? a[q] : 0.0; yrep[q] = u ? yrep[q] : 0.0; nrinv[q] = u ? -nrinv[q] : 0.0; }
                 if (half) mf_follow<0, 8>(a, yrep, nrinv); else mf_follow<0, 16>(a, yrep, nrinv);
                 if (in) {
 #pragma unroll
@@ -309,6 +349,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
             }
         }
         __syncthreads();
+#ifdef CALIPSO_LDL_TRACE
+        { const long long t1 = wall_clock64(); mf_pan += t1 - mf_t0; mf_t0 = t1; }
+#endif
         const int ntl = (m - pe + 15) / 16;                                    // 16-row tiles of the trailing part
         // the tiles of the lower triangle (bi >= bj), row-major, dealt round-robin to the wavefronts: every wavefront gets the same number of tiles to within
         // one (whole tile rows per wavefront left the one with the longest rows 1.7 x the average).  Two accumulator chains per tile (a dependent
@@ -320,30 +363,54 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
             while (bi * (bi + 1) / 2 > t) --bi;
             const int bj = t - bi * (bi + 1) / 2;
             const int ia = pe + 16 * bi + fr;                                  // the row this lane feeds to the first operand
-            const int ra = ia * (ia + 1) / 2;
             const int jbr = pe + 16 * bj + fr;                                  // ... to the second operand
-            const int rb = jbr * (jbr + 1) / 2;
+            // every LDS read below is unconditional, from a clamped (always valid) address, and all of them are issued before the first use: a load inside a
+            // conditional becomes an exec-masked block with its own wait (measured: 2400 cycles per tile that way)
+            const int iac = min(ia, m - 1), jbc = min(jbr, m - 1);
+            const int ra = iac * (iac + 1) / 2, rb = jbc * (jbc + 1) / 2;
+            double af[4], bf[4], rf[4], old[4];
+            int oidx[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int kc = min(kb + 4 * kk + fk, pe - 1);
+                af[kk] = F[ra + kc]; bf[kk] = F[rb + kc]; rf[kk] = rinv[kc];
+            }
+            const int j = pe + 16 * bj + fr;                                    // result column (second operand's tile)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = pe + 16 * bi + fk + 4 * rr;                       // result row (first operand's tile)
+                const int ic = min(i, m - 1), jc = min(j, ic);
+                oidx[rr] = ic * (ic + 1) / 2 + jc;
+                old[rr] = F[oidx[rr]];
+            }
             double av[4], bv[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const int k = kb + 4 * kk + fk;
-                av[kk] = (k < pe && ia < m) ? F[ra + k] * rinv[k] : 0.0;
-                bv[kk] = (k < pe && jbr < m) ? F[rb + k] : 0.0;
+                const bool kin = kb + 4 * kk + fk < pe;
+                av[kk] = (kin && ia < m) ? af[kk] * rf[kk] : 0.0;
+                bv[kk] = (kin && jbr < m) ? bf[kk] : 0.0;
             }
             calipso_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
-            const int j = pe + 16 * bj + fr;                                    // result column (second operand's tile)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int i = pe + 16 * bi + fk + 4 * rr;                       // result row (first operand's tile)
-                if (i < m && j <= i) F[i * (i + 1) / 2 + j] -= acc[rr] + acc2[rr];
+                const int i = pe + 16 * bi + fk + 4 * rr;
+                if (i < m && j <= i) F[oidx[rr]] = old[rr] - (acc[rr] + acc2[rr]);
             }
         }
+#ifdef CALIPSO_LDL_TRACE
+        __syncthreads();
+        mf_upd += wall_clock64() - mf_t0;
+#endif
     }
     __syncthreads();
+    MF_STAMP(4);
+#ifdef CALIPSO_LDL_TRACE
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { g_mf_trace[(mf_tr & 63) * 12 + 8] = mf_pan; g_mf_trace[(mf_tr & 63) * 12 + 9] = mf_upd; }
+#endif
     double* P = panel + d.panel_off[s];                                        // column-major m x c: column k contiguous over the rows
     // write-out: a wavefront per column of the panel (lanes along the rows: contiguous stores) / per row of the update matrix (lanes along the columns)
     for (int k = wave; k < c; k += MF_THREADS / 64) {
@@ -355,6 +422,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
         const double* Fa = F + (c + a) * (c + a + 1) / 2 + c;
         for (int b = lane; b <= a; b += 64) U[(size_t)a * r + b] = Fa[b];
     }
+    MF_STAMP(5);
 }
 
 // forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors.
@@ -703,6 +771,16 @@ int sparse_reserve_solve(calipso_hip_sparse* s, int batch) {
 }
 void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]) { out[0] = sp->levels; out[1] = sp->max_front; out[2] = sp->nnzU; out[3] = sp->mf ? 2 : (sp->lds_acc ? 1 : 0); }
 }  // namespace calipso
+
+#ifdef CALIPSO_LDL_TRACE
+extern "C" int32_t calipso_hip_debug_mf_trace(long long* out, int32_t reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace), sizeof(long long) * 64 * 12) != hipSuccess) return -1;
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_mf_trace_n), sizeof(int)) != hipSuccess) return -1;
+    if (reset) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mf_trace_n), &z, sizeof(int)); }
+    return n;
+}
+#endif
 
 extern "C" {
 
