@@ -152,8 +152,14 @@ __global__ void k_sp_permute_out(const double* __restrict__ x, const int* __rest
 // ascending order: fixed summation order), the first c columns are eliminated by a dense LDL^T in LDS (one barrier per pivot column), the
 // m x c panel of L goes to global memory and U_s = F_s[c.., c..] to the node's slot of the update pool.  One launch per LEVEL of the node tree:
 // for a T-stage trajectory problem that is ~log2 T launches for the whole factorisation — the stages are eliminated in parallel, level by level.
+// One record per node in LAUNCH order and one per (node, child): what a workgroup needs to find its front comes with ONE load each instead of a chain of
+// dependent table look-ups (order -> nfirst / ncols / nrows -> childptr -> children -> upd_off / rowptr ...: 0.7 us per hop on a cold launch).
+struct MfNode { int s, f, c, r; int rowptr, chfirst, nch, alp0; int alp1, pad0, pad1, pad2; long long panel_off, upd_off, u_off, foff; };
+struct MfChild { int rc, rowptr; long long upd_off, u_off; };
 struct MfDev {
     int nnodes;
+    const MfNode* nrec;                       // [launch position]
+    const MfChild* crec;                      // [chfirst + q], children in ascending order
     const int* order;                         // nodes sorted by level
     const int *nfirst, *ncols, *nrows;        // per node: first column, c, r
     const int *rowptr, *rows;                 // R_s (global, permuted row indices), ascending
@@ -217,45 +223,61 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     if (threadIdx.x == 0) mf_tr_s = (blockIdx.x == 0 && blockIdx.y == 0) ? atomicAdd(&g_mf_trace_n, 1) : 0;
     __syncthreads();
     const int mf_tr = mf_tr_s;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_mf_trace[(mf_tr & 63) * 12 + 10] = d.ncols[d.order[first]]; g_mf_trace[(mf_tr & 63) * 12 + 11] = d.ncols[d.order[first]] + d.nrows[d.order[first]]; }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_mf_trace[(mf_tr & 63) * 12 + 10] = d.nrec[first].c; g_mf_trace[(mf_tr & 63) * 12 + 11] = d.nrec[first].c + d.nrec[first].r; }
 #endif
     MF_STAMP(0);
     constexpr int MF_RC = MF_THREADS / 16;        // row classes of the panel step (16 panel columns x MF_RC rows at a time)
     extern __shared__ __attribute__((aligned(16))) double Flds[];
     __shared__ int relS[256];                                                  // relative indices of the child being extend-added (LDS fronts: r <= 196)
     __shared__ double rinvS[64];                                               // GF: reciprocal pivots (a node has at most 64 columns)
-    const int s = d.order[first + blockIdx.x];
-    const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r, nt = m * (m + 1) / 2;
+    const MfNode nd = d.nrec[first + blockIdx.x];
+    const int f = nd.f, c = nd.c, r = nd.r, m = c + r, nt = m * (m + 1) / 2;
     const int tid = threadIdx.x;
     const size_t z = sl.use ? (size_t)sl.slot[blockIdx.y] : (size_t)blockIdx.y;   // storage slot of this instance of the batch
-    double* F = GF ? d.fpool + z * d.sPool + d.foff[s] : Flds;                  // GF: the front lives in global memory (L2-resident)
+    double* F = GF ? d.fpool + z * d.sPool + nd.foff : Flds;                    // GF: the front lives in global memory (L2-resident)
     double* ycol = GF ? rinvS : F + nt;
     const double* Aval = d.Aval + z * d.sA;
     double* upd = d.upd + z * d.sUpd; double* panel = d.panel + z * d.sPanel; double* Dg = d.D + z * d.sD;
     for (int e = tid; e < nt; e += MF_THREADS) F[e] = 0.0;
     __syncthreads();
     MF_STAMP(1);
-    for (int p = d.Alp[f] + tid; p < d.Alp[f + c]; p += MF_THREADS) F[d.Aloc[p]] = Aval[d.Asrc[p]];
+    for (int p = nd.alp0 + tid; p < nd.alp1; p += MF_THREADS) F[d.Aloc[p]] = Aval[d.Asrc[p]];
     __syncthreads();
     MF_STAMP(2);
-    for (int q = d.childptr[s]; q < d.childptr[s + 1]; ++q) {                 // extend-add, children in ascending order
-        const int ch = d.children[q];
-        const int rc = d.nrows[ch];
-        const double* U = upd + d.upd_off[ch];
-        const int* rel = d.rel + d.rowptr[ch];
+    for (int q = 0; q < nd.nch; ++q) {                                         // extend-add, children in ascending order
+        const MfChild cr = d.crec[nd.chfirst + q];
+        const int rc = cr.rc;
+        const double* U = upd + cr.upd_off;
+        const int* rel = d.rel + cr.rowptr;
         if (!GF) { for (int a = tid; a < rc; a += MF_THREADS) relS[a] = rel[a]; }
         __syncthreads();
-        for (int a = tid >> 5; a < rc; a += MF_THREADS / 32) {                 // a row of the child's update matrix per 32 lanes, coalesced along b
-            const int rla = GF ? rel[a] : relS[a];
-            const int ra = rla * (rla + 1) / 2;                                // rel is increasing: the lower triangle lands in the lower triangle
-            const double* Ua = U + (size_t)a * rc;
-            if (GF) { for (int b = tid & 31; b <= a; b += 32) F[ra + rel[b]] += Ua[b]; }
-            else {
-                double uv[7];                                                  // (rc <= 196: at most seven chunks of 32) all loads of the row in flight, then the LDS updates
+        if (GF) {
+            for (int a = tid >> 5; a < rc; a += MF_THREADS / 32) {             // a row of the child's update matrix per 32 lanes, coalesced along b
+                const int rla = rel[a];
+                const int ra = rla * (rla + 1) / 2;                            // rel is increasing: the lower triangle lands in the lower triangle
+                const double* Ua = U + (size_t)a * rc;
+                for (int b = tid & 31; b <= a; b += 32) F[ra + rel[b]] += Ua[b];
+            }
+        } else {
+            // a row of the child's update matrix per 32 lanes (rc <= 196: at most seven chunks of 32 columns); the values of the NEXT row of this lane group
+            // travel while the current one is added into the front (one memory round trip per row otherwise: 7 rows x 0.8 us per child)
+            const int lb = tid & 31;
+            int a = tid >> 5;
+            double uv[7];
 #pragma unroll
-                for (int q = 0; q < 7; ++q) { const int b = (tid & 31) + 32 * q; uv[q] = b <= a ? Ua[b] : 0.0; }
+            for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; uv[q] = (a < rc && b <= a) ? U[(size_t)a * rc + b] : 0.0; }
+            while (a < rc) {
+                const int an = a + MF_THREADS / 32;
+                double un[7];
 #pragma unroll
-                for (int q = 0; q < 7; ++q) { const int b = (tid & 31) + 32 * q; if (b <= a) F[ra + relS[b]] += uv[q]; }
+                for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; un[q] = (an < rc && b <= an) ? U[(size_t)an * rc + b] : 0.0; }
+                const int rla = relS[a];
+                const int ra = rla * (rla + 1) / 2;                            // rel is increasing: the lower triangle lands in the lower triangle
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; if (b <= a) F[ra + relS[b]] += uv[q]; }
+#pragma unroll
+                for (int q = 0; q < 7; ++q) uv[q] = un[q];
+                a = an;
             }
         }
         __syncthreads();
@@ -411,13 +433,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
 #ifdef CALIPSO_LDL_TRACE
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { g_mf_trace[(mf_tr & 63) * 12 + 8] = mf_pan; g_mf_trace[(mf_tr & 63) * 12 + 9] = mf_upd; }
 #endif
-    double* P = panel + d.panel_off[s];                                        // column-major m x c: column k contiguous over the rows
+    double* P = panel + nd.panel_off;                                          // column-major m x c: column k contiguous over the rows
     // write-out: a wavefront per column of the panel (lanes along the rows: contiguous stores) / per row of the update matrix (lanes along the columns)
     for (int k = wave; k < c; k += MF_THREADS / 64) {
         const double rk = rinv[k];
         for (int i = lane; i < m; i += 64) P[i + (size_t)k * m] = i > k ? F[i * (i + 1) / 2 + k] * rk : 0.0;
     }
-    double* U = upd + d.upd_off[s];
+    double* U = upd + nd.upd_off;
     for (int a = wave; a < r; a += MF_THREADS / 64) {
         const double* Fa = F + (c + a) * (c + a + 1) / 2 + c;
         for (int b = lane; b <= a; b += 64) U[(size_t)a * r + b] = Fa[b];
@@ -438,22 +460,22 @@ __device__ __forceinline__ double mf_readlane_d(double v, int lane) {
 template <int MF_THREADS, bool GP>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int s = d.order[first + blockIdx.x];
-    const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
+    const MfNode nd = d.nrec[first + blockIdx.x];
+    const int f = nd.f, c = nd.c, r = nd.r, m = c + r;
     double* v = sm;                                                            // m
     double* part = sm + m;                                                     // 4 r
     double* x = X + (size_t)blockIdx.y * n;                                    // blockIdx.y = instance * nrhs + right-hand side
     double* ubase = d.uvec + (size_t)blockIdx.y * usum;
     const double* panel = d.panel + (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)) * d.sPanel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* P = panel + d.panel_off[s];
+    const double* P = panel + nd.panel_off;
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] : 0.0;
     __syncthreads();
-    for (int q = d.childptr[s]; q < d.childptr[s + 1]; ++q) {
-        const int ch = d.children[q];
-        const int rc = d.nrows[ch];
-        const double* u = ubase + d.u_off[ch];
-        const int* rel = d.rel + d.rowptr[ch];
+    for (int q = 0; q < nd.nch; ++q) {
+        const MfChild cr = d.crec[nd.chfirst + q];
+        const int rc = cr.rc;
+        const double* u = ubase + cr.u_off;
+        const int* rel = d.rel + cr.rowptr;
         for (int a = tid; a < rc; a += MF_THREADS) v[rel[a]] += u[a];
         __syncthreads();
     }
@@ -486,7 +508,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
         part[idx] = acc;
     }
     __syncthreads();
-    double* u = ubase + d.u_off[s];
+    double* u = ubase + nd.u_off;
     for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a] - ((part[a] + part[r + a]) + (part[2 * r + a] + part[3 * r + a]));
 }
 // backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C.  One wavefront per column for the product with L21'
@@ -494,15 +516,15 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
 template <int MF_THREADS, bool GP>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int s = d.order[first + blockIdx.x];
-    const int f = d.nfirst[s], c = d.ncols[s], r = d.nrows[s], m = c + r;
+    const MfNode nd = d.nrec[first + blockIdx.x];
+    const int f = nd.f, c = nd.c, r = nd.r, m = c + r;
     double* v = sm;
     double* x = X + (size_t)blockIdx.y * n;
     const size_t zs = (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs));
     const double* panel = d.panel + zs * d.sPanel; const double* Dg = d.D + zs * d.sD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* P = panel + d.panel_off[s];
-    const int* R = d.rows + d.rowptr[s];
+    const double* P = panel + nd.panel_off;
+    const int* R = d.rows + nd.rowptr;
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] / Dg[f + i] : x[R[i - c]];
     __syncthreads();
     {
@@ -1080,6 +1102,23 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
             (rc = upload(s, m_rowptr, &md.rowptr)) || (rc = upload(s, m_rowsv, &md.rows)) || (rc = upload(s, m_rel, &md.rel)) || (rc = upload(s, m_childptr, &md.childptr)) ||
             (rc = upload(s, m_children, &md.children)) || (rc = upload(s, m_panel_off, &md.panel_off)) || (rc = upload(s, m_upd_off, &md.upd_off)) ||
             (rc = upload(s, m_u_off, &md.u_off)) || (rc = upload(s, m_Aloc, &md.Aloc)) || (rc = upload(s, m_foff, &md.foff))) return rc;
+        {
+            std::vector<MfNode> nrec((size_t)NN);
+            std::vector<MfChild> crec;
+            for (int pos = 0; pos < NN; ++pos) {
+                const int t = m_order[(size_t)pos];
+                MfNode& nd = nrec[(size_t)pos];
+                nd.s = t; nd.f = m_first[(size_t)t]; nd.c = m_cols[(size_t)t]; nd.r = m_rows[(size_t)t];
+                nd.rowptr = m_rowptr[(size_t)t]; nd.chfirst = (int)crec.size(); nd.nch = m_childptr[(size_t)t + 1] - m_childptr[(size_t)t];
+                nd.alp0 = (int)Alp[(size_t)nd.f]; nd.alp1 = (int)Alp[(size_t)(nd.f + nd.c)]; nd.pad0 = nd.pad1 = nd.pad2 = 0;
+                nd.panel_off = m_panel_off[(size_t)t]; nd.upd_off = m_upd_off[(size_t)t]; nd.u_off = m_u_off[(size_t)t]; nd.foff = m_foff.empty() ? 0 : m_foff[(size_t)t];
+                for (int q = m_childptr[(size_t)t]; q < m_childptr[(size_t)t + 1]; ++q) {
+                    const int ch = m_children[(size_t)q];
+                    crec.push_back({m_rows[(size_t)ch], m_rowptr[(size_t)ch], m_upd_off[(size_t)ch], m_u_off[(size_t)ch]});
+                }
+            }
+            if ((rc = upload(s, nrec, &md.nrec)) || (rc = upload(s, crec, &md.crec))) return rc;
+        }
         s->pool_total = pool_total;
         if ((rc = alloc_values(s, 1))) return rc;      // (again: now with the pool of the global-memory fronts)
         md.Alp = s->d.Alp; md.Asrc = s->d.Asrc;
