@@ -469,6 +469,22 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
     const double* panel = d.panel + (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)) * d.sPanel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* P = panel + nd.panel_off;
+    // Every entry of the panel this thread will need is requested FIRST (the panel does not depend on the vector): the lower triangle of L11 by wavefront 0
+    // (two batches of 32 columns), the first slice of L21 by everybody; the assembly of the vector runs while they travel.
+    const int cs = (c + 3) / 4;                                                // columns per slice of the product with L21 (c <= 64: at most 16)
+    double pl0[32], pl1[32], pv0[16];
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) { pl0[q] = (q < c && lane > q && lane < c) ? P[lane + (size_t)q * m] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) { const int k = 32 + q; pl1[q] = (k < c && lane > k && lane < c) ? P[lane + (size_t)k * m] : 0.0; }
+    }
+    {
+        const int idx = tid, a = r > 0 ? idx % r : 0, q4 = r > 0 ? idx / r : 0, kbeg = q4 * cs, kend = min(c, kbeg + cs);
+        const double* Pi = P + (c + a);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pv0[q] = (idx < 4 * r && kbeg + q < kend) ? Pi[(size_t)(kbeg + q) * m] : 0.0;
+    }
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] : 0.0;
     __syncthreads();
     for (int q = 0; q < nd.nch; ++q) {
@@ -481,29 +497,26 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
     }
     if (wave == 0) {
         double vi = lane < c ? v[lane] : 0.0;
-        // the whole lower triangle of L11 travels before the first step (two batches of 32 columns: every load of a batch is in flight at once; a batch
-        // per 8 columns would expose one memory round trip per batch)
-        for (int k0 = 0; k0 < c; k0 += 32) {
-            double pl[32];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) { const int k = k0 + q; pl[q] = (k < c && lane > k && lane < c) ? P[lane + (size_t)k * m] : 0.0; }
+        for (int q = 0; q < 32; ++q) { if (q < c) vi = fma(-pl0[q], mf_readlane_d(vi, q), vi); }
 #pragma unroll
-            for (int q = 0; q < 32; ++q) { const int k = k0 + q; if (k < c) vi = fma(-pl[q], mf_readlane_d(vi, k), vi); }
-        }
+        for (int q = 0; q < 32; ++q) { const int k = 32 + q; if (k < c) vi = fma(-pl1[q], mf_readlane_d(vi, k), vi); }
         if (lane < c) { v[lane] = vi; x[f + lane] = vi; }
     }
     __syncthreads();
-    const int cs = (c + 3) / 4;
     for (int idx = tid; idx < 4 * r; idx += MF_THREADS) {
-        const int a = idx % r, q = idx / r, kbeg = q * cs, kend = min(c, kbeg + cs);
+        const int a = idx % r, q4 = idx / r, kbeg = q4 * cs, kend = min(c, kbeg + cs);
         const double* Pi = P + (c + a);
         double acc = 0.0;
-        for (int k = kbeg; k < kend; k += 8) {                                 // (eight loads in flight)
-            double pv[8];
+        if (idx == tid) {                                                       // the slice fetched at the top
 #pragma unroll
-            for (int q = 0; q < 8; ++q) pv[q] = k + q < kend ? Pi[(size_t)(k + q) * m] : 0.0;
+            for (int q = 0; q < 16; ++q) acc += pv0[q] * (kbeg + q < kend ? v[kbeg + q] : 0.0);
+        } else {
+            double pv[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += pv[q] * (k + q < kend ? v[k + q] : 0.0);
+            for (int q = 0; q < 16; ++q) pv[q] = kbeg + q < kend ? Pi[(size_t)(kbeg + q) * m] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc += pv[q] * (kbeg + q < kend ? v[kbeg + q] : 0.0);
         }
         part[idx] = acc;
     }
@@ -525,10 +538,20 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* P = panel + nd.panel_off;
     const int* R = d.rows + nd.rowptr;
+    constexpr int NW = MF_THREADS / 64, CPW = 64 / NW;                         // columns per wavefront: k = wave + NW q (c <= 64); their loads travel together
+    // the panel entries of the first row chunk (and, wavefront 0, the rows of L11 it will walk) are requested before the vector is assembled
+    double pvf[CPW], pl0[32], pl1[32];
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) { const int k = wave + NW * q; pvf[q] = (k < c && lane < r) ? P[(c + lane) + (size_t)k * m] : 0.0; }
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) { const int i = c - 1 - q; pl0[q] = (i >= 1 && lane < i) ? P[i + (size_t)lane * m] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) { const int i = c - 33 - q; pl1[q] = (i >= 1 && lane < i) ? P[i + (size_t)lane * m] : 0.0; }
+    }
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] / Dg[f + i] : x[R[i - c]];
     __syncthreads();
     {
-        constexpr int NW = MF_THREADS / 64, CPW = 64 / NW;                     // columns per wavefront: k = wave + NW q (c <= 64); their loads travel together
         double acc[CPW];
 #pragma unroll
         for (int q = 0; q < CPW; ++q) acc[q] = 0.0;
@@ -536,8 +559,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
             const int a = a0 + lane;
             const double va = a < r ? v[c + a] : 0.0;
             double pv[CPW];
+            if (a0 == 0) {
 #pragma unroll
-            for (int q = 0; q < CPW; ++q) { const int k = wave + NW * q; pv[q] = (k < c && a < r) ? P[(c + a) + (size_t)k * m] : 0.0; }
+                for (int q = 0; q < CPW; ++q) pv[q] = pvf[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) { const int k = wave + NW * q; pv[q] = (k < c && a < r) ? P[(c + a) + (size_t)k * m] : 0.0; }
+            }
 #pragma unroll
             for (int q = 0; q < CPW; ++q) acc[q] += pv[q] * va;
         }
@@ -551,13 +579,10 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
     __syncthreads();
     if (wave == 0) {
         double zk = lane < c ? v[lane] : 0.0;
-        for (int i0 = c - 1; i0 >= 1; i0 -= 32) {
-            double pl[32];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) { const int i = i0 - q; pl[q] = (i >= 1 && lane < i) ? P[i + (size_t)lane * m] : 0.0; }
+        for (int q = 0; q < 32; ++q) { const int i = c - 1 - q; if (i >= 1) zk = fma(-pl0[q], mf_readlane_d(zk, i), zk); }
 #pragma unroll
-            for (int q = 0; q < 32; ++q) { const int i = i0 - q; if (i >= 1) zk = fma(-pl[q], mf_readlane_d(zk, i), zk); }
-        }
+        for (int q = 0; q < 32; ++q) { const int i = c - 33 - q; if (i >= 1) zk = fma(-pl1[q], mf_readlane_d(zk, i), zk); }
         if (lane < c) x[f + lane] = zk;
     }
 }
