@@ -190,7 +190,10 @@ constexpr int MF_MAX_FRONT_GLOBAL = 1024;     // larger fronts live in global me
 
 // The front is symmetric: only its lower triangle is held, packed row by row (row i starts at i (i + 1) / 2), which lets fronts of up to 196 rows
 // fit the 160 KiB of LDS (a full square would stop at 141).
-__device__ __forceinline__ int tri(int i, int k) { return i * (i + 1) / 2 + k; }     // i >= k
+// i (i + 1) / 2 for a row index below 4096 by the full-rate 24-bit multiply (a 32-bit integer multiply issues at a quarter of the rate, and the trailing
+// update of a front is bound by exactly this index arithmetic)
+__device__ __forceinline__ int tri0(int i) { return (int)(__umul24((unsigned)i, (unsigned)(i + 1)) >> 1); }
+__device__ __forceinline__ int tri(int i, int k) { return tri0(i) + k; }     // i >= k
 
 // rows of a front below the 64 its owner wavefront took (pivot16.hpp): the same rank-1 updates with the pivots already known — the pivot column's rows of the
 // diagonal 16 x 16 block (unscaled, replicated in every 16-lane row) and the reciprocal pivots come from LDS
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     __shared__ int relS[256];                                                  // relative indices of the child being extend-added (LDS fronts: r <= 196)
     __shared__ double rinvS[64];                                               // GF: reciprocal pivots (a node has at most 64 columns)
     const MfNode nd = d.nrec[first + blockIdx.x];
-    const int f = nd.f, c = nd.c, r = nd.r, m = c + r, nt = m * (m + 1) / 2;
+    const int f = nd.f, c = nd.c, r = nd.r, m = c + r, nt = tri0(m);
     const int tid = threadIdx.x;
     const size_t z = sl.use ? (size_t)sl.slot[blockIdx.y] : (size_t)blockIdx.y;   // storage slot of this instance of the batch
     double* F = GF ? d.fpool + z * d.sPool + nd.foff : Flds;                    // GF: the front lives in global memory (L2-resident)
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
         if (GF) {
             for (int a = tid >> 5; a < rc; a += MF_THREADS / 32) {             // a row of the child's update matrix per 32 lanes, coalesced along b
                 const int rla = rel[a];
-                const int ra = rla * (rla + 1) / 2;                            // rel is increasing: the lower triangle lands in the lower triangle
+                const int ra = tri0(rla);                            // rel is increasing: the lower triangle lands in the lower triangle
                 const double* Ua = U + (size_t)a * rc;
                 for (int b = tid & 31; b <= a; b += 32) F[ra + rel[b]] += Ua[b];
             }
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; un[q] = (an < rc && b <= an) ? U[(size_t)an * rc + b] : 0.0; }
                 const int rla = relS[a];
-                const int ra = rla * (rla + 1) / 2;                            // rel is increasing: the lower triangle lands in the lower triangle
+                const int ra = tri0(rla);                            // rel is increasing: the lower triangle lands in the lower triangle
 #pragma unroll
                 for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; if (b <= a) F[ra + relS[b]] += uv[q]; }
 #pragma unroll
@@ -309,14 +312,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
                 const int row = kb + lane;
                 const bool in = row < m;
                 const int rowc = min(row, m - 1);
-                const int trow = rowc * (rowc + 1) / 2 + kb;                   // (loads unconditional from a valid address, then selected: no exec-masked blocks)
+                const int trow = tri0(rowc) + kb;                   // (loads unconditional from a valid address, then selected: no exec-masked blocks)
                 double a[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) a[q] = F[trow + min(q, rowc - kb)];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) a[q] = (in && lane >= q && (q < 8 || !half)) ? a[q] : 0.0;
                 const int drow = min(kb + (lane & 15), m - 1);
-                const double y0 = F[drow * (drow + 1) / 2 + kb];
+                const double y0 = F[tri0(drow) + kb];
                 const int lo = __builtin_amdgcn_readlane(__double2loint(a[0]), 0), hi = __builtin_amdgcn_readlane(__double2hiint(a[0]), 0);
                 if (half) calipso::Pivot<0, false, 8>::run(a, (unsigned)(uintptr_t)(Yp + lane * MF_PY), (unsigned)(uintptr_t)(Yp + (lane & 15) * MF_PY), nullptr, 0,
                                                            calipso::fast_rcp(__hiloint2double(hi, lo)), y0);
@@ -339,9 +342,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
                 const int row = base + lane;
                 const bool in = row < m;
                 const int rowc = min(row, m - 1);
-                const int trow = rowc * (rowc + 1) / 2 + kb;
+                const int trow = tri0(rowc) + kb;
                 const int drow = min(kb + (lane & 15), m - 1);
-                const double* Fd = F + drow * (drow + 1) / 2 + kb;
+                const double* Fd = F + tri0(drow) + kb;
                 double a[16], yrep[16], nrinv[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { a[q] = F[trow + q]; yrep[q] = Fd[q]; nrinv[q] = rinv[min(kb + q, pe - 1)]; }
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
                 int i = j + 1 + (tid >> 4);                                      // rows i >= k of this thread's residue class
                 if (i < k) i += ((k - i + MF_RC - 1) / MF_RC) * MF_RC;
                 for (; i < m; i += MF_RC) {
-                    double* Fi = F + i * (i + 1) / 2;
+                    double* Fi = F + tri0(i);
                     Fi[k] -= Fi[j] * ykj;
                 }
             }
@@ -378,18 +381,18 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
         // the tiles of the lower triangle (bi >= bj), row-major, dealt round-robin to the wavefronts: every wavefront gets the same number of tiles to within
         // one (whole tile rows per wavefront left the one with the longest rows 1.7 x the average).  Two accumulator chains per tile (a dependent
         // v_mfma_f64_16x16x4 issues every 64 cycles).
-        const int ntile = ntl * (ntl + 1) / 2;
+        const int ntile = tri0(ntl);
         for (int t = wave; t < ntile; t += MF_THREADS / 64) {
             int bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
             while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-            while (bi * (bi + 1) / 2 > t) --bi;
-            const int bj = t - bi * (bi + 1) / 2;
+            while (tri0(bi) > t) --bi;
+            const int bj = t - tri0(bi);
             const int ia = pe + 16 * bi + fr;                                  // the row this lane feeds to the first operand
             const int jbr = pe + 16 * bj + fr;                                  // ... to the second operand
             // every LDS read below is unconditional, from a clamped (always valid) address, and all of them are issued before the first use: a load inside a
             // conditional becomes an exec-masked block with its own wait (measured: 2400 cycles per tile that way)
             const int iac = min(ia, m - 1), jbc = min(jbr, m - 1);
-            const int ra = iac * (iac + 1) / 2, rb = jbc * (jbc + 1) / 2;
+            const int ra = tri0(iac), rb = tri0(jbc);
             double af[4], bf[4], rf[4], old[4];
             int oidx[4];
 #pragma unroll
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
             for (int rr = 0; rr < 4; ++rr) {
                 const int i = pe + 16 * bi + fk + 4 * rr;                       // result row (first operand's tile)
                 const int ic = min(i, m - 1), jc = min(j, ic);
-                oidx[rr] = ic * (ic + 1) / 2 + jc;
+                oidx[rr] = tri0(ic) + jc;
                 old[rr] = F[oidx[rr]];
             }
             double av[4], bv[4];
@@ -437,11 +440,11 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     // write-out: a wavefront per column of the panel (lanes along the rows: contiguous stores) / per row of the update matrix (lanes along the columns)
     for (int k = wave; k < c; k += MF_THREADS / 64) {
         const double rk = rinv[k];
-        for (int i = lane; i < m; i += 64) P[i + (size_t)k * m] = i > k ? F[i * (i + 1) / 2 + k] * rk : 0.0;
+        for (int i = lane; i < m; i += 64) P[i + (size_t)k * m] = i > k ? F[tri0(i) + k] * rk : 0.0;
     }
     double* U = upd + nd.upd_off;
     for (int a = wave; a < r; a += MF_THREADS / 64) {
-        const double* Fa = F + (c + a) * (c + a + 1) / 2 + c;
+        const double* Fa = F + tri0(c + a) + c;
         for (int b = lane; b <= a; b += 64) U[(size_t)a * r + b] = Fa[b];
     }
     MF_STAMP(5);
