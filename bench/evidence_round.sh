@@ -15,6 +15,7 @@ timeout 600 python bench.py --config C4T --batch 48 --group 16 --lanes 3 --no-cp
 f=$(find $O/stats_c4t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_c4t_group.csv; rm -rf $O/stats_c4t
 timeout 300 python bench/ldl_trace.py > $O/ldl_chain_timeline.txt 2>&1
 timeout 300 python bench/mf_trace.py > $O/mf_trace.txt 2>&1
+timeout 300 python bench/ldl_bulk_trace.py 12 > $O/ldl_bulk_trace.txt 2>&1
 bash bench/step_gaps.sh > /dev/null 2>&1; cp gpurun_out/step_gaps.txt $O/step_gaps_under_rocprof.txt
 hipcc -O3 --offload-arch=gfx950 bench/diag_bench3.hip -o /tmp/d3 2>/dev/null && timeout 60 /tmp/d3 > $O/diag_bench3.txt
 ls -la $O | head -60

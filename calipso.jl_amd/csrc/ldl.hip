@@ -65,8 +65,14 @@ constexpr int CPS = NB;            // column stride of the column block handed t
 #ifdef CALIPSO_LDL_TRACE
 __device__ long long g_ldl_trace[64 * 16];
 #define LDL_STAMP(step, slot) do { if (threadIdx.x == 0 && (step) < 64) g_ldl_trace[(step) * 16 + (slot)] = wall_clock64(); } while (0)
+// one worker workgroup of the FIRST two-panel pass (k0 == 0): core-clock stamps of its first 32 tiles, 8 slots each
+__device__ long long g_ldl_bulk[32 * 8 + 32 * 16 * 2];    // + per wavefront: start / end of the MFMA phase
+#define BULK_WAVE_STAMP(slot) do { if (MODE == 2 && bulk_traced && bulk_tile < 32 && (threadIdx.x & 63) == 0) g_ldl_bulk[32 * 8 + (bulk_tile * 16 + (threadIdx.x >> 6)) * 2 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define BULK_STAMP(slot) do { if (MODE == 2 && bulk_traced && bulk_tile < 32 && threadIdx.x == 0) g_ldl_bulk[bulk_tile * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define LDL_STAMP(step, slot) do { } while (0)
+#define BULK_STAMP(slot) do { } while (0)
+#define BULK_WAVE_STAMP(slot) do { } while (0)
 #endif
 
 
@@ -463,6 +469,10 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
     // half the address registers
     const int offC = (wr * 16 + fr) + (wc * 16 + fk) * NP, offY = row + cb * NP;
     double cS[4], yv[NH][4];              // operands of the current tile: the entries of S this lane updates, its share of the raw column panels
+#ifdef CALIPSO_LDL_TRACE
+    const bool bulk_traced = k0 == 0 && (int)blockIdx.x == (int)bt.n + 16;
+    int bulk_tile = 0;
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) cS[r] = (S + (i0 + (size_t)j0 * NP))[offC + 4 * r * NP];
 #pragma unroll
@@ -490,12 +500,14 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
             nextrow = in0 != i0 || doff != 0;
         }
         const double* Sn = S + doff;
+        BULK_STAMP(0);
         if (newrow) {
 #pragma unroll
             for (int h = 0; h < NH; ++h)
                 form_Z(S + i0 + (size_t)(k0 + h * NB) * NP, NP, Mk + (size_t)h * NB * NB, Ys, Ms, Zs + h * TT * LDT, row, cb, wr, wc, fr, fk);
             if (t == 0) LDL_STAMP(r0 / NB, 1);
         }
+        BULK_STAMP(1);
         if constexpr (NH == 2) {
             // both column panels are staged at once (the second one in the buffer form_Z uses for M: free between two changes of tile row): two
             // barriers per tile instead of four, and the two products run back to back on the matrix cores.  Same arithmetic, same order.
@@ -504,7 +516,10 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
 #pragma unroll
                 for (int it = 0; it < 4; ++it) (h ? Ms : Ys)[row * LDT + cb + it * 16] = yv[h][it];
             }
+            BULK_STAMP(2);
             lds_barrier();
+            BULK_STAMP(3);
+            BULK_WAVE_STAMP(0);
             if (more) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cN[r] = (Sn + (in0 + (size_t)jn0 * NP))[offC + 4 * r * NP];
@@ -520,6 +535,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cS[r] -= acc[r];
             }
+            BULK_STAMP(4);
+            BULK_WAVE_STAMP(1);
         } else {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
@@ -556,7 +573,12 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
         item += 1; off += doff; S += doff; Minv += doff; Mk += doff;
 #pragma unroll
         for (int r = 0; r < 4; ++r) cS[r] = cN[r];
+        BULK_STAMP(5);
         lds_barrier();                            // the operand reads of this tile are done before LDS is refilled
+        BULK_STAMP(6);
+#ifdef CALIPSO_LDL_TRACE
+        ++bulk_tile;
+#endif
     }
 }
 
@@ -931,6 +953,7 @@ static bool replay_or_capture(calipso_hip_solver* s, hipGraphExec_t& exec, bool&
 
 #ifdef CALIPSO_LDL_TRACE
 }  // namespace calipso
+extern "C" int32_t calipso_hip_debug_ldl_bulk_trace(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(calipso::g_ldl_bulk), sizeof(long long) * (32 * 8 + 32 * 16 * 2)) == hipSuccess ? 0 : -1; }
 extern "C" int32_t calipso_hip_debug_ldl_trace(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(calipso::g_ldl_trace), sizeof(long long) * 64 * 16) == hipSuccess ? 0 : -1; }
 namespace calipso {
 #endif
