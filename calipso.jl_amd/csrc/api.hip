@@ -589,7 +589,7 @@ static void refine_solve(H* s) {
 // iterative_refinement.jl:1-52.  zsx_valid: zsx already holds [gx; hx] step_x (it does right after do_sds(s, 0))
 static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid = false) {
     const Options& o = s->opt; const Dims& d = s->d;
-    fill_d(s, s->step_correction, s->d.N, 0.0);
+    // (fill!(step_correction, 0) of iterative_refinement.jl:5 is only launched when no round follows: the first round's k_recover writes every entry)
     if (!zsx_valid && d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->step, s->zsx, 1.0, 0.0, SP_Z);
     refine_residual(s, true);                  // (k_refine_x itself publishes the norm: no separate read-back launch)
     if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
@@ -598,6 +598,7 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
     int it = 0;
     while (it <= o.max_iterative_refinement) {
         if (norm <= o.iterative_refinement_tolerance && it >= o.min_iterative_refinement) {
+            if (it == 0) fill_d(s, s->step_correction, s->d.N, 0.0);
             if (rounds) *rounds = it;
             if (final_norm) *final_norm = norm;
             s->stats.last_refine = it; s->stats.refine_max = std::max<calipso::i64>(s->stats.refine_max, it);
@@ -609,6 +610,7 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
         norm = s->hscal[7];
         it += 1;
     }
+    if (it == 0) fill_d(s, s->step_correction, s->d.N, 0.0);      // (max_iterative_refinement < 0)
     if (rounds) *rounds = it;
     if (final_norm) *final_norm = norm;
     s->stats.last_refine = it; s->stats.refine_max = std::max<calipso::i64>(s->stats.refine_max, it);
@@ -634,7 +636,7 @@ static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
     return CALIPSO_OK;
 }
 
-static int do_cone_search(H* s, double* a_s, double* a_t) {
+static int do_cone_search(H* s, double* a_s, double* a_t, bool emit_candidate = true) {
     const Options& o = s->opt;
     if (s->d.nc == 0) { *a_s = 1.0; *a_t = 1.0; return CALIPSO_OK; }
     launch_cone_search(s);
@@ -646,7 +648,7 @@ static int do_cone_search(H* s, double* a_s, double* a_t) {
     for (int k = 0; k < ks; ++k) as = o.scaling_line_search * as;
     for (int k = 0; k < kt; ++k) at = o.scaling_line_search * at;
     *a_s = as; *a_t = at;
-    launch_cone_candidate(s, as, at);
+    if (emit_candidate) launch_cone_candidate(s, as, at);
     return CALIPSO_OK;
 }
 
@@ -715,11 +717,9 @@ static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equali
     rc = evaluate(s, eval, user, 0, CALIPSO_EVAL_OBJECTIVE_GRADIENT | CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT | CALIPSO_EVAL_CONE_DUAL_GRADIENT);   // :100-104
     if (rc < 0) return rc;
     launch_cone(s, s->solution, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);   // :106-109
-    launch_merit(s, s->solution);                                                       // :112-116
-    launch_merit_gradient(s);                                                           // :118-124
+    launch_merit_and_gradient(s);                                                       // :112-116, :118-124 (one launch)
     launch_residual(s);                                                                 // :127
-    launch_violations(s);                                                               // :130-135
-    launch_constraint_violation(s, s->solution, 4, 14);                                 // :170-172 (computed early: one read-back, published by the kernel itself)
+    launch_violations_and_constraint(s, 4, 14);                                         // :130-135 and :170-172 (computed early: one read-back, published by the kernel itself)
     if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
     const double* hs = s->hscal;
     info.M = hs[4]; info.theta = hs[5];
@@ -747,12 +747,12 @@ static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equali
     int warn = do_search_direction(s, &info.nfact, &info.rounds);                       // :187
     if (warn < 0) return warn;
     EV(3);
-    rc = do_cone_search(s, &info.step_size, &info.step_size_t);                         // :190-221
+    rc = do_cone_search(s, &info.step_size, &info.step_size_t, false);                  // :190-221
     if (rc < 0) return rc;
     double step_size = info.step_size;
-    launch_axpy_points(s, step_size, 0);                                                // :224-229
-    launch_merit_gradient(s);   // (unchanged; kept resident)
-    launch_dot_merit(s);
+    // candidate s, t (:206-218), candidate x, r (:224-229) and the directional derivative of the merit function (its gradient is that of :118-124: the
+    // point has not moved) in one launch
+    launch_first_candidate(s, info.step_size, info.step_size_t);
     double Mh, thetah;
     rc = candidate_merit(s, eval, user, &Mh, &thetah, true);                            // :231-250
     if (rc < 0) return rc;

@@ -129,14 +129,20 @@ __global__ __launch_bounds__(CONE_THREADS) void k_cone_search(BatchSc bt, Dims d
     inst_shift(bt.b, sol, step);
     inst_shift_i(bt.b, icount);
     const double tau = bt.sc[blockIdx.z].tau;
-    // block 0: slack s with Delta s ; block 1: slack dual t with Delta t   (separate step sizes, solve.jl:190-221)
+    // block 0: slack s with Delta s ; block 1: slack dual t with Delta t   (separate step sizes, solve.jl:190-221).  Each block owns its words of
+    // icount (6 .. 31 / 32 .. 63): the masks are gathered in LDS and stored whole, so nothing has to clear them beforehand
+    __shared__ int lm[32];
+    if (threadIdx.x < 32) lm[threadIdx.x] = 0;
+    __syncthreads();
     const int off = blockIdx.x == 0 ? d.os() : d.ot();
-    violation_masks(d, cd, sol + off, step + off, tau, sls, nk, icount + (blockIdx.x == 0 ? 6 : 32));
+    violation_masks(d, cd, sol + off, step + off, tau, sls, nk, lm);
+    __syncthreads();
+    const int first = blockIdx.x == 0 ? 6 : 32, words = blockIdx.x == 0 ? 26 : 32;
+    if ((int)threadIdx.x < words) icount[first + threadIdx.x] = lm[threadIdx.x];
 }
 
 void launch_cone_search(calipso_hip_solver* s) {
-    fill_i(s, s->icount + 6, 58, 0);
-    if (s->d.nc == 0) return;
+    if (s->d.nc == 0) { fill_i(s, s->icount + 6, 58, 0); return; }
     const int nk = (int)s->opt.max_cone_line_search + 1;
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_cone_search, dim3(2, 1, B.b.n), dim3(CONE_THREADS), 0, s->stream, B, s->d, s->cone, s->solution, s->step,

@@ -226,13 +226,13 @@ static int gb_refinement(G* g, const Set& a, std::vector<int>& rc, std::vector<i
     std::vector<double> norm(B, 0.0), norm0(B, 0.0);
     std::vector<int> it(B, 0);
     g_activate(g, a);
-    fill_d(s, s->step_correction, s->d.N, 0.0);
     gb_refine_residual(g);
     if (g_read_d(g, a, 7, 1)) return CALIPSO_ERR_HIP;
     for (int i : a) { norm[i] = g->hs[i]->hscal[7]; norm0[i] = norm[i]; }
     Set run = a;
+    bool first_pass = true;
     while (!run.empty()) {
-        Set sub;
+        Set sub, none;
         for (int i : run) {
             H* h = g->hs[i]; const Options& o = h->opt;
             bool finished = false;
@@ -247,8 +247,12 @@ static int gb_refinement(G* g, const Set& a, std::vector<int>& rc, std::vector<i
             if (finished) {
                 rounds[i] = it[i];
                 h->stats.last_refine = it[i]; h->stats.refine_max = std::max<calipso::i64>(h->stats.refine_max, it[i]);
+                if (it[i] == 0) none.push_back(i);
             } else sub.push_back(i);
         }
+        // fill!(step_correction, 0) (iterative_refinement.jl:5) only for the members that take no round: the first round's k_recover writes every entry
+        if (first_pass && !none.empty()) { g_activate(g, none); fill_d(s, s->step_correction, s->d.N, 0.0); }
+        first_pass = false;
         if (sub.empty()) break;
         g_activate(g, sub);
         gb_refine_solve(g);
@@ -287,11 +291,9 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
         if (e0 < 0) return e0;
     }
     launch_cone(s, s->solution, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);
-    launch_merit(s, s->solution);
-    launch_merit_gradient(s);
+    launch_merit_and_gradient(s);
     launch_residual(s);
-    launch_violations(s);
-    launch_constraint_violation(s, s->solution);
+    launch_violations_and_constraint(s);
     if (g_read_d(g, a0, 4, 14)) return CALIPSO_ERR_HIP;
     Set a;
     for (int i : a0) {
@@ -354,18 +356,13 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
         a = alive(a, rc);
         if (a.empty()) { EV(4); return CALIPSO_OK; }
         g_activate(g, a);
-        std::vector<double> la, lt;
-        for (int i : a) { la.push_back(as[i]); lt.push_back(at[i]); }
-        launch_cone_candidate_batch(s, la.data(), lt.data());
     }
     for (int i : a) { info[i].step_size = as[i]; info[i].step_size_t = at[i]; step_size[i] = as[i]; }
-    {
-        std::vector<double> la;
-        for (int i : a) la.push_back(step_size[i]);
-        launch_axpy_points_batch(s, la.data(), 0);                                         // :224-229
+    {   // candidate s, t (:206-218), candidate x, r (:224-229) and the directional derivative of the merit function in one launch (api.hip: inner_iteration)
+        std::vector<double> la, lt;
+        for (int i : a) { la.push_back(as[i]); lt.push_back(at[i]); }
+        launch_first_candidate_batch(s, la.data(), lt.data());
     }
-    launch_merit_gradient(s);
-    launch_dot_merit(s);
     std::vector<double> Mh(B, 0.0), thetah(B, 0.0), dd(B, 0.0);
     e = gb_candidate_merit(g, a, Mh, thetah);                                            // :231-250
     if (e < 0) return e;

@@ -188,6 +188,7 @@ struct calipso_hip_solver {
     double *solution = nullptr, *candidate = nullptr, *lambda = nullptr, *parameters = nullptr;
     double *residual = nullptr, *residual_error = nullptr, *step = nullptr, *step_correction = nullptr, *saved_point = nullptr;
     double *residual_symmetric = nullptr, *step_symmetric = nullptr, *merit_gradient = nullptr;
+    bool pad_done = false;               // launch_scale_rows wrote the unit pivots of the padded rows of S for the launch_schur that follows
     double* Kdense = nullptr;  // n*n, allocated on first request
     // factorisation
     double* S = nullptr;        // NP*NP: Schur complement onto x, then L (unit lower) in place
@@ -276,7 +277,11 @@ void launch_axpy_points_batch(calipso_hip_solver* s, const double* step_size, in
 void launch_accept_batch(calipso_hip_solver* s, const double* step_size);
 void launch_merit(calipso_hip_solver* s, const double* point);  // -> dscal[4] (M), uses dscal[0], dscal[1]
 void launch_merit_gradient(calipso_hip_solver* s);
+void launch_merit_and_gradient(calipso_hip_solver* s);      // merit at the current point + its gradient, one launch
+void launch_first_candidate(calipso_hip_solver* s, double a_s, double a_t);                        // first candidate of the line search + directional derivative, one launch
+void launch_first_candidate_batch(calipso_hip_solver* s, const double* a_s, const double* a_t);
 void launch_constraint_violation(calipso_hip_solver* s, const double* point, int pub_first = 0, int pub_count = 0);   // -> dscal[5]
+void launch_violations_and_constraint(calipso_hip_solver* s, int pub_first = 0, int pub_count = 0);   // both at the current point, one launch
 void launch_dot_merit(calipso_hip_solver* s);                   // -> dscal[6]
 void launch_Hmul(calipso_hip_solver* s, const double* v, double* out);   // out = H v
 void launch_residual_error(calipso_hip_solver* s, const double* step);   // residual_error = residual - H step ; dscal[7] = inf-norm

@@ -140,9 +140,18 @@ void launch_cone_weights(calipso_hip_solver* s) {
 // WH = Omega_z * hx  (nc x nx): nonnegative rows scaled by -1/K_zz, second-order rows multiplied by the d x d block W
 constexpr int SCALE_COLS = 16;
 __global__ void k_scale_rows(Batch bt, Dims d, ConeDev cd, const double* __restrict__ hx, const double* __restrict__ wz,
-                             const double* __restrict__ Wsoc, double* __restrict__ WH, const int* __restrict__ zrow) {
+                             const double* __restrict__ Wsoc, double* __restrict__ WH, const int* __restrict__ zrow, double* __restrict__ Spad) {
     inst_shift(bt, hx, wz, Wsoc, WH);
     if (zrow) inst_shift_i(bt, zrow);
+    if (Spad) {
+        // k_pad_identity rides along (the launch in front of k_schur): the threads of the instance share the (NP - nx) x NP padded rows of S
+        inst_shift(bt, Spad);
+        const long long total = (long long)gridDim.x * gridDim.y * blockDim.x, count = (long long)(d.NP - d.nx) * d.NP;
+        for (long long e = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; e < count; e += total) {
+            const int i = d.nx + (int)(e / d.NP), j = (int)(e % d.NP);
+            if (j <= i) Spad[i + (size_t)j * d.NP] = (i == j) ? 1.0 : 0.0;
+        }
+    }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.nc) return;
     int st = 0, dim = 0;
@@ -168,10 +177,15 @@ __global__ void k_scale_rows(Batch bt, Dims d, ConeDev cd, const double* __restr
 }
 
 void launch_scale_rows(calipso_hip_solver* s) {
+    s->pad_done = false;
     if (s->d.nc == 0) return;
     if (s->blocks.on && s->blocks_effective) return;      // stage blocks: Omega is applied while k_schur_blocks stages its operand, WH is not formed
     const BatchSc B = batch_of(s);
-    hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, (s->d.nx + SCALE_COLS - 1) / SCALE_COLS, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH, s->band64 > 0 ? s->zrow : nullptr);
+    // the unit pivots of the padded rows of S are written by this launch when the dense k_schur follows (launch_schur then skips launch_pad_identity)
+    const bool pad = s->d.NP > s->d.nx && !(s->stage_parallel && s->spS);
+    s->pad_done = pad;
+    hipLaunchKernelGGL(k_scale_rows, dim3((s->d.nc + 255) / 256, (s->d.nx + SCALE_COLS - 1) / SCALE_COLS, B.b.n), dim3(256), 0, s->stream, B.b, s->d, s->cone, s->hx, s->wz, s->Wsoc, s->WH, s->band64 > 0 ? s->zrow : nullptr,
+                       pad ? s->S : (double*)nullptr);
 }
 
 // ---- Schur complement on the fp64 matrix cores -----------------------------------------------------------------------------
@@ -517,7 +531,8 @@ void launch_schur(calipso_hip_solver* s) {
     static const int flat_env = [] { const char* e = getenv("CALIPSO_HIP_SCHUR_FLAT"); return e ? atoi(e) : -1; }();
     const int flat = flat_env >= 0 ? flat_env : 1;
     const int grid = flat ? (int)(((long long)B.b.n * ntiles + 7) / 8 + 1) * 8 : ((ntiles + 7) / 8) * 8;
-    if (!(s->stage_parallel && s->spS)) launch_pad_identity(s);   // (the multifrontal path reads S only inside its nx x nx pattern)
+    if (!(s->stage_parallel && s->spS) && !s->pad_done) launch_pad_identity(s);   // (the multifrontal path reads S only inside its nx x nx pattern; k_scale_rows may have written the padding already)
+    s->pad_done = false;
     hipLaunchKernelGGL(k_schur, dim3(grid, 1, flat ? 1 : B.b.n), dim3(SCHUR_THREADS), SCHUR_LDS_BYTES, s->stream, B, s->d, s->Lsym, s->gx, s->hx, s->WH, s->S, s->krange, hb, ntiles, nj, flat);
 }
 

@@ -66,11 +66,8 @@ __device__ __forceinline__ void publish_tail(const double* dscal, int first, int
 }
 
 // the reductions of solve.jl:130-135,332-333 and optimality_error.jl:1-27 -> dscal[8..17]
-__global__ __launch_bounds__(RT) void k_violations(Batch bt, Dims d, int ptype, const double* __restrict__ res, const double* __restrict__ w,
-                                                    const double* __restrict__ g, const double* __restrict__ prod,
-                                                    double* __restrict__ dscal, int pub_first, int pub_count, double* __restrict__ hpub,
-                                                    unsigned long long* __restrict__ hseq, unsigned long long seq) {
-    inst_shift(bt, res, w, g, prod, dscal);
+__device__ __forceinline__ void violations_body(const Dims& d, int ptype, const double* __restrict__ res, const double* __restrict__ w,
+                                                const double* __restrict__ g, const double* __restrict__ prod, double* __restrict__ dscal) {
     const int tid = threadIdx.x;
     double rp = 0.0, rprim = 0.0, ry = 0.0, rz = 0.0, rt = 0.0, y1 = 0.0, z1 = 0.0, t1 = 0.0, ginf = 0.0, pinf = 0.0;
     for (int i = tid; i < d.N; i += RT) {
@@ -102,6 +99,13 @@ __global__ __launch_bounds__(RT) void k_violations(Batch bt, Dims d, int ptype, 
         for (int i = 0; i < RT / 64; ++i) r = is_max ? fmax(r, red[tid][i]) : r + red[tid][i];
         dscal[8 + tid] = (tid == 0 && ptype == 2) ? sqrt(r) : r;
     }
+}
+__global__ __launch_bounds__(RT) void k_violations(Batch bt, Dims d, int ptype, const double* __restrict__ res, const double* __restrict__ w,
+                                                    const double* __restrict__ g, const double* __restrict__ prod,
+                                                    double* __restrict__ dscal, int pub_first, int pub_count, double* __restrict__ hpub,
+                                                    unsigned long long* __restrict__ hseq, unsigned long long seq) {
+    inst_shift(bt, res, w, g, prod, dscal);
+    violations_body(d, ptype, res, w, g, prod, dscal);
     publish_tail(dscal, pub_first, pub_count, hpub, hseq, seq);
 }
 
@@ -387,12 +391,9 @@ void launch_accept_batch(calipso_hip_solver* s, const double* step_size) {
 }
 void launch_accept(calipso_hip_solver* s, double step_size) { launch_accept_batch(s, &step_size); }
 
-// merit(f, r, Phi, kappa, lambda, rho)   merit.jl:2-15  -> dscal[4]
-__global__ __launch_bounds__(RT) void k_merit(BatchSc bt, Dims d, const double* __restrict__ point, const double* __restrict__ lam,
-                                               double* __restrict__ dscal) {
-    __shared__ double sm[RT / 64];
-    inst_shift(bt.b, point, lam, dscal);
-    const Scalars sc = bt.sc[blockIdx.z];
+// merit(f, r, Phi, kappa, lambda, rho)   merit.jl:2-15  -> dscal[4]   (one workgroup of RT threads per instance; `sm` = RT / 64 doubles of LDS)
+__device__ __forceinline__ void merit_body(const Scalars sc, const Dims& d, const double* __restrict__ point, const double* __restrict__ lam,
+                                           double* __restrict__ dscal, double* sm) {
     const double* r = point + d.orr();
     double lr = 0.0, rr = 0.0;
     for (int i = threadIdx.x; i < d.ne; i += RT) { lr += lam[i] * r[i]; rr += r[i] * r[i]; }
@@ -406,35 +407,55 @@ __global__ __launch_bounds__(RT) void k_merit(BatchSc bt, Dims d, const double* 
         dscal[4] = M;
     }
 }
+__global__ __launch_bounds__(RT) void k_merit(BatchSc bt, Dims d, const double* __restrict__ point, const double* __restrict__ lam,
+                                               double* __restrict__ dscal) {
+    __shared__ double sm[RT / 64];
+    inst_shift(bt.b, point, lam, dscal);
+    merit_body(bt.sc[blockIdx.z], d, point, lam, dscal, sm);
+}
 void launch_merit(calipso_hip_solver* s, const double* point) {
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_merit, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, point, s->lambda, s->dscal);
 }
 
-// merit_gradient!   merit.jl:17-31
-__global__ void k_merit_gradient(BatchSc bt, Dims d, const double* __restrict__ w, const double* __restrict__ lam,
-                                 const double* __restrict__ fx, const double* __restrict__ bgrad, double* __restrict__ grad) {
-    inst_shift(bt.b, w, lam, fx, bgrad, grad);
-    const Scalars sc = bt.sc[blockIdx.z];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// merit_gradient!   merit.jl:17-31   (entry i of the instance the pointers were shifted to)
+__device__ __forceinline__ void merit_gradient_entry(const Scalars sc, const Dims& d, int i, const double* __restrict__ w, const double* __restrict__ lam,
+                                                     const double* __restrict__ fx, const double* __restrict__ bgrad, double* __restrict__ grad) {
     if (i >= d.n) return;
     if (i < d.nx) grad[i] = fx[i];
     else if (i < d.nx + d.ne) grad[i] = lam[i - d.nx] + sc.rho * w[d.orr() + i - d.nx];
     else grad[i] = -1.0 * sc.kappa * bgrad[i - d.nx - d.ne];
+}
+__global__ void k_merit_gradient(BatchSc bt, Dims d, const double* __restrict__ w, const double* __restrict__ lam,
+                                 const double* __restrict__ fx, const double* __restrict__ bgrad, double* __restrict__ grad) {
+    inst_shift(bt.b, w, lam, fx, bgrad, grad);
+    merit_gradient_entry(bt.sc[blockIdx.z], d, blockIdx.x * blockDim.x + threadIdx.x, w, lam, fx, bgrad, grad);
 }
 void launch_merit_gradient(calipso_hip_solver* s) {
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_merit_gradient, dim3((s->d.n + 255) / 256, 1, B.b.n), dim3(256), 0, s->stream, B, s->d, s->solution, s->lambda, s->fx,
                        s->barrier_gradient, s->merit_gradient);
 }
+// merit at the current point AND its gradient in one launch (solve.jl:112-124: the two are always wanted together there): workgroup 0 of an instance is
+// k_merit, the others are k_merit_gradient with RT-thread workgroups; operation for operation the two kernels above
+__global__ __launch_bounds__(RT) void k_merit_and_gradient(BatchSc bt, Dims d, const double* __restrict__ w, const double* __restrict__ lam, const double* __restrict__ fx,
+                                                            const double* __restrict__ bgrad, double* __restrict__ grad, double* __restrict__ dscal) {
+    __shared__ double sm[RT / 64];
+    inst_shift(bt.b, w, lam, fx, bgrad, grad, dscal);
+    const Scalars sc = bt.sc[blockIdx.z];
+    if (blockIdx.x == 0) merit_body(sc, d, w, lam, dscal, sm);
+    else merit_gradient_entry(sc, d, (blockIdx.x - 1) * RT + threadIdx.x, w, lam, fx, bgrad, grad);
+}
+void launch_merit_and_gradient(calipso_hip_solver* s) {
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_merit_and_gradient, dim3(1 + (s->d.n + RT - 1) / RT, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->solution, s->lambda, s->fx,
+                       s->barrier_gradient, s->merit_gradient, s->dscal);
+}
 
 // constraint_violation!   constraint_violation.jl:1-13 -> dscal[5]
-__global__ __launch_bounds__(RT) void k_constraint_violation(Batch bt, Dims d, int ptype, const double* __restrict__ point,
-                                                              const double* __restrict__ g, const double* __restrict__ hc,
-                                                              double* __restrict__ dscal, int pub_first, int pub_count, double* __restrict__ hpub,
-                                                              unsigned long long* __restrict__ hseq, unsigned long long seq) {
+__device__ __forceinline__ void constraint_violation_body(const Dims& d, int ptype, const double* __restrict__ point, const double* __restrict__ g,
+                                                          const double* __restrict__ hc, double* __restrict__ dscal) {
     __shared__ double sm[RT / 64];
-    inst_shift(bt, point, g, hc, dscal);
     double acc = 0.0;
     for (int i = threadIdx.x; i < d.ne + d.nc; i += RT) {
         const double c = (i < d.ne) ? g[i] - point[d.orr() + i] : hc[i - d.ne] - point[d.os() + i - d.ne];
@@ -445,6 +466,23 @@ __global__ __launch_bounds__(RT) void k_constraint_violation(Batch bt, Dims d, i
         if (ptype == 2) r = sqrt(r);
         dscal[5] = r / (double)(d.ne + d.nc);
     }
+}
+__global__ __launch_bounds__(RT) void k_constraint_violation(Batch bt, Dims d, int ptype, const double* __restrict__ point,
+                                                              const double* __restrict__ g, const double* __restrict__ hc,
+                                                              double* __restrict__ dscal, int pub_first, int pub_count, double* __restrict__ hpub,
+                                                              unsigned long long* __restrict__ hseq, unsigned long long seq) {
+    inst_shift(bt, point, g, hc, dscal);
+    constraint_violation_body(d, ptype, point, g, hc, dscal);
+    publish_tail(dscal, pub_first, pub_count, hpub, hseq, seq);
+}
+// k_violations and k_constraint_violation at the current point back to back in one workgroup (the head of the inner loop wants both: solve.jl:130-135, 170-172)
+__global__ __launch_bounds__(RT) void k_violations_and_constraint(Batch bt, Dims d, int ptype, int ctype, const double* __restrict__ res, const double* __restrict__ w,
+                                                                   const double* __restrict__ g, const double* __restrict__ prod, const double* __restrict__ hc,
+                                                                   double* __restrict__ dscal, int pub_first, int pub_count, double* __restrict__ hpub,
+                                                                   unsigned long long* __restrict__ hseq, unsigned long long seq) {
+    inst_shift(bt, res, w, g, prod, hc, dscal);
+    violations_body(d, ptype, res, w, g, prod, dscal);
+    constraint_violation_body(d, ctype, w, g, hc, dscal);
     publish_tail(dscal, pub_first, pub_count, hpub, hseq, seq);
 }
 void launch_constraint_violation(calipso_hip_solver* s, const double* point, int pub_first, int pub_count) {
@@ -455,19 +493,52 @@ void launch_constraint_violation(calipso_hip_solver* s, const double* point, int
                        pub ? ++s->pub_seq : 0ULL);
 }
 
-// d = dot(merit_gradient, step.primals)   line_search.jl:3,16 -> dscal[6]
-__global__ __launch_bounds__(RT) void k_dot(Batch bt, int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
-    __shared__ double sm[RT / 64];
-    inst_shift(bt, a, b, out);
+void launch_violations_and_constraint(calipso_hip_solver* s, int pub_first, int pub_count) {
+    const BatchSc B = batch_of(s);
+    const bool pub = pub_count > 0 && !s->cur;
+    hipLaunchKernelGGL(k_violations_and_constraint, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B.b, s->d, norm_type(s->opt.residual_norm), norm_type(s->opt.constraint_norm),
+                       s->residual, s->solution, s->g, s->cone_product, s->hc, s->dscal, pub_first, pub_count, pub ? s->hscal_dev : (double*)nullptr,
+                       pub ? s->hseq_dev : (unsigned long long*)nullptr, pub ? ++s->pub_seq : 0ULL);
+}
+
+// d = dot(merit_gradient, step.primals)   line_search.jl:3,16 -> dscal[6]   (one workgroup of RT threads per instance)
+__device__ __forceinline__ void dot_body(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, double* sm) {
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += RT) acc += a[i] * b[i];
     const double r = block_sum(acc, sm);
     if (threadIdx.x == 0) *out = r;
 }
+__global__ __launch_bounds__(RT) void k_dot(Batch bt, int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+    __shared__ double sm[RT / 64];
+    inst_shift(bt, a, b, out);
+    dot_body(n, a, b, out, sm);
+}
 void launch_dot_merit(calipso_hip_solver* s) {
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_dot, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B.b, s->d.n, s->merit_gradient, s->step, s->dscal + 6);
 }
+// The first candidate of the line search in ONE launch (solve.jl:206-208, 216-218, 224-229 and line_search.jl:3): x, r, s <- solution - a_s step (the residual
+// search starts at the cone step size), t <- solution - a_t step, and the directional derivative dot(merit_gradient, step) -> dscal[6] by the last
+// workgroup of the instance.  Entry for entry the expressions of k_cone_candidate / k_axpy_points / k_dot.
+__global__ __launch_bounds__(RT) void k_first_candidate(Batch bt, Dims d, const double* __restrict__ sol, const double* __restrict__ step, double* __restrict__ cand,
+                                                         PerInst as, PerInst at, const double* __restrict__ mgrad, double* __restrict__ dscal, int nb) {
+    __shared__ double sm[RT / 64];
+    inst_shift(bt, sol, step, cand, mgrad, dscal);
+    if ((int)blockIdx.x == nb) { dot_body(d.n, mgrad, step, dscal + 6, sm); return; }
+    const double a_s = as.v[blockIdx.z], a_t = at.v[blockIdx.z];
+    const int i = blockIdx.x * RT + threadIdx.x;
+    if (i < d.n) cand[i] = sol[i] - a_s * step[i];
+    else if (i < d.n + d.nc) { const int k = d.ot() + (i - d.n); cand[k] = sol[k] - a_t * step[k]; }
+}
+void launch_first_candidate_batch(calipso_hip_solver* s, const double* a_s, const double* a_t) {   // one (a_s, a_t) per covered instance
+    const BatchSc B = batch_of(s);
+    PerInst as, at;
+    for (int k = 0; k < B.b.n; ++k) { as.v[k] = a_s[k]; at.v[k] = a_t[k]; }
+    const int nb = (s->d.n + s->d.nc + RT - 1) / RT;
+    hipLaunchKernelGGL(k_first_candidate, dim3(nb + 1, 1, B.b.n), dim3(RT), 0, s->stream, B.b, s->d, s->solution, s->step, s->candidate, as, at, s->merit_gradient,
+                       s->dscal, nb);
+}
+void launch_first_candidate(calipso_hip_solver* s, double a_s, double a_t) { launch_first_candidate_batch(s, &a_s, &a_t); }
 
 // vector part of out = H v (block rows of residual_jacobian_variables.jl:1-108); the mat-vec parts were accumulated
 // into out_x, out_y, out_z beforehand.
