@@ -41,7 +41,7 @@ rows = []
 for k in range(1, nb):
     r = [us(t[k, 0], t[k - 1, 5]), us(t[k, 1], t[k, 0]), us(t[k, 2], t[k, 1]), us(t[k, 3], t[k, 2]), us(t[k, 4], t[k, 3]), us(t[k, 6], t[k, 4]), us(t[k, 5], t[k, 6])]
     rows.append(r + [us(t[k, 5], t[k, 0])])
-    if k <= 6 or k >= nb - 3:
+    if k <= 6 or k >= nb - 3 or os.environ.get("LDL_TRACE_ALL"):
         print("%4d " % k + " ".join("%7.2f" % v for v in rows[-1]))
 m = np.mean(np.array(rows), axis=0)
 print("mean " + " ".join("%7.2f" % v for v in m))

@@ -297,6 +297,9 @@ int32_t calipso_hip_destroy(H* s) {
     if (s->hseq) (void)hipHostFree(s->hseq);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     calipso::ldl_drop_graphs(s);
+    for (auto& e : s->ev_side) if (e) (void)hipEventDestroy(e);
+    if (s->hprog) (void)hipHostFree(s->hprog);
+    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return CALIPSO_OK;

@@ -239,6 +239,12 @@ struct calipso_hip_solver {
     void* ldl_aux = nullptr;      // ldlsolver.hip: staging of the caller's CSC matrix (handles made by calipso_hip_ldl_create)
     double* Hdense = nullptr; int* lu_ipiv = nullptr;   // fallback.hip: N x N unreduced matrix and pivots (allocated on first use)
     hipEvent_t ev[16];
+    hipStream_t stream2 = nullptr;       // second stream of the handle: the finish of completed solve blocks while the pivot chain runs (ldl.hip)
+    int ldl_forks = 0;                   // solve blocks the last enqueue_ldl_steps left to the second stream ...
+    int ldl_fork_block[8] = {}, ldl_fork_step[8] = {};   // ... block b may be finished once panel step ldl_fork_step has STARTED
+    unsigned long long ldl_epoch = 0;    // factorisations so far (tags the progress word)
+    unsigned long long *hprog = nullptr, *hprog_dev = nullptr;   // mapped host word: epoch << 16 | index of the last panel step that started
+    hipEvent_t ev_side[8] = {};          // [7]: the join (second stream -> main)
     hipGraphExec_t graph_ldl = nullptr, graph_ldl_fin = nullptr, graph_trsv = nullptr;   // captured once per handle (fixed launch sequences): panel steps, factor columns + block inverses, one triangular solve
     bool graph_ldl_tried = false, graph_ldl_fin_tried = false, graph_trsv_tried = false, use_graphs = true;
     calipso::i64 solve_block = 1024;   // "opt.solve_block": widest diagonal block of L whose inverse is assembled (1024: fewest launches per solve, what one system wants; 512: a quarter of the

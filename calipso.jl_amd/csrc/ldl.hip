@@ -293,11 +293,11 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(Batch bt, int NP, int
 // 16-lane fast index of the result is the contiguous row index r of the column-major panel.  One workgroup (16 wavefronts) per
 // 64 x 64 tile (blockIdx.x = tile row below the panel, blockIdx.y = panel); wavefront (wr, wc) computes the 16 x 16 tile rows 16 wr..,
 // columns 16 wc..; X is staged in LDS.  Off the critical path: 780 independent tiles at C3.
-__global__ __launch_bounds__(1024) void k_ldl_scale(Batch bt, int NP, int tb, int band_rows, double* __restrict__ S, const double* __restrict__ Dx,
+__global__ __launch_bounds__(1024) void k_ldl_scale(Batch bt, int NP, int tb, int band_rows, int p0, double* __restrict__ S, const double* __restrict__ Dx,
                                                      const double* __restrict__ Tinv) {
     __shared__ double Xs[NB * LDT];   // Xs[c][k]
     __shared__ double dinv[NB];
-    const int k0 = (int)blockIdx.y * NB;
+    const int k0 = (p0 + (int)blockIdx.y) * NB;       // panels p0 .. p0 + gridDim.y - 1
     const int rows = min(NP - k0 - NB, band_rows);           // banded S: the panel stops at the band
     if ((int)blockIdx.x * 64 >= rows) return;
     inst_shift(bt, S, Dx, Tinv);
@@ -424,8 +424,11 @@ __device__ __forceinline__ void form_Z(const double* __restrict__ Ap, int NP, co
 // concurrently on an XCD then touches the panels of one or two instances and neighbouring tile rows — they stay in that XCD's 4 MB L2.
 template <int MODE>
 __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int nx, int k0, int ntiles, int tb, double* __restrict__ S, double* __restrict__ Minv,
-                                                         double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount) {
+                                                         double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount,
+                                                         unsigned long long* __restrict__ hprog = nullptr, unsigned long long ptag = 0) {
     constexpr int NH = MODE == 2 ? 2 : 1;   // panels per pass
+    // progress word for the host (mapped memory; launch_ldl): this step has started, so everything the steps before it wrote is complete
+    if (hprog && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hprog, ptag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __shared__ double smem[step_lds_doubles(NH)];
     double* Zs = smem;                    // Zs[h][i][c]: Z = A(i, panel h) M_h of the current tile row
     double* Ys = smem + NH * TT * LDT;    // Ys[j][k]: rows of the j block of the raw panel (and the staging buffer of form_Z)
@@ -655,14 +658,14 @@ __global__ __launch_bounds__(1024) void k_tinv_merge(Batch bt, int NP, int tb, i
 // for 64 cycles per k (13.6 us at K = 512) and the levels have 20 .. 128 such tiles: the launch lasts as long as its longest tile.  Four times as many
 // tiles of a quarter of the work spread over four times as many CUs, and eight 256-thread workgroups per CU hide each other's load latency (the K loop
 // is load -> barrier -> MFMA -> barrier, no double buffering).  Same k order per output entry as the 64 x 64 version (the skipped k ranges are exact zeros).
-__global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, int half, int phase, const double* __restrict__ S, double* __restrict__ Tinv,
+__global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, int half, int phase, int pair0, const double* __restrict__ S, double* __restrict__ Tinv,
                                                        double* __restrict__ Ttmp) {
     constexpr int KC = 32, ldk = KC + 2;
     __shared__ double As[32 * ldk];       // As[i][k]
     __shared__ double Bs[32 * ldk];       // Bs[j][k]
     inst_shift(bt, S, Tinv, Ttmp);
     const int tiles = half / 32;
-    const int pair = blockIdx.x / (tiles * tiles);
+    const int pair = pair0 + blockIdx.x / (tiles * tiles);     // pairs pair0 .. of this level (a launch may cover one solve block only)
     const int tt = blockIdx.x % (tiles * tiles);
     const int tiy = tt / tiles, tjx = tt % tiles;
     const int g0 = pair * 2 * half;
@@ -713,6 +716,36 @@ __global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, 
     }
 }
 
+// second stream + events + progress word of the handle (created on first use; lowest priority: the pivot chain's workgroups are scheduled first.  Confining it
+// to a quarter of the compute units — hipExtStreamCreateWithCUMask — changed nothing: the chain's workgroup does not wait for a CU)
+static bool side_stream(calipso_hip_solver* s) {
+    if (s->stream2) return s->hprog_dev != nullptr && s->ev_side[7] != nullptr;
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+        if (hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, least) != hipSuccess) { s->stream2 = nullptr; return false; }
+    }
+    if (!s->hprog) {
+        if (hipHostMalloc((void**)&s->hprog, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { s->hprog = nullptr; return false; }
+        *s->hprog = 0;
+        if (hipHostGetDevicePointer((void**)&s->hprog_dev, s->hprog, 0) != hipSuccess) return false;
+    }
+    for (auto& e : s->ev_side)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return false; }
+    return true;
+}
+static void enqueue_ldl_finish_block(calipso_hip_solver* s, hipStream_t stream, int b);
+// Which finish work runs beside the chain: one instance alone, dense S, a solve block that is complete before the chain ends (otherwise nothing to overlap)
+static bool ldl_overlap(calipso_hip_solver* s) {
+    static const int env = [] { const char* e = getenv("CALIPSO_HIP_LDL_OVERLAP"); return e ? atoi(e) : 1; }();
+    static const bool graph_ldl_env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();   // (captured graphs: one stream, no overlap)
+    if (!env || graph_ldl_env || s->cur || s->band64 > 0) return false;
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
+    static const bool merge64 = [] { const char* e = getenv("CALIPSO_HIP_MERGE64"); return e && atoi(e) != 0; }();
+    if (merge64 || NP < 2 * tb || (NP / tb) > 6) return false;
+    return true;
+}
+
 // the panel steps (the pivot chain): NP / 64 launches
 static void enqueue_ldl_steps(calipso_hip_solver* s) {
     const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
@@ -736,6 +769,8 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     // flattened XCD-aware grid: one workgroup per instance for tile 0 (+ the diagonal block), then workers in multiples of 8 plus 7, so that
     // every XCD (workgroup index mod 8) has at least one worker for its share of the tile list; surplus workgroups leave at once
     auto grid = [&](int tiles) { const int workers = std::min(std::max(tiles - 1, 0), resident) * (int)nz; return dim3(nz + (workers ? (workers + 7) / 8 * 8 + 7 : 0)); };
+    const bool overlap = !pairs && ldl_overlap(s) && side_stream(s);
+    int forks = 0;
     for (int kb = 0; kb + 1 < nblk;) {
         const int k0 = kb * NB;
         const int rows = std::min(NP - k0 - NB, band * NB);  // banded S: the panel and its trailing update stop at the band
@@ -750,10 +785,18 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
         } else {
             const int ntiles = ntr * (ntr + 1) / 2;
             // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
-            hipLaunchKernelGGL((k_ldl_step<0>), grid(ntiles), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S, Minv, s->Dx, s->Tinv, s->icount);
+            hipLaunchKernelGGL((k_ldl_step<0>), grid(ntiles), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S, Minv, s->Dx, s->Tinv, s->icount,
+                               overlap ? s->hprog_dev : (unsigned long long*)nullptr, (s->ldl_epoch << 16) | (unsigned long long)kb);
+            // this step applies panel kb: if that is the last panel of a solve block, the block's finish can be queued on the second stream as soon as the
+            // NEXT step has started (launch_ldl watches the progress word) and runs while the chain goes on
+            if (overlap && (kb + 1) % (tb / NB) == 0 && kb + 2 < nblk && forks < 6) {
+                s->ldl_fork_block[forks] = kb / (tb / NB); s->ldl_fork_step[forks] = kb + 1;
+                ++forks;
+            }
             kb += 1;
         }
     }
+    s->ldl_forks = forks;              // (enqueue_ldl_finish joins the second stream)
 }
 
 // what follows the chain, fully parallel: the factor columns L = A X' D^-1 of every panel, then the inverses of the triangular-solve blocks
@@ -762,9 +805,24 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
     const Batch bt = batch_of(s).b;
     const unsigned nz = bt.n;
     const int band = s->band64 > 0 ? s->band64 : nblk;
+    {
+        static const int pairs_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_PAIRS"); return e ? atoi(e) : -1; }();
+        const bool pairs = s->band64 == 0 && (pairs_env >= 0 ? pairs_env != 0 : nz >= 4);
+        if (!pairs && ldl_overlap(s) && s->stream2) {
+            // the blocks whose last panel a panel step applied were finished beside the chain (launch_ldl); what is left is the last block(s).
+            // Join first: the solves need every block (the second stream is long done by now).  (The last block's finish on the second stream too, joined
+            // after the inertia read-back, was measured: 0.901 against 0.889 ms — the hand-over between the queues costs more than the overlap gives.)
+            if (s->ldl_forks) {
+                (void)hipEventRecord(s->ev_side[7], s->stream2);
+                (void)hipStreamWaitEvent(s->stream, s->ev_side[7], 0);
+            }
+            for (int b = s->ldl_forks; b * tb < NP; ++b) enqueue_ldl_finish_block(s, s->stream, b);
+            return;
+        }
+    }
     if (nblk > 1) {
         const int maxrows = std::min(NP - NB, band * NB);
-        hipLaunchKernelGGL(k_ldl_scale, dim3(maxrows / 64, nblk - 1, nz), dim3(1024), 0, s->stream, bt, NP, tb, band * NB, s->S, s->Dx, s->Tinv);
+        hipLaunchKernelGGL(k_ldl_scale, dim3(maxrows / 64, nblk - 1, nz), dim3(1024), 0, s->stream, bt, NP, tb, band * NB, 0, s->S, s->Dx, s->Tinv);
     }
     const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
     for (int level = 1; level <= 5; ++level) {
@@ -773,8 +831,28 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
         static const bool merge64 = [] { const char* e = getenv("CALIPSO_HIP_MERGE64"); return e && atoi(e) != 0; }();
         for (int phase = 0; phase < 2; ++phase) {
             if (merge64) hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles, 1, nz), dim3(1024), mg_lds, s->stream, bt, NP, tb, half, phase, s->S, s->Tinv, s->Ttmp);
-            else hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles * 4, 1, nz), dim3(256), 0, s->stream, bt, NP, tb, half, phase, s->S, s->Tinv, s->Ttmp);
+            else hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles * 4, 1, nz), dim3(256), 0, s->stream, bt, NP, tb, half, phase, 0, s->S, s->Tinv, s->Ttmp);
         }
+    }
+}
+
+// The same finish for ONE solve block b (columns b tb .. b tb + w - 1) on `stream`: the factor columns of its panels, then the merges of its inverse blocks.
+// Everything it reads is final once the panel step that applies the block's LAST panel has completed (the raw panel columns are only read by the step
+// that applies them; the X and D of a diagonal block are stored one step earlier), and what it writes — the scaled columns, the off-diagonal parts
+// of Tinv_b, its pairs of Ttmp — nothing else touches: one instance alone leaves most of the chip idle during a panel step (one 20 us pivot chain, a
+// shrinking trailing update), so the finish of the completed blocks runs THERE, on a second stream, instead of after the chain.
+static void enqueue_ldl_finish_block(calipso_hip_solver* s, hipStream_t stream, int b) {
+    const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
+    const Batch bt = batch_of(s).b;
+    const unsigned nz = bt.n;
+    const int w = std::min(tb, NP - b * tb), p0 = b * (tb / NB), np = std::min(w / NB, nblk - 1 - p0);   // (the last panel has no rows below it)
+    if (np > 0) hipLaunchKernelGGL(k_ldl_scale, dim3((NP - p0 * NB - NB) / 64, np, nz), dim3(1024), 0, stream, bt, NP, tb, NP, p0, s->S, s->Dx, s->Tinv);
+    for (int level = 1; level <= 5; ++level) {
+        const int half = 32 << level, tiles = half / 32;
+        if (2 * half > w) break;
+        const int pairs = w / (2 * half), pair0 = b * tb / (2 * half);
+        for (int phase = 0; phase < 2; ++phase)
+            hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles, 1, nz), dim3(256), 0, stream, bt, NP, tb, half, phase, pair0, s->S, s->Tinv, s->Ttmp);
     }
 }
 
@@ -977,9 +1055,27 @@ void launch_ldl(calipso_hip_solver* s) {
     }
     ldl_set_attributes();
     // (a group launch covers a changing set of instances: its kernel arguments differ from call to call, so no graph there)
-    const bool graphs = !s->cur && s->use_graphs;
+    // The panel steps are queued launch by launch (the host keeps ahead of a 20 us chain: 0.935 ms per factorisation at C3 against 0.950 as a captured graph), which
+    // also lets the host hand the completed solve blocks to the second stream while the chain runs (below): 0.889 ms.  CALIPSO_HIP_GRAPH_LDL=1 brings the
+    // graphs back (one stream, no overlap); the solves keep theirs (launch_trsv).
+    static const bool graph_ldl_env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();
+    const bool graphs = !s->cur && s->use_graphs && graph_ldl_env;
+    if (ldl_overlap(s)) (void)side_stream(s);       // (created outside a stream capture)
+    s->ldl_forks = 0;
+    s->ldl_epoch += 1;
     if (!graphs || !replay_or_capture(s, s->graph_ldl, s->graph_ldl_tried, [&] { enqueue_ldl_steps(s); })) enqueue_ldl_steps(s);
     (void)hipEventRecord(s->ev[14], s->stream);
+    // The host (which would only wait for the factorisation anyway) hands the completed solve blocks to the second stream: it watches the progress word
+    // the panel steps store and queues a block's finish when the step after the block's last panel has started.  (A hipStreamWaitEvent on the second
+    // stream instead was measured: a queue blocked on a barrier costs every dispatch of the chain's queue ~0.8 us — 30 us per factorisation.)
+    for (int f = 0; f < s->ldl_forks; ++f) {
+        const unsigned long long want = (s->ldl_epoch << 16) | (unsigned long long)s->ldl_fork_step[f];
+        unsigned spins = 0;
+        while (__atomic_load_n(s->hprog, __ATOMIC_ACQUIRE) < want) {
+            if ((++spins & 0xffffu) == 0 && hipStreamQuery(s->stream) != hipErrorNotReady) break;     // (the chain is through, or the queue faulted)
+        }
+        enqueue_ldl_finish_block(s, s->stream2, s->ldl_fork_block[f]);
+    }
     if (!graphs || !replay_or_capture(s, s->graph_ldl_fin, s->graph_ldl_fin_tried, [&] { enqueue_ldl_finish(s); })) enqueue_ldl_finish(s);
 }
 
