@@ -512,7 +512,20 @@ static int read_scalars(H* s, int first, int count) { return publish_and_wait(s,
 static int read_icount(H* s, int first, int count) { return publish_and_wait(s, s->icount + first, s->hicount_dev + first, count); }
 static double* point_of(H* s, int which) { return which == 0 ? s->solution : s->candidate; }
 
+// phase times of the last factorisation from its events (do_factorize does not wait for them when the chain published the inertia counts)
+static void factor_times(H* s) {
+    if (!s->factor_times_pending) return;
+    s->factor_times_pending = false;
+    if (hipEventSynchronize(s->ev[13]) != hipSuccess) return;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, s->ev[10], s->ev[11]); s->phase_ms[1] = ms;   // cone pivots + Omega*hx
+    (void)hipEventElapsedTime(&ms, s->ev[11], s->ev[12]); s->phase_ms[7] = ms;   // Schur complement (MFMA kernel), one launch
+    (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[13]); s->phase_ms[3] = ms;   // LDL^T of S
+    (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[14]); s->kernel_ms[0] = ms;   // of which the panel steps (the pivot chain)
+}
+
 static int do_factorize(H* s, int64_t inertia[3]) {
+    factor_times(s);                      // (before the events are recorded again)
     (void)hipEventRecord(s->ev[10], s->stream);
     launch_cone_weights(s);
     launch_scale_rows(s);
@@ -521,17 +534,17 @@ static int do_factorize(H* s, int64_t inertia[3]) {
     (void)hipEventRecord(s->ev[12], s->stream);
     launch_ldl(s);
     (void)hipEventRecord(s->ev[13], s->stream);
-    CK(hipMemcpyAsync(s->hicount, s->icount, sizeof(int) * 6, hipMemcpyDeviceToHost, s->stream));
-    SYNC();
-    s->stats.factorizations += 1;
-    {
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, s->ev[10], s->ev[11]); s->phase_ms[1] = ms;   // cone pivots + Omega*hx
-        (void)hipEventElapsedTime(&ms, s->ev[11], s->ev[12]); s->phase_ms[7] = ms;   // Schur complement (MFMA kernel), one launch
-        (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[13]); s->phase_ms[3] = ms;
-        (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[14]); s->kernel_ms[0] = ms;   // of which the panel steps (the pivot chain)   // LDL^T of S
-        s->phase_ms[8] += 1.0;
+    s->factor_times_pending = true;
+    if (s->ldl_pub_seq) {
+        // the last diagonal block published the counts when the pivot chain ended: the host goes on queueing behind the finish of the last solve block
+        if (wait_published(s, s->ldl_pub_seq)) return CALIPSO_ERR_HIP;
+    } else {
+        CK(hipMemcpyAsync(s->hicount, s->icount, sizeof(int) * 6, hipMemcpyDeviceToHost, s->stream));
+        SYNC();
+        factor_times(s);
     }
+    s->stats.factorizations += 1;
+    s->phase_ms[8] += 1.0;
     const int64_t pos = s->hicount[0] + s->hicount[3], nonpos = s->hicount[1] + s->hicount[4], zero = s->hicount[2] + s->hicount[5];
     inertia[0] = pos; inertia[1] = nonpos; inertia[2] = zero;
     if (zero > 0) { inertia[0] = -1; return CALIPSO_WARN_ZERO_PIVOT; }   // qdldl.jl:456,579: posDCount = -1
@@ -1125,6 +1138,7 @@ extern "C" {
 
 int32_t calipso_hip_phase_times(H* s, double out[9]) {
     if (!s || !out) return CALIPSO_ERR_ARGUMENT;
+    factor_times(s);
     for (int i = 0; i < 9; ++i) out[i] = s->phase_ms[i];
     return CALIPSO_OK;
 }
@@ -1132,6 +1146,7 @@ int32_t calipso_hip_phase_times(H* s, double out[9]) {
 int32_t calipso_hip_kernel_times(H* s, double out[8]) {
     if (!s || !out) return CALIPSO_ERR_ARGUMENT;
     for (int i = 0; i < 8; ++i) out[i] = 0.0;
+    factor_times(s);
     out[0] = s->kernel_ms[0];
     out[1] = (double)(s->d.NP / calipso::NB);
     out[2] = (double)s->d.NP;

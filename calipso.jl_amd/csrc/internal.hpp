@@ -240,6 +240,9 @@ struct calipso_hip_solver {
     double* Hdense = nullptr; int* lu_ipiv = nullptr;   // fallback.hip: N x N unreduced matrix and pivots (allocated on first use)
     hipEvent_t ev[16];
     hipStream_t stream2 = nullptr;       // second stream of the handle: the finish of completed solve blocks while the pivot chain runs (ldl.hip)
+    bool ldl_publish = false;            // launch_ldl: the last diagonal block may publish the inertia counts ...
+    unsigned long long ldl_pub_seq = 0;  // ... and did, under this sequence number (0: it did not; read them back)
+    bool factor_times_pending = false;   // the events of the last factorisation have not been read yet (api.hip: factor_times)
     int ldl_forks = 0;                   // solve blocks the last enqueue_ldl_steps left to the second stream ...
     int ldl_fork_block[8] = {}, ldl_fork_step[8] = {};   // ... block b may be finished once panel step ldl_fork_step has STARTED
     unsigned long long ldl_epoch = 0;    // factorisations so far (tags the progress word)

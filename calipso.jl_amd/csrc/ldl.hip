@@ -716,6 +716,12 @@ __global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, 
     }
 }
 
+__global__ void k_publish_inertia(const int* __restrict__ icount, int* __restrict__ hcount, unsigned long long* __restrict__ hseq, unsigned long long seq) {
+    if (threadIdx.x < 6) hcount[threadIdx.x] = icount[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // second stream + events + progress word of the handle (created on first use; lowest priority: the pivot chain's workgroups are scheduled first.  Confining it
 // to a quarter of the compute units — hipExtStreamCreateWithCUMask — changed nothing: the chain's workgroup does not wait for a CU)
 static bool side_stream(calipso_hip_solver* s) {
@@ -797,6 +803,13 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
         }
     }
     s->ldl_forks = forks;              // (enqueue_ldl_finish joins the second stream)
+    // A single handle outside a stream capture: the six inertia counts go to their mapped host words right behind the chain (+ the sequence number the host
+    // spins on, api.hip: wait_published) — the host learns the inertia when the pivot chain ends, not after the finish + a copy + a stream synchronisation
+    // (as arguments of the panel-step kernel itself the three words cost every launch 0.7 us).
+    if (s->ldl_publish && nz == 1) {
+        s->ldl_pub_seq = ++s->pub_seq;
+        hipLaunchKernelGGL(k_publish_inertia, dim3(1), dim3(64), 0, s->stream, s->icount, s->hicount_dev, s->hseq_dev, s->ldl_pub_seq);
+    }
 }
 
 // what follows the chain, fully parallel: the factor columns L = A X' D^-1 of every panel, then the inverses of the triangular-solve blocks
@@ -1062,6 +1075,9 @@ void launch_ldl(calipso_hip_solver* s) {
     const bool graphs = !s->cur && s->use_graphs && graph_ldl_env;
     if (ldl_overlap(s)) (void)side_stream(s);       // (created outside a stream capture)
     s->ldl_forks = 0;
+    s->ldl_pub_seq = 0;
+    static const bool pub_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_PUBLISH"); return !e || atoi(e) != 0; }();     // (experiment switch)
+    s->ldl_publish = pub_env && !graphs && !s->cur;       // (a captured launch would replay a stale sequence number)
     s->ldl_epoch += 1;
     if (!graphs || !replay_or_capture(s, s->graph_ldl, s->graph_ldl_tried, [&] { enqueue_ldl_steps(s); })) enqueue_ldl_steps(s);
     (void)hipEventRecord(s->ev[14], s->stream);
