@@ -164,7 +164,7 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->saved_point, N); SL(&s->saved_g, NE); SL(&s->saved_h, NC);
     SL(&s->residual_symmetric, n); SL(&s->step_symmetric, n); SL(&s->merit_gradient, n);
     SL(&s->S, cp ? plan.spacked : NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, cp ? 1 : NPd * NB);                     // structured: S = the tiles of the segment pairs, contiguous
-    SL(&s->Tinv, cp ? 1 : calipso::tinv_doubles(d.NP)); SL(&s->Ttmp, cp ? 1 : NPd * 512); SL(&s->zf2, NPd); SL(&s->WH, cp ? 1 : NC * NX);
+    SL(&s->Tinv, cp ? 1 : calipso::tinv_doubles(d.NP)); SL(&s->Ttmp, cp ? 1 : NPd * 1024); SL(&s->zf2, NPd); SL(&s->WH, cp ? 1 : NC * NX);
     SL(&s->wz, NC); SL(&s->kzz, NC);
     SL(&s->Wsoc, (size_t)woff); SL(&s->Bsoc, (size_t)woff); SL(&s->socwork, (size_t)2 * woff);
     SL(&icount_d, 32);                                        // 64 ints

@@ -196,7 +196,7 @@ struct calipso_hip_solver {
     double* refpart = nullptr;  // per workgroup of k_refine_local: its part of ||residual_error||_inf
     double* Ypanel = nullptr;   // NP*NB: M_k = (L_kk D_k L_kk')^-1 of every 64-column panel (ldl.hip: what the trailing update multiplies the raw panel with)
     double* Tinv = nullptr;     // tinv_doubles(NP): inverses of the unit-lower diagonal blocks of L (up to 1024 x 1024, the last one may be 512 wide)
-    double* Ttmp = nullptr;     // NP*512 scratch of the inverse assembly (one 1024 x 1024 product at the top level)
+    double* Ttmp = nullptr;     // NP*1024 scratch of the inverse assembly (NP*512: one 1024 x 1024 product at the top level; as much again so that every merge level has an area of its own, ldl.hip: merge_scratch)
     double* zf2 = nullptr;      // NP
     double* WH = nullptr;       // nc*nx: Omega_z * hx
     double* wz = nullptr;       // nc: Omega for nonnegative entries (-1/K_zz)
@@ -243,8 +243,8 @@ struct calipso_hip_solver {
     bool ldl_publish = false;            // launch_ldl: the last diagonal block may publish the inertia counts ...
     unsigned long long ldl_pub_seq = 0;  // ... and did, under this sequence number (0: it did not; read them back)
     bool factor_times_pending = false;   // the events of the last factorisation have not been read yet (api.hip: factor_times)
-    int ldl_forks = 0;                   // solve blocks the last enqueue_ldl_steps left to the second stream ...
-    int ldl_fork_block[8] = {}, ldl_fork_step[8] = {};   // ... block b may be finished once panel step ldl_fork_step has STARTED
+    int ldl_forks = 0;                   // ranges of columns the last enqueue_ldl_steps left to the second stream (the first ldl_forks of ldl_ranges) ...
+    std::vector<int> ldl_ranges;         // ... (first column, width) pairs, in order; range f may be finished once panel step (c0 + w) / 64 has STARTED
     unsigned long long ldl_epoch = 0;    // factorisations so far (tags the progress word)
     unsigned long long *hprog = nullptr, *hprog_dev = nullptr;   // mapped host word: epoch << 16 | index of the last panel step that started
     hipEvent_t ev_side[8] = {};          // [7]: the join (second stream -> main)

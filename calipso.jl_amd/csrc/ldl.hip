@@ -740,7 +740,8 @@ static bool side_stream(calipso_hip_solver* s) {
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return false; }
     return true;
 }
-static void enqueue_ldl_finish_block(calipso_hip_solver* s, hipStream_t stream, int b);
+static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f);
+static void ldl_plan_ranges(calipso_hip_solver* s);
 // Which finish work runs beside the chain: one instance alone, dense S, a solve block that is complete before the chain ends (otherwise nothing to overlap)
 static bool ldl_overlap(calipso_hip_solver* s) {
     static const int env = [] { const char* e = getenv("CALIPSO_HIP_LDL_OVERLAP"); return e ? atoi(e) : 1; }();
@@ -748,7 +749,7 @@ static bool ldl_overlap(calipso_hip_solver* s) {
     if (!env || graph_ldl_env || s->cur || s->band64 > 0) return false;
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
     static const bool merge64 = [] { const char* e = getenv("CALIPSO_HIP_MERGE64"); return e && atoi(e) != 0; }();
-    if (merge64 || NP < 2 * tb || (NP / tb) > 6) return false;
+    if (merge64 || NP < 1024 || NP > 8192 || tb < 256) return false;
     return true;
 }
 
@@ -777,6 +778,7 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     auto grid = [&](int tiles) { const int workers = std::min(std::max(tiles - 1, 0), resident) * (int)nz; return dim3(nz + (workers ? (workers + 7) / 8 * 8 + 7 : 0)); };
     const bool overlap = !pairs && ldl_overlap(s) && side_stream(s);
     int forks = 0;
+    if (overlap) ldl_plan_ranges(s);
     for (int kb = 0; kb + 1 < nblk;) {
         const int k0 = kb * NB;
         const int rows = std::min(NP - k0 - NB, band * NB);  // banded S: the panel and its trailing update stop at the band
@@ -795,10 +797,7 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
                                overlap ? s->hprog_dev : (unsigned long long*)nullptr, (s->ldl_epoch << 16) | (unsigned long long)kb);
             // this step applies panel kb: if that is the last panel of a solve block, the block's finish can be queued on the second stream as soon as the
             // NEXT step has started (launch_ldl watches the progress word) and runs while the chain goes on
-            if (overlap && (kb + 1) % (tb / NB) == 0 && kb + 2 < nblk && forks < 6) {
-                s->ldl_fork_block[forks] = kb / (tb / NB); s->ldl_fork_step[forks] = kb + 1;
-                ++forks;
-            }
+            if (overlap && 2 * forks < (int)s->ldl_ranges.size() && kb + 2 < nblk && (kb + 1) * NB == s->ldl_ranges[2 * forks] + s->ldl_ranges[2 * forks + 1]) ++forks;
             kb += 1;
         }
     }
@@ -829,7 +828,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
                 (void)hipEventRecord(s->ev_side[7], s->stream2);
                 (void)hipStreamWaitEvent(s->stream, s->ev_side[7], 0);
             }
-            for (int b = s->ldl_forks; b * tb < NP; ++b) enqueue_ldl_finish_block(s, s->stream, b);
+            for (int f = s->ldl_forks; 2 * f < (int)s->ldl_ranges.size(); ++f) enqueue_finish_feed(s, s->stream, f);
             return;
         }
     }
@@ -854,18 +853,48 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
 // that applies them; the X and D of a diagonal block are stored one step earlier), and what it writes — the scaled columns, the off-diagonal parts
 // of Tinv_b, its pairs of Ttmp — nothing else touches: one instance alone leaves most of the chip idle during a panel step (one 20 us pivot chain, a
 // shrinking trailing update), so the finish of the completed blocks runs THERE, on a second stream, instead of after the chain.
-static void enqueue_ldl_finish_block(calipso_hip_solver* s, hipStream_t stream, int b) {
+// The finish as a walk over the merge tree of the solve blocks.  The columns are cut into RANGES of FEED columns (a solve block narrower than that is one
+// range); when a range is complete (the panel step that applies its last panel has finished) the second stream gets, in this order:
+//   the factor columns of its panels; the merges inside the range (both phases, level by level);
+//   then up the tree: the range (or the node it has just completed) is either the LEFT child of its parent — the parent's first phase T = L21 X11 needs
+//   nothing else, it is queued and the walk stops — or the RIGHT child — the parent's second phase X21 = -X22 T is queued, the parent is complete, the walk
+//   goes on with it.
+// So when the chain ends only the last range and the second phases along the right edge of the last block are left.  A first phase may wait for its second
+// one while other merges run: every level has a scratch area of its own (merge_scratch).  Measured at C3 (ms per factorisation / per step): ranges of 64,
+// 128, 256 columns 0.868 / 2.418, 0.872 / 2.417, 0.868 / 2.422 (whole solve blocks of 1024: 0.889 / 2.43); with 2048-wide solve blocks 0.93-0.96 / 2.415-2.445:
+// the second phase of the 1024 -> 2048 merge and the right edge below it arrive together after step 31 and the second stream runs late, which costs
+// the factorisation what the six-launch solves save (solve + refinement 0.78 against 0.84 ms) — opt.solve_block stays 1024.
+static const int FEED = [] { const char* e = getenv("CALIPSO_HIP_LDL_FEED"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 256; }();
+static size_t merge_scratch(int NP, int half) { return (size_t)NP * (size_t)(half - 64) / 2; }   // a level holds NP / (2 half) products of half x half = NP half / 2 doubles; the levels below: NP (32 + 64 + ... + half / 4); all five: NP * 992
+static void enqueue_merge(calipso_hip_solver* s, hipStream_t stream, int half, int phase, int pair0, int pairs) {
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), tiles = half / 32;
+    const Batch bt = batch_of(s).b;
+    hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles, 1, bt.n), dim3(256), 0, stream, bt, NP, tb, half, phase, pair0, s->S, s->Tinv, s->Ttmp + merge_scratch(NP, half));
+}
+static void ldl_plan_ranges(calipso_hip_solver* s) {
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
+    s->ldl_ranges.clear();
+    for (int b0 = 0; b0 < NP; b0 += tb) {
+        const int wblk = std::min(tb, NP - b0), wr = std::min(FEED, wblk);
+        for (int c = b0; c < b0 + wblk; c += wr) { s->ldl_ranges.push_back(c); s->ldl_ranges.push_back(wr); }
+    }
+}
+static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f) {
     const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
     const Batch bt = batch_of(s).b;
     const unsigned nz = bt.n;
-    const int w = std::min(tb, NP - b * tb), p0 = b * (tb / NB), np = std::min(w / NB, nblk - 1 - p0);   // (the last panel has no rows below it)
+    const int c0 = s->ldl_ranges[2 * f], w = s->ldl_ranges[2 * f + 1];
+    const int b0 = c0 / tb * tb, wblk = std::min(tb, NP - b0);
+    const int p0 = c0 / NB, np = std::min(w / NB, nblk - 1 - p0);                     // (the last panel has no rows below it)
     if (np > 0) hipLaunchKernelGGL(k_ldl_scale, dim3((NP - p0 * NB - NB) / 64, np, nz), dim3(1024), 0, stream, bt, NP, tb, NP, p0, s->S, s->Dx, s->Tinv);
-    for (int level = 1; level <= 5; ++level) {
-        const int half = 32 << level, tiles = half / 32;
-        if (2 * half > w) break;
-        const int pairs = w / (2 * half), pair0 = b * tb / (2 * half);
-        for (int phase = 0; phase < 2; ++phase)
-            hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles, 1, nz), dim3(256), 0, stream, bt, NP, tb, half, phase, pair0, s->S, s->Tinv, s->Ttmp);
+    for (int half = 64; 2 * half <= w; half *= 2)
+        for (int phase = 0; phase < 2; ++phase) enqueue_merge(s, stream, half, phase, c0 / (2 * half), w / (2 * half));
+    int rel = c0 - b0;
+    for (int cur = w; 2 * cur <= wblk; cur *= 2) {          // the complete node: columns b0 + rel .. + cur - 1
+        const int pair = (b0 + (rel & ~(2 * cur - 1))) / (2 * cur);
+        if ((rel & (2 * cur - 1)) == 0) { enqueue_merge(s, stream, cur, 0, pair, 1); break; }
+        enqueue_merge(s, stream, cur, 1, pair, 1);
+        rel &= ~(2 * cur - 1);
     }
 }
 
@@ -1085,12 +1114,12 @@ void launch_ldl(calipso_hip_solver* s) {
     // the panel steps store and queues a block's finish when the step after the block's last panel has started.  (A hipStreamWaitEvent on the second
     // stream instead was measured: a queue blocked on a barrier costs every dispatch of the chain's queue ~0.8 us — 30 us per factorisation.)
     for (int f = 0; f < s->ldl_forks; ++f) {
-        const unsigned long long want = (s->ldl_epoch << 16) | (unsigned long long)s->ldl_fork_step[f];
+        const unsigned long long want = (s->ldl_epoch << 16) | (unsigned long long)((s->ldl_ranges[2 * f] + s->ldl_ranges[2 * f + 1]) / NB);
         unsigned spins = 0;
         while (__atomic_load_n(s->hprog, __ATOMIC_ACQUIRE) < want) {
             if ((++spins & 0xffffu) == 0 && hipStreamQuery(s->stream) != hipErrorNotReady) break;     // (the chain is through, or the queue faulted)
         }
-        enqueue_ldl_finish_block(s, s->stream2, s->ldl_fork_block[f]);
+        enqueue_finish_feed(s, s->stream2, f);
     }
     if (!graphs || !replay_or_capture(s, s->graph_ldl_fin, s->graph_ldl_fin_tried, [&] { enqueue_ldl_finish(s); })) enqueue_ldl_finish(s);
 }
