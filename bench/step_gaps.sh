@@ -14,14 +14,18 @@ diag = [i for i, n in enumerate(names) if "k_ldl_diag" in n]
 a, b = diag[-2], diag[-1]
 out = []; busy = 0; gaps = 0; big = 0
 prev_end = int(rows[a - 1]["End_Timestamp"])
+mainq = rows[a]["Queue_Id"]              # the queue of the handle's stream; its second stream (the finish of completed solve blocks beside the pivot chain) is another
+side = [r for r in rows[a:b] if r["Queue_Id"] != mainq]
 for r in rows[a:b]:
+    if r["Queue_Id"] != mainq: continue
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     g = (s - prev_end) / 1e3; d = (e - s) / 1e3
     busy += d; gaps += max(g, 0.0); big += g if g > 3.0 else 0.0
     short = r["Kernel_Name"].split("(")[0].replace("calipso::", "").replace("void ", "")
     out.append("%8.1f us idle  %8.1f us  %s" % (g, d, short))
     prev_end = max(prev_end, e)
-out.append("one step: %d launches, busy %.1f us, idle %.1f us (of which gaps > 3 us: %.1f us)" % (b - a, busy, gaps, big))
+out.append("one step: %d launches on the handle's stream, busy %.1f us, idle %.1f us (of which gaps > 3 us: %.1f us); %d more on its second stream beside the pivot chain (%.1f us of kernel time)"
+           % (b - a - len(side), busy, gaps, big, len(side), sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in side) / 1e3))
 open(sys.argv[2], "w").write("\n".join(out) + "\n")
 print(out[-1])
 PY
