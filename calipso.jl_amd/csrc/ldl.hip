@@ -746,7 +746,10 @@ static void ldl_plan_ranges(calipso_hip_solver* s);
 static bool ldl_overlap(calipso_hip_solver* s) {
     static const int env = [] { const char* e = getenv("CALIPSO_HIP_LDL_OVERLAP"); return e ? atoi(e) : 1; }();
     static const bool graph_ldl_env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();   // (captured graphs: one stream, no overlap)
-    if (!env || graph_ldl_env || s->cur || s->band64 > 0) return false;
+    // (groups: measured — one group of 12 alone 952 -> 962 steps/s, three groups in flight 1098 -> 1086: the other groups already fill the chain's idle time,
+    // and the finish as 60 small launches per group costs them more than the overlap gives; off unless asked for)
+    static const int group_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_OVERLAP_GROUPS"); return e ? atoi(e) : 0; }();
+    if (!env || graph_ldl_env || (s->cur && !group_env) || s->band64 > 0) return false;
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
     static const bool merge64 = [] { const char* e = getenv("CALIPSO_HIP_MERGE64"); return e && atoi(e) != 0; }();
     if (merge64 || NP < 1024 || NP > 8192 || tb < 256) return false;
@@ -776,16 +779,17 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     // flattened XCD-aware grid: one workgroup per instance for tile 0 (+ the diagonal block), then workers in multiples of 8 plus 7, so that
     // every XCD (workgroup index mod 8) has at least one worker for its share of the tile list; surplus workgroups leave at once
     auto grid = [&](int tiles) { const int workers = std::min(std::max(tiles - 1, 0), resident) * (int)nz; return dim3(nz + (workers ? (workers + 7) / 8 * 8 + 7 : 0)); };
-    const bool overlap = !pairs && ldl_overlap(s) && side_stream(s);
-    int forks = 0;
+    const bool overlap = ldl_overlap(s) && side_stream(s);
     if (overlap) ldl_plan_ranges(s);
+    unsigned long long* const hprog = overlap ? s->hprog_dev : (unsigned long long*)nullptr;
+    const unsigned long long epoch = s->ldl_epoch << 16;         // progress word = epoch | first panel the launch applies: every panel before it is released
     for (int kb = 0; kb + 1 < nblk;) {
         const int k0 = kb * NB;
         const int rows = std::min(NP - k0 - NB, band * NB);  // banded S: the panel and its trailing update stop at the band
         const int ntr = rows / TT;
         if (pairs && kb + 2 < nblk) {
             hipLaunchKernelGGL((k_ldl_step<1>), grid(ntr), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntr, tb, s->S, Minv, s->Dx,
-                               s->Tinv, s->icount);
+                               s->Tinv, s->icount, hprog, epoch | (unsigned long long)kb);
             const int ntr2 = ntr - 1, ntiles2 = ntr2 * (ntr2 + 1) / 2;
             hipLaunchKernelGGL((k_ldl_step<2>), grid(ntiles2), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles2, tb, s->S, Minv,
                                s->Dx, s->Tinv, s->icount);
@@ -794,13 +798,15 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
             const int ntiles = ntr * (ntr + 1) / 2;
             // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
             hipLaunchKernelGGL((k_ldl_step<0>), grid(ntiles), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S, Minv, s->Dx, s->Tinv, s->icount,
-                               overlap ? s->hprog_dev : (unsigned long long*)nullptr, (s->ldl_epoch << 16) | (unsigned long long)kb);
-            // this step applies panel kb: if that is the last panel of a solve block, the block's finish can be queued on the second stream as soon as the
-            // NEXT step has started (launch_ldl watches the progress word) and runs while the chain goes on
-            if (overlap && 2 * forks < (int)s->ldl_ranges.size() && kb + 2 < nblk && (kb + 1) * NB == s->ldl_ranges[2 * forks] + s->ldl_ranges[2 * forks + 1]) ++forks;
+                               hprog, epoch | (unsigned long long)kb);
             kb += 1;
         }
     }
+    // A range of columns can be finished on the second stream as soon as a launch that applies none of its panels has STARTED (the raw panel columns are
+    // only read by the launch that applies them): launch_ldl watches the progress word for that.  The launches carry the tags 0 .. nblk - 2 (a pair pass the
+    // tag of its first panel), so the ranges that end at or before panel nblk - 2 are handed over while the chain runs, the rest after it (enqueue_ldl_finish).
+    int forks = 0;
+    if (overlap) while (2 * forks < (int)s->ldl_ranges.size() && (s->ldl_ranges[2 * forks] + s->ldl_ranges[2 * forks + 1]) / NB <= nblk - 2) ++forks;
     s->ldl_forks = forks;              // (enqueue_ldl_finish joins the second stream)
     // A single handle outside a stream capture: the six inertia counts go to their mapped host words right behind the chain (+ the sequence number the host
     // spins on, api.hip: wait_published) — the host learns the inertia when the pivot chain ends, not after the finish + a copy + a stream synchronisation
@@ -818,9 +824,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
     const unsigned nz = bt.n;
     const int band = s->band64 > 0 ? s->band64 : nblk;
     {
-        static const int pairs_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_PAIRS"); return e ? atoi(e) : -1; }();
-        const bool pairs = s->band64 == 0 && (pairs_env >= 0 ? pairs_env != 0 : nz >= 4);
-        if (!pairs && ldl_overlap(s) && s->stream2) {
+        if (ldl_overlap(s) && s->stream2) {
             // the blocks whose last panel a panel step applied were finished beside the chain (launch_ldl); what is left is the last block(s).
             // Join first: the solves need every block (the second stream is long done by now).  (The last block's finish on the second stream too, joined
             // after the inertia read-back, was measured: 0.901 against 0.889 ms — the hand-over between the queues costs more than the overlap gives.)
