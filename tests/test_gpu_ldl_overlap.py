@@ -1,0 +1,50 @@
+"""GPU: the schedule of the LDL^T of one instance does not change its bits.  By default the finish of the factorisation (factor columns + merges of the
+inverse blocks) of the completed solve blocks runs on a second stream while the pivot chain goes on, fed by the host from a progress word, and the
+inertia counts are published right behind the chain (csrc/ldl.hip: launch_ldl); CALIPSO_HIP_LDL_OVERLAP=0 / CALIPSO_HIP_LDL_PUBLISH=0 /
+CALIPSO_HIP_GRAPH_LDL=1 select the one-stream schedules.  The switches are read once per process, so every variant runs in a process of its own;
+the Newton steps they take must agree bit for bit (same kernels, same operands, only the order in time of independent launches differs)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import hashlib, sys, os
+import numpy as np
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "tests")]
+from helpers import load_pkg
+from test_gpu_group import build
+pkg = load_pkg()
+out = []
+for shape, pid in (((1500, 300, 60, 30, 3), 41), ((2100, 200, 40, 20, 3), 42)):      # NP = 1536 (1024 + 512) and 2112 (two of 1024 + 64): ranges, tails, a narrow last block
+    s = build(pkg, pid, shape)
+    for it in range(2):
+        info = s.newton_step(advance=True)
+        assert info["status"] >= 0, info
+        out.append(hashlib.sha256(np.ascontiguousarray(s.data("step").all).tobytes()).hexdigest())
+        out.append(hashlib.sha256(np.ascontiguousarray(s.solution.all).tobytes()).hexdigest())
+        out.append(repr(sorted((k, v) for k, v in info.items() if k in ("status", "refinement_rounds", "factorizations", "step_size"))))
+print("DIGEST " + hashlib.sha256("\n".join(out).encode()).hexdigest())
+'''
+
+
+def run_variant(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("DIGEST ")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return lines[0]
+
+
+def test_newton_steps_do_not_depend_on_the_schedule_of_the_factorisation():
+    ref = run_variant({})
+    for env in ({"CALIPSO_HIP_LDL_OVERLAP": "0"}, {"CALIPSO_HIP_LDL_PUBLISH": "0"}, {"CALIPSO_HIP_GRAPH_LDL": "1"}, {"CALIPSO_HIP_LDL_FEED": "64"}):
+        assert run_variant(env) == ref, env
