@@ -26,6 +26,8 @@ import bench   # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 prob, pt, lam, w, s = bench.make_instance(pkg, pr, 0, bench.CONFIGS[name], 0)
+if os.environ.get("LDL_TRACE_SOLVE_BLOCK"):
+    s.set_option("solve_block", int(os.environ["LDL_TRACE_SOLVE_BLOCK"]))
 for _ in range(4):
     s.newton_step(advance=False)
 s.synchronize()

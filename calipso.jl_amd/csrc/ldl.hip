@@ -660,7 +660,7 @@ __global__ __launch_bounds__(1024) void k_tinv_merge(Batch bt, int NP, int tb, i
 // is load -> barrier -> MFMA -> barrier, no double buffering).  Same k order per output entry as the 64 x 64 version (the skipped k ranges are exact zeros).
 __global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, int half, int phase, int pair0, const double* __restrict__ S, double* __restrict__ Tinv,
                                                        double* __restrict__ Ttmp) {
-    constexpr int KC = 32, ldk = KC + 2;
+    constexpr int KC = 64, ldk = KC + 2;
     __shared__ double As[32 * ldk];       // As[i][k]
     __shared__ double Bs[32 * ldk];       // Bs[j][k]
     inst_shift(bt, S, Tinv, Ttmp);
@@ -688,25 +688,43 @@ __global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, 
     const int wi = wave >> 1, wj = wave & 1;
     const int fr = lane & 15, fk = lane >> 4;
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    for (int kc = kbeg; kc < kend; kc += KC) {
-        double av[4], bv[4];
+    // K in chunks of 64 (a last chunk of 32: kbeg, kend are multiples of 32); the operands of chunk c + 1 travel from global memory to registers while the
+    // matrix cores work on chunk c (round 3: KC = 32 without the prefetch left every stage one exposed memory round trip — a 1024-deep tile took ≈ 50 us)
+    double av[8], bv[8];
+    auto fetch = [&](int kc) {
+        const int kn = kend - kc < KC ? kend - kc : KC;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            av[it] = A[(tid & 31) + (size_t)(kc + (tid >> 5) + 8 * it) * lda];          // lanes along i
-            bv[it] = B[(kc + (tid & 31)) + (size_t)((tid >> 5) + 8 * it) * ldb];        // lanes along k
+        for (int it = 0; it < 8; ++it) {
+            const int ka = (tid >> 5) + 8 * it;                                           // A: lanes along i (32 rows), 8 k per pass
+            av[it] = ka < kn ? A[(tid & 31) + (size_t)(kc + ka) * lda] : 0.0;
+            const int kb = tid & 63, cb = (tid >> 6) + 4 * it;                            // B: lanes along k (64 consecutive), 4 columns per pass
+            bv[it] = kb < kn ? B[(kc + kb) + (size_t)cb * ldb] : 0.0;
         }
+    };
+    fetch(kbeg);
+    for (int kc = kbeg; kc < kend; kc += KC) {
+        const int kn = kend - kc < KC ? kend - kc : KC;
         __syncthreads();                                                                 // the previous chunk's fragments are read
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 8; ++it) {
             As[(tid & 31) * ldk + (tid >> 5) + 8 * it] = av[it];
-            Bs[((tid >> 5) + 8 * it) * ldk + (tid & 31)] = bv[it];
+            Bs[((tid >> 6) + 4 * it) * ldk + (tid & 63)] = bv[it];
         }
         __syncthreads();
+        if (kc + KC < kend) fetch(kc + KC);
 #pragma unroll
-        for (int kk = 0; kk < KC / 4; ++kk) {
+        for (int kk = 0; kk < 8; ++kk) {
             const double a = As[(wi * 16 + fr) * ldk + kk * 4 + fk];
             const double b = Bs[(wj * 16 + fr) * ldk + kk * 4 + fk];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);   // transposed: row <-> j, col <-> i
+        }
+        if (kn > 32) {
+#pragma unroll
+            for (int kk = 8; kk < 16; ++kk) {
+                const double a = As[(wi * 16 + fr) * ldk + kk * 4 + fk];
+                const double b = Bs[(wj * 16 + fr) * ldk + kk * 4 + fk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -727,6 +745,8 @@ __global__ void k_publish_inertia(const int* __restrict__ icount, int* __restric
 static bool side_stream(calipso_hip_solver* s) {
     if (s->stream2) return s->hprog_dev != nullptr && s->ev_side[7] != nullptr;
     {
+        // (lowest priority.  A CU mask — hipExtStreamCreateWithCUMask, half / three quarters / 15 of 16 of the compute units — is accepted and changes
+        // nothing, neither the duration of the second stream's kernels nor the panel steps that wait behind them: see DESIGN 5.0)
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
         if (hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, least) != hipSuccess) { s->stream2 = nullptr; return false; }
