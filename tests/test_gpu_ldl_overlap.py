@@ -24,6 +24,8 @@ pkg = load_pkg()
 out = []
 for shape, pid in (((1500, 300, 60, 30, 3), 41), ((2100, 200, 40, 20, 3), 42)):      # NP = 1536 (1024 + 512) and 2112 (two of 1024 + 64): ranges, tails, a narrow last block
     s = build(pkg, pid, shape)
+    if os.environ.get("CHILD_SOLVE_BLOCK"):
+        s.set_option("solve_block", int(os.environ["CHILD_SOLVE_BLOCK"]))
     for it in range(2):
         info = s.newton_step(advance=True)
         assert info["status"] >= 0, info
@@ -48,3 +50,13 @@ def test_newton_steps_do_not_depend_on_the_schedule_of_the_factorisation():
     ref = run_variant({})
     for env in ({"CALIPSO_HIP_LDL_OVERLAP": "0"}, {"CALIPSO_HIP_LDL_PUBLISH": "0"}, {"CALIPSO_HIP_GRAPH_LDL": "1"}, {"CALIPSO_HIP_LDL_FEED": "64"}):
         assert run_variant(env) == ref, env
+
+
+@pytest.mark.parametrize("solve_block", [2048, 512])
+def test_schedule_independence_holds_for_other_solve_block_widths(solve_block):
+    """opt.solve_block = 2048: a solve block of two 1024-wide halves whose joining merge is split over two hand-overs (first phase with the left half,
+    second with the right one); 512: more, narrower blocks.  NP = 2112 is 2048 + 64 / 4 x 512 + 64: the last block is a single panel."""
+    sb = {"CHILD_SOLVE_BLOCK": str(solve_block)}
+    ref = run_variant(dict(sb, CALIPSO_HIP_LDL_OVERLAP="0"))
+    for env in ({}, {"CALIPSO_HIP_LDL_FEED": "64"}, {"CALIPSO_HIP_LDL_FEED": "1024"}):
+        assert run_variant(dict(sb, **env)) == ref, (solve_block, env)
