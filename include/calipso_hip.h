@@ -16,7 +16,9 @@
  * Conventions
  *   - plain C: pointers + sizes, no C++/torch types; every function returns an int32 status.
  *   - all floating point is IEEE fp64; all indices are Int64 and 1-BASED (Julia's), matrices column-major.
- *   - the caller owns every host buffer; the opaque handle owns device memory, one HIP stream and its events.
+ *   - the caller owns every host buffer; the opaque handle owns device memory, one HIP stream and its events (and, created on first use, a second
+ *     stream that only ever carries the finish of a factorisation beside its pivot chain and is joined into the first before the call that
+ *     queued it returns: everything a caller orders or synchronises against is the first stream).
  *   - one handle = one problem shape (nx, np, ne, nc + cone layout); a handle is used by one host thread at a time;
  *     distinct handles are independent (as distinct `Solver`s are in the reference).
  *   - host arrays are named by the reference's own field names ("equality_jacobian_variables", "solution", ...).
