@@ -164,14 +164,48 @@ __global__ void k_scale_rows(Batch bt, Dims d, ConeDev cd, const double* __restr
         const int k = d.ne + c;
         col0 = max(col0, zrow[2 * k]); col1 = min(col1, zrow[2 * k + 1]);
     }
+    // the columns of a nonnegative row are independent loads: all SCALE_COLS of them are in flight at once (the loop written with its bounds as a predicate so
+    // that it unrolls; one column at a time left this kernel at 2 TB/s)
+    const int cbase = blockIdx.y * SCALE_COLS;
+    if (c < d.q) {
+        double hv[SCALE_COLS];
+#pragma unroll
+        for (int k = 0; k < SCALE_COLS; ++k) { const int col = cbase + k; hv[k] = (col >= col0 && col < col1) ? hx[c + (size_t)col * d.m] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < SCALE_COLS; ++k) { const int col = cbase + k; if (col >= col0 && col < col1) WH[c + (size_t)col * d.nc] = w0 * hv[k]; }
+        return;
+    }
+    if (dim <= 4) {
+        // small cones: the row of W once, then eight columns at a time with their (up to) four entries of hx in flight together; the sum in the order b = 0, 1, ...
+        double wr[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) wr[b] = b < dim ? W[(c - st) + b * dim] : 0.0;
+        for (int k0 = 0; k0 < SCALE_COLS; k0 += 8) {
+            double hv[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int col = cbase + k0 + k;
+                const bool in = col >= col0 && col < col1;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) hv[k][b] = (in && b < dim) ? hx[st + b + (size_t)col * d.m] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int col = cbase + k0 + k;
+                if (col >= col0 && col < col1) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) if (b < dim) v += wr[b] * hv[k][b];
+                    WH[c + (size_t)col * d.nc] = v;
+                }
+            }
+        }
+        return;
+    }
     for (int col = col0; col < col1; ++col) {
         const double* h = hx + (size_t)col * d.m;     // hx is the lower part of the stacked Jacobian (ld = m)
-        double v;
-        if (c < d.q) v = w0 * h[c];
-        else {
-            v = 0.0;
-            for (int b = 0; b < dim; ++b) v += W[(c - st) + b * dim] * h[st + b];
-        }
+        double v = 0.0;
+        for (int b = 0; b < dim; ++b) v += W[(c - st) + b * dim] * h[st + b];
         WH[c + (size_t)col * d.nc] = v;
     }
 }
