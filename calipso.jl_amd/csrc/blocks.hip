@@ -70,7 +70,14 @@ __global__ __launch_bounds__(256) void k_bgemv_n(Batch bt, const ZBlock* __restr
         double acc = 0.0;
         if (i < b.nrows) {
             const double* a = pk + b.off_c + i;
-            for (int j = p; j < b.ncols; j += 4) acc += a[(size_t)j * b.nrows] * x[b.col0 + j];
+            // eight of this lane's columns in flight together (the blocks are small: the kernel is a chain of memory round trips, not a stream); same order of the sum
+            for (int j0 = p; j0 < b.ncols; j0 += 32) {
+                double av[8], xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = j0 + 4 * u; const bool in = j < b.ncols; av[u] = in ? a[(size_t)j * b.nrows] : 0.0; xv[u] = in ? x[b.col0 + j] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (j0 + 4 * u < b.ncols) acc += av[u] * xv[u];
+            }
         }
         part[p][lane] = acc;
         __syncthreads();
@@ -96,10 +103,15 @@ __global__ __launch_bounds__(256) void k_bgemv_t(Batch bt, const Segment* __rest
             const double* a = pk + b.off_r + (sg.c0 - b.col0) + lane;
             const double* v1 = u1 + (b.row0 - rlo);
             const double* v2 = NV == 2 ? u2 + (b.row0 - rlo) : nullptr;
-            for (int i = p; i < b.nrows; i += 4) {
-                const double e = a[(size_t)i * b.ncols];
-                a1 += e * v1[i];
-                if (NV == 2) a2 += e * v2[i];
+            for (int i0 = p; i0 < b.nrows; i0 += 32) {          // eight rows in flight together, same order of the sums
+                double ev[8], w1[8], w2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 4 * u; const bool in = i < b.nrows;
+                    ev[u] = in ? a[(size_t)i * b.ncols] : 0.0; w1[u] = in ? v1[i] : 0.0; w2[u] = (NV == 2 && in) ? v2[i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (i0 + 4 * u < b.nrows) { a1 += ev[u] * w1[u]; if (NV == 2) a2 += ev[u] * w2[u]; }
             }
         }
     }
@@ -125,7 +137,13 @@ __global__ __launch_bounds__(256) void k_bgemv_l(Batch bt, const LBlock* __restr
     double acc = 0.0;
     if (i < b.n) {
         const double* a = pk + (trans ? b.off_r : b.off_c) + i;        // row-major copy read "down the rows" = the transpose
-        for (int j = p; j < b.n; j += 4) acc += a[(size_t)j * b.n] * x[b.c0 + j];
+        for (int j0 = p; j0 < b.n; j0 += 32) {                  // eight columns in flight together, same order of the sum
+            double av[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + 4 * u; const bool in = j < b.n; av[u] = in ? a[(size_t)j * b.n] : 0.0; xv[u] = in ? x[b.c0 + j] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j0 + 4 * u < b.n) acc += av[u] * xv[u];
+        }
     }
     part[p][lane] = acc;
     __syncthreads();
