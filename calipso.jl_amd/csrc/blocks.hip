@@ -189,20 +189,32 @@ __global__ __launch_bounds__(256) void k_schur_blocks(BatchSc bt, Dims d, ConeDe
             }
             const int kn = k1 - k0;
             __syncthreads();
-            for (int idx = tid; idx < 64 * SB_KC; idx += 256) {
-                const int k = idx % SB_KC, i = idx / SB_KC;
-                double va = 0.0, vb = 0.0, vr = 0.0;
-                if (k < kn) {
-                    const int row = b.row0 + k0 + k;                     // row of the stacked Jacobian
-                    if (i < sa.nc) va = pk[b.off_c + (size_t)(oa + i) * b.nrows + k0 + k];
-                    if (i < sb.nc) {
-                        const double raw = pk[b.off_c + (size_t)(ob + i) * b.nrows + k0 + k];
-                        if (row < d.ne) vb = omega_y * raw;
-                        else if (row < d.ne + d.q) vb = wz[row - d.ne] * raw;
-                        else vr = raw;                                    // a second-order cone row: W is applied below
-                    }
+            {
+                // every load of the chunk in flight before the first use (64 * SB_KC / 256 entries of each operand per thread): the blocks are small and the
+                // kernel is a chain of memory round trips — one entry at a time made it eight times as long as it has to be
+                constexpr int NIT = 64 * SB_KC / 256;
+                double va[NIT], rw[NIT], wv[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int idx = tid + 256 * it, k = idx % SB_KC, i = idx / SB_KC;
+                    const bool inb = k < kn;
+                    const int row = b.row0 + k0 + k;
+                    va[it] = (inb && i < sa.nc) ? pk[b.off_c + (size_t)(oa + i) * b.nrows + k0 + k] : 0.0;
+                    rw[it] = (inb && i < sb.nc) ? pk[b.off_c + (size_t)(ob + i) * b.nrows + k0 + k] : 0.0;
+                    wv[it] = (inb && i < sb.nc && row >= d.ne && row < d.ne + d.q) ? wz[row - d.ne] : 0.0;
                 }
-                As[i * SB_LD + k] = va; Bs[i * SB_LD + k] = vb; Rs[i * SB_LD + k] = vr;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int idx = tid + 256 * it, k = idx % SB_KC, i = idx / SB_KC;
+                    double vb = 0.0, vr = 0.0;
+                    if (k < kn && i < sb.nc) {
+                        const int row = b.row0 + k0 + k;                 // row of the stacked Jacobian
+                        if (row < d.ne) vb = omega_y * rw[it];
+                        else if (row < d.ne + d.q) vb = wv[it] * rw[it];
+                        else vr = rw[it];                                 // a second-order cone row: W is applied below
+                    }
+                    As[i * SB_LD + k] = va[it]; Bs[i * SB_LD + k] = vb; Rs[i * SB_LD + k] = vr;
+                }
             }
             __syncthreads();
             if (b.row0 + k1 > d.ne + d.q) {                              // (Omega_z B)[k][j] = sum_k' W[k][k'] B[k'][j] inside every cone of the chunk
