@@ -12,7 +12,13 @@ __global__ __launch_bounds__(1024) void k_qp_objective(Batch bt, int nx, const d
     __shared__ double sm[16];
     inst_shift(bt, x, Lx, q, dscal);
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nx; i += 1024) { a += x[i] * Lx[i]; b += q[i] * x[i]; }
+    for (int i0 = threadIdx.x; i0 < nx; i0 += 4 * 1024) {           // four entries of a thread in flight together, same order of its sums
+        double xv[4], lv[4], qv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * 1024; const bool in = i < nx; xv[u] = in ? x[i] : 0.0; lv[u] = in ? Lx[i] : 0.0; qv[u] = in ? q[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u * 1024 < nx) { a += xv[u] * lv[u]; b += qv[u] * xv[u]; }
+    }
     const double ra = block_sum(a, sm);
     const double rb = block_sum(b, sm);
     if (threadIdx.x == 0) dscal[0] = 0.5 * ra + rb;

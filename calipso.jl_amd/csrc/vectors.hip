@@ -70,17 +70,40 @@ __device__ __forceinline__ void violations_body(const Dims& d, int ptype, const 
                                                 const double* __restrict__ g, const double* __restrict__ prod, double* __restrict__ dscal) {
     const int tid = threadIdx.x;
     double rp = 0.0, rprim = 0.0, ry = 0.0, rz = 0.0, rt = 0.0, y1 = 0.0, z1 = 0.0, t1 = 0.0, ginf = 0.0, pinf = 0.0;
-    for (int i = tid; i < d.N; i += RT) {
-        const double v = res[i];
-        if (ptype == 0) rp = fmax(rp, fabs(v)); else rp += pnorm_term(v, ptype);
-        const double a = fabs(v);
-        if (i < d.n) rprim = fmax(rprim, a);
-        else if (i < d.oz()) ry = fmax(ry, a);
-        else if (i < d.ot()) rz = fmax(rz, a);
-        else rt = fmax(rt, a);
+    // one workgroup walks the whole vectors: eight of a thread's entries are fetched before the first is used (the loops were one memory round trip per
+    // entry); the order in which a thread combines its entries is unchanged
+    for (int i0 = tid; i0 < d.N; i0 += 8 * RT) {
+        double vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * RT; vv[u] = i < d.N ? res[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * RT;
+            if (i < d.N) {
+                const double v = vv[u];
+                if (ptype == 0) rp = fmax(rp, fabs(v)); else rp += pnorm_term(v, ptype);
+                const double a = fabs(v);
+                if (i < d.n) rprim = fmax(rprim, a);
+                else if (i < d.oz()) ry = fmax(ry, a);
+                else if (i < d.ot()) rz = fmax(rz, a);
+                else rt = fmax(rt, a);
+            }
+        }
     }
-    for (int i = tid; i < d.ne; i += RT) { y1 += fabs(w[d.oy() + i]); ginf = fmax(ginf, fabs(g[i])); }
-    for (int i = tid; i < d.nc; i += RT) { z1 += fabs(w[d.oz() + i]); t1 += fabs(w[d.ot() + i]); pinf = fmax(pinf, fabs(prod[i])); }
+    for (int i0 = tid; i0 < d.ne; i0 += 4 * RT) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * RT; const bool in = i < d.ne; a[u] = in ? w[d.oy() + i] : 0.0; b[u] = in ? g[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u * RT < d.ne) { y1 += fabs(a[u]); ginf = fmax(ginf, fabs(b[u])); }
+    }
+    for (int i0 = tid; i0 < d.nc; i0 += 4 * RT) {
+        double a[4], b[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * RT; const bool in = i < d.nc; a[u] = in ? w[d.oz() + i] : 0.0; b[u] = in ? w[d.ot() + i] : 0.0; c[u] = in ? prod[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u * RT < d.nc) { z1 += fabs(a[u]); t1 += fabs(b[u]); pinf = fmax(pinf, fabs(c[u])); }
+    }
     // the ten reductions share ONE barrier round: every wavefront reduces its ten values by shuffles, lane 0 parks them in LDS, and after the barrier
     // thread q combines the per-wave values of quantity q in wave order — the operations and their order are those of ten block_sum / block_max calls
     __shared__ double red[10][RT / 64];
@@ -457,9 +480,19 @@ __device__ __forceinline__ void constraint_violation_body(const Dims& d, int pty
                                                           const double* __restrict__ hc, double* __restrict__ dscal) {
     __shared__ double sm[RT / 64];
     double acc = 0.0;
-    for (int i = threadIdx.x; i < d.ne + d.nc; i += RT) {
-        const double c = (i < d.ne) ? g[i] - point[d.orr() + i] : hc[i - d.ne] - point[d.os() + i - d.ne];
-        if (ptype == 0) acc = fmax(acc, fabs(c)); else acc += pnorm_term(c, ptype);
+    for (int i0 = threadIdx.x; i0 < d.ne + d.nc; i0 += 4 * RT) {      // four entries of a thread in flight together, combined in the same order
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * RT; const bool in = i < d.ne + d.nc;
+            a[u] = !in ? 0.0 : (i < d.ne ? g[i] : hc[i - d.ne]);
+            b[u] = !in ? 0.0 : (i < d.ne ? point[d.orr() + i] : point[d.os() + i - d.ne]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u * RT < d.ne + d.nc) {
+            const double c = a[u] - b[u];
+            if (ptype == 0) acc = fmax(acc, fabs(c)); else acc += pnorm_term(c, ptype);
+        }
     }
     double r = (ptype == 0) ? block_max(acc, sm) : block_sum(acc, sm);
     if (threadIdx.x == 0) {
@@ -504,7 +537,13 @@ void launch_violations_and_constraint(calipso_hip_solver* s, int pub_first, int 
 // d = dot(merit_gradient, step.primals)   line_search.jl:3,16 -> dscal[6]   (one workgroup of RT threads per instance)
 __device__ __forceinline__ void dot_body(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, double* sm) {
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += RT) acc += a[i] * b[i];
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * RT) {             // four entries of a thread in flight together, same order of its sum
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * RT; av[u] = i < n ? a[i] : 0.0; bv[u] = i < n ? b[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u * RT < n) acc += av[u] * bv[u];
+    }
     const double r = block_sum(acc, sm);
     if (threadIdx.x == 0) *out = r;
 }
