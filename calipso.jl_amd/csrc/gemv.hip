@@ -208,8 +208,15 @@ __global__ __launch_bounds__(256) void k_gemv_n_reduce(Batch bt, int rows, int n
     const int i = blockIdx.x * 64 + r;
     double acc = 0.0;
     if (i < rows) {
-#pragma unroll 4
-        for (int c = p; c < nchunk; c += 4) acc += partial[(size_t)c * rows + i];
+        // all of this thread's partials (at most GN_MAXCHUNK / 4 = 16) in flight together, summed in the same order
+        static_assert(GN_MAXCHUNK <= 64, "16 partials per thread");
+        for (int c0 = p; c0 < nchunk; c0 += 64) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int c = c0 + 4 * u; v[u] = c < nchunk ? partial[(size_t)c * rows + i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (c0 + 4 * u < nchunk) acc += v[u];
+        }
     }
     part[p][r] = acc;
     __syncthreads();

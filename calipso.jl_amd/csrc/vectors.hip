@@ -826,15 +826,25 @@ __global__ __launch_bounds__(RT) void k_refine_x(BatchSc bt, Dims d, int have_m,
     const Scalars sc = bt.sc[blockIdx.z];
     double m = 0.0;
     for (int i = threadIdx.x; i < nparts; i += RT) m = fmax(m, part[i]);     // the other rows' part of the norm (k_refine_local)
-    for (int i = threadIdx.x; i < d.NP; i += RT) {
-        if (i < d.nx) {
-            const double hv = (lxv[i] + (have_m ? w1[i] : 0.0)) + sc.ep * v[i];
-            const double r = res[i] - hv;
-            e[i] = r;
-            rsym[i] = r;
-            xbuf[i] = have_m ? r + w2[i] : r;
-            m = fmax(m, fabs(r));
-        } else xbuf[i] = 0.0;
+    for (int i0 = threadIdx.x; i0 < d.NP; i0 += 4 * RT) {          // four of a thread's rows in flight together, combined in the same order
+        double lv[4], a1[4], a2[4], vv[4], rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * RT; const bool in = i < d.nx;
+            lv[u] = in ? lxv[i] : 0.0; a1[u] = (in && have_m) ? w1[i] : 0.0; a2[u] = (in && have_m) ? w2[i] : 0.0; vv[u] = in ? v[i] : 0.0; rv[u] = in ? res[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * RT;
+            if (i < d.nx) {
+                const double hv = (lv[u] + (have_m ? a1[u] : 0.0)) + sc.ep * vv[u];
+                const double r = rv[u] - hv;
+                e[i] = r;
+                rsym[i] = r;
+                xbuf[i] = have_m ? r + a2[u] : r;
+                m = fmax(m, fabs(r));
+            } else if (i < d.NP) xbuf[i] = 0.0;
+        }
     }
     const double mr = block_max(m, sm);
     if (threadIdx.x == 0) {
