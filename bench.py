@@ -460,12 +460,16 @@ def main():
     # is assembled for the triangular solves.  ONE system wants 1024 (10 instead of 18 dependent launches per solve); a GROUP wants 512 (its solves are
     # bandwidth-bound and the extra assembly level costs it 0.5 ms per step).  Set on every member: the first member's setting governs a group's launches, and a
     # member stepped alone with the same setting gets the same bits.
-    def solve_block(handles, value):
+    def solve_block(handles, value, wform=None):
         if staged is None:
             for h in handles:
                 h.set_option("solve_block", value)
+                if wform is not None:
+                    h.set_option("solve_wform", wform)
     # ---- warm-up: W steps of the single system (captures its launch graphs) ---------------------------------------------------
-    solve_block([wl.single], int(os.environ.get("CALIPSO_BENCH_SOLVE_BLOCK", "1024")))
+    # "opt.solve_wform": the solves through the stacked [Tinv_b; W_b] blocks (two dependent launches per solve block instead of four): on for ONE system, off
+    # for the members of a group (bandwidth-bound solves; the products would only cost them)
+    solve_block([wl.single], int(os.environ.get("CALIPSO_BENCH_SOLVE_BLOCK", "1024")), int(os.environ.get("CALIPSO_BENCH_SOLVE_WFORM", "1")))
     for _ in range(args.warmup):
         if not args.no_single:
             wl.single.newton_step(advance=False)
@@ -480,7 +484,7 @@ def main():
     # ---- warm-up of the batched pass; unit 0 alone (one group of G instances): its launches have the device to themselves => clean per-launch figures --
     alone, alone_chain, unit_rate = [], [], None
     if wl.batch is not None:
-        solve_block(wl.solvers if G > 1 else [], int(os.environ.get("CALIPSO_BENCH_GROUP_SOLVE_BLOCK", "512")))
+        solve_block(wl.solvers if G > 1 else [], int(os.environ.get("CALIPSO_BENCH_GROUP_SOLVE_BLOCK", "512")), int(os.environ.get("CALIPSO_BENCH_GROUP_SOLVE_WFORM", "0")))
         for _ in range(args.warmup):
             wl.batched_pass()
         barrier(wl)
@@ -639,6 +643,7 @@ def main():
             if w4.staged is None and w4.G > 1:
                 for h4 in w4.solvers:
                     h4.set_option("solve_block", 512)
+                    h4.set_option("solve_wform", 0)
             for _ in range(max(1, min(args.warmup, 2))):
                 w4.batched_pass()
             P4 = max(1, min(P, 10))

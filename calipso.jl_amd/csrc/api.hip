@@ -165,6 +165,7 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->residual_symmetric, n); SL(&s->step_symmetric, n); SL(&s->merit_gradient, n);
     SL(&s->S, cp ? plan.spacked : NPd * NPd); SL(&s->Dx, NPd); SL(&s->Ypanel, cp ? 1 : NPd * NB);                     // structured: S = the tiles of the segment pairs, contiguous
     SL(&s->Tinv, cp ? 1 : calipso::tinv_doubles(d.NP)); SL(&s->Ttmp, cp ? 1 : NPd * 1024); SL(&s->zf2, NPd); SL(&s->WH, cp ? 1 : NC * NX);
+    SL(&s->Wfac, (cp || !calipso::wform_layout_ok(d.NP, calipso::trsv_block(d.NP, 512))) ? 1 : NPd * NPd / 2);     // W-form blocks of the solves: < NP^2 / 2 doubles for every solve-block width
     SL(&s->wz, NC); SL(&s->kzz, NC);
     SL(&s->Wsoc, (size_t)woff); SL(&s->Bsoc, (size_t)woff); SL(&s->socwork, (size_t)2 * woff);
     SL(&icount_d, 32);                                        // 64 ints
@@ -361,7 +362,7 @@ static bool find_field(H* s, const std::string& name, Field& f) {
     IO ios[] = {{"opt.max_outer_iterations", &o.max_outer_iterations}, {"opt.max_residual_iterations", &o.max_residual_iterations},
                 {"opt.max_residual_line_search", &o.max_residual_line_search}, {"opt.max_cone_line_search", &o.max_cone_line_search},
                 {"opt.iterative_refinement", &o.iterative_refinement}, {"opt.max_iterative_refinement", &o.max_iterative_refinement},
-                {"opt.min_iterative_refinement", &o.min_iterative_refinement}, {"opt.solve_block", &s->solve_block}};
+                {"opt.min_iterative_refinement", &o.min_iterative_refinement}, {"opt.solve_block", &s->solve_block}, {"opt.solve_wform", &s->solve_wform}};
     for (auto& io : ios)
         if (name == io.n) { f.host = (double*)io.p; f.len = -1; return true; }   // len -1 marks an int64 slot
     return false;
@@ -385,6 +386,10 @@ int32_t calipso_hip_set_field(H* s, const char* name, const double* data, int64_
                 calipso::ldl_drop_graphs(s);
                 if (!s->compact) { CK(hipMemsetAsync(s->Tinv, 0, sizeof(double) * calipso::tinv_doubles(s->d.NP), s->stream)); CK(hipStreamSynchronize(s->stream)); }
             }
+        }
+        if (nm == "opt.solve_wform") {            // not an option of the reference either: the stacked [Tinv; W] form of the solves (ldl.hip)
+            if (v != 0 && v != 1) return fail_arg(s, "opt.solve_wform must be 0 or 1");
+            if (v != s->solve_wform) { CK(hipSetDevice(s->device)); CK(hipStreamSynchronize(s->stream)); calipso::ldl_drop_graphs(s); }
         }
         *(calipso::i64*)f.host = v;
         return CALIPSO_OK;
@@ -521,7 +526,7 @@ static void factor_times(H* s) {
     (void)hipEventElapsedTime(&ms, s->ev[10], s->ev[11]); s->phase_ms[1] = ms;   // cone pivots + Omega*hx
     (void)hipEventElapsedTime(&ms, s->ev[11], s->ev[12]); s->phase_ms[7] = ms;   // Schur complement (MFMA kernel), one launch
     (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[13]); s->phase_ms[3] = ms;   // LDL^T of S
-    (void)hipEventElapsedTime(&ms, s->ev[12], s->ev[14]); s->kernel_ms[0] = ms;   // of which the panel steps (the pivot chain)
+    s->kernel_ms[0] = hipEventElapsedTime(&ms, s->ev[12], s->ev[14]) == hipSuccess ? ms : 0.0;   // of which the panel steps (the pivot chain)
 }
 
 static int do_factorize(H* s, int64_t inertia[3]) {
@@ -535,6 +540,7 @@ static int do_factorize(H* s, int64_t inertia[3]) {
     launch_ldl(s);
     (void)hipEventRecord(s->ev[13], s->stream);
     s->factor_times_pending = true;
+    if (s->ldl_failed) { s->ldl_failed = false; SYNC(); return CALIPSO_ERR_HIP; }       // (s->err says why: launch_ldl / a dense mat-vec on a structured handle)
     if (s->ldl_pub_seq) {
         // the last diagonal block published the counts when the pivot chain ended: the host goes on queueing behind the finish of the last solve block
         if (wait_published(s, s->ldl_pub_seq)) return CALIPSO_ERR_HIP;
@@ -1148,7 +1154,7 @@ int32_t calipso_hip_kernel_times(H* s, double out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = 0.0;
     factor_times(s);
     out[0] = s->kernel_ms[0];
-    out[1] = (double)(s->d.NP / calipso::NB);
+    out[1] = (double)s->ldl_step_launches;              // k_ldl_diag + the k_ldl_step launches the last blocked factorisation queued
     out[2] = (double)s->d.NP;
     out[3] = (double)(s->slab_doubles * sizeof(double));
     return CALIPSO_OK;

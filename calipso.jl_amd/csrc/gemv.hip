@@ -139,7 +139,7 @@ static Sparsity sparsity_of(const calipso_hip_solver* s, int kind) {
 void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind) {
     if (cols == 0) return;
     if (blocks_gemv_t(s, kind, x, nullptr, y, nullptr, alpha, beta)) return;       // stage blocks (blocks.hip)
-    if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; return; }
+    if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; s->ldl_failed = true; return; }   // (sticky: the driver reports CALIPSO_ERR_HIP)
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, A, ld, x, y, alpha, beta);
 }
@@ -147,7 +147,7 @@ void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, 
 void gemv_t2(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x1, const double* x2, double* y1, double* y2, int kind) {
     if (cols == 0) return;
     if (blocks_gemv_t(s, kind, x1, x2, y1, y2, 1.0, 0.0)) return;
-    if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; return; }
+    if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; s->ldl_failed = true; return; }   // (sticky: the driver reports CALIPSO_ERR_HIP)
     const BatchSc B = batch_of(s);
     hipLaunchKernelGGL(k_gemv_t2, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, A, ld, x1, x2, y1, y2);
 }
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_gemv_both(Batch bt, Sparsity sp, int ro
 // yt = A'u + beta_t*yt and yn = A x in one pass over A
 void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t, int kind) {
     if (rows == 0 || cols == 0) return;
-    if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; return; }
+    if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; s->ldl_failed = true; return; }   // (sticky: the driver reports CALIPSO_ERR_HIP)
     const BatchSc B = batch_of(s);
     const int cw = BOTH_CW;   // (8 is 1 % faster for a single cache-resident instance, 16 for groups streaming from HBM)
     const int ncg = (cols + cw - 1) / cw, nrr = (rows + 64 * BOTH_RQ - 1) / (64 * BOTH_RQ);
@@ -317,7 +317,7 @@ void gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2,
 void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind) {
     if (rows == 0) return;
     if (blocks_gemv_n(s, kind, x, y, alpha, beta)) return;
-    if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; return; }
+    if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; s->ldl_failed = true; return; }   // (sticky: the driver reports CALIPSO_ERR_HIP)
     int rb, nchunk, chunk;
     gemv_n_chunks(rows, cols, rb, nchunk, chunk);
     const BatchSc B = batch_of(s);

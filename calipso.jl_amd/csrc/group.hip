@@ -124,6 +124,8 @@ static int g_effective_blocks(G* g) {
     if (any && !all) { s->err = "the members of a group must agree on calipso_hip_set_stage_blocks (all on with one block structure, or all off)"; return CALIPSO_ERR_ARGUMENT; }
     for (H* h : g->hs)     // the inverse blocks of the solves are laid out per member for ITS "opt.solve_block"; the group's launches use the base handle's
         if (h->solve_block != s->solve_block) { s->err = "the members of a group must agree on opt.solve_block"; return CALIPSO_ERR_ARGUMENT; }
+    for (H* h : g->hs)
+        if (h->solve_wform != s->solve_wform) { s->err = "the members of a group must agree on opt.solve_wform"; return CALIPSO_ERR_ARGUMENT; }
     s->blocks_effective = true;
     return CALIPSO_OK;
 }

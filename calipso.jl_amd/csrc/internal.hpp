@@ -32,6 +32,16 @@ inline size_t tinv_doubles(int NP) {      // every block is stored with the lead
     for (int limit : {512, 1024, 2048}) { const size_t tb = (size_t)trsv_block(NP, limit); const size_t n = ((size_t)NP + tb - 1) / tb * tb * tb; most = n > most ? n : most; }
     return most;
 }
+// W-form of the triangular solves (ldl.hip): W_b = L[rows below block b, block b] * Tinv_b for every solve block b that has rows below it, stored block after
+// block with leading dimension rb = NP - k0 - w (the rows below).  With it a forward step  u_b = Tinv_b b_b ; b_below -= L[below, b] u_b  is ONE mat-vec with
+// the stacked matrix [Tinv_b; W_b] on b_b, and a backward step  v_b = Tinv_b'(z_b - L[below, b]' v_below) = [Tinv_b; W_b]'[z_b; -v_below]  as well: a solve is
+// 2 nb dependent launches instead of 4 nb - 2.
+inline bool wform_layout_ok(int NP, int tb) { return NP > tb && NP <= 4096; }
+inline size_t wform_offset(int NP, int tb, int kb) {
+    size_t off = 0;
+    for (int b = 0; b < kb; ++b) { const int k0 = b * tb, w = tb < NP - k0 ? tb : NP - k0; off += (size_t)(NP - k0 - w) * (size_t)w; }
+    return off;
+}
 constexpr int CONE_MASK_WORDS = 26;                     // icount[6..31] (slack) and icount[32..57] (slack dual): one bit per trial step size
 constexpr int CONE_MASK_TRIALS = 32 * CONE_MASK_WORDS;  // => max_cone_line_search <= 831
 
@@ -198,6 +208,7 @@ struct calipso_hip_solver {
     double* Tinv = nullptr;     // tinv_doubles(NP): inverses of the unit-lower diagonal blocks of L (up to 1024 x 1024, the last one may be 512 wide)
     double* Ttmp = nullptr;     // NP*1024 scratch of the inverse assembly (NP*512: one 1024 x 1024 product at the top level; as much again so that every merge level has an area of its own, ldl.hip: merge_scratch)
     double* zf2 = nullptr;      // NP
+    double* Wfac = nullptr;     // NP*NP/2: the W-form blocks of the triangular solves (wform_offset)
     double* WH = nullptr;       // nc*nx: Omega_z * hx
     double* wz = nullptr;       // nc: Omega for nonnegative entries (-1/K_zz)
     double* kzz = nullptr;      // nc: K_zz diagonal for nonnegative entries
@@ -243,8 +254,12 @@ struct calipso_hip_solver {
     bool ldl_publish = false;            // launch_ldl: the last diagonal block may publish the inertia counts ...
     unsigned long long ldl_pub_seq = 0;  // ... and did, under this sequence number (0: it did not; read them back)
     bool factor_times_pending = false;   // the events of the last factorisation have not been read yet (api.hip: factor_times)
-    int ldl_forks = 0;                   // ranges of columns the last enqueue_ldl_steps left to the second stream (the first ldl_forks of ldl_ranges) ...
+    bool ldl_overlap_on = false;         // the decision enqueue_ldl_steps took for the factorisation in progress (second stream ready, ranges planned): enqueue_ldl_finish follows it
+    bool ldl_failed = false;             // launch_ldl could not factor (a structured handle whose multifrontal path refused): do_factorize reports it
+    int ldl_step_launches = 0;           // panel-step launches (k_ldl_diag + k_ldl_step) of the last blocked factorisation
+    int ldl_forks = 0;                   // feeds the last enqueue_ldl_steps left to the second stream (the first ldl_forks of ldl_feeds); the ranges of columns they refer to: ...
     std::vector<int> ldl_ranges;         // ... (first column, width) pairs, in order; range f may be finished once panel step (c0 + w) / 64 has STARTED
+    std::vector<int> ldl_feeds;          // (panel step that must have started, kind, argument) triples in hand-over order; kind 0: finish of range `argument`, 1: W-form product of solve block `argument`
     unsigned long long ldl_epoch = 0;    // factorisations so far (tags the progress word)
     unsigned long long *hprog = nullptr, *hprog_dev = nullptr;   // mapped host word: epoch << 16 | index of the last panel step that started
     hipEvent_t ev_side[8] = {};          // [7]: the join (second stream -> main)
@@ -252,6 +267,8 @@ struct calipso_hip_solver {
     bool graph_ldl_tried = false, graph_ldl_fin_tried = false, graph_trsv_tried = false, use_graphs = true;
     calipso::i64 solve_block = 1024;   // "opt.solve_block": widest diagonal block of L whose inverse is assembled (1024: fewest launches per solve, what one system wants; 512: a quarter of the
                                                         // inverse-assembly flops, what a group wants — its solves are bandwidth-bound).  Members of a group use the leader's.
+    calipso::i64 solve_wform = 1;      // "opt.solve_wform": the triangular solves through the stacked [Tinv_b; W_b] blocks (internal.hpp: wform_offset): 2 launches per solve block instead of 4.
+                                       // ONE system wants it (its solves are chains of latency-bound launches); a group, whose solves are bandwidth-bound, does not need the extra products.
     double kernel_ms[4] = {0};   // [0] the panel-step launches (k_ldl_diag + k_ldl_step) of the last factorisation
     double phase_ms[9] = {0};
     // filter (filter.jl:1-13), host side
@@ -333,6 +350,7 @@ bool blocks_entry_offsets(const calipso_hip_solver* s, int which, int row, int c
 void launch_ldl(calipso_hip_solver* s);
 void ldl_drop_graphs(calipso_hip_solver* s);
 void launch_trsv(calipso_hip_solver* s, double* x);            // x (length NP) <- S^-1 x using L, D
+bool wform_on(const calipso_hip_solver* s);                    // the solves of this handle (or of the group launch in progress) go through the W-form blocks
 // solvek.hip
 void launch_copy_pad(calipso_hip_solver* s, const double* src, int n, double* dst, int npad);
 void launch_init_point(calipso_hip_solver* s);                 // initialize_slacks!/duals! (initialize.jl:15-36), r <- g

@@ -28,6 +28,7 @@
 #include "pivot16.hpp"
 
 #include <algorithm>
+#include <array>
 #include <mutex>
 
 namespace calipso {
@@ -658,32 +659,10 @@ __global__ __launch_bounds__(1024) void k_tinv_merge(Batch bt, int NP, int tb, i
 // for 64 cycles per k (13.6 us at K = 512) and the levels have 20 .. 128 such tiles: the launch lasts as long as its longest tile.  Four times as many
 // tiles of a quarter of the work spread over four times as many CUs, and eight 256-thread workgroups per CU hide each other's load latency (the K loop
 // is load -> barrier -> MFMA -> barrier, no double buffering).  Same k order per output entry as the 64 x 64 version (the skipped k ranges are exact zeros).
-__global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, int half, int phase, int pair0, const double* __restrict__ S, double* __restrict__ Tinv,
-                                                       double* __restrict__ Ttmp) {
+// C(32 x 32) = alpha * A(32 x K) * B(K x 32) over k in [kbeg, kend) (multiples of 32), 256 threads; As / Bs: 32 * 66 doubles of LDS each
+__device__ __forceinline__ void merge32_tile(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, double* __restrict__ Cc, int ldc, int kbeg, int kend,
+                                             double alpha, double* __restrict__ As, double* __restrict__ Bs) {
     constexpr int KC = 64, ldk = KC + 2;
-    __shared__ double As[32 * ldk];       // As[i][k]
-    __shared__ double Bs[32 * ldk];       // Bs[j][k]
-    inst_shift(bt, S, Tinv, Ttmp);
-    const int tiles = half / 32;
-    const int pair = pair0 + blockIdx.x / (tiles * tiles);     // pairs pair0 .. of this level (a launch may cover one solve block only)
-    const int tt = blockIdx.x % (tiles * tiles);
-    const int tiy = tt / tiles, tjx = tt % tiles;
-    const int g0 = pair * 2 * half;
-    const int q = g0 / tb, o = g0 % tb;
-    double* T = Tinv + (size_t)q * tb * tb;
-    double* tmp = Ttmp + (size_t)pair * half * half;
-    const double* A; const double* B; double* Cc; int lda, ldb, ldc, kbeg, kend; double alpha;
-    if (phase == 0) {        // tmp(half x half) = L21 * X11
-        A = S + (g0 + half + tiy * 32) + (size_t)g0 * NP; lda = NP;
-        B = T + o + (size_t)(o + tjx * 32) * tb; ldb = tb;
-        Cc = tmp + tiy * 32 + (size_t)(tjx * 32) * half; ldc = half;
-        kbeg = tjx * 32; kend = half; alpha = 1.0;           // X11 is lower triangular: rows k < 32 tjx of its column tile are zero
-    } else {                 // X21 = -X22 * tmp
-        A = T + (o + half + tiy * 32) + (size_t)(o + half) * tb; lda = tb;
-        B = tmp + (size_t)(tjx * 32) * half; ldb = half;
-        Cc = T + (o + half + tiy * 32) + (size_t)(o + tjx * 32) * tb; ldc = tb;
-        kbeg = 0; kend = (tiy + 1) * 32; alpha = -1.0;       // X22 is lower triangular: columns k >= 32 (tiy + 1) of its row tile are zero
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int fr = lane & 15, fk = lane >> 4;
@@ -734,6 +713,85 @@ __global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, 
     }
 }
 
+__global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, int half, int phase, int pair0, const double* __restrict__ S, double* __restrict__ Tinv,
+                                                       double* __restrict__ Ttmp) {
+    __shared__ double As[32 * 66];       // As[i][k]
+    __shared__ double Bs[32 * 66];       // Bs[j][k]
+    inst_shift(bt, S, Tinv, Ttmp);
+    const int tiles = half / 32;
+    const int pair = pair0 + blockIdx.x / (tiles * tiles);     // pairs pair0 .. of this level (a launch may cover one solve block only)
+    const int tt = blockIdx.x % (tiles * tiles);
+    const int tiy = tt / tiles, tjx = tt % tiles;
+    const int g0 = pair * 2 * half;
+    const int q = g0 / tb, o = g0 % tb;
+    double* T = Tinv + (size_t)q * tb * tb;
+    double* tmp = Ttmp + (size_t)pair * half * half;
+    if (phase == 0)          // tmp(half x half) = L21 * X11; X11 is lower triangular: rows k < 32 tjx of its column tile are zero
+        merge32_tile(S + (g0 + half + tiy * 32) + (size_t)g0 * NP, NP, T + o + (size_t)(o + tjx * 32) * tb, tb, tmp + tiy * 32 + (size_t)(tjx * 32) * half, half, tjx * 32, half, 1.0, As, Bs);
+    else                     // X21 = -X22 * tmp; X22 is lower triangular: columns k >= 32 (tiy + 1) of its row tile are zero
+        merge32_tile(T + (o + half + tiy * 32) + (size_t)(o + half) * tb, tb, tmp + (size_t)(tjx * 32) * half, half, T + (o + half + tiy * 32) + (size_t)(o + tjx * 32) * tb, tb, 0,
+                     (tiy + 1) * 32, -1.0, As, Bs);
+}
+
+// The same product by a FEW persistent workgroups of 1024 threads (64 x 64 output tiles, 16 wavefronts with one 16 x 16 MFMA tile each, K in chunks of 64 with the next
+// chunk's operands prefetched into registers): what runs on the second stream BESIDE the pivot chain.  A 1024-thread workgroup owns a compute unit, exactly like a
+// worker of k_ldl_step: G of them leave 256 - G compute units to the panel steps, whereas the 1536 small workgroups of the 32 x 32 form land on every compute unit and
+// keep the next panel step's workgroups (which need whole units) waiting for 20-35 us.  Tiles in the order of decreasing depth (column tile 0 has K = w).
+__global__ __launch_bounds__(1024) void k_wform_product64(Batch bt, int NP, int tb, int kb, int w, int rb, const double* __restrict__ S, const double* __restrict__ Tinv, double* __restrict__ Wb) {
+    constexpr int KC = 64, ldk = KC + 2;
+    __shared__ double As[64 * ldk];       // As[i][k]
+    __shared__ double Bs[64 * ldk];       // Bs[j][k]
+    inst_shift(bt, S, Tinv, Wb);
+    const int tr = rb / 64, ntiles = tr * (w / 64), k0 = kb * tb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 2, wj = wave & 3, fr = lane & 15, fk = lane >> 4;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tiy = t % tr, tjx = t / tr;
+        const double* A = S + (k0 + w + tiy * 64) + (size_t)k0 * NP;                                // A[i + k * NP] = L[k0 + w + 64 tiy + i, k0 + k]
+        const double* B = Tinv + (size_t)kb * tb * tb + (size_t)(tjx * 64) * tb;                    // B[k + j * tb] = Tinv_kb[k, 64 tjx + j]: zero for k < 64 tjx
+        const int kbeg = tjx * 64;
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        double av[4], bv[4];
+        auto fetch = [&](int kc) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                av[it] = A[lane + (size_t)(kc + wave + 16 * it) * NP];                              // lanes along i, 16 k per pass
+                bv[it] = B[(kc + lane) + (size_t)(wave + 16 * it) * tb];                            // lanes along k, 16 columns per pass
+            }
+        };
+        fetch(kbeg);
+        for (int kc = kbeg; kc < w; kc += KC) {
+            __syncthreads();                                                                        // the previous chunk's fragments are read
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                As[lane * ldk + wave + 16 * it] = av[it];
+                Bs[(wave + 16 * it) * ldk + lane] = bv[it];
+            }
+            __syncthreads();
+            if (kc + KC < w) fetch(kc + KC);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const double a = As[(wi * 16 + fr) * ldk + kk * 4 + fk];
+                const double b = Bs[(wj * 16 + fr) * ldk + kk * 4 + fk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);                     // transposed: row <-> j, col <-> i
+            }
+        }
+        double* Cc = Wb + tiy * 64 + (size_t)(tjx * 64) * rb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cc[(wi * 16 + fr) + (size_t)(wj * 16 + fk + 4 * r) * rb] = acc[r];
+    }
+}
+
+// W-form block of solve block kb (internal.hpp: wform_offset): W = L[k0 + w .. NP, k0 .. k0 + w) * Tinv_kb, rb = NP - k0 - w rows, leading dimension rb.  One 32 x 32 tile per
+// workgroup (blockIdx.x = tile row + (rb / 32) * tile column); Tinv_kb is lower triangular: the k range of column tile tjx starts at 32 tjx.
+__global__ __launch_bounds__(256) void k_wform_product(Batch bt, int NP, int tb, int kb, int w, int rb, const double* __restrict__ S, const double* __restrict__ Tinv, double* __restrict__ Wb) {
+    __shared__ double As[32 * 66];
+    __shared__ double Bs[32 * 66];
+    inst_shift(bt, S, Tinv, Wb);
+    const int tr = rb / 32, tiy = blockIdx.x % tr, tjx = blockIdx.x / tr, k0 = kb * tb;
+    merge32_tile(S + (k0 + w + tiy * 32) + (size_t)k0 * NP, NP, Tinv + (size_t)kb * tb * tb + (size_t)(tjx * 32) * tb, tb, Wb + tiy * 32 + (size_t)(tjx * 32) * rb, rb, tjx * 32, w, 1.0, As, Bs);
+}
+
 __global__ void k_publish_inertia(const int* __restrict__ icount, int* __restrict__ hcount, unsigned long long* __restrict__ hseq, unsigned long long seq) {
     if (threadIdx.x < 6) hcount[threadIdx.x] = icount[threadIdx.x];
     __threadfence_system();
@@ -744,23 +802,29 @@ __global__ void k_publish_inertia(const int* __restrict__ icount, int* __restric
 // to a quarter of the compute units — hipExtStreamCreateWithCUMask — changed nothing: the chain's workgroup does not wait for a CU)
 static bool side_stream(calipso_hip_solver* s) {
     if (s->stream2) return s->hprog_dev != nullptr && s->ev_side[7] != nullptr;
-    {
-        // (lowest priority.  A CU mask — hipExtStreamCreateWithCUMask, half / three quarters / 15 of 16 of the compute units — is accepted and changes
-        // nothing, neither the duration of the second stream's kernels nor the panel steps that wait behind them: see DESIGN 5.0)
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
-        if (hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, least) != hipSuccess) { s->stream2 = nullptr; return false; }
-    }
+    // (lowest priority.  A CU mask — hipExtStreamCreateWithCUMask, half / three quarters / 15 of 16 of the compute units — is accepted and changes
+    // nothing, neither the duration of the second stream's kernels nor the panel steps that wait behind them: see DESIGN 5.0)
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) return false;
+    bool ok = true;
     if (!s->hprog) {
-        if (hipHostMalloc((void**)&s->hprog, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { s->hprog = nullptr; return false; }
-        *s->hprog = 0;
-        if (hipHostGetDevicePointer((void**)&s->hprog_dev, s->hprog, 0) != hipSuccess) return false;
+        if (hipHostMalloc((void**)&s->hprog, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { s->hprog = nullptr; ok = false; }
+        else {
+            *s->hprog = 0;
+            if (hipHostGetDevicePointer((void**)&s->hprog_dev, s->hprog, 0) != hipSuccess) { s->hprog_dev = nullptr; ok = false; }
+        }
     }
     for (auto& e : s->ev_side)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return false; }
+        if (ok && !e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; ok = false; }
+    if (!ok) { (void)hipStreamDestroy(st); return false; }      // no half-made second stream: the factorisation keeps the one-stream schedule
+    s->stream2 = st;
     return true;
 }
 static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f);
+static void enqueue_wform(calipso_hip_solver* s, hipStream_t stream, int kb);
+static void enqueue_feed(calipso_hip_solver* s, hipStream_t stream, int i, bool beside);
 static void ldl_plan_ranges(calipso_hip_solver* s);
 // Which finish work runs beside the chain: one instance alone, dense S, a solve block that is complete before the chain ends (otherwise nothing to overlap)
 static bool ldl_overlap(calipso_hip_solver* s) {
@@ -800,7 +864,9 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     // every XCD (workgroup index mod 8) has at least one worker for its share of the tile list; surplus workgroups leave at once
     auto grid = [&](int tiles) { const int workers = std::min(std::max(tiles - 1, 0), resident) * (int)nz; return dim3(nz + (workers ? (workers + 7) / 8 * 8 + 7 : 0)); };
     const bool overlap = ldl_overlap(s) && side_stream(s);
+    s->ldl_overlap_on = overlap;
     if (overlap) ldl_plan_ranges(s);
+    int launches = 1;
     unsigned long long* const hprog = overlap ? s->hprog_dev : (unsigned long long*)nullptr;
     const unsigned long long epoch = s->ldl_epoch << 16;         // progress word = epoch | first panel the launch applies: every panel before it is released
     for (int kb = 0; kb + 1 < nblk;) {
@@ -813,20 +879,21 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
             const int ntr2 = ntr - 1, ntiles2 = ntr2 * (ntr2 + 1) / 2;
             hipLaunchKernelGGL((k_ldl_step<2>), grid(ntiles2), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles2, tb, s->S, Minv,
                                s->Dx, s->Tinv, s->icount);
-            kb += 2;
+            kb += 2; launches += 2;
         } else {
             const int ntiles = ntr * (ntr + 1) / 2;
             // trailing update; its tile 0 also factors the next diagonal block (k0 + 64)
             hipLaunchKernelGGL((k_ldl_step<0>), grid(ntiles), dim3(TR_THREADS), 0, s->stream, bt, NP, s->d.nx, k0, ntiles, tb, s->S, Minv, s->Dx, s->Tinv, s->icount,
                                hprog, epoch | (unsigned long long)kb);
-            kb += 1;
+            kb += 1; launches += 1;
         }
     }
+    s->ldl_step_launches = launches;
     // A range of columns can be finished on the second stream as soon as a launch that applies none of its panels has STARTED (the raw panel columns are
     // only read by the launch that applies them): launch_ldl watches the progress word for that.  The launches carry the tags 0 .. nblk - 2 (a pair pass the
     // tag of its first panel), so the ranges that end at or before panel nblk - 2 are handed over while the chain runs, the rest after it (enqueue_ldl_finish).
     int forks = 0;
-    if (overlap) while (2 * forks < (int)s->ldl_ranges.size() && (s->ldl_ranges[2 * forks] + s->ldl_ranges[2 * forks + 1]) / NB <= nblk - 2) ++forks;
+    if (overlap) while (3 * forks < (int)s->ldl_feeds.size() && s->ldl_feeds[3 * forks] <= nblk - 2) ++forks;
     s->ldl_forks = forks;              // (enqueue_ldl_finish joins the second stream)
     // A single handle outside a stream capture: the six inertia counts go to their mapped host words right behind the chain (+ the sequence number the host
     // spins on, api.hip: wait_published) — the host learns the inertia when the pivot chain ends, not after the finish + a copy + a stream synchronisation
@@ -844,7 +911,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
     const unsigned nz = bt.n;
     const int band = s->band64 > 0 ? s->band64 : nblk;
     {
-        if (ldl_overlap(s) && s->stream2) {
+        if (s->ldl_overlap_on) {
             // the blocks whose last panel a panel step applied were finished beside the chain (launch_ldl); what is left is the last block(s).
             // Join first: the solves need every block (the second stream is long done by now).  (The last block's finish on the second stream too, joined
             // after the inertia read-back, was measured: 0.901 against 0.889 ms — the hand-over between the queues costs more than the overlap gives.)
@@ -852,7 +919,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
                 (void)hipEventRecord(s->ev_side[7], s->stream2);
                 (void)hipStreamWaitEvent(s->stream, s->ev_side[7], 0);
             }
-            for (int f = s->ldl_forks; 2 * f < (int)s->ldl_ranges.size(); ++f) enqueue_finish_feed(s, s->stream, f);
+            for (int f = s->ldl_forks; 3 * f < (int)s->ldl_feeds.size(); ++f) enqueue_feed(s, s->stream, f, false);
             return;
         }
     }
@@ -870,6 +937,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
             else hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles * 4, 1, nz), dim3(256), 0, s->stream, bt, NP, tb, half, phase, 0, s->S, s->Tinv, s->Ttmp);
         }
     }
+    if (wform_on(s)) for (int kb = 0; kb * tb < NP; ++kb) enqueue_wform(s, s->stream, kb);
 }
 
 // The same finish for ONE solve block b (columns b tb .. b tb + w - 1) on `stream`: the factor columns of its panels, then the merges of its inverse blocks.
@@ -895,13 +963,39 @@ static void enqueue_merge(calipso_hip_solver* s, hipStream_t stream, int half, i
     const Batch bt = batch_of(s).b;
     hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles, 1, bt.n), dim3(256), 0, stream, bt, NP, tb, half, phase, pair0, s->S, s->Tinv, s->Ttmp + merge_scratch(NP, half));
 }
+// workgroups of the W-form product beside the chain (k_wform_product64): it is handed over once the trailing update has shrunk enough to leave them their compute units
+static const int WFORM_WGS = [] { const char* e = getenv("CALIPSO_HIP_WFORM_WGS"); const int v = e ? atoi(e) : 128; return v >= 8 && v <= 240 ? v : 128; }();
 static void ldl_plan_ranges(calipso_hip_solver* s) {
-    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
+    const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
     s->ldl_ranges.clear();
+    s->ldl_feeds.clear();
+    const bool wf = wform_on(s);
+    std::vector<std::array<int, 3>> feeds;
     for (int b0 = 0; b0 < NP; b0 += tb) {
         const int wblk = std::min(tb, NP - b0), wr = std::min(FEED, wblk);
-        for (int c = b0; c < b0 + wblk; c += wr) { s->ldl_ranges.push_back(c); s->ldl_ranges.push_back(wr); }
+        for (int c = b0; c < b0 + wblk; c += wr) {
+            feeds.push_back({(c + wr) / NB, 0, (int)s->ldl_ranges.size() / 2});
+            s->ldl_ranges.push_back(c); s->ldl_ranges.push_back(wr);
+        }
+        if (wf && b0 + wblk < NP) {
+            // the block's product: after its last range, and not before the panel step whose trailing update (tiles + the chain's workgroup) leaves WFORM_WGS compute units free
+            int step = (b0 + wblk) / NB;
+            while (step < nblk - 1) { const int ntr = nblk - 1 - step; if (ntr * (ntr + 1) / 2 + WFORM_WGS <= 248) break; ++step; }
+            feeds.push_back({step, 1, b0 / tb});
+        }
     }
+    std::stable_sort(feeds.begin(), feeds.end(), [](const std::array<int, 3>& a, const std::array<int, 3>& b) { return a[0] < b[0]; });
+    for (const auto& f : feeds) { s->ldl_feeds.push_back(f[0]); s->ldl_feeds.push_back(f[1]); s->ldl_feeds.push_back(f[2]); }
+}
+// feed i of the plan on `stream`; beside: the pivot chain is still running (the product takes its few-workgroup form)
+static void enqueue_feed(calipso_hip_solver* s, hipStream_t stream, int i, bool beside) {
+    const int kind = s->ldl_feeds[3 * i + 1], arg = s->ldl_feeds[3 * i + 2];
+    if (kind == 0) { enqueue_finish_feed(s, stream, arg); return; }
+    if (!beside) { enqueue_wform(s, stream, arg); return; }
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
+    const int k0 = arg * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
+    const Batch bt = batch_of(s).b;
+    hipLaunchKernelGGL(k_wform_product64, dim3(std::min(WFORM_WGS, (rb / 64) * (w / 64)), 1, bt.n), dim3(1024), 0, stream, bt, NP, tb, arg, w, rb, s->S, s->Tinv, s->Wfac + wform_offset(NP, tb, arg));
 }
 static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f) {
     const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
@@ -914,12 +1008,15 @@ static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f
     for (int half = 64; 2 * half <= w; half *= 2)
         for (int phase = 0; phase < 2; ++phase) enqueue_merge(s, stream, half, phase, c0 / (2 * half), w / (2 * half));
     int rel = c0 - b0;
+    bool block_done = w == wblk;                            // (a range that is a whole solve block)
     for (int cur = w; 2 * cur <= wblk; cur *= 2) {          // the complete node: columns b0 + rel .. + cur - 1
         const int pair = (b0 + (rel & ~(2 * cur - 1))) / (2 * cur);
         if ((rel & (2 * cur - 1)) == 0) { enqueue_merge(s, stream, cur, 0, pair, 1); break; }
         enqueue_merge(s, stream, cur, 1, pair, 1);
         rel &= ~(2 * cur - 1);
+        if (2 * cur == wblk) block_done = true;             // the node just completed is the whole block
     }
+    (void)block_done;     // (the block's W-form product is a feed of its own in the plan: ldl_plan_ranges)
 }
 
 // ---- triangular solves with blocks of up to 1024 columns ---------------------------------------------------------------------------
@@ -1038,8 +1135,127 @@ __global__ __launch_bounds__(256) void k_trsv_update_t(Batch bt, int NP, int k0,
     if (lane == 0) z[c] -= acc;
 }
 
+// ---- W-form solves (internal.hpp: wform_offset): one launch per solve block and direction -------------------------------------------------
+// forward, block kb: the stacked matrix [Tinv_kb; W_kb] (w + rb rows) times b_kb: rows < w give u_kb (and z_kb = u_kb / D), rows >= w are subtracted from the
+// right-hand side below the block.  ROWS rows per workgroup, the first w / ROWS workgroups take the triangular part (as k_trsv_block_n), the others W.
+template <int ROWS, int PARTS, int CPT>
+__global__ __launch_bounds__(ROWS * PARTS) void k_trsv_fwd(Batch bt, int kb, int tb, int w, int rb, const double* __restrict__ Tinv, const double* __restrict__ Wb, double* __restrict__ b,
+                                                            const double* __restrict__ Dx, double* __restrict__ u, double* __restrict__ z) {
+    constexpr int W = PARTS * CPT;
+    __shared__ double bs[W];
+    __shared__ double part[PARTS][ROWS];
+    inst_shift(bt, Tinv, Wb, b, Dx, u, z);
+    const int tid = threadIdx.x, k0 = kb * tb;
+    const int r = tid % ROWS, p = tid / ROWS;
+    const int nA = w / ROWS;
+    const bool below = (int)blockIdx.x >= nA;
+    const int blk = below ? (int)blockIdx.x - nA : (int)blockIdx.x;
+    const int row = blk * ROWS + r;
+    const double* M = below ? Wb + row : Tinv + (size_t)kb * tb * tb + row;
+    const size_t ld = below ? (size_t)rb : (size_t)tb;
+    const int cend = below ? w : blk * ROWS + ROWS;     // lower triangular: columns beyond the workgroup's last row are zero
+    double acc = 0.0;
+    for (int c0 = 0; c0 < cend; c0 += W) {
+        double v[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) { const int c = c0 + p + PARTS * q; v[q] = (c < cend) ? M[(size_t)c * ld] : 0.0; }
+        if (c0) __syncthreads();
+        for (int i = tid; i < W; i += ROWS * PARTS) bs[i] = c0 + i < w ? b[k0 + c0 + i] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) acc += v[q] * bs[p + PARTS * q];
+    }
+    part[p][r] = acc;
+    __syncthreads();
+    if (tid < ROWS) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) s += part[q][tid];
+        const int gi = k0 + (below ? w : 0) + blk * ROWS + tid;
+        if (below) b[gi] -= s;                    // (rows >= k0 + w: no workgroup of this launch reads them)
+        else { u[gi] = s; z[gi] = s / Dx[gi]; }
+    }
+}
+// backward, block kb: v_kb = [Tinv_kb; W_kb]' [z_kb; -v_below]: one wavefront per column, lanes stride down the stacked column (w rows of Tinv_kb from the diagonal
+// on, then rb rows of W_kb), every load of a lane in flight before the first use.  NCH = 64-row groups of the stacked column (w + rb <= 64 NCH).  x holds v of the
+// blocks below (written by the launches before this one); the block's own v goes to x[k0 ..].
+template <int NCH>
+__global__ __launch_bounds__(256) void k_trsv_bwd(Batch bt, int kb, int tb, int w, int rb, const double* __restrict__ Tinv, const double* __restrict__ Wb, const double* __restrict__ z,
+                                                   double* __restrict__ x) {
+    __shared__ double zs[NCH * 64];
+    inst_shift(bt, Tinv, Wb, z, x);
+    const int tid = threadIdx.x, lane = tid & 63, k0 = kb * tb;
+    const int c = blockIdx.x * 4 + (tid >> 6);
+    const double* T = Tinv + (size_t)kb * tb * tb + (size_t)c * tb;
+    const double* Wc = Wb + (size_t)c * rb;
+    // the column's loads go out FIRST (they do not depend on the vector): the fill of zs below and its barrier run under their latency
+    double tv[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int r = lane + 64 * q;
+        tv[q] = r < w ? (r >= (c & ~63) ? T[r] : 0.0) : (r < w + rb ? Wc[r - w] : 0.0);     // column c of Tinv_kb is zero above row c
+    }
+    {
+        constexpr int PER = NCH * 64 / 256;
+        double zv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const int i = tid + 256 * u; zv[u] = i < w ? z[k0 + i] : (i < w + rb ? -x[k0 + i] : 0.0); }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) zs[tid + 256 * u] = zv[u];
+    }
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) acc += tv[q] * zs[lane + 64 * q];
+    acc = wave_sum(acc);
+    if (lane == 0) x[k0 + c] = acc;
+}
+template <int NCH>
+static void launch_trsv_bwd(hipStream_t st, unsigned nz, const Batch& bt, int kb, int tb, int w, int rb, const double* Tinv, const double* Wb, const double* z, double* x) {
+    hipLaunchKernelGGL(k_trsv_bwd<NCH>, dim3(w / 4, 1, nz), dim3(256), 0, st, bt, kb, tb, w, rb, Tinv, Wb, z, x);
+}
+
+bool wform_on(const calipso_hip_solver* s) {
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
+    return s->solve_wform != 0 && !s->compact && s->band64 == 0 && !(s->stage_parallel && s->spS) && wform_layout_ok(NP, tb);
+}
+// the W-form products of solve block kb (after its factor columns and its inverse block are complete)
+static void enqueue_wform(calipso_hip_solver* s, hipStream_t stream, int kb) {
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
+    const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
+    if (rb <= 0) return;
+    const Batch bt = batch_of(s).b;
+    hipLaunchKernelGGL(k_wform_product, dim3((rb / 32) * (w / 32), 1, bt.n), dim3(256), 0, stream, bt, NP, tb, kb, w, rb, s->S, s->Tinv, s->Wfac + wform_offset(NP, tb, kb));
+}
+static void enqueue_trsv_wform(calipso_hip_solver* s, double* x) {
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), nb = (NP + tb - 1) / tb;
+    double* u = s->zf;
+    double* z = s->zf2;
+    const Batch bt = batch_of(s).b;
+    const unsigned nz = bt.n;
+    for (int kb = 0; kb < nb; ++kb) {
+        const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
+        const double* Wb = s->Wfac + wform_offset(NP, tb, kb);
+        if (w > 512) hipLaunchKernelGGL((k_trsv_fwd<16, 32, 32>), dim3((w + rb) / 16, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z);
+        else hipLaunchKernelGGL((k_trsv_fwd<16, 16, 32>), dim3((w + rb) / 16, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z);
+    }
+    for (int kb = nb - 1; kb >= 0; --kb) {
+        const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
+        const double* Wb = s->Wfac + wform_offset(NP, tb, kb);
+        const int nch = (w + rb + 63) / 64;
+        if (nch <= 8) launch_trsv_bwd<8>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
+        else if (nch <= 16) launch_trsv_bwd<16>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
+        else if (nch <= 24) launch_trsv_bwd<24>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
+        else if (nch <= 32) launch_trsv_bwd<32>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
+        else if (nch <= 40) launch_trsv_bwd<40>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
+        else if (nch <= 48) launch_trsv_bwd<48>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
+        else launch_trsv_bwd<64>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
+    }
+}
+
 // x (length NP, padded entries zero) <- S^-1 x
 static void enqueue_trsv(calipso_hip_solver* s, double* x) {
+    if (wform_on(s)) { enqueue_trsv_wform(s, x); return; }
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), nb = (NP + tb - 1) / tb;
     double* u = s->zf;         // forward result (unscaled), consumed by the updates
     double* z = s->zf2;        // D^-1 u, then overwritten block by block with v
@@ -1112,10 +1328,21 @@ void ldl_drop_graphs(calipso_hip_solver* s) {       // the captured launch seque
 // ev[14] marks the end of the panel steps (the pivot chain), so that their duration can be reported apart from the parallel finish
 // (calipso_hip_kernel_times)
 void launch_ldl(calipso_hip_solver* s) {
+    // state of the previous factorisation that do_factorize / enqueue_ldl_finish would otherwise act on: a blocked factorisation that published its inertia
+    // counts followed by a stage-parallel one on the same handle must not leave do_factorize waiting for a sequence number that was consumed long ago
+    s->ldl_forks = 0;
+    s->ldl_pub_seq = 0;
+    s->ldl_overlap_on = false;
+    s->ldl_failed = false;
     if (s->stage_parallel && s->spS) {        // stage-parallel: multifrontal LDL^T of S over its nested-dissection tree (sparse.hip)
         const Batch bt = batch_of(s).b;
         if (sparse_factor_from_dense(s->spS, s->stream, bt, s->S, s->spS_src, s->icount) == CALIPSO_OK) { (void)hipEventRecord(s->ev[14], s->stream); return; }
-        if (s->compact) { s->err = "structured handle: the multifrontal factorisation was refused and there is no blocked one to fall back to"; (void)hipEventRecord(s->ev[14], s->stream); return; }
+        if (s->compact) {
+            s->err = "structured handle: the multifrontal factorisation was refused and there is no blocked one to fall back to";
+            s->ldl_failed = true;             // (do_factorize turns it into CALIPSO_ERR_HIP: no stale inertia, no solve with an absent factor)
+            (void)hipEventRecord(s->ev[14], s->stream);
+            return;
+        }
         s->stage_parallel = false;            // (a group larger than the reserved batch: back to the blocked factorisation)
         launch_pad_identity(s);               // launch_schur skipped the padding of S for the multifrontal path: the blocked one needs its unit pivots
     }
@@ -1127,8 +1354,6 @@ void launch_ldl(calipso_hip_solver* s) {
     static const bool graph_ldl_env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();
     const bool graphs = !s->cur && s->use_graphs && graph_ldl_env;
     if (ldl_overlap(s)) (void)side_stream(s);       // (created outside a stream capture)
-    s->ldl_forks = 0;
-    s->ldl_pub_seq = 0;
     static const bool pub_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_PUBLISH"); return !e || atoi(e) != 0; }();     // (experiment switch)
     s->ldl_publish = pub_env && !graphs && !s->cur;       // (a captured launch would replay a stale sequence number)
     s->ldl_epoch += 1;
@@ -1138,12 +1363,12 @@ void launch_ldl(calipso_hip_solver* s) {
     // the panel steps store and queues a block's finish when the step after the block's last panel has started.  (A hipStreamWaitEvent on the second
     // stream instead was measured: a queue blocked on a barrier costs every dispatch of the chain's queue ~0.8 us — 30 us per factorisation.)
     for (int f = 0; f < s->ldl_forks; ++f) {
-        const unsigned long long want = (s->ldl_epoch << 16) | (unsigned long long)((s->ldl_ranges[2 * f] + s->ldl_ranges[2 * f + 1]) / NB);
+        const unsigned long long want = (s->ldl_epoch << 16) | (unsigned long long)s->ldl_feeds[3 * f];
         unsigned spins = 0;
         while (__atomic_load_n(s->hprog, __ATOMIC_ACQUIRE) < want) {
             if ((++spins & 0xffffu) == 0 && hipStreamQuery(s->stream) != hipErrorNotReady) break;     // (the chain is through, or the queue faulted)
         }
-        enqueue_finish_feed(s, s->stream2, f);
+        enqueue_feed(s, s->stream2, f, true);
     }
     if (!graphs || !replay_or_capture(s, s->graph_ldl_fin, s->graph_ldl_fin_tried, [&] { enqueue_ldl_finish(s); })) enqueue_ldl_finish(s);
 }

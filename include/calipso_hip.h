@@ -155,7 +155,10 @@ int32_t calipso_hip_device_count(void);
  *   the reference: "opt.solve_block" (512, 1024 or 2048, default 1024) — the widest diagonal block of the factor of S whose inverse is assembled for the
  *   triangular solves.  It changes the summation order of the solves (not the factor): 1024 suits one system (fewer dependent launches), 512 suits
  *   a group (one merge level less; its solves are bandwidth-bound); 2048 is there for larger systems (at nx = 2432 its extra merge level costs 0.15 ms
- *   and saves 0.07).  Set it on every member of a group (the first member's value governs the group's launches). */
+ *   and saves 0.07).  Set it on every member of a group (the first member's value governs the group's launches).  And "opt.solve_wform" (0 or 1,
+ *   default 1): the solves (linear_solve!, linear_solver.jl:52-60) multiply with the stacked blocks [Tinv_b; W_b], W_b = L[below, b] Tinv_b formed once per
+ *   factorisation, so that a solve is two dependent launches per solve block instead of four; same factor, different summation order.  One system wants it; a
+ *   group (bandwidth-bound solves) does not need the extra products.  The members of a group must agree on it. */
 int32_t calipso_hip_set_field(calipso_hip_solver*, const char* name, const double* data, int64_t len);
 int32_t calipso_hip_get_field(calipso_hip_solver*, const char* name, double* data, int64_t len);
 /* The scatter of evaluate! on the device (evaluate.jl:37-121): register `methods.<field>_sparsity` once — `count` (row, col)
