@@ -208,10 +208,12 @@ class Exchange:
     ncclAllGather / ncclAllReduce); with the gloo backend (CPU-side tests: two ranks sharing one GPU cannot form an RCCL communicator)
     through torch.distributed (calipso.jl_amd/batch.py: gather_results)."""
 
-    def __init__(self, pkg, dist, backend, rank, world, device):
+    def __init__(self, pkg, dist, backend, rank, world, device, try_comm=None):
         self.pkg, self.dist, self.rank, self.world = pkg, dist, rank, world
         self.comm, self.path = None, "torch.distributed (%s)" % backend
-        if world == 1 or backend == "nccl":
+        if try_comm is None:
+            try_comm = world == 1 or backend == "nccl"
+        if try_comm:
             uid = [pkg.Comm.unique_id() if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(uid, src=0)
@@ -222,7 +224,7 @@ class Exchange:
                 ok, why = 0, str(e)
             if world > 1:                                             # every rank takes the same path
                 import torch
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda:%d" % device)
+                flag = torch.tensor([ok], dtype=torch.int32, device=("cuda:%d" % device) if backend == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())
             if ok:
@@ -380,16 +382,44 @@ def main():
     if args.force_device >= 0:
         local_rank = args.force_device
     if args.spawn_check:
-        ranks = [rank]
+        # No GPU is touched: the ranks report in, then run the post-round exchange of config 4 on synthetic status rows — the block-contiguous shard of
+        # world x --c4-batch problem ids, one row [ok, problem id, rank, group] per instance, gathered in global id order.  CALIPSO_BENCH_FAKE_COMM_FAIL_RANKS
+        # ("1,3") makes the product communicator "fail" on those ranks: every rank must then agree to fall back to torch.distributed.
+        ranks, extra = [rank], {}
         if world > 1:
             import torch.distributed as dist
             dist.init_process_group("gloo")
             ranks = [None] * world
             dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "0"))))
+            from __graft_entry__ import load_package
+            load_package()
+            from calipso_jl_amd.batch import shard_range
+            failing = [int(v) for v in os.environ.get("CALIPSO_BENCH_FAKE_COMM_FAIL_RANKS", "").split(",") if v.strip()]
+
+            class _StubComm:                              # stands for calipso_hip_comm_init (needs a GPU): succeeds or fails as the test asks
+                def __init__(self, r, w, uid, device=0):
+                    if r in failing:
+                        raise RuntimeError("no communicator on rank %d (simulated)" % r)
+
+                @staticmethod
+                def unique_id():
+                    return b"stub"
+
+                def close(self):
+                    pass
+
+            class _StubPkg:
+                Comm = _StubComm
+            ids = list(shard_range(world * args.c4_batch, rank, world))
+            ex = Exchange(_StubPkg, dist, "gloo", rank, world, 0, try_comm=bool(failing))
+            rows, tot, _ = ex.gather([[1, pid, rank, k // max(1, args.c4_group)] for k, pid in enumerate(ids)], [float(len(ids))])
+            extra = {"c4_shard": [ids[0], ids[-1], len(ids)] if ids else [], "gathered_ids": [int(v) for v in rows[:, 1]], "gathered_ranks": [int(v) for v in rows[:, 2]],
+                     "gathered_groups": [int(v) for v in rows[:, 3]], "counter_total": float(tot[0]), "exchange_path": ex.path, "comm_left_open": ex.comm is not None}
+            ex.close()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"spawn_check": True, "n_gpus": world, "gpus_argument": args.gpus, "ranks": ranks,
-                              "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"}))
+            print(json.dumps(dict({"spawn_check": True, "n_gpus": world, "gpus_argument": args.gpus, "ranks": ranks,
+                                   "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"}, **extra)))
         return
     torch.cuda.set_device(local_rank)
     if world > 1:

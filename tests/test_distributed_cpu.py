@@ -118,3 +118,28 @@ def test_c4_sharding_of_256_instances():
         assert [len(g) for g in groups] == [16, 16] and groups[0][0] == 32 * rank and groups[1][0] == 32 * rank + 16
         seen += ids
     assert seen == list(range(256))
+
+
+@pytest.mark.parametrize("failing", ["", "2,5"])
+def test_bench_eight_ranks_shard_config4_and_gather_in_problem_order(failing):
+    """`python bench.py --gpus 8 --spawn-check`: eight gloo ranks (no GPU), BASELINE config 4's sharding (256 problems: 32 per rank in two groups of 16) and the
+    post-round exchange on synthetic status rows — every rank's rows arrive on rank 0 in global problem-id order.  With a product communicator that cannot be
+    created on SOME ranks (simulated) every rank must agree to fall back to torch.distributed, and none may keep a half-made communicator."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CALIPSO_BENCH_FAKE_COMM_FAIL_RANKS"] = failing
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--spawn-check"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and sorted(tuple(r) for r in d["ranks"]) == [(r, r) for r in range(8)]
+    assert d["c4_shard"] == [0, 31, 32]                                   # rank 0: ids 0..31
+    assert d["gathered_ids"] == list(range(256))
+    assert d["gathered_ranks"] == [pid // 32 for pid in range(256)]
+    assert d["gathered_groups"] == [(pid % 32) // 16 for pid in range(256)]
+    assert d["counter_total"] == 256.0 and d["comm_left_open"] is False
+    if failing:
+        assert "could not be created on every rank" in d["exchange_path"]
+    else:
+        assert d["exchange_path"].startswith("torch.distributed (gloo)")

@@ -264,3 +264,25 @@ def test_group_larger_than_the_reserved_stage_parallel_batch_falls_back_to_the_b
             assert x == y and x["status"] == 0, (it, x, y)
             assert np.all(np.isfinite(m.solution.all)) and np.array_equal(r.solution.all, m.solution.all)
     g.close(); gref.close()
+
+
+def test_stage_parallel_switched_on_after_a_blocked_step_on_the_same_handle():
+    """A blocked factorisation publishes its inertia counts under a sequence number; a stage-parallel factorisation on the SAME handle afterwards must not
+    wait for that (long consumed) number — launch_ldl forgets the state of the previous factorisation first (round-3 advisory: this order used to end in
+    'scalar read-back did not arrive')."""
+    pkg = load_pkg()
+    shape = STAGED[1]                                   # NP = 2560: the blocked path takes the two-stream schedule and publishes
+    prob, ref = build(pkg, 7, *shape)
+    _, s = build(pkg, 7, *shape)
+    for h in (ref, s):
+        h.analyze_structure()
+    a = s.newton_step(advance=False)                    # blocked LDL^T (publishes)
+    assert a["status"] >= 0
+    s.set_stage_parallel(True)
+    b = s.newton_step(advance=False)                    # multifrontal on the same handle
+    assert b["status"] >= 0 and b["factorizations"] == a["factorizations"]
+    r = ref.newton_step(advance=False)
+    assert np.abs(ref.data("step").all - s.data("step").all).max() <= 1e-9 * max(1.0, np.abs(ref.data("step").all).max())
+    s.set_stage_parallel(False)
+    c = s.newton_step(advance=False)                    # and back to the blocked one
+    assert c == r
