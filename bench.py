@@ -469,18 +469,28 @@ def main():
         return elapsed, infos, sch
 
     def run_single(wl, K):
-        infos, sch, ldl, chain, sd, tot, cw = [], [], [], [], [], [], []
+        """timed region: K Newton steps back to back, nothing else between them; returns (elapsed, infos)"""
+        infos = []
         barrier(wl)
         t0 = time.perf_counter()
         for _ in range(K):
             infos.append(wl.single.newton_step(advance=False))
-            pt_ = wl.single.phase_times()
-            sch.append(pt_[7]); ldl.append(pt_[3]); sd.append(pt_[2]); tot.append(pt_[6]); cw.append(pt_[1])
-            chain.append(wl.single.kernel_times()[0])
         barrier(wl)
         elapsed = max_over_ranks(time.perf_counter() - t0)
         assert all(i["status"] >= 0 for i in infos), "a Newton step of the timed region failed"
-        return elapsed, infos, dict(schur=sch, ldl=ldl, chain=chain, sd=sd, total=tot, cone=cw)
+        return elapsed, infos
+
+    def single_phases(wl, K):
+        """a SECOND, untimed-for-the-headline region of K steps in which the handle's HIP-event phase times are read after every step (the queries
+        synchronise on the events: they do not belong between the steps of the timed region)"""
+        sch, ldl, chain, sd, tot, cw, mv = [], [], [], [], [], [], []
+        for _ in range(K):
+            wl.single.newton_step(advance=False)
+            pt_ = wl.single.phase_times()
+            kt_ = wl.single.kernel_times()
+            sch.append(pt_[7]); ldl.append(pt_[3]); sd.append(pt_[2]); tot.append(pt_[6]); cw.append(pt_[1])
+            chain.append(kt_[0]); mv.append(kt_[4])
+        return dict(schur=sch, ldl=ldl, chain=chain, sd=sd, total=tot, cone=cw, matvec=mv)
 
     # =================================================================== headline workload ======================================
     wl = Workload(pkg, pr, args.config, rank, world, local_rank, args.batch, args.group, args.lanes, args.dense_structure, args.no_stage_parallel, args.no_stage_blocks, args.dense_buffers)
@@ -509,7 +519,8 @@ def main():
     K = args.steps
     single_elapsed, single_infos, ph = None, [], None
     if not args.no_single:
-        single_elapsed, single_infos, ph = run_single(wl, K)
+        single_elapsed, single_infos = run_single(wl, K)
+        ph = single_phases(wl, max(3, min(K, 10)))
 
     # ---- warm-up of the batched pass; unit 0 alone (one group of G instances): its launches have the device to themselves => clean per-launch figures --
     alone, alone_chain, unit_rate = [], [], None
@@ -556,7 +567,7 @@ def main():
     flops_ldl = nx ** 3 / 3.0
     n_ldl_launch = max(1, NP // 64 - 1)
     pmc = {}
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name
@@ -565,12 +576,17 @@ def main():
             pmc = {}
 
     def pmc_traffic(section, kernel_prefix, scale=1.0):
+        """HBM bytes per launch (PMC passes, profiles/) of the kernel VARIANT that carries the section's work: among the counter rows whose name starts with
+        the prefix, the one with the most bytes over its sampled launches (a group's factorisation runs k_ldl_step<2> with a few <1> launches beside it, one system <0>)"""
         if args.config != "C3":
             return None
+        best, best_total = None, -1.0
         for kname, e in pmc.get(section, {}).items():
-            if kname.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e and (section != "single" or "<0>" in kname or "k_ldl_step" not in kname):
-                return e["hbm_bytes_per_launch"] * scale
-        return None
+            if kname.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
+                total = e["hbm_bytes_per_launch"] * max(1, e.get("launches_sampled", 1))
+                if total > best_total:
+                    best, best_total = e, total
+        return best["hbm_bytes_per_launch"] * scale if best else None
 
     def entry(kernel, flops_per_factor, launches, ms_total, inst, section, prefix, step_ms):
         ms_launch = ms_total / launches
@@ -604,7 +620,15 @@ def main():
     cands.sort(key=lambda c: -c["ms_per_step"])
     roof = dict(cands[0])
     roof["secondary"] = cands[1:]
-    roof["dominance"] = ("the kernel with the largest share of the headline step among all kernels (profiles/r03_kernel_stats_single.csv lists every kernel); "
+    if ph is not None and np.mean(ph["matvec"]) > 0:
+        # the HBM-bound side of the step: the mat-vec kernel of a refinement residual ([gx; hx]' times two vectors + Lxx times one, one pass over both), ONE
+        # launch timed live per step with HIP events on the handle's stream (calipso_hip_kernel_times [4]); algorithmic bytes = the two blocks read once
+        mv_ms = float(np.mean(ph["matvec"]))
+        mv_bytes = 8.0 * (m * nx + nx * nx)
+        roof["secondary"].append({"kernel": "k_gemv_t2_and_n (refinement residual: [gx; hx]'(v_yz, Omega b_m) and Lxx v_x in one pass)", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                                  "achieved": mv_bytes / (mv_ms * 1e-3) * 1e-9, "frac": mv_bytes / (mv_ms * 1e-3) * 1e-9 / 8000.0, "bytes_per_launch": mv_bytes, "avg_launch_ms": mv_ms,
+                                  "launches_per_step": 1 + int(single_infos[-1]["refinement_rounds"]), "traffic": pmc_traffic("single", "calipso::k_gemv_t2_and_n")})
+    roof["dominance"] = ("the kernel with the largest share of the headline step among all kernels (profiles/r04_kernel_stats_single.csv lists every kernel); "
                          "HIP-event durations of this run")
     roof["peak_measured"] = peak_measured
     roof["peak_note"] = ("peak = datasheet fp64 matrix rate (not tabulated in MI355X_MICROARCH.md); peak_measured = calipso_hip_mfma_f64_peak in this run; "
@@ -669,7 +693,7 @@ def main():
             for _ in range(max(1, min(args.warmup, 2))):
                 w4.single.newton_step(advance=False)
             K4 = max(3, min(K, 10))
-            e1, i1, _ = run_single(w4, K4)
+            e1, i1 = run_single(w4, K4)
             if w4.staged is None and w4.G > 1:
                 for h4 in w4.solvers:
                     h4.set_option("solve_block", 512)
@@ -693,6 +717,10 @@ def main():
         "config": {"workload": workload,
                    "parallelism": "one system per GPU: replicas only; batched: independent problems per GPU (no data-path collective)",
                    "refinement_rounds": refinement_rounds, "factorizations_per_step": factorizations,
+                   "cpu_baseline_rows": "cpu_baseline.kind = 'port': the repo's single-thread C++ restatement of the reference's CPU path (oracle/), NOT the Julia reference (no julia on the box: "
+                                        "B2 says so); value = B0(i), one factorisation per step (favourable to the reference); B0_ii (the reference's re-factorisation before every solve) is "
+                                        + ("MEASURED in this run (--cpu-baseline-full)" if args.cpu_baseline_full else "DERIVED from B0(i) + separately timed factorisations (measured: false; --cpu-baseline-full measures it, ~90 s more)")
+                                        + "; B1 = LAPACK on all cores, not the reference",
                    "batched": batched, "c4": c4, "roofline_phases": cfg_phases},
         "roofline": roof,
     }

@@ -23,6 +23,7 @@ python - <<PY
 import csv
 rows=list(csv.DictReader(open("$O/quick_${TAG}_kernel_stats.csv")))
 rows=[r for r in rows if "mfma_f64_peak" not in r["Name"]]
+steps=float([r for r in rows if "k_schur" in r["Name"]][0]["Calls"])      # one Schur complement per Newton step
 for r in sorted(rows,key=lambda r:-float(r["TotalDurationNs"]))[:32]:
-    print("%-70s calls/step %6.1f avg %7.2f us  per step %7.1f us" % (r["Name"][:70], int(r["Calls"])/12.0, float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/12e3))
+    print("%-70s calls/step %6.1f avg %7.2f us  per step %7.1f us" % (r["Name"][:70], int(r["Calls"])/steps, float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/steps/1e3))
 PY

@@ -158,7 +158,7 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     SL(&s->Lxx, cp ? 1 : NX * NX); SL(&s->Lsym, cp ? plan.packed : NX * NX); SL(&s->Z, cp ? 1 : M * NX);     // structured: Lsym is the region of the packed blocks
     SL(&s->fx, NX); SL(&s->gyx, NX); SL(&s->hzx, NX); SL(&s->gh, M);
     SL(&s->cone_product, NC); SL(&s->cone_target, NC); SL(&s->barrier_gradient, NC);
-    SL(&s->dscal, 64); SL(&s->refpart, (NE + NC + 255) / 256 + 1 + (size_t)d.n_wide);
+    SL(&s->dscal, 64); SL(&s->refpart, std::max((NE + NC + 255) / 256 + 1, M + 2) + (size_t)d.n_wide);
     SL(&s->solution, N); SL(&s->candidate, N); SL(&s->lambda, NE); SL(&s->parameters, (size_t)d.np);
     SL(&s->residual, N); SL(&s->residual_error, N); SL(&s->step, N); SL(&s->step_correction, N);
     SL(&s->saved_point, N); SL(&s->saved_g, NE); SL(&s->saved_h, NC);
@@ -199,6 +199,9 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     rc |= dalloc(s, &s->cone.soc_start, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.soc_dim, (size_t)d.n_soc);
     rc |= dalloc(s, &s->cone.soc_woff, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.entry_soc, NC);
     rc |= dalloc(s, &s->cone.wide, (size_t)d.n_wide);
+    std::vector<int> zgrp;
+    calipso::solve_tail_plan(d, s->h_soc_start, s->h_soc_dim, zgrp);
+    if (zgrp.size() >= 2) { rc |= dalloc(s, &s->zgrp, zgrp.size()); s->n_zgrp = (int)zgrp.size() - 1; }
     if (rc) return CALIPSO_ERR_HIP;
     CK(hipHostMalloc((void**)&s->hscal, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     CK(hipHostMalloc((void**)&s->hicount, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
@@ -213,6 +216,7 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
         for (size_t g = 0; g < KG; ++g) { kr[4 * g] = 0; kr[4 * g + 1] = d.ne; kr[4 * g + 2] = 0; kr[4 * g + 3] = d.nc; }
         CK(hipMemcpy(s->krange, kr.data(), sizeof(int) * kr.size(), hipMemcpyHostToDevice));
     }
+    if (s->zgrp) CK(hipMemcpy(s->zgrp, zgrp.data(), sizeof(int) * zgrp.size(), hipMemcpyHostToDevice));
     if (d.n_soc) {
         CK(hipMemcpy(s->cone.soc_start, s->h_soc_start.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
         CK(hipMemcpy(s->cone.soc_dim, s->h_soc_dim.data(), sizeof(int) * d.n_soc, hipMemcpyHostToDevice));
@@ -291,7 +295,7 @@ int32_t calipso_hip_destroy(H* s) {
     calipso::blocks_release(s);
     double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
     for (double* p : dp) if (p) (void)hipFree(p);
-    int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc, s->cone.wide};
+    int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc, s->cone.wide, s->zgrp};
     for (int* p : ip) if (p) (void)hipFree(p);
     if (s->hscal) (void)hipHostFree(s->hscal);
     if (s->hicount) (void)hipHostFree(s->hicount);
@@ -583,11 +587,16 @@ static int do_inertia_correction(H* s, int64_t* nfact) {
     return CALIPSO_OK;
 }
 
-static void do_sds(H* s, int which, double* accumulate = nullptr) {
+// refine_follows: the caller goes straight on to a refinement residual of s->step (which = 0 only: the local rows of that residual then come out of the same launch)
+static void do_sds(H* s, int which, double* accumulate = nullptr, bool refine_follows = false) {
     const double* res = which == 0 ? s->residual : s->residual_error;
     double* st = which == 0 ? s->step : s->step_correction;
     launch_residual_symmetric(s, res);     // b, and the first operands of the condensed solve (xbuf, t1)
-    linear_solve_device(s);                // dx = S^-1(...) in xbuf, t2 = [gx; hx] dx
+    // one launch for t2 = [gx; hx] dx, the back-substitution and the recovery (vectors.hip: k_solve_tail) where the handle allows it (which = 0, no accumulation: its zsx rule)
+    const bool tail = which == 0 && !accumulate && s->d.m > 0;
+    linear_solve_device(s, !tail);         // dx = S^-1(...) in xbuf (, t2 = [gx; hx] dx)
+    if (tail && launch_solve_tail(s, 0, false, refine_follows)) return;
+    if (tail) gemv_n(s, s->d.m, s->d.nx, s->Z, s->d.m, s->xbuf, s->t2, 1.0, 0.0, SP_Z);
     // dy, dz back-substitution + dr, ds, dt recovery (+ step += correction); which = 0 also leaves zsx = [gx; hx] step_x = t2 for the refinement
     launch_recover(s, st, res, accumulate, which == 0 ? 1 : 0);
 }
@@ -604,6 +613,7 @@ static void refine_residual(H* s, bool publish = false) {
 static void refine_solve(H* s) {
     const Dims& d = s->d;
     launch_trsv(s, s->xbuf);
+    if (d.m && launch_solve_tail(s, 1, true, true)) return;       // t2, recovery, step += correction, zsx += t2 and the local rows of the next residual: one launch
     if (d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->xbuf, s->t2, 1.0, 0.0, SP_Z);
     launch_recover(s, s->step_correction, s->residual_error, s->step, 2);
 }
@@ -644,7 +654,7 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
 static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
     int rc = do_inertia_correction(s, nfact);
     if (rc < 0) return rc;
-    do_sds(s, 0);
+    do_sds(s, 0, nullptr, s->opt.iterative_refinement != 0);
     if (s->opt.iterative_refinement) {
         rc = do_refinement(s, rounds, nullptr, true);
         if (rc < 0) return rc;
@@ -766,6 +776,7 @@ static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equali
     if (rc < 0) return rc;
     // cone!(jacobian=true) (:183-185): the arrow/diagonal Jacobians are functions of (s, t) and are formed inside the kernels
     EV(2);
+    s->time_matvec = true;                                                              // (the first refinement residual of the step is timed: kernel_times [4])
     int warn = do_search_direction(s, &info.nfact, &info.rounds);                       // :187
     if (warn < 0) return warn;
     EV(3);
@@ -1157,6 +1168,10 @@ int32_t calipso_hip_kernel_times(H* s, double out[8]) {
     out[1] = (double)s->ldl_step_launches;              // k_ldl_diag + the k_ldl_step launches the last blocked factorisation queued
     out[2] = (double)s->d.NP;
     out[3] = (double)(s->slab_doubles * sizeof(double));
+    if (s->matvec_timed && hipEventSynchronize(s->ev[6]) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->ev[5], s->ev[6]) == hipSuccess) { out[4] = ms; out[5] = 8.0 * ((double)s->d.m * s->d.nx + (double)s->d.nx * s->d.nx); }
+    }
     return CALIPSO_OK;
 }
 

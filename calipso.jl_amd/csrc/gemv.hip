@@ -309,8 +309,11 @@ void gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2,
     gemv_n_chunks(d.nx, d.nx, rb, nchunk, chunk);
     const int nt2 = (d.nx + 3) / 4;
     const BatchSc B = batch_of(s);
+    const bool timed = s->time_matvec && !s->cur;
+    if (timed) (void)hipEventRecord(s->ev[5], s->stream);
     hipLaunchKernelGGL(k_gemv_t2_and_n, dim3(nt2 + rb * nchunk, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, SP_Z), d.m, d.nx, s->Z, d.m, x1, x2, y1, y2, nt2,
                        sparsity_of(s, SP_LXX), rb, d.nx, d.nx, chunk, s->Lxx, d.nx, xl, s->gemv_partial);
+    if (timed) { (void)hipEventRecord(s->ev[6], s->stream); s->time_matvec = false; s->matvec_timed = true; }
     hipLaunchKernelGGL(k_gemv_n_reduce, dim3((d.nx + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, d.nx, nchunk, s->gemv_partial, yl, 1.0, 0.0);
 }
 

@@ -199,12 +199,15 @@ static int gb_inertia_correction(G* g, const Set& a, std::vector<int>& rc, std::
     return CALIPSO_OK;
 }
 
-static void gb_sds(G* g, const Set& a, int which, bool accumulate) {
+static void gb_sds(G* g, const Set& a, int which, bool accumulate, bool refine_follows = false) {
     H* s = g->base;
     g_activate(g, a);
     const double* res = which == 0 ? s->residual : s->residual_error;
     launch_residual_symmetric(s, res);
-    linear_solve_device(s);
+    const bool tail = which == 0 && !accumulate && s->d.m > 0;          // (api.hip: do_sds)
+    linear_solve_device(s, !tail);
+    if (tail && launch_solve_tail(s, 0, false, refine_follows)) return;
+    if (tail) gemv_n(s, s->d.m, s->d.nx, s->Z, s->d.m, s->xbuf, s->t2, 1.0, 0.0, SP_Z);
     launch_recover(s, which == 0 ? s->step : s->step_correction, res, accumulate ? s->step : nullptr, which == 0 ? 1 : 0);   // which = 0: zsx = [gx; hx] step_x
 }
 // the two halves of a refinement round for the active members (api.hip: refine_residual / refine_solve)
@@ -217,6 +220,7 @@ static void gb_refine_residual(G* g) {
 static void gb_refine_solve(G* g) {
     H* s = g->base; const Dims& d = s->d;
     launch_trsv(s, s->xbuf);
+    if (d.m && launch_solve_tail(s, 1, true, true)) return;       // (api.hip: refine_solve)
     if (d.m) gemv_n(s, d.m, d.nx, s->Z, d.m, s->xbuf, s->t2, 1.0, 0.0, SP_Z);
     launch_recover(s, s->step_correction, s->residual_error, s->step, 2);
 }
@@ -334,9 +338,9 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
     if (e < 0) return e;
     a = alive(a, rc);
     if (!a.empty()) {
-        gb_sds(g, a, 0, false);
         Set ref;
         for (int i : a) if (g->hs[i]->opt.iterative_refinement) ref.push_back(i);
+        gb_sds(g, a, 0, false, ref.size() == a.size());      // every member refines: the local rows of the first residual come out of the solve's last launch
         if (!ref.empty()) { e = gb_refinement(g, ref, rc, rounds); if (e < 0) return e; }
     }
     for (int i : a) { info[i].nfact = nfact[i]; info[i].rounds = rounds[i]; }

@@ -203,7 +203,10 @@ struct calipso_hip_solver {
     // factorisation
     double* S = nullptr;        // NP*NP: Schur complement onto x, then L (unit lower) in place
     double* Dx = nullptr;       // NP: pivots of S
-    double* refpart = nullptr;  // per workgroup of k_refine_local: its part of ||residual_error||_inf
+    double* refpart = nullptr;  // per workgroup of k_refine_local / k_solve_tail: its part of ||residual_error||_inf
+    int refparts = 0;           // how many of them the last producer wrote (k_refine_x combines them)
+    int* zgrp = nullptr; int n_zgrp = 0;   // k_solve_tail (vectors.hip): first row of every group of whole constraints (<= 16 rows of [gx; hx]); shape-only, outside the slab
+    bool refine_local_done = false;        // the solve tail just queued also formed the local rows of the refinement residual: the next launch_refine_local is a no-op
     double* Ypanel = nullptr;   // NP*NB: M_k = (L_kk D_k L_kk')^-1 of every 64-column panel (ldl.hip: what the trailing update multiplies the raw panel with)
     double* Tinv = nullptr;     // tinv_doubles(NP): inverses of the unit-lower diagonal blocks of L (up to 1024 x 1024, the last one may be 512 wide)
     double* Ttmp = nullptr;     // NP*1024 scratch of the inverse assembly (NP*512: one 1024 x 1024 product at the top level; as much again so that every merge level has an area of its own, ldl.hip: merge_scratch)
@@ -269,6 +272,7 @@ struct calipso_hip_solver {
                                                         // inverse-assembly flops, what a group wants — its solves are bandwidth-bound).  Members of a group use the leader's.
     calipso::i64 solve_wform = 1;      // "opt.solve_wform": the triangular solves through the stacked [Tinv_b; W_b] blocks (internal.hpp: wform_offset): 2 launches per solve block instead of 4.
                                        // ONE system wants it (its solves are chains of latency-bound launches); a group, whose solves are bandwidth-bound, does not need the extra products.
+    bool time_matvec = false, matvec_timed = false;   // the next gemv_refine_pair brackets its mat-vec launch with ev[5] / ev[6] (once per Newton step: calipso_hip_kernel_times [4])
     double kernel_ms[4] = {0};   // [0] the panel-step launches (k_ldl_diag + k_ldl_step) of the last factorisation
     double phase_ms[9] = {0};
     // filter (filter.jl:1-13), host side
@@ -296,6 +300,9 @@ void launch_recover(calipso_hip_solver* s, double* step, const double* res, doub
 // one refinement residual in two kernels around the mat-vecs (see vectors.hip): rows r, s, y, z, t of residual_error = residual - H step from
 // zsx, the condensed b_m and t1 = Omega b_m, partial norm -> dscal[18]; then the x rows, dscal[7] = ||residual_error||_inf, xbuf = [b_x + w2; 0]
 void launch_refine_local(calipso_hip_solver* s);
+// t2 = [gx; hx] dx + launch_recover (+ launch_refine_local when with_refine) in ONE launch; false: not available for this handle (the caller takes the separate launches)
+bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool with_refine);
+void solve_tail_plan(const Dims& d, const std::vector<int>& soc_start, const std::vector<int>& soc_dim, std::vector<int>& grp);
 void launch_refine_x(calipso_hip_solver* s, bool publish = false);   // publish: dscal[7] also to the handle's mapped host mirror + sequence number
 void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s);
 void launch_accept(calipso_hip_solver* s, double step_size);
@@ -357,7 +364,7 @@ void launch_init_point(calipso_hip_solver* s);                 // initialize_sla
 void launch_lambda_update(calipso_hip_solver* s);              // lambda += rho * r (solve.jl:362-364)
 void launch_jacobian_parameters(calipso_hip_solver* s);        // residual_jacobian_parameters.jl:1-40
 void launch_negate_copy(calipso_hip_solver* s, const double* src, double* dst, int n);
-void linear_solve_device(calipso_hip_solver* s);               // middle of the condensed solve (operands from k_residual_symmetric)
+void linear_solve_device(calipso_hip_solver* s, bool with_t2 = true);   // middle of the condensed solve (operands from k_residual_symmetric); with_t2 = false: the caller's k_solve_tail forms t2 = [gx; hx] dx
 void launch_solve_from_b(calipso_hip_solver* s);               // step_symmetric = K^-1 residual_symmetric for a caller-provided b
 // gemm.hip
 void gemm(calipso_hip_solver* s, int M, int N, int K, double alpha, const double* A, int lda, bool transA, const double* B, int ldb, double beta,

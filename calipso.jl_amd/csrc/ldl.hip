@@ -737,12 +737,12 @@ __global__ __launch_bounds__(256) void k_tinv_merge32(Batch bt, int NP, int tb, 
 // chunk's operands prefetched into registers): what runs on the second stream BESIDE the pivot chain.  A 1024-thread workgroup owns a compute unit, exactly like a
 // worker of k_ldl_step: G of them leave 256 - G compute units to the panel steps, whereas the 1536 small workgroups of the 32 x 32 form land on every compute unit and
 // keep the next panel step's workgroups (which need whole units) waiting for 20-35 us.  Tiles in the order of decreasing depth (column tile 0 has K = w).
-__global__ __launch_bounds__(1024) void k_wform_product64(Batch bt, int NP, int tb, int kb, int w, int rb, const double* __restrict__ S, const double* __restrict__ Tinv, double* __restrict__ Wb) {
+__global__ __launch_bounds__(1024) void k_wform_product64(Batch bt, int NP, int tb, int kb, int w, int rb, int rows, const double* __restrict__ S, const double* __restrict__ Tinv, double* __restrict__ Wb) {
     constexpr int KC = 64, ldk = KC + 2;
     __shared__ double As[64 * ldk];       // As[i][k]
     __shared__ double Bs[64 * ldk];       // Bs[j][k]
     inst_shift(bt, S, Tinv, Wb);
-    const int tr = rb / 64, ntiles = tr * (w / 64), k0 = kb * tb;
+    const int tr = rows / 64, ntiles = tr * (w / 64), k0 = kb * tb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 2, wj = wave & 3, fr = lane & 15, fk = lane >> 4;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -784,11 +784,11 @@ __global__ __launch_bounds__(1024) void k_wform_product64(Batch bt, int NP, int 
 
 // W-form block of solve block kb (internal.hpp: wform_offset): W = L[k0 + w .. NP, k0 .. k0 + w) * Tinv_kb, rb = NP - k0 - w rows, leading dimension rb.  One 32 x 32 tile per
 // workgroup (blockIdx.x = tile row + (rb / 32) * tile column); Tinv_kb is lower triangular: the k range of column tile tjx starts at 32 tjx.
-__global__ __launch_bounds__(256) void k_wform_product(Batch bt, int NP, int tb, int kb, int w, int rb, const double* __restrict__ S, const double* __restrict__ Tinv, double* __restrict__ Wb) {
+__global__ __launch_bounds__(256) void k_wform_product(Batch bt, int NP, int tb, int kb, int w, int rb, int rows, const double* __restrict__ S, const double* __restrict__ Tinv, double* __restrict__ Wb) {
     __shared__ double As[32 * 66];
     __shared__ double Bs[32 * 66];
     inst_shift(bt, S, Tinv, Wb);
-    const int tr = rb / 32, tiy = blockIdx.x % tr, tjx = blockIdx.x / tr, k0 = kb * tb;
+    const int tr = rows / 32, tiy = blockIdx.x % tr, tjx = blockIdx.x / tr, k0 = kb * tb;
     merge32_tile(S + (k0 + w + tiy * 32) + (size_t)k0 * NP, NP, Tinv + (size_t)kb * tb * tb + (size_t)(tjx * 32) * tb, tb, Wb + tiy * 32 + (size_t)(tjx * 32) * rb, rb, tjx * 32, w, 1.0, As, Bs);
 }
 
@@ -825,6 +825,7 @@ static bool side_stream(calipso_hip_solver* s) {
 static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f);
 static void enqueue_wform(calipso_hip_solver* s, hipStream_t stream, int kb);
 static void enqueue_feed(calipso_hip_solver* s, hipStream_t stream, int i, bool beside);
+static int wform_rows(const calipso_hip_solver* s, int rb);
 static void ldl_plan_ranges(calipso_hip_solver* s);
 // Which finish work runs beside the chain: one instance alone, dense S, a solve block that is complete before the chain ends (otherwise nothing to overlap)
 static bool ldl_overlap(calipso_hip_solver* s) {
@@ -995,7 +996,8 @@ static void enqueue_feed(calipso_hip_solver* s, hipStream_t stream, int i, bool 
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
     const int k0 = arg * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
     const Batch bt = batch_of(s).b;
-    hipLaunchKernelGGL(k_wform_product64, dim3(std::min(WFORM_WGS, (rb / 64) * (w / 64)), 1, bt.n), dim3(1024), 0, stream, bt, NP, tb, arg, w, rb, s->S, s->Tinv, s->Wfac + wform_offset(NP, tb, arg));
+    const int rows = wform_rows(s, rb);
+    hipLaunchKernelGGL(k_wform_product64, dim3(std::min(WFORM_WGS, (rows / 64) * (w / 64)), 1, bt.n), dim3(1024), 0, stream, bt, NP, tb, arg, w, rb, rows, s->S, s->Tinv, s->Wfac + wform_offset(NP, tb, arg));
 }
 static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f) {
     const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
@@ -1180,7 +1182,7 @@ __global__ __launch_bounds__(ROWS * PARTS) void k_trsv_fwd(Batch bt, int kb, int
 // on, then rb rows of W_kb), every load of a lane in flight before the first use.  NCH = 64-row groups of the stacked column (w + rb <= 64 NCH).  x holds v of the
 // blocks below (written by the launches before this one); the block's own v goes to x[k0 ..].
 template <int NCH>
-__global__ __launch_bounds__(256) void k_trsv_bwd(Batch bt, int kb, int tb, int w, int rb, const double* __restrict__ Tinv, const double* __restrict__ Wb, const double* __restrict__ z,
+__global__ __launch_bounds__(256) void k_trsv_bwd(Batch bt, int kb, int tb, int w, int rb, int rows, const double* __restrict__ Tinv, const double* __restrict__ Wb, const double* __restrict__ z,
                                                    double* __restrict__ x) {
     __shared__ double zs[NCH * 64];
     inst_shift(bt, Tinv, Wb, z, x);
@@ -1193,13 +1195,13 @@ __global__ __launch_bounds__(256) void k_trsv_bwd(Batch bt, int kb, int tb, int 
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
         const int r = lane + 64 * q;
-        tv[q] = r < w ? (r >= (c & ~63) ? T[r] : 0.0) : (r < w + rb ? Wc[r - w] : 0.0);     // column c of Tinv_kb is zero above row c
+        tv[q] = r < w ? (r >= (c & ~63) ? T[r] : 0.0) : (r < w + rows ? Wc[r - w] : 0.0);     // column c of Tinv_kb is zero above row c; rows <= rb: what of W_kb can be non-zero
     }
     {
         constexpr int PER = NCH * 64 / 256;
         double zv[PER];
 #pragma unroll
-        for (int u = 0; u < PER; ++u) { const int i = tid + 256 * u; zv[u] = i < w ? z[k0 + i] : (i < w + rb ? -x[k0 + i] : 0.0); }
+        for (int u = 0; u < PER; ++u) { const int i = tid + 256 * u; zv[u] = i < w ? z[k0 + i] : (i < w + rows ? -x[k0 + i] : 0.0); }
 #pragma unroll
         for (int u = 0; u < PER; ++u) zs[tid + 256 * u] = zv[u];
     }
@@ -1211,13 +1213,19 @@ __global__ __launch_bounds__(256) void k_trsv_bwd(Batch bt, int kb, int tb, int 
     if (lane == 0) x[k0 + c] = acc;
 }
 template <int NCH>
-static void launch_trsv_bwd(hipStream_t st, unsigned nz, const Batch& bt, int kb, int tb, int w, int rb, const double* Tinv, const double* Wb, const double* z, double* x) {
-    hipLaunchKernelGGL(k_trsv_bwd<NCH>, dim3(w / 4, 1, nz), dim3(256), 0, st, bt, kb, tb, w, rb, Tinv, Wb, z, x);
+static void launch_trsv_bwd(hipStream_t st, unsigned nz, const Batch& bt, int kb, int tb, int w, int rb, int rows, const double* Tinv, const double* Wb, const double* z, double* x) {
+    hipLaunchKernelGGL(k_trsv_bwd<NCH>, dim3(w / 4, 1, nz), dim3(256), 0, st, bt, kb, tb, w, rb, rows, Tinv, Wb, z, x);
 }
 
 bool wform_on(const calipso_hip_solver* s) {
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
-    return s->solve_wform != 0 && !s->compact && s->band64 == 0 && !(s->stage_parallel && s->spS) && wform_layout_ok(NP, tb);
+    return s->solve_wform != 0 && !s->compact && !(s->stage_parallel && s->spS) && wform_layout_ok(NP, tb);
+}
+// rows of W_kb that can be non-zero: all rb of them, or — banded S (structure.hip) — the rows the block's columns reach (the others are exact zeros: skipping
+// them changes no bit, which is what keeps the banded treatment bitwise the dense one)
+static int wform_rows(const calipso_hip_solver* s, int rb) {
+    if (s->band64 <= 0) return rb;
+    return std::min(rb, ((s->half_bandwidth + 63) / 64) * 64);
 }
 // the W-form products of solve block kb (after its factor columns and its inverse block are complete)
 static void enqueue_wform(calipso_hip_solver* s, hipStream_t stream, int kb) {
@@ -1225,7 +1233,8 @@ static void enqueue_wform(calipso_hip_solver* s, hipStream_t stream, int kb) {
     const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
     if (rb <= 0) return;
     const Batch bt = batch_of(s).b;
-    hipLaunchKernelGGL(k_wform_product, dim3((rb / 32) * (w / 32), 1, bt.n), dim3(256), 0, stream, bt, NP, tb, kb, w, rb, s->S, s->Tinv, s->Wfac + wform_offset(NP, tb, kb));
+    const int rows = wform_rows(s, rb);
+    hipLaunchKernelGGL(k_wform_product, dim3((rows / 32) * (w / 32), 1, bt.n), dim3(256), 0, stream, bt, NP, tb, kb, w, rb, rows, s->S, s->Tinv, s->Wfac + wform_offset(NP, tb, kb));
 }
 static void enqueue_trsv_wform(calipso_hip_solver* s, double* x) {
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), nb = (NP + tb - 1) / tb;
@@ -1236,20 +1245,21 @@ static void enqueue_trsv_wform(calipso_hip_solver* s, double* x) {
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
         const double* Wb = s->Wfac + wform_offset(NP, tb, kb);
-        if (w > 512) hipLaunchKernelGGL((k_trsv_fwd<16, 32, 32>), dim3((w + rb) / 16, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z);
-        else hipLaunchKernelGGL((k_trsv_fwd<16, 16, 32>), dim3((w + rb) / 16, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z);
+        const int rows = wform_rows(s, rb);
+        if (w > 512) hipLaunchKernelGGL((k_trsv_fwd<16, 32, 32>), dim3((w + rows) / 16, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z);
+        else hipLaunchKernelGGL((k_trsv_fwd<16, 16, 32>), dim3((w + rows) / 16, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z);
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
         const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
         const double* Wb = s->Wfac + wform_offset(NP, tb, kb);
-        const int nch = (w + rb + 63) / 64;
-        if (nch <= 8) launch_trsv_bwd<8>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
-        else if (nch <= 16) launch_trsv_bwd<16>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
-        else if (nch <= 24) launch_trsv_bwd<24>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
-        else if (nch <= 32) launch_trsv_bwd<32>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
-        else if (nch <= 40) launch_trsv_bwd<40>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
-        else if (nch <= 48) launch_trsv_bwd<48>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
-        else launch_trsv_bwd<64>(s->stream, nz, bt, kb, tb, w, rb, s->Tinv, Wb, z, x);
+        const int rows = wform_rows(s, rb), nch = (w + rows + 63) / 64;
+        if (nch <= 8) launch_trsv_bwd<8>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
+        else if (nch <= 16) launch_trsv_bwd<16>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
+        else if (nch <= 24) launch_trsv_bwd<24>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
+        else if (nch <= 32) launch_trsv_bwd<32>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
+        else if (nch <= 40) launch_trsv_bwd<40>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
+        else if (nch <= 48) launch_trsv_bwd<48>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
+        else launch_trsv_bwd<64>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
     }
 }
 

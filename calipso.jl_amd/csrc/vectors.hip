@@ -857,9 +857,307 @@ __global__ __launch_bounds__(RT) void k_refine_x(BatchSc bt, Dims d, int have_m,
     }
 }
 
+// ---- tail of a condensed solve in ONE launch: t2 = [gx; hx] dx, back-substitution + recovery (k_recover), and the local rows of the refinement residual that
+// follows (k_refine_local) -------------------------------------------------------------------------------------------------------------------------------
+// Every refinement round used to run  k_gemv_n_partial -> k_gemv_n_reduce -> k_recover -> k_refine_local: four dependent launches of 4 - 12 us in which only the first
+// moves data worth mentioning.  Here a workgroup owns up to 16 consecutive rows of [gx; hx] that are WHOLE constraints (the table `grp`, built on the host: equality
+// rows and nonnegative entries one by one, second-order cones undivided — handles whose cones all have dimension <= 4), forms their entries of t2 completely (16 rows
+// x 32 column parts, 32 columns per thread and pass, all loads of a pass in flight; partial sums combined in a fixed order through LDS), and the thread that owns a
+// constraint goes straight on with what k_recover and k_refine_local do for it — same operations in the same order, the new step entries handed over in registers.
+// The x entries of the step are spread over the workgroups.  Nothing crosses constraints, so no workgroup waits for another.
+struct TailArgs {
+    const double* w; const double* res; const double* resid; const double* wz; const double* Wsoc;
+    double* rsym; double* dsym; double* step; double* accum; double* zsx; double* e; double* t1;
+    int zsx_mode, do_refine;
+};
+__device__ __forceinline__ double tail_equality(const Dims& d, const Scalars& sc, const TailArgs& A, int k, double t2k) {
+    const double Hrr = sc.rho + sc.ep;
+    const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
+    const double dy = -1.0 * omega_y * (A.rsym[d.nx + k] - t2k);
+    A.dsym[d.nx + k] = dy;
+    double zk = t2k;
+    if (A.zsx_mode == 2) zk = A.zsx[k] + t2k;
+    if (A.zsx_mode) A.zsx[k] = zk; else zk = A.zsx[k];
+    const double dr = (A.res[d.orr() + k] + dy) / Hrr;
+    A.step[d.oy() + k] = dy;
+    A.step[d.orr() + k] = dr;
+    double vy = dy, vr = dr;
+    if (A.accum) { vy = A.accum[d.oy() + k] + dy; vr = A.accum[d.orr() + k] + dr; A.accum[d.oy() + k] = vy; A.accum[d.orr() + k] = vr; }
+    if (!A.do_refine) return 0.0;
+    // k_refine_local, equality item
+    const int ir = d.orr() + k, iy = d.oy() + k;
+    const double hr = (sc.rho + sc.ep) * vr - vy;
+    const double er = A.resid[ir] - hr;
+    const double hy = zk + (-vr + (0.0 - sc.ed) * vy);
+    const double ey = A.resid[iy] - hy;
+    A.e[ir] = er; A.e[iy] = ey;
+    double b = ey;
+    b += er / Hrr;
+    A.rsym[d.nx + k] = b;
+    A.t1[k] = omega_y * b;
+    return fmax(fabs(er), fabs(ey));
+}
+__device__ __forceinline__ double tail_nonnegative(const Dims& d, const Scalars& sc, const TailArgs& A, int k, double t2k) {
+    const double Hss = 0.0 + sc.ep;
+    const double dz = -1.0 * A.wz[k] * (A.rsym[d.nx + d.ne + k] - t2k);
+    A.dsym[d.nx + d.ne + k] = dz;
+    double zk = t2k;
+    if (A.zsx_mode == 2) zk = A.zsx[d.ne + k] + t2k;
+    if (A.zsx_mode) A.zsx[d.ne + k] = zk; else zk = A.zsx[d.ne + k];
+    const double Sb = A.w[d.os() + k] - sc.ed, Ti = A.w[d.ot() + k], Pi = Hss;
+    const double rt = A.res[d.ot() + k], rs = A.res[d.os() + k];
+    const double ds = (rt + Sb * (rs + dz)) / (Ti + Sb * Pi);
+    const double dt = (rt - Ti * ds) / Sb;
+    A.step[d.oz() + k] = dz; A.step[d.os() + k] = ds; A.step[d.ot() + k] = dt;
+    double vz = dz, vs = ds, vt = dt;
+    if (A.accum) {
+        vz = A.accum[d.oz() + k] + dz; vs = A.accum[d.os() + k] + ds; vt = A.accum[d.ot() + k] + dt;
+        A.accum[d.oz() + k] = vz; A.accum[d.os() + k] = vs; A.accum[d.ot() + k] = vt;
+    }
+    if (!A.do_refine) return 0.0;
+    const int is = d.os() + k, iz = d.oz() + k, it = d.ot() + k;
+    const double hs = (0.0 + sc.ep) * vs - vz - vt;
+    const double es = A.resid[is] - hs;
+    const double hz = zk + (-vs + (0.0 - sc.ed) * vz);
+    const double ez = A.resid[iz] - hz;
+    const double ht = Ti * vs + (A.w[d.os() + k] - sc.ed) * vt;
+    const double et = A.resid[it] - ht;
+    A.e[is] = es; A.e[iz] = ez; A.e[it] = et;
+    double b = ez;
+    b += (et + Sb * es) / (Ti + Sb * Pi);
+    A.rsym[d.nx + d.ne + k] = b;
+    A.t1[d.ne + k] = A.wz[k] * b;
+    return fmax(fmax(fabs(es), fabs(ez)), fabs(et));
+}
+// second-order cone j of dimension <= 4; t2c[a] = entry of t2 of its row a
+__device__ __forceinline__ double tail_soc_small(const Dims& d, const Scalars& sc, const ConeDev& cd, const TailArgs& A, int j, const double* t2c) {
+    constexpr int MD = 4;
+    const double Hss = 0.0 + sc.ep;
+    const int st = cd.soc_start[j], dim = cd.soc_dim[j], woff = cd.soc_woff[j];
+    double sl[MD], t[MD], rs[MD], rt[MD], bb[MD], tt[MD], zz[MD], W[MD * MD], az[MD], as[MD], at[MD], res_s[MD], res_z[MD], res_t[MD];
+#pragma unroll
+    for (int a = 0; a < MD; ++a) {
+        const bool in = a < dim;
+        sl[a] = in ? A.w[d.os() + st + a] : 0.0; t[a] = in ? A.w[d.ot() + st + a] : 0.0;
+        rs[a] = in ? A.res[d.os() + st + a] : 0.0; rt[a] = in ? A.res[d.ot() + st + a] : 0.0;
+        bb[a] = in ? A.rsym[d.nx + d.ne + st + a] : 0.0; tt[a] = in ? t2c[a] : 0.0;
+        zz[a] = (in && A.zsx_mode != 1) ? A.zsx[d.ne + st + a] : 0.0;
+        az[a] = (in && A.accum) ? A.accum[d.oz() + st + a] : 0.0; as[a] = (in && A.accum) ? A.accum[d.os() + st + a] : 0.0; at[a] = (in && A.accum) ? A.accum[d.ot() + st + a] : 0.0;
+        res_s[a] = (in && A.do_refine) ? A.resid[d.os() + st + a] : 0.0; res_z[a] = (in && A.do_refine) ? A.resid[d.oz() + st + a] : 0.0;
+        res_t[a] = (in && A.do_refine) ? A.resid[d.ot() + st + a] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < MD * MD; ++e) W[e] = 0.0;
+#pragma unroll
+    for (int c = 0; c < MD; ++c)
+#pragma unroll
+        for (int a = 0; a < MD; ++a) if (a < dim && c < dim) W[a + c * MD] = A.Wsoc[woff + a + c * dim];
+    double u[MD], v[MD], ds[MD], o[MD], dz[MD], zk[MD];
+#pragma unroll
+    for (int a = 0; a < MD; ++a) { o[a] = bb[a] - tt[a]; u[a] = 0.0; v[a] = 0.0; ds[a] = 0.0; dz[a] = 0.0; zk[a] = A.zsx_mode == 1 ? tt[a] : (A.zsx_mode == 2 ? zz[a] + tt[a] : zz[a]); }
+    if (A.zsx_mode) {
+#pragma unroll
+        for (int a = 0; a < MD; ++a) if (a < dim) A.zsx[d.ne + st + a] = zk[a];
+    }
+#pragma unroll
+    for (int a = 0; a < MD; ++a) if (a < dim) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < MD; ++c) if (c < dim) s += W[a + c * MD] * o[c];
+        dz[a] = -1.0 * s;
+        A.dsym[d.nx + d.ne + st + a] = dz[a];
+    }
+    const double sb1 = sl[0] - sc.ed;
+    u[0] = t[0] + sb1 * Hss;
+#pragma unroll
+    for (int k = 1; k < MD; ++k) if (k < dim) u[k] = t[k] + sl[k] * Hss;
+    double acc = sb1 * (rs[0] + dz[0]);
+#pragma unroll
+    for (int k = 1; k < MD; ++k) if (k < dim) acc += sl[k] * (rs[k] + dz[k]);
+    v[0] = rt[0] + acc;
+#pragma unroll
+    for (int k = 1; k < MD; ++k) if (k < dim) v[k] = rt[k] + (sl[k] * (rs[0] + dz[0]) + sb1 * (rs[k] + dz[k]));
+    arrow_inverse_small<MD>(dim, u, v, ds);
+    acc = t[0] * ds[0];
+#pragma unroll
+    for (int k = 1; k < MD; ++k) if (k < dim) acc += t[k] * ds[k];
+    v[0] = rt[0] - acc;
+#pragma unroll
+    for (int k = 1; k < MD; ++k) if (k < dim) v[k] = rt[k] - (t[k] * ds[0] + t[0] * ds[k]);
+    u[0] = sb1;
+#pragma unroll
+    for (int k = 1; k < MD; ++k) if (k < dim) u[k] = sl[k];
+    arrow_inverse_small<MD>(dim, u, v, o);                       // o = dt
+    double lvz[MD], lvs[MD], lvt[MD];
+#pragma unroll
+    for (int k = 0; k < MD; ++k) {
+        lvz[k] = dz[k]; lvs[k] = ds[k]; lvt[k] = o[k];
+        if (k < dim) {
+            A.step[d.oz() + st + k] = dz[k]; A.step[d.os() + st + k] = ds[k]; A.step[d.ot() + st + k] = o[k];
+            if (A.accum) {
+                lvz[k] = az[k] + dz[k]; lvs[k] = as[k] + ds[k]; lvt[k] = at[k] + o[k];
+                A.accum[d.oz() + st + k] = lvz[k]; A.accum[d.os() + st + k] = lvs[k]; A.accum[d.ot() + st + k] = lvt[k];
+            }
+        }
+    }
+    if (!A.do_refine) return 0.0;
+    // k_refine_local, small cone
+    double m = 0.0;
+    double qs[MD], qt[MD], qz[MD];
+#pragma unroll
+    for (int a = 0; a < MD; ++a) { qs[a] = 0.0; qt[a] = 0.0; qz[a] = 0.0; }
+#pragma unroll
+    for (int a = 0; a < MD; ++a) if (a < dim) {
+        const int k = st + a;
+        const double hs = (0.0 + sc.ep) * lvs[a] - lvz[a] - lvt[a];
+        qs[a] = res_s[a] - hs;
+        const double hz = zk[a] + (-lvs[a] + (0.0 - sc.ed) * lvz[a]);
+        qz[a] = res_z[a] - hz;
+        double ht;
+        if (a == 0) {
+            ht = t[0] * lvs[0] + (sl[0] - sc.ed) * lvt[0];
+#pragma unroll
+            for (int q = 1; q < MD; ++q) if (q < dim) ht += t[q] * lvs[q] + sl[q] * lvt[q];
+        } else {
+            ht = t[a] * lvs[0] + sl[a] * lvt[0];
+            ht += t[0] * lvs[a] + (sl[0] - sc.ed) * lvt[a];
+        }
+        qt[a] = res_t[a] - ht;
+        A.e[d.os() + k] = qs[a]; A.e[d.oz() + k] = qz[a]; A.e[d.ot() + k] = qt[a];
+        m = fmax(m, fmax(fmax(fabs(qs[a]), fabs(qz[a])), fabs(qt[a])));
+    }
+    double uu[MD], vv[MD], oo[MD];
+#pragma unroll
+    for (int a = 0; a < MD; ++a) { uu[a] = 0.0; vv[a] = 0.0; oo[a] = 0.0; }
+    uu[0] = t[0] + sb1 * Hss;
+#pragma unroll
+    for (int k = 1; k < MD; ++k) if (k < dim) uu[k] = t[k] + sl[k] * Hss;
+    double ac2 = sb1 * qs[0];
+#pragma unroll
+    for (int k = 1; k < MD; ++k) if (k < dim) ac2 += sl[k] * qs[k];
+    vv[0] = ac2 + qt[0];
+#pragma unroll
+    for (int k = 1; k < MD; ++k) if (k < dim) vv[k] = (sl[k] * qs[0] + sb1 * qs[k]) + qt[k];
+    arrow_inverse_small<MD>(dim, uu, vv, oo);
+#pragma unroll
+    for (int k = 0; k < MD; ++k) if (k < dim) { oo[k] = qz[k] + oo[k]; A.rsym[d.nx + d.ne + st + k] = oo[k]; }
+#pragma unroll
+    for (int a = 0; a < MD; ++a) if (a < dim) {
+        double ss = 0.0;
+#pragma unroll
+        for (int b2 = 0; b2 < MD; ++b2) if (b2 < dim) ss += W[a + b2 * MD] * oo[b2];
+        A.t1[d.ne + st + a] = ss;
+    }
+    return m;
+}
+
+constexpr int TAIL_ROWS = 16, TAIL_PARTS = 32, TAIL_CPT = 32;
+__global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc bt, Dims d, ConeDev cd, const int* __restrict__ grp, int ngrp, const int* rowrange, const double* __restrict__ Z,
+                                                                        const double* __restrict__ dx, const double* w, const double* res, const double* resid, const double* wz,
+                                                                        const double* Wsoc, double* rsym, double* dsym, double* step, double* accum, double* zsx, double* e, double* t1,
+                                                                        double* __restrict__ part, int zsx_mode, int do_refine) {
+    constexpr int ROWS = TAIL_ROWS, PARTS = TAIL_PARTS, CPT = TAIL_CPT, W = PARTS * CPT;
+    __shared__ double xs[W];
+    __shared__ double psum[PARTS][ROWS];
+    __shared__ double t2s[ROWS];
+    __shared__ double sm[ROWS * PARTS / 64];
+    inst_shift(bt.b, Z, dx, w, res, resid, wz, Wsoc, rsym, dsym, step, zsx, e, t1, part);
+    if (accum) inst_shift(bt.b, accum);
+    if (rowrange) inst_shift_i(bt.b, rowrange);
+    const Scalars sc = bt.sc[blockIdx.z];
+    const int tid = threadIdx.x, r = tid % ROWS, p = tid / ROWS;
+    const int g = blockIdx.x;
+    const int r0 = grp[g], nrows = grp[g + 1] - r0;
+    // ---- t2 rows r0 .. r0 + nrows - 1 ------------------------------------------------------------------------------
+    const bool live = r < nrows;
+    const double* Zr = Z + r0 + r;
+    // an analysed structure (structure.hip): the columns of the row that can be non-zero — the loads outside are predicated off, the sums are those of the dense rows
+    int jlo = 0, jhi = d.nx;
+    if (rowrange && live) { jlo = rowrange[2 * (r0 + r)]; jhi = rowrange[2 * (r0 + r) + 1]; }
+    double acc = 0.0;
+    for (int c0 = 0; c0 < d.nx; c0 += W) {
+        double v[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) { const int c = c0 + p + PARTS * q; v[q] = (live && c < d.nx && c >= jlo && c < jhi) ? Zr[(size_t)c * d.m] : 0.0; }
+        if (c0) __syncthreads();
+        for (int i = tid; i < W; i += ROWS * PARTS) xs[i] = c0 + i < d.nx ? dx[c0 + i] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) acc += v[q] * xs[p + PARTS * q];
+    }
+    psum[p][r] = acc;
+    // ---- x entries of the step (this workgroup's share) ---------------------------------------------------------------
+    {
+        const int xsz = (d.nx + ngrp - 1) / ngrp, xend = min(d.nx, (g + 1) * xsz);
+        for (int i = g * xsz + tid; i < xend; i += ROWS * PARTS) {
+            const double v = dx[i];
+            dsym[i] = v; step[i] = v;
+            if (accum) accum[i] += v;
+        }
+    }
+    __syncthreads();
+    if (tid < ROWS) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) s += psum[q][tid];
+        t2s[tid] = s;
+    }
+    __syncthreads();
+    // ---- the constraints of these rows --------------------------------------------------------------------------------
+    double m = 0.0;
+    if (tid < nrows) {
+        TailArgs A{w, res, resid, wz, Wsoc, rsym, dsym, step, accum, zsx, e, t1, zsx_mode, do_refine};
+        const int row = r0 + tid;
+        if (row < d.ne) m = tail_equality(d, sc, A, row, t2s[tid]);
+        else if (row < d.ne + d.q) m = tail_nonnegative(d, sc, A, row - d.ne, t2s[tid]);
+        else {
+            const int c = row - d.ne, j = cd.entry_soc[c];
+            if (c == cd.soc_start[j]) m = tail_soc_small(d, sc, cd, A, j, t2s + tid);      // (the cone's rows follow its first one inside the group)
+        }
+    }
+    if (do_refine) {
+        const double mr = block_max(m, sm);
+        if (tid == 0) part[g] = mr;
+    }
+}
+// can the solves of this handle (or of the group launch in progress) end in k_solve_tail?
+static bool solve_tail_ok(const calipso_hip_solver* s) {
+    static const bool env = [] { const char* e = getenv("CALIPSO_HIP_SOLVE_TAIL"); return !e || atoi(e) != 0; }();
+    return env && s->zgrp && s->d.m > 0 && !s->compact && !(s->blocks.on && s->blocks_effective);
+}
+bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool with_refine) {
+    if (!solve_tail_ok(s)) return false;
+    const BatchSc B = batch_of(s);
+    const double* res = which == 0 ? s->residual : s->residual_error;
+    double* st = which == 0 ? s->step : s->step_correction;
+    hipLaunchKernelGGL(k_solve_tail, dim3(s->n_zgrp, 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), 0, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
+                       s->residual, s->wz, s->Wsoc, s->residual_symmetric, s->step_symmetric, st, accumulate ? s->step : (double*)nullptr, s->zsx, s->residual_error, s->t1, s->refpart,
+                       which == 0 ? 1 : 2, with_refine ? 1 : 0);
+    s->refine_local_done = with_refine;
+    if (with_refine) s->refparts = s->n_zgrp;
+    return true;
+}
+// the row groups of k_solve_tail: whole constraints, at most 16 rows each (host, at create)
+void solve_tail_plan(const Dims& d, const std::vector<int>& soc_start, const std::vector<int>& soc_dim, std::vector<int>& grp) {
+    grp.clear();
+    if (d.m == 0 || d.n_wide > 0) return;
+    grp.push_back(0);
+    int fill = 0, row = 0;
+    auto item = [&](int size) {
+        if (fill + size > TAIL_ROWS) { grp.push_back(row); fill = 0; }
+        fill += size; row += size;
+    };
+    for (int k = 0; k < d.ne + d.q; ++k) item(1);
+    for (size_t j = 0; j < soc_dim.size(); ++j) item(soc_dim[j]);
+    grp.push_back(row);
+    (void)soc_start;
+}
+
 void launch_refine_local(calipso_hip_solver* s) {
+    if (s->refine_local_done) { s->refine_local_done = false; return; }       // k_solve_tail formed these rows with the step it had just recovered
     const BatchSc B = batch_of(s);
     const int items = s->d.ne + s->d.q + s->d.n_soc;
+    s->refparts = items ? (items + RL_THREADS - 1) / RL_THREADS + s->d.n_wide : 0;
     if (items == 0) return;
     hipLaunchKernelGGL(k_refine_local, dim3((items + RL_THREADS - 1) / RL_THREADS, 1, B.b.n), dim3(RL_THREADS), 0, s->stream, B, s->d, s->cone, s->solution, s->step,
                        s->residual, s->zsx, s->wz, s->Wsoc, s->residual_error, s->residual_symmetric, s->t1, s->refpart);
@@ -869,7 +1167,7 @@ void launch_refine_x(calipso_hip_solver* s, bool publish) {
     const BatchSc B = batch_of(s);
     const int items = s->d.ne + s->d.q + s->d.n_soc;
     hipLaunchKernelGGL(k_refine_x, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->d.m > 0 ? 1 : 0, s->step, s->residual, s->lxv, s->w1, s->w2, s->residual_error,
-                       s->residual_symmetric, s->xbuf, s->dscal, s->refpart, (items + RL_THREADS - 1) / RL_THREADS + s->d.n_wide,
+                       s->residual_symmetric, s->xbuf, s->dscal, s->refpart, s->refparts,
                        publish ? s->hscal_dev : (double*)nullptr, publish ? s->hseq_dev : (unsigned long long*)nullptr, publish ? ++s->pub_seq : 0ULL);
 }
 

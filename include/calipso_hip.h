@@ -420,7 +420,9 @@ int32_t calipso_hip_phase_times(calipso_hip_solver*, double out[9]);
 /* per-kernel figures of the last factorisation and the handle's layout (bench.py: the live launch durations behind `roofline`):
  * [0] ms of the panel-step launches of the LDL^T of the Schur complement (k_ldl_diag + k_ldl_step: the pivot chain, one launch per 64
  *     pivots; HIP events around exactly these launches; the rest of [3] above is the parallel finish: factor columns + block inverses)
- * [1] number of those launches   [2] NP = padded order of the Schur complement   [3] bytes of the handle's device slab   [4..7] reserved (0) */
+ * [1] number of those launches   [2] NP = padded order of the Schur complement   [3] bytes of the handle's device slab
+ * [4] ms of ONE launch of the refinement residual's mat-vec kernel (k_gemv_t2_and_n: [gx; hx]' times two vectors and Lxx times one, the first residual of the
+ *     last calipso_hip_newton_step; 0 when the handle takes another path) and [5] the bytes it reads, 8 (m nx + nx^2)   [6..7] reserved (0) */
 int32_t calipso_hip_kernel_times(calipso_hip_solver*, double out[8]);
 int32_t calipso_hip_synchronize(calipso_hip_solver*);
 
