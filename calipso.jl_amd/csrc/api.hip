@@ -305,6 +305,9 @@ int32_t calipso_hip_destroy(H* s) {
     for (auto& e : s->ev_side) if (e) (void)hipEventDestroy(e);
     if (s->hprog) (void)hipHostFree(s->hprog);
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
+    if (s->chain_flags) (void)hipFree(s->chain_flags);
+    if (s->ev_worker) (void)hipEventDestroy(s->ev_worker);
+    if (s->stream3) (void)hipStreamDestroy(s->stream3);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return CALIPSO_OK;
@@ -548,10 +551,12 @@ static int do_factorize(H* s, int64_t inertia[3]) {
     if (s->ldl_pub_seq) {
         // the last diagonal block published the counts when the pivot chain ended: the host goes on queueing behind the finish of the last solve block
         if (wait_published(s, s->ldl_pub_seq)) return CALIPSO_ERR_HIP;
+        if (!calipso::ldl_chain_ok(s)) { SYNC(); return CALIPSO_ERR_HIP; }
     } else {
         CK(hipMemcpyAsync(s->hicount, s->icount, sizeof(int) * 6, hipMemcpyDeviceToHost, s->stream));
         SYNC();
         factor_times(s);
+        if (!calipso::ldl_chain_ok(s)) return CALIPSO_ERR_HIP;
     }
     s->stats.factorizations += 1;
     s->phase_ms[8] += 1.0;

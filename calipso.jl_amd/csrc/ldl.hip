@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <mutex>
 
 namespace calipso {
@@ -162,8 +163,9 @@ __device__ __forceinline__ void blk_XW(v4d t, int Rr, int Cc, double* __restrict
 
 // acc: tile (R, C) = (w >> 2, w & 3) of the block, acc[q] = A(16 R + fr, 16 C + fk + 4 q) with fr = lane & 15, fk = lane >> 4 (tiles above the diagonal are
 // ignored).  smem: DIAG_LDS_DOUBLES doubles that no wavefront of the workgroup still reads (the caller has a barrier behind its last LDS read).
+// Mkeep (the persistent chain of k_ldl_chain): an LDS copy of M ([c][k], row stride LDT) for the chain's own next update.
 __device__ __forceinline__ void diag_block(double* __restrict__ smem, v4d acc, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
-                                           double* __restrict__ Tinv, double* __restrict__ Minv, int* __restrict__ icount) {
+                                           double* __restrict__ Tinv, double* __restrict__ Minv, int* __restrict__ icount, double* __restrict__ Mkeep = nullptr) {
     double* Lk = smem;                       // Lk[i][k] = L[i][k] (k fastest)
     double* XT = Lk + NB * LDT;              // XT[a][r] = X[r][a]
     double* XTs = XT + NB * LDT;             // ... scaled by the reciprocal pivot of row r
@@ -171,7 +173,9 @@ __device__ __forceinline__ void diag_block(double* __restrict__ smem, v4d acc, i
     double* cp = Yk + NB * YS;               // cp[c][i]: column block r after the updates of the rounds before, for its owner
     double* dpiv = cp + 16 * CPS;            // the 64 pivots
     double* dinv = dpiv + NB;                // and their reciprocals
-    const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));            // (opaque: inside the persistent loop of k_ldl_chain nothing derived from it may be hoisted and held across the rounds)
+    const int i = tid & 63, w = tid >> 6;
     const int R = w >> 2, C = w & 3, fr = i & 15, fk = i >> 4;
     v4d xacc = (v4d){0.0, 0.0, 0.0, 0.0};   // a block product of the inverse carried from one phase to the next
     LDL_STAMP(k0 / NB, 2);
@@ -250,6 +254,10 @@ __device__ __forceinline__ void diag_block(double* __restrict__ smem, v4d acc, i
         LDL_STAMP(k0 / NB, 6);
 #pragma unroll
         for (int q = 0; q < 4; ++q) Mo[(wb * 16 + fr) + (size_t)(wa * 16 + fk + 4 * q) * NB] = m[q];   // lane holds M(a = fk + 4 q, b = fr) = M(b, a): 128-byte runs along fr
+        if (Mkeep) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Mkeep[(wb * 16 + fr) * LDT + wa * 16 + fk + 4 * q] = m[q];     // Mkeep[c][k] = what form_Z reads as Mk[c + k * NB]
+        }
     }
     // everything that goes to global memory leaves here, after the last barrier: D and the inertia counts (compute_inertia!), the strictly
     // lower L of the block and X = L11^-1 on the diagonal of the triangular-solve inverse block (zeros above), both from their LDS copies:
@@ -426,8 +434,12 @@ __device__ __forceinline__ void form_Z(const double* __restrict__ Ap, int NP, co
 template <int MODE>
 __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int nx, int k0, int ntiles, int tb, double* __restrict__ S, double* __restrict__ Minv,
                                                          double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount,
-                                                         unsigned long long* __restrict__ hprog = nullptr, unsigned long long ptag = 0) {
+                                                         unsigned long long* __restrict__ hprog = nullptr, unsigned long long ptag = 0, unsigned* __restrict__ tready = nullptr,
+                                                         unsigned tval = 0) {
     constexpr int NH = MODE == 2 ? 2 : 1;   // panels per pass
+    // tready != nullptr (one instance, MODE 0): the DECOUPLED schedule (k_ldl_chain below).  Tile 0 — the next diagonal block — belongs to the persistent chain
+    // workgroup; workgroup 0 of this launch takes tiles 1 and 2 instead (the raw panel rows and the diagonal tile the chain needs NEXT), stores them, releases them
+    // (agent scope) and raises tready = tval; the other workgroups share the tiles from 3 on.  The host queues the launch once the chain has published M of this panel.
     // progress word for the host (mapped memory; launch_ldl): this step has started, so everything the steps before it wrote is complete
     if (hprog && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hprog, ptag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __shared__ double smem[step_lds_doubles(NH)];
@@ -448,14 +460,18 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
     long long item = 0, item_end = 0, off = 0;
     {
         const int nz = bt.n, W = (int)gridDim.x, lin = (int)blockIdx.x;
-        if (lin < nz) { off = bt.delta[lin]; }
-        else {
+        if (lin < nz) {
+            off = bt.delta[lin];
+            if (tready) { if (ntiles < 2) return; item = 0; item_end = ntiles - 1 < 2 ? ntiles - 1 : 2; t = 1; }
+        } else {
             if (ntiles < 2) return;
             const int k = lin & 7;
             const int first = nz + ((k - (nz & 7) + 8) & 7);              // first worker of this XCD (the host grid holds one for every XCD)
             const int u = (lin - first) >> 3, Uk = (W - 1 - first) / 8 + 1;
-            const long long G = (long long)nz * (ntiles - 1);
-            const long long lo = (long long)k * G / 8, hi = (long long)(k + 1) * G / 8;
+            const long long lead = tready ? 2 : 0;                        // (decoupled: the first two items are workgroup 0's)
+            const long long G = (long long)nz * (ntiles - 1) - lead;
+            if (G <= 0) return;
+            const long long lo = lead + (long long)k * G / 8, hi = lead + (long long)(k + 1) * G / 8;
             const long long chunk = (hi - lo + Uk - 1) / Uk;
             item = lo + (long long)u * chunk; item_end = item + chunk < hi ? item + chunk : hi;
             if (item >= item_end) return;
@@ -572,7 +588,19 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) (S + (i0 + (size_t)j0 * NP))[offC + 4 * r * NP] = cS[r];
-        if (!more) return;
+        if (!more) {
+            if (tready && blockIdx.x == 0) {
+                // hand-over to the chain workgroup (another CU, possibly another XCD): every wave's stores are out (__syncthreads waits for them), ONE lane
+                // releases at agent scope, then the flag (MI355X_MICROARCH.md: plain stores -> barrier -> release fence -> asm wait -> relaxed agent flag)
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(tready, tval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
         t = tn; i0 = in0; j0 = jn0; newrow = nextrow;
         item += 1; off += doff; S += doff; Minv += doff; Mk += doff;
 #pragma unroll
@@ -583,6 +611,113 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
 #ifdef CALIPSO_LDL_TRACE
         ++bulk_tile;
 #endif
+    }
+}
+
+// ---- the DECOUPLED schedule (experiment, off unless CALIPSO_HIP_LDL_DECOUPLED=1): one persistent workgroup carries the pivot chain through ALL panels ------------
+// In the launch-per-panel schedule the chain workgroup of launch k cannot start before launch k - 1 has ended everywhere (kernel boundary: 2.4 us on the chain
+// every 64 pivots, then a cold read of M_k and of the two tiles it needs).  Here the chain is ONE launch that never ends between panels (k_ldl_chain, on the
+// handle's main stream); the trailing updates are launches of k_ldl_step<0> (tready mode) on a second stream, queued by the host — which only waits for the
+// factorisation anyway — as soon as the chain has published the M_k they apply:
+//     chain, panel k:   tiles P = (k+1, k), Q = (k+1, k+1) of update k - 1  (flag tready, raised by workgroup 0 of that update after its first two tiles)
+//                       ->  Q -= P M_k P'  (M_k from LDS, where the previous panel left it)  ->  64 pivots, X, M_{k+1} (diag_block)  ->  release, "M_{k+1} is there"
+//     host:             sees M_k  ->  queues update k, whose workgroup 0 takes tiles (k+2, k+1), (k+2, k+1) FIRST, releases them and raises tready
+// Hand-overs follow MI355X_MICROARCH.md: plain stores -> barrier -> ONE agent-scope release -> flag; reader: ONE relaxed poll -> ONE agent-scope acquire -> barrier
+// -> plain loads.  Every wait is bounded (a chain that is not served stores the failure tag and leaves; the factorisation is reported as failed), and the streams
+// are probed once per handle for distinct hardware queues (a chain whose updates sit behind it in its own queue would never be served).
+// MEASURED (C3, profiles/r04_decoupled_chain_timeline.txt): the same arithmetic and the same bits, 0.82-0.85 ms per chain against 0.835 for the launch-per-panel
+// schedule — the release (1.7 us) and the poll + acquire (1.7 us) on the chain cost what the kernel boundary did, and the two tiles the chain waits for come out
+// of a relay (publish -> host -> launch -> two tile updates -> release -> acquire -> cold loads: ~20 us) that is as long as a panel of the chain itself.
+// A second form — updates queued ahead of time and gated on a device word, write-through hand-overs without fences, the next tiles prefetched under the previous
+// block's last phases — brought the chain's own work to 17.7 us per panel (from 21.0) and lost it again waiting 7 - 28 us per panel for the relay; it is not kept.
+constexpr unsigned CHAIN_FAIL = 0xffffu;
+__device__ __forceinline__ bool wait_word(const unsigned* p, unsigned target, unsigned maxspins) {
+    for (unsigned spins = 0; spins < maxspins; ++spins) {
+        if ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return true;      // (wrap-safe; every lane reads the same word)
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+__global__ __launch_bounds__(TR_THREADS) void k_ldl_chain(int NP, int nx, int nblk, int tb, double* __restrict__ S, double* __restrict__ Minv, double* __restrict__ Dx,
+                                                           double* __restrict__ Tinv, int* __restrict__ icount, const unsigned* __restrict__ tready, unsigned tbase,
+                                                           unsigned long long* __restrict__ hchain, unsigned long long epoch, int* __restrict__ hcount,
+                                                           unsigned long long* __restrict__ hseq, unsigned long long seq) {
+    __shared__ double smem[step_lds_doubles(1)];
+    __shared__ double Mkeep[NB * LDT];
+    __shared__ int dead;
+    double* Zs = smem;
+    double* Ys = smem + TT * LDT;
+    if (threadIdx.x == 0) dead = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int k = -1; k + 1 < nblk; ++k) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));         // (opaque per panel: what is derived from the lane index is formed here, not hoisted out of the loop and held across diag_block)
+        const int lane = tid & 63, wave = tid >> 6;
+        const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fk = lane >> 4;
+        const int row = (lane & 7) + 8 * ((lane >> 4) & 1) + 16 * (wave & 3);
+        const int cb = ((lane >> 3) & 1) + 2 * ((lane >> 5) & 1) + 4 * (wave >> 2);
+        const int k0 = k * NB, r0 = k0 + NB;
+        const int offC = (wr * 16 + fr) + (wc * 16 + fk) * NP, offY = row + cb * NP;
+        double cS[4];
+        if (k < 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cS[r] = wr >= wc ? S[offC + 4 * r * NP] : 0.0;
+        } else {
+            // update k - 1's first two tiles (k = 0: they are the Schur complement's own): wave 0 waits for the word and acquires, the others follow behind the barrier
+            if (k > 0) {
+                if (wave == 0) {
+                    if (!dead && !wait_word(tready, tbase + (unsigned)k, 1u << 19)) dead = 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+            }
+            LDL_STAMP(r0 / NB, 0);
+            double pn[4];
+            const double* Qp = S + ((size_t)r0 + (size_t)r0 * NP);
+            const double* Pp = S + ((size_t)r0 + (size_t)k0 * NP);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cS[r] = Qp[offC + 4 * r * NP];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) pn[it] = Pp[offY + it * 16 * NP];
+            // Ys <- P (rows of the raw panel: both operands of this tile), Z = P M_k -> Zs, Q -= Z P'
+#pragma unroll
+            for (int it = 0; it < 4; ++it) Ys[row * LDT + cb + it * 16] = pn[it];
+            lds_barrier();
+            const v4d z = frag_product((unsigned)(uintptr_t)(Ys + (wr * 16 + fr) * LDT + fk), (unsigned)(uintptr_t)(Mkeep + (wc * 16 + fr) * LDT + fk));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Zs[(wr * 16 + fr) * LDT + wc * 16 + fk + 4 * r] = z[r];
+            lds_barrier();
+            LDL_STAMP(r0 / NB, 1);
+            const v4d acc = frag_product((unsigned)(uintptr_t)(Zs + (wr * 16 + fr) * LDT + fk), (unsigned)(uintptr_t)(Ys + (wc * 16 + fr) * LDT + fk));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cS[r] -= acc[r];
+            lds_barrier();
+        }
+        diag_block(smem, (v4d){cS[0], cS[1], cS[2], cS[3]}, NP, nx, r0, tb, S, Dx, Tinv, Minv, icount, Mkeep);
+        // M_{k+1} (and block k + 1's D, L, X) are stored: release, then tell the host, which queues update k + 1 (the last update with tiles of its own is nblk - 3).
+        // The LAST wave publishes, so that wave 0 is free to poll for the next tiles meanwhile
+        if (k + 3 < nblk) {
+            __syncthreads();                              // every wave's stores are out
+            if (tid == TR_THREADS - 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(hchain, epoch | (unsigned long long)(k + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    // the factor is complete: the six inertia counts go to their mapped host words (the three of the constraint part were counted before this launch), then the
+    // sequence number do_factorize waits for, then the chain's last tag (or the failure tag)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (hcount) {
+            for (int i = 0; i < 6; ++i) hcount[i] = __hip_atomic_load(icount + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __hip_atomic_store(hchain, epoch | (dead ? (unsigned long long)CHAIN_FAIL : (unsigned long long)nblk), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -810,9 +945,9 @@ static bool side_stream(calipso_hip_solver* s) {
     if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) return false;
     bool ok = true;
     if (!s->hprog) {
-        if (hipHostMalloc((void**)&s->hprog, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { s->hprog = nullptr; ok = false; }
+        if (hipHostMalloc((void**)&s->hprog, 4 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { s->hprog = nullptr; ok = false; }     // [0] updates, [1] chain
         else {
-            *s->hprog = 0;
+            s->hprog[0] = 0; s->hprog[1] = 0;
             if (hipHostGetDevicePointer((void**)&s->hprog_dev, s->hprog, 0) != hipSuccess) { s->hprog_dev = nullptr; ok = false; }
         }
     }
@@ -1335,6 +1470,121 @@ void ldl_drop_graphs(calipso_hip_solver* s) {       // the captured launch seque
     s->graph_ldl_tried = false; s->graph_ldl_fin_tried = false; s->graph_trsv_tried = false;
 }
 
+// The decoupled schedule (k_ldl_chain): one instance alone, dense S, the two-stream finish available; CALIPSO_HIP_LDL_DECOUPLED=1 turns it on.
+static bool ldl_decoupled(calipso_hip_solver* s) {
+    static const int env = [] { const char* e = getenv("CALIPSO_HIP_LDL_DECOUPLED"); return e ? atoi(e) : 0; }();     // an experiment (see k_ldl_chain): off unless asked for
+    return env && !s->cur && s->decoupled_ok >= 0 && ldl_overlap(s) && s->d.NP / NB >= 8;
+}
+// A kernel that waits for work of ANOTHER stream needs that stream on another hardware queue: HIP multiplexes streams onto a few queues, and a chain whose updates
+// sit behind it in its own queue would never be served.  Probed once per handle: a kernel on the first stream waits (bounded, ~80 ms at most) for a word that a
+// kernel on the second stream sets.
+__global__ void k_probe_wait(unsigned* __restrict__ flag, unsigned* __restrict__ out) {
+    unsigned seen = 2;
+    for (unsigned spins = 0; spins < (1u << 16); ++spins) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { seen = 1; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    out[0] = seen;
+}
+__global__ void k_probe_set(unsigned* __restrict__ flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static bool streams_concurrent(calipso_hip_solver* s, hipStream_t waiting, hipStream_t serving) {
+    unsigned* words = reinterpret_cast<unsigned*>(s->vtmp);              // [0] flag [1] result (scratch of the handle; nothing else runs on it now)
+    unsigned host[2] = {0u, 0u};
+    if (hipMemcpyAsync(words, host, sizeof host, hipMemcpyHostToDevice, waiting) != hipSuccess || hipStreamSynchronize(waiting) != hipSuccess) return false;
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, waiting, words, words + 1);
+    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, serving, words);
+    if (hipStreamSynchronize(serving) != hipSuccess || hipStreamSynchronize(waiting) != hipSuccess) return false;
+    if (hipMemcpy(host, words, sizeof host, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return host[1] == 1u;
+}
+static bool worker_stream(calipso_hip_solver* s) {
+    if (s->stream3) return true;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+    if (hipStreamCreateWithPriority(&s->stream3, hipStreamNonBlocking, greatest) != hipSuccess) { s->stream3 = nullptr; return false; }
+    if (hipEventCreateWithFlags(&s->ev_worker, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(s->stream3); s->stream3 = nullptr; s->ev_worker = nullptr; return false; }
+    return true;
+}
+// returns false when the schedule is not available (the caller takes the launch-per-panel one); on a chain that was not served sets s->ldl_failed
+static bool launch_ldl_decoupled(calipso_hip_solver* s) {
+    if (!side_stream(s) || !worker_stream(s)) return false;
+    if (s->decoupled_ok == 0) {          // first use: the chain (main stream) must run beside its updates and beside the finish
+        s->decoupled_ok = streams_concurrent(s, s->stream, s->stream3) && streams_concurrent(s, s->stream, s->stream2) ? 1 : -1;
+        if (s->decoupled_ok < 0) return false;
+    }
+    if (!s->chain_flags) {               // the flag word, in fine-grained (XCD-coherent) device memory
+        if (hipExtMallocWithFlags((void**)&s->chain_flags, 256, hipDeviceMallocFinegrained) != hipSuccess) { s->chain_flags = nullptr; s->decoupled_ok = -1; return false; }
+        if (hipMemset(s->chain_flags, 0, 256) != hipSuccess) { s->decoupled_ok = -1; return false; }
+    }
+    const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
+    const Batch bt = batch_of(s).b;
+    double* Minv = s->Ypanel;
+    s->ldl_overlap_on = true;
+    ldl_plan_ranges(s);
+    s->ldl_epoch += 1;
+    const unsigned long long epoch = s->ldl_epoch << 16;
+    const unsigned tbase = (unsigned)(s->ldl_epoch << 8);
+    unsigned* const tready = s->chain_flags;          // update k - 1 -> chain: tbase + k = "tiles (k+1, k), (k+1, k+1) are stored"
+    unsigned long long* const hchain = s->hprog + 1;
+    s->ldl_pub_seq = s->ldl_publish ? ++s->pub_seq : 0;
+    hipLaunchKernelGGL(k_ldl_chain, dim3(1), dim3(TR_THREADS), 0, s->stream, NP, s->d.nx, nblk, tb, s->S, Minv, s->Dx, s->Tinv, s->icount, tready, tbase, s->hprog_dev + 1, epoch,
+                       s->ldl_pub_seq ? s->hicount_dev : (int*)nullptr, s->hseq_dev, s->ldl_pub_seq);
+    (void)hipEventRecord(s->ev[14], s->stream);
+    // update kb applies panel kb to the tiles from (kb + 2, kb + 1) on (the last one that has tiles of its own is nblk - 3); the finish of the completed ranges runs
+    // beside the chain as in the launch-per-panel schedule (the updates carry the tags 0 .. nblk - 3)
+    const int resident = 248, last_update = nblk - 3;
+    auto grid = [&](int tiles) { const int workers = std::min(std::max(tiles - 3, 0), resident); return dim3(1 + (workers ? (workers + 7) / 8 * 8 + 7 : 0)); };
+    int forks = 0;
+    while (3 * forks < (int)s->ldl_feeds.size() && s->ldl_feeds[3 * forks] <= last_update) ++forks;
+    int next_update = 0, next_feed = 0;
+    unsigned long long spins = 0;
+    bool failed = false;
+    const auto t_start = std::chrono::steady_clock::now();
+    while (next_update <= last_update || next_feed < forks) {
+        const unsigned long long c = __atomic_load_n(hchain, __ATOMIC_ACQUIRE);
+        if (c == (epoch | (unsigned long long)CHAIN_FAIL)) { failed = true; break; }
+        if (next_update <= last_update && c >= (epoch | (unsigned long long)(next_update + 1)) && (c >> 16) == s->ldl_epoch) {
+            const int kb = next_update, k0 = kb * NB, ntr = (NP - k0 - NB) / TT, ntiles = ntr * (ntr + 1) / 2;
+            hipLaunchKernelGGL((k_ldl_step<0>), grid(ntiles), dim3(TR_THREADS), 0, s->stream3, bt, NP, s->d.nx, k0, ntiles, tb, s->S, Minv, s->Dx, s->Tinv, s->icount,
+                               s->hprog_dev, epoch | (unsigned long long)kb, tready, tbase + (unsigned)kb + 1u);
+            ++next_update; spins = 0;
+            continue;
+        }
+        if (next_feed < forks && __atomic_load_n(s->hprog, __ATOMIC_ACQUIRE) >= (epoch | (unsigned long long)s->ldl_feeds[3 * next_feed])) {
+            enqueue_feed(s, s->stream2, next_feed, true);
+            ++next_feed; spins = 0;
+            continue;
+        }
+        if ((++spins & 0xfffffu) == 0) {                  // nothing moved for a while (~10 ms): is the chain still there?
+            if (hipStreamQuery(s->stream) != hipErrorNotReady) { failed = true; break; }      // it has left (or the queue faulted) with updates / feeds still to hand out
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 20.0) { failed = true; break; }
+        }
+    }
+    s->ldl_step_launches = 1 + next_update;
+    s->ldl_forks = next_feed;
+    (void)hipEventRecord(s->ev_worker, s->stream3);
+    (void)hipStreamWaitEvent(s->stream, s->ev_worker, 0);          // the main stream (the chain) goes on when the last update is through
+    s->decoupled_check = true;                                      // do_factorize looks at the chain's last tag once it has the inertia counts
+    if (failed) {
+        s->err = "LDL^T: the pivot-chain workgroup was not served in time (decoupled schedule)";
+        s->ldl_failed = true;
+        (void)hipStreamSynchronize(s->stream3);
+        (void)hipStreamSynchronize(s->stream2);
+        (void)hipStreamSynchronize(s->stream);
+        s->ldl_pub_seq = 0;
+        s->ldl_forks = (int)s->ldl_feeds.size() / 3;      // nothing more to queue
+    }
+    return true;
+}
+// after the factorisation has been waited for: did the chain end with its last tag?
+bool ldl_chain_ok(calipso_hip_solver* s) {
+    if (!s->decoupled_check) return true;
+    s->decoupled_check = false;
+    const unsigned long long c = __atomic_load_n(s->hprog + 1, __ATOMIC_ACQUIRE);
+    if ((c & 0xffffu) == CHAIN_FAIL && (c >> 16) == s->ldl_epoch) { s->err = "LDL^T: the pivot-chain workgroup was not served in time (decoupled schedule)"; return false; }
+    return true;
+}
+
 // ev[14] marks the end of the panel steps (the pivot chain), so that their duration can be reported apart from the parallel finish
 // (calipso_hip_kernel_times)
 void launch_ldl(calipso_hip_solver* s) {
@@ -1366,6 +1616,10 @@ void launch_ldl(calipso_hip_solver* s) {
     if (ldl_overlap(s)) (void)side_stream(s);       // (created outside a stream capture)
     static const bool pub_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_PUBLISH"); return !e || atoi(e) != 0; }();     // (experiment switch)
     s->ldl_publish = pub_env && !graphs && !s->cur;       // (a captured launch would replay a stale sequence number)
+    if (!graphs && ldl_decoupled(s) && launch_ldl_decoupled(s)) {
+        if (!s->ldl_failed) enqueue_ldl_finish(s);
+        return;
+    }
     s->ldl_epoch += 1;
     if (!graphs || !replay_or_capture(s, s->graph_ldl, s->graph_ldl_tried, [&] { enqueue_ldl_steps(s); })) enqueue_ldl_steps(s);
     (void)hipEventRecord(s->ev[14], s->stream);
