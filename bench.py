@@ -366,6 +366,8 @@ def main():
                     "in groups of 16); it only runs with --config C3")
     ap.add_argument("--c4-batch", type=int, default=32, help="config.c4: instances per GPU (BASELINE config 4: 256 problems over 8 GPUs)")
     ap.add_argument("--c4-group", type=int, default=16)
+    ap.add_argument("--c4-all", type=int, default=256, help="config.c4: also time ALL the problems of BASELINE config 4 (256) on this one GPU for the stage-structured variant\n"
+                    "(groups of up to 128 members, two in flight); 0 skips it")
     ap.add_argument("--c4-configs", default=None, help="the configurations of the config.c4 block (default: C4,C4T with --config C3, none otherwise)")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: gloo lets two ranks share one GPU")
     ap.add_argument("--force-device", type=int, default=-1, help="testing only: every rank uses this device ordinal")
@@ -679,6 +681,21 @@ def main():
     wl.close()
     del wl
 
+    def structured_roofline(w, n_r, seconds_per_instance_step, what):
+        """Executed flops and bytes of ONE Newton step of a structured handle (calipso_hip_structure_work: Schur complement by segment pairs + the multifrontal LDL^T
+        of S; bytes: the packed blocks of [gx; hx] and Lxx once per pass over them — Schur complement, 2 n_r + 3 mat-vec passes over [gx; hx], n_r + 1 over Lxx — and
+        the fronts of L once for the factorisation (written) and twice per solve) against both ceilings.  Such a step is neither: its kernels are small and the step is
+        bound by launch latency, which is what the fractions say."""
+        sw = w.single.structure_work()
+        flops = sw["schur_flops"] + sw["factor_flops"]
+        passes = 1 + (2 * n_r + 3) + (n_r + 1)
+        byts = 8.0 * (sw["packed_doubles"] / 2.0 * passes + sw["factor_nnz"] * (1 + 2 * (1 + n_r)))      # (packed_doubles counts both orientations; a pass reads one)
+        tf = flops / seconds_per_instance_step * 1e-12
+        gb = byts / seconds_per_instance_step * 1e-9
+        return {"what": what, "flops_executed_per_step": flops, "schur_flops": sw["schur_flops"], "factor_flops": sw["factor_flops"], "bytes_executed_per_step": byts,
+                "us_per_instance_step": 1e6 * seconds_per_instance_step, "achieved_TFLOPs": tf, "frac_mfma": tf / FP64_MFMA_PEAK_TFLOPS, "achieved_GBs": gb, "frac_hbm": gb / 8000.0,
+                "bound": "launch latency (neither ceiling is near: see frac_mfma / frac_hbm)"}
+
     # =================================================================== config.c4: BASELINE config 4 ===========================
     # 256 quadruped-gait-sized problems sharded over 8 GPUs = 32 instances per GPU, here in groups of 16, two groups in flight: C4 (the dense
     # treatment of that size) and C4T (the same size with the stage structure of a 41-stage trajectory problem: band-limited Schur complement,
@@ -707,8 +724,23 @@ def main():
                          "batched_newton_steps_per_s": r2, "batched_problems_per_s_of_10_steps": r2 / 10.0, "ms_per_pass": 1e3 * e2 / P4, "passes": P4,
                          "refinement_rounds": int(i2[0]["refinement_rounds"]), "stage_parallel": w4.stage_parallel, "stage_blocks": w4.stage_blocks,
                          "device_bytes_per_instance": w4.single.device_bytes()}
+            if w4.staged is not None and w4.structured:
+                c4[cname]["roofline"] = structured_roofline(w4, int(i2[0]["refinement_rounds"]), 1e-3 * c4[cname]["ms_per_pass"] / w4.B, "%d instances in groups of %d" % (w4.B, w4.G))
             w4.close()
             del w4
+            if cname == "C4T" and args.c4_all > 0:
+                # the WHOLE batch of config 4 on this GPU (what one GPU does with all 256 problems): groups of up to 128 members, two in flight
+                ga = min(128, args.c4_all)
+                wa = Workload(pkg, pr, cname, rank, world, local_rank, args.c4_all, ga, 2)
+                for _ in range(2):
+                    wa.batched_pass()
+                ea, ia, _ = run_batched(wa, P4)
+                ra = world * wa.B * P4 / ea
+                c4[cname]["all_%d_on_one_gpu" % args.c4_all] = {"instances_per_gpu": wa.B, "instances_per_group": ga, "groups_in_flight": 2, "batched_newton_steps_per_s": ra,
+                                                               "batched_problems_per_s_of_10_steps": ra / 10.0, "ms_per_pass": 1e3 * ea / P4,
+                                                               "roofline": structured_roofline(wa, int(ia[0]["refinement_rounds"]), ea / P4 / wa.B, "%d instances in groups of %d" % (wa.B, ga))}
+                wa.close()
+                del wa
 
     out = {
         "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": steps_timed,

@@ -409,6 +409,12 @@ class Solver:
         self._L.calipso_hip_kernel_times(self._h, _pd(out))
         return out
 
+    def structure_work(self):
+        """work of one Newton step on a handle that exploits its stage structure: dict(schur_flops, packed_doubles, segment_pairs, factor_flops, factor_nnz, order, structured)"""
+        out = np.zeros(8)
+        self._check(self._L.calipso_hip_structure_work(self._h, _pd(out)), "structure_work")
+        return dict(schur_flops=out[0], packed_doubles=out[1], segment_pairs=int(out[2]), factor_flops=out[3], factor_nnz=out[4], order=int(out[5]), structured=bool(out[6]))
+
     def padded_nx(self):
         return int(self.kernel_times()[2])
 
@@ -445,7 +451,7 @@ class Solver:
 
 
 class Group:
-    """Up to 16 Solver handles of one shape (same dimensions and cone layout, same device) stepped in lockstep: every kernel
+    """Up to 128 Solver handles of one shape (same dimensions and cone layout, same device) stepped in lockstep: every kernel
     launch of a group step covers all members (include/calipso_hip.h, "groups").  The reference has no counterpart — its
     `Solver`s are independent objects; this is how BASELINE config C4 keeps many of them in flight on one GPU."""
 

@@ -63,6 +63,7 @@ SYMBOLS = {
     "calipso_hip_newton_step": (_i32, [_vp, _i32, _pd]),
     "calipso_hip_phase_times": (_i32, [_vp, _pd]),
     "calipso_hip_kernel_times": (_i32, [_vp, _pd]),
+    "calipso_hip_structure_work": (_i32, [_vp, _pd]),
     "calipso_hip_analyze_structure": (_i32, [_vp, _pi64]),
     "calipso_hip_clear_structure": (_i32, [_vp]),
     "calipso_hip_set_stage_parallel": (_i32, [_vp, _i32, _i32, _pi64]),

@@ -952,7 +952,6 @@ int32_t calipso_hip_differentiate(H* s, calipso_eval_fn eval, void* user) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
     const Dims& d = s->d;
     if (d.np == 0) return CALIPSO_OK;
-    if (s->compact) { s->err = "calipso_hip_differentiate is not available on a structured handle"; return CALIPSO_ERR_ARGUMENT; }
     int rc = evaluate(s, eval, user, 0, CALIPSO_EVAL_OBJECTIVE_JACOBIAN_PARAMETERS | CALIPSO_EVAL_EQUALITY_JACOBIAN_PARAMETERS |
                                            CALIPSO_EVAL_EQUALITY_DUAL_JACOBIAN_PARAMETERS | CALIPSO_EVAL_CONE_JACOBIAN_PARAMETERS |
                                            CALIPSO_EVAL_CONE_DUAL_JACOBIAN_PARAMETERS);
@@ -975,9 +974,17 @@ int32_t calipso_hip_differentiate(H* s, calipso_eval_fn eval, void* user) {
     double* t1M = zM + NPd * p;                    // m  x p   Omega b_m
     double* t2M = t1M + M * p;                     // m  x p   [gx; hx] dx
     launch_residual_symmetric_multi(s, s->jacobian_parameters, p, rsymM, xbufM, t1M);
-    if (d.m) gemm(s, d.nx, p, d.m, 1.0, s->Z, d.m, true, t1M, d.m, 1.0, xbufM, d.NP);      // b_x + [gx; hx]' Omega b_m
+    // (a handle that works on stage blocks — every structured handle — takes the products block by block, all columns in one launch each; its factor lives in the
+    // fronts of the multifrontal LDL^T, which take all columns through the tree together: trsm_multi)
+    if (d.m && !blocks_gemm_t(s, t1M, d.m, xbufM, d.NP, p, 1.0)) {
+        if (s->compact) { s->err = "calipso_hip_differentiate: the block products are not available on this structured handle"; return CALIPSO_ERR_HIP; }
+        gemm(s, d.nx, p, d.m, 1.0, s->Z, d.m, true, t1M, d.m, 1.0, xbufM, d.NP);           // b_x + [gx; hx]' Omega b_m
+    }
     trsm_multi(s, xbufM, p, uM, zM);                                                        // dx = S^-1 (...)
-    if (d.m) gemm(s, d.m, p, d.nx, 1.0, s->Z, d.m, false, xbufM, d.NP, 0.0, t2M, d.m);      // [gx; hx] dx
+    if (d.m && !blocks_gemm_n(s, xbufM, d.NP, t2M, d.m, p)) {
+        if (s->compact) { s->err = "calipso_hip_differentiate: the block products are not available on this structured handle"; return CALIPSO_ERR_HIP; }
+        gemm(s, d.m, p, d.nx, 1.0, s->Z, d.m, false, xbufM, d.NP, 0.0, t2M, d.m);          // [gx; hx] dx
+    }
     launch_recover_multi(s, s->jacobian_parameters, p, rsymM, xbufM, t2M, s->solution_sensitivity, -1.0);   // :54-56 sensitivity = -step
     SYNC();
     return CALIPSO_OK;
@@ -1177,6 +1184,17 @@ int32_t calipso_hip_kernel_times(H* s, double out[8]) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s->ev[5], s->ev[6]) == hipSuccess) { out[4] = ms; out[5] = 8.0 * ((double)s->d.m * s->d.nx + (double)s->d.nx * s->d.nx); }
     }
+    return CALIPSO_OK;
+}
+
+// Work of one Newton step on a handle that uses its stage structure (stage blocks and / or the multifrontal factorisation of S): what bench.py prices such
+// handles with (the dense nx^3 / 3 says nothing about a factorisation over the stage tree).
+int32_t calipso_hip_structure_work(H* s, double out[8]) {
+    if (!s || !out) return CALIPSO_ERR_ARGUMENT;
+    for (int i = 0; i < 8; ++i) out[i] = 0.0;
+    if (s->blocks.on) { out[0] = s->blocks.schur_flops; out[1] = (double)s->blocks.packed; out[2] = (double)s->blocks.npairs; }
+    if (s->stage_parallel && s->spS) { double w[3]; calipso::sparse_work(s->spS, w); out[3] = w[0]; out[4] = w[1]; out[5] = w[2]; }
+    out[6] = s->compact ? 1.0 : 0.0;
     return CALIPSO_OK;
 }
 

@@ -58,10 +58,12 @@ __global__ __launch_bounds__(256) void k_blocks_pack_l(Batch bt, const LBlock* _
 
 // ---- y[rows of a block] = B x[columns of the block]: one workgroup per block, lanes along the rows, four column parts ---------------------------
 // rows [rlo, rhi) of the stacked Jacobian take part (gx only, hx only, or both); vectors indexed from row rlo
+// (blockIdx.y: right-hand-side column of the multi-column use of differentiate!, strides ldx / ldy; one column otherwise)
 __global__ __launch_bounds__(256) void k_bgemv_n(Batch bt, const ZBlock* __restrict__ blk, int rlo, int rhi, const double* __restrict__ pk, const double* __restrict__ x,
-                                                  double* __restrict__ y) {
+                                                  double* __restrict__ y, long long ldx = 0, long long ldy = 0) {
     __shared__ double part[4][64];
     inst_shift(bt, pk, x, y);
+    x += (long long)blockIdx.y * ldx; y += (long long)blockIdx.y * ldy;
     const ZBlock b = blk[blockIdx.x];
     if (b.row0 < rlo || b.row0 >= rhi) return;
     const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
@@ -89,10 +91,11 @@ __global__ __launch_bounds__(256) void k_bgemv_n(Batch bt, const ZBlock* __restr
 template <int NV>
 __global__ __launch_bounds__(256) void k_bgemv_t(Batch bt, const Segment* __restrict__ seg, const int* __restrict__ segblk, const ZBlock* __restrict__ blk, int rlo, int rhi,
                                                   const double* __restrict__ pk, const double* __restrict__ u1, const double* __restrict__ u2, double* __restrict__ y1,
-                                                  double* __restrict__ y2, double alpha, double beta) {
+                                                  double* __restrict__ y2, double alpha, double beta, long long ldu = 0, long long ldy = 0) {
     __shared__ double part[NV][4][64];
     inst_shift(bt, pk, u1, y1);
     if (NV == 2) inst_shift(bt, u2, y2);
+    u1 += (long long)blockIdx.y * ldu; y1 += (long long)blockIdx.y * ldy;        // (blockIdx.y: right-hand-side column, NV = 1 only)
     const Segment sg = seg[blockIdx.x];
     const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
     double a1 = 0.0, a2 = 0.0;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void k_schur_blocks(BatchSc bt, Dims d, ConeDe
     __shared__ double Bs[64 * SB_LD];      // Bs[j][k] = (Omega B)[k][b-column j]
     __shared__ double Rs[64 * SB_LD];      // raw rows of a second-order cone before its W block is applied
     inst_shift(bt.b, pk, wz, Wsoc, S);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const SegPair pr = pairs[blockIdx.x];
     const Segment sa = seg[pr.a], sb = seg[pr.b];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -312,6 +315,22 @@ bool blocks_gemv_t(calipso_hip_solver* s, int kind, const double* u1, const doub
     const int rlo = kind == SP_HX ? d.ne : 0, rhi = kind == SP_GX ? d.ne : d.m;
     if (u2) hipLaunchKernelGGL(k_bgemv_t<2>, dim3(B.nseg, 1, bs.b.n), dim3(256), 0, s->stream, bs.b, B.d_seg, B.d_segblk, B.d_blk, rlo, rhi, s->Lsym, u1, u2, y1, y2, 1.0, 0.0);
     else hipLaunchKernelGGL(k_bgemv_t<1>, dim3(B.nseg, 1, bs.b.n), dim3(256), 0, s->stream, bs.b, B.d_seg, B.d_segblk, B.d_blk, rlo, rhi, s->Lsym, u1, (const double*)nullptr, y1, (double*)nullptr, alpha, beta);
+    return true;
+}
+// Y(:, c) = [gx; hx] X(:, c) and Y(:, c) = [gx; hx]' U(:, c) + beta Y(:, c) for p columns in one launch each (differentiate! on a handle that works on blocks)
+bool blocks_gemm_n(calipso_hip_solver* s, const double* X, long long ldx, double* Y, long long ldy, int p) {
+    if (!blocks_usable(s) || p < 1) return false;
+    const StageBlocks& B = s->blocks;
+    const BatchSc bs = batch_of(s);
+    hipLaunchKernelGGL(k_bgemv_n, dim3(B.nblk, p, 1), dim3(256), 0, s->stream, bs.b, B.d_blk, 0, s->d.m, s->Lsym, X, Y, ldx, ldy);
+    return true;
+}
+bool blocks_gemm_t(calipso_hip_solver* s, const double* U, long long ldu, double* Y, long long ldy, int p, double beta) {
+    if (!blocks_usable(s) || p < 1) return false;
+    const StageBlocks& B = s->blocks;
+    const BatchSc bs = batch_of(s);
+    hipLaunchKernelGGL(k_bgemv_t<1>, dim3(B.nseg, p, 1), dim3(256), 0, s->stream, bs.b, B.d_seg, B.d_segblk, B.d_blk, 0, s->d.m, s->Lsym, U, (const double*)nullptr, Y, (double*)nullptr, 1.0, beta,
+                       ldu, ldy);
     return true;
 }
 bool blocks_schur(calipso_hip_solver* s) {
@@ -462,6 +481,9 @@ int blocks_install(calipso_hip_solver* s, const BlockPlan& P) {
     B.nblk = (int)P.zb.size(); B.nlb = (int)P.lb.size(); B.nseg = (int)P.seg.size(); B.npairs = (int)P.pairs.size(); B.max_lb = P.max_lb; B.packed = P.packed;
     B.signature = P.signature;
     B.h_blk = P.zb; B.h_lblk = P.lb; B.h_pairs = P.pairs; B.h_seg = P.seg; B.h_seg_of_col = P.seg_of_col;
+    B.schur_flops = 0.0;
+    for (const SegPair& pr : P.pairs)
+        for (int q = 0; q < pr.count; ++q) B.schur_flops += 2.0 * (double)P.zb[(size_t)P.pairblk[(size_t)pr.first + q]].nrows * (double)P.seg[(size_t)pr.a].nc * (double)P.seg[(size_t)pr.b].nc;
     B.on = true;
     return CALIPSO_OK;
 }

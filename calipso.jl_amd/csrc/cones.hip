@@ -128,7 +128,7 @@ __global__ __launch_bounds__(CONE_THREADS) void k_cone_search(BatchSc bt, Dims d
                                                                int* __restrict__ icount) {
     inst_shift(bt.b, sol, step);
     inst_shift_i(bt.b, icount);
-    const double tau = bt.sc[blockIdx.z].tau;
+    const double tau = bt.scal(blockIdx.z).tau;
     // block 0: slack s with Delta s ; block 1: slack dual t with Delta t   (separate step sizes, solve.jl:190-221).  Each block owns its words of
     // icount (6 .. 31 / 32 .. 63): the masks are gathered in LDS and stored whole, so nothing has to clear them beforehand
     __shared__ int lm[32];

@@ -24,6 +24,11 @@ struct calipso_hip_group {
     calipso::BatchSc desc;             // instance list of the launches being enqueued (base->cur points here)
     double *hgather = nullptr, *hgather_dev = nullptr;   // MAX_BATCH x 64 doubles: pinned host buffer and its device-side address
     int *higather = nullptr, *higather_dev = nullptr;    // MAX_BATCH x 64 ints
+    // the per-member scalars of the launches (BatchSc::sctab): a ring of device tables, each uploaded from its pinned twin in stream order when the active set or a
+    // member's scalars differ from what the current table holds (steady Newton steps re-use one table: the same members, the same kappa / rho / regularisation)
+    static constexpr int SC_RING = 8;
+    calipso::Scalars *sc_dev = nullptr, *sc_pin = nullptr;   // SC_RING x MAX_BATCH each
+    int sc_slot = 0, sc_n = -1, sc_pending = 0;              // the table in use, how many members it holds (-1: none yet), uploads since the last synchronisation
     std::vector<calipso_eval_fn> evals;              // host evaluation callbacks of the members without a device evaluator
     std::vector<void*> users;
     int saved_band = 0, saved_hb = 0;                // the base handle's own structure while a group call overrides it
@@ -45,12 +50,25 @@ __global__ void k_gather_i(Batch bt, const int* __restrict__ src, int count, int
 static void g_activate(G* g, const Set& a) {
     BatchSc& b = g->desc;
     b.b.n = (int)a.size();
+    const calipso::Scalars* cur = g->sc_n == (int)a.size() ? g->sc_pin + (size_t)g->sc_slot * MAX_BATCH : nullptr;
+    bool same = cur != nullptr;
     for (size_t k = 0; k < a.size(); ++k) {
         H* h = g->hs[a[k]];
         b.b.delta[k] = (long long)((reinterpret_cast<intptr_t>(h->slab) - reinterpret_cast<intptr_t>(g->base->slab)) / (intptr_t)sizeof(double));
         b.b.slot[k] = (int)a[k];
-        b.sc[k] = h->sc;
+        if (same && std::memcmp(&cur[k], &h->sc, sizeof(calipso::Scalars)) != 0) same = false;
     }
+    if (!same) {
+        // a new table: the next ring slot, filled on the host and copied in stream order (the launches queued so far keep reading the previous one).  A pinned
+        // twin is only re-used SC_RING uploads later; should that many be pending without a synchronisation in between, drain the stream first
+        if (++g->sc_pending >= G::SC_RING - 1) { (void)hipStreamSynchronize(g->base->stream); g->sc_pending = 0; }
+        g->sc_slot = (g->sc_slot + 1) % G::SC_RING;
+        calipso::Scalars* pin = g->sc_pin + (size_t)g->sc_slot * MAX_BATCH;
+        for (size_t k = 0; k < a.size(); ++k) pin[k] = g->hs[a[k]]->sc;
+        (void)hipMemcpyAsync(g->sc_dev + (size_t)g->sc_slot * MAX_BATCH, pin, sizeof(calipso::Scalars) * a.size(), hipMemcpyHostToDevice, g->base->stream);
+        g->sc_n = (int)a.size();
+    }
+    b.sctab = g->sc_dev + (size_t)g->sc_slot * MAX_BATCH;
     g->base->cur = &g->desc;
 }
 // dscal[first .. first+count) of every member of `a` (the active set) -> that member's hscal
@@ -59,6 +77,7 @@ static int g_read_d(G* g, const Set& a, int first, int count) {
     // the gather kernel stores straight into pinned host memory (one launch, no separate copy)
     hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + first, count, g->hgather_dev);
     SYNC();
+    g->sc_pending = 0;
     for (size_t k = 0; k < a.size(); ++k)
         for (int i = 0; i < count; ++i) g->hs[a[k]]->hscal[first + i] = g->hgather[k * 64 + i];
     return 0;
@@ -67,6 +86,7 @@ static int g_read_i(G* g, const Set& a, int first, int count) {
     H* s = g->base;
     hipLaunchKernelGGL(k_gather_i, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->icount + first, count, g->higather_dev);
     SYNC();
+    g->sc_pending = 0;
     for (size_t k = 0; k < a.size(); ++k)
         for (int i = 0; i < count; ++i) g->hs[a[k]]->hicount[first + i] = g->higather[k * 64 + i];
     return 0;
@@ -483,6 +503,8 @@ int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, ca
     CK(hipHostMalloc((void**)&g->higather, sizeof(int) * 64 * MAX_BATCH, hipHostMallocMapped));
     CK(hipHostGetDevicePointer((void**)&g->hgather_dev, g->hgather, 0));
     CK(hipHostGetDevicePointer((void**)&g->higather_dev, g->higather, 0));
+    CK(hipMalloc((void**)&g->sc_dev, sizeof(calipso::Scalars) * G::SC_RING * MAX_BATCH));
+    CK(hipHostMalloc((void**)&g->sc_pin, sizeof(calipso::Scalars) * G::SC_RING * MAX_BATCH, hipHostMallocDefault));
     return CALIPSO_OK;
 }
 
@@ -501,6 +523,8 @@ int32_t calipso_hip_group_destroy(calipso_hip_group* g) {
     for (H* h : g->hs) h->owner = nullptr;
     if (g->hgather) (void)hipHostFree(g->hgather);
     if (g->higather) (void)hipHostFree(g->higather);
+    if (g->sc_dev) (void)hipFree(g->sc_dev);
+    if (g->sc_pin) (void)hipHostFree(g->sc_pin);
     delete g;
     return CALIPSO_OK;
 }

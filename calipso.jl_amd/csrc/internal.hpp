@@ -76,15 +76,19 @@ struct Scalars {
 // "buffer X of instance k" = "buffer X of the base handle" + delta[k] doubles, for every X.  Kernels take this by value, use
 // blockIdx.z as the instance slot and shift their pointers (device_utils.hpp: inst_shift).  A single handle is a batch of one
 // with delta 0; a group (group.hip) steps several same-shape handles in lockstep through the same launches.
-constexpr int MAX_BATCH = 32;
+constexpr int MAX_BATCH = 128;
 struct Batch {
     int n = 1;                       // gridDim.z
     long long delta[MAX_BATCH] = {0};
     int slot[MAX_BATCH] = {0};       // the member's index in its group (0 for a handle stepped alone): addresses per-member storage outside the slabs
 };
-struct BatchSc {                     // + the per-instance scalars
+// + the per-instance scalars.  A handle stepped alone carries its scalars by value (sc1); a group's (up to 128 x 48 bytes: more than a kernel may take as arguments
+// beside the instance list) sit in a device table the group driver uploads in stream order whenever the active set or a member's scalars change (group.hip).
+struct BatchSc {
     Batch b;
-    Scalars sc[MAX_BATCH];
+    const Scalars* sctab = nullptr;
+    Scalars sc1;
+    __host__ __device__ const Scalars& scal(int z) const { return sctab ? sctab[z] : sc1; }
 };
 
 // Structure of the matrix a mat-vec works on (structure.hip): the loads of entries that are structurally zero are predicated off;
@@ -135,6 +139,7 @@ struct StageBlocks {
     unsigned long long signature = 0;   // of the block structure (members of a group must share it)
     ZBlock* d_blk = nullptr; LBlock* d_lblk = nullptr; Segment* d_seg = nullptr; int* d_segblk = nullptr; SegPair* d_pairs = nullptr; int* d_pairblk = nullptr;
     int* d_colrange = nullptr;          // per column of Lxx: [first, last + 1) row of its Hessian block (uploads are re-checked against it)
+    double schur_flops = 0.0;           // multiply-adds x 2 of one k_schur_blocks launch per instance (sum over the segment pairs of the covering blocks' rows x columns x columns)
     std::vector<ZBlock> h_blk; std::vector<LBlock> h_lblk; std::vector<SegPair> h_pairs; std::vector<Segment> h_seg; std::vector<int> h_seg_of_col;   // host copies (uploads of structured handles are packed on the host)
 };
 struct BlockPlan {                      // blocks.hip: blocks_plan (host only)
@@ -353,6 +358,8 @@ void blocks_pack(calipso_hip_solver* s, bool z, bool l);
 bool blocks_gemv_n(calipso_hip_solver* s, int kind, const double* x, double* y, double alpha, double beta);
 bool blocks_gemv_t(calipso_hip_solver* s, int kind, const double* u1, const double* u2, double* y1, double* y2, double alpha, double beta);
 bool blocks_schur(calipso_hip_solver* s);
+bool blocks_gemm_n(calipso_hip_solver* s, const double* X, long long ldx, double* Y, long long ldy, int p);                  // Y(:, c) = [gx; hx] X(:, c), p columns
+bool blocks_gemm_t(calipso_hip_solver* s, const double* U, long long ldu, double* Y, long long ldy, int p, double beta);     // Y(:, c) = [gx; hx]' U(:, c) + beta Y(:, c)
 bool blocks_plan(const Dims& d, const std::vector<int>& zrow, const std::vector<int>& lreach, BlockPlan& P, std::string& err);
 int blocks_install(calipso_hip_solver* s, const BlockPlan& P);
 int blocks_unpack_dense(calipso_hip_solver* s, double** Lxx, double** Z);
@@ -402,7 +409,7 @@ int evaluate_point(calipso_hip_solver* s, calipso_eval_fn eval, void* user, int 
 inline BatchSc batch_of(const calipso_hip_solver* s) {
     if (s->cur) return *s->cur;
     BatchSc b;
-    b.b.n = 1; b.b.delta[0] = 0; b.sc[0] = s->sc;
+    b.b.n = 1; b.b.delta[0] = 0; b.sctab = nullptr; b.sc1 = s->sc;
     return b;
 }
 // batched fills / copies (vectors.hip) — replace hipMemsetAsync / hipMemcpyAsync on the hot path so that groups are covered
@@ -415,6 +422,7 @@ int sparse_solve_inplace(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt
 int sparse_reserve_solve(calipso_hip_sparse* sp, int batch);
 int sparse_solve_inplace_multi(calipso_hip_sparse* sp, hipStream_t st, int slot, double* X, long long ld, int p);
 void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]);
+void sparse_work(const calipso_hip_sparse* sp, double out[3]);      // flops of one numeric factorisation, nnz(L) of the fronts, order
 int nested_dissection_pieces(i64 n, const i64* colptr, const i64* rowval, i64* perm, std::vector<std::pair<int, int>>& pieces);   // ordering.hip
 void fill_d(calipso_hip_solver* s, double* p, size_t n, double v);
 void fill_i(calipso_hip_solver* s, int* p, size_t n, int v);

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(1024) void k_cone_weights(BatchSc bt, Dims d, ConeD
     __shared__ int smi[3][16];
     inst_shift(bt.b, w, kzz, wz, Bsoc, Wsoc, work);
     inst_shift_i(bt.b, icount);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const int tid = threadIdx.x;
     const double* sl = w + d.os();
     const double* t = w + d.ot();
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur(BatchSc bt, Dims d, con
         const long long o = bt.b.delta[z];
         Lsym += o; gx += o; hx += o; WH += o; S += o; kr += 2 * o;
     }
-    const Scalars sc = bt.sc[z];
+    const Scalars sc = bt.scal(z);
     const int TJ = 16 * nj;
     int bi, bj;
     if (hb > 0) schur_tile_banded(t, d.nx, TJ, hb, bi, bj);

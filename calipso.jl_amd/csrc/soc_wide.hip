@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_cone_weights_wide(BatchSc bt, Dims d, Co
     __shared__ double ycol[MAX_SOC_DIM];
     inst_shift(bt.b, w, Bsoc, Wsoc);
     inst_shift_i(bt.b, icount);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const int j = cd.wide[blockIdx.x];
     const int st = cd.soc_start[j], dim = cd.soc_dim[j], off = cd.soc_woff[j];
     const int a = threadIdx.x;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void k_cone_weights_wide(BatchSc bt, Dims d, Co
 __global__ __launch_bounds__(64) void k_residual_symmetric_wide(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ res_,
                                                                  const double* __restrict__ Wsoc, double* __restrict__ rsym_, double* __restrict__ t1_) {
     inst_shift(bt.b, w, res_, Wsoc, rsym_, t1_);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const double* res = res_ + (size_t)blockIdx.y * d.N;
     double* rsym = rsym_ + (size_t)blockIdx.y * d.n;
     double* t1 = t1_ + (size_t)blockIdx.y * d.m;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void k_recover_wide(BatchSc bt, Dims d, ConeDev
     inst_shift(bt.b, w, res_, b_, t2_, Wsoc, dsym_, step_);
     if (accum) inst_shift(bt.b, accum);
     if (zsx_mode) inst_shift(bt.b, zsx);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const double* res = res_ + (size_t)blockIdx.y * d.N;
     const double* b = b_ + (size_t)blockIdx.y * d.n;
     const double* t2 = t2_ + (size_t)blockIdx.y * d.m;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void k_refine_local_wide(BatchSc bt, Dims d, Co
                                                            const double* __restrict__ zsx, const double* __restrict__ Wsoc, double* __restrict__ e, double* __restrict__ rsym,
                                                            double* __restrict__ t1, double* __restrict__ part, int part0) {
     inst_shift(bt.b, w, v, res, zsx, Wsoc, e, rsym, t1, part);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const int j = cd.wide[blockIdx.x];
     const int st = cd.soc_start[j], dim = cd.soc_dim[j];
     const int a = threadIdx.x;

@@ -112,7 +112,7 @@ void launch_init_point(calipso_hip_solver* s) {
 
 __global__ void k_lambda_update(BatchSc bt, Dims d, const double* __restrict__ w, double* __restrict__ lam) {
     inst_shift(bt.b, w, lam);
-    const double rho = bt.sc[blockIdx.z].rho;
+    const double rho = bt.scal(blockIdx.z).rho;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d.ne) lam[i] = lam[i] + rho * w[d.orr() + i];
 }

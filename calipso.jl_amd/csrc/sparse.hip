@@ -819,6 +819,7 @@ int sparse_reserve_solve(calipso_hip_sparse* s, int batch) {
     }
     return CALIPSO_OK;
 }
+void sparse_work(const calipso_hip_sparse* sp, double out[3]) { out[0] = (double)sp->flops; out[1] = (double)sp->nnzL; out[2] = (double)sp->n; }
 void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]) { out[0] = sp->levels; out[1] = sp->max_front; out[2] = sp->nnzU; out[3] = sp->mf ? 2 : (sp->lds_acc ? 1 : 0); }
 }  // namespace calipso
 

@@ -16,7 +16,7 @@ __global__ void k_residual(BatchSc bt, Dims d, const double* __restrict__ w, con
                            const double* __restrict__ g, const double* __restrict__ hc, const double* __restrict__ prod,
                            const double* __restrict__ targ, double* __restrict__ res) {
     inst_shift(bt.b, w, lam, fx, gyx, hzx, g, hc, prod, targ, res);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N) return;
     double v;
@@ -148,7 +148,7 @@ __global__ void k_residual_symmetric(BatchSc bt, Dims d, ConeDev cd, const doubl
                                      const double* __restrict__ wz, const double* __restrict__ Wsoc, double* __restrict__ rsym_,
                                      double* __restrict__ xbuf_, double* __restrict__ t1_) {
     inst_shift(bt.b, w, res_, wz, Wsoc, rsym_, xbuf_, t1_);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     // blockIdx.y = right-hand-side column (differentiate!: one column per parameter); columns are N / n / NP / m apart
     const double* res = res_ + (size_t)blockIdx.y * d.N;
     double* rsym = rsym_ + (size_t)blockIdx.y * d.n;
@@ -248,7 +248,7 @@ __global__ void k_recover(BatchSc bt, Dims d, ConeDev cd, const double* __restri
     inst_shift(bt.b, w, res_, b_, dx_, t2_, wz, Wsoc, dsym_, step_);
     if (accum) inst_shift(bt.b, accum);
     if (zsx_mode) inst_shift(bt.b, zsx);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     // blockIdx.y = right-hand-side column (see k_residual_symmetric); dsym_ may be null for the multi-column use
     const double* res = res_ + (size_t)blockIdx.y * d.N;
     const double* b = b_ + (size_t)blockIdx.y * d.n;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(RT) void k_merit(BatchSc bt, Dims d, const double* 
                                                double* __restrict__ dscal) {
     __shared__ double sm[RT / 64];
     inst_shift(bt.b, point, lam, dscal);
-    merit_body(bt.sc[blockIdx.z], d, point, lam, dscal, sm);
+    merit_body(bt.scal(blockIdx.z), d, point, lam, dscal, sm);
 }
 void launch_merit(calipso_hip_solver* s, const double* point) {
     const BatchSc B = batch_of(s);
@@ -452,7 +452,7 @@ __device__ __forceinline__ void merit_gradient_entry(const Scalars sc, const Dim
 __global__ void k_merit_gradient(BatchSc bt, Dims d, const double* __restrict__ w, const double* __restrict__ lam,
                                  const double* __restrict__ fx, const double* __restrict__ bgrad, double* __restrict__ grad) {
     inst_shift(bt.b, w, lam, fx, bgrad, grad);
-    merit_gradient_entry(bt.sc[blockIdx.z], d, blockIdx.x * blockDim.x + threadIdx.x, w, lam, fx, bgrad, grad);
+    merit_gradient_entry(bt.scal(blockIdx.z), d, blockIdx.x * blockDim.x + threadIdx.x, w, lam, fx, bgrad, grad);
 }
 void launch_merit_gradient(calipso_hip_solver* s) {
     const BatchSc B = batch_of(s);
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(RT) void k_merit_and_gradient(BatchSc bt, Dims d, c
                                                             const double* __restrict__ bgrad, double* __restrict__ grad, double* __restrict__ dscal) {
     __shared__ double sm[RT / 64];
     inst_shift(bt.b, w, lam, fx, bgrad, grad, dscal);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     if (blockIdx.x == 0) merit_body(sc, d, w, lam, dscal, sm);
     else merit_gradient_entry(sc, d, (blockIdx.x - 1) * RT + threadIdx.x, w, lam, fx, bgrad, grad);
 }
@@ -584,7 +584,7 @@ void launch_first_candidate(calipso_hip_solver* s, double a_s, double a_t) { lau
 __global__ void k_Hmul_vec(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,
                            double* __restrict__ out) {
     inst_shift(bt.b, w, v, out);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d.N) return;
     if (i < d.nx) {
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(RT) void k_Hmul_err(BatchSc bt, Dims d, ConeDev cd,
                                                   const double* __restrict__ res, double* __restrict__ e, double* __restrict__ out) {
     __shared__ double sm[RT / 64];
     inst_shift(bt.b, w, v, res, e, out);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const double* sl = w + d.os(); const double* t = w + d.ot();
     const double* vs = v + d.os(); const double* vt = v + d.ot();
     double m = 0.0;
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_refine_local(BatchSc bt, Dims d,
                                                               double* __restrict__ t1, double* __restrict__ part) {
     __shared__ double sm[RL_THREADS / 64];
     inst_shift(bt.b, w, v, res, zsx, wz, Wsoc, e, rsym, t1, part);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const double* sl = w + d.os(); const double* t = w + d.ot();
     const double* vs = v + d.os(); const double* vt = v + d.ot();
     const double Hrr = sc.rho + sc.ep, Hss = 0.0 + sc.ep;
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(RT) void k_refine_x(BatchSc bt, Dims d, int have_m,
                                                   double* __restrict__ hpub, unsigned long long* __restrict__ hseq, unsigned long long seq) {
     __shared__ double sm[RT / 64];
     inst_shift(bt.b, v, res, lxv, w1, w2, e, rsym, xbuf, dscal, part);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     double m = 0.0;
     for (int i = threadIdx.x; i < nparts; i += RT) m = fmax(m, part[i]);     // the other rows' part of the norm (k_refine_local)
     for (int i0 = threadIdx.x; i0 < d.NP; i0 += 4 * RT) {          // four of a thread's rows in flight together, combined in the same order
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc b
     inst_shift(bt.b, Z, dx, w, res, resid, wz, Wsoc, rsym, dsym, step, zsx, e, t1, part);
     if (accum) inst_shift(bt.b, accum);
     if (rowrange) inst_shift_i(bt.b, rowrange);
-    const Scalars sc = bt.sc[blockIdx.z];
+    const Scalars sc = bt.scal(blockIdx.z);
     const int tid = threadIdx.x, r = tid % ROWS, p = tid / ROWS;
     const int g = blockIdx.x;
     const int r0 = grp[g], nrows = grp[g + 1] - r0;

@@ -129,8 +129,11 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
  * blocks couple, and the multifrontal factor of the Schur complement: O(stages x block^2) device memory — none of the dense nx^2 / (ne + nc) nx / NP^2 buffers of
  * calipso_hip_create exist.  Uploads: calipso_hip_set_field with the dense host arrays of ProblemData (packed on the host; a non-zero outside the declared
  * structure is an error), calipso_hip_set_sparsity + calipso_hip_scatter_field / _hessian (straight into the blocks), calipso_hip_qp_attach.  Everything
- * else of this header works as on a dense handle, except: no device evaluators, no calipso_hip_differentiate, no calipso_hip_analyze_structure /
- * clear_structure / set_stage_parallel(off) / set_stage_blocks(off) (the structure is fixed); members of a group must share one structure. */
+ * else of this header works as on a dense handle — calipso_hip_differentiate included (differentiate.jl:1-61: the products with [gx; hx] block by block for all
+ * parameter columns at once, the solves through the fronts for all columns together) — except: no device evaluators (they write the dense ProblemData
+ * arrays, which do not exist here), no calipso_hip_analyze_structure / clear_structure / set_stage_parallel(off) / set_stage_blocks(off) (the structure is
+ * fixed); members of a group must share one structure.  The Hessian must have at least two diagonal blocks (dynamics whose y'f Hessian couples x_t with
+ * x_{t+1}, e.g. implicit integrators, declare one block and are refused: use calipso_hip_create + calipso_hip_analyze_structure for those). */
 int32_t calipso_hip_create_structured(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx, int64_t n_soc,
                                       const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device, const int64_t* row_first, const int64_t* row_last,
                                       int64_t n_hessian_blocks, const int64_t* hessian_block_start, calipso_hip_solver** out);
@@ -266,7 +269,7 @@ int32_t calipso_hip_qp_evaluate(calipso_hip_solver*, int32_t which, uint32_t fla
 int32_t calipso_hip_newton_step(calipso_hip_solver*, int32_t advance, double info[6]);
 /* ---- groups: several handles of one shape stepped in lockstep through the same kernel launches ------------------------------
  * The reference has no batching: distinct `Solver`s are simply independent; BASELINE config C4 runs many of them
- * per GPU.  A group covers up to 32 handles created with identical dimensions and cone layout on one device; every launch of a
+ * per GPU.  A group covers up to 128 handles created with identical dimensions and cone layout on one device; every launch of a
  * group step carries all members (the instance is a grid dimension), so the latency-bound parts of the step cost the same for
  * the whole group as for one handle.  Per member the arithmetic is exactly that of calipso_hip_newton_step.  Members stay
  * usable through the single-handle entry points between group calls (not concurrently with them). */
@@ -424,6 +427,10 @@ int32_t calipso_hip_phase_times(calipso_hip_solver*, double out[9]);
  * [4] ms of ONE launch of the refinement residual's mat-vec kernel (k_gemv_t2_and_n: [gx; hx]' times two vectors and Lxx times one, the first residual of the
  *     last calipso_hip_newton_step; 0 when the handle takes another path) and [5] the bytes it reads, 8 (m nx + nx^2)   [6..7] reserved (0) */
 int32_t calipso_hip_kernel_times(calipso_hip_solver*, double out[8]);
+/* work of one Newton step on a handle that exploits its stage structure (src/trajectory_optimization/sparsity.jl:28-129 is where the reference's structure
+ * comes from): [0] flops of the Schur complement by segment pairs (k_schur_blocks)   [1] doubles of the packed blocks of [gx; hx] and Lxx (both orientations)
+ * [2] segment pairs   [3] flops of one multifrontal LDL^T of S   [4] nnz(L) of its fronts   [5] order of S   [6] 1 for a structured handle   [7] reserved */
+int32_t calipso_hip_structure_work(calipso_hip_solver*, double out[8]);
 int32_t calipso_hip_synchronize(calipso_hip_solver*);
 
 /* SplitMix64 uniform stream of SURVEY.md 8(d): seed = 0xCA11B50000000000 + 4096*problem_id + stream_id,

@@ -706,3 +706,43 @@ def declared_structure(prob):
         nz = np.nonzero(Hp[:, j])[0]
         reach = max(reach, j, int(nz.max()) if nz.size else j)
     return dict(row_first=first, row_last=last, hessian_block_start=np.array(starts, dtype=np.int64))
+
+
+def structure_from_pattern(prob, samples=3, seed=0):
+    """the declared structure of ANY problem object with evaluate(): the union of the non-zero patterns of its Jacobians and Lagrangian Hessian over a few random
+    points (what the reference holds as methods.*_sparsity, src/trajectory_optimization/sparsity.jl:28-129) -> the arguments of calipso_hip_create_structured"""
+    rng = np.random.default_rng(seed)
+    Zp = np.zeros((prob.ne + prob.nc, prob.nx), dtype=bool)
+    Hp = np.zeros((prob.nx, prob.nx), dtype=bool)
+    theta = np.asarray(getattr(prob, "parameters", np.zeros(0)), dtype=np.float64)
+    sizes = {"objective": 1, "objective_gradient_variables": prob.nx, "equality_constraint": prob.ne, "cone_constraint": prob.nc,
+             "equality_dual_jacobian_variables": prob.nx, "cone_dual_jacobian_variables": prob.nx, "equality_jacobian_variables": prob.ne * prob.nx,
+             "cone_jacobian_variables": prob.nc * prob.nx, "objective_jacobian_variables_variables": prob.nx ** 2,
+             "equality_dual_jacobian_variables_variables": prob.nx ** 2, "cone_dual_jacobian_variables_variables": prob.nx ** 2}
+    for _ in range(samples):
+        out = {}
+        getter = lambda name: out.setdefault(name, np.zeros(sizes[name]))          # (evaluate writes column-major flat buffers)
+        prob.evaluate(ALL_VARIABLE_FLAGS, rng.standard_normal(prob.nx), rng.standard_normal(prob.ne), rng.standard_normal(prob.nc), theta, getter)
+        rows = []
+        if prob.ne:
+            rows.append(np.asarray(out["equality_jacobian_variables"]).reshape(prob.nx, prob.ne).T != 0.0)
+        if prob.nc:
+            rows.append(np.asarray(out["cone_jacobian_variables"]).reshape(prob.nx, prob.nc).T != 0.0)
+        if rows:
+            Zp |= np.vstack(rows)
+        for name in ("objective_jacobian_variables_variables", "equality_dual_jacobian_variables_variables", "cone_dual_jacobian_variables_variables"):
+            if name in out:
+                M = np.asarray(out[name]).reshape(prob.nx, prob.nx) != 0.0
+                Hp |= M | M.T
+    first = np.ones(Zp.shape[0], dtype=np.int64); last = np.zeros(Zp.shape[0], dtype=np.int64)
+    for k in range(Zp.shape[0]):
+        nz = np.nonzero(Zp[k])[0]
+        if nz.size:
+            first[k], last[k] = nz[0] + 1, nz[-1] + 1
+    starts, reach = [1], -1
+    for j in range(prob.nx):
+        if j > starts[-1] - 1 and reach < j:
+            starts.append(j + 1)
+        nz = np.nonzero(Hp[:, j])[0]
+        reach = max(reach, j, int(nz.max()) if nz.size else j)
+    return dict(row_first=first, row_last=last, hessian_block_start=np.array(starts, dtype=np.int64))

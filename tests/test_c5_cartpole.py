@@ -63,3 +63,36 @@ def test_c5_hip_sensitivities_match_oracle(oracle_mod):
     # dR/dtheta assembled on the device equals the oracle's (residual_jacobian_parameters.jl:1-40)
     J = s.data("jacobian_parameters")
     assert np.abs(J - o.mat("jacobian_parameters", o.N, prob.np)).max() <= 1e-9
+
+
+@pytest.mark.gpu
+def test_c5_as_a_trajectory_problem_on_a_structured_handle(oracle_mod):
+    """C5 is a trajectory problem (examples/autotuning/cartpole.jl:85-146: 10 stages of 4 states + 1 action, dynamics between neighbours): declared as such it
+    runs on a structured handle — stage blocks, multifrontal LDL^T of S — and differentiate! (differentiate.jl:1-61) takes its 102 columns through the blocks and
+    the fronts together.  Same iterations and sensitivities as the oracle (1e-6) and as the dense handle."""
+    import time
+    prob = problem()
+    pkg = load_pkg()
+    st = pr.structure_from_pattern(prob)
+    assert len(st["hessian_block_start"]) >= 10                              # at least one Hessian block per stage (the cart position couples with nothing: blocks of its own)
+    s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, parameters=prob.parameters, options=OPTS, structure=st)
+    dense = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, parameters=prob.parameters, options=OPTS)
+    for h in (s, dense):
+        pkg.initialize_b(h, prob.x0)
+        assert pkg.solve_b(h)
+    o, sto = run_oracle(oracle_mod, prob, **OPTS)
+    assert sto == 1 and s.stats()["total_iterations"] == o.stats()["total_iterations"] == dense.stats()["total_iterations"]
+    assert np.abs(s.solution.all - o.point()["all"]).max() <= 1e-6 * max(1.0, np.abs(o.point()["all"]).max())
+    S_cpu = o.mat("solution_sensitivity", o.N, prob.np)
+    S_str, S_dense = s.data("solution_sensitivity"), dense.data("solution_sensitivity")
+    assert np.abs(S_str - S_cpu).max() <= 1e-6 * max(1.0, np.abs(S_cpu).max())
+    assert np.abs(S_str - S_dense).max() <= 1e-8 * max(1.0, np.abs(S_dense).max())
+    assert s.device_bytes() < dense.device_bytes()
+    # timed side by side: differentiate! alone on the two handles (the batched LDS-resident path for thousands of such systems: tests/test_gpu_small.py)
+    for name, h in (("structured", s), ("dense", dense)):
+        h.differentiate(); h.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            h.differentiate()
+        h.synchronize()
+        print("differentiate! on the %s handle: %.3f ms" % (name, (time.perf_counter() - t0) / 20 * 1e3))

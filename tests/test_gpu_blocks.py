@@ -259,3 +259,48 @@ def test_structured_group_and_whole_solve():
     assert pkg.solve_b(dense) and pkg.solve_b(s)
     assert (dense.stats()["total_iterations"], dense.stats()["outer"]) == (s.stats()["total_iterations"], s.stats()["outer"])
     assert close(s.solution.all, dense.solution.all, 1e-7)
+
+
+@pytest.mark.parametrize("members", [64, 128])
+def test_large_structured_groups_are_bitwise_the_single_steps(members):
+    """Groups of 64 and 128 structured handles (internal.hpp: MAX_BATCH = 128; the members' scalars travel in a device table, group.hip): every member gets
+    the bits of the same handle stepped alone — sampled members over two advancing steps, so the table is re-used, then replaced when scalars move."""
+    pkg = load_pkg()
+    shape = SHAPES[0]
+    ids = list(range(100, 100 + members))
+    mem = [build_structured(pkg, p, *shape)[1] for p in ids]
+    sample = sorted({0, 1, 31, 32, 33, members // 2, members - 2, members - 1})
+    singles = {k: build_structured(pkg, ids[k], *shape)[1] for k in sample}
+    # members with different scalars (the table holds them per member)
+    for k in (1, members - 1):
+        for h in (mem[k], singles[k]):
+            h.set("central_path", [0.05]); h.set("penalty", [7.0])
+    g = pkg.Group(mem)
+    for it in range(2):
+        got = g.newton_step(advance=True)
+        for k in sample:
+            ref = singles[k].newton_step(advance=True)
+            assert ref == got[k] and ref["status"] == 0, (it, k, ref, got[k])
+            assert np.array_equal(singles[k].data("step").all, mem[k].data("step").all)
+            assert np.array_equal(singles[k].solution.all, mem[k].solution.all)
+    g.close()
+    with pytest.raises(pkg.CalipsoHipError):
+        pkg.Group(mem + [build_structured(pkg, 999, *shape)[1]] * (129 - members))       # 129 members: above the limit
+
+
+def test_group_of_forty_dense_members_is_bitwise_the_single_steps():
+    pkg = load_pkg()
+    from test_gpu_group import build as build_dense, same
+    shape = (300, 120, 30, 10, 3)
+    ids = list(range(200, 240))
+    mem = [build_dense(pkg, p, shape) for p in ids]
+    sample = [0, 17, 31, 32, 39]
+    singles = {k: build_dense(pkg, ids[k], shape) for k in sample}
+    g = pkg.Group(mem)
+    for it in range(2):
+        got = g.newton_step(advance=True)
+        for k in sample:
+            ref = singles[k].newton_step(advance=True)
+            assert ref == got[k] and ref["status"] == 0
+            assert same(singles[k].data("step").all, mem[k].data("step").all) and same(singles[k].solution.all, mem[k].solution.all)
+    g.close()
