@@ -391,6 +391,7 @@ int blocks_unpack_dense(calipso_hip_solver* s, double** Lxx, double** Z) {
 bool blocks_plan(const Dims& d, const std::vector<int>& zrow, const std::vector<int>& lreach, BlockPlan& P, std::string& err) {
     const int nx = d.nx, m = d.m, ne = d.ne;
     if ((int)zrow.size() != 2 * m || (int)lreach.size() != nx) { err = "calipso_hip_set_stage_blocks: call calipso_hip_analyze_structure first"; return false; }
+    if (d.max_dim > 64) { err = "calipso_hip_set_stage_blocks: the block kernels take second-order cones up to dimension 64 (wider cones: the dense treatment)"; return false; }
     std::vector<LBlock>& lb = P.lb; std::vector<ZBlock>& zb = P.zb;
     lb.clear(); zb.clear();
     {   // Hessian blocks: a new block starts at column p when no entry of columns < p reaches p or beyond
