@@ -185,8 +185,9 @@ typedef double calipso_v4d __attribute__((ext_vector_type(4)));
 constexpr int MF_BIG = 96;
 constexpr int MF_MAX_FRONT = 196;             // (m (m + 1) / 2 + 2 m) doubles <= 160 KiB: the front's lower triangle, packed, + the pivot-column buffers
 constexpr int MF_PY = 18;                     // row stride of the exchange rows of an in-register panel (pivot16.hpp)
-constexpr int MF_MAX_FRONT_GLOBAL = 1024;     // larger fronts live in global memory (L2): same algorithm, every access a memory access — slower, but
-                                              // still tree-parallel; beyond this the column method takes over
+constexpr int MF_MAX_FRONT_GLOBAL = 4095;     // larger fronts live in global memory (L2): same algorithm, every access a memory access — slower (one workgroup
+                                              // per front: a 1500-row front is ~0.5 ms), but still tree-parallel; 4095 is where the 24-bit index arithmetic of
+                                              // the packed triangle ends (tri0): beyond it the column method takes over
 
 // The front is symmetric: only its lower triangle is held, packed row by row (row i starts at i (i + 1) / 2), which lets fronts of up to 196 rows
 // fit the 160 KiB of LDS (a full square would stop at 141).

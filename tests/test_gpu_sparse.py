@@ -241,7 +241,8 @@ def test_global_accumulator_path_beyond_the_lds_limit(oracle_mod):
 
 def test_fronts_larger_than_the_lds_live_in_global_memory(oracle_mod):
     """a 2-D grid has separators of ~sqrt(n) vertices: the top fronts (hundreds of rows) exceed one CU's LDS and are factored in global memory by
-    the same kernels; a front beyond 1024 rows (one dense block) sends the whole matrix to the column method — same answers either way"""
+    the same kernels — up to 4095 rows (a dense block of 1500 and a mesh with a 1500-vertex separator below); beyond that the column method takes the whole
+    matrix — same answers either way"""
     pkg = load_pkg()
     g = 180
     I = sp.identity(g, format="csc")
@@ -265,15 +266,45 @@ def test_fronts_larger_than_the_lds_live_in_global_memory(oracle_mod):
     C.factorize(A); C.factorize(A)
     assert tf < C.timing()[0]                                    # the tree-parallel fronts beat the column method on this matrix
     S.close(); C.close()
-    # one dense block of 1500: its first front would have 1500 rows
+    # one dense block of 1500: its first front has 1500 rows — a global-memory front (round 3: the column method took over at 1024)
     M = rng.standard_normal((1500, 1500)); Kd = M @ M.T + 1500 * np.eye(1500)
     Ad = sp.csc_matrix(np.triu(Kd))
     Sd = pkg.SparseLDL(Ad, method="nested_dissection")
-    assert Sd.info["numeric"].startswith("columns")
+    assert Sd.info["numeric"] == "multifrontal"
     assert Sd.factorize(Ad) == 0
     bd = rng.standard_normal(1500)
     assert np.abs(Kd @ Sd.solve(bd) - bd).max() <= 1e-8 * np.abs(bd).max() * 10
-    Sd.close()
+    Sd.factorize(Ad)
+    Cd = pkg.SparseLDL(Ad, method="nested_dissection_columns")
+    Cd.factorize(Ad); Cd.factorize(Ad)
+    print("dense block of 1500: fronts %.2f ms, column method %.2f ms" % (Sd.timing()[0], Cd.timing()[0]))
+    Sd.close(); Cd.close()
+    # two 60 x 60 meshes joined through a separator of 1500 vertices (every separator vertex touches its neighbours in the separator and one vertex of each mesh)
+    gm, ns = 60, 1500
+    Tm = sp.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(gm, gm), format="csc")
+    Km = (sp.kron(sp.identity(gm), Tm) + sp.kron(Tm, sp.identity(gm))).tocsc()
+    nm = gm * gm
+    Ssep = sp.diags([-0.5, 6.0, -0.5], [-1, 0, 1], shape=(ns, ns), format="lil")
+    band = 40
+    for off in range(2, band):
+        Ssep.setdiag(-0.01, off); Ssep.setdiag(-0.01, -off)
+    C1 = sp.lil_matrix((ns, nm)); C2 = sp.lil_matrix((ns, nm))
+    for i in range(ns):
+        C1[i, (i * 7) % nm] = -0.3; C2[i, (i * 11) % nm] = -0.3
+    Kw = sp.bmat([[Km, None, C1.T], [None, Km, C2.T], [C1, C2, Ssep]], format="csc")
+    Kw.sort_indices()
+    Aw = sp.triu(Kw).tocsc()
+    Sw = pkg.SparseLDL(Aw, method="nested_dissection")
+    assert Sw.factorize(Aw) == 0 and Sw.inertia[2] == 0
+    bw = rng.standard_normal(Kw.shape[0])
+    xw = Sw.solve(bw)
+    assert np.abs(Kw @ xw - bw).max() <= 1e-8 * max(1.0, np.abs(xw).max())
+    Sw.factorize(Aw)
+    Cw = pkg.SparseLDL(Aw, method="nested_dissection_columns")
+    Cw.factorize(Aw); Cw.factorize(Aw)
+    print("two meshes + separator of 1500 (n = %d): %s, largest front %s rows, fronts %.2f ms, column method %.2f ms" % (
+        Kw.shape[0], Sw.info["numeric"], Sw.info.get("largest_front", "?"), Sw.timing()[0], Cw.timing()[0]))
+    Sw.close(); Cw.close()
 
 
 @pytest.mark.parametrize("method", ["nested_dissection", "nested_dissection_columns"])
