@@ -611,8 +611,9 @@ static void do_sds(H* s, int which, double* accumulate = nullptr, bool refine_fo
 static void refine_residual(H* s, bool publish = false) {
     const Dims& d = s->d;
     launch_refine_local(s);
-    gemv_refine_pair(s, s->step + d.oy(), s->t1, s->w1, s->w2, s->step, s->lxv);      // [gx; hx]'(two vectors) and Lxx step_x: one launch (gemv.hip)
-    launch_refine_x(s, publish);
+    // [gx; hx]'(two vectors) and Lxx step_x: one launch (gemv.hip); the partial sums of the second are combined by the kernel that consumes them
+    const int nchunk = gemv_refine_pair(s, s->step + d.oy(), s->t1, s->w1, s->w2, s->step, s->lxv, true);
+    if (nchunk > 0) launch_refine_x_fused(s, publish, nchunk); else launch_refine_x(s, publish);
 }
 // the condensed solve for the operands refine_residual left (xbuf, residual_symmetric); step += correction, zsx += [gx; hx] dx
 static void refine_solve(H* s) {

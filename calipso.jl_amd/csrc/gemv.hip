@@ -298,12 +298,12 @@ static void gemv_n_chunks(int rows, int cols, int& rb, int& nchunk, int& chunk) 
 }
 
 // y1 = Z'x1, y2 = Z'x2 (Z = [gx; hx], m x nx) and yl = Lxx xl in one launch + the reduction of the second (api.hip: refine_residual)
-void gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2, double* y1, double* y2, const double* xl, double* yl) {
+int gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2, double* y1, double* y2, const double* xl, double* yl, bool defer_reduce) {
     const Dims& d = s->d;
     if (d.m == 0 || s->blocks.on || s->compact) {              // no constraints, or the block kernels (blocks.hip): the two calls as they were
         if (d.m) gemv_t2(s, d.m, d.nx, s->Z, d.m, x1, x2, y1, y2, SP_Z);
         gemv_n(s, d.nx, d.nx, s->Lxx, d.nx, xl, yl, 1.0, 0.0, SP_LXX);
-        return;
+        return 0;
     }
     int rb, nchunk, chunk;
     gemv_n_chunks(d.nx, d.nx, rb, nchunk, chunk);
@@ -314,7 +314,9 @@ void gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2,
     hipLaunchKernelGGL(k_gemv_t2_and_n, dim3(nt2 + rb * nchunk, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, SP_Z), d.m, d.nx, s->Z, d.m, x1, x2, y1, y2, nt2,
                        sparsity_of(s, SP_LXX), rb, d.nx, d.nx, chunk, s->Lxx, d.nx, xl, s->gemv_partial);
     if (timed) { (void)hipEventRecord(s->ev[6], s->stream); s->time_matvec = false; s->matvec_timed = true; }
+    if (defer_reduce) return nchunk;
     hipLaunchKernelGGL(k_gemv_n_reduce, dim3((d.nx + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, d.nx, nchunk, s->gemv_partial, yl, 1.0, 0.0);
+    return 0;
 }
 
 void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind) {

@@ -234,8 +234,8 @@ static void gb_sds(G* g, const Set& a, int which, bool accumulate, bool refine_f
 static void gb_refine_residual(G* g) {
     H* s = g->base; const Dims& d = s->d;
     launch_refine_local(s);
-    gemv_refine_pair(s, s->step + d.oy(), s->t1, s->w1, s->w2, s->step, s->lxv);      // [gx; hx]'(two vectors) and Lxx step_x: one launch (gemv.hip)
-    launch_refine_x(s);
+    const int nchunk = gemv_refine_pair(s, s->step + d.oy(), s->t1, s->w1, s->w2, s->step, s->lxv, true);      // (api.hip: refine_residual)
+    if (nchunk > 0) launch_refine_x_fused(s, false, nchunk); else launch_refine_x(s);
 }
 static void gb_refine_solve(G* g) {
     H* s = g->base; const Dims& d = s->d;

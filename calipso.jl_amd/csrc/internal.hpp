@@ -313,7 +313,8 @@ void launch_refine_local(calipso_hip_solver* s);
 // t2 = [gx; hx] dx + launch_recover (+ launch_refine_local when with_refine) in ONE launch; false: not available for this handle (the caller takes the separate launches)
 bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool with_refine);
 void solve_tail_plan(const Dims& d, const std::vector<int>& soc_start, const std::vector<int>& soc_dim, std::vector<int>& grp);
-void launch_refine_x(calipso_hip_solver* s, bool publish = false);   // publish: dscal[7] also to the handle's mapped host mirror + sequence number
+void launch_refine_x(calipso_hip_solver* s, bool publish = false);
+void launch_refine_x_fused(calipso_hip_solver* s, bool publish, int nchunk);   // the same with the reduction of the nchunk partial sums of Lxx step_x (gemv_refine_pair) folded in   // publish: dscal[7] also to the handle's mapped host mirror + sequence number
 void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s);
 void launch_accept(calipso_hip_solver* s, double step_size);
 void launch_axpy_points_batch(calipso_hip_solver* s, const double* step_size, int with_s);
@@ -334,7 +335,9 @@ void launch_assemble_K(calipso_hip_solver* s);
 void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
 void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
 void gemv_t2(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x1, const double* x2, double* y1, double* y2, int kind = SP_DENSE);   // y1 = A'x1, y2 = A'x2, one pass
-void gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2, double* y1, double* y2, const double* xl, double* yl);   // gemv_t2 on [gx; hx] and gemv_n on Lxx in one launch
+// gemv_t2 on [gx; hx] and gemv_n on Lxx in one launch.  defer_reduce: the column-chunk partial sums of Lxx xl stay in gemv_partial and their number is returned (> 0) for
+// launch_refine_x_fused to combine; 0: yl holds the product
+int gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2, double* y1, double* y2, const double* xl, double* yl, bool defer_reduce = false);
 void gemv_both(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, const double* u, double* yn, double* yt, double beta_t,
                int kind = SP_DENSE);   // yn = A x, yt = A'u + beta_t*yt, one pass over A
 // `kind` names the block (SP_Z, SP_GX, SP_HX, SP_LXX) so that a handle with an analysed structure skips its structural zeros

@@ -560,9 +560,13 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
         } else {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
+            // tile 0 (the next diagonal block): its column operand IS its row operand, which form_Z has just staged in Ys and whose readers it has waited for —
+            // nothing to stage, no barrier (0.4 us less on the pivot chain of every panel)
+            if (t != 0) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) Ys[row * LDT + cb + it * 16] = yv[h][it];
-            lds_barrier();
+                for (int it = 0; it < 4; ++it) Ys[row * LDT + cb + it * 16] = yv[h][it];
+                lds_barrier();
+            }
             // the registers just staged are free: fetch the SAME panel's share of the next tile into them (one tile = NH units ahead)
             if (more) {
                 if (h + 1 == NH) {

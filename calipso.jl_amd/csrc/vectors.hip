@@ -3,6 +3,8 @@
 // N is ~10^4: elementwise kernels are a handful of workgroups; every reduction is ONE workgroup with a fixed
 // summation order (deterministic), its result written to the device scalar block `dscal`.
 #include <algorithm>
+#include <mutex>
+
 #include "internal.hpp"
 #include "device_utils.hpp"
 
@@ -1051,13 +1053,13 @@ __device__ __forceinline__ double tail_soc_small(const Dims& d, const Scalars& s
     return m;
 }
 
-constexpr int TAIL_ROWS = 16, TAIL_PARTS = 32, TAIL_CPT = 32;
+constexpr int TAIL_ROWS = 16, TAIL_PARTS = 32, TAIL_CPT = 16;
 __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc bt, Dims d, ConeDev cd, const int* __restrict__ grp, int ngrp, const int* rowrange, const double* __restrict__ Z,
                                                                         const double* __restrict__ dx, const double* w, const double* res, const double* resid, const double* wz,
                                                                         const double* Wsoc, double* rsym, double* dsym, double* step, double* accum, double* zsx, double* e, double* t1,
                                                                         double* __restrict__ part, int zsx_mode, int do_refine) {
     constexpr int ROWS = TAIL_ROWS, PARTS = TAIL_PARTS, CPT = TAIL_CPT, W = PARTS * CPT;
-    __shared__ double xs[W];
+    extern __shared__ __attribute__((aligned(16))) double xs[];      // dx, whole (nx rounded up to a multiple of W doubles, zero padded): ONE barrier for the mat-vec
     __shared__ double psum[PARTS][ROWS];
     __shared__ double t2s[ROWS];
     __shared__ double sm[ROWS * PARTS / 64];
@@ -1074,16 +1076,27 @@ __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc b
     // an analysed structure (structure.hip): the columns of the row that can be non-zero — the loads outside are predicated off, the sums are those of the dense rows
     int jlo = 0, jhi = d.nx;
     if (rowrange && live) { jlo = rowrange[2 * (r0 + r)]; jhi = rowrange[2 * (r0 + r) + 1]; }
-    double acc = 0.0;
-    for (int c0 = 0; c0 < d.nx; c0 += W) {
-        double v[CPT];
+    const int npass = (d.nx + W - 1) / W;
+    // the first pass's loads go out before dx is staged (they do not depend on it); from then on pass k + 1 travels while pass k is summed: the row is a stream
+    // of loads with two batches of CPT in flight, not a chain of round trips
+    double va[CPT], vb[CPT];
+    auto fetch = [&](int c0, double (&v)[CPT]) {
 #pragma unroll
         for (int q = 0; q < CPT; ++q) { const int c = c0 + p + PARTS * q; v[q] = (live && c < d.nx && c >= jlo && c < jhi) ? Zr[(size_t)c * d.m] : 0.0; }
-        if (c0) __syncthreads();
-        for (int i = tid; i < W; i += ROWS * PARTS) xs[i] = c0 + i < d.nx ? dx[c0 + i] : 0.0;
-        __syncthreads();
+    };
+    fetch(0, va);
+    for (int i = tid; i < npass * W; i += ROWS * PARTS) xs[i] = i < d.nx ? dx[i] : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+    for (int k = 0; k < npass; k += 2) {
+        if (k + 1 < npass) fetch((k + 1) * W, vb);
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) acc += v[q] * xs[p + PARTS * q];
+        for (int q = 0; q < CPT; ++q) acc += va[q] * xs[k * W + p + PARTS * q];
+        if (k + 1 < npass) {
+            if (k + 2 < npass) fetch((k + 2) * W, va);
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) acc += vb[q] * xs[(k + 1) * W + p + PARTS * q];
+        }
     }
     psum[p][r] = acc;
     // ---- x entries of the step (this workgroup's share) ---------------------------------------------------------------
@@ -1130,7 +1143,14 @@ bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool w
     const BatchSc B = batch_of(s);
     const double* res = which == 0 ? s->residual : s->residual_error;
     double* st = which == 0 ? s->step : s->step_correction;
-    hipLaunchKernelGGL(k_solve_tail, dim3(s->n_zgrp, 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), 0, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
+    constexpr int TW = TAIL_PARTS * TAIL_CPT;
+    const size_t lds = sizeof(double) * (size_t)((s->d.nx + TW - 1) / TW) * TW;
+    if (lds > 48 * 1024) {
+        static std::once_flag big;       // (> 64 KB of dynamic LDS must be asked for)
+        std::call_once(big, [] { (void)hipFuncSetAttribute((const void*)k_solve_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
+        if (lds > 96 * 1024) return false;
+    }
+    hipLaunchKernelGGL(k_solve_tail, dim3(s->n_zgrp, 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), lds, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
                        s->residual, s->wz, s->Wsoc, s->residual_symmetric, s->step_symmetric, st, accumulate ? s->step : (double*)nullptr, s->zsx, s->residual_error, s->t1, s->refpart,
                        which == 0 ? 1 : 2, with_refine ? 1 : 0);
     s->refine_local_done = with_refine;
@@ -1162,6 +1182,76 @@ void launch_refine_local(calipso_hip_solver* s) {
     hipLaunchKernelGGL(k_refine_local, dim3((items + RL_THREADS - 1) / RL_THREADS, 1, B.b.n), dim3(RL_THREADS), 0, s->stream, B, s->d, s->cone, s->solution, s->step,
                        s->residual, s->zsx, s->wz, s->Wsoc, s->residual_error, s->residual_symmetric, s->t1, s->refpart);
     launch_refine_local_wide(s, (items + RL_THREADS - 1) / RL_THREADS);      // their partial norms follow the ones of the kernel above in refpart
+}
+// k_refine_x with the reduction of the Hessian product folded in: the column-chunk partial sums of Lxx step_x (k_gemv_t2_and_n leaves nchunk of them per row) are
+// combined HERE, in the order k_gemv_n_reduce combines them (four lanes per row, every fourth chunk each, then (0 + 1) + (2 + 3): the same bits), 64 rows per
+// workgroup; the norm is a maximum over workgroups — exact in any order — through an atomic maximum on the bit pattern of the (non-negative) doubles, and the
+// workgroup that arrives last (a ticket counter) adds the other rows' parts, stores dscal[7] and publishes.  One launch less per refinement residual.
+__global__ __launch_bounds__(256) void k_refine_x_fused(BatchSc bt, Dims d, int have_m, int nchunk, const double* __restrict__ partial, const double* __restrict__ v,
+                                                         const double* __restrict__ res, const double* __restrict__ w1, const double* __restrict__ w2, double* __restrict__ e,
+                                                         double* __restrict__ rsym, double* __restrict__ xbuf, double* __restrict__ dscal, const double* __restrict__ part, int nparts,
+                                                         double* __restrict__ hpub, unsigned long long* __restrict__ hseq, unsigned long long seq) {
+    __shared__ double ps[4][64];
+    __shared__ double sm[4];
+    __shared__ int last;
+    inst_shift(bt.b, partial, v, res, w1, w2, e, rsym, xbuf, dscal, part);
+    const Scalars sc = bt.scal(blockIdx.z);
+    const int r = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + r;
+    double acc = 0.0;
+    if (i < d.nx) {
+        for (int c0 = p; c0 < nchunk; c0 += 64) {
+            double pv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int c = c0 + 4 * u; pv[u] = c < nchunk ? partial[(size_t)c * d.nx + i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (c0 + 4 * u < nchunk) acc += pv[u];
+        }
+    }
+    ps[p][r] = acc;
+    __syncthreads();
+    double m = 0.0;
+    if (p == 0) {
+        if (i < d.nx) {
+            const double lv = (ps[0][r] + ps[1][r]) + (ps[2][r] + ps[3][r]);
+            const double hv = (lv + (have_m ? w1[i] : 0.0)) + sc.ep * v[i];
+            const double rr = res[i] - hv;
+            e[i] = rr;
+            rsym[i] = rr;
+            xbuf[i] = have_m ? rr + w2[i] : rr;
+            m = fabs(rr);
+        } else if (i < d.NP) xbuf[i] = 0.0;
+    }
+    const double mr = block_max(m, sm);
+    unsigned long long* nb = reinterpret_cast<unsigned long long*>(dscal + 60);
+    unsigned* ticket = reinterpret_cast<unsigned*>(dscal + 61);
+    if (threadIdx.x == 0) {
+        atomicMax(nb, (unsigned long long)__double_as_longlong(mr));          // (non-negative doubles order like their bit patterns)
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    double mm = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 256) mm = fmax(mm, part[k]);     // the other rows' part of the norm (k_refine_local / k_solve_tail)
+    const double mo = block_max(mm, sm);
+    if (threadIdx.x == 0) {
+        const double mx = fmax(mo, __longlong_as_double((long long)__hip_atomic_load(nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        dscal[7] = mx;
+        __hip_atomic_store(nb, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next residual
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hpub) {
+            hpub[7] = mx;
+            __threadfence_system();
+            __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+void launch_refine_x_fused(calipso_hip_solver* s, bool publish, int nchunk) {
+    const BatchSc B = batch_of(s);
+    hipLaunchKernelGGL(k_refine_x_fused, dim3((s->d.NP + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B, s->d, s->d.m > 0 ? 1 : 0, nchunk, s->gemv_partial, s->step, s->residual, s->w1, s->w2,
+                       s->residual_error, s->residual_symmetric, s->xbuf, s->dscal, s->refpart, s->refparts, publish ? s->hscal_dev : (double*)nullptr,
+                       publish ? s->hseq_dev : (unsigned long long*)nullptr, publish ? ++s->pub_seq : 0ULL);
 }
 void launch_refine_x(calipso_hip_solver* s, bool publish) {
     const BatchSc B = batch_of(s);
