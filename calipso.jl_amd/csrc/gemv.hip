@@ -193,8 +193,9 @@ __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, Sparsity s
 __global__ __launch_bounds__(256) void k_gemv_t2_and_n(Batch bt, Sparsity spz, int rowsz, int colsz, const double* __restrict__ Z, int ldz, const double* __restrict__ x1,
                                                         const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2, int nt2, Sparsity spl, int rb,
                                                         int rowsl, int colsl, int chunk, const double* __restrict__ L, int ldl, const double* __restrict__ xl,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, const int* __restrict__ gate = nullptr, int gate_epoch = 0) {
     static_assert(GN_ROWS == 256, "one block size for both bodies");
+    if (gate && gate[0] == gate_epoch) return;        // (internal.hpp: gate)
     const int b = blockIdx.x;
     if (b < nt2) gemv_t2_body(bt, spz, b, rowsz, colsz, Z, ldz, x1, x2, y1, y2);
     else gemv_n_partial_body(bt, spl, (b - nt2) % rb, (b - nt2) / rb, 0, rowsl, colsl, chunk, L, ldl, xl, partial);
@@ -312,7 +313,7 @@ int gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2, 
     const bool timed = s->time_matvec && !s->cur;
     if (timed) (void)hipEventRecord(s->ev[5], s->stream);
     hipLaunchKernelGGL(k_gemv_t2_and_n, dim3(nt2 + rb * nchunk, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, SP_Z), d.m, d.nx, s->Z, d.m, x1, x2, y1, y2, nt2,
-                       sparsity_of(s, SP_LXX), rb, d.nx, d.nx, chunk, s->Lxx, d.nx, xl, s->gemv_partial);
+                       sparsity_of(s, SP_LXX), rb, d.nx, d.nx, chunk, s->Lxx, d.nx, xl, s->gemv_partial, s->gate_epoch ? s->gate : (const int*)nullptr, s->gate_epoch);
     if (timed) { (void)hipEventRecord(s->ev[6], s->stream); s->time_matvec = false; s->matvec_timed = true; }
     if (defer_reduce) return nchunk;
     hipLaunchKernelGGL(k_gemv_n_reduce, dim3((d.nx + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, d.nx, nchunk, s->gemv_partial, yl, 1.0, 0.0);

@@ -211,6 +211,9 @@ struct calipso_hip_solver {
     double* refpart = nullptr;  // per workgroup of k_refine_local / k_solve_tail: its part of ||residual_error||_inf
     int refparts = 0;           // how many of them the last producer wrote (k_refine_x combines them)
     int* zgrp = nullptr; int n_zgrp = 0;   // k_solve_tail (vectors.hip): first row of every group of whole constraints (<= 16 rows of [gx; hx]); shape-only, outside the slab
+    // speculative refinement rounds (api.hip: do_refinement): while gate_epoch != 0 the launchers of a round's kernels pass (gate, gate_epoch) and the kernels leave at
+    // once when gate[0] == gate_epoch — "this refinement has converged" (set by the residual kernel that saw it), so rounds queued ahead of the host's knowledge cost nothing
+    int* gate = nullptr; int gate_epoch = 0; int gate_counter = 0;
     bool refine_local_done = false;        // the solve tail just queued also formed the local rows of the refinement residual: the next launch_refine_local is a no-op
     double* Ypanel = nullptr;   // NP*NB: M_k = (L_kk D_k L_kk')^-1 of every 64-column panel (ldl.hip: what the trailing update multiplies the raw panel with)
     double* Tinv = nullptr;     // tinv_doubles(NP): inverses of the unit-lower diagonal blocks of L (up to 1024 x 1024, the last one may be 512 wide)
@@ -312,9 +315,11 @@ void launch_recover(calipso_hip_solver* s, double* step, const double* res, doub
 void launch_refine_local(calipso_hip_solver* s);
 // t2 = [gx; hx] dx + launch_recover (+ launch_refine_local when with_refine) in ONE launch; false: not available for this handle (the caller takes the separate launches)
 bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool with_refine);
+bool solve_tail_available(const calipso_hip_solver* s);
 void solve_tail_plan(const Dims& d, const std::vector<int>& soc_start, const std::vector<int>& soc_dim, std::vector<int>& grp);
 void launch_refine_x(calipso_hip_solver* s, bool publish = false);
-void launch_refine_x_fused(calipso_hip_solver* s, bool publish, int nchunk);   // the same with the reduction of the nchunk partial sums of Lxx step_x (gemv_refine_pair) folded in   // publish: dscal[7] also to the handle's mapped host mirror + sequence number
+void launch_refine_x_fused(calipso_hip_solver* s, bool publish, int nchunk, int it = -1, bool last_queued = false);   // it >= 0: speculative round index (see gate)
+void launch_trsv_direct(calipso_hip_solver* s, double* x);      // launch_trsv without the captured graph (its kernels then carry the handle's current gate)   // the same with the reduction of the nchunk partial sums of Lxx step_x (gemv_refine_pair) folded in   // publish: dscal[7] also to the handle's mapped host mirror + sequence number
 void launch_axpy_points(calipso_hip_solver* s, double step_size, int with_s);
 void launch_accept(calipso_hip_solver* s, double step_size);
 void launch_axpy_points_batch(calipso_hip_solver* s, const double* step_size, int with_s);

@@ -1281,7 +1281,9 @@ __global__ __launch_bounds__(256) void k_trsv_update_t(Batch bt, int NP, int k0,
 // right-hand side below the block.  ROWS rows per workgroup, the first w / ROWS workgroups take the triangular part (as k_trsv_block_n), the others W.
 template <int ROWS, int PARTS, int CPT>
 __global__ __launch_bounds__(ROWS * PARTS) void k_trsv_fwd(Batch bt, int kb, int tb, int w, int rb, const double* __restrict__ Tinv, const double* __restrict__ Wb, double* __restrict__ b,
-                                                            const double* __restrict__ Dx, double* __restrict__ u, double* __restrict__ z) {
+                                                            const double* __restrict__ Dx, double* __restrict__ u, double* __restrict__ z, const int* __restrict__ gate = nullptr,
+                                                            int gate_epoch = 0) {
+    if (gate && gate[0] == gate_epoch) return;        // a round queued ahead of a refinement that has converged meanwhile (internal.hpp: gate)
     constexpr int W = PARTS * CPT;
     __shared__ double bs[W];
     __shared__ double part[PARTS][ROWS];
@@ -1322,7 +1324,8 @@ __global__ __launch_bounds__(ROWS * PARTS) void k_trsv_fwd(Batch bt, int kb, int
 // blocks below (written by the launches before this one); the block's own v goes to x[k0 ..].
 template <int NCH>
 __global__ __launch_bounds__(256) void k_trsv_bwd(Batch bt, int kb, int tb, int w, int rb, int rows, const double* __restrict__ Tinv, const double* __restrict__ Wb, const double* __restrict__ z,
-                                                   double* __restrict__ x) {
+                                                   double* __restrict__ x, const int* __restrict__ gate = nullptr, int gate_epoch = 0) {
+    if (gate && gate[0] == gate_epoch) return;
     __shared__ double zs[NCH * 64];
     inst_shift(bt, Tinv, Wb, z, x);
     const int tid = threadIdx.x, lane = tid & 63, k0 = kb * tb;
@@ -1352,8 +1355,9 @@ __global__ __launch_bounds__(256) void k_trsv_bwd(Batch bt, int kb, int tb, int 
     if (lane == 0) x[k0 + c] = acc;
 }
 template <int NCH>
-static void launch_trsv_bwd(hipStream_t st, unsigned nz, const Batch& bt, int kb, int tb, int w, int rb, int rows, const double* Tinv, const double* Wb, const double* z, double* x) {
-    hipLaunchKernelGGL(k_trsv_bwd<NCH>, dim3(w / 4, 1, nz), dim3(256), 0, st, bt, kb, tb, w, rb, rows, Tinv, Wb, z, x);
+static void launch_trsv_bwd(hipStream_t st, unsigned nz, const Batch& bt, int kb, int tb, int w, int rb, int rows, const double* Tinv, const double* Wb, const double* z, double* x,
+                            const int* gate, int ge) {
+    hipLaunchKernelGGL(k_trsv_bwd<NCH>, dim3(w / 4, 1, nz), dim3(256), 0, st, bt, kb, tb, w, rb, rows, Tinv, Wb, z, x, gate, ge);
 }
 
 bool wform_on(const calipso_hip_solver* s) {
@@ -1381,24 +1385,26 @@ static void enqueue_trsv_wform(calipso_hip_solver* s, double* x) {
     double* z = s->zf2;
     const Batch bt = batch_of(s).b;
     const unsigned nz = bt.n;
+    const int* gate = s->gate_epoch ? s->gate : (const int*)nullptr;
+    const int ge = s->gate_epoch;
     for (int kb = 0; kb < nb; ++kb) {
         const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
         const double* Wb = s->Wfac + wform_offset(NP, tb, kb);
         const int rows = wform_rows(s, rb);
-        if (w > 512) hipLaunchKernelGGL((k_trsv_fwd<16, 32, 32>), dim3((w + rows) / 16, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z);
-        else hipLaunchKernelGGL((k_trsv_fwd<16, 16, 32>), dim3((w + rows) / 16, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z);
+        if (w > 512) hipLaunchKernelGGL((k_trsv_fwd<16, 32, 32>), dim3((w + rows) / 16, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z, gate, ge);
+        else hipLaunchKernelGGL((k_trsv_fwd<16, 16, 32>), dim3((w + rows) / 16, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z, gate, ge);
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
         const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
         const double* Wb = s->Wfac + wform_offset(NP, tb, kb);
         const int rows = wform_rows(s, rb), nch = (w + rows + 63) / 64;
-        if (nch <= 8) launch_trsv_bwd<8>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
-        else if (nch <= 16) launch_trsv_bwd<16>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
-        else if (nch <= 24) launch_trsv_bwd<24>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
-        else if (nch <= 32) launch_trsv_bwd<32>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
-        else if (nch <= 40) launch_trsv_bwd<40>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
-        else if (nch <= 48) launch_trsv_bwd<48>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
-        else launch_trsv_bwd<64>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x);
+        if (nch <= 8) launch_trsv_bwd<8>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x, gate, ge);
+        else if (nch <= 16) launch_trsv_bwd<16>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x, gate, ge);
+        else if (nch <= 24) launch_trsv_bwd<24>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x, gate, ge);
+        else if (nch <= 32) launch_trsv_bwd<32>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x, gate, ge);
+        else if (nch <= 40) launch_trsv_bwd<40>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x, gate, ge);
+        else if (nch <= 48) launch_trsv_bwd<48>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x, gate, ge);
+        else launch_trsv_bwd<64>(s->stream, nz, bt, kb, tb, w, rb, rows, s->Tinv, Wb, z, x, gate, ge);
     }
 }
 
@@ -1641,6 +1647,10 @@ void launch_ldl(calipso_hip_solver* s) {
     if (!graphs || !replay_or_capture(s, s->graph_ldl_fin, s->graph_ldl_fin_tried, [&] { enqueue_ldl_finish(s); })) enqueue_ldl_finish(s);
 }
 
+void launch_trsv_direct(calipso_hip_solver* s, double* x) {
+    if (s->stage_parallel && s->spS) { (void)sparse_solve_inplace(s->spS, s->stream, batch_of(s).b, x); return; }
+    enqueue_trsv(s, x);
+}
 void launch_trsv(calipso_hip_solver* s, double* x) {
     if (s->stage_parallel && s->spS) { (void)sparse_solve_inplace(s->spS, s->stream, batch_of(s).b, x); return; }
     if (s->cur || x != s->xbuf || !s->use_graphs || !replay_or_capture(s, s->graph_trsv, s->graph_trsv_tried, [&] { enqueue_trsv(s, s->xbuf); })) enqueue_trsv(s, x);

@@ -1057,7 +1057,8 @@ constexpr int TAIL_ROWS = 16, TAIL_PARTS = 32, TAIL_CPT = 16;
 __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc bt, Dims d, ConeDev cd, const int* __restrict__ grp, int ngrp, const int* rowrange, const double* __restrict__ Z,
                                                                         const double* __restrict__ dx, const double* w, const double* res, const double* resid, const double* wz,
                                                                         const double* Wsoc, double* rsym, double* dsym, double* step, double* accum, double* zsx, double* e, double* t1,
-                                                                        double* __restrict__ part, int zsx_mode, int do_refine) {
+                                                                        double* __restrict__ part, int zsx_mode, int do_refine, const int* __restrict__ gate = nullptr, int gate_epoch = 0) {
+    if (gate && gate[0] == gate_epoch) return;        // (internal.hpp: gate)
     constexpr int ROWS = TAIL_ROWS, PARTS = TAIL_PARTS, CPT = TAIL_CPT, W = PARTS * CPT;
     extern __shared__ __attribute__((aligned(16))) double xs[];      // dx, whole (nx rounded up to a multiple of W doubles, zero padded): ONE barrier for the mat-vec
     __shared__ double psum[PARTS][ROWS];
@@ -1138,6 +1139,7 @@ static bool solve_tail_ok(const calipso_hip_solver* s) {
     static const bool env = [] { const char* e = getenv("CALIPSO_HIP_SOLVE_TAIL"); return !e || atoi(e) != 0; }();
     return env && s->zgrp && s->d.m > 0 && !s->compact && !(s->blocks.on && s->blocks_effective);
 }
+bool solve_tail_available(const calipso_hip_solver* s) { return solve_tail_ok(s); }
 bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool with_refine) {
     if (!solve_tail_ok(s)) return false;
     const BatchSc B = batch_of(s);
@@ -1152,7 +1154,7 @@ bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool w
     }
     hipLaunchKernelGGL(k_solve_tail, dim3(s->n_zgrp, 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), lds, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
                        s->residual, s->wz, s->Wsoc, s->residual_symmetric, s->step_symmetric, st, accumulate ? s->step : (double*)nullptr, s->zsx, s->residual_error, s->t1, s->refpart,
-                       which == 0 ? 1 : 2, with_refine ? 1 : 0);
+                       which == 0 ? 1 : 2, with_refine ? 1 : 0, s->gate_epoch ? s->gate : (const int*)nullptr, s->gate_epoch);
     s->refine_local_done = with_refine;
     if (with_refine) s->refparts = s->n_zgrp;
     return true;
@@ -1190,11 +1192,22 @@ void launch_refine_local(calipso_hip_solver* s) {
 __global__ __launch_bounds__(256) void k_refine_x_fused(BatchSc bt, Dims d, int have_m, int nchunk, const double* __restrict__ partial, const double* __restrict__ v,
                                                          const double* __restrict__ res, const double* __restrict__ w1, const double* __restrict__ w2, double* __restrict__ e,
                                                          double* __restrict__ rsym, double* __restrict__ xbuf, double* __restrict__ dscal, const double* __restrict__ part, int nparts,
-                                                         double* __restrict__ hpub, unsigned long long* __restrict__ hseq, unsigned long long seq) {
+                                                         double* __restrict__ hpub, unsigned long long* __restrict__ hseq, unsigned long long seq, int* __restrict__ gate = nullptr,
+                                                         int gate_epoch = 0, int it = -1, int min_it = 0, double tol = 0.0, int last_queued = 0) {
     __shared__ double ps[4][64];
     __shared__ double sm[4];
     __shared__ int last;
     inst_shift(bt.b, partial, v, res, w1, w2, e, rsym, xbuf, dscal, part);
+    // Speculative rounds (api.hip: do_refinement): gate[0] = epoch of the refinement that has converged, gate[1] = residuals evaluated (0 = only the initial one),
+    // dscal[58] = first norm, dscal[59] = last norm.  A residual queued behind the converging one does nothing — except the LAST queued one, which reports.
+    if (gate && gate[0] == gate_epoch) {
+        if (last_queued && blockIdx.x == 0 && threadIdx.x == 0 && hpub) {
+            hpub[7] = dscal[59]; hpub[20] = dscal[58]; hpub[21] = (double)gate[1]; hpub[22] = 1.0;
+            __threadfence_system();
+            __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     const Scalars sc = bt.scal(blockIdx.z);
     const int r = threadIdx.x & 63, p = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + r;
@@ -1240,18 +1253,29 @@ __global__ __launch_bounds__(256) void k_refine_x_fused(BatchSc bt, Dims d, int 
         dscal[7] = mx;
         __hip_atomic_store(nb, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next residual
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (hpub) {
+        int stopped = 0;
+        if (gate) {
+            if (it == 0) dscal[58] = mx;
+            dscal[59] = mx;
+            gate[1] = it;
+            if (mx <= tol && it >= min_it) { gate[0] = gate_epoch; stopped = 1; }      // iterative_refinement.jl:14-16: the loop ends here
+        }
+        if (hpub && (!gate || last_queued)) {
             hpub[7] = mx;
+            if (gate) { hpub[20] = dscal[58]; hpub[21] = (double)it; hpub[22] = (double)stopped; }
             __threadfence_system();
             __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
-void launch_refine_x_fused(calipso_hip_solver* s, bool publish, int nchunk) {
+void launch_refine_x_fused(calipso_hip_solver* s, bool publish, int nchunk, int it, bool last_queued) {
     const BatchSc B = batch_of(s);
+    const bool spec = it >= 0 && s->gate_epoch != 0;
+    const bool pub = publish && (!spec || last_queued);          // speculative rounds: only the last queued residual reports to the host
     hipLaunchKernelGGL(k_refine_x_fused, dim3((s->d.NP + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B, s->d, s->d.m > 0 ? 1 : 0, nchunk, s->gemv_partial, s->step, s->residual, s->w1, s->w2,
-                       s->residual_error, s->residual_symmetric, s->xbuf, s->dscal, s->refpart, s->refparts, publish ? s->hscal_dev : (double*)nullptr,
-                       publish ? s->hseq_dev : (unsigned long long*)nullptr, publish ? ++s->pub_seq : 0ULL);
+                       s->residual_error, s->residual_symmetric, s->xbuf, s->dscal, s->refpart, s->refparts, pub ? s->hscal_dev : (double*)nullptr,
+                       pub ? s->hseq_dev : (unsigned long long*)nullptr, pub ? ++s->pub_seq : 0ULL, spec ? s->gate : (int*)nullptr, s->gate_epoch, it,
+                       (int)s->opt.min_iterative_refinement, s->opt.iterative_refinement_tolerance, last_queued ? 1 : 0);
 }
 void launch_refine_x(calipso_hip_solver* s, bool publish) {
     const BatchSc B = batch_of(s);
