@@ -99,6 +99,14 @@ function HIPSolver(solver::CALIPSO.Solver; device::Integer=0, structure=nothing)
             (Int64, Int64, Int64, Int64, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Ptr{Cvoid}}),
             d.variables, d.parameters, d.equality_dual, d.cone_dual, length(nn), nn, length(soc), ptr, flat, device, rf, rl, length(hb), hb, href)
     end
+    if rc != 0 && structure !== nothing
+        # the declared structure has nothing for the block path to exploit (one Hessian block: e.g. dynamics whose y'f Hessian couples x_t with x_{t+1}, src/
+        # trajectory_optimization/dynamics.jl:245-259): a dense handle instead, whose banded / stage-parallel treatment calipso_hip_analyze_structure can still turn on
+        @warn "calipso_hip_create_structured refused the declared structure ($(last_error(C_NULL))); falling back to a dense handle"
+        rc = ccall((:calipso_hip_create, lib), Int32,
+            (Int64, Int64, Int64, Int64, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ptr{Ptr{Cvoid}}),
+            d.variables, d.parameters, d.equality_dual, d.cone_dual, length(nn), nn, length(soc), ptr, flat, device, href)
+    end
     rc != 0 && throw(HIPError(rc, "calipso_hip_create: $(last_error(href[]))"))
     hs = HIPSolver(href[], solver, @cfunction($(evaluate_callback), Int32, (Ptr{Cvoid}, UInt32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64})))
     finalizer(x -> ccall((:calipso_hip_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), hs)
