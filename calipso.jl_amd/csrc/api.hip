@@ -294,7 +294,7 @@ int32_t calipso_hip_destroy(H* s) {
     if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
     if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
     calipso::blocks_release(s);
-    double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi};
+    double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi, s->evalL, s->evalZ};
     for (double* p : dp) if (p) (void)hipFree(p);
     int* ip[] = {s->cone.soc_start, s->cone.soc_dim, s->cone.soc_woff, s->cone.entry_soc, s->cone.wide, s->zgrp, s->gate};
     for (int* p : ip) if (p) (void)hipFree(p);
@@ -737,6 +737,14 @@ static int device_evaluate(H* s, const double* pt, uint32_t flags) {
     o.equality_jacobian_variables = d.ne ? s->gx : nullptr;
     o.cone_jacobian_variables = d.nc ? s->hx : nullptr;
     o.jacobian_ld = d.m;
+    if (s->compact) {
+        if (!s->evalL) {
+            if (dalloc(s, &s->evalL, (size_t)d.nx * d.nx) || dalloc(s, &s->evalZ, (size_t)std::max(1, d.m) * d.nx)) return CALIPSO_ERR_HIP;
+        }
+        o.lagrangian_hessian = s->evalL;
+        o.equality_jacobian_variables = d.ne ? s->evalZ : nullptr;
+        o.cone_jacobian_variables = d.nc ? s->evalZ + d.ne : nullptr;
+    }
     o.lagrangian_gradient_parameters = d.np ? s->lgp : nullptr;
     o.equality_jacobian_parameters = (d.np && d.ne) ? s->gp : nullptr;
     o.cone_jacobian_parameters = (d.np && d.nc) ? s->hp : nullptr;
@@ -745,6 +753,10 @@ static int device_evaluate(H* s, const double* pt, uint32_t flags) {
     if (rc != 0) { s->err = "device evaluator failed"; return CALIPSO_ERR_CALLBACK; }
     const uint32_t hess = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
     if (flags & hess) s->hessian_dirty = true;
+    if (s->compact) {
+        const bool jz = (flags & (CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE_JACOBIAN)) != 0, hl = (flags & hess) != 0;
+        return (jz || hl) ? blocks_pack_from(s, s->evalL, s->evalZ, hl, jz) : CALIPSO_OK;
+    }
     // blocks written behind our back: an analysed stage-banded structure has to be re-checked against them (as set_field does)
     if (structure_active(s) && (flags & hess)) { const int v = structure_validate(s, 0); if (v < 0) return v; }
     if (structure_active(s) && (flags & CALIPSO_EVAL_EQUALITY_JACOBIAN) && d.ne) { const int v = structure_validate(s, 1); if (v < 0) return v; }
@@ -954,7 +966,8 @@ int32_t calipso_hip_initialize(H* s, const double* guess) {
 
 int32_t calipso_hip_set_device_evaluator(H* s, calipso_device_eval_fn fn, void* user) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
-    if (s->compact && fn) { s->err = "device evaluators write the dense ProblemData layout, which a structured handle does not hold"; return CALIPSO_ERR_ARGUMENT; }
+    // (a structured handle holds no dense ProblemData arrays: the evaluator then writes into dense scratch arrays of the handle — allocated on its first evaluation:
+    // nx^2 + (ne + nc) nx doubles — whose entries go into the blocks behind it; what lies outside the declared structure must be zero: device_evaluate checks)
     s->dev_eval = fn; s->dev_eval_user = user;
     return CALIPSO_OK;
 }

@@ -285,6 +285,46 @@ void blocks_pack(calipso_hip_solver* s, bool z, bool l) {
     if (l && B.nlb) hipLaunchKernelGGL(k_blocks_pack_l, dim3(B.nlb), dim3(256), 0, s->stream, one, B.d_lblk, s->d.nx, s->Lxx, s->Lsym);
 }
 
+// A device evaluator on a structured handle writes the dense ProblemData layout into scratch arrays of the handle (api.hip: device_evaluate); from there the values go
+// into the blocks, and what lies outside the declared structure must be zero: one pass over the dense array per check (the price of a dense interchange format).
+__global__ __launch_bounds__(256) void k_check_z_outside(const ZBlock* __restrict__ blk, int m, int nx, const double* __restrict__ Z, int* __restrict__ flag) {
+    const ZBlock b = blk[blockIdx.x];
+    const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
+    int bad = 0;
+    for (int i0 = 0; i0 < b.nrows; i0 += 64) {
+        const int i = i0 + lane;
+        if (i >= b.nrows) continue;
+        for (int j = p; j < nx; j += 4) if ((j < b.col0 || j >= b.col0 + b.ncols) && Z[(b.row0 + i) + (size_t)j * m] != 0.0) bad = 1;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+__global__ void k_check_l_outside(int nx, const int* __restrict__ colrange, const double* __restrict__ L, int* __restrict__ flag) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)nx * nx) return;
+    const int i = (int)(e % nx), j = (int)(e / nx);
+    if ((i < colrange[2 * j] || i >= colrange[2 * j + 1]) && L[e] != 0.0) atomicOr(flag, 2);
+}
+int blocks_pack_from(calipso_hip_solver* s, const double* L, const double* Z, bool l, bool z) {
+    StageBlocks& B = s->blocks;
+    if (!B.on) return CALIPSO_ERR_ARGUMENT;
+    const Dims& d = s->d;
+    const Batch one;
+    int* flag = s->icount + 60;
+    CK(hipMemsetAsync(flag, 0, sizeof(int), s->stream));
+    if (z && B.nblk) {
+        hipLaunchKernelGGL(k_check_z_outside, dim3(B.nblk), dim3(256), 0, s->stream, B.d_blk, d.m, d.nx, Z, flag);
+        hipLaunchKernelGGL(k_blocks_pack_z, dim3(B.nblk), dim3(256), 0, s->stream, one, B.d_blk, d.m, Z, s->Lsym);
+    }
+    if (l && B.nlb) {
+        if (B.d_colrange) hipLaunchKernelGGL(k_check_l_outside, dim3((unsigned)(((size_t)d.nx * d.nx + 255) / 256)), dim3(256), 0, s->stream, d.nx, B.d_colrange, L, flag);
+        hipLaunchKernelGGL(k_blocks_pack_l, dim3(B.nlb), dim3(256), 0, s->stream, one, B.d_lblk, d.nx, L, s->Lsym);
+    }
+    CK(hipMemcpyAsync(s->hicount + 60, flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    CK(hipStreamSynchronize(s->stream));
+    if (s->hicount[60] != 0) { s->err = "the device evaluator wrote non-zeros outside the declared structure of the handle"; return CALIPSO_ERR_ARGUMENT; }
+    return CALIPSO_OK;
+}
+
 static bool blocks_usable(const calipso_hip_solver* s) { return s->blocks.on && s->blocks_effective; }
 
 bool blocks_gemv_n(calipso_hip_solver* s, int kind, const double* x, double* y, double alpha, double beta) {

@@ -176,6 +176,7 @@ struct calipso_hip_solver {
     void* cb_user = nullptr;
     calipso_device_eval_fn dev_eval = nullptr;   // user evaluation on the device (include/calipso_hip.h): enqueues on `stream`, never syncs
     void* dev_eval_user = nullptr;
+    double *evalL = nullptr, *evalZ = nullptr;   // structured handle with a device evaluator: dense scratch (nx^2, m nx) the evaluator writes; packed into the blocks behind it
     std::map<std::string, double*> optd;
     // host copies of the layout
     std::vector<int> h_soc_start, h_soc_dim, h_soc_woff;
@@ -363,6 +364,7 @@ void launch_pad_identity(calipso_hip_solver* s);
 // then takes the dense-layout kernel.
 void blocks_release(calipso_hip_solver* s);
 void blocks_pack(calipso_hip_solver* s, bool z, bool l);
+int blocks_pack_from(calipso_hip_solver* s, const double* L, const double* Z, bool l, bool z);   // dense arrays -> blocks, with the check that nothing lies outside the structure (synchronises)
 bool blocks_gemv_n(calipso_hip_solver* s, int kind, const double* x, double* y, double alpha, double beta);
 bool blocks_gemv_t(calipso_hip_solver* s, int kind, const double* u1, const double* u2, double* y1, double* y2, double alpha, double beta);
 bool blocks_schur(calipso_hip_solver* s);

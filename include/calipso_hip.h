@@ -130,9 +130,10 @@ int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
  * calipso_hip_create exist.  Uploads: calipso_hip_set_field with the dense host arrays of ProblemData (packed on the host; a non-zero outside the declared
  * structure is an error), calipso_hip_set_sparsity + calipso_hip_scatter_field / _hessian (straight into the blocks), calipso_hip_qp_attach.  Everything
  * else of this header works as on a dense handle — calipso_hip_differentiate included (differentiate.jl:1-61: the products with [gx; hx] block by block for all
- * parameter columns at once, the solves through the fronts for all columns together) — except: no device evaluators (they write the dense ProblemData
- * arrays, which do not exist here), no calipso_hip_analyze_structure / clear_structure / set_stage_parallel(off) / set_stage_blocks(off) (the structure is
- * fixed); members of a group must share one structure.  The Hessian must have at least two diagonal blocks (dynamics whose y'f Hessian couples x_t with
+ * parameter columns at once, the solves through the fronts for all columns together) and device evaluators (they write the dense ProblemData layout: on such a
+ * handle into dense scratch arrays — nx^2 + (ne + nc) nx doubles, allocated on the first evaluation — whose entries go into the blocks behind the evaluator; a
+ * non-zero outside the declared structure is an error) — except: no calipso_hip_analyze_structure / clear_structure / set_stage_parallel(off) /
+ * set_stage_blocks(off) (the structure is fixed); members of a group must share one structure.  The Hessian must have at least two diagonal blocks (dynamics whose y'f Hessian couples x_t with
  * x_{t+1}, e.g. implicit integrators, declare one block and are refused: use calipso_hip_create + calipso_hip_analyze_structure for those). */
 int32_t calipso_hip_create_structured(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx, int64_t n_soc,
                                       const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device, const int64_t* row_first, const int64_t* row_last,

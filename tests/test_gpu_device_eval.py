@@ -126,3 +126,46 @@ def test_group_members_with_user_device_evaluators():
     g.close()
     for u in users:
         UL.qp_user_destroy(u)
+
+
+def test_device_evaluator_on_a_structured_handle():
+    """a STRUCTURED handle (calipso_hip_create_structured) holds no dense Lxx / [gx; hx]: the user's kernels write the dense ProblemData layout into scratch
+    arrays of the handle and the entries go into the blocks behind them — same fields, same solve as the dense handle with the same evaluator; an evaluator
+    that writes outside the declared structure is refused."""
+    pkg, UL = load_pkg(), user_lib()
+    prob, pt, lam = pr.staged_conic_qp(pkg.splitmix_uniform, 9, 6, 8, 4, 3, 1, 3)
+    user = make_qp_user(UL, prob)
+    kw = dict(nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices)
+    counted = CountingProblem(prob)
+    st = pkg.Solver(counted, prob.nx, 0, prob.ne, prob.nc, structure=pr.declared_structure(prob), **kw)
+    st.set_device_evaluator(fnptr(UL.qp_device_eval), user)
+    dense = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, **kw)
+    dense.set_device_evaluator(fnptr(UL.qp_device_eval), user)
+    w = np.random.default_rng(1).standard_normal(st.N)
+    for s in (st, dense):
+        s.set("solution", w)
+        s.device_evaluate(pr.ALL_VARIABLE_FLAGS, 0)
+    for name, ln in (("objective", 1), ("objective_gradient_variables", prob.nx), ("equality_constraint", prob.ne), ("cone_constraint", prob.nc),
+                     ("equality_dual_jacobian_variables", prob.nx), ("cone_dual_jacobian_variables", prob.nx), ("lagrangian_hessian", prob.nx ** 2),
+                     ("equality_jacobian_variables", prob.ne * prob.nx), ("cone_jacobian_variables", prob.nc * prob.nx)):
+        assert np.array_equal(st.get(name, ln), dense.get(name, ln)), name
+    x0 = np.zeros(prob.nx)
+    for s in (st, dense):
+        pkg.initialize_b(s, x0)
+    assert pkg.solve_b(st) and pkg.solve_b(dense)
+    assert counted.calls == 0
+    assert st.stats()["total_iterations"] == dense.stats()["total_iterations"]
+    assert np.abs(st.solution.all - dense.solution.all).max() <= 1e-8 * max(1.0, np.abs(dense.solution.all).max())
+    UL.qp_user_destroy(user)
+    # the same structure, but the user's A couples the first and the last stage
+    import copy
+    bad = copy.copy(prob)
+    bad.A = prob.A.copy()
+    bad.A[0, prob.nx - 1] = 0.7
+    user2 = make_qp_user(UL, bad)
+    st2 = pkg.Solver(bad, prob.nx, 0, prob.ne, prob.nc, structure=pr.declared_structure(prob), **kw)
+    st2.set_device_evaluator(fnptr(UL.qp_device_eval), user2)
+    st2.set("solution", w)
+    with pytest.raises(pkg.CalipsoHipError, match="outside the declared structure"):
+        st2.device_evaluate(pr.ALL_VARIABLE_FLAGS, 0)
+    UL.qp_user_destroy(user2)
