@@ -380,6 +380,7 @@ void launch_ldl(calipso_hip_solver* s);
 void ldl_drop_graphs(calipso_hip_solver* s);
 bool ldl_chain_ok(calipso_hip_solver* s);
 void launch_trsv(calipso_hip_solver* s, double* x);            // x (length NP) <- S^-1 x using L, D
+bool lastblock_sym_on(const calipso_hip_solver* s);   // the last solve block as one symmetric mat-vec (ldl.hip)
 bool wform_on(const calipso_hip_solver* s);                    // the solves of this handle (or of the group launch in progress) go through the W-form blocks
 // solvek.hip
 void launch_copy_pad(calipso_hip_solver* s, const double* src, int n, double* dst, int npad);

@@ -931,6 +931,63 @@ __global__ __launch_bounds__(256) void k_wform_product(Batch bt, int NP, int tb,
     merge32_tile(S + (k0 + w + tiy * 32) + (size_t)k0 * NP, NP, Tinv + (size_t)kb * tb * tb + (size_t)(tjx * 32) * tb, tb, Wb + tiy * 32 + (size_t)(tjx * 32) * rb, rb, tjx * 32, w, 1.0, As, Bs);
 }
 
+// The LAST solve block has nothing below it: its forward step u = Tinv b, z = u / D and its backward step v = Tinv' z are two dependent launches on the same small block.
+// With Msym = Tinv' D^-1 Tinv (= the inverse of the block's Schur complement, symmetric, w x w) they are ONE mat-vec v = Msym b (k_block_sym): a solve is 2 nb - 1 launches.
+// Msym is formed once per factorisation, when the block's inverse is complete (C3: 512 x 512, 0.09 GF): tile (a0, b0) = sum_r T[r][a] T[r][b] / d[r] over r >= max(a0, b0)
+// (T is lower triangular; the rows scaled by the reciprocal pivots), both operands fetched with the lanes along r; 32 x 32 tiles, 256 threads, the chunk loop of merge32_tile.
+__global__ __launch_bounds__(256) void k_lastblock_sym(Batch bt, int tb, int kb, int w, const double* __restrict__ Tinv, const double* __restrict__ Dx, double* __restrict__ Msym) {
+    constexpr int KC = 128, ldk = KC + 2;       // (chunks of 128: a tile is a chain of load -> barrier -> 32 MFMAs per wavefront; the fewer links the better — 21 us with 64, K = 512)
+    __shared__ double As[32 * ldk];
+    __shared__ double Bs[32 * ldk];
+    inst_shift(bt, Tinv, Dx, Msym);
+    const int tr = w / 32, ta = blockIdx.x % tr, tbj = blockIdx.x / tr, k0 = kb * tb;
+    const double* TA = Tinv + (size_t)kb * tb * tb + (size_t)(ta * 32) * tb;
+    const double* TB = Tinv + (size_t)kb * tb * tb + (size_t)(tbj * 32) * tb;
+    const double* dd = Dx + k0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1, fr = lane & 15, fk = lane >> 4;
+    const int kbeg = 32 * (ta > tbj ? ta : tbj);
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = (v4d){0.0, 0.0, 0.0, 0.0};       // (two chains: one wavefront per SIMD, nothing else hides the latency of a dependent MFMA)
+    double av[16], bv[16], dv[2];
+    auto fetch = [&](int kc) {                                                             // (loads only: the reciprocal pivots are formed when the chunk is parked in LDS)
+        const int kn = w - kc < KC ? w - kc : KC;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kr = lane + 64 * h;                                                  // lanes along r (64 consecutive), 4 columns per pass, two halves of the chunk
+            dv[h] = kr < kn ? dd[kc + kr] : 1.0;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int cb = wave + 4 * it;
+                av[8 * h + it] = kr < kn ? TA[(kc + kr) + (size_t)cb * tb] : 0.0;
+                bv[8 * h + it] = kr < kn ? TB[(kc + kr) + (size_t)cb * tb] : 0.0;
+            }
+        }
+    };
+    fetch(kbeg);
+    for (int kc = kbeg; kc < w; kc += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double dk = 1.0 / dv[h];                                                 // (one division per row and chunk: the row's reciprocal pivot)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) { As[(wave + 4 * it) * ldk + lane + 64 * h] = av[8 * h + it] * dk; Bs[(wave + 4 * it) * ldk + lane + 64 * h] = bv[8 * h + it]; }
+        }
+        __syncthreads();
+        if (kc + KC < w) fetch(kc + KC);
+#pragma unroll
+        for (int kk = 0; kk < KC / 4; ++kk) {                                              // (rows beyond the block are zeros in LDS)
+            const double a = As[(wi * 16 + fr) * ldk + kk * 4 + fk];
+            const double b = Bs[(wj * 16 + fr) * ldk + kk * 4 + fk];
+            if (kk & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc1, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);           // transposed: row <-> column index b, col <-> row index a
+        }
+    }
+    acc += acc1;
+    double* Cc = Msym + ta * 32 + (size_t)(tbj * 32) * w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cc[(wi * 16 + fr) + (size_t)(wj * 16 + fk + 4 * r) * w] = acc[r];
+}
+
 __global__ void k_publish_inertia(const int* __restrict__ icount, int* __restrict__ hcount, unsigned long long* __restrict__ hseq, unsigned long long seq) {
     if (threadIdx.x < 6) hcount[threadIdx.x] = icount[threadIdx.x];
     __threadfence_system();
@@ -965,6 +1022,7 @@ static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f
 static void enqueue_wform(calipso_hip_solver* s, hipStream_t stream, int kb);
 static void enqueue_feed(calipso_hip_solver* s, hipStream_t stream, int i, bool beside);
 static int wform_rows(const calipso_hip_solver* s, int rb);
+static void enqueue_lastblock_sym(calipso_hip_solver* s, hipStream_t stream);
 static void ldl_plan_ranges(calipso_hip_solver* s);
 // Which finish work runs beside the chain: one instance alone, dense S, a solve block that is complete before the chain ends (otherwise nothing to overlap)
 static bool ldl_overlap(calipso_hip_solver* s) {
@@ -1060,6 +1118,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
                 (void)hipStreamWaitEvent(s->stream, s->ev_side[7], 0);
             }
             for (int f = s->ldl_forks; 3 * f < (int)s->ldl_feeds.size(); ++f) enqueue_feed(s, s->stream, f, false);
+            enqueue_lastblock_sym(s, s->stream);
             return;
         }
     }
@@ -1078,6 +1137,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
         }
     }
     if (wform_on(s)) for (int kb = 0; kb * tb < NP; ++kb) enqueue_wform(s, s->stream, kb);
+    enqueue_lastblock_sym(s, s->stream);
 }
 
 // The same finish for ONE solve block b (columns b tb .. b tb + w - 1) on `stream`: the factor columns of its panels, then the merges of its inverse blocks.
@@ -1282,7 +1342,7 @@ __global__ __launch_bounds__(256) void k_trsv_update_t(Batch bt, int NP, int k0,
 template <int ROWS, int PARTS, int CPT>
 __global__ __launch_bounds__(ROWS * PARTS) void k_trsv_fwd(Batch bt, int kb, int tb, int w, int rb, const double* __restrict__ Tinv, const double* __restrict__ Wb, double* __restrict__ b,
                                                             const double* __restrict__ Dx, double* __restrict__ u, double* __restrict__ z, const int* __restrict__ gate = nullptr,
-                                                            int gate_epoch = 0) {
+                                                            int gate_epoch = 0, int snap = 0) {
     if (gate && gate[0] == gate_epoch) return;        // a round queued ahead of a refinement that has converged meanwhile (internal.hpp: gate)
     constexpr int W = PARTS * CPT;
     __shared__ double bs[W];
@@ -1294,6 +1354,10 @@ __global__ __launch_bounds__(ROWS * PARTS) void k_trsv_fwd(Batch bt, int kb, int
     const bool below = (int)blockIdx.x >= nA;
     const int blk = below ? (int)blockIdx.x - nA : (int)blockIdx.x;
     const int row = blk * ROWS + r;
+    if (below && snap && blk * ROWS >= snap - 1) {        // (snap = 1 + the rows of W_kb that can be non-zero: a banded S — the rows beyond take no update, only the copy)
+        if (tid < ROWS) { const int gi = k0 + w + blk * ROWS + tid; u[gi] = b[gi]; }
+        return;
+    }
     const double* M = below ? Wb + row : Tinv + (size_t)kb * tb * tb + row;
     const size_t ld = below ? (size_t)rb : (size_t)tb;
     const int cend = below ? w : blk * ROWS + ROWS;     // lower triangular: columns beyond the workgroup's last row are zero
@@ -1315,8 +1379,11 @@ __global__ __launch_bounds__(ROWS * PARTS) void k_trsv_fwd(Batch bt, int kb, int
 #pragma unroll
         for (int q = 0; q < PARTS; ++q) s += part[q][tid];
         const int gi = k0 + (below ? w : 0) + blk * ROWS + tid;
-        if (below) b[gi] -= s;                    // (rows >= k0 + w: no workgroup of this launch reads them)
-        else { u[gi] = s; z[gi] = s / Dx[gi]; }
+        if (below) {                              // (rows >= k0 + w: no workgroup of this launch reads them)
+            const double nv = b[gi] - s;
+            b[gi] = nv;
+            if (snap) u[gi] = nv;                 // the block before the last one: a copy of the final right-hand side of the last block for k_block_sym (which writes b in place)
+        } else { u[gi] = s; z[gi] = s / Dx[gi]; }
     }
 }
 // backward, block kb: v_kb = [Tinv_kb; W_kb]' [z_kb; -v_below]: one wavefront per column, lanes stride down the stacked column (w rows of Tinv_kb from the diagonal
@@ -1360,9 +1427,56 @@ static void launch_trsv_bwd(hipStream_t st, unsigned nz, const Batch& bt, int kb
     hipLaunchKernelGGL(k_trsv_bwd<NCH>, dim3(w / 4, 1, nz), dim3(256), 0, st, bt, kb, tb, w, rb, rows, Tinv, Wb, z, x, gate, ge);
 }
 
+// v = Msym b for the last solve block (k_lastblock_sym): 16 rows per workgroup, the column parts of a row combined through LDS as in k_trsv_fwd
+template <int ROWS, int PARTS, int CPT>
+__global__ __launch_bounds__(ROWS * PARTS) void k_block_sym(Batch bt, int k0, int w, const double* __restrict__ Msym, const double* __restrict__ in, double* __restrict__ x,
+                                                             const int* __restrict__ gate = nullptr, int gate_epoch = 0) {
+    if (gate && gate[0] == gate_epoch) return;
+    constexpr int W = PARTS * CPT;
+    __shared__ double bs[W];
+    __shared__ double part[PARTS][ROWS];
+    inst_shift(bt, Msym, in, x);
+    const int tid = threadIdx.x, r = tid % ROWS, p = tid / ROWS;
+    const int row = blockIdx.x * ROWS + r;
+    const double* M = Msym + row;
+    double acc = 0.0;
+    for (int c0 = 0; c0 < w; c0 += W) {
+        double v[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) { const int c = c0 + p + PARTS * q; v[q] = (c < w) ? M[(size_t)c * w] : 0.0; }
+        if (c0) __syncthreads();
+        for (int i = tid; i < W; i += ROWS * PARTS) bs[i] = c0 + i < w ? in[k0 + c0 + i] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) acc += v[q] * bs[p + PARTS * q];
+    }
+    part[p][r] = acc;
+    __syncthreads();
+    if (tid < ROWS) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) s += part[q][tid];
+        x[k0 + blockIdx.x * ROWS + tid] = s;
+    }
+}
+
 bool wform_on(const calipso_hip_solver* s) {
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
     return s->solve_wform != 0 && !s->compact && !(s->stage_parallel && s->spS) && wform_layout_ok(NP, tb);
+}
+// the last solve block through its symmetric inverse (k_lastblock_sym / k_block_sym): with the W-form
+static const int LASTSYM = [] { const char* e = getenv("CALIPSO_HIP_LASTBLOCK_SYM"); return e ? atoi(e) : 1; }();
+bool lastblock_sym_on(const calipso_hip_solver* s) {
+    if (!LASTSYM || !wform_on(s)) return false;
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), nb = (NP + tb - 1) / tb;
+    return nb >= 2;
+}
+static void enqueue_lastblock_sym(calipso_hip_solver* s, hipStream_t stream) {
+    if (!lastblock_sym_on(s)) return;
+    const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), nb = (NP + tb - 1) / tb;
+    const int k0 = (nb - 1) * tb, w = NP - k0;
+    const Batch bt = batch_of(s).b;
+    hipLaunchKernelGGL(k_lastblock_sym, dim3((w / 32) * (w / 32), 1, bt.n), dim3(256), 0, stream, bt, tb, nb - 1, w, s->Tinv, s->Dx, s->Wfac + wform_offset(NP, tb, nb - 1));
 }
 // rows of W_kb that can be non-zero: all rb of them, or — banded S (structure.hip) — the rows the block's columns reach (the others are exact zeros: skipping
 // them changes no bit, which is what keeps the banded treatment bitwise the dense one)
@@ -1387,14 +1501,23 @@ static void enqueue_trsv_wform(calipso_hip_solver* s, double* x) {
     const unsigned nz = bt.n;
     const int* gate = s->gate_epoch ? s->gate : (const int*)nullptr;
     const int ge = s->gate_epoch;
-    for (int kb = 0; kb < nb; ++kb) {
+    const bool sym = lastblock_sym_on(s);            // the last block as ONE launch (k_block_sym)
+    for (int kb = 0; kb < nb - (sym ? 1 : 0); ++kb) {
         const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
         const double* Wb = s->Wfac + wform_offset(NP, tb, kb);
         const int rows = wform_rows(s, rb);
-        if (w > 512) hipLaunchKernelGGL((k_trsv_fwd<16, 32, 32>), dim3((w + rows) / 16, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z, gate, ge);
-        else hipLaunchKernelGGL((k_trsv_fwd<16, 16, 32>), dim3((w + rows) / 16, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z, gate, ge);
+        const int snap = (sym && kb == nb - 2) ? 1 + rows : 0;          // the block before the last one leaves a copy of the last block's final right-hand side in u
+        const int grows = snap ? rb : rows;
+        if (w > 512) hipLaunchKernelGGL((k_trsv_fwd<16, 32, 32>), dim3((w + grows) / 16, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z, gate, ge, snap);
+        else hipLaunchKernelGGL((k_trsv_fwd<16, 16, 32>), dim3((w + grows) / 16, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, rb, s->Tinv, Wb, x, s->Dx, u, z, gate, ge, snap);
     }
-    for (int kb = nb - 1; kb >= 0; --kb) {
+    if (sym) {
+        const int k0 = (nb - 1) * tb, w = NP - k0;
+        const double* Msym = s->Wfac + wform_offset(NP, tb, nb - 1);
+        if (w > 512) hipLaunchKernelGGL((k_block_sym<16, 32, 32>), dim3(w / 16, 1, nz), dim3(512), 0, s->stream, bt, k0, w, Msym, u, x, gate, ge);
+        else hipLaunchKernelGGL((k_block_sym<16, 16, 32>), dim3(w / 16, 1, nz), dim3(256), 0, s->stream, bt, k0, w, Msym, u, x, gate, ge);
+    }
+    for (int kb = nb - 1 - (sym ? 1 : 0); kb >= 0; --kb) {
         const int k0 = kb * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
         const double* Wb = s->Wfac + wform_offset(NP, tb, kb);
         const int rows = wform_rows(s, rb), nch = (w + rows + 63) / 64;

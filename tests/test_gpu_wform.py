@@ -102,3 +102,38 @@ def test_wform_group_members_get_the_bits_of_a_handle_stepped_alone():
     with pytest.raises(pkg.CalipsoHipError, match="agree on opt.solve_wform"):
         g.newton_step(advance=False)
     g.close()
+
+
+def test_last_block_through_its_symmetric_inverse_agrees_with_the_two_triangular_launches(tmp_path):
+    """the last solve block has nothing below it: by default its forward and backward steps are ONE mat-vec with Msym = Tinv' D^-1 Tinv (ldl.hip: k_lastblock_sym,
+    k_block_sym); CALIPSO_HIP_LASTBLOCK_SYM=0 (read once per process) keeps the two triangular launches.  Same Newton step to rounding, same refinement rounds."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    child = r'''
+import sys, os
+import numpy as np
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "tests")]
+from helpers import load_pkg
+from test_gpu_group import build
+pkg = load_pkg()
+out = []
+for shape, pid in (((1500, 300, 60, 30, 3), 41), ((2100, 200, 40, 20, 3), 42)):      # NP = 1536 (1024 + 512) and 2112 (1024 + 1024 + 64)
+    s = build(pkg, pid, shape)
+    info = s.newton_step(advance=False)
+    assert info["status"] == 0, info
+    out.append(np.array(s.data("step").all))
+    out.append(np.array([info["refinement_rounds"]], dtype=np.float64))
+np.save(sys.argv[1], np.concatenate(out))
+'''
+    res = {}
+    for v in ("1", "0"):
+        f = str(tmp_path / ("sym%s.npy" % v))
+        e = dict(os.environ, CALIPSO_HIP_LASTBLOCK_SYM=v)
+        r = subprocess.run([sys.executable, "-c", child % {"root": ROOT}, f], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[v] = np.load(f)
+    assert res["1"].shape == res["0"].shape
+    assert np.abs(res["1"] - res["0"]).max() <= 1e-9 * max(1.0, np.abs(res["0"]).max())
+    assert not np.array_equal(res["1"], res["0"])          # (identical bits would mean the switch did nothing)
