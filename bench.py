@@ -475,8 +475,11 @@ def main():
         infos = []
         barrier(wl)
         t0 = time.perf_counter()
-        for _ in range(K):
-            infos.append(wl.single.newton_step(advance=False))
+        if os.environ.get("CALIPSO_BENCH_STEP_CALLS", "0") == "1":      # one C call per step from this loop (what the bench did up to round 4: + the interpreter between the steps)
+            for _ in range(K):
+                infos.append(wl.single.newton_step(advance=False))
+        else:                                                          # the K steps in ONE call of the C ABI (calipso_hip_newton_steps): the loop a caller of the library runs natively
+            infos = wl.single.newton_steps(K, advance=False)
         barrier(wl)
         elapsed = max_over_ranks(time.perf_counter() - t0)
         assert all(i["status"] >= 0 for i in infos), "a Newton step of the timed region failed"

@@ -398,6 +398,15 @@ class Solver:
         return dict(status=rc, step_size=info[0], step_size_cone_slack_dual=info[1], refinement_rounds=int(info[2]),
                     factorizations=int(info[3]), merit_candidate=info[4], violation_candidate=info[5])
 
+    def newton_steps(self, count, advance=False):
+        """`count` Newton steps in one call (calipso_hip_newton_steps): the list of the per-step dicts newton_step returns"""
+        info = np.zeros(6 * max(int(count), 1))
+        status = np.zeros(max(int(count), 1), dtype=np.int32)
+        self._check(self._L.calipso_hip_newton_steps(self._h, int(count), int(advance), _pd(info), status.ctypes.data_as(C.POINTER(C.c_int32))), "newton_steps")
+        I = info.reshape(-1, 6)
+        return [dict(status=int(status[k]), step_size=I[k, 0], step_size_cone_slack_dual=I[k, 1], refinement_rounds=int(I[k, 2]), factorizations=int(I[k, 3]),
+                     merit_candidate=I[k, 4], violation_candidate=I[k, 5]) for k in range(int(count))]
+
     def phase_times(self):
         out = np.zeros(9)
         self._L.calipso_hip_phase_times(self._h, _pd(out))

@@ -61,6 +61,7 @@ SYMBOLS = {
     "calipso_hip_qp_attach": (_i32, [_vp, _pd, _pd, _pd, _pd, _pd, _pd, _dbl]),
     "calipso_hip_qp_evaluate": (_i32, [_vp, _i32, _u32]),
     "calipso_hip_newton_step": (_i32, [_vp, _i32, _pd]),
+    "calipso_hip_newton_steps": (_i32, [_vp, _i32, _i32, _pd, _pi32]),
     "calipso_hip_phase_times": (_i32, [_vp, _pd]),
     "calipso_hip_kernel_times": (_i32, [_vp, _pd]),
     "calipso_hip_structure_work": (_i32, [_vp, _pd]),

@@ -1159,7 +1159,20 @@ int32_t calipso_hip_qp_evaluate(H* s, int32_t which, uint32_t flags) {
     return CALIPSO_OK;
 }
 
-int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) {
+static int32_t newton_step_impl(H* s, int32_t advance, double info_out[6], bool last);
+int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) { return newton_step_impl(s, advance, info_out, true); }
+// `count` steps in ONE call: what a host loop of calipso_hip_newton_step calls does, without returning to the host language between the steps (no stream
+// synchronisation and no event queries between them either: the steps wait for what they need through the published words, as a step does internally)
+int32_t calipso_hip_newton_steps(H* s, int32_t count, int32_t advance, double* info_out, int32_t* status_out) {
+    if (!s || count < 0 || (count > 0 && !status_out)) return CALIPSO_ERR_ARGUMENT;
+    for (int32_t k = 0; k < count; ++k) {
+        const int32_t rc = newton_step_impl(s, advance, info_out ? info_out + 6 * (size_t)k : nullptr, k + 1 == count);
+        status_out[k] = rc;
+        if (rc < 0) { CK(hipStreamSynchronize(s->stream)); return rc; }
+    }
+    return CALIPSO_OK;
+}
+static int32_t newton_step_impl(H* s, int32_t advance, double info_out[6], bool last) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
     if (!s->qp.attached && !s->dev_eval) { s->err = "calipso_hip_newton_step needs a device evaluator (calipso_hip_qp_attach or calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
     const Dims& d = s->d;
@@ -1192,11 +1205,12 @@ int32_t calipso_hip_newton_step(H* s, int32_t advance, double info_out[6]) {
         const double keep_ep = s->sc.ep, keep_ed = s->sc.ed;
         s->sc = saved_sc; s->sc.ep = keep_ep; s->sc.ed = keep_ed;   // eps_last restored: every benchmark step repeats IC-1
     }
-    SYNC();
     if (info_out) {
         info_out[0] = info.step_size; info_out[1] = info.step_size_t; info_out[2] = info.rounds; info_out[3] = (double)info.nfact;
         info_out[4] = info.Mh; info_out[5] = info.thetah;
     }
+    if (!last) return rc;             // (calipso_hip_newton_steps: the next step follows in stream order)
+    SYNC();
     float ms = 0.f;
     if (info.exit_kind == 0) {
         (void)hipEventElapsedTime(&ms, s->ev[0], s->ev[1]); s->phase_ms[0] = ms;

@@ -268,6 +268,10 @@ int32_t calipso_hip_qp_evaluate(calipso_hip_solver*, int32_t which, uint32_t fla
  * attached; if `advance` is 0 the iterate is restored afterwards (benchmark mode: every step does identical work).
  * info[0]=step_size info[1]=step_size_t info[2]=refinement rounds info[3]=factorizations info[4]=M_candidate info[5]=theta_candidate */
 int32_t calipso_hip_newton_step(calipso_hip_solver*, int32_t advance, double info[6]);
+/* `count` such steps in one call — the loop a caller would write around calipso_hip_newton_step (solve.jl:107-377 runs its iterations without leaving the
+ * solver either): info = count x 6 doubles (may be NULL), status = count return codes; stops at the first failing step (its code is returned).  The stream is
+ * synchronised and the phase timers are read after the LAST step only. */
+int32_t calipso_hip_newton_steps(calipso_hip_solver*, int32_t count, int32_t advance, double* info, int32_t* status);
 /* ---- groups: several handles of one shape stepped in lockstep through the same kernel launches ------------------------------
  * The reference has no batching: distinct `Solver`s are simply independent; BASELINE config C4 runs many of them
  * per GPU.  A group covers up to 128 handles created with identical dimensions and cone layout on one device; every launch of a

@@ -307,3 +307,17 @@ def test_solve_block_option_keeps_group_and_single_bitwise_and_agrees_across_set
     with pytest.raises(pkg.CalipsoHipError, match="agree on opt.solve_block"):
         g.newton_step(advance=False)
     g.close()
+
+
+def test_newton_steps_in_one_call_are_the_steps_called_one_by_one():
+    """calipso_hip_newton_steps: K steps without returning to the host language in between — same infos, same iterates, bit for bit"""
+    pkg = load_pkg()
+    a, b = build(pkg, 9), build(pkg, 9)
+    one = [a.newton_step(advance=True) for _ in range(3)]
+    many = b.newton_steps(3, advance=True)
+    assert one == many
+    assert same(a.solution.all, b.solution.all) and same(a.data("step").all, b.data("step").all)
+    assert b.newton_steps(0) == []
+    again = b.newton_steps(2, advance=False)                       # benchmark mode: the iterate is restored after every step
+    assert again[0] == again[1]
+    assert same(a.solution.all, b.solution.all)
