@@ -161,8 +161,9 @@ int32_t calipso_hip_device_count(void);
  *   a group (one merge level less; its solves are bandwidth-bound); 2048 is there for larger systems (at nx = 2432 its extra merge level costs 0.15 ms
  *   and saves 0.07).  Set it on every member of a group (the first member's value governs the group's launches).  And "opt.solve_wform" (0 or 1,
  *   default 1): the solves (linear_solve!, linear_solver.jl:52-60) multiply with the stacked blocks [Tinv_b; W_b], W_b = L[below, b] Tinv_b formed once per
- *   factorisation, so that a solve is two dependent launches per solve block instead of four; same factor, different summation order.  One system wants it; a
- *   group (bandwidth-bound solves) does not need the extra products.  The members of a group must agree on it. */
+ *   factorisation, so that a solve is two dependent launches per solve block instead of four — and ONE for the last block, which has nothing below it and goes
+ *   through the symmetric inverse Tinv' D^-1 Tinv of its Schur complement; same factor, different summation order.  One system wants it; a group
+ *   (bandwidth-bound solves) does not need the extra products.  The members of a group must agree on it. */
 int32_t calipso_hip_set_field(calipso_hip_solver*, const char* name, const double* data, int64_t len);
 int32_t calipso_hip_get_field(calipso_hip_solver*, const char* name, double* data, int64_t len);
 /* The scatter of evaluate! on the device (evaluate.jl:37-121): register `methods.<field>_sparsity` once — `count` (row, col)
