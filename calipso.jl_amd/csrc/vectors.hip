@@ -1069,7 +1069,11 @@ __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc b
     if (rowrange) inst_shift_i(bt.b, rowrange);
     const Scalars sc = bt.scal(blockIdx.z);
     const int tid = threadIdx.x, r = tid % ROWS, p = tid / ROWS;
-    const int g = blockIdx.x;
+    // workgroup b runs on XCD b % 8 (dispatch order; used for speed only): every XCD takes a CONTIGUOUS eighth of the row groups — the 128-byte runs of 16 rows down a
+    // column are not aligned to the cache lines (the leading dimension m is not a multiple of 16), so neighbouring row groups share the lines at their common edge, and
+    // share them through an L2 only when they run on the same XCD
+    const int per = (ngrp + 7) / 8, g = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (g >= ngrp) return;
     const int r0 = grp[g], nrows = grp[g + 1] - r0;
     // ---- t2 rows r0 .. r0 + nrows - 1 ------------------------------------------------------------------------------
     const bool live = r < nrows;
@@ -1152,7 +1156,7 @@ bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool w
         std::call_once(big, [] { (void)hipFuncSetAttribute((const void*)k_solve_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
         if (lds > 96 * 1024) return false;
     }
-    hipLaunchKernelGGL(k_solve_tail, dim3(s->n_zgrp, 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), lds, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
+    hipLaunchKernelGGL(k_solve_tail, dim3((s->n_zgrp + 7) / 8 * 8, 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), lds, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
                        s->residual, s->wz, s->Wsoc, s->residual_symmetric, s->step_symmetric, st, accumulate ? s->step : (double*)nullptr, s->zsx, s->residual_error, s->t1, s->refpart,
                        which == 0 ? 1 : 2, with_refine ? 1 : 0, s->gate_epoch ? s->gate : (const int*)nullptr, s->gate_epoch);
     s->refine_local_done = with_refine;
