@@ -1216,6 +1216,9 @@ __global__ __launch_bounds__(256) void k_refine_x_fused(BatchSc bt, Dims d, int 
     const int r = threadIdx.x & 63, p = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + r;
     double acc = 0.0;
+    // the row's own operands travel with the partial sums (fetched behind the barrier they were one more memory round trip at the end of a 7 us kernel)
+    double w1i = 0.0, w2i = 0.0, vi0 = 0.0, resi = 0.0;
+    if (p == 0 && i < d.nx) { w1i = have_m ? w1[i] : 0.0; w2i = have_m ? w2[i] : 0.0; vi0 = v[i]; resi = res[i]; }
     if (i < d.nx) {
         for (int c0 = p; c0 < nchunk; c0 += 64) {
             double pv[16];
@@ -1231,11 +1234,11 @@ __global__ __launch_bounds__(256) void k_refine_x_fused(BatchSc bt, Dims d, int 
     if (p == 0) {
         if (i < d.nx) {
             const double lv = (ps[0][r] + ps[1][r]) + (ps[2][r] + ps[3][r]);
-            const double hv = (lv + (have_m ? w1[i] : 0.0)) + sc.ep * v[i];
-            const double rr = res[i] - hv;
+            const double hv = (lv + w1i) + sc.ep * vi0;
+            const double rr = resi - hv;
             e[i] = rr;
             rsym[i] = rr;
-            xbuf[i] = have_m ? rr + w2[i] : rr;
+            xbuf[i] = have_m ? rr + w2i : rr;
             m = fabs(rr);
         } else if (i < d.NP) xbuf[i] = 0.0;
     }
