@@ -1361,6 +1361,10 @@ __global__ __launch_bounds__(ROWS * PARTS) void k_trsv_fwd(Batch bt, int kb, int
     const double* M = below ? Wb + row : Tinv + (size_t)kb * tb * tb + row;
     const size_t ld = below ? (size_t)rb : (size_t)tb;
     const int cend = below ? w : blk * ROWS + ROWS;     // lower triangular: columns beyond the workgroup's last row are zero
+    // what the row's result is combined with (its right-hand side entry below the block, its pivot inside it) travels with the matrix loads: fetched where it is used,
+    // behind the last barrier, it was one more memory round trip at the end of a 6 us kernel
+    double tail_operand = 0.0;
+    if (tid < ROWS) { const int gi0 = k0 + (below ? w : 0) + blk * ROWS + tid; tail_operand = below ? b[gi0] : Dx[gi0]; }
     double acc = 0.0;
     for (int c0 = 0; c0 < cend; c0 += W) {
         double v[CPT];
@@ -1380,10 +1384,10 @@ __global__ __launch_bounds__(ROWS * PARTS) void k_trsv_fwd(Batch bt, int kb, int
         for (int q = 0; q < PARTS; ++q) s += part[q][tid];
         const int gi = k0 + (below ? w : 0) + blk * ROWS + tid;
         if (below) {                              // (rows >= k0 + w: no workgroup of this launch reads them)
-            const double nv = b[gi] - s;
+            const double nv = tail_operand - s;
             b[gi] = nv;
             if (snap) u[gi] = nv;                 // the block before the last one: a copy of the final right-hand side of the last block for k_block_sym (which writes b in place)
-        } else { u[gi] = s; z[gi] = s / Dx[gi]; }
+        } else { u[gi] = s; z[gi] = s / tail_operand; }
     }
 }
 // backward, block kb: v_kb = [Tinv_kb; W_kb]' [z_kb; -v_below]: one wavefront per column, lanes stride down the stacked column (w rows of Tinv_kb from the diagonal
