@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256) void k_gemv_t(Batch bt, Sparsity sp, int rows,
                                                  double* __restrict__ y, double alpha, double beta) {
     inst_shift(bt, A, x, y);
     if (sp.kr) inst_shift_i(bt, sp.kr);
+    // (x from global memory: one vector of nx or m doubles stays in the L1 of the compute unit — staged in LDS as k_gemv_t2 stages its TWO vectors, which together do not,
+    // this kernel was 13 % slower: 12.1 against 10.7 us at C3)
     const int lane = threadIdx.x & 63;
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= cols) return;
@@ -123,8 +125,43 @@ __device__ __forceinline__ void gemv_t2_body(Batch bt, Sparsity sp, int bx, int 
     const double r1 = wave_sum(p0 + p1), r2 = wave_sum(q0 + q1);
     if (lane == 0) { y1[col] = r1; y2[col] = r2; }
 }
+// The same product of a DENSE block with the two vectors in LDS: every wavefront of a launch reads all of both, and together (40 KB at C3) they do not stay in the 32 KB L1
+// of a compute unit beside the matrix stream — from global memory each wavefront issued twice as many loads for them as for its column (k_gemv_t2_and_n: 22.9 -> 21 us).
+// The first batch of the column's loads goes out BEFORE the workgroup stages the vectors: they travel under the staging.  Same terms in the same order: same bits.
+__device__ __forceinline__ void gemv_t2_dense_lds(Batch bt, int bx, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x1,
+                                                  const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2, double* __restrict__ xs) {
+    inst_shift(bt, A, x1, x2, y1, y2);
+    const int lane = threadIdx.x & 63;
+    const int col = bx * 4 + (threadIdx.x >> 6);
+    const bool valid = col < cols;
+    const double* a = A + (size_t)(valid ? col : 0) * ld;
+    double v[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) { const int i = lane + 64 * q; v[q] = (valid && i < rows) ? a[i] : 0.0; }
+    for (int i = threadIdx.x; i < rows; i += 256) { xs[i] = x1[i]; xs[rows + i] = x2[i]; }
+    __syncthreads();
+    if (!valid) return;
+    double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
+    for (int base = 0; base < rows; base += 64 * 24) {
+        if (base) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) { const int i = base + lane + 64 * q; v[q] = i < rows ? a[i] : 0.0; }
+        }
+#pragma unroll
+        for (int q = 0; q < 24; q += 2) {
+            const int i = base + lane + 64 * q;
+            const bool in0 = i < rows, in1 = i + 64 < rows;
+            p0 = fma(v[q], in0 ? xs[i] : 0.0, p0); p1 = fma(v[q + 1], in1 ? xs[i + 64] : 0.0, p1);
+            q0 = fma(v[q], in0 ? xs[rows + i] : 0.0, q0); q1 = fma(v[q + 1], in1 ? xs[rows + i + 64] : 0.0, q1);
+        }
+    }
+    const double r1 = wave_sum(p0 + p1), r2 = wave_sum(q0 + q1);
+    if (lane == 0) { y1[col] = r1; y2[col] = r2; }
+}
 __global__ __launch_bounds__(256) void k_gemv_t2(Batch bt, Sparsity sp, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x1,
-                                                  const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2) {
+                                                  const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2, int lds_x = 0) {
+    extern __shared__ __attribute__((aligned(16))) double t2s_lds[];
+    if (lds_x && sp.kind == SP_DENSE) { gemv_t2_dense_lds(bt, blockIdx.x, rows, cols, A, ld, x1, x2, y1, y2, t2s_lds); return; }
     gemv_t2_body(bt, sp, blockIdx.x, rows, cols, A, ld, x1, x2, y1, y2);
 }
 
@@ -136,6 +173,11 @@ static Sparsity sparsity_of(const calipso_hip_solver* s, int kind) {
     return sp;
 }
 
+// the vector(s) of a transposed product staged in LDS by every workgroup (dense blocks; what fits the 48 KB a kernel gets without asking)
+static int gemv_lds_x(size_t bytes) {
+    static const int env = [] { const char* e = getenv("CALIPSO_HIP_GEMV_LDS_X"); return e ? atoi(e) : 1; }();
+    return env && bytes <= 48 * 1024 ? 1 : 0;
+}
 void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind) {
     if (cols == 0) return;
     if (blocks_gemv_t(s, kind, x, nullptr, y, nullptr, alpha, beta)) return;       // stage blocks (blocks.hip)
@@ -149,7 +191,8 @@ void gemv_t2(calipso_hip_solver* s, int rows, int cols, const double* A, int ld,
     if (blocks_gemv_t(s, kind, x1, x2, y1, y2, 1.0, 0.0)) return;
     if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; s->ldl_failed = true; return; }   // (sticky: the driver reports CALIPSO_ERR_HIP)
     const BatchSc B = batch_of(s);
-    hipLaunchKernelGGL(k_gemv_t2, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, A, ld, x1, x2, y1, y2);
+    const int lds_x = gemv_lds_x(2 * sizeof(double) * (size_t)rows);
+    hipLaunchKernelGGL(k_gemv_t2, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), lds_x ? 2 * sizeof(double) * (size_t)rows : 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, A, ld, x1, x2, y1, y2, lds_x);
 }
 
 constexpr int GN_ROWS = 256;    // rows per workgroup
@@ -193,10 +236,15 @@ __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, Sparsity s
 __global__ __launch_bounds__(256) void k_gemv_t2_and_n(Batch bt, Sparsity spz, int rowsz, int colsz, const double* __restrict__ Z, int ldz, const double* __restrict__ x1,
                                                         const double* __restrict__ x2, double* __restrict__ y1, double* __restrict__ y2, int nt2, Sparsity spl, int rb,
                                                         int rowsl, int colsl, int chunk, const double* __restrict__ L, int ldl, const double* __restrict__ xl,
-                                                        double* __restrict__ partial, const int* __restrict__ gate = nullptr, int gate_epoch = 0) {
+                                                        double* __restrict__ partial, const int* __restrict__ gate = nullptr, int gate_epoch = 0, int lds_x = 0) {
     static_assert(GN_ROWS == 256, "one block size for both bodies");
     if (gate && gate[0] == gate_epoch) return;        // (internal.hpp: gate)
+    extern __shared__ __attribute__((aligned(16))) double t2_lds[];
     const int b = blockIdx.x;
+    if (b < nt2 && lds_x && spz.kind == SP_DENSE) {
+        gemv_t2_dense_lds(bt, b, rowsz, colsz, Z, ldz, x1, x2, y1, y2, t2_lds);
+        return;
+    }
     if (b < nt2) gemv_t2_body(bt, spz, b, rowsz, colsz, Z, ldz, x1, x2, y1, y2);
     else gemv_n_partial_body(bt, spl, (b - nt2) % rb, (b - nt2) / rb, 0, rowsl, colsl, chunk, L, ldl, xl, partial);
 }
@@ -312,8 +360,10 @@ int gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2, 
     const BatchSc B = batch_of(s);
     const bool timed = s->time_matvec && !s->cur;
     if (timed) (void)hipEventRecord(s->ev[5], s->stream);
-    hipLaunchKernelGGL(k_gemv_t2_and_n, dim3(nt2 + rb * nchunk, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, SP_Z), d.m, d.nx, s->Z, d.m, x1, x2, y1, y2, nt2,
-                       sparsity_of(s, SP_LXX), rb, d.nx, d.nx, chunk, s->Lxx, d.nx, xl, s->gemv_partial, s->gate_epoch ? s->gate : (const int*)nullptr, s->gate_epoch);
+    const size_t xbytes = 2 * sizeof(double) * (size_t)d.m;
+    const int lds_x = gemv_lds_x(xbytes);
+    hipLaunchKernelGGL(k_gemv_t2_and_n, dim3(nt2 + rb * nchunk, 1, B.b.n), dim3(256), lds_x ? xbytes : 0, s->stream, B.b, sparsity_of(s, SP_Z), d.m, d.nx, s->Z, d.m, x1, x2, y1, y2, nt2,
+                       sparsity_of(s, SP_LXX), rb, d.nx, d.nx, chunk, s->Lxx, d.nx, xl, s->gemv_partial, s->gate_epoch ? s->gate : (const int*)nullptr, s->gate_epoch, lds_x);
     if (timed) { (void)hipEventRecord(s->ev[6], s->stream); s->time_matvec = false; s->matvec_timed = true; }
     if (defer_reduce) return nchunk;
     hipLaunchKernelGGL(k_gemv_n_reduce, dim3((d.nx + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, d.nx, nchunk, s->gemv_partial, yl, 1.0, 0.0);
