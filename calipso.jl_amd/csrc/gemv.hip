@@ -205,6 +205,12 @@ __device__ __forceinline__ void gemv_n_partial_body(Batch bt, Sparsity sp, int b
     const int i = bx * GN_ROWS + threadIdx.x;
     const int c0 = by * chunk;
     const int c1 = min(cols, c0 + chunk);
+    // the chunk's entries of x: every lane needs all of them, at the same time.  As loads they were as many vector-memory instructions as the matrix itself (the
+    // compiler does not turn them into scalar loads); a chunk of at most 64 columns is fetched ONCE — lane l holds x[c0 + l], loaded while every lane is still
+    // active (v_readlane reads a lane's register whether or not the lane is) — and handed out by v_readlane
+    const bool xb = c1 - c0 <= 64;
+    const int ln = threadIdx.x & 63;
+    const double xr = (xb && c0 + ln < c1) ? x[c0 + ln] : 0.0;
     if (i >= rows) return;
     // columns of row i that can be non-zero (loads outside are predicated off; the summation order is that of the dense kernel)
     int jlo = 0, jhi = cols;
@@ -212,6 +218,11 @@ __device__ __forceinline__ void gemv_n_partial_body(Batch bt, Sparsity sp, int b
     else if (sp.kind != SP_DENSE) { jlo = sp.rowrange[2 * (row_off + i)]; jhi = sp.rowrange[2 * (row_off + i) + 1]; }
     double acc0 = 0.0, acc1 = 0.0;
     if (sp.kind != SP_DENSE && (c1 <= jlo || c0 >= jhi)) { partial[(size_t)by * rows + i] = 0.0; return; }   // nothing of this chunk is inside the row's range
+    auto xat = [&](int j) -> double {          // j is wave-uniform
+        if (!xb) return x[j];
+        const int l = j - c0;
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xr), l), __builtin_amdgcn_readlane(__double2loint(xr), l));
+    };
     // batches of 24 loads per lane, all issued before the first use
     for (int j0 = c0; j0 < c1; j0 += 24) {
         if (sp.kind != SP_DENSE && (j0 + 24 <= jlo || j0 >= jhi)) continue;                                             // (a batch of exact zeros)
@@ -220,8 +231,8 @@ __device__ __forceinline__ void gemv_n_partial_body(Batch bt, Sparsity sp, int b
         for (int q = 0; q < 24; ++q) { const int j = j0 + q; v[q] = (j < c1 && j >= jlo && j < jhi) ? A[i + (size_t)j * ld] : 0.0; }
 #pragma unroll
         for (int q = 0; q < 24; q += 2) {
-            acc0 += v[q] * (j0 + q < c1 ? x[j0 + q] : 0.0);
-            acc1 += v[q + 1] * (j0 + q + 1 < c1 ? x[j0 + q + 1] : 0.0);
+            acc0 += v[q] * (j0 + q < c1 ? xat(j0 + q) : 0.0);
+            acc1 += v[q + 1] * (j0 + q + 1 < c1 ? xat(j0 + q + 1) : 0.0);
         }
     }
     partial[(size_t)by * rows + i] = acc0 + acc1;
