@@ -56,8 +56,9 @@ __device__ __forceinline__ void structured_column(const BlockRanges& br, int row
 }
 
 __global__ __launch_bounds__(256) void k_gemv_t(Batch bt, Sparsity sp, int rows, int cols, const double* __restrict__ A, int ld, const double* __restrict__ x,
-                                                 double* __restrict__ y, double alpha, double beta) {
+                                                 double* __restrict__ y, double alpha, double beta, const double* __restrict__ add = nullptr) {
     inst_shift(bt, A, x, y);
+    if (add) inst_shift(bt, add);
     if (sp.kr) inst_shift_i(bt, sp.kr);
     // (x from global memory: one vector of nx or m doubles stays in the L1 of the compute unit — staged in LDS as k_gemv_t2 stages its TWO vectors, which together do not,
     // this kernel was 13 % slower: 12.1 against 10.7 us at C3)
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void k_gemv_t(Batch bt, Sparsity sp, int rows,
         }
     }
     const double r = wave_sum(acc0 + acc1);
-    if (lane == 0) y[col] = (beta == 0.0) ? alpha * r : alpha * r + beta * y[col];
+    if (lane == 0) y[col] = add ? alpha * r + add[col] : ((beta == 0.0) ? alpha * r : alpha * r + beta * y[col]);
 }
 
 // y1 = A'x1 and y2 = A'x2 with ONE pass over A: the refinement residual needs [gx; hx]'(step_y; step_z) and the condensed solve that follows
@@ -178,12 +179,12 @@ static int gemv_lds_x(size_t bytes) {
     static const int env = [] { const char* e = getenv("CALIPSO_HIP_GEMV_LDS_X"); return e ? atoi(e) : 1; }();
     return env && bytes <= 48 * 1024 ? 1 : 0;
 }
-void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind) {
+void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind, const double* add) {
     if (cols == 0) return;
-    if (blocks_gemv_t(s, kind, x, nullptr, y, nullptr, alpha, beta)) return;       // stage blocks (blocks.hip)
+    if (blocks_gemv_t(s, kind, x, nullptr, y, nullptr, alpha, beta)) { if (add) launch_add(s, y, add, cols); return; }       // stage blocks (blocks.hip)
     if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; s->ldl_failed = true; return; }   // (sticky: the driver reports CALIPSO_ERR_HIP)
     const BatchSc B = batch_of(s);
-    hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, A, ld, x, y, alpha, beta);
+    hipLaunchKernelGGL(k_gemv_t, dim3((cols + 3) / 4, 1, B.b.n), dim3(256), 0, s->stream, B.b, sparsity_of(s, kind), rows, cols, A, ld, x, y, alpha, beta, add);
 }
 
 void gemv_t2(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x1, const double* x2, double* y1, double* y2, int kind) {
@@ -261,9 +262,11 @@ __global__ __launch_bounds__(256) void k_gemv_t2_and_n(Batch bt, Sparsity spz, i
 }
 
 // y = alpha * sum_chunks partial + beta*y: 64 rows per workgroup, 4 lanes per row each summing every 4th chunk in a fixed order
-__global__ __launch_bounds__(256) void k_gemv_n_reduce(Batch bt, int rows, int nchunk, const double* __restrict__ partial, double* __restrict__ y, double alpha, double beta) {
+__global__ __launch_bounds__(256) void k_gemv_n_reduce(Batch bt, int rows, int nchunk, const double* __restrict__ partial, double* __restrict__ y, double alpha, double beta,
+                                                       const double* __restrict__ add = nullptr) {
     __shared__ double part[4][64];
     inst_shift(bt, partial, y);
+    if (add) inst_shift(bt, add);
     const int r = threadIdx.x & 63, p = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + r;
     double acc = 0.0;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void k_gemv_n_reduce(Batch bt, int rows, int n
     __syncthreads();
     if (threadIdx.x < 64 && i < rows) {
         const double v = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
-        y[i] = (beta == 0.0) ? alpha * v : alpha * v + beta * y[i];
+        y[i] = add ? alpha * v + add[i] : ((beta == 0.0) ? alpha * v : alpha * v + beta * y[i]);
     }
 }
 
@@ -381,9 +384,9 @@ int gemv_refine_pair(calipso_hip_solver* s, const double* x1, const double* x2, 
     return 0;
 }
 
-void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind) {
+void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind, const double* add) {
     if (rows == 0) return;
-    if (blocks_gemv_n(s, kind, x, y, alpha, beta)) return;
+    if (blocks_gemv_n(s, kind, x, y, alpha, beta)) { if (add) launch_add(s, y, add, rows); return; }
     if (s->compact) { s->err = "internal: a dense mat-vec was requested on a structured handle"; s->ldl_failed = true; return; }   // (sticky: the driver reports CALIPSO_ERR_HIP)
     int rb, nchunk, chunk;
     gemv_n_chunks(rows, cols, rb, nchunk, chunk);
@@ -391,7 +394,7 @@ void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, 
     if (nchunk > 0)
         hipLaunchKernelGGL(k_gemv_n_partial, dim3(rb, nchunk, B.b.n), dim3(GN_ROWS), 0, s->stream, B.b, sparsity_of(s, kind), kind == SP_HX ? s->d.ne : 0, rows, cols, chunk, A, ld,
                            x, s->gemv_partial);
-    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, rows, nchunk, s->gemv_partial, y, alpha, beta);
+    hipLaunchKernelGGL(k_gemv_n_reduce, dim3((rows + 63) / 64, 1, B.b.n), dim3(256), 0, s->stream, B.b, rows, nchunk, s->gemv_partial, y, alpha, beta, add);
 }
 
 }  // namespace calipso

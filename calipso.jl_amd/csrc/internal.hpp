@@ -338,8 +338,10 @@ void launch_residual_error(calipso_hip_solver* s, const double* step);   // resi
 void launch_add(calipso_hip_solver* s, double* y, const double* x, int len);    // y += x
 void launch_assemble_K(calipso_hip_solver* s);
 // gemv.hip
-void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
-void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE);
+void gemv_n(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE,
+            const double* add = nullptr);      // add: y = alpha A x + add (beta must be 0): the vector a caller would add in a launch of its own
+void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind = SP_DENSE,
+            const double* add = nullptr);      // (as for gemv_n)
 void gemv_t2(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x1, const double* x2, double* y1, double* y2, int kind = SP_DENSE);   // y1 = A'x1, y2 = A'x2, one pass
 // gemv_t2 on [gx; hx] and gemv_n on Lxx in one launch.  defer_reduce: the column-chunk partial sums of Lxx xl stay in gemv_partial and their number is returned (> 0) for
 // launch_refine_x_fused to combine; 0: yl holds the product

@@ -39,22 +39,22 @@ void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t fla
     const Batch bt = batch_of(s).b;
     const unsigned nz = bt.n;
     if (flags & (CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_OBJECTIVE_GRADIENT)) {
-        gemv_t(s, d.nx, d.nx, s->Lxx, d.nx, x, Lx, 1.0, 0.0, SP_LXX);   // Lxx is symmetric for the QP
-        if (flags & CALIPSO_EVAL_OBJECTIVE)
+        // (the vector a product is shifted by rides in the product's own epilogue — a + 1.0 * b either way: the same bits as the separate k_vec_add launches)
+        if (!(flags & CALIPSO_EVAL_OBJECTIVE)) gemv_t(s, d.nx, d.nx, s->Lxx, d.nx, x, s->fx, 1.0, 0.0, SP_LXX, s->qp.q);   // gradient only: fx = Lxx x + q; Lxx is symmetric for the QP
+        else {
+            gemv_t(s, d.nx, d.nx, s->Lxx, d.nx, x, Lx, 1.0, 0.0, SP_LXX);
             hipLaunchKernelGGL(k_qp_objective, dim3(1, 1, nz), dim3(1024), 0, s->stream, bt, d.nx, x, Lx, s->qp.q, s->dscal);
-        if (flags & CALIPSO_EVAL_OBJECTIVE_GRADIENT)
-            hipLaunchKernelGGL(k_vec_add, dim3((d.nx + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.nx, Lx, s->qp.q, 1.0, s->fx);
+            if (flags & CALIPSO_EVAL_OBJECTIVE_GRADIENT)
+                hipLaunchKernelGGL(k_vec_add, dim3((d.nx + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.nx, Lx, s->qp.q, 1.0, s->fx);
+        }
     }
     const bool want_g = (flags & CALIPSO_EVAL_EQUALITY) && d.ne, want_h = (flags & CALIPSO_EVAL_CONE) && d.nc;
     if (want_g && want_h) {            // [g; h] = [gx; hx] x + [-b; hvec]  — one pass over the stacked Jacobian
-        gemv_n(s, d.m, d.nx, s->Z, d.m, x, s->gh, 1.0, 0.0, SP_Z);
-        hipLaunchKernelGGL(k_vec_add, dim3((d.m + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.m, s->gh, s->qp.bh, 1.0, s->gh);
+        gemv_n(s, d.m, d.nx, s->Z, d.m, x, s->gh, 1.0, 0.0, SP_Z, s->qp.bh);
     } else if (want_g) {
-        gemv_n(s, d.ne, d.nx, s->gx, d.m, x, s->g, 1.0, 0.0, SP_GX);
-        hipLaunchKernelGGL(k_vec_add, dim3((d.ne + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.ne, s->g, s->qp.bh, 1.0, s->g);
+        gemv_n(s, d.ne, d.nx, s->gx, d.m, x, s->g, 1.0, 0.0, SP_GX, s->qp.bh);
     } else if (want_h) {
-        gemv_n(s, d.nc, d.nx, s->hx, d.m, x, s->hc, 1.0, 0.0, SP_HX);
-        hipLaunchKernelGGL(k_vec_add, dim3((d.nc + 255) / 256, 1, nz), dim3(256), 0, s->stream, bt, d.nc, s->hc, s->qp.bh + d.ne, 1.0, s->hc);
+        gemv_n(s, d.nc, d.nx, s->hx, d.m, x, s->hc, 1.0, 0.0, SP_HX, s->qp.bh + d.ne);
     }
     if (flags & CALIPSO_EVAL_EQUALITY_DUAL_GRADIENT) {
         if (d.ne) gemv_t(s, d.ne, d.nx, s->gx, d.m, y, s->gyx, 1.0, 0.0, SP_GX);
