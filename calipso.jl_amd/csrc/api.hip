@@ -783,8 +783,7 @@ static int candidate_merit(H* s, calipso_eval_fn eval, void* user, double* Mh, d
     int rc = evaluate(s, eval, user, 1, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);   // solve.jl:231-235
     if (rc < 0) return rc;
     launch_cone(s, s->candidate, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);                         // :237-240
-    launch_merit(s, s->candidate);
-    launch_constraint_violation(s, s->candidate, 4, with_dd ? 3 : 2);                                           // (the kernel publishes: no read-back launch)
+    launch_merit_and_constraint(s, s->candidate, 4, with_dd ? 3 : 2);                                           // merit + violation in one launch; the kernel publishes: no read-back launch
     if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
     *Mh = s->hscal[4]; *thetah = s->hscal[5];
     return CALIPSO_OK;

@@ -331,6 +331,7 @@ void launch_merit_and_gradient(calipso_hip_solver* s);      // merit at the curr
 void launch_first_candidate(calipso_hip_solver* s, double a_s, double a_t);                        // first candidate of the line search + directional derivative, one launch
 void launch_first_candidate_batch(calipso_hip_solver* s, const double* a_s, const double* a_t);
 void launch_constraint_violation(calipso_hip_solver* s, const double* point, int pub_first = 0, int pub_count = 0);   // -> dscal[5]
+void launch_merit_and_constraint(calipso_hip_solver* s, const double* point, int pub_first, int pub_count);   // k_merit + k_constraint_violation in one launch
 void launch_violations_and_constraint(calipso_hip_solver* s, int pub_first = 0, int pub_count = 0);   // both at the current point, one launch
 void launch_dot_merit(calipso_hip_solver* s);                   // -> dscal[6]
 void launch_Hmul(calipso_hip_solver* s, const double* v, double* out);   // out = H v

@@ -528,6 +528,25 @@ void launch_constraint_violation(calipso_hip_solver* s, const double* point, int
                        pub ? ++s->pub_seq : 0ULL);
 }
 
+// k_merit and k_constraint_violation of a candidate back to back in one workgroup (solve.jl:242-250: the line search wants both, then the host decides): the two bodies
+// as they are, one launch less on the path between the refinement and the accepted step
+__global__ __launch_bounds__(RT) void k_merit_and_constraint(BatchSc bt, Dims d, int ptype, const double* __restrict__ point, const double* __restrict__ lam,
+                                                              const double* __restrict__ g, const double* __restrict__ hc, double* __restrict__ dscal, int pub_first,
+                                                              int pub_count, double* __restrict__ hpub, unsigned long long* __restrict__ hseq, unsigned long long seq) {
+    __shared__ double sm[RT / 64];
+    inst_shift(bt.b, point, lam, g, hc, dscal);
+    merit_body(bt.scal(blockIdx.z), d, point, lam, dscal, sm);
+    __syncthreads();
+    constraint_violation_body(d, ptype, point, g, hc, dscal);
+    publish_tail(dscal, pub_first, pub_count, hpub, hseq, seq);
+}
+void launch_merit_and_constraint(calipso_hip_solver* s, const double* point, int pub_first, int pub_count) {
+    const BatchSc B = batch_of(s);
+    const bool pub = pub_count > 0 && !s->cur;
+    hipLaunchKernelGGL(k_merit_and_constraint, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, norm_type(s->opt.constraint_norm), point, s->lambda, s->g, s->hc, s->dscal,
+                       pub_first, pub_count, pub ? s->hscal_dev : (double*)nullptr, pub ? s->hseq_dev : (unsigned long long*)nullptr, pub ? ++s->pub_seq : 0ULL);
+}
+
 void launch_violations_and_constraint(calipso_hip_solver* s, int pub_first, int pub_count) {
     const BatchSc B = batch_of(s);
     const bool pub = pub_count > 0 && !s->cur;
