@@ -709,8 +709,11 @@ static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
 static int do_cone_search(H* s, double* a_s, double* a_t, bool emit_candidate = true) {
     const Options& o = s->opt;
     if (s->d.nc == 0) { *a_s = 1.0; *a_t = 1.0; return CALIPSO_OK; }
-    launch_cone_search(s);
-    if (read_icount(s, 6, 58)) return CALIPSO_ERR_HIP;
+    {   // the kernel publishes its masks itself (no k_publish_words launch behind it)
+        const unsigned long long seq = ++s->pub_seq;
+        launch_cone_search(s, seq);
+        if (wait_published(s, seq)) return CALIPSO_ERR_HIP;
+    }
     const int ks = first_feasible_trial(s->hicount + 6, o.max_cone_line_search), kt = first_feasible_trial(s->hicount + 32, o.max_cone_line_search);
     if (ks < 0 || kt < 0) { s->err = "cone search failure"; return CALIPSO_ERR_CONE_SEARCH; }   // solve.jl:210,220
     // step sizes as the reference forms them: repeated multiplication by scaling_line_search (the kernel tested exactly these)

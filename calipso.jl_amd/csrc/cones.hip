@@ -125,7 +125,8 @@ __device__ __forceinline__ void violation_masks(const Dims& d, const ConeDev& cd
 
 __global__ __launch_bounds__(CONE_THREADS) void k_cone_search(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ sol,
                                                                const double* __restrict__ step, double sls, int nk,
-                                                               int* __restrict__ icount) {
+                                                               int* __restrict__ icount, int* __restrict__ hdst = nullptr, unsigned long long* __restrict__ hseq = nullptr,
+                                                               unsigned long long seq = 0, unsigned* __restrict__ ticket = nullptr) {
     inst_shift(bt.b, sol, step);
     inst_shift_i(bt.b, icount);
     const double tau = bt.scal(blockIdx.z).tau;
@@ -139,14 +140,30 @@ __global__ __launch_bounds__(CONE_THREADS) void k_cone_search(BatchSc bt, Dims d
     __syncthreads();
     const int first = blockIdx.x == 0 ? 6 : 32, words = blockIdx.x == 0 ? 26 : 32;
     if ((int)threadIdx.x < words) icount[first + threadIdx.x] = lm[threadIdx.x];
+    // a single handle: the masks go straight to the mapped host words as well, and the block that finishes second stores the sequence number the host spins on
+    // (api.hip: wait_published) — what a k_publish_words launch behind this kernel did
+    if (hdst) {
+        if ((int)threadIdx.x < words) hdst[first + threadIdx.x] = lm[threadIdx.x];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (atomicAdd(ticket, 1u) == 1u) {
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
-void launch_cone_search(calipso_hip_solver* s) {
+void launch_cone_search(calipso_hip_solver* s, unsigned long long publish_seq) {
     if (s->d.nc == 0) { fill_i(s, s->icount + 6, 58, 0); return; }
     const int nk = (int)s->opt.max_cone_line_search + 1;
     const BatchSc B = batch_of(s);
+    const bool pub = publish_seq != 0 && !s->cur;
     hipLaunchKernelGGL(k_cone_search, dim3(2, 1, B.b.n), dim3(CONE_THREADS), 0, s->stream, B, s->d, s->cone, s->solution, s->step,
-                       s->opt.scaling_line_search, nk > CONE_MASK_TRIALS ? CONE_MASK_TRIALS : nk, s->icount);
+                       s->opt.scaling_line_search, nk > CONE_MASK_TRIALS ? CONE_MASK_TRIALS : nk, s->icount, pub ? s->hicount_dev : (int*)nullptr,
+                       pub ? s->hseq_dev : (unsigned long long*)nullptr, publish_seq, reinterpret_cast<unsigned*>(s->dscal + 62));
 }
 
 // candidate s, t for the chosen step sizes (solve.jl:206-208, 216-218)
