@@ -537,10 +537,25 @@ static void factor_times(H* s) {
     s->kernel_ms[0] = hipEventElapsedTime(&ms, s->ev[12], s->ev[14]) == hipSuccess ? ms : 0.0;   // of which the panel steps (the pivot chain)
 }
 
-static int do_factorize(H* s, int64_t inertia[3]) {
+static int do_factorize(H* s, int64_t inertia[3], bool rhs_ahead_ok = false) {
     factor_times(s);                      // (before the events are recorded again)
     (void)hipEventRecord(s->ev[10], s->stream);
     launch_cone_weights(s);
+    // the operands of the first condensed solve (search_direction_symmetric!: residual_symmetric!, then b_x += [gx; hx]'(Omega b_m)) need these pivots and nothing of the
+    // factor: on the handle's second stream they run beside k_schur (ldl.hip: ldl_rhs_stream; joined with the finish of the factorisation) instead of behind it
+    s->rhs_ahead = false; s->rhs_joined = false;
+    if (rhs_ahead_ok) {
+        if (hipStream_t st2 = calipso::ldl_rhs_stream(s)) {
+            (void)hipEventRecord(s->ev_side[6], s->stream);
+            (void)hipStreamWaitEvent(st2, s->ev_side[6], 0);
+            hipStream_t keep = s->stream;
+            s->stream = st2;
+            launch_residual_symmetric(s, s->residual);
+            if (s->d.m) calipso::gemv_t(s, s->d.m, s->d.nx, s->Z, s->d.m, s->t1, s->xbuf, 1.0, 1.0, calipso::SP_Z);
+            s->stream = keep;
+            s->rhs_ahead = true;
+        }
+    }
     launch_scale_rows(s);
     (void)hipEventRecord(s->ev[11], s->stream);
     launch_schur(s);
@@ -569,19 +584,19 @@ static int do_factorize(H* s, int64_t inertia[3]) {
 
 // inertia.jl:30-80.  Quirk kept: the `primal_regularization_last == 0.0` test of :48 compares a Vector with a Float64 and is
 // always false, so IC-3 always takes max(min_regularization, scaling_regularization_last * eps_last).
-static int do_inertia_correction(H* s, int64_t* nfact) {
+static int do_inertia_correction(H* s, int64_t* nfact, bool rhs_ahead_ok = false) {
     Options& o = s->opt; Scalars& sc = s->sc;
     int64_t in[3];
     int64_t count = 0;
     sc.ep = o.primal_regularization_initial;
     sc.ed = o.dual_regularization_initial;
-    int rc = do_factorize(s, in); count++;                       // IC-1
+    int rc = do_factorize(s, in, rhs_ahead_ok); count++;         // IC-1
     if (rc < 0) return rc;
     if (inertia_ok(s, in)) { if (nfact) *nfact = count; return CALIPSO_OK; }
     if (in[2] != 0) sc.ed = o.dual_regularization * std::pow(sc.kappa, o.dual_regularization_exponent);   // IC-2
     sc.ep = std::max(o.min_regularization, o.scaling_regularization_last * sc.ep_last);                   // IC-3
     while (!inertia_ok(s, in)) {
-        rc = do_factorize(s, in); count++;                       // IC-4
+        rc = do_factorize(s, in, rhs_ahead_ok); count++;         // IC-4 (the operands are formed again with the new regularisation)
         if (rc < 0) return rc;
         if (inertia_ok(s, in)) break;
         if (sc.ep_last == 0.0) sc.ep = o.scaling_regularization_initial * sc.ep;   // IC-5
@@ -597,10 +612,17 @@ static int do_inertia_correction(H* s, int64_t* nfact) {
 static void do_sds(H* s, int which, double* accumulate = nullptr, bool refine_follows = false) {
     const double* res = which == 0 ? s->residual : s->residual_error;
     double* st = which == 0 ? s->step : s->step_correction;
-    launch_residual_symmetric(s, res);     // b, and the first operands of the condensed solve (xbuf, t1)
+    if (which == 0 && s->rhs_ahead && !s->rhs_joined && s->stream2 && s->ev_side[7]) {      // (a finish that did not join the second stream: join it here)
+        (void)hipEventRecord(s->ev_side[7], s->stream2);
+        (void)hipStreamWaitEvent(s->stream, s->ev_side[7], 0);
+        s->rhs_joined = true;
+    }
+    const bool ready = which == 0 && s->rhs_ahead && s->rhs_joined;      // (do_factorize queued them on the second stream and the factorisation's finish has joined it)
+    s->rhs_ahead = false;
+    if (!ready) launch_residual_symmetric(s, res);     // b, and the first operands of the condensed solve (xbuf, t1)
     // one launch for t2 = [gx; hx] dx, the back-substitution and the recovery (vectors.hip: k_solve_tail) where the handle allows it (which = 0, no accumulation: its zsx rule)
     const bool tail = which == 0 && !accumulate && s->d.m > 0;
-    linear_solve_device(s, !tail);         // dx = S^-1(...) in xbuf (, t2 = [gx; hx] dx)
+    linear_solve_device(s, !tail, ready);  // dx = S^-1(...) in xbuf (, t2 = [gx; hx] dx)
     if (tail && launch_solve_tail(s, 0, false, refine_follows)) return;
     if (tail) gemv_n(s, s->d.m, s->d.nx, s->Z, s->d.m, s->xbuf, s->t2, 1.0, 0.0, SP_Z);
     // dy, dz back-substitution + dr, ds, dt recovery (+ step += correction); which = 0 also leaves zsx = [gx; hx] step_x = t2 for the refinement
@@ -690,7 +712,7 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
 }
 
 static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
-    int rc = do_inertia_correction(s, nfact);
+    int rc = do_inertia_correction(s, nfact, true);
     if (rc < 0) return rc;
     do_sds(s, 0, nullptr, s->opt.iterative_refinement != 0);
     if (s->opt.iterative_refinement) {

@@ -176,6 +176,7 @@ struct calipso_hip_solver {
     void* cb_user = nullptr;
     calipso_device_eval_fn dev_eval = nullptr;   // user evaluation on the device (include/calipso_hip.h): enqueues on `stream`, never syncs
     void* dev_eval_user = nullptr;
+    bool rhs_ahead = false, rhs_joined = false;   // the operands of the first condensed solve were queued on the second stream during this factorisation (ldl.hip: ldl_rhs_stream) / the main stream has joined it
     double *evalL = nullptr, *evalZ = nullptr;   // structured handle with a device evaluator: dense scratch (nx^2, m nx) the evaluator writes; packed into the blocks behind it
     std::map<std::string, double*> optd;
     // host copies of the layout
@@ -392,7 +393,8 @@ void launch_init_point(calipso_hip_solver* s);                 // initialize_sla
 void launch_lambda_update(calipso_hip_solver* s);              // lambda += rho * r (solve.jl:362-364)
 void launch_jacobian_parameters(calipso_hip_solver* s);        // residual_jacobian_parameters.jl:1-40
 void launch_negate_copy(calipso_hip_solver* s, const double* src, double* dst, int n);
-void linear_solve_device(calipso_hip_solver* s, bool with_t2 = true);   // middle of the condensed solve (operands from k_residual_symmetric); with_t2 = false: the caller's k_solve_tail forms t2 = [gx; hx] dx
+void linear_solve_device(calipso_hip_solver* s, bool with_t2 = true, bool rhs_ready = false);   // rhs_ready: xbuf already holds b_x + [gx; hx]'(Omega b_m)
+hipStream_t ldl_rhs_stream(calipso_hip_solver* s);   // middle of the condensed solve (operands from k_residual_symmetric); with_t2 = false: the caller's k_solve_tail forms t2 = [gx; hx] dx
 void launch_solve_from_b(calipso_hip_solver* s);               // step_symmetric = K^-1 residual_symmetric for a caller-provided b
 // gemm.hip
 void gemm(calipso_hip_solver* s, int M, int N, int K, double alpha, const double* A, int lda, bool transA, const double* B, int ldb, double beta,

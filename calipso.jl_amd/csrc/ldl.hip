@@ -1113,9 +1113,10 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
             // the blocks whose last panel a panel step applied were finished beside the chain (launch_ldl); what is left is the last block(s).
             // Join first: the solves need every block (the second stream is long done by now).  (The last block's finish on the second stream too, joined
             // after the inertia read-back, was measured: 0.901 against 0.889 ms — the hand-over between the queues costs more than the overlap gives.)
-            if (s->ldl_forks) {
+            if (s->ldl_forks || s->rhs_ahead) {
                 (void)hipEventRecord(s->ev_side[7], s->stream2);
                 (void)hipStreamWaitEvent(s->stream, s->ev_side[7], 0);
+                s->rhs_joined = true;
             }
             for (int f = s->ldl_forks; 3 * f < (int)s->ldl_feeds.size(); ++f) enqueue_feed(s, s->stream, f, false);
             enqueue_lastblock_sym(s, s->stream);
@@ -1724,6 +1725,17 @@ bool ldl_chain_ok(calipso_hip_solver* s) {
 
 // ev[14] marks the end of the panel steps (the pivot chain), so that their duration can be reported apart from the parallel finish
 // (calipso_hip_kernel_times)
+// The right-hand side of the first condensed solve (k_residual_symmetric, then b_x += [gx; hx]'(Omega b_m)) needs the cone pivots, not the factor: do_factorize queues it
+// on the second stream of a handle whose factorisation will use that stream (and join it before the solves: enqueue_ldl_finish), where it runs on the compute units
+// k_schur leaves free instead of between the factorisation and the first solve.  nullptr: no such stream — the operands are formed where they always were.
+hipStream_t ldl_rhs_stream(calipso_hip_solver* s) {
+    static const bool env = [] { const char* e = getenv("CALIPSO_HIP_RHS_AHEAD"); return !e || atoi(e) != 0; }();
+    static const bool graph_ldl_env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();
+    if (!env || s->cur || s->compact || (s->stage_parallel && s->spS) || (s->use_graphs && graph_ldl_env)) return nullptr;
+    if (!ldl_overlap(s) || !side_stream(s) || ldl_decoupled(s)) return nullptr;
+    return s->stream2;
+}
+
 void launch_ldl(calipso_hip_solver* s) {
     // state of the previous factorisation that do_factorize / enqueue_ldl_finish would otherwise act on: a blocked factorisation that published its inertia
     // counts followed by a stage-parallel one on the same handle must not leave do_factorize waiting for a sequence number that was consumed long ago

@@ -26,9 +26,9 @@ void launch_negate_copy(calipso_hip_solver* s, const double* src, double* dst, i
 
 // operands prepared by k_residual_symmetric: xbuf = [b_x; 0], t1 = Omega b_m.  Leaves dx in xbuf and t2 = [gx; hx] dx; the
 // back-substitution [dy; dz] = -Omega (b_m - t2) is fused into k_recover.
-void linear_solve_device(calipso_hip_solver* s, bool with_t2) {
+void linear_solve_device(calipso_hip_solver* s, bool with_t2, bool rhs_ready) {
     const Dims& d = s->d;
-    if (d.m) gemv_t(s, d.m, d.nx, s->Z, d.m, s->t1, s->xbuf, 1.0, 1.0, SP_Z);           // b_x + gx'(omega_y b_y) + hx'(Omega_z b_z)
+    if (d.m && !rhs_ready) gemv_t(s, d.m, d.nx, s->Z, d.m, s->t1, s->xbuf, 1.0, 1.0, SP_Z);           // b_x + gx'(omega_y b_y) + hx'(Omega_z b_z)
     launch_trsv(s, s->xbuf);                                                       // xbuf = S^-1 xbuf
     if (d.m && with_t2) gemv_n(s, d.m, d.nx, s->Z, d.m, s->xbuf, s->t2, 1.0, 0.0, SP_Z);            // t2 = [gx; hx] dx
 }

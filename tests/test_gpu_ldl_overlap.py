@@ -50,7 +50,8 @@ def test_newton_steps_do_not_depend_on_the_schedule_of_the_factorisation():
     ref = run_variant({})
     for env in ({"CALIPSO_HIP_LDL_OVERLAP": "0"}, {"CALIPSO_HIP_LDL_PUBLISH": "0"}, {"CALIPSO_HIP_GRAPH_LDL": "1"}, {"CALIPSO_HIP_LDL_FEED": "64"},
                 {"CALIPSO_HIP_LDL_DECOUPLED": "1"},       # the persistent chain workgroup (k_ldl_chain: an experiment, off by default): same arithmetic, same bits
-                {"CALIPSO_HIP_WFORM_WGS": "64"}):
+                {"CALIPSO_HIP_WFORM_WGS": "64"},
+                {"CALIPSO_HIP_RHS_AHEAD": "0"}):          # the operands of the first condensed solve on the main stream behind the factorisation instead of on the second stream beside k_schur
         assert run_variant(env) == ref, env
 
 
