@@ -302,8 +302,8 @@ namespace calipso {
 // ---- launchers (each enqueues on s->stream; no host synchronisation unless stated) -------------------------------
 // cones.hip
 void launch_cone(calipso_hip_solver* s, const double* point, int flags);
-void launch_cone_search(calipso_hip_solver* s, unsigned long long publish_seq = 0);   // (publish_seq != 0, a single handle: the kernel itself publishes the masks + this sequence number)
-//               // fills icount[6..] violation bit masks for alpha = scaling_line_search^k
+// fills icount[6..] violation bit masks for alpha = scaling_line_search^k (publish_seq != 0, a single handle: the kernel itself publishes the masks + this sequence number)
+void launch_cone_search(calipso_hip_solver* s, unsigned long long publish_seq = 0);
 void launch_cone_candidate(calipso_hip_solver* s, double a_s, double a_t);
 void launch_cone_candidate_batch(calipso_hip_solver* s, const double* a_s, const double* a_t);   // one pair per covered instance
 void launch_cone_violation_host(calipso_hip_solver* s, const double* xhat_dev, const double* x_dev, double tau);
