@@ -195,6 +195,7 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     s->krange = reinterpret_cast<int*>(krange_d);
     s->zrow = reinterpret_cast<int*>(zrow_d);
     s->gx = s->Z; s->hx = s->Z + NE; s->g = s->gh; s->hc = s->gh + NE;
+    s->Lf = s->S;
     schur_plan(s);
     rc |= dalloc(s, &s->cone.soc_start, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.soc_dim, (size_t)d.n_soc);
     rc |= dalloc(s, &s->cone.soc_woff, (size_t)d.n_soc); rc |= dalloc(s, &s->cone.entry_soc, NC);
@@ -289,6 +290,7 @@ int32_t calipso_hip_destroy(H* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     nonsymmetric_release(s);
     ldlsolver_release(s);
+    calipso::lfac_release(s);
     scatter_release(s);
     if (s->spS) { (void)calipso_hip_sparse_destroy(s->spS); s->spS = nullptr; }
     if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
@@ -306,9 +308,6 @@ int32_t calipso_hip_destroy(H* s) {
     for (auto& e : s->ev_side) if (e) (void)hipEventDestroy(e);
     if (s->hprog) (void)hipHostFree(s->hprog);
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
-    if (s->chain_flags) (void)hipFree(s->chain_flags);
-    if (s->ev_worker) (void)hipEventDestroy(s->ev_worker);
-    if (s->stream3) (void)hipStreamDestroy(s->stream3);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return CALIPSO_OK;
@@ -567,12 +566,10 @@ static int do_factorize(H* s, int64_t inertia[3], bool rhs_ahead_ok = false) {
     if (s->ldl_pub_seq) {
         // the last diagonal block published the counts when the pivot chain ended: the host goes on queueing behind the finish of the last solve block
         if (wait_published(s, s->ldl_pub_seq)) return CALIPSO_ERR_HIP;
-        if (!calipso::ldl_chain_ok(s)) { SYNC(); return CALIPSO_ERR_HIP; }
     } else {
         CK(hipMemcpyAsync(s->hicount, s->icount, sizeof(int) * 6, hipMemcpyDeviceToHost, s->stream));
         SYNC();
         factor_times(s);
-        if (!calipso::ldl_chain_ok(s)) return CALIPSO_ERR_HIP;
     }
     s->stats.factorizations += 1;
     s->phase_ms[8] += 1.0;

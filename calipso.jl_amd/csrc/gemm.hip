@@ -81,13 +81,13 @@ void trsm_multi(calipso_hip_solver* s, double* X, int p, double* U, double* Zm) 
         const int k0 = kb * tb, w = std::min(tb, NP - k0);
         gemm(s, w, p, w, 1.0, s->Tinv + (size_t)kb * tb * tb, tb, false, X + k0, NP, 0.0, U + k0, NP);
         const int rest = NP - k0 - w;
-        if (rest > 0) gemm(s, rest, p, w, -1.0, s->S + (k0 + w) + (size_t)k0 * NP, NP, false, U + k0, NP, 1.0, X + k0 + w, NP);
+        if (rest > 0) gemm(s, rest, p, w, -1.0, s->Lf + (k0 + w) + (size_t)k0 * NP, NP, false, U + k0, NP, 1.0, X + k0 + w, NP);
     }
     hipLaunchKernelGGL(k_scale_rows_by_dinv, dim3((NP + 255) / 256, p), dim3(256), 0, s->stream, NP, p, s->Dx, U, Zm);
     for (int kb = nb - 1; kb >= 0; --kb) {
         const int k0 = kb * tb, w = std::min(tb, NP - k0);
         gemm(s, w, p, w, 1.0, s->Tinv + (size_t)kb * tb * tb, tb, true, Zm + k0, NP, 0.0, X + k0, NP);
-        if (k0 > 0) gemm(s, k0, p, w, -1.0, s->S + k0, NP, true, X + k0, NP, 1.0, Zm, NP);
+        if (k0 > 0) gemm(s, k0, p, w, -1.0, s->Lf + k0, NP, true, X + k0, NP, 1.0, Zm, NP);
     }
 }
 

@@ -261,14 +261,12 @@ struct calipso_hip_solver {
     double* dsym_multi = nullptr; // n * np
     void* scatter_aux = nullptr;  // scatter.hip: registered sparsity patterns of the evaluate! scatter
     void* ldl_aux = nullptr;      // ldlsolver.hip: staging of the caller's CSC matrix (handles made by calipso_hip_ldl_create)
+    void* lfac_aux = nullptr;     // lfac.hip: plan and buffers of the left-looking schedule (one dense system alone)
+    bool lfac_failed = false;     // its buffers could not be had: the handle keeps k_schur + the right-looking panel steps
+    double* Lf = nullptr;         // where the factor columns L of the last blocked factorisation live: S (scaled in place) or lfac.hip's buffer
     double* Hdense = nullptr; int* lu_ipiv = nullptr;   // fallback.hip: N x N unreduced matrix and pivots (allocated on first use)
     hipEvent_t ev[16];
     hipStream_t stream2 = nullptr;       // second stream of the handle: the finish of completed solve blocks while the pivot chain runs (ldl.hip)
-    hipStream_t stream3 = nullptr;       // third stream: the trailing updates of the decoupled schedule (the chain itself runs on `stream`); ev_worker joins it
-    hipEvent_t ev_worker = nullptr;
-    unsigned* chain_flags = nullptr;     // fine-grained device memory: the two flag words of the decoupled schedule (ldl.hip)
-    bool decoupled_check = false;        // the last factorisation took the decoupled schedule: api.hip asks ldl_chain_ok() once the inertia counts are in
-    int decoupled_ok = 0;                // 0: not probed yet, 1: the three streams run on distinct hardware queues, -1: they do not (the launch-per-panel schedule stays)
     bool ldl_publish = false;            // launch_ldl: the last diagonal block may publish the inertia counts ...
     unsigned long long ldl_pub_seq = 0;  // ... and did, under this sequence number (0: it did not; read them back)
     bool factor_times_pending = false;   // the events of the last factorisation have not been read yet (api.hip: factor_times)
@@ -383,10 +381,16 @@ int blocks_download_dense(calipso_hip_solver* s, int which, double* data);
 bool blocks_entry_offsets(const calipso_hip_solver* s, int which, int row, int col, long long* off_c, long long* off_r);
 void launch_ldl(calipso_hip_solver* s);
 void ldl_drop_graphs(calipso_hip_solver* s);
-bool ldl_chain_ok(calipso_hip_solver* s);
 void launch_trsv(calipso_hip_solver* s, double* x);            // x (length NP) <- S^-1 x using L, D
 bool lastblock_sym_on(const calipso_hip_solver* s);   // the last solve block as one symmetric mat-vec (ldl.hip)
 bool wform_on(const calipso_hip_solver* s);                    // the solves of this handle (or of the group launch in progress) go through the W-form blocks
+// lfac.hip: the left-looking schedule of one dense system (the Schur complement's products under the pivot chain)
+bool lfac_on(const calipso_hip_solver* s);
+bool lfac_ready(calipso_hip_solver* s);          // lfac_on, and the plan / buffers exist
+int lfac_enqueue(calipso_hip_solver* s, unsigned long long* hprog, unsigned long long epoch);   // returns the launches queued (0: not available)
+double* lfac_factor_buffer(calipso_hip_solver* s);
+void lfac_release(calipso_hip_solver* s);
+void lfac_describe(calipso_hip_solver* s, double out[8]);
 // solvek.hip
 void launch_copy_pad(calipso_hip_solver* s, const double* src, int n, double* dst, int npad);
 void launch_init_point(calipso_hip_solver* s);                 // initialize_slacks!/duals! (initialize.jl:15-36), r <- g

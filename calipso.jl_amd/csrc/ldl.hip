@@ -24,8 +24,8 @@
 // from the 64 x 64 inverses by four levels of small matrix-core GEMMs (k_tinv_*), so a solve is 2 launches per block
 // (10 launches for NP = 2560) instead of a 2560-long dependent chain.
 #include "internal.hpp"
-#include "device_utils.hpp"
-#include "pivot16.hpp"
+#define LDL_TRACE_OWNER      // the timeline stamps of -DCALIPSO_LDL_TRACE live in this translation unit
+#include "ldl_device.hpp"
 
 #include <algorithm>
 #include <array>
@@ -34,253 +34,6 @@
 
 namespace calipso {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int TB = 2048;           // largest triangular-solve block; the block actually used is tb = min(opt.solve_block, NP); the last block of a solve may be narrower
-constexpr int LDT = NB + 2;        // LDS leading dimension of a k-fastest 64-deep operand panel
-
-// ---- diagonal block ---------------------------------------------------------------------------------------------------------
-// The 2500 sequential pivots of S are the critical path of the factorisation; this block is tuned with the stand-alone harnesses
-// bench/diag_bench3.hip (this design; profiles/r03_diag_bench3.txt) and bench/diag_bench2.hip / diag_bench.hip (its predecessors: four-column
-// mini-panels exchanged through LDS, one barrier each; 13.5 us in the pivot loop).  1024 threads = 16 wavefronts; wavefront (R, C) = (w >> 2, w & 3)
-// holds the 16 x 16 tile (R, C) of the block in the accumulator layout of v_mfma_f64_16x16x4 for the whole factorisation (exactly what the
-// trailing update of k_ldl_step leaves in its registers: no hand-over).  Four ROUNDS of 16 columns:
-//   [A] the tiles of column block r go to LDS (cp), barrier;
-//   [owner] wavefront (r, r) takes the 16 columns with lane = row and factors them alone, in registers: no LDS traffic and no barrier between
-//       pivots.  The pivot-row entry a rank-1 update needs is fused into the multiply-add by DPP (v_fmac_f64_dpp row_newbcast: lane K of
-//       every 16-lane row to all lanes of that row) — for that, the pivot column is read back from LDS, where it goes anyway, as "its rows of
-//       the diagonal 16 x 16 block, replicated in every 16-lane row".  The reciprocal chain of the next pivot (v_rcp_f64 + two Newton steps)
-//       is threaded by hand through the updates of the current one (a wavefront issues in order).  Unscaled columns (Yk), L (Lk) and the
-//       pivots go to LDS, barrier;
-//   [C] the tiles right of the block take the rank-16 update on the matrix cores (4 MFMAs per tile).
-// X = L11^-1 is assembled meanwhile by the wavefronts that have nothing to do: the 16 x 16 diagonal inverses in-wave by DPP (four helper
-// wavefronts, kept off the SIMD of the owner), the blocks below by products on the matrix cores, X_RC = -X_RR (sum_K L_RK X_KC), with the
-// inner sum handed from one MFMA chain to the next in registers (the k order of an MFMA is free).  Two short phases remain after the last
-// pivot; then M = X' D^-1 X on the matrix cores (what the next panel step multiplies the raw panel with) and ALL global stores: D, L, X, M.
-// Nothing is written to global memory before the last barrier (a pending store would make a barrier wait on memory).
-// Measured (bench/diag_bench3.hip, one block alone): 14.3 us per launch against 18.2 for the four-column design.
-constexpr int DIAG_THREADS = 1024;
-constexpr int YS = 18;             // row stride of the 16-column panel of unscaled pivot columns (k fastest; 36 dwords: conflict-free fragment reads)
-constexpr int CPS = NB;            // column stride of the column block handed to the next owner
-
-// Optional timeline of the pivot chain (build with -DCALIPSO_LDL_TRACE; bench/ldl_trace.py reads it through calipso_hip_debug_ldl_trace):
-// 100 MHz wall-clock stamps of the workgroup that carries tile 0 + the diagonal block, instance 0, per panel step.
-#ifdef CALIPSO_LDL_TRACE
-__device__ long long g_ldl_trace[64 * 16];
-#define LDL_STAMP(step, slot) do { if (threadIdx.x == 0 && (step) < 64) g_ldl_trace[(step) * 16 + (slot)] = wall_clock64(); } while (0)
-// one worker workgroup of the FIRST two-panel pass (k0 == 0): core-clock stamps of its first 32 tiles, 8 slots each
-__device__ long long g_ldl_bulk[32 * 8 + 32 * 16 * 2];    // + per wavefront: start / end of the MFMA phase
-#define BULK_WAVE_STAMP(slot) do { if (MODE == 2 && bulk_traced && bulk_tile < 32 && (threadIdx.x & 63) == 0) g_ldl_bulk[32 * 8 + (bulk_tile * 16 + (threadIdx.x >> 6)) * 2 + (slot)] = __builtin_readcyclecounter(); } while (0)
-#define BULK_STAMP(slot) do { if (MODE == 2 && bulk_traced && bulk_tile < 32 && threadIdx.x == 0) g_ldl_bulk[bulk_tile * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define LDL_STAMP(step, slot) do { } while (0)
-#define BULK_STAMP(slot) do { } while (0)
-#define BULK_WAVE_STAMP(slot) do { } while (0)
-#endif
-
-
-// LDS carve (doubles): Lk | Yk | cp | XT | XTs | dpiv | dinv
-constexpr int DIAG_LDS_DOUBLES = 3 * NB * LDT + NB * YS + 16 * CPS + 2 * NB;
-
-__device__ __forceinline__ void lds_barrier_all() {                  // workgroup barrier that orders LDS traffic only (global stores stay in flight)
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
-}
-// -- diagonal 16 x 16 inverse, in-wave by DPP: a helper wavefront grows columns 4 hq .. 4 hq + 3 (lane & 15 = row; the four 16-lane rows compute the
-// same).  X = G_14^-1 ... G_0^-1 applied to the identity: x[i] -= L[i][j] x[j] for i > j, j = 0 .. 14 in turn (x[j] by the row broadcast)
-template <int J> __device__ __forceinline__ void xrr_steps(double (&x)[4], const double (&nl)[15]) {
-    if constexpr (J < 15) {
-        asm volatile("v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                     "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
-                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "v"(nl[J]), "n"(J));      // (three instructions between a write of x[c] and its next DPP read)
-        xrr_steps<J + 1>(x, nl);
-    }
-}
-__device__ __forceinline__ void xrr_helper(int r, int hq, int i, const double* __restrict__ Lk, const double* __restrict__ dinv, double* __restrict__ XT,
-                                           double* __restrict__ XTs) {
-    const int ii = i & 15;
-    double nl[15], x[4];
-    const double* Lrow = Lk + (16 * r + ii) * LDT + 16 * r;
-#pragma unroll
-    for (int j = 0; j < 15; ++j) nl[j] = Lrow[j];                       // (all loads in flight before the first use)
-#pragma unroll
-    for (int j = 0; j < 15; ++j) nl[j] = (ii > j) ? -nl[j] : 0.0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) x[c] = (ii == 4 * hq + c) ? 1.0 : 0.0;
-    asm volatile("s_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-    xrr_steps<0>(x, nl);
-    if (i < 16) {
-        const double di = dinv[16 * r + ii];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { XT[(16 * r + 4 * hq + c) * LDT + 16 * r + ii] = x[c]; XTs[(16 * r + 4 * hq + c) * LDT + 16 * r + ii] = x[c] * di; }
-    }
-}
-// one column of a diagonal inverse per wavefront (after the last pivot every wavefront is free)
-template <int J> __device__ __forceinline__ void xrr1_steps(double& x, const double (&nl)[15]) {
-    if constexpr (J < 15) {
-        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(nl[J]), "n"(J));
-        xrr1_steps<J + 1>(x, nl);
-    }
-}
-__device__ __forceinline__ void xrr_column(int r, int c, int i, const double* __restrict__ Lk, const double* __restrict__ dinv, double* __restrict__ XT,
-                                           double* __restrict__ XTs) {
-    const int ii = i & 15;
-    double nl[15];
-    const double* Lrow = Lk + (16 * r + ii) * LDT + 16 * r;
-#pragma unroll
-    for (int j = 0; j < 15; ++j) nl[j] = Lrow[j];
-#pragma unroll
-    for (int j = 0; j < 15; ++j) nl[j] = (ii > j) ? -nl[j] : 0.0;
-    double x = (ii == c) ? 1.0 : 0.0;
-    xrr1_steps<0>(x, nl);
-    if (i < 16) { XT[(16 * r + c) * LDT + 16 * r + ii] = x; XTs[(16 * r + c) * LDT + 16 * r + ii] = x * dinv[16 * r + ii]; }
-}
-// t += L_RK X_KC (16 x 16 blocks): lane (fr, fk) holds t[q] = (row 16 R + fk + 4 q, column 16 C + fr).  XT[a][r] = X[r][a], Lk[i][k] = L[i][k], both
-// k-fastest with stride LDT: the fragment reads of a 32-lane half hit 32 distinct bank pairs
-__device__ __forceinline__ v4d blk_LX(v4d t, int Rr, int K, int Cc, const double* __restrict__ Lk, const double* __restrict__ XT, int fr, int fk) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const double f = Lk[(16 * Rr + fr) * LDT + 16 * K + 4 * kk + fk];
-        const double s = XT[(16 * Cc + fr) * LDT + 16 * K + 4 * kk + fk];
-        t = __builtin_amdgcn_mfma_f64_16x16x4f64(f, s, t, 0, 0, 0);
-    }
-    return t;
-}
-// X_RC = -X_RR W_RC with W still in the accumulator registers of the wavefront that formed it (t[q] = W(16 R + fk + 4 q, 16 C + fr)): the matrix
-// cores sum over k in any order, so k-step kk takes k = fk + 4 kk — lane (fr, fk) then supplies t[kk] as it stands, and the X_RR operand is read to match
-__device__ __forceinline__ void blk_XW(v4d t, int Rr, int Cc, double* __restrict__ XT, double* __restrict__ XTs, const double* __restrict__ dinv, int fr, int fk) {
-    v4d x = (v4d){0.0, 0.0, 0.0, 0.0};
-    double f[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) f[kk] = XT[(16 * Rr + fk + 4 * kk) * LDT + 16 * Rr + fr];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(-f[kk], t[kk], x, 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        XT[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = x[q];
-        XTs[(16 * Cc + fr) * LDT + 16 * Rr + fk + 4 * q] = x[q] * dinv[16 * Rr + fk + 4 * q];
-    }
-}
-
-// acc: tile (R, C) = (w >> 2, w & 3) of the block, acc[q] = A(16 R + fr, 16 C + fk + 4 q) with fr = lane & 15, fk = lane >> 4 (tiles above the diagonal are
-// ignored).  smem: DIAG_LDS_DOUBLES doubles that no wavefront of the workgroup still reads (the caller has a barrier behind its last LDS read).
-// Mkeep (the persistent chain of k_ldl_chain): an LDS copy of M ([c][k], row stride LDT) for the chain's own next update.
-__device__ __forceinline__ void diag_block(double* __restrict__ smem, v4d acc, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
-                                           double* __restrict__ Tinv, double* __restrict__ Minv, int* __restrict__ icount, double* __restrict__ Mkeep = nullptr) {
-    double* Lk = smem;                       // Lk[i][k] = L[i][k] (k fastest)
-    double* XT = Lk + NB * LDT;              // XT[a][r] = X[r][a]
-    double* XTs = XT + NB * LDT;             // ... scaled by the reciprocal pivot of row r
-    double* Yk = XTs + NB * LDT;             // Yk[i][j] = unscaled column 16 r + j of the current round
-    double* cp = Yk + NB * YS;               // cp[c][i]: column block r after the updates of the rounds before, for its owner
-    double* dpiv = cp + 16 * CPS;            // the 64 pivots
-    double* dinv = dpiv + NB;                // and their reciprocals
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));            // (opaque: inside the persistent loop of k_ldl_chain nothing derived from it may be hoisted and held across the rounds)
-    const int i = tid & 63, w = tid >> 6;
-    const int R = w >> 2, C = w & 3, fr = i & 15, fk = i >> 4;
-    v4d xacc = (v4d){0.0, 0.0, 0.0, 0.0};   // a block product of the inverse carried from one phase to the next
-    LDL_STAMP(k0 / NB, 2);
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        if (C == r && R >= r) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cp[(fk + 4 * q) * CPS + 16 * R + fr] = acc[q];
-        }
-        lds_barrier_all();
-        if (w == 5 * r) {
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = cp[c * CPS + i];
-            const double y0 = cp[16 * r + (i & 15)];
-            Yk[i * YS] = a[0];
-            const int lo = __builtin_amdgcn_readlane(__double2loint(a[0]), 16 * r), hi = __builtin_amdgcn_readlane(__double2hiint(a[0]), 16 * r);
-            Pivot<0, true>::run(a, (unsigned)(uintptr_t)(Yk + i * YS), (unsigned)(uintptr_t)(Yk + (16 * r + (i & 15)) * YS), Lk + i * LDT + 16 * r, 16 * r,
-                          fast_rcp(__hiloint2double(hi, lo)), y0);
-            if (i < 16) { const double d = Yk[(16 * r + i) * YS + i]; dpiv[16 * r + i] = d; dinv[16 * r + i] = fast_rcp(d); }   // (its own stores: the LDS queue of a wavefront is in order)
-        }
-        // while the owner (wavefront 5 r, SIMD r) is busy — nothing else is put on its SIMD: the diagonal inverse of the previous round and the block
-        // products whose operands are visible
-        if (r == 1) { const int hq = w == 2 ? 0 : w == 3 ? 1 : w == 6 ? 2 : w == 7 ? 3 : -1; if (hq >= 0) xrr_helper(0, hq, i, Lk, dinv, XT, XTs); }
-        if (r == 2) { const int hq = w == 1 ? 0 : w == 3 ? 1 : w == 4 ? 2 : w == 8 ? 3 : -1; if (hq >= 0) xrr_helper(1, hq, i, Lk, dinv, XT, XTs); }
-        if (r == 3) {
-            const int hq = w == 1 ? 0 : w == 2 ? 1 : w == 6 ? 2 : w == 4 ? 3 : -1;
-            if (hq >= 0) xrr_helper(2, hq, i, Lk, dinv, XT, XTs);
-            if (w == 9) xacc = blk_LX(xacc, 2, 1, 0, Lk, XT, fr, fk);                                                                  // W_20 += L_21 X_10
-            if (w == 8) { xacc = blk_LX(xacc, 3, 0, 0, Lk, XT, fr, fk); xacc = blk_LX(xacc, 3, 1, 0, Lk, XT, fr, fk); }               // W_30' = L_30 X_00 + L_31 X_10
-            if (w == 12) xacc = blk_LX(xacc, 3, 1, 1, Lk, XT, fr, fk);                                                                // W_31' = L_31 X_11
-        }
-        lds_barrier_all();
-        if (R >= C && C > r) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const double yf = Yk[(16 * C + fr) * YS + 4 * kk + fk];
-                const double lf = Lk[(16 * R + fr) * LDT + 16 * r + 4 * kk + fk];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-yf, lf, acc, 0, 0, 0);
-            }
-        }
-        if (r == 2) {
-            if (w == 7) { const v4d t = blk_LX((v4d){0.0, 0.0, 0.0, 0.0}, 1, 0, 0, Lk, XT, fr, fk); blk_XW(t, 1, 0, XT, XTs, dinv, fr, fk); }   // X_10 = -X_11 (L_10 X_00)
-            if (w == 9) xacc = blk_LX(xacc, 2, 0, 0, Lk, XT, fr, fk);                                                                 // W_20' = L_20 X_00
-            if (w == 4) xacc = blk_LX(xacc, 2, 1, 1, Lk, XT, fr, fk);                                                                 // W_21 = L_21 X_11
-        }
-    }
-    LDL_STAMP(k0 / NB, 3);
-    // after the last pivot: X_33 (one column per wavefront), X_20, X_21, W_32; then X_30, X_31, X_32
-    if (w != 9 && w != 4 && w != 7) xrr_column(3, w, i, Lk, dinv, XT, XTs);
-    if (w == 0) xrr_column(3, 9, i, Lk, dinv, XT, XTs);
-    if (w == 1) xrr_column(3, 4, i, Lk, dinv, XT, XTs);
-    if (w == 2) xrr_column(3, 7, i, Lk, dinv, XT, XTs);
-    if (w == 9) blk_XW(xacc, 2, 0, XT, XTs, dinv, fr, fk);
-    if (w == 4) blk_XW(xacc, 2, 1, XT, XTs, dinv, fr, fk);
-    if (w == 7) xacc = blk_LX(xacc, 3, 2, 2, Lk, XT, fr, fk);                                                                             // W_32 = L_32 X_22
-    lds_barrier_all();
-    if (w == 8) { xacc = blk_LX(xacc, 3, 2, 0, Lk, XT, fr, fk); blk_XW(xacc, 3, 0, XT, XTs, dinv, fr, fk); }
-    if (w == 12) { xacc = blk_LX(xacc, 3, 2, 1, Lk, XT, fr, fk); blk_XW(xacc, 3, 1, XT, XTs, dinv, fr, fk); }
-    if (w == 7) blk_XW(xacc, 3, 2, XT, XTs, dinv, fr, fk);
-    lds_barrier_all();
-    LDL_STAMP(k0 / NB, 4);
-    // M = X' D^-1 X = (L11 D L11')^-1: what the NEXT launch multiplies the raw panel with.  M[a][b] = sum_r X[r][a] X[r][b] / d[r] on the matrix
-    // cores: wavefront (wa, wb) forms the 16 x 16 tile (rows a, columns b); both operand fragments are "row a (b), k index r" reads of X'.
-    {
-        const int wa = R, wb = C;
-        v4d m = (v4d){0.0, 0.0, 0.0, 0.0};
-        // X[r][a] = 0 for r < a: the k blocks above the later of the two tile origins contribute exact zeros and are skipped (the workgroup's 256
-        // MFMAs shrink to 120; the matrix cores of one CU are what bounds this product)
-        for (int kk = 4 * (wa > wb ? wa : wb); kk < NB / 4; ++kk) {
-            const double xa = XTs[(wa * 16 + fr) * LDT + 4 * kk + fk];
-            const double xb = XT[(wb * 16 + fr) * LDT + 4 * kk + fk];
-            m = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, xb, m, 0, 0, 0);
-        }
-        double* Mo = Minv + (size_t)(k0 / NB) * NB * NB;
-        LDL_STAMP(k0 / NB, 6);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Mo[(wb * 16 + fr) + (size_t)(wa * 16 + fk + 4 * q) * NB] = m[q];   // lane holds M(a = fk + 4 q, b = fr) = M(b, a): 128-byte runs along fr
-        if (Mkeep) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Mkeep[(wb * 16 + fr) * LDT + wa * 16 + fk + 4 * q] = m[q];     // Mkeep[c][k] = what form_Z reads as Mk[c + k * NB]
-        }
-    }
-    // everything that goes to global memory leaves here, after the last barrier: D and the inertia counts (compute_inertia!), the strictly
-    // lower L of the block and X = L11^-1 on the diagonal of the triangular-solve inverse block (zeros above), both from their LDS copies:
-    // thread (i, w) stores row i of columns 4 w .. 4 w + 3
-    if (tid < NB) {
-        const double d = dpiv[tid];
-        Dx[k0 + tid] = d;
-        const bool real = k0 + tid < nx;                                  // (padding rows carry unit pivots that are not counted)
-        const int pos = __popcll(__ballot(real && d > 0.0)), nonpos = __popcll(__ballot(real && d <= 0.0)), zero = __popcll(__ballot(real && d == 0.0));
-        if (tid == 0) { atomicAdd(&icount[3], pos); atomicAdd(&icount[4], nonpos); atomicAdd(&icount[5], zero); }
-    }
-    {
-        const int q = k0 / tb, o = k0 % tb;
-        double* T = Tinv + (size_t)q * tb * tb;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = 4 * w + c;
-            T[(o + i) + (size_t)(o + k) * tb] = (i >= k) ? XT[k * LDT + i] : 0.0;
-            if (i > k) S[(k0 + i) + (size_t)(k0 + k) * NP] = Lk[i * LDT + k];
-        }
-    }
-    LDL_STAMP(k0 / NB, 5);
-}
 
 __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(Batch bt, int NP, int nx, int k0, int tb, double* __restrict__ S, double* __restrict__ Dx,
                                                             double* __restrict__ Tinv, double* __restrict__ Minv, int* __restrict__ icount) {
@@ -302,14 +55,14 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_ldl_diag(Batch bt, int NP, int
 // 16-lane fast index of the result is the contiguous row index r of the column-major panel.  One workgroup (16 wavefronts) per
 // 64 x 64 tile (blockIdx.x = tile row below the panel, blockIdx.y = panel); wavefront (wr, wc) computes the 16 x 16 tile rows 16 wr..,
 // columns 16 wc..; X is staged in LDS.  Off the critical path: 780 independent tiles at C3.
-__global__ __launch_bounds__(1024) void k_ldl_scale(Batch bt, int NP, int tb, int band_rows, int p0, double* __restrict__ S, const double* __restrict__ Dx,
+__global__ __launch_bounds__(1024) void k_ldl_scale(Batch bt, int NP, int tb, int band_rows, int p0, const double* S, double* Lout, const double* __restrict__ Dx,
                                                      const double* __restrict__ Tinv) {
     __shared__ double Xs[NB * LDT];   // Xs[c][k]
     __shared__ double dinv[NB];
     const int k0 = (p0 + (int)blockIdx.y) * NB;       // panels p0 .. p0 + gridDim.y - 1
     const int rows = min(NP - k0 - NB, band_rows);           // banded S: the panel stops at the band
     if ((int)blockIdx.x * 64 >= rows) return;
-    inst_shift(bt, S, Dx, Tinv);
+    inst_shift(bt, S, Lout, Dx, Tinv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fk = lane >> 4;
@@ -336,17 +89,10 @@ __global__ __launch_bounds__(1024) void k_ldl_scale(Batch bt, int NP, int tb, in
     for (int r = 0; r < 4; ++r) {
         const int c = wc * 16 + fk + 4 * r;   // MFMA row  -> panel column
         const int row = r0 + fr;              // MFMA col  -> panel row (contiguous)
-        S[row + (size_t)(k0 + c) * NP] = acc[r] * dinv[c];
+        Lout[row + (size_t)(k0 + c) * NP] = acc[r] * dinv[c];     // (Lout == S: in place — every lane holds its raw entries since the barrier; lfac.hip: a buffer of its own)
     }
 }
 
-// ---- panel step: A22 -= (A21 M) A21' ---------------------------------------------------------------------------------------------
-// 64 x 64 tile of the lower triangle per workgroup of 1024 threads (16 wavefronts, one 16 x 16 MFMA tile each).  ONE workgroup is resident
-// per CU (registers).  Small tiles keep all 256 CUs busy on the shrinking trailing matrix.  The tile is computed transposed (MFMA row <->
-// column j of S) so result stores are 128-byte runs.
-constexpr int TR_THREADS = 1024;
-constexpr int TT = 64;
-constexpr int step_lds_doubles(int nh) { return (nh + 2) * TT * LDT > DIAG_LDS_DOUBLES ? (nh + 2) * TT * LDT : DIAG_LDS_DOUBLES; }   // Zs[nh] | Ys | Ms
 // Tile 0 of the trailing update IS the next diagonal block: its workgroup keeps going and factors that block (diag_block),
 // so the 64-column pivot chain of panel k+1 runs inside this launch, overlapped with the other tiles, and a panel step is ONE launch.
 // Workgroups are persistent: workgroup 0 takes tile 0 (and then the diagonal block), workgroup w >= 1 walks a CONTIGUOUS run of the
@@ -364,69 +110,6 @@ __device__ __forceinline__ void trailing_tile_index(int t, int& ti, int& tj) {
 //         read and written once per 128 pivots instead of once per 64 — the early, HBM-bound updates of a group move half the bytes.  The
 //         arithmetic is that of two MODE 0 passes, operation for operation (a separate accumulator per panel, subtracted in panel order),
 //         so the pair schedule (MODE 1 + MODE 2) and the plain one (MODE 0 twice) give the same bits.
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access of the wave (vmcnt(0)): in the
-// tile loop below that would put the write latency of the tile just stored, and the arrival of the operands prefetched for the next one, on
-// the critical path of every tile.  Tiles are disjoint in global memory; only the LDS panels are shared between the waves.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0), vmcnt / expcnt untouched
-    __builtin_amdgcn_s_barrier();
-}
-// acc[r] = sum_k Y[16 wc + fk + 4 r][k] L[16 wr + fr][k] for one wavefront: 16 v_mfma_f64_16x16x4_f64 on fragments of two k-fastest LDS panels (row stride
-// LDT), lb / yb = LDS byte addresses of this lane's row of the B / A operand panel at k = fk.  MFMA fragments by explicit ds_read_b64 (lane
-// (fr, fk) reads row fr, k = 4 kk + fk: dword address 132 fr + 2 fk + 8 kk — the 32 lanes of a half-wave hit 32 distinct bank pairs modulo 64).
-// Plain loads would be paired by the compiler into ds_read2_b64 / ds_read_b128, whose lane groups conflict 2-way on this layout.  A ring of two
-// register groups of four k-steps: the reads of group g + 2 are issued as soon as the MFMAs of group g have taken their operands, so 16 doubles
-// hold the fragments instead of 32; the waits release the loads to the matrix cores in order (LDS returns in order).
-__device__ __forceinline__ v4d frag_product(const unsigned lb, const unsigned yb) {
-    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    double fl[8], fy[8];
-#define TR_READ(G, KK0)                                                                                                                    \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                                      \
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fl[(G) * 4 + q]) : "v"(lb), "n"(((KK0) + q) * 32) : "memory");                 \
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fy[(G) * 4 + q]) : "v"(yb), "n"(((KK0) + q) * 32) : "memory");                 \
-    }
-#define TR_WAIT(N, G)                                                                                                                      \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fl[(G) * 4]), "+v"(fy[(G) * 4]), "+v"(fl[(G) * 4 + 1]), "+v"(fy[(G) * 4 + 1]),               \
-                 "+v"(fl[(G) * 4 + 2]), "+v"(fy[(G) * 4 + 2]), "+v"(fl[(G) * 4 + 3]), "+v"(fy[(G) * 4 + 3]) :: "memory")
-#define TR_MFMA(G)                                                                                                                         \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fy[(G) * 4 + q], fl[(G) * 4 + q], acc, 0, 0, 0);
-    TR_READ(0, 0) TR_READ(1, 4)
-    TR_WAIT(8, 0); TR_MFMA(0)
-    TR_READ(0, 8)
-    TR_WAIT(8, 1); TR_MFMA(1)
-    TR_READ(1, 12)
-    TR_WAIT(8, 0); TR_MFMA(0)
-    TR_WAIT(0, 1); TR_MFMA(1)
-#undef TR_READ
-#undef TR_WAIT
-#undef TR_MFMA
-    return acc;
-}
-
-// Z = A(i, panel) M into Zs (LDS, [row i][c fastest], ld LDT): on a change of tile row.  The raw rows travel through `stage` (the buffer the
-// column operand uses afterwards) and M (symmetric, 32 KB, in L2 for every workgroup of the launch) through `Ms`, both fetched in ONE batch of
-// global loads (the workgroup that carries the pivot chain pays one memory round trip here, not two).
-__device__ __forceinline__ void form_Z(const double* __restrict__ Ap, int NP, const double* __restrict__ Mk, double* __restrict__ stage, double* __restrict__ Ms,
-                                       double* __restrict__ Zs, int row, int cb, int wr, int wc, int fr, int fk) {
-    double av[4], mv[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        av[it] = Ap[row + (size_t)(cb + it * 16) * NP];
-        mv[it] = Mk[row + (size_t)(cb + it * 16) * NB];
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        stage[row * LDT + cb + it * 16] = av[it];
-        Ms[row * LDT + cb + it * 16] = mv[it];           // Ms[c][k] = M[c][k]
-    }
-    lds_barrier();
-    // Z[i][c] = sum_k A[i][k] M[c][k]: the fragment sequence of the tile product with (Ms, stage) in the places of (Ys, Zs); this lane receives
-    // Z(i = 16 wr + fr, c = 16 wc + fk + 4 r)
-    const v4d z = frag_product((unsigned)(uintptr_t)(stage + (wr * 16 + fr) * LDT + fk), (unsigned)(uintptr_t)(Ms + (wc * 16 + fr) * LDT + fk));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Zs[(wr * 16 + fr) * LDT + wc * 16 + fk + 4 * r] = z[r];
-    lds_barrier();                        // Z visible; every read of `stage` / Ms is done (they are refilled next)
-}
 // ONE grid dimension over all instances of the launch.  Workgroup w runs on XCD w % 8 (dispatch order; used for speed only); the first bt.n
 // workgroups take tile 0 of one instance each (and then its diagonal block), the others share the remaining (instance, tile) pairs so that every XCD
 // owns a CONTIGUOUS eighth of the instance-major, tile-row-major list and every workgroup of that XCD a contiguous run of it: what runs
@@ -434,12 +117,8 @@ __device__ __forceinline__ void form_Z(const double* __restrict__ Ap, int NP, co
 template <int MODE>
 __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int nx, int k0, int ntiles, int tb, double* __restrict__ S, double* __restrict__ Minv,
                                                          double* __restrict__ Dx, double* __restrict__ Tinv, int* __restrict__ icount,
-                                                         unsigned long long* __restrict__ hprog = nullptr, unsigned long long ptag = 0, unsigned* __restrict__ tready = nullptr,
-                                                         unsigned tval = 0) {
+                                                         unsigned long long* __restrict__ hprog = nullptr, unsigned long long ptag = 0) {
     constexpr int NH = MODE == 2 ? 2 : 1;   // panels per pass
-    // tready != nullptr (one instance, MODE 0): the DECOUPLED schedule (k_ldl_chain below).  Tile 0 — the next diagonal block — belongs to the persistent chain
-    // workgroup; workgroup 0 of this launch takes tiles 1 and 2 instead (the raw panel rows and the diagonal tile the chain needs NEXT), stores them, releases them
-    // (agent scope) and raises tready = tval; the other workgroups share the tiles from 3 on.  The host queues the launch once the chain has published M of this panel.
     // progress word for the host (mapped memory; launch_ldl): this step has started, so everything the steps before it wrote is complete
     if (hprog && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hprog, ptag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __shared__ double smem[step_lds_doubles(NH)];
@@ -462,16 +141,14 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
         const int nz = bt.n, W = (int)gridDim.x, lin = (int)blockIdx.x;
         if (lin < nz) {
             off = bt.delta[lin];
-            if (tready) { if (ntiles < 2) return; item = 0; item_end = ntiles - 1 < 2 ? ntiles - 1 : 2; t = 1; }
         } else {
             if (ntiles < 2) return;
             const int k = lin & 7;
             const int first = nz + ((k - (nz & 7) + 8) & 7);              // first worker of this XCD (the host grid holds one for every XCD)
             const int u = (lin - first) >> 3, Uk = (W - 1 - first) / 8 + 1;
-            const long long lead = tready ? 2 : 0;                        // (decoupled: the first two items are workgroup 0's)
-            const long long G = (long long)nz * (ntiles - 1) - lead;
+            const long long G = (long long)nz * (ntiles - 1);
             if (G <= 0) return;
-            const long long lo = lead + (long long)k * G / 8, hi = lead + (long long)(k + 1) * G / 8;
+            const long long lo = (long long)k * G / 8, hi = (long long)(k + 1) * G / 8;
             const long long chunk = (hi - lo + Uk - 1) / Uk;
             item = lo + (long long)u * chunk; item_end = item + chunk < hi ? item + chunk : hi;
             if (item >= item_end) return;
@@ -593,16 +270,6 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
 #pragma unroll
         for (int r = 0; r < 4; ++r) (S + (i0 + (size_t)j0 * NP))[offC + 4 * r * NP] = cS[r];
         if (!more) {
-            if (tready && blockIdx.x == 0) {
-                // hand-over to the chain workgroup (another CU, possibly another XCD): every wave's stores are out (__syncthreads waits for them), ONE lane
-                // releases at agent scope, then the flag (MI355X_MICROARCH.md: plain stores -> barrier -> release fence -> asm wait -> relaxed agent flag)
-                __syncthreads();
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(tready, tval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
             return;
         }
         t = tn; i0 = in0; j0 = jn0; newrow = nextrow;
@@ -615,113 +282,6 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
 #ifdef CALIPSO_LDL_TRACE
         ++bulk_tile;
 #endif
-    }
-}
-
-// ---- the DECOUPLED schedule (experiment, off unless CALIPSO_HIP_LDL_DECOUPLED=1): one persistent workgroup carries the pivot chain through ALL panels ------------
-// In the launch-per-panel schedule the chain workgroup of launch k cannot start before launch k - 1 has ended everywhere (kernel boundary: 2.4 us on the chain
-// every 64 pivots, then a cold read of M_k and of the two tiles it needs).  Here the chain is ONE launch that never ends between panels (k_ldl_chain, on the
-// handle's main stream); the trailing updates are launches of k_ldl_step<0> (tready mode) on a second stream, queued by the host — which only waits for the
-// factorisation anyway — as soon as the chain has published the M_k they apply:
-//     chain, panel k:   tiles P = (k+1, k), Q = (k+1, k+1) of update k - 1  (flag tready, raised by workgroup 0 of that update after its first two tiles)
-//                       ->  Q -= P M_k P'  (M_k from LDS, where the previous panel left it)  ->  64 pivots, X, M_{k+1} (diag_block)  ->  release, "M_{k+1} is there"
-//     host:             sees M_k  ->  queues update k, whose workgroup 0 takes tiles (k+2, k+1), (k+2, k+1) FIRST, releases them and raises tready
-// Hand-overs follow MI355X_MICROARCH.md: plain stores -> barrier -> ONE agent-scope release -> flag; reader: ONE relaxed poll -> ONE agent-scope acquire -> barrier
-// -> plain loads.  Every wait is bounded (a chain that is not served stores the failure tag and leaves; the factorisation is reported as failed), and the streams
-// are probed once per handle for distinct hardware queues (a chain whose updates sit behind it in its own queue would never be served).
-// MEASURED (C3, profiles/r04_decoupled_chain_timeline.txt): the same arithmetic and the same bits, 0.82-0.85 ms per chain against 0.835 for the launch-per-panel
-// schedule — the release (1.7 us) and the poll + acquire (1.7 us) on the chain cost what the kernel boundary did, and the two tiles the chain waits for come out
-// of a relay (publish -> host -> launch -> two tile updates -> release -> acquire -> cold loads: ~20 us) that is as long as a panel of the chain itself.
-// A second form — updates queued ahead of time and gated on a device word, write-through hand-overs without fences, the next tiles prefetched under the previous
-// block's last phases — brought the chain's own work to 17.7 us per panel (from 21.0) and lost it again waiting 7 - 28 us per panel for the relay; it is not kept.
-constexpr unsigned CHAIN_FAIL = 0xffffu;
-__device__ __forceinline__ bool wait_word(const unsigned* p, unsigned target, unsigned maxspins) {
-    for (unsigned spins = 0; spins < maxspins; ++spins) {
-        if ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return true;      // (wrap-safe; every lane reads the same word)
-        __builtin_amdgcn_s_sleep(8);
-    }
-    return false;
-}
-__global__ __launch_bounds__(TR_THREADS) void k_ldl_chain(int NP, int nx, int nblk, int tb, double* __restrict__ S, double* __restrict__ Minv, double* __restrict__ Dx,
-                                                           double* __restrict__ Tinv, int* __restrict__ icount, const unsigned* __restrict__ tready, unsigned tbase,
-                                                           unsigned long long* __restrict__ hchain, unsigned long long epoch, int* __restrict__ hcount,
-                                                           unsigned long long* __restrict__ hseq, unsigned long long seq) {
-    __shared__ double smem[step_lds_doubles(1)];
-    __shared__ double Mkeep[NB * LDT];
-    __shared__ int dead;
-    double* Zs = smem;
-    double* Ys = smem + TT * LDT;
-    if (threadIdx.x == 0) dead = 0;
-    __syncthreads();
-#pragma unroll 1
-    for (int k = -1; k + 1 < nblk; ++k) {
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));         // (opaque per panel: what is derived from the lane index is formed here, not hoisted out of the loop and held across diag_block)
-        const int lane = tid & 63, wave = tid >> 6;
-        const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fk = lane >> 4;
-        const int row = (lane & 7) + 8 * ((lane >> 4) & 1) + 16 * (wave & 3);
-        const int cb = ((lane >> 3) & 1) + 2 * ((lane >> 5) & 1) + 4 * (wave >> 2);
-        const int k0 = k * NB, r0 = k0 + NB;
-        const int offC = (wr * 16 + fr) + (wc * 16 + fk) * NP, offY = row + cb * NP;
-        double cS[4];
-        if (k < 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cS[r] = wr >= wc ? S[offC + 4 * r * NP] : 0.0;
-        } else {
-            // update k - 1's first two tiles (k = 0: they are the Schur complement's own): wave 0 waits for the word and acquires, the others follow behind the barrier
-            if (k > 0) {
-                if (wave == 0) {
-                    if (!dead && !wait_word(tready, tbase + (unsigned)k, 1u << 19)) dead = 1;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                __syncthreads();
-            }
-            LDL_STAMP(r0 / NB, 0);
-            double pn[4];
-            const double* Qp = S + ((size_t)r0 + (size_t)r0 * NP);
-            const double* Pp = S + ((size_t)r0 + (size_t)k0 * NP);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cS[r] = Qp[offC + 4 * r * NP];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) pn[it] = Pp[offY + it * 16 * NP];
-            // Ys <- P (rows of the raw panel: both operands of this tile), Z = P M_k -> Zs, Q -= Z P'
-#pragma unroll
-            for (int it = 0; it < 4; ++it) Ys[row * LDT + cb + it * 16] = pn[it];
-            lds_barrier();
-            const v4d z = frag_product((unsigned)(uintptr_t)(Ys + (wr * 16 + fr) * LDT + fk), (unsigned)(uintptr_t)(Mkeep + (wc * 16 + fr) * LDT + fk));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Zs[(wr * 16 + fr) * LDT + wc * 16 + fk + 4 * r] = z[r];
-            lds_barrier();
-            LDL_STAMP(r0 / NB, 1);
-            const v4d acc = frag_product((unsigned)(uintptr_t)(Zs + (wr * 16 + fr) * LDT + fk), (unsigned)(uintptr_t)(Ys + (wc * 16 + fr) * LDT + fk));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cS[r] -= acc[r];
-            lds_barrier();
-        }
-        diag_block(smem, (v4d){cS[0], cS[1], cS[2], cS[3]}, NP, nx, r0, tb, S, Dx, Tinv, Minv, icount, Mkeep);
-        // M_{k+1} (and block k + 1's D, L, X) are stored: release, then tell the host, which queues update k + 1 (the last update with tiles of its own is nblk - 3).
-        // The LAST wave publishes, so that wave 0 is free to poll for the next tiles meanwhile
-        if (k + 3 < nblk) {
-            __syncthreads();                              // every wave's stores are out
-            if (tid == TR_THREADS - 64) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(hchain, epoch | (unsigned long long)(k + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
-    // the factor is complete: the six inertia counts go to their mapped host words (the three of the constraint part were counted before this launch), then the
-    // sequence number do_factorize waits for, then the chain's last tag (or the failure tag)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (hcount) {
-            for (int i = 0; i < 6; ++i) hcount[i] = __hip_atomic_load(icount + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        __hip_atomic_store(hchain, epoch | (dead ? (unsigned long long)CHAIN_FAIL : (unsigned long long)nblk), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1044,7 +604,8 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     const Batch bt = batch_of(s).b;
     const unsigned nz = bt.n;
     double* Minv = s->Ypanel;           // NP x 64: M_k of every panel (the buffer held round 2's unscaled panels)
-    hipLaunchKernelGGL(k_ldl_diag, dim3(1, 1, nz), dim3(DIAG_THREADS), 0, s->stream, bt, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, Minv, s->icount);
+    const bool lfac = lfac_ready(s);      // one dense system alone: the left-looking schedule of lfac.hip (the same chain, the Schur complement's products under it)
+    if (!lfac) hipLaunchKernelGGL(k_ldl_diag, dim3(1, 1, nz), dim3(DIAG_THREADS), 0, s->stream, bt, NP, s->d.nx, 0, tb, s->S, s->Dx, s->Tinv, Minv, s->icount);
     const int band = s->band64 > 0 ? s->band64 : nblk;     // 64-row blocks below a diagonal block that can be non-zero (structure.hip)
     // persistent workgroups: one is resident per CU (registers, LDS): 248 workers + the workgroups that carry the diagonal blocks = everything resident
     // at once, 31 + 1 per XCD for one instance.  Since round 3's diagonal block (19 us) the early launches of ONE instance are bound by the trailing update,
@@ -1067,7 +628,8 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     int launches = 1;
     unsigned long long* const hprog = overlap ? s->hprog_dev : (unsigned long long*)nullptr;
     const unsigned long long epoch = s->ldl_epoch << 16;         // progress word = epoch | first panel the launch applies: every panel before it is released
-    for (int kb = 0; kb + 1 < nblk;) {
+    if (lfac) launches = lfac_enqueue(s, hprog, epoch);
+    for (int kb = 0; !lfac && kb + 1 < nblk;) {
         const int k0 = kb * NB;
         const int rows = std::min(NP - k0 - NB, band * NB);  // banded S: the panel and its trailing update stop at the band
         const int ntr = rows / TT;
@@ -1125,7 +687,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
     }
     if (nblk > 1) {
         const int maxrows = std::min(NP - NB, band * NB);
-        hipLaunchKernelGGL(k_ldl_scale, dim3(maxrows / 64, nblk - 1, nz), dim3(1024), 0, s->stream, bt, NP, tb, band * NB, 0, s->S, s->Dx, s->Tinv);
+        hipLaunchKernelGGL(k_ldl_scale, dim3(maxrows / 64, nblk - 1, nz), dim3(1024), 0, s->stream, bt, NP, tb, band * NB, 0, s->S, s->Lf, s->Dx, s->Tinv);
     }
     const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
     for (int level = 1; level <= 5; ++level) {
@@ -1133,8 +695,8 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
         if (2 * half > tb) break;
         static const bool merge64 = [] { const char* e = getenv("CALIPSO_HIP_MERGE64"); return e && atoi(e) != 0; }();
         for (int phase = 0; phase < 2; ++phase) {
-            if (merge64) hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles, 1, nz), dim3(1024), mg_lds, s->stream, bt, NP, tb, half, phase, s->S, s->Tinv, s->Ttmp);
-            else hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles * 4, 1, nz), dim3(256), 0, s->stream, bt, NP, tb, half, phase, 0, s->S, s->Tinv, s->Ttmp);
+            if (merge64) hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles, 1, nz), dim3(1024), mg_lds, s->stream, bt, NP, tb, half, phase, s->Lf, s->Tinv, s->Ttmp);
+            else hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles * 4, 1, nz), dim3(256), 0, s->stream, bt, NP, tb, half, phase, 0, s->Lf, s->Tinv, s->Ttmp);
         }
     }
     if (wform_on(s)) for (int kb = 0; kb * tb < NP; ++kb) enqueue_wform(s, s->stream, kb);
@@ -1162,7 +724,7 @@ static size_t merge_scratch(int NP, int half) { return (size_t)NP * (size_t)(hal
 static void enqueue_merge(calipso_hip_solver* s, hipStream_t stream, int half, int phase, int pair0, int pairs) {
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), tiles = half / 32;
     const Batch bt = batch_of(s).b;
-    hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles, 1, bt.n), dim3(256), 0, stream, bt, NP, tb, half, phase, pair0, s->S, s->Tinv, s->Ttmp + merge_scratch(NP, half));
+    hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles, 1, bt.n), dim3(256), 0, stream, bt, NP, tb, half, phase, pair0, s->Lf, s->Tinv, s->Ttmp + merge_scratch(NP, half));
 }
 // workgroups of the W-form product beside the chain (k_wform_product64): it is handed over once the trailing update has shrunk enough to leave them their compute units
 static const int WFORM_WGS = [] { const char* e = getenv("CALIPSO_HIP_WFORM_WGS"); const int v = e ? atoi(e) : 128; return v >= 8 && v <= 240 ? v : 128; }();
@@ -1197,7 +759,7 @@ static void enqueue_feed(calipso_hip_solver* s, hipStream_t stream, int i, bool 
     const int k0 = arg * tb, w = std::min(tb, NP - k0), rb = NP - k0 - w;
     const Batch bt = batch_of(s).b;
     const int rows = wform_rows(s, rb);
-    hipLaunchKernelGGL(k_wform_product64, dim3(std::min(WFORM_WGS, (rows / 64) * (w / 64)), 1, bt.n), dim3(1024), 0, stream, bt, NP, tb, arg, w, rb, rows, s->S, s->Tinv, s->Wfac + wform_offset(NP, tb, arg));
+    hipLaunchKernelGGL(k_wform_product64, dim3(std::min(WFORM_WGS, (rows / 64) * (w / 64)), 1, bt.n), dim3(1024), 0, stream, bt, NP, tb, arg, w, rb, rows, s->Lf, s->Tinv, s->Wfac + wform_offset(NP, tb, arg));
 }
 static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f) {
     const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
@@ -1206,7 +768,7 @@ static void enqueue_finish_feed(calipso_hip_solver* s, hipStream_t stream, int f
     const int c0 = s->ldl_ranges[2 * f], w = s->ldl_ranges[2 * f + 1];
     const int b0 = c0 / tb * tb, wblk = std::min(tb, NP - b0);
     const int p0 = c0 / NB, np = std::min(w / NB, nblk - 1 - p0);                     // (the last panel has no rows below it)
-    if (np > 0) hipLaunchKernelGGL(k_ldl_scale, dim3((NP - p0 * NB - NB) / 64, np, nz), dim3(1024), 0, stream, bt, NP, tb, NP, p0, s->S, s->Dx, s->Tinv);
+    if (np > 0) hipLaunchKernelGGL(k_ldl_scale, dim3((NP - p0 * NB - NB) / 64, np, nz), dim3(1024), 0, stream, bt, NP, tb, NP, p0, s->S, s->Lf, s->Dx, s->Tinv);
     for (int half = 64; 2 * half <= w; half *= 2)
         for (int phase = 0; phase < 2; ++phase) enqueue_merge(s, stream, half, phase, c0 / (2 * half), w / (2 * half));
     int rel = c0 - b0;
@@ -1496,7 +1058,7 @@ static void enqueue_wform(calipso_hip_solver* s, hipStream_t stream, int kb) {
     if (rb <= 0) return;
     const Batch bt = batch_of(s).b;
     const int rows = wform_rows(s, rb);
-    hipLaunchKernelGGL(k_wform_product, dim3((rows / 32) * (w / 32), 1, bt.n), dim3(256), 0, stream, bt, NP, tb, kb, w, rb, rows, s->S, s->Tinv, s->Wfac + wform_offset(NP, tb, kb));
+    hipLaunchKernelGGL(k_wform_product, dim3((rows / 32) * (w / 32), 1, bt.n), dim3(256), 0, stream, bt, NP, tb, kb, w, rb, rows, s->Lf, s->Tinv, s->Wfac + wform_offset(NP, tb, kb));
 }
 static void enqueue_trsv_wform(calipso_hip_solver* s, double* x) {
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), nb = (NP + tb - 1) / tb;
@@ -1553,10 +1115,10 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
         // and 0.73 - 0.75 with 8 rows or 16 / 64 columns per thread.
         if (w > 512) {                                                                        // (a block with rows below it is tb = 512, 1024 or 2048 wide)
             hipLaunchKernelGGL((k_trsv_block_n<16, 32, 32>), dim3(w / 16, 1, nz), dim3(512), 0, s->stream, bt, kb, tb, w, s->Tinv, x, s->Dx, u, z);
-            if (rest > 0) hipLaunchKernelGGL((k_trsv_update_n<16, 32, 32>), dim3(rest / 16, 1, nz), dim3(512), 0, s->stream, bt, NP, k0, w, s->S, u, x);
+            if (rest > 0) hipLaunchKernelGGL((k_trsv_update_n<16, 32, 32>), dim3(rest / 16, 1, nz), dim3(512), 0, s->stream, bt, NP, k0, w, s->Lf, u, x);
         } else {
             hipLaunchKernelGGL((k_trsv_block_n<16, 16, 32>), dim3(w / 16, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, s->Tinv, x, s->Dx, u, z);
-            if (rest > 0) hipLaunchKernelGGL((k_trsv_update_n<16, 16, 32>), dim3(rest / 16, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, s->S, u, x);
+            if (rest > 0) hipLaunchKernelGGL((k_trsv_update_n<16, 16, 32>), dim3(rest / 16, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, s->Lf, u, x);
         }
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
@@ -1565,8 +1127,8 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
         else hipLaunchKernelGGL(k_trsv_block_t<1024>, dim3(w / 4, 1, nz), dim3(256), 0, s->stream, bt, kb, tb, w, s->Tinv, z, x);
         if (kb > 0) {
             const int cfirst = s->band64 > 0 ? std::max(0, ((k0 - s->half_bandwidth) / 4) * 4) : 0;   // columns left of the block that reach into it
-            if (w > 1024) hipLaunchKernelGGL(k_trsv_update_t<2048>, dim3((k0 - cfirst) / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, cfirst, s->S, x, z);
-            else hipLaunchKernelGGL(k_trsv_update_t<1024>, dim3((k0 - cfirst) / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, cfirst, s->S, x, z);
+            if (w > 1024) hipLaunchKernelGGL(k_trsv_update_t<2048>, dim3((k0 - cfirst) / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, cfirst, s->Lf, x, z);
+            else hipLaunchKernelGGL(k_trsv_update_t<1024>, dim3((k0 - cfirst) / 4, 1, nz), dim3(256), 0, s->stream, bt, NP, k0, w, cfirst, s->Lf, x, z);
         }
     }
 }
@@ -1608,121 +1170,6 @@ void ldl_drop_graphs(calipso_hip_solver* s) {       // the captured launch seque
     s->graph_ldl_tried = false; s->graph_ldl_fin_tried = false; s->graph_trsv_tried = false;
 }
 
-// The decoupled schedule (k_ldl_chain): one instance alone, dense S, the two-stream finish available; CALIPSO_HIP_LDL_DECOUPLED=1 turns it on.
-static bool ldl_decoupled(calipso_hip_solver* s) {
-    static const int env = [] { const char* e = getenv("CALIPSO_HIP_LDL_DECOUPLED"); return e ? atoi(e) : 0; }();     // an experiment (see k_ldl_chain): off unless asked for
-    return env && !s->cur && s->decoupled_ok >= 0 && ldl_overlap(s) && s->d.NP / NB >= 8;
-}
-// A kernel that waits for work of ANOTHER stream needs that stream on another hardware queue: HIP multiplexes streams onto a few queues, and a chain whose updates
-// sit behind it in its own queue would never be served.  Probed once per handle: a kernel on the first stream waits (bounded, ~80 ms at most) for a word that a
-// kernel on the second stream sets.
-__global__ void k_probe_wait(unsigned* __restrict__ flag, unsigned* __restrict__ out) {
-    unsigned seen = 2;
-    for (unsigned spins = 0; spins < (1u << 16); ++spins) {
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { seen = 1; break; }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    out[0] = seen;
-}
-__global__ void k_probe_set(unsigned* __restrict__ flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static bool streams_concurrent(calipso_hip_solver* s, hipStream_t waiting, hipStream_t serving) {
-    unsigned* words = reinterpret_cast<unsigned*>(s->vtmp);              // [0] flag [1] result (scratch of the handle; nothing else runs on it now)
-    unsigned host[2] = {0u, 0u};
-    if (hipMemcpyAsync(words, host, sizeof host, hipMemcpyHostToDevice, waiting) != hipSuccess || hipStreamSynchronize(waiting) != hipSuccess) return false;
-    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, waiting, words, words + 1);
-    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, serving, words);
-    if (hipStreamSynchronize(serving) != hipSuccess || hipStreamSynchronize(waiting) != hipSuccess) return false;
-    if (hipMemcpy(host, words, sizeof host, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    return host[1] == 1u;
-}
-static bool worker_stream(calipso_hip_solver* s) {
-    if (s->stream3) return true;
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
-    if (hipStreamCreateWithPriority(&s->stream3, hipStreamNonBlocking, greatest) != hipSuccess) { s->stream3 = nullptr; return false; }
-    if (hipEventCreateWithFlags(&s->ev_worker, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(s->stream3); s->stream3 = nullptr; s->ev_worker = nullptr; return false; }
-    return true;
-}
-// returns false when the schedule is not available (the caller takes the launch-per-panel one); on a chain that was not served sets s->ldl_failed
-static bool launch_ldl_decoupled(calipso_hip_solver* s) {
-    if (!side_stream(s) || !worker_stream(s)) return false;
-    if (s->decoupled_ok == 0) {          // first use: the chain (main stream) must run beside its updates and beside the finish
-        s->decoupled_ok = streams_concurrent(s, s->stream, s->stream3) && streams_concurrent(s, s->stream, s->stream2) ? 1 : -1;
-        if (s->decoupled_ok < 0) return false;
-    }
-    if (!s->chain_flags) {               // the flag word, in fine-grained (XCD-coherent) device memory
-        if (hipExtMallocWithFlags((void**)&s->chain_flags, 256, hipDeviceMallocFinegrained) != hipSuccess) { s->chain_flags = nullptr; s->decoupled_ok = -1; return false; }
-        if (hipMemset(s->chain_flags, 0, 256) != hipSuccess) { s->decoupled_ok = -1; return false; }
-    }
-    const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
-    const Batch bt = batch_of(s).b;
-    double* Minv = s->Ypanel;
-    s->ldl_overlap_on = true;
-    ldl_plan_ranges(s);
-    s->ldl_epoch += 1;
-    const unsigned long long epoch = s->ldl_epoch << 16;
-    const unsigned tbase = (unsigned)(s->ldl_epoch << 8);
-    unsigned* const tready = s->chain_flags;          // update k - 1 -> chain: tbase + k = "tiles (k+1, k), (k+1, k+1) are stored"
-    unsigned long long* const hchain = s->hprog + 1;
-    s->ldl_pub_seq = s->ldl_publish ? ++s->pub_seq : 0;
-    hipLaunchKernelGGL(k_ldl_chain, dim3(1), dim3(TR_THREADS), 0, s->stream, NP, s->d.nx, nblk, tb, s->S, Minv, s->Dx, s->Tinv, s->icount, tready, tbase, s->hprog_dev + 1, epoch,
-                       s->ldl_pub_seq ? s->hicount_dev : (int*)nullptr, s->hseq_dev, s->ldl_pub_seq);
-    (void)hipEventRecord(s->ev[14], s->stream);
-    // update kb applies panel kb to the tiles from (kb + 2, kb + 1) on (the last one that has tiles of its own is nblk - 3); the finish of the completed ranges runs
-    // beside the chain as in the launch-per-panel schedule (the updates carry the tags 0 .. nblk - 3)
-    const int resident = 248, last_update = nblk - 3;
-    auto grid = [&](int tiles) { const int workers = std::min(std::max(tiles - 3, 0), resident); return dim3(1 + (workers ? (workers + 7) / 8 * 8 + 7 : 0)); };
-    int forks = 0;
-    while (3 * forks < (int)s->ldl_feeds.size() && s->ldl_feeds[3 * forks] <= last_update) ++forks;
-    int next_update = 0, next_feed = 0;
-    unsigned long long spins = 0;
-    bool failed = false;
-    const auto t_start = std::chrono::steady_clock::now();
-    while (next_update <= last_update || next_feed < forks) {
-        const unsigned long long c = __atomic_load_n(hchain, __ATOMIC_ACQUIRE);
-        if (c == (epoch | (unsigned long long)CHAIN_FAIL)) { failed = true; break; }
-        if (next_update <= last_update && c >= (epoch | (unsigned long long)(next_update + 1)) && (c >> 16) == s->ldl_epoch) {
-            const int kb = next_update, k0 = kb * NB, ntr = (NP - k0 - NB) / TT, ntiles = ntr * (ntr + 1) / 2;
-            hipLaunchKernelGGL((k_ldl_step<0>), grid(ntiles), dim3(TR_THREADS), 0, s->stream3, bt, NP, s->d.nx, k0, ntiles, tb, s->S, Minv, s->Dx, s->Tinv, s->icount,
-                               s->hprog_dev, epoch | (unsigned long long)kb, tready, tbase + (unsigned)kb + 1u);
-            ++next_update; spins = 0;
-            continue;
-        }
-        if (next_feed < forks && __atomic_load_n(s->hprog, __ATOMIC_ACQUIRE) >= (epoch | (unsigned long long)s->ldl_feeds[3 * next_feed])) {
-            enqueue_feed(s, s->stream2, next_feed, true);
-            ++next_feed; spins = 0;
-            continue;
-        }
-        if ((++spins & 0xfffffu) == 0) {                  // nothing moved for a while (~10 ms): is the chain still there?
-            if (hipStreamQuery(s->stream) != hipErrorNotReady) { failed = true; break; }      // it has left (or the queue faulted) with updates / feeds still to hand out
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 20.0) { failed = true; break; }
-        }
-    }
-    s->ldl_step_launches = 1 + next_update;
-    s->ldl_forks = next_feed;
-    (void)hipEventRecord(s->ev_worker, s->stream3);
-    (void)hipStreamWaitEvent(s->stream, s->ev_worker, 0);          // the main stream (the chain) goes on when the last update is through
-    s->decoupled_check = true;                                      // do_factorize looks at the chain's last tag once it has the inertia counts
-    if (failed) {
-        s->err = "LDL^T: the pivot-chain workgroup was not served in time (decoupled schedule)";
-        s->ldl_failed = true;
-        (void)hipStreamSynchronize(s->stream3);
-        (void)hipStreamSynchronize(s->stream2);
-        (void)hipStreamSynchronize(s->stream);
-        s->ldl_pub_seq = 0;
-        s->ldl_forks = (int)s->ldl_feeds.size() / 3;      // nothing more to queue
-    }
-    return true;
-}
-// after the factorisation has been waited for: did the chain end with its last tag?
-bool ldl_chain_ok(calipso_hip_solver* s) {
-    if (!s->decoupled_check) return true;
-    s->decoupled_check = false;
-    const unsigned long long c = __atomic_load_n(s->hprog + 1, __ATOMIC_ACQUIRE);
-    if ((c & 0xffffu) == CHAIN_FAIL && (c >> 16) == s->ldl_epoch) { s->err = "LDL^T: the pivot-chain workgroup was not served in time (decoupled schedule)"; return false; }
-    return true;
-}
-
 // ev[14] marks the end of the panel steps (the pivot chain), so that their duration can be reported apart from the parallel finish
 // (calipso_hip_kernel_times)
 // The right-hand side of the first condensed solve (k_residual_symmetric, then b_x += [gx; hx]'(Omega b_m)) needs the cone pivots, not the factor: do_factorize queues it
@@ -1732,7 +1179,7 @@ hipStream_t ldl_rhs_stream(calipso_hip_solver* s) {
     static const bool env = [] { const char* e = getenv("CALIPSO_HIP_RHS_AHEAD"); return !e || atoi(e) != 0; }();
     static const bool graph_ldl_env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();
     if (!env || s->cur || s->compact || (s->stage_parallel && s->spS) || (s->use_graphs && graph_ldl_env)) return nullptr;
-    if (!ldl_overlap(s) || !side_stream(s) || ldl_decoupled(s)) return nullptr;
+    if (!ldl_overlap(s) || !side_stream(s)) return nullptr;
     return s->stream2;
 }
 
@@ -1755,6 +1202,7 @@ void launch_ldl(calipso_hip_solver* s) {
         s->stage_parallel = false;            // (a group larger than the reserved batch: back to the blocked factorisation)
         launch_pad_identity(s);               // launch_schur skipped the padding of S for the multifrontal path: the blocked one needs its unit pivots
     }
+    s->Lf = lfac_factor_buffer(s);        // where this factorisation's factor columns go: S (scaled in place) or, under the left-looking schedule, lfac.hip's buffer
     ldl_set_attributes();
     // (a group launch covers a changing set of instances: its kernel arguments differ from call to call, so no graph there)
     // The panel steps are queued launch by launch (the host keeps ahead of a 20 us chain: 0.935 ms per factorisation at C3 against 0.950 as a captured graph), which
@@ -1765,10 +1213,6 @@ void launch_ldl(calipso_hip_solver* s) {
     if (ldl_overlap(s)) (void)side_stream(s);       // (created outside a stream capture)
     static const bool pub_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_PUBLISH"); return !e || atoi(e) != 0; }();     // (experiment switch)
     s->ldl_publish = pub_env && !graphs && !s->cur;       // (a captured launch would replay a stale sequence number)
-    if (!graphs && ldl_decoupled(s) && launch_ldl_decoupled(s)) {
-        if (!s->ldl_failed) enqueue_ldl_finish(s);
-        return;
-    }
     s->ldl_epoch += 1;
     if (!graphs || !replay_or_capture(s, s->graph_ldl, s->graph_ldl_tried, [&] { enqueue_ldl_steps(s); })) enqueue_ldl_steps(s);
     (void)hipEventRecord(s->ev[14], s->stream);

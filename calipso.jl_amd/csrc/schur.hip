@@ -557,6 +557,11 @@ void launch_schur(calipso_hip_solver* s) {
     std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_LDS_BYTES); });
     if (blocks_schur(s)) return;          // stage blocks: S by segment pairs from the packed blocks (blocks.hip)
     if (s->hessian_dirty && !s->cur) { launch_symmetrize(s); s->hessian_dirty = false; }   // (a group refreshes its members itself)
+    if (lfac_ready(s)) {                  // one dense system alone: the products are slices of the panel launches (lfac.hip), queued by launch_ldl
+        if (!s->pad_done) launch_pad_identity(s);
+        s->pad_done = false;
+        return;
+    }
     const BatchSc B = batch_of(s);
     const int hb = s->band64 > 0 ? s->half_bandwidth : 0;       // > 0: only the tiles inside the band (structure.hip)
     const int nj = (B.b.n == 1 && hb == 0) ? s->schur_nj : schur_choose(s->d.nx, B.b.n, hb);

@@ -1,4 +1,5 @@
-"""GPU: the schedule of the LDL^T of one instance does not change its bits.  By default the finish of the factorisation (factor columns + merges of the
+"""GPU: the schedule of the LDL^T of one instance does not change its bits.  One dense system alone takes the left-looking schedule of csrc/lfac.hip (the products of
+the Schur complement as slices of the panel launches, deferred trailing updates; CALIPSO_HIP_LFAC=0: k_schur + the right-looking panel steps a group takes).  By default the finish of the factorisation (factor columns + merges of the
 inverse blocks) of the completed solve blocks runs on a second stream while the pivot chain goes on, fed by the host from a progress word, and the
 inertia counts are published right behind the chain (csrc/ldl.hip: launch_ldl); CALIPSO_HIP_LDL_OVERLAP=0 / CALIPSO_HIP_LDL_PUBLISH=0 /
 CALIPSO_HIP_GRAPH_LDL=1 select the one-stream schedules.  The switches are read once per process, so every variant runs in a process of its own;
@@ -48,8 +49,9 @@ def run_variant(env):
 
 def test_newton_steps_do_not_depend_on_the_schedule_of_the_factorisation():
     ref = run_variant({})
-    for env in ({"CALIPSO_HIP_LDL_OVERLAP": "0"}, {"CALIPSO_HIP_LDL_PUBLISH": "0"}, {"CALIPSO_HIP_GRAPH_LDL": "1"}, {"CALIPSO_HIP_LDL_FEED": "64"},
-                {"CALIPSO_HIP_LDL_DECOUPLED": "1"},       # the persistent chain workgroup (k_ldl_chain: an experiment, off by default): same arithmetic, same bits
+    for env in ({"CALIPSO_HIP_LFAC": "0"},                # k_schur + the right-looking panel steps instead of the left-looking schedule of csrc/lfac.hip: the same operations per entry in the same order
+                {"CALIPSO_HIP_LFAC": "0", "CALIPSO_HIP_LDL_OVERLAP": "0"},
+                {"CALIPSO_HIP_LDL_OVERLAP": "0"}, {"CALIPSO_HIP_LDL_PUBLISH": "0"}, {"CALIPSO_HIP_GRAPH_LDL": "1"}, {"CALIPSO_HIP_LDL_FEED": "64"},
                 {"CALIPSO_HIP_WFORM_WGS": "64"},
                 {"CALIPSO_HIP_RHS_AHEAD": "0"}):          # the operands of the first condensed solve on the main stream behind the factorisation instead of on the second stream beside k_schur
         assert run_variant(env) == ref, env
