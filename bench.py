@@ -489,13 +489,15 @@ def main():
         """a SECOND, untimed-for-the-headline region of K steps in which the handle's HIP-event phase times are read after every step (the queries
         synchronise on the events: they do not belong between the steps of the timed region)"""
         sch, ldl, chain, sd, tot, cw, mv = [], [], [], [], [], [], []
+        kt_ = np.zeros(8)
         for _ in range(K):
             wl.single.newton_step(advance=False)
             pt_ = wl.single.phase_times()
             kt_ = wl.single.kernel_times()
             sch.append(pt_[7]); ldl.append(pt_[3]); sd.append(pt_[2]); tot.append(pt_[6]); cw.append(pt_[1])
             chain.append(kt_[0]); mv.append(kt_[4])
-        return dict(schur=sch, ldl=ldl, chain=chain, sd=sd, total=tot, cone=cw, matvec=mv)
+        # (read here: later the handle is the base of a group and its figures are the group's) [1] launches of the panel steps, [6] left-looking schedule, [7] its buffers
+        return dict(schur=sch, ldl=ldl, chain=chain, sd=sd, total=tot, cone=cw, matvec=mv, kt=[float(v) for v in kt_])
 
     # =================================================================== headline workload ======================================
     wl = Workload(pkg, pr, args.config, rank, world, local_rank, args.batch, args.group, args.lanes, args.dense_structure, args.no_stage_parallel, args.no_stage_blocks, args.dense_buffers)
@@ -572,7 +574,7 @@ def main():
     flops_ldl = nx ** 3 / 3.0
     n_ldl_launch = max(1, NP // 64 - 1)
     pmc = {}
-    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name
@@ -602,12 +604,20 @@ def main():
         e["frac"] = e["achieved"] / FP64_MFMA_PEAK_TFLOPS
         return e
     K_LDL = "k_ldl_step (LDL^T of the nx x nx Schur complement S, one launch per 64 pivots: trailing update on v_mfma_f64_16x16x4_f64, its first workgroup factors the next diagonal block)"
+    K_LFAC = ("k_lfac (one dense system alone: the left-looking schedule of csrc/lfac.hip — every launch = the pivot chain's workgroup for one 64-pivot panel + 255 workers on "
+              "slices of S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx) and on the deferred trailing updates, v_mfma_f64_16x16x4_f64; flops = Schur complement + nx^3/3)")
     K_SCH = "k_schur (S = Lxx + eps*I + omega*gx'gx + hx'(Omega hx), v_mfma_f64_16x16x4_f64)"
     cands = []
     if ph is not None:
         step_ms = float(np.mean(ph["total"]))
-        cands = [entry(K_LDL, flops_ldl, n_ldl_launch, float(np.mean(ph["chain"])), 1, "single", "calipso::k_ldl_step", step_ms),
-                 entry(K_SCH, flops_schur, 1, float(np.mean(ph["schur"])), 1, "single", "calipso::k_schur", step_ms)]
+        kt_single = ph["kt"]
+        if kt_single[6] > 0:      # the Schur complement's products are slices of the panel launches: ONE kernel carries both (calipso_hip_kernel_times [6])
+            cands = [entry(K_LFAC, flops_schur + flops_ldl, max(1, int(kt_single[1])), float(np.mean(ph["chain"])), 1, "single", "calipso::k_lfac", step_ms)]
+            cands[0]["flops_schur"] = flops_schur; cands[0]["flops_ldl"] = flops_ldl
+            cands[0]["schedule_buffers_bytes"] = kt_single[7]
+        else:
+            cands = [entry(K_LDL, flops_ldl, n_ldl_launch, float(np.mean(ph["chain"])), 1, "single", "calipso::k_ldl_step", step_ms),
+                     entry(K_SCH, flops_schur, 1, float(np.mean(ph["schur"])), 1, "single", "calipso::k_schur", step_ms)]
     grp = None
     if alone:
         al = np.mean(np.asarray(alone), axis=0)
@@ -633,7 +643,7 @@ def main():
         roof["secondary"].append({"kernel": "k_gemv_t2_and_n (refinement residual: [gx; hx]'(v_yz, Omega b_m) and Lxx v_x in one pass)", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
                                   "achieved": mv_bytes / (mv_ms * 1e-3) * 1e-9, "frac": mv_bytes / (mv_ms * 1e-3) * 1e-9 / 8000.0, "bytes_per_launch": mv_bytes, "avg_launch_ms": mv_ms,
                                   "launches_per_step": 1 + int(single_infos[-1]["refinement_rounds"]), "traffic": pmc_traffic("single", "calipso::k_gemv_t2_and_n")})
-    roof["dominance"] = ("the kernel with the largest share of the headline step among all kernels (profiles/r04_kernel_stats_single.csv lists every kernel); "
+    roof["dominance"] = ("the kernel with the largest share of the headline step among all kernels (profiles/r05_kernel_stats_single.csv lists every kernel); "
                          "HIP-event durations of this run")
     roof["peak_measured"] = peak_measured
     roof["peak_note"] = ("peak = datasheet fp64 matrix rate (not tabulated in MI355X_MICROARCH.md); peak_measured = calipso_hip_mfma_f64_peak in this run; "

@@ -14,7 +14,7 @@ head = float(a[4]) if len(a) > 4 else 0.0
 NP = (nx + 511) // 512 * 512 if nx > 512 else nx
 out = np.zeros(6 * 256)
 n = f(NP // 64, nx, ne, nc, budget, head, out.ctypes.data, 256)
-print("nx %d ne %d nc %d NP %d budget %.1f us (0: the library's scan; chosen %.1f): %d launches" % (nx, ne, nc, NP, budget, out[6 * 255], n))
+print("nx %d ne %d nc %d NP %d budget %.1f us (0: the library's scan; chosen budget %.1f margin %d): %d launches" % (nx, ne, nc, NP, budget, out[6 * 255], int(out[6 * 255 + 1]), n))
 o = out[:6 * n].reshape(n, 6)
 for l in range(n):
     print("launch %3d  longest worker %6.1f us  items %4d (schur %4d far %4d row %3d)  mean worker %5.1f" % (l - 2, o[l, 0], o[l, 1], o[l, 2], o[l, 3], o[l, 4], o[l, 5]))

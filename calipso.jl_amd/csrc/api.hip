@@ -6,6 +6,7 @@
 #include <array>
 #include <atomic>
 #include <cmath>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +23,19 @@ int check(H* s, hipError_t e, const char* what) {
     snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
     if (s) s->err = buf;
     return CALIPSO_ERR_HIP;
+}
+bool lds_attribute(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, bool> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(kernel, dev);
+    const auto it = done.find(key);
+    if (it != done.end()) return it->second;
+    const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    done[key] = ok;
+    return ok;
 }
 }  // namespace calipso
 
@@ -606,15 +620,15 @@ static int do_inertia_correction(H* s, int64_t* nfact, bool rhs_ahead_ok = false
 }
 
 // refine_follows: the caller goes straight on to a refinement residual of s->step (which = 0 only: the local rows of that residual then come out of the same launch)
-static void do_sds(H* s, int which, double* accumulate = nullptr, bool refine_follows = false) {
+static void do_sds(H* s, int which, double* accumulate = nullptr, bool refine_follows = false, bool use_ahead = false) {      // use_ahead: the caller is do_search_direction, right behind the factorisation that queued the operands ahead
     const double* res = which == 0 ? s->residual : s->residual_error;
     double* st = which == 0 ? s->step : s->step_correction;
-    if (which == 0 && s->rhs_ahead && !s->rhs_joined && s->stream2 && s->ev_side[7]) {      // (a finish that did not join the second stream: join it here)
+    if (which == 0 && s->rhs_ahead && !s->rhs_joined && s->stream2 && s->ev_side[7]) {      // (also when the operands are not used: nothing of the second stream stays in flight)      // (a finish that did not join the second stream: join it here)
         (void)hipEventRecord(s->ev_side[7], s->stream2);
         (void)hipStreamWaitEvent(s->stream, s->ev_side[7], 0);
         s->rhs_joined = true;
     }
-    const bool ready = which == 0 && s->rhs_ahead && s->rhs_joined;      // (do_factorize queued them on the second stream and the factorisation's finish has joined it)
+    const bool ready = use_ahead && which == 0 && s->rhs_ahead && s->rhs_joined;      // (do_factorize queued them on the second stream and the factorisation's finish has joined it)
     s->rhs_ahead = false;
     if (!ready) launch_residual_symmetric(s, res);     // b, and the first operands of the condensed solve (xbuf, t1)
     // one launch for t2 = [gx; hx] dx, the back-substitution and the recovery (vectors.hip: k_solve_tail) where the handle allows it (which = 0, no accumulation: its zsx rule)
@@ -693,6 +707,9 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
             s->stats.last_refine = it; s->stats.refine_max = std::max<calipso::i64>(s->stats.refine_max, it);
             return CALIPSO_OK;
         }
+        // a residual with a NaN in it reports +inf (vectors.hip: rabs): the reference's norm is NaN there, its loop condition `norm > tol` false — it leaves as soon
+        // as the minimum number of rounds is done and fails (iterative_refinement.jl:14-16, 45-51)
+        if (!std::isfinite(norm) && it >= o.min_iterative_refinement) break;
         refine_solve(s);                   // step += step_correction fused into the recovery kernel
         refine_residual(s, true);
         if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
@@ -703,15 +720,20 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
     if (rounds) *rounds = it;
     if (final_norm) *final_norm = norm;
     s->stats.last_refine = it; s->stats.refine_max = std::max<calipso::i64>(s->stats.refine_max, it);
-    if (norm <= norm0) return CALIPSO_OK;
+    if (std::isfinite(norm) && norm <= norm0) return CALIPSO_OK;
     s->stats.refine_fail += 1;
     return CALIPSO_WARN_REFINEMENT;
 }
 
 static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
     int rc = do_inertia_correction(s, nfact, true);
-    if (rc < 0) return rc;
-    do_sds(s, 0, nullptr, s->opt.iterative_refinement != 0);
+    if (rc < 0) {
+        // operands queued ahead on the second stream belong to a factorisation that failed: wait for them, forget them (a later solve forms its own)
+        if (s->rhs_ahead && s->stream2) (void)hipStreamSynchronize(s->stream2);
+        s->rhs_ahead = false; s->rhs_joined = false;
+        return rc;
+    }
+    do_sds(s, 0, nullptr, s->opt.iterative_refinement != 0, true);
     if (s->opt.iterative_refinement) {
         rc = do_refinement(s, rounds, nullptr, true);
         if (rc < 0) return rc;
@@ -776,8 +798,8 @@ static int device_evaluate(H* s, const double* pt, uint32_t flags) {
     const uint32_t hess = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
     if (flags & hess) s->hessian_dirty = true;
     if (s->compact) {
-        const bool jz = (flags & (CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE_JACOBIAN)) != 0, hl = (flags & hess) != 0;
-        return (jz || hl) ? blocks_pack_from(s, s->evalL, s->evalZ, hl, jz) : CALIPSO_OK;
+        const bool jg = (flags & CALIPSO_EVAL_EQUALITY_JACOBIAN) != 0 && d.ne > 0, jh = (flags & CALIPSO_EVAL_CONE_JACOBIAN) != 0 && d.nc > 0, hl = (flags & hess) != 0;
+        return (jg || jh || hl) ? blocks_pack_from(s, s->evalL, s->evalZ, hl, jg, jh) : CALIPSO_OK;
     }
     // blocks written behind our back: an analysed stage-banded structure has to be re-checked against them (as set_field does)
     if (structure_active(s) && (flags & hess)) { const int v = structure_validate(s, 0); if (v < 0) return v; }
@@ -1265,6 +1287,7 @@ int32_t calipso_hip_kernel_times(H* s, double out[8]) {
     out[1] = (double)s->ldl_step_launches;              // k_ldl_diag + the k_ldl_step launches the last blocked factorisation queued
     out[2] = (double)s->d.NP;
     out[3] = (double)(s->slab_doubles * sizeof(double));
+    { double lf[8]; calipso::lfac_describe(s, lf); out[6] = s->lfac_last ? 1.0 : 0.0; out[7] = lf[5]; }
     if (s->matvec_timed && hipEventSynchronize(s->ev[6]) == hipSuccess) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s->ev[5], s->ev[6]) == hipSuccess) { out[4] = ms; out[5] = 8.0 * ((double)s->d.m * s->d.nx + (double)s->d.nx * s->d.nx); }

@@ -33,12 +33,13 @@ namespace calipso {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // ---- pack --------------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blocks_pack_z(Batch bt, const ZBlock* __restrict__ blk, int m, const double* __restrict__ Z, double* __restrict__ pk) {
+__global__ __launch_bounds__(256) void k_blocks_pack_z(Batch bt, const ZBlock* __restrict__ blk, int m, const double* __restrict__ Z, double* __restrict__ pk, int rlo = 0, int rhi = 1 << 30) {
     inst_shift(bt, Z, pk);
     const ZBlock b = blk[blockIdx.x];
     const int total = b.nrows * b.ncols;
     for (int idx = threadIdx.x; idx < total; idx += 256) {
         const int i = idx % b.nrows, j = idx / b.nrows;
+        if (b.row0 + i < rlo || b.row0 + i >= rhi) continue;      // (only the rows of the Jacobian that was written: blocks_pack_from)
         const double v = Z[(size_t)(b.row0 + i) + (size_t)(b.col0 + j) * m];
         pk[b.off_c + idx] = v;                                 // column-major, ld = nrows
         pk[b.off_r + (size_t)i * b.ncols + j] = v;             // row-major, ld = ncols
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_schur_blocks(BatchSc bt, Dims d, ConeDe
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------------
 void blocks_release(calipso_hip_solver* s) {
     StageBlocks& B = s->blocks;
-    for (void* p : {(void*)B.d_blk, (void*)B.d_lblk, (void*)B.d_seg, (void*)B.d_segblk, (void*)B.d_pairs, (void*)B.d_pairblk, (void*)B.d_colrange}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)B.d_blk, (void*)B.d_lblk, (void*)B.d_seg, (void*)B.d_segblk, (void*)B.d_pairs, (void*)B.d_pairblk, (void*)B.d_colrange, (void*)B.d_rowcov}) if (p) (void)hipFree(p);
     B = StageBlocks();
 }
 
@@ -287,15 +288,23 @@ void blocks_pack(calipso_hip_solver* s, bool z, bool l) {
 
 // A device evaluator on a structured handle writes the dense ProblemData layout into scratch arrays of the handle (api.hip: device_evaluate); from there the values go
 // into the blocks, and what lies outside the declared structure must be zero: one pass over the dense array per check (the price of a dense interchange format).
-__global__ __launch_bounds__(256) void k_check_z_outside(const ZBlock* __restrict__ blk, int m, int nx, const double* __restrict__ Z, int* __restrict__ flag) {
+__global__ __launch_bounds__(256) void k_check_z_outside(const ZBlock* __restrict__ blk, int m, int nx, const double* __restrict__ Z, int* __restrict__ flag, int rlo, int rhi) {
     const ZBlock b = blk[blockIdx.x];
     const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;
     int bad = 0;
     for (int i0 = 0; i0 < b.nrows; i0 += 64) {
         const int i = i0 + lane;
-        if (i >= b.nrows) continue;
+        if (i >= b.nrows || b.row0 + i < rlo || b.row0 + i >= rhi) continue;
         for (int j = p; j < nx; j += 4) if ((j < b.col0 || j >= b.col0 + b.ncols) && Z[(b.row0 + i) + (size_t)j * m] != 0.0) bad = 1;
     }
+    if (bad) atomicOr(flag, 1);
+}
+// rows of [gx; hx] that NO block covers must be zero altogether (k_check_z_outside only visits the rows of a block)
+__global__ __launch_bounds__(256) void k_check_z_uncovered(const int* __restrict__ rowcov, int m, int nx, const double* __restrict__ Z, int* __restrict__ flag, int rlo, int rhi) {
+    const int r = rlo + (int)blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
+    if (r >= rhi || rowcov[r]) return;
+    int bad = 0;
+    for (int j = p; j < nx; j += 4) if (Z[r + (size_t)j * m] != 0.0) bad = 1;
     if (bad) atomicOr(flag, 1);
 }
 __global__ void k_check_l_outside(int nx, const int* __restrict__ colrange, const double* __restrict__ L, int* __restrict__ flag) {
@@ -304,16 +313,29 @@ __global__ void k_check_l_outside(int nx, const int* __restrict__ colrange, cons
     const int i = (int)(e % nx), j = (int)(e / nx);
     if ((i < colrange[2 * j] || i >= colrange[2 * j + 1]) && L[e] != 0.0) atomicOr(flag, 2);
 }
-int blocks_pack_from(calipso_hip_solver* s, const double* L, const double* Z, bool l, bool z) {
+int blocks_pack_from(calipso_hip_solver* s, const double* L, const double* Z, bool l, bool zg, bool zh) {
     StageBlocks& B = s->blocks;
     if (!B.on) return CALIPSO_ERR_ARGUMENT;
     const Dims& d = s->d;
     const Batch one;
     int* flag = s->icount + 60;
     CK(hipMemsetAsync(flag, 0, sizeof(int), s->stream));
-    if (z && B.nblk) {
-        hipLaunchKernelGGL(k_check_z_outside, dim3(B.nblk), dim3(256), 0, s->stream, B.d_blk, d.m, d.nx, Z, flag);
-        hipLaunchKernelGGL(k_blocks_pack_z, dim3(B.nblk), dim3(256), 0, s->stream, one, B.d_blk, d.m, Z, s->Lsym);
+    // only the rows of the Jacobians the evaluator was asked for are checked and packed (gx: [0, ne), hx: [ne, m)): the others keep what set_field / scatter / an
+    // earlier evaluation put into their blocks
+    const int rlo = zg ? 0 : d.ne, rhi = zh ? d.m : d.ne;
+    if ((zg || zh) && rhi > rlo) {
+        if (!B.d_rowcov) {          // which rows some block covers (host copy of the blocks: once per handle)
+            std::vector<int> cov((size_t)std::max(1, d.m), 0);
+            for (const ZBlock& b : B.h_blk) for (int i = 0; i < b.nrows; ++i) if (b.row0 + i < d.m) cov[b.row0 + i] = 1;
+            CK(hipMalloc((void**)&B.d_rowcov, cov.size() * sizeof(int)));
+            CK(hipMemcpyAsync(B.d_rowcov, cov.data(), cov.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+            CK(hipStreamSynchronize(s->stream));      // (cov leaves scope)
+        }
+        hipLaunchKernelGGL(k_check_z_uncovered, dim3((rhi - rlo + 63) / 64), dim3(256), 0, s->stream, B.d_rowcov, d.m, d.nx, Z, flag, rlo, rhi);
+        if (B.nblk) {
+            hipLaunchKernelGGL(k_check_z_outside, dim3(B.nblk), dim3(256), 0, s->stream, B.d_blk, d.m, d.nx, Z, flag, rlo, rhi);
+            hipLaunchKernelGGL(k_blocks_pack_z, dim3(B.nblk), dim3(256), 0, s->stream, one, B.d_blk, d.m, Z, s->Lsym, rlo, rhi);
+        }
     }
     if (l && B.nlb) {
         if (B.d_colrange) hipLaunchKernelGGL(k_check_l_outside, dim3((unsigned)(((size_t)d.nx * d.nx + 255) / 256)), dim3(256), 0, s->stream, d.nx, B.d_colrange, L, flag);

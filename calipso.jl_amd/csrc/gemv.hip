@@ -211,14 +211,19 @@ __device__ __forceinline__ void gemv_n_partial_body(Batch bt, Sparsity sp, int b
     // active (v_readlane reads a lane's register whether or not the lane is) — and handed out by v_readlane
     const bool xb = c1 - c0 <= 64;
     const int ln = threadIdx.x & 63;
-    const double xr = (xb && c0 + ln < c1) ? x[c0 + ln] : 0.0;
-    if (i >= rows) return;
+    double xr = (xb && c0 + ln < c1) ? x[c0 + ln] : 0.0;
+    asm volatile("" : "+v"(xr));                  // (the chunk of x is in the registers of ALL 64 lanes before any lane stands aside: the load cannot sink below the predicates)
+    // No lane leaves before the end: a lane beyond the last row (or whose row has nothing in this chunk) runs the loop with its loads predicated off, so that
+    // every v_readlane below reads a lane that is still there.
+    const bool inrow = i < rows;
     // columns of row i that can be non-zero (loads outside are predicated off; the summation order is that of the dense kernel)
     int jlo = 0, jhi = cols;
-    if (sp.kind == SP_LXX) { jlo = i - sp.hb; jhi = i + sp.hb + 1; }
-    else if (sp.kind != SP_DENSE) { jlo = sp.rowrange[2 * (row_off + i)]; jhi = sp.rowrange[2 * (row_off + i) + 1]; }
+    if (inrow) {
+        if (sp.kind == SP_LXX) { jlo = i - sp.hb; jhi = i + sp.hb + 1; }
+        else if (sp.kind != SP_DENSE) { jlo = sp.rowrange[2 * (row_off + i)]; jhi = sp.rowrange[2 * (row_off + i) + 1]; }
+    } else { jlo = 0; jhi = 0; }                  // (an empty range: every load of the lane is off)
+    const bool any = inrow && !(sp.kind != SP_DENSE && (c1 <= jlo || c0 >= jhi));      // something of this chunk lies inside the row's range (else its partial sum is an exact 0.0)
     double acc0 = 0.0, acc1 = 0.0;
-    if (sp.kind != SP_DENSE && (c1 <= jlo || c0 >= jhi)) { partial[(size_t)by * rows + i] = 0.0; return; }   // nothing of this chunk is inside the row's range
     auto xat = [&](int j) -> double {          // j is wave-uniform
         if (!xb) return x[j];
         const int l = j - c0;
@@ -226,17 +231,17 @@ __device__ __forceinline__ void gemv_n_partial_body(Batch bt, Sparsity sp, int b
     };
     // batches of 24 loads per lane, all issued before the first use
     for (int j0 = c0; j0 < c1; j0 += 24) {
-        if (sp.kind != SP_DENSE && (j0 + 24 <= jlo || j0 >= jhi)) continue;                                             // (a batch of exact zeros)
+        const bool batch_in = any && (sp.kind == SP_DENSE || !(j0 + 24 <= jlo || j0 >= jhi));                             // (outside: a batch of exact zeros, not added)
         double v[24];
 #pragma unroll
-        for (int q = 0; q < 24; ++q) { const int j = j0 + q; v[q] = (j < c1 && j >= jlo && j < jhi) ? A[i + (size_t)j * ld] : 0.0; }
+        for (int q = 0; q < 24; ++q) { const int j = j0 + q; v[q] = (batch_in && j < c1 && j >= jlo && j < jhi) ? A[i + (size_t)j * ld] : 0.0; }
 #pragma unroll
         for (int q = 0; q < 24; q += 2) {
-            acc0 += v[q] * (j0 + q < c1 ? xat(j0 + q) : 0.0);
-            acc1 += v[q + 1] * (j0 + q + 1 < c1 ? xat(j0 + q + 1) : 0.0);
+            const double x0 = j0 + q < c1 ? xat(j0 + q) : 0.0, x1 = j0 + q + 1 < c1 ? xat(j0 + q + 1) : 0.0;        // (read by every lane, used by those inside)
+            if (batch_in) { acc0 += v[q] * x0; acc1 += v[q + 1] * x1; }
         }
     }
-    partial[(size_t)by * rows + i] = acc0 + acc1;
+    if (inrow) partial[(size_t)by * rows + i] = acc0 + acc1;
 }
 __global__ __launch_bounds__(GN_ROWS) void k_gemv_n_partial(Batch bt, Sparsity sp, int row_off, int rows, int cols, int chunk, const double* __restrict__ A, int ld,
                                                              const double* __restrict__ x, double* __restrict__ partial) {

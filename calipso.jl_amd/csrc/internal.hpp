@@ -139,6 +139,7 @@ struct StageBlocks {
     unsigned long long signature = 0;   // of the block structure (members of a group must share it)
     ZBlock* d_blk = nullptr; LBlock* d_lblk = nullptr; Segment* d_seg = nullptr; int* d_segblk = nullptr; SegPair* d_pairs = nullptr; int* d_pairblk = nullptr;
     int* d_colrange = nullptr;          // per column of Lxx: [first, last + 1) row of its Hessian block (uploads are re-checked against it)
+    int* d_rowcov = nullptr;            // per row of [gx; hx]: covered by some block (blocks_pack_from; made on first use)
     double schur_flops = 0.0;           // multiply-adds x 2 of one k_schur_blocks launch per instance (sum over the segment pairs of the covering blocks' rows x columns x columns)
     std::vector<ZBlock> h_blk; std::vector<LBlock> h_lblk; std::vector<SegPair> h_pairs; std::vector<Segment> h_seg; std::vector<int> h_seg_of_col;   // host copies (uploads of structured handles are packed on the host)
 };
@@ -262,6 +263,7 @@ struct calipso_hip_solver {
     void* scatter_aux = nullptr;  // scatter.hip: registered sparsity patterns of the evaluate! scatter
     void* ldl_aux = nullptr;      // ldlsolver.hip: staging of the caller's CSC matrix (handles made by calipso_hip_ldl_create)
     void* lfac_aux = nullptr;     // lfac.hip: plan and buffers of the left-looking schedule (one dense system alone)
+    bool lfac_last = false;       // the last blocked factorisation took it
     bool lfac_failed = false;     // its buffers could not be had: the handle keeps k_schur + the right-looking panel steps
     double* Lf = nullptr;         // where the factor columns L of the last blocked factorisation live: S (scaled in place) or lfac.hip's buffer
     double* Hdense = nullptr; int* lu_ipiv = nullptr;   // fallback.hip: N x N unreduced matrix and pivots (allocated on first use)
@@ -367,7 +369,7 @@ void launch_pad_identity(calipso_hip_solver* s);
 // then takes the dense-layout kernel.
 void blocks_release(calipso_hip_solver* s);
 void blocks_pack(calipso_hip_solver* s, bool z, bool l);
-int blocks_pack_from(calipso_hip_solver* s, const double* L, const double* Z, bool l, bool z);   // dense arrays -> blocks, with the check that nothing lies outside the structure (synchronises)
+int blocks_pack_from(calipso_hip_solver* s, const double* L, const double* Z, bool l, bool zg, bool zh);   // zg / zh: the equality / cone Jacobian was written   // dense arrays -> blocks, with the check that nothing lies outside the structure (synchronises)
 bool blocks_gemv_n(calipso_hip_solver* s, int kind, const double* x, double* y, double alpha, double beta);
 bool blocks_gemv_t(calipso_hip_solver* s, int kind, const double* u1, const double* u2, double* y1, double* y2, double alpha, double beta);
 bool blocks_schur(calipso_hip_solver* s);
@@ -423,6 +425,9 @@ inline bool structure_active(const calipso_hip_solver* s) { return s->band64 > 0
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 
 int check(calipso_hip_solver* s, hipError_t e, const char* what);
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that wants more than 64 KB of dynamic LDS: function attributes are PER DEVICE, so once per (kernel, current
+// device) — not once per process — and the result is kept: false = the attribute was refused there (the caller takes its fallback)
+bool lds_attribute(const void* kernel, int bytes);
 // evaluate!(problem, methods, idx, point, parameters; flags) at the current (which = 0) or candidate (1) point: the attached device
 // evaluator, else the host callback (api.hip)
 int evaluate_point(calipso_hip_solver* s, calipso_eval_fn eval, void* user, int which, uint32_t flags);

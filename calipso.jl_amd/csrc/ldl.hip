@@ -628,6 +628,7 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     int launches = 1;
     unsigned long long* const hprog = overlap ? s->hprog_dev : (unsigned long long*)nullptr;
     const unsigned long long epoch = s->ldl_epoch << 16;         // progress word = epoch | first panel the launch applies: every panel before it is released
+    s->lfac_last = lfac;
     if (lfac) launches = lfac_enqueue(s, hprog, epoch);
     for (int kb = 0; !lfac && kb + 1 < nblk;) {
         const int k0 = kb * NB;
@@ -1137,8 +1138,7 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
 // they are captured once per handle into hipGraphs and replayed, so the host issues one graph launch instead of queueing every
 // kernel (the GPU otherwise waits on the host between the many few-microsecond kernels).
 void ldl_set_attributes() {
-    static std::once_flag done;      // > 64 KiB of dynamic LDS must be requested explicitly; host lanes may arrive here concurrently
-    std::call_once(done, [] { (void)hipFuncSetAttribute((const void*)k_tinv_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 64 * (128 + 2) * sizeof(double))); });
+    (void)lds_attribute((const void*)k_tinv_merge, (int)(2 * 64 * (128 + 2) * sizeof(double)));      // > 64 KiB of dynamic LDS must be requested explicitly, on every device
 }
 
 template <typename F>

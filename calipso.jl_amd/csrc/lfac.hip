@@ -221,22 +221,26 @@ __device__ __forceinline__ void item_row(const LfacArgs& a, const LItem it, cons
     // the tile that takes its last panel and the column operand of that product travel with the operands of Z
     double* T1 = a.S + ((size_t)i * TT + (size_t)(k + 1) * TT * a.NP);
     const double* A1 = a.S + ((size_t)(k + 1) * TT + (size_t)k0 * a.NP);
+    // it.c: bit 0 — tile (i, k+2) too; bit 1 — ONLY that tile (the other half of a row item the planner has cut in two where workers idle: Z is formed by both
+    // halves — the same operands, the same bits — and kept by the half that owns tile (i, k+1))
+    const bool second = (it.c & 1) != 0, first = (it.c & 2) == 0;
     double c1[4], y1[4];
+    if (first) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c1[r] = T1[offC + 4 * r * a.NP];
+        for (int r = 0; r < 4; ++r) c1[r] = T1[offC + 4 * r * a.NP];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) y1[q] = A1[offY + q * 16 * a.NP];
+        for (int q = 0; q < 4; ++q) y1[q] = A1[offY + q * 16 * a.NP];
+    }
     v4d z;
     form_Z(a.S + ((size_t)i * TT + (size_t)k0 * a.NP), a.NP, a.Minv + (size_t)k * NB * NB, Ys, Ms, Zs, L.row, L.cb, L.wr, L.wc, L.fr, L.fk, &z);
-    {
+    if (first) {
         double* Zg = a.Zbuf + ((size_t)i * TT + (size_t)k0 * a.NP);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Zg[offC + 4 * r * a.NP] = z[r];
-    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Ys[L.row * LDT + L.cb + q * 16] = y1[q];
-    lds_barrier();
-    const bool second = (it.c & 1) != 0;
+        for (int q = 0; q < 4; ++q) Ys[L.row * LDT + L.cb + q * 16] = y1[q];
+        lds_barrier();
+    }
     double* T2 = a.S + ((size_t)i * TT + (size_t)(k + 2) * TT * a.NP);
     double c2[4], y2[4];
     if (second) {
@@ -246,7 +250,7 @@ __device__ __forceinline__ void item_row(const LfacArgs& a, const LItem it, cons
 #pragma unroll
         for (int q = 0; q < 4; ++q) y2[q] = A2[offY + q * 16 * a.NP];
     }
-    {
+    if (first) {
         const v4d acc = frag_product((unsigned)(uintptr_t)(Zs + (L.wr * 16 + L.fr) * LDT + L.fk), (unsigned)(uintptr_t)(Ys + (L.wc * 16 + L.fr) * LDT + L.fk));
 #pragma unroll
         for (int r = 0; r < 4; ++r) T1[offC + 4 * r * a.NP] = c1[r] - acc[r];
@@ -327,10 +331,11 @@ struct LfacPlan {
     std::vector<int> item0;                 // per launch (index = k + 2): offset of its (W + 1) worker offsets in wfirst
     std::vector<LItem> items;
     std::vector<int> wfirst;
-    double budget = 0.0;
+    double budget = 0.0; int margin = 0;
     std::vector<double> load;               // per launch: the longest worker (cost units) — diagnostics
     std::vector<int> counts;                // per launch: items
     std::vector<double> mean;               // per launch: mean worker load
+    std::vector<int> busy;                  // per launch: workers that have items (the launch's grid: the others would leave at once)
 };
 struct LfacAux {
     LfacPlan plan;
@@ -345,10 +350,11 @@ constexpr double LFAC_CHAIN_US = 19.4;      // what the chain's workgroup makes 
 static double cost_schur(int stages, int P = 1) { return (P == 1 ? 1.6 : P == 2 ? 1.08 : 0.8) * stages + 3.5; }      // (measured: bench/lfac_items.py, less the launch boundary)
 static double cost_far(int panels) { return 3.1 * panels + 2.5; }
 static double cost_row(int pending) { return 15.0 + 2.2 * pending; }
+static double cost_row_half(int pending, bool second) { return second ? 11.0 + 2.2 * pending : 10.0; }      // a row item cut in two (item_row: it.c)
 static int stages_within(double us, int P = 1) { const int n = (int)((us - 3.5) / (P == 1 ? 1.6 : P == 2 ? 1.08 : 0.8)); return n < 1 ? 1 : n; }
 
 // budget: the duration (us) a panel launch should have — the chain's workgroup takes ~19; head: the duration of launch -2 (0: long enough for whole tiles)
-static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W, double budget, double head) {
+static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W, double budget, double head, int margin = 1 << 20) {
     P = LfacPlan();
     P.nblk = nblk; P.W = W; P.budget = budget;
     P.nst0 = (ne + LKT - 1) / LKT; P.nst = P.nst0 + (nc + LKT - 1) / LKT;
@@ -434,6 +440,7 @@ static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W,
             size_t served = 0;
             for (const Cand& c : cand) {
                 if (slots <= 0) break;
+                if (!c.hard && c.needed <= -margin * spl_later && ell != -2) break;      // (margin: how many launches ahead of its need a tile may be served — what waits leaves its worker's time to the tail of the chain)
                 ++served;
                 Tile& t = T(c.i, c.j);
                 const int R = nst - t.st;
@@ -478,6 +485,24 @@ static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W,
             t.pn += n;
             its.push_back({cost_far(n), it}); used += cost_far(n);
         }
+        // where workers idle (the tail of the chain: a launch is as long as its longest item, and that is a row item) every row item is cut in two halves on two
+        // workers: Z is formed twice, the two tiles of the row are updated side by side
+        if (ell >= 0) {
+            int rows = 0;
+            for (const auto& ci : its) rows += ci.second.kind == LI_ROW;
+            if (rows > 0 && (int)its.size() + rows <= W) {
+                const size_t n0 = its.size();
+                for (size_t q = 0; q < n0; ++q) {
+                    if (its[q].second.kind != LI_ROW) continue;
+                    LItem b = its[q].second;
+                    const int pend = b.j - b.a;
+                    its[q].second.c = 0; its[q].first = cost_row_half(0, false);
+                    b.c = 3;
+                    its.push_back({cost_row_half(pend, true), b});
+                    used += cost_row_half(0, false) + cost_row_half(pend, true) - cost_row(pend);
+                }
+            }
+        }
         // longest item first onto the least loaded worker
         std::stable_sort(its.begin(), its.end(), [](const std::pair<double, LItem>& x, const std::pair<double, LItem>& y) { return x.first > y.first; });
         std::vector<std::vector<LItem>> per(W);
@@ -495,6 +520,7 @@ static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W,
         for (int w = 0; w < W; ++w) { P.wfirst.push_back((int)P.items.size()); for (const LItem& it : per[w]) P.items.push_back(it); }
         P.wfirst.push_back((int)P.items.size());
         P.load.push_back(longest); P.counts.push_back((int)its.size()); P.mean.push_back(used / W);
+        { int busy = 0; for (int w = 0; w < W; ++w) if (!per[w].empty()) busy = w + 1; P.busy.push_back(busy); }
     }
     for (int j = 0; j < nblk; ++j) for (int i = j; i < nblk; ++i) if (T(i, j).st != nst || T(i, j).pn != j) return false;      // every tile complete?
     return true;
@@ -517,10 +543,12 @@ static bool lfac_best_plan(LfacPlan& best, int nblk, int nx, int ne, int nc, int
     double best_e = 0.0;
     for (double b = pin_b ? LFAC_BUDGET : 19.0; b <= (pin_b ? LFAC_BUDGET : 40.0); b += 1.5) {
         for (double h = pin_h ? LFAC_HEAD : 50.0; h <= (pin_h ? LFAC_HEAD : 130.0); h += 10.0) {
-            LfacPlan P;
-            if (!lfac_make_plan(P, nblk, nx, ne, nc, W, b, h)) continue;
-            const double e = lfac_plan_estimate(P);
-            if (!have || e < best_e) { best = P; best_e = e; have = true; }
+            for (int margin : {1 << 20, 3, 2, 1, 0}) {
+                LfacPlan P;
+                if (!lfac_make_plan(P, nblk, nx, ne, nc, W, b, h, margin)) continue;
+                const double e = lfac_plan_estimate(P);
+                if (!have || e < best_e) { best = P; best_e = e; have = true; best.margin = margin; }
+            }
         }
     }
     for (double b = 60.0; !have && b <= 400.0; b *= 1.5) have = lfac_make_plan(best, nblk, nx, ne, nc, W, b, 0.0);      // (shapes the scan does not cover)
@@ -594,13 +622,14 @@ int lfac_enqueue(calipso_hip_solver* s, unsigned long long* hprog, unsigned long
         a.wfirst = A->d_wfirst + A->plan.item0[ell + 2];
         a.hprog = ell >= 0 ? hprog : (unsigned long long*)nullptr;
         a.ptag = epoch | (unsigned long long)(ell >= 0 ? ell : 0);
-        hipLaunchKernelGGL(k_lfac, dim3(1 + A->plan.W), dim3(TR_THREADS), 0, s->stream, a);
+        hipLaunchKernelGGL(k_lfac, dim3(1 + A->plan.busy[ell + 2]), dim3(TR_THREADS), 0, s->stream, a);
         ++launches;
     }
     return launches;
 }
 
-// diagnostics for bench.py / tests: [0] launches, [1] items, [2] budget, [3] longest worker of the head, [4] mean longest worker of the panel launches
+// diagnostics for bench.py / tests: [0] launches, [1] items, [2] budget, [3] longest worker of the head, [4] mean longest worker of the panel launches, [5] bytes of the
+// schedule's buffers, [6] budget (us per panel launch) the scan chose, [7] the plan's own estimate of the launches' total (us)
 void lfac_describe(calipso_hip_solver* s, double out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = 0.0;
     LfacAux* A = static_cast<LfacAux*>(s->lfac_aux);
@@ -609,6 +638,8 @@ void lfac_describe(calipso_hip_solver* s, double out[8]) {
     double sum = 0.0; int n = 0;
     for (size_t l = 2; l < A->plan.load.size(); ++l) { sum += A->plan.load[l]; ++n; }
     out[4] = n ? sum / n : 0.0;
+    out[5] = 2.0 * (double)A->NP * A->NP * sizeof(double) + (double)A->plan.items.size() * sizeof(LItem) + (double)A->plan.wfirst.size() * sizeof(int);      // bytes outside the slab
+    out[6] = A->plan.budget; out[7] = lfac_plan_estimate(A->plan);
 }
 
 }  // namespace calipso
@@ -618,7 +649,7 @@ void lfac_describe(calipso_hip_solver* s, double out[8]) {
 extern "C" int32_t calipso_hip_debug_lfac_plan(int32_t nblk, int32_t nx, int32_t ne, int32_t nc, double budget, double head, double* out, int32_t max_launches) {
     calipso::LfacPlan P;
     if (budget <= 0.0 ? !calipso::lfac_best_plan(P, nblk, nx, ne, nc, 255) : !calipso::lfac_make_plan(P, nblk, nx, ne, nc, 255, budget, head)) return 0;
-    if (max_launches > 0) out[6 * (max_launches - 1)] = P.budget;
+    if (max_launches > 0) { out[6 * (max_launches - 1)] = P.budget; out[6 * (max_launches - 1) + 1] = P.margin; out[6 * (max_launches - 1) + 2] = P.load.empty() ? 0.0 : P.load[0]; }
     const int nl = (int)P.item0.size();
     for (int l = 0; l < nl && l < max_launches; ++l) {
         const int w0 = P.item0[l];
@@ -637,7 +668,7 @@ extern "C" int32_t calipso_hip_debug_lfac_plan(int32_t nblk, int32_t nx, int32_t
 // Timing of synthetic item lists on the real kernel (bench/lfac_items.py; the handle's factor is garbage afterwards): every worker gets `per_worker` items of one kind —
 // kind 0: SCHUR slices of n stages split P ways (skew: every worker at a stage range of its own), 1: FAR items of n panels, 2: ROW items with n pending panels.  Returns the
 // mean duration of the launch in microseconds (5 launches), < 0 on failure.
-extern "C" double calipso_hip_debug_lfac_items(calipso_hip_solver* s, int32_t kind, int32_t n, int32_t P, int32_t per_worker, int32_t skew) {
+extern "C" double calipso_hip_debug_lfac_items(calipso_hip_solver* s, int32_t kind, int32_t n, int32_t P, int32_t per_worker, int32_t skew, int32_t active) {
     using namespace calipso;
     if (!s || !lfac_ready(s)) return -1.0;
     LfacAux* A = static_cast<LfacAux*>(s->lfac_aux);
@@ -648,7 +679,7 @@ extern "C" double calipso_hip_debug_lfac_items(calipso_hip_solver* s, int32_t ki
     size_t next = 0;
     for (int w = 0; w < W; ++w) {
         wfirst.push_back((int)items.size());
-        for (int q = 0; q < per_worker; ++q) {
+        for (int q = 0; q < per_worker && (active <= 0 || (w * active) / W != ((w + 1) * active) / W); ++q) {      // active > 0: only that many workers (spread evenly) get items
             LItem it{};
             if (kind == 0) {
                 const auto ij = tiles[(next++) % tiles.size()];
@@ -660,7 +691,7 @@ extern "C" double calipso_hip_debug_lfac_items(calipso_hip_solver* s, int32_t ki
                 it.kind = LI_FAR; it.i = (short)ij.first; it.j = (short)ij.second; it.a = 0; it.b = (short)n;
             } else {
                 const int k = n + (w % 3), i = k + 2 + (int)((next++) % (size_t)(nblk - k - 2));
-                it.kind = LI_ROW; it.i = (short)i; it.j = (short)k; it.a = (short)(k - n); it.c = 1;
+                it.kind = LI_ROW; it.i = (short)i; it.j = (short)k; it.a = (short)(k - n); it.c = (short)(kind == 3 ? 0 : kind == 4 ? 3 : 1);      // kind 3 / 4: the two halves of a row item
             }
             items.push_back(it);
         }

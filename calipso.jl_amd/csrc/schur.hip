@@ -553,8 +553,7 @@ void launch_pad_identity(calipso_hip_solver* s) {
 }
 
 void launch_schur(calipso_hip_solver* s) {
-    static std::once_flag attr;      // (several host lanes launch concurrently: one of them sets the attribute, the others wait for it)
-    std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)k_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHUR_LDS_BYTES); });
+    (void)lds_attribute((const void*)k_schur, (int)SCHUR_LDS_BYTES);      // (per device; several host lanes may arrive concurrently)
     if (blocks_schur(s)) return;          // stage blocks: S by segment pairs from the packed blocks (blocks.hip)
     if (s->hessian_dirty && !s->cur) { launch_symmetrize(s); s->hessian_dirty = false; }   // (a group refreshes its members itself)
     if (lfac_ready(s)) {                  // one dense system alone: the products are slices of the panel launches (lfac.hip), queued by launch_ldl

@@ -54,6 +54,9 @@ void launch_residual(calipso_hip_solver* s) {
 }
 
 __device__ __forceinline__ double pnorm_term(double v, int ptype) { return ptype == 2 ? v * v : fabs(v); }
+// |v| as a term of the infinity norm of a refinement residual, with NaN -> +inf: fmax / block_max / the atomic maximum on bit patterns drop a NaN, and a norm of 0 would
+// read as "converged" (iterative_refinement.jl:14-16 sees norm(., Inf) = NaN, NaN <= tol false, and goes on to the failure path: so does +inf)
+__device__ __forceinline__ double rabs(double v) { return v != v ? __longlong_as_double(0x7ff0000000000000ll) : fabs(v); }
 
 // A read-back without a launch of its own: the LAST kernel in front of a scalar read-back (one workgroup, a single handle) copies dscal[first .. first +
 // count) — its own results and those of the kernels before it on the stream — to the handle's mapped host mirror and then stores the sequence number the
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(RT) void k_Hmul_err(BatchSc bt, Dims d, ConeDev cd,
         }
         const double r = res[i] - hv;
         e[i] = r;
-        m = fmax(m, fabs(r));
+        m = fmax(m, rabs(r));
     }
     const double r = block_max(m, sm);
     if (threadIdx.x == 0) *out = r;
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_refine_local(BatchSc bt, Dims d,
         const double hy = zsx[iy - d.oy()] + (-v[d.orr() + iy - d.oy()] + (0.0 - sc.ed) * v[iy]);
         const double ey = res[iy] - hy;
         e[ir] = er; e[iy] = ey;
-        m = fmax(fabs(er), fabs(ey));
+        m = fmax(rabs(er), rabs(ey));
         double b = ey;
         b += er / Hrr;
         rsym[d.nx + ee] = b;
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_refine_local(BatchSc bt, Dims d,
         const double ht = t[k] * vs[k] + (sl[k] - sc.ed) * vt[k];
         const double et = res[it] - ht;
         e[is] = es; e[iz] = ez; e[it] = et;
-        m = fmax(fmax(fabs(es), fabs(ez)), fabs(et));
+        m = fmax(fmax(rabs(es), rabs(ez)), rabs(et));
         const double Sb = w[d.os() + k] - sc.ed, Ti = w[d.ot() + k], Pi = Hss;
         double b = ez;
         b += (et + Sb * es) / (Ti + Sb * Pi);
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_refine_local(BatchSc bt, Dims d,
                 }
                 rt[a] = lres_t[a] - ht;
                 e[d.os() + k] = rs[a]; e[d.oz() + k] = rz[a]; e[d.ot() + k] = rt[a];
-                m = fmax(m, fmax(fmax(fabs(rs[a]), fabs(rz[a])), fabs(rt[a])));
+                m = fmax(m, fmax(fmax(rabs(rs[a]), rabs(rz[a])), rabs(rt[a])));
             }
             double u[MD], vv[MD], o[MD];
 #pragma unroll
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(RT) void k_refine_x(BatchSc bt, Dims d, int have_m,
                 e[i] = r;
                 rsym[i] = r;
                 xbuf[i] = have_m ? r + a2[u] : r;
-                m = fmax(m, fabs(r));
+                m = fmax(m, rabs(r));
             } else if (i < d.NP) xbuf[i] = 0.0;
         }
     }
@@ -916,7 +919,7 @@ __device__ __forceinline__ double tail_equality(const Dims& d, const Scalars& sc
     b += er / Hrr;
     A.rsym[d.nx + k] = b;
     A.t1[k] = omega_y * b;
-    return fmax(fabs(er), fabs(ey));
+    return fmax(rabs(er), rabs(ey));
 }
 __device__ __forceinline__ double tail_nonnegative(const Dims& d, const Scalars& sc, const TailArgs& A, int k, double t2k) {
     const double Hss = 0.0 + sc.ep;
@@ -948,7 +951,7 @@ __device__ __forceinline__ double tail_nonnegative(const Dims& d, const Scalars&
     b += (et + Sb * es) / (Ti + Sb * Pi);
     A.rsym[d.nx + d.ne + k] = b;
     A.t1[d.ne + k] = A.wz[k] * b;
-    return fmax(fmax(fabs(es), fabs(ez)), fabs(et));
+    return fmax(fmax(rabs(es), rabs(ez)), rabs(et));
 }
 // second-order cone j of dimension <= 4; t2c[a] = entry of t2 of its row a
 __device__ __forceinline__ double tail_soc_small(const Dims& d, const Scalars& sc, const ConeDev& cd, const TailArgs& A, int j, const double* t2c) {
@@ -1045,7 +1048,7 @@ __device__ __forceinline__ double tail_soc_small(const Dims& d, const Scalars& s
         }
         qt[a] = res_t[a] - ht;
         A.e[d.os() + k] = qs[a]; A.e[d.oz() + k] = qz[a]; A.e[d.ot() + k] = qt[a];
-        m = fmax(m, fmax(fmax(fabs(qs[a]), fabs(qz[a])), fabs(qt[a])));
+        m = fmax(m, fmax(fmax(rabs(qs[a]), rabs(qz[a])), rabs(qt[a])));
     }
     double uu[MD], vv[MD], oo[MD];
 #pragma unroll
@@ -1171,9 +1174,7 @@ bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool w
     constexpr int TW = TAIL_PARTS * TAIL_CPT;
     const size_t lds = sizeof(double) * (size_t)((s->d.nx + TW - 1) / TW) * TW;
     if (lds > 48 * 1024) {
-        static std::once_flag big;       // (> 64 KB of dynamic LDS must be asked for)
-        std::call_once(big, [] { (void)hipFuncSetAttribute((const void*)k_solve_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
-        if (lds > 96 * 1024) return false;
+        if (lds > 96 * 1024 || !lds_attribute((const void*)k_solve_tail, 96 * 1024)) return false;      // (> 64 KB of dynamic LDS must be asked for, on every device; refused: the separate kernels)
     }
     hipLaunchKernelGGL(k_solve_tail, dim3((s->n_zgrp + 7) / 8 * 8, 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), lds, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
                        s->residual, s->wz, s->Wsoc, s->residual_symmetric, s->step_symmetric, st, accumulate ? s->step : (double*)nullptr, s->zsx, s->residual_error, s->t1, s->refpart,
@@ -1258,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_refine_x_fused(BatchSc bt, Dims d, int 
             e[i] = rr;
             rsym[i] = rr;
             xbuf[i] = have_m ? rr + w2i : rr;
-            m = fabs(rr);
+            m = rabs(rr);
         } else if (i < d.NP) xbuf[i] = 0.0;
     }
     const double mr = block_max(m, sm);

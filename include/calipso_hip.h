@@ -431,7 +431,10 @@ int32_t calipso_hip_phase_times(calipso_hip_solver*, double out[9]);
  *     pivots; HIP events around exactly these launches; the rest of [3] above is the parallel finish: factor columns + block inverses)
  * [1] number of those launches   [2] NP = padded order of the Schur complement   [3] bytes of the handle's device slab
  * [4] ms of ONE launch of the refinement residual's mat-vec kernel (k_gemv_t2_and_n: [gx; hx]' times two vectors and Lxx times one, the first residual of the
- *     last calipso_hip_newton_step; 0 when the handle takes another path) and [5] the bytes it reads, 8 (m nx + nx^2)   [6..7] reserved (0) */
+ *     last calipso_hip_newton_step; 0 when the handle takes another path) and [5] the bytes it reads, 8 (m nx + nx^2)
+ * [6] 1 when the last factorisation took the left-looking schedule of one dense system (csrc/lfac.hip: the products of the Schur complement as slices of the panel
+ *     launches — [0] / [1] then cover k_lfac's launches, Schur complement included, and phase [7] of calipso_hip_phase_times is ~0)   [7] bytes of that schedule's
+ *     buffers outside the slab (Z = A M of every panel, the factor columns, the launch plan) */
 int32_t calipso_hip_kernel_times(calipso_hip_solver*, double out[8]);
 /* work of one Newton step on a handle that exploits its stage structure (src/trajectory_optimization/sparsity.jl:28-129 is where the reference's structure
  * comes from): [0] flops of the Schur complement by segment pairs (k_schur_blocks)   [1] doubles of the packed blocks of [gx; hx] and Lxx (both orientations)
