@@ -75,6 +75,78 @@ def staged_shape(st):
     return (T * nv, (T - 1) * nd, T * nn, T * nsoc, dim)
 
 
+def config_c2(pkg, pr, device):
+    """BASELINE config 2: the pendulum swing-up (T = 11; test/examples/pendulum.jl) as ONE full solve!: every inner Newton iteration of solve.jl:98-353 on the device,
+    the Symbolics-generated evaluate! replaced by the restated problem functions on the host (callback: tests/problems.py).  Iterations are checked against the
+    oracle-made golden trace (tests/golden/c2_pendulum_trace.npz)."""
+    prob = pr.pendulum(action_guess=np.zeros(10))
+    ms = []
+    its = 0
+    for rep in range(4):
+        s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, device=device)
+        pkg.initialize_b(s, prob.x0)
+        s.synchronize()
+        t0 = time.perf_counter()
+        ok = pkg.solve_b(s)
+        s.synchronize()
+        ms.append(1e3 * (time.perf_counter() - t0))
+        its = int(s.stats()["total_iterations"])
+        sol = s.get("solution", s.N)
+        s.close() if hasattr(s, "close") else None
+    out = {"workload": "pendulum swing-up T = 11 (nx = %d, ne = %d, nc = %d), one solve! with host evaluation callbacks" % (prob.nx, prob.ne, prob.nc), "solved": bool(ok),
+           "newton_iterations": its, "solve_ms": float(np.median(ms[1:])), "solve_ms_all": ms, "ms_per_newton_iteration": float(np.median(ms[1:])) / max(1, its),
+           "note": "a 56 x 56 condensed system: the time is launch latency + host callbacks, not device throughput (the batched LDS-resident path of config.c5 is what many such systems take)"}
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "c2_pendulum_trace.npz"))
+        out["golden_trace_iterations"] = int(g["trace"].shape[0])
+        out["matches_golden_solution_1e-6"] = bool(np.abs(sol - g["solution"]).max() <= 1e-6 * max(1.0, np.abs(g["solution"]).max()))
+    except Exception as e:      # (fixture missing: say so, do not fail the bench)
+        out["golden"] = "unavailable: %s" % e
+    return out
+
+
+def config_c5(pkg, pr, device):
+    """BASELINE config 5: cart-pole auto-tuning sensitivities dw*/dtheta (examples/autotuning/cartpole.jl:179-227, src/solver/differentiate.jl:1-61): nx = 49, ne = 40,
+    102 parameter columns.  (a) differentiate! on one handle (dense and declared as the trajectory problem it is); (b) the batched LDS-resident path (csrc/small.hip:
+    calipso_hip_small_*) for the back-solves of 1024 MPC steps at once, priced against HBM (its inputs and outputs are read / written once)."""
+    prob = pr.cartpole_mpc()
+    opts = dict(residual_tolerance=1e-3, optimality_tolerance=1e-3, equality_tolerance=1e-3, complementarity_tolerance=1e-3, slack_tolerance=1e-3, differentiate=1)
+    out = {"workload": "cart-pole MPC sensitivities: nx = %d, ne = %d, %d parameter columns" % (prob.nx, prob.ne, prob.np)}
+    for name, st in (("dense_handle", None), ("structured_handle", pr.structure_from_pattern(prob))):
+        s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, parameters=prob.parameters, options=opts, structure=st, device=device)
+        pkg.initialize_b(s, prob.x0)
+        ok = pkg.solve_b(s)
+        s.differentiate(); s.synchronize()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            s.differentiate()
+        s.synchronize()
+        dms = 1e3 * (time.perf_counter() - t0) / reps
+        out[name] = {"solved": bool(ok), "newton_iterations": int(s.stats()["total_iterations"]), "differentiate_ms": dms, "back_solves_per_s": prob.np / (dms * 1e-3),
+                     "device_bytes": int(s.device_bytes())}
+    n, nrhs, batch = prob.nx + prob.ne + prob.nc, prob.np, 1024
+    rng = np.random.default_rng(0)
+    Q = rng.standard_normal((n, n))
+    K = Q @ Q.T + n * np.eye(n)
+    K[prob.nx:, prob.nx:] = -K[prob.nx:, prob.nx:]; K[:prob.nx, prob.nx:] *= 0.1; K[prob.nx:, :prob.nx] = K[:prob.nx, prob.nx:].T
+    Bm = rng.standard_normal((batch, n, nrhs))
+    sb = pkg.SmallBatch(n, nrhs, batch)
+    sb.set(np.repeat(K[None], batch, axis=0), Bm)
+    sb.solve()
+    ms = min(sb.solve() for _ in range(5))
+    X, inr, bad = sb.get()
+    okb = bad == 0 and float(np.abs(K @ X[batch - 1] - Bm[batch - 1]).max()) < 1e-8
+    sb.close()
+    bytes_io = 8.0 * batch * (n * n + 2 * n * nrhs)
+    out["batched_small_systems"] = {"n": n, "right_hand_sides": nrhs, "batch": batch, "launch_ms": ms, "instances_per_s": batch / (ms * 1e-3), "back_solves_per_s": batch * nrhs / (ms * 1e-3),
+                                    "residual_ok": bool(okb),
+                                    "roofline": {"bound": "hbm", "bytes": bytes_io, "achieved_GBs": bytes_io / (ms * 1e-3) * 1e-9, "frac": bytes_io / (ms * 1e-3) * 1e-9 / 8000.0,
+                                                 "flops": batch * (n ** 3 / 3.0 + 2.0 * n * n * nrhs), "note": "one workgroup per instance, the matrix and its right-hand sides in LDS: K, B read once, X written once; "
+                                                 "the work per instance is a dependent chain of %d pivots — latency, not bandwidth, is what bounds a launch" % n}}
+    return out
+
+
 def cpu_baseline(shape, name="C3", staged=None, samples=3, full=False):
     """CPU rows of SURVEY.md 8(d) on the GPU box's host, same C3 problem 0 (ONE Newton step each):
       B0(i)   the oracle (faithful single-thread restatement of the reference's CPU path: assemble + sparse up-looking LDL^T in QDLDL's
@@ -358,6 +430,7 @@ def main():
     ap.add_argument("--dense-buffers", action="store_true", help="stage-structured configs: handles made by calipso_hip_create + analyze_structure + set_stage_parallel + set_stage_blocks\n"
                     "(the dense Lxx / [gx; hx] / S buffers exist beside the blocks) instead of structured handles (calipso_hip_create_structured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c2-c5", action="store_true", help="skip config.c2 (pendulum solve!) and config.c5 (cart-pole sensitivities): BASELINE configs 2 and 5, rank 0 at N = 1 only, ~10 s")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="measure B0(ii) (re-factorisation before every solve) instead of deriving it (~1 min more)")
     ap.add_argument("--cpu-samples", type=int, default=3)
     ap.add_argument("--no-single", action="store_true", help="profiling runs: skip the single-system region (every launch in the trace then carries a\n"
@@ -755,6 +828,14 @@ def main():
                 wa.close()
                 del wa
 
+    c2 = c5 = None
+    if rank == 0 and world == 1 and not args.no_c2_c5 and args.config == "C3":
+        try:
+            c2 = config_c2(pkg, pr, local_rank if args.force_device < 0 else args.force_device)
+            c5 = config_c5(pkg, pr, local_rank if args.force_device < 0 else args.force_device)
+        except Exception as e:      # (never lose the headline line to a side figure)
+            c2 = c2 or {"error": repr(e)}
+            c5 = c5 or {"error": repr(e)}
     out = {
         "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": steps_timed,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps_timed, "higher_is_better": True, "scaling": "weak",
@@ -766,7 +847,7 @@ def main():
                                         "B2 says so); value = B0(i), one factorisation per step (favourable to the reference); B0_ii (the reference's re-factorisation before every solve) is "
                                         + ("MEASURED in this run (--cpu-baseline-full)" if args.cpu_baseline_full else "DERIVED from B0(i) + separately timed factorisations (measured: false; --cpu-baseline-full measures it, ~90 s more)")
                                         + "; B1 = LAPACK on all cores, not the reference",
-                   "batched": batched, "c4": c4, "roofline_phases": cfg_phases},
+                   "batched": batched, "c4": c4, "c2": c2, "c5": c5, "roofline_phases": cfg_phases},
         "roofline": roof,
     }
     exchange.close()

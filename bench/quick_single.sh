@@ -11,7 +11,7 @@ for i in 1 2; do
 import json
 d=json.loads([l for l in open("$O/quick_${TAG}_$i.json") if l.startswith("{")][-1])
 p=d["config"]["roofline_phases"]["single_system"]
-r=d["roofline"]; ch=r if "k_ldl" in r["kernel"] else r["secondary"][0]
+r=d["roofline"]; ch=r if ("k_ldl" in r["kernel"] or "k_lfac" in r["kernel"]) else r["secondary"][0]
 print("$TAG run $i: value %.1f  ms/step %.3f  solve_and_refine %.3f  schur %.3f  ldl %.3f  chain %.3f (%d launches)" % (d["value"], d["ms_per_step"], p["solve_and_refine"]["ms"], p["factor"]["schur_ms"], p["factor"]["ldl_ms"], ch["ms_per_step"], ch["launches_per_step"]))
 PY
 done
@@ -23,7 +23,7 @@ python - <<PY
 import csv
 rows=list(csv.DictReader(open("$O/quick_${TAG}_kernel_stats.csv")))
 rows=[r for r in rows if "mfma_f64_peak" not in r["Name"]]
-steps=float([r for r in rows if "k_schur" in r["Name"]][0]["Calls"])      # one Schur complement per Newton step
+steps=float([r for r in rows if "k_cone_search" in r["Name"]][0]["Calls"])      # one cone search per Newton step
 for r in sorted(rows,key=lambda r:-float(r["TotalDurationNs"]))[:32]:
     print("%-70s calls/step %6.1f avg %7.2f us  per step %7.1f us" % (r["Name"][:70], int(r["Calls"])/steps, float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/steps/1e3))
 PY

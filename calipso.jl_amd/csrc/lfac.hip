@@ -33,7 +33,7 @@ namespace calipso {
 constexpr int LKT = 32;            // constraint rows per Schur stage (schur.hip: KT — the stage boundaries are part of the arithmetic)
 constexpr int LLDK = LKT + 2;
 constexpr int LFAC_LDS_DOUBLES = 4 * TT * LDT > DIAG_LDS_DOUBLES ? 4 * TT * LDT : DIAG_LDS_DOUBLES;     // two operand pairs of the deferred updates | the diagonal block | four Schur stage buffers
-static_assert(4 * TT * LLDK <= LFAC_LDS_DOUBLES, "Schur stage buffers");
+static_assert(6 * TT * LLDK <= LFAC_LDS_DOUBLES, "Schur stage buffers (a ring of three)");
 
 enum { LI_SCHUR = 0, LI_FAR = 1, LI_ROW = 2 };
 struct LItem { short kind, i, j, a, b, c, pad0, pad1; };     // SCHUR: tile (i, j), stages [a, b), c bit 0: first slice, bit 1: last (epilogue); FAR: tile (i, j), panels [a, b); ROW: row i, panel j, pending panels of tile (i, j + 2) from a
@@ -104,33 +104,55 @@ __device__ __forceinline__ void item_schur(const LfacArgs& a, const LItem it, co
         Bs[c * LLDK + k] = (kin && vB0) ? scale * rb[set][0] : 0.0;
         Bs[(c + 32) * LLDK + k] = (kin && vB1) ? scale * rb[set][1] : 0.0;
     };
+    // A ring of THREE stage buffers in LDS and two register sets: stage s + 2 is parked while stage s is computed (its operands were requested at stage s - 2), so the
+    // first half of the fragments of stage s + 1 — parked during stage s - 1, visible since the barrier that ended it — is read BEFORE the barrier that ends stage s,
+    // under the last matrix instructions of the stage: the next stage's matrix instructions start right behind the barrier instead of behind a round of LDS reads
+    // (bench/lfac_item_bench.hip: 1.63 -> 1.43 us per stage).  The arithmetic per entry is untouched.
     const int s0 = it.a, s1 = it.b;
+    double fa[8], fb[8];
+    auto reads = [&](int buf, int half) {          // fragments 4 half .. 4 half + 3 of the stage in buffer buf
+        const unsigned ab = (unsigned)(uintptr_t)(smem + (size_t)buf * 2 * TT * LLDK + (wr * 16 + L.fr) * LLDK + L.fk);
+        const unsigned bb = (unsigned)(uintptr_t)(smem + (size_t)buf * 2 * TT * LLDK + TT * LLDK + (L.wc * 16 + L.fr) * LLDK + L.fk);
+        if (half == 0) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[kk]) : "v"(ab), "n"(kk * 32) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[kk]) : "v"(bb), "n"(kk * 32) : "memory");
+            }
+        } else {
+#pragma unroll
+            for (int kk = 4; kk < 8; ++kk) {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[kk]) : "v"(ab), "n"(kk * 32) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[kk]) : "v"(bb), "n"(kk * 32) : "memory");
+            }
+        }
+    };
     if (s1 > s0) {
         fetch(s0, 0);
         if (s0 + 1 < s1) fetch(s0 + 1, 1);
         park(0, 0, s0);
+        if (s0 + 1 < s1) park(1, 1, s0 + 1);
         if (s0 + 2 < s1) fetch(s0 + 2, 0);
+        if (s0 + 3 < s1) fetch(s0 + 3, 1);
     }
     lds_barrier();
-    // one stage: rel = stage index relative to s0 (its parity picks the LDS buffer and the register set; the loop below is unrolled by two so that both are static)
-    auto stage = [&](int st, int par, auto inner) {      // inner: a stage with at least three more behind it — no conditions around its requests (the bulk of the loop is straight-line code)
-        const double* As = smem + (size_t)par * 2 * TT * LLDK;
-        const double* Bs = As + TT * LLDK;
-        if (decltype(inner)::value || st + 1 < s1) park(par ^ 1, par ^ 1, st + 1);  // (the buffer is free since the barrier that ended stage st - 1; its operands were fetched two stages ago)
-        if (decltype(inner)::value || st + 3 < s1) fetch(st + 3, par ^ 1);
+    if (mf && s1 > s0) reads(0, 0);
+    // one stage; u = (stage - s0) mod 6 picks the buffer (u mod 3) and the register set (u mod 2): the loop is unrolled by six so that both are static.  inner: at
+    // least four more stages behind it — no conditions around its requests (the bulk of the loop is straight-line code)
+    auto stage = [&](int st, auto uc, auto inner) {
+        constexpr int u = decltype(uc)::value, buf = u % 3, set = u & 1;
         if (mf) {
-            const unsigned ab = (unsigned)(uintptr_t)(As + (wr * 16 + L.fr) * LLDK + L.fk);
-            const unsigned bb = (unsigned)(uintptr_t)(Bs + (L.wc * 16 + L.fr) * LLDK + L.fk);
-            double fa[8], fb[8];
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[kk]) : "v"(ab), "n"(kk * 32) : "memory");
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[kk]) : "v"(bb), "n"(kk * 32) : "memory");
-            }
+            reads(buf, 1);
             asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fa[1]), "+v"(fb[1]), "+v"(fa[2]), "+v"(fb[2]), "+v"(fa[3]), "+v"(fb[3]) :: "memory");
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[kk], fa[kk], acc, 0, 0, 0);
+        }
+        if (decltype(inner)::value || st + 2 < s1) park((u + 2) % 3, set, st + 2);      // (its buffer held stage st - 1: every wavefront is past the barrier behind that stage)
+        if (decltype(inner)::value || st + 4 < s1) fetch(st + 4, set);
+        if (mf) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[4]), "+v"(fb[4]), "+v"(fa[5]), "+v"(fb[5]), "+v"(fa[6]), "+v"(fb[6]), "+v"(fa[7]), "+v"(fb[7]) :: "memory");
+            // (the first half's registers are free: the matrix instructions that read them issued long ago — the pattern of frag_product's ring)
+            if (decltype(inner)::value || st + 1 < s1) reads((u + 1) % 3, 0);
 #pragma unroll
             for (int kk = 4; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[kk], fa[kk], acc, 0, 0, 0);
         }
@@ -138,14 +160,19 @@ __device__ __forceinline__ void item_schur(const LfacArgs& a, const LItem it, co
     };
     int st = s0;
 #pragma unroll 1
-    for (; st + 4 < s1; st += 2) {
-        stage(st, 0, std::true_type());
-        stage(st + 1, 1, std::true_type());
+    for (; st + 9 < s1; st += 6) {
+        stage(st, std::integral_constant<int, 0>(), std::true_type()); stage(st + 1, std::integral_constant<int, 1>(), std::true_type());
+        stage(st + 2, std::integral_constant<int, 2>(), std::true_type()); stage(st + 3, std::integral_constant<int, 3>(), std::true_type());
+        stage(st + 4, std::integral_constant<int, 4>(), std::true_type()); stage(st + 5, std::integral_constant<int, 5>(), std::true_type());
     }
 #pragma unroll 1
-    for (; st < s1; st += 2) {
-        stage(st, 0, std::false_type());
-        if (st + 1 < s1) stage(st + 1, 1, std::false_type());
+    for (; st < s1; st += 6) {
+        stage(st, std::integral_constant<int, 0>(), std::false_type());
+        if (st + 1 < s1) stage(st + 1, std::integral_constant<int, 1>(), std::false_type());
+        if (st + 2 < s1) stage(st + 2, std::integral_constant<int, 2>(), std::false_type());
+        if (st + 3 < s1) stage(st + 3, std::integral_constant<int, 3>(), std::false_type());
+        if (st + 4 < s1) stage(st + 4, std::integral_constant<int, 4>(), std::false_type());
+        if (st + 5 < s1) stage(st + 5, std::integral_constant<int, 5>(), std::false_type());
     }
     if (!mf) return;
     if (it.c & 2) {
@@ -347,11 +374,11 @@ struct LfacAux {
 // cost model (microseconds on one compute unit while the whole chip is busy: the fp64 matrix cores sustain ~41 TFLOP/s on real data, 161 GFLOP/s per unit — a
 // 64 x 64 x 64 product 3.3 us, a Schur stage 1.64 us; bench/lfac_item_bench.hip): what balances the workers of a launch against the chain's workgroup
 constexpr double LFAC_CHAIN_US = 19.4;      // what the chain's workgroup makes a panel launch last at least (C3: profiles/r05_lfac_timeline.txt)
-static double cost_schur(int stages, int P = 1) { return (P == 1 ? 1.6 : P == 2 ? 1.08 : 0.8) * stages + 3.5; }      // (measured: bench/lfac_items.py, less the launch boundary)
+static double cost_schur(int stages, int P = 1) { return (P == 1 ? 1.52 : P == 2 ? 1.05 : 0.8) * stages + 3.3; }      // (measured: bench/lfac_items.py, less the launch boundary)
 static double cost_far(int panels) { return 3.1 * panels + 2.5; }
 static double cost_row(int pending) { return 15.0 + 2.2 * pending; }
 static double cost_row_half(int pending, bool second) { return second ? 11.0 + 2.2 * pending : 10.0; }      // a row item cut in two (item_row: it.c)
-static int stages_within(double us, int P = 1) { const int n = (int)((us - 3.5) / (P == 1 ? 1.6 : P == 2 ? 1.08 : 0.8)); return n < 1 ? 1 : n; }
+static int stages_within(double us, int P = 1) { const int n = (int)((us - 3.3) / (P == 1 ? 1.52 : P == 2 ? 1.05 : 0.8)); return n < 1 ? 1 : n; }
 
 // budget: the duration (us) a panel launch should have — the chain's workgroup takes ~19; head: the duration of launch -2 (0: long enough for whole tiles)
 static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W, double budget, double head, int margin = 1 << 20) {
