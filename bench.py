@@ -82,8 +82,12 @@ def config_c2(pkg, pr, device):
     prob = pr.pendulum(action_guess=np.zeros(10))
     ms = []
     its = 0
+    accepted = []
     for rep in range(4):
         s = pkg.Solver(prob, prob.nx, prob.np, prob.ne, prob.nc, device=device)
+        accepted = []
+        if rep == 0:      # (the untimed first solve counts the accepted iterates the way the golden trace was recorded: one callback_inner call each)
+            s.set_callbacks(inner=lambda sv: accepted.append(1))
         pkg.initialize_b(s, prob.x0)
         s.synchronize()
         t0 = time.perf_counter()
@@ -91,6 +95,7 @@ def config_c2(pkg, pr, device):
         s.synchronize()
         ms.append(1e3 * (time.perf_counter() - t0))
         its = int(s.stats()["total_iterations"])
+        if rep == 0: trace_rows = len(accepted)
         sol = s.get("solution", s.N)
         s.close() if hasattr(s, "close") else None
     out = {"workload": "pendulum swing-up T = 11 (nx = %d, ne = %d, nc = %d), one solve! with host evaluation callbacks" % (prob.nx, prob.ne, prob.nc), "solved": bool(ok),
@@ -98,7 +103,9 @@ def config_c2(pkg, pr, device):
            "note": "a 56 x 56 condensed system: the time is launch latency + host callbacks, not device throughput (the batched LDS-resident path of config.c5 is what many such systems take)"}
     try:
         g = np.load(os.path.join(ROOT, "tests", "golden", "c2_pendulum_trace.npz"))
-        out["golden_trace_iterations"] = int(g["trace"].shape[0])
+        out["accepted_iterates"] = trace_rows
+        out["golden_trace_accepted_iterates"] = int(g["trace"].shape[0])
+        out["same_iterations_as_golden_trace"] = bool(trace_rows == int(g["trace"].shape[0]))
         out["matches_golden_solution_1e-6"] = bool(np.abs(sol - g["solution"]).max() <= 1e-6 * max(1.0, np.abs(g["solution"]).max()))
     except Exception as e:      # (fixture missing: say so, do not fail the bench)
         out["golden"] = "unavailable: %s" % e

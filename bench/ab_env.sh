@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 NAME=$1; shift
 for v in "$@"; do
-  env $NAME=$v python bench.py --batch 0 --no-c4 --no-cpu-baseline --steps 30 > gpurun_out/ab_env.json 2>gpurun_out/ab_env.err
+  env $NAME=$v python bench.py --batch 0 --no-c4 --no-c2-c5 --no-cpu-baseline --steps 30 > gpurun_out/ab_env.json 2>gpurun_out/ab_env.err
   python - <<PY
 import json
 d=json.loads([l for l in open("gpurun_out/ab_env.json") if l.startswith("{")][-1])

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for w in 1 0 1 0; do
-  CALIPSO_BENCH_SOLVE_WFORM=$w python bench.py --batch 0 --no-c4 --no-cpu-baseline --steps 30 > gpurun_out/ab_wform_$w.json 2>gpurun_out/ab_wform_$w.err
+  CALIPSO_BENCH_SOLVE_WFORM=$w python bench.py --batch 0 --no-c4 --no-c2-c5 --no-cpu-baseline --steps 30 > gpurun_out/ab_wform_$w.json 2>gpurun_out/ab_wform_$w.err
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_wform_$w.json"))

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Copy the summaries of bench/evidence_round.sh (gpurun_out/round/, scratch) into profiles/ under the round's prefix: bash bench/collect_profiles.sh r05
+P=${1:-r05}; R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/round; D=$R/profiles
+cpy() { [ -s "$O/$1" ] && cp "$O/$1" "$D/${P}_$2"; }
+cpy bench_default.json bench_default.json
+cpy bench_single_under_rocprof.json bench_single_under_rocprof.json
+cpy bench_group_under_rocprof.json bench_group_under_rocprof.json
+cpy kernel_stats_single.csv kernel_stats_single.csv
+cpy kernel_stats_group.csv kernel_stats_group.csv
+cpy kernel_stats_c4t_group.csv kernel_stats_c4t_group.csv
+cpy pmc_summary.json pmc_summary.json
+for m in single group; do for c in FETCH_SIZE WRITE_SIZE MfmaUtil SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do cpy pmc_${m}_$c.csv pmc_${m}_$c.csv; done; done
+cpy bench_C4.json bench_C4.json
+cpy bench_C4T.json bench_C4T.json
+cpy bench_C4T_192.json bench_C4T_192.json
+cpy ldl_steps_single.txt ldl_steps_single_right_looking.txt
+cpy ldl_steps_group12_pairs.txt ldl_steps_group12_pairs.txt
+cpy lfac_timeline.txt lfac_timeline.txt
+cpy lfac_items.txt lfac_items.txt
+cpy ldl_chain_timeline.txt ldl_chain_timeline_right_looking.txt
+cpy mf_trace.txt mf_front_timeline.txt
+cpy ldl_bulk_trace.txt ldl_bulk_trace.txt
+cpy step_gaps_under_rocprof.txt step_gaps_under_rocprof.txt
+cpy diag_bench3.txt diag_bench3.txt
+ls $D | grep "^${P}_" | wc -l

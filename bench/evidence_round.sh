@@ -10,10 +10,12 @@ bash bench/ldl_step_times.sh 12 1 > /dev/null 2>&1; cp gpurun_out/ldlsteps_12_1/
 for c in C4 C4T; do
   timeout 600 python bench.py --config $c --batch 32 --group 16 --lanes 2 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err < /dev/null
 done
-timeout 600 python bench.py --config C4T --batch 192 --group 64 --lanes 3 --no-cpu-baseline --no-single --no-c4 > $O/bench_C4T_192.json 2> /dev/null < /dev/null
+timeout 600 python bench.py --config C4T --batch 192 --group 64 --lanes 3 --no-cpu-baseline --no-single --no-c4 --no-c2-c5 > $O/bench_C4T_192.json 2> /dev/null < /dev/null
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4t -- python $R/bench.py --config C4T --batch 64 --group 64 --lanes 1 --steps 10 --warmup 2 --batched-passes 10 --no-cpu-baseline --no-single > $O/bench_c4t_group_under_rocprof.json 2> /dev/null < /dev/null)
 f=$(find $O/stats_c4t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_c4t_group.csv; rm -rf $O/stats_c4t
-timeout 300 python bench/ldl_trace.py > $O/ldl_chain_timeline.txt 2>&1
+bash bench/lfac_trace.sh round > $O/lfac_timeline.txt 2>&1      # per-launch timeline of the left-looking factorisation (one dense system)
+timeout 300 python bench/lfac_items.py > $O/lfac_items.txt 2>&1
+CALIPSO_HIP_LFAC=0 timeout 300 python bench/ldl_trace.py > $O/ldl_chain_timeline.txt 2>&1      # the right-looking chain (what a group's members take), stamped build
 timeout 300 python bench/mf_trace.py > $O/mf_trace.txt 2>&1
 timeout 300 python bench/ldl_bulk_trace.py 12 > $O/ldl_bulk_trace.txt 2>&1
 bash bench/step_gaps.sh > /dev/null 2>&1; cp gpurun_out/step_gaps.txt $O/step_gaps_under_rocprof.txt

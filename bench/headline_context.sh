@@ -1,7 +1,7 @@
 #!/bin/bash
 # the headline step with and without the other instances of the default bench in the process: bash bench/headline_context.sh
 cd "$(dirname "$0")/.."
-for args in "--batch 0 --no-c4" "--batch 36 --no-c4 --batched-passes 2" "--batch 0 --no-c4" "--batch 36 --no-c4 --batched-passes 2"; do
+for args in "--batch 0 --no-c4 --no-c2-c5" "--batch 36 --no-c4 --no-c2-c5 --batched-passes 2" "--batch 0 --no-c4 --no-c2-c5" "--batch 36 --no-c4 --no-c2-c5 --batched-passes 2"; do
   for q in "" 8; do
     GPU_MAX_HW_QUEUES=$q python bench.py $args --no-cpu-baseline --steps 30 2>/dev/null | grep '^{' | tail -1 | python -c "
 import json,sys

@@ -4,9 +4,10 @@ G=${1:-12}; P=${2:-1}   # G = 0: the single-system region instead of a group
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/ldlsteps_${G}_$P; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 if [ "$G" = 0 ]; then ARGS="--batch 0 --steps 2 --warmup 1"; else ARGS="--batch $G --group $G --lanes 1 --steps 2 --warmup 1 --batched-passes 2 --no-single"; fi
+# (the right-looking schedule — CALIPSO_HIP_LFAC=0: what a group takes; one dense system alone takes the left-looking one, bench/lfac_trace.sh —
 # (the listing is taken with the finish AFTER the chain — CALIPSO_HIP_LDL_OVERLAP=0 —: under the tracer the host feeds the second stream late and the join
 # waits for it; the product's default, the finish of completed solve blocks beside the chain, is timed below without the tracer)
-CALIPSO_HIP_LDL_OVERLAP=0 CALIPSO_HIP_LDL_PAIRS=$P timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python $R/bench.py $ARGS --no-cpu-baseline --no-c4 > $O/bench.json 2> $O/err.log < /dev/null
+CALIPSO_HIP_LFAC=0 CALIPSO_HIP_LDL_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python $R/bench.py $ARGS --no-cpu-baseline --no-c4 --no-c2-c5 > $O/bench.json 2> $O/err.log < /dev/null
 f=$(find $O/tr -name "*kernel_trace.csv" | head -1)
 python - "$f" "$O/steps.txt" <<'PY'
 import csv, sys
@@ -28,7 +29,7 @@ open(sys.argv[2], "w").write("\n".join(out) + "\n")
 PY
 rm -rf $O/tr
 if [ "$G" = 0 ]; then
-  cd $R && timeout 300 python bench.py --batch 0 --no-cpu-baseline --no-c4 2>/dev/null | python -c "
+  cd $R && timeout 300 python bench.py --batch 0 --no-cpu-baseline --no-c4 --no-c2-c5 2>/dev/null | python -c "
 import json, sys
 for l in sys.stdin:
     if l.startswith('{\"metric'):

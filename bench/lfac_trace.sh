@@ -5,7 +5,7 @@ TAG=${1:-t}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/lfac_trace_$TAG -- python $R/bench.py --batch 0 --steps 4 --warmup 2 --no-cpu-baseline --no-c4 > /dev/null 2> $O/lfac_trace_$TAG.err < /dev/null
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/lfac_trace_$TAG -- python $R/bench.py --batch 0 --steps 4 --warmup 2 --no-cpu-baseline --no-c4 --no-c2-c5 > /dev/null 2> $O/lfac_trace_$TAG.err < /dev/null
 f=$(find $O/lfac_trace_$TAG -name "*kernel_trace.csv" | head -1)
 python - <<PY
 import csv

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
 for i in 1 2; do
-  python bench.py --batch 0 --no-c4 --no-cpu-baseline --steps 30 > $O/quick_${TAG}_$i.json 2> $O/quick_${TAG}_$i.err
+  python bench.py --batch 0 --no-c4 --no-c2-c5 --no-cpu-baseline --steps 30 > $O/quick_${TAG}_$i.json 2> $O/quick_${TAG}_$i.err
   python - <<PY
 import json
 d=json.loads([l for l in open("$O/quick_${TAG}_$i.json") if l.startswith("{")][-1])
@@ -16,7 +16,7 @@ print("$TAG run $i: value %.1f  ms/step %.3f  solve_and_refine %.3f  schur %.3f 
 PY
 done
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/quick_stats_$TAG -- python $R/bench.py --batch 0 --steps 10 --warmup 2 --no-cpu-baseline --no-c4 > /dev/null 2> $O/quick_stats_$TAG.err < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/quick_stats_$TAG -- python $R/bench.py --batch 0 --steps 10 --warmup 2 --no-cpu-baseline --no-c4 --no-c2-c5 > /dev/null 2> $O/quick_stats_$TAG.err < /dev/null
 f=$(find $O/quick_stats_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/quick_${TAG}_kernel_stats.csv
 rm -rf $O/quick_stats_$TAG
 python - <<PY

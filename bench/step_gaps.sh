@@ -3,14 +3,14 @@
 # (gaps above 3 us are what the host or a read-back put there).  bash bench/step_gaps.sh  ->  gpurun_out/step_gaps.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/gaps; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python $R/bench.py --batch 0 --steps 4 --warmup 2 --no-cpu-baseline --no-c4 > $O/bench.json 2> $O/err.log < /dev/null
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python $R/bench.py --batch 0 --steps 4 --warmup 2 --no-cpu-baseline --no-c4 --no-c2-c5 > $O/bench.json 2> $O/err.log < /dev/null
 f=$(find $O/tr -name "*kernel_trace.csv" | head -1)
 python - "$f" "$R/gpurun_out/step_gaps.txt" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-diag = [i for i, n in enumerate(names) if "k_ldl_diag" in n]
+diag = [i for i, n in enumerate(names) if "k_cone_weights" in n and "wide" not in n]      # one per factorisation = per Newton step here
 a, b = diag[-2], diag[-1]
 out = []; busy = 0; gaps = 0; big = 0
 prev_end = int(rows[a - 1]["End_Timestamp"])

@@ -122,7 +122,6 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
         CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         const int k = n_handles.fetch_add(1);
         int span = least - greatest;   // numerically lower = higher priority
-        if (const char* e = getenv("CALIPSO_HIP_PRIORITY_CLASSES")) { const int c = atoi(e); if (c >= 1 && c - 1 < span) span = c - 1; }   // experiments
         const int prio = span > 0 ? greatest + (k % (span + 1)) : least;
         CK(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio));
     }
@@ -247,7 +246,6 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
     for (int j = 0; j < d.n_soc; ++j)
         for (int k = 0; k < s->h_soc_dim[j]; ++k) es[s->h_soc_start[j] + k] = j;
     if (d.nc) CK(hipMemcpy(s->cone.entry_soc, es.data(), sizeof(int) * d.nc, hipMemcpyHostToDevice));
-    if (const char* g = getenv("CALIPSO_HIP_GRAPHS")) s->use_graphs = atoi(g) != 0;
     s->hpoint.assign(N, 0.0);
     s->hparams.assign((size_t)d.np, 0.0);
     Options& o = s->opt;

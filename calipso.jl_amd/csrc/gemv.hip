@@ -176,8 +176,7 @@ static Sparsity sparsity_of(const calipso_hip_solver* s, int kind) {
 
 // the vector(s) of a transposed product staged in LDS by every workgroup (dense blocks; what fits the 48 KB a kernel gets without asking)
 static int gemv_lds_x(size_t bytes) {
-    static const int env = [] { const char* e = getenv("CALIPSO_HIP_GEMV_LDS_X"); return e ? atoi(e) : 1; }();
-    return env && bytes <= 48 * 1024 ? 1 : 0;
+    return bytes <= 48 * 1024 ? 1 : 0;
 }
 void gemv_t(calipso_hip_solver* s, int rows, int cols, const double* A, int ld, const double* x, double* y, double alpha, double beta, int kind, const double* add) {
     if (cols == 0) return;

@@ -287,77 +287,10 @@ __global__ __launch_bounds__(TR_THREADS) void k_ldl_step(Batch bt, int NP, int n
 
 // ---- inverses of the (up to) 1024 x 1024 diagonal blocks from the 64 x 64 ones -----------------------------------------------------------
 // inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1  C^-1].  Level 1 joins 64-blocks into 128-blocks, level 2 joins 128-blocks into
-// 256-blocks, ... level 4 joins 512-blocks into 1024-blocks (a trailing 512-block of NP stays as it is).  Each level is two launches of the same 64 x 64-output-tile GEMM (T = B * A^-1, then X21 = -C^-1 * T).
-// C_tile(64 x 64) = alpha * A(64 x K) * B(K x 64), K <= 128, operands staged whole in LDS, 1024 threads (16 wavefronts, one
-// 16 x 16 MFMA tile each).
-struct GemmDesc { const double* A; int lda; const double* B; int ldb; double* C; int ldc; };
-
-// k runs over [kbeg, kend) only (multiples of 64): the triangular operand of a merge is zero outside that range
-__device__ __forceinline__ void gemm_tile64(const GemmDesc g, int kbeg, int kend, double alpha, double* smem) {
-    constexpr int KC = 128;                 // K chunk held in LDS
-    double* As = smem;                      // As[i][k], ld KC+2
-    double* Bs = smem + 64 * (KC + 2);      // Bs[j][k]
-    const int ldk = KC + 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 2, wj = wave & 3;
-    const int fr = lane & 15, fk = lane >> 4;
-    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    for (int kc = kbeg; kc < kend; kc += KC) {
-        const int kn = (kend - kc) < KC ? (kend - kc) : KC;
-        __syncthreads();
-        for (int idx = tid; idx < 64 * kn; idx += 1024) {
-            const int i = idx & 63, kk = idx >> 6;            // A column-major: lanes along i (contiguous)
-            As[i * ldk + kk] = g.A[i + (size_t)(kc + kk) * g.lda];
-        }
-        for (int idx = tid; idx < 64 * kn; idx += 1024) {
-            const int kk = idx % kn, j = idx / kn;            // B column-major: lanes along k (contiguous)
-            Bs[j * ldk + kk] = g.B[(kc + kk) + (size_t)j * g.ldb];
-        }
-        __syncthreads();
-        for (int kk = 0; kk < kn / 4; ++kk) {
-            const double a = As[(wi * 16 + fr) * ldk + kk * 4 + fk];
-            const double b = Bs[(wj * 16 + fr) * ldk + kk * 4 + fk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc, 0, 0, 0);   // transposed: row <-> j, col <-> i
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int j = wj * 16 + fk + 4 * r, i = wi * 16 + fr;
-        g.C[i + (size_t)j * g.ldc] = alpha * acc[r];
-    }
-}
-
-// level 1 .. 5: half = 64, 128, 256, 512, 1024; phase 0: T = L21 * X11 ; phase 1: X21 = -X22 * T
-__global__ __launch_bounds__(1024) void k_tinv_merge(Batch bt, int NP, int tb, int half, int phase, const double* __restrict__ S, double* __restrict__ Tinv,
-                                                      double* __restrict__ Ttmp) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    inst_shift(bt, S, Tinv, Ttmp);
-    const int tiles = half / 64;                 // tiles per side of the half x half result
-    const int pair = blockIdx.x / (tiles * tiles);
-    const int tt = blockIdx.x % (tiles * tiles);
-    const int tiy = tt / tiles, tjx = tt % tiles;
-    const int g0 = pair * 2 * half;              // first row/col of the pair in the global numbering
-    const int q = g0 / tb, o = g0 % tb;
-    double* T = Tinv + (size_t)q * tb * tb;
-    double* tmp = Ttmp + (size_t)pair * half * half;
-    GemmDesc g;
-    if (phase == 0) {        // tmp(half x half) = L21 * X11
-        g.A = S + (g0 + half + tiy * 64) + (size_t)g0 * NP; g.lda = NP;
-        g.B = T + o + (size_t)(o + tjx * 64) * tb; g.ldb = tb;
-        g.C = tmp + tiy * 64 + (size_t)(tjx * 64) * half; g.ldc = half;
-        gemm_tile64(g, tjx * 64, half, 1.0, smem);          // X11 is lower triangular: rows k < 64 tjx of its column tile are zero
-    } else {                 // X21 = -X22 * tmp
-        g.A = T + (o + half + tiy * 64) + (size_t)(o + half) * tb; g.lda = tb;
-        g.B = tmp + (size_t)(tjx * 64) * half; g.ldb = half;
-        g.C = T + (o + half + tiy * 64) + (size_t)(o + tjx * 64) * tb; g.ldc = tb;
-        gemm_tile64(g, 0, (tiy + 1) * 64, -1.0, smem);      // X22 is lower triangular: columns k >= 64 (tiy + 1) of its row tile are zero
-    }
-}
-
-// The same merge with 32 x 32 output tiles and 256 threads (4 wavefronts, one 16 x 16 MFMA tile each).  A 64 x 64 tile keeps ONE CU's matrix cores busy
-// for 64 cycles per k (13.6 us at K = 512) and the levels have 20 .. 128 such tiles: the launch lasts as long as its longest tile.  Four times as many
-// tiles of a quarter of the work spread over four times as many CUs, and eight 256-thread workgroups per CU hide each other's load latency (the K loop
-// is load -> barrier -> MFMA -> barrier, no double buffering).  Same k order per output entry as the 64 x 64 version (the skipped k ranges are exact zeros).
+// 256-blocks, ... level 4 joins 512-blocks into 1024-blocks (a trailing 512-block of NP stays as it is).  Each level is two launches of one small matrix-core GEMM
+// (T = B * A^-1, then X21 = -C^-1 * T) with 32 x 32 output tiles and 256 threads (4 wavefronts, one 16 x 16 MFMA tile each): many small tiles spread over the
+// compute units and eight workgroups per unit hide each other's load latency (round 2's 64 x 64 tiles — 13.6 us for one tile at K = 512 — lasted as long as their
+// longest tile).  The skipped k ranges are exact zeros of the triangular operand.
 // C(32 x 32) = alpha * A(32 x K) * B(K x 32) over k in [kbeg, kend) (multiples of 32), 256 threads; As / Bs: 32 * 66 doubles of LDS each
 __device__ __forceinline__ void merge32_tile(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, double* __restrict__ Cc, int ldc, int kbeg, int kend,
                                              double alpha, double* __restrict__ As, double* __restrict__ Bs) {
@@ -556,6 +489,12 @@ __global__ void k_publish_inertia(const int* __restrict__ icount, int* __restric
 }
 // second stream + events + progress word of the handle (created on first use; lowest priority: the pivot chain's workgroups are scheduled first.  Confining it
 // to a quarter of the compute units — hipExtStreamCreateWithCUMask — changed nothing: the chain's workgroup does not wait for a CU)
+// CALIPSO_HIP_GRAPH_LDL=1: the panel steps and the finish as captured graphs on ONE stream (no second stream, no left-looking schedule): the reference point of
+// tests/test_gpu_ldl_overlap.py
+static bool graph_ldl_requested() {
+    static const bool env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();
+    return env;
+}
 static bool side_stream(calipso_hip_solver* s) {
     if (s->stream2) return s->hprog_dev != nullptr && s->ev_side[7] != nullptr;
     // (lowest priority.  A CU mask — hipExtStreamCreateWithCUMask, half / three quarters / 15 of 16 of the compute units — is accepted and changes
@@ -587,14 +526,11 @@ static void ldl_plan_ranges(calipso_hip_solver* s);
 // Which finish work runs beside the chain: one instance alone, dense S, a solve block that is complete before the chain ends (otherwise nothing to overlap)
 static bool ldl_overlap(calipso_hip_solver* s) {
     static const int env = [] { const char* e = getenv("CALIPSO_HIP_LDL_OVERLAP"); return e ? atoi(e) : 1; }();
-    static const bool graph_ldl_env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();   // (captured graphs: one stream, no overlap)
-    // (groups: measured — one group of 12 alone 952 -> 962 steps/s, three groups in flight 1098 -> 1086: the other groups already fill the chain's idle time,
-    // and the finish as 60 small launches per group costs them more than the overlap gives; off unless asked for)
-    static const int group_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_OVERLAP_GROUPS"); return e ? atoi(e) : 0; }();
-    if (!env || graph_ldl_env || (s->cur && !group_env) || s->band64 > 0) return false;
+    // (groups: measured in round 4 — one group of 12 alone 952 -> 962 steps/s, three groups in flight 1098 -> 1086: the other groups already fill the chain's idle
+    // time, and the finish as 60 small launches per group costs them more than the overlap gives: groups keep one stream)
+    if (!env || graph_ldl_requested() || s->cur || s->band64 > 0) return false;
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block);
-    static const bool merge64 = [] { const char* e = getenv("CALIPSO_HIP_MERGE64"); return e && atoi(e) != 0; }();
-    if (merge64 || NP < 1024 || NP > 8192 || tb < 256) return false;
+    if (NP < 1024 || NP > 8192 || tb < 256) return false;
     return true;
 }
 
@@ -610,15 +546,12 @@ static void enqueue_ldl_steps(calipso_hip_solver* s) {
     // persistent workgroups: one is resident per CU (registers, LDS): 248 workers + the workgroups that carry the diagonal blocks = everything resident
     // at once, 31 + 1 per XCD for one instance.  Since round 3's diagonal block (19 us) the early launches of ONE instance are bound by the trailing update,
     // and a second wave of workgroups costs 5 us per launch (21.5 against 26.4 us at 512); a group of 12 gains 2 % (2.50 against 2.56 ms per factorisation).
-    static const int resident_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_RESIDENT"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
-    const int resident_total = resident_env ? resident_env : 248;
-    const int resident = std::max(2, resident_total / (int)nz);
+    const int resident = std::max(2, 248 / (int)nz);
     // Pair schedule (dense S, several instances per launch): the first tile column of panel k's update (whose tile 0 factors diagonal block
     // k + 1), then BOTH panels in one pass over the rest.  Same arithmetic as the plain schedule (k_ldl_step, MODE 2), half
     // the read-modify-write traffic on the trailing matrix; one instance alone is bound by the pivot chain, not by traffic, and keeps the
     // plain schedule (one launch per panel).
-    static const int pairs_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_PAIRS"); return e ? atoi(e) : -1; }();
-    const bool pairs = s->band64 == 0 && (pairs_env >= 0 ? pairs_env != 0 : nz >= 4);
+    const bool pairs = s->band64 == 0 && nz >= 4;
     // flattened XCD-aware grid: one workgroup per instance for tile 0 (+ the diagonal block), then workers in multiples of 8 plus 7, so that
     // every XCD (workgroup index mod 8) has at least one worker for its share of the tile list; surplus workgroups leave at once
     auto grid = [&](int tiles) { const int workers = std::min(std::max(tiles - 1, 0), resident) * (int)nz; return dim3(nz + (workers ? (workers + 7) / 8 * 8 + 7 : 0)); };
@@ -690,15 +623,11 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
         const int maxrows = std::min(NP - NB, band * NB);
         hipLaunchKernelGGL(k_ldl_scale, dim3(maxrows / 64, nblk - 1, nz), dim3(1024), 0, s->stream, bt, NP, tb, band * NB, 0, s->S, s->Lf, s->Dx, s->Tinv);
     }
-    const size_t mg_lds = 2 * 64 * (128 + 2) * sizeof(double);
     for (int level = 1; level <= 5; ++level) {
         const int half = 32 << level, tiles = half / 64, pairs = NP / (2 * half);
         if (2 * half > tb) break;
-        static const bool merge64 = [] { const char* e = getenv("CALIPSO_HIP_MERGE64"); return e && atoi(e) != 0; }();
-        for (int phase = 0; phase < 2; ++phase) {
-            if (merge64) hipLaunchKernelGGL(k_tinv_merge, dim3(pairs * tiles * tiles, 1, nz), dim3(1024), mg_lds, s->stream, bt, NP, tb, half, phase, s->Lf, s->Tinv, s->Ttmp);
-            else hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles * 4, 1, nz), dim3(256), 0, s->stream, bt, NP, tb, half, phase, 0, s->Lf, s->Tinv, s->Ttmp);
-        }
+        for (int phase = 0; phase < 2; ++phase)
+            hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles * 4, 1, nz), dim3(256), 0, s->stream, bt, NP, tb, half, phase, 0, s->Lf, s->Tinv, s->Ttmp);
     }
     if (wform_on(s)) for (int kb = 0; kb * tb < NP; ++kb) enqueue_wform(s, s->stream, kb);
     enqueue_lastblock_sym(s, s->stream);
@@ -720,7 +649,7 @@ static void enqueue_ldl_finish(calipso_hip_solver* s) {
 // 128, 256 columns 0.868 / 2.418, 0.872 / 2.417, 0.868 / 2.422 (whole solve blocks of 1024: 0.889 / 2.43); with 2048-wide solve blocks 0.93-0.96 / 2.415-2.445:
 // the second phase of the 1024 -> 2048 merge and the right edge below it arrive together after step 31 and the second stream runs late, which costs
 // the factorisation what the six-launch solves save (solve + refinement 0.78 against 0.84 ms) — opt.solve_block stays 1024.
-static const int FEED = [] { const char* e = getenv("CALIPSO_HIP_LDL_FEED"); const int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 256; }();
+constexpr int FEED = 256;
 static size_t merge_scratch(int NP, int half) { return (size_t)NP * (size_t)(half - 64) / 2; }   // a level holds NP / (2 half) products of half x half = NP half / 2 doubles; the levels below: NP (32 + 64 + ... + half / 4); all five: NP * 992
 static void enqueue_merge(calipso_hip_solver* s, hipStream_t stream, int half, int phase, int pair0, int pairs) {
     const int NP = s->d.NP, tb = trsv_block(NP, (int)s->solve_block), tiles = half / 32;
@@ -728,7 +657,7 @@ static void enqueue_merge(calipso_hip_solver* s, hipStream_t stream, int half, i
     hipLaunchKernelGGL(k_tinv_merge32, dim3(pairs * tiles * tiles, 1, bt.n), dim3(256), 0, stream, bt, NP, tb, half, phase, pair0, s->Lf, s->Tinv, s->Ttmp + merge_scratch(NP, half));
 }
 // workgroups of the W-form product beside the chain (k_wform_product64): it is handed over once the trailing update has shrunk enough to leave them their compute units
-static const int WFORM_WGS = [] { const char* e = getenv("CALIPSO_HIP_WFORM_WGS"); const int v = e ? atoi(e) : 128; return v >= 8 && v <= 240 ? v : 128; }();
+constexpr int WFORM_WGS = 128;
 static void ldl_plan_ranges(calipso_hip_solver* s) {
     const int NP = s->d.NP, nblk = NP / NB, tb = trsv_block(NP, (int)s->solve_block);
     s->ldl_ranges.clear();
@@ -1137,9 +1066,6 @@ static void enqueue_trsv(calipso_hip_solver* s, double* x) {
 // The factorisation of S and the triangular solves are fixed kernel sequences with fixed arguments (118 and 18 launches):
 // they are captured once per handle into hipGraphs and replayed, so the host issues one graph launch instead of queueing every
 // kernel (the GPU otherwise waits on the host between the many few-microsecond kernels).
-void ldl_set_attributes() {
-    (void)lds_attribute((const void*)k_tinv_merge, (int)(2 * 64 * (128 + 2) * sizeof(double)));      // > 64 KiB of dynamic LDS must be requested explicitly, on every device
-}
 
 template <typename F>
 static bool replay_or_capture(calipso_hip_solver* s, hipGraphExec_t& exec, bool& tried, F enqueue) {
@@ -1177,8 +1103,7 @@ void ldl_drop_graphs(calipso_hip_solver* s) {       // the captured launch seque
 // k_schur leaves free instead of between the factorisation and the first solve.  nullptr: no such stream — the operands are formed where they always were.
 hipStream_t ldl_rhs_stream(calipso_hip_solver* s) {
     static const bool env = [] { const char* e = getenv("CALIPSO_HIP_RHS_AHEAD"); return !e || atoi(e) != 0; }();
-    static const bool graph_ldl_env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();
-    if (!env || s->cur || s->compact || (s->stage_parallel && s->spS) || (s->use_graphs && graph_ldl_env)) return nullptr;
+    if (!env || s->cur || s->compact || (s->stage_parallel && s->spS) || (s->use_graphs && graph_ldl_requested())) return nullptr;
     if (!ldl_overlap(s) || !side_stream(s)) return nullptr;
     return s->stream2;
 }
@@ -1203,13 +1128,11 @@ void launch_ldl(calipso_hip_solver* s) {
         launch_pad_identity(s);               // launch_schur skipped the padding of S for the multifrontal path: the blocked one needs its unit pivots
     }
     s->Lf = lfac_factor_buffer(s);        // where this factorisation's factor columns go: S (scaled in place) or, under the left-looking schedule, lfac.hip's buffer
-    ldl_set_attributes();
     // (a group launch covers a changing set of instances: its kernel arguments differ from call to call, so no graph there)
     // The panel steps are queued launch by launch (the host keeps ahead of a 20 us chain: 0.935 ms per factorisation at C3 against 0.950 as a captured graph), which
     // also lets the host hand the completed solve blocks to the second stream while the chain runs (below): 0.889 ms.  CALIPSO_HIP_GRAPH_LDL=1 brings the
     // graphs back (one stream, no overlap); the solves keep theirs (launch_trsv).
-    static const bool graph_ldl_env = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();
-    const bool graphs = !s->cur && s->use_graphs && graph_ldl_env;
+    const bool graphs = !s->cur && s->use_graphs && graph_ldl_requested();
     if (ldl_overlap(s)) (void)side_stream(s);       // (created outside a stream capture)
     static const bool pub_env = [] { const char* e = getenv("CALIPSO_HIP_LDL_PUBLISH"); return !e || atoi(e) != 0; }();     // (experiment switch)
     s->ldl_publish = pub_env && !graphs && !s->cur;       // (a captured launch would replay a stale sequence number)

@@ -401,15 +401,15 @@ static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W,
         const double target = ell == -2 ? head : budget;
         double used = 0.0;
         if (ell >= 0) {
-            if (T(ell + 1, ell + 1).st != nst || T(ell + 1, ell + 1).pn != ell) { if (getenv("CALIPSO_HIP_LFAC_DEBUG")) fprintf(stderr, "plan: chain tile of launch %d: st %d pn %d\n", ell, T(ell + 1, ell + 1).st, T(ell + 1, ell + 1).pn); return false; }
+            if (T(ell + 1, ell + 1).st != nst || T(ell + 1, ell + 1).pn != ell) return false;
             T(ell + 1, ell + 1).pn = ell + 1;                                         // the chain's tile
             for (int i = ell + 2; i < nblk; ++i) {
                 Tile& t1 = T(i, ell + 1);
-                if (t1.st != nst || t1.pn != ell) { if (getenv("CALIPSO_HIP_LFAC_DEBUG")) fprintf(stderr, "plan: launch %d row %d first tile: st %d pn %d\n", ell, i, t1.st, t1.pn); return false; }
+                if (t1.st != nst || t1.pn != ell) return false;
                 t1.pn = ell + 1;
                 LItem it{}; it.kind = LI_ROW; it.i = (short)i; it.j = (short)ell; it.c = 1;
                 Tile& t2 = T(i, ell + 2);
-                if (t2.st != nst) { if (getenv("CALIPSO_HIP_LFAC_DEBUG")) fprintf(stderr, "plan: launch %d row %d second tile: st %d\n", ell, i, t2.st); return false; }
+                if (t2.st != nst) return false;
                 it.a = (short)t2.pn;
                 const double c = cost_row(ell - t2.pn);
                 t2.pn = ell + 1;
@@ -553,8 +553,6 @@ static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W,
     return true;
 }
 
-static const double LFAC_BUDGET = [] { const char* e = getenv("CALIPSO_HIP_LFAC_BUDGET"); const double v = e ? atof(e) : 19.0; return v >= 8.0 && v <= 200.0 ? v : 19.0; }();      // us per panel launch
-static const double LFAC_HEAD = [] { const char* e = getenv("CALIPSO_HIP_LFAC_HEAD"); const double v = e ? atof(e) : 0.0; return v >= 0.0 && v <= 1000.0 ? v : 0.0; }();         // us of launch -2 (0: whole tiles)
 
 // what the plan's own cost model says the launches take: the head as long as its longest worker, a panel launch at least as long as the chain's workgroup
 static double lfac_plan_estimate(const LfacPlan& P) {
@@ -563,13 +561,12 @@ static double lfac_plan_estimate(const LfacPlan& P) {
     return e;
 }
 // The launch length (budget) and the head are chosen by the model (it reproduces the measured timeline within a few percent: profiles/r05_lfac_timeline.txt): a scan
-// of both, unless the environment pins them.  The planner costs a few milliseconds per candidate, once per handle.
+// of both (a fixed pair can be tried through calipso_hip_debug_lfac_plan / bench/lfac_plan.py).  The planner costs a few milliseconds per candidate, once per handle.
 static bool lfac_best_plan(LfacPlan& best, int nblk, int nx, int ne, int nc, int W) {
-    const bool pin_b = getenv("CALIPSO_HIP_LFAC_BUDGET") != nullptr, pin_h = getenv("CALIPSO_HIP_LFAC_HEAD") != nullptr;
     bool have = false;
     double best_e = 0.0;
-    for (double b = pin_b ? LFAC_BUDGET : 19.0; b <= (pin_b ? LFAC_BUDGET : 40.0); b += 1.5) {
-        for (double h = pin_h ? LFAC_HEAD : 50.0; h <= (pin_h ? LFAC_HEAD : 130.0); h += 10.0) {
+    for (double b = 19.0; b <= 40.0; b += 1.5) {
+        for (double h = 50.0; h <= 130.0; h += 10.0) {
             for (int margin : {1 << 20, 3, 2, 1, 0}) {
                 LfacPlan P;
                 if (!lfac_make_plan(P, nblk, nx, ne, nc, W, b, h, margin)) continue;

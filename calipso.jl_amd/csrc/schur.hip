@@ -566,8 +566,7 @@ void launch_schur(calipso_hip_solver* s) {
     const int nj = (B.b.n == 1 && hb == 0) ? s->schur_nj : schur_choose(s->d.nx, B.b.n, hb);
     const int ntiles = schur_tiles(s->d.nx, nj, hb);
     // every XCD gets ceil(n ntiles / 8) workgroups: enough for its share [k G / 8, (k + 1) G / 8) of the list
-    static const int flat_env = [] { const char* e = getenv("CALIPSO_HIP_SCHUR_FLAT"); return e ? atoi(e) : -1; }();
-    const int flat = flat_env >= 0 ? flat_env : 1;
+    const int flat = 1;      // (one flattened grid over all instances; the per-instance grid rows of round 2 remain in the kernel for z-launches)
     const int grid = flat ? (int)(((long long)B.b.n * ntiles + 7) / 8 + 1) * 8 : ((ntiles + 7) / 8) * 8;
     if (!(s->stage_parallel && s->spS) && !s->pad_done) launch_pad_identity(s);   // (the multifrontal path reads S only inside its nx x nx pattern; k_scale_rows may have written the padding already)
     s->pad_done = false;

@@ -236,7 +236,7 @@ int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_
     int rc = calipso_hip_sparse_create(nx, colptr.data(), rowval.data(), 4, nullptr, s->device, &sp);
     int64_t desc[4] = {0, 0, 0, 0};
     if (rc == CALIPSO_OK && sp) sparse_describe(sp, desc);
-    static const int64_t max_front = [] { const char* e = getenv("CALIPSO_HIP_STAGE_PARALLEL_MAXFRONT"); return e ? (int64_t)atoi(e) : (int64_t)196; }();
+    const int64_t max_front = 196;
     if (rc != CALIPSO_OK || !sparse_is_multifrontal(sp) || desc[1] > max_front) {    // (default: LDS-resident fronts only)
         s->err = rc != CALIPSO_OK ? std::string("calipso_hip_set_stage_parallel: ") + calipso_hip_sparse_last_error(sp)
                                   : std::string("calipso_hip_set_stage_parallel: a front of the dissection of S exceeds one CU's LDS (196 rows): the blocked factorisation stays");

@@ -2,7 +2,8 @@
 the Schur complement as slices of the panel launches, deferred trailing updates; CALIPSO_HIP_LFAC=0: k_schur + the right-looking panel steps a group takes).  By default the finish of the factorisation (factor columns + merges of the
 inverse blocks) of the completed solve blocks runs on a second stream while the pivot chain goes on, fed by the host from a progress word, and the
 inertia counts are published right behind the chain (csrc/ldl.hip: launch_ldl); CALIPSO_HIP_LDL_OVERLAP=0 / CALIPSO_HIP_LDL_PUBLISH=0 /
-CALIPSO_HIP_GRAPH_LDL=1 select the one-stream schedules.  The switches are read once per process, so every variant runs in a process of its own;
+CALIPSO_HIP_GRAPH_LDL=1 select the one-stream schedules.  These, CALIPSO_HIP_RHS_AHEAD, CALIPSO_HIP_SPEC_REFINE (here), CALIPSO_HIP_LASTBLOCK_SYM (test_gpu_wform.py) and
+CALIPSO_HIP_SOLVE_TAIL (below, to rounding) are ALL the environment switches of the library.  The switches are read once per process, so every variant runs in a process of its own;
 the Newton steps they take must agree bit for bit (same kernels, same operands, only the order in time of independent launches differs)."""
 import hashlib
 import os
@@ -51,9 +52,9 @@ def test_newton_steps_do_not_depend_on_the_schedule_of_the_factorisation():
     ref = run_variant({})
     for env in ({"CALIPSO_HIP_LFAC": "0"},                # k_schur + the right-looking panel steps instead of the left-looking schedule of csrc/lfac.hip: the same operations per entry in the same order
                 {"CALIPSO_HIP_LFAC": "0", "CALIPSO_HIP_LDL_OVERLAP": "0"},
-                {"CALIPSO_HIP_LDL_OVERLAP": "0"}, {"CALIPSO_HIP_LDL_PUBLISH": "0"}, {"CALIPSO_HIP_GRAPH_LDL": "1"}, {"CALIPSO_HIP_LDL_FEED": "64"},
-                {"CALIPSO_HIP_WFORM_WGS": "64"},
-                {"CALIPSO_HIP_RHS_AHEAD": "0"}):          # the operands of the first condensed solve on the main stream behind the factorisation instead of on the second stream beside k_schur
+                {"CALIPSO_HIP_LDL_OVERLAP": "0"}, {"CALIPSO_HIP_LDL_PUBLISH": "0"}, {"CALIPSO_HIP_GRAPH_LDL": "1"},
+                {"CALIPSO_HIP_RHS_AHEAD": "0"},           # the operands of the first condensed solve on the main stream behind the factorisation instead of on the second stream
+                {"CALIPSO_HIP_SPEC_REFINE": "0"}):        # refinement rounds one by one, a host wait each, instead of queued ahead behind a device-side gate: same kernels, same order
         assert run_variant(env) == ref, env
 
 
@@ -62,6 +63,25 @@ def test_schedule_independence_holds_for_other_solve_block_widths(solve_block):
     """opt.solve_block = 2048: a solve block of two 1024-wide halves whose joining merge is split over two hand-overs (first phase with the left half,
     second with the right one); 512: more, narrower blocks.  NP = 2112 is 2048 + 64 / 4 x 512 + 64: the last block is a single panel."""
     sb = {"CHILD_SOLVE_BLOCK": str(solve_block)}
-    ref = run_variant(dict(sb, CALIPSO_HIP_LDL_OVERLAP="0"))
-    for env in ({}, {"CALIPSO_HIP_LDL_FEED": "64"}, {"CALIPSO_HIP_LDL_FEED": "1024"}):
+    ref = run_variant(dict(sb, CALIPSO_HIP_LDL_OVERLAP="0", CALIPSO_HIP_LFAC="0"))
+    for env in ({}, {"CALIPSO_HIP_LFAC": "0"}, {"CALIPSO_HIP_LDL_OVERLAP": "0"}):
         assert run_variant(dict(sb, **env)) == ref, (solve_block, env)
+
+
+def test_separate_solve_tail_kernels_agree_with_the_fused_launch():
+    """CALIPSO_HIP_SOLVE_TAIL=0: t2 = [gx; hx] dx, the back-substitution, the recovery and the local rows of the next refinement residual as separate launches
+    instead of k_solve_tail: the same quantities in another summation order — the steps agree to rounding, the round counts are the same"""
+    child = CHILD.replace('out.append(hashlib.sha256(np.ascontiguousarray(s.data("step").all).tobytes()).hexdigest())', 'np.save(os.environ["CHILD_OUT"] + "_%d_%d.npy" % (pid, it), s.data("step").all)')
+    import tempfile
+    import numpy as np
+    with tempfile.TemporaryDirectory() as d:
+        outs = {}
+        for tag, env in (("fused", {}), ("separate", {"CALIPSO_HIP_SOLVE_TAIL": "0"})):
+            e = dict(os.environ); e.update(env); e["CHILD_OUT"] = os.path.join(d, tag)
+            r = subprocess.run([sys.executable, "-c", child % {"root": ROOT}], env=e, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[tag] = r.stdout
+        for pid in (41, 42):
+            for it in range(2):
+                a = np.load(os.path.join(d, "fused_%d_%d.npy" % (pid, it))); b = np.load(os.path.join(d, "separate_%d_%d.npy" % (pid, it)))
+                assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max()), (pid, it)
