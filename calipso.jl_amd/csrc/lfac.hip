@@ -374,6 +374,7 @@ struct LfacAux {
 // cost model (microseconds on one compute unit while the whole chip is busy: the fp64 matrix cores sustain ~41 TFLOP/s on real data, 161 GFLOP/s per unit — a
 // 64 x 64 x 64 product 3.3 us, a Schur stage 1.64 us; bench/lfac_item_bench.hip): what balances the workers of a launch against the chain's workgroup
 constexpr double LFAC_CHAIN_US = 19.4;      // what the chain's workgroup makes a panel launch last at least (C3: profiles/r05_lfac_timeline.txt)
+constexpr double LFAC_LAUNCH_US = 2.8;      // a launch whose workers all carry items lasts its longest worker + this (boundary, dispatch skew): items no longer than LFAC_CHAIN_US - this ride for free
 static double cost_schur(int stages, int P = 1) { return (P == 1 ? 1.52 : P == 2 ? 1.05 : 0.8) * stages + 3.3; }      // (measured: bench/lfac_items.py, less the launch boundary)
 static double cost_far(int panels) { return 3.1 * panels + 2.5; }
 static double cost_row(int pending) { return 15.0 + 2.2 * pending; }
@@ -417,7 +418,7 @@ static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W,
             }
         }
         // Deferred panels: a tile takes at most per_item a launch; `behind` ones whatever the load, the others where workers are left over (below)
-        const int per_item = std::max(1, (int)((LFAC_CHAIN_US - 2.5) / 3.1));     // (sized for the chain's workgroup, not for the launch: behind the constraint products the launches are as short as the chain)
+        const int per_item = std::max(1, (int)((LFAC_CHAIN_US - LFAC_LAUNCH_US - 2.5) / 3.1));     // (sized for the chain's workgroup, not for the launch: behind the constraint products the launches are as short as the chain)
         std::vector<std::pair<int, int>> far_optional;
         for (const auto& ij : order) {
             const int i = ij.first, j = ij.second, D = deadline(i, j);
@@ -459,7 +460,7 @@ static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W,
             if (ell != -2) {
                 int most = 0;
                 for (const Cand& c : cand) most = std::max(most, c.needed);
-                len = std::min(target, std::max(LFAC_CHAIN_US, cost_schur(most)));
+                len = std::min(target, std::max(LFAC_CHAIN_US - LFAC_LAUNCH_US, cost_schur(most)));
             }
             // a tile that needs more stages than one workgroup gives it in a launch of this length is split over 2 or 4 workgroups (rows of the tile; the kernel's
             // it.pad0 / it.pad1) — a few urgent tiles do not stretch the launch for everybody; only beyond that the launch gets longer
@@ -557,7 +558,7 @@ static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W,
 // what the plan's own cost model says the launches take: the head as long as its longest worker, a panel launch at least as long as the chain's workgroup
 static double lfac_plan_estimate(const LfacPlan& P) {
     double e = P.load.empty() ? 0.0 : P.load[0];
-    for (size_t l = 1; l < P.load.size(); ++l) e += std::max(P.load[l], LFAC_CHAIN_US);
+    for (size_t l = 1; l < P.load.size(); ++l) e += std::max(P.load[l] + LFAC_LAUNCH_US, LFAC_CHAIN_US);
     return e;
 }
 // The launch length (budget) and the head are chosen by the model (it reproduces the measured timeline within a few percent: profiles/r05_lfac_timeline.txt): a scan

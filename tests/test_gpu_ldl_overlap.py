@@ -71,7 +71,7 @@ def test_schedule_independence_holds_for_other_solve_block_widths(solve_block):
 def test_separate_solve_tail_kernels_agree_with_the_fused_launch():
     """CALIPSO_HIP_SOLVE_TAIL=0: t2 = [gx; hx] dx, the back-substitution, the recovery and the local rows of the next refinement residual as separate launches
     instead of k_solve_tail: the same quantities in another summation order — the steps agree to rounding, the round counts are the same"""
-    child = CHILD.replace('out.append(hashlib.sha256(np.ascontiguousarray(s.data("step").all).tobytes()).hexdigest())', 'np.save(os.environ["CHILD_OUT"] + "_%d_%d.npy" % (pid, it), s.data("step").all)')
+    child = CHILD.replace('out.append(hashlib.sha256(np.ascontiguousarray(s.data("step").all).tobytes()).hexdigest())', 'np.save(os.environ["CHILD_OUT"] + "_" + str(pid) + "_" + str(it) + ".npy", s.data("step").all)')
     import tempfile
     import numpy as np
     with tempfile.TemporaryDirectory() as d:
