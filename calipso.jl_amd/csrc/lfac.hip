@@ -374,7 +374,7 @@ struct LfacAux {
 // cost model (microseconds on one compute unit while the whole chip is busy: the fp64 matrix cores sustain ~41 TFLOP/s on real data, 161 GFLOP/s per unit — a
 // 64 x 64 x 64 product 3.3 us, a Schur stage 1.64 us; bench/lfac_item_bench.hip): what balances the workers of a launch against the chain's workgroup
 constexpr double LFAC_CHAIN_US = 19.4;      // what the chain's workgroup makes a panel launch last at least (C3: profiles/r05_lfac_timeline.txt)
-constexpr double LFAC_LAUNCH_US = 2.8;      // a launch whose workers all carry items lasts its longest worker + this (boundary, dispatch skew): items no longer than LFAC_CHAIN_US - this ride for free
+constexpr double LFAC_LAUNCH_US = 0.0;      // (a launch whose workers all carry items lasts its longest worker + ~2.8 us of boundary and dispatch skew; pricing it — 1.4, 2.8 — made the scan choose plans that MEASURE 1-2 % slower: 1.105 / 1.12 ms against 1.095, so the scan keeps the bare model)
 static double cost_schur(int stages, int P = 1) { return (P == 1 ? 1.52 : P == 2 ? 1.05 : 0.8) * stages + 3.3; }      // (measured: bench/lfac_items.py, less the launch boundary)
 static double cost_far(int panels) { return 3.1 * panels + 2.5; }
 static double cost_row(int pending) { return 15.0 + 2.2 * pending; }
