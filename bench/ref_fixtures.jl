@@ -122,6 +122,52 @@ function run_kat(name)
     println("wrote ", joinpath(GOLDEN, "ref_" * name * ".txt"))
 end
 
+# search_direction! as a whole (search_direction.jl:1-23) from the default regularisation start: the cases whose answers no closed form of test/solver/problem.jl holds —
+# the IC-1 .. IC-6 sequence of inertia_correction! (inertia.jl:30-80) on a non-convex Hessian, and a second-order cone of dimension 12 (test/solver/portfolio.jl:33-62)
+# going through the condensed blocks, the triu-only factorisation and the refinement.  Inputs: tests/golden/<name>_inputs.txt (make_golden.py: kat_search_direction).
+function run_search_direction(name)
+    d = read_records(joinpath(GOLDEN, name * "_inputs.txt"))
+    P, q, A, b, G, h = d["P"], vec(d["q"]), d["A"], vec(d["b"]), d["G"], vec(d["h"])
+    nx = length(q)
+    scale = d["objective_scale"][1]
+    nonneg = Int.(vec(d["nonnegative_indices"]))
+    ptr = Int.(vec(d["second_order_ptr"]))
+    flat = Int.(vec(d["second_order_indices"]))
+    soc = [flat[ptr[k]+1:ptr[k+1]] for k in 1:length(ptr)-1]
+    isempty(soc) && (soc = [Int[]])
+    objective(z) = scale * (transpose(z) * P * z) + transpose(q) * z
+    equality(z) = A * z - b
+    cone(z) = h - G * z
+    solver = Solver(objective, equality, cone, nx; nonnegative_indices=nonneg, second_order_indices=soc)
+    solver.solution.all .= vec(d["w"])
+    solver.central_path .= d["central_path"][1]; solver.penalty .= d["penalty"][1]; solver.dual .= vec(d["dual"])
+    solver.fraction_to_boundary[1] = d["fraction_to_boundary"][1]
+    solver.primal_regularization[1] = 0.0; solver.primal_regularization_last[1] = 0.0; solver.dual_regularization[1] = 0.0
+    idx = solver.indices
+    CALIPSO.evaluate!(solver.problem, solver.methods, idx, solver.solution, solver.parameters,
+        objective=true, objective_gradient_variables=true, objective_jacobian_variables_variables=true,
+        equality_constraint=true, equality_jacobian_variables=true, equality_dual_jacobian_variables=true,
+        equality_dual_jacobian_variables_variables=true, cone_constraint=true, cone_jacobian_variables=true,
+        cone_dual_jacobian_variables=true, cone_dual_jacobian_variables_variables=true)
+    CALIPSO.cone!(solver.problem, solver.cone_methods, idx, solver.solution, product=true, jacobian=true, target=true)
+    CALIPSO.residual!(solver.data, solver.problem, idx, solver.solution, solver.central_path, solver.penalty, solver.dual)
+    CALIPSO.search_direction!(solver)
+    CALIPSO.compute_inertia!(solver.linear_solver)
+    inr = solver.linear_solver.inertia
+    open(joinpath(GOLDEN, "ref_" * name * ".txt"), "w") do io
+        write_record(io, "residual", solver.data.residual.all)
+        write_record(io, "inertia", Float64[inr.positive, inr.negative, inr.zero])
+        write_record(io, "primal_regularization", solver.primal_regularization[1])
+        write_record(io, "primal_regularization_last", solver.primal_regularization_last[1])
+        write_record(io, "dual_regularization", solver.dual_regularization[1])
+        write_record(io, "step", solver.data.step.all)
+    end
+    println("wrote ", joinpath(GOLDEN, "ref_" * name * ".txt"))
+end
+
 for name in ("kat_qp_10_5_5", "kat_soc_6_3_9")
     run_kat(name)
+end
+for name in ("kat_sd_nonconvex_12_3_4", "kat_sd_portfolio_soc12")
+    run_search_direction(name)
 end

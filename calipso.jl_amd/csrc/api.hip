@@ -522,15 +522,13 @@ static int publish_and_wait(H* s, const void* dsrc, void* hdst_dev, int words) {
 }
 // spin until the sequence number `seq` (written by a publish kernel or by a producer kernel itself) has arrived
 static int wait_published(H* s, unsigned long long seq) {
-    unsigned spins = 0;
-    while (__atomic_load_n(s->hseq, __ATOMIC_ACQUIRE) != seq) {
-        if ((++spins & 0x3ffffu) == 0) {                      // a faulted queue would never publish: look at the stream now and then
-            const hipError_t q = hipStreamQuery(s->stream);
-            if (q != hipSuccess && q != hipErrorNotReady) return calipso::check(s, q, "publish_and_wait");
-            if (q == hipSuccess && __atomic_load_n(s->hseq, __ATOMIC_ACQUIRE) != seq) { s->err = "scalar read-back did not arrive"; return CALIPSO_ERR_HIP; }
-        }
-    }
-    return 0;
+    hipError_t q = hipSuccess;
+    const bool ok = host_wait([&] { return __atomic_load_n(s->hseq, __ATOMIC_ACQUIRE) == seq; },
+                              [&] { q = hipStreamQuery(s->stream); return q == hipErrorNotReady; });      // a faulted queue would never publish: look at the stream now and then
+    if (ok) return 0;
+    if (q != hipSuccess && q != hipErrorNotReady) return calipso::check(s, q, "publish_and_wait");
+    s->err = "scalar read-back did not arrive";
+    return CALIPSO_ERR_HIP;
 }
 static int read_scalars(H* s, int first, int count) { return publish_and_wait(s, s->dscal + first, s->hscal_dev + first, 2 * count); }
 static int read_icount(H* s, int first, int count) { return publish_and_wait(s, s->icount + first, s->hicount_dev + first, count); }

@@ -2,13 +2,28 @@
 // (group.hip): inertia test, filter, line-search predicates.  Pure C++ on the handle's host state; nothing here touches the device.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <thread>
 
 #include "internal.hpp"
 
 typedef calipso_hip_solver H;
 #define SYNC() CK(hipStreamSynchronize(s->stream))
+
+// One place for the host's waits on words the device publishes (sequence numbers of read-backs, the progress word of the panel launches): a short pure spin — the
+// read-back of ONE handle is 5-10 us away and a yield costs more than that — then yields, then short sleeps: 24 handles waiting (3 lanes x 8 ranks) do not hold 24 cores.
+// `ready` is polled; `alive` is asked now and then (false: the stream faulted or ended without publishing — stop waiting).  Returns `ready()`.
+template <typename Ready, typename Alive> static inline bool host_wait(Ready ready, Alive alive) {
+    for (unsigned spins = 0;; ++spins) {
+        if (ready()) return true;
+        if (spins < (1u << 15)) continue;                                     // ~30-60 us of pure spinning
+        if ((spins & 0x3ffu) == 0 && !alive()) return ready();
+        if (spins < (1u << 19)) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
 
 static inline bool inertia_ok(const H* s, const int64_t in[3]) { return in[0] == s->d.nx && in[1] == s->d.ne + s->d.nc && in[2] == 0; }   // inertia.jl:7-11
 

@@ -26,6 +26,7 @@
 #include "internal.hpp"
 #define LDL_TRACE_OWNER      // the timeline stamps of -DCALIPSO_LDL_TRACE live in this translation unit
 #include "ldl_device.hpp"
+#include "host_logic.hpp"
 
 #include <algorithm>
 #include <array>
@@ -1144,10 +1145,7 @@ void launch_ldl(calipso_hip_solver* s) {
     // stream instead was measured: a queue blocked on a barrier costs every dispatch of the chain's queue ~0.8 us — 30 us per factorisation.)
     for (int f = 0; f < s->ldl_forks; ++f) {
         const unsigned long long want = (s->ldl_epoch << 16) | (unsigned long long)s->ldl_feeds[3 * f];
-        unsigned spins = 0;
-        while (__atomic_load_n(s->hprog, __ATOMIC_ACQUIRE) < want) {
-            if ((++spins & 0xffffu) == 0 && hipStreamQuery(s->stream) != hipErrorNotReady) break;     // (the chain is through, or the queue faulted)
-        }
+        (void)host_wait([&] { return __atomic_load_n(s->hprog, __ATOMIC_ACQUIRE) >= want; }, [&] { return hipStreamQuery(s->stream) == hipErrorNotReady; });     // (not alive: the chain is through, or the queue faulted)
         enqueue_feed(s, s->stream2, f, true);
     }
     if (!graphs || !replay_or_capture(s, s->graph_ldl_fin, s->graph_ldl_fin_tried, [&] { enqueue_ldl_finish(s); })) enqueue_ldl_finish(s);

@@ -111,3 +111,29 @@ def test_hip_matches_golden_trace(name, maker):
     scale = np.maximum(1.0, np.abs(g["trace"]).max(axis=1, keepdims=True))
     assert (np.abs(tr - g["trace"]) / scale).max() <= 1e-6               # iterates agree (rounding differs with elimination order)
     assert np.abs(s.get("solution", s.N) - g["solution"]).max() <= 1e-6 * max(1.0, np.abs(g["solution"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kat_sd_nonconvex_12_3_4", "kat_sd_portfolio_soc12"])
+def test_hip_matches_golden_search_direction(name):
+    """search_direction! as a whole from the default regularisation start (search_direction.jl:1-23, inertia.jl:30-80): the same walk through IC-1 .. IC-6 (the same
+    final regularisation to the bit), the same inertia, the step to 1e-8 — on a non-convex Hessian and through a second-order cone of dimension 12"""
+    from test_reference_fixtures import sd_problem
+    g = load(name)
+    prob, t = sd_problem(name)
+    pkg = load_pkg()
+    s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices)
+    s.set("solution", g["w"])
+    if prob.ne:
+        s.set("dual", g["lam"])
+    for nm in ("central_path", "penalty", "primal_regularization", "dual_regularization", "fraction_to_boundary"):
+        s.set(nm, [t[nm][0, 0]])
+    s.evaluate(pr.ALL_VARIABLE_FLAGS, 0)
+    s.cone(product=True, target=True)
+    s.residual()
+    rc = s.search_direction()
+    assert rc == g["status"][0]
+    for nm in ("primal_regularization", "primal_regularization_last", "dual_regularization"):
+        assert s.scalar(nm) == g[nm][0], nm
+    st = s.data("step").all
+    assert np.abs(st - g["step"]).max() <= 1e-8 * max(1.0, np.abs(g["step"]).max())
