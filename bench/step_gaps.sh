@@ -1,9 +1,10 @@
 #!/bin/bash
 # One Newton step of the single C3 system under rocprofv3 --kernel-trace: every launch of the last step in order, with the idle time in front of it
 # (gaps above 3 us are what the host or a read-back put there).  bash bench/step_gaps.sh  ->  gpurun_out/step_gaps.txt
+# BENCH_ARGS="--config C4T --batch 32 --group 32 --lanes 1 --no-single --batched-passes 4" bash bench/step_gaps.sh: one step of a group instead
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/gaps; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python $R/bench.py --batch 0 --steps 4 --warmup 2 --no-cpu-baseline --no-c4 --no-c2-c5 > $O/bench.json 2> $O/err.log < /dev/null
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python $R/bench.py ${BENCH_ARGS:---batch 0 --steps 4 --warmup 2} --no-cpu-baseline --no-c4 --no-c2-c5 > $O/bench.json 2> $O/err.log < /dev/null
 f=$(find $O/tr -name "*kernel_trace.csv" | head -1)
 python - "$f" "$R/gpurun_out/step_gaps.txt" <<'PY'
 import csv, sys

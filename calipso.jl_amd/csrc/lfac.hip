@@ -544,6 +544,23 @@ static bool lfac_make_plan(LfacPlan& P, int nblk, int nx, int ne, int nc, int W,
             lw.first += ci.first; longest = std::max(longest, lw.first);
             pq.push(lw);
         }
+        // the two tiles the NEXT launch's chain workgroup starts with — (ell + 2, ell + 1) and (ell + 2, ell + 2), the row items of row ell + 2 — are written on the
+        // XCD the chain's workgroup runs on (block 0: XCD 0; worker w is block w + 1): its loads then hit that XCD's L2 instead of going to memory (0.3 - 0.6 us per launch)
+        if (ell >= 0) {
+            int slot = 7;
+            for (int w = 0; w < W && slot < W; ++w) {
+                bool has = false;
+                for (const LItem& it : per[w]) has = has || (it.kind == LI_ROW && it.i == ell + 2);
+                if (!has || (w + 1) % 8 == 0) continue;
+                while (slot < W) {
+                    bool busy_slot = false;
+                    for (const LItem& it : per[slot]) busy_slot = busy_slot || (it.kind == LI_ROW && it.i == ell + 2);
+                    if (!busy_slot) break;
+                    slot += 8;
+                }
+                if (slot < W) { std::swap(per[w], per[slot]); slot += 8; }
+            }
+        }
         P.item0.push_back((int)P.wfirst.size());
         for (int w = 0; w < W; ++w) { P.wfirst.push_back((int)P.items.size()); for (const LItem& it : per[w]) P.items.push_back(it); }
         P.wfirst.push_back((int)P.items.size());
