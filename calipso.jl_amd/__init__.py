@@ -364,6 +364,11 @@ class Solver:
         self._check(self._L.calipso_hip_set_device_evaluator(self._h, fn_ptr, user), "set_device_evaluator")
         self._device_eval = fn_ptr is not None
 
+    def set_device_block_evaluator(self, fn_ptr, user=None):
+        """structured handles: install an evaluator that writes the packed blocks themselves (calipso_device_block_eval_fn): no dense scratch on the device"""
+        self._check(self._L.calipso_hip_set_device_block_evaluator(self._h, fn_ptr, user), "set_device_block_evaluator")
+        self._device_eval = fn_ptr is not None
+
     def device_evaluate(self, flags, which=0):
         self._check(self._L.calipso_hip_device_evaluate(self._h, which, int(flags)), "device_evaluate")
 

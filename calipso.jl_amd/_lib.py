@@ -55,6 +55,7 @@ SYMBOLS = {
     "calipso_hip_solve": (_i32, [_vp, EVAL_FN, _vp]),
     "calipso_hip_differentiate": (_i32, [_vp, EVAL_FN, _vp]),
     "calipso_hip_set_device_evaluator": (_i32, [_vp, C.c_void_p, _vp]),
+    "calipso_hip_set_device_block_evaluator": (_i32, [_vp, C.c_void_p, _vp]),
     "calipso_hip_device_evaluate": (_i32, [_vp, _i32, _u32]),
     "calipso_hip_set_callbacks": (_i32, [_vp, C.c_void_p, C.c_void_p, _vp]),
     "calipso_hip_stats": (_i32, [_vp, _pi64]),

@@ -766,6 +766,28 @@ static int do_cone_search(H* s, double* a_s, double* a_t, bool emit_candidate = 
 // kernels on the handle's stream (the launches that follow are ordered behind them) — no download of the point, no upload of blocks
 static int device_evaluate(H* s, const double* pt, uint32_t flags) {
     const Dims& d = s->d;
+    const uint32_t hess_flags = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
+    if (s->compact && s->dev_block_eval) {
+        // the evaluator writes the packed blocks themselves: no dense scratch, nothing to check (nothing outside the blocks exists), only the second orientation
+        // of the blocks it was asked for to refresh behind it
+        if (int rc = calipso::blocks_descriptors(s)) return rc;
+        calipso_device_block_data o;
+        o.objective = s->dscal + 0; o.objective_gradient_variables = s->fx;
+        o.equality_constraint = d.ne ? s->g : nullptr; o.cone_constraint = d.nc ? s->hc : nullptr;
+        o.equality_dual_jacobian_variables = s->gyx; o.cone_dual_jacobian_variables = s->hzx;
+        o.lagrangian_gradient_parameters = d.np ? s->lgp : nullptr;
+        o.equality_jacobian_parameters = (d.np && d.ne) ? s->gp : nullptr;
+        o.cone_jacobian_parameters = (d.np && d.nc) ? s->hp : nullptr;
+        o.nx = d.nx; o.np = d.np; o.ne = d.ne; o.nc = d.nc;
+        const calipso::StageBlocks& B = s->blocks;
+        o.n_jacobian_blocks = (int64_t)B.h_jdesc.size(); o.jacobian_blocks = B.h_jdesc.data(); o.jacobian_blocks_device = B.d_jdesc;
+        o.n_hessian_blocks = (int64_t)B.h_hdesc.size(); o.hessian_blocks = B.h_hdesc.data(); o.hessian_blocks_device = B.d_hdesc;
+        const int rc = s->dev_block_eval(s->dev_block_eval_user, flags, pt, pt + d.oy(), pt + d.oz(), s->parameters, &o, (void*)s->stream);
+        if (rc != 0) { s->err = "device evaluator failed"; return CALIPSO_ERR_CALLBACK; }
+        if (flags & hess_flags) s->hessian_dirty = true;
+        calipso::blocks_mirror(s, (flags & hess_flags) != 0, (flags & CALIPSO_EVAL_EQUALITY_JACOBIAN) != 0 && d.ne > 0, (flags & CALIPSO_EVAL_CONE_JACOBIAN) != 0 && d.nc > 0);
+        return CALIPSO_OK;
+    }
     calipso_device_problem_data o;
     o.objective = s->dscal + 0;
     o.objective_gradient_variables = s->fx;
@@ -780,6 +802,7 @@ static int device_evaluate(H* s, const double* pt, uint32_t flags) {
     if (s->compact) {
         if (!s->evalL) {
             if (dalloc(s, &s->evalL, (size_t)d.nx * d.nx) || dalloc(s, &s->evalZ, (size_t)std::max(1, d.m) * d.nx)) return CALIPSO_ERR_HIP;
+            s->scratch_bytes = sizeof(double) * ((size_t)d.nx * d.nx + (size_t)std::max(1, d.m) * d.nx);
         }
         o.lagrangian_hessian = s->evalL;
         o.equality_jacobian_variables = d.ne ? s->evalZ : nullptr;
@@ -809,7 +832,7 @@ namespace calipso { int evaluate_point(calipso_hip_solver* s, calipso_eval_fn ev
 static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t flags) {
     double* pt = point_of(s, which);
     if (s->qp.attached) { launch_qp_evaluate(s, pt, flags); return CALIPSO_OK; }
-    if (s->dev_eval) return device_evaluate(s, pt, flags);
+    if (s->dev_eval || s->dev_block_eval) return device_evaluate(s, pt, flags);
     if (!eval) { s->err = "no evaluation callback and no device evaluator attached"; return CALIPSO_ERR_ARGUMENT; }
     CK(hipMemcpyAsync(s->hpoint.data(), pt, sizeof(double) * s->d.N, hipMemcpyDeviceToHost, s->stream));
     SYNC();
@@ -1012,12 +1035,21 @@ int32_t calipso_hip_set_device_evaluator(H* s, calipso_device_eval_fn fn, void* 
     // (a structured handle holds no dense ProblemData arrays: the evaluator then writes into dense scratch arrays of the handle — allocated on its first evaluation:
     // nx^2 + (ne + nc) nx doubles — whose entries go into the blocks behind it; what lies outside the declared structure must be zero: device_evaluate checks)
     s->dev_eval = fn; s->dev_eval_user = user;
+    if (fn) s->dev_block_eval = nullptr;
+    return CALIPSO_OK;
+}
+
+int32_t calipso_hip_set_device_block_evaluator(H* s, calipso_device_block_eval_fn fn, void* user) {
+    if (!s) return CALIPSO_ERR_ARGUMENT;
+    if (!s->compact) return fail_arg(s, "calipso_hip_set_device_block_evaluator: only a structured handle (calipso_hip_create_structured) has blocks to write");
+    s->dev_block_eval = fn; s->dev_block_eval_user = user;
+    if (fn) s->dev_eval = nullptr;
     return CALIPSO_OK;
 }
 
 int32_t calipso_hip_device_evaluate(H* s, int32_t which, uint32_t flags) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
-    if (!s->dev_eval) { s->err = "no device evaluator installed (calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
+    if (!s->dev_eval && !s->dev_block_eval) { s->err = "no device evaluator installed (calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
     CK(hipSetDevice(s->device));
     return device_evaluate(s, point_of(s, which), flags);
 }
@@ -1217,7 +1249,7 @@ int32_t calipso_hip_newton_steps(H* s, int32_t count, int32_t advance, double* i
 }
 static int32_t newton_step_impl(H* s, int32_t advance, double info_out[6], bool last) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
-    if (!s->qp.attached && !s->dev_eval) { s->err = "calipso_hip_newton_step needs a device evaluator (calipso_hip_qp_attach or calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
+    if (!s->qp.attached && !s->dev_eval && !s->dev_block_eval) { s->err = "calipso_hip_newton_step needs a device evaluator (calipso_hip_qp_attach or calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
     const Dims& d = s->d;
     const Scalars saved_sc = s->sc;
     std::vector<double> ft, fm; calipso::i64 fi = 0;
@@ -1282,7 +1314,7 @@ int32_t calipso_hip_kernel_times(H* s, double out[8]) {
     out[0] = s->kernel_ms[0];
     out[1] = (double)s->ldl_step_launches;              // k_ldl_diag + the k_ldl_step launches the last blocked factorisation queued
     out[2] = (double)s->d.NP;
-    out[3] = (double)(s->slab_doubles * sizeof(double));
+    out[3] = (double)(s->slab_doubles * sizeof(double) + s->scratch_bytes);
     { double lf[8]; calipso::lfac_describe(s, lf); out[6] = s->lfac_last ? 1.0 : 0.0; out[7] = lf[5]; }
     if (s->matvec_timed && hipEventSynchronize(s->ev[6]) == hipSuccess) {
         float ms = 0.f;

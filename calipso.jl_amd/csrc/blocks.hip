@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_schur_blocks(BatchSc bt, Dims d, ConeDe
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------------
 void blocks_release(calipso_hip_solver* s) {
     StageBlocks& B = s->blocks;
-    for (void* p : {(void*)B.d_blk, (void*)B.d_lblk, (void*)B.d_seg, (void*)B.d_segblk, (void*)B.d_pairs, (void*)B.d_pairblk, (void*)B.d_colrange, (void*)B.d_rowcov}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)B.d_blk, (void*)B.d_lblk, (void*)B.d_seg, (void*)B.d_segblk, (void*)B.d_pairs, (void*)B.d_pairblk, (void*)B.d_colrange, (void*)B.d_rowcov, (void*)B.d_jdesc, (void*)B.d_hdesc}) if (p) (void)hipFree(p);
     B = StageBlocks();
 }
 
@@ -345,6 +345,45 @@ int blocks_pack_from(calipso_hip_solver* s, const double* L, const double* Z, bo
     CK(hipStreamSynchronize(s->stream));
     if (s->hicount[60] != 0) { s->err = "the device evaluator wrote non-zeros outside the declared structure of the handle"; return CALIPSO_ERR_ARGUMENT; }
     return CALIPSO_OK;
+}
+
+// ---- a device evaluator that writes the blocks (calipso_device_block_eval_fn): descriptors of the column-major copies, and the row-major copies behind it ----------
+int blocks_descriptors(calipso_hip_solver* s) {
+    StageBlocks& B = s->blocks;
+    if (!B.on) return CALIPSO_ERR_ARGUMENT;
+    if (!B.h_jdesc.empty() || !B.h_hdesc.empty()) return CALIPSO_OK;
+    for (const ZBlock& b : B.h_blk) B.h_jdesc.push_back({b.row0, b.nrows, b.col0, b.ncols, s->Lsym + b.off_c, b.nrows});
+    for (const LBlock& b : B.h_lblk) B.h_hdesc.push_back({b.c0, b.n, b.c0, b.n, s->Lsym + b.off_c, b.n});
+    auto up = [&](const std::vector<calipso_device_block>& h, calipso_device_block** d) {
+        if (hipMalloc((void**)d, std::max<size_t>(1, h.size()) * sizeof(calipso_device_block)) != hipSuccess) return false;
+        return h.empty() || hipMemcpy(*d, h.data(), h.size() * sizeof(calipso_device_block), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(B.h_jdesc, &B.d_jdesc) || !up(B.h_hdesc, &B.d_hdesc)) { s->err = "block descriptors: device allocation failed"; return CALIPSO_ERR_HIP; }
+    return CALIPSO_OK;
+}
+__global__ __launch_bounds__(256) void k_blocks_mirror_z(Batch bt, const ZBlock* __restrict__ blk, double* __restrict__ pk, int rlo, int rhi) {
+    inst_shift(bt, pk);
+    const ZBlock b = blk[blockIdx.x];
+    const int total = b.nrows * b.ncols;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int i = idx % b.nrows, j = idx / b.nrows;
+        if (b.row0 + i < rlo || b.row0 + i >= rhi) continue;
+        pk[b.off_r + (size_t)i * b.ncols + j] = pk[b.off_c + idx];
+    }
+}
+__global__ __launch_bounds__(256) void k_blocks_mirror_l(Batch bt, const LBlock* __restrict__ blk, double* __restrict__ pk) {
+    inst_shift(bt, pk);
+    const LBlock b = blk[blockIdx.x];
+    const int total = b.n * b.n;
+    for (int idx = threadIdx.x; idx < total; idx += 256) { const int i = idx % b.n, j = idx / b.n; pk[b.off_r + (size_t)i * b.n + j] = pk[b.off_c + idx]; }
+}
+void blocks_mirror(calipso_hip_solver* s, bool l, bool zg, bool zh) {
+    StageBlocks& B = s->blocks;
+    if (!B.on) return;
+    const Batch one;
+    const int rlo = zg ? 0 : s->d.ne, rhi = zh ? s->d.m : s->d.ne;
+    if ((zg || zh) && rhi > rlo && B.nblk) hipLaunchKernelGGL(k_blocks_mirror_z, dim3(B.nblk), dim3(256), 0, s->stream, one, B.d_blk, s->Lsym, rlo, rhi);
+    if (l && B.nlb) hipLaunchKernelGGL(k_blocks_mirror_l, dim3(B.nlb), dim3(256), 0, s->stream, one, B.d_lblk, s->Lsym);
 }
 
 static bool blocks_usable(const calipso_hip_solver* s) { return s->blocks.on && s->blocks_effective; }

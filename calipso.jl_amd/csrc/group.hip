@@ -97,7 +97,7 @@ static int g_read_i(G* g, const Set& a, int first, int count) {
 static int gb_evaluate(G* g, const Set& a, int which, uint32_t flags) {
     H* s = g->base;
     Set dev, user_dev, host;
-    for (int i : a) (g->hs[i]->qp.attached ? dev : (g->hs[i]->dev_eval ? user_dev : host)).push_back(i);
+    for (int i : a) (g->hs[i]->qp.attached ? dev : ((g->hs[i]->dev_eval || g->hs[i]->dev_block_eval) ? user_dev : host)).push_back(i);
     if (!dev.empty()) {
         g_activate(g, dev);
         launch_qp_evaluate(s, which == 0 ? s->solution : s->candidate, flags);
@@ -540,7 +540,7 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
     Set all;
     for (size_t i = 0; i < B; ++i) {
         H* h = g->hs[i];
-        if (!h->qp.attached && !h->dev_eval) { s->err = "calipso_hip_group_newton_step needs a device evaluator on every member (calipso_hip_qp_attach or calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
+        if (!h->qp.attached && !h->dev_eval && !h->dev_block_eval) { s->err = "calipso_hip_group_newton_step needs a device evaluator on every member (calipso_hip_qp_attach or calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
         if (h != s) CK(hipStreamSynchronize(h->stream));   // uploads made through the member's own stream are complete
         all.push_back((int)i);
     }
@@ -612,7 +612,7 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
     Set all;
     for (size_t i = 0; i < B; ++i) {
         H* h = g->hs[i];
-        if (!h->qp.attached && !h->dev_eval && (i >= g->evals.size() || !g->evals[i])) {
+        if (!h->qp.attached && !h->dev_eval && !h->dev_block_eval && (i >= g->evals.size() || !g->evals[i])) {
             s->err = "calipso_hip_group_solve: member without a device evaluator and without a callback (calipso_hip_group_set_evaluators)";
             return CALIPSO_ERR_ARGUMENT;
         }

@@ -139,6 +139,8 @@ struct StageBlocks {
     unsigned long long signature = 0;   // of the block structure (members of a group must share it)
     ZBlock* d_blk = nullptr; LBlock* d_lblk = nullptr; Segment* d_seg = nullptr; int* d_segblk = nullptr; SegPair* d_pairs = nullptr; int* d_pairblk = nullptr;
     int* d_colrange = nullptr;          // per column of Lxx: [first, last + 1) row of its Hessian block (uploads are re-checked against it)
+    std::vector<calipso_device_block> h_jdesc, h_hdesc;   // descriptors of the blocks for a calipso_device_block_eval_fn (host copies; values = device addresses of the base handle)
+    calipso_device_block *d_jdesc = nullptr, *d_hdesc = nullptr;
     int* d_rowcov = nullptr;            // per row of [gx; hx]: covered by some block (blocks_pack_from; made on first use)
     double schur_flops = 0.0;           // multiply-adds x 2 of one k_schur_blocks launch per instance (sum over the segment pairs of the covering blocks' rows x columns x columns)
     std::vector<ZBlock> h_blk; std::vector<LBlock> h_lblk; std::vector<SegPair> h_pairs; std::vector<Segment> h_seg; std::vector<int> h_seg_of_col;   // host copies (uploads of structured handles are packed on the host)
@@ -177,6 +179,9 @@ struct calipso_hip_solver {
     void* cb_user = nullptr;
     calipso_device_eval_fn dev_eval = nullptr;   // user evaluation on the device (include/calipso_hip.h): enqueues on `stream`, never syncs
     void* dev_eval_user = nullptr;
+    calipso_device_block_eval_fn dev_block_eval = nullptr;   // structured handles: the evaluator writes the packed blocks (no dense scratch)
+    void* dev_block_eval_user = nullptr;
+    size_t scratch_bytes = 0;                    // dense scratch of a structured handle with a dense-layout device evaluator (evalL / evalZ)
     bool rhs_ahead = false, rhs_joined = false;   // the operands of the first condensed solve were queued on the second stream during this factorisation (ldl.hip: ldl_rhs_stream) / the main stream has joined it
     double *evalL = nullptr, *evalZ = nullptr;   // structured handle with a device evaluator: dense scratch (nx^2, m nx) the evaluator writes; packed into the blocks behind it
     std::map<std::string, double*> optd;
@@ -369,7 +374,9 @@ void launch_pad_identity(calipso_hip_solver* s);
 // then takes the dense-layout kernel.
 void blocks_release(calipso_hip_solver* s);
 void blocks_pack(calipso_hip_solver* s, bool z, bool l);
-int blocks_pack_from(calipso_hip_solver* s, const double* L, const double* Z, bool l, bool zg, bool zh);   // zg / zh: the equality / cone Jacobian was written   // dense arrays -> blocks, with the check that nothing lies outside the structure (synchronises)
+int blocks_pack_from(calipso_hip_solver* s, const double* L, const double* Z, bool l, bool zg, bool zh);
+int blocks_descriptors(calipso_hip_solver* s);                                   // (once) the calipso_device_block arrays of the handle's blocks, host and device
+void blocks_mirror(calipso_hip_solver* s, bool l, bool zg, bool zh);             // second orientation of the blocks a block evaluator has just written   // zg / zh: the equality / cone Jacobian was written   // dense arrays -> blocks, with the check that nothing lies outside the structure (synchronises)
 bool blocks_gemv_n(calipso_hip_solver* s, int kind, const double* x, double* y, double alpha, double beta);
 bool blocks_gemv_t(calipso_hip_solver* s, int kind, const double* u1, const double* u2, double* y1, double* y2, double alpha, double beta);
 bool blocks_schur(calipso_hip_solver* s);

@@ -212,6 +212,16 @@ function CALIPSO.initialize!(hs::HIPSolver, guess)
     return
 end
 
+"""device-side evaluation (src/solver/evaluate.jl:37-121 as kernels on the solver's stream): `fn` = address of a `calipso_device_eval_fn` (dense ProblemData layout) or,
+with `blocks = true` on a handle made with `structure = ...`, of a `calipso_device_block_eval_fn` that writes the handle's packed blocks (no dense scratch);
+`user` is handed to it unchanged.  solve! then never calls back into Julia for an evaluation."""
+function set_device_evaluator!(hs::HIPSolver, fn::Ptr{Cvoid}, user::Ptr{Cvoid} = C_NULL; blocks::Bool = false)
+    rc = blocks ? ccall((:calipso_hip_set_device_block_evaluator, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), hs.handle, fn, user) :
+                  ccall((:calipso_hip_set_device_evaluator, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), hs.handle, fn, user)
+    check(hs.handle, rc, "set_device_evaluator!")
+    return
+end
+
 "solve!(solver)::Bool  src/solver/solve.jl:8-377 — results are copied back into the wrapped Solver's fields"
 function CALIPSO.solve!(hs::HIPSolver)
     rc = GC.@preserve hs ccall((:calipso_hip_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), hs.handle, hs.eval_cfunction, pointer_from_objref(hs))

@@ -111,6 +111,26 @@ typedef struct calipso_device_problem_data {
 typedef int32_t (*calipso_device_eval_fn)(void* user, uint32_t flags, const double* x, const double* y, const double* z, const double* theta,
                                           const calipso_device_problem_data* out, void* hip_stream);
 
+/* The same for a STRUCTURED handle (calipso_hip_create_structured), without the dense interchange arrays: the generated functions of evaluate! (evaluate.jl:37-121)
+ * write the non-zeros of the Jacobians and of the Hessian where the sparsity lists say (methods.*_sparsity, src/trajectory_optimization/sparsity.jl:28-129) — here
+ * straight into the handle's packed blocks.  A block = rows [row0, row0 + nrows) x columns [col0, col0 + ncols) (0-based; rows numbered in the stacked matrix
+ * [equality; cone]: cone row k is row ne + k), values column-major with leading dimension ld, a DEVICE pointer into the handle's own storage.  Hessian blocks are the
+ * diagonal blocks of the Lagrangian Hessian (row0 = col0, nrows = ncols).  The descriptor arrays exist twice: on the host (`*_blocks`) and on the device
+ * (`*_blocks_device`, for kernels that walk them).  An evaluator asked for a Jacobian / the Hessian writes EVERY entry of every block of it (zeros included);
+ * nothing outside the blocks exists, so nothing can be written there.  The vector fields are those of calipso_device_problem_data.  With such an evaluator a
+ * structured handle never allocates the nx^2 + (ne + nc) nx doubles of dense scratch that calipso_device_eval_fn costs it. */
+typedef struct calipso_device_block { int64_t row0, nrows, col0, ncols; double* values; int64_t ld; } calipso_device_block;
+typedef struct calipso_device_block_data {
+    double* objective; double* objective_gradient_variables; double* equality_constraint; double* cone_constraint;
+    double* equality_dual_jacobian_variables; double* cone_dual_jacobian_variables;
+    double* lagrangian_gradient_parameters; double* equality_jacobian_parameters; double* cone_jacobian_parameters;
+    int64_t nx, np, ne, nc;
+    int64_t n_jacobian_blocks; const calipso_device_block* jacobian_blocks; const calipso_device_block* jacobian_blocks_device;
+    int64_t n_hessian_blocks; const calipso_device_block* hessian_blocks; const calipso_device_block* hessian_blocks_device;
+} calipso_device_block_data;
+typedef int32_t (*calipso_device_block_eval_fn)(void* user, uint32_t flags, const double* x, const double* y, const double* z, const double* theta,
+                                                const calipso_device_block_data* out, void* hip_stream);
+
 /* callback_inner(custom, solver) / callback_outer(custom, solver)  (solver.jl:183,193; called at solve.jl:350,371) */
 typedef void (*calipso_callback_fn)(void* user, calipso_hip_solver* solver);
 
@@ -251,6 +271,9 @@ int32_t calipso_hip_differentiate(calipso_hip_solver*, calipso_eval_fn eval, voi
 /* install a device-side evaluator (NULL removes it): calipso_hip_solve / calipso_hip_differentiate / the group drivers then call it instead
  * of the host callback (their `eval` argument may be NULL), and calipso_hip_device_evaluate runs it on point `which` (0 solution, 1 candidate) */
 int32_t calipso_hip_set_device_evaluator(calipso_hip_solver*, calipso_device_eval_fn fn, void* user);
+/* structured handles only (CALIPSO_ERR_ARGUMENT otherwise): the evaluator writes the packed blocks (calipso_device_block_data above); replaces an evaluator set by
+ * calipso_hip_set_device_evaluator.  evaluate.jl:37-121 */
+int32_t calipso_hip_set_device_block_evaluator(calipso_hip_solver*, calipso_device_block_eval_fn fn, void* user);
 int32_t calipso_hip_device_evaluate(calipso_hip_solver*, int32_t which, uint32_t flags);
 /* install the per-inner-iteration / per-outer-update callbacks (NULL disables; options.callback_inner/outer) */
 int32_t calipso_hip_set_callbacks(calipso_hip_solver*, calipso_callback_fn inner, calipso_callback_fn outer, void* user);
@@ -429,7 +452,8 @@ int32_t calipso_hip_phase_times(calipso_hip_solver*, double out[9]);
 /* per-kernel figures of the last factorisation and the handle's layout (bench.py: the live launch durations behind `roofline`):
  * [0] ms of the panel-step launches of the LDL^T of the Schur complement (k_ldl_diag + k_ldl_step: the pivot chain, one launch per 64
  *     pivots; HIP events around exactly these launches; the rest of [3] above is the parallel finish: factor columns + block inverses)
- * [1] number of those launches   [2] NP = padded order of the Schur complement   [3] bytes of the handle's device slab
+ * [1] number of those launches   [2] NP = padded order of the Schur complement   [3] bytes of the handle's device slab + the dense scratch a structured handle
+ *     allocates for a calipso_device_eval_fn (none with a calipso_device_block_eval_fn)
  * [4] ms of ONE launch of the refinement residual's mat-vec kernel (k_gemv_t2_and_n: [gx; hx]' times two vectors and Lxx times one, the first residual of the
  *     last calipso_hip_newton_step; 0 when the handle takes another path) and [5] the bytes it reads, 8 (m nx + nx^2)
  * [6] 1 when the last factorisation took the left-looking schedule of one dense system (csrc/lfac.hip: the products of the Schur complement as slices of the panel

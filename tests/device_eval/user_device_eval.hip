@@ -70,7 +70,48 @@ __global__ void k_qp_user(uint32_t flags, QpUser u, const double* __restrict__ x
         if (flags & CALIPSO_EVAL_CONE) { double r = u.h[k]; for (int j = 0; j < nx; ++j) r -= u.G[k * nx + j] * x[j]; o.cone_constraint[k] = r; }
 }
 
+// the same quadratic program for a STRUCTURED handle: the Jacobians and the Hessian go straight into the handle's packed blocks (calipso_device_block_eval_fn) —
+// one workgroup per block walks its entries; rows of the stacked matrix [equality; cone]: row r < ne is row r of A, row r >= ne is row r - ne of -G
+__global__ void k_qp_user_blocks(uint32_t flags, QpUser u, calipso_device_block_data o) {
+    const int nj = (int)o.n_jacobian_blocks, nh = (int)o.n_hessian_blocks;
+    const int b = blockIdx.x;
+    if (b < nj) {
+        const calipso_device_block k = o.jacobian_blocks_device[b];
+        for (int64_t idx = threadIdx.x; idx < k.nrows * k.ncols; idx += blockDim.x) {
+            const int64_t i = idx % k.nrows, j = idx / k.nrows, r = k.row0 + i, c = k.col0 + j;
+            const bool eq = r < u.ne;
+            if (eq && !(flags & CALIPSO_EVAL_EQUALITY_JACOBIAN)) continue;
+            if (!eq && !(flags & CALIPSO_EVAL_CONE_JACOBIAN)) continue;
+            k.values[i + j * k.ld] = eq ? u.A[r * u.nx + c] : -u.G[(r - u.ne) * u.nx + c];
+        }
+    } else if (b < nj + nh && (flags & (CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN))) {
+        const calipso_device_block k = o.hessian_blocks_device[b - nj];
+        for (int64_t idx = threadIdx.x; idx < k.nrows * k.ncols; idx += blockDim.x) {
+            const int64_t i = idx % k.nrows, j = idx / k.nrows, r = k.row0 + i, c = k.col0 + j;
+            k.values[i + j * k.ld] = (flags & CALIPSO_EVAL_OBJECTIVE_HESSIAN) ? u.c * (u.P[r * u.nx + c] + u.P[c * u.nx + r]) : 0.0;
+        }
+    }
+}
+
 extern "C" {
+
+int32_t qp_block_device_eval(void* user, uint32_t flags, const double* x, const double* y, const double* z, const double* theta,
+                             const calipso_device_block_data* out, void* hip_stream) {
+    (void)theta;
+    const QpUser* u = (const QpUser*)user;
+    if (!u || out->nx != u->nx || out->ne != u->ne || out->nc != u->nc) return 1;
+    // the vector fields through the dense-layout kernel with the matrix flags masked off ...
+    calipso_device_problem_data v = {};
+    v.objective = out->objective; v.objective_gradient_variables = out->objective_gradient_variables; v.equality_constraint = out->equality_constraint;
+    v.cone_constraint = out->cone_constraint; v.equality_dual_jacobian_variables = out->equality_dual_jacobian_variables;
+    v.cone_dual_jacobian_variables = out->cone_dual_jacobian_variables; v.nx = out->nx; v.np = out->np; v.ne = out->ne; v.nc = out->nc;
+    const uint32_t matrices = CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE_JACOBIAN | CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
+    hipLaunchKernelGGL(k_qp_user, dim3(8), dim3(64), 0, (hipStream_t)hip_stream, flags & ~matrices, *u, x, y, z, v);
+    // ... the matrices block by block
+    const int nb = (int)(out->n_jacobian_blocks + out->n_hessian_blocks);
+    if ((flags & matrices) && nb > 0) hipLaunchKernelGGL(k_qp_user_blocks, dim3(nb), dim3(128), 0, (hipStream_t)hip_stream, flags, *u, *out);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 int32_t wachter_device_eval(void* user, uint32_t flags, const double* x, const double* y, const double* z, const double* theta,
                             const calipso_device_problem_data* out, void* hip_stream) {

@@ -169,3 +169,44 @@ def test_device_evaluator_on_a_structured_handle():
     with pytest.raises(pkg.CalipsoHipError, match="outside the declared structure"):
         st2.device_evaluate(pr.ALL_VARIABLE_FLAGS, 0)
     UL.qp_user_destroy(user2)
+
+
+def test_block_evaluator_writes_the_blocks_of_a_structured_handle_without_dense_scratch():
+    """calipso_device_block_eval_fn: the user's kernels write the packed Jacobian / Hessian blocks of a structured handle directly (what the reference's generated functions
+    do through their sparsity lists, evaluate.jl:37-121): the same fields and the same solve as the dense-layout evaluator on the same handle type, and no nx^2 + m nx
+    scratch on the device"""
+    pkg, UL = load_pkg(), user_lib()
+    prob, pt, lam = pr.staged_conic_qp(pkg.splitmix_uniform, 9, 6, 8, 4, 3, 1, 3)
+    user = make_qp_user(UL, prob)
+    kw = dict(nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices)
+    counted = CountingProblem(prob)
+    blk = pkg.Solver(counted, prob.nx, 0, prob.ne, prob.nc, structure=pr.declared_structure(prob), **kw)
+    blk.set_device_block_evaluator(fnptr(UL.qp_block_device_eval), user)
+    scr = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, structure=pr.declared_structure(prob), **kw)
+    scr.set_device_evaluator(fnptr(UL.qp_device_eval), user)
+    bytes_before = blk.device_bytes()
+    w = np.random.default_rng(1).standard_normal(blk.N)
+    for s in (blk, scr):
+        s.set("solution", w)
+        s.device_evaluate(pr.ALL_VARIABLE_FLAGS, 0)
+    for name, ln in (("objective", 1), ("objective_gradient_variables", prob.nx), ("equality_constraint", prob.ne), ("cone_constraint", prob.nc),
+                     ("equality_dual_jacobian_variables", prob.nx), ("cone_dual_jacobian_variables", prob.nx), ("lagrangian_hessian", prob.nx ** 2),
+                     ("equality_jacobian_variables", prob.ne * prob.nx), ("cone_jacobian_variables", prob.nc * prob.nx)):
+        assert np.array_equal(blk.get(name, ln), scr.get(name, ln)), name
+    assert blk.device_bytes() == bytes_before                                             # nothing was allocated for the evaluation ...
+    assert scr.device_bytes() >= bytes_before + 8 * (prob.nx ** 2 + (prob.ne + prob.nc) * prob.nx)   # ... where the dense-layout evaluator costs the handle its dense scratch
+    # only one Jacobian asked for: the other one's blocks keep their values
+    blk.device_evaluate(pr.EQUALITY_JACOBIAN, 0)
+    assert np.array_equal(blk.get("cone_jacobian_variables", prob.nc * prob.nx), scr.get("cone_jacobian_variables", prob.nc * prob.nx))
+    x0 = np.zeros(prob.nx)
+    for s in (blk, scr):
+        pkg.initialize_b(s, x0)
+    assert pkg.solve_b(blk) and pkg.solve_b(scr)
+    assert counted.calls == 0
+    assert blk.stats()["total_iterations"] == scr.stats()["total_iterations"]
+    assert np.array_equal(blk.solution.all, scr.solution.all)                             # the same blocks, the same launches
+    # a dense handle has no blocks to write
+    dense = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, **kw)
+    with pytest.raises(Exception):
+        dense.set_device_block_evaluator(fnptr(UL.qp_block_device_eval), user)
+    UL.qp_user_destroy(user)
