@@ -24,6 +24,7 @@
 #include "internal.hpp"
 #include "device_utils.hpp"
 #include "pivot16.hpp"
+#include "ldl_device.hpp"
 
 using calipso::i64;
 
@@ -156,6 +157,7 @@ __global__ void k_sp_permute_out(const double* __restrict__ x, const int* __rest
 // dependent table look-ups (order -> nfirst / ncols / nrows -> childptr -> children -> upd_off / rowptr ...: 0.7 us per hop on a cold launch).
 struct MfNode { int s, f, c, r; int rowptr, chfirst, nch, alp0; int alp1, pad0, pad1, pad2; long long panel_off, upd_off, u_off, foff; };
 struct MfChild { int rc, rowptr; long long upd_off, u_off; };
+struct MfRowItem { long long uoff; int relptr, a; };   // row a of a child's update matrix (offset in the update pool), the child's relative indices
 struct MfDev {
     int nnodes;
     const MfNode* nrec;                       // [launch position]
@@ -174,7 +176,13 @@ struct MfDev {
     const long long* foff;                    // per node: offset of its front in fpool (levels reuse the pool)
     long long sPool;
     long long sA, sPanel, sUpd, sD;           // instance strides (batched factorisation of matrices with one pattern)
+    // fronts factored by many workgroups (sparse_wide.hpp): per row of such a front (MfNode::pad0 + row) its entries of A and its child rows
+    const int *wptrE, *wptrC;                 // [pad0 + row .. + 1]: ranges in wEcol / wEsrc and in wC
+    const int *wEcol, *wEsrc;                 // local column in the front, index into Aval
+    const MfRowItem* wC;                      // children in ascending order
+    double* wscr;                             // X, M, L11, D of the diagonal blocks of one level: (matrix, node of the level)
 };
+
 // storage slot of launch instance z: z itself, or — for the members of a group's (shrinking) active set — slot[z].  A separate read-only kernel
 // argument: indexing an array inside a struct the kernel also modifies would push the whole struct to scratch memory.
 struct MfSlots { int use; int slot[calipso::MAX_BATCH]; };
@@ -591,7 +599,10 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
     }
 }
 
-struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; bool global; int ypan; };   // ypan: room for the 64 x MF_PY exchange rows of the in-register panels
+#include "sparse_wide.hpp"
+
+int g_wide_fronts = 1;         // calipso_hip_debug_wide_fronts: 0 = the one-workgroup kernel for the global-memory fronts too (plans made afterwards)
+struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; bool global; int ypan; MfWide wide; };   // ypan: room for the 64 x MF_PY exchange rows of the in-register panels
 // launch helpers: the thread count of a level is fixed by the analyse phase (MfSeg::threads)
 #define MF_LAUNCH(KERNEL, G, GRID, LDS, STREAM, ...)                                                                              \
     do {                                                                                                                          \
@@ -623,6 +634,7 @@ struct calipso_hip_sparse {
     int max_front = 0, nnodes = 0;
     int batch = 1, selected = 0;                 // matrices of this pattern factored together / the one get_factor reads
     long long upd_total = 0, pool_total = 0;
+    int wide_count = 0;                          // most fronts of one level factored by many workgroups (their scratch: sparse_wide.hpp)
     std::vector<i64> inertia_all;                // batch x 3
     std::vector<void*> dev;                      // every device allocation
     SpDev d{};
@@ -648,13 +660,14 @@ namespace {
 // (re)allocate everything that holds VALUES, for `batch` matrices of the analysed pattern: instance-major
 int alloc_values(calipso_hip_sparse* s, int batch) {
     const size_t B = (size_t)batch;
-    for (double** pp : {&s->d_Aval, &s->d.Lx, &s->d.D, &s->md.panel, &s->md.upd, &s->md.fpool}) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+    for (double** pp : {&s->d_Aval, &s->d.Lx, &s->d.D, &s->md.panel, &s->md.upd, &s->md.fpool, &s->md.wscr}) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
     PK(hipMalloc((void**)&s->d_Aval, sizeof(double) * B * std::max<size_t>((size_t)s->nnzA, 1)));
     PK(hipMalloc((void**)&s->d.D, sizeof(double) * B * (size_t)s->n));
     if (s->mf) {
         PK(hipMalloc((void**)&s->md.panel, sizeof(double) * B * std::max<size_t>((size_t)s->panel_total, 1)));
         PK(hipMalloc((void**)&s->md.upd, sizeof(double) * B * std::max<size_t>((size_t)s->upd_total, 1)));
         if (s->pool_total) PK(hipMalloc((void**)&s->md.fpool, sizeof(double) * B * (size_t)s->pool_total));
+        if (s->wide_count) PK(hipMalloc((void**)&s->md.wscr, sizeof(double) * B * (size_t)s->wide_count * WF_SCR));
     } else {
         PK(hipMalloc((void**)&s->d.Lx, sizeof(double) * B * std::max<size_t>((size_t)s->nnzL, 1)));
     }
@@ -678,8 +691,10 @@ int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
 
 void enqueue_factor(calipso_hip_sparse* s) {
     if (s->mf) {
-        for (const MfSeg& g : s->mplan)
-            MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, (unsigned)s->batch), g.lds_factor, s->stream, s->md, MfSlots{}, g.first, g.ypan);
+        for (const MfSeg& g : s->mplan) {
+            if (g.wide.on) mf_wide_factor(s->stream, s->md, MfSlots{}, g.wide, g.first, g.count, (unsigned)s->batch);
+            else MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, (unsigned)s->batch), g.lds_factor, s->stream, s->md, MfSlots{}, g.first, g.ypan);
+        }
         return;
     }
     const size_t lds = s->lds_acc ? sizeof(double) * (size_t)s->n : 0;
@@ -762,7 +777,10 @@ int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch
     MfSlots sl{};
     sl.use = 1;
     for (int k = 0; k < bt.n; ++k) sl.slot[k] = bt.slot[k];
-    for (const MfSeg& g : sp->mplan) MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, nz), g.lds_factor, st, sp->md, sl, g.first, g.ypan);
+    for (const MfSeg& g : sp->mplan) {
+        if (g.wide.on) mf_wide_factor(st, sp->md, sl, g.wide, g.first, g.count, nz);
+        else MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, nz), g.lds_factor, st, sp->md, sl, g.first, g.ypan);
+    }
     hipLaunchKernelGGL(k_count_signs, dim3(1, 1, nz), dim3(256), 0, st, bt, sp->d.D, sp->n, icount);
     sp->factored = true;
     return CALIPSO_OK;
@@ -824,6 +842,8 @@ void sparse_work(const calipso_hip_sparse* sp, double out[3]) { out[0] = (double
 void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]) { out[0] = sp->levels; out[1] = sp->max_front; out[2] = sp->nnzU; out[3] = sp->mf ? 2 : (sp->lds_acc ? 1 : 0); }
 }  // namespace calipso
 
+// (tests / A-B timing) how plans made AFTERWARDS treat fronts beyond the LDS: 1 = many workgroups per front (default), 0 = one; returns the old value
+extern "C" int32_t calipso_hip_debug_wide_fronts(int32_t on) { const int was = g_wide_fronts; if (on >= 0) g_wide_fronts = on != 0; return was; }
 #ifdef CALIPSO_LDL_TRACE
 extern "C" int32_t calipso_hip_debug_mf_trace(long long* out, int32_t reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_trace), sizeof(long long) * 64 * 12) != hipSuccess) return -1;
@@ -844,7 +864,7 @@ int32_t calipso_hip_sparse_destroy(calipso_hip_sparse* s) {
     if (s->stream && s->owns_stream) (void)hipStreamSynchronize(s->stream);
     if (s->graph_factor) (void)hipGraphExecDestroy(s->graph_factor);
     for (void* p : s->dev) if (p) (void)hipFree(p);
-    for (double* p : {s->d_Aval, s->d.Lx, s->d.D, s->md.panel, s->md.upd, s->md.fpool}) if (p) (void)hipFree(p);
+    for (double* p : {s->d_Aval, s->d.Lx, s->d.D, s->md.panel, s->md.upd, s->md.fpool, s->md.wscr}) if (p) (void)hipFree(p);
     if (s->d_rhs) (void)hipFree(s->d_rhs);
     if (s->d_x) (void)hipFree(s->d_x);
     if (s->md.uvec) (void)hipFree(s->md.uvec);
@@ -996,6 +1016,9 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
     // last resort: chunks of 64 columns with the oversized fronts in global memory (MF_MAX_FRONT_GLOBAL)
     std::vector<long long> m_foff;
     long long pool_total = 0;
+    std::vector<int> m_wbase, w_ptrE, w_ptrC, w_Ecol, w_Esrc;     // fronts factored by many workgroups (sparse_wide.hpp)
+    std::vector<MfRowItem> w_C;
+    int wide_count = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
         const int width = attempt < 7 ? (int[]){64, 56, 48, 40, 32, 24, 16}[attempt] : 64;
         const int front_limit = attempt < 7 ? MF_MAX_FRONT : MF_MAX_FRONT_GLOBAL;
@@ -1074,6 +1097,7 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
             }
             m_order.resize((size_t)NN);
             m_foff.assign((size_t)NN, 0); pool_total = 0;
+            m_wbase.assign((size_t)NN, -1); w_ptrE.clear(); w_ptrC.clear(); w_Ecol.clear(); w_Esrc.clear(); w_C.clear(); wide_count = 0;
             std::iota(m_order.begin(), m_order.end(), 0);
             std::stable_sort(m_order.begin(), m_order.end(), [&](int a, int b) { return lev[(size_t)a] < lev[(size_t)b]; });
             for (int a = 0; a < NN;) {
@@ -1093,7 +1117,37 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                 }
                 int ypan = 0;                                             // full 16-column panels of fronts with >= 32 rows go through registers (pivot16.hpp) when the LDS has room for the exchange rows
                 if (!glob && mmax >= 32 && lf + sizeof(double) * 64 * MF_PY <= (size_t)(160 * 1024 - 2048)) { ypan = 1; lf += sizeof(double) * 64 * MF_PY; }
-                mplan.push_back({a, b - a, lf, ls, mmax > (size_t)MF_BIG ? 512 : 256, glob, ypan});
+                MfWide wide;                                              // fronts beyond the LDS: many workgroups per front (sparse_wide.hpp)
+                if (glob && g_wide_fronts) {
+                    wide.on = 1;
+                    wide_count = std::max(wide_count, b - a);
+                    for (int q = a; q < b; ++q) {
+                        const int t = m_order[(size_t)q], f = m_first[(size_t)t], c = m_cols[(size_t)t], r = m_rows[(size_t)t], mm = c + r;
+                        wide.m = std::max(wide.m, mm); wide.r = std::max(wide.r, r);
+                        // per row of the front: its entries of A (any order: distinct targets) and the child rows that land in it, children ascending
+                        const int base = (int)w_ptrE.size();
+                        m_wbase[(size_t)t] = base;
+                        std::vector<int> cntE((size_t)mm + 1, 0), cntC((size_t)mm + 1, 0);
+                        const std::vector<int>& rt = R[(size_t)t];
+                        auto local = [&](int i) { return i < f + c ? i - f : c + (int)(std::lower_bound(rt.begin(), rt.end(), i) - rt.begin()); };
+                        for (int j = f; j < f + c; ++j) for (int e = Alp[(size_t)j]; e < Alp[(size_t)j + 1]; ++e) ++cntE[(size_t)local(Ali[(size_t)e]) + 1];
+                        for (int ch : kids[(size_t)t]) for (int k = 0; k < m_rows[(size_t)ch]; ++k) ++cntC[(size_t)m_rel[(size_t)m_rowptr[(size_t)ch] + (size_t)k] + 1];
+                        const int e0 = (int)w_Ecol.size(), c0 = (int)w_C.size();
+                        for (int i = 0; i < mm; ++i) { cntE[(size_t)i + 1] += cntE[(size_t)i]; cntC[(size_t)i + 1] += cntC[(size_t)i]; }
+                        for (int i = 0; i <= mm; ++i) { w_ptrE.push_back(e0 + cntE[(size_t)i]); w_ptrC.push_back(c0 + cntC[(size_t)i]); }
+                        w_Ecol.resize((size_t)e0 + (size_t)cntE[(size_t)mm]); w_Esrc.resize(w_Ecol.size()); w_C.resize((size_t)c0 + (size_t)cntC[(size_t)mm]);
+                        std::vector<int> atE(cntE.begin(), cntE.end() - 1), atC(cntC.begin(), cntC.end() - 1);
+                        for (int j = f; j < f + c; ++j) for (int e = Alp[(size_t)j]; e < Alp[(size_t)j + 1]; ++e) {
+                            const int at = e0 + atE[(size_t)local(Ali[(size_t)e])]++;
+                            w_Ecol[(size_t)at] = j - f; w_Esrc[(size_t)at] = Asrc[(size_t)e];
+                        }
+                        for (int ch : kids[(size_t)t]) for (int k = 0; k < m_rows[(size_t)ch]; ++k) {       // kids are ascending: so is every row's item list
+                            const int at = c0 + atC[(size_t)m_rel[(size_t)m_rowptr[(size_t)ch] + (size_t)k]]++;
+                            w_C[(size_t)at] = {m_upd_off[(size_t)ch] + (long long)k * m_rows[(size_t)ch], m_rowptr[(size_t)ch], k};
+                        }
+                    }
+                }
+                mplan.push_back({a, b - a, lf, ls, mmax > (size_t)MF_BIG ? 512 : 256, glob, ypan, wide});
                 mf_widest = std::max(mf_widest, b - a);
                 a = b;
             }
@@ -1140,7 +1194,7 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                 MfNode& nd = nrec[(size_t)pos];
                 nd.s = t; nd.f = m_first[(size_t)t]; nd.c = m_cols[(size_t)t]; nd.r = m_rows[(size_t)t];
                 nd.rowptr = m_rowptr[(size_t)t]; nd.chfirst = (int)crec.size(); nd.nch = m_childptr[(size_t)t + 1] - m_childptr[(size_t)t];
-                nd.alp0 = (int)Alp[(size_t)nd.f]; nd.alp1 = (int)Alp[(size_t)(nd.f + nd.c)]; nd.pad0 = nd.pad1 = nd.pad2 = 0;
+                nd.alp0 = (int)Alp[(size_t)nd.f]; nd.alp1 = (int)Alp[(size_t)(nd.f + nd.c)]; nd.pad0 = m_wbase.empty() ? -1 : m_wbase[(size_t)t]; nd.pad1 = nd.pad2 = 0;
                 nd.panel_off = m_panel_off[(size_t)t]; nd.upd_off = m_upd_off[(size_t)t]; nd.u_off = m_u_off[(size_t)t]; nd.foff = m_foff.empty() ? 0 : m_foff[(size_t)t];
                 for (int q = m_childptr[(size_t)t]; q < m_childptr[(size_t)t + 1]; ++q) {
                     const int ch = m_children[(size_t)q];
@@ -1149,8 +1203,11 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
             }
             if ((rc = upload(s, nrec, &md.nrec)) || (rc = upload(s, crec, &md.crec))) return rc;
         }
-        s->pool_total = pool_total;
+        s->pool_total = pool_total; s->wide_count = wide_count;
+        if (wide_count && ((rc = upload(s, w_ptrE, &md.wptrE)) || (rc = upload(s, w_ptrC, &md.wptrC)) || (rc = upload(s, w_Ecol, &md.wEcol)) ||
+                           (rc = upload(s, w_Esrc, &md.wEsrc)) || (rc = upload(s, w_C, &md.wC)))) return rc;
         if ((rc = alloc_values(s, 1))) return rc;      // (again: now with the pool of the global-memory fronts)
+        for (const MfSeg& g : s->mplan) if (g.wide.on && !mf_wide_prepare(&s->err)) return CALIPSO_ERR_HIP;
         md.Alp = s->d.Alp; md.Asrc = s->d.Asrc;
         for (const void* fn : {(const void*)k_mf_factor<256, false>, (const void*)k_mf_factor<512, false>, (const void*)k_mf_forward<256, false>,
                                (const void*)k_mf_forward<512, false>, (const void*)k_mf_backward<256, false>, (const void*)k_mf_backward<512, false>})

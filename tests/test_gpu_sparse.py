@@ -443,3 +443,91 @@ def test_error_paths_of_the_sparse_handle():
     assert np.abs(2.0 * X[1] - X[0]).max() <= 1e-12 * np.abs(X[0]).max()
     S.close()
     S.close()                                                     # idempotent
+
+
+def _wide_fronts(pkg, on):
+    """calipso_hip_debug_wide_fronts: plans made afterwards give the global-memory fronts to many workgroups (1, the default) or to one (0); returns the old value"""
+    fn = pkg._lib.lib().calipso_hip_debug_wide_fronts
+    fn.restype = C.c_int32
+    return fn(C.c_int32(on))
+
+
+def test_wide_fronts_by_many_workgroups_match_the_one_workgroup_kernel_and_the_oracle(oracle_mod):
+    """round 5: a front beyond the LDS is assembled, factored and pushed up by a handful of multi-workgroup launches (sparse_wide.hpp) instead of one
+    workgroup: same factor as the oracle's QDLDL (1e-10), same as the one-workgroup kernel to rounding, same bits from run to run, a batch gets the
+    bits a matrix gets alone — on a quasi-definite matrix (pivots of both signs in the wide fronts) with fronts of ~300 to 1100 rows and nodes of fewer
+    than 64 columns, and faster on the 1500-row cases of the test above."""
+    pkg = load_pkg()
+    rng = np.random.default_rng(5)
+    # two meshes joined through a dense-ish separator of 700 + a quasi-definite tail: the separator's chunks are wide fronts with children
+    gm, ns, nq = 24, 700, 150
+    Tm = sp.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(gm, gm), format="csc")
+    Km = (sp.kron(sp.identity(gm), Tm) + sp.kron(Tm, sp.identity(gm))).tocsc()
+    nm = gm * gm
+    B = rng.standard_normal((ns, ns)) * (rng.random((ns, ns)) < 0.3)
+    Ssep = sp.csc_matrix(B @ B.T / ns + 4.0 * np.eye(ns))
+    C1 = sp.lil_matrix((ns, nm)); C2 = sp.lil_matrix((ns, nm))
+    for i in range(ns):
+        C1[i, (i * 7) % nm] = -0.3; C2[i, (i * 11) % nm] = -0.3
+    G = sp.csc_matrix(rng.standard_normal((nq, ns)) * (rng.random((nq, ns)) < 0.2))
+    Kw = sp.bmat([[Km, None, C1.T, None], [None, Km, C2.T, None], [C1, C2, Ssep, G.T], [None, None, G, -0.5 * sp.identity(nq)]], format="csc")
+    Kw.sort_indices()
+    Aw = sp.triu(Kw).tocsc()
+    n = Kw.shape[0]
+    b = rng.standard_normal((n, 3))
+    was = _wide_fronts(pkg, 1)
+    try:
+        W = pkg.SparseLDL(Aw, method="nested_dissection")
+        assert W.info["numeric"] == "multifrontal"
+        assert W.factorize(Aw) == 0
+        assert W.inertia == (2 * nm + ns, nq, 0)
+        perm, Lw, Dw = W.factor()
+        xw = W.solve(b)
+        assert np.abs(Kw @ xw - b).max() <= 1e-9 * max(1.0, np.abs(xw).max())
+        ref = oracle_factor(oracle_mod, Kw, perm)
+        assert np.abs(Dw - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
+        assert abs(Lw - ref["L"]).max() <= 1e-10 * max(1.0, abs(ref["L"]).max())
+        W.factorize(Aw)
+        _, Lw2, Dw2 = W.factor()
+        assert np.array_equal(Dw, Dw2) and (Lw != Lw2).nnz == 0           # run to run: the same bits
+        tw = W.timing()[0]
+        # a batch of three (the second and third with other values): every matrix gets the bits it gets alone
+        A2 = Aw.copy(); A2.data = A2.data * (1.0 + 0.01 * rng.standard_normal(A2.nnz)); A2 = A2 + sp.diags(np.r_[np.full(2 * nm + ns, 3.0), np.full(nq, -3.0)])
+        A2 = sp.triu(A2).tocsc(); A2.sort_indices()
+        assert np.array_equal(A2.indices, Aw.indices)
+        W.factorize(A2)
+        _, L2, D2 = W.factor()
+        W.set_batch(3)
+        W.factorize(np.stack([Aw.data, A2.data, Aw.data]))
+        for z, (Lr, Dr) in enumerate(((Lw, Dw), (L2, D2), (Lw, Dw))):
+            W.select(z)
+            _, Lz, Dz = W.factor()
+            assert np.array_equal(Dz, Dr) and (Lz != Lr).nnz == 0
+        W.close()
+        _wide_fronts(pkg, 0)
+        O = pkg.SparseLDL(Aw, method="nested_dissection")
+        assert O.factorize(Aw) == 0
+        _, Lo, Do = O.factor()
+        O.factorize(Aw)
+        to = O.timing()[0]
+        O.close()
+        assert np.abs(Dw - Do).max() <= 1e-12 * np.abs(Do).max() and abs(Lw - Lo).max() <= 1e-11 * max(1.0, abs(Lo).max())
+        print("separator of %d + %d (n = %d): many workgroups per front %.2f ms, one workgroup %.2f ms" % (ns, nq, n, tw, to))
+        assert tw < to
+        # a dense block of 1500 (24 chained fronts of up to 1500 rows)
+        M = rng.standard_normal((1500, 1500)); Kd = M @ M.T + 1500 * np.eye(1500)
+        Ad = sp.csc_matrix(np.triu(Kd))
+        bd = rng.standard_normal(1500)
+        times = {}
+        for on in (1, 0):
+            _wide_fronts(pkg, on)
+            Sd = pkg.SparseLDL(Ad, method="nested_dissection")
+            assert Sd.factorize(Ad) == 0
+            assert np.abs(Kd @ Sd.solve(bd) - bd).max() <= 1e-8 * np.abs(bd).max() * 10
+            Sd.factorize(Ad)
+            times[on] = Sd.timing()[0]
+            Sd.close()
+        print("dense block of 1500: many workgroups per front %.2f ms, one workgroup %.2f ms" % (times[1], times[0]))
+        assert times[1] < 0.25 * times[0]
+    finally:
+        _wide_fronts(pkg, was)
