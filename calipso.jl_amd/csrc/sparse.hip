@@ -156,7 +156,8 @@ __global__ void k_sp_permute_out(const double* __restrict__ x, const int* __rest
 // One record per node in LAUNCH order and one per (node, child): what a workgroup needs to find its front comes with ONE load each instead of a chain of
 // dependent table look-ups (order -> nfirst / ncols / nrows -> childptr -> children -> upd_off / rowptr ...: 0.7 us per hop on a cold launch).
 struct MfNode { int s, f, c, r; int rowptr, chfirst, nch, alp0; int alp1, pad0, pad1, pad2; long long panel_off, upd_off, u_off, foff; };
-struct MfChild { int rc, rowptr; long long upd_off, u_off; };
+// pad0: first row record of a front factored by many workgroups (sparse_wide.hpp; -1: none), pad1: launch position of the parent (-1: a root), pad2: the level's ypan
+struct MfChild { int rc, rowptr; long long upd_off, u_off; int pos, pad; };   // pos: the child's launch position
 struct MfRowItem { long long uoff; int relptr, a; };   // row a of a child's update matrix (offset in the update pool), the child's relative indices
 struct MfDev {
     int nnodes;
@@ -223,29 +224,20 @@ template <int J, int NC> __device__ __forceinline__ void mf_follow(double (&a)[1
 #ifdef CALIPSO_LDL_TRACE
 __device__ long long g_mf_trace[64 * 12];
 __device__ int g_mf_trace_n;
-#define MF_STAMP(slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_mf_trace[(mf_tr & 63) * 12 + (slot)] = wall_clock64(); } while (0)
+#define MF_STAMP(slot) do { if (mf_traced && threadIdx.x == 0) g_mf_trace[(mf_tr & 63) * 12 + (slot)] = wall_clock64(); } while (0)
 #else
 #define MF_STAMP(slot) do { } while (0)
 #endif
 
+// one front: assembly, the partial LDL^T of its first c columns, the panel and the update matrix to global memory (every thread of the workgroup arrives)
 template <int MF_THREADS, bool GF>
-__global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first, int ypan) {
-#ifdef CALIPSO_LDL_TRACE
-    __shared__ int mf_tr_s;
-    if (threadIdx.x == 0) mf_tr_s = (blockIdx.x == 0 && blockIdx.y == 0) ? atomicAdd(&g_mf_trace_n, 1) : 0;
-    __syncthreads();
-    const int mf_tr = mf_tr_s;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g_mf_trace[(mf_tr & 63) * 12 + 10] = d.nrec[first].c; g_mf_trace[(mf_tr & 63) * 12 + 11] = d.nrec[first].c + d.nrec[first].r; }
-#endif
+__device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd, const size_t z, const int ypan, double* __restrict__ Flds, const bool mf_traced, const int mf_tr) {
     MF_STAMP(0);
     constexpr int MF_RC = MF_THREADS / 16;        // row classes of the panel step (16 panel columns x MF_RC rows at a time)
-    extern __shared__ __attribute__((aligned(16))) double Flds[];
     __shared__ int relS[256];                                                  // relative indices of the child being extend-added (LDS fronts: r <= 196)
     __shared__ double rinvS[64];                                               // GF: reciprocal pivots (a node has at most 64 columns)
-    const MfNode nd = d.nrec[first + blockIdx.x];
     const int f = nd.f, c = nd.c, r = nd.r, m = c + r, nt = tri0(m);
     const int tid = threadIdx.x;
-    const size_t z = sl.use ? (size_t)sl.slot[blockIdx.y] : (size_t)blockIdx.y;   // storage slot of this instance of the batch
     double* F = GF ? d.fpool + z * d.sPool + nd.foff : Flds;                    // GF: the front lives in global memory (L2-resident)
     double* ycol = GF ? rinvS : F + nt;
     const double* Aval = d.Aval + z * d.sA;
@@ -443,7 +435,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     __syncthreads();
     MF_STAMP(4);
 #ifdef CALIPSO_LDL_TRACE
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { g_mf_trace[(mf_tr & 63) * 12 + 8] = mf_pan; g_mf_trace[(mf_tr & 63) * 12 + 9] = mf_upd; }
+    if (mf_traced && tid == 0) { g_mf_trace[(mf_tr & 63) * 12 + 8] = mf_pan; g_mf_trace[(mf_tr & 63) * 12 + 9] = mf_upd; }
 #endif
     double* P = panel + nd.panel_off;                                          // column-major m x c: column k contiguous over the rows
     // write-out: a wavefront per column of the panel (lanes along the rows: contiguous stores) / per row of the update matrix (lanes along the columns)
@@ -459,6 +451,23 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     MF_STAMP(5);
 }
 
+template <int MF_THREADS, bool GF>
+__global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first, int ypan) {
+    extern __shared__ __attribute__((aligned(16))) double Flds[];
+    bool mf_traced = false; int mf_tr = 0;
+#ifdef CALIPSO_LDL_TRACE
+    __shared__ int mf_tr_s;
+    mf_traced = blockIdx.x == 0 && blockIdx.y == 0;
+    if (threadIdx.x == 0) mf_tr_s = mf_traced ? atomicAdd(&g_mf_trace_n, 1) : 0;
+    __syncthreads();
+    mf_tr = mf_tr_s;
+    if (mf_traced && threadIdx.x == 0) { g_mf_trace[(mf_tr & 63) * 12 + 10] = d.nrec[first].c; g_mf_trace[(mf_tr & 63) * 12 + 11] = d.nrec[first].c + d.nrec[first].r; }
+#endif
+    const MfNode nd = d.nrec[first + blockIdx.x];
+    const size_t z = sl.use ? (size_t)sl.slot[blockIdx.y] : (size_t)blockIdx.y;   // storage slot of this instance of the batch
+    mf_factor_node<MF_THREADS, GF>(d, nd, z, ypan, Flds, mf_traced, mf_tr);
+}
+
 // forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors.
 // The c <= 64 dependent steps of the triangular solve run in ONE wavefront (lane = row, y_k by v_readlane, no barrier: ~20 cycles per step instead of a
 // workgroup barrier); the product with L21 is spread over all threads (four k-slices per row, combined in a fixed order).  The panel is read where it
@@ -469,16 +478,16 @@ __device__ __forceinline__ double mf_readlane_d(double v, int lane) {
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
 }
-template <int MF_THREADS, bool GP>
-__global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const MfNode nd = d.nrec[first + blockIdx.x];
+// (one node and right-hand side: yi = instance * nrhs + right-hand side, zs = the instance's storage slot; every thread of the workgroup arrives)
+template <int MF_THREADS>
+__device__ __forceinline__ void mf_forward_node(const MfDev& d, const MfNode& nd, const size_t yi, const size_t zs, int n, long long usum, double* __restrict__ X,
+                                                double* __restrict__ sm) {
     const int f = nd.f, c = nd.c, r = nd.r, m = c + r;
     double* v = sm;                                                            // m
     double* part = sm + m;                                                     // 4 r
-    double* x = X + (size_t)blockIdx.y * n;                                    // blockIdx.y = instance * nrhs + right-hand side
-    double* ubase = d.uvec + (size_t)blockIdx.y * usum;
-    const double* panel = d.panel + (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)) * d.sPanel;
+    double* x = X + yi * n;
+    double* ubase = d.uvec + yi * usum;
+    const double* panel = d.panel + zs * d.sPanel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* P = panel + nd.panel_off;
     // Every entry of the panel this thread will need is requested FIRST (the panel does not depend on the vector): the lower triangle of L11 by wavefront 0
@@ -536,16 +545,19 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
     double* u = ubase + nd.u_off;
     for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a] - ((part[a] + part[r + a]) + (part[2 * r + a] + part[3 * r + a]));
 }
+template <int MF_THREADS, bool GP>
+__global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const MfNode nd = d.nrec[first + blockIdx.x];                              // blockIdx.y = instance * nrhs + right-hand side
+    mf_forward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, usum, X, sm);
+}
 // backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C.  One wavefront per column for the product with L21'
 // (lanes along the rows, contiguous), then the c dependent steps in one wavefront (lane = column, x_i by v_readlane).
-template <int MF_THREADS, bool GP>
-__global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const MfNode nd = d.nrec[first + blockIdx.x];
+template <int MF_THREADS>
+__device__ __forceinline__ void mf_backward_node(const MfDev& d, const MfNode& nd, const size_t yi, const size_t zs, int n, double* __restrict__ X, double* __restrict__ sm) {
     const int f = nd.f, c = nd.c, r = nd.r, m = c + r;
     double* v = sm;
-    double* x = X + (size_t)blockIdx.y * n;
-    const size_t zs = (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs));
+    double* x = X + yi * n;
     const double* panel = d.panel + zs * d.sPanel; const double* Dg = d.D + zs * d.sD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* P = panel + nd.panel_off;
@@ -597,6 +609,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
         for (int q = 0; q < 32; ++q) { const int i = c - 33 - q; if (i >= 1) zk = fma(-pl1[q], mf_readlane_d(zk, i), zk); }
         if (lane < c) x[f + lane] = zk;
     }
+}
+template <int MF_THREADS, bool GP>
+__global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const MfNode nd = d.nrec[first + blockIdx.x];
+    mf_backward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, X, sm);
 }
 
 #include "sparse_wide.hpp"
@@ -689,14 +707,23 @@ int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
     return CALIPSO_OK;
 }
 
-void enqueue_factor(calipso_hip_sparse* s) {
-    if (s->mf) {
-        for (const MfSeg& g : s->mplan) {
-            if (g.wide.on) mf_wide_factor(s->stream, s->md, MfSlots{}, g.wide, g.first, g.count, (unsigned)s->batch);
-            else MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, (unsigned)s->batch), g.lds_factor, s->stream, s->md, MfSlots{}, g.first, g.ypan);
-        }
-        return;
+// the numeric factorisation of nz matrices (storage slots sl) on stream st: a launch per level of the tree (fronts beyond the LDS: three, sparse_wide.hpp)
+void mf_enqueue_factor(calipso_hip_sparse* s, hipStream_t st, const MfSlots& sl, unsigned nz) {
+    for (const MfSeg& g : s->mplan) {
+        if (g.wide.on) mf_wide_factor(st, s->md, sl, g.wide, g.first, g.count, nz);
+        else MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, nz), g.lds_factor, st, s->md, sl, g.first, g.ypan);
     }
+}
+// both sweeps of a solve for ny = instances x nrhs columns of X (already permuted)
+void mf_enqueue_solve(calipso_hip_sparse* s, hipStream_t st, const MfSlots& sl, unsigned ny, int nrhs, double* X) {
+    for (const MfSeg& g : s->mplan)
+        MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, st, s->md, sl, g.first, s->n, nrhs, s->usum, X);
+    for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g)
+        MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, st, s->md, sl, g->first, s->n, nrhs, X);
+}
+
+void enqueue_factor(calipso_hip_sparse* s) {
+    if (s->mf) { mf_enqueue_factor(s, s->stream, MfSlots{}, (unsigned)s->batch); return; }
     const size_t lds = s->lds_acc ? sizeof(double) * (size_t)s->n : 0;
     for (int z = 0; z < s->batch; ++z) {                    // the column method takes the matrices of a batch one after the other
         SpDev d = s->d;
@@ -777,10 +804,7 @@ int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch
     MfSlots sl{};
     sl.use = 1;
     for (int k = 0; k < bt.n; ++k) sl.slot[k] = bt.slot[k];
-    for (const MfSeg& g : sp->mplan) {
-        if (g.wide.on) mf_wide_factor(st, sp->md, sl, g.wide, g.first, g.count, nz);
-        else MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, nz), g.lds_factor, st, sp->md, sl, g.first, g.ypan);
-    }
+    mf_enqueue_factor(sp, st, sl, nz);
     hipLaunchKernelGGL(k_count_signs, dim3(1, 1, nz), dim3(256), 0, st, bt, sp->d.D, sp->n, icount);
     sp->factored = true;
     return CALIPSO_OK;
@@ -793,10 +817,7 @@ int sparse_solve_inplace(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt
     sl.use = 1;
     for (int k = 0; k < bt.n; ++k) { if (bt.slot[k] >= sp->batch) return CALIPSO_ERR_ARGUMENT; sl.slot[k] = bt.slot[k]; }
     hipLaunchKernelGGL(k_permute_in_slab, dim3(gx, 1, nz), dim3(256), 0, st, bt, x, sp->d_perm, sp->n, sp->d_x);
-    for (const MfSeg& g : sp->mplan)
-        MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, nz), g.lds_solve, st, sp->md, sl, g.first, sp->n, 1, sp->usum, sp->d_x);
-    for (auto g = sp->mplan.rbegin(); g != sp->mplan.rend(); ++g)
-        MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, nz), g->lds_solve, st, sp->md, sl, g->first, sp->n, 1, sp->d_x);
+    mf_enqueue_solve(sp, st, sl, nz, 1, sp->d_x);
     hipLaunchKernelGGL(k_permute_out_slab, dim3(gx, 1, nz), dim3(256), 0, st, bt, sp->d_x, sp->d_perm, sp->n, x);
     return CALIPSO_OK;
 }
@@ -811,10 +832,7 @@ int sparse_solve_inplace_multi(calipso_hip_sparse* s, hipStream_t st, int slot, 
     sl.slot[0] = slot;
     const unsigned gx = (unsigned)((s->n + 255) / 256), ny = (unsigned)p;
     hipLaunchKernelGGL(k_permute_in_cols, dim3(gx, ny), dim3(256), 0, st, X, ld, s->d_perm, s->n, s->d_x);
-    for (const MfSeg& g : s->mplan)
-        MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, st, s->md, sl, g.first, s->n, p, s->usum, s->d_x);
-    for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g)
-        MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, st, s->md, sl, g->first, s->n, p, s->d_x);
+    mf_enqueue_solve(s, st, sl, ny, p, s->d_x);
     hipLaunchKernelGGL(k_permute_out_cols, dim3(gx, ny), dim3(256), 0, st, s->d_x, s->d_perm, s->n, X, ld);
     return CALIPSO_OK;
 }
@@ -842,6 +860,7 @@ void sparse_work(const calipso_hip_sparse* sp, double out[3]) { out[0] = (double
 void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]) { out[0] = sp->levels; out[1] = sp->max_front; out[2] = sp->nnzU; out[3] = sp->mf ? 2 : (sp->lds_acc ? 1 : 0); }
 }  // namespace calipso
 
+// (tests / A-B timing) how plans made AFTERWARDS treat fronts beyond the LDS: 1 = many workgroups per front (default), 0 = one; returns the old value
 // (tests / A-B timing) how plans made AFTERWARDS treat fronts beyond the LDS: 1 = many workgroups per front (default), 0 = one; returns the old value
 extern "C" int32_t calipso_hip_debug_wide_fronts(int32_t on) { const int was = g_wide_fronts; if (on >= 0) g_wide_fronts = on != 0; return was; }
 #ifdef CALIPSO_LDL_TRACE
@@ -1189,16 +1208,20 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
         {
             std::vector<MfNode> nrec((size_t)NN);
             std::vector<MfChild> crec;
+            std::vector<int> pos_of((size_t)NN, 0), ypan_of((size_t)NN, 0);
+            for (int pos = 0; pos < NN; ++pos) pos_of[(size_t)m_order[(size_t)pos]] = pos;
+            for (const MfSeg& g : mplan) for (int q = 0; q < g.count; ++q) ypan_of[(size_t)(g.first + q)] = g.ypan;
             for (int pos = 0; pos < NN; ++pos) {
                 const int t = m_order[(size_t)pos];
                 MfNode& nd = nrec[(size_t)pos];
                 nd.s = t; nd.f = m_first[(size_t)t]; nd.c = m_cols[(size_t)t]; nd.r = m_rows[(size_t)t];
                 nd.rowptr = m_rowptr[(size_t)t]; nd.chfirst = (int)crec.size(); nd.nch = m_childptr[(size_t)t + 1] - m_childptr[(size_t)t];
-                nd.alp0 = (int)Alp[(size_t)nd.f]; nd.alp1 = (int)Alp[(size_t)(nd.f + nd.c)]; nd.pad0 = m_wbase.empty() ? -1 : m_wbase[(size_t)t]; nd.pad1 = nd.pad2 = 0;
+                nd.alp0 = (int)Alp[(size_t)nd.f]; nd.alp1 = (int)Alp[(size_t)(nd.f + nd.c)]; nd.pad0 = m_wbase.empty() ? -1 : m_wbase[(size_t)t];
+                nd.pad1 = m_parent[(size_t)t] >= 0 ? pos_of[(size_t)m_parent[(size_t)t]] : -1; nd.pad2 = ypan_of[(size_t)pos];
                 nd.panel_off = m_panel_off[(size_t)t]; nd.upd_off = m_upd_off[(size_t)t]; nd.u_off = m_u_off[(size_t)t]; nd.foff = m_foff.empty() ? 0 : m_foff[(size_t)t];
                 for (int q = m_childptr[(size_t)t]; q < m_childptr[(size_t)t + 1]; ++q) {
                     const int ch = m_children[(size_t)q];
-                    crec.push_back({m_rows[(size_t)ch], m_rowptr[(size_t)ch], m_upd_off[(size_t)ch], m_u_off[(size_t)ch]});
+                    crec.push_back({m_rows[(size_t)ch], m_rowptr[(size_t)ch], m_upd_off[(size_t)ch], m_u_off[(size_t)ch], pos_of[(size_t)ch], 0});
                 }
             }
             if ((rc = upload(s, nrec, &md.nrec)) || (rc = upload(s, crec, &md.crec))) return rc;
@@ -1323,10 +1346,7 @@ static int32_t sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const double* b
             PK(hipMalloc((void**)&s->md.uvec, sizeof(double) * need_u));
             s->cap_uvec = need_u;
         }
-        for (const MfSeg& g : s->mplan)
-            MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, s->stream, s->md, MfSlots{}, g.first, s->n, (int)nrhs, s->usum, s->d_x);
-        for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g)
-            MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, s->stream, s->md, MfSlots{}, g->first, s->n, (int)nrhs, s->d_x);
+        mf_enqueue_solve(s, s->stream, MfSlots{}, ny, (int)nrhs, s->d_x);
     } else {
         for (int z = 0; z < s->batch; ++z) {
             SpDev d = s->d;
