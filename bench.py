@@ -200,8 +200,9 @@ def cpu_baseline(shape, name="C3", staged=None, samples=3, full=False):
     t_fact = time.perf_counter() - t0
     t_i = float(np.median(times))
     extra = 1 + n_r                                # hidden re-factorisations: one per linear_solve! (first solve + n_r refinement solves)
-    b0ii = dict(value=1.0 / (t_i + extra * t_fact), unit="Newton steps/s", cores=1, factorizations_per_step=1 + extra, measured=False,
-                how="B0(i) median + %d x one separately timed factorisation (%.2f s)" % (extra, t_fact))
+    # (not derived any more: a figure that was not measured does not go into the line; one factorisation timed alone says what it would cost)
+    b0ii = dict(value=None, measured=False, factorizations_per_step=1 + extra, one_factorisation_s=t_fact,
+                how="not run by default (%d factorisations of %.1f s per step): --cpu-baseline-full measures it" % (1 + extra, t_fact))
     if full:
         of = fresh(1)
         dt, _ = one_step(of)
@@ -785,9 +786,19 @@ def main():
         byts = 8.0 * (sw["packed_doubles"] / 2.0 * passes + sw["factor_nnz"] * (1 + 2 * (1 + n_r)))      # (packed_doubles counts both orientations; a pass reads one)
         tf = flops / seconds_per_instance_step * 1e-12
         gb = byts / seconds_per_instance_step * 1e-9
-        return {"what": what, "flops_executed_per_step": flops, "schur_flops": sw["schur_flops"], "factor_flops": sw["factor_flops"], "bytes_executed_per_step": byts,
-                "us_per_instance_step": 1e6 * seconds_per_instance_step, "achieved_TFLOPs": tf, "frac_mfma": tf / FP64_MFMA_PEAK_TFLOPS, "achieved_GBs": gb, "frac_hbm": gb / 8000.0,
-                "bound": "launch latency (neither ceiling is near: see frac_mfma / frac_hbm)"}
+        out = {"what": what, "flops_executed_per_step": flops, "schur_flops": sw["schur_flops"], "factor_flops": sw["factor_flops"], "bytes_executed_per_step": byts,
+               "us_per_instance_step": 1e6 * seconds_per_instance_step, "achieved_TFLOPs": tf, "frac_mfma": tf / FP64_MFMA_PEAK_TFLOPS, "achieved_GBs": gb, "frac_hbm": gb / 8000.0,
+               "bound": "hbm" if gb / 8000.0 >= tf / FP64_MFMA_PEAK_TFLOPS else "mfma",
+               "limited_by": "launch latency: ~110 dependent launches of a few microseconds of work per step (frac_mfma and frac_hbm are both far from 1)"}
+        # the multifrontal factorisation of the LAST group factorisation that went through this handle's tree (events around its launches: k_gather_dense, one k_mf_factor
+        # per level, k_count_signs; the other lane's kernels run beside it)
+        ms = float(w.single.kernel_times()[0])
+        if ms > 0.0 and sw["factor_flops"] > 0:
+            tfk = sw["factor_flops"] * w.G / ms * 1e-9
+            out["kernels"] = {"k_mf_factor": {"bound": "mfma", "ms_per_group_factorisation": ms, "members": w.G, "flops_executed": sw["factor_flops"] * w.G,
+                                              "achieved": tfk, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfk / FP64_MFMA_PEAK_TFLOPS,
+                                              "note": "one launch per level of the stage tree (6-7), one workgroup per front and member; the levels near the root hold 1-5 fronts per member"}}
+        return out
 
     # =================================================================== config.c4: BASELINE config 4 ===========================
     # 256 quadruped-gait-sized problems sharded over 8 GPUs = 32 instances per GPU, here in groups of 16, two groups in flight: C4 (the dense
@@ -834,6 +845,25 @@ def main():
                                                                "roofline": structured_roofline(wa, int(ia[0]["refinement_rounds"]), ea / P4 / wa.B, "%d instances in groups of %d" % (wa.B, ga))}
                 wa.close()
                 del wa
+                # config 4 is 256 problems on 8 GPUs: what N GPUs would make of it from the per-GPU rates measured HERE at 256 / N instances (no collective on the data path:
+                # a projection from one GPU's measurements, the driver's SCALE run is the measurement)
+                if args.c4_all == 256 and world == 1:
+                    per_gpu = {256: ra / world, args.c4_batch: r2 / world}
+                    for bb in (128, 64):
+                        if bb in per_gpu:
+                            continue
+                        wb = Workload(pkg, pr, cname, rank, world, local_rank, bb, min(128, bb), 2)
+                        for _ in range(2):
+                            wb.batched_pass()
+                        eb, _, _ = run_batched(wb, P4)
+                        per_gpu[bb] = wb.B * P4 / eb
+                        wb.close()
+                        del wb
+                    if all(k in per_gpu for k in (256, 128, 64, 32)):
+                        c4[cname]["strong_scaling_projection"] = {
+                            "what": "256 problems over N GPUs = 256 / N instances per GPU, each rate measured on ONE GPU; speedup = N x rate(256 / N) / rate(256)",
+                            "steps_per_s_per_gpu": {str(k): per_gpu[k] for k in (256, 128, 64, 32)},
+                            "speedup": {str(n): n * per_gpu[256 // n] / per_gpu[256] for n in (1, 2, 4, 8)}}
 
     c2 = c5 = None
     if rank == 0 and world == 1 and not args.no_c2_c5 and args.config == "C3":
@@ -852,7 +882,7 @@ def main():
                    "refinement_rounds": refinement_rounds, "factorizations_per_step": factorizations,
                    "cpu_baseline_rows": "cpu_baseline.kind = 'port': the repo's single-thread C++ restatement of the reference's CPU path (oracle/), NOT the Julia reference (no julia on the box: "
                                         "B2 says so); value = B0(i), one factorisation per step (favourable to the reference); B0_ii (the reference's re-factorisation before every solve) is "
-                                        + ("MEASURED in this run (--cpu-baseline-full)" if args.cpu_baseline_full else "DERIVED from B0(i) + separately timed factorisations (measured: false; --cpu-baseline-full measures it, ~90 s more)")
+                                        + ("MEASURED in this run (--cpu-baseline-full)" if args.cpu_baseline_full else "NOT in this line (value: null; --cpu-baseline-full measures it, ~100 s more)")
                                         + "; B1 = LAPACK on all cores, not the reference",
                    "batched": batched, "c4": c4, "c2": c2, "c5": c5, "roofline_phases": cfg_phases},
         "roofline": roof,

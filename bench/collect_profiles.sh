@@ -8,6 +8,7 @@ cpy bench_group_under_rocprof.json bench_group_under_rocprof.json
 cpy kernel_stats_single.csv kernel_stats_single.csv
 cpy kernel_stats_group.csv kernel_stats_group.csv
 cpy kernel_stats_c4t_group.csv kernel_stats_c4t_group.csv
+[ -s "$O/kernel_stats_c4t_group.csv" ] && python3 "$R/bench/steps_only_stats.py" "$O/kernel_stats_c4t_group.csv" "$D/${P}_kernel_stats_c4t_group_steps_only.csv"
 cpy pmc_summary.json pmc_summary.json
 for m in single group; do for c in FETCH_SIZE WRITE_SIZE MfmaUtil SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do cpy pmc_${m}_$c.csv pmc_${m}_$c.csv; done; done
 cpy bench_C4.json bench_C4.json
@@ -22,4 +23,7 @@ cpy mf_trace.txt mf_front_timeline.txt
 cpy ldl_bulk_trace.txt ldl_bulk_trace.txt
 cpy step_gaps_under_rocprof.txt step_gaps_under_rocprof.txt
 cpy diag_bench3.txt diag_bench3.txt
+cpy wide_fronts.txt wide_fronts.txt
+cpy kernel_stats_wide_fronts.csv kernel_stats_wide_fronts.csv
+[ -s "$R/gpurun_out/sparse_ldl_rate.json" ] && cp "$R/gpurun_out/sparse_ldl_rate.json" "$D/${P}_sparse_ldl_rate.json"
 ls $D | grep "^${P}_" | wc -l

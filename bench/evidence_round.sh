@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/ cites for a round, in one call on the GPU box (bash bench/evidence_round.sh): output under gpurun_out/round/.
 #   profile_round.sh (default bench line, kernel stats and PMC passes of the single system and of one group), the per-launch durations of the
-#   LDL^T chain (single / group), the C4 and C4T bench lines and the kernel stats of one C4T group, the chain timeline, the block harnesses.
+#   LDL^T chain (single / group), the C4 and C4T bench lines and the kernel stats of one C4T group, the chain timeline, the block harnesses, the wide fronts of the multifrontal path.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/round; mkdir -p $O
 cd $R
 bash bench/profile_round.sh 12 > $O/profile_round.log 2>&1
@@ -19,5 +19,9 @@ CALIPSO_HIP_LFAC=0 timeout 300 python bench/ldl_trace.py > $O/ldl_chain_timeline
 timeout 300 python bench/mf_trace.py > $O/mf_trace.txt 2>&1
 timeout 300 python bench/ldl_bulk_trace.py 12 > $O/ldl_bulk_trace.txt 2>&1
 bash bench/step_gaps.sh > /dev/null 2>&1; cp gpurun_out/step_gaps.txt $O/step_gaps_under_rocprof.txt
+timeout 300 python bench/wide_fronts.py 1500 5 > $O/wide_fronts.txt 2>&1      # fronts beyond the LDS: many workgroups per front against one (sparse_wide.hpp)
+timeout 200 python bench/wide_fronts.py 4000 2 1 >> $O/wide_fronts.txt 2>&1
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_wf -- python $R/bench/wide_fronts.py 1500 5 1 > /dev/null 2>&1 < /dev/null)
+f=$(find $O/stats_wf -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_wide_fronts.csv; rm -rf $O/stats_wf
 hipcc -O3 --offload-arch=gfx950 bench/diag_bench3.hip -o /tmp/d3 2>/dev/null && timeout 60 /tmp/d3 > $O/diag_bench3.txt
 ls -la $O | head -60
