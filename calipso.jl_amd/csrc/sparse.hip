@@ -158,7 +158,7 @@ __global__ void k_sp_permute_out(const double* __restrict__ x, const int* __rest
 struct MfNode { int s, f, c, r; int rowptr, chfirst, nch, alp0; int alp1, pad0, pad1, pad2; long long panel_off, upd_off, u_off, foff; };
 // pad0: first row record of a front factored by many workgroups (sparse_wide.hpp; -1: none), pad1: launch position of the parent (-1: a root), pad2: the level's ypan
 struct MfChild { int rc, rowptr; long long upd_off, u_off; int pos, pad; };   // pos: the child's launch position
-struct MfRowItem { long long uoff; int relptr, a; };   // row a of a child's update matrix (offset in the update pool), the child's relative indices
+struct MfRowItem { long long uoff; int relptr, a, uo, pad; };   // row a of a child's update matrix (offset in the update pool), the child's relative indices, the row's entry of the child's vector (solves)
 struct MfDev {
     int nnodes;
     const MfNode* nrec;                       // [launch position]
@@ -194,9 +194,10 @@ typedef double calipso_v4d __attribute__((ext_vector_type(4)));
 constexpr int MF_BIG = 96;
 constexpr int MF_MAX_FRONT = 196;             // (m (m + 1) / 2 + 2 m) doubles <= 160 KiB: the front's lower triangle, packed, + the pivot-column buffers
 constexpr int MF_PY = 18;                     // row stride of the exchange rows of an in-register panel (pivot16.hpp)
-constexpr int MF_MAX_FRONT_GLOBAL = 4095;     // larger fronts live in global memory (L2): same algorithm, every access a memory access — slower (one workgroup
-                                              // per front: a 1500-row front is ~0.5 ms), but still tree-parallel; 4095 is where the 24-bit index arithmetic of
-                                              // the packed triangle ends (tri0): beyond it the column method takes over
+constexpr int MF_MAX_FRONT_WIDE = 8192;       // fronts factored and solved by many workgroups (sparse_wide.hpp); beyond: the column method
+constexpr int MF_MAX_FRONT_GLOBAL = 4095;     // the ONE-workgroup kernels on fronts in global memory (calipso_hip_debug_wide_fronts(0): the A/B reference of
+                                              // sparse_wide.hpp): same algorithm as in LDS, every access a memory access (a 1500-row front is ~2 ms); 4095 is where
+                                              // the 24-bit index arithmetic of the packed triangle ends (tri0)
 
 // The front is symmetric: only its lower triangle is held, packed row by row (row i starts at i (i + 1) / 2), which lets fronts of up to 196 rows
 // fit the 160 KiB of LDS (a full square would stop at 141).
@@ -653,6 +654,9 @@ struct calipso_hip_sparse {
     int batch = 1, selected = 0;                 // matrices of this pattern factored together / the one get_factor reads
     long long upd_total = 0, pool_total = 0;
     int wide_count = 0;                          // most fronts of one level factored by many workgroups (their scratch: sparse_wide.hpp)
+    int wide_blocks = 1;                         // most row blocks of such a front in the backward sweep
+    double* wpart = nullptr;                     // partial products of the backward sweep: (column of the solve, node of the level, row block, 64)
+    size_t cap_wpart = 0;
     std::vector<i64> inertia_all;                // batch x 3
     std::vector<void*> dev;                      // every device allocation
     SpDev d{};
@@ -707,6 +711,18 @@ int upload(calipso_hip_sparse* s, const std::vector<T>& h, const T** out) {
     return CALIPSO_OK;
 }
 
+// room for the partial products of the wide fronts' backward sweep, for `cols` columns per solve
+int mf_reserve_wide_solve(calipso_hip_sparse* s, size_t cols) {
+    if (!s->wide_count) return CALIPSO_OK;
+    const size_t need = cols * (size_t)s->wide_count * (size_t)s->wide_blocks * 64;
+    if (need > s->cap_wpart) {
+        if (s->wpart) (void)hipFree(s->wpart);
+        s->wpart = nullptr; s->cap_wpart = 0;
+        PK(hipMalloc((void**)&s->wpart, sizeof(double) * need));
+        s->cap_wpart = need;
+    }
+    return CALIPSO_OK;
+}
 // the numeric factorisation of nz matrices (storage slots sl) on stream st: a launch per level of the tree (fronts beyond the LDS: three, sparse_wide.hpp)
 void mf_enqueue_factor(calipso_hip_sparse* s, hipStream_t st, const MfSlots& sl, unsigned nz) {
     for (const MfSeg& g : s->mplan) {
@@ -716,10 +732,15 @@ void mf_enqueue_factor(calipso_hip_sparse* s, hipStream_t st, const MfSlots& sl,
 }
 // both sweeps of a solve for ny = instances x nrhs columns of X (already permuted)
 void mf_enqueue_solve(calipso_hip_sparse* s, hipStream_t st, const MfSlots& sl, unsigned ny, int nrhs, double* X) {
-    for (const MfSeg& g : s->mplan)
-        MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, st, s->md, sl, g.first, s->n, nrhs, s->usum, X);
-    for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g)
-        MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, st, s->md, sl, g->first, s->n, nrhs, X);
+    const bool wide_ok = s->wpart && (size_t)ny * (size_t)s->wide_count * (size_t)s->wide_blocks * 64 <= s->cap_wpart;
+    for (const MfSeg& g : s->mplan) {
+        if (g.wide.solve && wide_ok) mf_wide_forward(st, s->md, sl, g.wide, g.first, g.count, ny, s->n, nrhs, s->usum, X);
+        else MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, st, s->md, sl, g.first, s->n, nrhs, s->usum, X);
+    }
+    for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g) {
+        if (g->wide.solve && wide_ok) mf_wide_backward(st, s->md, sl, g->wide, g->first, g->count, ny, s->n, nrhs, X, s->wpart, s->wide_blocks);
+        else MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, st, s->md, sl, g->first, s->n, nrhs, X);
+    }
 }
 
 void enqueue_factor(calipso_hip_sparse* s) {
@@ -854,7 +875,7 @@ int sparse_reserve_solve(calipso_hip_sparse* s, int batch) {
         PK(hipMalloc((void**)&s->md.uvec, sizeof(double) * need_u));
         s->cap_uvec = need_u;
     }
-    return CALIPSO_OK;
+    return mf_reserve_wide_solve(s, (size_t)batch);
 }
 void sparse_work(const calipso_hip_sparse* sp, double out[3]) { out[0] = (double)sp->flops; out[1] = (double)sp->nnzL; out[2] = (double)sp->n; }
 void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]) { out[0] = sp->levels; out[1] = sp->max_front; out[2] = sp->nnzU; out[3] = sp->mf ? 2 : (sp->lds_acc ? 1 : 0); }
@@ -887,6 +908,7 @@ int32_t calipso_hip_sparse_destroy(calipso_hip_sparse* s) {
     if (s->d_rhs) (void)hipFree(s->d_rhs);
     if (s->d_x) (void)hipFree(s->d_x);
     if (s->md.uvec) (void)hipFree(s->md.uvec);
+    if (s->wpart) (void)hipFree(s->wpart);
     if (s->e0) (void)hipEventDestroy(s->e0);
     if (s->e1) (void)hipEventDestroy(s->e1);
     if (s->stream && s->owns_stream) (void)hipStreamDestroy(s->stream);
@@ -1040,7 +1062,7 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
     int wide_count = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
         const int width = attempt < 7 ? (int[]){64, 56, 48, 40, 32, 24, 16}[attempt] : 64;
-        const int front_limit = attempt < 7 ? MF_MAX_FRONT : MF_MAX_FRONT_GLOBAL;
+        const int front_limit = attempt < 7 ? MF_MAX_FRONT : (g_wide_fronts ? MF_MAX_FRONT_WIDE : MF_MAX_FRONT_GLOBAL);
         if (method != 4 || base_pieces.empty() || use_mf) break;
         pieces.clear();
         for (const auto& bp : base_pieces) for (int o = 0; o < bp.second; o += width) pieces.push_back({bp.first + o, std::min(width, bp.second - o)});
@@ -1085,6 +1107,7 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                 m_u_off[(size_t)t] = usum; usum += r;
                 m_rowsv.insert(m_rowsv.end(), R[(size_t)t].begin(), R[(size_t)t].end());
             }
+            if (upd_total + panel_total > (1ll << 31)) { use_mf = false; continue; }      // (16 GiB of update matrices + panels per matrix: the column method instead)
             // relative indices into the parent's front, children lists, levels
             m_rel.assign(m_rowsv.size(), 0);
             std::vector<std::vector<int>> kids((size_t)NN);
@@ -1142,7 +1165,7 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                     wide_count = std::max(wide_count, b - a);
                     for (int q = a; q < b; ++q) {
                         const int t = m_order[(size_t)q], f = m_first[(size_t)t], c = m_cols[(size_t)t], r = m_rows[(size_t)t], mm = c + r;
-                        wide.m = std::max(wide.m, mm); wide.r = std::max(wide.r, r);
+                        wide.m = std::max(wide.m, mm); wide.r = std::max(wide.r, r); wide.nch = std::max(wide.nch, (int)kids[(size_t)t].size());
                         // per row of the front: its entries of A (any order: distinct targets) and the child rows that land in it, children ascending
                         const int base = (int)w_ptrE.size();
                         m_wbase[(size_t)t] = base;
@@ -1162,10 +1185,11 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                         }
                         for (int ch : kids[(size_t)t]) for (int k = 0; k < m_rows[(size_t)ch]; ++k) {       // kids are ascending: so is every row's item list
                             const int at = c0 + atC[(size_t)m_rel[(size_t)m_rowptr[(size_t)ch] + (size_t)k]]++;
-                            w_C[(size_t)at] = {m_upd_off[(size_t)ch] + (long long)k * m_rows[(size_t)ch], m_rowptr[(size_t)ch], k};
+                            w_C[(size_t)at] = {m_upd_off[(size_t)ch] + (long long)k * m_rows[(size_t)ch], m_rowptr[(size_t)ch], k, (int)(m_u_off[(size_t)ch] + k), 0};
                         }
                     }
                 }
+                wide.solve = wide.on && (wide.m > 2048 || wide.nch > 4);
                 mplan.push_back({a, b - a, lf, ls, mmax > (size_t)MF_BIG ? 512 : 256, glob, ypan, wide});
                 mf_widest = std::max(mf_widest, b - a);
                 a = b;
@@ -1227,6 +1251,7 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
             if ((rc = upload(s, nrec, &md.nrec)) || (rc = upload(s, crec, &md.crec))) return rc;
         }
         s->pool_total = pool_total; s->wide_count = wide_count;
+        for (const MfSeg& g : mplan) if (g.wide.solve) s->wide_blocks = std::max(s->wide_blocks, (g.wide.r + WF_SOLVE_ROWS - 1) / WF_SOLVE_ROWS);
         if (wide_count && ((rc = upload(s, w_ptrE, &md.wptrE)) || (rc = upload(s, w_ptrC, &md.wptrC)) || (rc = upload(s, w_Ecol, &md.wEcol)) ||
                            (rc = upload(s, w_Esrc, &md.wEsrc)) || (rc = upload(s, w_C, &md.wC)))) return rc;
         if ((rc = alloc_values(s, 1))) return rc;      // (again: now with the pool of the global-memory fronts)
@@ -1346,6 +1371,7 @@ static int32_t sparse_solve(calipso_hip_sparse* s, int64_t nrhs, const double* b
             PK(hipMalloc((void**)&s->md.uvec, sizeof(double) * need_u));
             s->cap_uvec = need_u;
         }
+        { const int wrc = mf_reserve_wide_solve(s, cols); if (wrc) return wrc; }
         mf_enqueue_solve(s, s->stream, MfSlots{}, ny, (int)nrhs, s->d_x);
     } else {
         for (int z = 0; z < s->batch; ++z) {

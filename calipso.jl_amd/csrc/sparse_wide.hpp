@@ -23,11 +23,13 @@
 constexpr int WF_LDT = 66;                                           // row stride of the operand tiles in LDS (k fastest: conflict-free fragment reads)
 constexpr int WF_UPDATE_LDS = 3 * 64 * WF_LDT * (int)sizeof(double);
 constexpr int WF_DIAG_LDS = calipso::DIAG_LDS_DOUBLES * (int)sizeof(double);
-constexpr int WF_ROWS = 4;                                           // rows of a front per k_wf_assemble workgroup (a wavefront each)
+constexpr int WF_ROWS = 4;                                           // rows of a front per k_wf_assemble workgroup (a wavefront each); fewer where 4 rows exceed the LDS
+constexpr int WF_ASSEMBLE_LDS = 160 * 1024 - 2048;
+constexpr int WF_SOLVE_ROWS = 1024;                                  // rows of L21 per workgroup of the backward sweep's partial products
 // scratch of one (node of the level, matrix): X | M | L11 (64 x 64 column-major each) | D (64) | counters
 constexpr int WF_SCR_X = 0, WF_SCR_M = 4096, WF_SCR_L = 8192, WF_SCR_D = 12288, WF_SCR_I = 12352, WF_SCR = 12416;
 
-__device__ __forceinline__ int wf_tri(int i) { return (i * (i + 1)) >> 1; }                 // m <= 4095: fits 24 bits
+__device__ __forceinline__ int wf_tri(int i) { return (i * (i + 1)) >> 1; }                 // m <= MF_MAX_FRONT_WIDE: fits 31 bits
 __device__ __forceinline__ size_t wf_slot(const MfSlots& sl) { return sl.use ? (size_t)sl.slot[blockIdx.z] : (size_t)blockIdx.z; }
 __device__ __forceinline__ double* wf_scratch(const MfDev& d) { return d.wscr + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * WF_SCR; }
 
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(64 * WF_ROWS) void k_wf_assemble(const MfDev d, con
     extern __shared__ __attribute__((aligned(16))) double wf_rows_lds[];
     const MfNode nd = d.nrec[first + blockIdx.y];
     const int m = nd.c + nd.r, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = WF_ROWS * (int)blockIdx.x + wave;
+    const int row = (int)(blockDim.x >> 6) * (int)blockIdx.x + wave;
     if (row >= m) return;                                             // (no workgroup barrier below: a wavefront works alone on its row)
     const size_t z = wf_slot(sl);
     double* acc = wf_rows_lds + (size_t)wave * stride;
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(64 * WF_ROWS) void k_wf_assemble(const MfDev d, con
     const double* upd = d.upd + z * d.sUpd;
     const int base = nd.pad0 + row;
     const int e0 = d.wptrE[base], e1 = d.wptrE[base + 1], c0 = d.wptrC[base], c1 = d.wptrC[base + 1];
-    MfRowItem it = c0 < c1 ? d.wC[c0] : MfRowItem{0, 0, 0};
+    MfRowItem it = c0 < c1 ? d.wC[c0] : MfRowItem{0, 0, 0, 0, 0};
     for (int e = lane; e <= row; e += 64) acc[e] = 0.0;
     for (int p = e0 + lane; p < e1; p += 64) acc[d.wEcol[p]] = Aval[d.wEsrc[p]];      // (the LDS queue of a wavefront is in order)
     for (int q = c0; q < c1; ++q) {
@@ -210,11 +212,11 @@ __global__ __launch_bounds__(256) void k_wf_update(const MfDev d, const MfSlots 
 }
 
 // what a level's launches must cover (maxima over its nodes)
-struct MfWide { int on = 0; int m = 0, r = 0; };
+struct MfWide { int on = 0; int m = 0, r = 0, nch = 0; int solve = 0; };   // solve: the sweeps of this level by many workgroups too (measured cross-over: ~2200 rows, or many children per node)
 
 inline bool mf_wide_prepare(std::string* err) {
     if (!calipso::lds_attribute((const void*)k_wf_update, WF_UPDATE_LDS) || !calipso::lds_attribute((const void*)k_wf_diag, WF_DIAG_LDS) ||
-        !calipso::lds_attribute((const void*)k_wf_assemble, 160 * 1024 - 2048)) {
+        !calipso::lds_attribute((const void*)k_wf_assemble, WF_ASSEMBLE_LDS)) {
         if (err) *err = "the wide-front kernels: the LDS attribute was refused";
         return false;
     }
@@ -223,11 +225,149 @@ inline bool mf_wide_prepare(std::string* err) {
 
 inline void mf_wide_factor(hipStream_t st, const MfDev& md, const MfSlots& sl, const MfWide& w, int first, int count, unsigned nz) {
     const int stride = (w.m + 1) & ~1;
-    hipLaunchKernelGGL(k_wf_assemble, dim3((unsigned)((w.m + WF_ROWS - 1) / WF_ROWS), (unsigned)count, nz), dim3(64 * WF_ROWS),
-                       sizeof(double) * (size_t)stride * WF_ROWS, st, md, sl, first, stride);
+    int rows = WF_ROWS;
+    while (rows > 1 && sizeof(double) * (size_t)stride * rows > (size_t)WF_ASSEMBLE_LDS) rows >>= 1;
+    hipLaunchKernelGGL(k_wf_assemble, dim3((unsigned)((w.m + rows - 1) / rows), (unsigned)count, nz), dim3(64 * rows),
+                       sizeof(double) * (size_t)stride * rows, st, md, sl, first, stride);
     hipLaunchKernelGGL(k_wf_diag, dim3(1, (unsigned)count, nz), dim3(calipso::DIAG_THREADS), WF_DIAG_LDS, st, md, sl, first);
     if (w.r > 0) {
         const int nb = (w.r + 63) / 64;
         hipLaunchKernelGGL(k_wf_update, dim3((unsigned)(nb * (nb + 1) / 2 + nb), (unsigned)count, nz), dim3(256), WF_UPDATE_LDS, st, md, sl, first);
     }
+}
+
+// ---- the sweeps of a solve through such fronts ------------------------------------------------------------------------------------------------
+// One workgroup per node (k_mf_forward / k_mf_backward) keeps the front's vector in LDS (5 m doubles: m <= 4044) and reads the m x c panel alone (13 us at
+// 1500 rows, 27 at 4000).  Here a level is two launches per sweep, grid = (row block, node, instance x right-hand side):
+//   forward   k_wfs_head: v_C = b_C + the children's rows that land in the node's own columns (the per-row items of the assembly), y_C = L11^-1 v_C in one
+//             wavefront;  k_wfs_tail: u_R = (children's rows) - L21 y_C, a thread per row, four k-slices combined in k_mf_forward's order;
+//   backward  k_wfs_dot: partial products L21' x_R per block of WF_SOLVE_ROWS rows (a wavefront per 16 columns, lanes along the rows);
+//             k_wfs_back: z_C = y_C / D - the partial products in ascending block order, x_C = L11^-T z_C in one wavefront.
+// yi = blockIdx.z = instance * nrhs + right-hand side; the partial products of a level live in wpart[(yi * nodes of the level + node) * blocks * 64].
+__global__ __launch_bounds__(64) void k_wfs_head(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
+    const MfNode nd = d.nrec[first + blockIdx.y];
+    const int f = nd.f, c = nd.c, m = c + nd.r, lane = threadIdx.x;
+    const size_t yi = blockIdx.z;
+    double* x = X + yi * n;
+    const double* ubase = d.uvec + yi * usum;
+    const double* P = d.panel + (size_t)(sl.use ? sl.slot[yi / nrhs] : (int)(yi / nrhs)) * d.sPanel + nd.panel_off;
+    double pl0[32], pl1[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) pl0[q] = (q < c && lane > q && lane < c) ? P[lane + (size_t)q * m] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { const int k = 32 + q; pl1[q] = (k < c && lane > k && lane < c) ? P[lane + (size_t)k * m] : 0.0; }
+    double vi = 0.0;
+    if (lane < c) {
+        vi = x[f + lane];
+        const int base = nd.pad0 + lane;
+        for (int q = d.wptrC[base]; q < d.wptrC[base + 1]; ++q) vi += ubase[d.wC[q].uo];      // children in ascending order
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { if (q < c) vi = fma(-pl0[q], mf_readlane_d(vi, q), vi); }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { const int k = 32 + q; if (k < c) vi = fma(-pl1[q], mf_readlane_d(vi, k), vi); }
+    if (lane < c) x[f + lane] = vi;
+}
+
+__global__ __launch_bounds__(256) void k_wfs_tail(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, const double* __restrict__ X) {
+    __shared__ double y[64];
+    const MfNode nd = d.nrec[first + blockIdx.y];
+    const int f = nd.f, c = nd.c, r = nd.r, m = c + r, tid = threadIdx.x;
+    if ((int)blockIdx.x * 256 >= r) return;
+    const size_t yi = blockIdx.z;
+    const double* x = X + yi * n;
+    double* ubase = d.uvec + yi * usum;
+    const double* P = d.panel + (size_t)(sl.use ? sl.slot[yi / nrhs] : (int)(yi / nrhs)) * d.sPanel + nd.panel_off;
+    if (tid < 64) y[tid] = tid < c ? x[f + tid] : 0.0;
+    __syncthreads();
+    const int a = (int)blockIdx.x * 256 + tid;
+    if (a >= r) return;
+    double v = 0.0;
+    {
+        const int base = nd.pad0 + c + a;
+        for (int q = d.wptrC[base]; q < d.wptrC[base + 1]; ++q) v += ubase[d.wC[q].uo];
+    }
+    const int cs = (c + 3) / 4;
+    const double* Pi = P + (c + a);
+    double part[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const int kbeg = q4 * cs, kend = min(c, kbeg + cs);
+        double pv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pv[q] = kbeg + q < kend ? Pi[(size_t)(kbeg + q) * m] : 0.0;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += pv[q] * (kbeg + q < kend ? y[kbeg + q] : 0.0);
+        part[q4] = acc;
+    }
+    ubase[nd.u_off + a] = v - ((part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__global__ __launch_bounds__(256) void k_wfs_dot(const MfDev d, const MfSlots sl, int first, int n, int nrhs, int nblk, const double* __restrict__ X, double* __restrict__ wpart) {
+    const MfNode nd = d.nrec[first + blockIdx.y];
+    const int c = nd.c, r = nd.r, m = c + r, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a_beg = (int)blockIdx.x * WF_SOLVE_ROWS, a_end = min(r, a_beg + WF_SOLVE_ROWS);
+    const size_t yi = blockIdx.z;
+    double* out = wpart + ((yi * gridDim.y + blockIdx.y) * (size_t)nblk + blockIdx.x) * 64;
+    if (a_beg >= r) { if (tid < 64) out[tid] = 0.0; return; }
+    const double* x = X + yi * n;
+    const double* P = d.panel + (size_t)(sl.use ? sl.slot[yi / nrhs] : (int)(yi / nrhs)) * d.sPanel + nd.panel_off;
+    const int* R = d.rows + nd.rowptr;
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    for (int a0 = a_beg; a0 < a_end; a0 += 64) {
+        const int a = a0 + lane;
+        const bool in = a < a_end;
+        const double va = in ? x[R[in ? a : a_beg]] : 0.0;
+        double pv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int k = wave + 4 * q; pv[q] = (k < c && in) ? P[(c + a) + (size_t)k * m] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += pv[q] * va;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const double t = calipso::wave_sum(acc[q]);
+        if (lane == 0) out[wave + 4 * q] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_wfs_back(const MfDev d, const MfSlots sl, int first, int n, int nrhs, int nblk, double* __restrict__ X, const double* __restrict__ wpart) {
+    const MfNode nd = d.nrec[first + blockIdx.y];
+    const int f = nd.f, c = nd.c, r = nd.r, m = c + r, lane = threadIdx.x;
+    const size_t yi = blockIdx.z;
+    double* x = X + yi * n;
+    const size_t zs = (size_t)(sl.use ? sl.slot[yi / nrhs] : (int)(yi / nrhs));
+    const double* P = d.panel + zs * d.sPanel + nd.panel_off;
+    const double* Dg = d.D + zs * d.sD;
+    double pl0[32], pl1[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { const int i = c - 1 - q; pl0[q] = (i >= 1 && lane < i) ? P[i + (size_t)lane * m] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { const int i = c - 33 - q; pl1[q] = (i >= 1 && lane < i) ? P[i + (size_t)lane * m] : 0.0; }
+    double zk = 0.0;
+    if (lane < c) {
+        zk = x[f + lane] / Dg[f + lane];
+        const double* in = wpart + (yi * gridDim.y + blockIdx.y) * (size_t)nblk * 64 + lane;
+        double t = 0.0;
+        const int used = (r + WF_SOLVE_ROWS - 1) / WF_SOLVE_ROWS;
+        for (int b = 0; b < used; ++b) t += in[(size_t)b * 64];
+        zk -= t;
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { const int i = c - 1 - q; if (i >= 1) zk = fma(-pl0[q], mf_readlane_d(zk, i), zk); }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { const int i = c - 33 - q; if (i >= 1) zk = fma(-pl1[q], mf_readlane_d(zk, i), zk); }
+    if (lane < c) x[f + lane] = zk;
+}
+
+inline void mf_wide_forward(hipStream_t st, const MfDev& md, const MfSlots& sl, const MfWide& w, int first, int count, unsigned ny, int n, int nrhs, long long usum, double* X) {
+    hipLaunchKernelGGL(k_wfs_head, dim3(1, (unsigned)count, ny), dim3(64), 0, st, md, sl, first, n, nrhs, usum, X);
+    if (w.r > 0) hipLaunchKernelGGL(k_wfs_tail, dim3((unsigned)((w.r + 255) / 256), (unsigned)count, ny), dim3(256), 0, st, md, sl, first, n, nrhs, usum, X);
+}
+inline void mf_wide_backward(hipStream_t st, const MfDev& md, const MfSlots& sl, const MfWide& w, int first, int count, unsigned ny, int n, int nrhs, double* X, double* wpart, int nblk) {
+    if (w.r > 0) hipLaunchKernelGGL(k_wfs_dot, dim3((unsigned)((w.r + WF_SOLVE_ROWS - 1) / WF_SOLVE_ROWS), (unsigned)count, ny), dim3(256), 0, st, md, sl, first, n, nrhs, nblk, X, wpart);
+    hipLaunchKernelGGL(k_wfs_back, dim3(1, (unsigned)count, ny), dim3(64), 0, st, md, sl, first, n, nrhs, nblk, X, wpart);
 }

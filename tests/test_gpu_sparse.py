@@ -241,8 +241,8 @@ def test_global_accumulator_path_beyond_the_lds_limit(oracle_mod):
 
 def test_fronts_larger_than_the_lds_live_in_global_memory(oracle_mod):
     """a 2-D grid has separators of ~sqrt(n) vertices: the top fronts (hundreds of rows) exceed one CU's LDS and are factored in global memory by
-    the same kernels — up to 4095 rows (a dense block of 1500 and a mesh with a 1500-vertex separator below); beyond that the column method takes the whole
-    matrix — same answers either way"""
+    many workgroups per front (round 5, csrc/sparse_wide.hpp) — up to 8192 rows (a dense block of 1500 and a mesh with a 1500-vertex separator below); beyond that
+    the column method takes the whole matrix — same answers either way"""
     pkg = load_pkg()
     g = 180
     I = sp.identity(g, format="csc")
@@ -529,5 +529,24 @@ def test_wide_fronts_by_many_workgroups_match_the_one_workgroup_kernel_and_the_o
             Sd.close()
         print("dense block of 1500: many workgroups per front %.2f ms, one workgroup %.2f ms" % (times[1], times[0]))
         assert times[1] < 0.25 * times[0]
+        # beyond 4095 rows (where the one-workgroup kernels and their LDS-resident sweeps end): fronts of up to 4300 rows, the sweeps of the solve by many workgroups
+        # too; a quasi-definite matrix (the last 300 pivots negative), three right-hand sides
+        _wide_fronts(pkg, 1)
+        nb, nq2 = 4000, 300
+        M = rng.standard_normal((nb, nb)); H = M @ M.T / nb + 2.0 * np.eye(nb)
+        G2 = rng.standard_normal((nq2, nb)) / np.sqrt(nb)
+        C2 = rng.standard_normal((nq2, nq2)); C2 = C2 @ C2.T / nq2 + np.eye(nq2)             # (dense: one clique of 4300 vertices — a diagonal block would make 300 leaves of 4001 rows)
+        Kq = np.block([[H, G2.T], [G2, -C2]])
+        Aq = sp.csc_matrix(np.triu(Kq))
+        Sq = pkg.SparseLDL(Aq, method="nested_dissection")
+        assert Sq.info["numeric"] == "multifrontal"
+        assert Sq.factorize(Aq) == 0 and Sq.inertia == (nb, nq2, 0)
+        bq = rng.standard_normal((nb + nq2, 3))
+        xq = Sq.solve(bq)
+        assert np.abs(Kq @ xq - bq).max() <= 1e-9 * max(1.0, np.abs(xq).max())
+        xr = np.linalg.solve(Kq, bq)
+        assert np.abs(xq - xr).max() <= 1e-9 * max(1.0, np.abs(xr).max())
+        print("quasi-definite block of 4300: factor %.2f ms, solve (3 right-hand sides) %.2f ms" % Sq.timing())
+        Sq.close()
     finally:
         _wide_fronts(pkg, was)
