@@ -362,6 +362,19 @@ def test_zero_pivot_in_the_multifrontal_path():
     S.close()
 
 
+def test_zero_pivot_in_a_front_factored_by_many_workgroups():
+    """a 300 x 300 matrix of ones (rank one: the second pivot is exactly 1 - 1 = 0 whatever the order) is one clique = fronts of up to 300 rows in global memory
+    (csrc/sparse_wide.hpp): the zero pivot is reported as QDLDL reports it (positive = -1, everything from it on counted as zero)"""
+    pkg = load_pkg()
+    K = sp.csc_matrix(np.ones((300, 300)))
+    S = pkg.SparseLDL(sp.triu(K).tocsc(), method="nested_dissection")
+    assert S.info["numeric"] == "multifrontal"
+    assert S.factorize(sp.triu(K).tocsc()) == 1
+    _, _, D = S.factor()
+    assert D[0] == 1.0 and D[1] == 0.0 and S.inertia == (-1, 299, 299)
+    S.close()
+
+
 def test_device_resident_values_and_right_hand_sides():
     """calipso_hip_sparse_factorize_device / _solve_device: nothing but pointers crosses the boundary; same bits as the host-array calls"""
     if torch is None:
