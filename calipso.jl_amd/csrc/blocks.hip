@@ -161,9 +161,10 @@ __global__ __launch_bounds__(256) void k_bgemv_l(Batch bt, const LBlock* __restr
 // S[a][b] (na x nb <= 64 x 64) = Lsym[a][b] + ep I + sum over the blocks covering both segments of B[:, a]' Omega B[:, b].  256 threads: wavefront w forms
 // rows 16 w .. 16 w + 15 of the tile (four 16 x 16 MFMA tiles).  Rows of a block are taken in chunks of at most SB_KC that never split a second-order
 // cone.  LDS panels are k-fastest with stride SB_KC + 2 (the conflict-free fragment layout of schur.hip / ldl.hip).
-// SB_KC = 32 (3 panels x 64 x 34 doubles = 51 KB of LDS: three workgroups per CU) unless a cone is wider than that (then 64: one workgroup per CU)
+// SB_KC = 32 (3 panels x 64 x 34 doubles = 51 KB of LDS: three workgroups per CU — the launch bound holds the registers to 168 for that: 2 spilled, +3 % on C4T with
+// 192 instances against two per CU) unless a cone is wider than that (then 64: one workgroup per CU)
 template <int SB_KC>
-__global__ __launch_bounds__(256) void k_schur_blocks(BatchSc bt, Dims d, ConeDev cd, const SegPair* __restrict__ pairs, const int* __restrict__ pairblk, const Segment* __restrict__ seg,
+__global__ __launch_bounds__(256, SB_KC == 32 ? 3 : 1) void k_schur_blocks(BatchSc bt, Dims d, ConeDev cd, const SegPair* __restrict__ pairs, const int* __restrict__ pairblk, const Segment* __restrict__ seg,
                                                        const ZBlock* __restrict__ blk, const LBlock* __restrict__ lblk, const double* __restrict__ pk, const double* __restrict__ wz,
                                                        const double* __restrict__ Wsoc, double* __restrict__ S, int packed_S) {
     constexpr int SB_LD = SB_KC + 2;
