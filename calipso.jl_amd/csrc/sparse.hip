@@ -631,6 +631,14 @@ struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; bool
     } while (0)
 
 
+// the sweeps of a solve: 256 threads whatever the front (their 175-184 registers allow two wavefronts per SIMD: TWO workgroups of 256 per compute unit instead of one
+// of 512 — a level of a batch has more fronts than compute units, and the node's work is a few microseconds; the bits do not depend on the thread count)
+#define MF_LAUNCH_SOLVE(KERNEL, G, GRID, LDS, STREAM, ...)                                                                        \
+    do {                                                                                                                          \
+        if ((G).global) hipLaunchKernelGGL((KERNEL<512, true>), GRID, dim3(512), LDS, STREAM, __VA_ARGS__);                       \
+        else hipLaunchKernelGGL((KERNEL<256, false>), GRID, dim3(256), LDS, STREAM, __VA_ARGS__);                                \
+    } while (0)
+
 struct Segment { int first, count; bool chain; };
 
 }  // namespace
@@ -735,11 +743,11 @@ void mf_enqueue_solve(calipso_hip_sparse* s, hipStream_t st, const MfSlots& sl, 
     const bool wide_ok = s->wpart && (size_t)ny * (size_t)s->wide_count * (size_t)s->wide_blocks * 64 <= s->cap_wpart;
     for (const MfSeg& g : s->mplan) {
         if (g.wide.solve && wide_ok) mf_wide_forward(st, s->md, sl, g.wide, g.first, g.count, ny, s->n, nrhs, s->usum, X);
-        else MF_LAUNCH(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, st, s->md, sl, g.first, s->n, nrhs, s->usum, X);
+        else MF_LAUNCH_SOLVE(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, st, s->md, sl, g.first, s->n, nrhs, s->usum, X);
     }
     for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g) {
         if (g->wide.solve && wide_ok) mf_wide_backward(st, s->md, sl, g->wide, g->first, g->count, ny, s->n, nrhs, X, s->wpart, s->wide_blocks);
-        else MF_LAUNCH(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, st, s->md, sl, g->first, s->n, nrhs, X);
+        else MF_LAUNCH_SOLVE(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, st, s->md, sl, g->first, s->n, nrhs, X);
     }
 }
 
