@@ -306,6 +306,7 @@ int32_t calipso_hip_destroy(H* s) {
     scatter_release(s);
     if (s->spS) { (void)calipso_hip_sparse_destroy(s->spS); s->spS = nullptr; }
     if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
+    if (s->spS_inv) { (void)hipFree(s->spS_inv); s->spS_inv = nullptr; }
     if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
     calipso::blocks_release(s);
     double* dp[] = {s->slab, s->Kdense, s->multi_rhs, s->dsym_multi, s->evalL, s->evalZ};

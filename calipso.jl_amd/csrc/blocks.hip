@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void k_bgemv_l(Batch bt, const LBlock* __restr
 template <int SB_KC>
 __global__ __launch_bounds__(256, SB_KC == 32 ? 3 : 1) void k_schur_blocks(BatchSc bt, Dims d, ConeDev cd, const SegPair* __restrict__ pairs, const int* __restrict__ pairblk, const Segment* __restrict__ seg,
                                                        const ZBlock* __restrict__ blk, const LBlock* __restrict__ lblk, const double* __restrict__ pk, const double* __restrict__ wz,
-                                                       const double* __restrict__ Wsoc, double* __restrict__ S, int packed_S) {
+                                                       const double* __restrict__ Wsoc, double* __restrict__ S, int packed_S, double* __restrict__ Aval, long long sA,
+                                                       const int* __restrict__ inv) {
     constexpr int SB_LD = SB_KC + 2;
     __shared__ double As[64 * SB_LD];      // As[i][k] = B[k][a-column i]
     __shared__ double Bs[64 * SB_LD];      // Bs[j][k] = (Omega B)[k][b-column j]
@@ -264,7 +265,11 @@ __global__ __launch_bounds__(256, SB_KC == 32 ? 3 : 1) void k_schur_blocks(Batch
                     v += pk[lb.off_c + (size_t)min(li, lj) + (size_t)max(li, lj) * lb.n];
                 }
                 if (gi == gj) v += sc.ep;
-                if (packed_S) S[pr.soff + i + (size_t)j * sa.nc] = v;          // structured handles: the tile, contiguous (column-major, ld = rows of segment a)
+                if (packed_S) {                                                // structured handles: the tile, contiguous (column-major, ld = rows of segment a)
+                    const size_t cell = pr.soff + i + (size_t)j * sa.nc;
+                    S[cell] = v;
+                    if (inv) { const int e = inv[cell]; if (e >= 0) Aval[(size_t)bt.b.slot[blockIdx.z] * (size_t)sA + (size_t)e] = v; }      // ... and the multifrontal factorisation's copy (no gather launch)
+                }
                 else S[(size_t)gi + (size_t)gj * d.NP] = v;
             }
         }
@@ -445,10 +450,16 @@ bool blocks_schur(calipso_hip_solver* s) {
         for (int k = 0; k < bs.b.n; ++k) (void)hipMemsetAsync(s->S + bs.b.delta[k], 0, sizeof(double) * (size_t)s->d.NP * s->d.NP, s->stream);
         launch_pad_identity(s);
     }
+    // a structured handle whose S goes through the multifrontal factorisation: the kernel writes that factorisation's values too (structure.hip: spS_inv)
+    double* Aval = nullptr; long long sA = 0;
+    const bool direct = s->compact && s->stage_parallel && s->spS && s->spS_inv && bs.b.n <= sparse_batch(s->spS);
+    if (direct) sparse_values(s->spS, &Aval, &sA);
+    const int* inv = direct ? s->spS_inv : nullptr;
+    s->spS_values_current = direct;
     if (s->d.max_dim <= 32) hipLaunchKernelGGL(k_schur_blocks<32>, dim3(B.npairs, 1, bs.b.n), dim3(256), 0, s->stream, bs, s->d, s->cone, B.d_pairs, B.d_pairblk, B.d_seg, B.d_blk, B.d_lblk,
-                                               s->Lsym, s->wz, s->Wsoc, s->S, s->compact ? 1 : 0);
+                                               s->Lsym, s->wz, s->Wsoc, s->S, s->compact ? 1 : 0, Aval, sA, inv);
     else hipLaunchKernelGGL(k_schur_blocks<64>, dim3(B.npairs, 1, bs.b.n), dim3(256), 0, s->stream, bs, s->d, s->cone, B.d_pairs, B.d_pairblk, B.d_seg, B.d_blk, B.d_lblk, s->Lsym, s->wz,
-                            s->Wsoc, s->S, s->compact ? 1 : 0);
+                            s->Wsoc, s->S, s->compact ? 1 : 0, Aval, sA, inv);
     return true;
 }
 

@@ -247,6 +247,8 @@ struct calipso_hip_solver {
     bool compact = false;                     // structured handle (calipso_hip_create_structured): no dense Lxx / [gx; hx] / S / Tinv exist, only the blocks
     calipso_hip_sparse* spS = nullptr;
     long long* spS_src = nullptr;             // device: offset (row + col * NP) in S of every pattern entry
+    bool spS_values_current = false;          // k_schur_blocks has just written the multifrontal values of the active instances (consumed by launch_ldl)
+    int* spS_inv = nullptr;                   // structured handle: for every cell of the packed S the pattern entry it is (-1: none) — k_schur_blocks writes the multifrontal values itself
     int* d_reach = nullptr;                   // device copy of h_reach while the stage-parallel factorisation is on: uploads are re-checked against the skyline
     bool stage_parallel = false;
     calipso::i64 structure_resets = 0;   // uploads that broke an analysed structure (the handle went back to dense)
@@ -450,7 +452,8 @@ inline BatchSc batch_of(const calipso_hip_solver* s) {
 bool sparse_is_multifrontal(const calipso_hip_sparse* sp);
 void sparse_borrow_stream(calipso_hip_sparse* sp, hipStream_t st);
 int sparse_batch(const calipso_hip_sparse* sp);
-int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, const double* S, const long long* src, int* icount);
+int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, const double* S, const long long* src, int* icount, bool values_in_place = false);
+void sparse_values(calipso_hip_sparse* sp, double** values, long long* stride);      // the batch x nnz values the factorisation reads (instance-major)
 int sparse_solve_inplace(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, double* x);
 int sparse_reserve_solve(calipso_hip_sparse* sp, int batch);
 int sparse_solve_inplace_multi(calipso_hip_sparse* sp, hipStream_t st, int slot, double* X, long long ld, int p);

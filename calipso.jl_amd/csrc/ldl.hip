@@ -1118,7 +1118,7 @@ void launch_ldl(calipso_hip_solver* s) {
     s->ldl_failed = false;
     if (s->stage_parallel && s->spS) {        // stage-parallel: multifrontal LDL^T of S over its nested-dissection tree (sparse.hip)
         const Batch bt = batch_of(s).b;
-        if (sparse_factor_from_dense(s->spS, s->stream, bt, s->S, s->spS_src, s->icount) == CALIPSO_OK) { (void)hipEventRecord(s->ev[14], s->stream); return; }
+        if (sparse_factor_from_dense(s->spS, s->stream, bt, s->S, s->spS_src, s->icount, s->compact && s->spS_inv && s->spS_values_current) == CALIPSO_OK) { s->spS_values_current = false; (void)hipEventRecord(s->ev[14], s->stream); return; }
         if (s->compact) {
             s->err = "structured handle: the multifrontal factorisation was refused and there is no blocked one to fall back to";
             s->ldl_failed = true;             // (do_factorize turns it into CALIPSO_ERR_HIP: no stale inertia, no solve with an absent factor)

@@ -692,6 +692,7 @@ int alloc_values(calipso_hip_sparse* s, int batch) {
     const size_t B = (size_t)batch;
     for (double** pp : {&s->d_Aval, &s->d.Lx, &s->d.D, &s->md.panel, &s->md.upd, &s->md.fpool, &s->md.wscr}) if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
     PK(hipMalloc((void**)&s->d_Aval, sizeof(double) * B * std::max<size_t>((size_t)s->nnzA, 1)));
+    PK(hipMemset(s->d_Aval, 0, sizeof(double) * B * std::max<size_t>((size_t)s->nnzA, 1)));      // (entries a structured handle never writes are structural zeros)
     PK(hipMalloc((void**)&s->d.D, sizeof(double) * B * (size_t)s->n));
     if (s->mf) {
         PK(hipMalloc((void**)&s->md.panel, sizeof(double) * B * std::max<size_t>((size_t)s->panel_total, 1)));
@@ -825,11 +826,13 @@ void sparse_borrow_stream(calipso_hip_sparse* sp, hipStream_t st) {
 }
 int sparse_batch(const calipso_hip_sparse* sp) { return sp ? sp->batch : 0; }
 // gather the pattern's entries from the dense S of every instance of `bt`, factor, add the pivot signs to the instances' counters
-int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, const double* S, const long long* src, int* icount) {
+void sparse_values(calipso_hip_sparse* sp, double** values, long long* stride) { *values = sp ? sp->d_Aval : nullptr; *stride = sp ? (long long)sp->nnzA : 0; }
+// values_in_place: the caller has written the pattern's entries into sparse_values() itself (structured handles: blocks.hip) — no gather
+int sparse_factor_from_dense(calipso_hip_sparse* sp, hipStream_t st, const Batch& bt, const double* S, const long long* src, int* icount, bool values_in_place) {
     if (!sp || !sp->mf || bt.n > sp->batch) return CALIPSO_ERR_ARGUMENT;
     for (int k = 0; k < bt.n; ++k) if (bt.slot[k] >= sp->batch) return CALIPSO_ERR_ARGUMENT;
     const unsigned nz = (unsigned)bt.n;
-    hipLaunchKernelGGL(k_gather_dense, dim3((unsigned)((sp->nnzA + 255) / 256), 1, nz), dim3(256), 0, st, bt, S, src, (long long)sp->nnzA, sp->d_Aval);
+    if (!values_in_place) hipLaunchKernelGGL(k_gather_dense, dim3((unsigned)((sp->nnzA + 255) / 256), 1, nz), dim3(256), 0, st, bt, S, src, (long long)sp->nnzA, sp->d_Aval);
     MfSlots sl{};
     sl.use = 1;
     for (int k = 0; k < bt.n; ++k) sl.slot[k] = bt.slot[k];

@@ -199,6 +199,7 @@ int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_
     CK(hipStreamSynchronize(s->stream));
     if (s->spS) { (void)calipso_hip_sparse_destroy(s->spS); s->spS = nullptr; }
     if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
+    if (s->spS_inv) { (void)hipFree(s->spS_inv); s->spS_inv = nullptr; }
     if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
     s->stage_parallel = false;
     if (!on) { if (s->compact) { s->err = "calipso_hip_set_stage_parallel: a structured handle always factors through the multifrontal path"; return CALIPSO_ERR_ARGUMENT; } return CALIPSO_OK; }
@@ -248,11 +249,18 @@ int32_t calipso_hip_set_stage_parallel(calipso_hip_solver* s, int32_t on, int32_
     {
         hipError_t e = hipMalloc((void**)&s->spS_src, sizeof(long long) * std::max<size_t>(src.size(), 1));
         if (e == hipSuccess) e = hipMemcpy(s->spS_src, src.data(), sizeof(long long) * src.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess && s->compact) {     // the inverse map: which pattern entry a cell of the packed S is (cells above the diagonal of a diagonal tile: none)
+            std::vector<int> inv(s->blocks_zero_cell + 1, -1);       // (the packed S ends with the zero cell: api.hip)
+            for (size_t q = 0; q < src.size(); ++q) if (src[q] != (long long)s->blocks_zero_cell) inv[(size_t)src[q]] = (int)q;
+            e = hipMalloc((void**)&s->spS_inv, sizeof(int) * inv.size());
+            if (e == hipSuccess) e = hipMemcpy(s->spS_inv, inv.data(), sizeof(int) * inv.size(), hipMemcpyHostToDevice);
+        }
         if (e == hipSuccess) e = hipMalloc((void**)&s->d_reach, sizeof(int) * (size_t)std::max(nx, 1));
         if (e == hipSuccess) e = hipMemcpy(s->d_reach, s->h_reach.data(), sizeof(int) * (size_t)nx, hipMemcpyHostToDevice);
         if (e != hipSuccess) {                                          // nothing half-built stays behind
             (void)calipso_hip_sparse_destroy(sp);
             if (s->spS_src) { (void)hipFree(s->spS_src); s->spS_src = nullptr; }
+            if (s->spS_inv) { (void)hipFree(s->spS_inv); s->spS_inv = nullptr; }
             if (s->d_reach) { (void)hipFree(s->d_reach); s->d_reach = nullptr; }
             return calipso::check(s, e, "calipso_hip_set_stage_parallel");
         }
