@@ -24,7 +24,11 @@ from helpers import load_pkg
 from test_gpu_group import build
 pkg = load_pkg()
 out = []
-for shape, pid in (((1500, 300, 60, 30, 3), 41), ((2100, 200, 40, 20, 3), 42)):      # NP = 1536 (1024 + 512) and 2112 (two of 1024 + 64): ranges, tails, a narrow last block
+used = []
+SHAPES = (((1500, 300, 60, 30, 3), 41), ((2100, 200, 40, 20, 3), 42))      # NP = 1536 (1024 + 512) and 2112 (two of 1024 + 64): ranges, tails, a narrow last block
+if os.environ.get("CHILD_SHAPES"):
+    SHAPES = tuple((tuple(int(v) for v in t.split(",")), 50 + k) for k, t in enumerate(os.environ["CHILD_SHAPES"].split(";")))
+for shape, pid in SHAPES:
     s = build(pkg, pid, shape)
     if os.environ.get("CHILD_SOLVE_BLOCK"):
         s.set_option("solve_block", int(os.environ["CHILD_SOLVE_BLOCK"]))
@@ -34,6 +38,8 @@ for shape, pid in (((1500, 300, 60, 30, 3), 41), ((2100, 200, 40, 20, 3), 42)): 
         out.append(hashlib.sha256(np.ascontiguousarray(s.data("step").all).tobytes()).hexdigest())
         out.append(hashlib.sha256(np.ascontiguousarray(s.solution.all).tobytes()).hexdigest())
         out.append(repr(sorted((k, v) for k, v in info.items() if k in ("status", "refinement_rounds", "factorizations", "step_size"))))
+    used.append(int(s.kernel_times()[6]))          # 1: the last factorisation took the left-looking schedule
+print("LFAC " + "".join(str(u) for u in used))
 print("DIGEST " + hashlib.sha256("\n".join(out).encode()).hexdigest())
 '''
 
@@ -45,6 +51,7 @@ def run_variant(env):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("DIGEST ")]
     assert len(lines) == 1, r.stdout[-2000:]
+    run_variant.lfac = [l for l in r.stdout.splitlines() if l.startswith("LFAC ")][0][5:]
     return lines[0]
 
 
@@ -66,6 +73,17 @@ def test_schedule_independence_holds_for_other_solve_block_widths(solve_block):
     ref = run_variant(dict(sb, CALIPSO_HIP_LDL_OVERLAP="0", CALIPSO_HIP_LFAC="0"))
     for env in ({}, {"CALIPSO_HIP_LFAC": "0"}, {"CALIPSO_HIP_LDL_OVERLAP": "0"}):
         assert run_variant(dict(sb, **env)) == ref, (solve_block, env)
+
+
+@pytest.mark.parametrize("shapes", ["1000,40,0,0,3;1024,0,64,0,3", "1100,5,0,4,3;1300,700,100,50,4", "3000,1500,200,100,3"])
+def test_left_looking_schedule_on_edge_shapes(shapes):
+    """the planner of csrc/lfac.hip on shapes its scan was not tuned on: two stages of constraints and no cone (m = 40), no equality (m = 64), a single partial stage (m = 17),
+    cones of dimension 4, NP = 1024 (the smallest it takes) to 3072 — against the right-looking schedule, bit for bit"""
+    sh = {"CHILD_SHAPES": shapes}
+    a = run_variant(dict(sh)); la = run_variant.lfac
+    b = run_variant(dict(sh, CALIPSO_HIP_LFAC="0")); lb = run_variant.lfac
+    assert set(la) == {"1"} and set(lb) == {"0"}, (la, lb)          # the default really took the left-looking schedule on every shape
+    assert a == b, shapes
 
 
 def test_separate_solve_tail_kernels_agree_with_the_fused_launch():
