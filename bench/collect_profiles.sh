@@ -18,6 +18,7 @@ cpy ldl_steps_single.txt ldl_steps_single_right_looking.txt
 cpy ldl_steps_group12_pairs.txt ldl_steps_group12_pairs.txt
 cpy lfac_timeline.txt lfac_timeline.txt
 cpy lfac_items.txt lfac_items.txt
+cpy lfac_sizes.txt lfac_sizes.txt
 cpy ldl_chain_timeline.txt ldl_chain_timeline_right_looking.txt
 cpy mf_trace.txt mf_front_timeline.txt
 cpy ldl_bulk_trace.txt ldl_bulk_trace.txt

@@ -15,6 +15,7 @@ timeout 600 python bench.py --config C4T --batch 192 --group 64 --lanes 3 --no-c
 f=$(find $O/stats_c4t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_c4t_group.csv; rm -rf $O/stats_c4t
 bash bench/lfac_trace.sh round > $O/lfac_timeline.txt 2>&1      # per-launch timeline of the left-looking factorisation (one dense system)
 timeout 300 python bench/lfac_items.py > $O/lfac_items.txt 2>&1
+timeout 600 python bench/lfac_sizes.py > $O/lfac_sizes.txt 2>&1          # left-looking against right-looking at other sizes than C3
 CALIPSO_HIP_LFAC=0 timeout 300 python bench/ldl_trace.py > $O/ldl_chain_timeline.txt 2>&1      # the right-looking chain (what a group's members take), stamped build
 timeout 300 python bench/mf_trace.py > $O/mf_trace.txt 2>&1
 timeout 300 python bench/ldl_bulk_trace.py 12 > $O/ldl_bulk_trace.txt 2>&1
