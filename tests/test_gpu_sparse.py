@@ -362,6 +362,46 @@ def test_zero_pivot_in_the_multifrontal_path():
     S.close()
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_wide_fronts_on_random_quasidefinite_structures(seed):
+    """a banded SPD block with a dense arrow (40 variables coupled to everything), sparse random coupling to a negative-definite block: nested dissection puts the arrow and
+    the band's separators into fronts of several hundred rows with MANY children each (the per-row child lists of k_wf_assemble / k_wfs_head / k_wfs_tail) — inertia and
+    residual against the matrix itself, three right-hand sides, a batch of two"""
+    pkg = load_pkg()
+    rng = np.random.default_rng(100 + seed)
+    n1, nq, na = 2500, 300, 40
+    band = sp.diags([rng.uniform(-0.3, 0.3, n1 - k) for k in range(1, 25)], list(range(1, 25)), shape=(n1, n1))
+    A = (band + band.T + sp.diags(np.full(n1, 30.0))).tolil()
+    arrow = rng.standard_normal((na, n1)) * 0.2
+    A[:na, :] = arrow; A[:, :na] = arrow.T
+    A[:na, :na] = arrow[:, :na] @ arrow[:, :na].T + 60.0 * np.eye(na)
+    A = sp.csc_matrix(A); A = ((A + A.T) * 0.5).tocsc()
+    B = sp.random(nq, n1, density=0.004, random_state=np.random.RandomState(seed), data_rvs=lambda k: rng.standard_normal(k)).tocsc()
+    C = sp.diags(rng.uniform(0.5, 2.0, nq))
+    K = sp.bmat([[A, B.T], [B, -C]], format="csc"); K.sort_indices()
+    U = sp.triu(K).tocsc()
+    S = pkg.SparseLDL(U, method="nested_dissection")
+    assert S.info["numeric"] == "multifrontal"
+    assert S.factorize(U) == 0 and S.inertia == (n1, nq, 0)
+    b = rng.standard_normal((n1 + nq, 3))
+    x = S.solve(b)
+    assert np.abs(K @ x - b).max() <= 1e-9 * max(1.0, np.abs(x).max())
+    _, L1, D1 = S.factor()
+    S.set_batch(2)
+    U2 = U.copy(); U2.data = U2.data * (1.0 + 0.001 * rng.standard_normal(U2.nnz))
+    U2 = (U2 + sp.diags(np.r_[np.full(n1, 5.0), np.full(nq, -5.0)])).tocsc(); U2.sort_indices()
+    assert np.array_equal(U2.indices, U.indices)
+    S.factorize(np.stack([U2.data, U.data]))
+    S.select(1)
+    _, L2, D2 = S.factor()
+    assert np.array_equal(D1, D2) and (L1 != L2).nnz == 0            # in a batch: the bits it gets alone
+    K2 = (U2 + sp.triu(U2, 1).T).tocsc()
+    xb = S.solve(np.stack([b[:, 0], b[:, 0]]))
+    assert np.abs(K2 @ xb[0] - b[:, 0]).max() <= 1e-9 * max(1.0, np.abs(xb[0]).max())
+    assert np.array_equal(xb[1], x[:, 0])
+    S.close()
+
+
 def test_zero_pivot_in_a_front_factored_by_many_workgroups():
     """a 300 x 300 matrix of ones (rank one: the second pivot is exactly 1 - 1 = 0 whatever the order) is one clique = fronts of up to 300 rows in global memory
     (csrc/sparse_wide.hpp): the zero pivot is reported as QDLDL reports it (positive = -1, everything from it on counted as zero)"""
