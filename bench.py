@@ -421,8 +421,8 @@ class Workload:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="N > 1 outside torch.distributed.run: bench.py re-launches itself as N ranks (one per GPU)")
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=36, help="batched region: independent problem instances per GPU (B), arranged in groups of --group\n"
                     "members; --lanes groups are in flight at a time, see calipso.jl_amd/batch.py.  0 skips the batched region")
     ap.add_argument("--lanes", type=int, default=3, help="host threads / HIP streams driving the units (groups or single instances) concurrently")
