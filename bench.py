@@ -75,7 +75,108 @@ def staged_shape(st):
     return (T * nv, (T - 1) * nd, T * nn, T * nsoc, dim)
 
 
-def config_c2(pkg, pr, device):
+def _oracle_mod():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    return oracle
+
+
+def cpu_solve_baseline(prob, opts=None, reps=3, differentiate_reps=0):
+    """The oracle (oracle/: the repo's single-thread C++ restatement of the reference's CPU path — kind "port", NOT the Julia reference) on the SAME problem, same options,
+    same host evaluation functions (tests/problems.py), on this box's host: one solve! (median of `reps`), and differentiate! alone where asked.  Reported next to the
+    GPU figure whichever of the two wins."""
+    oracle = _oracle_mod()
+
+    def fresh():
+        o = oracle.OracleSolver(prob.nx, prob.np, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
+        for k, v in (opts or {}).items():
+            (o.set_opt if isinstance(v, float) else o.set_int)(k, v)
+        if prob.np:
+            o.buf("parameters")[:] = prob.parameters
+        o.point()["x"][:] = prob.x0
+        return o
+    ts, st, its, o = [], 0, 0, None
+    for _ in range(max(1, reps)):
+        o = fresh()
+        t0 = time.perf_counter()
+        st = o.solve(prob)
+        ts.append(1e3 * (time.perf_counter() - t0))
+        its = o.stats()["total_iterations"]
+    out = {"kind": "port", "cores": 1, "unit": "ms per solve!", "value": float(np.median(ts)), "solve_ms_all": ts, "solved": bool(st == 1), "newton_iterations": int(its),
+           "ms_per_newton_iteration": float(np.median(ts)) / max(1, int(its)),
+           "sample": "%d solve!s of the same problem by the oracle on one host core (evaluation = the same Python functions the GPU path calls back into)" % len(ts)}
+    if differentiate_reps > 0:
+        o.differentiate(prob)
+        t0 = time.perf_counter()
+        for _ in range(differentiate_reps):
+            o.differentiate(prob)
+        dms = 1e3 * (time.perf_counter() - t0) / differentiate_reps
+        out["differentiate_ms"] = dms
+        out["back_solves_per_s"] = prob.np / (dms * 1e-3)
+    return out
+
+
+def cpu_step_baseline(shape, staged=None, samples=1):
+    """B0(i) alone (one Newton step of problem 0 by the oracle, ONE factorisation, one host core) for a configuration other than the headline's: config.c4"""
+    oracle = _oracle_mod()
+    import problems as pr
+    nx, ne, n_nn, n_soc, dim = shape
+    if staged is not None:
+        prob, pt, lam = pr.staged_conic_qp(oracle.splitmix_uniform, 0, *staged)
+    else:
+        prob, pt, lam = pr.synthetic_conic_qp(oracle.splitmix_uniform, 0, nx, ne, n_nn, n_soc, dim)
+    o = oracle.OracleSolver(prob.nx, 0, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
+    o.point()["all"][:] = np.concatenate([pt[k] for k in "xrsyzt"])
+    o.buf("dual")[:] = lam
+    o.buf("central_path")[0] = 0.17
+    o.buf("penalty")[0] = 52.0
+    o.set_int("linear_solve_refactor", 0)
+    ts, rc = [], 0
+    for _ in range(max(1, samples)):
+        t0 = time.perf_counter()
+        prob.evaluate(pr.ALL_VARIABLE_FLAGS, pt["x"], pt["y"], pt["z"], np.zeros(0), o.buf)
+        o.cone(product=True, jacobian=True, target=True, barrier=True, barrier_gradient=True)
+        o.residual()
+        rc = o.search_direction()
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return {"kind": "port", "cores": 1, "unit": "Newton steps/s", "value": 1.0 / t, "seconds_per_step": t, "status": int(rc),
+            "sample": "%d Newton step(s) of problem 0 by the oracle, one factorisation per step (favourable to the reference)%s" % (
+                len(ts), "" if staged is None else "; the port assembles and factors the stage blocks as DENSE blocks — the reference's sparse LDL^T would exploit the stage structure, "
+                "so this row understates what the reference's CPU path does on a trajectory problem")}
+
+
+def config_c3_solve(pkg, pr, device, shape, cpu=True):
+    """A REAL solve! of one C3-shaped problem (advancing iterates: central-path / penalty updates, inertia-correction retries, line searches — not the repeated
+    non-advancing step of the headline): solve.jl:8-377 on the device with the attached QP evaluator, cold start (initialize_slacks! / initialize_duals!)."""
+    nx, ne, n_nn, n_soc, dim = shape
+    prob, pt, lam = pr.synthetic_conic_qp(pkg.splitmix_uniform, 1, nx, ne, n_nn, n_soc, dim)
+    out = {"workload": "one solve! (cold start, default options) of C3 problem 1: nx = %d, ne = %d, nc = %d" % (prob.nx, prob.ne, prob.nc)}
+    ms, st = [], None
+    for rep in range(2):                    # (the first solve pays the plan scan / first-use allocations of a fresh handle)
+        s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices, second_order_indices=prob.second_order_indices, device=device)
+        s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, 0.5)
+        pkg.initialize_b(s, pt["x"])
+        s.synchronize()
+        t0 = time.perf_counter()
+        try:
+            ok = pkg.solve_b(s)
+            err = None
+        except pkg.CalipsoHipError as e:
+            ok, err = False, str(e)
+        s.synchronize()
+        ms.append(1e3 * (time.perf_counter() - t0))
+        st = s.stats()
+        kt = s.kernel_times()
+        s.__del__()
+    out.update({"solved": bool(ok), "error": err, "solve_ms": ms[-1], "solve_ms_first": ms[0], "newton_iterations": int(st["total_iterations"]), "newton_steps_with_a_direction": int(st["newton_steps"]),
+                "outer_iterations": int(st["outer"]), "factorizations": int(st["factorizations"]), "max_refinement_rounds": int(st["max_refinement_rounds"]),
+                "refinement_failures": int(st["refinement_failures"]), "lu_fallbacks": int(st["fallbacks"]),
+                "newton_steps_per_s": st["newton_steps"] / (ms[-1] * 1e-3) if ms[-1] > 0 else None, "left_looking_schedule": int(kt[6])})
+    return out
+
+
+def config_c2(pkg, pr, device, cpu=True):
     """BASELINE config 2: the pendulum swing-up (T = 11; test/examples/pendulum.jl) as ONE full solve!: every inner Newton iteration of solve.jl:98-353 on the device,
     the Symbolics-generated evaluate! replaced by the restated problem functions on the host (callback: tests/problems.py).  Iterations are checked against the
     oracle-made golden trace (tests/golden/c2_pendulum_trace.npz)."""
@@ -109,10 +210,16 @@ def config_c2(pkg, pr, device):
         out["matches_golden_solution_1e-6"] = bool(np.abs(sol - g["solution"]).max() <= 1e-6 * max(1.0, np.abs(g["solution"]).max()))
     except Exception as e:      # (fixture missing: say so, do not fail the bench)
         out["golden"] = "unavailable: %s" % e
+    if cpu:
+        try:
+            out["cpu_baseline"] = cpu_solve_baseline(prob)
+            out["gpu_over_cpu"] = out["cpu_baseline"]["value"] / out["solve_ms"]      # > 1: the GPU path is faster; a 56 x 56 system is launch latency against arithmetic in cache
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
     return out
 
 
-def config_c5(pkg, pr, device):
+def config_c5(pkg, pr, device, cpu=True):
     """BASELINE config 5: cart-pole auto-tuning sensitivities dw*/dtheta (examples/autotuning/cartpole.jl:179-227, src/solver/differentiate.jl:1-61): nx = 49, ne = 40,
     102 parameter columns.  (a) differentiate! on one handle (dense and declared as the trajectory problem it is); (b) the batched LDS-resident path (csrc/small.hip:
     calipso_hip_small_*) for the back-solves of 1024 MPC steps at once, priced against HBM (its inputs and outputs are read / written once)."""
@@ -132,6 +239,12 @@ def config_c5(pkg, pr, device):
         dms = 1e3 * (time.perf_counter() - t0) / reps
         out[name] = {"solved": bool(ok), "newton_iterations": int(s.stats()["total_iterations"]), "differentiate_ms": dms, "back_solves_per_s": prob.np / (dms * 1e-3),
                      "device_bytes": int(s.device_bytes())}
+    if cpu:
+        try:
+            out["cpu_baseline"] = cpu_solve_baseline(prob, opts, reps=2, differentiate_reps=5)
+            out["gpu_over_cpu_differentiate"] = out["cpu_baseline"]["differentiate_ms"] / out["dense_handle"]["differentiate_ms"]
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
     n, nrhs, batch = prob.nx + prob.ne + prob.nc, prob.np, 1024
     rng = np.random.default_rng(0)
     Q = rng.standard_normal((n, n))
@@ -291,6 +404,7 @@ class Exchange:
     def __init__(self, pkg, dist, backend, rank, world, device, try_comm=None):
         self.pkg, self.dist, self.rank, self.world = pkg, dist, rank, world
         self.comm, self.path = None, "torch.distributed (%s)" % backend
+        self.ranks_reported = None          # the size the PRODUCT's RCCL communicator itself reports (ncclCommCount); None: the exchange went through torch.distributed
         if try_comm is None:
             try_comm = world == 1 or backend == "nccl"
         if try_comm:
@@ -308,6 +422,10 @@ class Exchange:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())
             if ok:
+                try:
+                    self.ranks_reported = int(self.comm.size()[0])
+                except Exception:
+                    self.ranks_reported = None
                 self.path = "calipso_hip_comm_gather_status / calipso_hip_comm_allreduce_sum (RCCL ncclAllGather / ncclAllReduce, csrc/comm.hip)"
             else:
                 self.close()
@@ -830,6 +948,14 @@ def main():
                          "device_bytes_per_instance": w4.single.device_bytes()}
             if w4.staged is not None and w4.structured:
                 c4[cname]["roofline"] = structured_roofline(w4, int(i2[0]["refinement_rounds"]), 1e-3 * c4[cname]["ms_per_pass"] / w4.B, "%d instances in groups of %d" % (w4.B, w4.G))
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                try:
+                    cb4 = cpu_step_baseline(w4.shape, w4.staged, samples=1)
+                    cb4["gpu_single_over_cpu"] = c4[cname]["single_system_steps_per_s"] / cb4["value"]
+                    cb4["gpu_batched_over_cpu"] = r2 / cb4["value"]
+                    c4[cname]["cpu_baseline"] = cb4
+                except Exception as e:
+                    c4[cname]["cpu_baseline"] = {"error": repr(e)}
             w4.close()
             del w4
             if cname == "C4T" and args.c4_all > 0:
@@ -868,11 +994,17 @@ def main():
     c2 = c5 = None
     if rank == 0 and world == 1 and not args.no_c2_c5 and args.config == "C3":
         try:
-            c2 = config_c2(pkg, pr, local_rank if args.force_device < 0 else args.force_device)
-            c5 = config_c5(pkg, pr, local_rank if args.force_device < 0 else args.force_device)
+            c2 = config_c2(pkg, pr, local_rank if args.force_device < 0 else args.force_device, cpu=not args.no_cpu_baseline)
+            c5 = config_c5(pkg, pr, local_rank if args.force_device < 0 else args.force_device, cpu=not args.no_cpu_baseline)
         except Exception as e:      # (never lose the headline line to a side figure)
             c2 = c2 or {"error": repr(e)}
             c5 = c5 or {"error": repr(e)}
+    c3_solve = None
+    if rank == 0 and world == 1 and not args.no_c2_c5 and args.config == "C3":
+        try:
+            c3_solve = config_c3_solve(pkg, pr, local_rank if args.force_device < 0 else args.force_device, shape)
+        except Exception as e:
+            c3_solve = {"error": repr(e)}
     out = {
         "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": steps_timed,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps_timed, "higher_is_better": True, "scaling": "weak",
@@ -884,7 +1016,8 @@ def main():
                                         "B2 says so); value = B0(i), one factorisation per step (favourable to the reference); B0_ii (the reference's re-factorisation before every solve) is "
                                         + ("MEASURED in this run (--cpu-baseline-full)" if args.cpu_baseline_full else "NOT in this line (value: null; --cpu-baseline-full measures it, ~100 s more)")
                                         + "; B1 = LAPACK on all cores, not the reference",
-                   "batched": batched, "c4": c4, "c2": c2, "c5": c5, "roofline_phases": cfg_phases},
+                   "batched": batched, "c4": c4, "c2": c2, "c5": c5, "c3_solve": c3_solve, "roofline_phases": cfg_phases,
+                   "rccl_ranks": exchange.ranks_reported, "exchange_path": exchange.path},
         "roofline": roof,
     }
     exchange.close()

@@ -837,6 +837,14 @@ class Comm:
             raise CalipsoHipError("comm_init failed (%d): %s" % (rc, self._L.calipso_hip_comm_last_error(h if h.value else None).decode()))
         self._c = h
 
+    def size(self):
+        """(ranks, own rank) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)"""
+        out = np.zeros(2, dtype=np.int32)
+        rc = self._L.calipso_hip_comm_size(self._c, out.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc < 0:
+            raise CalipsoHipError("comm_size failed (%d): %s" % (rc, self._L.calipso_hip_comm_last_error(self._c).decode()))
+        return int(out[0]), int(out[1])
+
     def gather_status(self, rows, capacity):
         rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
         out = np.zeros((int(capacity), 4), dtype=np.int32)

@@ -103,6 +103,7 @@ SYMBOLS = {
     "calipso_hip_comm_unique_id": (_i32, [C.POINTER(C.c_uint8)]),
     "calipso_hip_comm_init": (_i32, [_i32, _i32, C.POINTER(C.c_uint8), _i32, C.POINTER(_vp)]),
     "calipso_hip_comm_destroy": (_i32, [_vp]),
+    "calipso_hip_comm_size": (_i32, [_vp, _pi32]),
     "calipso_hip_comm_last_error": (C.c_char_p, [_vp]),
     "calipso_hip_comm_gather_status": (_i64, [_vp, _pi32, _i64, _pi32, _i64, _pi64]),
     "calipso_hip_comm_allreduce_sum": (_i32, [_vp, _pd, _i64]),

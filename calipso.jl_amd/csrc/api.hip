@@ -26,15 +26,15 @@ int check(H* s, hipError_t e, const char* what) {
 }
 bool lds_attribute(const void* kernel, int bytes) {
     static std::mutex mu;
-    static std::map<std::pair<const void*, int>, bool> done;
+    static std::map<std::pair<const void*, int>, std::pair<int, int>> done;      // (kernel, device) -> (largest size granted, smallest size refused; 0 / INT_MAX: none yet)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_pair(kernel, dev);
-    const auto it = done.find(key);
-    if (it != done.end()) return it->second;
+    auto& e = done.emplace(std::make_pair(kernel, dev), std::make_pair(0, 0x7fffffff)).first->second;
+    if (bytes <= e.first) return true;           // a size this large was granted before
+    if (bytes >= e.second) return false;         // a size this small was refused before
     const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-    done[key] = ok;
+    if (ok) e.first = bytes; else { e.second = bytes; (void)hipGetLastError(); }
     return ok;
 }
 }  // namespace calipso
@@ -704,9 +704,11 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
             s->stats.last_refine = it; s->stats.refine_max = std::max<calipso::i64>(s->stats.refine_max, it);
             return CALIPSO_OK;
         }
-        // a residual with a NaN in it reports +inf (vectors.hip: rabs): the reference's norm is NaN there, its loop condition `norm > tol` false — it leaves as soon
-        // as the minimum number of rounds is done and fails (iterative_refinement.jl:14-16, 45-51)
-        if (!std::isfinite(norm) && it >= o.min_iterative_refinement) break;
+        // a residual with a NaN in it reports +inf (vectors.hip: rabs).  The reference's norm is NaN there: `norm <= tol` is never true, so its loop (`while iteration <=
+        // max_iterative_refinement`, iterative_refinement.jl:14-44) runs ALL its rounds on NaNs before it fails (:45-51).  DEVIATION, same outcome: the rounds that cannot
+        // change the verdict are not run — the loop leaves as soon as the minimum number of rounds is done, fails (WARN_REFINEMENT -> the H \ residual fallback) and
+        // reports the reference's round count (max_iterative_refinement + 1) in rounds / stats so that the statistics agree with the reference's
+        if (!std::isfinite(norm) && it >= o.min_iterative_refinement) { it = (int)std::max<calipso::i64>(it, o.max_iterative_refinement + 1); break; }
         refine_solve(s);                   // step += step_correction fused into the recovery kernel
         refine_residual(s, true);
         if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
@@ -1316,7 +1318,7 @@ int32_t calipso_hip_kernel_times(H* s, double out[8]) {
     out[1] = (double)s->ldl_step_launches;              // k_ldl_diag + the k_ldl_step launches the last blocked factorisation queued
     out[2] = (double)s->d.NP;
     out[3] = (double)(s->slab_doubles * sizeof(double) + s->scratch_bytes);
-    { double lf[8]; calipso::lfac_describe(s, lf); out[6] = s->lfac_last ? 1.0 : 0.0; out[7] = lf[5]; }
+    { double lf[8]; calipso::lfac_describe(s, lf); out[6] = s->lfac_last ? 1.0 : (s->lfac_failed ? -1.0 : 0.0); out[7] = lf[5]; }      // [6] = -1: the left-looking schedule was wanted and could not be had (no plan / no memory; calipso_hip_last_error says which)
     if (s->matvec_timed && hipEventSynchronize(s->ev[6]) == hipSuccess) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s->ev[5], s->ev[6]) == hipSuccess) { out[4] = ms; out[5] = 8.0 * ((double)s->d.m * s->d.nx + (double)s->d.nx * s->d.nx); }

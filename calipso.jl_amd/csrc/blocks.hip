@@ -452,7 +452,9 @@ bool blocks_schur(calipso_hip_solver* s) {
     }
     // a structured handle whose S goes through the multifrontal factorisation: the kernel writes that factorisation's values too (structure.hip: spS_inv)
     double* Aval = nullptr; long long sA = 0;
-    const bool direct = s->compact && s->stage_parallel && s->spS && s->spS_inv && bs.b.n <= sparse_batch(s->spS);
+    bool direct = s->compact && s->stage_parallel && s->spS && s->spS_inv && bs.b.n <= sparse_batch(s->spS);
+    // (the kernel writes Aval[slot * sA + e]: every member SLOT of the launch — not only their number — must lie inside the reserved batch)
+    for (int k = 0; direct && k < bs.b.n; ++k) if (bs.b.slot[k] < 0 || bs.b.slot[k] >= sparse_batch(s->spS)) direct = false;
     if (direct) sparse_values(s->spS, &Aval, &sA);
     const int* inv = direct ? s->spS_inv : nullptr;
     s->spS_values_current = direct;

@@ -29,6 +29,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -43,7 +45,7 @@ Rccl& rccl() {
     }
     if (!r.lib) { r.err = std::string("cannot load librccl: ") + dlerror(); return r; }
 #define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name)); if (!r.field) { r.err = std::string("librccl lacks ") + name; return r; }
-    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount"); SYM(CommUserRank, "ncclCommUserRank");
     SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     return r;
@@ -87,6 +89,17 @@ int32_t calipso_hip_comm_init(int32_t rank, int32_t nranks, const uint8_t id[128
     ncclUniqueId u;
     std::memcpy(&u, id, 128);
     NC(R.CommInitRank(&c->comm, nranks, u, rank));
+    return CALIPSO_OK;
+}
+
+// what the COMMUNICATOR reports (ncclCommCount / ncclCommUserRank), not what the caller passed to calipso_hip_comm_init: a job whose ranks did not all join shows here
+int32_t calipso_hip_comm_size(calipso_hip_comm* c, int32_t out[2]) {
+    if (!c || !out || !c->comm) return CALIPSO_ERR_ARGUMENT;
+    Rccl& R = rccl();
+    int n = 0, r = -1;
+    NC(R.CommCount(c->comm, &n));
+    NC(R.CommUserRank(c->comm, &r));
+    out[0] = n; out[1] = r;
     return CALIPSO_OK;
 }
 

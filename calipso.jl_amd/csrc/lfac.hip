@@ -25,7 +25,15 @@
 #include "ldl_device.hpp"
 
 #include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <queue>
+#include <thread>
 #include <type_traits>
 
 namespace calipso {
@@ -369,6 +377,7 @@ struct LfacAux {
     int NP = 0, ne = 0, nc = 0;
     double *Zbuf = nullptr, *Lfac = nullptr;
     LItem* d_items = nullptr; int* d_wfirst = nullptr;
+    double plan_ms = 0.0;                   // host time of the plan scan this handle paid (0: the shape's plan was in the process-wide cache)
 };
 
 // cost model (microseconds on one compute unit while the whole chip is busy: the fp64 matrix cores sustain ~41 TFLOP/s on real data, 161 GFLOP/s per unit — a
@@ -580,29 +589,76 @@ static double lfac_plan_estimate(const LfacPlan& P) {
 }
 // The launch length (budget) and the head are chosen by the model (it reproduces the measured timeline within a few percent: profiles/r05_lfac_timeline.txt): a scan
 // of both (a fixed pair can be tried through calipso_hip_debug_lfac_plan / bench/lfac_plan.py).  The planner costs a few milliseconds per candidate, once per handle.
-static bool lfac_best_plan(LfacPlan& best, int nblk, int nx, int ne, int nc, int W) {
-    bool have = false;
-    double best_e = 0.0;
-    // (a candidate costs ~ nblk^2 microseconds of host time: 630 of them are 0.4 s at C3's 40 panels and 8 s at 128 — a coarser grid beyond 48 panels)
+static bool lfac_scan_plans(LfacPlan& best, int nblk, int nx, int ne, int nc, int W) {
+    // (a candidate costs ~ nblk^2 microseconds of host time: 630 of them are 0.4 s at C3's 40 panels and 8 s at 128 on ONE core — a coarser grid beyond 48 panels, and
+    // the candidates are independent: they are dealt over the host's cores, the winner is the first of the cheapest in candidate order whatever the thread count)
+    struct Cand { double b, h; int margin; };
+    std::vector<Cand> cands;
     const bool coarse = nblk > 48;
-    for (double b = 19.0; b <= 40.0; b += coarse ? 3.0 : 1.5) {
-        for (double h = 50.0; h <= 130.0; h += coarse ? 20.0 : 10.0) {
+    for (double b = 19.0; b <= 40.0; b += coarse ? 3.0 : 1.5)
+        for (double h = 50.0; h <= 130.0; h += coarse ? 20.0 : 10.0)
             for (int margin : {1 << 20, 3, 2, 1, 0}) {
                 if (coarse && margin != (1 << 20) && margin != 1) continue;
-                LfacPlan P;
-                if (!lfac_make_plan(P, nblk, nx, ne, nc, W, b, h, margin)) continue;
-                const double e = lfac_plan_estimate(P);
-                if (!have || e < best_e) { best = P; best_e = e; have = true; best.margin = margin; }
+                cands.push_back({b, h, margin});
             }
+    static const int env_threads = [] { const char* e = getenv("CALIPSO_HIP_LFAC_PLAN_THREADS"); return e ? atoi(e) : 0; }();
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = std::max(1, std::min<int>({env_threads > 0 ? env_threads : 16, hw ? (int)hw : 1, (int)cands.size()}));
+    std::vector<double> est(cands.size(), -1.0);            // the model's estimate of every feasible candidate (-1: infeasible)
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t c; (c = next.fetch_add(1)) < cands.size();) {
+            LfacPlan P;
+            if (lfac_make_plan(P, nblk, nx, ne, nc, W, cands[c].b, cands[c].h, cands[c].margin)) est[c] = lfac_plan_estimate(P);
         }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
     }
-    for (double b = 60.0; !have && b <= 400.0; b *= 1.5) have = lfac_make_plan(best, nblk, nx, ne, nc, W, b, 0.0);      // (shapes the scan does not cover)
-    return have;
+    int win = -1;
+    for (size_t c = 0; c < cands.size(); ++c) if (est[c] >= 0.0 && (win < 0 || est[c] < est[(size_t)win])) win = (int)c;
+    if (win >= 0) {
+        if (!lfac_make_plan(best, nblk, nx, ne, nc, W, cands[(size_t)win].b, cands[(size_t)win].h, cands[(size_t)win].margin)) return false;     // (deterministic: the same plan again)
+        best.margin = cands[(size_t)win].margin;
+        return true;
+    }
+    for (double b = 60.0; b <= 400.0; b *= 1.5) if (lfac_make_plan(best, nblk, nx, ne, nc, W, b, 0.0)) return true;      // (shapes the scan does not cover)
+    return false;
+}
+// One plan per SHAPE and process: handles of one shape (the lanes of bench.py, the members of a batch stepped alone, a handle re-created per MPC step) share it — the
+// scan runs once, every later handle of the shape finds its plan here (a shape that cannot be planned is remembered too).
+static std::shared_ptr<const LfacPlan> lfac_cached_plan(int nblk, int nx, int ne, int nc, int W, double* host_ms = nullptr) {
+    static std::mutex mu;
+    static std::map<std::array<int, 5>, std::shared_ptr<const LfacPlan>> cache;
+    const std::array<int, 5> key{nblk, nx, ne, nc, W};
+    std::lock_guard<std::mutex> lock(mu);      // (a second handle of the shape arriving during the scan waits for it instead of scanning again)
+    if (host_ms) *host_ms = 0.0;
+    const auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto P = std::make_shared<LfacPlan>();
+    std::shared_ptr<const LfacPlan> out;
+    if (lfac_scan_plans(*P, nblk, nx, ne, nc, W)) out = P;
+    cache[key] = out;
+    if (host_ms) *host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return out;
+}
+static bool lfac_best_plan(LfacPlan& best, int nblk, int nx, int ne, int nc, int W) {
+    const auto P = lfac_cached_plan(nblk, nx, ne, nc, W);
+    if (!P) return false;
+    best = *P;
+    return true;
 }
 
 bool lfac_on(const calipso_hip_solver* s) {
     static const int env = [] { const char* e = getenv("CALIPSO_HIP_LFAC"); return e ? atoi(e) : 1; }();
-    if (!env || s->cur || s->band64 > 0 || s->compact || s->blocks.on || (s->stage_parallel && s->spS) || s->lfac_failed) return false;
+    // CALIPSO_HIP_GRAPH_LDL=1 (ldl.hip: the panel steps as a captured graph on one stream) has no left-looking schedule: k_lfac takes the handle's scalars (rho, the
+    // regularisation) BY VALUE, so a replayed capture would rebuild S with the scalars of the first factorisation
+    static const bool graph_ldl = [] { const char* e = getenv("CALIPSO_HIP_GRAPH_LDL"); return e && atoi(e) != 0; }();
+    if (!env || graph_ldl || s->cur || s->band64 > 0 || s->compact || s->blocks.on || (s->stage_parallel && s->spS) || s->lfac_failed) return false;
     return s->d.NP >= 1024 && s->d.NP <= 8192 && s->d.m > 0;
 }
 
@@ -627,8 +683,19 @@ static LfacAux* lfac_prepare(calipso_hip_solver* s) {
     A = new LfacAux();
     A->NP = NP; A->ne = s->d.ne; A->nc = s->d.nc;
     bool ok = false;
-    ok = lfac_best_plan(A->plan, nblk, s->d.nx, s->d.ne, s->d.nc, 255);
+    {
+        double ms = 0.0;
+        const auto P = lfac_cached_plan(nblk, s->d.nx, s->d.ne, s->d.nc, 255, &ms);
+        A->plan_ms = ms;
+        if (P) { A->plan = *P; ok = true; }
+        else {      // (not an error: the handle keeps k_schur + the right-looking panel steps — but say so: calipso_hip_last_error, calipso_hip_kernel_times[6] = -1)
+            char buf[256];
+            snprintf(buf, sizeof buf, "note: no left-looking plan meets its deadlines for nx = %d, ne = %d, nc = %d (NP = %d): the right-looking schedule is kept", s->d.nx, s->d.ne, s->d.nc, NP);
+            s->err = buf;
+        }
+    }
     const size_t nn = (size_t)NP * NP;
+    const bool planned = ok;
     ok = ok && hipMalloc((void**)&A->Zbuf, nn * sizeof(double)) == hipSuccess && hipMalloc((void**)&A->Lfac, nn * sizeof(double)) == hipSuccess &&
          hipMalloc((void**)&A->d_items, std::max<size_t>(1, A->plan.items.size()) * sizeof(LItem)) == hipSuccess &&
          hipMalloc((void**)&A->d_wfirst, A->plan.wfirst.size() * sizeof(int)) == hipSuccess &&
@@ -636,7 +703,10 @@ static LfacAux* lfac_prepare(calipso_hip_solver* s) {
          hipMemcpy(A->d_wfirst, A->plan.wfirst.data(), A->plan.wfirst.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(A->Lfac, 0, nn * sizeof(double)) == hipSuccess;
     s->lfac_aux = A;
-    if (!ok) { lfac_release(s); s->lfac_failed = true; return nullptr; }
+    if (!ok) {
+        if (planned) { (void)hipGetLastError(); s->err = "note: the buffers of the left-looking schedule (2 NP^2 doubles) could not be allocated: the right-looking schedule is kept"; }
+        lfac_release(s); s->lfac_failed = true; return nullptr;
+    }
     return A;
 }
 
@@ -684,10 +754,17 @@ void lfac_describe(calipso_hip_solver* s, double out[8]) {
     for (size_t l = 2; l < A->plan.load.size(); ++l) { sum += A->plan.load[l]; ++n; }
     out[4] = n ? sum / n : 0.0;
     out[5] = 2.0 * (double)A->NP * A->NP * sizeof(double) + (double)A->plan.items.size() * sizeof(LItem) + (double)A->plan.wfirst.size() * sizeof(int);      // bytes outside the slab
-    out[6] = A->plan.budget; out[7] = lfac_plan_estimate(A->plan);
+    out[6] = A->plan_ms; out[7] = lfac_plan_estimate(A->plan);      // [6]: host milliseconds this handle spent scanning plans (0: cache hit)
 }
 
 }  // namespace calipso
+
+// the handle's schedule (bench/lfac_sizes.py): lfac_describe's eight numbers — [6] = host milliseconds of the plan scan this handle paid (0: cache hit)
+extern "C" int32_t calipso_hip_debug_lfac_describe(calipso_hip_solver* s, double out[8]) {
+    if (!s || !out) return CALIPSO_ERR_ARGUMENT;
+    calipso::lfac_describe(s, out);
+    return CALIPSO_OK;
+}
 
 // plan diagnostics without a device (tests, bench): per launch [longest worker (cost units), items, SCHUR items, FAR items, ROW items, longest ROW item]; returns the number of
 // launches, 0 if the shape cannot be planned within the budget

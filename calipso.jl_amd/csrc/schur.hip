@@ -554,6 +554,7 @@ void launch_pad_identity(calipso_hip_solver* s) {
 
 void launch_schur(calipso_hip_solver* s) {
     (void)lds_attribute((const void*)k_schur, (int)SCHUR_LDS_BYTES);      // (per device; several host lanes may arrive concurrently)
+    s->spS_values_current = false;        // (only a k_schur_blocks launch of THIS factorisation may have written the multifrontal values: blocks_schur sets it)
     if (blocks_schur(s)) return;          // stage blocks: S by segment pairs from the packed blocks (blocks.hip)
     if (s->hessian_dirty && !s->cur) { launch_symmetrize(s); s->hessian_dirty = false; }   // (a group refreshes its members itself)
     if (lfac_ready(s)) {                  // one dense system alone: the products are slices of the panel launches (lfac.hip), queued by launch_ldl

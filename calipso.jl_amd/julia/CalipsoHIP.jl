@@ -510,6 +510,13 @@ function HIPComm(rank::Integer, nranks::Integer, id::Vector{UInt8}; device::Inte
     finalizer(x -> ccall((:calipso_hip_comm_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), comm)
     return comm
 end
+"(ranks, own rank) as the live communicator reports them (ncclCommCount / ncclCommUserRank)"
+function comm_size(c::HIPComm)
+    out = zeros(Int32, 2)
+    rc = ccall((:calipso_hip_comm_size, lib), Int32, (Ptr{Cvoid}, Ptr{Int32}), c.handle, out)
+    rc == 0 || error("calipso_hip_comm_size failed ($rc)")
+    return Int(out[1]), Int(out[2])
+end
 "all-gather of the per-problem status rows (4 x k Int32 per rank, k may differ) in global problem-id order; `capacity` = total rows"
 function gather_status(c::HIPComm, rows::Matrix{Int32}, capacity::Integer)
     out = zeros(Int32, 4, capacity); counts = zeros(Int64, c.nranks)
@@ -523,7 +530,7 @@ function allreduce_sum!(c::HIPComm, v::Vector{Float64})
     return v
 end
 
-export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPComm, comm_unique_id, gather_status, allreduce_sum!, newton_step!,
+export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPComm, comm_unique_id, comm_size, gather_status, allreduce_sum!, newton_step!,
        search_direction_nonsymmetric!, analyze_structure!, clear_structure!, set_stage_parallel!, set_stage_blocks!, declared_structure, kernel_times, sync_scalars!, copy_back!
 
 end # module

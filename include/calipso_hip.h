@@ -433,6 +433,8 @@ typedef struct calipso_hip_comm calipso_hip_comm;
 int32_t calipso_hip_comm_unique_id(uint8_t id[128]);
 int32_t calipso_hip_comm_init(int32_t rank, int32_t nranks, const uint8_t id[128], int32_t device, calipso_hip_comm** out);
 int32_t calipso_hip_comm_destroy(calipso_hip_comm*);
+/* out[0] = ncclCommCount, out[1] = ncclCommUserRank of the live communicator (what RCCL itself reports: the self-check of a multi-GPU run) */
+int32_t calipso_hip_comm_size(calipso_hip_comm*, int32_t out[2]);
 const char* calipso_hip_comm_last_error(calipso_hip_comm*);
 /* rows: n_rows x 4 int32 of this rank (row counts may differ between ranks); all_rows: capacity cap_rows rows, filled in global
  * problem-id order; counts_out[nranks] (may be NULL) = rows per rank.  Returns the total row count or a negative status. */

@@ -94,6 +94,9 @@ def test_bench_line_contract():
     e = c4["smallT"]
     assert e["batched_newton_steps_per_s"] > 0 and e["single_system_steps_per_s"] > 0 and e["device_bytes_per_instance"] > 0
     assert abs(e["batched_problems_per_s_of_10_steps"] - e["batched_newton_steps_per_s"] / 10.0) < 1e-9
+    cb4 = e["cpu_baseline"]                                           # the oracle on the box's host beside the GPU figure (reported, never compared)
+    assert cb4["kind"] == "port" and cb4["cores"] == 1 and cb4["value"] > 0 and cb4["status"] == 0 and cb4["gpu_batched_over_cpu"] > 0
+    assert d["config"]["rccl_ranks"] == 1                             # the size the product's RCCL communicator itself reports (ncclCommCount)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and isinstance(c["sample"], str)
     assert len(c["samples_s"]) == 2
@@ -118,5 +121,5 @@ def test_bench_two_ranks_on_one_gpu(torchrun):
     assert abs(two["value"] - 2 * 3 / (two["ms_per_step"] * 3e-3)) <= 1e-6 * two["value"]         # both ranks' steps over the max time
     b2 = two["config"]["batched"]
     assert b2["instances_per_gpu"] == 4 and abs(b2["newton_steps_per_s"] - 2 * 4 * 3 / (b2["ms_per_pass"] * 3e-3)) <= 1e-6 * b2["newton_steps_per_s"]
-    assert "torch.distributed (gloo)" in b2["post_round_exchange"]
+    assert "torch.distributed (gloo)" in b2["post_round_exchange"] and two["config"]["rccl_ranks"] is None      # (no RCCL communicator between two ranks on one device)
     print("two ranks on one GPU (%s): %.1f steps/s single, %.1f batched" % ("torchrun" if torchrun else "self-spawned", two["value"], b2["newton_steps_per_s"]))

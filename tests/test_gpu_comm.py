@@ -15,6 +15,7 @@ def test_comm_single_rank_roundtrip():
     uid = pkg.Comm.unique_id()
     assert len(uid) == 128 and any(uid)
     c = pkg.Comm(0, 1, uid, device=0)
+    assert c.size() == (1, 0)                         # ncclCommCount / ncclCommUserRank of the live communicator
     rows = np.array([[1, 10 + i, 6, 3 * i] for i in range(5)], dtype=np.int32)
     out, counts = c.gather_status(rows, 5)
     assert np.array_equal(out, rows) and counts.tolist() == [5]
