@@ -25,20 +25,23 @@ from test_gpu_group import build
 pkg = load_pkg()
 out = []
 used = []
+facts = []
 SHAPES = (((1500, 300, 60, 30, 3), 41), ((2100, 200, 40, 20, 3), 42))      # NP = 1536 (1024 + 512) and 2112 (two of 1024 + 64): ranges, tails, a narrow last block
 if os.environ.get("CHILD_SHAPES"):
     SHAPES = tuple((tuple(int(v) for v in t.split(",")), 50 + k) for k, t in enumerate(os.environ["CHILD_SHAPES"].split(";")))
 for shape, pid in SHAPES:
-    s = build(pkg, pid, shape)
+    s = build(pkg, pid, shape, indefinite=float(os.environ.get("CHILD_INDEFINITE", "0")))
     if os.environ.get("CHILD_SOLVE_BLOCK"):
         s.set_option("solve_block", int(os.environ["CHILD_SOLVE_BLOCK"]))
     for it in range(2):
         info = s.newton_step(advance=True)
         assert info["status"] >= 0, info
+        facts.append(info["factorizations"])
         out.append(hashlib.sha256(np.ascontiguousarray(s.data("step").all).tobytes()).hexdigest())
         out.append(hashlib.sha256(np.ascontiguousarray(s.solution.all).tobytes()).hexdigest())
         out.append(repr(sorted((k, v) for k, v in info.items() if k in ("status", "refinement_rounds", "factorizations", "step_size"))))
     used.append(int(s.kernel_times()[6]))          # 1: the last factorisation took the left-looking schedule
+print("FACT " + " ".join(str(s_) for s_ in facts))
 print("LFAC " + "".join(str(u) for u in used))
 print("DIGEST " + hashlib.sha256("\n".join(out).encode()).hexdigest())
 '''
@@ -52,6 +55,7 @@ def run_variant(env):
     lines = [l for l in r.stdout.splitlines() if l.startswith("DIGEST ")]
     assert len(lines) == 1, r.stdout[-2000:]
     run_variant.lfac = [l for l in r.stdout.splitlines() if l.startswith("LFAC ")][0][5:]
+    run_variant.facts = [int(v) for v in [l for l in r.stdout.splitlines() if l.startswith("FACT ")][0][5:].split()]
     return lines[0]
 
 
@@ -63,6 +67,19 @@ def test_newton_steps_do_not_depend_on_the_schedule_of_the_factorisation():
                 {"CALIPSO_HIP_RHS_AHEAD": "0"},           # the operands of the first condensed solve on the main stream behind the factorisation instead of on the second stream
                 {"CALIPSO_HIP_SPEC_REFINE": "0"}):        # refinement rounds one by one, a host wait each, instead of queued ahead behind a device-side gate: same kernels, same order
         assert run_variant(env) == ref, env
+
+
+def test_refactorisations_of_the_inertia_correction_under_every_schedule():
+    """a non-convex Hessian: IC-1 fails its inertia test and inertia_correction! (inertia.jl:30-80) factors again with a larger primal regularisation — the scalars of the
+    SECOND factorisation of a step differ from those of the first.  Every schedule must rebuild S with the current scalars: under CALIPSO_HIP_GRAPH_LDL=1 (panel steps
+    replayed from a captured graph) the left-looking schedule, whose kernel carries the scalars by value, must not be captured (round-5 advisor finding)."""
+    sh = {"CHILD_SHAPES": "1100,200,40,20,3", "CHILD_INDEFINITE": "6.0"}
+    ref = run_variant(dict(sh, CALIPSO_HIP_LFAC="0", CALIPSO_HIP_LDL_OVERLAP="0"))
+    assert max(run_variant.facts) >= 2, run_variant.facts            # the regularisation loop really ran
+    for env in ({}, {"CALIPSO_HIP_GRAPH_LDL": "1"}, {"CALIPSO_HIP_LFAC": "0", "CALIPSO_HIP_GRAPH_LDL": "1"}, {"CALIPSO_HIP_LDL_PUBLISH": "0"}):
+        assert run_variant(dict(sh, **env)) == ref, env
+        if env.get("CALIPSO_HIP_GRAPH_LDL") == "1":
+            assert set(run_variant.lfac) == {"0"}                       # no left-looking schedule inside a captured graph
 
 
 @pytest.mark.parametrize("solve_block", [2048, 512])
