@@ -37,6 +37,13 @@ bool lds_attribute(const void* kernel, int bytes) {
     if (ok) e.first = bytes; else { e.second = bytes; (void)hipGetLastError(); }
     return ok;
 }
+// CALIPSO_HIP_FAULT_INJECT=launch (tests/test_gpu_robustness.py): a launch the runtime must refuse (1 MB of dynamic LDS) in the middle of the factorisation's launches —
+// what a kernel whose configuration the device cannot serve looks like to the host: nothing is returned, the error sits in hipGetLastError (host_logic.hpp: launch_errors)
+__global__ void k_fault_probe(int* p) { if (p) *p = 1; }
+void inject_refused_launch(hipStream_t stream) {
+    static const bool inject = [] { const char* f = getenv("CALIPSO_HIP_FAULT_INJECT"); return f && strstr(f, "launch") != nullptr; }();
+    if (inject) hipLaunchKernelGGL(k_fault_probe, dim3(1), dim3(64), 1u << 20, stream, (int*)nullptr);
+}
 }  // namespace calipso
 
 static std::string g_create_err;
@@ -523,8 +530,11 @@ static int publish_and_wait(H* s, const void* dsrc, void* hdst_dev, int words) {
 }
 // spin until the sequence number `seq` (written by a publish kernel or by a producer kernel itself) has arrived
 static int wait_published(H* s, unsigned long long seq) {
+    if (launch_errors(s, "a kernel launch of this phase was refused")) return CALIPSO_ERR_HIP;
     hipError_t q = hipSuccess;
-    const bool ok = host_wait([&] { return __atomic_load_n(s->hseq, __ATOMIC_ACQUIRE) == seq; },
+    // (>=: the sequence numbers of a handle only grow and only the publishes of its own in-order stream store them — a wait for an EARLIER number than the last one
+    // published is satisfied, not a hang; what was published under the earlier number is still in its mapped words)
+    const bool ok = host_wait([&] { return __atomic_load_n(s->hseq, __ATOMIC_ACQUIRE) >= seq; },
                               [&] { q = hipStreamQuery(s->stream); return q == hipErrorNotReady; });      // a faulted queue would never publish: look at the stream now and then
     if (ok) return 0;
     if (q != hipSuccess && q != hipErrorNotReady) return calipso::check(s, q, "publish_and_wait");
@@ -567,6 +577,7 @@ static int do_factorize(H* s, int64_t inertia[3], bool rhs_ahead_ok = false) {
         }
     }
     launch_scale_rows(s);
+    calipso::inject_refused_launch(s->stream);
     (void)hipEventRecord(s->ev[11], s->stream);
     launch_schur(s);
     (void)hipEventRecord(s->ev[12], s->stream);
@@ -578,6 +589,7 @@ static int do_factorize(H* s, int64_t inertia[3], bool rhs_ahead_ok = false) {
         // the last diagonal block published the counts when the pivot chain ended: the host goes on queueing behind the finish of the last solve block
         if (wait_published(s, s->ldl_pub_seq)) return CALIPSO_ERR_HIP;
     } else {
+        if (launch_errors(s, "a kernel launch of the factorisation was refused")) return CALIPSO_ERR_HIP;
         CK(hipMemcpyAsync(s->hicount, s->icount, sizeof(int) * 6, hipMemcpyDeviceToHost, s->stream));
         SYNC();
         factor_times(s);
@@ -592,13 +604,18 @@ static int do_factorize(H* s, int64_t inertia[3], bool rhs_ahead_ok = false) {
 
 // inertia.jl:30-80.  Quirk kept: the `primal_regularization_last == 0.0` test of :48 compares a Vector with a Float64 and is
 // always false, so IC-3 always takes max(min_regularization, scaling_regularization_last * eps_last).
-static int do_inertia_correction(H* s, int64_t* nfact, bool rhs_ahead_ok = false) {
+// first_in / first_rc: IC-1 (the factorisation with the initial regularisation) was queued — and its inertia read — by the caller already (inner_iteration: ahead of the
+// host's exit tests); the loop goes on from its result
+static int do_inertia_correction(H* s, int64_t* nfact, bool rhs_ahead_ok = false, const int64_t* first_in = nullptr, int first_rc = 0) {
     Options& o = s->opt; Scalars& sc = s->sc;
     int64_t in[3];
     int64_t count = 0;
     sc.ep = o.primal_regularization_initial;
     sc.ed = o.dual_regularization_initial;
-    int rc = do_factorize(s, in, rhs_ahead_ok); count++;         // IC-1
+    int rc;
+    if (first_in) { in[0] = first_in[0]; in[1] = first_in[1]; in[2] = first_in[2]; rc = first_rc; }
+    else rc = do_factorize(s, in, rhs_ahead_ok);
+    count++;                                                     // IC-1
     if (rc < 0) return rc;
     if (inertia_ok(s, in)) { if (nfact) *nfact = count; return CALIPSO_OK; }
     if (in[2] != 0) sc.ed = o.dual_regularization * std::pow(sc.kappa, o.dual_regularization_exponent);   // IC-2
@@ -666,6 +683,8 @@ static bool spec_refinement_ok(H* s) {
     return env && !s->cur && s->gate && s->d.m > 0 && !s->compact && !s->blocks.on && !(s->stage_parallel && s->spS) && wform_on(s) && solve_tail_available(s) &&
            s->opt.max_iterative_refinement >= 1;
 }
+// the round-by-round part of iterative_refinement! from a known state (norm of the current residual_error, the initial norm, rounds done); ran_more: a round was run here
+static int refinement_loop(H* s, double norm, double norm0, int it, int* rounds, double* final_norm, bool* ran_more);
 static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid = false) {
     const Options& o = s->opt; const Dims& d = s->d;
     // (fill!(step_correction, 0) of iterative_refinement.jl:5 is only launched when no round follows: the first round's k_recover writes every entry)
@@ -687,6 +706,9 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
             launch_refine_x_fused(s, true, nchunk, k, k == spec);
         }
         s->gate_epoch = 0;
+        // refine_defer (inner_iteration): the caller queues what follows the search direction behind these rounds and reads the report with ITS read-back
+        // (do_refinement_resume) — no host wait here
+        if (s->refine_defer) { s->refine_pending = true; if (rounds) *rounds = -1; return CALIPSO_OK; }
         if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
         norm = s->hscal[7]; norm0 = s->hscal[20]; it = (int)s->hscal[21]; met = s->hscal[22] != 0.0;
     } else {
@@ -696,6 +718,16 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
         norm0 = norm;
     }
     (void)met;
+    return refinement_loop(s, norm, norm0, it, rounds, final_norm, nullptr);
+}
+// the report of the speculative rounds has arrived with a later read-back of the caller: go on from it
+static int do_refinement_resume(H* s, int* rounds, bool* ran_more) {
+    s->refine_pending = false;
+    return refinement_loop(s, s->hscal[7], s->hscal[20], (int)s->hscal[21], rounds, nullptr, ran_more);
+}
+static int refinement_loop(H* s, double norm, double norm0, int it, int* rounds, double* final_norm, bool* ran_more) {
+    const Options& o = s->opt;
+    if (ran_more) *ran_more = false;
     while (it <= o.max_iterative_refinement) {
         if (norm <= o.iterative_refinement_tolerance && it >= o.min_iterative_refinement) {
             if (it == 0) fill_d(s, s->step_correction, s->d.N, 0.0);
@@ -709,6 +741,7 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
         // change the verdict are not run — the loop leaves as soon as the minimum number of rounds is done, fails (WARN_REFINEMENT -> the H \ residual fallback) and
         // reports the reference's round count (max_iterative_refinement + 1) in rounds / stats so that the statistics agree with the reference's
         if (!std::isfinite(norm) && it >= o.min_iterative_refinement) { it = (int)std::max<calipso::i64>(it, o.max_iterative_refinement + 1); break; }
+        if (ran_more) *ran_more = true;
         refine_solve(s);                   // step += step_correction fused into the recovery kernel
         refine_residual(s, true);
         if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
@@ -724,8 +757,9 @@ static int do_refinement(H* s, int* rounds, double* final_norm, bool zsx_valid =
     return CALIPSO_WARN_REFINEMENT;
 }
 
-static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
-    int rc = do_inertia_correction(s, nfact, true);
+// defer: the refinement's speculative rounds are queued and NOT waited for (s->refine_pending; the caller reads their report later and calls search_direction_finish)
+static int do_search_direction(H* s, int64_t* nfact, int* rounds, const int64_t* first_in = nullptr, int first_rc = 0, bool defer = false) {
+    int rc = do_inertia_correction(s, nfact, true, first_in, first_rc);
     if (rc < 0) {
         // operands queued ahead on the second stream belong to a factorisation that failed: wait for them, forget them (a later solve forms its own)
         if (s->rhs_ahead && s->stream2) (void)hipStreamSynchronize(s->stream2);
@@ -734,7 +768,9 @@ static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
     }
     do_sds(s, 0, nullptr, s->opt.iterative_refinement != 0, true);
     if (s->opt.iterative_refinement) {
+        s->refine_defer = defer; s->refine_pending = false;
         rc = do_refinement(s, rounds, nullptr, true);
+        s->refine_defer = false;
         if (rc < 0) return rc;
         if (rc == CALIPSO_WARN_REFINEMENT) {
             // the reference falls back to `H \ residual` on the unreduced system (search_direction.jl:22,113): fallback.hip
@@ -744,6 +780,29 @@ static int do_search_direction(H* s, int64_t* nfact, int* rounds) {
         }
     }
     return CALIPSO_OK;
+}
+// the rest of do_search_direction once the deferred refinement report has arrived; step_changed: the step is not the one the caller queued work on (further rounds ran,
+// or the fallback replaced it)
+static int search_direction_finish(H* s, int* rounds, bool* step_changed) {
+    bool more = false;
+    const int rc = do_refinement_resume(s, rounds, &more);
+    *step_changed = more;
+    if (rc < 0) return rc;
+    if (rc == CALIPSO_WARN_REFINEMENT) {
+        const int fr = nonsymmetric_solve(s, s->residual, s->step);
+        if (fr < 0) return fr;
+        *step_changed = true;
+        return CALIPSO_WARN_REFINEMENT;
+    }
+    return CALIPSO_OK;
+}
+// Queueing ahead of the host's knowledge inside a Newton step (a single handle with a device-side evaluator; CALIPSO_HIP_SPEC_STEP=0: every decision waited for in
+// place, as up to round 5): IC-1 of the search direction is queued before the host has seen the norms of the exit tests, and the cone search, the first candidate and its
+// merit are queued behind the refinement before its report is read.  The host takes every decision the reference takes, from the same numbers — it only takes
+// them later; work queued on a prediction that fails (an exit, a refinement that needs more rounds) is repeated the plain way.
+static bool spec_step_ok(const H* s) {
+    static const bool env = [] { const char* e = getenv("CALIPSO_HIP_SPEC_STEP"); return !e || atoi(e) != 0; }();
+    return env && !s->cur && (s->qp.attached || s->dev_eval || s->dev_block_eval);
 }
 
 static int do_cone_search(H* s, double* a_s, double* a_t, bool emit_candidate = true) {
@@ -845,11 +904,12 @@ static int evaluate(H* s, calipso_eval_fn eval, void* user, int which, uint32_t 
     return CALIPSO_OK;
 }
 
-static int candidate_merit(H* s, calipso_eval_fn eval, void* user, double* Mh, double* thetah, bool with_dd = false) {   // with_dd: dscal[6] (launch_dot_merit, queued before) travels along
+static int candidate_merit(H* s, calipso_eval_fn eval, void* user, double* Mh, double* thetah, bool with_dd = false, bool queue_only = false) {   // with_dd: dscal[6] (launch_dot_merit, queued before) travels along
     int rc = evaluate(s, eval, user, 1, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);   // solve.jl:231-235
     if (rc < 0) return rc;
     launch_cone(s, s->candidate, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);                         // :237-240
     launch_merit_and_constraint(s, s->candidate, 4, with_dd ? 3 : 2);                                           // merit + violation in one launch; the kernel publishes: no read-back launch
+    if (queue_only) return CALIPSO_OK;                                                                          // (the caller waits for s->pub_seq and reads hscal[4..6])
     if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
     *Mh = s->hscal[4]; *thetah = s->hscal[5];
     return CALIPSO_OK;
@@ -867,7 +927,33 @@ static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equali
     launch_merit_and_gradient(s);                                                       // :112-116, :118-124 (one launch)
     launch_residual(s);                                                                 // :127
     launch_violations_and_constraint(s, 4, 14);                                         // :130-135 and :170-172 (computed early: one read-back, published by the kernel itself)
-    if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
+    uint32_t fl = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE_JACOBIAN;
+    if (o.constraint_tensor != 0.0) fl |= CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
+    // Queue-ahead (spec_step_ok): when the last step of this handle went on to a search direction with its optimality error well above the exit thresholds, this one
+    // very likely does too — :175-181 and IC-1 are queued BEFORE the host has seen the norms (they arrive with the inertia counts, in stream order).  Should an exit test
+    // hold after all, the factorisation was for nothing: its traces (regularisation, counters, operands queued on the second stream) are undone.
+    const bool spec = spec_step_ok(s);
+    const bool ahead = spec && s->spec_ahead_ok;
+    const Scalars sc_before = sc;
+    int64_t in0[3] = {0, 0, 0};
+    int rc0 = 0;
+    if (ahead) {
+        EV(1);
+        rc = evaluate(s, eval, user, 0, fl);                                            // :175-181
+        if (rc < 0) return rc;
+        EV(2);
+        sc.ep = o.primal_regularization_initial; sc.ed = o.dual_regularization_initial;
+        rc0 = do_factorize(s, in0, true);                                               // IC-1 of inertia_correction! (its read-back is behind the norms' in the stream)
+        if (rc0 < 0) return rc0;
+    } else if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
+    auto undo_ahead = [&] {
+        if (!ahead) return;
+        if (s->rhs_ahead && s->stream2) (void)hipStreamSynchronize(s->stream2);
+        s->rhs_ahead = false; s->rhs_joined = false;
+        sc.ep = sc_before.ep; sc.ed = sc_before.ed;
+        s->stats.factorizations -= 1; s->phase_ms[8] -= 1.0;
+        s->spec_ahead_ok = false;
+    };
     const double* hs = s->hscal;
     info.M = hs[4]; info.theta = hs[5];
     info.residual_violation = hs[8] / (double)d.N;
@@ -875,35 +961,68 @@ static int inner_iteration(H* s, calipso_eval_fn eval, void* user, double equali
     const double scn = (d.nc > 0) ? std::max(100.0, hs[15] / (double)d.nc) / 100.0 : 1.0;                             // :9
     info.optimality = std::max(std::max(hs[9] / sd, hs[10]), std::max(hs[11], hs[12] / scn));
     info.slack_violation = std::max(hs[10], hs[11]);
-    EV(1);
+    if (!ahead) EV(1);
     if (info.residual_violation < o.residual_tolerance && info.slack_violation < o.slack_tolerance &&
         equality_violation <= o.equality_tolerance && cone_product_violation <= o.complementarity_tolerance) {   // :138-143
+        undo_ahead();
+        s->spec_ahead_ok = false;
         info.exit_kind = 1;
         return CALIPSO_OK;
     }
-    if (info.optimality <= std::max(o.central_path_update_tolerance * sc.kappa, o.optimality_tolerance)) {        // :165
+    const double exit2 = std::max(o.central_path_update_tolerance * sc_before.kappa, o.optimality_tolerance);
+    if (info.optimality <= exit2) {                                                                               // :165
+        undo_ahead();
+        s->spec_ahead_ok = false;
         info.exit_kind = 2;
         return CALIPSO_OK;
     }
-    uint32_t fl = CALIPSO_EVAL_OBJECTIVE_HESSIAN | CALIPSO_EVAL_EQUALITY_JACOBIAN | CALIPSO_EVAL_CONE_JACOBIAN;
-    if (o.constraint_tensor != 0.0) fl |= CALIPSO_EVAL_EQUALITY_DUAL_HESSIAN | CALIPSO_EVAL_CONE_DUAL_HESSIAN;
-    rc = evaluate(s, eval, user, 0, fl);                                                // :175-181
-    if (rc < 0) return rc;
-    // cone!(jacobian=true) (:183-185): the arrow/diagonal Jacobians are functions of (s, t) and are formed inside the kernels
-    EV(2);
+    s->spec_ahead_ok = info.optimality > 4.0 * exit2 && info.residual_violation >= o.residual_tolerance;          // (the next step's prediction)
+    if (!ahead) {
+        rc = evaluate(s, eval, user, 0, fl);                                            // :175-181
+        if (rc < 0) return rc;
+        // cone!(jacobian=true) (:183-185): the arrow/diagonal Jacobians are functions of (s, t) and are formed inside the kernels
+        EV(2);
+    }
     s->time_matvec = true;                                                              // (the first refinement residual of the step is timed: kernel_times [4])
-    int warn = do_search_direction(s, &info.nfact, &info.rounds);                       // :187
+    int warn = do_search_direction(s, &info.nfact, &info.rounds, ahead ? in0 : nullptr, rc0, spec && d.nc > 0);   // :187
     if (warn < 0) return warn;
-    EV(3);
-    rc = do_cone_search(s, &info.step_size, &info.step_size_t, false);                  // :190-221
-    if (rc < 0) return rc;
-    double step_size = info.step_size;
-    // candidate s, t (:206-218), candidate x, r (:224-229) and the directional derivative of the merit function (its gradient is that of :118-124: the
-    // point has not moved) in one launch
-    launch_first_candidate(s, info.step_size, info.step_size_t);
-    double Mh, thetah;
-    rc = candidate_merit(s, eval, user, &Mh, &thetah, true);                            // :231-250
-    if (rc < 0) return rc;
+    double step_size = 1.0, Mh = 0.0, thetah = 0.0;
+    bool tail_done = false;
+    if (s->refine_pending) {
+        // the refinement's rounds are queued, its report not read: the cone search (:190-221), the first candidate — its step sizes taken from the masks on the
+        // device — and the candidate's merit / violation (:231-250) go behind them, ONE read-back brings the report, the masks and the three scalars
+        EV(3);
+        launch_cone_search(s, ++s->pub_seq);
+        launch_first_candidate_from_masks(s);
+        rc = candidate_merit(s, eval, user, &Mh, &thetah, true, true);
+        if (rc < 0) return rc;
+        if (wait_published(s, s->pub_seq)) return CALIPSO_ERR_HIP;
+        bool step_changed = false;
+        const int w2 = search_direction_finish(s, &info.rounds, &step_changed);
+        if (w2 < 0) return w2;
+        warn = std::max(warn, w2);
+        if (!step_changed) {
+            const int ks = first_feasible_trial(s->hicount + 6, o.max_cone_line_search), kt = first_feasible_trial(s->hicount + 32, o.max_cone_line_search);
+            if (ks < 0 || kt < 0) { s->err = "cone search failure"; return CALIPSO_ERR_CONE_SEARCH; }   // solve.jl:210,220
+            double as = 1.0, at = 1.0;                                                   // (what k_first_candidate_masks formed from the same masks)
+            for (int k = 0; k < ks; ++k) as = o.scaling_line_search * as;
+            for (int k = 0; k < kt; ++k) at = o.scaling_line_search * at;
+            info.step_size = as; info.step_size_t = at; step_size = as;
+            Mh = s->hscal[4]; thetah = s->hscal[5];
+            tail_done = true;
+        }
+    }
+    if (!tail_done) {
+        EV(3);
+        rc = do_cone_search(s, &info.step_size, &info.step_size_t, false);              // :190-221
+        if (rc < 0) return rc;
+        step_size = info.step_size;
+        // candidate s, t (:206-218), candidate x, r (:224-229) and the directional derivative of the merit function (its gradient is that of :118-124: the
+        // point has not moved) in one launch
+        launch_first_candidate(s, info.step_size, info.step_size_t);
+        rc = candidate_merit(s, eval, user, &Mh, &thetah, true);                        // :231-250
+        if (rc < 0) return rc;
+    }
     const double dd = s->hscal[6];
     const double M = info.M, theta = info.theta;
     calipso::i64 residual_iteration = 0;
@@ -1120,6 +1239,7 @@ int32_t calipso_hip_solve(H* s, calipso_eval_fn eval, void* user) {
     CK(hipSetDevice(s->device));
     Options& o = s->opt; Scalars& sc = s->sc; const Dims& d = s->d;
     s->stats = Stats();
+    s->spec_ahead_ok = false;
     int rc;
     if (o.warmstart == 0.0) {
         rc = evaluate(s, eval, user, 0, CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);      // initialize_slacks! initialize.jl:15-29

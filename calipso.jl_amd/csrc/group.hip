@@ -74,6 +74,7 @@ static void g_activate(G* g, const Set& a) {
 // dscal[first .. first+count) of every member of `a` (the active set) -> that member's hscal
 static int g_read_d(G* g, const Set& a, int first, int count) {
     H* s = g->base;
+    if (launch_errors(s, "a kernel launch of this phase of the group step was refused")) return CALIPSO_ERR_HIP;
     // the gather kernel stores straight into pinned host memory (one launch, no separate copy)
     hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + first, count, g->hgather_dev);
     SYNC();
@@ -84,6 +85,7 @@ static int g_read_d(G* g, const Set& a, int first, int count) {
 }
 static int g_read_i(G* g, const Set& a, int first, int count) {
     H* s = g->base;
+    if (launch_errors(s, "a kernel launch of this phase of the group step was refused")) return CALIPSO_ERR_HIP;
     hipLaunchKernelGGL(k_gather_i, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->icount + first, count, g->higather_dev);
     SYNC();
     g->sc_pending = 0;
@@ -162,6 +164,7 @@ static int gb_factorize(G* g, const Set& a, std::vector<std::array<int64_t, 3>>&
     (void)hipEventRecord(s->ev[10], s->stream);
     launch_cone_weights(s);
     launch_scale_rows(s);
+    calipso::inject_refused_launch(s->stream);
     (void)hipEventRecord(s->ev[11], s->stream);
     launch_schur(s);
     (void)hipEventRecord(s->ev[12], s->stream);

@@ -12,6 +12,16 @@
 typedef calipso_hip_solver H;
 #define SYNC() CK(hipStreamSynchronize(s->stream))
 
+// A kernel launch that the runtime refuses (a launch configuration the device cannot serve: LDS, registers, grid) reports through hipGetLastError only — the launch macros
+// return nothing — and everything queued behind it would run on stale data.  Every host wait of a Newton step (api.hip: wait_published / publish_and_wait, group.hip:
+// g_read_*) asks for it first: a refused launch of the phase just queued surfaces as CALIPSO_ERR_HIP at the phase's own read-back, not as a wrong inertia or a failed
+// line search later.  (hipErrorNotReady is what the liveness polls of host_wait leave behind: not an error.)
+static inline int launch_errors(H* s, const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess || e == hipErrorNotReady) return 0;
+    return calipso::check(s, e, where);
+}
+
 // One place for the host's waits on words the device publishes (sequence numbers of read-backs, the progress word of the panel launches): a short pure spin — the
 // read-back of ONE handle is 5-10 us away and a yield costs more than that — then yields, then short sleeps: 24 handles waiting (3 lanes x 8 ranks) do not hold 24 cores.
 // `ready` is polled; `alive` is asked now and then (false: the stream faulted or ended without publishing — stop waiting).  Returns `ready()`.

@@ -222,6 +222,8 @@ struct calipso_hip_solver {
     // speculative refinement rounds (api.hip: do_refinement): while gate_epoch != 0 the launchers of a round's kernels pass (gate, gate_epoch) and the kernels leave at
     // once when gate[0] == gate_epoch — "this refinement has converged" (set by the residual kernel that saw it), so rounds queued ahead of the host's knowledge cost nothing
     int* gate = nullptr; int gate_epoch = 0; int gate_counter = 0;
+    bool refine_defer = false, refine_pending = false;   // api.hip: the speculative rounds of a refinement are queued, their report is read with a later read-back of the caller
+    bool spec_ahead_ok = false;            // api.hip: inner_iteration may queue IC-1 ahead of its exit tests (the last step went on to a search direction, far from the thresholds)
     bool refine_local_done = false;        // the solve tail just queued also formed the local rows of the refinement residual: the next launch_refine_local is a no-op
     double* Ypanel = nullptr;   // NP*NB: M_k = (L_kk D_k L_kk')^-1 of every 64-column panel (ldl.hip: what the trailing update multiplies the raw panel with)
     double* Tinv = nullptr;     // tinv_doubles(NP): inverses of the unit-lower diagonal blocks of L (up to 1024 x 1024, the last one may be 512 wide)
@@ -339,6 +341,7 @@ void launch_merit_gradient(calipso_hip_solver* s);
 void launch_merit_and_gradient(calipso_hip_solver* s);      // merit at the current point + its gradient, one launch
 void launch_first_candidate(calipso_hip_solver* s, double a_s, double a_t);                        // first candidate of the line search + directional derivative, one launch
 void launch_first_candidate_batch(calipso_hip_solver* s, const double* a_s, const double* a_t);
+void launch_first_candidate_from_masks(calipso_hip_solver* s);                                     // the step sizes from the cone-search masks on the device (no host round trip)
 void launch_constraint_violation(calipso_hip_solver* s, const double* point, int pub_first = 0, int pub_count = 0);   // -> dscal[5]
 void launch_merit_and_constraint(calipso_hip_solver* s, const double* point, int pub_first, int pub_count);   // k_merit + k_constraint_violation in one launch
 void launch_violations_and_constraint(calipso_hip_solver* s, int pub_first = 0, int pub_count = 0);   // both at the current point, one launch
@@ -434,6 +437,7 @@ inline bool structure_active(const calipso_hip_solver* s) { return s->band64 > 0
 void launch_qp_evaluate(calipso_hip_solver* s, const double* point, uint32_t flags);
 
 int check(calipso_hip_solver* s, hipError_t e, const char* what);
+void inject_refused_launch(hipStream_t stream);      // test hook (CALIPSO_HIP_FAULT_INJECT=launch): a launch the runtime refuses, queued among the factorisation's
 // hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that wants more than 64 KB of dynamic LDS: function attributes are PER DEVICE, so once per (kernel, current
 // device) — not once per process — and the result is kept: false = the attribute was refused there (the caller takes its fallback)
 bool lds_attribute(const void* kernel, int bytes);

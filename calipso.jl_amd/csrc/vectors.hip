@@ -603,6 +603,40 @@ void launch_first_candidate_batch(calipso_hip_solver* s, const double* a_s, cons
 }
 void launch_first_candidate(calipso_hip_solver* s, double a_s, double a_t) { launch_first_candidate_batch(s, &a_s, &a_t); }
 
+// The same launch with the step sizes taken from the cone-search masks ON THE DEVICE (a single handle: api.hip queues the first candidate behind the cone search without
+// a host round trip in between).  Every workgroup repeats what the host does with the published masks (host_logic.hpp: first_feasible_trial, then api.hip's repeated
+// multiplication by scaling_line_search — the same IEEE operations, so the host's step sizes are these to the bit); no feasible trial: NaN (the host sees the same masks
+// and raises "cone search failure").
+__global__ __launch_bounds__(RT) void k_first_candidate_masks(Batch bt, Dims d, const double* __restrict__ sol, const double* __restrict__ step, double* __restrict__ cand,
+                                                               const int* __restrict__ icount, double sls, int nk, const double* __restrict__ mgrad, double* __restrict__ dscal,
+                                                               int nb) {
+    __shared__ double sm[RT / 64];
+    __shared__ double sa[2];
+    inst_shift(bt, sol, step, cand, mgrad, dscal);
+    inst_shift_i(bt, icount);
+    if ((int)blockIdx.x == nb) { dot_body(d.n, mgrad, step, dscal + 6, sm); return; }
+    if (threadIdx.x < 2) {
+        const int* mask = icount + (threadIdx.x == 0 ? 6 : 32);
+        int kk = -1;
+        for (int k = 0; k < nk; ++k) if (!(mask[k >> 5] & (1 << (k & 31)))) { kk = k; break; }
+        double a = 1.0;
+        for (int k = 0; k < kk; ++k) a = sls * a;
+        sa[threadIdx.x] = kk < 0 ? __longlong_as_double(0x7ff8000000000000LL) : a;
+    }
+    __syncthreads();
+    const double a_s = sa[0], a_t = sa[1];
+    const int i = blockIdx.x * RT + threadIdx.x;
+    if (i < d.n) cand[i] = sol[i] - a_s * step[i];
+    else if (i < d.n + d.nc) { const int k = d.ot() + (i - d.n); cand[k] = sol[k] - a_t * step[k]; }
+}
+void launch_first_candidate_from_masks(calipso_hip_solver* s) {      // nc > 0, a single handle; behind launch_cone_search on the same stream
+    const BatchSc B = batch_of(s);
+    const int nb = (s->d.n + s->d.nc + RT - 1) / RT;
+    const int nk = (int)std::min<i64>(s->opt.max_cone_line_search + 1, CONE_MASK_TRIALS);
+    hipLaunchKernelGGL(k_first_candidate_masks, dim3(nb + 1, 1, B.b.n), dim3(RT), 0, s->stream, B.b, s->d, s->solution, s->step, s->candidate, s->icount,
+                       s->opt.scaling_line_search, nk, s->merit_gradient, s->dscal, nb);
+}
+
 // vector part of out = H v (block rows of residual_jacobian_variables.jl:1-108); the mat-vec parts were accumulated
 // into out_x, out_y, out_z beforehand.
 __global__ void k_Hmul_vec(BatchSc bt, Dims d, ConeDev cd, const double* __restrict__ w, const double* __restrict__ v,

@@ -160,3 +160,48 @@ def test_group_outlives_its_members():
     g1.close()
     g2 = pkg.Group([s1, s2])
     g2.close()
+
+
+FAULT_CHILD = r'''
+import sys, os
+import numpy as np
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "tests")]
+from helpers import load_pkg
+from test_gpu_group import build
+pkg = load_pkg()
+# the injected fault: a launch the runtime must refuse (1 MB of dynamic LDS) queued among the launches of every factorisation
+s = build(pkg, 7, (200, 60, 20, 10, 3))
+for what, call in (("factorize", lambda: s.factorize()), ("newton_step", lambda: s.newton_step(advance=False))):
+    try:
+        call()
+        print("NOERROR " + what)
+    except pkg.CalipsoHipError as e:
+        print("RAISED %%s: %%s" %% (what, str(e).replace("\n", " ")))
+g = pkg.Group([build(pkg, 8, (200, 60, 20, 10, 3)), build(pkg, 9, (200, 60, 20, 10, 3))])
+try:
+    g.newton_step(advance=False)
+    print("NOERROR group")
+except pkg.CalipsoHipError as e:
+    print("RAISED group: " + str(e).replace("\n", " "))
+print("DONE")
+'''
+
+
+def test_a_refused_kernel_launch_is_reported_not_stepped_over():
+    """fault injection (CALIPSO_HIP_FAULT_INJECT=launch: a launch with 1 MB of dynamic LDS among the factorisation's — what a kernel whose configuration the device cannot
+    serve looks like): the launch macros return nothing, the error sits in hipGetLastError — the host must find it at the phase's own read-back and return CALIPSO_ERR_HIP
+    (include/calipso_hip.h) instead of going on as if every kernel had run, or hanging.  Single handle (direct call and Newton step) and a group.  (Raising the > 64 KB
+    dynamic-LDS attribute turned out NOT to be required by this runtime — a k_schur launch with 139 KB runs without it — so withholding it is no fault to inject.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, CALIPSO_HIP_FAULT_INJECT="launch")
+    r = subprocess.run([sys.executable, "-c", FAULT_CHILD % {"root": root}], env=e, capture_output=True, text=True, timeout=300)      # (a hang would hit the timeout)
+    assert r.returncode == 0 and "DONE" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("RAISED", "NOERROR"))]
+    assert len(lines) == 3 and all(l.startswith("RAISED") for l in lines), lines
+    assert all("refused" in l and "(-" in l for l in lines), lines
+    # the same child without the fault: no error
+    r2 = subprocess.run([sys.executable, "-c", FAULT_CHILD % {"root": root}], env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and [l for l in r2.stdout.splitlines() if l.startswith(("RAISED", "NOERROR"))] == ["NOERROR factorize", "NOERROR newton_step", "NOERROR group"], r2.stdout[-2000:]
