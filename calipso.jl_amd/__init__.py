@@ -815,6 +815,100 @@ class SmallBatch:
             pass
 
 
+class SmallNewtonBatch:
+    """Solver / initialize! / solve! (src/solver/solver.jl:46-150, initialize.jl:9-48, solve.jl:8-377) for `batch` independent small conic QPs of one shape in ONE
+    kernel launch: a workgroup per instance, everything in LDS, every decision of solve! on the device (include/calipso_hip.h, "solve! for a batch of SMALL conic QPs";
+    csrc/smallnewton.hip).  QP data as qp_attach: min c x'Px + q'x s.t. Ax = b, h - Gx >= 0 (nonnegative cones)."""
+
+    def __init__(self, nx, ne, nc, batch, device=0, options=None):
+        self._L = lib()
+        self.nx, self.ne, self.nc, self.batch = int(nx), int(ne), int(nc), int(batch)
+        self.N = self.nx + 2 * self.ne + 3 * self.nc
+        h = C.c_void_p()
+        rc = self._L.calipso_hip_smallnewton_create(self.nx, self.ne, self.nc, self.batch, device, C.byref(h))
+        if rc != 0:
+            msg = self._L.calipso_hip_smallnewton_last_error(h if h.value else None).decode()
+            if h.value:
+                self._L.calipso_hip_smallnewton_destroy(h)
+            raise CalipsoHipError("calipso_hip_smallnewton_create failed (%d): %s" % (rc, msg))
+        self._h = h
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise CalipsoHipError("%s failed (%d): %s" % (what, rc, self._L.calipso_hip_smallnewton_last_error(self._h).decode()))
+        return rc
+
+    def set_option(self, name, value):
+        self._check(self._L.calipso_hip_smallnewton_set_option(self._h, name.encode(), float(value)), "smallnewton_set_option(%s)" % name)
+
+    def set_qp(self, P, q, A, b, G, h, objective_scale=0.5, shared=None):
+        """arrays of ONE problem (P (nx, nx), q (nx), A (ne, nx), ...) shared by all instances, or stacked along a leading batch axis"""
+        P = np.asarray(P, dtype=np.float64)
+        if shared is None:
+            shared = P.ndim == 2
+        K = 1 if shared else self.batch
+        cm = lambda M, r, c: np.ascontiguousarray(np.transpose(np.asarray(M, dtype=np.float64).reshape(K, r, c), (0, 2, 1))).reshape(-1) if r * c else np.zeros(1)
+        vv = lambda a, n: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(K, n)).reshape(-1) if n else np.zeros(1)
+        Pc, Ac, Gc = cm(P, self.nx, self.nx), cm(A, self.ne, self.nx), cm(G, self.nc, self.nx)
+        qv, bv, hv = vv(q, self.nx), vv(b, self.ne), vv(h, self.nc)
+        self._check(self._L.calipso_hip_smallnewton_set_qp(self._h, _pd(Pc), _pd(qv), _pd(Ac), _pd(bv), _pd(Gc), _pd(hv), float(objective_scale), int(bool(shared))), "smallnewton_set_qp")
+
+    def set_state(self, w=None, dual=None, scalars=None):
+        """w: (batch, N) points; dual: (batch, ne) multiplier estimates; scalars: (batch, 3) [central_path, fraction_to_boundary, penalty]"""
+        f = lambda a, n: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(self.batch, n)).reshape(-1)
+        ww, ll, ss = f(w, self.N), f(dual, max(self.ne, 1)) if (dual is not None and self.ne) else None, f(scalars, 3)
+        self._check(self._L.calipso_hip_smallnewton_set_state(self._h, _pd(ww) if ww is not None else None, _pd(ll) if ll is not None else None, _pd(ss) if ss is not None else None), "smallnewton_set_state")
+
+    def initialize(self, x0):
+        """initialize!(solver, guess) for every instance: x0 (batch, nx) or one guess for all"""
+        x0 = np.asarray(x0, dtype=np.float64)
+        w = np.zeros((self.batch, self.N))
+        w[:, :self.nx] = x0.reshape(-1, self.nx)
+        self.set_state(w=w)
+
+    def get_state(self):
+        w = np.zeros(self.batch * self.N); lam = np.zeros(self.batch * max(self.ne, 1)); sc = np.zeros(self.batch * 6); cn = np.zeros(self.batch * 8, dtype=np.int64)
+        self._check(self._L.calipso_hip_smallnewton_get_state(self._h, _pd(w), _pd(lam), _pd(sc), _pi(cn)), "smallnewton_get_state")
+        names = ("total_iterations", "outer", "factorizations", "refinement_failures", "max_refinement_rounds", "last_refinement_rounds", "newton_steps", "accepted_iterates")
+        return dict(solution=w.reshape(self.batch, self.N), dual=lam.reshape(self.batch, -1)[:, :self.ne], scalars=sc.reshape(self.batch, 6),
+                    counters={n: cn.reshape(self.batch, 8)[:, i].copy() for i, n in enumerate(names)})
+
+    def keep_trace(self, rows):
+        self._trace_rows = int(rows)
+        self._check(self._L.calipso_hip_smallnewton_trace(self._h, int(rows), None), "smallnewton_trace")
+
+    def trace(self, rows=None):
+        rows = int(rows if rows is not None else self._trace_rows)
+        out = np.zeros(self.batch * rows * self.N)
+        self._check(self._L.calipso_hip_smallnewton_trace(self._h, rows, _pd(out)), "smallnewton_trace")
+        return out.reshape(self.batch, rows, self.N)
+
+    def solve(self):
+        """solve! of every instance, one launch: (result (batch,) int32 — 1 converged, 0 caps reached, < 0 see include/calipso_hip.h —, launch milliseconds)"""
+        res = np.zeros(self.batch, dtype=np.int32); ms = C.c_double(0.0)
+        self._check(self._L.calipso_hip_smallnewton_solve(self._h, res.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms)), "smallnewton_solve")
+        return res, float(ms.value)
+
+    def steps(self, count, advance=False):
+        """`count` Newton steps of every instance in one launch: (info (batch, 8), status (batch,), launch milliseconds)"""
+        info = np.zeros(self.batch * 8); st = np.zeros(self.batch, dtype=np.int32); ms = C.c_double(0.0)
+        self._check(self._L.calipso_hip_smallnewton_steps(self._h, int(count), int(bool(advance)), _pd(info), st.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms)), "smallnewton_steps")
+        return info.reshape(self.batch, 8), st, float(ms.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.calipso_hip_smallnewton_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Comm:
     """RCCL communicator of the batched path (include/calipso_hip.h, "multi-GPU exchange"): one process per GPU; the only
     collectives are the post-round all-gather of per-problem status rows and the all-reduce of counters."""

@@ -100,6 +100,16 @@ SYMBOLS = {
     "calipso_hip_small_set": (_i32, [_vp, _pd, _pd]),
     "calipso_hip_small_solve": (_i32, [_vp, _pd]),
     "calipso_hip_small_get": (_i32, [_vp, _pd, _pi64]),
+    "calipso_hip_smallnewton_create": (_i32, [_i64, _i64, _i64, _i64, _i32, C.POINTER(_vp)]),
+    "calipso_hip_smallnewton_destroy": (_i32, [_vp]),
+    "calipso_hip_smallnewton_last_error": (C.c_char_p, [_vp]),
+    "calipso_hip_smallnewton_set_option": (_i32, [_vp, C.c_char_p, _dbl]),
+    "calipso_hip_smallnewton_set_qp": (_i32, [_vp, _pd, _pd, _pd, _pd, _pd, _pd, _dbl, _i32]),
+    "calipso_hip_smallnewton_set_state": (_i32, [_vp, _pd, _pd, _pd]),
+    "calipso_hip_smallnewton_get_state": (_i32, [_vp, _pd, _pd, _pd, _pi64]),
+    "calipso_hip_smallnewton_trace": (_i32, [_vp, _i32, _pd]),
+    "calipso_hip_smallnewton_solve": (_i32, [_vp, _pi32, _pd]),
+    "calipso_hip_smallnewton_steps": (_i32, [_vp, _i32, _i32, _pd, _pi32, _pd]),
     "calipso_hip_comm_unique_id": (_i32, [C.POINTER(C.c_uint8)]),
     "calipso_hip_comm_init": (_i32, [_i32, _i32, C.POINTER(C.c_uint8), _i32, C.POINTER(_vp)]),
     "calipso_hip_comm_destroy": (_i32, [_vp]),

@@ -425,6 +425,35 @@ int32_t calipso_hip_small_set(calipso_hip_small*, const double* K, const double*
 int32_t calipso_hip_small_solve(calipso_hip_small*, double* ms);
 int32_t calipso_hip_small_get(calipso_hip_small*, double* X, int64_t* inertia);
 
+/* ---- solve! for a batch of SMALL conic QPs, the whole Newton iteration in one kernel (csrc/smallnewton.hip) ----------------------------------
+ * Solver / initialize! / solve! (src/solver/solver.jl:46-150, initialize.jl:9-48, solve.jl:8-377) for `batch` independent problems of ONE shape that are too small
+ * for the general path to be anything but launch latency (the MPC problems of examples/autotuning/cartpole.jl:179-227: n = 89): one workgroup per instance, problem
+ * data, iterates and the factor in the compute unit's LDS, every decision of solve.jl:98-368 (exit tests, inertia_correction!, iterative_refinement!, cone search,
+ * filter line search, outer updates) on the device, ONE launch per call.  Evaluator: the QP of calipso_hip_qp_attach (min c x'Px + q'x s.t. Ax = b, h - Gx >= 0) with
+ * nonnegative cones only; residual_norm = constraint_norm = 1.  Points have the layout of point.jl:13-22 (N = nx + 2 ne + 3 nc).  Limits: nx <= 256 and the
+ * instance must fit 160 KB of LDS (n up to ~200), else CALIPSO_ERR_ARGUMENT at create: the general path (calipso_hip_create + groups) takes those.
+ *   create(nx, ne, nc, batch, device)        set_option(name, value): options.jl:6-59 by name
+ *   set_qp(P, q, A, b, G, h, c, shared)      column-major host arrays, batch-major (instance k at k * size) or ONE problem for all (shared != 0)
+ *   set_state(w, lambda, scalars)            points (batch x N; initialize!: x in the first nx entries), lambda (batch x ne), [central_path, fraction_to_boundary, penalty] (batch x 3)
+ *   solve(result, ms)                        solve! of every instance: 1 converged, 0 iteration caps, CALIPSO_ERR_INERTIA / CALIPSO_ERR_CONE_SEARCH (the reference's error()s),
+ *                                            -100 - CALIPSO_WARN_REFINEMENT where the reference would fall back to `H \ residual` (search_direction.jl:22: left to the general path)
+ *   steps(count, advance, info, status, ms)  `count` passes of the inner loop body (solve.jl:98-353) from the resident state = calipso_hip_newton_steps for the batch
+ *   get_state(w, lambda, scalars, counters)  scalars batch x 6 [central_path, fraction_to_boundary, penalty, primal_regularization, primal_regularization_last, dual_regularization],
+ *                                            counters batch x 8 [total_iterations, outer, factorizations, refinement failures, max / last refinement rounds, Newton steps, accepted iterates]
+ *   trace(rows, NULL) keeps the first `rows` accepted iterates of every instance (solution.all after solve.jl:309-326); trace(rows, out) reads them (batch x rows x N) */
+typedef struct calipso_hip_smallnewton calipso_hip_smallnewton;
+int32_t calipso_hip_smallnewton_create(int64_t nx, int64_t ne, int64_t nc, int64_t batch, int32_t device, calipso_hip_smallnewton** out);
+int32_t calipso_hip_smallnewton_destroy(calipso_hip_smallnewton*);
+const char* calipso_hip_smallnewton_last_error(calipso_hip_smallnewton*);
+int32_t calipso_hip_smallnewton_set_option(calipso_hip_smallnewton*, const char* name, double value);
+int32_t calipso_hip_smallnewton_set_qp(calipso_hip_smallnewton*, const double* P, const double* q, const double* A, const double* b, const double* G, const double* h,
+                                       double objective_scale, int32_t shared);
+int32_t calipso_hip_smallnewton_set_state(calipso_hip_smallnewton*, const double* w, const double* lambda, const double* scalars);
+int32_t calipso_hip_smallnewton_get_state(calipso_hip_smallnewton*, double* w, double* lambda, double* scalars, int64_t* counters);
+int32_t calipso_hip_smallnewton_trace(calipso_hip_smallnewton*, int32_t rows, double* out);
+int32_t calipso_hip_smallnewton_solve(calipso_hip_smallnewton*, int32_t* result, double* ms);
+int32_t calipso_hip_smallnewton_steps(calipso_hip_smallnewton*, int32_t count, int32_t advance, double* info, int32_t* status, double* ms);
+
 /* ---- multi-GPU exchange of the batched path: RCCL over xGMI, one process per GPU ---------------------------------
  * Problem instances are sharded block-contiguously over ranks and never interact (the reference's `Solver`s are independent); the
  * only exchange is after a batch round: all-gather of per-problem status rows, all-reduce of counters.  RCCL is dlopen'ed on first

@@ -61,7 +61,7 @@ def test_no_cpu_fallback():
     assert "no HIP device" in str(e.value)
     # every other handle type of the ABI as well: the LinearSolver seam (dense and sparse), the batched small systems
     import scipy.sparse as sp
-    for make in (lambda: pkg.LDLSolver(4), lambda: pkg.SparseLDL(sp.identity(4, format="csc")), lambda: pkg.SmallBatch(4, 1, 2)):
+    for make in (lambda: pkg.LDLSolver(4), lambda: pkg.SparseLDL(sp.identity(4, format="csc")), lambda: pkg.SmallBatch(4, 1, 2), lambda: pkg.SmallNewtonBatch(4, 2, 2, 3)):
         with pytest.raises(pkg.CalipsoHipError) as e:
             make()
         assert "no HIP device" in str(e.value)

@@ -1,0 +1,112 @@
+"""GPU (-m gpu): solve! for a batch of small conic QPs in ONE kernel launch (csrc/smallnewton.hip, calipso_hip_smallnewton_*): every instance's accepted iterates,
+iteration counts, factorisation counts and result agree with the ORACLE's solve! of the same problem (solve.jl:8-377; per accepted iterate 1e-8), with the general
+device path (calipso_hip_solve with the attached QP evaluator) and — in benchmark mode — a non-advancing step leaves the state untouched."""
+import numpy as np
+import pytest
+
+import problems as pr
+from helpers import load_pkg
+from test_oracle_solve import run as run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(1.0, np.abs(np.asarray(b)).max())
+
+
+def make_batch(pkg, probs, **opts):
+    p0 = probs[0]
+    sn = pkg.SmallNewtonBatch(p0.nx, p0.ne, p0.nc, len(probs), options=opts)
+    st = lambda name: np.stack([np.asarray(getattr(p, name), dtype=np.float64) for p in probs])
+    sn.set_qp(st("P"), st("q"), st("A"), st("b"), st("G"), st("h"), objective_scale=p0.c, shared=False)
+    sn.initialize(np.stack([p.x0 for p in probs]))
+    return sn
+
+
+@pytest.mark.parametrize("shape", [(10, 4, 6), (12, 0, 9), (9, 5, 0), (49, 40, 0), (30, 12, 24)])
+def test_batched_solve_matches_the_oracle_per_accepted_iterate(oracle_mod, shape):
+    pkg = load_pkg()
+    nx, ne, nc = shape
+    probs = [pr.random_qp(nx, ne, nc, seed=100 + k, nonnegative_indices=list(range(1, nc + 1))) for k in range(6)]
+    sn = make_batch(pkg, probs)
+    sn.keep_trace(64)
+    res, ms = sn.solve()
+    st = sn.get_state()
+    tr = sn.trace()
+    for k, prob in enumerate(probs):
+        o, status = run_oracle(oracle_mod, prob)
+        assert status == int(res[k]) == 1, (k, status, res[k])
+        os_ = o.stats()
+        assert st["counters"]["total_iterations"][k] == os_["total_iterations"], (k, st["counters"]["total_iterations"][k], os_["total_iterations"])
+        assert st["counters"]["outer"][k] == os_["outer"]
+        assert 1 <= st["counters"]["factorizations"][k] <= os_["factorizations"]      # (the oracle also counts the reference's hidden re-factorisation before every solve, linear_solver.jl:53)
+        assert st["counters"]["max_refinement_rounds"][k] == os_["max_refinement_rounds"]
+        ot = o.trace()
+        rows = int(st["counters"]["accepted_iterates"][k])
+        assert rows == ot.shape[0] and rows >= 3
+        for r in range(min(rows, 64)):
+            assert rel(tr[k, r], ot[r]) <= 1e-8, (k, r, rel(tr[k, r], ot[r]))
+        assert rel(st["solution"][k], o.point()["all"]) <= 1e-8
+        assert rel(st["dual"][k], o.buf("dual")) <= 1e-8 if ne else True
+        assert abs(st["scalars"][k, 0] - o.buf("central_path")[0]) <= 1e-15 and abs(st["scalars"][k, 2] - o.buf("penalty")[0]) <= 1e-9
+    sn.close()
+
+
+def test_batched_solve_agrees_with_the_general_device_path():
+    """the same problems through calipso_hip_solve (one handle each, attached QP evaluator): same iteration counts, solutions to 1e-8"""
+    pkg = load_pkg()
+    probs = [pr.random_qp(14, 6, 8, seed=300 + k, nonnegative_indices=list(range(1, 9))) for k in range(4)]
+    sn = make_batch(pkg, probs)
+    res, _ = sn.solve()
+    st = sn.get_state()
+    for k, prob in enumerate(probs):
+        s = pkg.Solver(prob, prob.nx, 0, prob.ne, prob.nc, nonnegative_indices=prob.nonnegative_indices)
+        s.qp_attach(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, prob.c)
+        pkg.initialize_b(s, prob.x0)
+        assert pkg.solve_b(s) and res[k] == 1
+        assert s.stats()["total_iterations"] == st["counters"]["total_iterations"][k] and s.stats()["factorizations"] == st["counters"]["factorizations"][k]
+        assert rel(st["solution"][k], s.solution.all) <= 1e-8
+    sn.close()
+
+
+def test_one_problem_shared_by_the_batch_and_benchmark_steps():
+    """shared problem data (one copy for all instances), different starting points; steps(advance=False) repeats the same step and leaves the state as it was"""
+    pkg = load_pkg()
+    prob = pr.random_qp(20, 8, 10, seed=7, nonnegative_indices=list(range(1, 11)))
+    B = 33
+    sn = pkg.SmallNewtonBatch(prob.nx, prob.ne, prob.nc, B)
+    sn.set_qp(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, objective_scale=prob.c)
+    rng = np.random.default_rng(0)
+    sn.initialize(prob.x0[None, :] + 0.1 * rng.standard_normal((B, prob.nx)))
+    res, _ = sn.solve()
+    assert (res == 1).all()
+    sols = sn.get_state()["solution"]
+    assert rel(sols, np.repeat(sols[:1], B, axis=0)) <= 1e-6              # one convex problem: every start reaches the same solution (to the solver's tolerances)
+    # benchmark steps from an interior state: put every instance back to a strictly feasible interior point with a large central-path parameter
+    w = sols.copy()
+    n_, ne, nc = prob.nx + prob.ne + prob.nc, prob.ne, prob.nc
+    w[:, prob.nx + ne:prob.nx + ne + nc] += 0.5; w[:, -nc:] += 0.5
+    sn.set_state(w=w, scalars=np.tile([0.17, 0.99, 52.0], (B, 1)))
+    before = sn.get_state()
+    info1, st1, _ = sn.steps(1, advance=False)
+    info3, st3, _ = sn.steps(3, advance=False)
+    after = sn.get_state()
+    assert (st1 == 0).all() and (st3 == 0).all() and (info1[:, 6] == 0).all()
+    assert np.array_equal(info1, info3)                                       # the third repetition of the step is the first
+    assert np.array_equal(before["solution"], after["solution"]) and np.array_equal(before["scalars"][:, :3], after["scalars"][:, :3])
+    info_a, st_a, _ = sn.steps(1, advance=True)
+    assert np.array_equal(info_a[:, :6], info1[:, :6]) and not np.array_equal(sn.get_state()["solution"], before["solution"])
+    sn.close()
+
+
+def test_limits_are_refused():
+    pkg = load_pkg()
+    with pytest.raises(pkg.CalipsoHipError, match="LDS"):
+        pkg.SmallNewtonBatch(200, 150, 100, 2)
+    sn = pkg.SmallNewtonBatch(5, 2, 3, 2)
+    with pytest.raises(pkg.CalipsoHipError, match="no problem data"):
+        sn.solve()
+    with pytest.raises(pkg.CalipsoHipError):
+        sn.set_option("residual_norm", 2.0)
+    sn.close()
