@@ -176,6 +176,58 @@ def config_c3_solve(pkg, pr, device, shape, cpu=True):
     return out
 
 
+def config_small_newton(pkg, pr, device, cpu=True, batch=4096, steps=20):
+    """The batched small-problem path (csrc/smallnewton.hip, calipso_hip_smallnewton_*): `batch` QPs of C5's shape (nx = 49, ne = 40: the cart-pole MPC problem of
+    examples/autotuning/cartpole.jl:85-146 is that size; here random strictly convex QPs, test/solver/problem.jl:3-23) — whole solve!s in ONE launch, and `steps`
+    non-advancing Newton steps per instance in one launch (the headline's step, for the batch).  The oracle solves a sample of the same problems on one host core."""
+    nx, ne, nc = 49, 40, 0
+    nprob = 32
+    probs = [pr.random_qp(nx, ne, nc, seed=1000 + k, nonnegative_indices=[]) for k in range(nprob)]
+    idx = np.arange(batch) % nprob
+    st = lambda name: np.stack([np.asarray(getattr(probs[i], name), dtype=np.float64) for i in idx])
+    sn = pkg.SmallNewtonBatch(nx, ne, nc, batch, device=device)
+    sn.set_qp(st("P"), st("q"), st("A"), st("b"), st("G"), st("h"), objective_scale=probs[0].c, shared=False)
+    rng = np.random.default_rng(0)
+    x0 = np.stack([probs[i].x0 for i in idx]) + 0.01 * rng.standard_normal((batch, nx))
+    ms_all = []
+    for _ in range(3):
+        sn.initialize(x0)
+        res, ms = sn.solve()
+        ms_all.append(ms)
+    stt = sn.get_state()
+    its, nst = stt["counters"]["total_iterations"], stt["counters"]["newton_steps"]
+    ms = min(ms_all)
+    out = {"workload": "%d random convex QPs of C5's shape (nx = %d, ne = %d, n = %d), one workgroup per instance, one launch" % (batch, nx, ne, nx + ne),
+           "solve": {"launch_ms": ms, "converged": int((res == 1).sum()), "solves_per_s": batch / (ms * 1e-3), "newton_steps_per_s": float(nst.sum()) / (ms * 1e-3),
+                     "mean_newton_iterations": float(its.mean()), "max_refinement_rounds": int(stt["counters"]["max_refinement_rounds"].max())}}
+    w = stt["solution"].copy()
+    w[:, :nx] += 0.05 * rng.standard_normal((batch, nx))
+    sn.set_state(w=w, scalars=np.tile([0.17, 0.99, 52.0], (batch, 1)))
+    sn.steps(2, advance=False)
+    msk = min(sn.steps(steps, advance=False)[2] for _ in range(3))
+    info, stat, _ = sn.steps(1, advance=False)
+    bytes_inst = 8.0 * (nx * nx + ne * nx + nx + ne + 2 * (nx + 2 * ne))
+    out["steps"] = {"count_per_instance": steps, "launch_ms": msk, "newton_steps_per_s": batch * steps / (msk * 1e-3), "stepped": int(((stat == 0) & (info[:, 6] == 0)).sum()),
+                    "refinement_rounds": float(info[:, 2].mean()),
+                    "roofline": {"bound": "latency (neither HBM nor MFMA: ~75 dependent workgroup phases per step, two workgroups resident per compute unit)",
+                                 "hbm_frac": batch * bytes_inst / (msk * 1e-3) / 8e12, "note": "an instance's data is read once per LAUNCH (%.0f KB), not per step" % (bytes_inst / 1e3)}}
+    sn.close()
+    if cpu:
+        try:
+            oracle = _oracle_mod()
+            ts = []
+            for k in range(6):
+                o = oracle.OracleSolver(nx, 0, ne, nc, probs[k].nonnegative_indices, probs[k].second_order_indices)
+                o.point()["x"][:] = probs[k].x0
+                t0 = time.perf_counter(); stc = o.solve(probs[k]); ts.append(time.perf_counter() - t0)
+            out["cpu_baseline"] = {"kind": "port", "cores": 1, "unit": "solve!s/s", "value": 1.0 / float(np.median(ts)), "solve_ms": 1e3 * float(np.median(ts)),
+                                   "sample": "%d solve!s of the same problems by the oracle, one host core, evaluation through Python callbacks" % len(ts)}
+            out["solve"]["gpu_over_cpu"] = out["solve"]["solves_per_s"] / out["cpu_baseline"]["value"]
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
 def config_c2(pkg, pr, device, cpu=True):
     """BASELINE config 2: the pendulum swing-up (T = 11; test/examples/pendulum.jl) as ONE full solve!: every inner Newton iteration of solve.jl:98-353 on the device,
     the Symbolics-generated evaluate! replaced by the restated problem functions on the host (callback: tests/problems.py).  Iterations are checked against the
@@ -999,12 +1051,16 @@ def main():
         except Exception as e:      # (never lose the headline line to a side figure)
             c2 = c2 or {"error": repr(e)}
             c5 = c5 or {"error": repr(e)}
-    c3_solve = None
+    c3_solve = small_newton = None
     if rank == 0 and world == 1 and not args.no_c2_c5 and args.config == "C3":
         try:
             c3_solve = config_c3_solve(pkg, pr, local_rank if args.force_device < 0 else args.force_device, shape)
         except Exception as e:
             c3_solve = {"error": repr(e)}
+        try:
+            small_newton = config_small_newton(pkg, pr, local_rank if args.force_device < 0 else args.force_device, cpu=not args.no_cpu_baseline)
+        except Exception as e:
+            small_newton = {"error": repr(e)}
     out = {
         "metric": "Newton steps/sec (n~5k KKT)", "value": value, "unit": "Newton steps/s", "n_gpus": world, "steps": steps_timed,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps_timed, "higher_is_better": True, "scaling": "weak",
@@ -1016,7 +1072,7 @@ def main():
                                         "B2 says so); value = B0(i), one factorisation per step (favourable to the reference); B0_ii (the reference's re-factorisation before every solve) is "
                                         + ("MEASURED in this run (--cpu-baseline-full)" if args.cpu_baseline_full else "NOT in this line (value: null; --cpu-baseline-full measures it, ~100 s more)")
                                         + "; B1 = LAPACK on all cores, not the reference",
-                   "batched": batched, "c4": c4, "c2": c2, "c5": c5, "c3_solve": c3_solve, "roofline_phases": cfg_phases,
+                   "batched": batched, "c4": c4, "c2": c2, "c5": c5, "c3_solve": c3_solve, "small_newton": small_newton, "roofline_phases": cfg_phases,
                    "rccl_ranks": exchange.ranks_reported, "exchange_path": exchange.path},
         "roofline": roof,
     }

@@ -31,7 +31,7 @@ struct calipso_hip_smallnewton {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *P = nullptr, *q = nullptr, *Z = nullptr, *bh = nullptr;      // Lxx = 2 c P (nx x nx), q, Z = [A; -G] (m x nx, ld m), bh = [-b; h]: per instance or shared
-    double *w = nullptr, *lam = nullptr, *sc = nullptr, *filt = nullptr, *info = nullptr, *trace = nullptr;
+    double *w = nullptr, *lam = nullptr, *sc = nullptr, *filt = nullptr, *info = nullptr, *trace = nullptr, *prof = nullptr;
     long long* cnt = nullptr; int* status = nullptr;
     int trace_rows = 0;
     size_t lds_bytes = 0;
@@ -59,18 +59,18 @@ struct Dm {
 };
 
 // LDS carve-up (offsets in doubles): the same function sizes the launch on the host and places the pointers on the device
-struct Lay { int Lxx, Z, S, q, bh, lam, sol, cand, step, res, rerr, corr, tmpN, rsym, dsym, mgrad, fx, gzx, gh, ghc, cprod, bgrad, wz, D, Dinv, xb, t1, t2, ycol, red, total; };
+struct Lay { int Lxx, Z, S, q, bh, lam, sol, cand, step, res, rerr, corr, tmpN, rsym, mgrad, fx, gzx, gh, ghc, cprod, bgrad, wz, D, Dinv, xb, t1, t2, ycol, red, total; };
 __host__ __device__ inline Lay layout(const Dm& d) {
     Lay L; int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
     L.Lxx = take(d.lds * d.nx); L.Z = take(d.ldz * d.nx); L.S = take(d.lds * d.nx);
     L.q = take(d.nx); L.bh = take(d.m); L.lam = take(d.ne);
     L.sol = take(d.N); L.cand = take(d.N); L.step = take(d.N); L.res = take(d.N); L.rerr = take(d.N); L.corr = take(d.N); L.tmpN = take(d.N);
-    L.rsym = take(d.n); L.dsym = take(d.n); L.mgrad = take(d.n);
+    L.rsym = take(d.n); L.mgrad = take(d.n);
     L.fx = take(d.nx); L.gzx = take(d.nx); L.gh = take(d.m); L.ghc = take(d.m);
     L.cprod = take(d.nc); L.bgrad = take(d.nc); L.wz = take(d.nc);
     L.D = take(d.nx); L.Dinv = take(d.nx); L.xb = take(d.nx); L.t1 = take(d.m); L.t2 = take(d.m);
-    L.ycol = take(2 * d.nx);
+    L.ycol = take(8 * d.nx);
     L.red = take(64);
     L.total = o;
     return L;
@@ -79,7 +79,7 @@ __host__ __device__ inline Lay layout(const Dm& d) {
 struct Args {
     Dm d; Options o;
     const double *P, *q, *Z, *bh; long long sP, sq, sZ, sbh;      // element strides per instance (0: one problem shared by all)
-    double *w, *lam, *sc, *filt, *info, *trace; long long* cnt; int* status;
+    double *w, *lam, *sc, *filt, *info, *trace, *prof; long long* cnt; int* status;
     int batch, mode, count, advance, trace_rows;
 };
 
@@ -132,14 +132,40 @@ __device__ __forceinline__ void mv_t(const double* M, int ld, int rows, int cols
     }
 }
 
+// v_readlane of a double: the value lane `src` (wave-uniform) holds
+__device__ __forceinline__ double rl(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+template <int R> __device__ __forceinline__ double pick(const double (&x)[R], int cu) {
+    if constexpr (R == 1) return x[0];
+    else return cu == 0 ? x[0] : x[1];
+}
+
+// 1 / d on the pivot chain: v_rcp_f64 and two Newton steps (an IEEE division is ~25 dependent instructions; the pivots are exact zeros only for singular matrices,
+// which the inertia test reports: d = 0 gives inf here as the division does)
+__device__ __forceinline__ double recip(double d) {
+    const double r0 = __builtin_amdgcn_rcp(d);
+    double r = r0;
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return d == 0.0 ? r0 : r;
+}
+
 struct Ctx {
     Dm d; const Options* o;
-    double *Lxx, *Z, *S, *q, *bh, *lam, *sol, *cand, *step, *res, *rerr, *corr, *tmpN, *rsym, *dsym, *mgrad, *fx, *gzx, *gh, *ghc, *cprod, *bgrad, *wz, *D, *Dinv, *xb, *t1, *t2, *ycol, *red;
+    double *Lxx, *Z, *S, *q, *bh, *lam, *sol, *cand, *step, *res, *rerr, *corr, *tmpN, *rsym, *mgrad, *fx, *gzx, *gh, *ghc, *cprod, *bgrad, *wz, *D, *Dinv, *xb, *t1, *t2, *ycol, *red;
     double* filt;                                   // global: [pairs theta | pairs merit | cache theta | cache merit | saved theta | saved merit], max_filter each
     // uniform scalars (every thread holds the same values)
     double kappa, tau, rho, ep, ep_last, ed, fcur, fcand, eqv, cpv, omega_y, kyy;
     long long filter_index, nfact_total, rfail, rmax, rlast, nsteps;
     int tid, mf;      // mf = options.max_filter
+#ifdef SN_TRACE
+    long long tph[12]; long long tlast;
+    __device__ __forceinline__ void stamp(int k) { const long long t = wall_clock64(); tph[k] += t - tlast; tlast = t; }
+#else
+    __device__ __forceinline__ void stamp(int) {}
+#endif
 
     // ---- evaluate! of the QP (qp.hip): which = the point (sol / cand) ------------------------------------------------------------------------
     __device__ __forceinline__ double eval_objective(const double* p) {        // f = 1/2 x'Lxx x + q'x   (uses xb as scratch)
@@ -190,8 +216,47 @@ struct Ctx {
         __syncthreads();
     }
 
+    template <int RP> __device__ __forceinline__ void panel_(int j0, int jb, int lane, double* pan) {
+        constexpr int JB = 8;
+                            double pr[RP][JB];
+        #pragma unroll
+                            for (int r = 0; r < RP; ++r) {
+                                const int i = j0 + lane + 64 * r;
+        #pragma unroll
+                                for (int c = 0; c < JB; ++c) pr[r][c] = (i < d.nx && c < jb && j0 + c <= i) ? S[i + (j0 + c) * d.lds] : 0.0;
+                            }
+        #pragma unroll
+                            for (int u = 0; u < JB; ++u) {
+                                if (u < jb) {                                           // (uniform)
+                                    const double dj = rl(pr[0][u], u);                  // row j0 + u sits in lane u, chunk 0
+                                    const double rinv = recip(dj);
+                                    if (lane == 0) { D[j0 + u] = dj; Dinv[j0 + u] = rinv; }
+                                    double yk[JB];
+        #pragma unroll
+                                    for (int c = u + 1; c < JB; ++c) yk[c] = rl(pr[0][u], c);      // raw entries of the pivot column in the panel's own rows
+        #pragma unroll
+                                    for (int r = 0; r < RP; ++r) {
+                                        const int i = j0 + lane + 64 * r;
+                                        const double y = pr[r][u];
+                                        if (i > j0 + u && i < d.nx) pan[u * d.nx + i] = y;
+                                        const double li = y * rinv;
+        #pragma unroll
+                                        for (int c = u + 1; c < JB; ++c) pr[r][c] -= li * yk[c];     // (entries above the diagonal take garbage: never read)
+                                        if (i > j0 + u) pr[r][u] = li;
+                                    }
+                                }
+                            }
+        #pragma unroll
+                            for (int r = 0; r < RP; ++r) {
+                                const int i = j0 + lane + 64 * r;
+        #pragma unroll
+                                for (int c = 0; c < JB; ++c) if (i < d.nx && c < jb && j0 + c < i) S[i + (j0 + c) * d.lds] = pr[r][c];
+                            }
+    }
+
     // ---- factorize! + compute_inertia! of the condensed matrix for the current (ep, ed): returns true when the inertia is (nx, ne + nc, 0) ---------
     __device__ __forceinline__ bool factorize(int& zero_pivots) {
+        stamp(1);
         kyy = -1.0 / (rho + ep) + (0.0 - ed);
         omega_y = -1.0 / kyy;
         int pos = 0, nonpos = 0, zero = 0;
@@ -224,62 +289,105 @@ struct Ctx {
             S[i + j * d.lds] = v;
         }
         __syncthreads();
-        // right-looking LDL^T in place (unit lower L below the diagonal), one barrier per pivot: the unscaled pivot column travels through ycol (two buffers)
-        for (int i = tid; i < d.nx; i += NT) ycol[i] = S[i];
-        const int ti = tid >> 4, tk = tid & 15;
-        for (int j = 0; j < d.nx; ++j) {
-            __syncthreads();
-            const double* y = ycol + (j & 1) * d.nx;
-            double* yn = ycol + ((j + 1) & 1) * d.nx;
-            const double dj = y[j];
-            const double rinv = 1.0 / dj;
-            if (tid == 0) { D[j] = dj; Dinv[j] = rinv; }
-            for (int i = j + 1 + ti; i < d.nx; i += 16) {
-                const double li = y[i] * rinv;
-                for (int k = j + 1 + tk; k <= i; k += 16) {
-                    const double v = S[i + k * d.lds] - li * y[k];
-                    S[i + k * d.lds] = v;
-                    if (k == j + 1) yn[i] = v;
+        stamp(2);
+        // Blocked right-looking LDL^T in place (unit lower L below the diagonal), panels of 8 columns.  A panel is factored by ONE wavefront in registers: lane l holds
+        // the panel entries of the rows j0 + l (+ 64, 128, 192), the pivot row's entries travel by v_readlane — no barrier and no LDS round trip between the 8 pivots —
+        // and leaves the raw (unscaled) pivot columns in `ycol` (8 x nx); then all threads apply the panel to the trailing matrix, entry by entry in pivot order
+        // (S(i, k) -= l_i y_k for the panel's pivots in turn: the arithmetic of the column-by-column algorithm), two barriers per panel instead of one per pivot.
+        {
+            constexpr int JB = 8;
+            const int lane = tid & 63, wave = tid >> 6;
+            const int ti = tid >> 4, tk = tid & 15;
+            double* pan = ycol;
+            for (int j0 = 0; j0 < d.nx; j0 += JB) {
+                const int jb = d.nx - j0 < JB ? d.nx - j0 : JB;
+                stamp(3);
+                if (wave == 0) { if (d.nx - j0 <= 64) panel_<1>(j0, jb, lane, pan); else panel_<2>(j0, jb, lane, pan); }
+                __syncthreads();
+                stamp(9);
+                const int base = j0 + jb;
+                for (int i = base + ti; i < d.nx; i += 16) {
+                    double li[JB];
+#pragma unroll
+                    for (int u = 0; u < JB; ++u) li[u] = u < jb ? S[i + (j0 + u) * d.lds] : 0.0;
+                    // three entries of the row at a time: their chains of 8 dependent multiply-adds interleave (one entry alone is ~230 cycles of latency)
+                    constexpr int KU = 3;
+                    for (int k0 = base + tk; k0 <= i; k0 += 16 * KU) {
+                        double v[KU];
+#pragma unroll
+                        for (int q = 0; q < KU; ++q) { const int k = k0 + 16 * q; v[q] = k <= i ? S[i + k * d.lds] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < JB; ++u) {
+#pragma unroll
+                            for (int q = 0; q < KU; ++q) { const int k = k0 + 16 * q; if (u < jb && k <= i) v[q] -= li[u] * pan[u * d.nx + k]; }
+                        }
+#pragma unroll
+                        for (int q = 0; q < KU; ++q) { const int k = k0 + 16 * q; if (k <= i) S[i + k * d.lds] = v[q]; }
+                    }
                 }
-                if (tk == 0) S[i + j * d.lds] = li;
+                __syncthreads();
             }
         }
-        __syncthreads();
         double c2[3] = {0.0, 0.0, 0.0};
         for (int i = tid; i < d.nx; i += NT) { const double dv = D[i]; if (dv > 0.0) c2[0] += 1.0; else c2[1] += 1.0; if (dv == 0.0) c2[2] += 1.0; }
         block_sum(c2, red);
         pos += (int)c2[0]; nonpos += (int)c2[1]; zero += (int)c2[2];
         nfact_total += 1;
+        stamp(3);
         zero_pivots = zero;
         return zero == 0 && pos == d.nx && nonpos == d.ne + d.nc;
     }
 
     // ---- xb <- S^-1 xb with the factors in S / Dinv: one wavefront, lane-owned rows in registers, the pivot entry by v_readlane (no barrier inside) ----------
-    __device__ __forceinline__ void solve_S() {
+    __device__ __forceinline__ void solve_S() { if (d.nx <= 64) solve_S_<1>(); else solve_S_<2>(); }
+    template <int RPL> __device__ __forceinline__ void solve_S_() {
         if (tid < 64) {
-            constexpr int RPL = 4;                      // rows per lane: nx <= 256
+            constexpr int PF = 8;              // rows per lane (nx <= 256); pivots whose column entries are fetched together (one LDS latency per PF pivots)
             double x[RPL];
 #pragma unroll
             for (int u = 0; u < RPL; ++u) { const int i = tid + 64 * u; x[u] = i < d.nx ? xb[i] : 0.0; }
-            auto bcast = [&](int k) -> double {
-                const int u = k >> 6, src = k & 63;
-                double v = x[0];
-                if (u == 1) v = x[1]; else if (u == 2) v = x[2]; else if (u == 3) v = x[3];
-                const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-                return __hiloint2double(hi, lo);
-            };
-            for (int k = 0; k < d.nx; ++k) {            // L u = b
-                const double xk = bcast(k);
-                const double* col = S + k * d.lds;
+            const int nchunk = (d.nx + 63) >> 6;        // (uniform) chunks of 64 rows in use
+            for (int k0 = 0; k0 < d.nx; k0 += PF) {     // L u = b, PF columns at a time
+                double l[RPL][PF];
 #pragma unroll
-                for (int u = 0; u < RPL; ++u) { const int i = tid + 64 * u; if (i > k && i < d.nx) x[u] -= col[i] * xk; }
+                for (int u = 0; u < RPL; ++u) {
+                    const int i = tid + 64 * u;
+#pragma unroll
+                    for (int q = 0; q < PF; ++q) l[u][q] = (u < nchunk && i < d.nx && k0 + q < d.nx && i > k0 + q) ? S[i + (k0 + q) * d.lds] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    const int k = k0 + q;
+                    if (k < d.nx) {                      // (uniform)
+                        const int cu = k >> 6, src = k & 63;
+                        const double xs = pick<RPL>(x, cu);
+                        const double xk = rl(xs, src);
+#pragma unroll
+                        for (int u = 0; u < RPL; ++u) x[u] -= l[u][q] * xk;      // (zero multipliers for the rows at or above the pivot)
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < RPL; ++u) { const int i = tid + 64 * u; if (i < d.nx) x[u] *= Dinv[i]; }
-            for (int k = d.nx - 1; k >= 0; --k) {       // L' v = u
-                const double xk = bcast(k);
+            for (int k1 = d.nx; k1 > 0; k1 -= PF) {      // L' v = u, from the last column
+                double l[RPL][PF];
 #pragma unroll
-                for (int u = 0; u < RPL; ++u) { const int i = tid + 64 * u; if (i < k) x[u] -= S[k + i * d.lds] * xk; }
+                for (int u = 0; u < RPL; ++u) {
+                    const int i = tid + 64 * u;
+#pragma unroll
+                    for (int q = 0; q < PF; ++q) { const int k = k1 - 1 - q; l[u][q] = (u < nchunk && k >= 0 && i < k) ? S[k + i * d.lds] : 0.0; }
+                }
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    const int k = k1 - 1 - q;
+                    if (k >= 0) {
+                        const int cu = k >> 6, src = k & 63;
+                        const double xs = pick<RPL>(x, cu);
+                        const double xk = rl(xs, src);
+#pragma unroll
+                        for (int u = 0; u < RPL; ++u) x[u] -= l[u][q] * xk;
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < RPL; ++u) { const int i = tid + 64 * u; if (i < d.nx) xb[i] = x[u]; }
@@ -383,6 +491,7 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
     const Dm& d = c.d; const Options& o = *c.o; const int tid = c.tid;
     StepOut out;
     double* sol = c.sol; double* cand = c.cand; double* step = c.step; double* res = c.res;
+    c.stamp(11);
     // :100-104 gradients, :106-109 barrier + barrier gradient
     c.eval_gradients(sol);
     double s4[4] = {0.0, 0.0, 0.0, 0.0};      // Phi, lambda'r, r'r, -
@@ -432,44 +541,47 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
     if (may_converge && residual_violation < o.residual_tolerance && slack_violation < o.slack_tolerance && c.eqv <= o.equality_tolerance &&
         c.cpv <= o.complementarity_tolerance) { out.exit_kind = 1; return out; }                           // :138-143
     if (optimality <= fmax(o.central_path_update_tolerance * c.kappa, o.optimality_tolerance)) { out.exit_kind = 2; return out; }      // :165
+    c.stamp(0);
     // :175-185: the Hessian and the Jacobians of a QP are constant; the cone Jacobians are functions of (s, t) formed where they are used
     // ---- :187 search_direction!: inertia_correction! (inertia.jl:30-80, quirk B-1: IC-3 always takes max(min_regularization, scaling_regularization_last * eps_last))
-    {
+    {   // (one loop, ONE instance of the factorisation's code: IC-1, then IC-4 as often as the inertia test fails)
         int zero = 0, count = 0;
         c.ep = o.primal_regularization_initial; c.ed = o.dual_regularization_initial;
-        bool ok = c.factorize(zero); ++count;                                                               // IC-1
-        if (!ok) {
-            if (zero != 0) c.ed = o.dual_regularization * pow(c.kappa, o.dual_regularization_exponent);      // IC-2
-            c.ep = fmax(o.min_regularization, o.scaling_regularization_last * c.ep_last);                   // IC-3
-            while (!ok) {
-                ok = c.factorize(zero); ++count;                                                             // IC-4
-                if (ok) break;
+        for (;;) {
+            const bool ok = c.factorize(zero); ++count;                                                      // IC-1 / IC-4
+            if (ok) { if (count > 1) c.ep_last = c.ep; break; }
+            if (count == 1) {
+                if (zero != 0) c.ed = o.dual_regularization * pow(c.kappa, o.dual_regularization_exponent);  // IC-2
+                c.ep = fmax(o.min_regularization, o.scaling_regularization_last * c.ep_last);               // IC-3
+            } else {
                 if (c.ep_last == 0.0) c.ep = o.scaling_regularization_initial * c.ep;                        // IC-5
                 else c.ep = o.scaling_regularization * c.ep;
                 if (c.ep > o.max_regularization) { out.rc = CALIPSO_ERR_INERTIA; out.nfact = count; return out; }      // IC-6
             }
-            c.ep_last = c.ep;
         }
         out.nfact = count;
     }
-    c.search_direction_symmetric(res, step);
-    if (o.iterative_refinement) {                                                                           // iterative_refinement.jl:1-52
-        double norm = c.residual_error();
-        const double norm0 = norm;
+    c.stamp(1);
+    {   // search_direction_symmetric!(step, residual), then iterative_refinement! (iterative_refinement.jl:1-52) — one loop, ONE instance of the solve's and the residual's code:
+        // the first pass is the solve for the step itself, every further pass a correction round
         int it = 0;
-        bool good = false;
-        while (it <= o.max_iterative_refinement) {
-            if (norm <= o.iterative_refinement_tolerance && it >= o.min_iterative_refinement) { good = true; break; }
-            c.search_direction_symmetric(c.rerr, c.corr);
-            for (int i = tid; i < d.N; i += NT) step[i] += c.corr[i];
-            __syncthreads();
+        bool first = true, good = false;
+        double norm = 0.0, norm0 = 0.0;
+        for (;;) {
+            c.search_direction_symmetric(first ? res : c.rerr, first ? step : c.corr);
+            if (first) c.stamp(4);
+            if (!o.iterative_refinement) { good = true; break; }
+            if (!first) { for (int i = tid; i < d.N; i += NT) step[i] += c.corr[i]; __syncthreads(); it += 1; }
             norm = c.residual_error();
-            it += 1;
+            if (first) { norm0 = norm; first = false; }
+            if (it > o.max_iterative_refinement) break;                                                      // `while iteration <= max_iterative_refinement`
+            if (norm <= o.iterative_refinement_tolerance && it >= o.min_iterative_refinement) { good = true; break; }
         }
         out.rounds = it;
-        c.rlast = it; if (it > c.rmax) c.rmax = it;
+        if (o.iterative_refinement) { c.rlast = it; if (it > c.rmax) c.rmax = it; }
         if (!good && !(norm <= norm0)) { c.rfail += 1; out.rc = CALIPSO_WARN_REFINEMENT; return out; }      // (the reference would take H \ residual: left to the general path)
     }
+    c.stamp(5);
     // ---- :190-221 cone search: separate step sizes for s and t -----------------------------------------------------------------------------------------
     double a_s = 1.0, a_t = 1.0;
     if (d.nc > 0) {
@@ -510,10 +622,12 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
         Mh = c.fcand + (v[1] + 0.5 * c.rho * v[2]) - c.kappa * v[0];
         thetah = (d.ne + d.nc > 0) ? v[3] / (double)(d.ne + d.nc) : 0.0;
     };
+    c.stamp(6);
     double Mh, thetah;
-    candidate_merit(Mh, thetah);
     int residual_iteration = 0;
-    while (residual_iteration < o.max_residual_line_search) {                                               // :254-302
+    for (;;) {                                                                                              // :231-250, then :254-302
+        candidate_merit(Mh, thetah);
+        if (!(residual_iteration < o.max_residual_line_search)) break;
         if (c.check_filter(thetah, Mh)) {
             if (theta <= o.slack_tolerance && switching_condition(step_size, dd, o.merit_exponent, theta, o.violation_exponent, 1.0) &&
                 armijo(M, Mh, dd, step_size, o.armijo_tolerance, o.machine_tolerance)) break;
@@ -522,12 +636,12 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
         step_size = o.scaling_line_search * step_size;
         for (int i = tid; i < d.n; i += NT) cand[i] = sol[i] - step_size * step[i];                          // :268-276 (x, r, s; t keeps its own step size)
         __syncthreads();
-        candidate_merit(Mh, thetah);
         residual_iteration += 1;
     }
     if (residual_iteration >= o.max_residual_line_search) out.rc = CALIPSO_WARN_LINE_SEARCH;
     if (!switching_condition(step_size, dd, o.merit_exponent, theta, o.violation_exponent, 1.0) || !armijo(M, Mh, dd, step_size, o.armijo_tolerance, o.machine_tolerance))
         c.augment_filter((1.0 - o.violation_tolerance) * theta, M - o.merit_tolerance * theta);              // filter.jl:81-89
+    c.stamp(7);
     // :309-326 accept
     for (int i = tid; i < d.n; i += NT) sol[i] = cand[i];
     for (int i = tid; i < d.m; i += NT) sol[d.oy() + i] = sol[d.oy() + i] - step_size * step[d.oy() + i];
@@ -542,6 +656,7 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
     block_max(v2, c.red);
     c.eqv = v2[0]; c.cpv = v2[1];
     c.nsteps += 1;
+    c.stamp(8);
     out.step_size = step_size; out.Mh = Mh; out.thetah = thetah;
     return out;
 }
@@ -555,7 +670,7 @@ __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
     Ctx c;
     c.d = d; c.o = &a.o; c.tid = tid;
     c.Lxx = sm + L.Lxx; c.Z = sm + L.Z; c.S = sm + L.S; c.q = sm + L.q; c.bh = sm + L.bh; c.lam = sm + L.lam; c.sol = sm + L.sol; c.cand = sm + L.cand; c.step = sm + L.step;
-    c.res = sm + L.res; c.rerr = sm + L.rerr; c.corr = sm + L.corr; c.tmpN = sm + L.tmpN; c.rsym = sm + L.rsym; c.dsym = sm + L.dsym; c.mgrad = sm + L.mgrad;
+    c.res = sm + L.res; c.rerr = sm + L.rerr; c.corr = sm + L.corr; c.tmpN = sm + L.tmpN; c.rsym = sm + L.rsym; c.mgrad = sm + L.mgrad;
     c.fx = sm + L.fx; c.gzx = sm + L.gzx; c.gh = sm + L.gh; c.ghc = sm + L.ghc; c.cprod = sm + L.cprod; c.bgrad = sm + L.bgrad; c.wz = sm + L.wz;
     c.D = sm + L.D; c.Dinv = sm + L.Dinv; c.xb = sm + L.xb; c.t1 = sm + L.t1; c.t2 = sm + L.t2; c.ycol = sm + L.ycol; c.red = sm + L.red;
     c.mf = (int)a.o.max_filter;
@@ -581,6 +696,10 @@ __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
     c.filter_index = cnt[CN_FILTER]; c.nfact_total = cnt[CN_FACT]; c.rfail = cnt[CN_RFAIL]; c.rmax = cnt[CN_RMAX]; c.rlast = cnt[CN_RLAST]; c.nsteps = cnt[CN_STEPS];
     long long total_iterations = cnt[CN_TOTAL], outer = cnt[CN_OUTER], trace_row = cnt[CN_TRACE];
     __syncthreads();
+#ifdef SN_TRACE
+    for (int k = 0; k < 12; ++k) c.tph[k] = 0;
+    c.tlast = wall_clock64();
+#endif
     int status = 0;
     StepOut last;
     auto load_lambda = [&] { const double* lg = a.lam + (size_t)inst * (d.ne > 0 ? d.ne : 1); for (int i = tid; i < d.ne; i += NT) lam[i] = lg[i]; __syncthreads(); };
@@ -588,8 +707,9 @@ __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
         if (a.trace && trace_row < a.trace_rows) { double* tr = a.trace + ((size_t)inst * a.trace_rows + (size_t)trace_row) * d.N; for (int i = tid; i < d.N; i += NT) tr[i] = c.sol[i]; }
         trace_row += 1;
     };
-    if (a.mode == MODE_SOLVE) {
-        // ---- solve!(solver)  solve.jl:8-377 ------------------------------------------------------------------------------------------------------
+    const bool solving = a.mode == MODE_SOLVE;
+    if (solving) {
+        // ---- solve!(solver)  solve.jl:8-96: initialisation ------------------------------------------------------------------------------------------
         c.nfact_total = 0; c.rfail = 0; c.rmax = 0; c.rlast = 0; c.nsteps = 0; trace_row = 0;
         if (o.warmstart == 0.0) {                                                                            // initialize_slacks! / initialize_duals!  initialize.jl:15-36
             c.eval_constraints(c.sol, c.gh);
@@ -602,52 +722,51 @@ __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
         for (int i = tid; i < d.ne; i += NT) lam[i] = o.dual_initial;
         __syncthreads();
         total_iterations = 1;
-        c.fcur = c.eval_objective(c.sol);                                                                    // :78-83
-        c.eval_constraints(c.sol, c.gh);
-        {
-            double v[1] = {0.0};
-            for (int i = tid; i < d.ne; i += NT) v[0] = fmax(v[0], fabs(c.gh[i]));
-            block_max(v, c.red);
-            c.eqv = v[0];                                                                                    // :85
-            c.cpv = 0.0;                                                                                     // :86 reads cone_product BEFORE cone!(product): zeros on a fresh solver (quirk B-6)
-        }
-        c.cone_product(c.sol);                                                                               // :88-91 (the target of a nonnegative cone is 1)
         c.filter_reset();                                                                                    // :95
-        bool done = false;
-        for (long long j = 1; j <= o.max_outer_iterations && !done; ++j) {
-            outer = j;
-            for (long long i = 1; i <= o.max_residual_iterations; ++i) {
-                last = inner_iteration(c, true);
-                if (last.rc < 0 || last.rc == CALIPSO_WARN_REFINEMENT) { status = last.rc < 0 ? last.rc : -100 - last.rc; done = true; break; }
-                if (last.exit_kind == 1) { status = 1; done = true; break; }
-                if (last.exit_kind == 2) break;
-                total_iterations += 1;
-                record_trace();
+    } else load_lambda();
+    // :78-83 (solve!) / the values at the resident point (steps: a resident state does not carry them)
+    c.fcur = c.eval_objective(c.sol);
+    c.eval_constraints(c.sol, c.gh);
+    if (solving) {
+        double v[1] = {0.0};
+        for (int i = tid; i < d.ne; i += NT) v[0] = fmax(v[0], fabs(c.gh[i]));
+        block_max(v, c.red);
+        c.eqv = v[0];                                                                                        // :85
+        c.cpv = 0.0;                                                                                         // :86 reads cone_product BEFORE cone!(product): zeros on a fresh solver (quirk B-6)
+    }
+    c.cone_product(c.sol);                                                                                   // :88-91 (the target of a nonnegative cone is 1)
+    // ---- the loops of solve.jl:97-372 (solving) or `count` passes of the inner loop body from the resident state (calipso_hip_newton_steps: never "converged",
+    // exit kind 2 leaves the point as it is) — ONE loop, one instance of the iteration's code
+    long long jo = 1, ii = 1;
+    int kdone = 0;
+    if (solving) outer = 1;
+    for (;;) {
+        if (solving ? jo > o.max_outer_iterations : kdone >= a.count) break;
+        const double kap = c.kappa, tau = c.tau, rho = c.rho, epl = c.ep_last, fc = c.fcur;
+        const long long fidx = c.filter_index;
+        const bool restore = !solving && !a.advance;
+        if (restore && tid == 0) for (long long i = 0; i < fidx; ++i) { c.filt[4 * mf_ + i] = c.filt[i]; c.filt[5 * mf_ + i] = c.filt[mf_ + i]; }
+        last = inner_iteration(c, solving);
+        if (last.rc < 0 || last.rc == CALIPSO_WARN_REFINEMENT) { status = last.rc < 0 ? last.rc : -100 - last.rc; break; }
+        if (solving) {
+            if (last.exit_kind == 1) { status = 1; break; }                                                  // :138-160
+            bool inner_done = last.exit_kind == 2;                                                           // :165
+            if (!inner_done) { total_iterations += 1; record_trace(); ii += 1; if (ii > o.max_residual_iterations) inner_done = true; }
+            if (inner_done) {
+                c.kappa = fmax(o.residual_tolerance / 10.0, fmin(o.central_path_scaling * c.kappa, pow(c.kappa, o.central_path_exponent)));      // :356
+                c.tau = fmax(0.99, 1.0 - c.kappa);                                                           // :359
+                for (int i = tid; i < d.ne; i += NT) lam[i] = lam[i] + c.rho * c.sol[d.orr() + i];           // :362-364
+                __syncthreads();
+                c.rho = fmin(fmax(o.penalty_scaling * c.rho, 1.0 / c.kappa), o.max_penalty);                 // :365
+                c.filter_reset();                                                                            // :368
+                jo += 1; ii = 1;
+                if (jo <= o.max_outer_iterations) outer = jo;
             }
-            if (done) break;
-            c.kappa = fmax(o.residual_tolerance / 10.0, fmin(o.central_path_scaling * c.kappa, pow(c.kappa, o.central_path_exponent)));      // :356
-            c.tau = fmax(0.99, 1.0 - c.kappa);                                                               // :359
-            for (int i = tid; i < d.ne; i += NT) lam[i] = lam[i] + c.rho * c.sol[d.orr() + i];               // :362-364
-            __syncthreads();
-            c.rho = fmin(fmax(o.penalty_scaling * c.rho, 1.0 / c.kappa), o.max_penalty);                     // :365
-            c.filter_reset();                                                                                // :368
-        }
-    } else {
-        // ---- `count` passes of the inner loop body from the resident state (calipso_hip_newton_steps): never "converged", exit kind 2 leaves the point as it is ----
-        load_lambda();
-        c.eval_constraints(c.sol, c.gh);            // the values at the current point (a resident state does not carry them)
-        c.fcur = c.eval_objective(c.sol);
-        c.cone_product(c.sol);
-        for (int k = 0; k < a.count; ++k) {
-            const double kap = c.kappa, tau = c.tau, rho = c.rho, epl = c.ep_last, fc = c.fcur;
-            const long long fidx = c.filter_index;
-            if (!a.advance && tid == 0) for (long long i = 0; i < fidx; ++i) { c.filt[4 * mf_ + i] = c.filt[i]; c.filt[5 * mf_ + i] = c.filt[mf_ + i]; }
-            last = inner_iteration(c, false);
-            if (last.rc < 0 || last.rc == CALIPSO_WARN_REFINEMENT) { status = last.rc < 0 ? last.rc : -100 - last.rc; break; }
+        } else {
             if (last.exit_kind == 0) { total_iterations += 1; record_trace(); }
-            if (!a.advance) {
-                // restore (benchmark mode): the point from the instance's global copy (untouched until the write-back), scalars from registers, the filter's pairs
-                // from their saved copy (entries beyond the index are never read)
+            if (restore) {
+                // benchmark mode: the point from the instance's global copy (untouched until the write-back), scalars from registers, the filter's pairs from their
+                // saved copy (entries beyond the index are never read)
                 const double* w = a.w + (size_t)inst * d.N;
                 for (int i = tid; i < d.N; i += NT) c.sol[i] = w[i];
                 if (tid == 0) for (long long i = 0; i < fidx; ++i) { c.filt[i] = c.filt[4 * mf_ + i]; c.filt[mf_ + i] = c.filt[5 * mf_ + i]; }
@@ -656,6 +775,7 @@ __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
                 c.eval_constraints(c.sol, c.gh);
                 c.cone_product(c.sol);
             }
+            kdone += 1;
         }
     }
     // ---- write the state back -----------------------------------------------------------------------------------------------------------------------
@@ -675,6 +795,9 @@ __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
         cnt[CN_TOTAL] = total_iterations; cnt[CN_OUTER] = outer; cnt[CN_FACT] = c.nfact_total; cnt[CN_RFAIL] = c.rfail; cnt[CN_RMAX] = c.rmax; cnt[CN_RLAST] = c.rlast;
         cnt[CN_STEPS] = c.nsteps; cnt[CN_TRACE] = trace_row;
         a.status[inst] = status;
+#ifdef SN_TRACE
+        if (a.prof && inst == 0) for (int k = 0; k < 12; ++k) a.prof[k] = (double)c.tph[k] * 0.01;      // microseconds (100 MHz)
+#endif
         double* inf = a.info + (size_t)inst * IN_COUNT;
         inf[IN_STEP] = last.step_size; inf[IN_STEP_T] = last.step_size_t; inf[IN_ROUNDS] = last.rounds; inf[IN_NFACT] = last.nfact; inf[IN_MH] = last.Mh; inf[IN_THETAH] = last.thetah;
         inf[IN_EXIT] = last.exit_kind; inf[IN_OPT] = last.optimality;
@@ -701,7 +824,7 @@ int launch(SN* s, int mode, int count, int advance) {
     a.P = s->P; a.q = s->q; a.Z = s->Z; a.bh = s->bh;
     a.sP = s->shared_qp ? 0 : (long long)(nx * nx); a.sq = s->shared_qp ? 0 : (long long)nx; a.sZ = s->shared_qp ? 0 : (long long)(std::max<size_t>(m, 1) * nx);
     a.sbh = s->shared_qp ? 0 : (long long)std::max<size_t>(m, 1);
-    a.w = s->w; a.lam = s->lam; a.sc = s->sc; a.filt = s->filt; a.info = s->info; a.trace = s->trace; a.cnt = s->cnt; a.status = s->status;
+    a.w = s->w; a.lam = s->lam; a.sc = s->sc; a.filt = s->filt; a.info = s->info; a.trace = s->trace; a.prof = s->prof; a.cnt = s->cnt; a.status = s->status;
     a.batch = s->batch; a.mode = mode; a.count = count; a.advance = advance; a.trace_rows = s->trace_rows;
     static_assert(sizeof(Args) <= 3800, "kernel arguments");
     SK(hipEventRecord(s->ev0, s->stream));
@@ -724,7 +847,7 @@ const char* calipso_hip_smallnewton_last_error(calipso_hip_smallnewton* s) { ret
 int32_t calipso_hip_smallnewton_create(int64_t nx, int64_t ne, int64_t nc, int64_t batch, int32_t device, calipso_hip_smallnewton** out) {
     if (!out) return CALIPSO_ERR_ARGUMENT;
     *out = nullptr;
-    if (nx < 1 || ne < 0 || nc < 0 || batch < 1 || nx > 256 || batch > (1 << 22)) { g_sn_err = "calipso_hip_smallnewton_create: 1 <= nx <= 256, ne, nc >= 0, batch >= 1"; return CALIPSO_ERR_ARGUMENT; }
+    if (nx < 1 || ne < 0 || nc < 0 || batch < 1 || nx > 128 || batch > (1 << 22)) { g_sn_err = "calipso_hip_smallnewton_create: 1 <= nx <= 128, ne, nc >= 0, batch >= 1"; return CALIPSO_ERR_ARGUMENT; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { g_sn_err = "no HIP device available (libcalipso_hip has no CPU path)"; return CALIPSO_ERR_HIP; }
     SN* s = new SN();
@@ -739,7 +862,7 @@ int32_t calipso_hip_smallnewton_create(int64_t nx, int64_t ne, int64_t nc, int64
     SK(hipEventCreate(&s->ev0)); SK(hipEventCreate(&s->ev1));
     const size_t B = (size_t)batch, N = (size_t)d.N;
     auto alloc = [&](double** p, size_t n) { if (hipMalloc((void**)p, sizeof(double) * std::max<size_t>(n, 1)) != hipSuccess) return false; return hipMemsetAsync(*p, 0, sizeof(double) * std::max<size_t>(n, 1), s->stream) == hipSuccess; };
-    if (!alloc(&s->w, B * N) || !alloc(&s->lam, B * std::max(1, d.ne)) || !alloc(&s->sc, B * SC_COUNT) || !alloc(&s->filt, B * 6 * (size_t)s->opt.max_filter) || !alloc(&s->info, B * IN_COUNT))
+    if (!alloc(&s->w, B * N) || !alloc(&s->lam, B * std::max(1, d.ne)) || !alloc(&s->sc, B * SC_COUNT) || !alloc(&s->filt, B * 6 * (size_t)s->opt.max_filter) || !alloc(&s->info, B * IN_COUNT) || !alloc(&s->prof, 16))
         return fail(s, CALIPSO_ERR_HIP, "calipso_hip_smallnewton_create: device allocation failed");
     SK(hipMalloc((void**)&s->cnt, sizeof(long long) * B * CN_COUNT)); SK(hipMemsetAsync(s->cnt, 0, sizeof(long long) * B * CN_COUNT, s->stream));
     SK(hipMalloc((void**)&s->status, sizeof(int) * B)); SK(hipMemsetAsync(s->status, 0, sizeof(int) * B, s->stream));
@@ -756,7 +879,7 @@ int32_t calipso_hip_smallnewton_destroy(calipso_hip_smallnewton* s) {
     if (!s) return CALIPSO_OK;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (double* p : {s->P, s->q, s->Z, s->bh, s->w, s->lam, s->sc, s->filt, s->info, s->trace}) if (p) (void)hipFree(p);
+    for (double* p : {s->P, s->q, s->Z, s->bh, s->w, s->lam, s->sc, s->filt, s->info, s->trace, s->prof}) if (p) (void)hipFree(p);
     if (s->cnt) (void)hipFree(s->cnt);
     if (s->status) (void)hipFree(s->status);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -896,6 +1019,14 @@ int32_t calipso_hip_smallnewton_steps(calipso_hip_smallnewton* s, int32_t count,
     if (info) SK(hipMemcpy(info, s->info, sizeof(double) * (size_t)s->batch * IN_COUNT, hipMemcpyDeviceToHost));
     if (status) SK(hipMemcpy(status, s->status, sizeof(int) * (size_t)s->batch, hipMemcpyDeviceToHost));
     if (ms) *ms = s->last_ms;
+    return CALIPSO_OK;
+}
+
+// phase clocks of instance 0 in the last launch, microseconds (a build with -DSN_TRACE; zeros otherwise): [0] evaluation + residual + norms, [1] inertia logic, [2] cone
+// weights + assembly of S, [3] LDL^T, [4] first condensed solve, [5] refinement, [6] cone search + candidate, [7] candidate merit + line search, [8] accept, [9] of the LDL^T: the panels (one wavefront), [3] then holds its trailing updates, [11] between steps
+int32_t calipso_hip_debug_smallnewton_profile(calipso_hip_smallnewton* s, double out[12]) {
+    if (!s || !out) return CALIPSO_ERR_ARGUMENT;
+    SK(hipMemcpy(out, s->prof, sizeof(double) * 12, hipMemcpyDeviceToHost));
     return CALIPSO_OK;
 }
 

@@ -489,6 +489,47 @@ function CALIPSO.solve!(g::HIPGroup)
     return res
 end
 
+# ---- solve! for a batch of small QPs in one kernel launch (include/calipso_hip.h: calipso_hip_smallnewton_*; csrc/smallnewton.hip) ----------------
+"`batch` independent QPs (min c x'Px + q'x s.t. Ax = b, h - Gx >= 0) of one shape: `HIPSmallNewton(nx, ne, nc, batch)`, `set_qp!`, `initialize!`, `solve!` — every instance's whole solve! in ONE launch."
+mutable struct HIPSmallNewton
+    handle::Ptr{Cvoid}
+    nx::Int; ne::Int; nc::Int; batch::Int
+end
+function HIPSmallNewton(nx::Integer, ne::Integer, nc::Integer, batch::Integer; device::Integer=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:calipso_hip_smallnewton_create, lib), Int32, (Int64, Int64, Int64, Int64, Int32, Ptr{Ptr{Cvoid}}), nx, ne, nc, batch, device, h)
+    rc == 0 || error("calipso_hip_smallnewton_create failed ($rc): " * unsafe_string(ccall((:calipso_hip_smallnewton_last_error, lib), Cstring, (Ptr{Cvoid},), h[])))
+    s = HIPSmallNewton(h[], nx, ne, nc, batch)
+    finalizer(x -> ccall((:calipso_hip_smallnewton_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), s)
+    return s
+end
+sn_check(s::HIPSmallNewton, rc, what) = rc < 0 ? error("$what failed ($rc): " * unsafe_string(ccall((:calipso_hip_smallnewton_last_error, lib), Cstring, (Ptr{Cvoid},), s.handle))) : rc
+"column-major arrays of ONE problem (shared = true) or stacked along a trailing batch dimension: P (nx, nx[, batch]), A (ne, nx[, batch]), G (nc, nx[, batch])"
+function set_qp!(s::HIPSmallNewton, P, q, A, b, G, h; objective_scale::Float64=0.5, shared::Bool=ndims(P) == 2)
+    f(a) = isempty(a) ? zeros(1) : collect(Float64, vec(a))
+    sn_check(s, ccall((:calipso_hip_smallnewton_set_qp, lib), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Int32),
+                      s.handle, f(P), f(q), f(A), f(b), f(G), f(h), objective_scale, shared ? 1 : 0), "calipso_hip_smallnewton_set_qp")
+end
+"initialize!(solver, guess) for every instance: x0 is nx x batch"
+function initialize!(s::HIPSmallNewton, x0::AbstractMatrix)
+    N = s.nx + 2 * s.ne + 3 * s.nc
+    w = zeros(N, s.batch); w[1:s.nx, :] .= x0
+    sn_check(s, ccall((:calipso_hip_smallnewton_set_state, lib), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), s.handle, w, C_NULL, C_NULL), "calipso_hip_smallnewton_set_state")
+end
+"solve!(solver) for every instance in one launch: (result per instance, launch milliseconds)"
+function solve!(s::HIPSmallNewton)
+    res = zeros(Int32, s.batch); ms = Ref{Float64}(0.0)
+    sn_check(s, ccall((:calipso_hip_smallnewton_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}), s.handle, res, ms), "calipso_hip_smallnewton_solve")
+    return res, ms[]
+end
+"solution.all of every instance (N x batch)"
+function solution(s::HIPSmallNewton)
+    N = s.nx + 2 * s.ne + 3 * s.nc
+    w = zeros(N, s.batch)
+    sn_check(s, ccall((:calipso_hip_smallnewton_get_state, lib), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}), s.handle, w, C_NULL, C_NULL, C_NULL), "calipso_hip_smallnewton_get_state")
+    return w
+end
+
 # ---- multi-GPU exchange (include/calipso_hip.h: calipso_hip_comm_*): RCCL over xGMI, one process per GPU -------------------------
 "RCCL communicator: `id = comm_unique_id()` on one rank, distributed by the launcher (file / MPI / Distributed.jl), then `HIPComm(rank, nranks, id; device)` on every rank."
 mutable struct HIPComm
@@ -530,7 +571,7 @@ function allreduce_sum!(c::HIPComm, v::Vector{Float64})
     return v
 end
 
-export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPComm, comm_unique_id, comm_size, gather_status, allreduce_sum!, newton_step!,
+export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPSmallNewton, set_qp!, solution, HIPComm, comm_unique_id, comm_size, gather_status, allreduce_sum!, newton_step!,
        search_direction_nonsymmetric!, analyze_structure!, clear_structure!, set_stage_parallel!, set_stage_blocks!, declared_structure, kernel_times, sync_scalars!, copy_back!
 
 end # module

@@ -430,7 +430,7 @@ int32_t calipso_hip_small_get(calipso_hip_small*, double* X, int64_t* inertia);
  * for the general path to be anything but launch latency (the MPC problems of examples/autotuning/cartpole.jl:179-227: n = 89): one workgroup per instance, problem
  * data, iterates and the factor in the compute unit's LDS, every decision of solve.jl:98-368 (exit tests, inertia_correction!, iterative_refinement!, cone search,
  * filter line search, outer updates) on the device, ONE launch per call.  Evaluator: the QP of calipso_hip_qp_attach (min c x'Px + q'x s.t. Ax = b, h - Gx >= 0) with
- * nonnegative cones only; residual_norm = constraint_norm = 1.  Points have the layout of point.jl:13-22 (N = nx + 2 ne + 3 nc).  Limits: nx <= 256 and the
+ * nonnegative cones only; residual_norm = constraint_norm = 1.  Points have the layout of point.jl:13-22 (N = nx + 2 ne + 3 nc).  Limits: nx <= 128 and the
  * instance must fit 160 KB of LDS (n up to ~200), else CALIPSO_ERR_ARGUMENT at create: the general path (calipso_hip_create + groups) takes those.
  *   create(nx, ne, nc, batch, device)        set_option(name, value): options.jl:6-59 by name
  *   set_qp(P, q, A, b, G, h, c, shared)      column-major host arrays, batch-major (instance k at k * size) or ONE problem for all (shared != 0)

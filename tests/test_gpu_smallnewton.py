@@ -103,7 +103,7 @@ def test_one_problem_shared_by_the_batch_and_benchmark_steps():
 def test_limits_are_refused():
     pkg = load_pkg()
     with pytest.raises(pkg.CalipsoHipError, match="LDS"):
-        pkg.SmallNewtonBatch(200, 150, 100, 2)
+        pkg.SmallNewtonBatch(100, 150, 100, 2)
     sn = pkg.SmallNewtonBatch(5, 2, 3, 2)
     with pytest.raises(pkg.CalipsoHipError, match="no problem data"):
         sn.solve()
