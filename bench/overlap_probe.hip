@@ -91,6 +91,8 @@ int main() {
         else hipStreamCreateWithFlags(&g_streams[i], hipStreamNonBlocking);
     }
     // (1) which pairs of streams sit on different hardware queues?  A on half the compute units: B must overlap if the queues differ
+    // (0) A on ONE, 8, 64 compute units: does B get the rest of the chip?
+    for (int ga : {1, 8, 64}) { g_gridA = ga; g_sa = 0; g_sb = 1; probe<5>(64 * 1024, 5000, src, n, out, 512); g_sa = 0; g_sb = 2; probe<5>(64 * 1024, 5000, src, n, out, 512); }
     g_gridA = 128;
     for (int a : {0, 1, 2}) for (int b : {0, 1, 2, 3}) { if (a == b) continue; g_sa = a; g_sb = b; probe<5>(64 * 1024, 5000, src, n, out, 512); }
     // (2) A on every compute unit
