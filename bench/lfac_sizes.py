@@ -19,7 +19,10 @@ t0 = time.perf_counter()
 for _ in range(10): s.newton_step(advance=False)
 dt = (time.perf_counter() - t0) / 10
 kt = s.kernel_times()
-print("RESULT lfac %%d  first step %%.2f s  step %%.3f ms  pivot chain / panel launches %%.3f ms (%%d launches)" %% (int(kt[6]), first, 1e3 * dt, kt[0], int(kt[1])))
+import ctypes, numpy as np
+from calipso_jl_amd._lib import lib
+d8 = np.zeros(8); f = lib().calipso_hip_debug_lfac_describe; f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]; f(s._h, d8.ctypes.data)
+print("RESULT lfac %%d (-1: wanted, no plan: %%s)  first step %%.3f s (plan scan %%.1f ms)  step %%.3f ms  pivot chain / panel launches %%.3f ms (%%d launches)" %% (int(kt[6]), lib().calipso_hip_last_error(s._h).decode()[:90] if int(kt[6]) < 0 else "-", first, d8[6], 1e3 * dt, kt[0], int(kt[1])))
 '''
 shapes = (sys.argv[1] if len(sys.argv) > 1 else "1000,300,60,30,3;1500,300,60,30,3;2500,1500,500,250,2;4000,2000,600,200,3;6000,3000,1000,300,3").split(";")
 for sh in shapes:

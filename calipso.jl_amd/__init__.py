@@ -843,6 +843,11 @@ class SmallNewtonBatch:
     def set_option(self, name, value):
         self._check(self._L.calipso_hip_smallnewton_set_option(self._h, name.encode(), float(value)), "smallnewton_set_option(%s)" % name)
 
+    def set_cones(self, n_nonnegative, second_order_dims=()):
+        """cone layout: the first n_nonnegative cone entries nonnegative, then second-order cones of the given dimensions (contiguous)"""
+        dims = np.ascontiguousarray(list(second_order_dims), dtype=np.int64)
+        self._check(self._L.calipso_hip_smallnewton_set_cones(self._h, int(n_nonnegative), int(dims.size), _pi(dims) if dims.size else None), "smallnewton_set_cones")
+
     def set_qp(self, P, q, A, b, G, h, objective_scale=0.5, shared=None):
         """arrays of ONE problem (P (nx, nx), q (nx), A (ne, nx), ...) shared by all instances, or stacked along a leading batch axis"""
         P = np.asarray(P, dtype=np.float64)

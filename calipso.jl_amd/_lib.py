@@ -104,6 +104,7 @@ SYMBOLS = {
     "calipso_hip_smallnewton_destroy": (_i32, [_vp]),
     "calipso_hip_smallnewton_last_error": (C.c_char_p, [_vp]),
     "calipso_hip_smallnewton_set_option": (_i32, [_vp, C.c_char_p, _dbl]),
+    "calipso_hip_smallnewton_set_cones": (_i32, [_vp, _i64, _i64, _pi64]),
     "calipso_hip_smallnewton_set_qp": (_i32, [_vp, _pd, _pd, _pd, _pd, _pd, _pd, _dbl, _i32]),
     "calipso_hip_smallnewton_set_state": (_i32, [_vp, _pd, _pd, _pd]),
     "calipso_hip_smallnewton_get_state": (_i32, [_vp, _pd, _pd, _pd, _pi64]),

@@ -603,7 +603,7 @@ static bool lfac_scan_plans(LfacPlan& best, int nblk, int nx, int ne, int nc, in
             }
     static const int env_threads = [] { const char* e = getenv("CALIPSO_HIP_LFAC_PLAN_THREADS"); return e ? atoi(e) : 0; }();
     unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = std::max(1, std::min<int>({env_threads > 0 ? env_threads : 16, hw ? (int)hw : 1, (int)cands.size()}));
+    const int nthreads = std::max(1, std::min<int>({env_threads > 0 ? env_threads : 64, hw ? (int)hw : 1, (int)cands.size()}));      // (the host has nothing else to do: the first factorisation of the shape waits for this)
     std::vector<double> est(cands.size(), -1.0);            // the model's estimate of every feasible candidate (-1: infeasible)
     std::atomic<size_t> next{0};
     auto work = [&] {

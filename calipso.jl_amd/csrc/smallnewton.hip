@@ -25,6 +25,8 @@
 
 struct calipso_hip_smallnewton {
     int nx = 0, ne = 0, nc = 0, batch = 0, device = 0;
+    int nq = 0; std::vector<int> soc_start, soc_dim, soc_woff; int wsz = 0, maxd = 0;      // cone layout: nq nonnegative entries, then the second-order cones (contiguous)
+    int *d_soc = nullptr;                                                                   // device: [start | dim | woff], nsoc each
     calipso::Options opt;
     double objective_scale = 0.5;
     bool shared_qp = false, have_qp = false;
@@ -50,7 +52,7 @@ enum { IN_STEP = 0, IN_STEP_T, IN_ROUNDS, IN_NFACT, IN_MH, IN_THETAH, IN_EXIT, I
 enum { MODE_SOLVE = 0, MODE_STEPS = 1 };
 
 struct Dm {
-    int nx, ne, nc, m, n, N, ldz, lds;      // ldz: leading dimension of Z in LDS (odd: conflict-free column walks), lds: of S / Lxx
+    int nx, ne, nc, m, n, N, ldz, lds, q, nsoc, wsz, maxd;      // q nonnegative entries first, then nsoc second-order cones (contiguous ranges); wsz = sum of dim^2; ldz: leading dimension of Z in LDS (odd: conflict-free column walks), lds: of S / Lxx
     __host__ __device__ int orr() const { return nx; }
     __host__ __device__ int os() const { return nx + ne; }
     __host__ __device__ int oy() const { return nx + ne + nc; }
@@ -59,7 +61,7 @@ struct Dm {
 };
 
 // LDS carve-up (offsets in doubles): the same function sizes the launch on the host and places the pointers on the device
-struct Lay { int Lxx, Z, S, q, bh, lam, sol, cand, step, res, rerr, corr, tmpN, rsym, mgrad, fx, gzx, gh, ghc, cprod, bgrad, wz, D, Dinv, xb, t1, t2, ycol, red, total; };
+struct Lay { int Lxx, Z, S, q, bh, lam, sol, cand, step, res, rerr, corr, tmpN, rsym, mgrad, fx, gzx, gh, ghc, cprod, bgrad, wz, wsoc, bsoc, vsoc, D, Dinv, xb, t1, t2, ycol, red, total; };
 __host__ __device__ inline Lay layout(const Dm& d) {
     Lay L; int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
@@ -68,7 +70,7 @@ __host__ __device__ inline Lay layout(const Dm& d) {
     L.sol = take(d.N); L.cand = take(d.N); L.step = take(d.N); L.res = take(d.N); L.rerr = take(d.N); L.corr = take(d.N); L.tmpN = take(d.N);
     L.rsym = take(d.n); L.mgrad = take(d.n);
     L.fx = take(d.nx); L.gzx = take(d.nx); L.gh = take(d.m); L.ghc = take(d.m);
-    L.cprod = take(d.nc); L.bgrad = take(d.nc); L.wz = take(d.nc);
+    L.cprod = take(d.nc); L.bgrad = take(d.nc); L.wz = take(d.nc); L.wsoc = take(d.wsz); L.bsoc = take(d.wsz); L.vsoc = take(4 * d.maxd * d.nsoc);
     L.D = take(d.nx); L.Dinv = take(d.nx); L.xb = take(d.nx); L.t1 = take(d.m); L.t2 = take(d.m);
     L.ycol = take(8 * d.nx);
     L.red = take(64);
@@ -80,6 +82,7 @@ struct Args {
     Dm d; Options o;
     const double *P, *q, *Z, *bh; long long sP, sq, sZ, sbh;      // element strides per instance (0: one problem shared by all)
     double *w, *lam, *sc, *filt, *info, *trace, *prof; long long* cnt; int* status;
+    const int *soc_start, *soc_dim, *soc_woff;      // per second-order cone: first cone-local index, dimension, offset of its dim x dim blocks
     int batch, mode, count, advance, trace_rows;
 };
 
@@ -132,6 +135,22 @@ __device__ __forceinline__ void mv_t(const double* M, int ld, int rows, int cols
     }
 }
 
+// second_order_vector_inverse(u, x) (cones/second_order.jl:50-60): arrow(u)^-1 x, the reference's operations in its order
+__device__ __forceinline__ void arrow_inverse(int n, const double* u, const double* x, double* out) {
+    double uu = 0.0;
+    for (int i = 1; i < n; ++i) uu += u[i] * u[i];
+    const double alpha = -1.0 / (u[0] * u[0]) * uu;
+    const double beta = 1.0 / (1.0 + alpha);
+    double d0 = 0.0;
+    for (int i = 1; i < n; ++i) d0 += (u[i] / u[0]) * x[i];
+    const double x0_1 = x[0] - d0;
+    double d1 = 0.0;
+    for (int i = 1; i < n; ++i) { const double o = x[i] - beta * ((u[i] / u[0]) * x0_1); out[i] = o; d1 += (u[i] / u[0]) * o; }
+    const double x2_1 = x[0] - d1;
+    out[0] = 1.0 / u[0] * x2_1;
+    for (int i = 1; i < n; ++i) out[i] = 1.0 / u[0] * out[i];
+}
+
 // v_readlane of a double: the value lane `src` (wave-uniform) holds
 __device__ __forceinline__ double rl(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
@@ -154,7 +173,8 @@ __device__ __forceinline__ double recip(double d) {
 
 struct Ctx {
     Dm d; const Options* o;
-    double *Lxx, *Z, *S, *q, *bh, *lam, *sol, *cand, *step, *res, *rerr, *corr, *tmpN, *rsym, *mgrad, *fx, *gzx, *gh, *ghc, *cprod, *bgrad, *wz, *D, *Dinv, *xb, *t1, *t2, *ycol, *red;
+    double *Lxx, *Z, *S, *q, *bh, *lam, *sol, *cand, *step, *res, *rerr, *corr, *tmpN, *rsym, *mgrad, *fx, *gzx, *gh, *ghc, *cprod, *bgrad, *wz, *wsoc, *bsoc, *vsoc, *D, *Dinv, *xb, *t1, *t2, *ycol, *red;
+    const int *soc_start, *soc_dim, *soc_woff;
     double* filt;                                   // global: [pairs theta | pairs merit | cache theta | cache merit | saved theta | saved merit], max_filter each
     // uniform scalars (every thread holds the same values)
     double kappa, tau, rho, ep, ep_last, ed, fcur, fcand, eqv, cpv, omega_y, kyy;
@@ -186,9 +206,24 @@ struct Ctx {
         __syncthreads();
     }
 
-    // ---- cone!(product) for nonnegative cones: s o t ----------------------------------------------------------------------------------------
+    // cone_target (cone.jl:55-59): 1 for nonnegative entries and for the first entry of a second-order cone, 0 for its other entries
+    __device__ __forceinline__ double target(int i) const {
+        if (i < d.q) return 1.0;
+        for (int j = 0; j < d.nsoc; ++j) if (i == soc_start[j]) return 1.0;
+        return 0.0;
+    }
+
+    // ---- cone!(product): s o t ----------------------------------------------------------------------------------------
     __device__ __forceinline__ void cone_product(const double* p) {
-        for (int i = tid; i < d.nc; i += NT) cprod[i] = p[d.os() + i] * p[d.ot() + i];
+        for (int i = tid; i < d.q; i += NT) cprod[i] = p[d.os() + i] * p[d.ot() + i];
+        for (int j = tid; j < d.nsoc; j += NT) {                 // second_order_product (second_order.jl:17)
+            const int st = soc_start[j], dm = soc_dim[j];
+            const double* a = p + d.os() + st; const double* b = p + d.ot() + st;
+            double dot = 0.0;
+            for (int e = 0; e < dm; ++e) dot += a[e] * b[e];
+            cprod[st] = dot;
+            for (int e = 1; e < dm; ++e) cprod[st + e] = a[0] * b[e] + b[0] * a[e];
+        }
         __syncthreads();
     }
 
@@ -208,10 +243,18 @@ struct Ctx {
             out[d.oy() + i] = t2[i] - v[d.orr() + i] + (0.0 - ed) * v[d.oy() + i];
         }
         for (int i = tid; i < d.nc; i += NT) {
-            const double sl = sol[d.os() + i], t = sol[d.ot() + i];
             out[d.os() + i] = (0.0 + ep) * v[d.os() + i] - v[d.oz() + i] - v[d.ot() + i];
             out[d.oz() + i] = t2[d.ne + i] - v[d.os() + i] + (0.0 - ed) * v[d.oz() + i];
-            out[d.ot() + i] = t * v[d.os() + i] + (sl - ed) * v[d.ot() + i];
+            if (i < d.q) { const double sl = sol[d.os() + i], t = sol[d.ot() + i]; out[d.ot() + i] = t * v[d.os() + i] + (sl - ed) * v[d.ot() + i]; }
+        }
+        for (int j = tid; j < d.nsoc; j += NT) {                 // arrow(t) v_s + (arrow(s) - ed I) v_t
+            const int st = soc_start[j], dm = soc_dim[j];
+            const double* sl = sol + d.os() + st; const double* t = sol + d.ot() + st;
+            const double* vs = v + d.os() + st; const double* vt = v + d.ot() + st;
+            double acc = t[0] * vs[0] + (sl[0] - ed) * vt[0];
+            for (int e = 1; e < dm; ++e) acc += t[e] * vs[e] + sl[e] * vt[e];
+            out[d.ot() + st] = acc;
+            for (int e = 1; e < dm; ++e) out[d.ot() + st + e] = (t[e] * vs[0] + sl[e] * vt[0]) + (t[0] * vs[e] + (sl[0] - ed) * vt[e]);
         }
         __syncthreads();
     }
@@ -263,12 +306,49 @@ struct Ctx {
         if (d.ne > 0) { if (kyy > 0.0) pos += d.ne; else nonpos += d.ne; if (kyy == 0.0) zero += d.ne; }
         // nonnegative entries: K_zz = -Sb / (T + Sb P) + D with Sb = s - ed, T = t, P = ep, D = -ed   (residual_jacobian_variables.jl:139-143)
         double cnt[3] = {0.0, 0.0, 0.0};
-        for (int i = tid; i < d.nc; i += NT) {
+        for (int i = tid; i < d.q; i += NT) {
             const double Sb = sol[d.os() + i] - ed, T = sol[d.ot() + i];
             const double kz = -1.0 * Sb / (T + Sb * ep) + (0.0 - ed);
             wz[i] = -1.0 / kz;
             if (kz > 0.0) cnt[0] += 1.0; else cnt[1] += 1.0;
             if (kz == 0.0) cnt[2] += 1.0;
+        }
+        // second-order cones (residual_jacobian_variables.jl:145-164): the block  B = -(Cs + Cbar_t P)^-1 Cbar_t + D  column by column through the closed-form arrow
+        // inverse (quirk: second_order_matrix_inverse uses only the FIRST ROW of its matrix, second_order.jl:63-65), then what a factorisation of triu(K) sees — the upper
+        // triangle mirrored —, its LDL^T in the natural order (the pivots count towards the inertia) and Omega = -B_sym^-1.  One thread per cone.
+        for (int j = tid; j < d.nsoc; j += NT) {
+            const int st = soc_start[j], dm = soc_dim[j];
+            double* B = bsoc + soc_woff[j]; double* W = wsoc + soc_woff[j];
+            double* u = vsoc + 4 * d.maxd * j; double* col = u + d.maxd; double* o = col + d.maxd; double* dg = o + d.maxd;
+            const double* sl = sol + d.os() + st; const double* t = sol + d.ot() + st;
+            for (int b = 0; b < dm; ++b) u[b] = t[b] + (sl[b] - (b == 0 ? ed : 0.0)) * ep;
+            for (int i = 0; i < dm; ++i) {
+                for (int a = 0; a < dm; ++a) col[a] = (a == i ? sl[0] - ed : 0.0) + ((i == 0 && a > 0) ? sl[a] : 0.0) + ((a == 0 && i > 0) ? sl[i] : 0.0);      // column i of arrow(s) - ed I
+                arrow_inverse(dm, u, col, o);
+                for (int a = 0; a < dm; ++a) B[a + i * dm] = -o[a] + (a == i ? (0.0 - ed) : 0.0);
+            }
+            for (int a = 0; a < dm; ++a) for (int b = 0; b < a; ++b) B[a + b * dm] = B[b + a * dm];      // triu mirrored
+            // LDL^T of B_sym in place (unit lower in the strict lower triangle, pivots in dg)
+            for (int k = 0; k < dm; ++k) {
+                double dk = B[k + k * dm];
+                for (int p2 = 0; p2 < k; ++p2) dk -= B[k + p2 * dm] * B[k + p2 * dm] * dg[p2];
+                dg[k] = dk;
+                if (dk > 0.0) cnt[0] += 1.0; else cnt[1] += 1.0;
+                if (dk == 0.0) cnt[2] += 1.0;
+                for (int i = k + 1; i < dm; ++i) {
+                    double v = B[i + k * dm];
+                    for (int p2 = 0; p2 < k; ++p2) v -= B[i + p2 * dm] * B[k + p2 * dm] * dg[p2];
+                    B[i + k * dm] = v / dk;
+                }
+            }
+            // Omega = -(L D L')^-1, column by column
+            for (int c0 = 0; c0 < dm; ++c0) {
+                for (int a = 0; a < dm; ++a) col[a] = a == c0 ? 1.0 : 0.0;
+                for (int k = 0; k < dm; ++k) for (int i = k + 1; i < dm; ++i) col[i] -= B[i + k * dm] * col[k];
+                for (int k = 0; k < dm; ++k) col[k] /= dg[k];
+                for (int k = dm - 1; k >= 0; --k) for (int i = 0; i < k; ++i) col[i] -= B[k + i * dm] * col[k];
+                for (int a = 0; a < dm; ++a) W[a + c0 * dm] = -col[a];
+            }
         }
         block_sum(cnt, red);         // (also the barrier behind wz)
         pos += (int)cnt[0]; nonpos += (int)cnt[1]; zero += (int)cnt[2];
@@ -283,7 +363,16 @@ struct Ctx {
             double a = 0.0;
             const double* zi = Z + i * d.ldz; const double* zj = Z + j * d.ldz;
             for (int k = 0; k < d.ne; ++k) a += zi[k] * omega_y * zj[k];
-            for (int k = 0; k < d.nc; ++k) a += zi[d.ne + k] * wz[k] * zj[d.ne + k];
+            for (int k = 0; k < d.q; ++k) a += zi[d.ne + k] * wz[k] * zj[d.ne + k];
+            for (int c0 = 0; c0 < d.nsoc; ++c0) {
+                const int st = d.ne + soc_start[c0], dm = soc_dim[c0];
+                const double* W = wsoc + soc_woff[c0];
+                for (int b = 0; b < dm; ++b) {
+                    double wv = 0.0;
+                    for (int a2 = 0; a2 < dm; ++a2) wv += zi[st + a2] * W[a2 + b * dm];
+                    a += wv * zj[st + b];
+                }
+            }
             double v = Lxx[j + i * d.lds] + a;
             if (i == j) v += ep;
             S[i + j * d.lds] = v;
@@ -400,10 +489,26 @@ struct Ctx {
         const double hrr = rho + ep;
         for (int i = tid; i < d.nx; i += NT) rsym[i] = r[i];
         for (int i = tid; i < d.ne; i += NT) { const double v = r[d.oy() + i] + r[d.orr() + i] / hrr; rsym[d.nx + i] = v; t1[i] = omega_y * v; }
-        for (int i = tid; i < d.nc; i += NT) {
+        for (int i = tid; i < d.q; i += NT) {
             const double Sb = sol[d.os() + i] - ed, T = sol[d.ot() + i];
             const double v = r[d.oz() + i] + (r[d.ot() + i] + Sb * r[d.os() + i]) / (T + Sb * ep);
             rsym[d.nx + d.ne + i] = v; t1[d.ne + i] = wz[i] * v;
+        }
+        for (int j = tid; j < d.nsoc; j += NT) {                 // residual.jl:84-99: b_z += (Cs + Cbar_t P)^-1 (r_t + Cbar_t r_s), then Omega b_z of the cone
+            const int st = soc_start[j], dm = soc_dim[j];
+            double* u = vsoc + 4 * d.maxd * j; double* v = u + d.maxd; double* o = v + d.maxd;
+            const double* sl = sol + d.os() + st; const double* t = sol + d.ot() + st;
+            const double* rs = r + d.os() + st; const double* rt = r + d.ot() + st;
+            for (int b = 0; b < dm; ++b) u[b] = t[b] + (sl[b] - (b == 0 ? ed : 0.0)) * ep;
+            double acc = (sl[0] - ed) * rs[0];
+            for (int e = 1; e < dm; ++e) acc += sl[e] * rs[e];
+            v[0] = acc + rt[0];
+            for (int e = 1; e < dm; ++e) v[e] = (sl[e] * rs[0] + (sl[0] - ed) * rs[e]) + rt[e];
+            arrow_inverse(dm, u, v, o);
+            double* bz = rsym + d.nx + d.ne + st;
+            for (int e = 0; e < dm; ++e) bz[e] = r[d.oz() + st + e] + o[e];
+            const double* W = wsoc + soc_woff[j];
+            for (int a2 = 0; a2 < dm; ++a2) { double wv = 0.0; for (int b = 0; b < dm; ++b) wv += W[a2 + b * dm] * bz[b]; t1[d.ne + st + a2] = wv; }
         }
         __syncthreads();
         mv_t(Z, d.ldz, d.m, d.nx, t1, xb, rsym);                 // b_x + [A; -G]' (Omega b_m)
@@ -417,13 +522,37 @@ struct Ctx {
             out[d.oy() + i] = dy;
             out[d.orr() + i] = (r[d.orr() + i] + dy) / hrr;
         }
-        for (int i = tid; i < d.nc; i += NT) {
+        for (int i = tid; i < d.q; i += NT) {
             const double dz = -wz[i] * (rsym[d.nx + d.ne + i] - t2[d.ne + i]);
             const double Sb = sol[d.os() + i] - ed, T = sol[d.ot() + i];
             const double ds = (r[d.ot() + i] + Sb * (r[d.os() + i] + dz)) / (T + Sb * ep);
             out[d.oz() + i] = dz;
             out[d.os() + i] = ds;
             out[d.ot() + i] = (r[d.ot() + i] - T * ds) / Sb;
+        }
+        for (int j = tid; j < d.nsoc; j += NT) {                 // search_direction.jl:80-101 for a second-order cone
+            const int st = soc_start[j], dm = soc_dim[j];
+            double* u = vsoc + 4 * d.maxd * j; double* v = u + d.maxd; double* o = v + d.maxd; double* ct = o + d.maxd;
+            const double* sl = sol + d.os() + st; const double* t = sol + d.ot() + st;
+            const double* rs = r + d.os() + st; const double* rt = r + d.ot() + st;
+            const double* W = wsoc + soc_woff[j];
+            const double* bz = rsym + d.nx + d.ne + st;
+            double* dz = out + d.oz() + st; double* ds = out + d.os() + st; double* dt = out + d.ot() + st;
+            for (int a2 = 0; a2 < dm; ++a2) { double wv = 0.0; for (int b = 0; b < dm; ++b) wv += W[a2 + b * dm] * (bz[b] - t2[d.ne + st + b]); dz[a2] = -wv; }
+            for (int b = 0; b < dm; ++b) u[b] = t[b] + (sl[b] - (b == 0 ? ed : 0.0)) * ep;
+            double acc = (sl[0] - ed) * (rs[0] + dz[0]);
+            for (int e = 1; e < dm; ++e) acc += sl[e] * (rs[e] + dz[e]);
+            v[0] = rt[0] + acc;
+            for (int e = 1; e < dm; ++e) v[e] = rt[e] + (sl[e] * (rs[0] + dz[0]) + (sl[0] - ed) * (rs[e] + dz[e]));
+            arrow_inverse(dm, u, v, o);
+            for (int e = 0; e < dm; ++e) ds[e] = o[e];
+            for (int b = 0; b < dm; ++b) ct[b] = sl[b] - (b == 0 ? ed : 0.0);          // first row of Cbar_t = arrow(s) - ed I
+            double a0 = t[0] * ds[0];
+            for (int e = 1; e < dm; ++e) a0 += t[e] * ds[e];
+            v[0] = rt[0] - a0;
+            for (int e = 1; e < dm; ++e) v[e] = rt[e] - (t[e] * ds[0] + t[0] * ds[e]);
+            arrow_inverse(dm, ct, v, o);
+            for (int e = 0; e < dm; ++e) dt[e] = o[e];
         }
         __syncthreads();
     }
@@ -495,7 +624,18 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
     // :100-104 gradients, :106-109 barrier + barrier gradient
     c.eval_gradients(sol);
     double s4[4] = {0.0, 0.0, 0.0, 0.0};      // Phi, lambda'r, r'r, -
-    for (int i = tid; i < d.nc; i += NT) { const double sl = sol[d.os() + i]; s4[0] += log(sl); c.bgrad[i] = 1.0 / sl; }
+    for (int i = tid; i < d.q; i += NT) { const double sl = sol[d.os() + i]; s4[0] += log(sl); c.bgrad[i] = 1.0 / sl; }
+    for (int j = tid; j < d.nsoc; j += NT) {                     // second_order.jl:13-14
+        const int st = c.soc_start[j], dm = c.soc_dim[j];
+        const double* sl = sol + d.os() + st;
+        double dd2 = 0.0;
+        for (int e = 1; e < dm; ++e) dd2 += sl[e] * sl[e];
+        const double det = sl[0] * sl[0] - dd2;
+        s4[0] += 0.5 * log(det);
+        const double sc = 1.0 / det;
+        c.bgrad[st] = sc * sl[0];
+        for (int e = 1; e < dm; ++e) c.bgrad[st + e] = sc * (-sl[e]);
+    }
     for (int i = tid; i < d.ne; i += NT) { const double r = sol[d.orr() + i]; s4[1] += c.lam[i] * r; s4[2] += r * r; }
     block_sum(s4, c.red);
     const double M = c.fcur + (s4[1] + 0.5 * c.rho * s4[2]) - c.kappa * s4[0];                                               // :112-116 merit.jl:2-15
@@ -512,7 +652,7 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
     for (int i = tid; i < d.nc; i += NT) {
         res[d.os() + i] = -sol[d.oz() + i] - sol[d.ot() + i];
         res[d.oz() + i] = c.gh[d.ne + i] - sol[d.os() + i];
-        res[d.ot() + i] = c.cprod[i] - c.kappa * 1.0;
+        res[d.ot() + i] = c.cprod[i] - c.kappa * c.target(i);
     }
     __syncthreads();
     // :130-135, :170-172 norms
@@ -592,7 +732,14 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
             int it = 0;
             for (;;) {
                 double v[1] = {0.0};
-                for (int i = tid; i < d.nc; i += NT) if (sol[off + i] - a * step[off + i] <= omt * sol[off + i]) v[0] = 1.0;      // nonnegative.jl:29-34
+                for (int i = tid; i < d.q; i += NT) if (sol[off + i] - a * step[off + i] <= omt * sol[off + i]) v[0] = 1.0;      // nonnegative.jl:29-34
+                for (int j = tid; j < d.nsoc; j += NT) {                                                                              // second_order.jl:45-47
+                    const int st = c.soc_start[j], dm = c.soc_dim[j];
+                    const double* x = sol + off + st; const double* dx = step + off + st;
+                    double nrm = 0.0;
+                    for (int e = 1; e < dm; ++e) { const double df = (x[e] - a * dx[e]) - omt * x[e]; nrm += df * df; }
+                    if ((x[0] - a * dx[0]) - omt * x[0] <= sqrt(nrm)) v[0] = 1.0;
+                }
                 block_max(v, c.red);
                 if (v[0] == 0.0) break;
                 a = o.scaling_line_search * a;
@@ -616,7 +763,14 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
         c.fcand = c.eval_objective(cand);
         c.eval_constraints(cand, c.ghc);
         double v[4] = {0.0, 0.0, 0.0, 0.0};      // Phi, lambda'r, r'r, theta numerator
-        for (int i = tid; i < d.nc; i += NT) { const double sl = cand[d.os() + i]; v[0] += log(sl); v[3] += fabs(c.ghc[d.ne + i] - sl); }
+        for (int i = tid; i < d.nc; i += NT) { const double sl = cand[d.os() + i]; if (i < d.q) v[0] += log(sl); v[3] += fabs(c.ghc[d.ne + i] - sl); }
+        for (int j = tid; j < d.nsoc; j += NT) {
+            const int st = c.soc_start[j], dm = c.soc_dim[j];
+            const double* sl = cand + d.os() + st;
+            double dd2 = 0.0;
+            for (int e = 1; e < dm; ++e) dd2 += sl[e] * sl[e];
+            v[0] += 0.5 * log(sl[0] * sl[0] - dd2);
+        }
         for (int i = tid; i < d.ne; i += NT) { const double r = cand[d.orr() + i]; v[1] += lam[i] * r; v[2] += r * r; v[3] += fabs(c.ghc[i] - r); }
         block_sum(v, c.red);
         Mh = c.fcand + (v[1] + 0.5 * c.rho * v[2]) - c.kappa * v[0];
@@ -671,7 +825,8 @@ __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
     c.d = d; c.o = &a.o; c.tid = tid;
     c.Lxx = sm + L.Lxx; c.Z = sm + L.Z; c.S = sm + L.S; c.q = sm + L.q; c.bh = sm + L.bh; c.lam = sm + L.lam; c.sol = sm + L.sol; c.cand = sm + L.cand; c.step = sm + L.step;
     c.res = sm + L.res; c.rerr = sm + L.rerr; c.corr = sm + L.corr; c.tmpN = sm + L.tmpN; c.rsym = sm + L.rsym; c.mgrad = sm + L.mgrad;
-    c.fx = sm + L.fx; c.gzx = sm + L.gzx; c.gh = sm + L.gh; c.ghc = sm + L.ghc; c.cprod = sm + L.cprod; c.bgrad = sm + L.bgrad; c.wz = sm + L.wz;
+    c.fx = sm + L.fx; c.gzx = sm + L.gzx; c.gh = sm + L.gh; c.ghc = sm + L.ghc; c.cprod = sm + L.cprod; c.bgrad = sm + L.bgrad; c.wz = sm + L.wz; c.wsoc = sm + L.wsoc; c.bsoc = sm + L.bsoc; c.vsoc = sm + L.vsoc;
+    c.soc_start = a.soc_start; c.soc_dim = a.soc_dim; c.soc_woff = a.soc_woff;
     c.D = sm + L.D; c.Dinv = sm + L.Dinv; c.xb = sm + L.xb; c.t1 = sm + L.t1; c.t2 = sm + L.t2; c.ycol = sm + L.ycol; c.red = sm + L.red;
     c.mf = (int)a.o.max_filter;
     const long long mf_ = c.mf;
@@ -714,7 +869,7 @@ __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
         if (o.warmstart == 0.0) {                                                                            // initialize_slacks! / initialize_duals!  initialize.jl:15-36
             c.eval_constraints(c.sol, c.gh);
             for (int i = tid; i < d.ne; i += NT) { c.sol[d.orr() + i] = c.gh[i]; c.sol[d.oy() + i] = 0.0; }
-            for (int i = tid; i < d.nc; i += NT) { c.sol[d.os() + i] = 1.0; c.sol[d.oz() + i] = 0.0; c.sol[d.ot() + i] = 1.0; }
+            for (int i = tid; i < d.nc; i += NT) { const double v0 = c.target(i) != 0.0 ? 1.0 : 0.1; c.sol[d.os() + i] = v0; c.sol[d.oz() + i] = 0.0; c.sol[d.ot() + i] = v0; }      // nonnegative.jl:2-8, second_order.jl:2-10
             __syncthreads();
         }
         c.kappa = o.central_path_initial; c.tau = fmax(0.99, 1.0 - c.kappa);                                 // initialize.jl:38-42
@@ -812,6 +967,7 @@ thread_local std::string g_sn_err;
 Dm dims_of(const SN* s) {
     Dm d; d.nx = s->nx; d.ne = s->ne; d.nc = s->nc; d.m = s->ne + s->nc; d.n = s->nx + d.m; d.N = s->nx + 2 * s->ne + 3 * s->nc;
     d.ldz = (d.m > 0 ? d.m : 1) | 1; d.lds = s->nx | 1;
+    d.q = s->nq; d.nsoc = (int)s->soc_dim.size(); d.wsz = s->wsz; d.maxd = s->maxd;
     return d;
 }
 
@@ -825,6 +981,7 @@ int launch(SN* s, int mode, int count, int advance) {
     a.sP = s->shared_qp ? 0 : (long long)(nx * nx); a.sq = s->shared_qp ? 0 : (long long)nx; a.sZ = s->shared_qp ? 0 : (long long)(std::max<size_t>(m, 1) * nx);
     a.sbh = s->shared_qp ? 0 : (long long)std::max<size_t>(m, 1);
     a.w = s->w; a.lam = s->lam; a.sc = s->sc; a.filt = s->filt; a.info = s->info; a.trace = s->trace; a.prof = s->prof; a.cnt = s->cnt; a.status = s->status;
+    { const int ns = (int)s->soc_dim.size(); a.soc_start = s->d_soc; a.soc_dim = s->d_soc ? s->d_soc + ns : nullptr; a.soc_woff = s->d_soc ? s->d_soc + 2 * ns : nullptr; }
     a.batch = s->batch; a.mode = mode; a.count = count; a.advance = advance; a.trace_rows = s->trace_rows;
     static_assert(sizeof(Args) <= 3800, "kernel arguments");
     SK(hipEventRecord(s->ev0, s->stream));
@@ -852,6 +1009,7 @@ int32_t calipso_hip_smallnewton_create(int64_t nx, int64_t ne, int64_t nc, int64
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { g_sn_err = "no HIP device available (libcalipso_hip has no CPU path)"; return CALIPSO_ERR_HIP; }
     SN* s = new SN();
     s->nx = (int)nx; s->ne = (int)ne; s->nc = (int)nc; s->batch = (int)batch; s->device = device;
+    s->nq = (int)nc;                                  // all cone entries nonnegative until calipso_hip_smallnewton_set_cones says otherwise
     *out = s;
     const Dm d = dims_of(s);
     s->lds_bytes = sizeof(double) * (size_t)layout(d).total;
@@ -881,11 +1039,38 @@ int32_t calipso_hip_smallnewton_destroy(calipso_hip_smallnewton* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (double* p : {s->P, s->q, s->Z, s->bh, s->w, s->lam, s->sc, s->filt, s->info, s->trace, s->prof}) if (p) (void)hipFree(p);
     if (s->cnt) (void)hipFree(s->cnt);
+    if (s->d_soc) (void)hipFree(s->d_soc);
     if (s->status) (void)hipFree(s->status);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+    return CALIPSO_OK;
+}
+
+// The cone layout (indices.jl:45-63 in the only arrangement the reference is self-consistent for): the first n_nonnegative cone entries are nonnegative,
+// the rest are n_soc second-order cones of the given dimensions, one after the other.  Dimensions 2 .. 16 (one thread per cone forms its d x d block: wider cones belong to
+// the general path); n_nonnegative + sum(dims) must be nc.
+int32_t calipso_hip_smallnewton_set_cones(calipso_hip_smallnewton* s, int64_t n_nonnegative, int64_t n_soc, const int64_t* dims) {
+    if (!s || n_nonnegative < 0 || n_soc < 0 || (n_soc > 0 && !dims)) return CALIPSO_ERR_ARGUMENT;
+    long long total = n_nonnegative;
+    for (int64_t j = 0; j < n_soc; ++j) { if (dims[j] < 2 || dims[j] > 16) return fail(s, CALIPSO_ERR_ARGUMENT, "calipso_hip_smallnewton_set_cones: second-order cones of dimension 2 .. 16"); total += dims[j]; }
+    if (total != s->nc) return fail(s, CALIPSO_ERR_LAYOUT, "calipso_hip_smallnewton_set_cones: n_nonnegative + sum(dims) must equal nc");
+    SK(hipSetDevice(s->device));
+    s->nq = (int)n_nonnegative;
+    s->soc_start.clear(); s->soc_dim.clear(); s->soc_woff.clear(); s->wsz = 0; s->maxd = 0;
+    int at = s->nq;
+    for (int64_t j = 0; j < n_soc; ++j) { s->soc_start.push_back(at); s->soc_dim.push_back((int)dims[j]); s->soc_woff.push_back(s->wsz); at += (int)dims[j]; s->wsz += (int)(dims[j] * dims[j]); s->maxd = std::max(s->maxd, (int)dims[j]); }
+    if (s->d_soc) { (void)hipFree(s->d_soc); s->d_soc = nullptr; }
+    if (n_soc > 0) {
+        std::vector<int> h;
+        h.insert(h.end(), s->soc_start.begin(), s->soc_start.end()); h.insert(h.end(), s->soc_dim.begin(), s->soc_dim.end()); h.insert(h.end(), s->soc_woff.begin(), s->soc_woff.end());
+        SK(hipMalloc((void**)&s->d_soc, sizeof(int) * h.size()));
+        SK(hipMemcpy(s->d_soc, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+    }
+    s->lds_bytes = sizeof(double) * (size_t)layout(dims_of(s)).total;
+    if (s->lds_bytes > 160 * 1024) return fail(s, CALIPSO_ERR_ARGUMENT, "calipso_hip_smallnewton_set_cones: the problem no longer fits the 160 KB of LDS of a compute unit");
+    if (s->lds_bytes > 64 * 1024) (void)calipso::lds_attribute((const void*)k_smallnewton, 160 * 1024);
     return CALIPSO_OK;
 }
 

@@ -430,7 +430,7 @@ int32_t calipso_hip_small_get(calipso_hip_small*, double* X, int64_t* inertia);
  * for the general path to be anything but launch latency (the MPC problems of examples/autotuning/cartpole.jl:179-227: n = 89): one workgroup per instance, problem
  * data, iterates and the factor in the compute unit's LDS, every decision of solve.jl:98-368 (exit tests, inertia_correction!, iterative_refinement!, cone search,
  * filter line search, outer updates) on the device, ONE launch per call.  Evaluator: the QP of calipso_hip_qp_attach (min c x'Px + q'x s.t. Ax = b, h - Gx >= 0) with
- * nonnegative cones only; residual_norm = constraint_norm = 1.  Points have the layout of point.jl:13-22 (N = nx + 2 ne + 3 nc).  Limits: nx <= 128 and the
+ * nonnegative and second-order cones (dimension <= 16; wider: the general path); residual_norm = constraint_norm = 1.  Points have the layout of point.jl:13-22 (N = nx + 2 ne + 3 nc).  Limits: nx <= 128 and the
  * instance must fit 160 KB of LDS (n up to ~200), else CALIPSO_ERR_ARGUMENT at create: the general path (calipso_hip_create + groups) takes those.
  *   create(nx, ne, nc, batch, device)        set_option(name, value): options.jl:6-59 by name
  *   set_qp(P, q, A, b, G, h, c, shared)      column-major host arrays, batch-major (instance k at k * size) or ONE problem for all (shared != 0)
@@ -446,6 +446,8 @@ int32_t calipso_hip_smallnewton_create(int64_t nx, int64_t ne, int64_t nc, int64
 int32_t calipso_hip_smallnewton_destroy(calipso_hip_smallnewton*);
 const char* calipso_hip_smallnewton_last_error(calipso_hip_smallnewton*);
 int32_t calipso_hip_smallnewton_set_option(calipso_hip_smallnewton*, const char* name, double value);
+/* cone layout (indices.jl:45-63): the first n_nonnegative cone entries nonnegative (default: all nc), then n_soc second-order cones of dims[j] (2 .. 16) entries each, contiguous */
+int32_t calipso_hip_smallnewton_set_cones(calipso_hip_smallnewton*, int64_t n_nonnegative, int64_t n_soc, const int64_t* dims);
 int32_t calipso_hip_smallnewton_set_qp(calipso_hip_smallnewton*, const double* P, const double* q, const double* A, const double* b, const double* G, const double* h,
                                        double objective_scale, int32_t shared);
 int32_t calipso_hip_smallnewton_set_state(calipso_hip_smallnewton*, const double* w, const double* lambda, const double* scalars);

@@ -53,6 +53,50 @@ def test_batched_solve_matches_the_oracle_per_accepted_iterate(oracle_mod, shape
     sn.close()
 
 
+@pytest.mark.parametrize("layout", [(12, 4, 4, (3, 3)), (20, 8, 0, (4, 3, 3)), (16, 5, 6, (5,)), (30, 10, 3, (3, 3, 3, 3)), (10, 3, 8, (3,)), (14, 6, 10, (4,))])
+def test_batched_solve_with_second_order_cones_matches_the_oracle(oracle_mod, layout):
+    """nonnegative entries followed by second-order cones (the friction-cone / portfolio shapes of the reference's tests): the arrow blocks, the closed-form inverses of
+    cones/second_order.jl:50-65 with their first-row quirk, the triu-symmetrised cone block (which makes the first solve inexact: refinement rounds > 1) — per accepted
+    iterate against the oracle, 1e-8"""
+    pkg = load_pkg()
+    nx, ne, q, dims = layout
+    nc = q + sum(dims)
+    soc, at = [], q + 1
+    for dm in dims:
+        soc.append(list(range(at, at + dm))); at += dm
+    probs = [pr.random_qp(nx, ne, nc, seed=500 + k, nonnegative_indices=list(range(1, q + 1)), second_order_indices=soc) for k in range(5)]
+    p0 = probs[0]
+    sn = pkg.SmallNewtonBatch(nx, ne, nc, len(probs))
+    sn.set_cones(q, dims)
+    st_ = lambda name: np.stack([np.asarray(getattr(p, name), dtype=np.float64) for p in probs])
+    sn.set_qp(st_("P"), st_("q"), st_("A"), st_("b"), st_("G"), st_("h"), objective_scale=p0.c, shared=False)
+    sn.initialize(np.stack([p.x0 for p in probs]))
+    sn.keep_trace(96)
+    res, _ = sn.solve()
+    st = sn.get_state()
+    tr = sn.trace()
+    rounds_seen, compared = 0, 0
+    for k, prob in enumerate(probs):
+        o, status = run_oracle(oracle_mod, prob)
+        os_ = o.stats()
+        if os_["lu_fallbacks"] > 0:                       # the reference fell back to H \ residual: this path stops there and says so
+            assert res[k] == -102, (k, res[k])
+            continue
+        assert status == int(res[k]) == 1, (k, status, res[k])
+        compared += 1
+        assert st["counters"]["total_iterations"][k] == os_["total_iterations"] and st["counters"]["outer"][k] == os_["outer"]
+        assert st["counters"]["max_refinement_rounds"][k] == os_["max_refinement_rounds"]
+        rounds_seen = max(rounds_seen, int(os_["max_refinement_rounds"]))
+        ot = o.trace()
+        rows = int(st["counters"]["accepted_iterates"][k])
+        assert rows == ot.shape[0]
+        for r in range(min(rows, 96)):
+            assert rel(tr[k, r], ot[r]) <= 1e-8, (k, r, rel(tr[k, r], ot[r]))
+        assert rel(st["solution"][k], o.point()["all"]) <= 1e-8
+    assert compared == 0 or rounds_seen >= 2              # the triu-symmetrised cone blocks do make refinement work (cold-started cone problems often end in the reference's fallback: compared == 0)
+    sn.close()
+
+
 def test_batched_solve_agrees_with_the_general_device_path():
     """the same problems through calipso_hip_solve (one handle each, attached QP evaluator): same iteration counts, solutions to 1e-8"""
     pkg = load_pkg()
