@@ -171,7 +171,7 @@ __device__ __forceinline__ double recip(double d) {
     return d == 0.0 ? r0 : r;
 }
 
-struct Ctx {
+template <bool SOC> struct CtxT {
     Dm d; const Options* o;
     double *Lxx, *Z, *S, *q, *bh, *lam, *sol, *cand, *step, *res, *rerr, *corr, *tmpN, *rsym, *mgrad, *fx, *gzx, *gh, *ghc, *cprod, *bgrad, *wz, *wsoc, *bsoc, *vsoc, *D, *Dinv, *xb, *t1, *t2, *ycol, *red;
     const int *soc_start, *soc_dim, *soc_woff;
@@ -209,14 +209,14 @@ struct Ctx {
     // cone_target (cone.jl:55-59): 1 for nonnegative entries and for the first entry of a second-order cone, 0 for its other entries
     __device__ __forceinline__ double target(int i) const {
         if (i < d.q) return 1.0;
-        for (int j = 0; j < d.nsoc; ++j) if (i == soc_start[j]) return 1.0;
+        for (int j = 0; SOC && j < d.nsoc; ++j) if (i == soc_start[j]) return 1.0;
         return 0.0;
     }
 
     // ---- cone!(product): s o t ----------------------------------------------------------------------------------------
     __device__ __forceinline__ void cone_product(const double* p) {
         for (int i = tid; i < d.q; i += NT) cprod[i] = p[d.os() + i] * p[d.ot() + i];
-        for (int j = tid; j < d.nsoc; j += NT) {                 // second_order_product (second_order.jl:17)
+        for (int j = tid; SOC && j < d.nsoc; j += NT) {                 // second_order_product (second_order.jl:17)
             const int st = soc_start[j], dm = soc_dim[j];
             const double* a = p + d.os() + st; const double* b = p + d.ot() + st;
             double dot = 0.0;
@@ -247,7 +247,7 @@ struct Ctx {
             out[d.oz() + i] = t2[d.ne + i] - v[d.os() + i] + (0.0 - ed) * v[d.oz() + i];
             if (i < d.q) { const double sl = sol[d.os() + i], t = sol[d.ot() + i]; out[d.ot() + i] = t * v[d.os() + i] + (sl - ed) * v[d.ot() + i]; }
         }
-        for (int j = tid; j < d.nsoc; j += NT) {                 // arrow(t) v_s + (arrow(s) - ed I) v_t
+        for (int j = tid; SOC && j < d.nsoc; j += NT) {                 // arrow(t) v_s + (arrow(s) - ed I) v_t
             const int st = soc_start[j], dm = soc_dim[j];
             const double* sl = sol + d.os() + st; const double* t = sol + d.ot() + st;
             const double* vs = v + d.os() + st; const double* vt = v + d.ot() + st;
@@ -316,7 +316,7 @@ struct Ctx {
         // second-order cones (residual_jacobian_variables.jl:145-164): the block  B = -(Cs + Cbar_t P)^-1 Cbar_t + D  column by column through the closed-form arrow
         // inverse (quirk: second_order_matrix_inverse uses only the FIRST ROW of its matrix, second_order.jl:63-65), then what a factorisation of triu(K) sees — the upper
         // triangle mirrored —, its LDL^T in the natural order (the pivots count towards the inertia) and Omega = -B_sym^-1.  One thread per cone.
-        for (int j = tid; j < d.nsoc; j += NT) {
+        for (int j = tid; SOC && j < d.nsoc; j += NT) {
             const int st = soc_start[j], dm = soc_dim[j];
             double* B = bsoc + soc_woff[j]; double* W = wsoc + soc_woff[j];
             double* u = vsoc + 4 * d.maxd * j; double* col = u + d.maxd; double* o = col + d.maxd; double* dg = o + d.maxd;
@@ -364,7 +364,7 @@ struct Ctx {
             const double* zi = Z + i * d.ldz; const double* zj = Z + j * d.ldz;
             for (int k = 0; k < d.ne; ++k) a += zi[k] * omega_y * zj[k];
             for (int k = 0; k < d.q; ++k) a += zi[d.ne + k] * wz[k] * zj[d.ne + k];
-            for (int c0 = 0; c0 < d.nsoc; ++c0) {
+            for (int c0 = 0; SOC && c0 < d.nsoc; ++c0) {
                 const int st = d.ne + soc_start[c0], dm = soc_dim[c0];
                 const double* W = wsoc + soc_woff[c0];
                 for (int b = 0; b < dm; ++b) {
@@ -494,7 +494,7 @@ struct Ctx {
             const double v = r[d.oz() + i] + (r[d.ot() + i] + Sb * r[d.os() + i]) / (T + Sb * ep);
             rsym[d.nx + d.ne + i] = v; t1[d.ne + i] = wz[i] * v;
         }
-        for (int j = tid; j < d.nsoc; j += NT) {                 // residual.jl:84-99: b_z += (Cs + Cbar_t P)^-1 (r_t + Cbar_t r_s), then Omega b_z of the cone
+        for (int j = tid; SOC && j < d.nsoc; j += NT) {                 // residual.jl:84-99: b_z += (Cs + Cbar_t P)^-1 (r_t + Cbar_t r_s), then Omega b_z of the cone
             const int st = soc_start[j], dm = soc_dim[j];
             double* u = vsoc + 4 * d.maxd * j; double* v = u + d.maxd; double* o = v + d.maxd;
             const double* sl = sol + d.os() + st; const double* t = sol + d.ot() + st;
@@ -530,7 +530,7 @@ struct Ctx {
             out[d.os() + i] = ds;
             out[d.ot() + i] = (r[d.ot() + i] - T * ds) / Sb;
         }
-        for (int j = tid; j < d.nsoc; j += NT) {                 // search_direction.jl:80-101 for a second-order cone
+        for (int j = tid; SOC && j < d.nsoc; j += NT) {                 // search_direction.jl:80-101 for a second-order cone
             const int st = soc_start[j], dm = soc_dim[j];
             double* u = vsoc + 4 * d.maxd * j; double* v = u + d.maxd; double* o = v + d.maxd; double* ct = o + d.maxd;
             const double* sl = sol + d.os() + st; const double* t = sol + d.ot() + st;
@@ -616,7 +616,7 @@ __device__ __forceinline__ bool armijo(double m, double mc, double dd, double st
 struct StepOut { int exit_kind = 0; int rc = 0; double step_size = 1.0, step_size_t = 1.0, Mh = 0.0, thetah = 0.0, optimality = 0.0; int rounds = 0; int nfact = 0; };
 
 // one pass of the inner loop body of solve! (solve.jl:98-353); equality_violation / cone_product_violation as the caller holds them (:85-86, :332-333)
-__device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
+template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>& c, bool may_converge) {
     const Dm& d = c.d; const Options& o = *c.o; const int tid = c.tid;
     StepOut out;
     double* sol = c.sol; double* cand = c.cand; double* step = c.step; double* res = c.res;
@@ -625,7 +625,7 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
     c.eval_gradients(sol);
     double s4[4] = {0.0, 0.0, 0.0, 0.0};      // Phi, lambda'r, r'r, -
     for (int i = tid; i < d.q; i += NT) { const double sl = sol[d.os() + i]; s4[0] += log(sl); c.bgrad[i] = 1.0 / sl; }
-    for (int j = tid; j < d.nsoc; j += NT) {                     // second_order.jl:13-14
+    for (int j = tid; SOC && j < d.nsoc; j += NT) {                     // second_order.jl:13-14
         const int st = c.soc_start[j], dm = c.soc_dim[j];
         const double* sl = sol + d.os() + st;
         double dd2 = 0.0;
@@ -733,7 +733,7 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
             for (;;) {
                 double v[1] = {0.0};
                 for (int i = tid; i < d.q; i += NT) if (sol[off + i] - a * step[off + i] <= omt * sol[off + i]) v[0] = 1.0;      // nonnegative.jl:29-34
-                for (int j = tid; j < d.nsoc; j += NT) {                                                                              // second_order.jl:45-47
+                for (int j = tid; SOC && j < d.nsoc; j += NT) {                                                                              // second_order.jl:45-47
                     const int st = c.soc_start[j], dm = c.soc_dim[j];
                     const double* x = sol + off + st; const double* dx = step + off + st;
                     double nrm = 0.0;
@@ -764,7 +764,7 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
         c.eval_constraints(cand, c.ghc);
         double v[4] = {0.0, 0.0, 0.0, 0.0};      // Phi, lambda'r, r'r, theta numerator
         for (int i = tid; i < d.nc; i += NT) { const double sl = cand[d.os() + i]; if (i < d.q) v[0] += log(sl); v[3] += fabs(c.ghc[d.ne + i] - sl); }
-        for (int j = tid; j < d.nsoc; j += NT) {
+        for (int j = tid; SOC && j < d.nsoc; j += NT) {
             const int st = c.soc_start[j], dm = c.soc_dim[j];
             const double* sl = cand + d.os() + st;
             double dd2 = 0.0;
@@ -815,13 +815,13 @@ __device__ __forceinline__ StepOut inner_iteration(Ctx& c, bool may_converge) {
     return out;
 }
 
-__global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
+template <bool SOC> __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int inst = blockIdx.x, tid = threadIdx.x;
     if (inst >= a.batch) return;
     const Dm d = a.d;
     const Lay L = layout(d);
-    Ctx c;
+    CtxT<SOC> c;
     c.d = d; c.o = &a.o; c.tid = tid;
     c.Lxx = sm + L.Lxx; c.Z = sm + L.Z; c.S = sm + L.S; c.q = sm + L.q; c.bh = sm + L.bh; c.lam = sm + L.lam; c.sol = sm + L.sol; c.cand = sm + L.cand; c.step = sm + L.step;
     c.res = sm + L.res; c.rerr = sm + L.rerr; c.corr = sm + L.corr; c.tmpN = sm + L.tmpN; c.rsym = sm + L.rsym; c.mgrad = sm + L.mgrad;
@@ -985,7 +985,8 @@ int launch(SN* s, int mode, int count, int advance) {
     a.batch = s->batch; a.mode = mode; a.count = count; a.advance = advance; a.trace_rows = s->trace_rows;
     static_assert(sizeof(Args) <= 3800, "kernel arguments");
     SK(hipEventRecord(s->ev0, s->stream));
-    hipLaunchKernelGGL(k_smallnewton, dim3((unsigned)s->batch), dim3(NT), s->lds_bytes, s->stream, a);
+    if (s->soc_dim.empty()) hipLaunchKernelGGL(k_smallnewton<false>, dim3((unsigned)s->batch), dim3(NT), s->lds_bytes, s->stream, a);
+    else hipLaunchKernelGGL(k_smallnewton<true>, dim3((unsigned)s->batch), dim3(NT), s->lds_bytes, s->stream, a);
     SK(hipGetLastError());
     SK(hipEventRecord(s->ev1, s->stream));
     SK(hipStreamSynchronize(s->stream));
@@ -1015,7 +1016,7 @@ int32_t calipso_hip_smallnewton_create(int64_t nx, int64_t ne, int64_t nc, int64
     s->lds_bytes = sizeof(double) * (size_t)layout(d).total;
     if (s->lds_bytes > 160 * 1024) return fail(s, CALIPSO_ERR_ARGUMENT, "calipso_hip_smallnewton_create: the problem does not fit the 160 KB of LDS of a compute unit (" + std::to_string(s->lds_bytes) + " bytes): the general path takes it");
     SK(hipSetDevice(device));
-    if (s->lds_bytes > 64 * 1024) (void)calipso::lds_attribute((const void*)k_smallnewton, 160 * 1024);
+    if (s->lds_bytes > 64 * 1024) { (void)calipso::lds_attribute((const void*)k_smallnewton<false>, 160 * 1024); (void)calipso::lds_attribute((const void*)k_smallnewton<true>, 160 * 1024); }
     SK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     SK(hipEventCreate(&s->ev0)); SK(hipEventCreate(&s->ev1));
     const size_t B = (size_t)batch, N = (size_t)d.N;
@@ -1070,7 +1071,7 @@ int32_t calipso_hip_smallnewton_set_cones(calipso_hip_smallnewton* s, int64_t n_
     }
     s->lds_bytes = sizeof(double) * (size_t)layout(dims_of(s)).total;
     if (s->lds_bytes > 160 * 1024) return fail(s, CALIPSO_ERR_ARGUMENT, "calipso_hip_smallnewton_set_cones: the problem no longer fits the 160 KB of LDS of a compute unit");
-    if (s->lds_bytes > 64 * 1024) (void)calipso::lds_attribute((const void*)k_smallnewton, 160 * 1024);
+    if (s->lds_bytes > 64 * 1024) { (void)calipso::lds_attribute((const void*)k_smallnewton<false>, 160 * 1024); (void)calipso::lds_attribute((const void*)k_smallnewton<true>, 160 * 1024); }
     return CALIPSO_OK;
 }
 
