@@ -504,6 +504,10 @@ function HIPSmallNewton(nx::Integer, ne::Integer, nc::Integer, batch::Integer; d
     return s
 end
 sn_check(s::HIPSmallNewton, rc, what) = rc < 0 ? error("$what failed ($rc): " * unsafe_string(ccall((:calipso_hip_smallnewton_last_error, lib), Cstring, (Ptr{Cvoid},), s.handle))) : rc
+"cone layout: the first `n_nonnegative` cone entries nonnegative, then second-order cones of the given dimensions (contiguous; 2 .. 16 entries each)"
+function set_cones!(s::HIPSmallNewton, n_nonnegative::Integer, dims::Vector{Int64}=Int64[])
+    sn_check(s, ccall((:calipso_hip_smallnewton_set_cones, lib), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}), s.handle, n_nonnegative, length(dims), isempty(dims) ? C_NULL : dims), "calipso_hip_smallnewton_set_cones")
+end
 "column-major arrays of ONE problem (shared = true) or stacked along a trailing batch dimension: P (nx, nx[, batch]), A (ne, nx[, batch]), G (nc, nx[, batch])"
 function set_qp!(s::HIPSmallNewton, P, q, A, b, G, h; objective_scale::Float64=0.5, shared::Bool=ndims(P) == 2)
     f(a) = isempty(a) ? zeros(1) : collect(Float64, vec(a))
@@ -571,7 +575,7 @@ function allreduce_sum!(c::HIPComm, v::Vector{Float64})
     return v
 end
 
-export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPSmallNewton, set_qp!, solution, HIPComm, comm_unique_id, comm_size, gather_status, allreduce_sum!, newton_step!,
+export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPSmallNewton, set_cones!, set_qp!, solution, HIPComm, comm_unique_id, comm_size, gather_status, allreduce_sum!, newton_step!,
        search_direction_nonsymmetric!, analyze_structure!, clear_structure!, set_stage_parallel!, set_stage_blocks!, declared_structure, kernel_times, sync_scalars!, copy_back!
 
 end # module
