@@ -825,7 +825,7 @@ def main():
     flops_ldl = nx ** 3 / 3.0
     n_ldl_launch = max(1, NP // 64 - 1)
     pmc = {}
-    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             pmc["_file"] = "profiles/" + name

@@ -144,6 +144,52 @@ def test_one_problem_shared_by_the_batch_and_benchmark_steps():
     sn.close()
 
 
+def test_nonconvex_instances_run_the_regularisation_loop_like_the_oracle(oracle_mod):
+    """P with negative curvature: IC-1 fails its inertia test and inertia_correction! (inertia.jl:30-80) factors again with growing primal regularisation — on the device,
+    per instance (the convex members of the same batch take one factorisation per step): same iterates, iteration counts and final regularisation as the oracle"""
+    pkg = load_pkg()
+    probs = []
+    for k, shift in enumerate((0.0, 3.0, 0.0, 8.0)):
+        p = pr.random_qp(12, 5, 7, seed=700 + k, nonnegative_indices=list(range(1, 8)))
+        p = pr.ConicQP(p.P - shift * np.eye(12), p.q, p.A, p.b, p.G, p.h, nonnegative_indices=p.nonnegative_indices, x0=p.x0, objective_scale=p.c)
+        probs.append(p)
+    sn = make_batch(pkg, probs, max_outer_iterations=6)
+    sn.keep_trace(64)
+    res, _ = sn.solve()
+    st = sn.get_state()
+    tr = sn.trace()
+    facts = []
+    for k, prob in enumerate(probs):
+        o, status = run_oracle(oracle_mod, prob, max_outer_iterations=6)
+        os_ = o.stats()
+        if os_["lu_fallbacks"] > 0:
+            assert res[k] == -102
+            continue
+        assert status == int(res[k]), (k, status, res[k])                      # 1 converged or 0: the iteration caps of a problem that is unbounded below
+        assert st["counters"]["total_iterations"][k] == os_["total_iterations"]
+        ot = o.trace()
+        rows = int(st["counters"]["accepted_iterates"][k])
+        assert rows == ot.shape[0]
+        for r in range(min(rows, 64)):
+            assert rel(tr[k, r], ot[r]) <= 1e-7, (k, r, rel(tr[k, r], ot[r]))
+        assert abs(st["scalars"][k, 4] - o.buf("primal_regularization_last")[0]) <= 1e-12 * max(1.0, abs(o.buf("primal_regularization_last")[0]))
+        facts.append(int(st["counters"]["factorizations"][k]) - int(st["counters"]["newton_steps"][k]))
+    assert max(facts) > 0 and min(facts) == 0                                  # some instances re-factored, the convex ones never
+    sn.close()
+
+
+def test_unconstrained_and_single_instance():
+    pkg = load_pkg()
+    prob = pr.random_qp(15, 0, 0, seed=9, nonnegative_indices=[])
+    sn = make_batch(pkg, [prob])
+    res, _ = sn.solve()
+    assert res[0] == 1
+    x = sn.get_state()["solution"][0, :15]
+    xs = np.linalg.solve(2.0 * prob.c * prob.P, -prob.q)                       # min c x'Px + q'x
+    assert rel(x, xs) <= 1e-4                                                  # (to the solver's tolerances: residual_tolerance 1e-4, primal regularisation 1e-7)
+    sn.close()
+
+
 def test_limits_are_refused():
     pkg = load_pkg()
     with pytest.raises(pkg.CalipsoHipError, match="LDS"):
