@@ -94,6 +94,21 @@ static int g_read_i(G* g, const Set& a, int first, int count) {
     return 0;
 }
 
+// icount[ifirst ..) and dscal[dfirst ..) of every member of `a` with ONE stream synchronisation (two gather launches)
+static int g_read_both(G* g, const Set& a, int ifirst, int icnt, int dfirst, int dcnt) {
+    H* s = g->base;
+    if (launch_errors(s, "a kernel launch of this phase of the group step was refused")) return CALIPSO_ERR_HIP;
+    hipLaunchKernelGGL(k_gather_i, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->icount + ifirst, icnt, g->higather_dev);
+    hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + dfirst, dcnt, g->hgather_dev);
+    SYNC();
+    g->sc_pending = 0;
+    for (size_t k = 0; k < a.size(); ++k) {
+        for (int i = 0; i < icnt; ++i) g->hs[a[k]]->hicount[ifirst + i] = g->higather[k * 64 + i];
+        for (int i = 0; i < dcnt; ++i) g->hs[a[k]]->hscal[dfirst + i] = g->hgather[k * 64 + i];
+    }
+    return 0;
+}
+
 // evaluate! for the members of `a` at their current (which = 0) or candidate (1) point: one batched launch sequence for the members
 // with a device evaluator, the host callback (on the member's own stream, after the group's stream has drained) for the others
 static int gb_evaluate(G* g, const Set& a, int which, uint32_t flags) {
@@ -295,21 +310,22 @@ static int gb_refinement(G* g, const Set& a, std::vector<int>& rc, std::vector<i
 
 static Set alive(const Set& a, const std::vector<int>& rc) { Set r; for (int i : a) if (rc[i] >= 0) r.push_back(i); return r; }
 
-static int gb_candidate_merit(G* g, const Set& a, std::vector<double>& Mh, std::vector<double>& thetah) {
+static int gb_candidate_merit(G* g, const Set& a, std::vector<double>& Mh, std::vector<double>& thetah, bool queue_only = false, int extra = 0) {      // extra: dscal[6] travels along
     H* s = g->base;
     const int e = gb_evaluate(g, a, 1, CALIPSO_EVAL_OBJECTIVE | CALIPSO_EVAL_EQUALITY | CALIPSO_EVAL_CONE);
     if (e < 0) return e;
     launch_cone(s, s->candidate, CALIPSO_CONE_BARRIER | CALIPSO_CONE_BARRIER_GRADIENT);
     launch_merit(s, s->candidate);
     launch_constraint_violation(s, s->candidate);
-    if (g_read_d(g, a, 4, 2)) return CALIPSO_ERR_HIP;
+    if (queue_only) return CALIPSO_OK;
+    if (g_read_d(g, a, 4, 2 + extra)) return CALIPSO_ERR_HIP;
     for (int i : a) { Mh[i] = g->hs[i]->hscal[4]; thetah[i] = g->hs[i]->hscal[5]; }
     return CALIPSO_OK;
 }
 
 // the body of the inner loop of solve! (solve.jl:98-353) for every member of `a0`, device evaluator attached
 static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, std::vector<int>& rc,
-                              const std::vector<double>* eq_violation = nullptr, const std::vector<double>* cp_violation = nullptr) {
+                              const std::vector<double>* eq_violation = nullptr, const std::vector<double>* cp_violation = nullptr, bool read_final = true) {
     H* s = g->base;
     const Dims& d = s->d;
     const size_t B = g->hs.size();
@@ -369,34 +385,54 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
     for (int i : a) { info[i].nfact = nfact[i]; info[i].rounds = rounds[i]; }
     EV(3);
     if (a.empty()) { EV(4); return CALIPSO_OK; }
-    // cone search (:190-221)
+    // cone search (:190-221), first candidate (:206-229) and its merit / violation (:231-250).  When every member evaluates on the device, the three are queued back to
+    // back — the step sizes of the first candidate formed from the search's masks ON THE DEVICE (vectors.hip: k_first_candidate_masks, the host's operations) — and ONE
+    // synchronisation brings the masks and the three scalars of every member (were three synchronisations); the host forms the same step sizes from the same masks.
     std::vector<double> as(B, 1.0), at(B, 1.0), step_size(B, 1.0);
+    std::vector<double> Mh(B, 0.0), thetah(B, 0.0), dd(B, 0.0);
     g_activate(g, a);
-    if (d.nc) {
-        launch_cone_search(s);
-        if (g_read_i(g, a, 6, 58)) return CALIPSO_ERR_HIP;
-        for (int i : a) {
+    bool all_device = d.nc > 0;
+    for (int i : a) all_device = all_device && (g->hs[i]->qp.attached || g->hs[i]->dev_eval || g->hs[i]->dev_block_eval);
+    auto step_sizes_from_masks = [&](const Set& set) {
+        for (int i : set) {
             H* h = g->hs[i]; const Options& o = h->opt;
             const int ks = first_feasible_trial(h->hicount + 6, o.max_cone_line_search), kt = first_feasible_trial(h->hicount + 32, o.max_cone_line_search);
             if (ks < 0 || kt < 0) { h->err = "cone search failure"; rc[i] = CALIPSO_ERR_CONE_SEARCH; continue; }
             for (int k = 0; k < ks; ++k) as[i] = o.scaling_line_search * as[i];
             for (int k = 0; k < kt; ++k) at[i] = o.scaling_line_search * at[i];
         }
+    };
+    if (all_device) {
+        launch_cone_search(s);
+        launch_first_candidate_from_masks(s);
+        e = gb_candidate_merit(g, a, Mh, thetah, true);
+        if (e < 0) return e;
+        if (g_read_both(g, a, 6, 58, 4, 3)) return CALIPSO_ERR_HIP;
+        step_sizes_from_masks(a);
+        for (int i : a) { Mh[i] = g->hs[i]->hscal[4]; thetah[i] = g->hs[i]->hscal[5]; dd[i] = g->hs[i]->hscal[6]; }
         a = alive(a, rc);
         if (a.empty()) { EV(4); return CALIPSO_OK; }
         g_activate(g, a);
+        for (int i : a) { info[i].step_size = as[i]; info[i].step_size_t = at[i]; step_size[i] = as[i]; }
+    } else {
+        if (d.nc) {
+            launch_cone_search(s);
+            if (g_read_i(g, a, 6, 58)) return CALIPSO_ERR_HIP;
+            step_sizes_from_masks(a);
+            a = alive(a, rc);
+            if (a.empty()) { EV(4); return CALIPSO_OK; }
+            g_activate(g, a);
+        }
+        for (int i : a) { info[i].step_size = as[i]; info[i].step_size_t = at[i]; step_size[i] = as[i]; }
+        {   // candidate s, t (:206-218), candidate x, r (:224-229) and the directional derivative of the merit function in one launch (api.hip: inner_iteration)
+            std::vector<double> la, lt;
+            for (int i : a) { la.push_back(as[i]); lt.push_back(at[i]); }
+            launch_first_candidate_batch(s, la.data(), lt.data());
+        }
+        e = gb_candidate_merit(g, a, Mh, thetah, false, 1);                                // :231-250 (+ the directional derivative, dscal[6])
+        if (e < 0) return e;
+        for (int i : a) dd[i] = g->hs[i]->hscal[6];
     }
-    for (int i : a) { info[i].step_size = as[i]; info[i].step_size_t = at[i]; step_size[i] = as[i]; }
-    {   // candidate s, t (:206-218), candidate x, r (:224-229) and the directional derivative of the merit function in one launch (api.hip: inner_iteration)
-        std::vector<double> la, lt;
-        for (int i : a) { la.push_back(as[i]); lt.push_back(at[i]); }
-        launch_first_candidate_batch(s, la.data(), lt.data());
-    }
-    std::vector<double> Mh(B, 0.0), thetah(B, 0.0), dd(B, 0.0);
-    e = gb_candidate_merit(g, a, Mh, thetah);                                            // :231-250
-    if (e < 0) return e;
-    if (g_read_d(g, a, 6, 1)) return CALIPSO_ERR_HIP;
-    for (int i : a) dd[i] = g->hs[i]->hscal[6];
     // residual line search (:254-302): the members still back-tracking form the next launch's instance list
     std::vector<calipso::i64> ls_it(B, 0);
     Set run = a;
@@ -442,7 +478,8 @@ static int gb_inner_iteration(G* g, const Set& a0, std::vector<IterInfo>& info, 
     }
     launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT);                                     // :328-330
     launch_violations(s);                                                                  // :332-333
-    if (g_read_d(g, a, 16, 2)) return CALIPSO_ERR_HIP;
+    // (read_final = false: a benchmark step — nobody reads the two norms; the kernel computes them all the same and the caller's synchronisation is behind it)
+    if (read_final && g_read_d(g, a, 16, 2)) return CALIPSO_ERR_HIP;
     EV(4);
     return CALIPSO_OK;
 }
@@ -569,7 +606,7 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
     std::vector<IterInfo> info(B);
     std::vector<int> rc(B, 0);
     EV(8);
-    int e = gb_inner_iteration(g, all, info, rc);
+    int e = gb_inner_iteration(g, all, info, rc, nullptr, nullptr, false);
     EV(9);
     if (e < 0) return e;
     if (!advance) {
