@@ -27,3 +27,8 @@ timeout 200 python bench/wide_fronts.py 4000 2 1 >> $O/wide_fronts.txt 2>&1
 f=$(find $O/stats_wf -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_wide_fronts.csv; rm -rf $O/stats_wf
 hipcc -O3 --offload-arch=gfx950 bench/diag_bench3.hip -o /tmp/d3 2>/dev/null && timeout 60 /tmp/d3 > $O/diag_bench3.txt
 ls -la $O | head -60
+# round 6: the small-problem kernel (rates, phase clocks), what overlaps on this chip (probes), the 256-thread Schur viability probe
+for a in "49 40 0 4096 20" "49 40 20 4096 10" "24 12 24 8192 20"; do timeout 200 python bench/small_newton_rate.py $a 2>/dev/null | tail -1 > $O/small_newton_rate_$(echo $a | tr ' ' '_').json; done
+bash bench/small_newton_phases.sh 2>&1 | tail -14 > $O/small_newton_phases.txt
+for p in overlap_probe overlap_probe2 overlap_probe3 overlap_probe4 schur64_probe; do hipcc --offload-arch=gfx950 -O3 bench/$p.hip -o /tmp/$p 2>/dev/null && timeout 120 /tmp/$p > $O/$p.txt 2>&1; done
+ls -la $O | wc -l

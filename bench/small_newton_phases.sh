@@ -2,7 +2,7 @@
 # phase clocks of one instance of the batched small-problem kernel (GPU box): rebuilds csrc/smallnewton.hip with -DSN_TRACE in place, runs, restores the plain build
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R/calipso.jl_amd/csrc
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result"
-hipcc $FL -DSN_TRACE -c smallnewton.hip -o smallnewton.o && hipcc --offload-arch=gfx950 -shared -fPIC -o ../libcalipso_hip.so *.o -ldl
+hipcc $FL -DSN_TRACE ${SN_EXTRA:-} -c smallnewton.hip -o smallnewton.o && hipcc --offload-arch=gfx950 -shared -fPIC -o ../libcalipso_hip.so *.o -ldl
 cd $R
 python - "$@" <<'PY'
 import ctypes as C, os, sys, numpy as np

@@ -46,6 +46,9 @@ using calipso::Options;
 typedef calipso_hip_smallnewton SN;
 
 constexpr int NT = 256;
+#ifndef SN_JB
+#define SN_JB 8          // columns per panel of the LDL^T (bench/small_newton_phases.sh builds other values)
+#endif
 enum { SC_KAPPA = 0, SC_TAU, SC_RHO, SC_EP, SC_EPLAST, SC_ED, SC_EQV, SC_CPV, SC_F, SC_COUNT = 16 };
 enum { CN_TOTAL = 0, CN_OUTER, CN_INNER, CN_FACT, CN_RFAIL, CN_RMAX, CN_RLAST, CN_STEPS, CN_FILTER, CN_TRACE, CN_COUNT = 16 };
 enum { IN_STEP = 0, IN_STEP_T, IN_ROUNDS, IN_NFACT, IN_MH, IN_THETAH, IN_EXIT, IN_OPT, IN_COUNT = 8 };
@@ -72,7 +75,7 @@ __host__ __device__ inline Lay layout(const Dm& d) {
     L.fx = take(d.nx); L.gzx = take(d.nx); L.gh = take(d.m); L.ghc = take(d.m);
     L.cprod = take(d.nc); L.bgrad = take(d.nc); L.wz = take(d.nc); L.wsoc = take(d.wsz); L.bsoc = take(d.wsz); L.vsoc = take(4 * d.maxd * d.nsoc);
     L.D = take(d.nx); L.Dinv = take(d.nx); L.xb = take(d.nx); L.t1 = take(d.m); L.t2 = take(d.m);
-    L.ycol = take(8 * d.nx);
+    L.ycol = take(SN_JB * d.nx);
     L.red = take(64);
     L.total = o;
     return L;
@@ -114,6 +117,21 @@ template <int K> __device__ __forceinline__ void block_max(double (&v)[K], doubl
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = fmax(fmax(red[k * 4], red[k * 4 + 1]), fmax(red[k * 4 + 2], red[k * 4 + 3]));
+}
+// KS sums and KM maxima with ONE pair of barriers
+template <int KS, int KM> __device__ __forceinline__ void block_sum_max(double (&sv)[KS], double (&mv)[KM], double* red) {
+    static_assert((KS + KM) * 4 <= 64, "reduction scratch");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { const double s = wave_sum(sv[k]); if (lane == 0) red[k * 4 + wave] = s; }
+#pragma unroll
+    for (int k = 0; k < KM; ++k) { const double s = wave_max(mv[k]); if (lane == 0) red[(KS + k) * 4 + wave] = s; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KS; ++k) sv[k] = (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
+#pragma unroll
+    for (int k = 0; k < KM; ++k) mv[k] = fmax(fmax(red[(KS + k) * 4], red[(KS + k) * 4 + 1]), fmax(red[(KS + k) * 4 + 2], red[(KS + k) * 4 + 3]));
 }
 // |v| with NaN -> +inf: a NaN in a residual must FAIL the refinement's `norm <= tolerance` test (Julia's norm is NaN there), not slip through fmax
 __device__ __forceinline__ double nabs(double v) { return v != v ? __longlong_as_double(0x7ff0000000000000LL) : fabs(v); }
@@ -260,7 +278,7 @@ template <bool SOC> struct CtxT {
     }
 
     template <int RP> __device__ __forceinline__ void panel_(int j0, int jb, int lane, double* pan) {
-        constexpr int JB = 8;
+        constexpr int JB = SN_JB;
                             double pr[RP][JB];
         #pragma unroll
                             for (int r = 0; r < RP; ++r) {
@@ -350,8 +368,7 @@ template <bool SOC> struct CtxT {
                 for (int a = 0; a < dm; ++a) W[a + c0 * dm] = -col[a];
             }
         }
-        block_sum(cnt, red);         // (also the barrier behind wz)
-        pos += (int)cnt[0]; nonpos += (int)cnt[1]; zero += (int)cnt[2];
+        __syncthreads();             // (wz, wsoc are read by every thread below; the pivot-sign counts of this part join those of D in ONE reduction at the end)
         // S(i, j), i >= j: what triu(K) holds of the Hessian (Lxx[j, i]) + ep on the diagonal + sum_k Z[k, i] Omega_k Z[k, j]
         const int ntri = d.nx * (d.nx + 1) / 2;
         for (int e = tid; e < ntri; e += NT) {
@@ -384,7 +401,7 @@ template <bool SOC> struct CtxT {
         // and leaves the raw (unscaled) pivot columns in `ycol` (8 x nx); then all threads apply the panel to the trailing matrix, entry by entry in pivot order
         // (S(i, k) -= l_i y_k for the panel's pivots in turn: the arithmetic of the column-by-column algorithm), two barriers per panel instead of one per pivot.
         {
-            constexpr int JB = 8;
+            constexpr int JB = SN_JB;
             const int lane = tid & 63, wave = tid >> 6;
             const int ti = tid >> 4, tk = tid & 15;
             double* pan = ycol;
@@ -417,7 +434,7 @@ template <bool SOC> struct CtxT {
                 __syncthreads();
             }
         }
-        double c2[3] = {0.0, 0.0, 0.0};
+        double c2[3] = {cnt[0], cnt[1], cnt[2]};
         for (int i = tid; i < d.nx; i += NT) { const double dv = D[i]; if (dv > 0.0) c2[0] += 1.0; else c2[1] += 1.0; if (dv == 0.0) c2[2] += 1.0; }
         block_sum(c2, red);
         pos += (int)c2[0]; nonpos += (int)c2[1]; zero += (int)c2[2];
@@ -637,8 +654,7 @@ template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>
         for (int e = 1; e < dm; ++e) c.bgrad[st + e] = sc * (-sl[e]);
     }
     for (int i = tid; i < d.ne; i += NT) { const double r = sol[d.orr() + i]; s4[1] += c.lam[i] * r; s4[2] += r * r; }
-    block_sum(s4, c.red);
-    const double M = c.fcur + (s4[1] + 0.5 * c.rho * s4[2]) - c.kappa * s4[0];                                               // :112-116 merit.jl:2-15
+    if (SOC) __syncthreads();                  // (the barrier gradient of a cone is written by the cone's thread, read entry by entry below)
     const double* lam = c.lam;
     for (int i = tid; i < d.nx; i += NT) c.mgrad[i] = c.fx[i];                                                               // :118-124
     for (int i = tid; i < d.ne; i += NT) c.mgrad[d.nx + i] = lam[i] + c.rho * sol[d.orr() + i];
@@ -669,8 +685,12 @@ template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>
         if (i >= d.ot()) n4[2] += fabs(sol[i]);
         if (i >= d.oy() && i < d.ot()) n4[3] += a;      // res_y = g - r, res_z = h - s: the entries of constraint_violation.jl:1-13
     }
-    block_sum(n4, c.red);
-    block_max(m4, c.red);
+    {   // the merit's three sums, the four norm sums and the four maxima: one reduction
+        double sv[7] = {s4[0], s4[1], s4[2], n4[0], n4[1], n4[2], n4[3]};
+        block_sum_max(sv, m4, c.red);
+        s4[0] = sv[0]; s4[1] = sv[1]; s4[2] = sv[2]; n4[0] = sv[3]; n4[1] = sv[4]; n4[2] = sv[5]; n4[3] = sv[6];
+    }
+    const double M = c.fcur + (s4[1] + 0.5 * c.rho * s4[2]) - c.kappa * s4[0];                                               // :112-116 merit.jl:2-15
     const double residual_violation = n4[0] / (double)d.N;
     const double sd = (d.ne + d.nc > 0) ? fmax(100.0, n4[1] / (double)(d.ne + d.nc)) / 100.0 : 1.0;      // optimality_error.jl:8
     const double scn = (d.nc > 0) ? fmax(100.0, n4[2] / (double)d.nc) / 100.0 : 1.0;                     // :9
@@ -759,10 +779,12 @@ template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>
     for (int i = tid; i < d.n; i += NT) cand[i] = sol[i] - step_size * step[i];
     for (int i = tid; i < d.nc; i += NT) cand[d.ot() + i] = sol[d.ot() + i] - a_t * step[d.ot() + i];
     __syncthreads();
-    auto candidate_merit = [&](double& Mh, double& thetah) {                                                // :231-250 / :278-297
-        c.fcand = c.eval_objective(cand);
-        c.eval_constraints(cand, c.ghc);
-        double v[4] = {0.0, 0.0, 0.0, 0.0};      // Phi, lambda'r, r'r, theta numerator
+    auto candidate_merit = [&](double& Mh, double& thetah) {                                                // :231-250 / :278-297: evaluate!(objective, equality, cone), cone!(barrier), merit, violation
+        mv_n(c.Lxx, d.lds, d.nx, d.nx, cand, c.xb, nullptr);
+        mv_n(c.Z, d.ldz, d.m, d.nx, cand, c.ghc, c.bh);
+        __syncthreads();
+        double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // Phi, lambda'r, r'r, theta numerator, x'Lxx x, q'x
+        for (int i = tid; i < d.nx; i += NT) { v[4] += cand[i] * c.xb[i]; v[5] += c.q[i] * cand[i]; }
         for (int i = tid; i < d.nc; i += NT) { const double sl = cand[d.os() + i]; if (i < d.q) v[0] += log(sl); v[3] += fabs(c.ghc[d.ne + i] - sl); }
         for (int j = tid; SOC && j < d.nsoc; j += NT) {
             const int st = c.soc_start[j], dm = c.soc_dim[j];
@@ -773,6 +795,7 @@ template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>
         }
         for (int i = tid; i < d.ne; i += NT) { const double r = cand[d.orr() + i]; v[1] += lam[i] * r; v[2] += r * r; v[3] += fabs(c.ghc[i] - r); }
         block_sum(v, c.red);
+        c.fcand = 0.5 * v[4] + v[5];
         Mh = c.fcand + (v[1] + 0.5 * c.rho * v[2]) - c.kappa * v[0];
         thetah = (d.ne + d.nc > 0) ? v[3] / (double)(d.ne + d.nc) : 0.0;
     };
