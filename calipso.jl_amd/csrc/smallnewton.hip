@@ -138,17 +138,38 @@ __device__ __forceinline__ double nabs(double v) { return v != v ? __longlong_as
 
 // y[r] = sum_c M[r + c ld] x[c] (+ add[r]), r < rows: a thread per row (consecutive rows in consecutive lanes: conflict-free), x broadcast
 __device__ __forceinline__ void mv_n(const double* M, int ld, int rows, int cols, const double* x, double* y, const double* add) {
+    // (one thread walks a whole row: with a single accumulator every multiply-add waits for its own LDS round trip — 49 columns were 3.3 us; four accumulators over
+    // batches of eight columns keep eight loads in flight)
     for (int r = threadIdx.x; r < rows; r += NT) {
-        double a = 0.0;
-        for (int c = 0; c < cols; ++c) a += M[r + c * ld] * x[c];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int c = 0;
+        for (; c + 8 <= cols; c += 8) {
+            double mv[8], xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { mv[q] = M[r + (c + q) * ld]; xv[q] = x[c + q]; }
+            a0 += mv[0] * xv[0]; a1 += mv[1] * xv[1]; a2 += mv[2] * xv[2]; a3 += mv[3] * xv[3];
+            a0 += mv[4] * xv[4]; a1 += mv[5] * xv[5]; a2 += mv[6] * xv[6]; a3 += mv[7] * xv[7];
+        }
+        for (; c < cols; ++c) a0 += M[r + c * ld] * x[c];
+        const double a = (a0 + a1) + (a2 + a3);
         y[r] = add ? a + add[r] : a;
     }
 }
 // y[c] = sum_r M[r + c ld] x[r] (+ add[c]), c < cols: a thread per column (ld odd: conflict-free)
 __device__ __forceinline__ void mv_t(const double* M, int ld, int rows, int cols, const double* x, double* y, const double* add) {
     for (int c = threadIdx.x; c < cols; c += NT) {
-        double a = 0.0;
-        for (int r = 0; r < rows; ++r) a += M[r + c * ld] * x[r];
+        const double* col = M + c * ld;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int r = 0;
+        for (; r + 8 <= rows; r += 8) {
+            double mv[8], xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { mv[q] = col[r + q]; xv[q] = x[r + q]; }
+            a0 += mv[0] * xv[0]; a1 += mv[1] * xv[1]; a2 += mv[2] * xv[2]; a3 += mv[3] * xv[3];
+            a0 += mv[4] * xv[4]; a1 += mv[5] * xv[5]; a2 += mv[6] * xv[6]; a3 += mv[7] * xv[7];
+        }
+        for (; r < rows; ++r) a0 += col[r] * x[r];
+        const double a = (a0 + a1) + (a2 + a3);
         y[c] = add ? a + add[c] : a;
     }
 }
@@ -252,9 +273,18 @@ template <bool SOC> struct CtxT {
         mv_n(Z, d.ldz, d.m, d.nx, v, t2, nullptr);                      // [A; -G] vx
         __syncthreads();
         for (int c = tid; c < d.nx; c += NT) {
-            double a = 0.0;
-            for (int r = 0; r < d.m; ++r) a += Z[r + c * d.ldz] * v[d.oy() + r];
-            out[c] = (xb[c] + ep * v[c]) + a;
+            const double* col = Z + c * d.ldz; const double* vy = v + d.oy();
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int r = 0;
+            for (; r + 8 <= d.m; r += 8) {
+                double mv[8], xv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { mv[q] = col[r + q]; xv[q] = vy[r + q]; }
+                a0 += mv[0] * xv[0]; a1 += mv[1] * xv[1]; a2 += mv[2] * xv[2]; a3 += mv[3] * xv[3];
+                a0 += mv[4] * xv[4]; a1 += mv[5] * xv[5]; a2 += mv[6] * xv[6]; a3 += mv[7] * xv[7];
+            }
+            for (; r < d.m; ++r) a0 += col[r] * vy[r];
+            out[c] = (xb[c] + ep * v[c]) + ((a0 + a1) + (a2 + a3));
         }
         for (int i = tid; i < d.ne; i += NT) {
             out[d.orr() + i] = (rho + ep) * v[d.orr() + i] - v[d.oy() + i];
@@ -379,8 +409,18 @@ template <bool SOC> struct CtxT {
             const int j = e - i * (i + 1) / 2;
             double a = 0.0;
             const double* zi = Z + i * d.ldz; const double* zj = Z + j * d.ldz;
-            for (int k = 0; k < d.ne; ++k) a += zi[k] * omega_y * zj[k];
-            for (int k = 0; k < d.q; ++k) a += zi[d.ne + k] * wz[k] * zj[d.ne + k];
+            {
+                double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+                int k = 0;
+                for (; k + 4 <= d.ne; k += 4) { e0 += zi[k] * zj[k]; e1 += zi[k + 1] * zj[k + 1]; e2 += zi[k + 2] * zj[k + 2]; e3 += zi[k + 3] * zj[k + 3]; }
+                for (; k < d.ne; ++k) e0 += zi[k] * zj[k];
+                a += omega_y * ((e0 + e1) + (e2 + e3));
+                const double* ci = zi + d.ne; const double* cj = zj + d.ne;
+                e0 = e1 = e2 = e3 = 0.0;
+                for (k = 0; k + 4 <= d.q; k += 4) { e0 += ci[k] * wz[k] * cj[k]; e1 += ci[k + 1] * wz[k + 1] * cj[k + 1]; e2 += ci[k + 2] * wz[k + 2] * cj[k + 2]; e3 += ci[k + 3] * wz[k + 3] * cj[k + 3]; }
+                for (; k < d.q; ++k) e0 += ci[k] * wz[k] * cj[k];
+                a += (e0 + e1) + (e2 + e3);
+            }
             for (int c0 = 0; SOC && c0 < d.nsoc; ++c0) {
                 const int st = d.ne + soc_start[c0], dm = soc_dim[c0];
                 const double* W = wsoc + soc_woff[c0];
