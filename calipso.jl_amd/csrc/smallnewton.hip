@@ -64,14 +64,14 @@ struct Dm {
 };
 
 // LDS carve-up (offsets in doubles): the same function sizes the launch on the host and places the pointers on the device
-struct Lay { int Lxx, Z, S, q, bh, lam, sol, cand, step, res, rerr, corr, tmpN, rsym, mgrad, fx, gzx, gh, ghc, cprod, bgrad, wz, wsoc, bsoc, vsoc, D, Dinv, xb, t1, t2, ycol, red, total; };
+struct Lay { int Lxx, Z, S, q, bh, lam, sol, cand, step, res, rerr, corr, rsym, fx, gzx, gh, ghc, cprod, bgrad, wz, wsoc, bsoc, vsoc, D, Dinv, xb, t1, t2, ycol, red, total; };
 __host__ __device__ inline Lay layout(const Dm& d) {
     Lay L; int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
     L.Lxx = take(d.lds * d.nx); L.Z = take(d.ldz * d.nx); L.S = take(d.lds * d.nx);
     L.q = take(d.nx); L.bh = take(d.m); L.lam = take(d.ne);
-    L.sol = take(d.N); L.cand = take(d.N); L.step = take(d.N); L.res = take(d.N); L.rerr = take(d.N); L.corr = take(d.N); L.tmpN = take(d.N);
-    L.rsym = take(d.n); L.mgrad = take(d.n);
+    L.sol = take(d.N); L.cand = take(d.N); L.step = take(d.N); L.res = take(d.N); L.rerr = take(d.N); L.corr = take(d.N);
+    L.rsym = take(d.n);
     L.fx = take(d.nx); L.gzx = take(d.nx); L.gh = take(d.m); L.ghc = take(d.m);
     L.cprod = take(d.nc); L.bgrad = take(d.nc); L.wz = take(d.nc); L.wsoc = take(d.wsz); L.bsoc = take(d.wsz); L.vsoc = take(4 * d.maxd * d.nsoc);
     L.D = take(d.nx); L.Dinv = take(d.nx); L.xb = take(d.nx); L.t1 = take(d.m); L.t2 = take(d.m);
@@ -212,7 +212,7 @@ __device__ __forceinline__ double recip(double d) {
 
 template <bool SOC> struct CtxT {
     Dm d; const Options* o;
-    double *Lxx, *Z, *S, *q, *bh, *lam, *sol, *cand, *step, *res, *rerr, *corr, *tmpN, *rsym, *mgrad, *fx, *gzx, *gh, *ghc, *cprod, *bgrad, *wz, *wsoc, *bsoc, *vsoc, *D, *Dinv, *xb, *t1, *t2, *ycol, *red;
+    double *Lxx, *Z, *S, *q, *bh, *lam, *sol, *cand, *step, *res, *rerr, *corr, *rsym, *fx, *gzx, *gh, *ghc, *cprod, *bgrad, *wz, *wsoc, *bsoc, *vsoc, *D, *Dinv, *xb, *t1, *t2, *ycol, *red;
     const int *soc_start, *soc_dim, *soc_woff;
     double* filt;                                   // global: [pairs theta | pairs merit | cache theta | cache merit | saved theta | saved merit], max_filter each
     // uniform scalars (every thread holds the same values)
@@ -616,9 +616,9 @@ template <bool SOC> struct CtxT {
 
     // residual_error = residual - H step; returns its inf-norm
     __device__ __forceinline__ double residual_error() {
-        Hmul(step, tmpN);
+        Hmul(step, rerr);                          // (H step lands in residual_error itself and is turned into residual - H step in place: no N-vector of scratch)
         double v[1] = {0.0};
-        for (int i = tid; i < d.N; i += NT) { const double e = res[i] - tmpN[i]; rerr[i] = e; v[0] = fmax(v[0], nabs(e)); }
+        for (int i = tid; i < d.N; i += NT) { const double e = res[i] - rerr[i]; rerr[i] = e; v[0] = fmax(v[0], nabs(e)); }
         block_max(v, red);
         return v[0];
     }
@@ -694,11 +694,9 @@ template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>
         for (int e = 1; e < dm; ++e) c.bgrad[st + e] = sc * (-sl[e]);
     }
     for (int i = tid; i < d.ne; i += NT) { const double r = sol[d.orr() + i]; s4[1] += c.lam[i] * r; s4[2] += r * r; }
-    if (SOC) __syncthreads();                  // (the barrier gradient of a cone is written by the cone's thread, read entry by entry below)
     const double* lam = c.lam;
-    for (int i = tid; i < d.nx; i += NT) c.mgrad[i] = c.fx[i];                                                               // :118-124
-    for (int i = tid; i < d.ne; i += NT) c.mgrad[d.nx + i] = lam[i] + c.rho * sol[d.orr() + i];
-    for (int i = tid; i < d.nc; i += NT) c.mgrad[d.nx + d.ne + i] = -1.0 * c.kappa * c.bgrad[i];
+    // :118-124 merit_gradient = [fx; lambda + rho r; -kappa barrier_gradient]: not stored — its only use is the directional derivative below, formed from the parts
+    // (the point does not move in between)
     // :127 residual!
     for (int i = tid; i < d.nx; i += NT) res[i] = c.fx[i] + c.gzx[i];
     for (int i = tid; i < d.ne; i += NT) {
@@ -813,7 +811,9 @@ template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>
     double step_size = a_s;
     // candidate (:206-218, :224-229) and the directional derivative of the merit function
     double dd1[1] = {0.0};
-    for (int i = tid; i < d.n; i += NT) dd1[0] += c.mgrad[i] * step[i];
+    for (int i = tid; i < d.nx; i += NT) dd1[0] += c.fx[i] * step[i];
+    for (int i = tid; i < d.ne; i += NT) dd1[0] += (lam[i] + c.rho * sol[d.orr() + i]) * step[d.orr() + i];
+    for (int i = tid; i < d.nc; i += NT) dd1[0] += (-1.0 * c.kappa * c.bgrad[i]) * step[d.os() + i];
     block_sum(dd1, c.red);
     const double dd = dd1[0];
     for (int i = tid; i < d.n; i += NT) cand[i] = sol[i] - step_size * step[i];
@@ -887,7 +887,7 @@ template <bool SOC> __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args 
     CtxT<SOC> c;
     c.d = d; c.o = &a.o; c.tid = tid;
     c.Lxx = sm + L.Lxx; c.Z = sm + L.Z; c.S = sm + L.S; c.q = sm + L.q; c.bh = sm + L.bh; c.lam = sm + L.lam; c.sol = sm + L.sol; c.cand = sm + L.cand; c.step = sm + L.step;
-    c.res = sm + L.res; c.rerr = sm + L.rerr; c.corr = sm + L.corr; c.tmpN = sm + L.tmpN; c.rsym = sm + L.rsym; c.mgrad = sm + L.mgrad;
+    c.res = sm + L.res; c.rerr = sm + L.rerr; c.corr = sm + L.corr; c.rsym = sm + L.rsym;
     c.fx = sm + L.fx; c.gzx = sm + L.gzx; c.gh = sm + L.gh; c.ghc = sm + L.ghc; c.cprod = sm + L.cprod; c.bgrad = sm + L.bgrad; c.wz = sm + L.wz; c.wsoc = sm + L.wsoc; c.bsoc = sm + L.bsoc; c.vsoc = sm + L.vsoc;
     c.soc_start = a.soc_start; c.soc_dim = a.soc_dim; c.soc_woff = a.soc_woff;
     c.D = sm + L.D; c.Dinv = sm + L.Dinv; c.xb = sm + L.xb; c.t1 = sm + L.t1; c.t2 = sm + L.t2; c.ycol = sm + L.ycol; c.red = sm + L.red;
