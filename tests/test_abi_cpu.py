@@ -75,3 +75,31 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".jl", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "import oracle" not in txt and "calipso_oracle" not in txt, os.path.join(dp, f)
+
+
+def test_left_looking_plan_does_not_depend_on_the_scan_threads():
+    """the plan scan of csrc/lfac.hip deals its candidates over host threads (CALIPSO_HIP_LFAC_PLAN_THREADS, default: up to 64): the winner must be the first of the cheapest in
+    candidate order whatever the thread count — the launch plan of a shape (and so the schedule every handle of that shape runs) is a function of the shape alone"""
+    import subprocess
+    import sys
+    child = r'''
+import ctypes, os, sys, hashlib
+import numpy as np
+L = ctypes.CDLL(os.path.join(%r, "calipso.jl_amd", "libcalipso_hip.so"))
+f = L.calipso_hip_debug_lfac_plan
+f.argtypes = [ctypes.c_int32] * 4 + [ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int32]
+f.restype = ctypes.c_int32
+h = hashlib.sha256()
+for shape in ((16, 1000, 300, 150), (24, 1500, 300, 150), (40, 2500, 1500, 1000)):
+    out = np.zeros(6 * 256)
+    n = f(*shape, 0.0, 0.0, out.ctypes.data, 256)
+    assert n == shape[0] + 1, (shape, n)
+    h.update(out.tobytes())
+print("PLAN " + h.hexdigest())
+''' % ROOT
+    digests = []
+    for threads in ("1", "3", "8"):
+        r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, CALIPSO_HIP_LFAC_PLAN_THREADS=threads), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("PLAN ")][0])
+    assert len(set(digests)) == 1, digests
