@@ -23,6 +23,11 @@ struct calipso_hip_group {
     H* base = nullptr;                 // hs[0]: its stream carries every launch, its buffers are the address origin
     calipso::BatchSc desc;             // instance list of the launches being enqueued (base->cur points here)
     double *hgather = nullptr, *hgather_dev = nullptr;   // MAX_BATCH x 64 doubles: pinned host buffer and its device-side address
+    // read-backs without hipStreamSynchronize: the gather kernel's last workgroup stores a sequence number behind the data (system-scope release) and the host spins on it
+    // (host_logic.hpp: host_wait) — what a single handle's read-backs do (api.hip: wait_published): a stream synchronisation costs ~5 us more per read-back, and a group step
+    // has ten of them on its critical path
+    unsigned long long *hseq = nullptr, *hseq_dev = nullptr; unsigned long long seq = 0;
+    unsigned* ticket = nullptr;                          // device word: workgroups of a gather launch that have stored their rows
     int *higather = nullptr, *higather_dev = nullptr;    // MAX_BATCH x 64 ints
     // the per-member scalars of the launches (BatchSc::sctab): a ring of device tables, each uploaded from its pinned twin in stream order when the active set or a
     // member's scalars differ from what the current table holds (steady Newton steps re-use one table: the same members, the same kappa / rho / regularisation)
@@ -38,14 +43,32 @@ struct calipso_hip_group {
 typedef calipso_hip_group G;
 typedef std::vector<int> Set;          // member indices
 
-__global__ void k_gather_d(Batch bt, const double* __restrict__ src, int count, double* __restrict__ dst) {
+// (hseq != nullptr: the last workgroup of the launch to arrive publishes `seq`)
+__device__ __forceinline__ void gather_publish(unsigned* __restrict__ ticket, unsigned long long* __restrict__ hseq, unsigned long long seq) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && hseq) {
+        if (atomicAdd(ticket, 1u) == gridDim.z - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ void k_gather_d(Batch bt, const double* __restrict__ src, int count, double* __restrict__ dst, unsigned* __restrict__ ticket = nullptr,
+                           unsigned long long* __restrict__ hseq = nullptr, unsigned long long seq = 0) {
     inst_shift(bt, src);
     if ((int)threadIdx.x < count) dst[blockIdx.z * 64 + threadIdx.x] = src[threadIdx.x];
+    gather_publish(ticket, hseq, seq);
 }
-__global__ void k_gather_i(Batch bt, const int* __restrict__ src, int count, int* __restrict__ dst) {
+__global__ void k_gather_i(Batch bt, const int* __restrict__ src, int count, int* __restrict__ dst, unsigned* __restrict__ ticket = nullptr,
+                           unsigned long long* __restrict__ hseq = nullptr, unsigned long long seq = 0) {
     inst_shift_i(bt, src);
     if ((int)threadIdx.x < count) dst[blockIdx.z * 64 + threadIdx.x] = src[threadIdx.x];
+    gather_publish(ticket, hseq, seq);
 }
+// wait for the sequence number of the last gather launch (everything queued before it on the group's stream has completed by then)
+static int g_wait_seq(calipso_hip_group* g);
 
 static void g_activate(G* g, const Set& a) {
     BatchSc& b = g->desc;
@@ -71,14 +94,25 @@ static void g_activate(G* g, const Set& a) {
     b.sctab = g->sc_dev + (size_t)g->sc_slot * MAX_BATCH;
     g->base->cur = &g->desc;
 }
+static int g_wait_seq(G* g) {
+    H* s = g->base;
+    const unsigned long long want = g->seq;
+    hipError_t q = hipSuccess;
+    const bool ok = host_wait([&] { return __atomic_load_n(g->hseq, __ATOMIC_ACQUIRE) >= want; },
+                              [&] { q = hipStreamQuery(s->stream); return q == hipErrorNotReady; });
+    g->sc_pending = 0;
+    if (ok) return 0;
+    if (q != hipSuccess && q != hipErrorNotReady) return calipso::check(s, q, "group read-back");
+    s->err = "group read-back did not arrive";
+    return CALIPSO_ERR_HIP;
+}
 // dscal[first .. first+count) of every member of `a` (the active set) -> that member's hscal
 static int g_read_d(G* g, const Set& a, int first, int count) {
     H* s = g->base;
     if (launch_errors(s, "a kernel launch of this phase of the group step was refused")) return CALIPSO_ERR_HIP;
     // the gather kernel stores straight into pinned host memory (one launch, no separate copy)
-    hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + first, count, g->hgather_dev);
-    SYNC();
-    g->sc_pending = 0;
+    hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + first, count, g->hgather_dev, g->ticket, g->hseq_dev, ++g->seq);
+    if (g_wait_seq(g)) return CALIPSO_ERR_HIP;
     for (size_t k = 0; k < a.size(); ++k)
         for (int i = 0; i < count; ++i) g->hs[a[k]]->hscal[first + i] = g->hgather[k * 64 + i];
     return 0;
@@ -86,9 +120,8 @@ static int g_read_d(G* g, const Set& a, int first, int count) {
 static int g_read_i(G* g, const Set& a, int first, int count) {
     H* s = g->base;
     if (launch_errors(s, "a kernel launch of this phase of the group step was refused")) return CALIPSO_ERR_HIP;
-    hipLaunchKernelGGL(k_gather_i, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->icount + first, count, g->higather_dev);
-    SYNC();
-    g->sc_pending = 0;
+    hipLaunchKernelGGL(k_gather_i, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->icount + first, count, g->higather_dev, g->ticket, g->hseq_dev, ++g->seq);
+    if (g_wait_seq(g)) return CALIPSO_ERR_HIP;
     for (size_t k = 0; k < a.size(); ++k)
         for (int i = 0; i < count; ++i) g->hs[a[k]]->hicount[first + i] = g->higather[k * 64 + i];
     return 0;
@@ -99,9 +132,8 @@ static int g_read_both(G* g, const Set& a, int ifirst, int icnt, int dfirst, int
     H* s = g->base;
     if (launch_errors(s, "a kernel launch of this phase of the group step was refused")) return CALIPSO_ERR_HIP;
     hipLaunchKernelGGL(k_gather_i, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->icount + ifirst, icnt, g->higather_dev);
-    hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + dfirst, dcnt, g->hgather_dev);
-    SYNC();
-    g->sc_pending = 0;
+    hipLaunchKernelGGL(k_gather_d, dim3(1, 1, (unsigned)a.size()), dim3(64), 0, s->stream, g->desc.b, s->dscal + dfirst, dcnt, g->hgather_dev, g->ticket, g->hseq_dev, ++g->seq);
+    if (g_wait_seq(g)) return CALIPSO_ERR_HIP;
     for (size_t k = 0; k < a.size(); ++k) {
         for (int i = 0; i < icnt; ++i) g->hs[a[k]]->hicount[ifirst + i] = g->higather[k * 64 + i];
         for (int i = 0; i < dcnt; ++i) g->hs[a[k]]->hscal[dfirst + i] = g->hgather[k * 64 + i];
@@ -543,6 +575,11 @@ int32_t calipso_hip_group_create(calipso_hip_solver** handles, int32_t count, ca
     CK(hipHostMalloc((void**)&g->higather, sizeof(int) * 64 * MAX_BATCH, hipHostMallocMapped));
     CK(hipHostGetDevicePointer((void**)&g->hgather_dev, g->hgather, 0));
     CK(hipHostGetDevicePointer((void**)&g->higather_dev, g->higather, 0));
+    CK(hipHostMalloc((void**)&g->hseq, sizeof(unsigned long long), hipHostMallocMapped));
+    g->hseq[0] = 0;
+    CK(hipHostGetDevicePointer((void**)&g->hseq_dev, g->hseq, 0));
+    CK(hipMalloc((void**)&g->ticket, sizeof(unsigned)));
+    CK(hipMemset(g->ticket, 0, sizeof(unsigned)));
     CK(hipMalloc((void**)&g->sc_dev, sizeof(calipso::Scalars) * G::SC_RING * MAX_BATCH));
     CK(hipHostMalloc((void**)&g->sc_pin, sizeof(calipso::Scalars) * G::SC_RING * MAX_BATCH, hipHostMallocDefault));
     return CALIPSO_OK;
@@ -563,6 +600,8 @@ int32_t calipso_hip_group_destroy(calipso_hip_group* g) {
     for (H* h : g->hs) h->owner = nullptr;
     if (g->hgather) (void)hipHostFree(g->hgather);
     if (g->higather) (void)hipHostFree(g->higather);
+    if (g->hseq) (void)hipHostFree(g->hseq);
+    if (g->ticket) (void)hipFree(g->ticket);
     if (g->sc_dev) (void)hipFree(g->sc_dev);
     if (g->sc_pin) (void)hipHostFree(g->sc_pin);
     delete g;
