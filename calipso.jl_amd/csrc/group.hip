@@ -96,6 +96,8 @@ static void g_activate(G* g, const Set& a) {
 }
 static int g_wait_seq(G* g) {
     H* s = g->base;
+    static const bool sync_env = [] { const char* e = getenv("CALIPSO_HIP_GROUP_SYNC"); return e && atoi(e) != 0; }();      // (experiment switch: the stream synchronisation of rounds 1-5)
+    if (sync_env) { SYNC(); g->sc_pending = 0; return 0; }
     const unsigned long long want = g->seq;
     hipError_t q = hipSuccess;
     const bool ok = host_wait([&] { return __atomic_load_n(g->hseq, __ATOMIC_ACQUIRE) >= want; },

@@ -453,7 +453,7 @@ __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd,
 }
 
 template <int MF_THREADS, bool GF>
-__global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first, int ypan, int run = 1) {
+__global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const MfSlots sl, int first, int ypan) {
     extern __shared__ __attribute__((aligned(16))) double Flds[];
     bool mf_traced = false; int mf_tr = 0;
 #ifdef CALIPSO_LDL_TRACE
@@ -464,14 +464,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_factor(const MfDev d, const M
     mf_tr = mf_tr_s;
     if (mf_traced && threadIdx.x == 0) { g_mf_trace[(mf_tr & 63) * 12 + 10] = d.nrec[first].c; g_mf_trace[(mf_tr & 63) * 12 + 11] = d.nrec[first].c + d.nrec[first].r; }
 #endif
+    const MfNode nd = d.nrec[first + blockIdx.x];
     const size_t z = sl.use ? (size_t)sl.slot[blockIdx.y] : (size_t)blockIdx.y;   // storage slot of this instance of the batch
-    // run > 1: the launch covers `run` consecutive levels of ONE node each (the chain at the top of a stage tree: grid.x = 1) — the workgroup takes them in turn; what a
-    // node hands to its parent (update matrix, pivots) was written by this very workgroup: a workgroup barrier orders it
-    for (int q = 0; q < run; ++q) {
-        if (q) __syncthreads();
-        const MfNode nd = d.nrec[first + blockIdx.x + q];
-        mf_factor_node<MF_THREADS, GF>(d, nd, z, ypan, Flds, mf_traced, mf_tr);
-    }
+    mf_factor_node<MF_THREADS, GF>(d, nd, z, ypan, Flds, mf_traced, mf_tr);
 }
 
 // forward: v = [b_C ; 0] + children's contributions;  y_C = L11^-1 v_C;  v_R -= L21 y_C  -> the node's contribution to its ancestors.
@@ -552,13 +547,10 @@ __device__ __forceinline__ void mf_forward_node(const MfDev& d, const MfNode& nd
     for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a] - ((part[a] + part[r + a]) + (part[2 * r + a] + part[3 * r + a]));
 }
 template <int MF_THREADS, bool GP>
-__global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X, int run = 1) {
+__global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    for (int q = 0; q < run; ++q) {                                            // (run > 1: a chain of single-node levels, child before parent — k_mf_factor has the note)
-        if (q) __syncthreads();
-        const MfNode nd = d.nrec[first + blockIdx.x + q];                      // blockIdx.y = instance * nrhs + right-hand side
-        mf_forward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, usum, X, sm);
-    }
+    const MfNode nd = d.nrec[first + blockIdx.x];                              // blockIdx.y = instance * nrhs + right-hand side
+    mf_forward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, usum, X, sm);
 }
 // backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C.  One wavefront per column for the product with L21'
 // (lanes along the rows, contiguous), then the c dependent steps in one wavefront (lane = column, x_i by v_readlane).
@@ -620,13 +612,10 @@ __device__ __forceinline__ void mf_backward_node(const MfDev& d, const MfNode& n
     }
 }
 template <int MF_THREADS, bool GP>
-__global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X, int run = 1) {
+__global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    for (int q = run - 1; q >= 0; --q) {                                       // (run > 1: a chain of single-node levels, parent before child)
-        if (q != run - 1) __syncthreads();
-        const MfNode nd = d.nrec[first + blockIdx.x + q];
-        mf_backward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, X, sm);
-    }
+    const MfNode nd = d.nrec[first + blockIdx.x];
+    mf_backward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, X, sm);
 }
 
 #include "sparse_wide.hpp"
@@ -744,48 +733,22 @@ int mf_reserve_wide_solve(calipso_hip_sparse* s, size_t cols) {
     return CALIPSO_OK;
 }
 // the numeric factorisation of nz matrices (storage slots sl) on stream st: a launch per level of the tree (fronts beyond the LDS: three, sparse_wide.hpp)
-// Consecutive levels of ONE node each (the top of a stage tree ends in such a chain: 21, 10, 5, 3, 1, 1 nodes per level at 41 stages) go out as one launch whose workgroup takes
-// the nodes in turn (k_mf_factor: `run`): a level of one small front is a launch boundary and little else.  Same nodes, same arithmetic, same order per node: same bits.
-// mf_chain_length(i): how many segments from i on form such a chain (1: none); CALIPSO_HIP_MF_CHAIN=0 keeps a launch per level.
-static int mf_chain_length(const calipso_hip_sparse* s, size_t i, bool solve) {
-    static const bool env = [] { const char* e = getenv("CALIPSO_HIP_MF_CHAIN"); return !e || atoi(e) != 0; }();
-    const std::vector<MfSeg>& P = s->mplan;
-    if (!env || P[i].count != 1 || P[i].wide.on || P[i].wide.solve || P[i].global) return 1;
-    int run = 1;
-    while (i + run < P.size()) {
-        const MfSeg& a = P[i + run - 1]; const MfSeg& b = P[i + run];
-        if (b.count != 1 || b.wide.on || b.wide.solve || b.global || b.first != a.first + 1 || b.threads != P[i].threads || (!solve && b.ypan != P[i].ypan)) break;
-        ++run;
-    }
-    return run;
-}
 void mf_enqueue_factor(calipso_hip_sparse* s, hipStream_t st, const MfSlots& sl, unsigned nz) {
-    for (size_t i = 0; i < s->mplan.size();) {
-        const MfSeg& g = s->mplan[i];
-        if (g.wide.on) { mf_wide_factor(st, s->md, sl, g.wide, g.first, g.count, nz); ++i; continue; }
-        const int run = mf_chain_length(s, i, false);
-        size_t lds = g.lds_factor;
-        for (int q = 1; q < run; ++q) lds = std::max(lds, s->mplan[i + q].lds_factor);
-        MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, nz), lds, st, s->md, sl, g.first, g.ypan, run);
-        i += (size_t)run;
+    for (const MfSeg& g : s->mplan) {
+        if (g.wide.on) mf_wide_factor(st, s->md, sl, g.wide, g.first, g.count, nz);
+        else MF_LAUNCH(k_mf_factor, g, dim3((unsigned)g.count, nz), g.lds_factor, st, s->md, sl, g.first, g.ypan);
     }
 }
 // both sweeps of a solve for ny = instances x nrhs columns of X (already permuted)
 void mf_enqueue_solve(calipso_hip_sparse* s, hipStream_t st, const MfSlots& sl, unsigned ny, int nrhs, double* X) {
     const bool wide_ok = s->wpart && (size_t)ny * (size_t)s->wide_count * (size_t)s->wide_blocks * 64 <= s->cap_wpart;
-    // (chains of single-node levels: one launch, mf_chain_length; the same grouping forwards and backwards)
-    std::vector<std::pair<size_t, int>> groups;
-    for (size_t i = 0; i < s->mplan.size();) { const int run = (s->mplan[i].wide.solve && wide_ok) ? 1 : mf_chain_length(s, i, true); groups.push_back({i, run}); i += (size_t)run; }
-    auto lds_of = [&](size_t i, int run) { size_t l = 0; for (int q = 0; q < run; ++q) l = std::max(l, s->mplan[i + q].lds_solve); return l; };
-    for (const auto& gr : groups) {
-        const MfSeg& g = s->mplan[gr.first];
+    for (const MfSeg& g : s->mplan) {
         if (g.wide.solve && wide_ok) mf_wide_forward(st, s->md, sl, g.wide, g.first, g.count, ny, s->n, nrhs, s->usum, X);
-        else MF_LAUNCH_SOLVE(k_mf_forward, g, dim3((unsigned)g.count, ny), lds_of(gr.first, gr.second), st, s->md, sl, g.first, s->n, nrhs, s->usum, X, gr.second);
+        else MF_LAUNCH_SOLVE(k_mf_forward, g, dim3((unsigned)g.count, ny), g.lds_solve, st, s->md, sl, g.first, s->n, nrhs, s->usum, X);
     }
-    for (auto gr = groups.rbegin(); gr != groups.rend(); ++gr) {
-        const MfSeg& g = s->mplan[gr->first];
-        if (g.wide.solve && wide_ok) mf_wide_backward(st, s->md, sl, g.wide, g.first, g.count, ny, s->n, nrhs, X, s->wpart, s->wide_blocks);
-        else MF_LAUNCH_SOLVE(k_mf_backward, g, dim3((unsigned)g.count, ny), lds_of(gr->first, gr->second), st, s->md, sl, g.first, s->n, nrhs, X, gr->second);
+    for (auto g = s->mplan.rbegin(); g != s->mplan.rend(); ++g) {
+        if (g->wide.solve && wide_ok) mf_wide_backward(st, s->md, sl, g->wide, g->first, g->count, ny, s->n, nrhs, X, s->wpart, s->wide_blocks);
+        else MF_LAUNCH_SOLVE(k_mf_backward, (*g), dim3((unsigned)g->count, ny), g->lds_solve, st, s->md, sl, g->first, s->n, nrhs, X);
     }
 }
 

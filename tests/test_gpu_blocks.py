@@ -304,37 +304,3 @@ def test_group_of_forty_dense_members_is_bitwise_the_single_steps():
             assert ref == got[k] and ref["status"] == 0
             assert same(singles[k].data("step").all, mem[k].data("step").all) and same(singles[k].solution.all, mem[k].solution.all)
     g.close()
-
-
-CHAIN_CHILD = r'''
-import hashlib, sys, os
-import numpy as np
-sys.path[:0] = [%(root)r, os.path.join(%(root)r, "tests")]
-from helpers import load_pkg
-from test_gpu_blocks import build_structured
-pkg = load_pkg()
-out = []
-for pid, shape in ((5, (41, 56, 54, 6, 6, 2)), (6, (12, 40, 30, 4, 2, 3)), (7, (25, 20, 14, 3, 1, 3))):
-    prob, s = build_structured(pkg, pid, *shape)
-    for it in range(3):
-        info = s.newton_step(advance=True)
-        assert info["status"] >= 0, info
-        out.append(hashlib.sha256(np.ascontiguousarray(s.solution.all).tobytes()).hexdigest())
-        out.append(repr(sorted((k, v) for k, v in info.items() if k in ("status", "refinement_rounds", "factorizations", "step_size"))))
-print("DIGEST " + hashlib.sha256("\n".join(out).encode()).hexdigest())
-'''
-
-
-def test_chain_of_single_node_levels_in_one_launch_keeps_the_bits():
-    """the top of a stage tree ends in levels of ONE front each: they go out as one launch whose workgroup takes the nodes in turn (sparse.hip: mf_chain_length, factorisation and
-    both sweeps of a solve); CALIPSO_HIP_MF_CHAIN=0 keeps a launch per level — same nodes, same arithmetic per node: the Newton steps of structured handles agree bit for bit"""
-    import subprocess
-    import sys
-    import os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    digests = []
-    for v in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", CHAIN_CHILD % {"root": root}], env=dict(os.environ, CALIPSO_HIP_MF_CHAIN=v), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST ")][0])
-    assert digests[0] == digests[1]
