@@ -4,6 +4,7 @@
 #   LDL^T chain (single / group), the C4 and C4T bench lines and the kernel stats of one C4T group, the chain timeline, the block harnesses, the wide fronts of the multifrontal path.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/round; mkdir -p $O
 cd $R
+make -C calipso.jl_amd/csrc trace > /dev/null 2>&1      # the stamped build (bench/ldl_trace.py, mf_trace.py, ldl_bulk_trace.py): a stale one lacks the ABI of the round
 bash bench/profile_round.sh 12 > $O/profile_round.log 2>&1
 bash bench/ldl_step_times.sh 0 0 > /dev/null 2>&1; cp gpurun_out/ldlsteps_0_0/steps.txt $O/ldl_steps_single.txt
 bash bench/ldl_step_times.sh 12 1 > /dev/null 2>&1; cp gpurun_out/ldlsteps_12_1/steps.txt $O/ldl_steps_group12_pairs.txt
