@@ -1238,6 +1238,7 @@ int32_t calipso_hip_solve(H* s, calipso_eval_fn eval, void* user) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
     CK(hipSetDevice(s->device));
     Options& o = s->opt; Scalars& sc = s->sc; const Dims& d = s->d;
+    (void)hipGetLastError();      // (launch_errors: this call's launches only)
     s->stats = Stats();
     s->spec_ahead_ok = false;
     int rc;
@@ -1372,6 +1373,7 @@ int32_t calipso_hip_newton_steps(H* s, int32_t count, int32_t advance, double* i
 }
 static int32_t newton_step_impl(H* s, int32_t advance, double info_out[6], bool last) {
     if (!s) return CALIPSO_ERR_ARGUMENT;
+    (void)hipGetLastError();      // (launch_errors reports what THIS call's launches leave behind, not an earlier call's)
     if (!s->qp.attached && !s->dev_eval && !s->dev_block_eval) { s->err = "calipso_hip_newton_step needs a device evaluator (calipso_hip_qp_attach or calipso_hip_set_device_evaluator)"; return CALIPSO_ERR_ARGUMENT; }
     const Dims& d = s->d;
     const Scalars saved_sc = s->sc;

@@ -617,6 +617,7 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
     const Dims& d = s->d;
     const size_t B = g->hs.size();
     CK(hipSetDevice(s->device));
+    (void)hipGetLastError();      // (launch_errors: this call's launches only)
     { const int oc = g_check_options(g); if (oc < 0) return oc; }
     Set all;
     for (size_t i = 0; i < B; ++i) {
@@ -689,6 +690,7 @@ int32_t calipso_hip_group_solve(calipso_hip_group* g, int32_t* result) {
     const Dims& d = s->d;
     const size_t B = g->hs.size();
     CK(hipSetDevice(s->device));
+    (void)hipGetLastError();      // (launch_errors: this call's launches only)
     { const int oc = g_check_options(g); if (oc < 0) return oc; }
     Set all;
     for (size_t i = 0; i < B; ++i) {

@@ -1138,7 +1138,7 @@ int32_t calipso_hip_smallnewton_set_cones(calipso_hip_smallnewton* s, int64_t n_
     return CALIPSO_OK;
 }
 
-// options.jl:6-59 by name (the hot-path subset; max_filter must be set before the first launch resizes nothing: it is fixed at create = 1000)
+// options.jl:6-59 by name (the hot-path subset)
 int32_t calipso_hip_smallnewton_set_option(calipso_hip_smallnewton* s, const char* name, double value) {
     if (!s || !name) return CALIPSO_ERR_ARGUMENT;
     Options& o = s->opt;
@@ -1155,7 +1155,24 @@ int32_t calipso_hip_smallnewton_set_option(calipso_hip_smallnewton* s, const cha
 #undef OD
 #undef OI
     if (n == "residual_norm" || n == "constraint_norm") { if (value == 1.0) return CALIPSO_OK; return fail(s, CALIPSO_ERR_ARGUMENT, "calipso_hip_smallnewton: only the 1-norm (the default) for " + n); }
-    if (n == "max_filter") { if ((calipso::i64)value == o.max_filter) return CALIPSO_OK; return fail(s, CALIPSO_ERR_ARGUMENT, "calipso_hip_smallnewton: max_filter is fixed at its default"); }
+    if (n == "max_filter") {      // filter.jl:7-13: the instances' filter pairs live in global memory (6 x max_filter doubles each): re-sized here, emptied
+        if (value < 1.0 || value > 1.0e6) return fail(s, CALIPSO_ERR_ARGUMENT, "calipso_hip_smallnewton: 1 <= max_filter <= 1e6");
+        if ((calipso::i64)value == (calipso::i64)o.max_filter) return CALIPSO_OK;
+        SK(hipSetDevice(s->device));
+        SK(hipStreamSynchronize(s->stream));
+        double* nf = nullptr;
+        const size_t cnt = (size_t)s->batch * 6 * (size_t)value;
+        SK(hipMalloc((void**)&nf, sizeof(double) * cnt));
+        SK(hipMemset(nf, 0, sizeof(double) * cnt));
+        if (s->filt) (void)hipFree(s->filt);
+        s->filt = nf;
+        o.max_filter = (double)(calipso::i64)value;
+        std::vector<long long> cn((size_t)s->batch * CN_COUNT);
+        SK(hipMemcpy(cn.data(), s->cnt, sizeof(long long) * cn.size(), hipMemcpyDeviceToHost));
+        for (int k = 0; k < s->batch; ++k) cn[(size_t)k * CN_COUNT + CN_FILTER] = 0;
+        SK(hipMemcpy(s->cnt, cn.data(), sizeof(long long) * cn.size(), hipMemcpyHostToDevice));
+        return CALIPSO_OK;
+    }
     return fail(s, CALIPSO_ERR_ARGUMENT, "calipso_hip_smallnewton_set_option: unknown option " + n);
 }
 

@@ -178,6 +178,20 @@ def test_nonconvex_instances_run_the_regularisation_loop_like_the_oracle(oracle_
     sn.close()
 
 
+def test_filter_capacity_option(oracle_mod):
+    """options.max_filter (filter.jl:7-13): a smaller filter array per instance — the solve does not depend on the capacity as long as the pairs fit"""
+    pkg = load_pkg()
+    probs = [pr.random_qp(10, 4, 6, seed=100 + k, nonnegative_indices=list(range(1, 7))) for k in range(3)]
+    a = make_batch(pkg, probs)
+    b = make_batch(pkg, probs, max_filter=16)
+    ra, _ = a.solve(); rb, _ = b.solve()
+    assert (ra == 1).all() and (rb == 1).all()
+    assert np.array_equal(a.get_state()["solution"], b.get_state()["solution"])
+    with pytest.raises(pkg.CalipsoHipError):
+        a.set_option("max_filter", 0)
+    a.close(); b.close()
+
+
 def test_unconstrained_and_single_instance():
     pkg = load_pkg()
     prob = pr.random_qp(15, 0, 0, seed=9, nonnegative_indices=[])
