@@ -45,7 +45,11 @@ namespace {
 using calipso::Options;
 typedef calipso_hip_smallnewton SN;
 
-constexpr int NT = 256;
+#ifndef SN_NT
+#define SN_NT 256        // threads per workgroup = per instance (bench/small_newton_phases.sh builds other values)
+#endif
+constexpr int NT = SN_NT, NW = NT / 64;
+static_assert(NT == 64 || NT == 128 || NT == 256, "one, two or four wavefronts per instance");
 #ifndef SN_JB
 #define SN_JB 8          // columns per panel of the LDL^T (bench/small_newton_phases.sh builds other values)
 #endif
@@ -107,7 +111,7 @@ template <int K> __device__ __forceinline__ void block_sum(double (&v)[K], doubl
     for (int k = 0; k < K; ++k) { const double s = wave_sum(v[k]); if (lane == 0) red[k * 4 + wave] = s; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
+    for (int k = 0; k < K; ++k) { double t = red[k * 4]; for (int w = 1; w < NW; ++w) t += red[k * 4 + w]; v[k] = t; }
 }
 template <int K> __device__ __forceinline__ void block_max(double (&v)[K], double* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -116,7 +120,7 @@ template <int K> __device__ __forceinline__ void block_max(double (&v)[K], doubl
     for (int k = 0; k < K; ++k) { const double s = wave_max(v[k]); if (lane == 0) red[k * 4 + wave] = s; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = fmax(fmax(red[k * 4], red[k * 4 + 1]), fmax(red[k * 4 + 2], red[k * 4 + 3]));
+    for (int k = 0; k < K; ++k) { double t = red[k * 4]; for (int w = 1; w < NW; ++w) t = fmax(t, red[k * 4 + w]); v[k] = t; }
 }
 // KS sums and KM maxima with ONE pair of barriers
 template <int KS, int KM> __device__ __forceinline__ void block_sum_max(double (&sv)[KS], double (&mv)[KM], double* red) {
@@ -129,9 +133,9 @@ template <int KS, int KM> __device__ __forceinline__ void block_sum_max(double (
     for (int k = 0; k < KM; ++k) { const double s = wave_max(mv[k]); if (lane == 0) red[(KS + k) * 4 + wave] = s; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < KS; ++k) sv[k] = (red[k * 4] + red[k * 4 + 1]) + (red[k * 4 + 2] + red[k * 4 + 3]);
+    for (int k = 0; k < KS; ++k) { double t = red[k * 4]; for (int w = 1; w < NW; ++w) t += red[k * 4 + w]; sv[k] = t; }
 #pragma unroll
-    for (int k = 0; k < KM; ++k) mv[k] = fmax(fmax(red[(KS + k) * 4], red[(KS + k) * 4 + 1]), fmax(red[(KS + k) * 4 + 2], red[(KS + k) * 4 + 3]));
+    for (int k = 0; k < KM; ++k) { double t = red[(KS + k) * 4]; for (int w = 1; w < NW; ++w) t = fmax(t, red[(KS + k) * 4 + w]); mv[k] = t; }
 }
 // |v| with NaN -> +inf: a NaN in a residual must FAIL the refinement's `norm <= tolerance` test (Julia's norm is NaN there), not slip through fmax
 __device__ __forceinline__ double nabs(double v) { return v != v ? __longlong_as_double(0x7ff0000000000000LL) : fabs(v); }
@@ -452,7 +456,7 @@ template <bool SOC> struct CtxT {
                 __syncthreads();
                 stamp(9);
                 const int base = j0 + jb;
-                for (int i = base + ti; i < d.nx; i += 16) {
+                for (int i = base + ti; i < d.nx; i += NT / 16) {
                     double li[JB];
 #pragma unroll
                     for (int u = 0; u < JB; ++u) li[u] = u < jb ? S[i + (j0 + u) * d.lds] : 0.0;
