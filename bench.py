@@ -197,7 +197,12 @@ def config_small_newton(pkg, pr, device, cpu=True, batch=4096, steps=20):
     stt = sn.get_state()
     its, nst = stt["counters"]["total_iterations"], stt["counters"]["newton_steps"]
     ms = min(ms_all)
+    import ctypes as C
+    from calipso_jl_amd._lib import lib
+    dsc = np.zeros(4); fdsc = lib().calipso_hip_debug_smallnewton_describe; fdsc.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    fdsc(sn._h, dsc.ctypes.data_as(C.POINTER(C.c_double)))
     out = {"workload": "%d random convex QPs of C5's shape (nx = %d, ne = %d, n = %d), one workgroup per instance, one launch" % (batch, nx, ne, nx + ne),
+           "kernel": {"threads_per_instance": int(dsc[0]), "lds_bytes_per_instance": int(dsc[1]), "instances_per_compute_unit": int(dsc[2]), "compute_units": int(dsc[3])},
            "solve": {"launch_ms": ms, "converged": int((res == 1).sum()), "solves_per_s": batch / (ms * 1e-3), "newton_steps_per_s": float(nst.sum()) / (ms * 1e-3),
                      "mean_newton_iterations": float(its.mean()), "max_refinement_rounds": int(stt["counters"]["max_refinement_rounds"].max())}}
     w = stt["solution"].copy()
@@ -209,7 +214,8 @@ def config_small_newton(pkg, pr, device, cpu=True, batch=4096, steps=20):
     bytes_inst = 8.0 * (nx * nx + ne * nx + nx + ne + 2 * (nx + 2 * ne))
     out["steps"] = {"count_per_instance": steps, "launch_ms": msk, "newton_steps_per_s": batch * steps / (msk * 1e-3), "stepped": int(((stat == 0) & (info[:, 6] == 0)).sum()),
                     "refinement_rounds": float(info[:, 2].mean()),
-                    "roofline": {"bound": "latency (neither HBM nor MFMA: ~75 dependent workgroup phases per step, two workgroups resident per compute unit)",
+                    "roofline": {"bound": "latency (neither HBM nor MFMA: ~75 dependent workgroup phases per step; throughput = resident instances / latency of one, %d instances per compute unit)" % int(dsc[2]),
+                                 "us_per_step_of_a_resident_instance": msk * 1e3 / steps / max(1.0, batch / max(1.0, dsc[2] * dsc[3])),
                                  "hbm_frac": batch * bytes_inst / (msk * 1e-3) / 8e12, "note": "an instance's data is read once per LAUNCH (%.0f KB), not per step" % (bytes_inst / 1e3)}}
     sn.close()
     if cpu:

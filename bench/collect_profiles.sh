@@ -27,7 +27,7 @@ cpy step_gaps_under_rocprof.txt step_gaps_under_rocprof.txt
 cpy diag_bench3.txt diag_bench3.txt
 cpy wide_fronts.txt wide_fronts.txt
 cpy kernel_stats_wide_fronts.csv kernel_stats_wide_fronts.csv
-for f in small_newton_rate_49_40_0_4096_20.json small_newton_rate_49_40_20_4096_10.json small_newton_rate_24_12_24_8192_20.json small_newton_phases.txt schur64_probe.txt; do cpy $f $f; done
+for f in small_newton_rate_49_40_0_4096_20.json small_newton_rate_49_40_20_4096_10.json small_newton_rate_24_12_24_8192_20.json small_newton_phases.txt small_newton_threads.txt schur64_probe.txt; do cpy $f $f; done
 cpy overlap_probe.txt overlap_probe_1.txt; cpy overlap_probe2.txt overlap_probe_2_short_kernels.txt; cpy overlap_probe3.txt overlap_probe_3_which_property.txt; cpy overlap_probe4.txt overlap_probe_4_saturating_mfma.txt
 [ -s "$R/gpurun_out/sparse_ldl_rate.json" ] && cp "$R/gpurun_out/sparse_ldl_rate.json" "$D/${P}_sparse_ldl_rate.json"
 ls $D | grep "^${P}_" | wc -l

@@ -31,5 +31,6 @@ ls -la $O | head -60
 # round 6: the small-problem kernel (rates, phase clocks), what overlaps on this chip (probes), the 256-thread Schur viability probe
 for a in "49 40 0 4096 20" "49 40 20 4096 10" "24 12 24 8192 20"; do timeout 200 python bench/small_newton_rate.py $a 2>/dev/null | tail -1 > $O/small_newton_rate_$(echo $a | tr ' ' '_').json; done
 bash bench/small_newton_phases.sh 2>&1 | tail -14 > $O/small_newton_phases.txt
+bash bench/small_newton_threads.sh > $O/small_newton_threads.txt 2>&1
 for p in overlap_probe overlap_probe2 overlap_probe3 overlap_probe4 schur64_probe; do hipcc --offload-arch=gfx950 -O3 bench/$p.hip -o /tmp/$p 2>/dev/null && timeout 120 /tmp/$p > $O/$p.txt 2>&1; done
 ls -la $O | wc -l

@@ -18,6 +18,7 @@ B = int(a[3]) if len(a) > 3 else 4096
 K = 10
 prob = pr.random_qp(nx, ne, nc, seed=1000, nonnegative_indices=list(range(1, nc + 1)))
 sn = pkg.SmallNewtonBatch(nx, ne, nc, B)
+if os.environ.get("SN_THREADS"): sn.set_option("threads", int(os.environ["SN_THREADS"]))
 sn.set_qp(prob.P, prob.q, prob.A, prob.b, prob.G, prob.h, objective_scale=prob.c)
 sn.initialize(np.tile(prob.x0, (B, 1)))
 res, ms = sn.solve()
@@ -30,7 +31,8 @@ for Bn in (B,):
     out = np.zeros(12)
     f = lib().calipso_hip_debug_smallnewton_profile; f.argtypes = [C.c_void_p, C.POINTER(C.c_double)]; f(sn._h, out.ctypes.data_as(C.POINTER(C.c_double)))
     names = ["eval+residual+norms", "inertia logic", "weights + S assembly", "LDL^T trailing updates", "first solve", "refinement", "cone search + candidate", "merit + line search", "accept", "LDL^T panels (1 wave)", "-", "between steps"]
-    print("shape (%d, %d, %d), batch %d, %d steps: launch %.3f ms = %.1f us per step per resident slot; instance 0, us per step:" % (nx, ne, nc, B, K, msk, msk * 1e3 / K / max(1, B / 512)))
+    dsc = np.zeros(4); g = lib().calipso_hip_debug_smallnewton_describe; g.argtypes = [C.c_void_p, C.POINTER(C.c_double)]; g(sn._h, dsc.ctypes.data_as(C.POINTER(C.c_double)))
+    print("shape (%d, %d, %d), batch %d, %d steps, %d threads and %d B of LDS per instance, %d instances per compute unit: launch %.3f ms = %.1f us per step of a resident instance; instance 0, us per step:" % (nx, ne, nc, B, K, dsc[0], dsc[1], dsc[2], msk, msk * 1e3 / K / max(1, B / (dsc[2] * dsc[3]))))
     for n_, v in zip(names, out):
         if n_ != "-": print("   %-26s %8.2f" % (n_, v / K))
     print("   sum %.2f   rounds %.1f" % (out.sum() / K, info[0, 2]))

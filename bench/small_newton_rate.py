@@ -20,10 +20,15 @@ def main():
     idx = np.arange(B) % nprob
     st = lambda name: np.stack([np.asarray(getattr(probs[i], name), dtype=np.float64) for i in idx])
     sn = pkg.SmallNewtonBatch(nx, ne, nc, B)
+    if os.environ.get("SN_THREADS"): sn.set_option("threads", int(os.environ["SN_THREADS"]))      # threads per instance (0 / unset: chosen by the LDS footprint)
     sn.set_qp(st("P"), st("q"), st("A"), st("b"), st("G"), st("h"), objective_scale=probs[0].c, shared=False)
     rng = np.random.default_rng(0)
     x0 = np.stack([probs[i].x0 for i in idx]) + 0.01 * rng.standard_normal((B, nx))
-    out = {"shape": [nx, ne, nc], "n": nx + ne + nc, "batch": B}
+    import ctypes as C
+    from calipso_jl_amd._lib import lib
+    dsc = np.zeros(4); f = lib().calipso_hip_debug_smallnewton_describe; f.argtypes = [C.c_void_p, C.POINTER(C.c_double)]; f(sn._h, dsc.ctypes.data_as(C.POINTER(C.c_double)))
+    out = {"shape": [nx, ne, nc], "n": nx + ne + nc, "batch": B, "threads": os.environ.get("SN_THREADS", "auto"),
+           "kernel": {"threads_per_instance": int(dsc[0]), "lds_bytes_per_instance": int(dsc[1]), "instances_per_compute_unit": int(dsc[2]), "compute_units": int(dsc[3])}}
     ms_all = []
     for rep in range(3):
         sn.initialize(x0)
@@ -46,7 +51,7 @@ def main():
     msk = min(x[2] for x in t)
     info, stat = t[0][0], t[0][1]
     out["steps"] = {"count_per_instance": K, "launch_ms": msk, "newton_steps_per_s": B * K / (msk * 1e-3), "ok": int((stat == 0).sum()), "stepped": int((info[:, 6] == 0).sum()),
-                    "refinement_rounds_mean": float(info[:, 2].mean()), "us_per_step_per_instance_slot": msk * 1e3 / K}
+                    "refinement_rounds_mean": float(info[:, 2].mean()), "us_per_step_of_a_resident_instance": msk * 1e3 / K / max(1.0, B / max(1.0, dsc[2] * dsc[3]))}
     # bytes an instance moves once per launch (problem data + state): the HBM side of the roofline is irrelevant here — say so with the number
     bytes_inst = 8.0 * (nx * nx + (ne + nc) * nx + nx + (ne + nc) + 2 * (nx + 2 * ne + 3 * nc))
     out["steps"]["hbm_fraction"] = B * bytes_inst / (msk * 1e-3) / 8e12

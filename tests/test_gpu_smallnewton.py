@@ -24,12 +24,17 @@ def make_batch(pkg, probs, **opts):
     return sn
 
 
-@pytest.mark.parametrize("shape", [(10, 4, 6), (12, 0, 9), (9, 5, 0), (49, 40, 0), (30, 12, 24)])
-def test_batched_solve_matches_the_oracle_per_accepted_iterate(oracle_mod, shape):
+# threads per instance: 0 = the library's choice by the LDS footprint (csrc/smallnewton.hip: sn_threads), else the build of the kernel with that workgroup size
+THREADS = [0, 64, 128, 256]
+
+
+@pytest.mark.parametrize("threads", THREADS)
+@pytest.mark.parametrize("shape", [(10, 4, 6), (12, 0, 9), (9, 5, 0), (49, 40, 0), (30, 12, 24), (70, 20, 10)])
+def test_batched_solve_matches_the_oracle_per_accepted_iterate(oracle_mod, shape, threads):
     pkg = load_pkg()
     nx, ne, nc = shape
     probs = [pr.random_qp(nx, ne, nc, seed=100 + k, nonnegative_indices=list(range(1, nc + 1))) for k in range(6)]
-    sn = make_batch(pkg, probs)
+    sn = make_batch(pkg, probs, threads=threads)
     sn.keep_trace(64)
     res, ms = sn.solve()
     st = sn.get_state()
@@ -53,8 +58,9 @@ def test_batched_solve_matches_the_oracle_per_accepted_iterate(oracle_mod, shape
     sn.close()
 
 
+@pytest.mark.parametrize("threads", THREADS)
 @pytest.mark.parametrize("layout", [(12, 4, 4, (3, 3)), (20, 8, 0, (4, 3, 3)), (16, 5, 6, (5,)), (30, 10, 3, (3, 3, 3, 3)), (10, 3, 8, (3,)), (14, 6, 10, (4,))])
-def test_batched_solve_with_second_order_cones_matches_the_oracle(oracle_mod, layout):
+def test_batched_solve_with_second_order_cones_matches_the_oracle(oracle_mod, layout, threads):
     """nonnegative entries followed by second-order cones (the friction-cone / portfolio shapes of the reference's tests): the arrow blocks, the closed-form inverses of
     cones/second_order.jl:50-65 with their first-row quirk, the triu-symmetrised cone block (which makes the first solve inexact: refinement rounds > 1) — per accepted
     iterate against the oracle, 1e-8"""
@@ -66,7 +72,7 @@ def test_batched_solve_with_second_order_cones_matches_the_oracle(oracle_mod, la
         soc.append(list(range(at, at + dm))); at += dm
     probs = [pr.random_qp(nx, ne, nc, seed=500 + k, nonnegative_indices=list(range(1, q + 1)), second_order_indices=soc) for k in range(5)]
     p0 = probs[0]
-    sn = pkg.SmallNewtonBatch(nx, ne, nc, len(probs))
+    sn = pkg.SmallNewtonBatch(nx, ne, nc, len(probs), options={"threads": threads})
     sn.set_cones(q, dims)
     st_ = lambda name: np.stack([np.asarray(getattr(p, name), dtype=np.float64) for p in probs])
     sn.set_qp(st_("P"), st_("q"), st_("A"), st_("b"), st_("G"), st_("h"), objective_scale=p0.c, shared=False)
