@@ -428,11 +428,12 @@ int32_t calipso_hip_small_get(calipso_hip_small*, double* X, int64_t* inertia);
 /* ---- solve! for a batch of SMALL conic QPs, the whole Newton iteration in one kernel (csrc/smallnewton.hip) ----------------------------------
  * Solver / initialize! / solve! (src/solver/solver.jl:46-150, initialize.jl:9-48, solve.jl:8-377) for `batch` independent problems of ONE shape that are too small
  * for the general path to be anything but launch latency (the MPC problems of examples/autotuning/cartpole.jl:179-227: n = 89): one workgroup per instance, problem
- * data, iterates and the factor in the compute unit's LDS, every decision of solve.jl:98-368 (exit tests, inertia_correction!, iterative_refinement!, cone search,
+ * data ([A; -G], q, [-b; h]; the Hessian block stays in L2), iterates and the factor in the compute unit's LDS, every decision of solve.jl:98-368 (exit tests, inertia_correction!, iterative_refinement!, cone search,
  * filter line search, outer updates) on the device, ONE launch per call.  Evaluator: the QP of calipso_hip_qp_attach (min c x'Px + q'x s.t. Ax = b, h - Gx >= 0) with
  * nonnegative and second-order cones (dimension <= 16; wider: the general path); residual_norm = constraint_norm = 1.  Points have the layout of point.jl:13-22 (N = nx + 2 ne + 3 nc).  Limits: nx <= 128 and the
  * instance must fit 160 KB of LDS (n up to ~200), else CALIPSO_ERR_ARGUMENT at create: the general path (calipso_hip_create + groups) takes those.
- *   create(nx, ne, nc, batch, device)        set_option(name, value): options.jl:6-59 by name
+ *   create(nx, ne, nc, batch, device)        set_option(name, value): options.jl:6-59 by name; plus "threads" = threads per instance (0: chosen by the LDS footprint so that
+ *                                            a compute unit holds as many instances as fit; 64, 128 or 256 force a build of the kernel)
  *   set_qp(P, q, A, b, G, h, c, shared)      column-major host arrays, batch-major (instance k at k * size) or ONE problem for all (shared != 0)
  *   set_state(w, lambda, scalars)            points (batch x N; initialize!: x in the first nx entries), lambda (batch x ne), [central_path, fraction_to_boundary, penalty] (batch x 3)
  *   solve(result, ms)                        solve! of every instance: 1 converged, 0 iteration caps, CALIPSO_ERR_INERTIA / CALIPSO_ERR_CONE_SEARCH (the reference's error()s),
