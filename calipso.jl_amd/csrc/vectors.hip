@@ -1109,6 +1109,9 @@ __device__ __forceinline__ double tail_soc_small(const Dims& d, const Scalars& s
     return m;
 }
 
+#ifndef TAIL_EXP
+#define TAIL_EXP 0       // (bench/tail_probe.sh: 1 = no constraint code, 2 = no constraint code and two workgroups per row group, 3 = no mat-vec loads)
+#endif
 constexpr int TAIL_ROWS = 16, TAIL_PARTS = 32, TAIL_CPT = 16;
 __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc bt, Dims d, ConeDev cd, const int* __restrict__ grp, int ngrp, const int* rowrange, const double* __restrict__ Z,
                                                                         const double* __restrict__ dx, const double* w, const double* res, const double* resid, const double* wz,
@@ -1128,7 +1131,11 @@ __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc b
     // workgroup b runs on XCD b % 8 (dispatch order; used for speed only): every XCD takes a CONTIGUOUS eighth of the row groups — the 128-byte runs of 16 rows down a
     // column are not aligned to the cache lines (the leading dimension m is not a multiple of 16), so neighbouring row groups share the lines at their common edge, and
     // share them through an L2 only when they run on the same XCD
+#if TAIL_EXP == 2
+    const int per = (ngrp + 7) / 8, g = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 4), half = ((int)blockIdx.x >> 3) & 1;
+#else
     const int per = (ngrp + 7) / 8, g = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+#endif
     if (g >= ngrp) return;
     const int r0 = grp[g], nrows = grp[g + 1] - r0;
     // ---- t2 rows r0 .. r0 + nrows - 1 ------------------------------------------------------------------------------
@@ -1137,6 +1144,12 @@ __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc b
     // an analysed structure (structure.hip): the columns of the row that can be non-zero — the loads outside are predicated off, the sums are those of the dense rows
     int jlo = 0, jhi = d.nx;
     if (rowrange && live) { jlo = rowrange[2 * (r0 + r)]; jhi = rowrange[2 * (r0 + r) + 1]; }
+#if TAIL_EXP == 2
+    { const int W2 = PARTS * CPT, np2 = (d.nx + W2 - 1) / W2, cut = ((np2 + 1) / 2) * W2; if (half == 0) jhi = cut; else jlo = cut; }
+#endif
+#if TAIL_EXP == 3
+    jhi = 0;
+#endif
     const int npass = (d.nx + W - 1) / W;
     // the first pass's loads go out before dx is staged (they do not depend on it); from then on pass k + 1 travels while pass k is summed: the row is a stream
     // of loads with two batches of CPT in flight, not a chain of round trips
@@ -1177,6 +1190,10 @@ __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc b
         t2s[tid] = s;
     }
     __syncthreads();
+#if TAIL_EXP == 1 || TAIL_EXP == 2
+    if (tid < nrows) t1[r0 + tid] = t2s[tid];
+    return;
+#endif
     // ---- the constraints of these rows --------------------------------------------------------------------------------
     double m = 0.0;
     if (tid < nrows) {
@@ -1210,7 +1227,7 @@ bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool w
     if (lds > 48 * 1024) {
         if (lds > 96 * 1024 || !lds_attribute((const void*)k_solve_tail, 96 * 1024)) return false;      // (> 64 KB of dynamic LDS must be asked for, on every device; refused: the separate kernels)
     }
-    hipLaunchKernelGGL(k_solve_tail, dim3((s->n_zgrp + 7) / 8 * 8, 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), lds, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
+    hipLaunchKernelGGL(k_solve_tail, dim3((s->n_zgrp + 7) / 8 * 8 * (TAIL_EXP == 2 ? 2 : 1), 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), lds, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
                        s->residual, s->wz, s->Wsoc, s->residual_symmetric, s->step_symmetric, st, accumulate ? s->step : (double*)nullptr, s->zsx, s->residual_error, s->t1, s->refpart,
                        which == 0 ? 1 : 2, with_refine ? 1 : 0, s->gate_epoch ? s->gate : (const int*)nullptr, s->gate_epoch);
     s->refine_local_done = with_refine;
