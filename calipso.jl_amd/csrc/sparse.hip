@@ -155,9 +155,12 @@ __global__ void k_sp_permute_out(const double* __restrict__ x, const int* __rest
 // for a T-stage trajectory problem that is ~log2 T launches for the whole factorisation — the stages are eliminated in parallel, level by level.
 // One record per node in LAUNCH order and one per (node, child): what a workgroup needs to find its front comes with ONE load each instead of a chain of
 // dependent table look-ups (order -> nfirst / ncols / nrows -> childptr -> children -> upd_off / rowptr ...: 0.7 us per hop on a cold launch).
-struct MfNode { int s, f, c, r; int rowptr, chfirst, nch, alp0; int alp1, pad0, pad1, pad2; long long panel_off, upd_off, u_off, foff; };
+struct MfNode { int s, f, c, r; int rowptr, chfirst, nch, alp0; int alp1, pad0, pad1, pad2; long long panel_off, upd_off, u_off, foff; int xa0, xa1; };
 // pad0: first row record of a front factored by many workgroups (sparse_wide.hpp; -1: none), pad1: launch position of the parent (-1: a root), pad2: the level's ypan
 struct MfChild { int rc, rowptr; long long upd_off, u_off; int pos, pad; };   // pos: the child's launch position
+// one entry of a child's update matrix on its way into the parent's LDS front (MfNode::xa0 .. xa1, children in ascending order, a child's lower triangle row by row):
+// usrc = its offset in the instance's update pool, tq = its place in the parent's packed front | the child's ordinal << 16
+struct MfXItem { unsigned usrc, tq; };
 struct MfRowItem { long long uoff; int relptr, a, uo, pad; };   // row a of a child's update matrix (offset in the update pool), the child's relative indices, the row's entry of the child's vector (solves)
 struct MfDev {
     int nnodes;
@@ -181,6 +184,7 @@ struct MfDev {
     const int *wptrE, *wptrC;                 // [pad0 + row .. + 1]: ranges in wEcol / wEsrc and in wC
     const int *wEcol, *wEsrc;                 // local column in the front, index into Aval
     const MfRowItem* wC;                      // children in ascending order
+    const MfXItem* xit;                       // extend-add items of the LDS fronts (nullptr: none)
     double* wscr;                             // X, M, L11, D of the diagonal blocks of one level: (matrix, node of the level)
 };
 
@@ -206,20 +210,6 @@ constexpr int MF_MAX_FRONT_GLOBAL = 4095;     // the ONE-workgroup kernels on fr
 __device__ __forceinline__ int tri0(int i) { return (int)(__umul24((unsigned)i, (unsigned)(i + 1)) >> 1); }
 __device__ __forceinline__ int tri(int i, int k) { return tri0(i) + k; }     // i >= k
 
-// rows of a front below the 64 its owner wavefront took (pivot16.hpp): the same rank-1 updates with the pivots already known — the pivot column's rows of the
-// diagonal 16 x 16 block (unscaled, replicated in every 16-lane row) and the reciprocal pivots come from LDS
-template <int J, int NC> __device__ __forceinline__ void mf_follow(double (&a)[16], const double (&yrep)[16], const double (&nrinv)[16]) {
-    if constexpr (J + 1 < NC) {
-        const double nl = a[J] * nrinv[J];
-        asm volatile("s_nop 1" :: "v"(nl));
-#define MF_UPD(K) if constexpr ((K) < NC) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a[(K) & 15]) : "v"(yrep[J]), "v"(nl), "n"((K) & 15))
-        MF_UPD(J + 1); MF_UPD(J + 2); MF_UPD(J + 3); MF_UPD(J + 4); MF_UPD(J + 5); MF_UPD(J + 6); MF_UPD(J + 7); MF_UPD(J + 8);
-        MF_UPD(J + 9); MF_UPD(J + 10); MF_UPD(J + 11); MF_UPD(J + 12); MF_UPD(J + 13); MF_UPD(J + 14); MF_UPD(J + 15);
-#undef MF_UPD
-        mf_follow<J + 1, NC>(a, yrep, nrinv);
-    }
-}
-
 // Optional timeline of one front per level (build with -DCALIPSO_LDL_TRACE: `make trace`; bench/mf_trace.py reads it through calipso_hip_debug_mf_trace):
 // 100 MHz wall-clock stamps of workgroup (0, 0) of every k_mf_factor launch, keyed by the launch's `first` node index.
 #ifdef CALIPSO_LDL_TRACE
@@ -230,6 +220,57 @@ __device__ int g_mf_trace_n;
 #define MF_STAMP(slot) do { } while (0)
 #endif
 
+// The trailing update of one panel (columns kb .. pe - 1, pe - kb = 4 NK) by one wavefront: its 16 x 16 tiles of the lower triangle beyond pe, row-major, every NW-th.
+// F[i][j] -= sum_k (y_ik / d_k) y_jk on the fp64 matrix cores (first operand = scaled rows of the i tile, second = rows of the j tile; two accumulator chains per tile:
+// a dependent v_mfma_f64_16x16x4 issues every 64 cycles).  (bi, bj) advance on scalar registers; a tile needs ONE triangular index per operand and one for its
+// results (the others follow by i -> i + 4: + 4 i + 10); everything is branch-free — rows past the front are clamped for the loads and masked for the stores — so that
+// the operands of the NEXT tile are requested before the matrix instructions of the current one (the panel columns are not written here and two tiles do not overlap):
+// a wavefront's tiles no longer pay an LDS round trip each.
+struct MfTile { double af[4], bf[4], old[4]; int o[4]; bool s[4]; };
+template <int NK>
+__device__ __forceinline__ void mf_tile_load(MfTile& T, const double* __restrict__ F, int m, int kb, int pe, int bi, int bj, int fr, int fk) {
+    const int i0 = pe + 16 * bi + fk, j = pe + 16 * bj + fr;
+    const double* Fa = F + tri0(min(pe + 16 * bi + fr, m - 1)) + kb + fk;
+    const double* Fb = F + tri0(min(j, m - 1)) + kb + fk;
+    int t = tri0(i0);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = i0 + 4 * rr;
+        T.s[rr] = j <= i && i < m;
+        T.o[rr] = T.s[rr] ? t + j : 0;
+        t += 4 * i + 10;
+    }
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) { T.af[kk] = Fa[4 * kk]; T.bf[kk] = Fb[4 * kk]; }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) T.old[rr] = F[T.o[rr]];
+}
+template <int NK, int NW>
+__device__ __forceinline__ void mf_update_tiles(double* __restrict__ F, const double (&rfh)[4], int m, int kb, int pe, int wv, int ntile, int fr, int fk) {
+    if (wv >= ntile) return;
+    int bi = 0, bj = wv;
+    while (bj > bi) { bj -= bi + 1; ++bi; }
+    MfTile A, B;
+    mf_tile_load<NK>(A, F, m, kb, pe, bi, bj, fr, fk);
+    for (int t = wv; t < ntile; t += NW) {
+        if (t + NW < ntile) { bj += NW; while (bj > bi) { bj -= bi + 1; ++bi; } }     // (the last tile requests itself again: no branch around the requests)
+        mf_tile_load<NK>(B, F, m, kb, pe, bi, bj, fr, fk);
+        calipso_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A.af[0] * rfh[0], A.bf[0], acc, 0, 0, 0);
+        if constexpr (NK > 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(A.af[1] * rfh[1], A.bf[1], acc2, 0, 0, 0);
+        if constexpr (NK > 2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A.af[2] * rfh[2], A.bf[2], acc, 0, 0, 0);
+        if constexpr (NK > 3) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(A.af[3] * rfh[3], A.bf[3], acc2, 0, 0, 0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) if (A.s[rr]) F[A.o[rr]] = A.old[rr] - (acc[rr] + acc2[rr]);
+        A = B;
+    }
+}
+// the barriers of the factorisation loop: a front in LDS needs the LDS traffic ordered, not the global stores in flight (the panel of L leaves column block by
+// column block under the loop, and __syncthreads() would wait for every store at every barrier); a front in global memory needs the full one
+template <bool GF> __device__ __forceinline__ void mf_barrier() {
+    if constexpr (GF) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 // one front: assembly, the partial LDL^T of its first c columns, the panel and the update matrix to global memory (every thread of the workgroup arrives)
 template <int MF_THREADS, bool GF>
 __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd, const size_t z, const int ypan, double* __restrict__ Flds, const bool mf_traced, const int mf_tr) {
@@ -243,49 +284,102 @@ __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd,
     double* ycol = GF ? rinvS : F + nt;
     const double* Aval = d.Aval + z * d.sA;
     double* upd = d.upd + z * d.sUpd; double* panel = d.panel + z * d.sPanel; double* Dg = d.D + z * d.sD;
-    for (int e = tid; e < nt; e += MF_THREADS) F[e] = 0.0;
-    __syncthreads();
-    MF_STAMP(1);
-    for (int p = nd.alp0 + tid; p < nd.alp1; p += MF_THREADS) F[d.Aloc[p]] = Aval[d.Asrc[p]];
-    __syncthreads();
-    MF_STAMP(2);
-    for (int q = 0; q < nd.nch; ++q) {                                         // extend-add, children in ascending order
-        const MfChild cr = d.crec[nd.chfirst + q];
-        const int rc = cr.rc;
-        const double* U = upd + cr.upd_off;
-        const int* rel = d.rel + cr.rowptr;
-        if (!GF) { for (int a = tid; a < rc; a += MF_THREADS) relS[a] = rel[a]; }
+    // Assembly.  LDS fronts whose node carries extend-add items (MfXItem, built with the pattern): EVERY global load of the assembly is issued before anything waits —
+    // the node's entries of A (Aloc / Asrc, then the values they point to) and the children's update matrices (items, then the pool entries they name): two memory
+    // round trips for the whole front, the zero fill of the front under the first.  (Before: a round trip per 16 rows of a child, two for the own entries, one after
+    // the other: 10 of a front's 30 us.)  Same operations on every entry in the same order (children ascending; a child's entries land on distinct places), so the
+    // assembled front has the same bits.
+    bool fast = false;
+    if constexpr (!GF) fast = nd.xa0 >= 0;
+    if (fast) {
+        constexpr int AK = 8, XK = 8;
+        const unsigned* __restrict__ xit = reinterpret_cast<const unsigned*>(d.xit);
+        int al[AK], as[AK];
+        uint2 it[XK];
+        const int alast = max(nd.alp1 - 1, 0), xlast = max(nd.xa1 - 1, 0);
+#pragma unroll
+        for (int u = 0; u < AK; ++u) { const int p = min(nd.alp0 + tid + u * MF_THREADS, alast); al[u] = d.Aloc[p]; as[u] = d.Asrc[p]; }
+#pragma unroll
+        for (int u = 0; u < XK; ++u) { const int e = min(nd.xa0 + tid + u * MF_THREADS, xlast); it[u] = reinterpret_cast<const uint2*>(xit)[e]; }
+        unsigned qw0 = xit[2 * (size_t)min(nd.xa0, xlast) + 1], qw1 = xit[2 * (size_t)min(nd.xa0 + XK * MF_THREADS - 1, xlast) + 1];   // first / last child of the chunk
+        for (int e = tid; e < nt; e += MF_THREADS) F[e] = 0.0;
+        double av[AK], uv[XK];
+#pragma unroll
+        for (int u = 0; u < AK; ++u) av[u] = Aval[as[u]];
+#pragma unroll
+        for (int u = 0; u < XK; ++u) uv[u] = upd[it[u].x];
         __syncthreads();
-        if (GF) {
-            for (int a = tid >> 5; a < rc; a += MF_THREADS / 32) {             // a row of the child's update matrix per 32 lanes, coalesced along b
-                const int rla = rel[a];
-                const int ra = tri0(rla);                            // rel is increasing: the lower triangle lands in the lower triangle
-                const double* Ua = U + (size_t)a * rc;
-                for (int b = tid & 31; b <= a; b += 32) F[ra + rel[b]] += Ua[b];
+        MF_STAMP(1);
+#pragma unroll
+        for (int u = 0; u < AK; ++u) if (nd.alp0 + tid + u * MF_THREADS < nd.alp1) F[al[u]] = av[u];
+        for (int p = nd.alp0 + AK * MF_THREADS + tid; p < nd.alp1; p += MF_THREADS) F[d.Aloc[p]] = Aval[d.Asrc[p]];
+        __syncthreads();
+        MF_STAMP(2);
+        for (int cb = nd.xa0; cb < nd.xa1; cb += XK * MF_THREADS) {
+            if (cb > nd.xa0) {
+#pragma unroll
+                for (int u = 0; u < XK; ++u) { const int e = min(cb + tid + u * MF_THREADS, xlast); it[u] = reinterpret_cast<const uint2*>(xit)[e]; }
+#pragma unroll
+                for (int u = 0; u < XK; ++u) uv[u] = upd[it[u].x];
+                qw0 = xit[2 * (size_t)cb + 1]; qw1 = xit[2 * (size_t)min(cb + XK * MF_THREADS - 1, xlast) + 1];
             }
-        } else {
-            // a row of the child's update matrix per 32 lanes (rc <= 196: at most seven chunks of 32 columns); the values of the NEXT row of this lane group
-            // travel while the current one is added into the front (one memory round trip per row otherwise: 7 rows x 0.8 us per child)
-            const int lb = tid & 31;
-            int a = tid >> 5;
-            double uv[7];
+            // the children present in this chunk, in turn (a barrier between two children: both may add to one place, and the order of the sum is the children's)
+            const int qlo = (int)(qw0 >> 16), qhi = (int)(qw1 >> 16);
+            for (int q = qlo; q <= qhi; ++q) {
+                double cur[XK];                                                   // (all reads of the round before its writes: the places of ONE child are distinct)
 #pragma unroll
-            for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; uv[q] = (a < rc && b <= a) ? U[(size_t)a * rc + b] : 0.0; }
-            while (a < rc) {
-                const int an = a + MF_THREADS / 32;
-                double un[7];
+                for (int u = 0; u < XK; ++u) cur[u] = F[it[u].y & 0xffffu];
 #pragma unroll
-                for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; un[q] = (an < rc && b <= an) ? U[(size_t)an * rc + b] : 0.0; }
-                const int rla = relS[a];
-                const int ra = tri0(rla);                            // rel is increasing: the lower triangle lands in the lower triangle
-#pragma unroll
-                for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; if (b <= a) F[ra + relS[b]] += uv[q]; }
-#pragma unroll
-                for (int q = 0; q < 7; ++q) uv[q] = un[q];
-                a = an;
+                for (int u = 0; u < XK; ++u)
+                    if (cb + tid + u * MF_THREADS < nd.xa1 && (int)(it[u].y >> 16) == q) F[it[u].y & 0xffffu] = cur[u] + uv[u];
+                __syncthreads();
             }
         }
+    } else {
+        for (int e = tid; e < nt; e += MF_THREADS) F[e] = 0.0;
         __syncthreads();
+        MF_STAMP(1);
+        for (int p = nd.alp0 + tid; p < nd.alp1; p += MF_THREADS) F[d.Aloc[p]] = Aval[d.Asrc[p]];
+        __syncthreads();
+        MF_STAMP(2);
+        for (int q = 0; q < nd.nch; ++q) {                                         // extend-add, children in ascending order
+            const MfChild cr = d.crec[nd.chfirst + q];
+            const int rc = cr.rc;
+            const double* U = upd + cr.upd_off;
+            const int* rel = d.rel + cr.rowptr;
+            if (!GF) { for (int a = tid; a < rc; a += MF_THREADS) relS[a] = rel[a]; }
+            __syncthreads();
+            if (GF) {
+                for (int a = tid >> 5; a < rc; a += MF_THREADS / 32) {             // a row of the child's update matrix per 32 lanes, coalesced along b
+                    const int rla = rel[a];
+                    const int ra = tri0(rla);                            // rel is increasing: the lower triangle lands in the lower triangle
+                    const double* Ua = U + (size_t)a * rc;
+                    for (int b = tid & 31; b <= a; b += 32) F[ra + rel[b]] += Ua[b];
+                }
+            } else {
+                // a row of the child's update matrix per 32 lanes (rc <= 196: at most seven chunks of 32 columns); the values of the NEXT row of this lane group
+                // travel while the current one is added into the front (one memory round trip per row otherwise: 7 rows x 0.8 us per child)
+                const int lb = tid & 31;
+                int a = tid >> 5;
+                double uv[7];
+    #pragma unroll
+                for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; uv[q] = (a < rc && b <= a) ? U[(size_t)a * rc + b] : 0.0; }
+                while (a < rc) {
+                    const int an = a + MF_THREADS / 32;
+                    double un[7];
+    #pragma unroll
+                    for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; un[q] = (an < rc && b <= an) ? U[(size_t)an * rc + b] : 0.0; }
+                    const int rla = relS[a];
+                    const int ra = tri0(rla);                            // rel is increasing: the lower triangle lands in the lower triangle
+    #pragma unroll
+                    for (int q = 0; q < 7; ++q) { const int b = lb + 32 * q; if (b <= a) F[ra + relS[b]] += uv[q]; }
+    #pragma unroll
+                    for (int q = 0; q < 7; ++q) uv[q] = un[q];
+                    a = an;
+                }
+            }
+            __syncthreads();
+        }
     }
     // Partial dense LDL^T of the first c columns, blocked: panels of 16 columns.
     //   panel   column j is left UNSCALED in F (y_ij = l_ij d_j; nothing overwrites what the other rows still read, so ONE barrier per column);
@@ -293,6 +387,8 @@ __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd,
     //   update  F[i][j] -= sum_k (y_ik / d_k) y_jk over the panel, for every 16 x 16 tile of the trailing lower triangle on the fp64 matrix cores
     //           (v_mfma_f64_16x16x4: first operand = scaled rows of the i tile, second = rows of the j tile, K = 16 = one panel).
     double* rinv = ycol;                                                       // c reciprocal pivots (the 2 m doubles behind the front)
+    double* P = panel + nd.panel_off;                                          // the node's panel of L, column-major m x c: column k contiguous over the rows
+    int p_done = 0;                                                            // columns of it already written
     const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
     MF_STAMP(3);
 #ifdef CALIPSO_LDL_TRACE
@@ -305,21 +401,26 @@ __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd,
 #endif
         if (!GF && ypan && (pe - kb == 16 || pe - kb == 8) && m >= 32) {
             // A full panel through registers (pivot16.hpp; ldl.hip: diag_block has the design notes): wavefront 0 takes rows kb .. kb + 63 with lane = row and
-            // factors the 16 columns alone — no barrier between pivots —; the wavefronts behind it apply the same updates to the rows further down once the
-            // pivots are known.  Three barriers per panel instead of sixteen; the columns stay UNSCALED in the front, as the loop below leaves them.
-            double* Yp = F + nt + 2 * m;                                       // 64 exchange rows of MF_PY doubles (the owner's pivot columns, read back replicated)
+            // factors the 16 columns alone — no barrier between pivots.  The rows further down go to the wavefronts behind it AT THE SAME TIME: wavefront e >= 1 puts the
+            // 16 rows of the diagonal block in its lanes 0 .. 15 and rows kb + 64 + 48 (e - 1) ... in the other 48, and runs the same instruction sequence — the diagonal
+            // block is factored redundantly, to the same bits, so nobody waits for wavefront 0's pivots (m <= 196: at most three such wavefronts; they share the exchange
+            // rows: every writer of a diagonal row writes the same value, the other rows are never read).  Two barriers per panel instead of sixteen; the columns stay
+            // UNSCALED in the front, as the loop below leaves them.  (Before: the rows beyond the first 64 FOLLOWED in a phase of their own, 0.9 us and a barrier per panel.)
+            double* Yp = F + nt + 2 * m;                                       // 64 exchange rows of MF_PY doubles (the pivot columns, read back replicated)
             const bool half = pe - kb == 8;                                    // (a node of 56 columns ends in a half panel)
-            __syncthreads();
-            if (wave == 0) {
-                const int row = kb + lane;
-                const bool in = row < m;
+            mf_barrier<GF>();
+            const int xrow0 = kb + 64 + 48 * (wave - 1);
+            if (wave == 0 || xrow0 < m) {
+                const int row = (wave == 0 || lane < 16) ? kb + lane : xrow0 + lane - 16;
+                const bool in = row < m, mine = wave == 0 || lane >= 16;
                 const int rowc = min(row, m - 1);
                 const int trow = tri0(rowc) + kb;                   // (loads unconditional from a valid address, then selected: no exec-masked blocks)
+                const int below = rowc - kb;                        // columns 0 .. min(below, 15) of the panel exist in this row
                 double a[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = F[trow + min(q, rowc - kb)];
+                for (int q = 0; q < 16; ++q) a[q] = F[trow + min(q, below)];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = (in && lane >= q && (q < 8 || !half)) ? a[q] : 0.0;
+                for (int q = 0; q < 16; ++q) a[q] = (in && below >= q && (q < 8 || !half)) ? a[q] : 0.0;
                 const int drow = min(kb + (lane & 15), m - 1);
                 const double y0 = F[tri0(drow) + kb];
                 const int lo = __builtin_amdgcn_readlane(__double2loint(a[0]), 0), hi = __builtin_amdgcn_readlane(__double2hiint(a[0]), 0);
@@ -327,40 +428,30 @@ __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd,
                                                            calipso::fast_rcp(__hiloint2double(hi, lo)), y0);
                 else calipso::Pivot<0, false, 16>::run(a, (unsigned)(uintptr_t)(Yp + lane * MF_PY), (unsigned)(uintptr_t)(Yp + (lane & 15) * MF_PY), nullptr, 0,
                                                        calipso::fast_rcp(__hiloint2double(hi, lo)), y0);
-                if (in) {
+                if (in && mine) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) if (lane >= q && (q < 8 || !half)) F[trow + q] = a[q];
+                    for (int q = 0; q < 16; ++q) if (below >= q && (q < 8 || !half)) F[trow + q] = a[q];
                 }
-                if (lane < (half ? 8 : 16)) {
+                if (wave == 0 && lane < (half ? 8 : 16)) {
                     double dd = a[0];
 #pragma unroll
                     for (int q = 1; q < 16; ++q) dd = (lane == q) ? a[q] : dd;
                     rinv[kb + lane] = calipso::fast_rcp(dd);
                     Dg[f + kb + lane] = dd;
                 }
-            }
-            __syncthreads();
-            for (int base = kb + 64 * wave; wave >= 1 && base < m; base += 64 * (MF_THREADS / 64 - 1)) {
-                const int row = base + lane;
-                const bool in = row < m;
-                const int rowc = min(row, m - 1);
-                const int trow = tri0(rowc) + kb;
-                const int drow = min(kb + (lane & 15), m - 1);
-                const double* Fd = F + tri0(drow) + kb;
-                double a[16], yrep[16], nrinv[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) { a[q] = F[trow + q]; yrep[q] = Fd[q]; nrinv[q] = rinv[min(kb + q, pe - 1)]; }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) { const bool u = q < 8 || !half; a[q] = (in && u) ? a[q] : 0.0; yrep[q] = u ? yrep[q] : 0.0; nrinv[q] = u ? -nrinv[q] : 0.0; }
-                if (half) mf_follow<0, 8>(a, yrep, nrinv); else mf_follow<0, 16>(a, yrep, nrinv);
-                if (in) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) if (q < 8 || !half) F[trow + q] = a[q];
+            } else {
+                // the wavefronts without rows of this panel send the columns of the panels BEFORE it to the panel of L (they are final, and this step does not touch
+                // them): most of the write-out runs under the pivots instead of in the tail of the kernel
+                const int first_idle = 1 + max(0, (m - kb - 64 + 47) / 48), nidle = MF_THREADS / 64 - first_idle;
+                for (int k = p_done + (wave - first_idle); k < kb; k += nidle) {
+                    const double rk = rinv[k];
+                    for (int i = lane; i < m; i += 64) P[i + (size_t)k * m] = i > k ? F[tri0(i) + k] * rk : 0.0;
                 }
             }
+            if (1 + max(0, (m - kb - 64 + 47) / 48) < MF_THREADS / 64) p_done = kb;
         } else
         for (int j = kb; j < pe; ++j) {
-            __syncthreads();
+            mf_barrier<GF>();
             const double dj = F[tri(j, j)];
             const double rj = 1.0 / dj;
             if (tid == 0) { Dg[f + j] = dj; rinv[j] = rj; }
@@ -375,7 +466,7 @@ __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd,
                 }
             }
         }
-        __syncthreads();
+        mf_barrier<GF>();
 #ifdef CALIPSO_LDL_TRACE
         { const long long t1 = wall_clock64(); mf_pan += t1 - mf_t0; mf_t0 = t1; }
 #endif
@@ -384,7 +475,19 @@ __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd,
         // one (whole tile rows per wavefront left the one with the longest rows 1.7 x the average).  Two accumulator chains per tile (a dependent
         // v_mfma_f64_16x16x4 issues every 64 cycles).
         const int ntile = tri0(ntl);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int nk4 = ((pe - kb) & 3) == 0 ? (pe - kb) >> 2 : 0;            // k-steps of the panel when every lane of a step is inside it (0: the general body below)
+        if (nk4) {
+            double rfh[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) rfh[kk] = rinv[min(kb + 4 * kk + fk, pe - 1)];
+            if (nk4 == 4) mf_update_tiles<4, MF_THREADS / 64>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
+            else if (nk4 == 2) mf_update_tiles<2, MF_THREADS / 64>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
+            else if (nk4 == 3) mf_update_tiles<3, MF_THREADS / 64>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
+            else mf_update_tiles<1, MF_THREADS / 64>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
+        } else
         for (int t = wave; t < ntile; t += MF_THREADS / 64) {
+            // panels whose width is not a multiple of four: every read is unconditional, from a clamped address, the k steps outside the panel are zeroed
             int bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
             while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
             while (tri0(bi) > t) --bi;
@@ -429,18 +532,18 @@ __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd,
             }
         }
 #ifdef CALIPSO_LDL_TRACE
-        __syncthreads();
+        mf_barrier<GF>();
         mf_upd += wall_clock64() - mf_t0;
 #endif
     }
-    __syncthreads();
+    mf_barrier<GF>();
     MF_STAMP(4);
 #ifdef CALIPSO_LDL_TRACE
     if (mf_traced && tid == 0) { g_mf_trace[(mf_tr & 63) * 12 + 8] = mf_pan; g_mf_trace[(mf_tr & 63) * 12 + 9] = mf_upd; }
 #endif
-    double* P = panel + nd.panel_off;                                          // column-major m x c: column k contiguous over the rows
-    // write-out: a wavefront per column of the panel (lanes along the rows: contiguous stores) / per row of the update matrix (lanes along the columns)
-    for (int k = wave; k < c; k += MF_THREADS / 64) {
+    // write-out: what is left of the panel (a wavefront per column, lanes along the rows: contiguous stores) and the update matrix (a wavefront per row, lanes along
+    // the columns)
+    for (int k = p_done + wave; k < c; k += MF_THREADS / 64) {
         const double rk = rinv[k];
         for (int i = lane; i < m; i += 64) P[i + (size_t)k * m] = i > k ? F[tri0(i) + k] * rk : 0.0;
     }
@@ -509,13 +612,25 @@ __device__ __forceinline__ void mf_forward_node(const MfDev& d, const MfNode& nd
     }
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] : 0.0;
     __syncthreads();
-    for (int q = 0; q < nd.nch; ++q) {
-        const MfChild cr = d.crec[nd.chfirst + q];
-        const int rc = cr.rc;
-        const double* u = ubase + cr.u_off;
-        const int* rel = d.rel + cr.rowptr;
-        for (int a = tid; a < rc; a += MF_THREADS) v[rel[a]] += u[a];
+    // the children's contributions, two children at a time: both records, then both children's values and places travel together (one memory round trip per PAIR
+    // after the records instead of one per child); the sums stay in the children's order (a barrier between the two)
+    for (int q = 0; q < nd.nch; q += 2) {
+        const MfChild cr0 = d.crec[nd.chfirst + q];
+        const MfChild cr1 = d.crec[nd.chfirst + min(q + 1, nd.nch - 1)];
+        const int rc0 = cr0.rc, rc1 = q + 1 < nd.nch ? cr1.rc : 0;
+        const double* u0 = ubase + cr0.u_off; const double* u1 = ubase + cr1.u_off;
+        const int* rel0 = d.rel + cr0.rowptr; const int* rel1 = d.rel + cr1.rowptr;
+        const int a0 = min(tid, max(rc0 - 1, 0)), a1 = min(tid, max(rc1 - 1, 0));
+        const double w0 = u0[a0], w1 = rc1 ? u1[a1] : 0.0;
+        const int p0 = rel0[a0], p1 = rc1 ? rel1[a1] : 0;
+        if (tid < rc0) v[p0] += w0;
+        for (int a = tid + MF_THREADS; a < rc0; a += MF_THREADS) v[rel0[a]] += u0[a];
         __syncthreads();
+        if (rc1) {
+            if (tid < rc1) v[p1] += w1;
+            for (int a = tid + MF_THREADS; a < rc1; a += MF_THREADS) v[rel1[a]] += u1[a];
+            __syncthreads();
+        }
     }
     if (wave == 0) {
         double vi = lane < c ? v[lane] : 0.0;
@@ -1259,7 +1374,41 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                     crec.push_back({m_rows[(size_t)ch], m_rowptr[(size_t)ch], m_upd_off[(size_t)ch], m_u_off[(size_t)ch], pos_of[(size_t)ch], 0});
                 }
             }
-            if ((rc = upload(s, nrec, &md.nrec)) || (rc = upload(s, crec, &md.crec))) return rc;
+            // extend-add items of the fronts that live in LDS (k_mf_factor's assembly): per node the entries of its children's update matrices, children ascending, a
+            // child's lower triangle row by row; not built when a node has more than 65535 children or the table would exceed 512 MiB (the row-wise loop then)
+            std::vector<MfXItem> xit;
+            {
+                std::vector<char> lds_front((size_t)NN, 0);
+                for (const MfSeg& g : mplan) for (int q = 0; q < g.count; ++q) lds_front[(size_t)(g.first + q)] = !g.global;
+                size_t total = 0; bool ok = true;
+                for (int pos = 0; pos < NN && ok; ++pos) {
+                    if (!lds_front[(size_t)pos]) continue;
+                    const int t = m_order[(size_t)pos];
+                    if (m_childptr[(size_t)t + 1] - m_childptr[(size_t)t] > 65535) ok = false;
+                    for (int q = m_childptr[(size_t)t]; q < m_childptr[(size_t)t + 1]; ++q) { const size_t rch = (size_t)m_rows[(size_t)m_children[(size_t)q]]; total += rch * (rch + 1) / 2; }
+                }
+                if (ok && total <= ((size_t)512 << 20) / sizeof(MfXItem)) {
+                    xit.reserve(total + 1);
+                    for (int pos = 0; pos < NN; ++pos) {
+                        MfNode& nd = nrec[(size_t)pos];
+                        nd.xa0 = nd.xa1 = -1;
+                        if (!lds_front[(size_t)pos]) continue;
+                        const int t = m_order[(size_t)pos];
+                        nd.xa0 = (int)xit.size();
+                        for (int q = m_childptr[(size_t)t]; q < m_childptr[(size_t)t + 1]; ++q) {
+                            const int ch = m_children[(size_t)q], rch = m_rows[(size_t)ch];
+                            const int* rel = m_rel.data() + m_rowptr[(size_t)ch];
+                            const unsigned ord = (unsigned)(q - m_childptr[(size_t)t]);
+                            for (int a = 0; a < rch; ++a) for (int b = 0; b <= a; ++b)
+                                xit.push_back({(unsigned)(m_upd_off[(size_t)ch] + (long long)a * rch + b), (unsigned)(rel[a] * (rel[a] + 1) / 2 + rel[b]) | (ord << 16)});
+                        }
+                        nd.xa1 = (int)xit.size();
+                    }
+                    if (xit.empty()) xit.push_back({0u, 0u});
+                } else for (MfNode& nd : nrec) nd.xa0 = nd.xa1 = -1;
+            }
+            md.xit = nullptr;
+            if ((rc = upload(s, nrec, &md.nrec)) || (rc = upload(s, crec, &md.crec)) || (!xit.empty() && (rc = upload(s, xit, &md.xit)))) return rc;
         }
         s->pool_total = pool_total; s->wide_count = wide_count;
         for (const MfSeg& g : mplan) if (g.wide.solve) s->wide_blocks = std::max(s->wide_blocks, (g.wide.r + WF_SOLVE_ROWS - 1) / WF_SOLVE_ROWS);
