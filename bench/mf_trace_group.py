@@ -29,9 +29,10 @@ wl.batched_pass()
 n = L.calipso_hip_debug_mf_trace(buf, 0)
 t = np.array(buf[:], dtype=np.int64).reshape(64, 12)
 print("group of %d: %d k_mf_factor launches in one pass" % (G, n))
-print("%6s %4s %4s %7s %7s %7s %7s %7s %7s %8s" % ("launch", "c", "m", "zero", "own", "extend", "panels", "updates", "write", "total"))
+print("%6s %4s %4s %7s %7s %7s %7s %7s %7s %8s %9s" % ("launch", "c", "m", "zero", "own", "extend", "panels", "updates", "write", "total", "core MHz"))
 for k in range(min(n, 64)):
     r = t[k]
     us = lambda a, b: (r[a] - r[b]) / 100.0
-    print("%6d %4d %4d %7.2f %7.2f %7.2f %7.2f %7.2f %7.2f %8.2f" % (k, r[10], r[11], us(1, 0), us(2, 1), us(3, 2), r[8] / 100.0, r[9] / 100.0, us(5, 4), us(5, 0)))
+    print("%6d %4d %4d %7.2f %7.2f %7.2f %7.2f %7.2f %7.2f %8.2f %9.0f" % (k, r[10], r[11], us(1, 0), us(2, 1), us(3, 2), r[8] / 100.0, r[9] / 100.0, us(5, 4), us(5, 0),
+                                                                        (r[7] - r[6]) / max(us(5, 0), 1e-9)))
 wl.close()

@@ -215,9 +215,16 @@ __device__ __forceinline__ int tri(int i, int k) { return tri0(i) + k; }     // 
 #ifdef CALIPSO_LDL_TRACE
 __device__ long long g_mf_trace[64 * 12];
 __device__ int g_mf_trace_n;
-#define MF_STAMP(slot) do { if (mf_traced && threadIdx.x == 0) g_mf_trace[(mf_tr & 63) * 12 + (slot)] = wall_clock64(); } while (0)
+#define MF_STAMP(slot) do { if (mf_traced && threadIdx.x == 0) { g_mf_trace[(mf_tr & 63) * 12 + (slot)] = wall_clock64(); if ((slot) == 0) g_mf_trace[(mf_tr & 63) * 12 + 6] = __builtin_readcyclecounter(); if ((slot) == 5) g_mf_trace[(mf_tr & 63) * 12 + 7] = __builtin_readcyclecounter(); } } while (0)   // ([6], [7]: the core clock's counter at the first and the last stamp)
+// ... and of workgroup (0, 0) of the sweeps' launches (bench/mf_solve_trace.py, calipso_hip_debug_mfs_trace): [0 .. 5] stamps, [6] 0 forward / 1 backward, [7] c | m << 16
+__device__ long long g_mfs_trace[128 * 8];
+__device__ int g_mfs_trace_n;
+#define MFS_BEGIN(kind) __shared__ int mfs_tr_s; const bool mfs_on = blockIdx.x == 0 && blockIdx.y == 0; if (threadIdx.x == 0) mfs_tr_s = mfs_on ? (atomicAdd(&g_mfs_trace_n, 1) & 127) : 0; \
+    __syncthreads(); const int mfs_tr = mfs_tr_s; if (mfs_on && threadIdx.x == 0) { g_mfs_trace[mfs_tr * 8 + 6] = (kind); g_mfs_trace[mfs_tr * 8 + 7] = nd.c | ((nd.c + nd.r) << 16); }
+#define MFS_STAMP(slot) do { if (mfs_on && threadIdx.x == 0) g_mfs_trace[mfs_tr * 8 + (slot)] = wall_clock64(); } while (0)
 #else
 #define MF_STAMP(slot) do { } while (0)
+#define MFS_STAMP(slot) do { } while (0)
 #endif
 
 // The trailing update of one panel (columns kb .. pe - 1, pe - kb = 4 NK) by one wavefront: its 16 x 16 tiles of the lower triangle beyond pe, row-major, every NW-th.
@@ -585,7 +592,8 @@ __device__ __forceinline__ double mf_readlane_d(double v, int lane) {
 // (one node and right-hand side: yi = instance * nrhs + right-hand side, zs = the instance's storage slot; every thread of the workgroup arrives)
 template <int MF_THREADS>
 __device__ __forceinline__ void mf_forward_node(const MfDev& d, const MfNode& nd, const size_t yi, const size_t zs, int n, long long usum, double* __restrict__ X,
-                                                double* __restrict__ sm) {
+                                                double* __restrict__ sm, const bool mfs_on = false, const int mfs_tr = 0) {
+    MFS_STAMP(0);
     const int f = nd.f, c = nd.c, r = nd.r, m = c + r;
     double* v = sm;                                                            // m
     double* part = sm + m;                                                     // 4 r
@@ -612,6 +620,7 @@ __device__ __forceinline__ void mf_forward_node(const MfDev& d, const MfNode& nd
     }
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] : 0.0;
     __syncthreads();
+    MFS_STAMP(1);
     // the children's contributions, two children at a time: both records, then both children's values and places travel together (one memory round trip per PAIR
     // after the records instead of one per child); the sums stay in the children's order (a barrier between the two)
     for (int q = 0; q < nd.nch; q += 2) {
@@ -632,6 +641,7 @@ __device__ __forceinline__ void mf_forward_node(const MfDev& d, const MfNode& nd
             __syncthreads();
         }
     }
+    MFS_STAMP(2);
     if (wave == 0) {
         double vi = lane < c ? v[lane] : 0.0;
 #pragma unroll
@@ -641,6 +651,7 @@ __device__ __forceinline__ void mf_forward_node(const MfDev& d, const MfNode& nd
         if (lane < c) { v[lane] = vi; x[f + lane] = vi; }
     }
     __syncthreads();
+    MFS_STAMP(3);
     for (int idx = tid; idx < 4 * r; idx += MF_THREADS) {
         const int a = idx % r, q4 = idx / r, kbeg = q4 * cs, kend = min(c, kbeg + cs);
         const double* Pi = P + (c + a);
@@ -660,17 +671,25 @@ __device__ __forceinline__ void mf_forward_node(const MfDev& d, const MfNode& nd
     __syncthreads();
     double* u = ubase + nd.u_off;
     for (int a = tid; a < r; a += MF_THREADS) u[a] = v[c + a] - ((part[a] + part[r + a]) + (part[2 * r + a] + part[3 * r + a]));
+    MFS_STAMP(4);
 }
 template <int MF_THREADS, bool GP>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, long long usum, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const MfNode nd = d.nrec[first + blockIdx.x];                              // blockIdx.y = instance * nrhs + right-hand side
+#ifdef CALIPSO_LDL_TRACE
+    MFS_BEGIN(0)
+    mf_forward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, usum, X, sm, mfs_on, mfs_tr);
+#else
     mf_forward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, usum, X, sm);
+#endif
 }
 // backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C.  One wavefront per column for the product with L21'
 // (lanes along the rows, contiguous), then the c dependent steps in one wavefront (lane = column, x_i by v_readlane).
 template <int MF_THREADS>
-__device__ __forceinline__ void mf_backward_node(const MfDev& d, const MfNode& nd, const size_t yi, const size_t zs, int n, double* __restrict__ X, double* __restrict__ sm) {
+__device__ __forceinline__ void mf_backward_node(const MfDev& d, const MfNode& nd, const size_t yi, const size_t zs, int n, double* __restrict__ X, double* __restrict__ sm,
+                                                 const bool mfs_on = false, const int mfs_tr = 0) {
+    MFS_STAMP(0);
     const int f = nd.f, c = nd.c, r = nd.r, m = c + r;
     double* v = sm;
     double* x = X + yi * n;
@@ -691,6 +710,7 @@ __device__ __forceinline__ void mf_backward_node(const MfDev& d, const MfNode& n
     }
     for (int i = tid; i < m; i += MF_THREADS) v[i] = i < c ? x[f + i] / Dg[f + i] : x[R[i - c]];
     __syncthreads();
+    MFS_STAMP(1);
     {
         double acc[CPW];
 #pragma unroll
@@ -717,6 +737,7 @@ __device__ __forceinline__ void mf_backward_node(const MfDev& d, const MfNode& n
         }
     }
     __syncthreads();
+    MFS_STAMP(2);
     if (wave == 0) {
         double zk = lane < c ? v[lane] : 0.0;
 #pragma unroll
@@ -725,12 +746,18 @@ __device__ __forceinline__ void mf_backward_node(const MfDev& d, const MfNode& n
         for (int q = 0; q < 32; ++q) { const int i = c - 33 - q; if (i >= 1) zk = fma(-pl1[q], mf_readlane_d(zk, i), zk); }
         if (lane < c) x[f + lane] = zk;
     }
+    MFS_STAMP(3); MFS_STAMP(4);
 }
 template <int MF_THREADS, bool GP>
 __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const MfSlots sl, int first, int n, int nrhs, double* __restrict__ X) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const MfNode nd = d.nrec[first + blockIdx.x];
+#ifdef CALIPSO_LDL_TRACE
+    MFS_BEGIN(1)
+    mf_backward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, X, sm, mfs_on, mfs_tr);
+#else
     mf_backward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, X, sm);
+#endif
 }
 
 #include "sparse_wide.hpp"
@@ -1016,6 +1043,13 @@ extern "C" int32_t calipso_hip_debug_mf_trace(long long* out, int32_t reset) {
     int n = 0;
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_mf_trace_n), sizeof(int)) != hipSuccess) return -1;
     if (reset) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mf_trace_n), &z, sizeof(int)); }
+    return n;
+}
+extern "C" int32_t calipso_hip_debug_mfs_trace(long long* out, int32_t reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mfs_trace), sizeof(long long) * 128 * 8) != hipSuccess) return -1;
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_mfs_trace_n), sizeof(int)) != hipSuccess) return -1;
+    if (reset) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mfs_trace_n), &z, sizeof(int)); }
     return n;
 }
 #endif
