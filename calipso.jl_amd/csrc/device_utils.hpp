@@ -25,6 +25,35 @@ __device__ __forceinline__ double wave_max(double v) {
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
     return v;
 }
+// The same reductions with the result in LANE 63 only, by data-parallel moves on the vector unit: four shifts inside the rows of 16 lanes, then two row broadcasts.
+// __shfl_down above is two ds_bpermute through the LDS pipeline per step and each step waits for the one before (~0.4 us per sum): where a kernel is a chain of short
+// dependent phases (the multifrontal sweeps, the small-problem solve! kernel) these are what to call.  (Another summation order: other bits than wave_sum.)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_moved(double v) {     // the value from the lane the control names; 0 where there is none or the row is masked
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_l63(double v) {
+    v += dpp_moved<0x111, 0xf>(v);                                            // row_shr:1
+    v += dpp_moved<0x112, 0xf>(v);                                            // row_shr:2
+    v += dpp_moved<0x114, 0xf>(v);                                            // row_shr:4
+    v += dpp_moved<0x118, 0xf>(v);                                            // row_shr:8   -> lane 15 of every row holds the row's sum
+    v += dpp_moved<0x142, 0xa>(v);                                            // row_bcast:15 into rows 1 and 3
+    v += dpp_moved<0x143, 0xc>(v);                                            // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_moved_or_own(double v) {     // ... the lane's own value where there is none
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false), hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_l63(double v) {
+    v = fmax(v, dpp_moved_or_own<0x111, 0xf>(v));
+    v = fmax(v, dpp_moved_or_own<0x112, 0xf>(v));
+    v = fmax(v, dpp_moved_or_own<0x114, 0xf>(v));
+    v = fmax(v, dpp_moved_or_own<0x118, 0xf>(v));
+    v = fmax(v, dpp_moved_or_own<0x142, 0xa>(v));
+    v = fmax(v, dpp_moved_or_own<0x143, 0xc>(v));
+    return v;
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

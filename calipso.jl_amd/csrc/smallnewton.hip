@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "internal.hpp"
+#include "device_utils.hpp"
 
 struct calipso_hip_smallnewton {
     int nx = 0, ne = 0, nc = 0, batch = 0, device = 0;

@@ -5,21 +5,14 @@ constexpr int NT = SN_THREADS, NW = NT / 64;
 static_assert(NT == 64 || NT == 128 || NT == 256, "one, two or four wavefronts per instance");
 
 // ---- workgroup-wide reductions (every thread calls; all get the result) ----------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
+// (result in lane 63 only; data-parallel moves, not shuffles through the LDS pipeline: device_utils.hpp)
+__device__ __forceinline__ double wave_sum(double v) { return calipso::wave_sum_l63(v); }
+__device__ __forceinline__ double wave_max(double v) { return calipso::wave_max_l63(v); }
 template <int K> __device__ __forceinline__ void block_sum(double (&v)[K], double* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) { const double s = wave_sum(v[k]); if (lane == 0) red[k * 4 + wave] = s; }
+    for (int k = 0; k < K; ++k) { const double s = wave_sum(v[k]); if (lane == 63) red[k * 4 + wave] = s; }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; ++k) { double t = red[k * 4]; for (int w = 1; w < NW; ++w) t += red[k * 4 + w]; v[k] = t; }
@@ -28,7 +21,7 @@ template <int K> __device__ __forceinline__ void block_max(double (&v)[K], doubl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) { const double s = wave_max(v[k]); if (lane == 0) red[k * 4 + wave] = s; }
+    for (int k = 0; k < K; ++k) { const double s = wave_max(v[k]); if (lane == 63) red[k * 4 + wave] = s; }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; ++k) { double t = red[k * 4]; for (int w = 1; w < NW; ++w) t = fmax(t, red[k * 4 + w]); v[k] = t; }
@@ -39,9 +32,9 @@ template <int KS, int KM> __device__ __forceinline__ void block_sum_max(double (
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < KS; ++k) { const double s = wave_sum(sv[k]); if (lane == 0) red[k * 4 + wave] = s; }
+    for (int k = 0; k < KS; ++k) { const double s = wave_sum(sv[k]); if (lane == 63) red[k * 4 + wave] = s; }
 #pragma unroll
-    for (int k = 0; k < KM; ++k) { const double s = wave_max(mv[k]); if (lane == 0) red[(KS + k) * 4 + wave] = s; }
+    for (int k = 0; k < KM; ++k) { const double s = wave_max(mv[k]); if (lane == 63) red[(KS + k) * 4 + wave] = s; }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KS; ++k) { double t = red[k * 4]; for (int w = 1; w < NW; ++w) t += red[k * 4 + w]; sv[k] = t; }

@@ -684,21 +684,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_forward(const MfDev d, const 
     mf_forward_node<MF_THREADS>(d, nd, (size_t)blockIdx.y, (size_t)(sl.use ? sl.slot[blockIdx.y / nrhs] : (int)(blockIdx.y / nrhs)), n, usum, X, sm);
 #endif
 }
-// Sum over the 64 lanes of a wavefront, valid in LANE 63: four shifts inside the rows of 16 lanes and two row broadcasts, all data-parallel moves on the vector unit
-// (calipso::wave_sum's __shfl_down is two ds_bpermute per step through the LDS pipeline: 16 sums per wavefront were 3.8 of a backward node's 8 us, bench/mf_solve_trace.py)
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ double mf_dpp_add(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
-    return v + __hiloint2double(hi, lo);                                      // (lanes without a source, or outside the row mask, add zero)
-}
-__device__ __forceinline__ double mf_wave_sum63(double v) {
-    v = mf_dpp_add<0x111, 0xf>(v);                                            // row_shr:1
-    v = mf_dpp_add<0x112, 0xf>(v);                                            // row_shr:2
-    v = mf_dpp_add<0x114, 0xf>(v);                                            // row_shr:4
-    v = mf_dpp_add<0x118, 0xf>(v);                                            // row_shr:8   -> lane 15 of every row holds the row's sum
-    v = mf_dpp_add<0x142, 0xa>(v);                                            // row_bcast:15 into rows 1 and 3
-    v = mf_dpp_add<0x143, 0xc>(v);                                            // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    return v;
-}
 // backward: z_C = y_C / D_C - L21' x_R (x_R final: it belongs to ancestors);  x_C = L11^-T z_C.  One wavefront per column for the product with L21'
 // (lanes along the rows, contiguous), then the c dependent steps in one wavefront (lane = column, x_i by v_readlane).
 template <int MF_THREADS>
@@ -747,7 +732,7 @@ __device__ __forceinline__ void mf_backward_node(const MfDev& d, const MfNode& n
 #pragma unroll
         for (int q = 0; q < CPW; ++q) {
             const int k = wave + NW * q;
-            const double t = mf_wave_sum63(acc[q]);
+            const double t = calipso::wave_sum_l63(acc[q]);     // (16 sums per wavefront: by __shfl_down they were 3.8 of a node's 8 us, bench/mf_solve_trace.py)
             if (lane == 63 && k < c) v[k] -= t;
         }
     }
