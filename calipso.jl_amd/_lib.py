@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcalipso_hip.so")
+LIB_PATH = os.environ.get("CALIPSO_HIP_LIB") or os.path.join(_HERE, "libcalipso_hip.so")   # (CALIPSO_HIP_LIB: another build of the same library, for A/B timing)
 _LIB = None
 
 EVAL_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -14,17 +14,7 @@ template <typename... P> __device__ __forceinline__ void inst_shift_i(const Batc
     ((p += o), ...);
 }
 
-// ---- wave64 reductions by DPP/shuffle (a CDNA wavefront is 64 lanes) ------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
-    return v;
-}
+// ---- wave64 reductions (a CDNA wavefront is 64 lanes) ------------------------------------------------
 // The same reductions with the result in LANE 63 only, by data-parallel moves on the vector unit: four shifts inside the rows of 16 lanes, then two row broadcasts.
 // __shfl_down above is two ds_bpermute through the LDS pipeline per step and each step waits for the one before (~0.4 us per sum): where a kernel is a chain of short
 // dependent phases (the multifrontal sweeps, the small-problem solve! kernel) these are what to call.  (Another summation order: other bits than wave_sum.)
@@ -54,6 +44,12 @@ __device__ __forceinline__ double wave_max_l63(double v) {
     v = fmax(v, dpp_moved_or_own<0x143, 0xc>(v));
     return v;
 }
+// ... and in EVERY lane (what the callers that read lane 0, or broadcast it, expect): the total travels from lane 63 through a scalar register
+__device__ __forceinline__ double from_lane63(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ double wave_sum(double v) { return from_lane63(wave_sum_l63(v)); }
+__device__ __forceinline__ double wave_max(double v) { return from_lane63(wave_max_l63(v)); }
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -763,6 +763,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_mf_backward(const MfDev d, const
 #include "sparse_wide.hpp"
 
 int g_wide_fronts = 1;         // calipso_hip_debug_wide_fronts: 0 = the one-workgroup kernel for the global-memory fronts too (plans made afterwards)
+static int g_mf_items = 1;      // extend-add items for the LDS fronts (calipso_hip_debug_mf_items)
 struct MfSeg { int first, count; size_t lds_factor, lds_solve; int threads; bool global; int ypan; MfWide wide; };   // ypan: room for the 64 x MF_PY exchange rows of the in-register panels
 // launch helpers: the thread count of a level is fixed by the analyse phase (MfSeg::threads)
 #define MF_LAUNCH(KERNEL, G, GRID, LDS, STREAM, ...)                                                                              \
@@ -1036,6 +1037,8 @@ void sparse_describe(const calipso_hip_sparse* sp, int64_t out[4]) { out[0] = sp
 
 // (tests / A-B timing) how plans made AFTERWARDS treat fronts beyond the LDS: 1 = many workgroups per front (default), 0 = one; returns the old value
 // (tests / A-B timing) how plans made AFTERWARDS treat fronts beyond the LDS: 1 = many workgroups per front (default), 0 = one; returns the old value
+// (tests / A-B timing) whether plans made AFTERWARDS carry the extend-add items of the LDS fronts (1, default) or assemble child by child, row by row (0); returns the old value
+extern "C" int32_t calipso_hip_debug_mf_items(int32_t on) { const int was = g_mf_items; if (on >= 0) g_mf_items = on != 0; return was; }
 extern "C" int32_t calipso_hip_debug_wide_fronts(int32_t on) { const int was = g_wide_fronts; if (on >= 0) g_wide_fronts = on != 0; return was; }
 #ifdef CALIPSO_LDL_TRACE
 extern "C" int32_t calipso_hip_debug_mf_trace(long long* out, int32_t reset) {
@@ -1421,7 +1424,7 @@ static int32_t sparse_create_impl(int64_t n, const int64_t* colptr, const int64_
                     if (m_childptr[(size_t)t + 1] - m_childptr[(size_t)t] > 65535) ok = false;
                     for (int q = m_childptr[(size_t)t]; q < m_childptr[(size_t)t + 1]; ++q) { const size_t rch = (size_t)m_rows[(size_t)m_children[(size_t)q]]; total += rch * (rch + 1) / 2; }
                 }
-                if (ok && total <= ((size_t)512 << 20) / sizeof(MfXItem)) {
+                if (ok && g_mf_items && total <= ((size_t)512 << 20) / sizeof(MfXItem)) {
                     xit.reserve(total + 1);
                     for (int pos = 0; pos < NN; ++pos) {
                         MfNode& nd = nrec[(size_t)pos];

@@ -603,3 +603,51 @@ def test_wide_fronts_by_many_workgroups_match_the_one_workgroup_kernel_and_the_o
         Sq.close()
     finally:
         _wide_fronts(pkg, was)
+
+
+def _mf_items(pkg, on):
+    """calipso_hip_debug_mf_items: plans made afterwards carry the extend-add items of the LDS fronts (1, the default) or assemble child by child (0); returns the old value"""
+    fn = pkg._lib.lib().calipso_hip_debug_mf_items
+    fn.restype = C.c_int32
+    return fn(C.c_int32(on))
+
+
+@pytest.mark.parametrize("shape", [(41, 20, 8), (24, 5, 2), (64, 6, 2), (12, 40, 8)])
+def test_assembly_through_extend_add_items_has_the_bits_of_the_row_wise_assembly(oracle_mod, shape):
+    """round 6: an LDS front is assembled from a list of (pool entry, place in the front) items built with the pattern — every global load of the assembly in
+    flight at once — instead of child by child and row by row; the operations on every entry and their order are the same, so L, D and a solve are the SAME
+    BITS with and without the items (and equal the oracle's QDLDL to 1e-11), alone and in a batch.  Shapes: C4T-like stages (fronts of 56 / 112 / 168 rows: the
+    512-thread kernel, half panels), small stages (256-thread kernel), a deep tree, wide stages."""
+    pkg = load_pkg()
+    T, ns, nu = shape
+    rng = np.random.default_rng(100 + T)
+    K = staged_kkt(T, ns, nu, rng)
+    A = sp.triu(K).tocsc(); A.sort_indices()
+    n = K.shape[0]
+    b = rng.standard_normal(n)
+    out = {}
+    was = _mf_items(pkg, 1)
+    try:
+        for on in (1, 0):
+            _mf_items(pkg, on)
+            S = pkg.SparseLDL(A, method="nested_dissection")
+            assert S.info["numeric"] == "multifrontal"
+            assert S.factorize(A) == 0
+            perm, Lm, D = S.factor()
+            x = S.solve(b)
+            S.set_batch(3)
+            vals = np.stack([A.data, A.data * 1.0, A.data])
+            assert S.factorize(vals) == 0
+            S.select(2)
+            _, Lb, Db = S.factor()
+            out[on] = (perm, Lm.toarray(), D, x, Lb.toarray(), Db)
+            S.close()
+    finally:
+        _mf_items(pkg, was)
+    for k in range(6):
+        assert np.array_equal(out[1][k], out[0][k]), k
+    assert np.array_equal(out[1][1], out[1][4]) and np.array_equal(out[1][2], out[1][5])          # a batch member has the bits of the matrix alone
+    ref = oracle_factor(oracle_mod, K.toarray(), out[1][0])
+    assert np.abs(out[1][2] - ref["D"]).max() <= 1e-11 * np.abs(ref["D"]).max()
+    assert abs(out[1][1] - ref["L"]).max() <= 1e-11 * max(1.0, abs(ref["L"]).max())
+    assert np.abs(K @ out[1][3] - b).max() <= 1e-8 * max(1.0, np.abs(out[1][3]).max())
