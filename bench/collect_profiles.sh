@@ -22,6 +22,9 @@ cpy lfac_sizes.txt lfac_sizes.txt
 cpy ldl_chain_timeline.txt ldl_chain_timeline_right_looking.txt
 cpy mf_trace.txt mf_front_timeline.txt
 cpy mf_trace_group.txt mf_front_timeline_group.txt
+cpy mf_solve_trace.txt mf_solve_timeline.txt
+cpy c4t_group_stats.txt c4t_group_stats.txt
+cpy pmc_mf_factor.txt pmc_mf_factor.txt
 cpy ldl_bulk_trace.txt ldl_bulk_trace.txt
 cpy step_gaps_under_rocprof.txt step_gaps_under_rocprof.txt
 cpy diag_bench3.txt diag_bench3.txt

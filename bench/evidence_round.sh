@@ -20,6 +20,9 @@ timeout 600 python bench/lfac_sizes.py > $O/lfac_sizes.txt 2>&1          # left-
 CALIPSO_HIP_LFAC=0 timeout 300 python bench/ldl_trace.py > $O/ldl_chain_timeline.txt 2>&1      # the right-looking chain (what a group's members take), stamped build
 timeout 300 python bench/mf_trace.py > $O/mf_trace.txt 2>&1
 for g in 1 16 64; do timeout 200 python bench/mf_trace_group.py $g 2> /dev/null | head -9; done > $O/mf_trace_group.txt      # the same front while a group's other fronts run beside it
+timeout 200 python bench/mf_solve_trace.py 16 2> /dev/null > $O/mf_solve_trace.txt      # the phases of the sweeps' launches (forward / backward) in a group of 16
+bash bench/c4t_group_stats.sh > $O/c4t_group_stats.txt 2>&1                                 # kernel time per group step of 16 C4T members
+bash bench/pmc_mf_factor.sh > $O/pmc_mf_factor.txt 2>&1                                    # counters of k_mf_factor (a group of 16)
 timeout 300 python bench/ldl_bulk_trace.py 12 > $O/ldl_bulk_trace.txt 2>&1
 bash bench/step_gaps.sh > /dev/null 2>&1; cp gpurun_out/step_gaps.txt $O/step_gaps_under_rocprof.txt
 timeout 300 python bench/wide_fronts.py 1500 5 > $O/wide_fronts.txt 2>&1      # fronts beyond the LDS: many workgroups per front against one (sparse_wide.hpp)

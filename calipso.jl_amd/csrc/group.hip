@@ -639,10 +639,12 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
     std::vector<calipso::i64> fi(B, 0);
     g_activate(g, all);
     if (!advance) {
-        copy_d(s, s->saved_point, s->solution, d.N);
-        copy_d(s, s->saved_g, s->g, d.ne);
-        copy_d(s, s->saved_h, s->hc, d.nc);
-        copy_d(s, s->dscal + 32, s->dscal, 2);
+        {   // (one launch, as for a single handle: api.hip)
+            double* const dst[4] = {s->saved_point, s->saved_g, s->saved_h, s->dscal + 32};
+            const double* const src[4] = {s->solution, s->g, s->hc, s->dscal};
+            const size_t n[4] = {(size_t)d.N, (size_t)d.ne, (size_t)d.nc, 2};
+            copy4_d(s, dst, src, n);
+        }
         for (int i : all) { H* h = g->hs[i]; saved_sc[i] = h->sc; ft[i] = h->filter_theta; fm[i] = h->filter_merit; fi[i] = h->filter_index; }
     }
     std::vector<IterInfo> info(B);
@@ -653,10 +655,12 @@ int32_t calipso_hip_group_newton_step(calipso_hip_group* g, int32_t advance, dou
     if (e < 0) return e;
     if (!advance) {
         g_activate(g, all);
-        copy_d(s, s->solution, s->saved_point, d.N);
-        copy_d(s, s->g, s->saved_g, d.ne);
-        copy_d(s, s->hc, s->saved_h, d.nc);
-        copy_d(s, s->dscal, s->dscal + 32, 2);
+        {
+            double* const dst[4] = {s->solution, s->g, s->hc, s->dscal};
+            const double* const src[4] = {s->saved_point, s->saved_g, s->saved_h, s->dscal + 32};
+            const size_t n[4] = {(size_t)d.N, (size_t)d.ne, (size_t)d.nc, 2};
+            copy4_d(s, dst, src, n);
+        }
         launch_cone(s, s->solution, CALIPSO_CONE_PRODUCT);
         for (int i : all) {
             H* h = g->hs[i];
