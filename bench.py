@@ -205,6 +205,20 @@ def config_small_newton(pkg, pr, device, cpu=True, batch=4096, steps=20):
            "kernel": {"threads_per_instance": int(dsc[0]), "lds_bytes_per_instance": int(dsc[1]), "instances_per_compute_unit": int(dsc[2]), "compute_units": int(dsc[3])},
            "solve": {"launch_ms": ms, "converged": int((res == 1).sum()), "solves_per_s": batch / (ms * 1e-3), "newton_steps_per_s": float(nst.sum()) / (ms * 1e-3),
                      "mean_newton_iterations": float(its.mean()), "max_refinement_rounds": int(stt["counters"]["max_refinement_rounds"].max())}}
+    # differentiate! of the whole batch at its solutions, one launch (differentiate.jl:1-61): C5's 102 parameter columns, dR/dtheta the same for all instances
+    try:
+        N, pcol = nx + 2 * ne + 3 * nc, 102
+        Jp = np.zeros((N, pcol)); Jp[:nx, :nx] = np.eye(nx); Jp[nx + ne + nc:nx + 2 * ne + nc, nx:nx + ne] = -np.eye(ne); Jp[:nx, nx + ne:] = rng.standard_normal((nx, pcol - nx - ne))
+        msd, ok = 1e30, 0
+        for _ in range(3):
+            Sens, std, m1 = sn.differentiate(Jp)
+            msd = min(msd, m1); ok = int((std == 0).sum())
+        out["differentiate"] = {"columns": pcol, "launch_ms": msd, "differentiates_per_s": batch / (msd * 1e-3), "back_solves_per_s": batch * pcol / (msd * 1e-3), "inertia_ok": ok,
+                                "finite": bool(np.isfinite(Sens).all()), "note": "kernel time (HIP events); every column refined (iterative_refinement.jl:1-52); the general path's differentiate! of ONE C5 "
+                                "problem: config.c5 (GPU 0.6 ms, oracle 4.9 ms)"}
+        del Sens
+    except Exception as e:
+        out["differentiate"] = {"error": repr(e)}
     w = stt["solution"].copy()
     w[:, :nx] += 0.05 * rng.standard_normal((batch, nx))
     sn.set_state(w=w, scalars=np.tile([0.17, 0.99, 52.0], (batch, 1)))

@@ -902,6 +902,23 @@ class SmallNewtonBatch:
         self._check(self._L.calipso_hip_smallnewton_steps(self._h, int(count), int(bool(advance)), _pd(info), st.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms)), "smallnewton_steps")
         return info.reshape(self.batch, 8), st, float(ms.value)
 
+    def differentiate(self, jacobian_parameters):
+        """differentiate! of every instance at its resident point, one launch (differentiate.jl:1-61): jacobian_parameters (batch, N, p) = dR/dtheta per instance, or
+        (N, p) = one matrix for all instances; returns (sensitivity (batch, N, p) = dw/dtheta, status (batch,) — 1: the factorisation's inertia is not
+        (nx, ne + nc, 0) —, launch milliseconds)"""
+        J = np.asarray(jacobian_parameters, dtype=np.float64)
+        N = self.nx + 2 * self.ne + 3 * self.nc
+        shared = J.ndim == 2
+        if shared:
+            J = J[None]
+        if J.ndim != 3 or J.shape[0] != (1 if shared else self.batch) or J.shape[1] != N:
+            raise ValueError("jacobian_parameters must be (batch, N, p) or (N, p)")
+        p = J.shape[2]
+        Jc = np.ascontiguousarray(np.transpose(J, (0, 2, 1))).ravel()          # per instance column-major N x p
+        out = np.zeros(self.batch * N * p); st = np.zeros(self.batch, dtype=np.int32); ms = C.c_double(0.0)
+        self._check(self._L.calipso_hip_smallnewton_differentiate(self._h, int(p), int(shared), _pd(Jc), _pd(out), st.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms)), "smallnewton_differentiate")
+        return np.transpose(out.reshape(self.batch, p, N), (0, 2, 1)).copy(), st, float(ms.value)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.calipso_hip_smallnewton_destroy(self._h)

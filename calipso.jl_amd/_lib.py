@@ -111,6 +111,7 @@ SYMBOLS = {
     "calipso_hip_smallnewton_trace": (_i32, [_vp, _i32, _pd]),
     "calipso_hip_smallnewton_solve": (_i32, [_vp, _pi32, _pd]),
     "calipso_hip_smallnewton_steps": (_i32, [_vp, _i32, _i32, _pd, _pi32, _pd]),
+    "calipso_hip_smallnewton_differentiate": (_i32, [_vp, _i64, _i32, _pd, _pd, _pi32, _pd]),
     "calipso_hip_comm_unique_id": (_i32, [C.POINTER(C.c_uint8)]),
     "calipso_hip_comm_init": (_i32, [_i32, _i32, C.POINTER(C.c_uint8), _i32, C.POINTER(_vp)]),
     "calipso_hip_comm_destroy": (_i32, [_vp]),

@@ -35,6 +35,7 @@ struct calipso_hip_smallnewton {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *P = nullptr, *q = nullptr, *Z = nullptr, *bh = nullptr;      // Lxx = 2 c P (nx x nx), q, Z = [A; -G] (m x nx, ld m), bh = [-b; h]: per instance or shared
     double *w = nullptr, *lam = nullptr, *sc = nullptr, *filt = nullptr, *info = nullptr, *trace = nullptr, *prof = nullptr;
+    double *rtheta = nullptr, *sens = nullptr, *stf = nullptr; size_t cap_diff = 0; bool diff_shared = false;      // differentiate!: batch x N x p each
     long long* cnt = nullptr; int* status = nullptr;
     int trace_rows = 0;
     size_t lds_bytes = 0;
@@ -53,7 +54,7 @@ typedef calipso_hip_smallnewton SN;
 enum { SC_KAPPA = 0, SC_TAU, SC_RHO, SC_EP, SC_EPLAST, SC_ED, SC_EQV, SC_CPV, SC_F, SC_COUNT = 16 };
 enum { CN_TOTAL = 0, CN_OUTER, CN_INNER, CN_FACT, CN_RFAIL, CN_RMAX, CN_RLAST, CN_STEPS, CN_FILTER, CN_TRACE, CN_COUNT = 16 };
 enum { IN_STEP = 0, IN_STEP_T, IN_ROUNDS, IN_NFACT, IN_MH, IN_THETAH, IN_EXIT, IN_OPT, IN_COUNT = 8 };
-enum { MODE_SOLVE = 0, MODE_STEPS = 1 };
+enum { MODE_SOLVE = 0, MODE_STEPS = 1, MODE_DIFF = 2 };
 
 struct Dm {
     int nx, ne, nc, m, n, N, ldz, q, nsoc, wsz, maxd;      // q nonnegative entries first, then nsoc second-order cones (contiguous ranges); wsz = sum of dim^2; ldz: leading dimension of Z in LDS (odd: conflict-free column walks)
@@ -88,6 +89,8 @@ struct Args {
     double *w, *lam, *sc, *filt, *info, *trace, *prof; long long* cnt; int* status;
     const int *soc_start, *soc_dim, *soc_woff;      // per second-order cone: first cone-local index, dimension, offset of its dim x dim blocks
     int batch, mode, count, advance, trace_rows;
+    double* stf;                                    // batch x 2 nc: s and t at the last search direction (smallnewton_device.hpp: quirk B-7)
+    const double* rtheta; double* sens; long long srtheta;             // differentiate!: dR/dtheta and the sensitivities, per instance N x count, column-major
 };
 
 // the device code, once per workgroup size (launch() picks: sn_threads())
@@ -133,6 +136,9 @@ int grant_lds(SN* s) {
     (void)calipso::lds_attribute((const void*)t64::k_smallnewton<false>, 160 * 1024); (void)calipso::lds_attribute((const void*)t64::k_smallnewton<true>, 160 * 1024);
     (void)calipso::lds_attribute((const void*)t128::k_smallnewton<false>, 160 * 1024); (void)calipso::lds_attribute((const void*)t128::k_smallnewton<true>, 160 * 1024);
     (void)calipso::lds_attribute((const void*)t256::k_smallnewton<false>, 160 * 1024); (void)calipso::lds_attribute((const void*)t256::k_smallnewton<true>, 160 * 1024);
+    (void)calipso::lds_attribute((const void*)t64::k_smallnewton_diff<false>, 160 * 1024); (void)calipso::lds_attribute((const void*)t64::k_smallnewton_diff<true>, 160 * 1024);
+    (void)calipso::lds_attribute((const void*)t128::k_smallnewton_diff<false>, 160 * 1024); (void)calipso::lds_attribute((const void*)t128::k_smallnewton_diff<true>, 160 * 1024);
+    (void)calipso::lds_attribute((const void*)t256::k_smallnewton_diff<false>, 160 * 1024); (void)calipso::lds_attribute((const void*)t256::k_smallnewton_diff<true>, 160 * 1024);
     return CALIPSO_OK;
 }
 
@@ -148,10 +154,22 @@ int launch(SN* s, int mode, int count, int advance) {
     a.w = s->w; a.lam = s->lam; a.sc = s->sc; a.filt = s->filt; a.info = s->info; a.trace = s->trace; a.prof = s->prof; a.cnt = s->cnt; a.status = s->status;
     { const int ns = (int)s->soc_dim.size(); a.soc_start = s->d_soc; a.soc_dim = s->d_soc ? s->d_soc + ns : nullptr; a.soc_woff = s->d_soc ? s->d_soc + 2 * ns : nullptr; }
     a.batch = s->batch; a.mode = mode; a.count = count; a.advance = advance; a.trace_rows = s->trace_rows;
+    a.rtheta = s->rtheta; a.sens = s->sens; a.stf = s->stf; a.srtheta = s->diff_shared ? 0 : (long long)a.d.N * (long long)count;
     static_assert(sizeof(Args) <= 3800, "kernel arguments");
     SK(hipEventRecord(s->ev0, s->stream));
     const bool soc = !s->soc_dim.empty();
-    if (sn_threads(s) == 64) {
+    if (mode == MODE_DIFF) {
+        if (sn_threads(s) == 64) {
+            if (soc) hipLaunchKernelGGL(t64::k_smallnewton_diff<true>, dim3((unsigned)s->batch), dim3(64), s->lds_bytes, s->stream, a);
+            else hipLaunchKernelGGL(t64::k_smallnewton_diff<false>, dim3((unsigned)s->batch), dim3(64), s->lds_bytes, s->stream, a);
+        } else if (sn_threads(s) == 128) {
+            if (soc) hipLaunchKernelGGL(t128::k_smallnewton_diff<true>, dim3((unsigned)s->batch), dim3(128), s->lds_bytes, s->stream, a);
+            else hipLaunchKernelGGL(t128::k_smallnewton_diff<false>, dim3((unsigned)s->batch), dim3(128), s->lds_bytes, s->stream, a);
+        } else {
+            if (soc) hipLaunchKernelGGL(t256::k_smallnewton_diff<true>, dim3((unsigned)s->batch), dim3(256), s->lds_bytes, s->stream, a);
+            else hipLaunchKernelGGL(t256::k_smallnewton_diff<false>, dim3((unsigned)s->batch), dim3(256), s->lds_bytes, s->stream, a);
+        }
+    } else if (sn_threads(s) == 64) {
         if (soc) hipLaunchKernelGGL(t64::k_smallnewton<true>, dim3((unsigned)s->batch), dim3(64), s->lds_bytes, s->stream, a);
         else hipLaunchKernelGGL(t64::k_smallnewton<false>, dim3((unsigned)s->batch), dim3(64), s->lds_bytes, s->stream, a);
     } else if (sn_threads(s) == 128) {
@@ -195,7 +213,7 @@ int32_t calipso_hip_smallnewton_create(int64_t nx, int64_t ne, int64_t nc, int64
     SK(hipEventCreate(&s->ev0)); SK(hipEventCreate(&s->ev1));
     const size_t B = (size_t)batch, N = (size_t)d.N;
     auto alloc = [&](double** p, size_t n) { if (hipMalloc((void**)p, sizeof(double) * std::max<size_t>(n, 1)) != hipSuccess) return false; return hipMemsetAsync(*p, 0, sizeof(double) * std::max<size_t>(n, 1), s->stream) == hipSuccess; };
-    if (!alloc(&s->w, B * N) || !alloc(&s->lam, B * std::max(1, d.ne)) || !alloc(&s->sc, B * SC_COUNT) || !alloc(&s->filt, B * 6 * (size_t)s->opt.max_filter) || !alloc(&s->info, B * IN_COUNT) || !alloc(&s->prof, 16))
+    if (!alloc(&s->w, B * N) || !alloc(&s->lam, B * std::max(1, d.ne)) || !alloc(&s->sc, B * SC_COUNT) || !alloc(&s->filt, B * 6 * (size_t)s->opt.max_filter) || !alloc(&s->info, B * IN_COUNT) || !alloc(&s->prof, 16) || !alloc(&s->stf, B * 2 * (size_t)std::max(1, d.nc)))
         return fail(s, CALIPSO_ERR_HIP, "calipso_hip_smallnewton_create: device allocation failed");
     SK(hipMalloc((void**)&s->cnt, sizeof(long long) * B * CN_COUNT)); SK(hipMemsetAsync(s->cnt, 0, sizeof(long long) * B * CN_COUNT, s->stream));
     SK(hipMalloc((void**)&s->status, sizeof(int) * B)); SK(hipMemsetAsync(s->status, 0, sizeof(int) * B, s->stream));
@@ -212,7 +230,7 @@ int32_t calipso_hip_smallnewton_destroy(calipso_hip_smallnewton* s) {
     if (!s) return CALIPSO_OK;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (double* p : {s->P, s->q, s->Z, s->bh, s->w, s->lam, s->sc, s->filt, s->info, s->trace, s->prof}) if (p) (void)hipFree(p);
+    for (double* p : {s->P, s->q, s->Z, s->bh, s->w, s->lam, s->sc, s->filt, s->info, s->trace, s->prof, s->rtheta, s->sens, s->stf}) if (p) (void)hipFree(p);
     if (s->cnt) (void)hipFree(s->cnt);
     if (s->d_soc) (void)hipFree(s->d_soc);
     if (s->status) (void)hipFree(s->status);
@@ -398,6 +416,33 @@ int32_t calipso_hip_smallnewton_steps(calipso_hip_smallnewton* s, int32_t count,
     const int rc = launch(s, MODE_STEPS, count, advance);
     if (rc < 0) return rc;
     if (info) SK(hipMemcpy(info, s->info, sizeof(double) * (size_t)s->batch * IN_COUNT, hipMemcpyDeviceToHost));
+    if (status) SK(hipMemcpy(status, s->status, sizeof(int) * (size_t)s->batch, hipMemcpyDeviceToHost));
+    if (ms) *ms = s->last_ms;
+    return CALIPSO_OK;
+}
+
+// differentiate!(solver) for every instance in ONE launch (differentiate.jl:1-61) at the resident points (after calipso_hip_smallnewton_solve): one factorisation of
+// the condensed matrix with the regularisation solve! left, then search_direction_symmetric! per column of dR/dtheta and sensitivity = -1.0 * the result.
+// jacobian_parameters: batch x (N x p), column-major per instance (host), or ONE N x p matrix for all instances (shared != 0: the model of an MPC loop is the same
+// for every problem); sensitivity: batch x (N x p).  status[k]: 0, or 1 when the factorisation's inertia is not (nx, ne + nc, 0).
+int32_t calipso_hip_smallnewton_differentiate(calipso_hip_smallnewton* s, int64_t p, int32_t shared, const double* jacobian_parameters, double* sensitivity, int32_t* status, double* ms) {
+    if (!s || p < 1 || p > (1 << 20) || !jacobian_parameters || !sensitivity) return CALIPSO_ERR_ARGUMENT;
+    SK(hipSetDevice(s->device));
+    const Dm d = dims_of(s);
+    const size_t need = (size_t)s->batch * (size_t)d.N * (size_t)p;
+    if (need > s->cap_diff) {
+        if (s->rtheta) (void)hipFree(s->rtheta);
+        if (s->sens) (void)hipFree(s->sens);
+        s->rtheta = s->sens = nullptr; s->cap_diff = 0;
+        SK(hipMalloc((void**)&s->rtheta, sizeof(double) * need));
+        SK(hipMalloc((void**)&s->sens, sizeof(double) * need));
+        s->cap_diff = need;
+    }
+    SK(hipMemcpyAsync(s->rtheta, jacobian_parameters, sizeof(double) * (shared ? (size_t)d.N * (size_t)p : need), hipMemcpyHostToDevice, s->stream));
+    s->diff_shared = shared != 0;
+    const int rc = launch(s, MODE_DIFF, (int)p, 0);
+    if (rc < 0) return rc;
+    SK(hipMemcpy(sensitivity, s->sens, sizeof(double) * need, hipMemcpyDeviceToHost));
     if (status) SK(hipMemcpy(status, s->status, sizeof(int) * (size_t)s->batch, hipMemcpyDeviceToHost));
     if (ms) *ms = s->last_ms;
     return CALIPSO_OK;

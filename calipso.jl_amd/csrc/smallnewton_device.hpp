@@ -151,6 +151,7 @@ template <bool SOC> struct CtxT {
     double *Z, *S, *q, *bh, *lam, *sol, *cand, *step, *res, *rerr, *corr, *rsym, *fx, *gzx, *gh, *ghc, *cprod, *bgrad, *wz, *wsoc, *bsoc, *vsoc, *D, *Dinv, *xb, *t1, *t2, *ycol, *red;
     const int *soc_start, *soc_dim, *soc_woff;
     double* filt;                                   // global: [pairs theta | pairs merit | cache theta | cache merit | saved theta | saved merit], max_filter each
+    double* stf;                                    // global: the slacks s and t (nc each) the cone Jacobians of the LAST search direction were formed at (differentiate!'s quirk B-7)
     // uniform scalars (every thread holds the same values)
     double kappa, tau, rho, ep, ep_last, ed, fcur, fcand, eqv, cpv, omega_y, kyy;
     long long filter_index, nfact_total, rfail, rmax, rlast, nsteps;
@@ -684,6 +685,9 @@ template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>
     c.stamp(0);
     // :175-185: the Hessian and the Jacobians of a QP are constant; the cone Jacobians are functions of (s, t) formed where they are used
     // ---- :187 search_direction!: inertia_correction! (inertia.jl:30-80, quirk B-1: IC-3 always takes max(min_regularization, scaling_regularization_last * eps_last))
+    // :183-185 cone!(jacobian = true): the cone Jacobians of this search direction are functions of THIS point's s and t.  The reference keeps them as fields, and
+    // differentiate! (differentiate.jl:13-16) reads them where the last search direction left them — at the iterate BEFORE the final one (quirk B-7): remember which
+    for (int i = tid; i < d.nc; i += NT) { c.stf[i] = sol[d.os() + i]; c.stf[d.nc + i] = sol[d.ot() + i]; }
     {   // (one loop, ONE instance of the factorisation's code: IC-1, then IC-4 as often as the inertia test fails)
         int zero = 0, count = 0;
         c.ep = o.primal_regularization_initial; c.ed = o.dual_regularization_initial;
@@ -820,13 +824,10 @@ template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>
     return out;
 }
 
-template <bool SOC> __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int inst = blockIdx.x, tid = threadIdx.x;
-    if (inst >= a.batch) return;
+// the instance's context: the LDS carve, the problem data and the point into LDS (every thread of the workgroup; ends with the data written, not yet synchronised)
+template <bool SOC> __device__ __forceinline__ void bind_instance(CtxT<SOC>& c, const Args& a, double* sm, int inst, int tid) {
     const Dm d = a.d;
     const Lay L = layout(d);
-    CtxT<SOC> c;
     c.d = d; c.o = &a.o; c.tid = tid;
     c.Lg = a.P + (size_t)inst * a.sP; c.Z = sm + L.Z; c.S = sm + L.S; c.q = sm + L.q; c.bh = sm + L.bh; c.lam = sm + L.lam; c.sol = sm + L.sol; c.cand = sm + L.cand; c.step = sm + L.step;
     c.res = sm + L.res; c.rerr = sm + L.rerr; c.corr = sm + L.corr; c.rsym = sm + L.rsym;
@@ -834,19 +835,78 @@ template <bool SOC> __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args 
     c.soc_start = a.soc_start; c.soc_dim = a.soc_dim; c.soc_woff = a.soc_woff;
     c.D = sm + L.D; c.Dinv = sm + L.Dinv; c.xb = sm + L.xb; c.t1 = sm + L.t1; c.t2 = sm + L.t2; c.ycol = sm + L.ycol; c.red = sm + L.red;
     c.mf = (int)a.o.max_filter;
-    const long long mf_ = c.mf;
     c.filt = a.filt + (size_t)inst * 6 * (size_t)c.mf;
-    const Options& o = a.o;
-    // ---- problem and state into LDS ---------------------------------------------------------------------------------------------------------------
-    {
-        const double* q = a.q + (size_t)inst * a.sq;
-        const double* Zg = a.Z + (size_t)inst * a.sZ; const double* bh = a.bh + (size_t)inst * a.sbh;
-        for (int e = tid; e < d.m * d.nx; e += NT) c.Z[(e % d.m) + (e / d.m) * d.ldz] = Zg[e];
-        for (int i = tid; i < d.nx; i += NT) c.q[i] = q[i];
-        for (int i = tid; i < d.m; i += NT) c.bh[i] = bh[i];
-        const double* w = a.w + (size_t)inst * d.N;
-        for (int i = tid; i < d.N; i += NT) c.sol[i] = w[i];
+    c.stf = a.stf + (size_t)inst * 2 * (size_t)(d.nc > 0 ? d.nc : 1);
+    const double* q = a.q + (size_t)inst * a.sq;
+    const double* Zg = a.Z + (size_t)inst * a.sZ; const double* bh = a.bh + (size_t)inst * a.sbh;
+    for (int e = tid; e < d.m * d.nx; e += NT) c.Z[(e % d.m) + (e / d.m) * d.ldz] = Zg[e];
+    for (int i = tid; i < d.nx; i += NT) c.q[i] = q[i];
+    for (int i = tid; i < d.m; i += NT) c.bh[i] = bh[i];
+    const double* w = a.w + (size_t)inst * d.N;
+    for (int i = tid; i < d.N; i += NT) c.sol[i] = w[i];
+}
+
+// differentiate!(solver) for every instance of the batch (differentiate.jl:1-61) at the resident point: the condensed matrix for the regularisation the last
+// factorisation of solve! left (:13-20: residual_jacobian_variables!, the symmetric form, factorize!), then per parameter column search_direction_symmetric! on
+// the column of dR/dtheta (:29-52) and sensitivity = -1.0 * the result (:55-57).  dR/dtheta comes from the caller (residual_jacobian_parameters.jl:1-40 is the
+// caller's model: for the parametric QPs of the MPC loops it is constant); `count` = its columns.
+template <bool SOC> __global__ __launch_bounds__(NT, 2) void k_smallnewton_diff(Args a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    if (inst >= a.batch) return;
+    CtxT<SOC> c;
+    bind_instance(c, a, sm, inst, tid);
+    const Dm& d = c.d;
+    const double* gsc = a.sc + (size_t)inst * SC_COUNT;
+    c.kappa = gsc[SC_KAPPA]; c.tau = gsc[SC_TAU]; c.rho = gsc[SC_RHO]; c.ep = gsc[SC_EP]; c.ep_last = gsc[SC_EPLAST]; c.ed = gsc[SC_ED];
+    c.eqv = 0.0; c.cpv = 0.0; c.fcur = 0.0; c.fcand = 0.0; c.omega_y = 0.0; c.kyy = 0.0;
+    c.filter_index = 0; c.nfact_total = 0; c.rfail = 0; c.rmax = 0; c.rlast = 0; c.nsteps = 0;
+#ifdef SN_TRACE
+    for (int k = 0; k < 12; ++k) c.tph[k] = 0;
+    c.tlast = wall_clock64();
+#endif
+    __syncthreads();
+    // the cone Jacobians as the reference's differentiate! finds them: formed at the s, t of the last search direction (quirk B-7), not at the solution
+    for (int i = tid; i < d.nc; i += NT) { c.sol[d.os() + i] = c.stf[i]; c.sol[d.ot() + i] = c.stf[d.nc + i]; }
+    __syncthreads();
+    int zero = 0;
+    const bool inertia_ok = c.factorize(zero);
+    const double* J = a.rtheta + (size_t)inst * (size_t)a.srtheta;
+    double* Sn = a.sens + (size_t)inst * (size_t)d.N * (size_t)a.count;
+    for (int j = 0; j < a.count; ++j) {
+        for (int i = tid; i < d.N; i += NT) c.res[i] = J[(size_t)j * d.N + i];
+        __syncthreads();
+        // search_direction_symmetric!, then — for batches WITHOUT second-order cones — the correction rounds of iterative_refinement! (iterative_refinement.jl:1-52),
+        // ONE loop as in the Newton step.  The reference's differentiate! does not refine: its solve is QDLDL on the (nx + ne + nc) symmetric matrix; this path solves
+        // the CONDENSED nx system, the same thing in exact arithmetic when all cones are nonnegative orthants, but at a solution (penalty 1e7, central path 1e-7) five
+        // digits less accurate: the rounds give them back (against the oracle: 1e-5 without, 1e-9 with).  With second-order cones the reference's answer IS the
+        // unrefined solve with its triu-symmetrised cone blocks (quirk B-3): refining would move away from it, towards H^-1
+        int it = 0;
+        bool first = true;
+        for (;;) {
+            c.search_direction_symmetric(first ? c.res : c.rerr, first ? c.step : c.corr);
+            if (SOC || !a.o.iterative_refinement) break;
+            if (!first) { for (int i = tid; i < d.N; i += NT) c.step[i] += c.corr[i]; __syncthreads(); it += 1; }
+            const double norm = c.residual_error();
+            first = false;
+            if (it > a.o.max_iterative_refinement) break;
+            if (norm <= a.o.iterative_refinement_tolerance && it >= a.o.min_iterative_refinement) break;
+        }
+        for (int i = tid; i < d.N; i += NT) Sn[(size_t)j * d.N + i] = -1.0 * c.step[i];
+        __syncthreads();
     }
+    if (tid == 0) a.status[inst] = inertia_ok ? 0 : 1;      // (1: the factorisation's inertia is not (nx, ne + nc, 0); the reference does not look, the sensitivities are what they are)
+}
+
+template <bool SOC> __global__ __launch_bounds__(NT, 2) void k_smallnewton(Args a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    if (inst >= a.batch) return;
+    CtxT<SOC> c;
+    bind_instance(c, a, sm, inst, tid);
+    const Dm d = a.d;
+    const long long mf_ = c.mf;
+    const Options& o = a.o;
     double* lam = c.lam;
     double* gsc = a.sc + (size_t)inst * SC_COUNT;
     long long* cnt = a.cnt + (size_t)inst * CN_COUNT;

@@ -526,6 +526,16 @@ function solve!(s::HIPSmallNewton)
     sn_check(s, ccall((:calipso_hip_smallnewton_solve, lib), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}), s.handle, res, ms), "calipso_hip_smallnewton_solve")
     return res, ms[]
 end
+"differentiate!(solver) for every instance in one launch (differentiate.jl:1-61): jacobian_parameters is N x p x batch (dR/dtheta per instance) or N x p (one matrix for all); returns (sensitivity N x p x batch, status, ms)"
+function differentiate!(s::HIPSmallNewton, jacobian_parameters::AbstractArray{Float64})
+    N = s.nx + 2 * s.ne + 3 * s.nc
+    shared = ndims(jacobian_parameters) == 2
+    size(jacobian_parameters, 1) == N && (shared || size(jacobian_parameters, 3) == s.batch) || error("jacobian_parameters must be N x p x batch or N x p")
+    p = size(jacobian_parameters, 2)
+    J = Array{Float64}(jacobian_parameters); sens = zeros(N, p, s.batch); st = zeros(Int32, s.batch); ms = Ref{Float64}(0.0)
+    sn_check(s, ccall((:calipso_hip_smallnewton_differentiate, lib), Int32, (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}), s.handle, p, shared ? 1 : 0, J, sens, st, ms), "calipso_hip_smallnewton_differentiate")
+    return sens, st, ms[]
+end
 "solution.all of every instance (N x batch)"
 function solution(s::HIPSmallNewton)
     N = s.nx + 2 * s.ne + 3 * s.nc

@@ -456,6 +456,14 @@ int32_t calipso_hip_smallnewton_get_state(calipso_hip_smallnewton*, double* w, d
 int32_t calipso_hip_smallnewton_trace(calipso_hip_smallnewton*, int32_t rows, double* out);
 int32_t calipso_hip_smallnewton_solve(calipso_hip_smallnewton*, int32_t* result, double* ms);
 int32_t calipso_hip_smallnewton_steps(calipso_hip_smallnewton*, int32_t count, int32_t advance, double* info, int32_t* status, double* ms);
+/* differentiate!(solver)  differentiate.jl:1-61 for every instance in ONE launch, at the resident points (after calipso_hip_smallnewton_solve): the condensed matrix
+ * with the regularisation solve! left is factored once (:13-20), then search_direction_symmetric! per column of dR/dtheta (:29-52) and sensitivity = -1.0 * the
+ * result (:55-57).  jacobian_parameters (residual_jacobian_parameters.jl:1-40: the caller's model; constant for the parametric QPs of an MPC loop,
+ * examples/autotuning/cartpole.jl:179-227): batch x (N x p) doubles on the host, column-major per instance — or ONE N x p matrix for all instances (shared != 0) —,
+ * N = nx + 2 ne + 3 nc in the order of point.jl; sensitivity: batch x (N x p).  Batches without second-order cones refine every column (iterative_refinement.jl:1-52:
+ * the condensed solve is five digits short of the reference's QDLDL at a solution); with second-order cones the unrefined solve IS the reference's result (quirk B-3).
+ * The cone Jacobians are those of the last search direction, as the reference's fields are (quirk B-7).  status[k] = 0, or 1 when the inertia of the factorisation is not (nx, ne + nc, 0) (the reference does not look). */
+int32_t calipso_hip_smallnewton_differentiate(calipso_hip_smallnewton*, int64_t p, int32_t shared, const double* jacobian_parameters, double* sensitivity, int32_t* status, double* ms);
 
 /* ---- multi-GPU exchange of the batched path: RCCL over xGMI, one process per GPU ---------------------------------
  * Problem instances are sharded block-contiguously over ranks and never interact (the reference's `Solver`s are independent); the

@@ -220,3 +220,112 @@ def test_limits_are_refused():
     with pytest.raises(pkg.CalipsoHipError):
         sn.set_option("residual_norm", 2.0)
     sn.close()
+
+
+@pytest.mark.parametrize("threads", [0, 256])
+@pytest.mark.parametrize("layout", [(12, 5, 6, 0, 0), (49, 40, 0, 0, 0), (24, 9, 11, 0, 0)])
+def test_batched_differentiate_matches_the_oracle(oracle_mod, layout, threads):
+    """differentiate! of a batch in one launch (differentiate.jl:1-61; calipso_hip_smallnewton_differentiate): parametric conic QPs theta = [dq; db; dh]
+    (np = nx + ne + nc: every entry of dR/dtheta's three blocks is exercised), solved by the batched kernel, then sensitivities of every instance against the
+    ORACLE's differentiate! at its own solution (1e-7: the two solutions agree to 1e-8 and the condensed matrix at the solution is what it is) — R+ only,
+    mixed with second-order cones, C5's (49, 40, 0)."""
+    pkg = load_pkg()
+    nx, ne, nnn, nsoc, sdim = layout
+    probs = [pr.parametric_conic_qp(nx, ne, nnn, nsoc, sdim, seed=300 + k) for k in range(5)]
+    p0 = probs[0]
+    nc = p0.nc
+    opts = dict(residual_tolerance=1e-6, optimality_tolerance=1e-6, equality_tolerance=1e-6, complementarity_tolerance=1e-6, slack_tolerance=1e-6)
+    sn = pkg.SmallNewtonBatch(nx, ne, nc, len(probs), options=dict(threads=threads, **opts))
+    if nsoc:
+        sn.set_cones(nnn, [sdim] * nsoc)
+    st_ = lambda name: np.stack([np.asarray(getattr(p, name), dtype=np.float64) for p in probs])
+    sn.set_qp(st_("P"), st_("q"), st_("A"), st_("b"), st_("G"), st_("h"), objective_scale=p0.c, shared=False)
+    sn.initialize(np.stack([p.x0 for p in probs]))
+    res, _ = sn.solve()
+    N, npar = nx + 2 * ne + 3 * nc, nx + ne + nc
+    J = np.zeros((len(probs), N, npar))
+    oy, oz = nx + ne + nc, nx + 2 * ne + nc                                       # point.jl: x | r | s | y | z | t
+    J[:, :nx, :nx] = np.eye(nx)
+    J[:, oy:oy + ne, nx:nx + ne] = -np.eye(ne)
+    J[:, oz:oz + nc, nx + ne:] = np.eye(nc)
+    S, st, ms = sn.differentiate(J)
+    sol = sn.get_state()["solution"].copy()
+    compared, ok, So_all = 0, [], {}
+    for k, prob in enumerate(probs):
+        o, status = run_oracle(oracle_mod, prob, differentiate=1, **opts)
+        if o.stats()["lu_fallbacks"] > 0 or res[k] != 1:      # (cold-started cone problems may end in the reference's fallback to H \\ residual: this path stops there, -102)
+            assert res[k] == -102 or status != 1, (k, res[k], status)
+            continue
+        assert status == 1 and st[k] == 0
+        compared += 1
+        assert rel(sol[k], o.point()["all"]) <= 1e-8
+        assert np.abs(J[k] - o.mat("jacobian_parameters", o.N, prob.np)).max() == 0.0
+        So_all[k] = o.mat("solution_sensitivity", o.N, prob.np).copy()
+        # at its OWN solution: the points agree to 1e-8 absolute, but the duals of inactive and the slacks of active constraints are ~ kappa themselves and the
+        # condensed matrix carries their ratios: the sensitivities agree as far as that allows
+        assert rel(S[k], So_all[k]) <= 1e-3, (k, rel(S[k], So_all[k]))
+        sol[k] = o.point()["all"].copy()
+        ok.append(k)
+    assert compared == len(probs)
+    # at the ORACLE's solution (the same point to the bit; the scalars the batch's own solve! left — kappa, rho and the regularisation are equal): to rounding
+    sn.set_state(w=sol)
+    S, st1, _ = sn.differentiate(J)
+    for k in ok:
+        assert st1[k] == 0 and rel(S[k], So_all[k]) <= 1e-9, (k, rel(S[k], So_all[k]))
+    # a second call (a subset of the columns) reuses the buffers and gives the same columns; ONE matrix for all instances (the model is the same) as well
+    S2, st2, _ = sn.differentiate(J[:, :, :3])
+    assert np.array_equal(S2, S[:, :, :3])
+    S3, st3, _ = sn.differentiate(J[0])
+    assert np.array_equal(S3, S)
+    sn.close()
+
+
+@pytest.mark.parametrize("layout", [(20, 8, 4, 2, 3), (30, 10, 0, 3, 4), (16, 5, 6, 1, 5), (12, 4, 5, 0, 0)])
+def test_batched_differentiate_at_interior_points_with_second_order_cones(oracle_mod, layout):
+    """the same entry at INTERIOR points (well conditioned; cold-started cone problems mostly end in the reference's fallback, so there is no solution to stand on):
+    a non-advancing Newton step forms the cone Jacobians there (what differentiate! then finds, quirk B-7), and the sensitivities are compared column by column with
+    the ORACLE's residual_jacobian_variables! / factorize! / search_direction_symmetric! at the same point and scalars — second-order cones included, where the
+    reference's solve is the unrefined one with triu-symmetrised cone blocks (quirk B-3) and this path follows it; 1e-8"""
+    from helpers import interior_point
+    pkg = load_pkg()
+    nx, ne, nnn, nsoc, sdim = layout
+    probs = [pr.parametric_conic_qp(nx, ne, nnn, nsoc, sdim, seed=700 + k) for k in range(4)]
+    p0 = probs[0]
+    nc = p0.nc
+    kappa, tau, rho = 0.17, 0.99, 52.0
+    sn = pkg.SmallNewtonBatch(nx, ne, nc, len(probs))
+    if nsoc:
+        sn.set_cones(nnn, [sdim] * nsoc)
+    st_ = lambda name: np.stack([np.asarray(getattr(p, name), dtype=np.float64) for p in probs])
+    sn.set_qp(st_("P"), st_("q"), st_("A"), st_("b"), st_("G"), st_("h"), objective_scale=p0.c, shared=False)
+    N, npar = nx + 2 * ne + 3 * nc, nx + ne + nc
+    oy, oz = nx + ne + nc, nx + 2 * ne + nc
+    J = np.zeros((len(probs), N, npar))
+    J[:, :nx, :nx] = np.eye(nx)
+    J[:, oy:oy + ne, nx:nx + ne] = -np.eye(ne)
+    J[:, oz:oz + nc, nx + ne:] = np.eye(nc)
+    oracles, W, LAM = [], [], []
+    for k, prob in enumerate(probs):
+        pt, lam = interior_point(prob, seed=40 + k)
+        o = oracle_mod.OracleSolver(prob.nx, prob.np, prob.ne, prob.nc, prob.nonnegative_indices, prob.second_order_indices)
+        op = o.point()
+        for f in "xrsyzt":
+            op[f][:] = pt[f]
+        o.buf("dual")[:] = lam
+        for name, v in (("central_path", kappa), ("penalty", rho), ("primal_regularization", 1.0e-7), ("dual_regularization", 1.0e-7), ("fraction_to_boundary", tau)):
+            o.buf(name)[0] = v
+        prob.evaluate(pr.ALL_VARIABLE_FLAGS, op["x"], op["y"], op["z"], prob.parameters, o.buf)
+        o.cone(product=True, jacobian=True, target=True)
+        o.residual_jacobian_variables(); o.residual_jacobian_variables_symmetric()
+        oracles.append(o); W.append(op["all"].copy()); LAM.append(lam)
+    sn.set_state(w=np.stack(W), dual=np.stack(LAM) if ne else None, scalars=np.tile([kappa, tau, rho], (len(probs), 1)))
+    info, stp, _ = sn.steps(1, advance=False)                  # forms the cone Jacobians at these points, leaves the points where they are
+    assert (stp == 0).all(), stp
+    S, st, _ = sn.differentiate(J)
+    assert (st == 0).all()
+    for k, o in enumerate(oracles):
+        for j in range(npar):
+            o.buf("residual")[:] = J[k][:, j]
+            o.search_direction_symmetric(0, fact=(j == 0))
+            assert rel(S[k][:, j], -1.0 * o.buf("step")) <= 1e-8, (k, j, rel(S[k][:, j], -1.0 * o.buf("step")))
+    sn.close()
