@@ -1357,7 +1357,6 @@ void launch_refine_x_fused(calipso_hip_solver* s, bool publish, int nchunk, int 
 }
 void launch_refine_x(calipso_hip_solver* s, bool publish) {
     const BatchSc B = batch_of(s);
-    const int items = s->d.ne + s->d.q + s->d.n_soc;
     hipLaunchKernelGGL(k_refine_x, dim3(1, 1, B.b.n), dim3(RT), 0, s->stream, B, s->d, s->d.m > 0 ? 1 : 0, s->step, s->residual, s->lxv, s->w1, s->w2, s->residual_error,
                        s->residual_symmetric, s->xbuf, s->dscal, s->refpart, s->refparts,
                        publish ? s->hscal_dev : (double*)nullptr, publish ? s->hseq_dev : (unsigned long long*)nullptr, publish ? ++s->pub_seq : 0ULL);
