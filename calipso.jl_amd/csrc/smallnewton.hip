@@ -89,7 +89,7 @@ struct Args {
     double *w, *lam, *sc, *filt, *info, *trace, *prof; long long* cnt; int* status;
     const int *soc_start, *soc_dim, *soc_woff;      // per second-order cone: first cone-local index, dimension, offset of its dim x dim blocks
     int batch, mode, count, advance, trace_rows;
-    double* stf;                                    // batch x 2 nc: s and t at the last search direction (smallnewton_device.hpp: quirk B-7)
+    double* stf;                                    // batch x 2 nc: s and t at the last search direction (smallnewton_device.hpp: quirk B-12)
     const double* rtheta; double* sens; long long srtheta;             // differentiate!: dR/dtheta and the sensitivities, per instance N x count, column-major
 };
 

@@ -151,7 +151,7 @@ template <bool SOC> struct CtxT {
     double *Z, *S, *q, *bh, *lam, *sol, *cand, *step, *res, *rerr, *corr, *rsym, *fx, *gzx, *gh, *ghc, *cprod, *bgrad, *wz, *wsoc, *bsoc, *vsoc, *D, *Dinv, *xb, *t1, *t2, *ycol, *red;
     const int *soc_start, *soc_dim, *soc_woff;
     double* filt;                                   // global: [pairs theta | pairs merit | cache theta | cache merit | saved theta | saved merit], max_filter each
-    double* stf;                                    // global: the slacks s and t (nc each) the cone Jacobians of the LAST search direction were formed at (differentiate!'s quirk B-7)
+    double* stf;                                    // global: the slacks s and t (nc each) the cone Jacobians of the LAST search direction were formed at (differentiate!'s quirk B-12)
     // uniform scalars (every thread holds the same values)
     double kappa, tau, rho, ep, ep_last, ed, fcur, fcand, eqv, cpv, omega_y, kyy;
     long long filter_index, nfact_total, rfail, rmax, rlast, nsteps;
@@ -686,7 +686,7 @@ template <bool SOC> __device__ __forceinline__ StepOut inner_iteration(CtxT<SOC>
     // :175-185: the Hessian and the Jacobians of a QP are constant; the cone Jacobians are functions of (s, t) formed where they are used
     // ---- :187 search_direction!: inertia_correction! (inertia.jl:30-80, quirk B-1: IC-3 always takes max(min_regularization, scaling_regularization_last * eps_last))
     // :183-185 cone!(jacobian = true): the cone Jacobians of this search direction are functions of THIS point's s and t.  The reference keeps them as fields, and
-    // differentiate! (differentiate.jl:13-16) reads them where the last search direction left them — at the iterate BEFORE the final one (quirk B-7): remember which
+    // differentiate! (differentiate.jl:13-16) reads them where the last search direction left them — at the iterate BEFORE the final one (quirk B-12): remember which
     for (int i = tid; i < d.nc; i += NT) { c.stf[i] = sol[d.os() + i]; c.stf[d.nc + i] = sol[d.ot() + i]; }
     {   // (one loop, ONE instance of the factorisation's code: IC-1, then IC-4 as often as the inertia test fails)
         int zero = 0, count = 0;
@@ -866,7 +866,7 @@ template <bool SOC> __global__ __launch_bounds__(NT, 2) void k_smallnewton_diff(
     c.tlast = wall_clock64();
 #endif
     __syncthreads();
-    // the cone Jacobians as the reference's differentiate! finds them: formed at the s, t of the last search direction (quirk B-7), not at the solution
+    // the cone Jacobians as the reference's differentiate! finds them: formed at the s, t of the last search direction (quirk B-12), not at the solution
     for (int i = tid; i < d.nc; i += NT) { c.sol[d.os() + i] = c.stf[i]; c.sol[d.ot() + i] = c.stf[d.nc + i]; }
     __syncthreads();
     int zero = 0;

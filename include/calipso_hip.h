@@ -462,7 +462,7 @@ int32_t calipso_hip_smallnewton_steps(calipso_hip_smallnewton*, int32_t count, i
  * examples/autotuning/cartpole.jl:179-227): batch x (N x p) doubles on the host, column-major per instance — or ONE N x p matrix for all instances (shared != 0) —,
  * N = nx + 2 ne + 3 nc in the order of point.jl; sensitivity: batch x (N x p).  Batches without second-order cones refine every column (iterative_refinement.jl:1-52:
  * the condensed solve is five digits short of the reference's QDLDL at a solution); with second-order cones the unrefined solve IS the reference's result (quirk B-3).
- * The cone Jacobians are those of the last search direction, as the reference's fields are (quirk B-7).  status[k] = 0, or 1 when the inertia of the factorisation is not (nx, ne + nc, 0) (the reference does not look). */
+ * The cone Jacobians are those of the last search direction, as the reference's fields are (quirk B-12).  status[k] = 0, or 1 when the inertia of the factorisation is not (nx, ne + nc, 0) (the reference does not look). */
 int32_t calipso_hip_smallnewton_differentiate(calipso_hip_smallnewton*, int64_t p, int32_t shared, const double* jacobian_parameters, double* sensitivity, int32_t* status, double* ms);
 
 /* ---- multi-GPU exchange of the batched path: RCCL over xGMI, one process per GPU ---------------------------------

@@ -283,7 +283,7 @@ def test_batched_differentiate_matches_the_oracle(oracle_mod, layout, threads):
 @pytest.mark.parametrize("layout", [(20, 8, 4, 2, 3), (30, 10, 0, 3, 4), (16, 5, 6, 1, 5), (12, 4, 5, 0, 0)])
 def test_batched_differentiate_at_interior_points_with_second_order_cones(oracle_mod, layout):
     """the same entry at INTERIOR points (well conditioned; cold-started cone problems mostly end in the reference's fallback, so there is no solution to stand on):
-    a non-advancing Newton step forms the cone Jacobians there (what differentiate! then finds, quirk B-7), and the sensitivities are compared column by column with
+    a non-advancing Newton step forms the cone Jacobians there (what differentiate! then finds, quirk B-12), and the sensitivities are compared column by column with
     the ORACLE's residual_jacobian_variables! / factorize! / search_direction_symmetric! at the same point and scalars — second-order cones included, where the
     reference's solve is the unrefined one with triu-symmetrised cone blocks (quirk B-3) and this path follows it; 1e-8"""
     from helpers import interior_point
