@@ -230,11 +230,12 @@ __device__ int g_mfs_trace_n;
 // The trailing update of one panel (columns kb .. pe - 1, pe - kb = 4 NK) by one wavefront: its 16 x 16 tiles of the lower triangle beyond pe, row-major, every NW-th.
 // F[i][j] -= sum_k (y_ik / d_k) y_jk on the fp64 matrix cores (first operand = scaled rows of the i tile, second = rows of the j tile; two accumulator chains per tile:
 // a dependent v_mfma_f64_16x16x4 issues every 64 cycles).  (bi, bj) advance on scalar registers; a tile needs ONE triangular index per operand and one for its
-// results (the others follow by i -> i + 4: + 4 i + 10); everything is branch-free — rows past the front are clamped for the loads and masked for the stores — so that
-// the operands of the NEXT tile are requested before the matrix instructions of the current one (the panel columns are not written here and two tiles do not overlap):
-// a wavefront's tiles no longer pay an LDS round trip each.
+// results (the others follow by i -> i + 4: + 4 i + 10); everything up to the stores is branch-free — rows past the front are clamped for the loads and masked for the stores.  (Requesting the NEXT tile's operands ahead of the
+// current tile's matrix instructions was measured: nothing.)
 struct MfTile { double af[4], bf[4], old[4]; int o[4]; bool s[4]; };
-template <int NK>
+// LDSF: the front lives in LDS.  Its operand reads are explicit ds_read_b64 then: left to the compiler, the four k-steps of an operand become ds_read2_b64 pairs — half the
+// rate and other lane groups (16 contiguous lanes = 16 different rows of the packed triangle at one k: bank conflicts), which is what the update phase was waiting for
+template <int NK, bool LDSF>
 __device__ __forceinline__ void mf_tile_load(MfTile& T, const double* __restrict__ F, int m, int kb, int pe, int bi, int bj, int fr, int fk) {
     const int i0 = pe + 16 * bi + fk, j = pe + 16 * bj + fr;
     const double* Fa = F + tri0(min(pe + 16 * bi + fr, m - 1)) + kb + fk;
@@ -247,21 +248,38 @@ __device__ __forceinline__ void mf_tile_load(MfTile& T, const double* __restrict
         T.o[rr] = T.s[rr] ? t + j : 0;
         t += 4 * i + 10;
     }
+    if constexpr (LDSF) {
+        const unsigned ea = (unsigned)(uintptr_t)Fa, eb = (unsigned)(uintptr_t)Fb;
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) { T.af[kk] = Fa[4 * kk]; T.bf[kk] = Fb[4 * kk]; }
+        for (int kk = 0; kk < NK; ++kk) {
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(T.af[kk]) : "v"(ea), "n"(32 * kk) : "memory");
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(T.bf[kk]) : "v"(eb), "n"(32 * kk) : "memory");
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) { T.af[kk] = Fa[4 * kk]; T.bf[kk] = Fb[4 * kk]; }
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) T.old[rr] = F[T.o[rr]];
 }
-template <int NK, int NW>
+// (what the explicit reads of a tile return is there after this: the compiler does not count them)
+template <int NK> __device__ __forceinline__ void mf_tile_wait(MfTile& T) {
+    if constexpr (NK == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(T.af[0]), "+v"(T.af[1]), "+v"(T.af[2]), "+v"(T.af[3]), "+v"(T.bf[0]), "+v"(T.bf[1]), "+v"(T.bf[2]), "+v"(T.bf[3]) :: "memory");
+    else if constexpr (NK == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(T.af[0]), "+v"(T.af[1]), "+v"(T.af[2]), "+v"(T.bf[0]), "+v"(T.bf[1]), "+v"(T.bf[2]) :: "memory");
+    else if constexpr (NK == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(T.af[0]), "+v"(T.af[1]), "+v"(T.bf[0]), "+v"(T.bf[1]) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(T.af[0]), "+v"(T.bf[0]) :: "memory");
+}
+template <int NK, int NW, bool LDSF>
 __device__ __forceinline__ void mf_update_tiles(double* __restrict__ F, const double (&rfh)[4], int m, int kb, int pe, int wv, int ntile, int fr, int fk) {
     if (wv >= ntile) return;
     int bi = 0, bj = wv;
     while (bj > bi) { bj -= bi + 1; ++bi; }
-    MfTile A, B;
-    mf_tile_load<NK>(A, F, m, kb, pe, bi, bj, fr, fk);
     for (int t = wv; t < ntile; t += NW) {
-        if (t + NW < ntile) { bj += NW; while (bj > bi) { bj -= bi + 1; ++bi; } }     // (the last tile requests itself again: no branch around the requests)
-        mf_tile_load<NK>(B, F, m, kb, pe, bi, bj, fr, fk);
+        MfTile A;
+        mf_tile_load<NK, LDSF>(A, F, m, kb, pe, bi, bj, fr, fk);
+        bj += NW;
+        while (bj > bi) { bj -= bi + 1; ++bi; }
+        if constexpr (LDSF) mf_tile_wait<NK>(A);
         calipso_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A.af[0] * rfh[0], A.bf[0], acc, 0, 0, 0);
         if constexpr (NK > 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(A.af[1] * rfh[1], A.bf[1], acc2, 0, 0, 0);
@@ -269,7 +287,6 @@ __device__ __forceinline__ void mf_update_tiles(double* __restrict__ F, const do
         if constexpr (NK > 3) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(A.af[3] * rfh[3], A.bf[3], acc2, 0, 0, 0);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) if (A.s[rr]) F[A.o[rr]] = A.old[rr] - (acc[rr] + acc2[rr]);
-        A = B;
     }
 }
 // the barriers of the factorisation loop: a front in LDS needs the LDS traffic ordered, not the global stores in flight (the panel of L leaves column block by
@@ -488,10 +505,10 @@ __device__ __forceinline__ void mf_factor_node(const MfDev& d, const MfNode& nd,
             double rfh[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) rfh[kk] = rinv[min(kb + 4 * kk + fk, pe - 1)];
-            if (nk4 == 4) mf_update_tiles<4, MF_THREADS / 64>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
-            else if (nk4 == 2) mf_update_tiles<2, MF_THREADS / 64>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
-            else if (nk4 == 3) mf_update_tiles<3, MF_THREADS / 64>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
-            else mf_update_tiles<1, MF_THREADS / 64>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
+            if (nk4 == 4) mf_update_tiles<4, MF_THREADS / 64, !GF>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
+            else if (nk4 == 2) mf_update_tiles<2, MF_THREADS / 64, !GF>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
+            else if (nk4 == 3) mf_update_tiles<3, MF_THREADS / 64, !GF>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
+            else mf_update_tiles<1, MF_THREADS / 64, !GF>(F, rfh, m, kb, pe, wv, ntile, fr, fk);
         } else
         for (int t = wave; t < ntile; t += MF_THREADS / 64) {
             // panels whose width is not a multiple of four: every read is unconditional, from a clamped address, the k steps outside the panel are zeroed
