@@ -625,8 +625,22 @@ static bool lfac_scan_plans(LfacPlan& best, int nblk, int nx, int ne, int nc, in
         best.margin = cands[(size_t)win].margin;
         return true;
     }
-    for (double b = 60.0; b <= 400.0; b *= 1.5) if (lfac_make_plan(best, nblk, nx, ne, nc, W, b, 0.0)) return true;      // (shapes the scan does not cover)
-    return false;
+    // Shapes the grid does not cover — a tile's constraint products alone outlast the grid's longest head (cost_schur(nst, 4) > 130: m > ~5000), or the work per
+    // launch its longest budget (nx = 6000, m = 4900: 94 panels of >= 80 us of work each): longer launches, heads in multiples of the shortest one that can
+    // finish a tile (split four ways; from twice that a tile takes ONE worker and the first two columns fit the 255 slots), the cheapest by the model
+    {
+        const int nst = (ne + LKT - 1) / LKT + (nc + LKT - 1) / LKT;
+        const double h0 = std::max(50.0, cost_schur(nst, 4));
+        double best_e = -1.0;
+        for (double b = 40.0; b <= 640.0; b *= 1.25)
+            for (double hm : {1.0, 2.0, 3.0}) {
+                LfacPlan P;
+                if (!lfac_make_plan(P, nblk, nx, ne, nc, W, b, hm * h0)) continue;
+                const double e = lfac_plan_estimate(P);
+                if (best_e < 0.0 || e < best_e) { best_e = e; best = P; }
+            }
+        return best_e >= 0.0;
+    }
 }
 // One plan per SHAPE and process: handles of one shape (the lanes of bench.py, the members of a batch stepped alone, a handle re-created per MPC step) share it — the
 // scan runs once, every later handle of the shape finds its plan here (a shape that cannot be planned is remembered too).

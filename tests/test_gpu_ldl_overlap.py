@@ -93,10 +93,11 @@ def test_schedule_independence_holds_for_other_solve_block_widths(solve_block):
         assert run_variant(dict(sb, **env)) == ref, (solve_block, env)
 
 
-@pytest.mark.parametrize("shapes", ["1000,40,0,0,3;1024,0,64,0,3", "1100,5,0,4,3;1300,700,100,50,4", "3000,1500,200,100,3", "4000,2000,600,200,3"])
+@pytest.mark.parametrize("shapes", ["1000,40,0,0,3;1024,0,64,0,3", "1100,5,0,4,3;1300,700,100,50,4", "3000,1500,200,100,3", "4000,2000,600,200,3", "6000,3000,1000,300,3"])
 def test_left_looking_schedule_on_edge_shapes(shapes):
     """the planner of csrc/lfac.hip on shapes its scan was not tuned on: two stages of constraints and no cone (m = 40), no equality (m = 64), a single partial stage (m = 17),
-    cones of dimension 4, NP = 1024 (the smallest it takes) to 4096 (65 panels: the coarse scan) — against the right-looking schedule, bit for bit"""
+    cones of dimension 4, NP = 1024 (the smallest it takes) to 4096 (65 panels: the coarse scan) and 6016 (94 panels of 154 constraint stages: beyond the scan's grid, the plan
+    comes from its fall-back over longer launches and heads) — against the right-looking schedule, bit for bit"""
     sh = {"CHILD_SHAPES": shapes}
     a = run_variant(dict(sh)); la = run_variant.lfac
     b = run_variant(dict(sh, CALIPSO_HIP_LFAC="0")); lb = run_variant.lfac
