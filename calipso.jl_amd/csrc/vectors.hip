@@ -928,26 +928,53 @@ struct TailArgs {
     double* rsym; double* dsym; double* step; double* accum; double* zsx; double* e; double* t1;
     int zsx_mode, do_refine;
 };
-__device__ __forceinline__ double tail_equality(const Dims& d, const Scalars& sc, const TailArgs& A, int k, double t2k) {
+// What the owner thread of a constraint reads that does NOT depend on t2 — requested BEFORE the mat-vec's stream of loads, so that it is there when t2 is: left where
+// it is used, every read sat behind a store of the constraint code that may alias it (the arrays are not restrict: res and e ARE one array in a correction solve), a chain
+// of four to five dependent memory round trips per row that starts only when t2 is complete (bench/tail_probe.sh: 6 us of the launch's 18.4).  Every location is read
+// before the same thread writes it and no thread touches another constraint's rows, so reading early changes no value.  Second-order cones: the three index look-ups
+// (entry -> cone -> start / dimension / offset) travel here; their operands follow in one batch behind t2 (64 doubles would have to be held across the mat-vec).
+struct TailPre { double v[13]; int j, st, dim, woff; };
+__device__ __forceinline__ void tail_prefetch(const Dims& d, const ConeDev& cd, const TailArgs& A, int row, TailPre& P) {
+    if (row < d.ne) {
+        const int k = row, ir = d.orr() + k, iy = d.oy() + k;
+        P.v[0] = A.rsym[d.nx + k];
+        if (A.zsx_mode != 1) P.v[1] = A.zsx[k];
+        P.v[2] = A.res[ir];
+        if (A.accum) { P.v[3] = A.accum[iy]; P.v[4] = A.accum[ir]; }
+        if (A.do_refine) { P.v[5] = A.resid[ir]; P.v[6] = A.resid[iy]; }
+    } else if (row < d.ne + d.q) {
+        const int k = row - d.ne, is = d.os() + k, iz = d.oz() + k, it = d.ot() + k;
+        P.v[0] = A.wz[k]; P.v[1] = A.rsym[d.nx + d.ne + k];
+        if (A.zsx_mode != 1) P.v[2] = A.zsx[d.ne + k];
+        P.v[3] = A.w[is]; P.v[4] = A.w[it]; P.v[5] = A.res[it]; P.v[6] = A.res[is];
+        if (A.accum) { P.v[7] = A.accum[iz]; P.v[8] = A.accum[is]; P.v[9] = A.accum[it]; }
+        if (A.do_refine) { P.v[10] = A.resid[is]; P.v[11] = A.resid[iz]; P.v[12] = A.resid[it]; }
+    } else {
+        const int c = row - d.ne;
+        P.j = cd.entry_soc[c];
+        P.st = cd.soc_start[P.j]; P.dim = cd.soc_dim[P.j]; P.woff = cd.soc_woff[P.j];
+    }
+}
+__device__ __forceinline__ double tail_equality(const Dims& d, const Scalars& sc, const TailArgs& A, const TailPre& P, int k, double t2k) {
     const double Hrr = sc.rho + sc.ep;
     const double omega_y = -1.0 / (-1.0 / (sc.rho + sc.ep) + (0.0 - sc.ed));
-    const double dy = -1.0 * omega_y * (A.rsym[d.nx + k] - t2k);
+    const double dy = -1.0 * omega_y * (P.v[0] - t2k);
     A.dsym[d.nx + k] = dy;
     double zk = t2k;
-    if (A.zsx_mode == 2) zk = A.zsx[k] + t2k;
-    if (A.zsx_mode) A.zsx[k] = zk; else zk = A.zsx[k];
-    const double dr = (A.res[d.orr() + k] + dy) / Hrr;
+    if (A.zsx_mode == 2) zk = P.v[1] + t2k;
+    if (A.zsx_mode) A.zsx[k] = zk; else zk = P.v[1];
+    const double dr = (P.v[2] + dy) / Hrr;
     A.step[d.oy() + k] = dy;
     A.step[d.orr() + k] = dr;
     double vy = dy, vr = dr;
-    if (A.accum) { vy = A.accum[d.oy() + k] + dy; vr = A.accum[d.orr() + k] + dr; A.accum[d.oy() + k] = vy; A.accum[d.orr() + k] = vr; }
+    if (A.accum) { vy = P.v[3] + dy; vr = P.v[4] + dr; A.accum[d.oy() + k] = vy; A.accum[d.orr() + k] = vr; }
     if (!A.do_refine) return 0.0;
     // k_refine_local, equality item
     const int ir = d.orr() + k, iy = d.oy() + k;
     const double hr = (sc.rho + sc.ep) * vr - vy;
-    const double er = A.resid[ir] - hr;
+    const double er = P.v[5] - hr;
     const double hy = zk + (-vr + (0.0 - sc.ed) * vy);
-    const double ey = A.resid[iy] - hy;
+    const double ey = P.v[6] - hy;
     A.e[ir] = er; A.e[iy] = ey;
     double b = ey;
     b += er / Hrr;
@@ -955,43 +982,43 @@ __device__ __forceinline__ double tail_equality(const Dims& d, const Scalars& sc
     A.t1[k] = omega_y * b;
     return fmax(rabs(er), rabs(ey));
 }
-__device__ __forceinline__ double tail_nonnegative(const Dims& d, const Scalars& sc, const TailArgs& A, int k, double t2k) {
+__device__ __forceinline__ double tail_nonnegative(const Dims& d, const Scalars& sc, const TailArgs& A, const TailPre& P, int k, double t2k) {
     const double Hss = 0.0 + sc.ep;
-    const double dz = -1.0 * A.wz[k] * (A.rsym[d.nx + d.ne + k] - t2k);
+    const double dz = -1.0 * P.v[0] * (P.v[1] - t2k);
     A.dsym[d.nx + d.ne + k] = dz;
     double zk = t2k;
-    if (A.zsx_mode == 2) zk = A.zsx[d.ne + k] + t2k;
-    if (A.zsx_mode) A.zsx[d.ne + k] = zk; else zk = A.zsx[d.ne + k];
-    const double Sb = A.w[d.os() + k] - sc.ed, Ti = A.w[d.ot() + k], Pi = Hss;
-    const double rt = A.res[d.ot() + k], rs = A.res[d.os() + k];
+    if (A.zsx_mode == 2) zk = P.v[2] + t2k;
+    if (A.zsx_mode) A.zsx[d.ne + k] = zk; else zk = P.v[2];
+    const double Sb = P.v[3] - sc.ed, Ti = P.v[4], Pi = Hss;
+    const double rt = P.v[5], rs = P.v[6];
     const double ds = (rt + Sb * (rs + dz)) / (Ti + Sb * Pi);
     const double dt = (rt - Ti * ds) / Sb;
     A.step[d.oz() + k] = dz; A.step[d.os() + k] = ds; A.step[d.ot() + k] = dt;
     double vz = dz, vs = ds, vt = dt;
     if (A.accum) {
-        vz = A.accum[d.oz() + k] + dz; vs = A.accum[d.os() + k] + ds; vt = A.accum[d.ot() + k] + dt;
+        vz = P.v[7] + dz; vs = P.v[8] + ds; vt = P.v[9] + dt;
         A.accum[d.oz() + k] = vz; A.accum[d.os() + k] = vs; A.accum[d.ot() + k] = vt;
     }
     if (!A.do_refine) return 0.0;
     const int is = d.os() + k, iz = d.oz() + k, it = d.ot() + k;
     const double hs = (0.0 + sc.ep) * vs - vz - vt;
-    const double es = A.resid[is] - hs;
+    const double es = P.v[10] - hs;
     const double hz = zk + (-vs + (0.0 - sc.ed) * vz);
-    const double ez = A.resid[iz] - hz;
-    const double ht = Ti * vs + (A.w[d.os() + k] - sc.ed) * vt;
-    const double et = A.resid[it] - ht;
+    const double ez = P.v[11] - hz;
+    const double ht = Ti * vs + (P.v[3] - sc.ed) * vt;
+    const double et = P.v[12] - ht;
     A.e[is] = es; A.e[iz] = ez; A.e[it] = et;
     double b = ez;
     b += (et + Sb * es) / (Ti + Sb * Pi);
     A.rsym[d.nx + d.ne + k] = b;
-    A.t1[d.ne + k] = A.wz[k] * b;
+    A.t1[d.ne + k] = P.v[0] * b;
     return fmax(fmax(rabs(es), rabs(ez)), rabs(et));
 }
 // second-order cone j of dimension <= 4; t2c[a] = entry of t2 of its row a
-__device__ __forceinline__ double tail_soc_small(const Dims& d, const Scalars& sc, const ConeDev& cd, const TailArgs& A, int j, const double* t2c) {
+__device__ __forceinline__ double tail_soc_small(const Dims& d, const Scalars& sc, const TailArgs& A, const TailPre& P, const double* t2c) {
     constexpr int MD = 4;
     const double Hss = 0.0 + sc.ep;
-    const int st = cd.soc_start[j], dim = cd.soc_dim[j], woff = cd.soc_woff[j];
+    const int st = P.st, dim = P.dim, woff = P.woff;
     double sl[MD], t[MD], rs[MD], rt[MD], bb[MD], tt[MD], zz[MD], W[MD * MD], az[MD], as[MD], at[MD], res_s[MD], res_z[MD], res_t[MD];
 #pragma unroll
     for (int a = 0; a < MD; ++a) {
@@ -1151,6 +1178,11 @@ __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc b
     jhi = 0;
 #endif
     const int npass = (d.nx + W - 1) / W;
+    const TailArgs A{w, res, resid, wz, Wsoc, rsym, dsym, step, accum, zsx, e, t1, zsx_mode, do_refine};
+    TailPre P;
+#if TAIL_EXP == 0
+    if (tid < nrows) tail_prefetch(d, cd, A, r0 + tid, P);
+#endif
     // the first pass's loads go out before dx is staged (they do not depend on it); from then on pass k + 1 travels while pass k is summed: the row is a stream
     // of loads with two batches of CPT in flight, not a chain of round trips
     double va[CPT], vb[CPT];
@@ -1197,14 +1229,13 @@ __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc b
     // ---- the constraints of these rows --------------------------------------------------------------------------------
     double m = 0.0;
     if (tid < nrows) {
-        TailArgs A{w, res, resid, wz, Wsoc, rsym, dsym, step, accum, zsx, e, t1, zsx_mode, do_refine};
+#if TAIL_EXP != 0
+        tail_prefetch(d, cd, A, r0 + tid, P);
+#endif
         const int row = r0 + tid;
-        if (row < d.ne) m = tail_equality(d, sc, A, row, t2s[tid]);
-        else if (row < d.ne + d.q) m = tail_nonnegative(d, sc, A, row - d.ne, t2s[tid]);
-        else {
-            const int c = row - d.ne, j = cd.entry_soc[c];
-            if (c == cd.soc_start[j]) m = tail_soc_small(d, sc, cd, A, j, t2s + tid);      // (the cone's rows follow its first one inside the group)
-        }
+        if (row < d.ne) m = tail_equality(d, sc, A, P, row, t2s[tid]);
+        else if (row < d.ne + d.q) m = tail_nonnegative(d, sc, A, P, row - d.ne, t2s[tid]);
+        else if (row - d.ne == P.st) m = tail_soc_small(d, sc, A, P, t2s + tid);      // (the cone's rows follow its first one inside the group)
     }
     if (do_refine) {
         const double mr = block_max(m, sm);
