@@ -96,7 +96,7 @@ static int32_t create_impl(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64
         if (len == 0) continue;   // Indices allows empty vectors (indices.jl:22)
         for (int64_t p = 0; p < len; ++p)
             if (soc_idx[soc_ptr[j] + p] != next + p) { delete s; g_create_err = "second_order_indices must be contiguous blocks following the nonnegative entries"; return CALIPSO_ERR_LAYOUT; }
-        if (len > MAX_SOC_DIM) { delete s; g_create_err = "second-order cone dimension above the supported maximum (512)"; return CALIPSO_ERR_ARGUMENT; }
+        if (len > MAX_SOC_DIM) { delete s; g_create_err = "second-order cone dimension above the supported maximum (1024)"; return CALIPSO_ERR_ARGUMENT; }
         s->h_soc_start.push_back((int)(next - 1));
         s->h_soc_dim.push_back((int)len);
         s->h_soc_woff.push_back(woff);

@@ -16,7 +16,7 @@ typedef int64_t i64;
 
 constexpr int TILE = 128;   // Schur-complement (SYRK) workgroup tile
 constexpr int NB = 64;      // LDL^T panel width
-constexpr int MAX_SOC_DIM = 512;   // widest second-order cone (soc_wide.hip: up to eight elements per lane of the cone's wavefront)
+constexpr int MAX_SOC_DIM = 1024;  // widest second-order cone (soc_wide.hip: up to sixteen elements per lane of the cone's wavefront)
 constexpr int TRSV_BLOCK = 2048;   // widest diagonal block of L whose inverse is assembled for the triangular solves (ldl.hip)
 // limit: the handle's "opt.solve_block" (512, 1024 or 2048).  NP is a power of two up to 512 and a multiple of 512 beyond; the inverse of a block is assembled
 // by pairwise merges of equal halves, so every block of the layout — the last, narrower one included — must be 64 * 2^k wide: the widest power of two

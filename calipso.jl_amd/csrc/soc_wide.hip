@@ -1,5 +1,6 @@
 // soc_wide.hip — second-order cones of dimension > 4: ONE WAVEFRONT PER CONE, lane l holds elements l, l + 64, ... of every cone vector (E elements per
-// lane: dimension <= 64 E; E = 1 for cones up to 64, 2 / 4 / 8 for the wider ones up to 512 — the reference has no limit, cones/second_order.jl:1-69), so
+// lane: dimension <= 64 E; E = 1 for cones up to 64, 2 / 4 / 8 / 16 for the wider ones up to 1024 (MAX_SOC_DIM; at E = 16 the cone's vectors no longer fit the register
+// file and the compiler keeps part of them in scratch: slower, same arithmetic) — the reference has no limit, cones/second_order.jl:1-69), so
 // nothing lives in private arrays indexed at run time.
 //   cones/second_order.jl:50-65            second_order_vector_inverse (the closed-form arrow inverse)       -> arrow_inverse_wave
 //   residual_jacobian_variables.jl:151-164  K_zz block of a cone, column by column                            -> k_cone_weights_wide
@@ -333,8 +334,8 @@ __global__ __launch_bounds__(64) void k_refine_local_wide(BatchSc bt, Dims d, Co
 
 // ---- launchers (called by the launchers of schur.hip / vectors.hip right after their own kernel, only when the handle has wide cones) ----------
 // E = elements per lane for the widest cone of the handle
-static int wide_E(const calipso_hip_solver* s) { const int m = s->d.max_dim; return m <= 64 ? 1 : (m <= 128 ? 2 : (m <= 256 ? 4 : 8)); }
-#define WIDE_DISPATCH(E_, CALL) do { switch (E_) { case 1: { constexpr int E = 1; CALL; } break; case 2: { constexpr int E = 2; CALL; } break; case 4: { constexpr int E = 4; CALL; } break; default: { constexpr int E = 8; CALL; } } } while (0)
+static int wide_E(const calipso_hip_solver* s) { const int m = s->d.max_dim; return m <= 64 ? 1 : (m <= 128 ? 2 : (m <= 256 ? 4 : (m <= 512 ? 8 : 16))); }
+#define WIDE_DISPATCH(E_, CALL) do { switch (E_) { case 1: { constexpr int E = 1; CALL; } break; case 2: { constexpr int E = 2; CALL; } break; case 4: { constexpr int E = 4; CALL; } break; case 8: { constexpr int E = 8; CALL; } break; default: { constexpr int E = 16; CALL; } } } while (0)
 
 void launch_cone_weights_wide(calipso_hip_solver* s) {
     if (!s->d.n_wide) return;

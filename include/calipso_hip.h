@@ -138,7 +138,9 @@ typedef void (*calipso_callback_fn)(void* user, calipso_hip_solver* solver);
 /* Solver(methods, nx, np, ne, nc; nonnegative_indices, second_order_indices)   solver.jl:46-150, indices.jl:20-63.
  * nonneg_idx: n_nonneg cone-local indices (1-based); soc_ptr: n_soc+1 zero-based offsets into soc_idx (1-based,
  * first entry of each cone is its head).  The sets must be [1..q] followed by contiguous SOC blocks in order
- * (the only layout for which the reference is self-consistent), else CALIPSO_ERR_LAYOUT. */
+ * (the only layout for which the reference is self-consistent), else CALIPSO_ERR_LAYOUT.
+ * LIMIT: a second-order cone may have at most 1024 entries (csrc/soc_wide.hip: one wavefront per cone, up to sixteen entries per lane; the reference has none,
+ * cones/second_order.jl:1-69 — its largest is 12): wider cones are refused with CALIPSO_ERR_ARGUMENT and a message in calipso_hip_last_error(NULL). */
 int32_t calipso_hip_create(int64_t nx, int64_t np, int64_t ne, int64_t nc, int64_t n_nonneg, const int64_t* nonneg_idx,
                            int64_t n_soc, const int64_t* soc_ptr, const int64_t* soc_idx, int32_t device,
                            calipso_hip_solver** out);

@@ -62,11 +62,12 @@ def test_search_direction_shapes(oracle_mod, shape):
             assert a == a_g
 
 
-@pytest.mark.parametrize("dims", [[100], [130, 3, 70], [200, 12]], ids=lambda d: "soc" + "x".join(map(str, d)))
+@pytest.mark.parametrize("dims", [[100], [130, 3, 70], [200, 12], [600, 5], [1024]], ids=lambda d: "soc" + "x".join(map(str, d)))
 def test_second_order_cones_wider_than_a_wavefront(oracle_mod, dims):
     """cones of dimension > 64 (the reference has no limit: cones/second_order.jl:1-69): two / four elements per lane of the cone's wavefront
-    (csrc/soc_wide.hip); dimension 130 and 200 keep the d x d block of the cone outside the LDS.  Whole search_direction! against the oracle."""
-    nx, ne, n_nn = 260, 40, 6
+    (csrc/soc_wide.hip); dimension 130 and 200 keep the d x d block of the cone outside the LDS; 600 and 1024 (the maximum) take sixteen elements per lane.
+    Whole search_direction! against the oracle."""
+    nx, ne, n_nn = (260 if sum(dims) < 300 else 1100), 40, 6
     nonneg, soc, nc = soc_layout(n_nn, dims)
     prob = pr.random_qp(nx, ne, nc, seed=sum(dims), nonnegative_indices=nonneg, second_order_indices=soc)
     pt, lam = interior_point(prob, seed=2, tail=0.04)
@@ -89,6 +90,6 @@ def test_second_order_cones_wider_than_a_wavefront(oracle_mod, dims):
             a *= 0.5
         assert a == a_g
     with pytest.raises(load_pkg().CalipsoHipError):
-        n2, s2, c2 = soc_layout(0, [513])
+        n2, s2, c2 = soc_layout(0, [1025])
         p2 = pr.random_qp(20, 0, c2, seed=1, nonnegative_indices=n2, second_order_indices=s2)
         load_pkg().Solver(p2, p2.nx, 0, p2.ne, p2.nc, nonnegative_indices=n2, second_order_indices=s2)
