@@ -1140,12 +1140,18 @@ __device__ __forceinline__ double tail_soc_small(const Dims& d, const Scalars& s
 #define TAIL_EXP 0       // (bench/tail_probe.sh: 1 = no constraint code, 2 = no constraint code and two workgroups per row group, 3 = no mat-vec loads)
 #endif
 constexpr int TAIL_ROWS = 16, TAIL_PARTS = 32, TAIL_CPT = 16;
-__global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc bt, Dims d, ConeDev cd, const int* __restrict__ grp, int ngrp, const int* rowrange, const double* __restrict__ Z,
+// PT = column parts that are THREADS (32: 512 threads, one part each; 16: 256 threads, two parts each).  The 32 parts, their columns (part p: p, p + 32, ...) and the order
+// of every sum are the same for both: the bits do not depend on PT.  One system alone takes PT = 32 (its ~160 workgroups do not fill the chip: the more loads each has in
+// flight the better); a group's launch takes PT = 16: with ~200 registers per thread a compute unit holds ONE 512-thread workgroup but TWO of 256, and a workgroup streams
+// only between its staging of dx and the constraint code of its 16 owner threads — 3.7 TB/s with one resident workgroup per unit (profiles/r06_kernel_stats_group.csv).
+template <int PT>
+__global__ __launch_bounds__(TAIL_ROWS * PT) void k_solve_tail(BatchSc bt, Dims d, ConeDev cd, const int* __restrict__ grp, int ngrp, const int* rowrange, const double* __restrict__ Z,
                                                                         const double* __restrict__ dx, const double* w, const double* res, const double* resid, const double* wz,
                                                                         const double* Wsoc, double* rsym, double* dsym, double* step, double* accum, double* zsx, double* e, double* t1,
                                                                         double* __restrict__ part, int zsx_mode, int do_refine, const int* __restrict__ gate = nullptr, int gate_epoch = 0) {
     if (gate && gate[0] == gate_epoch) return;        // (internal.hpp: gate)
-    constexpr int ROWS = TAIL_ROWS, PARTS = TAIL_PARTS, CPT = TAIL_CPT, W = PARTS * CPT;
+    constexpr int ROWS = TAIL_ROWS, PARTS = TAIL_PARTS, CPT = TAIL_CPT, W = PARTS * CPT, NS = PARTS / PT, HB = CPT / NS, NT = ROWS * PT;
+    static_assert(PT == 32 || PT == 16, "one or two column parts per thread");
     extern __shared__ __attribute__((aligned(16))) double xs[];      // dx, whole (nx rounded up to a multiple of W doubles, zero padded): ONE barrier for the mat-vec
     __shared__ double psum[PARTS][ROWS];
     __shared__ double t2s[ROWS];
@@ -1183,32 +1189,45 @@ __global__ __launch_bounds__(TAIL_ROWS * TAIL_PARTS) void k_solve_tail(BatchSc b
 #if TAIL_EXP == 0
     if (tid < nrows) tail_prefetch(d, cd, A, r0 + tid, P);
 #endif
-    // the first pass's loads go out before dx is staged (they do not depend on it); from then on pass k + 1 travels while pass k is summed: the row is a stream
-    // of loads with two batches of CPT in flight, not a chain of round trips
-    double va[CPT], vb[CPT];
-    auto fetch = [&](int c0, double (&v)[CPT]) {
+    // the first batch's loads go out before dx is staged (they do not depend on it); from then on batch k + 1 travels while batch k is summed: the row is a stream
+    // of loads with two batches in flight, not a chain of round trips.  A batch = HB consecutive entries (columns c0 + 32 q) of each of the thread's NS parts:
+    // CPT loads per thread whatever PT; part p sums its entries q = 0, 1, ... of pass 0, then of pass 1, ... — one accumulator per part
+    double va[NS][HB], vb[NS][HB];
+    auto fetch = [&](int b, double (&v)[NS][HB]) {       // batch b: pass b / NS, entries (b % NS) HB .. + HB - 1
+        const int c0 = (b / NS) * W, q0 = (b % NS) * HB;
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) { const int c = c0 + p + PARTS * q; v[q] = (live && c < d.nx && c >= jlo && c < jhi) ? Zr[(size_t)c * d.m] : 0.0; }
+        for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+            for (int q = 0; q < HB; ++q) { const int c = c0 + (p + PT * sl) + PARTS * (q0 + q); v[sl][q] = (live && c < d.nx && c >= jlo && c < jhi) ? Zr[(size_t)c * d.m] : 0.0; }
     };
+    const int nb = npass * NS;
     fetch(0, va);
-    for (int i = tid; i < npass * W; i += ROWS * PARTS) xs[i] = i < d.nx ? dx[i] : 0.0;
+    for (int i = tid; i < npass * W; i += NT) xs[i] = i < d.nx ? dx[i] : 0.0;
     __syncthreads();
-    double acc = 0.0;
-    for (int k = 0; k < npass; k += 2) {
-        if (k + 1 < npass) fetch((k + 1) * W, vb);
+    double acc[NS];
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) acc += va[q] * xs[k * W + p + PARTS * q];
-        if (k + 1 < npass) {
-            if (k + 2 < npass) fetch((k + 2) * W, va);
+    for (int sl = 0; sl < NS; ++sl) acc[sl] = 0.0;
+    auto sum = [&](int b, const double (&v)[NS][HB]) {
+        const int c0 = (b / NS) * W, q0 = (b % NS) * HB;
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) acc += vb[q] * xs[(k + 1) * W + p + PARTS * q];
+        for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+            for (int q = 0; q < HB; ++q) acc[sl] += v[sl][q] * xs[c0 + (p + PT * sl) + PARTS * (q0 + q)];
+    };
+    for (int b = 0; b < nb; b += 2) {
+        if (b + 1 < nb) fetch(b + 1, vb);
+        sum(b, va);
+        if (b + 1 < nb) {
+            if (b + 2 < nb) fetch(b + 2, va);
+            sum(b + 1, vb);
         }
     }
-    psum[p][r] = acc;
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) psum[p + PT * sl][r] = acc[sl];
     // ---- x entries of the step (this workgroup's share) ---------------------------------------------------------------
     {
         const int xsz = (d.nx + ngrp - 1) / ngrp, xend = min(d.nx, (g + 1) * xsz);
-        for (int i = g * xsz + tid; i < xend; i += ROWS * PARTS) {
+        for (int i = g * xsz + tid; i < xend; i += NT) {
             const double v = dx[i];
             dsym[i] = v; step[i] = v;
             if (accum) accum[i] += v;
@@ -1255,12 +1274,20 @@ bool launch_solve_tail(calipso_hip_solver* s, int which, bool accumulate, bool w
     double* st = which == 0 ? s->step : s->step_correction;
     constexpr int TW = TAIL_PARTS * TAIL_CPT;
     const size_t lds = sizeof(double) * (size_t)((s->d.nx + TW - 1) / TW) * TW;
+    // (bench/ab_libs.sh: which form a launch takes; CALIPSO_HIP_TAIL_PT=32 / 16 forces one — the bits are the same)
+    static const int env_pt = [] { const char* e = getenv("CALIPSO_HIP_TAIL_PT"); return e ? atoi(e) : 0; }();
+    const bool narrow = env_pt ? env_pt == 16 : B.b.n >= 4;
+    const void* fn = narrow ? (const void*)k_solve_tail<16> : (const void*)k_solve_tail<32>;
     if (lds > 48 * 1024) {
-        if (lds > 96 * 1024 || !lds_attribute((const void*)k_solve_tail, 96 * 1024)) return false;      // (> 64 KB of dynamic LDS must be asked for, on every device; refused: the separate kernels)
+        if (lds > 96 * 1024 || !lds_attribute(fn, 96 * 1024)) return false;      // (> 64 KB of dynamic LDS must be asked for, on every device; refused: the separate kernels)
     }
-    hipLaunchKernelGGL(k_solve_tail, dim3((s->n_zgrp + 7) / 8 * 8 * (TAIL_EXP == 2 ? 2 : 1), 1, B.b.n), dim3(TAIL_ROWS * TAIL_PARTS), lds, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
-                       s->residual, s->wz, s->Wsoc, s->residual_symmetric, s->step_symmetric, st, accumulate ? s->step : (double*)nullptr, s->zsx, s->residual_error, s->t1, s->refpart,
-                       which == 0 ? 1 : 2, with_refine ? 1 : 0, s->gate_epoch ? s->gate : (const int*)nullptr, s->gate_epoch);
+    const dim3 grid((s->n_zgrp + 7) / 8 * 8 * (TAIL_EXP == 2 ? 2 : 1), 1, B.b.n);
+    auto go = [&](auto kern, int threads) {
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s->stream, B, s->d, s->cone, s->zgrp, s->n_zgrp, s->band64 > 0 ? s->zrow : (const int*)nullptr, s->Z, s->xbuf, s->solution, res,
+                           s->residual, s->wz, s->Wsoc, s->residual_symmetric, s->step_symmetric, st, accumulate ? s->step : (double*)nullptr, s->zsx, s->residual_error, s->t1, s->refpart,
+                           which == 0 ? 1 : 2, with_refine ? 1 : 0, s->gate_epoch ? s->gate : (const int*)nullptr, s->gate_epoch);
+    };
+    if (narrow) go(k_solve_tail<16>, TAIL_ROWS * 16); else go(k_solve_tail<32>, TAIL_ROWS * 32);
     s->refine_local_done = with_refine;
     if (with_refine) s->refparts = s->n_zgrp;
     return true;
