@@ -2,8 +2,8 @@
 the Schur complement as slices of the panel launches, deferred trailing updates; CALIPSO_HIP_LFAC=0: k_schur + the right-looking panel steps a group takes).  By default the finish of the factorisation (factor columns + merges of the
 inverse blocks) of the completed solve blocks runs on a second stream while the pivot chain goes on, fed by the host from a progress word, and the
 inertia counts are published right behind the chain (csrc/ldl.hip: launch_ldl); CALIPSO_HIP_LDL_OVERLAP=0 / CALIPSO_HIP_LDL_PUBLISH=0 /
-CALIPSO_HIP_GRAPH_LDL=1 select the one-stream schedules.  These, CALIPSO_HIP_RHS_AHEAD, CALIPSO_HIP_SPEC_REFINE, CALIPSO_HIP_SPEC_STEP (here), CALIPSO_HIP_LASTBLOCK_SYM (test_gpu_wform.py) and
-CALIPSO_HIP_SOLVE_TAIL (below, to rounding) are ALL the environment switches of the library.  The switches are read once per process, so every variant runs in a process of its own;
+CALIPSO_HIP_GRAPH_LDL=1 select the one-stream schedules.  These, CALIPSO_HIP_RHS_AHEAD, CALIPSO_HIP_SPEC_REFINE, CALIPSO_HIP_SPEC_STEP, CALIPSO_HIP_TAIL_PT (here), CALIPSO_HIP_LASTBLOCK_SYM (test_gpu_wform.py) and
+CALIPSO_HIP_SOLVE_TAIL (below, to rounding) are the environment switches of one handle's step (INTEGRATION.md lists all thirteen of the library).  The switches are read once per process, so every variant runs in a process of its own;
 the Newton steps they take must agree bit for bit (same kernels, same operands, only the order in time of independent launches differs)."""
 import hashlib
 import os
@@ -66,6 +66,7 @@ def test_newton_steps_do_not_depend_on_the_schedule_of_the_factorisation():
                 {"CALIPSO_HIP_LDL_OVERLAP": "0"}, {"CALIPSO_HIP_LDL_PUBLISH": "0"}, {"CALIPSO_HIP_GRAPH_LDL": "1"},
                 {"CALIPSO_HIP_RHS_AHEAD": "0"},           # the operands of the first condensed solve on the main stream behind the factorisation instead of on the second stream
                 {"CALIPSO_HIP_SPEC_REFINE": "0"},         # refinement rounds one by one, a host wait each, instead of queued ahead behind a device-side gate: same kernels, same order
+                {"CALIPSO_HIP_TAIL_PT": "16"},            # k_solve_tail with 256 threads (two of the 32 column parts per thread: what group launches take) instead of 512: the same parts, columns and order of every sum
                 {"CALIPSO_HIP_SPEC_STEP": "0"}):          # every decision of the step waited for in place instead of IC-1 queued ahead of the exit tests and the cone search / first candidate / merit behind the unread refinement report
         assert run_variant(env) == ref, env
 
