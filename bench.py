@@ -956,7 +956,7 @@ def main():
     if batched_elapsed is not None:
         brate = world * B * P / batched_elapsed
         batched = {"newton_steps_per_s": brate, "problems_per_s_of_10_steps": brate / 10.0, "instances_per_gpu": B, "instances_per_group": G,
-                   "groups_in_flight": wl.batch.lanes, "passes": P, "lanes_synchronised_per_pass": bool(args.lockstep_passes), "ms_per_pass": 1e3 * batched_elapsed / P, "one_group_alone_steps_per_s": unit_rate,
+                   "groups_in_flight": wl.batch.lanes, "lane_streams": wl.batch.stream_report, "passes": P, "lanes_synchronised_per_pass": bool(args.lockstep_passes), "ms_per_pass": 1e3 * batched_elapsed / P, "one_group_alone_steps_per_s": unit_rate,
                    "scaling": "weak (instances sharded block-contiguously over ranks, no data-path collective)", "post_round_exchange": exchange.path}
     workload = ("%s synthetic " + wl.kind(args.dense_structure) + "conic QP: %s; %s; 1 LDL^T factorisation, %d refinement round(s) per step") % (
         args.config, wl.describe(), "ONE system per GPU stepped sequentially (replicas at N > 1)" if single_elapsed is not None
@@ -999,6 +999,9 @@ def main():
     if c4_configs and not args.no_c4 and args.c4_batch > 0:
         c4 = {"instances_per_gpu": args.c4_batch, "instances_per_group": args.c4_group, "problems_total": world * args.c4_batch,
               "problem": "10 Newton steps of one instance (SURVEY 8(d))"}
+        # (CALIPSO_BENCH_C4_SHIFT=k: k small handles created first — shifts which hardware queues the lanes' streams get: the experiment behind BatchSolver.spread_streams,
+        # profiles/r06_ab_closing.txt)
+        _shift = [make_instance(pkg, pr, 900 + q, (16, 4, 4, 0, 3), local_rank)[4] for q in range(int(os.environ.get("CALIPSO_BENCH_C4_SHIFT", "0")))]
         for cname in [c for c in c4_configs.split(",") if c]:
             w4 = Workload(pkg, pr, cname, rank, world, local_rank, args.c4_batch, args.c4_group, 2)
             for _ in range(max(1, min(args.warmup, 2))):
@@ -1017,7 +1020,7 @@ def main():
             c4[cname] = {"workload": cname + " " + w4.kind(False) + w4.describe(), "single_system_steps_per_s": world * K4 / e1, "single_ms_per_step": 1e3 * e1 / K4,
                          "batched_newton_steps_per_s": r2, "batched_problems_per_s_of_10_steps": r2 / 10.0, "ms_per_pass": 1e3 * e2 / P4, "passes": P4,
                          "refinement_rounds": int(i2[0]["refinement_rounds"]), "stage_parallel": w4.stage_parallel, "stage_blocks": w4.stage_blocks,
-                         "device_bytes_per_instance": w4.single.device_bytes()}
+                         "device_bytes_per_instance": w4.single.device_bytes(), "lane_streams": w4.batch.stream_report if w4.batch is not None else None}
             if w4.staged is not None and w4.structured:
                 c4[cname]["roofline"] = structured_roofline(w4, int(i2[0]["refinement_rounds"]), 1e-3 * c4[cname]["ms_per_pass"] / w4.B, "%d instances in groups of %d" % (w4.B, w4.G))
             if rank == 0 and world == 1 and not args.no_cpu_baseline:

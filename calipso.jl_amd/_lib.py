@@ -121,6 +121,8 @@ SYMBOLS = {
     "calipso_hip_comm_allreduce_sum": (_i32, [_vp, _pd, _i64]),
     "calipso_hip_mfma_f64_peak": (_i32, [_i32, _pd]),
     "calipso_hip_synchronize": (_i32, [_vp]),
+    "calipso_hip_streams_concurrent": (_i32, [_vp, _vp, _pd]),
+    "calipso_hip_rebind_stream": (_i32, [_vp, _i32]),
     "calipso_hip_splitmix_uniform": (_i32, [_u64, _u64, _dbl, _dbl, _i64, _pd]),
 }
 

@@ -27,12 +27,46 @@ class BatchSolver:
     maps to distinct hardware queues; handles are created with priority class = creation index mod 3).  Instance k is always
     driven by host thread k mod lanes, so instances that run concurrently never share a priority class — streams of equal
     priority can be multiplexed onto one hardware queue, which serialises them and was measured to be slower than running
-    them back to back."""
+    them back to back.  Distinct classes are not enough (queues of different classes can still end up behind one dispatcher,
+    by the accident of how many streams the process created before): at creation the leaders of the lanes are PROBED and
+    rebound until they run side by side (spread_streams)."""
 
-    def __init__(self, solvers, lanes=3):
+    def __init__(self, solvers, lanes=3, spread_streams=True):
         self.solvers = list(solvers)
         self.lanes = max(1, min(int(lanes), len(self.solvers))) if self.solvers else 1
         self.pool = ThreadPoolExecutor(max_workers=self.lanes)
+        self.stream_report = self.spread_streams() if spread_streams and self.lanes > 1 else None
+
+    @staticmethod
+    def _leader(unit):
+        """the handle whose stream carries a unit's launches: a Solver itself, the first member of a Group"""
+        return unit.solvers[0] if hasattr(unit, "solvers") else unit
+
+    def spread_streams(self, max_rebinds=12):
+        """Units of different lanes run at the same time; whether their streams really run side by side depends on how the runtime mapped them to hardware
+        queues, i.e. on how many streams the process created before (calipso_hip_streams_concurrent measures it: BASELINE config 4's dense batch ran at 1290
+        or 1480 steps/s per GPU by that accident alone).  Probe every pair of leaders of different lanes; a unit whose stream collides with an earlier one gets
+        a new stream (calipso_hip_rebind_stream, cycling through the priority classes) until every pair runs side by side or `max_rebinds` is spent.  Returns
+        {"pairs": probed pairs, "collisions": found at first, "rebinds": streams replaced, "left": colliding pairs left}."""
+        leaders = [self._leader(u) for u in self.solvers]
+        if not all(hasattr(h, "streams_concurrent") for h in leaders):
+            return None
+        pairs = [(i, j) for j in range(len(leaders)) for i in range(j) if i % self.lanes != j % self.lanes]
+        if len(pairs) > 64:                     # (many small units: the first units of every lane stand for the rest)
+            pairs = [(i, j) for (i, j) in pairs if j < 2 * self.lanes]
+        report = dict(pairs=len(pairs), collisions=0, rebinds=0, left=0)
+        first = True
+        for attempt in range(max_rebinds + 1):
+            bad = [(i, j) for (i, j) in pairs if not leaders[i].streams_concurrent(leaders[j])[0]]
+            if first:
+                report["collisions"] = len(bad); first = False
+            report["left"] = len(bad)
+            if not bad or attempt == max_rebinds:
+                break
+            j = bad[0][1]                        # the later unit of the first colliding pair moves
+            leaders[j].rebind_stream((report["rebinds"] + j) % 3)
+            report["rebinds"] += 1
+        return report
 
     def _run(self, fn):
         """fn(solver) for every instance; lane w handles instances w, w+lanes, ... in order; results in instance order"""

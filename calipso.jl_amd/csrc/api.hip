@@ -509,6 +509,84 @@ int32_t calipso_hip_synchronize(H* s) { if (!s) return CALIPSO_ERR_ARGUMENT; SYN
 
 }  // extern "C"
 
+// ---- do the streams of two handles really run side by side? --------------------------------------------------------------------
+// Independent Solvers (solver.jl:46-150) stepped from different host threads share the GPU only as far as the runtime lets their streams: HIP streams are
+// multiplexed onto a few hardware queues, and two queues that end up behind one dispatcher serialise — a short kernel of one handle then waits until a long
+// kernel of the other has been dispatched COMPLETELY (all its workgroups placed), which is most of its duration.  Which streams collide depends on the order
+// in which the process created them and cannot be queried: BASELINE config 4's dense batch ran at 1290 or 1480 steps/s per GPU depending on how many handles
+// the process had created before (profiles/r06_ab_closing.txt).  So it is MEASURED: a kernel of far more workgroups than the chip holds on stream a, a
+// one-workgroup kernel on stream b right behind it; side by side, the small one is through in about the time of one workgroup of the large one.
+__global__ void k_probe_spin(long long ticks) {                       // (100 MHz wall clock)
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static int32_t probe_one_way(H* a, H* b, double* small_us, double* large_us) {
+    hipEvent_t ea0, ea1, eb0, eb1;
+    if (hipEventCreate(&ea0) != hipSuccess || hipEventCreate(&ea1) != hipSuccess || hipEventCreate(&eb0) != hipSuccess || hipEventCreate(&eb1) != hipSuccess) return CALIPSO_ERR_HIP;
+    int cus = 256;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, a->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+    (void)hipStreamSynchronize(a->stream); (void)hipStreamSynchronize(b->stream);
+    (void)hipEventRecord(ea0, a->stream);
+    hipLaunchKernelGGL(k_probe_spin, dim3(cus * 8 * 8), dim3(256), 0, a->stream, (long long)2000);      // eight rounds of 20 us: the dispatch lasts ~140 us
+    (void)hipEventRecord(ea1, a->stream);
+    (void)hipEventRecord(eb0, b->stream);
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b->stream, (long long)100);
+    (void)hipEventRecord(eb1, b->stream);
+    const bool ok = hipStreamSynchronize(a->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
+    float ta = 0.f, tb = 0.f;
+    const bool ok2 = ok && hipEventElapsedTime(&ta, ea0, ea1) == hipSuccess && hipEventElapsedTime(&tb, eb0, eb1) == hipSuccess;
+    (void)hipEventDestroy(ea0); (void)hipEventDestroy(ea1); (void)hipEventDestroy(eb0); (void)hipEventDestroy(eb1);
+    if (!ok2) return CALIPSO_ERR_HIP;
+    *small_us = 1e3 * (double)tb; *large_us = 1e3 * (double)ta;
+    return CALIPSO_OK;
+}
+
+extern "C" {
+
+// out[0] = 1 if a short kernel on either handle's stream gets through while a long kernel of the other is being dispatched (both directions, best of two tries
+// each), else 0; out[1], out[2] = the short kernel's time behind a's / b's long kernel (us), out[3] = the long kernel's duration (us)
+int32_t calipso_hip_streams_concurrent(H* a, H* b, double out[4]) {
+    if (!a || !b || !out || a == b || a->device != b->device) return CALIPSO_ERR_ARGUMENT;
+    { H* s = a; CK(hipSetDevice(a->device)); }
+    double worst[2] = {0.0, 0.0}, large = 0.0;
+    for (int dir = 0; dir < 2; ++dir) {
+        double best = 1e30;
+        for (int rep = 0; rep < 2; ++rep) {
+            double sm = 0.0, lg = 0.0;
+            const int32_t rc = dir == 0 ? probe_one_way(a, b, &sm, &lg) : probe_one_way(b, a, &sm, &lg);
+            if (rc != CALIPSO_OK) return rc;
+            best = std::min(best, sm); large = std::max(large, lg);
+        }
+        worst[dir] = best;
+    }
+    out[1] = worst[0]; out[2] = worst[1]; out[3] = large;
+    out[0] = (std::max(worst[0], worst[1]) < 0.4 * large) ? 1.0 : 0.0;
+    return CALIPSO_OK;
+}
+
+// A NEW stream for the handle (the old one is drained and destroyed): the runtime binds a new stream to the least used hardware queue of its priority class, so a
+// handle whose stream collides with another's (calipso_hip_streams_concurrent) gets another queue.  priority_class: 0, 1, 2 (the three classes calipso_hip_create
+// deals out by creation order), -1: keep the class.  Nothing else of the handle changes (events, captured launch graphs and the second stream do not depend on it).
+int32_t calipso_hip_rebind_stream(H* s, int32_t priority_class) {
+    if (!s || priority_class < -1 || priority_class > 2) return CALIPSO_ERR_ARGUMENT;
+    if (s->cur) return fail_arg(s, "a member of a live group launch cannot change its stream");
+    CK(hipSetDevice(s->device));
+    SYNC();
+    if (s->stream2) CK(hipStreamSynchronize(s->stream2));
+    int least = 0, greatest = 0, prio = 0;
+    CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (priority_class < 0) CK(hipStreamGetPriority(s->stream, &prio));
+    else { const int span = least - greatest; prio = span > 0 ? greatest + (priority_class % (span + 1)) : least; }
+    hipStream_t fresh = nullptr;
+    CK(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio));      // (created BEFORE the old one goes: the runtime must not hand the same queue back)
+    hipStream_t old = s->stream;
+    s->stream = fresh;
+    (void)hipStreamDestroy(old);
+    return CALIPSO_OK;
+}
+
+}  // extern "C"
+
 // ---- internal helpers -------------------------------------------------------------------------------------------------------
 // Scalar read-backs (refinement norms, merit / step-length decisions, cone-search masks: ~14 per Newton step).  A hipMemcpyAsync to pinned
 // memory + hipStreamSynchronize costs 11.4 us between two dependent kernels on this system; a one-workgroup kernel that stores the words

@@ -461,6 +461,33 @@ function HIPGroup(members::Vector{HIPSolver})
     finalizer(x -> ccall((:calipso_hip_group_destroy, lib), Int32, (Ptr{Cvoid},), x.handle), grp)
     return grp
 end
+"Do the HIP streams of two handles run side by side?  (calipso_hip_streams_concurrent: measured — a long kernel on one, a short one on the other, both ways)"
+function streams_concurrent(a::HIPSolver, b::HIPSolver)
+    out = zeros(Float64, 4)
+    rc = ccall((:calipso_hip_streams_concurrent, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), a.handle, b.handle, out)
+    rc == 0 || error("calipso_hip_streams_concurrent failed ($rc)")
+    return out[1] == 1.0, out[2], out[3], out[4]
+end
+"A new HIP stream (another hardware queue) for the handle: calipso_hip_rebind_stream; priority_class 0, 1, 2 or -1 (keep)."
+function rebind_stream!(s::HIPSolver, priority_class::Integer=-1)
+    rc = ccall((:calipso_hip_rebind_stream, lib), Int32, (Ptr{Cvoid}, Int32), s.handle, priority_class)
+    rc == 0 || error("calipso_hip_rebind_stream failed ($rc)")
+    return s
+end
+"""
+Handles (or the first members of groups) that are stepped at the same time from different tasks: probe every pair and give the later one of a colliding pair a new
+stream until all run side by side (what `BatchSolver.spread_streams` of the Python mirror does at creation).  Returns the number of streams replaced.
+"""
+function spread_streams!(leaders::Vector{HIPSolver}; max_rebinds::Integer=12)
+    rebinds = 0
+    for attempt in 0:max_rebinds
+        bad = [(i, j) for j in 1:length(leaders) for i in 1:j-1 if !streams_concurrent(leaders[i], leaders[j])[1]]
+        (isempty(bad) || attempt == max_rebinds) && break
+        rebind_stream!(leaders[bad[1][2]], (rebinds + bad[1][2]) % 3)
+        rebinds += 1
+    end
+    return rebinds
+end
 "One inner Newton iteration (solve.jl:98-353) for every member (device evaluator attached); returns (info 6 x B, status B)."
 function newton_step!(g::HIPGroup; advance::Bool=true)
     B = length(g.members)
@@ -585,7 +612,7 @@ function allreduce_sum!(c::HIPComm, v::Vector{Float64})
     return v
 end
 
-export HIPSolver, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPSmallNewton, set_cones!, set_qp!, solution, HIPComm, comm_unique_id, comm_size, gather_status, allreduce_sum!, newton_step!,
+export HIPSolver, streams_concurrent, rebind_stream!, spread_streams!, HIPLDLSolver, HIPSparseLDLSolver, hip_sparse_ldl_solver, HIPKKTSolver, hip_ldl_solver, HIPGroup, HIPSmallNewton, set_cones!, set_qp!, solution, HIPComm, comm_unique_id, comm_size, gather_status, allreduce_sum!, newton_step!,
        search_direction_nonsymmetric!, analyze_structure!, clear_structure!, set_stage_parallel!, set_stage_blocks!, declared_structure, kernel_times, sync_scalars!, copy_back!
 
 end # module

@@ -321,3 +321,33 @@ def test_newton_steps_in_one_call_are_the_steps_called_one_by_one():
     again = b.newton_steps(2, advance=False)                       # benchmark mode: the iterate is restored after every step
     assert again[0] == again[1]
     assert same(a.solution.all, b.solution.all)
+
+
+def test_lanes_of_a_batch_run_side_by_side():
+    """calipso_hip_streams_concurrent / calipso_hip_rebind_stream: whether the streams of two handles overlap is measured (a long kernel on one, a short one on the
+    other, both ways), a colliding handle gets a new stream and stays fully usable; BatchSolver probes the leaders of its lanes at creation and leaves no colliding
+    pair (BASELINE config 4's dense batch lost 14 % to such a collision, by the accident of how many streams the process had created before)."""
+    pkg = load_pkg()
+    from calipso_jl_amd.batch import BatchSolver
+    shape = (300, 60, 12, 6, 3)
+    hs = [build(pkg, 70 + k, shape) for k in range(6)]
+    ok, t_ab, t_ba, t_long = hs[0].streams_concurrent(hs[1])
+    assert t_long > 50.0 and min(t_ab, t_ba) > 0.0                       # the long kernel really is long (us), the short one was timed
+    ref = build(pkg, 72, shape)                                          # the same problem as hs[2], its stream untouched
+    hs[2].rebind_stream()                                                # a new stream, same priority class: the handle steps as before, bit for bit
+    hs[2].rebind_stream(1)
+    a = hs[2].newton_step(advance=True); b = ref.newton_step(advance=True)
+    assert a["status"] >= 0 and a == b
+    assert np.array_equal(hs[2].solution.all, ref.solution.all)
+    groups = [pkg.Group(hs[0:2]), pkg.Group(hs[2:4]), pkg.Group(hs[4:6])]
+    bs = BatchSolver(groups, lanes=3)
+    rep = bs.stream_report
+    assert rep is not None and rep["pairs"] == 3 and rep["left"] == 0, rep
+    for i in range(3):
+        for j in range(i):
+            assert hs[2 * i].streams_concurrent(hs[2 * j])[0]
+    infos = bs.newton_step(advance=False)
+    assert all(m["status"] >= 0 for g in infos for m in g)
+    bs.close()
+    with pytest.raises(pkg.CalipsoHipError):
+        hs[0].streams_concurrent(hs[0])
