@@ -35,7 +35,8 @@ class BatchSolver:
         self.solvers = list(solvers)
         self.lanes = max(1, min(int(lanes), len(self.solvers))) if self.solvers else 1
         self.pool = ThreadPoolExecutor(max_workers=self.lanes)
-        self.stream_report = self.spread_streams() if spread_streams and self.lanes > 1 else None
+        import os
+        self.stream_report = self.spread_streams() if spread_streams and self.lanes > 1 and os.environ.get("CALIPSO_BATCH_SPREAD_STREAMS", "1") != "0" else None
 
     @staticmethod
     def _leader(unit):
