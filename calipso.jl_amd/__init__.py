@@ -464,10 +464,10 @@ class Solver:
         self._check(self._L.calipso_hip_synchronize(self._h), "synchronize")
 
     def streams_concurrent(self, other):
-        """calipso_hip_streams_concurrent: (side by side?, short kernel behind self's long one [us], behind other's [us], the long kernel [us])"""
-        out = np.zeros(4)
+        """calipso_hip_streams_concurrent: (side by side?, short kernel behind self's long one [us], behind other's [us], the long kernel [us], one chain of short kernels alone [us], both chains at once [us])"""
+        out = np.zeros(6)
         self._check(self._L.calipso_hip_streams_concurrent(self._h, other._h, _pd(out)), "streams_concurrent")
-        return bool(out[0]), float(out[1]), float(out[2]), float(out[3])
+        return bool(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4]), float(out[5])
 
     def rebind_stream(self, priority_class=-1):
         """calipso_hip_rebind_stream: a new HIP stream for this handle (another hardware queue)"""

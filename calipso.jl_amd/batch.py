@@ -36,6 +36,10 @@ class BatchSolver:
         self.lanes = max(1, min(int(lanes), len(self.solvers))) if self.solvers else 1
         self.pool = ThreadPoolExecutor(max_workers=self.lanes)
         import os
+        if os.environ.get("CALIPSO_BATCH_LANE_CLASSES") and self.lanes > 1:       # (experiment: the priority class of every unit's leader by its lane, e.g. "1,1,1")
+            cls = [int(v) for v in os.environ["CALIPSO_BATCH_LANE_CLASSES"].split(",")]
+            for k, u in enumerate(self.solvers):
+                self._leader(u).rebind_stream(cls[(k % self.lanes) % len(cls)])
         self.stream_report = self.spread_streams() if spread_streams and self.lanes > 1 and os.environ.get("CALIPSO_BATCH_SPREAD_STREAMS", "1") != "0" else None
 
     @staticmethod

@@ -541,11 +541,40 @@ static int32_t probe_one_way(H* a, H* b, double* small_us, double* large_us) {
     return CALIPSO_OK;
 }
 
+// second test: CHAINS of short dependent kernels (what a latency-bound group step is: ~90 launches of a few microseconds) on both streams at once against one stream
+// alone.  Two streams of the HIGHEST priority class pass the first test and still run their chains one after the other (C4T, 32 instances in two lanes: 17.7 k
+// steps/s = one group alone, against 27.5 k in any other pair of classes).
+static int32_t probe_chains(H* a, H* b, double* alone_us, double* both_us) {
+    constexpr int N = 48;
+    hipEvent_t e[4];
+    for (auto& x : e) if (hipEventCreate(&x) != hipSuccess) return CALIPSO_ERR_HIP;
+    (void)hipStreamSynchronize(a->stream); (void)hipStreamSynchronize(b->stream);
+    (void)hipEventRecord(e[0], a->stream);
+    for (int i = 0; i < N; ++i) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a->stream, (long long)800);
+    (void)hipEventRecord(e[1], a->stream);
+    bool ok = hipStreamSynchronize(a->stream) == hipSuccess;
+    float t1 = 0.f, ta = 0.f, tb = 0.f;
+    ok = ok && hipEventElapsedTime(&t1, e[0], e[1]) == hipSuccess;
+    (void)hipEventRecord(e[0], a->stream); (void)hipEventRecord(e[2], b->stream);
+    for (int i = 0; i < N; ++i) {
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a->stream, (long long)800);
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b->stream, (long long)800);
+    }
+    (void)hipEventRecord(e[1], a->stream); (void)hipEventRecord(e[3], b->stream);
+    ok = ok && hipStreamSynchronize(a->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
+    ok = ok && hipEventElapsedTime(&ta, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&tb, e[2], e[3]) == hipSuccess;
+    for (auto& x : e) (void)hipEventDestroy(x);
+    if (!ok) return CALIPSO_ERR_HIP;
+    *alone_us = 1e3 * (double)t1; *both_us = 1e3 * (double)std::max(ta, tb);
+    return CALIPSO_OK;
+}
+
 extern "C" {
 
-// out[0] = 1 if a short kernel on either handle's stream gets through while a long kernel of the other is being dispatched (both directions, best of two tries
-// each), else 0; out[1], out[2] = the short kernel's time behind a's / b's long kernel (us), out[3] = the long kernel's duration (us)
-int32_t calipso_hip_streams_concurrent(H* a, H* b, double out[4]) {
+// out[0] = 1 if the two streams run side by side by BOTH tests, else 0.  Test 1: a short kernel on either stream gets through while a long kernel of the other is being
+// dispatched (both directions, best of two tries each): out[1], out[2] = the short kernel's time behind a's / b's long kernel (us), out[3] = the long kernel's duration
+// (us).  Test 2: chains of 48 short kernels on both streams at once take about as long as one chain alone: out[4] = one chain alone (us), out[5] = both at once (us).
+int32_t calipso_hip_streams_concurrent(H* a, H* b, double out[6]) {
     if (!a || !b || !out || a == b || a->device != b->device) return CALIPSO_ERR_ARGUMENT;
     { H* s = a; CK(hipSetDevice(a->device)); }
     double worst[2] = {0.0, 0.0}, large = 0.0;
@@ -562,7 +591,16 @@ int32_t calipso_hip_streams_concurrent(H* a, H* b, double out[4]) {
     out[1] = worst[0]; out[2] = worst[1]; out[3] = large;
     // side by side: the short kernel is through after about ONE round of the long kernel's workgroups (20 us of its ~170: measured 10 - 22 us both ways); the colliding
     // pairs measured 54 - 108 us one way (and a long kernel of 231 us instead of 170): the bar is a fifth of the long kernel
-    out[0] = (std::max(worst[0], worst[1]) < 0.2 * large) ? 1.0 : 0.0;
+    const bool test1 = std::max(worst[0], worst[1]) < 0.2 * large;
+    double alone = 0.0, both = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {          // (best of two: a hiccup of the host between the launches must not read as a collision)
+        double t1 = 0.0, t2 = 0.0;
+        const int32_t rc = probe_chains(a, b, &t1, &t2);
+        if (rc != CALIPSO_OK) return rc;
+        if (t2 / std::max(t1, 1e-9) < both / std::max(alone, 1e-9)) { alone = t1; both = t2; }
+    }
+    out[4] = alone; out[5] = both;
+    out[0] = (test1 && both < 1.4 * alone) ? 1.0 : 0.0;
     return CALIPSO_OK;
 }
 

@@ -463,10 +463,10 @@ function HIPGroup(members::Vector{HIPSolver})
 end
 "Do the HIP streams of two handles run side by side?  (calipso_hip_streams_concurrent: measured — a long kernel on one, a short one on the other, both ways)"
 function streams_concurrent(a::HIPSolver, b::HIPSolver)
-    out = zeros(Float64, 4)
+    out = zeros(Float64, 6)
     rc = ccall((:calipso_hip_streams_concurrent, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}), a.handle, b.handle, out)
     rc == 0 || error("calipso_hip_streams_concurrent failed ($rc)")
-    return out[1] == 1.0, out[2], out[3], out[4]
+    return out[1] == 1.0, out[2], out[3], out[4], out[5], out[6]
 end
 "A new HIP stream (another hardware queue) for the handle: calipso_hip_rebind_stream; priority_class 0, 1, 2 or -1 (keep)."
 function rebind_stream!(s::HIPSolver, priority_class::Integer=-1)

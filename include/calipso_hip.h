@@ -512,11 +512,12 @@ int32_t calipso_hip_synchronize(calipso_hip_solver*);
 /* Independent Solvers stepped from different host threads (solver.jl:46-150: the reference's Solvers are independent objects; batch.py: lanes) overlap on the GPU only
  * if the runtime put their streams behind different hardware dispatchers — which depends on the order in which the process created its streams and cannot be queried.
  * calipso_hip_streams_concurrent MEASURES it (a kernel of many more workgroups than the chip holds on one stream, a one-workgroup kernel on the other, both ways):
- * out[0] = 1 if the short kernel gets through while the long one is still being dispatched, else 0; out[1], out[2] = the short kernel's time behind a's / b's long
- * kernel (us); out[3] = the long kernel's duration (us).  calipso_hip_rebind_stream gives the handle a NEW stream (the old one is drained and destroyed; priority_class
+ * out[1], out[2] = the short kernel's time behind a's / b's long kernel (us), out[3] = the long kernel's duration (us) — and chains of 48 short kernels on both streams at
+ * once against one chain alone (out[4], out[5], us: two streams of the highest priority class pass the first test and still run their chains one after the other);
+ * out[0] = 1 if the streams run side by side by both tests, else 0.  calipso_hip_rebind_stream gives the handle a NEW stream (the old one is drained and destroyed; priority_class
  * 0, 1, 2 = the classes calipso_hip_create deals out by creation order, -1 = keep): the runtime binds it to the least used hardware queue of the class.  The Python
  * mirror's BatchSolver (and the Julia module's lanes) probe the leaders of their lanes at creation and rebind until every pair runs side by side. */
-int32_t calipso_hip_streams_concurrent(calipso_hip_solver* a, calipso_hip_solver* b, double out[4]);
+int32_t calipso_hip_streams_concurrent(calipso_hip_solver* a, calipso_hip_solver* b, double out[6]);
 int32_t calipso_hip_rebind_stream(calipso_hip_solver*, int32_t priority_class);
 
 /* SplitMix64 uniform stream of SURVEY.md 8(d): seed = 0xCA11B50000000000 + 4096*problem_id + stream_id,

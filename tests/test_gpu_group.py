@@ -331,8 +331,8 @@ def test_lanes_of_a_batch_run_side_by_side():
     from calipso_jl_amd.batch import BatchSolver
     shape = (300, 60, 12, 6, 3)
     hs = [build(pkg, 70 + k, shape) for k in range(6)]
-    ok, t_ab, t_ba, t_long = hs[0].streams_concurrent(hs[1])
-    assert t_long > 50.0 and min(t_ab, t_ba) > 0.0                       # the long kernel really is long (us), the short one was timed
+    ok, t_ab, t_ba, t_long, t_alone, t_both = hs[0].streams_concurrent(hs[1])
+    assert t_long > 50.0 and min(t_ab, t_ba) > 0.0 and t_both >= 0.5 * t_alone > 0.0                       # the long kernel really is long (us), the short one was timed
     ref = build(pkg, 72, shape)                                          # the same problem as hs[2], its stream untouched
     hs[2].rebind_stream()                                                # a new stream, same priority class: the handle steps as before, bit for bit
     hs[2].rebind_stream(1)
