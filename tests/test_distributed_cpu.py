@@ -84,6 +84,58 @@ def test_batch_lanes_keep_priority_classes_apart():
     b.close()
 
 
+def test_batch_spreads_the_streams_of_its_lanes():
+    """BatchSolver.spread_streams (no GPU: stand-ins for the handles): every pair of units of DIFFERENT lanes is probed, the later unit of a colliding pair is rebound
+    (cycling through the priority classes) until no pair collides or the budget is spent; units of one lane are never probed against each other; handles without
+    the probe (the Fake instances above) are left alone"""
+    load_pkg()
+    from calipso_jl_amd.batch import BatchSolver
+
+    class Leader:
+        probes = 0
+
+        def __init__(self, k, queue):
+            self.k, self.queue, self.rebound = k, queue, []
+
+        def streams_concurrent(self, other):
+            Leader.probes += 1
+            return (self.queue != other.queue, 10.0, 10.0, 170.0, 420.0, 425.0)
+
+        def rebind_stream(self, priority_class=-1):
+            self.rebound.append(priority_class)
+            self.queue = 100 + 10 * self.k + len(self.rebound)          # a queue nobody else has
+
+        def newton_step(self, advance=False):
+            return dict(status=0)
+
+    class Unit:                                                          # a group: the first member carries the launches
+        def __init__(self, leader):
+            self.solvers = [leader, object()]
+
+        def newton_step(self, advance=False):
+            return [dict(status=0)]
+
+    # four units in two lanes: units 0, 2 (lane 0) and 1, 3 (lane 1); 0 and 1 share a queue, 2 and 3 share another; 0 and 2 share one too (same lane: never probed)
+    ls = [Leader(0, 7), Leader(1, 7), Leader(2, 7), Leader(3, 8)]
+    b = BatchSolver([Unit(l) for l in ls], lanes=2)
+    rep = b.stream_report
+    assert rep["pairs"] == 4 and rep["collisions"] == 2 and rep["left"] == 0 and rep["rebinds"] == 1, rep      # (0, 1) and (1, 2) collide: unit 1 moves once
+    assert ls[1].rebound == [(0 + 1) % 3] and not ls[0].rebound and not ls[2].rebound and not ls[3].rebound
+    assert ls[0].queue == ls[2].queue == 7                               # the two units of lane 0 still share a queue: they never run at the same time
+    b.close()
+    # a pair that cannot be separated: the budget bounds the work, the report says what is left
+    class Stuck(Leader):
+        def rebind_stream(self, priority_class=-1):
+            self.rebound.append(priority_class)
+    st = [Stuck(0, 1), Stuck(1, 1)]
+    b = BatchSolver(st, lanes=2)
+    assert b.stream_report == dict(pairs=1, collisions=1, rebinds=12, left=1) and st[1].rebound == [(r + 1) % 3 for r in range(12)] and not st[0].rebound
+    b.close()
+    b = BatchSolver([Leader(0, 1)], lanes=3)                             # one unit: one lane, nothing to probe
+    assert b.stream_report is None
+    b.close()
+
+
 def test_bench_spawns_its_ranks():
     """`python bench.py --gpus N` (the driver's plain command form, no torch.distributed.run around it) must start N ranks itself.
     --spawn-check stops every rank before it touches a GPU, so the launch path is covered here: the ranks report in through a gloo
