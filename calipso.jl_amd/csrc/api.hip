@@ -520,9 +520,16 @@ __global__ void k_probe_spin(long long ticks) {                       // (100 MH
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
+struct ProbeEvents {                       // four events, destroyed whatever way the probe leaves
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = true;
+    ProbeEvents() { for (auto& x : e) ok = ok && hipEventCreate(&x) == hipSuccess; }
+    ~ProbeEvents() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
+};
 static int32_t probe_one_way(H* a, H* b, double* small_us, double* large_us) {
-    hipEvent_t ea0, ea1, eb0, eb1;
-    if (hipEventCreate(&ea0) != hipSuccess || hipEventCreate(&ea1) != hipSuccess || hipEventCreate(&eb0) != hipSuccess || hipEventCreate(&eb1) != hipSuccess) return CALIPSO_ERR_HIP;
+    ProbeEvents pe;
+    if (!pe.ok) return CALIPSO_ERR_HIP;
+    hipEvent_t ea0 = pe.e[0], ea1 = pe.e[1], eb0 = pe.e[2], eb1 = pe.e[3];
     int cus = 256;
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, a->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
     (void)hipStreamSynchronize(a->stream); (void)hipStreamSynchronize(b->stream);
@@ -535,7 +542,6 @@ static int32_t probe_one_way(H* a, H* b, double* small_us, double* large_us) {
     const bool ok = hipStreamSynchronize(a->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
     float ta = 0.f, tb = 0.f;
     const bool ok2 = ok && hipEventElapsedTime(&ta, ea0, ea1) == hipSuccess && hipEventElapsedTime(&tb, eb0, eb1) == hipSuccess;
-    (void)hipEventDestroy(ea0); (void)hipEventDestroy(ea1); (void)hipEventDestroy(eb0); (void)hipEventDestroy(eb1);
     if (!ok2) return CALIPSO_ERR_HIP;
     *small_us = 1e3 * (double)tb; *large_us = 1e3 * (double)ta;
     return CALIPSO_OK;
@@ -546,8 +552,9 @@ static int32_t probe_one_way(H* a, H* b, double* small_us, double* large_us) {
 // steps/s = one group alone, against 27.5 k in any other pair of classes).
 static int32_t probe_chains(H* a, H* b, double* alone_us, double* both_us) {
     constexpr int N = 48;
-    hipEvent_t e[4];
-    for (auto& x : e) if (hipEventCreate(&x) != hipSuccess) return CALIPSO_ERR_HIP;
+    ProbeEvents pe;
+    if (!pe.ok) return CALIPSO_ERR_HIP;
+    hipEvent_t (&e)[4] = pe.e;
     (void)hipStreamSynchronize(a->stream); (void)hipStreamSynchronize(b->stream);
     (void)hipEventRecord(e[0], a->stream);
     for (int i = 0; i < N; ++i) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a->stream, (long long)800);
@@ -563,7 +570,6 @@ static int32_t probe_chains(H* a, H* b, double* alone_us, double* both_us) {
     (void)hipEventRecord(e[1], a->stream); (void)hipEventRecord(e[3], b->stream);
     ok = ok && hipStreamSynchronize(a->stream) == hipSuccess && hipStreamSynchronize(b->stream) == hipSuccess;
     ok = ok && hipEventElapsedTime(&ta, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&tb, e[2], e[3]) == hipSuccess;
-    for (auto& x : e) (void)hipEventDestroy(x);
     if (!ok) return CALIPSO_ERR_HIP;
     *alone_us = 1e3 * (double)t1; *both_us = 1e3 * (double)std::max(ta, tb);
     return CALIPSO_OK;
