@@ -723,6 +723,12 @@ def main():
     def run_batched(wl, P, lockstep=False):
         """timed region over P passes of all B instances of the rank + the post-round exchange; returns (elapsed, infos, k_schur ms samples)"""
         sch = []
+        # the lanes' streams are probed once more right in front of the timed region (a few milliseconds; BatchSolver probed them at creation): what was created or
+        # destroyed in between may have re-shuffled the hardware queues
+        if wl.batch is not None and wl.batch.stream_report is not None:
+            again = wl.batch.spread_streams()
+            if again is not None:
+                wl.batch.stream_report = dict(wl.batch.stream_report, recheck_collisions=again["collisions"], recheck_rebinds=again["rebinds"], left=again["left"])
         barrier(wl)
         t0 = time.perf_counter()
         if lockstep:
