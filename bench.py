@@ -1025,6 +1025,8 @@ def main():
             for _ in range(max(1, min(args.warmup, 2))):
                 w4.batched_pass()
             P4 = max(1, min(P, 10))
+            if w4.staged is not None and w4.structured:
+                P4 *= 8             # (a pass of 32 structured instances is ~1.2 ms: ten passes are a 12 ms region in which ONE host hiccup moves the rate by 25 % — 19 to 26 k steps/s in six runs)
             e2, i2, _ = run_batched(w4, P4)
             r2 = world * w4.B * P4 / e2
             c4[cname] = {"workload": cname + " " + w4.kind(False) + w4.describe(), "single_system_steps_per_s": world * K4 / e1, "single_ms_per_step": 1e3 * e1 / K4,
