@@ -1010,6 +1010,7 @@ def main():
         _shift = [make_instance(pkg, pr, 900 + q, (16, 4, 4, 0, 3), local_rank)[4] for q in range(int(os.environ.get("CALIPSO_BENCH_C4_SHIFT", "0")))]
         for cname in [c for c in c4_configs.split(",") if c]:
             w4 = Workload(pkg, pr, cname, rank, world, local_rank, args.c4_batch, args.c4_group, 2)
+            # (CALIPSO_BENCH_PROBE_PRINT=1: the raw numbers of calipso_hip_streams_concurrent for the first two lanes' leaders on stderr, four times — profiles/r06_ab_closing.txt)
             if os.environ.get("CALIPSO_BENCH_PROBE_PRINT") and w4.batch is not None and len(w4.units) > 1:
                 la, lb = w4.batch._leader(w4.units[0]), w4.batch._leader(w4.units[1])
                 for _ in range(4):
